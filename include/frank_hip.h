@@ -1,0 +1,141 @@
+/*
+ * frank_hip.h -- C ABI of the MI355X (gfx950) visibility-fitting hot path.
+ *
+ * Drop-in boundary for discsim/frank v1.2.3.  The reference is pure Python with no
+ * FFI layer of its own; each entry point below names the reference interface
+ * (file:line under the reference tree) whose arithmetic it replaces, and
+ * INTEGRATION.md shows the ctypes binding a frank maintainer would add.
+ *
+ * Conventions
+ *   - plain C types, caller-owned buffers, no torch / numpy types in signatures;
+ *   - every function returns FH_OK (0) or a negative FH_ERR_* code and records a
+ *     message retrievable with fh_last_error() (thread-local);
+ *   - all matrices are row-major (NumPy C order), IEEE fp64;
+ *   - "host" pointers are ordinary malloc'd memory, "device" pointers are HIP
+ *     allocations on the context's device;
+ *   - handles are thread-compatible, not thread-safe; one HIP stream per fh_ctx;
+ *   - there is NO CPU fallback for device work: with no usable GPU the device entry
+ *     points fail with FH_ERR_HIP.
+ */
+#ifndef FRANK_HIP_H
+#define FRANK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FH_OK 0
+#define FH_ERR_INVALID (-1)       /* bad argument (ValueError / AttributeError in the reference)              */
+#define FH_ERR_QRANGE (-2)        /* q_k[-1] < max deprojected baseline: statistical_models.py:526-535        */
+#define FH_ERR_BAD_P (-3)         /* non-positive / NaN power spectrum: statistical_models.py:688-698         */
+#define FH_ERR_NOT_SPD (-4)       /* Cholesky failed and the SVD route could not be taken                     */
+#define FH_ERR_NOMEM (-5)
+#define FH_ERR_HIP (-6)           /* no GPU, or a HIP / rocBLAS / rocSOLVER / RCCL runtime error              */
+#define FH_ERR_UNSUPPORTED (-7)   /* e.g. nu != 0                                                             */
+
+/* vis_model: statistical_models.py:71-73, 486-496 */
+#define FH_VIS_OPT_THICK 0 /* H scaled by cos(inc) */
+#define FH_VIS_OPT_THIN 1  /* no scaling           */
+
+typedef struct fh_dht fh_dht; /* DiscreteHankelTransform, hankel.py:25-294        */
+typedef struct fh_vis fh_vis; /* a visibility table resident in HBM               */
+typedef struct fh_ctx fh_ctx; /* device + stream + workspaces for one DHT size    */
+typedef struct fh_comm fh_comm; /* RCCL communicator (one rank per GPU)           */
+
+/* SourceGeometry / FixedGeometry parameters, geometry.py:196-200, 372-396 (degrees, arcsec). */
+typedef struct fh_geometry {
+    double inc_deg, PA_deg, dRA_arcsec, dDec_arcsec;
+} fh_geometry;
+
+const char *fh_last_error(void);
+const char *fh_version(void);
+/* Number of usable HIP devices (0 => every device entry point returns FH_ERR_HIP). */
+int fh_device_count(int *count);
+
+/* ---- a1/a2/a4: DiscreteHankelTransform set-up -- host, O(N^2), once per fitter ----------------------------
+ * hankel.py:55-93.  Rmax in RADIANS (radial_fitters.py:441 converts from arcsec).  nu must be 0.            */
+int fh_dht_create(double Rmax_rad, int N, int nu, fh_dht **out);
+void fh_dht_destroy(fh_dht *dht);
+int fh_dht_size(const fh_dht *dht);
+/* Any output may be NULL.  r, q, scale_factor: N; zeros: N+1 (j_{0,1..N+1}); Ykm: N*N; scalars: 1.         */
+int fh_dht_get(const fh_dht *dht, double *r, double *q, double *zeros, double *Ykm, double *scale_factor,
+               double *Qmax, double *Rmax);
+
+/* ---- contexts ------------------------------------------------------------------------------------------- */
+int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out);
+void fh_ctx_destroy(fh_ctx *ctx);
+int fh_ctx_synchronize(fh_ctx *ctx);
+/* The context's hipStream_t (as void*), e.g. to record HIP events around the binning kernel. */
+void *fh_ctx_stream(fh_ctx *ctx);
+
+/* ---- a3/a7: design block H(q) on the GPU -------------------------------------------------------------------
+ * DHT.coefficients(q, direction) * scale: hankel.py:187-204, statistical_models.py:483-509.
+ * q: n host doubles (lambda for forward, radians for backward); H: n*N host doubles, row-major.
+ * direction 0 = forward, 1 = backward.  scale multiplies every entry (cos(inc), 1, or 1/cos(inc)).         */
+int fh_dht_coefficients(fh_ctx *ctx, const double *q, int64_t n, int direction, double scale, double *H);
+
+/* predict_visibilities: V = H(q) . I, chunk-free (statistical_models.py:279-329). q, V: n host doubles.     */
+int fh_predict_visibilities(fh_ctx *ctx, const double *q, int64_t n, const double *I, double scale, double *V);
+
+/* ---- visibility tables ------------------------------------------------------------------------------------
+ * Upload (u, v, Re V, Im V, w) to HBM as five fp64 columns (40 B / visibility).  Vim may be NULL (real V).
+ * n_w == 1 broadcasts a scalar weight (statistical_models.py:173).                                         */
+int fh_vis_upload(int device, const double *u, const double *v, const double *Vre, const double *Vim,
+                  const double *w, int64_t n_w, int64_t n, fh_vis **out);
+void fh_vis_destroy(fh_vis *vis);
+int64_t fh_vis_size(const fh_vis *vis);
+
+/* ---- a5-a8: map_visibilities = K1 `bin_gram` ---------------------------------------------------------------
+ * statistical_models.py:109-237 with geometry.py:69-79,111-131 and hankel.py:201-202 fused:
+ * phase-centre + deproject each visibility, q = hypot(u', v'), J0((q/Qmax) j_k) for all k, and accumulate the
+ * Bessel Gram G = X^T diag(w) X, g = X^T diag(w) Re V', sum w V'^2, sum log w, min/max q on the device.
+ *   fh_bin_reset      zero the context's sufficient statistics
+ *   fh_bin_visibilities  add rows [first, first+count) of `vis` (asynchronous on the context's stream)
+ *   fh_stats_device   device pointer / length (doubles) of the packed statistics, for an RCCL all-reduce
+ *   fh_stats_finalize apply the DHT scaling, unpack to M (N*N), j (N), H0, qmin, qmax (host, any may be NULL);
+ *                     the device copies of M and j stay in the context for fh_fit_normal(M = NULL).
+ *                     Returns FH_ERR_QRANGE iff check_qbounds and q_k[-1] < qmax (outputs are still written). */
+int fh_bin_reset(fh_ctx *ctx);
+int fh_bin_visibilities(fh_ctx *ctx, const fh_geometry *geom, const fh_vis *vis, int64_t first, int64_t count);
+int fh_stats_device(fh_ctx *ctx, double **sum_stats, int64_t *n_sum, double **minmax_stats);
+int fh_stats_finalize(fh_ctx *ctx, const fh_geometry *geom, int vis_model, int check_qbounds, double *M, double *j,
+                      double *H0, double *qmin, double *qmax);
+/* One-shot convenience with host arrays (what VisibilityMapping.map_visibilities binds to). */
+int fh_map_visibilities(fh_ctx *ctx, const fh_geometry *geom, int vis_model, int check_qbounds, const double *u,
+                        const double *v, const double *Vre, const double *Vim, const double *w, int64_t n_w,
+                        int64_t n, double *M, double *j, double *H0, double *qmin, double *qmax);
+
+/* ---- a11-a13: GaussianModel -------------------------------------------------------------------------------
+ * statistical_models.py:650-781.  p may be NULL (no prior).  M, j, p: host.  Outputs (host, any may be NULL):
+ * mu (N), chol (N*N, upper factor U with Dinv = U^T U in the upper triangle, as scipy.linalg.cho_factor),
+ * Sinv (N*N).  *used_svd is set when the Cholesky failed and the SVD pseudo-inverse (:747-755) was used.    */
+int fh_gaussian_model(fh_ctx *ctx, const double *M, const double *j, const double *p, double *mu, double *chol,
+                      double *Sinv, int *used_svd);
+/* Dsolve(b) with a previously returned factor (statistical_models.py:762-781). B: N*nrhs row-major, in place. */
+int fh_cho_solve(fh_ctx *ctx, const double *chol, double *B, int nrhs);
+
+/* ---- a10/a14/a15/a16: the power-spectrum iteration = K2 `fit_iterate` --------------------------------------
+ * FrankFitter._fit, method='Normal' (radial_fitters.py:737-832) with CriticalFilter.update_power_spectrum /
+ * check_convergence (filter.py:154-181), spectral_smoothing_matrix (filter.py:23-62) and GaussianModel
+ * (statistical_models.py:700-760), entirely on the device.
+ * M, j host (N*N, N) or both NULL to use the context's device copies from fh_stats_finalize.
+ * Outputs (host): mu (N), p (N), *niter = `count` at loop exit (caller applies the convergence_failure policy:
+ * success iff niter < max_iter, radial_fitters.py:788).  diag_p / diag_mu: NULL or (max_iter+1)*N receiving pI /
+ * MAP of every loop pass (:781-783).                                                                        */
+int fh_fit_normal(fh_ctx *ctx, const double *M, const double *j, double alpha, double p0, double wsmooth,
+                  double tol, int max_iter, double *mu, double *p, int *niter, double *diag_p, double *diag_mu);
+
+/* ---- multi-GPU: RCCL all-reduce of the sufficient statistics (one rank per GPU) ------------------------------
+ * The reduction being distributed is `Ms[i] += ...; js[i] += ...` (statistical_models.py:210-211) and the
+ * sum at :218; min/max q feed _check_uv_range (:512-535).                                                    */
+int fh_comm_unique_id(char id[128]);
+int fh_comm_create(const char id[128], int rank, int world, int device, fh_comm **out);
+void fh_comm_destroy(fh_comm *comm);
+int fh_comm_allreduce_stats(fh_comm *comm, fh_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRANK_HIP_H */

@@ -1,0 +1,195 @@
+"""ctypes front-end of the CPU oracle (oracle/frank_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+``cpu_baseline`` leg of bench.py -- never by anything under frank_amd/.
+Every function names the reference lines it restates (see the C file).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libfrank_oracle.so")
+
+FO_OK = 0
+FO_ERR_QRANGE = -2
+FO_ERR_BAD_P = -3
+FO_ERR_NOT_SPD = -4
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    srcs = [os.path.join(_HERE, f) for f in ("frank_oracle.c", "frank_oracle_lognormal.c")]
+    if (not force and os.path.exists(_SO)
+            and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
+        return _SO
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libfrank_oracle.so"],
+                          stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.fo_j0.restype = ctypes.c_double
+        _lib.fo_j0.argtypes = [ctypes.c_double]
+        _lib.fo_j1.restype = ctypes.c_double
+        _lib.fo_j1.argtypes = [ctypes.c_double]
+    return _lib
+
+
+def _f8(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def j0(x):
+    x = _f8(np.atleast_1d(x))
+    out = np.empty_like(x)
+    lib().fo_j0_array(_p(x), ctypes.c_int64(x.size), _p(out))
+    return out
+
+
+def jn_zeros0(nt):
+    z = np.empty(nt)
+    lib().fo_jn_zeros0(ctypes.c_int(nt), _p(z))
+    return z
+
+
+class DHT:
+    """DiscreteHankelTransform.__init__ (hankel.py:55-93), nu = 0."""
+
+    def __init__(self, Rmax, N):
+        self.Rmax, self.N = float(Rmax), int(N)
+        self.r, self.q, self.j_nk = np.empty(N), np.empty(N), np.empty(N)
+        self.Ykm, self.scale_factor = np.empty((N, N)), np.empty(N)
+        jn, qm = ctypes.c_double(), ctypes.c_double()
+        lib().fo_dht_setup(ctypes.c_double(Rmax), ctypes.c_int(N), _p(self.r), _p(self.q), _p(self.j_nk),
+                           ctypes.byref(jn), ctypes.byref(qm), _p(self.Ykm), _p(self.scale_factor))
+        self.j_nN, self.Qmax = jn.value, qm.value
+
+    def coefficients(self, q=None):
+        """hankel.py:187-204 (forward)."""
+        N = self.N
+        if q is None:
+            Y = np.empty((N, N))
+            lib().fo_dht_coefficients_self(ctypes.c_int(N), ctypes.c_double(self.j_nN),
+                                           ctypes.c_double(self.Qmax), _p(self.Ykm), _p(Y))
+            return Y
+        q = _f8(q)
+        H = np.empty((q.size, N))
+        lib().fo_dht_coefficients(ctypes.c_int(N), ctypes.c_double(self.Qmax), _p(self.j_nk),
+                                  _p(self.scale_factor), _p(q), ctypes.c_int64(q.size), _p(H))
+        return H
+
+    def transform(self, f):
+        """hankel.py:151-165 (forward, q=None)."""
+        f = _f8(f)
+        out = np.empty(self.N)
+        lib().fo_dht_transform_forward(ctypes.c_int(self.N), ctypes.c_double(self.Rmax),
+                                       ctypes.c_double(self.j_nN), _p(self.Ykm), _p(f), _p(out))
+        return out
+
+
+def apply_correction(u, v, V, inc, PA, dRA, dDec):
+    """SourceGeometry.apply_correction(use3D=True) (geometry.py:202-236)."""
+    u, v = _f8(u), _f8(v)
+    V = np.asarray(V)
+    Vre = _f8(V.real)
+    Vim = _f8(V.imag) if np.iscomplexobj(V) else None
+    n = u.size
+    up, vp, wp, Vr, Vi = (np.empty(n) for _ in range(5))
+    lib().fo_apply_correction(ctypes.c_int64(n), _p(u), _p(v), _p(Vre), _p(Vim), ctypes.c_double(inc),
+                              ctypes.c_double(PA), ctypes.c_double(dRA), ctypes.c_double(dDec), _p(up), _p(vp),
+                              _p(wp), _p(Vr), _p(Vi))
+    return up, vp, wp, Vr + 1j * Vi
+
+
+def map_visibilities(N, Rmax, geom, u, v, V, w, vis_model=0, check_qbounds=True, block_size=10 ** 5):
+    """VisibilityMapping.map_visibilities (statistical_models.py:109-237), single channel.
+
+    geom = (inc_deg, PA_deg, dRA_arcsec, dDec_arcsec); Rmax in radians.
+    Returns dict(M, j, null_likelihood, qmin, qmax, rc).
+    """
+    u, v = _f8(u), _f8(v)
+    V = np.asarray(V)
+    Vre = _f8(V.real)
+    Vim = _f8(V.imag) if np.iscomplexobj(V) else None
+    w = _f8(np.atleast_1d(w))
+    n = u.size
+    M, j = np.zeros((N, N)), np.zeros(N)
+    H0, qmin, qmax = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    rc = lib().fo_map_visibilities(
+        ctypes.c_int(N), ctypes.c_double(Rmax), ctypes.c_double(geom[0]), ctypes.c_double(geom[1]),
+        ctypes.c_double(geom[2]), ctypes.c_double(geom[3]), ctypes.c_int(vis_model),
+        ctypes.c_int(1 if check_qbounds else 0), ctypes.c_int64(block_size), ctypes.c_int64(n), _p(u), _p(v),
+        _p(Vre), _p(Vim), _p(w), ctypes.c_int64(w.size), _p(M), _p(j), ctypes.byref(H0), ctypes.byref(qmin),
+        ctypes.byref(qmax))
+    return dict(M=M, j=j, null_likelihood=H0.value, qmin=qmin.value, qmax=qmax.value, rc=rc)
+
+
+def gaussian_model(dht, M, j, p=None):
+    """GaussianModel(DHT, M, j, p) (statistical_models.py:650-760). Returns (mu, chol_upper, Sinv, rc)."""
+    N = dht.N
+    Y = dht.coefficients()
+    M, j = _f8(M), _f8(j)
+    mu, chol, Sinv = np.empty(N), np.empty((N, N)), np.zeros((N, N))
+    pp = None if p is None else _f8(p)
+    rc = lib().fo_gaussian_model(ctypes.c_int(N), _p(Y), _p(M), _p(j), _p(pp), _p(mu), _p(chol), _p(Sinv))
+    return mu, chol, Sinv, rc
+
+
+def smoothing_matrix(dht, weights):
+    """spectral_smoothing_matrix (filter.py:23-62) as a dense N x N array."""
+    N = dht.N
+    band = np.empty((5, N))
+    lib().fo_smoothing_matrix(ctypes.c_int(N), _p(dht.q), ctypes.c_double(weights), _p(band))
+    T = np.zeros((N, N))
+    for d in range(-2, 3):
+        for i in range(N):
+            if 0 <= i + d < N:
+                T[i, i + d] = band[d + 2, i]
+    return T, band
+
+
+def update_power_spectrum(dht, band, alpha, p0, p, mu, chol):
+    """CriticalFilter.update_power_spectrum (filter.py:154-177)."""
+    N = dht.N
+    Y = dht.coefficients()
+    out = np.empty(N)
+    lib().fo_update_power_spectrum(ctypes.c_int(N), _p(Y), _p(_f8(band)), ctypes.c_double(alpha),
+                                   ctypes.c_double(p0), _p(_f8(p)), _p(_f8(mu)), _p(_f8(chol)), _p(out))
+    return out
+
+
+def frank_fit_normal(N, Rmax, M, j, alpha=1.05, p0=1e-15, wsmooth=1e-4, tol=1e-3, max_iter=2000,
+                     diagnostics=False):
+    """FrankFitter._fit, method='Normal' (radial_fitters.py:737-832). Rmax in radians.
+
+    Returns dict(mu, p, niter, rc[, diag_p, diag_mu]).
+    """
+    M, j = _f8(M), _f8(j)
+    mu, p = np.empty(N), np.empty(N)
+    niter, nsvd = ctypes.c_int(0), ctypes.c_int(0)
+    dp = dm = None
+    if diagnostics:
+        dp, dm = np.zeros((max_iter + 1, N)), np.zeros((max_iter + 1, N))
+    rc = lib().fo_frank_fit_normal(ctypes.c_int(N), ctypes.c_double(Rmax), _p(M), _p(j), ctypes.c_double(alpha),
+                                   ctypes.c_double(p0), ctypes.c_double(wsmooth), ctypes.c_double(tol),
+                                   ctypes.c_int(max_iter), _p(mu), _p(p), ctypes.byref(niter), _p(dp), _p(dm),
+                                   ctypes.byref(nsvd))
+    out = dict(mu=mu, p=p, niter=niter.value, rc=rc, n_svd=nsvd.value)
+    if diagnostics:
+        out["diag_p"], out["diag_mu"] = dp[:niter.value], dm[:niter.value]
+    return out

@@ -1,0 +1,185 @@
+"""Pin the CPU oracle (oracle/frank_oracle.c) against the reference.
+
+Golden vectors: tests/golden/*.npz, produced by tools/make_golden.py importing
+discsim/frank v1.2.3 itself, plus the literal known-answer vectors of the reference's
+own data-free tests (frank/tests.py:37-94, 704-717).  CPU only.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_to_max, ulp_diff
+from frank_amd.constants import rad_to_arcsec
+from frank_amd.mock import MOCK_GEOMETRY, mock_disc_visibilities
+from oracle import oracle as fo
+
+GEOM = (MOCK_GEOMETRY["inc"], MOCK_GEOMETRY["PA"], MOCK_GEOMETRY["dRA"], MOCK_GEOMETRY["dDec"])
+RMAX = 2.0 / rad_to_arcsec
+
+
+def test_j0_matches_scipy_bitwise():
+    sp = pytest.importorskip("scipy.special")
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(0, 5, 20000), rng.uniform(5, 1000, 40000), 10 ** rng.uniform(-8, 0, 2000)])
+    assert np.array_equal(fo.j0(x), sp.j0(x))
+
+
+@pytest.mark.parametrize("N", [5, 20, 100, 300])
+def test_dht_setup(golden, N):
+    g = golden("dht_N%d.npz" % N)
+    d = fo.DHT(RMAX, N)
+    # collocation points: identical count / ordering, <= 1 ulp (hard part 6)
+    assert ulp_diff(np.append(d.j_nk, d.j_nN), g["zeros"]).max() <= 1
+    # r, q = Rmax*(j_k/j_N): two 1-ulp-different zeros enter each quotient
+    assert ulp_diff(d.r, g["r"]).max() <= 4 and ulp_diff(d.q, g["q"]).max() <= 4
+    assert ulp_diff(d.Qmax, g["Qmax"]).max() <= 2
+    np.testing.assert_allclose(d.scale_factor, g["scale_factor"], rtol=2e-13, atol=0)
+    # Ykm entries are O(1e-3..1) * J0(..): absolute agreement at the 1e-16 level
+    assert np.abs(d.Ykm - g["Ykm"]).max() <= 4e-16 * np.abs(g["Ykm"]).max() * 50
+    np.testing.assert_allclose(d.coefficients(), g["Y"], rtol=0, atol=1e-13 * np.abs(g["Y"]).max())
+    assert rel_to_max(d.transform(np.ones(N)), g["transform_ones"]) < 1e-12  # alternating sum: cancellation
+
+
+def test_collocation_points_reference_literals():
+    """frank/tests.py:704-717 (utilities.get_collocation_points(N=10), Rmax = 2 arcsec)."""
+    d = fo.DHT(RMAX, 10)
+    expected_r = [0.14239924, 0.32686567, 0.51242148, 0.69822343, 0.88411873,
+                  1.07005922, 1.25602496, 1.44200623, 1.62799772, 1.8139963]
+    expected_q = [39472.88305737, 90606.73736504, 142042.56471889, 193546.62066389,
+                  245076.55732463, 296619.01772663, 348168.47711355, 399722.24089812,
+                  451278.83939289, 502837.4032234]
+    np.testing.assert_allclose(d.r * rad_to_arcsec, expected_r, rtol=2e-5, atol=1e-8)
+    np.testing.assert_allclose(d.q, expected_q, rtol=2e-5, atol=1e-8)
+
+
+def test_hankel_gauss_reference_known_answer():
+    """frank/tests.py:37-94: Gaussian <-> Gaussian through the forward DHT, N=100, Rmax=5."""
+    d = fo.DHT(5.0, 100)
+    Ir = np.exp(-0.5 * d.r ** 2)
+    Iq = np.exp(-0.5 * (2 * np.pi * d.q) ** 2) * (2 * np.pi)
+    np.testing.assert_allclose(Iq, d.transform(Ir), atol=1e-5, rtol=0)
+    q = np.linspace(0.0, 1.0, 25)
+    np.testing.assert_allclose(np.exp(-0.5 * (2 * np.pi * q) ** 2) * 2 * np.pi, d.coefficients(q) @ Ir,
+                               atol=1e-4, rtol=0)
+    np.testing.assert_allclose(d.coefficients() @ Ir, d.transform(Ir), rtol=1e-7)
+    np.testing.assert_allclose(d.coefficients(d.q), d.coefficients(), atol=1e-12, rtol=0)
+
+
+@pytest.mark.parametrize("N", [100, 300])
+def test_dht_probe_coefficients(golden, N):
+    g = golden("dht_probe.npz")
+    d = fo.DHT(RMAX, N)
+    H = d.coefficients(g["q_N%d" % N])
+    ref = g["H_N%d" % N]
+    # H = (norm*sf_k) * j0(x): x may differ by 1 ulp when a zero differs by 1 ulp -> |dJ0| <= x*eps
+    assert np.abs(H - ref).max() <= 3e-13 * np.abs(ref).max()
+
+
+def test_geometry(golden):
+    g = golden("geometry_small.npz")
+    up, vp, wp, Vp = fo.apply_correction(g["u"], g["v"], g["V"], *GEOM)
+    for a, b in ((up, g["up"]), (vp, g["vp"]), (wp, g["wp"])):
+        assert ulp_diff(a, b).max() <= 1
+    np.testing.assert_allclose(Vp, g["Vp"], rtol=0, atol=4e-16 * np.abs(g["Vp"]).max())
+
+
+def test_map_small(golden):
+    g = golden("map_small.npz")
+    N = int(g["N"])
+    m = fo.map_visibilities(N, RMAX, GEOM, g["u"], g["v"], g["V"], g["w"], check_qbounds=False)
+    assert m["rc"] == 0
+    assert rel_to_max(m["M"], g["M"]) < 5e-14
+    assert rel_to_max(m["j"], g["j"]) < 5e-14
+    assert abs(m["null_likelihood"] - g["H0"]) <= 1e-13 * abs(g["H0"])
+    mt = fo.map_visibilities(N, RMAX, GEOM, g["u"], g["v"], g["V"], g["w"], vis_model=1, check_qbounds=False)
+    assert rel_to_max(mt["M"], g["M_thin"]) < 5e-14 and rel_to_max(mt["j"], g["j_thin"]) < 5e-14
+    ms = fo.map_visibilities(N, RMAX, GEOM, g["u"], g["v"], g["V"], 400.0, check_qbounds=False, block_size=777)
+    assert rel_to_max(ms["M"], g["M_scalar_w"]) < 5e-14
+    assert abs(ms["null_likelihood"] - g["H0_scalar_w"]) <= 1e-13 * abs(g["H0_scalar_w"])
+
+
+def test_map_qrange_error():
+    """statistical_models.py:526-535: ValueError when q_k[-1] < max(q)."""
+    u, v, V, w = mock_disc_visibilities(500, seed=2)
+    m = fo.map_visibilities(10, RMAX, GEOM, u, v, V, w, check_qbounds=True)
+    assert m["rc"] == fo.FO_ERR_QRANGE
+    assert fo.map_visibilities(10, RMAX, GEOM, u, v, V, w, check_qbounds=False)["rc"] == 0
+
+
+def test_gaussian_model_and_update(golden):
+    g = golden("map_small.npz")
+    N = int(g["N"])
+    d = fo.DHT(RMAX, N)
+    mu, chol, Sinv, rc = fo.gaussian_model(d, g["M"], g["j"], g["p_in"])
+    assert rc == 0
+    assert rel_to_max(Sinv, g["Sinv"]) < 1e-13
+    assert rel_to_max(mu, g["mu"]) < 1e-9
+    assert rel_to_max(np.triu(chol), g["chol_upper"]) < 1e-10
+    T, band = fo.smoothing_matrix(d, 1e-4)
+    p_new = fo.update_power_spectrum(d, band, 1.05, 1e-15, g["p_in"], mu, chol)
+    np.testing.assert_allclose(p_new, g["p_updated"], rtol=1e-8)
+    # no prior (FourierBesselFitter._fit, radial_fitters.py:576)
+    mu0, _, _, rc0 = fo.gaussian_model(d, g["M"], g["j"], None)
+    if rc0 == 0:
+        assert rel_to_max(mu0, g["I_fb"]) < 1e-4
+
+
+def test_gaussian_model_bad_p(golden):
+    g = golden("map_small.npz")
+    d = fo.DHT(RMAX, int(g["N"]))
+    p = g["p_in"].copy()
+    p[3] = -1.0
+    assert fo.gaussian_model(d, g["M"], g["j"], p)[3] == fo.FO_ERR_BAD_P
+    p[3] = np.nan
+    assert fo.gaussian_model(d, g["M"], g["j"], p)[3] == fo.FO_ERR_BAD_P
+
+
+@pytest.mark.parametrize("N", [20, 100])
+def test_smoothing_matrix(golden, N):
+    g = golden("smoothing_T.npz")
+    T, _ = fo.smoothing_matrix(fo.DHT(RMAX, N), float(g["w_N%d" % N]))
+    assert rel_to_max(T, g["T_N%d" % N]) < 1e-12
+
+
+def test_fit_sweep(golden):
+    """Two hyper-parameter points on one mapping; iteration counts differ widely."""
+    g = golden("sweep_N50_2e4.npz")
+    for tag in "ab":
+        out = fo.frank_fit_normal(50, RMAX, g["M"], g["j"], alpha=float(g["alpha_" + tag]),
+                                  wsmooth=float(g["wsmooth_" + tag]))
+        assert out["rc"] == 0 and out["n_svd"] == 0
+        assert out["niter"] == int(g["niter_" + tag])
+        assert rel_to_max(out["mu"], g["I_" + tag]) < 1e-6
+        np.testing.assert_allclose(out["p"], g["p_" + tag], rtol=1e-5)
+    out = fo.frank_fit_normal(50, RMAX, g["M"], g["j"], max_iter=10)
+    assert out["niter"] == int(g["niter_maxiter10"]) == 11
+    assert rel_to_max(out["mu"], g["I_maxiter10"]) < 1e-6
+
+
+def test_fit_config1_from_reference_M(golden):
+    """BASELINE config 1: N=100, 1e5 vis, Normal, alpha=1.05 -- iteration loop on the reference's own M, j."""
+    g = golden("fit_N100_1e5.npz")
+    out = fo.frank_fit_normal(100, RMAX, g["M"], g["j"], alpha=float(g["alpha"]), wsmooth=float(g["wsmooth"]),
+                              diagnostics=True)
+    assert out["niter"] == int(g["niter"])
+    assert rel_to_max(out["mu"], g["I"]) < 1e-6
+    np.testing.assert_allclose(out["diag_p"][:5], g["diag_p_first"], rtol=1e-6)
+    assert rel_to_max(out["diag_mu"][:5], g["diag_mu_first"]) < 1e-7
+    np.testing.assert_allclose(out["diag_p"][-1], g["diag_p_last"], rtol=1e-5)
+
+
+def test_fit_config1_end_to_end(golden):
+    """Same, but with M, j rebuilt by the oracle from the regenerated (seeded) visibilities."""
+    g = golden("fit_N100_1e5.npz")
+    u, v, V, w = mock_disc_visibilities(int(g["n"]), seed=int(g["seed"]), noise_seed=int(g["noise_seed"]))
+    import hashlib
+    h = hashlib.sha256()
+    for a in (u, v, V, w):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert h.hexdigest() == str(g["input_sha256"]), "mock generator no longer reproduces the fixture inputs"
+    m = fo.map_visibilities(100, RMAX, GEOM, u, v, V, w)
+    assert m["rc"] == 0
+    assert rel_to_max(m["M"], g["M"]) < 1e-13 and rel_to_max(m["j"], g["j"]) < 1e-13
+    assert abs(m["null_likelihood"] - float(g["H0"])) <= 1e-13 * abs(float(g["H0"]))
+    out = fo.frank_fit_normal(100, RMAX, m["M"], m["j"], alpha=float(g["alpha"]), wsmooth=float(g["wsmooth"]))
+    assert out["niter"] == int(g["niter"])
+    assert rel_to_max(out["mu"], g["I"]) < 1e-6

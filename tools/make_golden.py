@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ (run in the BUILD container only).
+
+This script imports the *reference itself* (discsim/frank v1.2.3 at /root/reference,
+with the container's numpy / scipy) and records inputs and outputs of the hot path on
+seeded synthetic data.  The reference cannot travel to the GPU box; these .npz files
+(data only) and the CPU oracle they pin are the referee there.
+
+    python3 tools/make_golden.py            # everything (~4 min: the N=300 fit is slow)
+    python3 tools/make_golden.py --quick    # skip the N=300 / 1e6 case
+"""
+import argparse
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, ".."))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+import scipy  # noqa: E402
+import frank  # noqa: E402
+from frank.constants import rad_to_arcsec  # noqa: E402
+from frank.filter import CriticalFilter, spectral_smoothing_matrix  # noqa: E402
+from frank.geometry import FixedGeometry  # noqa: E402
+from frank.hankel import DiscreteHankelTransform  # noqa: E402
+from frank.radial_fitters import FourierBesselFitter, FrankFitter  # noqa: E402
+from frank.statistical_models import GaussianModel  # noqa: E402
+
+from frank_amd.mock import MOCK_GEOMETRY, mock_disc_visibilities  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+META = dict(reference_version=frank.__version__, numpy=np.__version__, scipy=scipy.__version__)
+RMAX = 2.0  # arcsec
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrs, **{"meta_" + k: v for k, v in META.items()})
+    print("  wrote %-28s %8.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+def checksum(*arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def geom():
+    return FixedGeometry(**MOCK_GEOMETRY)
+
+
+def dht_fixtures():
+    print("DHT set-up (hankel.py:55-93)")
+    for N in (5, 20, 100, 300):
+        D = DiscreteHankelTransform(RMAX / rad_to_arcsec, N)
+        from scipy.special import jn_zeros
+        save("dht_N%d.npz" % N, Rmax=D.Rmax, N=N, zeros=jn_zeros(0, N + 1), r=D.r, q=D.q, Qmax=D.Qmax,
+             Ykm=D._Ykm, scale_factor=D._scale_factor, Y=D.coefficients(),
+             transform_ones=D.transform(np.ones(N)))
+    rng = np.random.default_rng(7)
+    probes = {}
+    for N in (100, 300):
+        D = DiscreteHankelTransform(RMAX / rad_to_arcsec, N)
+        q = np.concatenate([[0.0, 1.0, D.q[0], D.q[-1]], np.exp(rng.uniform(np.log(1e3), np.log(D.q[-1]), 60))])
+        probes["q_N%d" % N] = q
+        probes["H_N%d" % N] = D.coefficients(q)
+    save("dht_probe.npz", **probes)
+
+
+def geometry_fixture():
+    print("geometry.apply_correction (geometry.py:202-236)")
+    u, v, V, w = mock_disc_visibilities(256, seed=3, noise_seed=4)
+    up, vp, wp, Vp = geom().apply_correction(u, v, V, use3D=True)
+    save("geometry_small.npz", u=u, v=v, V=V, up=up, vp=vp, wp=wp, Vp=Vp, **MOCK_GEOMETRY)
+
+
+def map_small():
+    print("map_visibilities, N=40, 3000 vis (statistical_models.py:109-237)")
+    u, v, V, w = mock_disc_visibilities(3000, seed=11, noise_seed=12)
+    w = w * np.random.default_rng(13).uniform(0.5, 2.0, w.size)  # ragged weights
+    out = dict(u=u, v=v, V=V, w=w, N=40, Rmax=RMAX)
+    FB = FourierBesselFitter(RMAX, 40, geom(), verbose=False)
+    m = FB.preprocess_visibilities(u, v, V, w)
+    out.update(M=m["M"], j=m["j"], H0=m["null_likelihood"])
+    sol = FB.fit_preprocessed(m)  # no prior: GaussianModel(p=None), radial_fitters.py:576
+    out.update(I_fb=sol.I)
+    # optically thin variant (scale = 1, statistical_models.py:491-493)
+    FBt = FourierBesselFitter(RMAX, 40, geom(), assume_optically_thick=False, verbose=False)
+    mt = FBt.preprocess_visibilities(u, v, V, w)
+    out.update(M_thin=mt["M"], j_thin=mt["j"])
+    # scalar weight (statistical_models.py:173) and a different block size
+    FBb = FourierBesselFitter(RMAX, 40, geom(), block_size=777, verbose=False)
+    mb = FBb.preprocess_visibilities(u, v, V, 400.0)
+    out.update(M_scalar_w=mb["M"], j_scalar_w=mb["j"], H0_scalar_w=mb["null_likelihood"])
+    # one GaussianModel solve with a power-law prior + one power-spectrum update
+    D = FB._DHT
+    p = 1e-2 * (D.q / D.q[0]) ** -2
+    fit = GaussianModel(D, m["M"], m["j"], p)
+    filt = CriticalFilter(D, 1.05, 1e-15, 1e-4)
+    out.update(p_in=p, mu=fit.mean, Sinv=fit._Sinv, chol_upper=np.triu(fit._Dchol[0]),
+               p_updated=filt.update_power_spectrum(fit), cov_diag=np.diag(fit.covariance).copy())
+    save("map_small.npz", **out)
+
+
+def smoothing():
+    print("spectral_smoothing_matrix (filter.py:23-62)")
+    out = {}
+    for N, wgt in ((20, 1e-4), (100, 1e-2)):
+        D = DiscreteHankelTransform(RMAX / rad_to_arcsec, N)
+        out["T_N%d" % N] = np.asarray(spectral_smoothing_matrix(D, wgt).todense())
+        out["w_N%d" % N] = wgt
+    save("smoothing_T.npz", **out)
+
+
+def fit_case(name, N, n, alpha, wsmooth, keep_M, seed=0, noise_seed=50):
+    print("FrankFitter N=%d, %g vis, alpha=%g, wsmooth=%g (radial_fitters.py:737-832)" % (N, n, alpha, wsmooth))
+    u, v, V, w = mock_disc_visibilities(int(n), seed=seed, noise_seed=noise_seed)
+    FF = FrankFitter(RMAX, N, geom(), alpha=alpha, weights_smooth=wsmooth, store_iteration_diagnostics=True,
+                     verbose=False)
+    t0 = time.perf_counter()
+    m = FF.preprocess_visibilities(u, v, V, w)
+    t1 = time.perf_counter()
+    sol = FF.fit_preprocessed(m)
+    t2 = time.perf_counter()
+    d = FF.iteration_diagnostics
+    nit = d["num_iterations"]
+    out = dict(N=N, n=int(n), seed=seed, noise_seed=noise_seed, alpha=alpha, wsmooth=wsmooth, Rmax=RMAX,
+               input_sha256=checksum(u, v, V, w), j=m["j"], H0=m["null_likelihood"], I=sol.I,
+               p=sol.power_spectrum, niter=nit, diag_p_first=np.array(d["power_spectrum"][:5]),
+               diag_mu_first=np.array(d["MAP"][:5]), diag_p_last=d["power_spectrum"][-1],
+               diag_mu_last=d["MAP"][-1], t_map=t1 - t0, t_fit=t2 - t1,
+               M_diag=np.diag(m["M"]).copy(), M_row0=m["M"][0].copy(), M_fro=np.linalg.norm(m["M"]))
+    if keep_M:
+        out["M"] = m["M"]
+    print("    niter=%d  map %.2fs  fit %.2fs" % (nit, t1 - t0, t2 - t1))
+    save(name, **out)
+    return m, FF
+
+
+def sweep():
+    print("two-stage API sweep (radial_fitters.py:468-542), N=50, 2e4 vis")
+    u, v, V, w = mock_disc_visibilities(20000, seed=5, noise_seed=6)
+    out = dict(N=50, n=20000, seed=5, noise_seed=6, input_sha256=checksum(u, v, V, w))
+    FF0 = FrankFitter(RMAX, 50, geom(), verbose=False)
+    m = FF0.preprocess_visibilities(u, v, V, w)
+    out.update(M=m["M"], j=m["j"], H0=m["null_likelihood"])
+    for tag, (a, ws) in dict(a=(1.05, 1e-4), b=(1.3, 1e-1)).items():
+        FF = FrankFitter(RMAX, 50, geom(), alpha=a, weights_smooth=ws, store_iteration_diagnostics=True,
+                         verbose=False)
+        sol = FF.fit_preprocessed(m)
+        out["alpha_" + tag], out["wsmooth_" + tag] = a, ws
+        out["I_" + tag], out["p_" + tag] = sol.I, sol.power_spectrum
+        out["niter_" + tag] = FF.iteration_diagnostics["num_iterations"]
+        print("    alpha=%g ws=%g niter=%d" % (a, ws, out["niter_" + tag]))
+    # max_iter hit -> RuntimeError / ignore (radial_fitters.py:788-815)
+    FFi = FrankFitter(RMAX, 50, geom(), max_iter=10, convergence_failure="ignore",
+                      store_iteration_diagnostics=True, verbose=False)
+    soli = FFi.fit_preprocessed(m)
+    out.update(I_maxiter10=soli.I, p_maxiter10=soli.power_spectrum,
+               niter_maxiter10=FFi.iteration_diagnostics["num_iterations"])
+    save("sweep_N50_2e4.npz", **out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    dht_fixtures()
+    geometry_fixture()
+    map_small()
+    smoothing()
+    sweep()
+    fit_case("fit_N100_1e5.npz", 100, 1e5, 1.05, 1e-4, keep_M=True)
+    if not args.quick:
+        fit_case("fit_N300_1e6.npz", 300, 1e6, 1.05, 1e-4, keep_M=True)
+
+
+if __name__ == "__main__":
+    main()
