@@ -1,0 +1,119 @@
+"""ctypes binding of libfrank_hip.so (include/frank_hip.h).  No torch, no fallbacks.
+
+The shared object is built in-tree by __graft_entry__.build() / `make -C frank_amd/csrc`.
+If it is missing, importing this module raises; if it is present but no GPU is usable,
+every device entry point raises RuntimeError (FH_ERR_HIP) -- there is no CPU path.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfrank_hip.so")
+
+FH_OK = 0
+FH_ERR_INVALID = -1
+FH_ERR_QRANGE = -2
+FH_ERR_BAD_P = -3
+FH_ERR_NOT_SPD = -4
+FH_ERR_NOMEM = -5
+FH_ERR_HIP = -6
+FH_ERR_UNSUPPORTED = -7
+
+VIS_MODELS = {"opt_thick": 0, "opt_thin": 1}
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+
+
+class fh_geometry(ctypes.Structure):
+    _fields_ = [("inc_deg", ctypes.c_double), ("PA_deg", ctypes.c_double), ("dRA_arcsec", ctypes.c_double),
+                ("dDec_arcsec", ctypes.c_double)]
+
+
+# name -> (restype, argtypes); every symbol include/frank_hip.h declares
+SIGNATURES = {
+    "fh_last_error": (ctypes.c_char_p, []),
+    "fh_version": (ctypes.c_char_p, []),
+    "fh_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "fh_dht_create": (ctypes.c_int, [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
+    "fh_dht_destroy": (None, [_vp]),
+    "fh_dht_size": (ctypes.c_int, [_vp]),
+    "fh_dht_get": (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "fh_ctx_create": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_vp)]),
+    "fh_ctx_destroy": (None, [_vp]),
+    "fh_ctx_synchronize": (ctypes.c_int, [_vp]),
+    "fh_ctx_stream": (_vp, [_vp]),
+    "fh_dht_coefficients": (ctypes.c_int, [_vp, _dp, _i64, ctypes.c_int, ctypes.c_double, _dp]),
+    "fh_predict_visibilities": (ctypes.c_int, [_vp, _dp, _i64, _dp, ctypes.c_double, _dp]),
+    "fh_vis_upload": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _i64, _i64, ctypes.POINTER(_vp)]),
+    "fh_vis_destroy": (None, [_vp]),
+    "fh_vis_size": (_i64, [_vp]),
+    "fh_bin_reset": (ctypes.c_int, [_vp]),
+    "fh_bin_visibilities": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), _vp, _i64, _i64]),
+    "fh_bin_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    "fh_stats_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64), ctypes.POINTER(_vp)]),
+    "fh_stats_finalize": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), ctypes.c_int, ctypes.c_int, _dp, _dp, _dp,
+                                         _dp, _dp]),
+    "fh_map_visibilities": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), ctypes.c_int, ctypes.c_int, _dp, _dp,
+                                           _dp, _dp, _dp, _i64, _i64, _dp, _dp, _dp, _dp, _dp]),
+    "fh_gaussian_model": (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, ctypes.POINTER(ctypes.c_int)]),
+    "fh_cho_solve": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int]),
+    "fh_fit_normal": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                     ctypes.c_double, ctypes.c_int, _dp, _dp, ctypes.POINTER(ctypes.c_int), _dp, _dp]),
+    "fh_update_power_spectrum": (ctypes.c_int, [_vp, _dp, _dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                                _dp, _dp]),
+    "fh_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "fh_comm_create": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.POINTER(_vp)]),
+    "fh_comm_destroy": (None, [_vp]),
+    "fh_comm_allreduce_stats": (ctypes.c_int, [_vp, _vp]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "frank_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+        "`make -C frank_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH)
+for _name, (_res, _args) in SIGNATURES.items():
+    _f = getattr(lib, _name)  # AttributeError here = header / library mismatch
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+def last_error():
+    return lib.fh_last_error().decode("utf-8", "replace")
+
+
+def check(rc, value_error_codes=(FH_ERR_INVALID, FH_ERR_QRANGE, FH_ERR_BAD_P)):
+    """Map FH_ERR_* to the exception class the reference raises for the same condition."""
+    if rc == FH_OK:
+        return
+    msg = last_error()
+    if rc in value_error_codes:
+        raise ValueError(msg)
+    if rc == FH_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError("frank_amd [%d]: %s" % (rc, msg))
+
+
+def f8(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    lib.fh_device_count(ctypes.byref(n))
+    return n.value
+
+
+def make_geometry(geometry):
+    """fh_geometry from any object with inc / PA / dRA / dDec attributes (degrees, arcsec)."""
+    return fh_geometry(float(geometry.inc), float(geometry.PA), float(geometry.dRA), float(geometry.dDec))

@@ -1,0 +1,497 @@
+// K1 `bin_gram`: fused deprojection + Bessel design block + weighted Gram on gfx950.
+//
+// Replaces the chunk loop of VisibilityMapping.map_visibilities (statistical_models.py:165-218),
+// with geometry.apply_correction (geometry.py:69-79, 111-131) and DHT.coefficients
+// (hankel.py:201-202) fused in.  Per visibility i the kernel forms the row
+//     Xt[i, k] = sqrt(w_i) J0((q_i / Qmax) j_k)  (k < N),   Xt[i, N] = sqrt(w_i) Re V'_i,   0 beyond,
+// and accumulates the symmetric Gram  G = Xt^T Xt  with v_mfma_f64_16x16x4_f64, so that
+//     M[k,l] = a_k a_l G[k,l],  j[k] = a_k G[k,N],  sum w V'^2 = G[N,N],   a_k = norm sf_k scale.
+// The DHT scaling a_k (~1e-14) is applied once afterwards in fp64 (finalize kernel), so the
+// Gram itself has O(1) entries.
+//
+// Work decomposition (DESIGN.md "K1"):
+//   * one 512-thread workgroup per CU = 8 waves, two per SIMD: while one wave of a SIMD waits on the
+//     matrix pipe the other issues the J0 polynomial work (VALU), and the two are started in
+//     opposite phase (waves 0-3 produce-then-consume, waves 4-7 consume-then-produce);
+//   * the upper triangle of the NBT x NBT grid of 16x16 output tiles (190 tiles at N = 300) is kept
+//     in accumulator registers for the whole visibility stream.  190 tiles x 8 registers do not fit
+//     one CU beside the J0 temporaries, so for NBT = 19 the triangle is cut row-aligned into two
+//     PARTS (tile rows 0-6: 112 tiles, rows 7-18: 78 tiles); the grid is split between the parts
+//     in proportion to their tile counts, and every part streams ALL visibilities.  A part only
+//     evaluates the J0 columns it needs (part 1: columns >= 112), so J0 is evaluated 1.68x;
+//   * visibilities are streamed in super-chunks of 512 (one thread deprojects one visibility) and
+//     chunks of 16 rows; a chunk's rows are written to LDS (double-buffered) by all eight waves and
+//     read back as MFMA fragments (the A-fragment of block I is the B-fragment of block I);
+//   * each workgroup writes its partial tiles once; a second kernel reduces the slabs in a fixed
+//     order (bitwise reproducible) and a third applies the DHT scaling and mirrors the triangle.
+#include <hip/hip_runtime.h>
+
+#include <utility>
+
+#include "bessel.h"
+#include "kernels.h"
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kThreads = 512;
+constexpr int kWaves = 8;
+constexpr int kSuper = 512;  // visibilities per super-chunk (one per thread in the prologue)
+constexpr int kChunk = 16;   // rows per LDS buffer = 4 MFMA k-steps; 2 rows produced per wave
+constexpr int kChunksPerSuper = kSuper / kChunk;
+
+constexpr int xstride(int NBT) {  // LDS row stride in doubles, == 16 (mod 32): conflict-free fragment reads
+    return (NBT * 16) % 32 == 16 ? NBT * 16 : NBT * 16 + 16;
+}
+constexpr int ntiles(int NBT) { return NBT * (NBT + 1) / 2; }
+// t-th tile of the upper triangle in row-major order -> (I, J)
+constexpr int tile_I(int NBT, int t) {
+    int I = 0;
+    while (t >= NBT - I) {
+        t -= NBT - I;
+        ++I;
+    }
+    return I;
+}
+constexpr int tile_J(int NBT, int t) {
+    int I = 0;
+    while (t >= NBT - I) {
+        t -= NBT - I;
+        ++I;
+    }
+    return I + t;
+}
+constexpr int row_first_tile(int NBT, int I) { return I * NBT - I * (I - 1) / 2; }
+// parts: NBT = 19 -> rows [0,7) and [7,19); otherwise one part
+constexpr int nparts(int NBT) { return NBT > 13 ? 2 : 1; }
+constexpr int part_row0(int NBT, int P) { return (NBT > 13 && P == 1) ? 7 : 0; }
+constexpr int part_row1(int NBT, int P) { return (NBT > 13 && P == 0) ? 7 : NBT; }
+constexpr int part_tile0(int NBT, int P) { return row_first_tile(NBT, part_row0(NBT, P)); }
+constexpr int part_tile1(int NBT, int P) { return row_first_tile(NBT, part_row1(NBT, P)); }
+
+struct VisScalars {  // per-visibility results of the prologue, kept in LDS
+    double s;    // (1/Qmax) * q            -> x = s * j_k   (hankel.py:189,202)
+    double sw;   // sqrt(w)
+    double swV;  // sqrt(w) * Re V'
+};
+
+// geometry.py:69-79 (inverse phase shift, NumPy's Smith complex division), :111-131 (deproject),
+// statistical_models.py:166 (hypot).  Every product/sum rounds separately, as the NumPy expressions do.
+__device__ __forceinline__ void deproject_one(const BinParams &p, int64_t i, VisScalars &out, double &logw,
+                                              double &q_out) {
+#pragma clang fp contract(off)
+    const double u = p.u[i], v = p.v[i];
+    const double Vre = p.Vre[i];
+    const double Vim = p.Vim ? p.Vim[i] : 0.0;
+    const double w = p.w[p.w_scalar ? 0 : i];
+    const double phi = u * p.dRA + v * p.dDec;
+    double sn, cs;
+    sincos(phi, &sn, &cs);
+    double re;
+    if (fabs(cs) >= fabs(sn)) {
+        const double rat = sn / cs, scl = 1.0 / (cs + sn * rat);
+        re = (Vre + Vim * rat) * scl;
+    } else {
+        const double rat = cs / sn, scl = 1.0 / (sn + cs * rat);
+        re = (Vre * rat + Vim) * scl;
+    }
+    double up = u * p.cos_t - v * p.sin_t;
+    const double vp = u * p.sin_t + v * p.cos_t;
+    up = up * p.cos_i;
+    const double q = hypot(up, vp);
+    const double sw = sqrt(w);
+    out.s = p.inv_Qmax * q;
+    out.sw = sw;
+    out.swV = sw * re;
+    logw = log(w / (2 * M_PI));  // statistical_models.py:218
+    q_out = q;
+}
+
+template <int NBT, int P, int W, int T>
+__device__ __forceinline__ void mfma_one(v4f64 &acc, const double (&f)[NBT]) {
+    constexpr int tt = part_tile0(NBT, P) + W + T * kWaves;
+    constexpr int I = tile_I(NBT, tt), J = tile_J(NBT, tt);
+    // A[i][k] = Xt[k][16I+i] and B[k][j] = Xt[k][16J+j] share one fragment layout: lane -> (k = lane>>4, i|j = lane&15)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f[I], f[J], acc, 0, 0, 0);
+}
+template <int NBT, int P, int W, int TPW, int... Ts>
+__device__ __forceinline__ void mfma_all(v4f64 (&acc)[TPW], const double (&f)[NBT],
+                                         std::integer_sequence<int, Ts...>) {
+    (mfma_one<NBT, P, W, Ts>(acc[Ts], f), ...);
+}
+
+template <int NBT, int P, int W>
+__device__ __forceinline__ void wave_main(const BinParams &p, double *smem, int part_block, int part_nblocks) {
+    constexpr int NC = NBT * 16;
+    constexpr int XS = xstride(NBT);
+    constexpr int T0 = part_tile0(NBT, P), T1 = part_tile1(NBT, P);
+    constexpr int NTP = T1 - T0;                             // tiles of this part
+    constexpr int TPW = (NTP - W + kWaves - 1) / kWaves;     // tiles of this wave: T0 + W, T0 + W + 8, ...
+    constexpr int B0 = part_row0(NBT, P);                    // first column block this part needs
+    constexpr int C0 = B0 * 16;                              // first column
+    constexpr int NCG = (NC - C0 + 63) / 64;                 // column groups of 64 lanes
+    static_assert(TPW >= 1, "every wave owns at least one tile");
+
+    double *tab = smem;                                                                // FH_J0_TABLE_DOUBLES
+    VisScalars *vs = reinterpret_cast<VisScalars *>(tab + FH_J0_TABLE_DOUBLES);   // [2][kSuper]
+    double *X = reinterpret_cast<double *>(vs + 2 * kSuper);                           // [2][kChunk][XS]
+    double *red = X + 2 * kChunk * XS;                                                 // [3 * kWaves]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int N = p.N;
+
+    // zeros j_k of this lane's columns (col = C0 + cg*64 + lane); 0 beyond N so that J0 = 1 there
+    double jk[NCG];
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) {
+        const int col = C0 + cg * 64 + lane;
+        jk[cg] = col < N ? p.zeros[col] : 0.0;
+    }
+
+    v4f64 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
+
+    double sum_logw = 0.0, qmin = INFINITY, qmax = -INFINITY;
+
+    const int64_t nsuper = (p.count + kSuper - 1) / kSuper;
+    const int kk = lane >> 4, ii = lane & 15;
+
+    // ---- prologue of one super-chunk into vs[buf] -------------------------------------------------------
+    auto prologue = [&](int64_t sc, int buf) {
+        const int64_t i = sc * kSuper + tid;
+        VisScalars o;
+        if (sc < nsuper && i < p.count) {
+            double lw, q;
+            deproject_one(p, p.first + i, o, lw, q);
+            sum_logw += lw;
+            qmin = fmin(qmin, q);
+            qmax = fmax(qmax, q);
+        } else {
+            o.s = 0.0;
+            o.sw = 0.0;
+            o.swV = 0.0;  // padded rows contribute exactly zero
+        }
+        vs[buf * kSuper + tid] = o;
+    };
+    // ---- one J0 row (this wave produces rows 2W, 2W+1 of every chunk) -------------------------------------
+    auto produce_row = [&](int sbuf, int ch, int xbuf, int rr) {
+        const int row = W * 2 + rr;
+        const VisScalars o = vs[sbuf * kSuper + ch * kChunk + row];
+        double *xr = X + (xbuf * kChunk + row) * XS;
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg) {
+            const int col = C0 + cg * 64 + lane;
+            double x;
+            {
+#pragma clang fp contract(off)
+                x = o.s * jk[cg];  // fl(fl(k*q) * j_k), hankel.py:202
+            }
+            const double val = fh_j0(x, tab);
+            // columns < N: sqrt(w) J0;  column N: sqrt(w) Re V';  beyond: 0   (J0(0) = 1 there)
+            const double outv = col < N ? val * o.sw : (col == N ? o.swV : 0.0);
+            if ((NC - C0) % 64 == 0 || col < NC) xr[col] = outv;
+            // keep at most two evaluations in flight: bounds the live J0 temporaries beside the accumulators
+            if (cg % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // ---- MFMAs of one k-step (4 rows) of X[xbuf] ---------------------------------------------------------
+    auto consume_kstep = [&](int xbuf, int ks) {
+        const double *xb = X + (xbuf * kChunk + ks * 4 + kk) * XS + ii;
+        double f[NBT];
+#pragma unroll
+        for (int b = 0; b < NBT; ++b) f[b] = b >= B0 ? xb[b * 16] : 0.0;
+        mfma_all<NBT, P, W, TPW>(acc, f, std::make_integer_sequence<int, TPW>{});
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- main loop over this workgroup's super-chunks ----------------------------------------------------
+    int64_t sc = part_block;
+    int sbuf = 0, xbuf = 0;
+    if (sc < nsuper) {
+        prologue(sc, 0);
+        __syncthreads();
+        produce_row(0, 0, 0, 0);
+        produce_row(0, 0, 0, 1);
+        __syncthreads();
+    }
+    for (; sc < nsuper; sc += part_nblocks) {
+        const int64_t sc_next = sc + part_nblocks;
+        // next super-chunk's scalars (other vs buffer); visible after the first barrier below
+        prologue(sc_next, sbuf ^ 1);
+#pragma unroll 1
+        for (int ch = 0; ch < kChunksPerSuper; ++ch) {
+            const bool last = (ch == kChunksPerSuper - 1);
+            const bool more = !last || sc_next < nsuper;
+            const int nsb = last ? (sbuf ^ 1) : sbuf;
+            const int nch = last ? 0 : ch + 1;
+            // J0 rows of chunk c+1 (VALU) against the MFMAs of chunk c (matrix pipe); the two waves of a
+            // SIMD (W and W+4) run the two halves in opposite order.
+            if (W < 4) {
+                if (more) produce_row(nsb, nch, xbuf ^ 1, 0);
+                consume_kstep(xbuf, 0);
+                consume_kstep(xbuf, 1);
+                if (more) produce_row(nsb, nch, xbuf ^ 1, 1);
+                consume_kstep(xbuf, 2);
+                consume_kstep(xbuf, 3);
+            } else {
+                consume_kstep(xbuf, 0);
+                consume_kstep(xbuf, 1);
+                if (more) produce_row(nsb, nch, xbuf ^ 1, 0);
+                consume_kstep(xbuf, 2);
+                consume_kstep(xbuf, 3);
+                if (more) produce_row(nsb, nch, xbuf ^ 1, 1);
+            }
+            __syncthreads();
+            xbuf ^= 1;
+        }
+        sbuf ^= 1;
+    }
+
+    // ---- write this workgroup's partial tiles: slab[part_block][tile - T0][reg][lane] ----------------------
+    double *slab = p.partials[P] + (size_t)part_block * NTP * 256;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tl = W + t * kWaves;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(size_t)tl * 256 + r * 64 + lane] = acc[t][r];
+    }
+    // ---- block reduction of the scalar statistics (part 0 only; fixed order) -------------------------------
+    if (P == 0) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            sum_logw += __shfl_down(sum_logw, off);
+            qmin = fmin(qmin, __shfl_down(qmin, off));
+            qmax = fmax(qmax, __shfl_down(qmax, off));
+        }
+        if (lane == 0) {
+            red[W * 3 + 0] = sum_logw;
+            red[W * 3 + 1] = qmin;
+            red[W * 3 + 2] = qmax;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0, mn = INFINITY, mx = -INFINITY;
+            for (int w = 0; w < kWaves; ++w) {
+                s += red[w * 3 + 0];
+                mn = fmin(mn, red[w * 3 + 1]);
+                mx = fmax(mx, red[w * 3 + 2]);
+            }
+            double *ps = p.partial_scalars + (size_t)part_block * 4;
+            ps[0] = s;
+            ps[1] = mn;
+            ps[2] = mx;
+            ps[3] = 0.0;
+        }
+    }
+}
+
+template <int NBT, int P>
+__device__ __forceinline__ void part_main(const BinParams &p, double *smem, int part_block, int part_nblocks) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    switch (wave) {
+        case 0: wave_main<NBT, P, 0>(p, smem, part_block, part_nblocks); break;
+        case 1: wave_main<NBT, P, 1>(p, smem, part_block, part_nblocks); break;
+        case 2: wave_main<NBT, P, 2>(p, smem, part_block, part_nblocks); break;
+        case 3: wave_main<NBT, P, 3>(p, smem, part_block, part_nblocks); break;
+        case 4: wave_main<NBT, P, 4>(p, smem, part_block, part_nblocks); break;
+        case 5: wave_main<NBT, P, 5>(p, smem, part_block, part_nblocks); break;
+        case 6: wave_main<NBT, P, 6>(p, smem, part_block, part_nblocks); break;
+        default: wave_main<NBT, P, 7>(p, smem, part_block, part_nblocks); break;
+    }
+}
+
+template <int NBT>
+__global__ __launch_bounds__(kThreads, 2) void bin_gram_kernel(BinParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    for (int i = threadIdx.x; i < FH_J0_TABLE_DOUBLES; i += kThreads) smem[i] = p.j0_table[i];
+    __syncthreads();
+    const int b = blockIdx.x;
+    if (nparts(NBT) == 1 || b < p.part_blocks[0]) {
+        part_main<NBT, 0>(p, smem, b, p.part_blocks[0]);
+    } else {
+        part_main<NBT, nparts(NBT) - 1>(p, smem, b - p.part_blocks[0], p.part_blocks[1]);
+    }
+}
+
+template <int NBT>
+constexpr size_t bin_smem_bytes() {
+    return sizeof(double) * (FH_J0_TABLE_DOUBLES + 2 * kSuper * 3 + 2 * kChunk * xstride(NBT) + 3 * kWaves);
+}
+
+// Sum the per-workgroup slabs of every part in block order and add into the running statistics.
+__global__ void reduce_partials_kernel(ReduceParams rp, double *stats_sum, double *stats_minmax) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ne = (int64_t)rp.ntiles * 256;
+    if (e < ne) {
+        const int part = (rp.nparts > 1 && e >= (int64_t)rp.part_tile0[1] * 256) ? 1 : 0;
+        const int64_t pe = e - (int64_t)rp.part_tile0[part] * 256;
+        const int64_t stride = (int64_t)rp.part_ntiles[part] * 256;
+        const double *src = rp.partials[part];
+        double s = 0.0;
+        for (int b = 0; b < rp.part_blocks[part]; ++b) s += src[(size_t)b * stride + pe];
+        stats_sum[e] += s;
+    }
+    if (e == 0) {
+        double s = 0.0, mn = INFINITY, mx = -INFINITY;
+        for (int b = 0; b < rp.part_blocks[0]; ++b) {
+            s += rp.partial_scalars[b * 4 + 0];
+            mn = fmin(mn, rp.partial_scalars[b * 4 + 1]);
+            mx = fmax(mx, rp.partial_scalars[b * 4 + 2]);
+        }
+        stats_sum[ne + 0] += s;
+        // min/max are kept as (-qmin, qmax) so that one max-all-reduce serves both
+        stats_minmax[0] = fmax(stats_minmax[0], -mn);
+        stats_minmax[1] = fmax(stats_minmax[1], mx);
+    }
+}
+
+// Apply a_k a_l, unpack the upper-triangle tiles to the dense symmetric M (N*N), j (N) and sum w V^2.
+__global__ void finalize_stats_kernel(const double *stats_sum, int NBT, int N, const double *a, double *M, double *j,
+                                      double *sumwV2) {
+    const int t = blockIdx.x;  // tile
+    int I = 0, tt = t;
+    while (tt >= NBT - I) {
+        tt -= NBT - I;
+        ++I;
+    }
+    const int J = I + tt;
+    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+    const int row = 16 * I + (lane >> 4) + 4 * r;
+    const int col = 16 * J + (lane & 15);
+    const double g = stats_sum[(size_t)t * 256 + r * 64 + lane];
+    if (row < N && col < N) {
+        const double m = (a[row] * a[col]) * g;
+        if (I != J || row <= col) {
+            M[(size_t)row * N + col] = m;
+            M[(size_t)col * N + row] = m;
+        }
+    } else if (row < N && col == N) {
+        j[row] = a[row] * g;
+    } else if (row == N && col == N) {
+        *sumwV2 = g;
+    }
+}
+
+// a3/a7: H[i,k] = (norm*sf_k) * J0((kq*q_i) * j_k) * scale   (hankel.py:201-202, statistical_models.py:507)
+__global__ void coefficients_kernel(const double *q, int64_t n, int N, const double *zeros, const double *pref,
+                                    double inv_Q, double scale, const double *j0_table, double *H) {
+    __shared__ double tab[FH_J0_TABLE_DOUBLES];
+    for (int i = threadIdx.x; i < FH_J0_TABLE_DOUBLES; i += blockDim.x) tab[i] = j0_table[i];
+    __syncthreads();
+    const int64_t total = n * (int64_t)N;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / N;
+        const int k = (int)(e - i * N);
+        double x;
+        {
+#pragma clang fp contract(off)
+            x = (inv_Q * q[i]) * zeros[k];
+        }
+        H[e] = (pref[k] * fh_j0(x, tab)) * scale;
+    }
+}
+
+// predict_visibilities: V_i = sum_k H[i,k] I_k, one wave per visibility row (statistical_models.py:326-328)
+__global__ void predict_kernel(const double *q, int64_t n, int N, const double *zeros, const double *pref,
+                               double inv_Q, double scale, const double *I, const double *j0_table, double *V) {
+    __shared__ double tab[FH_J0_TABLE_DOUBLES];
+    for (int i = threadIdx.x; i < FH_J0_TABLE_DOUBLES; i += blockDim.x) tab[i] = j0_table[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        const double s = inv_Q * q[i];
+        double a = 0.0;
+        for (int k = lane; k < N; k += 64) {
+            const double h = (pref[k] * fh_j0(s * zeros[k], tab)) * scale;
+            a = fma(h, I[k], a);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off);
+        if (lane == 0) V[i] = a;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+int fh_k1_nbt_for(int N) {
+    const int nb = (N + 1 + 15) / 16;
+    if (nb <= 4) return 4;
+    if (nb <= 8) return 8;
+    if (nb <= 13) return 13;
+    if (nb <= 19) return 19;
+    return 0;  // N > 303: not covered by the register-resident kernel
+}
+int fh_k1_ntiles(int NBT) { return ntiles(NBT); }
+int fh_k1_nparts(int NBT) { return nparts(NBT); }
+int fh_k1_part_tile0(int NBT, int P) { return part_tile0(NBT, P); }
+int fh_k1_part_ntiles(int NBT, int P) { return part_tile1(NBT, P) - part_tile0(NBT, P); }
+int fh_k1_super() { return kSuper; }
+
+template <int NBT>
+static hipError_t launch_bin(const BinParams &p, hipStream_t stream) {
+    constexpr size_t smem = bin_smem_bytes<NBT>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_gram_kernel<NBT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = p.part_blocks[0] + (nparts(NBT) > 1 ? p.part_blocks[1] : 0);
+    hipLaunchKernelGGL(bin_gram_kernel<NBT>, dim3(grid), dim3(kThreads), smem, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t fh_k1_launch_bin(int NBT, const BinParams &p, hipStream_t stream) {
+    switch (NBT) {
+        case 4: return launch_bin<4>(p, stream);
+        case 8: return launch_bin<8>(p, stream);
+        case 13: return launch_bin<13>(p, stream);
+        case 19: return launch_bin<19>(p, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t fh_k1_launch_reduce(const ReduceParams &rp, double *stats_sum, double *stats_minmax,
+                               hipStream_t stream) {
+    const int64_t ne = (int64_t)rp.ntiles * 256;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, rp,
+                       stats_sum, stats_minmax);
+    return hipGetLastError();
+}
+
+hipError_t fh_k1_launch_finalize(const double *stats_sum, int NBT, int N, const double *a, double *M, double *j,
+                                 double *sumwV2, hipStream_t stream) {
+    hipLaunchKernelGGL(finalize_stats_kernel, dim3(ntiles(NBT)), dim3(256), 0, stream, stats_sum, NBT, N, a, M, j,
+                       sumwV2);
+    return hipGetLastError();
+}
+
+hipError_t fh_k1_launch_coefficients(const double *q, int64_t n, int N, const double *zeros, const double *pref,
+                                     double inv_Q, double scale, const double *j0_table, double *H,
+                                     hipStream_t stream) {
+    const int64_t total = n * (int64_t)N;
+    int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(coefficients_kernel, dim3(grid), dim3(256), 0, stream, q, n, N, zeros, pref, inv_Q, scale,
+                       j0_table, H);
+    return hipGetLastError();
+}
+
+hipError_t fh_k1_launch_predict(const double *q, int64_t n, int N, const double *zeros, const double *pref,
+                                double inv_Q, double scale, const double *I, const double *j0_table, double *V,
+                                hipStream_t stream) {
+    int grid = (int)((n + 3) / 4 < 4096 ? (n + 3) / 4 : 4096);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(predict_kernel, dim3(grid), dim3(256), 0, stream, q, n, N, zeros, pref, inv_Q, scale, I,
+                       j0_table, V);
+    return hipGetLastError();
+}

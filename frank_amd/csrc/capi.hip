@@ -1,0 +1,860 @@
+// C-ABI glue (include/frank_hip.h): handles, device buffers, kernel / rocBLAS / rocSOLVER / RCCL calls.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/frank_hip.h"
+#include "bessel.h"
+#include "dht_host.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return fail(FH_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define ROC_TRY(expr)                                                                               \
+    do {                                                                                            \
+        rocblas_status s_ = (expr);                                                                 \
+        if (s_ != rocblas_status_success)                                                           \
+            return fail(FH_ERR_HIP, "%s: rocblas status %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); \
+    } while (0)
+
+const double kRadToArcsec = 3600.0 * 180.0 / M_PI;  // frank/constants.py:23
+const double kDegToRad = M_PI / 180.0;              // frank/constants.py:25
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+}  // namespace
+
+struct fh_vis {
+    int device = 0;
+    int64_t n = 0;
+    int w_scalar = 0, has_im = 0;
+    DevBuf<double> u, v, Vre, Vim, w;
+};
+
+struct fh_ctx {
+    const fh_dht *dht = nullptr;
+    int device = 0, N = 0, NBT = 0, ntiles = 0, nparts = 1, num_cu = 0;
+    hipStream_t stream = nullptr;
+    rocblas_handle blas = nullptr;
+    // DHT constants on the device
+    DevBuf<double> zeros, j0_table, Y, Ykm, q, pref_fwd, pref_bwd;
+    // K1
+    int part_blocks[2] = {0, 0};
+    DevBuf<double> partials[2], partial_scalars, stats_sum, stats_minmax, a_scale, sumwV2;
+    // normal equations + K2 work
+    DevBuf<double> M, j, W, D, Z, p, p_old, mu, band_lu, diag_p, diag_mu;
+    DevBuf<int> flags, info;
+    bool have_device_Mj = false;
+    hipEvent_t ev_bin0 = nullptr, ev_bin1 = nullptr;
+    bool bin_timed = false;
+    // scratch for coefficient / predict calls
+    DevBuf<double> scratch_q, scratch_out, scratch_I;
+};
+
+struct fh_comm {
+    void *lib = nullptr;
+    void *comm = nullptr;
+    int rank = 0, world = 1;
+    int (*allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*destroy)(void *) = nullptr;
+    const char *(*errstr)(int) = nullptr;
+};
+
+extern "C" {
+
+const char *fh_last_error(void) { return g_err.c_str(); }
+const char *fh_version(void) { return "frank_amd 0.1 (gfx950)"; }
+
+int fh_device_count(int *count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    if (count) *count = n;
+    return FH_OK;
+}
+
+// ---- DHT (host) ---------------------------------------------------------------------------------------------
+int fh_dht_create(double Rmax_rad, int N, int nu, fh_dht **out) {
+    if (!out) return fail(FH_ERR_INVALID, "fh_dht_create: out is NULL");
+    if (nu != 0) return fail(FH_ERR_UNSUPPORTED, "fh_dht_create: only nu = 0 is implemented (got %d)", nu);
+    if (N < 1 || !(Rmax_rad > 0)) return fail(FH_ERR_INVALID, "fh_dht_create: need N >= 1 and Rmax > 0");
+    fh_dht *d = new fh_dht();
+    int rc = fh_dht_build(Rmax_rad, N, d);
+    if (rc != FH_OK) {
+        delete d;
+        return fail(rc, "fh_dht_create: set-up failed");
+    }
+    *out = d;
+    return FH_OK;
+}
+void fh_dht_destroy(fh_dht *dht) { delete dht; }
+int fh_dht_size(const fh_dht *dht) { return dht ? dht->N : 0; }
+int fh_dht_get(const fh_dht *d, double *r, double *q, double *zeros, double *Ykm, double *scale_factor, double *Qmax,
+               double *Rmax) {
+    if (!d) return fail(FH_ERR_INVALID, "fh_dht_get: dht is NULL");
+    const int N = d->N;
+    if (r) memcpy(r, d->r.data(), sizeof(double) * N);
+    if (q) memcpy(q, d->q.data(), sizeof(double) * N);
+    if (zeros) memcpy(zeros, d->zeros.data(), sizeof(double) * (N + 1));
+    if (Ykm) memcpy(Ykm, d->Ykm.data(), sizeof(double) * (size_t)N * N);
+    if (scale_factor) memcpy(scale_factor, d->scale_factor.data(), sizeof(double) * N);
+    if (Qmax) *Qmax = d->Qmax;
+    if (Rmax) *Rmax = d->Rmax;
+    return FH_OK;
+}
+
+// ---- contexts -------------------------------------------------------------------------------------------------
+int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
+    if (!dht || !out) return fail(FH_ERR_INVALID, "fh_ctx_create: NULL argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(FH_ERR_HIP, "no HIP device available: frank_amd has no CPU fallback for device work");
+    if (device < 0 || device >= ndev) return fail(FH_ERR_INVALID, "fh_ctx_create: device %d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    fh_ctx *c = new fh_ctx();
+    c->dht = dht;
+    c->device = device;
+    const int N = c->N = dht->N;
+    const size_t NN = (size_t)N * N;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    c->num_cu = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&c->ev_bin0));
+    HIP_TRY(hipEventCreate(&c->ev_bin1));
+    ROC_TRY(rocblas_create_handle(&c->blas));
+    ROC_TRY(rocblas_set_stream(c->blas, c->stream));
+    ROC_TRY(rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host));
+
+    // constants
+    std::vector<double> tab(FH_J0_TABLE_DOUBLES), Y(NN), pf(N), pb(N);
+    fh_j0_fill_table(tab.data());
+    fh_dht_self_coefficients(*dht, Y.data());
+    const double norm_f = 1 / (M_PI * dht->Qmax * dht->Qmax), norm_b = 1 / (M_PI * dht->Rmax * dht->Rmax);
+    for (int k = 0; k < N; ++k) {
+        pf[k] = norm_f * dht->scale_factor[k];  // (norm * self._scale_factor), hankel.py:201
+        pb[k] = norm_b * dht->scale_factor[k];
+    }
+    HIP_TRY(c->zeros.alloc(N + 1));
+    HIP_TRY(c->j0_table.alloc(tab.size()));
+    HIP_TRY(c->Y.alloc(NN));
+    HIP_TRY(c->Ykm.alloc(NN));
+    HIP_TRY(c->q.alloc(N));
+    HIP_TRY(c->pref_fwd.alloc(N));
+    HIP_TRY(c->pref_bwd.alloc(N));
+    HIP_TRY(hipMemcpy(c->zeros.p, dht->zeros.data(), sizeof(double) * (N + 1), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->j0_table.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->Y.p, Y.data(), sizeof(double) * NN, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->Ykm.p, dht->Ykm.data(), sizeof(double) * NN, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->q.p, dht->q.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->pref_fwd.p, pf.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->pref_bwd.p, pb.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+
+    // K1 workspaces (0 => N too large for the register-resident kernel; binning then reports FH_ERR_UNSUPPORTED)
+    c->NBT = fh_k1_nbt_for(N);
+    if (c->NBT) {
+        c->ntiles = fh_k1_ntiles(c->NBT);
+        c->nparts = fh_k1_nparts(c->NBT);
+        const int G = c->num_cu > 0 ? c->num_cu : 256;
+        if (c->nparts == 1) {
+            c->part_blocks[0] = G;
+            c->part_blocks[1] = 0;
+        } else {  // split the CUs in proportion to the parts' tile counts (equal MFMA time per workgroup)
+            const int t0 = fh_k1_part_ntiles(c->NBT, 0), t1 = fh_k1_part_ntiles(c->NBT, 1);
+            int g0 = (int)llround((double)G * t0 / (t0 + t1));
+            if (g0 < 1) g0 = 1;
+            if (g0 > G - 1) g0 = G - 1;
+            c->part_blocks[0] = g0;
+            c->part_blocks[1] = G - g0;
+        }
+        for (int P = 0; P < c->nparts; ++P)
+            HIP_TRY(c->partials[P].alloc((size_t)c->part_blocks[P] * fh_k1_part_ntiles(c->NBT, P) * 256));
+        HIP_TRY(c->partial_scalars.alloc((size_t)c->part_blocks[0] * 4));
+        HIP_TRY(c->stats_sum.alloc((size_t)c->ntiles * 256 + 2));
+        HIP_TRY(c->stats_minmax.alloc(2));
+        HIP_TRY(c->a_scale.alloc(N));
+        HIP_TRY(c->sumwV2.alloc(1));
+    }
+    // K2
+    HIP_TRY(c->M.alloc(NN));
+    HIP_TRY(c->j.alloc(N));
+    HIP_TRY(c->W.alloc(NN));
+    HIP_TRY(c->D.alloc(NN));
+    HIP_TRY(c->Z.alloc(NN));
+    HIP_TRY(c->p.alloc(N));
+    HIP_TRY(c->p_old.alloc(N));
+    HIP_TRY(c->mu.alloc(N));
+    HIP_TRY(c->band_lu.alloc(5 * (size_t)N));
+    HIP_TRY(c->flags.alloc(FIT_NFLAGS));
+    HIP_TRY(c->info.alloc(1));
+    HIP_TRY(hipMemset(c->info.p, 0, sizeof(int)));
+    HIP_TRY(hipMemset(c->flags.p, 0, sizeof(int) * FIT_NFLAGS));
+    *out = c;
+    return fh_bin_reset(c);
+}
+
+void fh_ctx_destroy(fh_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->blas) rocblas_destroy_handle(c->blas);
+    if (c->ev_bin0) (void)hipEventDestroy(c->ev_bin0);
+    if (c->ev_bin1) (void)hipEventDestroy(c->ev_bin1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+int fh_ctx_synchronize(fh_ctx *c) {
+    if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+void *fh_ctx_stream(fh_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// ---- a3/a7: H(q), predict ------------------------------------------------------------------------------------
+static int stage_q(fh_ctx *c, const double *q, int64_t n) {
+    if (c->scratch_q.n < (size_t)n) HIP_TRY(c->scratch_q.alloc((size_t)n));
+    HIP_TRY(hipMemcpyAsync(c->scratch_q.p, q, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    return FH_OK;
+}
+
+int fh_dht_coefficients(fh_ctx *c, const double *q, int64_t n, int direction, double scale, double *H) {
+    if (!c || !q || !H || n < 0) return fail(FH_ERR_INVALID, "fh_dht_coefficients: bad argument");
+    if (direction != 0 && direction != 1) return fail(FH_ERR_INVALID, "direction must be one of ['forward', 'backward']");
+    if (n == 0) return FH_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->N;
+    int rc = stage_q(c, q, n);
+    if (rc) return rc;
+    if (c->scratch_out.n < (size_t)n * N) HIP_TRY(c->scratch_out.alloc((size_t)n * N));
+    const double inv = direction == 0 ? 1. / c->dht->Qmax : 1. / c->dht->Rmax;  // hankel.py:189,192
+    HIP_TRY(fh_k1_launch_coefficients(c->scratch_q.p, n, N, c->zeros.p, direction == 0 ? c->pref_fwd.p : c->pref_bwd.p,
+                                      inv, scale, c->j0_table.p, c->scratch_out.p, c->stream));
+    HIP_TRY(hipMemcpyAsync(H, c->scratch_out.p, sizeof(double) * (size_t)n * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
+int fh_predict_visibilities(fh_ctx *c, const double *q, int64_t n, const double *I, double scale, double *V) {
+    if (!c || !q || !I || !V || n < 0) return fail(FH_ERR_INVALID, "fh_predict_visibilities: bad argument");
+    if (n == 0) return FH_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->N;
+    int rc = stage_q(c, q, n);
+    if (rc) return rc;
+    if (c->scratch_out.n < (size_t)n) HIP_TRY(c->scratch_out.alloc((size_t)n));
+    if (c->scratch_I.n < (size_t)N) HIP_TRY(c->scratch_I.alloc(N));
+    HIP_TRY(hipMemcpyAsync(c->scratch_I.p, I, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(fh_k1_launch_predict(c->scratch_q.p, n, N, c->zeros.p, c->pref_fwd.p, 1. / c->dht->Qmax, scale,
+                                 c->scratch_I.p, c->j0_table.p, c->scratch_out.p, c->stream));
+    HIP_TRY(hipMemcpyAsync(V, c->scratch_out.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
+// ---- visibility tables -------------------------------------------------------------------------------------------
+int fh_vis_upload(int device, const double *u, const double *v, const double *Vre, const double *Vim, const double *w,
+                  int64_t n_w, int64_t n, fh_vis **out) {
+    if (!out || n < 0 || (n > 0 && (!u || !v || !Vre || !w))) return fail(FH_ERR_INVALID, "fh_vis_upload: bad argument");
+    if (n_w != 1 && n_w != n) return fail(FH_ERR_INVALID, "fh_vis_upload: weights must have 1 or n entries");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(FH_ERR_HIP, "no HIP device available: frank_amd has no CPU fallback for device work");
+    HIP_TRY(hipSetDevice(device));
+    fh_vis *t = new fh_vis();
+    t->device = device;
+    t->n = n;
+    t->w_scalar = (n_w == 1 && n != 1) ? 1 : 0;
+    t->has_im = Vim ? 1 : 0;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    hipError_t e = t->u.alloc(nn);
+    if (e == hipSuccess) e = t->v.alloc(nn);
+    if (e == hipSuccess) e = t->Vre.alloc(nn);
+    if (e == hipSuccess && Vim) e = t->Vim.alloc(nn);
+    if (e == hipSuccess) e = t->w.alloc(t->w_scalar ? 1 : nn);
+    if (e != hipSuccess) {
+        delete t;
+        return fail(FH_ERR_NOMEM, "fh_vis_upload: hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    if (n > 0) {
+        const size_t b = sizeof(double) * (size_t)n;
+        e = hipMemcpy(t->u.p, u, b, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(t->v.p, v, b, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(t->Vre.p, Vre, b, hipMemcpyHostToDevice);
+        if (e == hipSuccess && Vim) e = hipMemcpy(t->Vim.p, Vim, b, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(t->w.p, w, t->w_scalar ? sizeof(double) : b, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            delete t;
+            return fail(FH_ERR_HIP, "fh_vis_upload: copy failed: %s", hipGetErrorString(e));
+        }
+    }
+    *out = t;
+    return FH_OK;
+}
+void fh_vis_destroy(fh_vis *vis) {
+    if (!vis) return;
+    (void)hipSetDevice(vis->device);
+    delete vis;
+}
+int64_t fh_vis_size(const fh_vis *vis) { return vis ? vis->n : 0; }
+
+// ---- K1 ----------------------------------------------------------------------------------------------------------
+int fh_bin_reset(fh_ctx *c) {
+    if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
+    if (!c->NBT) return FH_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->stats_sum.p, 0, sizeof(double) * c->stats_sum.n, c->stream));
+    const double init[2] = {-INFINITY, -INFINITY};  // (-qmin, qmax) under max
+    HIP_TRY(hipMemcpyAsync(c->stats_minmax.p, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_device_Mj = false;
+    return FH_OK;
+}
+
+int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int64_t first, int64_t count) {
+    if (!c || !g || !vis) return fail(FH_ERR_INVALID, "fh_bin_visibilities: NULL argument");
+    if (!c->NBT) return fail(FH_ERR_UNSUPPORTED, "N = %d: the bin_gram kernel covers N <= 303", c->N);
+    if (first < 0 || count < 0 || first + count > vis->n) return fail(FH_ERR_INVALID, "fh_bin_visibilities: bad range");
+    if (vis->device != c->device) return fail(FH_ERR_INVALID, "visibility table lives on another device");
+    HIP_TRY(hipSetDevice(c->device));
+    BinParams p{};
+    p.u = vis->u.p;
+    p.v = vis->v.p;
+    p.Vre = vis->Vre.p;
+    p.Vim = vis->has_im ? vis->Vim.p : nullptr;
+    p.w = vis->w.p;
+    p.w_scalar = vis->w_scalar;
+    p.first = first;
+    p.count = count;
+    // geometry.py:69-70 (dRA *= 2 pi / rad_to_arcsec), :111-115
+    p.dRA = g->dRA_arcsec * (2. * M_PI / kRadToArcsec);
+    p.dDec = g->dDec_arcsec * (2. * M_PI / kRadToArcsec);
+    const double inc = g->inc_deg * kDegToRad, PA = g->PA_deg * kDegToRad;
+    p.cos_t = cos(PA);
+    p.sin_t = sin(PA);
+    p.cos_i = cos(inc);
+    p.N = c->N;
+    p.inv_Qmax = 1. / c->dht->Qmax;
+    p.zeros = c->zeros.p;
+    p.j0_table = c->j0_table.p;
+    const int64_t nsuper = (count + fh_k1_super() - 1) / fh_k1_super();
+    ReduceParams rp{};
+    rp.nparts = c->nparts;
+    rp.ntiles = c->ntiles;
+    for (int P = 0; P < 2; ++P) {
+        int blocks = c->part_blocks[P];
+        if (P < c->nparts && nsuper < blocks) blocks = (int)(nsuper > 0 ? nsuper : 1);
+        p.part_blocks[P] = P < c->nparts ? blocks : 0;
+        p.partials[P] = c->partials[P].p;
+        rp.part_blocks[P] = p.part_blocks[P];
+        rp.part_tile0[P] = P < c->nparts ? fh_k1_part_tile0(c->NBT, P) : 0;
+        rp.part_ntiles[P] = P < c->nparts ? fh_k1_part_ntiles(c->NBT, P) : 0;
+        rp.partials[P] = c->partials[P].p;
+    }
+    p.partial_scalars = c->partial_scalars.p;
+    rp.partial_scalars = c->partial_scalars.p;
+    HIP_TRY(hipEventRecord(c->ev_bin0, c->stream));
+    HIP_TRY(fh_k1_launch_bin(c->NBT, p, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_bin1, c->stream));
+    c->bin_timed = true;
+    HIP_TRY(fh_k1_launch_reduce(rp, c->stats_sum.p, c->stats_minmax.p, c->stream));
+    c->have_device_Mj = false;
+    return FH_OK;
+}
+
+int fh_bin_last_kernel_ms(fh_ctx *c, float *ms) {
+    if (!c || !ms) return fail(FH_ERR_INVALID, "fh_bin_last_kernel_ms: NULL argument");
+    if (!c->bin_timed) return fail(FH_ERR_INVALID, "no bin_gram launch recorded yet");
+    HIP_TRY(hipEventSynchronize(c->ev_bin1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev_bin0, c->ev_bin1));
+    return FH_OK;
+}
+
+int fh_stats_device(fh_ctx *c, double **sum_stats, int64_t *n_sum, double **minmax_stats) {
+    if (!c || !c->NBT) return fail(FH_ERR_INVALID, "fh_stats_device: no binning workspace");
+    if (sum_stats) *sum_stats = c->stats_sum.p;
+    if (n_sum) *n_sum = (int64_t)c->stats_sum.n;
+    if (minmax_stats) *minmax_stats = c->stats_minmax.p;
+    return FH_OK;
+}
+
+int fh_stats_finalize(fh_ctx *c, const fh_geometry *g, int vis_model, int check_qbounds, double *M, double *j,
+                      double *H0, double *qmin, double *qmax) {
+    if (!c || !g) return fail(FH_ERR_INVALID, "fh_stats_finalize: NULL argument");
+    if (!c->NBT) return fail(FH_ERR_UNSUPPORTED, "N = %d: the bin_gram kernel covers N <= 303", c->N);
+    if (vis_model != FH_VIS_OPT_THICK && vis_model != FH_VIS_OPT_THIN)
+        return fail(FH_ERR_INVALID, "vis_model must be one of ['opt_thick', 'opt_thin'] here ('debris' is not built)");
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->N;
+    // a_k = ((norm * sf_k)) * scale : hankel.py:201 and statistical_models.py:490,507
+    const double scale = vis_model == FH_VIS_OPT_THICK ? cos(g->inc_deg * kDegToRad) : 1.0;
+    const double norm = 1 / (M_PI * c->dht->Qmax * c->dht->Qmax);
+    std::vector<double> a(N);
+    for (int k = 0; k < N; ++k) a[k] = (norm * c->dht->scale_factor[k]) * scale;
+    HIP_TRY(hipMemcpyAsync(c->a_scale.p, a.data(), sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(fh_k1_launch_finalize(c->stats_sum.p, c->NBT, N, c->a_scale.p, c->M.p, c->j.p, c->sumwV2.p, c->stream));
+    double tail[2], mm[2], swv2;
+    HIP_TRY(hipMemcpyAsync(tail, c->stats_sum.p + (size_t)c->ntiles * 256, sizeof tail, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(mm, c->stats_minmax.p, sizeof mm, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&swv2, c->sumwV2.p, sizeof swv2, hipMemcpyDeviceToHost, c->stream));
+    if (M) HIP_TRY(hipMemcpyAsync(M, c->M.p, sizeof(double) * (size_t)N * N, hipMemcpyDeviceToHost, c->stream));
+    if (j) HIP_TRY(hipMemcpyAsync(j, c->j.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_device_Mj = true;
+    if (H0) *H0 = 0.5 * (tail[0] - swv2);  // statistical_models.py:218
+    const double qmn = -mm[0], qmx = mm[1];
+    if (qmin) *qmin = qmn;
+    if (qmax) *qmax = qmx;
+    if (check_qbounds && c->dht->q[N - 1] < qmx)  // statistical_models.py:526
+        return fail(FH_ERR_QRANGE, "last collocation point %.3e < longest deprojected baseline %.3e", c->dht->q[N - 1], qmx);
+    return FH_OK;
+}
+
+int fh_map_visibilities(fh_ctx *c, const fh_geometry *g, int vis_model, int check_qbounds, const double *u,
+                        const double *v, const double *Vre, const double *Vim, const double *w, int64_t n_w, int64_t n,
+                        double *M, double *j, double *H0, double *qmin, double *qmax) {
+    if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
+    fh_vis *vis = nullptr;
+    int rc = fh_vis_upload(c->device, u, v, Vre, Vim, w, n_w, n, &vis);
+    if (rc) return rc;
+    rc = fh_bin_reset(c);
+    if (!rc) rc = fh_bin_visibilities(c, g, vis, 0, n);
+    if (!rc) rc = fh_stats_finalize(c, g, vis_model, check_qbounds, M, j, H0, qmin, qmax);
+    else (void)hipStreamSynchronize(c->stream);
+    fh_vis_destroy(vis);
+    return rc;
+}
+
+// ---- K2 -----------------------------------------------------------------------------------------------------------
+static FitState make_state(fh_ctx *c) {
+    FitState st{};
+    st.N = c->N;
+    st.Y = c->Y.p;
+    st.Ykm = c->Ykm.p;
+    st.q = c->q.p;
+    st.M = c->M.p;
+    st.j = c->j.p;
+    st.band_lu = c->band_lu.p;
+    st.W = c->W.p;
+    st.D = c->D.p;
+    st.Z = c->Z.p;
+    st.p = c->p.p;
+    st.p_old = c->p_old.p;
+    st.mu = c->mu.p;
+    st.flags = c->flags.p;
+    st.info = c->info.p;
+    st.transform_norm = (2 * M_PI * c->dht->Rmax * c->dht->Rmax) / c->dht->j_nN;  // hankel.py:155
+    return st;
+}
+
+// D = M + W^T Y (upper triangle in row-major terms is what potrf reads), factor, solve for mu.
+// Row-major buffers are column-major transposes: C_cm = D^T = Y^T W + M^T -> dgemm(N, T) on (Y_rm, W_rm) gives
+// C_cm[i + k*N] = sum_j Y_rm[j*N+i] ... we want D[i][k] = sum_j W[j][i] Y[j][k]; as column-major (ld N):
+// A_cm = W_rm viewed (N x N, A_cm[i + j*N] = W[j][i]) and B_cm = Y_rm (B_cm[k + j*N] = Y[j][k]) ->
+// D_cm[k + i*N]  (= row-major D[i][k]) = sum_j B_cm[k + j*N] * A_cm[i + j*N] = (B * A^T)[k][i].
+static int solve_posterior(fh_ctx *c, const FitState &st, bool with_prior, bool want_tr2) {
+    const int N = c->N;
+    const double one = 1.0;
+    if (with_prior) {
+        HIP_TRY(fh_k2_launch_prep(st, c->stream));
+        ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, N, N, N, &one, c->Y.p, N,
+                              c->W.p, N, &one, c->D.p, N));
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->D.p, c->M.p, sizeof(double) * (size_t)N * N, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->mu.p, c->j.p, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
+    }
+    // scipy.linalg.cho_factor(Dinv) = LAPACK dpotrf('U') on the row-major array == 'L' on its column-major view
+    ROC_TRY(rocsolver_dpotrf(c->blas, rocblas_fill_lower, N, c->D.p, N, c->info.p));
+    ROC_TRY(rocsolver_dpotrs(c->blas, rocblas_fill_lower, N, 1, c->D.p, N, c->mu.p, N));
+    if (want_tr2)  // Z_cm <- L^-1 Z_cm with Z_cm = Y^T  (the buffer holds row-major Y)
+        ROC_TRY(rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+                              rocblas_diagonal_non_unit, N, N, &one, c->D.p, N, c->Z.p, N));
+    return FH_OK;
+}
+
+// Host SVD pseudo-inverse solve, the reference's route when cho_factor raises (statistical_models.py:747-755).
+static void svd_pinv_solve(int n, const std::vector<double> &A, const std::vector<double> &b, std::vector<double> &x) {
+    std::vector<double> W(A), V((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {  // one-sided Jacobi (Hestenes)
+        double off = 0;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double al = 0, be = 0, ga = 0;
+                for (int i = 0; i < n; ++i) {
+                    const double a = W[(size_t)i * n + p], d = W[(size_t)i * n + q];
+                    al += a * a;
+                    be += d * d;
+                    ga += a * d;
+                }
+                if (ga == 0 || fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
+                off += fabs(ga) / sqrt(al * be);
+                const double zeta = (be - al) / (2 * ga);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+                const double cs = 1 / sqrt(1 + t * t), sn = cs * t;
+                for (int i = 0; i < n; ++i) {
+                    double a = W[(size_t)i * n + p], d = W[(size_t)i * n + q];
+                    W[(size_t)i * n + p] = cs * a - sn * d;
+                    W[(size_t)i * n + q] = sn * a + cs * d;
+                    a = V[(size_t)i * n + p];
+                    d = V[(size_t)i * n + q];
+                    V[(size_t)i * n + p] = cs * a - sn * d;
+                    V[(size_t)i * n + q] = sn * a + cs * d;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    x.assign(n, 0.0);
+    for (int k = 0; k < n; ++k) {
+        double s2 = 0, wb = 0;
+        for (int i = 0; i < n; ++i) {
+            s2 += W[(size_t)i * n + k] * W[(size_t)i * n + k];
+            wb += W[(size_t)i * n + k] * b[i];
+        }
+        if (s2 > 0)
+            for (int i = 0; i < n; ++i) x[i] += V[(size_t)i * n + k] * (wb / s2);
+    }
+}
+
+int fh_gaussian_model(fh_ctx *c, const double *M, const double *j, const double *p, double *mu, double *chol,
+                      double *Sinv, int *used_svd) {
+    if (!c || !M || !j) return fail(FH_ERR_INVALID, "fh_gaussian_model: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->N;
+    const size_t NN = (size_t)N * N;
+    if (used_svd) *used_svd = 0;
+    if (p)
+        for (int k = 0; k < N; ++k)
+            if (!(p[k] > 0.0)) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (p[%d] = %g)", k, p[k]);
+    HIP_TRY(hipMemcpyAsync(c->M.p, M, sizeof(double) * NN, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->j.p, j, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    if (p) HIP_TRY(hipMemcpyAsync(c->p.p, p, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int) * FIT_NFLAGS, c->stream));
+    c->have_device_Mj = false;
+    FitState st = make_state(c);
+    if (Sinv) {
+        if (p) {
+            const double one = 1.0, zero = 0.0;
+            HIP_TRY(fh_k2_launch_prep(st, c->stream));
+            ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, N, N, N, &one, c->Y.p,
+                                  N, c->W.p, N, &zero, c->Z.p, N));
+            HIP_TRY(hipMemcpyAsync(Sinv, c->Z.p, sizeof(double) * NN, hipMemcpyDeviceToHost, c->stream));
+        } else {
+            memset(Sinv, 0, sizeof(double) * NN);
+        }
+    }
+    int rc = solve_posterior(c, st, p != nullptr, false);
+    if (rc) return rc;
+    int info = 0;
+    HIP_TRY(hipMemcpyAsync(&info, c->info.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (mu) HIP_TRY(hipMemcpyAsync(mu, c->mu.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    if (chol) HIP_TRY(hipMemcpyAsync(chol, c->D.p, sizeof(double) * NN, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (info != 0) {
+        // not positive definite: rebuild Dinv and take the SVD route on the host, as the reference does
+        std::vector<double> Dinv(NN), bj(j, j + N), x;
+        if (p) {
+            const double one = 1.0;
+            HIP_TRY(fh_k2_launch_prep(st, c->stream));
+            ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, N, N, N, &one, c->Y.p,
+                                  N, c->W.p, N, &one, c->D.p, N));
+            HIP_TRY(hipMemcpyAsync(Dinv.data(), c->D.p, sizeof(double) * NN, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            for (int i = 0; i < N; ++i)  // the dgemm result is symmetric only to rounding; use the upper triangle
+                for (int k = 0; k < i; ++k) Dinv[(size_t)i * N + k] = Dinv[(size_t)k * N + i];
+        } else {
+            memcpy(Dinv.data(), M, sizeof(double) * NN);
+        }
+        svd_pinv_solve(N, Dinv, bj, x);
+        if (mu) memcpy(mu, x.data(), sizeof(double) * N);
+        if (used_svd) *used_svd = 1;
+    }
+    return FH_OK;
+}
+
+int fh_cho_solve(fh_ctx *c, const double *chol, double *B, int nrhs) {
+    if (!c || !chol || !B || nrhs < 1) return fail(FH_ERR_INVALID, "fh_cho_solve: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->N;
+    const size_t NN = (size_t)N * N, nb = (size_t)N * nrhs;
+    if (c->scratch_out.n < nb) HIP_TRY(c->scratch_out.alloc(nb));
+    HIP_TRY(hipMemcpyAsync(c->D.p, chol, sizeof(double) * NN, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->scratch_out.p, B, sizeof(double) * nb, hipMemcpyHostToDevice, c->stream));
+    // row-major B (N x nrhs) is the column-major (nrhs x N) matrix B^T:  X^T (L L^T) = B^T
+    const double one = 1.0;
+    ROC_TRY(rocblas_dtrsm(c->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose,
+                          rocblas_diagonal_non_unit, nrhs, N, &one, c->D.p, N, c->scratch_out.p, nrhs));
+    ROC_TRY(rocblas_dtrsm(c->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none,
+                          rocblas_diagonal_non_unit, nrhs, N, &one, c->D.p, N, c->scratch_out.p, nrhs));
+    HIP_TRY(hipMemcpyAsync(B, c->scratch_out.p, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
+// spectral_smoothing_matrix (filter.py:23-62) as bands, then LU of (T + I) without pivoting (T + I is SPD).
+// out: f1[N] (multiplier of row i-1), f2[N] (row i-2), d0[N] (pivots), u1[N], u2[N] (upper bands of U).
+static void smoothing_band_lu(const fh_dht &d, double weights, std::vector<double> &out) {
+    const int N = d.N;
+    std::vector<double> lq(N), dc(N, 0.0), de(N, 0.0), D0(N, 0.0), D1(N, 0.0), D2(N, 0.0);
+    std::vector<double> band(5 * (size_t)N, 0.0);
+    for (int i = 0; i < N; ++i) lq[i] = log(d.q[i]);
+    for (int i = 0; i + 2 < N; ++i) dc[i] = (lq[i + 2] - lq[i]) / 2;  // filter.py:42
+    for (int i = 0; i + 1 < N; ++i) de[i] = lq[i + 1] - lq[i];        // filter.py:43
+    for (int i = 1; i + 1 < N; ++i) {                                 // filter.py:48-50
+        D0[i] = 1 / (dc[i - 1] * de[i - 1]);
+        D1[i] = -(1 / de[i] + 1 / de[i - 1]) / dc[i - 1];
+        D2[i] = 1 / (dc[i - 1] * de[i]);
+    }
+    for (int i = 1; i + 1 < N; ++i) {  // T = Delta^T (dce Delta), filter.py:55-60
+        const double dce = dc[i - 1];
+        const int cols[3] = {i - 1, i, i + 1};
+        const double vals[3] = {D0[i], D1[i], D2[i]};
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) band[(size_t)(cols[b] - cols[a] + 2) * N + cols[a]] += vals[a] * (dce * vals[b]);
+    }
+    std::vector<double> A(5 * (size_t)N);
+    for (int i = 0; i < N; ++i)
+        for (int dd = -2; dd <= 2; ++dd) A[(size_t)i * 5 + dd + 2] = weights * band[(size_t)(dd + 2) * N + i] + (dd == 0 ? 1.0 : 0.0);
+    out.assign(5 * (size_t)N, 0.0);
+    double *f1 = out.data(), *f2 = f1 + N, *d0 = f2 + N, *u1 = d0 + N, *u2 = u1 + N;
+    for (int k = 0; k < N; ++k) {
+        const double piv = A[(size_t)k * 5 + 2];
+        for (int i = k + 1; i <= k + 2 && i < N; ++i) {
+            const int dk = k - i;
+            const double f = A[(size_t)i * 5 + dk + 2] / piv;
+            (dk == -1 ? f1 : f2)[i] = f;
+            if (f == 0) continue;
+            for (int cc = k + 1; cc <= k + 2 && cc < N; ++cc) A[(size_t)i * 5 + (cc - i + 2)] -= f * A[(size_t)k * 5 + (cc - k + 2)];
+            A[(size_t)i * 5 + dk + 2] = 0;
+        }
+    }
+    for (int i = 0; i < N; ++i) {
+        d0[i] = A[(size_t)i * 5 + 2];
+        u1[i] = A[(size_t)i * 5 + 3];
+        u2[i] = A[(size_t)i * 5 + 4];
+    }
+}
+
+int fh_fit_normal(fh_ctx *c, const double *M, const double *j, double alpha, double p0, double wsmooth, double tol,
+                  int max_iter, double *mu, double *p, int *niter, double *diag_p, double *diag_mu) {
+    if (!c || !mu || !p || !niter) return fail(FH_ERR_INVALID, "fh_fit_normal: NULL argument");
+    if ((M == nullptr) != (j == nullptr)) return fail(FH_ERR_INVALID, "fh_fit_normal: pass both M and j or neither");
+    if (!M && !c->have_device_Mj) return fail(FH_ERR_INVALID, "fh_fit_normal: no device-resident M, j (run fh_stats_finalize)");
+    if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
+    if (c->N > FIT_MAX_N) return fail(FH_ERR_UNSUPPORTED, "N = %d > %d", c->N, FIT_MAX_N);
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->N;
+    const size_t NN = (size_t)N * N;
+    if (M) {
+        HIP_TRY(hipMemcpyAsync(c->M.p, M, sizeof(double) * NN, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->j.p, j, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+        c->have_device_Mj = false;
+    }
+    std::vector<double> lu;
+    smoothing_band_lu(*c->dht, wsmooth, lu);
+    HIP_TRY(hipMemcpyAsync(c->band_lu.p, lu.data(), sizeof(double) * lu.size(), hipMemcpyHostToDevice, c->stream));
+    const bool want_diag = diag_p || diag_mu;
+    if (want_diag) {
+        const size_t need = (size_t)(max_iter + 1) * N;
+        if (c->diag_p.n < need) HIP_TRY(c->diag_p.alloc(need));
+        if (c->diag_mu.n < need) HIP_TRY(c->diag_mu.alloc(need));
+    }
+    FitState st = make_state(c);
+    st.alpha = alpha;
+    st.p0 = p0;
+    st.tol = tol;
+    st.max_iter = max_iter;
+    st.diag_p = want_diag ? c->diag_p.p : nullptr;
+    st.diag_mu = want_diag ? c->diag_mu.p : nullptr;
+
+    // radial_fitters.py:744-752: p = 1 -> fit -> power-law guess -> fit
+    HIP_TRY(fh_k2_launch_init(st, c->stream));
+    int rc = solve_posterior(c, st, true, false);
+    if (rc) return rc;
+    HIP_TRY(fh_k2_launch_powerlaw(st, c->stream));
+    rc = solve_posterior(c, st, true, true);
+    if (rc) return rc;
+
+    // radial_fitters.py:769-785, in batches; the device keeps the loop state and stops updating once converged
+    int flags[FIT_NFLAGS] = {0};
+    const int batch = 32;
+    for (int launched = 0; launched <= max_iter + 1;) {
+        for (int b = 0; b < batch; ++b, ++launched) {
+            HIP_TRY(fh_k2_launch_update(st, c->stream));
+            rc = solve_posterior(c, st, true, true);
+            if (rc) return rc;
+            if (want_diag) HIP_TRY(fh_k2_launch_record(st, c->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(flags, c->flags.p, sizeof flags, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (flags[FIT_FLAG_DONE] || flags[FIT_FLAG_BAD_P] || flags[FIT_FLAG_NOT_SPD]) break;
+    }
+    if (!flags[FIT_FLAG_DONE] && !flags[FIT_FLAG_BAD_P] && !flags[FIT_FLAG_NOT_SPD]) {
+        // one more update launch settles the `count <= max_iter` exit
+        HIP_TRY(fh_k2_launch_update(st, c->stream));
+        HIP_TRY(hipMemcpyAsync(flags, c->flags.p, sizeof flags, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    *niter = flags[FIT_FLAG_COUNT];
+    HIP_TRY(hipMemcpyAsync(mu, c->mu.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(p, c->p.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    const size_t nd = (size_t)flags[FIT_FLAG_COUNT] * N;
+    if (diag_p && nd) HIP_TRY(hipMemcpyAsync(diag_p, c->diag_p.p, sizeof(double) * nd, hipMemcpyDeviceToHost, c->stream));
+    if (diag_mu && nd) HIP_TRY(hipMemcpyAsync(diag_mu, c->diag_mu.p, sizeof(double) * nd, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (flags[FIT_FLAG_BAD_P]) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (non-positive or NaN) at iteration %d", *niter);
+    if (flags[FIT_FLAG_NOT_SPD])
+        return fail(FH_ERR_NOT_SPD, "Cholesky of M + S^-1 failed at iteration %d (the reference would switch to an SVD)", *niter);
+    return FH_OK;
+}
+
+int fh_update_power_spectrum(fh_ctx *c, const double *M, const double *j, const double *p, double alpha, double p0,
+                             double wsmooth, double *mu, double *p_new) {
+    if (!c || !M || !j || !p) return fail(FH_ERR_INVALID, "fh_update_power_spectrum: NULL argument");
+    if (c->N > FIT_MAX_N) return fail(FH_ERR_UNSUPPORTED, "N = %d > %d", c->N, FIT_MAX_N);
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->N;
+    for (int k = 0; k < N; ++k)
+        if (!(p[k] > 0.0)) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (p[%d] = %g)", k, p[k]);
+    std::vector<double> lu, zero(N, 0.0);
+    smoothing_band_lu(*c->dht, wsmooth, lu);
+    HIP_TRY(hipMemcpyAsync(c->M.p, M, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->j.p, j, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->p.p, p, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->p_old.p, zero.data(), sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->band_lu.p, lu.data(), sizeof(double) * lu.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int) * FIT_NFLAGS, c->stream));
+    c->have_device_Mj = false;
+    FitState st = make_state(c);
+    st.alpha = alpha;
+    st.p0 = p0;
+    st.tol = 0.0;
+    st.max_iter = 1 << 30;
+    int rc = solve_posterior(c, st, true, true);
+    if (rc) return rc;
+    if (mu) HIP_TRY(hipMemcpyAsync(mu, c->mu.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(fh_k2_launch_update(st, c->stream));
+    int flags[FIT_NFLAGS];
+    HIP_TRY(hipMemcpyAsync(flags, c->flags.p, sizeof flags, hipMemcpyDeviceToHost, c->stream));
+    if (p_new) HIP_TRY(hipMemcpyAsync(p_new, c->p.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (flags[FIT_FLAG_NOT_SPD]) return fail(FH_ERR_NOT_SPD, "Cholesky of M + S^-1 failed");
+    return FH_OK;
+}
+
+// ---- RCCL -------------------------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    int (*get_unique_id)(void *) = nullptr;
+    int (*allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*destroy)(void *) = nullptr;
+    const char *(*errstr)(int) = nullptr;
+};
+struct UniqueId {
+    char internal[128];
+};
+RcclApi g_rccl;
+int load_rccl() {
+    if (g_rccl.lib) return FH_OK;
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(FH_ERR_HIP, "cannot load librccl: %s", dlerror());
+    g_rccl.get_unique_id = (int (*)(void *))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.allreduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(lib, "ncclAllReduce");
+    g_rccl.destroy = (int (*)(void *))dlsym(lib, "ncclCommDestroy");
+    g_rccl.errstr = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.get_unique_id || !dlsym(lib, "ncclCommInitRank") || !g_rccl.allreduce || !g_rccl.destroy)
+        return fail(FH_ERR_HIP, "librccl lacks a required symbol");
+    g_rccl.lib = lib;
+    return FH_OK;
+}
+}  // namespace
+
+int fh_comm_unique_id(char id[128]) {
+    int rc = load_rccl();
+    if (rc) return rc;
+    int s = g_rccl.get_unique_id(id);
+    if (s != 0) return fail(FH_ERR_HIP, "ncclGetUniqueId: %s", g_rccl.errstr ? g_rccl.errstr(s) : "?");
+    return FH_OK;
+}
+
+int fh_comm_create(const char id[128], int rank, int world, int device, fh_comm **out) {
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) return fail(FH_ERR_INVALID, "fh_comm_create: bad argument");
+    int rc = load_rccl();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    fh_comm *cm = new fh_comm();
+    cm->rank = rank;
+    cm->world = world;
+    UniqueId uid;
+    memcpy(uid.internal, id, 128);
+    // ncclResult_t ncclCommInitRank(ncclComm_t*, int nranks, ncclUniqueId commId, int rank): the id travels by value
+    typedef int (*init_fn)(void **, int, UniqueId, int);
+    init_fn init = (init_fn)dlsym(g_rccl.lib, "ncclCommInitRank");
+    int s = init(&cm->comm, world, uid, rank);
+    if (s != 0) {
+        delete cm;
+        return fail(FH_ERR_HIP, "ncclCommInitRank: %s", g_rccl.errstr ? g_rccl.errstr(s) : "?");
+    }
+    *out = cm;
+    return FH_OK;
+}
+
+void fh_comm_destroy(fh_comm *cm) {
+    if (!cm) return;
+    if (cm->comm && g_rccl.destroy) g_rccl.destroy(cm->comm);
+    delete cm;
+}
+
+int fh_comm_allreduce_stats(fh_comm *cm, fh_ctx *c) {
+    if (!cm || !c || !c->NBT) return fail(FH_ERR_INVALID, "fh_comm_allreduce_stats: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    enum { kFloat64 = 8, kSum = 0, kMax = 2 };  // ncclDataType_t / ncclRedOp_t values (rccl.h)
+    int s = g_rccl.allreduce(c->stats_sum.p, c->stats_sum.p, c->stats_sum.n, kFloat64, kSum, cm->comm, c->stream);
+    if (s == 0) s = g_rccl.allreduce(c->stats_minmax.p, c->stats_minmax.p, 2, kFloat64, kMax, cm->comm, c->stream);
+    if (s != 0) return fail(FH_ERR_HIP, "ncclAllReduce: %s", g_rccl.errstr ? g_rccl.errstr(s) : "?");
+    c->have_device_Mj = false;
+    return FH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// Internal launch interface between the C-ABI glue (capi.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct BinParams {
+    // visibility columns (device), rows [first, first+count)
+    const double *u, *v, *Vre, *Vim, *w;
+    int w_scalar;
+    int64_t first, count;
+    // geometry (geometry.py:69-70,111-115): dRA, dDec already multiplied by 2 pi / rad_to_arcsec
+    double dRA, dDec, cos_t, sin_t, cos_i;
+    // DHT
+    int N;
+    double inv_Qmax;        // k = 1./Qmax, hankel.py:189
+    const double *zeros;    // j_k, N entries (device)
+    const double *j0_table; // FH_J0_TAYLOR (device)
+    // outputs
+    // grid split between the tile parts (bin_gram.hip): part_blocks[0] + part_blocks[1] workgroups
+    int part_blocks[2];
+    double *partials[2];     // per part: [part_blocks][part_ntiles][256]
+    double *partial_scalars; // [part_blocks[0]][4]  (sum log(w/2pi), qmin, qmax, -)
+};
+
+struct ReduceParams {
+    int nparts, ntiles;
+    int part_blocks[2], part_tile0[2], part_ntiles[2];
+    const double *partials[2];
+    const double *partial_scalars;
+};
+
+int fh_k1_nbt_for(int N);
+int fh_k1_ntiles(int NBT);
+int fh_k1_nparts(int NBT);
+int fh_k1_part_tile0(int NBT, int P);
+int fh_k1_part_ntiles(int NBT, int P);
+int fh_k1_super();
+hipError_t fh_k1_launch_bin(int NBT, const BinParams &p, hipStream_t stream);
+hipError_t fh_k1_launch_reduce(const ReduceParams &rp, double *stats_sum, double *stats_minmax, hipStream_t stream);
+hipError_t fh_k1_launch_finalize(const double *stats_sum, int NBT, int N, const double *a, double *M, double *j,
+                                 double *sumwV2, hipStream_t stream);
+hipError_t fh_k1_launch_coefficients(const double *q, int64_t n, int N, const double *zeros, const double *pref,
+                                     double inv_Q, double scale, const double *j0_table, double *H,
+                                     hipStream_t stream);
+hipError_t fh_k1_launch_predict(const double *q, int64_t n, int N, const double *zeros, const double *pref,
+                                double inv_Q, double scale, const double *I, const double *j0_table, double *V,
+                                hipStream_t stream);
+
+// ---- K2 ------------------------------------------------------------------------------------------------
+#define FIT_MAX_N 512
+enum { FIT_FLAG_DONE = 0, FIT_FLAG_COUNT = 1, FIT_FLAG_BAD_P = 2, FIT_FLAG_NOT_SPD = 3, FIT_FLAG_INFO = 4, FIT_NFLAGS = 8 };
+
+struct FitState {
+    int N, max_iter;
+    double alpha, p0, tol, transform_norm;  // transform_norm = 2 pi Rmax^2 / j_nN (hankel.py:155)
+    const double *Y, *Ykm, *q;              // DHT.coefficients(), _Ykm, collocation q (device)
+    const double *M, *j;                    // normal equations (device)
+    const double *band_lu;                  // 5*N: LU factors of the pentadiagonal T + I (host-factorised)
+    double *W, *D, *Z;                      // N*N work: diag(1/p) Y, Dinv -> Cholesky factor, triangular-solve rhs
+    double *p, *p_old, *mu;
+    int *flags;                             // FIT_NFLAGS
+    int *info;                              // rocSOLVER potrf info
+    double *diag_p, *diag_mu;               // optional (max_iter+1)*N each
+};
+
+hipError_t fh_k2_launch_init(const FitState &st, hipStream_t s);
+hipError_t fh_k2_launch_prep(const FitState &st, hipStream_t s);
+hipError_t fh_k2_launch_powerlaw(const FitState &st, hipStream_t s);
+hipError_t fh_k2_launch_update(const FitState &st, hipStream_t s);
+hipError_t fh_k2_launch_record(const FitState &st, hipStream_t s);

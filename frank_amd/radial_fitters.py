@@ -1,0 +1,379 @@
+"""FourierBesselFitter / FrankFitter / FrankRadialFit -- drop-ins for frank/radial_fitters.py:35-991.
+
+Same constructor signatures, methods, properties, defaults and error behaviour; the arithmetic runs on
+the MI355X through libfrank_hip:
+  preprocess_visibilities -> fh_map_visibilities (K1 bin_gram)
+  fit_preprocessed / _fit -> fh_fit_normal       (K2: the whole power-spectrum loop on the device)
+Result objects hold NumPy arrays only and pickle like the reference's (io.py:190).
+"""
+import abc
+import ctypes
+from collections import defaultdict
+import logging
+
+import numpy as np
+
+from frank_amd import _lib
+from frank_amd.constants import rad_to_arcsec
+from frank_amd.filter import CriticalFilter
+from frank_amd.hankel import DiscreteHankelTransform
+from frank_amd.statistical_models import GaussianModel, VisibilityMapping
+
+
+class FrankRadialFit(metaclass=abc.ABCMeta):
+    """Base class for results of frank fits (radial_fitters.py:35-219)."""
+
+    def __init__(self, vis_map, info, geometry):
+        self._vis_map = vis_map
+        self._geometry = geometry
+        self._info = info
+
+    def predict(self, u, v, I=None, geometry=None):
+        r"""Predict the visibilities in the sky-plane (radial_fitters.py:56-98)."""
+        if geometry is None:
+            geometry = self._geometry
+        if I is None:
+            I = self.I
+        if geometry is not None:
+            u, v, wz = geometry.deproject(u, v, use3D=True)
+        else:
+            wz = np.zeros_like(u)
+        q = np.hypot(u, v)
+        V = self._vis_map.predict_visibilities(I, q, wz, geometry=geometry)
+        if geometry is not None:
+            _, _, V = geometry.undo_correction(u, v, V)
+        return V
+
+    def predict_deprojected(self, q=None, I=None, geometry=None, block_size=10 ** 5,
+                            assume_optically_thick=True):
+        r"""Predict the visibilities in the deprojected-plane (radial_fitters.py:100-144)."""
+        if geometry is None:
+            geometry = self._geometry
+        if I is None:
+            I = self.I
+        if q is None:
+            q = self.q
+        return self._vis_map.predict_visibilities(I, q, q * 0, geometry=geometry)
+
+    @abc.abstractproperty
+    def MAP(self):
+        pass
+
+    @property
+    def I(self):
+        return self.MAP
+
+    @property
+    def r(self):
+        """Radius points, unit = arcsec"""
+        return self._vis_map.r
+
+    @property
+    def Rmax(self):
+        """Maximum radius, unit = arcsec"""
+        return self._vis_map.Rmax
+
+    @property
+    def q(self):
+        r"""Frequency points, unit = :math:`\lambda`"""
+        return self._vis_map.q
+
+    @property
+    def Qmax(self):
+        r"""Maximum frequency, unit = :math:`\lambda`"""
+        return self._vis_map.Qmax
+
+    @property
+    def size(self):
+        """Number of points in reconstruction"""
+        return self._vis_map.size
+
+    @property
+    def geometry(self):
+        """SourceGeometry object"""
+        return self._geometry
+
+    @property
+    def info(self):
+        """Fit quantities for reference"""
+        return self._info
+
+
+class FrankGaussianFit(FrankRadialFit):
+    """Result of a frank fit with a Gaussian brightness model (radial_fitters.py:222-322)."""
+
+    def __init__(self, DHT, fit, info={}, geometry=None):
+        FrankRadialFit.__init__(self, DHT, info, geometry)
+        self._fit = fit
+
+    def draw(self, N):
+        return np.random.multivariate_normal(self.mean, self.covariance, N)
+
+    def log_likelihood(self, I=None):
+        return self._fit.log_likelihood(I)
+
+    def solve_non_negative(self):
+        return self._fit.solve_non_negative()
+
+    @property
+    def mean(self):
+        """Posterior mean, unit = Jy / sr"""
+        return self._fit.mean
+
+    @property
+    def MAP(self):
+        """Posterior maximum, unit = Jy / sr"""
+        return self.mean
+
+    @property
+    def covariance(self):
+        """Posterior covariance, unit = (Jy / sr)**2"""
+        return self._fit.covariance
+
+    @property
+    def power_spectrum(self):
+        """Power spectrum coefficients"""
+        return self._fit.power_spectrum
+
+
+class FourierBesselFitter(object):
+    """Fourier-Bessel series model for fitting visibilities (radial_fitters.py:405-613).
+
+    Rmax is in arcsec here and radians at the DHT level (:441).
+    """
+
+    def __init__(self, Rmax, N, geometry, nu=0, block_data=True, assume_optically_thick=True, scale_height=None,
+                 block_size=10 ** 5, verbose=True):
+        Rmax /= rad_to_arcsec
+        self._geometry = geometry
+        self._DHT = DiscreteHankelTransform(Rmax, N, nu)
+        if assume_optically_thick:
+            if scale_height is not None:
+                raise ValueError("Optically thick models must have zero scale-height")
+            model = 'opt_thick'
+        elif scale_height is not None:
+            model = 'debris'
+        else:
+            model = 'opt_thin'
+        self._vis_map = VisibilityMapping(self._DHT, geometry, model, scale_height=scale_height,
+                                          block_data=block_data, block_size=block_size, check_qbounds=False,
+                                          verbose=verbose)
+        self._info = {'Rmax': self._DHT.Rmax * rad_to_arcsec, 'N': self._DHT.size}
+        self._verbose = verbose
+
+    def preprocess_visibilities(self, u, v, V, weights=1):
+        r"""Prepare the visibilities for fitting (radial_fitters.py:468-498): one bin_gram pass on the GPU."""
+        return self._vis_map.map_visibilities(u, v, V, weights)
+
+    def _build_matrices(self, mapping):
+        """radial_fitters.py:500-514"""
+        self._vis_map.check_hash(mapping['hash'])
+        self._M = mapping['M']
+        self._j = mapping['j']
+        self._H0 = mapping['null_likelihood']
+
+    def fit_method(self):
+        """Name of the fit method"""
+        return type(self).__name__
+
+    def fit_preprocessed(self, preproc_vis):
+        r"""Fit the pre-processed visibilties (radial_fitters.py:520-542)."""
+        if self._verbose:
+            logging.info('  Fitting pre-processed visibilities for brightness'
+                         ' profile using {}'.format(self.fit_method()))
+        self._build_matrices(preproc_vis)
+        return self._fit()
+
+    def fit(self, u, v, V, weights=1):
+        r"""Fit the visibilties (radial_fitters.py:544-572)."""
+        if self._verbose:
+            logging.info('  Fitting for brightness profile using {}'.format(self.fit_method()))
+        self._geometry.fit(u, v, V, weights)
+        mapping = self.preprocess_visibilities(u, v, V, weights)
+        self._build_matrices(mapping)
+        return self._fit()
+
+    def _fit(self):
+        """Fit step without a prior (radial_fitters.py:574-582)."""
+        fit = GaussianModel(self._DHT, self._M, self._j, noise_likelihood=self._H0)
+        self._sol = FrankGaussianFit(self._vis_map, fit, self._info, geometry=self._geometry.clone())
+        return self._sol
+
+    @property
+    def r(self):
+        """Radius points, unit = arcsec"""
+        return self._DHT.r * rad_to_arcsec
+
+    @property
+    def Rmax(self):
+        """Maximum radius, unit = arcsec"""
+        return self._DHT.Rmax * rad_to_arcsec
+
+    @property
+    def q(self):
+        r"""Frequency points, unit = :math:`\lambda`"""
+        return self._DHT.q
+
+    @property
+    def Qmax(self):
+        r"""Maximum frequency, unit = :math:`\lambda`"""
+        return self._DHT.Qmax
+
+    @property
+    def size(self):
+        """Number of points in reconstruction"""
+        return self._DHT.size
+
+    @property
+    def geometry(self):
+        """Geometry object"""
+        return self._geometry
+
+
+class FrankFitter(FourierBesselFitter):
+    """Gaussian-process fit with the MAP power spectrum (radial_fitters.py:616-991), method='Normal'.
+
+    Same defaults as the reference: alpha=1.05, p_0=1e-15 ('Normal'), weights_smooth=1e-4, tol=1e-3,
+    max_iter=2000, convergence_failure='raise'.
+    """
+
+    def __init__(self, Rmax, N, geometry, nu=0, block_data=True, block_size=10 ** 5, alpha=1.05, p_0=None,
+                 weights_smooth=1e-4, tol=1e-3, method='Normal', I_scale=1e5, max_iter=2000, check_qbounds=True,
+                 store_iteration_diagnostics=False, assume_optically_thick=True, scale_height=None, verbose=True,
+                 convergence_failure='raise'):
+        if method not in {'Normal', 'LogNormal'}:
+            raise ValueError('FrankFitter supports following mehods:\n\t{ "Normal", "LogNormal"}"')
+        if method == 'LogNormal':
+            raise NotImplementedError("method='LogNormal' (statistical_models.py:907-1295, minimizer.py) is the "
+                                      "next row of the hot-path table and is not built yet")
+        self._method = method
+        super(FrankFitter, self).__init__(Rmax, N, geometry, nu, block_data, assume_optically_thick, scale_height,
+                                          block_size, verbose)
+        # Reinstate the bounds check: FourierBesselFitter does not check bounds (radial_fitters.py:706-707)
+        self._vis_map.check_qbounds = check_qbounds
+        if p_0 is None:
+            p_0 = 1e-15 if method == 'Normal' else 1e-35
+        self._s_scale = np.log(I_scale)
+        self._filter = CriticalFilter(self._DHT, alpha, p_0, weights_smooth, tol)
+        self._max_iter = max_iter
+        self._store_iteration_diagnostics = store_iteration_diagnostics
+        self._info.update({'alpha': alpha, 'wsmooth': weights_smooth, 'p0': p_0, 'method': method})
+        if convergence_failure not in {'raise', 'warn', 'ignore'}:
+            raise ValueError("convergence_failure must be one of 'raise',"
+                             f"'warn', or 'ignore', nor {convergence_failure}")
+        self._convergence_failure = convergence_failure
+        self._hyper = (float(alpha), float(p_0), float(weights_smooth), float(tol))
+
+    def fit_method(self):
+        """Name of the fit method"""
+        return '{}: {} method'.format(type(self).__name__, self._method)
+
+    def _fit(self):
+        """The power-spectrum iteration (radial_fitters.py:737-832), run on the device by fh_fit_normal."""
+        N = self.size
+        alpha, p_0, wsmooth, tol = self._hyper
+        mu, p = np.empty(N), np.empty(N)
+        niter = ctypes.c_int(0)
+        dp = dm = None
+        if self._store_iteration_diagnostics:
+            self._iteration_diagnostics = defaultdict(list)
+            dp = np.zeros((self._max_iter + 1, N))
+            dm = np.zeros((self._max_iter + 1, N))
+        M, j = _lib.f8(self._M), _lib.f8(self._j)
+        rc = _lib.lib.fh_fit_normal(self._DHT.context(), _lib.ptr(M), _lib.ptr(j), alpha, p_0, wsmooth, tol,
+                                    int(self._max_iter), _lib.ptr(mu), _lib.ptr(p), ctypes.byref(niter),
+                                    _lib.ptr(dp), _lib.ptr(dm))
+        if rc == _lib.FH_ERR_BAD_P:
+            from frank_amd.statistical_models import _BAD_P_MSG
+            raise ValueError(_BAD_P_MSG)
+        _lib.check(rc)
+        count = niter.value
+
+        if self._store_iteration_diagnostics:
+            self._iteration_diagnostics['power_spectrum'] = [dp[i].copy() for i in range(count)]
+            self._iteration_diagnostics['MAP'] = [dm[i].copy() for i in range(count)]
+
+        # Check / report convergence (radial_fitters.py:787-815)
+        if count < self._max_iter:
+            if self._verbose:
+                logging.info('    Convergence criterion met at iteration {}'.format(count - 1))
+        else:
+            if self._verbose:
+                logging.info('    Convergence criterion not met; fit stopped at'
+                             ' max_iter specified in your parameter file, {}'.format(self._max_iter))
+            msg = f'Convergence not met within {self._max_iter} '
+            msg += 'iterations.\nTry increasing max_iter, or '
+            msg += 'try increasing alpha since convergence can '
+            msg += 'be very slow for alpha close to 1.'
+            if self._convergence_failure == 'raise':
+                msg += '\nAlternatively set convergence_failure to'
+                msg += "'warn' or 'ignore' to continue despite the"
+                msg += 'failure.'
+                raise RuntimeError(msg)
+            elif self._convergence_failure == 'warn':
+                if logging.getLogger().isEnabledFor(logging.INFO):
+                    logging.info(msg)
+                else:
+                    print(msg)
+
+        if self._store_iteration_diagnostics:
+            self._iteration_diagnostics['num_iterations'] = count
+
+        fit = GaussianModel._from_solution(self._DHT, self._M, self._j, p, mu, noise_likelihood=self._H0)
+        self._sol = FrankGaussianFit(self._vis_map, fit, self._info, geometry=self._geometry.clone())
+        self._ps = p
+        self._ps_cov = None
+        return self._sol
+
+    def _perform_fit(self, p, guess=None, fit_method=None):
+        """Posterior for a given p (radial_fitters.py:858-890)."""
+        if fit_method is None:
+            fit_method = self._method
+        if fit_method == 'Normal':
+            return GaussianModel(self._DHT, self._M, self._j, p, guess=guess, noise_likelihood=self._H0)
+        raise ValueError('fit_method must be one of the following:\n\t{"Normal", "LogNormal"}')
+
+    def draw_powerspectrum(self, Ndraw=1):
+        """radial_fitters.py:834-856"""
+        log_p = np.random.multivariate_normal(np.log(self._ps), self.MAP_spectrum_covariance, Ndraw)
+        return np.exp(log_p)
+
+    def log_prior(self, p=None):
+        """radial_fitters.py:892-919"""
+        if p is None:
+            p = self._ps
+        return self._filter.log_prior(p)
+
+    def log_likelihood(self, sol=None):
+        r"""radial_fitters.py:922-949"""
+        if sol is None:
+            sol = self.MAP_solution
+        return self.log_prior(sol.power_spectrum) + sol.log_likelihood()
+
+    def log_evidence_laplace(self):
+        r"""radial_fitters.py:951-967"""
+        Sigma_inv = self._filter.covariance_MAP(self._sol, ret_inv=True)
+        sign, logdet = np.linalg.slogdet(Sigma_inv / (2 * np.pi))
+        return self.log_likelihood() - 0.5 * logdet
+
+    @property
+    def MAP_solution(self):
+        """Reconstruction for the maximum a posteriori power spectrum"""
+        return self._sol
+
+    @property
+    def MAP_spectrum(self):
+        """Maximum a posteriori power spectrum"""
+        return self._ps
+
+    @property
+    def MAP_spectrum_covariance(self):
+        """Covariance matrix of the maximum a posteriori power spectrum"""
+        if self._ps_cov is None:
+            self._ps_cov = self._filter.covariance_MAP(self._sol)
+        return self._ps_cov
+
+    @property
+    def iteration_diagnostics(self):
+        """Power spectrum and posterior mean at each fit iteration, and number of iterations"""
+        return self._iteration_diagnostics

@@ -1,0 +1,374 @@
+"""VisibilityMapping and GaussianModel -- drop-ins for frank/statistical_models.py:29-904.
+
+Every array computation here is a call into libfrank_hip (HIP kernels, rocBLAS, rocSOLVER); the Python
+keeps the reference's signatures, attribute names, error behaviour and plain-NumPy results.
+"""
+import ctypes
+import logging
+
+import numpy as np
+
+from frank_amd import _lib
+from frank_amd.constants import rad_to_arcsec, deg_to_rad
+
+
+class VisibilityMapping:
+    r"""Builds the mapping between the visibility and image planes (statistical_models.py:29-568).
+
+    Same constructor as the reference.  `block_data` / `block_size` are accepted for compatibility: the
+    GPU kernel streams the visibility axis itself, so they do not change the result's meaning (the
+    reference's result depends on them only through summation order, ~1e-15 relative).
+    """
+
+    def __init__(self, DHT, geometry, vis_model='opt_thick', scale_height=None, block_data=True,
+                 block_size=10 ** 5, check_qbounds=True, verbose=True):
+        _vis_models = ['opt_thick', 'opt_thin', 'debris']
+        if vis_model not in _vis_models:
+            raise ValueError(f"vis_model must be one of {_vis_models}")  # statistical_models.py:71-73
+        if vis_model == 'debris':
+            if scale_height is None:
+                raise ValueError('You requested a model with a non-zero scale height'
+                                 ' but did not specify H(R) (scale_height=None)')
+            raise NotImplementedError("vis_model='debris' (statistical_models.py:494-496) is outside the "
+                                      "hot path built so far")
+        self._vis_model = vis_model
+        self.check_qbounds = check_qbounds
+        self._verbose = verbose
+        self._chunking = block_data
+        self._chunk_size = block_size
+        self._DHT = DHT
+        self._geometry = geometry
+        self._scale_height = None
+        if self._verbose:
+            if vis_model == 'opt_thick':
+                logging.info('  Assuming an optically thick model (the default): '
+                             'Scaling the total flux to account for the source inclination')
+            else:
+                logging.info('  Assuming an optically thin model: *Not* scaling the '
+                             'total flux to account for the source inclination')
+
+    def map_visibilities(self, u, v, V, weights, frequencies=None, geometry=None):
+        r"""M = H^T w H, j = H^T w Re(V), H0 (statistical_models.py:109-237) via the bin_gram kernel.
+
+        Returns the reference's dict: keys 'mult_freq', 'channels', 'M', 'j', 'null_likelihood', 'hash'.
+        As in the reference the correction always uses the geometry given at construction (:165); the
+        `geometry` argument only goes into the hash.
+        """
+        if frequencies is not None:
+            raise NotImplementedError("multi-frequency mapping (statistical_models.py:175-189) is unreachable "
+                                      "from FrankFitter and not built")
+        if geometry is None:
+            geometry = self._geometry
+        if self._verbose:
+            logging.info('    Building visibility matrices M and j')
+        u, v = _lib.f8(u), _lib.f8(v)
+        V = np.asarray(V)
+        Vre = _lib.f8(V.real)
+        Vim = _lib.f8(V.imag) if np.iscomplexobj(V) else None
+        w = _lib.f8(np.atleast_1d(weights))
+        n = u.size
+        if v.size != n or Vre.size != n or w.size not in (1, n):
+            raise ValueError("u, v, V (and weights) must have matching lengths")
+        N = self.size
+        M, j = np.empty((N, N)), np.empty(N)
+        H0, qmin, qmax = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        g = _lib.make_geometry(self._geometry)
+        rc = _lib.lib.fh_map_visibilities(
+            self._DHT.context(), ctypes.byref(g), _lib.VIS_MODELS[self._vis_model], 0, _lib.ptr(u), _lib.ptr(v),
+            _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), w.size, n, _lib.ptr(M), _lib.ptr(j), ctypes.byref(H0),
+            ctypes.byref(qmin), ctypes.byref(qmax))
+        _lib.check(rc)
+        self._check_uv_range(qmin.value, qmax.value)
+        return {
+            'mult_freq': False,
+            'channels': None,
+            'M': M,
+            'j': j,
+            'null_likelihood': H0.value,
+            'hash': [False, self._DHT, geometry, self._vis_model, self._scale_height],
+        }
+
+    def check_hash(self, hash, multi_freq=False, geometry=None):
+        """statistical_models.py:239-276"""
+        if geometry is None:
+            geometry = self._geometry
+        passed = (
+            multi_freq == hash[0] and
+            self._DHT.Rmax == hash[1].Rmax and
+            self._DHT.size == hash[1].size and
+            self._DHT.order == hash[1].order and
+            geometry.inc == hash[2].inc and
+            geometry.PA == hash[2].PA and
+            geometry.dRA == hash[2].dRA and
+            geometry.dDec == hash[2].dDec and
+            self._vis_model == hash[3]
+        )
+        if not passed:
+            return False
+        if self._scale_height is None:
+            return hash[4] is None
+        if hash[4] is None:
+            return False
+        return np.all(self._scale_height == hash[4])
+
+    def _scale(self, geometry=None):
+        if self._vis_model == 'opt_thick':  # statistical_models.py:486-490
+            if geometry is None:
+                geometry = self._geometry
+            return np.cos(geometry.inc * deg_to_rad)
+        return 1.0
+
+    def predict_visibilities(self, I, q, k=None, geometry=None):
+        r"""V(q) = H(q) I on the GPU (statistical_models.py:279-329)."""
+        q = _lib.f8(np.atleast_1d(q)).reshape(-1)
+        I = _lib.f8(I)
+        if I.size != self.size:
+            raise ValueError("I must have one value per collocation point")
+        V = np.empty(q.size)
+        _lib.check(_lib.lib.fh_predict_visibilities(self._DHT.context(), _lib.ptr(q), q.size, _lib.ptr(I),
+                                                    float(self._scale(geometry)), _lib.ptr(V)))
+        return V
+
+    def invert_visibilities(self, V, R, geometry=None):
+        r"""statistical_models.py:331-384 (backward coefficients on the GPU, 1/scale applied)."""
+        R = np.atleast_1d(R)
+        H = self._DHT._device_coefficients(R / rad_to_arcsec, 'backward', 1.0 / self._scale(geometry))
+        return np.dot(H, V)[R < self.Rmax]
+
+    def transform(self, f, q=None, direction='forward'):
+        """statistical_models.py:386-412"""
+        if direction == 'backward' and q is not None:
+            q = q / rad_to_arcsec
+        return self._DHT.transform(f, q, direction)
+
+    def DHT_coefficients(self, direction='forward'):
+        """statistical_models.py:414-433"""
+        return self._DHT.coefficients(direction=direction)
+
+    def _get_mapping_coefficients(self, qs, ks, geometry=None, inverse=False):
+        """H(q) with the model's scale (statistical_models.py:483-509), built on the GPU."""
+        scale = self._scale(geometry)
+        if inverse:
+            return self._DHT._device_coefficients(np.asarray(qs) / rad_to_arcsec, 'backward', 1.0 / scale)
+        return self._DHT._device_coefficients(qs, 'forward', scale)
+
+    def _check_uv_range(self, uvmin, uvmax=None):
+        """statistical_models.py:512-535 (takes the min / max the kernel reduced, or an array of baselines)."""
+        if uvmax is None:
+            uv = np.asarray(uvmin)
+            uvmin, uvmax = uv.min(), uv.max()
+        if self.check_qbounds:
+            if self.q[0] < uvmin:
+                logging.warning(r"WARNING: First collocation point, q[0] = {:.3e} \lambda,"
+                                " is at a baseline shorter than the"
+                                " shortest deprojected baseline in the dataset,"
+                                r" min(uv) = {:.3e} \lambda. For q[0] << min(uv),"
+                                " the fit's total flux may be biased"
+                                " low.".format(self.q[0], uvmin))
+            if self.q[-1] < uvmax:
+                raise ValueError(r"ERROR: Last collocation point, {:.3e} \lambda, is at"
+                                 " a shorter baseline than the longest deprojected"
+                                 r" baseline in the dataset, {:.3e} \lambda. Please"
+                                 " increase N in FrankMultFrequencyFitter (this is"
+                                 " `hyperparameters: n` if you're using a parameter"
+                                 " file). Or if you'd like to fit to shorter maximum baseline,"
+                                 " cut the (u, v) distribution before fitting"
+                                 " (`modify_data: baseline_range` in the"
+                                 " parameter file).".format(self.q[-1], uvmax))
+
+    @property
+    def r(self):
+        """Radius points, unit = arcsec"""
+        return self._DHT.r * rad_to_arcsec
+
+    @property
+    def Rmax(self):
+        """Maximum radius, unit = arcsec"""
+        return self._DHT.Rmax * rad_to_arcsec
+
+    @property
+    def q(self):
+        r"""Frequency points, unit = :math:`\lambda`"""
+        return self._DHT.q
+
+    @property
+    def Qmax(self):
+        r"""Maximum frequency, unit = :math:`\lambda`"""
+        return self._DHT.Qmax
+
+    @property
+    def size(self):
+        """Number of points in reconstruction"""
+        return self._DHT.size
+
+    @property
+    def scale_height(self):
+        return self._scale_height
+
+
+_BAD_P_MSG = ("Bad value in power spectrum. The power"
+              " spectrum must be positive and not contain"
+              " any NaN values. This is likely due to"
+              " your UVtable (incorrect units or weights), "
+              " or the deprojection being applied (incorrect"
+              " geometry and/or phase center). Else you may"
+              " want to adjust `rout` (ensure it is larger than"
+              " the source) or `n` (up to ~300).")
+
+
+class GaussianModel:
+    r"""Posterior of the Bayesian linear regression, D = (M + S(p)^-1)^-1, mu = D j
+    (statistical_models.py:571-904), single field / single channel, solved on the GPU
+    (rocBLAS dgemm + rocSOLVER potrf/potrs through fh_gaussian_model).
+    """
+
+    def __init__(self, DHT, M, j, p=None, scale=None, guess=None, Nfields=None, noise_likelihood=0):
+        self._DHT = DHT
+        M = np.asarray(M, dtype=np.float64)
+        j = np.asarray(j, dtype=np.float64)
+        if M.ndim == 3 and M.shape[0] == 1:
+            M = M[0]
+        if j.ndim == 2 and j.shape[0] == 1:
+            j = j[0]
+        if M.ndim != 2 or j.ndim != 1 or scale is not None or (Nfields not in (None, 1)):
+            raise NotImplementedError("multi-channel / multi-field GaussianModel (statistical_models.py:655-726) "
+                                      "is outside the hot path built so far")
+        self._Nfields = 1
+        if p is not None:
+            p = np.asarray(p, dtype=np.float64).reshape(-1)
+            if np.any(p <= 0) or np.any(np.isnan(p)):  # statistical_models.py:688-698
+                print(p)
+                raise ValueError(_BAD_P_MSG)
+        self._p = p
+        self._M = np.ascontiguousarray(M)
+        self._j = np.ascontiguousarray(j)
+        self._like_noise = noise_likelihood
+        self._Sinv = None
+        self._cov = None
+        self._Dchol = None
+        self._used_svd = False
+        self._mu = None
+        self._fit()
+
+    @classmethod
+    def _from_solution(cls, DHT, M, j, p, mu, noise_likelihood=0):
+        """Wrap a posterior the device loop already solved (no recomputation; factor rebuilt on demand)."""
+        self = cls.__new__(cls)
+        self._DHT = DHT
+        self._Nfields = 1
+        self._p = np.asarray(p, dtype=np.float64)
+        self._M = np.ascontiguousarray(M, dtype=np.float64)
+        self._j = np.ascontiguousarray(j, dtype=np.float64)
+        self._like_noise = noise_likelihood
+        self._Sinv = None
+        self._cov = None
+        self._Dchol = None
+        self._used_svd = False
+        self._mu = np.asarray(mu, dtype=np.float64)
+        return self
+
+    def _fit(self, want_sinv=False):
+        """statistical_models.py:732-760"""
+        N = self.size
+        mu, chol = np.empty(N), np.empty((N, N))
+        Sinv = np.empty((N, N)) if want_sinv else None
+        used_svd = ctypes.c_int(0)
+        p = None if self._p is None else _lib.f8(self._p)
+        _lib.check(_lib.lib.fh_gaussian_model(self._DHT.context(), _lib.ptr(self._M), _lib.ptr(self._j), _lib.ptr(p),
+                                              _lib.ptr(mu), _lib.ptr(chol), _lib.ptr(Sinv), ctypes.byref(used_svd)))
+        self._used_svd = bool(used_svd.value)
+        if self._mu is None or not self._used_svd:
+            self._mu = mu
+        self._Dchol = None if self._used_svd else chol
+        if want_sinv:
+            self._Sinv = Sinv if self._p is not None else None
+        self._cov = None
+
+    def _ensure_factor(self):
+        if self._Dchol is None and not self._used_svd:
+            mu_keep = self._mu
+            self._fit()
+            self._mu = mu_keep
+
+    def Dsolve(self, b):
+        r"""Compute D . b by solving D^-1 x = b (statistical_models.py:762-781)."""
+        self._ensure_factor()
+        b = np.asarray(b, dtype=np.float64)
+        if self._Dchol is None:
+            # Cholesky failed for this Dinv: same route as the reference (:779-781), on the host
+            Dinv = self._M + (self._sinv() if self._p is not None else 0)
+            U, s, V = np.linalg.svd(Dinv, full_matrices=False)
+            s1 = np.where(s > 0, 1. / s, 0)
+            return np.dot(V.T, np.multiply(np.dot(U.T, b).T, s1).T)
+        shape = b.shape
+        B = np.ascontiguousarray(b.reshape(self.size, -1))
+        _lib.check(_lib.lib.fh_cho_solve(self._DHT.context(), _lib.ptr(self._Dchol), _lib.ptr(B), B.shape[1]))
+        return B.reshape(shape)
+
+    def _sinv(self):
+        if self._Sinv is None and self._p is not None:
+            mu_keep = self._mu
+            self._fit(want_sinv=True)
+            self._mu = mu_keep
+        return self._Sinv
+
+    def draw(self, N):
+        """Compute N draws from the posterior (statistical_models.py:783-788; host RNG)."""
+        return np.random.multivariate_normal(self.mean.reshape(-1), self.covariance, N)
+
+    def log_likelihood(self, I=None):
+        r"""statistical_models.py:790-856 (host slogdet; the solves run on the GPU)."""
+        Sinv = self._sinv()
+        if I is None:
+            like = 0.5 * np.sum(self._j * self._mu)
+            if Sinv is not None:
+                Q = self.Dsolve(Sinv)
+                like += 0.5 * np.linalg.slogdet(Q)[1]
+        else:
+            Dinv = self._M + (Sinv if Sinv is not None else 0)
+            like = np.sum(self._j * I) - 0.5 * np.dot(I, np.dot(Dinv, I))
+            if Sinv is not None:
+                like += 0.5 * np.linalg.slogdet(2 * np.pi * Sinv)[1]
+        return like + self._like_noise
+
+    def solve_non_negative(self):
+        """statistical_models.py:858-866 (SciPy NNLS on the host; off the hot path)."""
+        import scipy.optimize
+        Sinv = self._sinv()
+        Dinv = self._M + (Sinv if Sinv is not None else 0)
+        return scipy.optimize.nnls(Dinv, self._j, maxiter=100 * len(self._j))[0]
+
+    @property
+    def mean(self):
+        """Posterior mean, unit = Jy / sr"""
+        return self._mu
+
+    @property
+    def MAP(self):
+        """Posterior maximum, unit = Jy / sr"""
+        return self.mean
+
+    @property
+    def covariance(self):
+        """Posterior covariance, unit = (Jy / sr)**2"""
+        if self._cov is None:
+            self._cov = self.Dsolve(np.eye(self.size))
+        return self._cov
+
+    @property
+    def s_0(self):
+        return 0
+
+    @property
+    def power_spectrum(self):
+        """Power spectrum coefficients"""
+        return self._p
+
+    @property
+    def num_fields(self):
+        return self._Nfields
+
+    @property
+    def size(self):
+        """Number of points in reconstruction"""
+        return self._DHT.size

@@ -99,6 +99,8 @@ int64_t fh_vis_size(const fh_vis *vis);
  *                     Returns FH_ERR_QRANGE iff check_qbounds and q_k[-1] < qmax (outputs are still written). */
 int fh_bin_reset(fh_ctx *ctx);
 int fh_bin_visibilities(fh_ctx *ctx, const fh_geometry *geom, const fh_vis *vis, int64_t first, int64_t count);
+/* Device time (ms, HIP events on the context's stream) of the most recent bin_gram launch alone. */
+int fh_bin_last_kernel_ms(fh_ctx *ctx, float *ms);
 int fh_stats_device(fh_ctx *ctx, double **sum_stats, int64_t *n_sum, double **minmax_stats);
 int fh_stats_finalize(fh_ctx *ctx, const fh_geometry *geom, int vis_model, int check_qbounds, double *M, double *j,
                       double *H0, double *qmin, double *qmax);
@@ -126,6 +128,12 @@ int fh_cho_solve(fh_ctx *ctx, const double *chol, double *B, int nrhs);
  * MAP of every loop pass (:781-783).                                                                        */
 int fh_fit_normal(fh_ctx *ctx, const double *M, const double *j, double alpha, double p0, double wsmooth,
                   double tol, int max_iter, double *mu, double *p, int *niter, double *diag_p, double *diag_mu);
+
+/* One pass of the loop body for a caller-supplied p: fit = GaussianModel(M, j, p); p_new =
+ * CriticalFilter.update_power_spectrum(fit) (filter.py:154-177).  M, j, p host; mu (N, posterior mean for p) and
+ * p_new (N) host outputs, either may be NULL.                                                                */
+int fh_update_power_spectrum(fh_ctx *ctx, const double *M, const double *j, const double *p, double alpha, double p0,
+                             double wsmooth, double *mu, double *p_new);
 
 /* ---- multi-GPU: RCCL all-reduce of the sufficient statistics (one rank per GPU) ------------------------------
  * The reduction being distributed is `Ms[i] += ...; js[i] += ...` (statistical_models.py:210-211) and the

@@ -1,0 +1,105 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads, exports every symbol that
+include/frank_hip.h declares, its host DHT set-up matches the reference fixtures, and the device
+entry points fail loudly (no CPU fallback) when there is no GPU."""
+import ctypes
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rel_to_max, ulp_diff
+from frank_amd.constants import rad_to_arcsec
+
+RMAX = 2.0 / rad_to_arcsec
+
+
+def test_library_exports_every_declared_symbol():
+    from frank_amd import _lib
+    header = open(os.path.join(ROOT, "include", "frank_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(fh_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 25
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), "libfrank_hip.so does not export %s" % name
+    assert declared == set(_lib.SIGNATURES), "frank_amd/_lib.py and include/frank_hip.h disagree"
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under frank_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "frank_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "frank_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+@pytest.mark.parametrize("N", [5, 20, 100, 300])
+def test_host_dht_matches_reference(golden, N):
+    from frank_amd import DiscreteHankelTransform
+    g = golden("dht_N%d.npz" % N)
+    d = DiscreteHankelTransform(RMAX, N)
+    assert d.size == N and d.order == 0
+    zeros = np.append(d._j_nk, d._j_nN)
+    assert ulp_diff(zeros, g["zeros"]).max() <= 1          # collocation zeros: <= 1 ulp of scipy.special.jn_zeros
+    assert ulp_diff(d.r, g["r"]).max() <= 4 and ulp_diff(d.q, g["q"]).max() <= 4
+    assert ulp_diff(d.Qmax, g["Qmax"]).max() <= 2
+    np.testing.assert_allclose(d._scale_factor, g["scale_factor"], rtol=2e-13)
+    assert np.abs(d._Ykm - g["Ykm"]).max() <= 2e-14 * np.abs(g["Ykm"]).max()
+    assert rel_to_max(d.coefficients(), g["Y"]) < 1e-13
+    assert rel_to_max(d.transform(np.ones(N)), g["transform_ones"]) < 1e-12
+    with pytest.raises(AttributeError):
+        d.coefficients(direction="sideways")             # hankel.py:194
+    with pytest.raises(AttributeError):
+        d.transform(np.ones(N), direction="sideways")    # hankel.py:159
+    d2 = pickle.loads(pickle.dumps(d))
+    assert np.array_equal(d2.q, d.q) and np.array_equal(d2._Ykm, d._Ykm)
+
+
+def test_collocation_points_reference_literals():
+    """frank/tests.py:704-717"""
+    from frank_amd import DiscreteHankelTransform
+    r, q = DiscreteHankelTransform.get_collocation_points(RMAX, 10)
+    np.testing.assert_allclose(r * rad_to_arcsec, [0.14239924, 0.32686567, 0.51242148, 0.69822343, 0.88411873,
+                                                   1.07005922, 1.25602496, 1.44200623, 1.62799772, 1.8139963],
+                               rtol=2e-5, atol=1e-8)
+    np.testing.assert_allclose(q, [39472.88305737, 90606.73736504, 142042.56471889, 193546.62066389,
+                                   245076.55732463, 296619.01772663, 348168.47711355, 399722.24089812,
+                                   451278.83939289, 502837.4032234], rtol=2e-5, atol=1e-8)
+
+
+def test_smoothing_matrix_host_mirror(golden):
+    from frank_amd import DiscreteHankelTransform
+    from frank_amd.filter import spectral_smoothing_matrix
+    g = golden("smoothing_T.npz")
+    for N in (20, 100):
+        T = spectral_smoothing_matrix(DiscreteHankelTransform(RMAX, N), float(g["w_N%d" % N]))
+        assert rel_to_max(T, g["T_N%d" % N]) < 1e-12
+
+
+def test_constructor_errors():
+    from frank_amd import FixedGeometry, FrankFitter, VisibilityMapping, DiscreteHankelTransform
+    geom = FixedGeometry(30.0, 40.0)
+    with pytest.raises(ValueError):
+        FrankFitter(2.0, 20, geom, method="Cauchy")                  # radial_fitters.py:697-699
+    with pytest.raises(ValueError):
+        FrankFitter(2.0, 20, geom, convergence_failure="explode")    # radial_fitters.py:728-730
+    with pytest.raises(ValueError):
+        VisibilityMapping(DiscreteHankelTransform(RMAX, 10), geom, vis_model="opaque")  # statistical_models.py:71-73
+    FF = FrankFitter(2.0, 20, geom, verbose=False)
+    assert FF._info == {'Rmax': pytest.approx(2.0), 'N': 20, 'alpha': 1.05, 'wsmooth': 1e-4, 'p0': 1e-15,
+                        'method': 'Normal'}
+    assert FF.Rmax == pytest.approx(2.0) and FF.size == 20 and FF.geometry is geom
+
+
+def test_device_entry_points_fail_loudly_without_a_gpu():
+    from frank_amd import _lib, FixedGeometry, FrankFitter
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    FF = FrankFitter(2.0, 20, FixedGeometry(30.0, 40.0), verbose=False)
+    x = np.full(8, 1e5)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        FF.fit(x, x, np.ones(8) + 0j, np.ones(8))
