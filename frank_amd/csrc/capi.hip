@@ -7,7 +7,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -84,6 +86,11 @@ struct fh_ctx {
     // normal equations + K2 work
     DevBuf<double> M, j, W, D, Z, p, p_old, mu, band_lu, diag_p, diag_mu;
     DevBuf<int> flags, info;
+    // K2 v2 (fit_loop): q-space operands and work buffers
+    int NP = 0;
+    bool use_rocsolver_loop = false;
+    DevBuf<double> Yinv, T1, Araw, Aq, bq, Cq, Wq, mu_out, p_out, p_init;
+    DevBuf<int> loop_result;
     bool have_device_Mj = false;
     hipEvent_t ev_bin0 = nullptr, ev_bin1 = nullptr;
     bool bin_timed = false;
@@ -229,6 +236,36 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     HIP_TRY(c->info.alloc(1));
     HIP_TRY(hipMemset(c->info.p, 0, sizeof(int)));
     HIP_TRY(hipMemset(c->flags.p, 0, sizeof(int) * FIT_NFLAGS));
+    // K2 v2: Y^-1 (cond(Y) ~ 1e2), q-space work buffers
+    {
+        c->NP = 16 * ((N + 15) / 16);
+        const size_t PP = (size_t)c->NP * c->NP;
+        // Y^-1 by LU on the device (in place; the inverse of the column-major view is the row-major inverse)
+        DevBuf<rocblas_int> ipiv;
+        HIP_TRY(ipiv.alloc(N));
+        HIP_TRY(c->Yinv.alloc(NN));
+        HIP_TRY(hipMemcpy(c->Yinv.p, Y.data(), sizeof(double) * NN, hipMemcpyHostToDevice));
+        ROC_TRY(rocsolver_dgetrf(c->blas, N, N, c->Yinv.p, N, ipiv.p, c->info.p));
+        ROC_TRY(rocsolver_dgetri(c->blas, N, c->Yinv.p, N, ipiv.p, c->info.p));
+        int inv_info = 0;
+        HIP_TRY(hipMemcpyAsync(&inv_info, c->info.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (inv_info != 0) return fail(FH_ERR_INVALID, "DHT coefficient matrix is singular (getri info %d)", inv_info);
+        HIP_TRY(c->T1.alloc(NN));
+        HIP_TRY(c->Araw.alloc(NN));
+        HIP_TRY(c->Aq.alloc(PP));
+        HIP_TRY(c->Cq.alloc(PP));
+        HIP_TRY(c->Wq.alloc(PP));
+        HIP_TRY(hipMemset(c->Cq.p, 0, sizeof(double) * PP));
+        HIP_TRY(hipMemset(c->Wq.p, 0, sizeof(double) * PP));
+        HIP_TRY(c->bq.alloc(N));
+        HIP_TRY(c->mu_out.alloc(N));
+        HIP_TRY(c->p_out.alloc(N));
+        HIP_TRY(c->p_init.alloc(N));
+        HIP_TRY(c->loop_result.alloc(2));
+        const char *env = getenv("FRANK_AMD_K2");
+        c->use_rocsolver_loop = env && strcmp(env, "rocsolver") == 0;
+    }
     *out = c;
     return fh_bin_reset(c);
 }
@@ -674,7 +711,7 @@ static void smoothing_band_lu(const fh_dht &d, double weights, std::vector<doubl
     }
 }
 
-int fh_fit_normal(fh_ctx *c, const double *M, const double *j, double alpha, double p0, double wsmooth, double tol,
+static int fit_normal_rocsolver(fh_ctx *c, const double *M, const double *j, double alpha, double p0, double wsmooth, double tol,
                   int max_iter, double *mu, double *p, int *niter, double *diag_p, double *diag_mu) {
     if (!c || !mu || !p || !niter) return fail(FH_ERR_INVALID, "fh_fit_normal: NULL argument");
     if ((M == nullptr) != (j == nullptr)) return fail(FH_ERR_INVALID, "fh_fit_normal: pass both M and j or neither");
@@ -747,7 +784,98 @@ int fh_fit_normal(fh_ctx *c, const double *M, const double *j, double alpha, dou
     return FH_OK;
 }
 
-int fh_update_power_spectrum(fh_ctx *c, const double *M, const double *j, const double *p, double alpha, double p0,
+// q-space operands of the fit_loop kernel: A = Y^-T M Y^-1 (symmetrised, padded), b = Y^-T j.
+static int prepare_qspace(fh_ctx *c) {
+    const int N = c->N;
+    const double one = 1.0, zero = 0.0;
+    // T1 = M Yinv (row-major) == column-major Yinv_buf * M_buf
+    ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, N, N, N, &one, c->Yinv.p, N,
+                          c->M.p, N, &zero, c->T1.p, N));
+    // Araw = Yinv^T T1 (row-major) == column-major T1_buf * Yinv_buf^T
+    ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, N, N, N, &one, c->T1.p, N,
+                          c->Yinv.p, N, &zero, c->Araw.p, N));
+    HIP_TRY(fh_k2_launch_symmetrize(c->Araw.p, N, c->NP, c->Aq.p, c->stream));
+    // b = Yinv^T j: the column-major view of the row-major Yinv buffer is Yinv^T
+    ROC_TRY(rocblas_dgemv(c->blas, rocblas_operation_none, N, N, &one, c->Yinv.p, N, c->j.p, 1, &zero, c->bq.p, 1));
+    return FH_OK;
+}
+
+static FitLoopParams make_loop_params(fh_ctx *c, int mode, double alpha, double p0, double tol, int max_iter) {
+    FitLoopParams P{};
+    P.N = c->N;
+    P.NP = c->NP;
+    P.max_iter = max_iter;
+    P.mode = mode;
+    P.alpha = alpha;
+    P.p0 = p0;
+    P.tol = tol;
+    // DHT.transform(MAP) = (2 pi Rmax^2 / j_nN) Ykm mu and m = Y mu with Y = (0.5 j_nN norm) Ykm
+    const double norm = 1 / (M_PI * c->dht->Qmax * c->dht->Qmax);
+    P.pl_scale = ((2 * M_PI * c->dht->Rmax * c->dht->Rmax) / c->dht->j_nN) / (0.5 * c->dht->j_nN * norm);
+    P.A = c->Aq.p;
+    P.bq = c->bq.p;
+    P.Yinv = c->Yinv.p;
+    P.q = c->q.p;
+    P.band_lu = c->band_lu.p;
+    P.p_init = nullptr;
+    P.C = c->Cq.p;
+    P.W = c->Wq.p;
+    P.mu_out = c->mu_out.p;
+    P.p_out = c->p_out.p;
+    P.result = c->loop_result.p;
+    return P;
+}
+
+int fh_fit_normal(fh_ctx *c, const double *M, const double *j, double alpha, double p0, double wsmooth, double tol,
+                  int max_iter, double *mu, double *p, int *niter, double *diag_p, double *diag_mu) {
+    if (!c || !mu || !p || !niter) return fail(FH_ERR_INVALID, "fh_fit_normal: NULL argument");
+    if (c->use_rocsolver_loop)
+        return fit_normal_rocsolver(c, M, j, alpha, p0, wsmooth, tol, max_iter, mu, p, niter, diag_p, diag_mu);
+    if ((M == nullptr) != (j == nullptr)) return fail(FH_ERR_INVALID, "fh_fit_normal: pass both M and j or neither");
+    if (!M && !c->have_device_Mj) return fail(FH_ERR_INVALID, "fh_fit_normal: no device-resident M, j (run fh_stats_finalize)");
+    if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
+    if (c->NP > 320) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 320", c->N);
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->N;
+    const size_t NN = (size_t)N * N;
+    if (M) {
+        HIP_TRY(hipMemcpyAsync(c->M.p, M, sizeof(double) * NN, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->j.p, j, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+        c->have_device_Mj = false;
+    }
+    std::vector<double> lu;
+    smoothing_band_lu(*c->dht, wsmooth, lu);
+    HIP_TRY(hipMemcpyAsync(c->band_lu.p, lu.data(), sizeof(double) * lu.size(), hipMemcpyHostToDevice, c->stream));
+    const bool want_diag = diag_p || diag_mu;
+    if (want_diag) {
+        const size_t need = (size_t)(max_iter + 1) * N;
+        if (c->diag_p.n < need) HIP_TRY(c->diag_p.alloc(need));
+        if (c->diag_mu.n < need) HIP_TRY(c->diag_mu.alloc(need));
+    }
+    int rc = prepare_qspace(c);
+    if (rc) return rc;
+    FitLoopParams P = make_loop_params(c, FIT_MODE_FULL, alpha, p0, tol, max_iter);
+    P.diag_p = want_diag ? c->diag_p.p : nullptr;
+    P.diag_mu = want_diag ? c->diag_mu.p : nullptr;
+    HIP_TRY(fh_k2_launch_loop(P, c->stream));
+    int result[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(result, c->loop_result.p, sizeof result, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(mu, c->mu_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(p, c->p_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *niter = result[0];
+    const size_t nd = (size_t)result[0] * N;
+    if (diag_p && nd) HIP_TRY(hipMemcpy(diag_p, c->diag_p.p, sizeof(double) * nd, hipMemcpyDeviceToHost));
+    if (diag_mu && nd) HIP_TRY(hipMemcpy(diag_mu, c->diag_mu.p, sizeof(double) * nd, hipMemcpyDeviceToHost));
+    if (result[1] == FIT_STATUS_BAD_P)
+        return fail(FH_ERR_BAD_P, "Bad value in power spectrum (non-positive or NaN) at iteration %d", *niter);
+    if (result[1] == FIT_STATUS_NOT_SPD)
+        return fail(FH_ERR_NOT_SPD, "Cholesky of the posterior precision failed at iteration %d (the reference would "
+                                    "switch to an SVD)", *niter);
+    return FH_OK;
+}
+
+static int update_power_spectrum_rocsolver(fh_ctx *c, const double *M, const double *j, const double *p, double alpha, double p0,
                              double wsmooth, double *mu, double *p_new) {
     if (!c || !M || !j || !p) return fail(FH_ERR_INVALID, "fh_update_power_spectrum: NULL argument");
     if (c->N > FIT_MAX_N) return fail(FH_ERR_UNSUPPORTED, "N = %d > %d", c->N, FIT_MAX_N);
@@ -778,6 +906,42 @@ int fh_update_power_spectrum(fh_ctx *c, const double *M, const double *j, const 
     if (p_new) HIP_TRY(hipMemcpyAsync(p_new, c->p.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (flags[FIT_FLAG_NOT_SPD]) return fail(FH_ERR_NOT_SPD, "Cholesky of M + S^-1 failed");
+    return FH_OK;
+}
+
+int fh_update_power_spectrum(fh_ctx *c, const double *M, const double *j, const double *p, double alpha, double p0,
+                             double wsmooth, double *mu, double *p_new) {
+    if (!c || !M || !j || !p) return fail(FH_ERR_INVALID, "fh_update_power_spectrum: NULL argument");
+    if (c->use_rocsolver_loop) return update_power_spectrum_rocsolver(c, M, j, p, alpha, p0, wsmooth, mu, p_new);
+    if (c->NP > 320) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 320", c->N);
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->N;
+    for (int k = 0; k < N; ++k)
+        if (!(p[k] > 0.0)) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (p[%d] = %g)", k, p[k]);
+    std::vector<double> lu;
+    smoothing_band_lu(*c->dht, wsmooth, lu);
+    HIP_TRY(hipMemcpyAsync(c->M.p, M, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->j.p, j, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->p_init.p, p, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->band_lu.p, lu.data(), sizeof(double) * lu.size(), hipMemcpyHostToDevice, c->stream));
+    c->have_device_Mj = false;
+    int rc = prepare_qspace(c);
+    if (rc) return rc;
+    // posterior mean for the given p
+    FitLoopParams P = make_loop_params(c, FIT_MODE_SOLVE, alpha, p0, 0.0, 1 << 30);
+    P.p_init = c->p_init.p;
+    if (mu) {
+        HIP_TRY(fh_k2_launch_loop(P, c->stream));
+        HIP_TRY(hipMemcpyAsync(mu, c->mu_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    }
+    P.mode = FIT_MODE_STEP;
+    HIP_TRY(fh_k2_launch_loop(P, c->stream));
+    int result[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(result, c->loop_result.p, sizeof result, hipMemcpyDeviceToHost, c->stream));
+    if (p_new) HIP_TRY(hipMemcpyAsync(p_new, c->p_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (result[1] == FIT_STATUS_NOT_SPD) return fail(FH_ERR_NOT_SPD, "Cholesky of the posterior precision failed");
+    if (result[1] == FIT_STATUS_BAD_P) return fail(FH_ERR_BAD_P, "Bad value in power spectrum after the update");
     return FH_OK;
 }
 

@@ -68,3 +68,27 @@ hipError_t fh_k2_launch_prep(const FitState &st, hipStream_t s);
 hipError_t fh_k2_launch_powerlaw(const FitState &st, hipStream_t s);
 hipError_t fh_k2_launch_update(const FitState &st, hipStream_t s);
 hipError_t fh_k2_launch_record(const FitState &st, hipStream_t s);
+
+// ---- K2 v2: single persistent kernel (fit_loop.hip) ---------------------------------------------------------
+enum { FIT_MODE_FULL = 0, FIT_MODE_STEP = 1, FIT_MODE_SOLVE = 2 };
+enum { FIT_STATUS_OK = 0, FIT_STATUS_BAD_P = 1, FIT_STATUS_NOT_SPD = 2 };
+
+struct FitLoopParams {
+    int N, NP, max_iter, mode;
+    double alpha, p0, tol;
+    double pl_scale;        // DHT.transform(MAP) = pl_scale * m, m = Y mu  (hankel.py:155,199)
+    const double *A;        // NP*NP, symmetric, zero padded: Y^-T M Y^-1
+    const double *bq;       // N: Y^-T j
+    const double *Yinv;     // N*N row-major: mu = Yinv m
+    const double *q;        // N collocation frequencies
+    const double *band_lu;  // 5N: LU factors of the pentadiagonal T + I
+    const double *p_init;   // N or NULL (= ones)
+    double *C, *W;          // NP*NP work: Cholesky factor, its inverse
+    double *mu_out, *p_out; // N
+    int *result;            // [0] count, [1] status
+    double *diag_p, *diag_mu;
+};
+
+size_t fh_k2_loop_smem_bytes(int NP);
+hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s);
+hipError_t fh_k2_launch_symmetrize(const double *Araw, int N, int NP, double *A, hipStream_t s);

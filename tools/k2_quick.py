@@ -1,0 +1,17 @@
+import sys, time, numpy as np
+sys.path.insert(0,'/root/repo')
+from frank_amd import FrankFitter, FixedGeometry
+from frank_amd.mock import MOCK_GEOMETRY
+from frank_amd.constants import rad_to_arcsec
+import os
+for name,N in (('sweep_N50_2e4.npz',50),('fit_N100_1e5.npz',100),('fit_N300_1e6.npz',300)):
+    g=np.load('/root/repo/tests/golden/'+name)
+    kw={}
+    if N==50: kw=dict(alpha=float(g['alpha_a']),weights_smooth=float(g['wsmooth_a']))
+    FF=FrankFitter(2.0,N,FixedGeometry(**MOCK_GEOMETRY),verbose=False,store_iteration_diagnostics=True,**kw)
+    m={'M':g['M'],'j':g['j'],'null_likelihood':0.0,'hash':[False,FF._DHT,FF._geometry,'opt_thick',None]}
+    t=time.time(); sol=FF.fit_preprocessed(m); dt=time.time()-t
+    t=time.time(); sol=FF.fit_preprocessed(m); dt=time.time()-t
+    I=g['I_a'] if N==50 else g['I']; ni=int(g['niter_a'] if N==50 else g['niter'])
+    nit=FF.iteration_diagnostics['num_iterations']
+    print(N,'niter',nit,ni,'rel',np.abs(sol.I-I).max()/np.abs(I).max(),'time %.1f ms  %.1f us/iter'%(1e3*dt,1e6*dt/nit))
