@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfrank_hip.so")
+LIB_PATH = os.environ.get("FRANK_AMD_LIB", os.path.join(_HERE, "libfrank_hip.so"))
 
 FH_OK = 0
 FH_ERR_INVALID = -1
@@ -63,6 +63,10 @@ SIGNATURES = {
     "fh_cho_solve": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int]),
     "fh_fit_normal": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                      ctypes.c_double, ctypes.c_int, _dp, _dp, ctypes.POINTER(ctypes.c_int), _dp, _dp]),
+    "fh_fit_slots": (ctypes.c_int, []),
+    "fh_fit_submit": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                     ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    "fh_fit_collect": (ctypes.c_int, [_vp, ctypes.c_int, _dp, _dp, ctypes.POINTER(ctypes.c_int)]),
     "fh_update_power_spectrum": (ctypes.c_int, [_vp, _dp, _dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                                 _dp, _dp]),
     "fh_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),

@@ -73,6 +73,15 @@ struct fh_vis {
     DevBuf<double> u, v, Vre, Vim, w;
 };
 
+struct FitSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t ready = nullptr;
+    DevBuf<double> Aq, bq, Cq, Wq, mu_out, p_out, band_lu;
+    DevBuf<int> result;
+    bool busy = false;
+};
+constexpr int kFitSlots = 32;
+
 struct fh_ctx {
     const fh_dht *dht = nullptr;
     int device = 0, N = 0, NBT = 0, ntiles = 0, nparts = 1, num_cu = 0;
@@ -91,6 +100,9 @@ struct fh_ctx {
     bool use_rocsolver_loop = false;
     DevBuf<double> Yinv, T1, Araw, Aq, bq, Cq, Wq, mu_out, p_out, p_init;
     DevBuf<int> loop_result;
+    DevBuf<long long> loop_timing;  // FIT_LOOP_TIMING debug builds only
+    FitSlot slots[kFitSlots];
+    int slots_busy = 0;
     bool have_device_Mj = false;
     hipEvent_t ev_bin0 = nullptr, ev_bin1 = nullptr;
     bool bin_timed = false;
@@ -274,6 +286,13 @@ void fh_ctx_destroy(fh_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &s : c->slots) {
+        if (s.stream) {
+            (void)hipStreamSynchronize(s.stream);
+            (void)hipStreamDestroy(s.stream);
+        }
+        if (s.ready) (void)hipEventDestroy(s.ready);
+    }
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev_bin0) (void)hipEventDestroy(c->ev_bin0);
     if (c->ev_bin1) (void)hipEventDestroy(c->ev_bin1);
@@ -417,8 +436,13 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     ReduceParams rp{};
     rp.nparts = c->nparts;
     rp.ntiles = c->ntiles;
+    // leave one CU per outstanding fit_loop kernel (each occupies a whole CU) so every bin_gram workgroup is resident
+    const int reserve = c->slots_busy < c->num_cu / 4 ? c->slots_busy : c->num_cu / 4;
+    const int G = c->part_blocks[0] + c->part_blocks[1];
     for (int P = 0; P < 2; ++P) {
         int blocks = c->part_blocks[P];
+        if (reserve > 0 && G > 0) blocks -= (reserve * c->part_blocks[P] + G - 1) / G;
+        if (blocks < 1 && P < c->nparts) blocks = 1;
         if (P < c->nparts && nsuper < blocks) blocks = (int)(nsuper > 0 ? nsuper : 1);
         p.part_blocks[P] = P < c->nparts ? blocks : 0;
         p.partials[P] = c->partials[P].p;
@@ -785,7 +809,7 @@ static int fit_normal_rocsolver(fh_ctx *c, const double *M, const double *j, dou
 }
 
 // q-space operands of the fit_loop kernel: A = Y^-T M Y^-1 (symmetrised, padded), b = Y^-T j.
-static int prepare_qspace(fh_ctx *c) {
+static int prepare_qspace(fh_ctx *c, double *Aq, double *bq) {
     const int N = c->N;
     const double one = 1.0, zero = 0.0;
     // T1 = M Yinv (row-major) == column-major Yinv_buf * M_buf
@@ -794,9 +818,9 @@ static int prepare_qspace(fh_ctx *c) {
     // Araw = Yinv^T T1 (row-major) == column-major T1_buf * Yinv_buf^T
     ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, N, N, N, &one, c->T1.p, N,
                           c->Yinv.p, N, &zero, c->Araw.p, N));
-    HIP_TRY(fh_k2_launch_symmetrize(c->Araw.p, N, c->NP, c->Aq.p, c->stream));
+    HIP_TRY(fh_k2_launch_symmetrize(c->Araw.p, N, c->NP, Aq, c->stream));
     // b = Yinv^T j: the column-major view of the row-major Yinv buffer is Yinv^T
-    ROC_TRY(rocblas_dgemv(c->blas, rocblas_operation_none, N, N, &one, c->Yinv.p, N, c->j.p, 1, &zero, c->bq.p, 1));
+    ROC_TRY(rocblas_dgemv(c->blas, rocblas_operation_none, N, N, &one, c->Yinv.p, N, c->j.p, 1, &zero, bq, 1));
     return FH_OK;
 }
 
@@ -823,6 +847,10 @@ static FitLoopParams make_loop_params(fh_ctx *c, int mode, double alpha, double 
     P.mu_out = c->mu_out.p;
     P.p_out = c->p_out.p;
     P.result = c->loop_result.p;
+#ifdef FIT_LOOP_TIMING
+    if (!c->loop_timing.p && c->loop_timing.alloc(16) == hipSuccess) (void)hipMemset(c->loop_timing.p, 0, 16 * sizeof(long long));
+    P.timing = c->loop_timing.p;
+#endif
     return P;
 }
 
@@ -852,7 +880,7 @@ int fh_fit_normal(fh_ctx *c, const double *M, const double *j, double alpha, dou
         if (c->diag_p.n < need) HIP_TRY(c->diag_p.alloc(need));
         if (c->diag_mu.n < need) HIP_TRY(c->diag_mu.alloc(need));
     }
-    int rc = prepare_qspace(c);
+    int rc = prepare_qspace(c, c->Aq.p, c->bq.p);
     if (rc) return rc;
     FitLoopParams P = make_loop_params(c, FIT_MODE_FULL, alpha, p0, tol, max_iter);
     P.diag_p = want_diag ? c->diag_p.p : nullptr;
@@ -909,6 +937,81 @@ static int update_power_spectrum_rocsolver(fh_ctx *c, const double *M, const dou
     return FH_OK;
 }
 
+int fh_fit_slots(void) { return kFitSlots; }
+
+int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol, int max_iter, int *ticket) {
+    if (!c || !ticket) return fail(FH_ERR_INVALID, "fh_fit_submit: NULL argument");
+    if (!c->have_device_Mj) return fail(FH_ERR_INVALID, "fh_fit_submit: no device-resident M, j (run fh_stats_finalize)");
+    if (c->NP > 320) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 320", c->N);
+    if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
+    HIP_TRY(hipSetDevice(c->device));
+    int si = -1;
+    for (int i = 0; i < kFitSlots; ++i)
+        if (!c->slots[i].busy) {
+            si = i;
+            break;
+        }
+    if (si < 0) return fail(FH_ERR_INVALID, "fh_fit_submit: all %d fit slots are outstanding; collect one first", kFitSlots);
+    FitSlot &s = c->slots[si];
+    const int N = c->N;
+    const size_t PP = (size_t)c->NP * c->NP;
+    if (!s.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
+        HIP_TRY(s.Aq.alloc(PP));
+        HIP_TRY(s.Cq.alloc(PP));
+        HIP_TRY(s.Wq.alloc(PP));
+        HIP_TRY(hipMemset(s.Cq.p, 0, sizeof(double) * PP));
+        HIP_TRY(hipMemset(s.Wq.p, 0, sizeof(double) * PP));
+        HIP_TRY(s.bq.alloc(N));
+        HIP_TRY(s.mu_out.alloc(N));
+        HIP_TRY(s.p_out.alloc(N));
+        HIP_TRY(s.band_lu.alloc(5 * (size_t)N));
+        HIP_TRY(s.result.alloc(2));
+    }
+    std::vector<double> lu;
+    smoothing_band_lu(*c->dht, wsmooth, lu);
+    HIP_TRY(hipMemcpyAsync(s.band_lu.p, lu.data(), sizeof(double) * lu.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `lu` is pageable host memory: make the copy complete before it dies
+    int rc = prepare_qspace(c, s.Aq.p, s.bq.p);  // on the context's stream, after the finalize that produced M, j
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(s.ready, c->stream));
+    HIP_TRY(hipStreamWaitEvent(s.stream, s.ready, 0));
+    FitLoopParams P = make_loop_params(c, FIT_MODE_FULL, alpha, p0, tol, max_iter);
+    P.A = s.Aq.p;
+    P.bq = s.bq.p;
+    P.band_lu = s.band_lu.p;
+    P.C = s.Cq.p;
+    P.W = s.Wq.p;
+    P.mu_out = s.mu_out.p;
+    P.p_out = s.p_out.p;
+    P.result = s.result.p;
+    HIP_TRY(fh_k2_launch_loop(P, s.stream));
+    s.busy = true;
+    ++c->slots_busy;
+    *ticket = si;
+    return FH_OK;
+}
+
+int fh_fit_collect(fh_ctx *c, int ticket, double *mu, double *p, int *niter) {
+    if (!c || ticket < 0 || ticket >= kFitSlots || !c->slots[ticket].busy)
+        return fail(FH_ERR_INVALID, "fh_fit_collect: bad ticket %d", ticket);
+    HIP_TRY(hipSetDevice(c->device));
+    FitSlot &s = c->slots[ticket];
+    const int N = c->N;
+    int result[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(result, s.result.p, sizeof result, hipMemcpyDeviceToHost, s.stream));
+    if (mu) HIP_TRY(hipMemcpyAsync(mu, s.mu_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, s.stream));
+    if (p) HIP_TRY(hipMemcpyAsync(p, s.p_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    s.busy = false;
+    --c->slots_busy;
+    if (niter) *niter = result[0];
+    if (result[1] == FIT_STATUS_BAD_P) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (non-positive or NaN)");
+    if (result[1] == FIT_STATUS_NOT_SPD) return fail(FH_ERR_NOT_SPD, "Cholesky of the posterior precision failed");
+    return FH_OK;
+}
+
 int fh_update_power_spectrum(fh_ctx *c, const double *M, const double *j, const double *p, double alpha, double p0,
                              double wsmooth, double *mu, double *p_new) {
     if (!c || !M || !j || !p) return fail(FH_ERR_INVALID, "fh_update_power_spectrum: NULL argument");
@@ -925,7 +1028,7 @@ int fh_update_power_spectrum(fh_ctx *c, const double *M, const double *j, const 
     HIP_TRY(hipMemcpyAsync(c->p_init.p, p, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->band_lu.p, lu.data(), sizeof(double) * lu.size(), hipMemcpyHostToDevice, c->stream));
     c->have_device_Mj = false;
-    int rc = prepare_qspace(c);
+    int rc = prepare_qspace(c, c->Aq.p, c->bq.p);
     if (rc) return rc;
     // posterior mean for the given p
     FitLoopParams P = make_loop_params(c, FIT_MODE_SOLVE, alpha, p0, 0.0, 1 << 30);
@@ -944,6 +1047,16 @@ int fh_update_power_spectrum(fh_ctx *c, const double *M, const double *j, const 
     if (result[1] == FIT_STATUS_BAD_P) return fail(FH_ERR_BAD_P, "Bad value in power spectrum after the update");
     return FH_OK;
 }
+
+#ifdef FIT_LOOP_TIMING
+// debug builds: cycles per phase of the fit_loop kernel accumulated since the context was created
+int fh_debug_loop_timing(fh_ctx *c, long long *out16) {
+    if (!c || !c->loop_timing.p) return FH_ERR_INVALID;
+    HIP_TRY(hipMemcpy(out16, c->loop_timing.p, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(c->loop_timing.p, 0, 16 * sizeof(long long)));
+    return FH_OK;
+}
+#endif
 
 // ---- RCCL -------------------------------------------------------------------------------------------------------------
 namespace {

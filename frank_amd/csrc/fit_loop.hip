@@ -22,6 +22,12 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#ifdef FIT_LOOP_TIMING
+#define TSTAMP(ph) do { if (threadIdx.x == 0) { long long now_ = clock64(); P.timing[ph] += now_ - t_last; t_last = now_; } } while (0)
+#else
+#define TSTAMP(ph) do { } while (0)
+#endif
+
 constexpr int KT = 1024;
 constexpr int NW = KT / 64;
 constexpr int PS = 17;  // LDS stride of the 16-wide panel rows (doubles)
@@ -107,6 +113,9 @@ __device__ bool solve_posterior(const FitLoopParams &P, const Smem &S) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = lane & 15, rg = lane >> 4;
     double *C = P.C, *W = P.W;
+#ifdef FIT_LOOP_TIMING
+    long long t_last = clock64();
+#endif
 
     // (1) C (lower triangle) = A + diag(1/p); padding rows/cols = identity
     for (int i = wave; i < NP; i += NW) {
@@ -120,6 +129,7 @@ __device__ bool solve_posterior(const FitLoopParams &P, const Smem &S) {
     }
     if (tid == 0) *S.flag = 0;
     __syncthreads();
+    TSTAMP(0);
 
     // (2) right-looking blocked Cholesky, 16-wide panels
     for (int k = 0; k < nb; ++k) {
@@ -128,6 +138,7 @@ __device__ bool solve_posterior(const FitLoopParams &P, const Smem &S) {
             if (!ok && lane == 0) *S.flag = 1;
         }
         __syncthreads();
+        TSTAMP(1);
         if (*S.flag) return false;
         const int r0 = 16 * (k + 1);
         // panel: row i solves x L_kk^T = C[i, 16k:16k+16]
@@ -151,6 +162,7 @@ __device__ bool solve_posterior(const FitLoopParams &P, const Smem &S) {
             }
         }
         __syncthreads();
+        TSTAMP(2);
         // trailing update C_IJ -= L_Ik L_Jk^T for k < J <= I (tiles dealt round-robin to the waves)
         int ctr = 0;
         for (int I = k + 1; I < nb; ++I) {
@@ -169,11 +181,13 @@ __device__ bool solve_posterior(const FitLoopParams &P, const Smem &S) {
             }
         }
         __syncthreads();
+        TSTAMP(3);
     }
 
     // (3) W_II = L_II^-1 for every diagonal tile
     for (int I = wave; I < nb; I += NW) invert_diag_tile(C, W, ld, I, lane, S.lw + wave * 16 * PS);
     __syncthreads();
+    TSTAMP(4);
 
     // (4) W_IJ = -W_II * sum_{K=J}^{I-1} L_IK W_KJ, block row by block row
     const int LS = NP + 1;  // LDS stride of the staged block row of L
@@ -184,6 +198,7 @@ __device__ bool solve_posterior(const FitLoopParams &P, const Smem &S) {
         }
         for (int e = tid; e < 256; e += KT) S.dl[(e >> 4) * PS + (e & 15)] = W[(size_t)(16 * I + (e >> 4)) * ld + 16 * I + (e & 15)];
         __syncthreads();
+        TSTAMP(5);
         for (int J = wave; J < I; J += NW) {
             v4f64 acc = {0.0, 0.0, 0.0, 0.0};
             for (int K = J; K < I; ++K) {
@@ -203,6 +218,7 @@ __device__ bool solve_posterior(const FitLoopParams &P, const Smem &S) {
             for (int r = 0; r < 4; ++r) wt[(size_t)(4 * r) * ld] = out[r];
         }
         __syncthreads();
+        TSTAMP(6);
     }
 
     // (5) y = W b
@@ -237,6 +253,7 @@ __device__ bool solve_posterior(const FitLoopParams &P, const Smem &S) {
         S.tr2[i] = S.red[NP + i] + S.red[3 * NP + i] + S.red[5 * NP + i];
     }
     __syncthreads();
+    TSTAMP(7);
     return true;
 }
 

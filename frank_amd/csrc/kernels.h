@@ -87,6 +87,7 @@ struct FitLoopParams {
     double *mu_out, *p_out; // N
     int *result;            // [0] count, [1] status
     double *diag_p, *diag_mu;
+    long long *timing;      // debug builds (FIT_LOOP_TIMING): cycles per phase
 };
 
 size_t fh_k2_loop_smem_bytes(int NP);

@@ -129,6 +129,16 @@ int fh_cho_solve(fh_ctx *ctx, const double *chol, double *B, int nrhs);
 int fh_fit_normal(fh_ctx *ctx, const double *M, const double *j, double alpha, double p0, double wsmooth,
                   double tol, int max_iter, double *mu, double *p, int *niter, double *diag_p, double *diag_mu);
 
+/* Pipelined form for independent fits (hyper-parameter sweeps, bootstraps, many sources -- fit.py:534-548,
+ * 770-782 call the fitter in a plain loop): fh_fit_submit enqueues the iteration of the context's device-resident
+ * M, j (from fh_stats_finalize) on one of the context's fit slots and returns at once; the fit_loop kernel occupies
+ * ONE compute unit, so the next fh_bin_visibilities overlaps with it.  fh_fit_collect waits for that fit and
+ * returns mu, p, niter exactly as fh_fit_normal does.  Tickets are collected in any order; at most
+ * fh_fit_slots() fits may be outstanding.                                                                     */
+int fh_fit_slots(void);
+int fh_fit_submit(fh_ctx *ctx, double alpha, double p0, double wsmooth, double tol, int max_iter, int *ticket);
+int fh_fit_collect(fh_ctx *ctx, int ticket, double *mu, double *p, int *niter);
+
 /* One pass of the loop body for a caller-supplied p: fit = GaussianModel(M, j, p); p_new =
  * CriticalFilter.update_power_spectrum(fit) (filter.py:154-177).  M, j, p host; mu (N, posterior mean for p) and
  * p_new (N) host outputs, either may be NULL.                                                                */

@@ -15,3 +15,12 @@ for name,N in (('sweep_N50_2e4.npz',50),('fit_N100_1e5.npz',100),('fit_N300_1e6.
     I=g['I_a'] if N==50 else g['I']; ni=int(g['niter_a'] if N==50 else g['niter'])
     nit=FF.iteration_diagnostics['num_iterations']
     print(N,'niter',nit,ni,'rel',np.abs(sol.I-I).max()/np.abs(I).max(),'time %.1f ms  %.1f us/iter'%(1e3*dt,1e6*dt/nit))
+
+if os.environ.get("FRANK_AMD_LIB"):
+    import ctypes
+    from frank_amd import _lib
+    out=(ctypes.c_longlong*16)()
+    _lib.lib.fh_debug_loop_timing(FF._DHT.context(), out)
+    names=['build C','diag factor','panel trsm','trailing','diag inverses','trtri stage','trtri compute','matvec']
+    tot=sum(out[:8])
+    for n_,v in zip(names,out[:8]): print('%-14s %8.1f us/iter  %5.1f%%'%(n_, v/2.1e3/ (2*nit+4) , 100*v/tot))
