@@ -169,6 +169,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
+    # Every outstanding fit_loop kernel lives on its own HIP stream; HIP multiplexes streams onto
+    # GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels sharing a queue serialise.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
     # load the HIP library BEFORE torch so that ROCm's own runtime libraries serve the process
     from frank_amd import _lib as L
     from frank_amd.mock import mock_disc_visibilities
@@ -259,7 +262,7 @@ def main():
                              "note": "steps are pipelined: fit i's iteration (one CU) overlaps fit i+1's binning"},
             "roofline": {"kernel": "bin_gram_kernel<19>", "bound": "mfma", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "kernel_ms": kms,
+                         "traffic": None, "kernel_ms": kms, "kernel_ms_per_step": [round(x, 2) for x in kernel_ms],
                          "algorithmic_flops_per_vis": Nc * (Nc + 1) + 2 * Nc,
                          "achieved_full_gram_equiv": flops_full / (kms * 1e-3) / 1e12,
                          "hbm_read_GBps": 40.0 * a.nvis / (kms * 1e-3) / 1e9 * (1.0 if Nc <= 207 else 2.0)},

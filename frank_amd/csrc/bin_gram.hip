@@ -1,29 +1,35 @@
-// K1 `bin_gram`: fused deprojection + Bessel design block + weighted Gram on gfx950.
+// K1 `bin_gram`: Bessel design block + weighted Gram on gfx950, after a deprojection pre-pass.
 //
 // Replaces the chunk loop of VisibilityMapping.map_visibilities (statistical_models.py:165-218),
 // with geometry.apply_correction (geometry.py:69-79, 111-131) and DHT.coefficients
-// (hankel.py:201-202) fused in.  Per visibility i the kernel forms the row
-//     Xt[i, k] = sqrt(w_i) J0((q_i / Qmax) j_k)  (k < N),   Xt[i, N] = sqrt(w_i) Re V'_i,   0 beyond,
-// and accumulates the symmetric Gram  G = Xt^T Xt  with v_mfma_f64_16x16x4_f64, so that
-//     M[k,l] = a_k a_l G[k,l],  j[k] = a_k G[k,N],  sum w V'^2 = G[N,N],   a_k = norm sf_k scale.
-// The DHT scaling a_k (~1e-14) is applied once afterwards in fp64 (finalize kernel), so the
-// Gram itself has O(1) entries.
+// (hankel.py:201-202) fused in.
 //
-// Work decomposition (DESIGN.md "K1"):
+//   K1a deproject_kernel   one thread per visibility (HBM-bound streaming pass, 40 B in / 24 B out):
+//                          phase-centre, deproject, q = hypot, and emit  s = q/Qmax, sqrt(w), sqrt(w) Re V';
+//                          per-block partial sums of log(w/2pi) and min/max q.
+//   K1b bin_gram_kernel    per visibility i form the row
+//                              Xt[i,k] = sqrt(w_i) J0(s_i j_k) (k < N),  Xt[i,N] = sqrt(w_i) Re V'_i,  0 beyond,
+//                          and accumulate the symmetric Gram G = Xt^T Xt with v_mfma_f64_16x16x4_f64, so that
+//                              M[k,l] = a_k a_l G[k,l],  j[k] = a_k G[k,N],  sum w V'^2 = G[N,N],  a_k = norm sf_k scale.
+// The DHT scaling a_k (~1e-14) is applied once afterwards in fp64 (finalize kernel): the Gram has O(1) entries.
+//
+// Work decomposition of K1b (DESIGN.md "K1"):
 //   * one 512-thread workgroup per CU = 8 waves, two per SIMD: while one wave of a SIMD waits on the
-//     matrix pipe the other issues the J0 polynomial work (VALU), and the two are started in
-//     opposite phase (waves 0-3 produce-then-consume, waves 4-7 consume-then-produce);
-//   * the upper triangle of the NBT x NBT grid of 16x16 output tiles (190 tiles at N = 300) is kept
-//     in accumulator registers for the whole visibility stream.  190 tiles x 8 registers do not fit
-//     one CU beside the J0 temporaries, so for NBT = 19 the triangle is cut row-aligned into two
-//     PARTS (tile rows 0-6: 112 tiles, rows 7-18: 78 tiles); the grid is split between the parts
-//     in proportion to their tile counts, and every part streams ALL visibilities.  A part only
-//     evaluates the J0 columns it needs (part 1: columns >= 112), so J0 is evaluated 1.68x;
-//   * visibilities are streamed in super-chunks of 512 (one thread deprojects one visibility) and
-//     chunks of 16 rows; a chunk's rows are written to LDS (double-buffered) by all eight waves and
-//     read back as MFMA fragments (the A-fragment of block I is the B-fragment of block I);
-//   * each workgroup writes its partial tiles once; a second kernel reduces the slabs in a fixed
-//     order (bitwise reproducible) and a third applies the DHT scaling and mirrors the triangle.
+//     matrix pipe the other issues the J0 polynomial work (VALU); waves 4-7 run half a chunk out of phase;
+//   * the upper triangle of the NBT x NBT grid of 16x16 output tiles (190 tiles at N = 300) stays in
+//     accumulator registers for the whole visibility stream.  190 tiles x 8 registers do not fit one CU
+//     beside the J0 temporaries, so for NBT = 19 the triangle is cut row-aligned into two PARTS (tile rows
+//     0-6: 112 tiles, rows 7-18: 78 tiles); the grid is split between the parts in proportion to their tile
+//     counts and every part streams ALL visibilities, evaluating only the J0 columns it needs (1.68x J0);
+//   * visibilities are streamed in super-chunks of 512 and chunks of 16 rows; a chunk's rows are written to
+//     LDS (double-buffered) by all eight waves and read back as MFMA fragments (the A-fragment of block I is
+//     the B-fragment of block I).  The loop is specialised per wave (static accumulator registers), with the J0
+//     evaluation rolled over the column groups so that a part's eight specialisations fit the I-cache;
+//   * super-chunks are handed out either statically (block b takes b, b+G, ...: bitwise reproducible, the
+//     default) or from an atomic counter (throughput mode, used while fit_loop kernels of earlier fits
+//     occupy CUs: a workgroup that starts late simply takes fewer super-chunks);
+//   * each workgroup writes its partial tiles once; a second kernel reduces the slabs in block order and a
+//     third applies the DHT scaling and mirrors the triangle.
 #include <hip/hip_runtime.h>
 
 #include <utility>
@@ -37,7 +43,7 @@ namespace {
 
 constexpr int kThreads = 512;
 constexpr int kWaves = 8;
-constexpr int kSuper = 512;  // visibilities per super-chunk (one per thread in the prologue)
+constexpr int kSuper = 512;  // visibilities per super-chunk (one LDS row of scalars per thread)
 constexpr int kChunk = 16;   // rows per LDS buffer = 4 MFMA k-steps; 2 rows produced per wave
 constexpr int kChunksPerSuper = kSuper / kChunk;
 
@@ -70,44 +76,71 @@ constexpr int part_row1(int NBT, int P) { return (NBT > 13 && P == 0) ? 7 : NBT;
 constexpr int part_tile0(int NBT, int P) { return row_first_tile(NBT, part_row0(NBT, P)); }
 constexpr int part_tile1(int NBT, int P) { return row_first_tile(NBT, part_row1(NBT, P)); }
 
-struct VisScalars {  // per-visibility results of the prologue, kept in LDS
-    double s;    // (1/Qmax) * q            -> x = s * j_k   (hankel.py:189,202)
-    double sw;   // sqrt(w)
-    double swV;  // sqrt(w) * Re V'
-};
-
+// ---- K1a ----------------------------------------------------------------------------------------------------
 // geometry.py:69-79 (inverse phase shift, NumPy's Smith complex division), :111-131 (deproject),
 // statistical_models.py:166 (hypot).  Every product/sum rounds separately, as the NumPy expressions do.
-__device__ __forceinline__ void deproject_one(const BinParams &p, int64_t i, VisScalars &out, double &logw,
-                                              double &q_out) {
+__global__ __launch_bounds__(256) void deproject_kernel(BinParams p) {
+    __shared__ double red[3 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double sum_logw = 0.0, qmin = INFINITY, qmax = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + tid; i < p.count; i += (int64_t)gridDim.x * blockDim.x) {
 #pragma clang fp contract(off)
-    const double u = p.u[i], v = p.v[i];
-    const double Vre = p.Vre[i];
-    const double Vim = p.Vim ? p.Vim[i] : 0.0;
-    const double w = p.w[p.w_scalar ? 0 : i];
-    const double phi = u * p.dRA + v * p.dDec;
-    double sn, cs;
-    sincos(phi, &sn, &cs);
-    double re;
-    if (fabs(cs) >= fabs(sn)) {
-        const double rat = sn / cs, scl = 1.0 / (cs + sn * rat);
-        re = (Vre + Vim * rat) * scl;
-    } else {
-        const double rat = cs / sn, scl = 1.0 / (sn + cs * rat);
-        re = (Vre * rat + Vim) * scl;
+        const int64_t g = p.first + i;
+        const double u = p.u[g], v = p.v[g];
+        const double Vre = p.Vre[g];
+        const double Vim = p.Vim ? p.Vim[g] : 0.0;
+        const double w = p.w[p.w_scalar ? 0 : g];
+        const double phi = u * p.dRA + v * p.dDec;
+        double sn, cs;
+        sincos(phi, &sn, &cs);
+        double re;
+        if (fabs(cs) >= fabs(sn)) {
+            const double rat = sn / cs, scl = 1.0 / (cs + sn * rat);
+            re = (Vre + Vim * rat) * scl;
+        } else {
+            const double rat = cs / sn, scl = 1.0 / (sn + cs * rat);
+            re = (Vre * rat + Vim) * scl;
+        }
+        double up = u * p.cos_t - v * p.sin_t;
+        const double vp = u * p.sin_t + v * p.cos_t;
+        up = up * p.cos_i;
+        const double q = hypot(up, vp);
+        const double sw = sqrt(w);
+        p.prep_s[i] = p.inv_Qmax * q;  // k * q, hankel.py:189,202
+        p.prep_sw[i] = sw;
+        p.prep_swV[i] = sw * re;
+        sum_logw += log(w / (2 * M_PI));  // statistical_models.py:218
+        qmin = fmin(qmin, q);
+        qmax = fmax(qmax, q);
     }
-    double up = u * p.cos_t - v * p.sin_t;
-    const double vp = u * p.sin_t + v * p.cos_t;
-    up = up * p.cos_i;
-    const double q = hypot(up, vp);
-    const double sw = sqrt(w);
-    out.s = p.inv_Qmax * q;
-    out.sw = sw;
-    out.swV = sw * re;
-    logw = log(w / (2 * M_PI));  // statistical_models.py:218
-    q_out = q;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        sum_logw += __shfl_down(sum_logw, off);
+        qmin = fmin(qmin, __shfl_down(qmin, off));
+        qmax = fmax(qmax, __shfl_down(qmax, off));
+    }
+    if (lane == 0) {
+        red[wave * 3 + 0] = sum_logw;
+        red[wave * 3 + 1] = qmin;
+        red[wave * 3 + 2] = qmax;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0, mn = INFINITY, mx = -INFINITY;
+        for (int w = 0; w < 4; ++w) {
+            s += red[w * 3 + 0];
+            mn = fmin(mn, red[w * 3 + 1]);
+            mx = fmax(mx, red[w * 3 + 2]);
+        }
+        double *ps = p.partial_scalars + (size_t)blockIdx.x * 4;
+        ps[0] = s;
+        ps[1] = mn;
+        ps[2] = mx;
+        ps[3] = 0.0;
+    }
 }
 
+// ---- K1b ----------------------------------------------------------------------------------------------------
 template <int NBT, int P, int W, int T>
 __device__ __forceinline__ void mfma_one(v4f64 &acc, const double (&f)[NBT]) {
     constexpr int tt = part_tile0(NBT, P) + W + T * kWaves;
@@ -126,166 +159,139 @@ __device__ __forceinline__ void wave_main(const BinParams &p, double *smem, int 
     constexpr int NC = NBT * 16;
     constexpr int XS = xstride(NBT);
     constexpr int T0 = part_tile0(NBT, P), T1 = part_tile1(NBT, P);
-    constexpr int NTP = T1 - T0;                             // tiles of this part
-    constexpr int TPW = (NTP - W + kWaves - 1) / kWaves;     // tiles of this wave: T0 + W, T0 + W + 8, ...
-    constexpr int B0 = part_row0(NBT, P);                    // first column block this part needs
-    constexpr int C0 = B0 * 16;                              // first column
-    constexpr int NCG = (NC - C0 + 63) / 64;                 // column groups of 64 lanes
+    constexpr int NTP = T1 - T0;                          // tiles of this part
+    constexpr int TPW = (NTP - W + kWaves - 1) / kWaves;  // tiles of this wave: T0 + W, T0 + W + 8, ...
+    constexpr int B0 = part_row0(NBT, P);                 // first column block this part needs
+    constexpr int C0 = B0 * 16;                           // first column
+    constexpr int NCG = (NC - C0 + 63) / 64;              // column groups of 64 lanes
+    constexpr bool kSkew = W >= 4;                        // second wave of each SIMD: half a chunk out of phase
     static_assert(TPW >= 1, "every wave owns at least one tile");
 
-    double *tab = smem;                                                                // FH_J0_TABLE_DOUBLES
-    VisScalars *vs = reinterpret_cast<VisScalars *>(tab + FH_J0_TABLE_DOUBLES);   // [2][kSuper]
-    double *X = reinterpret_cast<double *>(vs + 2 * kSuper);                           // [2][kChunk][XS]
-    double *red = X + 2 * kChunk * XS;                                                 // [3 * kWaves]
+    double *tab = smem;                                                      // FH_J0_TABLE_DOUBLES
+    double *vs_s = tab + FH_J0_TABLE_DOUBLES;                                // [2][kSuper] each
+    double *vs_sw = vs_s + 2 * kSuper;
+    double *vs_swV = vs_sw + 2 * kSuper;
+    double *X = vs_swV + 2 * kSuper;                                         // [2][kChunk][XS]
+    double *jkl = X + 2 * kChunk * XS;                                       // zeros j_k of columns C0.. (NCG*64)
+    int *scq = reinterpret_cast<int *>(jkl + NCG * 64);                      // [2] super-chunk queue
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int N = p.N;
+    const int kk = lane >> 4, ii = lane & 15;
+    const int nsup = (int)((p.count + kSuper - 1) / kSuper);
 
-    // zeros j_k of this lane's columns (col = C0 + cg*64 + lane); 0 beyond N so that J0 = 1 there
-    double jk[NCG];
-#pragma unroll
-    for (int cg = 0; cg < NCG; ++cg) {
-        const int col = C0 + cg * 64 + lane;
-        jk[cg] = col < N ? p.zeros[col] : 0.0;
-    }
+    for (int c = tid; c < NCG * 64; c += kThreads) jkl[c] = (C0 + c) < N ? p.zeros[C0 + c] : 0.0;  // J0(0) = 1 beyond N
 
     v4f64 acc[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
 
-    double sum_logw = 0.0, qmin = INFINITY, qmax = -INFINITY;
-
-    const int64_t nsuper = (p.count + kSuper - 1) / kSuper;
-    const int kk = lane >> 4, ii = lane & 15;
-
-    // ---- prologue of one super-chunk into vs[buf] -------------------------------------------------------
-    auto prologue = [&](int64_t sc, int buf) {
-        const int64_t i = sc * kSuper + tid;
-        VisScalars o;
-        if (sc < nsuper && i < p.count) {
-            double lw, q;
-            deproject_one(p, p.first + i, o, lw, q);
-            sum_logw += lw;
-            qmin = fmin(qmin, q);
-            qmax = fmax(qmax, q);
-        } else {
-            o.s = 0.0;
-            o.sw = 0.0;
-            o.swV = 0.0;  // padded rows contribute exactly zero
-        }
-        vs[buf * kSuper + tid] = o;
+    // ---- super-chunk hand-out: static stride (reproducible) or atomic counter (throughput mode) -------------
+    int *counter = p.work_counter ? p.work_counter + P : nullptr;
+    auto fetch = [&](int prev) -> int {  // thread 0 only
+        if (counter) return atomicAdd(counter, 1);
+        return prev < 0 ? part_block : prev + part_nblocks;
     };
-    // ---- one J0 row (this wave produces rows 2W, 2W+1 of every chunk) -------------------------------------
+    if (tid == 0) {
+        const int s0 = fetch(-1);
+        scq[0] = s0;
+        scq[1] = fetch(s0);
+    }
+    __syncthreads();
+    int cur = scq[0], nxt = scq[1];
+
+    // ---- scalars of one super-chunk into vs[buf] (coalesced copy of the K1a output) --------------------------
+    auto load_scalars = [&](int sc, int buf) {
+        const int64_t i = (int64_t)sc * kSuper + tid;
+        const bool ok = sc < nsup && i < p.count;
+        vs_s[buf * kSuper + tid] = ok ? p.prep_s[i] : 0.0;
+        vs_sw[buf * kSuper + tid] = ok ? p.prep_sw[i] : 0.0;   // padded rows contribute exactly zero
+        vs_swV[buf * kSuper + tid] = ok ? p.prep_swV[i] : 0.0;
+    };
+    // ---- one J0 row: this wave produces rows 2W, 2W+1 of every chunk, one 64-column group at a time -----------
     auto produce_row = [&](int sbuf, int ch, int xbuf, int rr) {
         const int row = W * 2 + rr;
-        const VisScalars o = vs[sbuf * kSuper + ch * kChunk + row];
-        double *xr = X + (xbuf * kChunk + row) * XS;
-#pragma unroll
+        const int vi = sbuf * kSuper + ch * kChunk + row;
+        const double s = vs_s[vi], sw = vs_sw[vi], swV = vs_swV[vi];
+        double *xr = X + (xbuf * kChunk + row) * XS + C0;
+#pragma unroll 1
         for (int cg = 0; cg < NCG; ++cg) {
-            const int col = C0 + cg * 64 + lane;
-            double x;
-            {
+            const int lc = cg * 64 + lane;  // column - C0
+            if ((NC - C0) % 64 == 0 || lc < NC - C0) {
+                double x;
+                {
 #pragma clang fp contract(off)
-                x = o.s * jk[cg];  // fl(fl(k*q) * j_k), hankel.py:202
+                    x = s * jkl[lc];  // fl(fl(k*q) * j_k), hankel.py:202
+                }
+                const double val = fh_j0(x, tab);
+                const int col = C0 + lc;
+                // columns < N: sqrt(w) J0;  column N: sqrt(w) Re V';  beyond: 0
+                xr[lc] = col < N ? val * sw : (col == N ? swV : 0.0);
             }
-            const double val = fh_j0(x, tab);
-            // columns < N: sqrt(w) J0;  column N: sqrt(w) Re V';  beyond: 0   (J0(0) = 1 there)
-            const double outv = col < N ? val * o.sw : (col == N ? o.swV : 0.0);
-            if ((NC - C0) % 64 == 0 || col < NC) xr[col] = outv;
-            // keep at most two evaluations in flight: bounds the live J0 temporaries beside the accumulators
-            if (cg % 2 == 1) __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    // ---- MFMAs of one k-step (4 rows) of X[xbuf] ---------------------------------------------------------
-    auto consume_kstep = [&](int xbuf, int ks) {
-        const double *xb = X + (xbuf * kChunk + ks * 4 + kk) * XS + ii;
-        double f[NBT];
+    // ---- MFMAs of two k-steps (8 rows) of X[xbuf] ---------------------------------------------------------
+    auto consume2 = [&](int xbuf, int ks0) {
 #pragma unroll
-        for (int b = 0; b < NBT; ++b) f[b] = b >= B0 ? xb[b * 16] : 0.0;
-        mfma_all<NBT, P, W, TPW>(acc, f, std::make_integer_sequence<int, TPW>{});
+        for (int ks = 0; ks < 2; ++ks) {
+            const double *xb = X + (xbuf * kChunk + (ks0 + ks) * 4 + kk) * XS + ii;
+            double f[NBT];
+#pragma unroll
+            for (int b = 0; b < NBT; ++b) f[b] = b >= B0 ? xb[b * 16] : 0.0;
+            mfma_all<NBT, P, W, TPW>(acc, f, std::make_integer_sequence<int, TPW>{});
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // ---- main loop over this workgroup's super-chunks ----------------------------------------------------
-    int64_t sc = part_block;
+    // ---- main loop --------------------------------------------------------------------------------------------
     int sbuf = 0, xbuf = 0;
-    if (sc < nsuper) {
-        prologue(sc, 0);
+    if (cur < nsup) {
+        load_scalars(cur, 0);
         __syncthreads();
         produce_row(0, 0, 0, 0);
         produce_row(0, 0, 0, 1);
         __syncthreads();
     }
-    for (; sc < nsuper; sc += part_nblocks) {
-        const int64_t sc_next = sc + part_nblocks;
-        // next super-chunk's scalars (other vs buffer); visible after the first barrier below
-        prologue(sc_next, sbuf ^ 1);
+    int qslot = 0;
+    while (cur < nsup) {
+        if (tid == 0) scq[qslot] = fetch(nxt);  // the super-chunk after next; read after this iteration's barriers
+        load_scalars(nxt, sbuf ^ 1);             // visible after the first barrier below
 #pragma unroll 1
         for (int ch = 0; ch < kChunksPerSuper; ++ch) {
             const bool last = (ch == kChunksPerSuper - 1);
-            const bool more = !last || sc_next < nsuper;
+            const bool more = !last || nxt < nsup;
             const int nsb = last ? (sbuf ^ 1) : sbuf;
             const int nch = last ? 0 : ch + 1;
-            // J0 rows of chunk c+1 (VALU) against the MFMAs of chunk c (matrix pipe); the two waves of a
-            // SIMD (W and W+4) run the two halves in opposite order.
-            if (W < 4) {
+            // J0 rows of chunk c+1 (VALU) against the MFMAs of chunk c (matrix pipe)
+            if (!kSkew) {
                 if (more) produce_row(nsb, nch, xbuf ^ 1, 0);
-                consume_kstep(xbuf, 0);
-                consume_kstep(xbuf, 1);
+                consume2(xbuf, 0);
                 if (more) produce_row(nsb, nch, xbuf ^ 1, 1);
-                consume_kstep(xbuf, 2);
-                consume_kstep(xbuf, 3);
+                consume2(xbuf, 2);
             } else {
-                consume_kstep(xbuf, 0);
-                consume_kstep(xbuf, 1);
+                consume2(xbuf, 0);
                 if (more) produce_row(nsb, nch, xbuf ^ 1, 0);
-                consume_kstep(xbuf, 2);
-                consume_kstep(xbuf, 3);
+                consume2(xbuf, 2);
                 if (more) produce_row(nsb, nch, xbuf ^ 1, 1);
             }
             __syncthreads();
             xbuf ^= 1;
         }
         sbuf ^= 1;
+        cur = nxt;
+        nxt = scq[qslot];
+        qslot ^= 1;
     }
 
-    // ---- write this workgroup's partial tiles: slab[part_block][tile - T0][reg][lane] ----------------------
+    // ---- write this workgroup's partial tiles: slab[part_block][tile - T0][reg][lane] --------------------------
     double *slab = p.partials[P] + (size_t)part_block * NTP * 256;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int tl = W + t * kWaves;
 #pragma unroll
         for (int r = 0; r < 4; ++r) slab[(size_t)tl * 256 + r * 64 + lane] = acc[t][r];
-    }
-    // ---- block reduction of the scalar statistics (part 0 only; fixed order) -------------------------------
-    if (P == 0) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            sum_logw += __shfl_down(sum_logw, off);
-            qmin = fmin(qmin, __shfl_down(qmin, off));
-            qmax = fmax(qmax, __shfl_down(qmax, off));
-        }
-        if (lane == 0) {
-            red[W * 3 + 0] = sum_logw;
-            red[W * 3 + 1] = qmin;
-            red[W * 3 + 2] = qmax;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            double s = 0, mn = INFINITY, mx = -INFINITY;
-            for (int w = 0; w < kWaves; ++w) {
-                s += red[w * 3 + 0];
-                mn = fmin(mn, red[w * 3 + 1]);
-                mx = fmax(mx, red[w * 3 + 2]);
-            }
-            double *ps = p.partial_scalars + (size_t)part_block * 4;
-            ps[0] = s;
-            ps[1] = mn;
-            ps[2] = mx;
-            ps[3] = 0.0;
-        }
     }
 }
 
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(kThreads, 2) void bin_gram_kernel(BinParams p) {
 
 template <int NBT>
 constexpr size_t bin_smem_bytes() {
-    return sizeof(double) * (FH_J0_TABLE_DOUBLES + 2 * kSuper * 3 + 2 * kChunk * xstride(NBT) + 3 * kWaves);
+    return sizeof(double) * (FH_J0_TABLE_DOUBLES + 3 * 2 * kSuper + 2 * kChunk * xstride(NBT) + ((NBT * 16 + 63) / 64) * 64 + 2);
 }
 
 // Sum the per-workgroup slabs of every part in block order and add into the running statistics.
@@ -337,7 +343,7 @@ __global__ void reduce_partials_kernel(ReduceParams rp, double *stats_sum, doubl
     }
     if (e == 0) {
         double s = 0.0, mn = INFINITY, mx = -INFINITY;
-        for (int b = 0; b < rp.part_blocks[0]; ++b) {
+        for (int b = 0; b < rp.scalar_blocks; ++b) {
             s += rp.partial_scalars[b * 4 + 0];
             mn = fmin(mn, rp.partial_scalars[b * 4 + 1]);
             mx = fmax(mx, rp.partial_scalars[b * 4 + 2]);
@@ -447,6 +453,11 @@ static hipError_t launch_bin(const BinParams &p, hipStream_t stream) {
     }
     const int grid = p.part_blocks[0] + (nparts(NBT) > 1 ? p.part_blocks[1] : 0);
     hipLaunchKernelGGL(bin_gram_kernel<NBT>, dim3(grid), dim3(kThreads), smem, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t fh_k1_launch_deproject(const BinParams &p, int blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(deproject_kernel, dim3(blocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

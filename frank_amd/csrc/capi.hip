@@ -91,7 +91,9 @@ struct fh_ctx {
     DevBuf<double> zeros, j0_table, Y, Ykm, q, pref_fwd, pref_bwd;
     // K1
     int part_blocks[2] = {0, 0};
-    DevBuf<double> partials[2], partial_scalars, stats_sum, stats_minmax, a_scale, sumwV2;
+    DevBuf<double> partials[2], partial_scalars, stats_sum, stats_minmax, a_scale, sumwV2, prep;
+    DevBuf<int> work_counter;
+    int deproject_blocks = 0;
     // normal equations + K2 work
     DevBuf<double> M, j, W, D, Z, p, p_old, mu, band_lu, diag_p, diag_mu;
     DevBuf<int> flags, info;
@@ -228,7 +230,9 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
         }
         for (int P = 0; P < c->nparts; ++P)
             HIP_TRY(c->partials[P].alloc((size_t)c->part_blocks[P] * fh_k1_part_ntiles(c->NBT, P) * 256));
-        HIP_TRY(c->partial_scalars.alloc((size_t)c->part_blocks[0] * 4));
+        c->deproject_blocks = 8 * G;
+        HIP_TRY(c->partial_scalars.alloc((size_t)c->deproject_blocks * 4));
+        HIP_TRY(c->work_counter.alloc(2));
         HIP_TRY(c->stats_sum.alloc((size_t)c->ntiles * 256 + 2));
         HIP_TRY(c->stats_minmax.alloc(2));
         HIP_TRY(c->a_scale.alloc(N));
@@ -268,8 +272,8 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
         HIP_TRY(c->Aq.alloc(PP));
         HIP_TRY(c->Cq.alloc(PP));
         HIP_TRY(c->Wq.alloc(PP));
-        HIP_TRY(hipMemset(c->Cq.p, 0, sizeof(double) * PP));
-        HIP_TRY(hipMemset(c->Wq.p, 0, sizeof(double) * PP));
+        HIP_TRY(hipMemsetAsync(c->Cq.p, 0, sizeof(double) * PP, c->stream));
+        HIP_TRY(hipMemsetAsync(c->Wq.p, 0, sizeof(double) * PP, c->stream));
         HIP_TRY(c->bq.alloc(N));
         HIP_TRY(c->mu_out.alloc(N));
         HIP_TRY(c->p_out.alloc(N));
@@ -433,6 +437,17 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     p.zeros = c->zeros.p;
     p.j0_table = c->j0_table.p;
     const int64_t nsuper = (count + fh_k1_super() - 1) / fh_k1_super();
+    if (nsuper > 0x7fffffff / 2) return fail(FH_ERR_UNSUPPORTED, "more than 2^39 visibilities in one call");
+    // K1a scratch: 24 B per visibility
+    const size_t need = (size_t)(count > 0 ? count : 1) * 3;
+    if (c->prep.n < need) HIP_TRY(c->prep.alloc(need));
+    p.prep_s = c->prep.p;
+    p.prep_sw = c->prep.p + (count > 0 ? count : 1);
+    p.prep_swV = c->prep.p + 2 * (size_t)(count > 0 ? count : 1);
+    // throughput mode while fit_loop kernels of earlier fits hold CUs (see bin_gram.hip)
+    const bool dynamic = c->slots_busy > 0;
+    p.work_counter = dynamic ? c->work_counter.p : nullptr;
+    if (dynamic) HIP_TRY(hipMemsetAsync(c->work_counter.p, 0, 2 * sizeof(int), c->stream));
     ReduceParams rp{};
     rp.nparts = c->nparts;
     rp.ntiles = c->ntiles;
@@ -453,6 +468,11 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     }
     p.partial_scalars = c->partial_scalars.p;
     rp.partial_scalars = c->partial_scalars.p;
+    int dblocks = (int)((count + 255) / 256);
+    if (dblocks > c->deproject_blocks) dblocks = c->deproject_blocks;
+    if (dblocks < 1) dblocks = 1;
+    rp.scalar_blocks = dblocks;
+    HIP_TRY(fh_k1_launch_deproject(p, dblocks, c->stream));
     HIP_TRY(hipEventRecord(c->ev_bin0, c->stream));
     HIP_TRY(fh_k1_launch_bin(c->NBT, p, c->stream));
     HIP_TRY(hipEventRecord(c->ev_bin1, c->stream));
@@ -961,8 +981,9 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
         HIP_TRY(s.Aq.alloc(PP));
         HIP_TRY(s.Cq.alloc(PP));
         HIP_TRY(s.Wq.alloc(PP));
-        HIP_TRY(hipMemset(s.Cq.p, 0, sizeof(double) * PP));
-        HIP_TRY(hipMemset(s.Wq.p, 0, sizeof(double) * PP));
+        // stream-ordered (a null-stream memset is NOT ordered against the non-blocking slot streams)
+        HIP_TRY(hipMemsetAsync(s.Cq.p, 0, sizeof(double) * PP, c->stream));
+        HIP_TRY(hipMemsetAsync(s.Wq.p, 0, sizeof(double) * PP, c->stream));
         HIP_TRY(s.bq.alloc(N));
         HIP_TRY(s.mu_out.alloc(N));
         HIP_TRY(s.p_out.alloc(N));

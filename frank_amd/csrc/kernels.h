@@ -16,14 +16,18 @@ struct BinParams {
     const double *zeros;    // j_k, N entries (device)
     const double *j0_table; // FH_J0_TAYLOR (device)
     // outputs
+    // K1a output (device, `count` entries each): s = q/Qmax, sqrt(w), sqrt(w) Re V'
+    double *prep_s, *prep_sw, *prep_swV;
+    // throughput mode: two ints (one per part) handing out super-chunks; NULL = static, reproducible split
+    int *work_counter;
     // grid split between the tile parts (bin_gram.hip): part_blocks[0] + part_blocks[1] workgroups
     int part_blocks[2];
     double *partials[2];     // per part: [part_blocks][part_ntiles][256]
-    double *partial_scalars; // [part_blocks[0]][4]  (sum log(w/2pi), qmin, qmax, -)
+    double *partial_scalars; // [deproject blocks][4]  (sum log(w/2pi), qmin, qmax, -)
 };
 
 struct ReduceParams {
-    int nparts, ntiles;
+    int nparts, ntiles, scalar_blocks;
     int part_blocks[2], part_tile0[2], part_ntiles[2];
     const double *partials[2];
     const double *partial_scalars;
@@ -35,6 +39,7 @@ int fh_k1_nparts(int NBT);
 int fh_k1_part_tile0(int NBT, int P);
 int fh_k1_part_ntiles(int NBT, int P);
 int fh_k1_super();
+hipError_t fh_k1_launch_deproject(const BinParams &p, int blocks, hipStream_t stream);
 hipError_t fh_k1_launch_bin(int NBT, const BinParams &p, hipStream_t stream);
 hipError_t fh_k1_launch_reduce(const ReduceParams &rp, double *stats_sum, double *stats_minmax, hipStream_t stream);
 hipError_t fh_k1_launch_finalize(const double *stats_sum, int NBT, int N, const double *a, double *M, double *j,
