@@ -216,28 +216,26 @@ def main():
         # BASELINE configs[3]: ONE fit whose visibilities are sharded over the ranks; RCCL all-reduce of the packed
         # upper-triangle Gram + scalars, then every rank holds M, j (rank 0's solve is the fit).
         import torch
-        ident = bytearray(128)
-        if rank == 0:
-            buf = ctypes.create_string_buffer(128)
-            L.check(L.lib.fh_comm_unique_id(buf))
-            ident[:] = buf.raw
-        tid = torch.tensor(list(ident), dtype=torch.uint8)
-        dist.broadcast(tid, 0)
-        comm = ctypes.c_void_p()
-        L.check(L.lib.fh_comm_create(bytes(tid.tolist()), rank, world, local_rank, ctypes.byref(comm)))
+        from frank_amd.distributed import RcclComm
+
+        def bcast(ident):
+            t = torch.tensor(list(ident if ident is not None else bytes(128)), dtype=torch.uint8)
+            dist.broadcast(t, 0)
+            return bytes(t.tolist())
+        comm = RcclComm(rank, world, local_rank, bcast)
         times = []
         for i in range(3):
             barrier()
             t0 = time.perf_counter()
             f.bin()
-            L.check(L.lib.fh_comm_allreduce_stats(comm, f.ctx))
+            comm.allreduce_stats(f.ctx)
             nit_s = f.solve()
             f.sync()
             barrier()
             times.append(time.perf_counter() - t0)
         sharded = {"nvis_total": a.nvis * world, "s_per_fit": min(times), "iterations": nit_s,
                    "collective": "RCCL all-reduce, %d doubles" % (190 * 256 + 2 if a.ncoll > 207 else 0)}
-        L.lib.fh_comm_destroy(comm)
+        comm.close()
 
     if rank == 0:
         fits = a.steps * world

@@ -1,0 +1,60 @@
+"""Multi-GPU helpers: the visibility axis shards, the (N x N + N) sufficient statistics all-reduce.
+
+M, j and H0 are plain sums over visibilities (statistical_models.py:210-211, 218) and the q-range check
+needs min / max (statistical_models.py:512-535), so rank r bins rows shard_range(n, r, world) and one
+all-reduce finishes the mapping.  On GPUs the payload is the packed upper-triangle Gram held by the
+context (fh_comm_allreduce_stats, RCCL over xGMI); `allreduce_mapping` is the same reduction on host
+arrays through any torch.distributed backend (gloo in the CPU tests).
+"""
+import numpy as np
+
+
+def shard_range(n, rank, world):
+    """Contiguous, near-equal slab [first, first + count) of n rows for `rank` of `world`."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank / world")
+    base, rem = divmod(int(n), int(world))
+    first = rank * base + min(rank, rem)
+    count = base + (1 if rank < rem else 0)
+    return first, count
+
+
+def allreduce_mapping(M, j, H0, qmin, qmax, group=None):
+    """Sum M, j, H0 and min/max the baseline range over the ranks of a torch.distributed group (in place safe)."""
+    import torch
+    import torch.distributed as dist
+    N = j.shape[0]
+    buf = torch.from_numpy(np.concatenate([np.asarray(M, dtype=np.float64).reshape(-1),
+                                           np.asarray(j, dtype=np.float64), [float(H0)]]))
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    # one max-reduce serves both ends of the range: (-qmin, qmax)
+    mm = torch.tensor([-float(qmin), float(qmax)], dtype=torch.float64)
+    dist.all_reduce(mm, op=dist.ReduceOp.MAX, group=group)
+    out = buf.numpy()
+    return out[:N * N].reshape(N, N).copy(), out[N * N:N * N + N].copy(), float(out[-1]), -float(mm[0]), float(mm[1])
+
+
+class RcclComm:
+    """RCCL communicator for the device-resident statistics (one rank per GPU)."""
+
+    def __init__(self, rank, world, device, broadcast_bytes):
+        """`broadcast_bytes(b: bytes | None) -> bytes` ships rank 0's 128-byte unique id to every rank."""
+        import ctypes
+        from frank_amd import _lib
+        self._lib = _lib
+        ident = None
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            _lib.check(_lib.lib.fh_comm_unique_id(buf))
+            ident = buf.raw
+        ident = broadcast_bytes(ident)
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.lib.fh_comm_create(ident, rank, world, device, ctypes.byref(self.handle)))
+
+    def allreduce_stats(self, ctx):
+        self._lib.check(self._lib.lib.fh_comm_allreduce_stats(self.handle, ctx))
+
+    def close(self):
+        if self.handle:
+            self._lib.lib.fh_comm_destroy(self.handle)
+            self.handle = None

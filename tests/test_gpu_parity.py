@@ -278,3 +278,64 @@ def test_linearity_and_permutation_1e6():
     # run-to-run bitwise reproducibility (fixed-order slab reduction)
     again = FB.preprocess_visibilities(u, v, V, w)
     assert np.array_equal(again["M"], full["M"]) and np.array_equal(again["j"], full["j"])
+
+
+def test_rccl_allreduce_single_rank():
+    """The RCCL path of the sharded mapping (fh_comm_*): with one rank the all-reduce must be the identity."""
+    import ctypes
+    from frank_amd import _lib, FourierBesselFitter
+    from frank_amd.distributed import RcclComm
+    u, v, V, w = mock_disc_visibilities(5000, seed=41, noise_seed=42)
+    FB = FourierBesselFitter(2.0, 40, geom(), verbose=False)
+    ref = FB.preprocess_visibilities(u, v, V, w)
+    ctx = FB._DHT.context()
+    vis = ctypes.c_void_p()
+    Vre, Vim = np.ascontiguousarray(V.real), np.ascontiguousarray(V.imag)
+    _lib.check(_lib.lib.fh_vis_upload(0, _lib.ptr(u), _lib.ptr(v), _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), w.size,
+                                      u.size, ctypes.byref(vis)))
+    g = _lib.make_geometry(geom())
+    comm = RcclComm(0, 1, 0, lambda ident: ident)
+    _lib.check(_lib.lib.fh_bin_reset(ctx))
+    _lib.check(_lib.lib.fh_bin_visibilities(ctx, ctypes.byref(g), vis, 0, u.size))
+    comm.allreduce_stats(ctx)
+    M, j = np.empty((40, 40)), np.empty(40)
+    H0, qmn, qmx = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    _lib.check(_lib.lib.fh_stats_finalize(ctx, ctypes.byref(g), 0, 0, _lib.ptr(M), _lib.ptr(j), ctypes.byref(H0),
+                                          ctypes.byref(qmn), ctypes.byref(qmx)))
+    comm.close()
+    _lib.lib.fh_vis_destroy(vis)
+    assert np.array_equal(M, ref["M"]) and np.array_equal(j, ref["j"]) and H0.value == ref["null_likelihood"]
+
+
+def test_pipelined_fits_match_synchronous(golden):
+    """fh_fit_submit / fh_fit_collect (fit_loop kernels on their own streams) == fh_fit_normal."""
+    import ctypes
+    from frank_amd import _lib, FrankFitter
+    g = golden("sweep_N50_2e4.npz")
+    u, v, V, w = mock_disc_visibilities(int(g["n"]), seed=int(g["seed"]), noise_seed=int(g["noise_seed"]))
+    FF = FrankFitter(2.0, 50, geom(), verbose=False)
+    sol = FF.fit(u, v, V, w)
+    ctx = FF._DHT.context()
+    vis = ctypes.c_void_p()
+    Vre, Vim = np.ascontiguousarray(V.real), np.ascontiguousarray(V.imag)
+    _lib.check(_lib.lib.fh_vis_upload(0, _lib.ptr(u), _lib.ptr(v), _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), w.size,
+                                      u.size, ctypes.byref(vis)))
+    gm = _lib.make_geometry(geom())
+    tickets = []
+    for _ in range(3):
+        _lib.check(_lib.lib.fh_bin_reset(ctx))
+        _lib.check(_lib.lib.fh_bin_visibilities(ctx, ctypes.byref(gm), vis, 0, u.size))
+        H0, a, b = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(_lib.lib.fh_stats_finalize(ctx, ctypes.byref(gm), 0, 1, None, None, ctypes.byref(H0),
+                                              ctypes.byref(a), ctypes.byref(b)))
+        t = ctypes.c_int(-1)
+        _lib.check(_lib.lib.fh_fit_submit(ctx, 1.05, 1e-15, 1e-4, 1e-3, 2000, ctypes.byref(t)))
+        tickets.append(t.value)
+    assert len(set(tickets)) == 3
+    for t in tickets:
+        mu, p, n = np.empty(50), np.empty(50), ctypes.c_int()
+        _lib.check(_lib.lib.fh_fit_collect(ctx, t, _lib.ptr(mu), _lib.ptr(p), ctypes.byref(n)))
+        assert n.value == int(g["niter_a"])
+        assert rel_to_max(mu, sol.I) < 1e-9      # throughput-mode binning may order the partial sums differently
+        assert rel_to_max(mu, g["I_a"]) < 1e-6
+    _lib.lib.fh_vis_destroy(vis)
