@@ -76,7 +76,7 @@ struct fh_vis {
 struct FitSlot {
     hipStream_t stream = nullptr;
     hipEvent_t ready = nullptr;
-    DevBuf<double> Aq, bq, Cq, Wq, mu_out, p_out, band_lu;
+    DevBuf<double> Aq, bq, Cq, Wq, Tq, WdT, cs, mu_out, p_out, band_lu;
     DevBuf<int> result;
     bool busy = false;
 };
@@ -100,7 +100,7 @@ struct fh_ctx {
     // K2 v2 (fit_loop): q-space operands and work buffers
     int NP = 0;
     bool use_rocsolver_loop = false;
-    DevBuf<double> Yinv, T1, Araw, Aq, bq, Cq, Wq, mu_out, p_out, p_init;
+    DevBuf<double> Yinv, T1, Araw, Aq, bq, Cq, Wq, Tq, WdT, cs, mu_out, p_out, p_init;
     DevBuf<int> loop_result;
     DevBuf<long long> loop_timing;  // FIT_LOOP_TIMING debug builds only
     FitSlot slots[kFitSlots];
@@ -254,7 +254,7 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     HIP_TRY(hipMemset(c->flags.p, 0, sizeof(int) * FIT_NFLAGS));
     // K2 v2: Y^-1 (cond(Y) ~ 1e2), q-space work buffers
     {
-        c->NP = 16 * ((N + 15) / 16);
+        c->NP = 16 * ((N + 1 + 15) / 16);  // at least one padding row: row N carries b (fit_loop.hip)
         const size_t PP = (size_t)c->NP * c->NP;
         // Y^-1 by LU on the device (in place; the inverse of the column-major view is the row-major inverse)
         DevBuf<rocblas_int> ipiv;
@@ -272,6 +272,9 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
         HIP_TRY(c->Aq.alloc(PP));
         HIP_TRY(c->Cq.alloc(PP));
         HIP_TRY(c->Wq.alloc(PP));
+        HIP_TRY(c->Tq.alloc(PP));
+        HIP_TRY(c->WdT.alloc((size_t)c->NP * 16));
+        HIP_TRY(c->cs.alloc((size_t)(c->NP / 16) * (c->NP / 16) * 16));
         HIP_TRY(hipMemsetAsync(c->Cq.p, 0, sizeof(double) * PP, c->stream));
         HIP_TRY(hipMemsetAsync(c->Wq.p, 0, sizeof(double) * PP, c->stream));
         HIP_TRY(c->bq.alloc(N));
@@ -838,9 +841,9 @@ static int prepare_qspace(fh_ctx *c, double *Aq, double *bq) {
     // Araw = Yinv^T T1 (row-major) == column-major T1_buf * Yinv_buf^T
     ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, N, N, N, &one, c->T1.p, N,
                           c->Yinv.p, N, &zero, c->Araw.p, N));
-    HIP_TRY(fh_k2_launch_symmetrize(c->Araw.p, N, c->NP, Aq, c->stream));
     // b = Yinv^T j: the column-major view of the row-major Yinv buffer is Yinv^T
     ROC_TRY(rocblas_dgemv(c->blas, rocblas_operation_none, N, N, &one, c->Yinv.p, N, c->j.p, 1, &zero, bq, 1));
+    HIP_TRY(fh_k2_launch_symmetrize(c->Araw.p, bq, N, c->NP, Aq, c->stream));
     return FH_OK;
 }
 
@@ -864,6 +867,9 @@ static FitLoopParams make_loop_params(fh_ctx *c, int mode, double alpha, double 
     P.p_init = nullptr;
     P.C = c->Cq.p;
     P.W = c->Wq.p;
+    P.T = c->Tq.p;
+    P.WdT = c->WdT.p;
+    P.cs = c->cs.p;
     P.mu_out = c->mu_out.p;
     P.p_out = c->p_out.p;
     P.result = c->loop_result.p;
@@ -981,6 +987,9 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
         HIP_TRY(s.Aq.alloc(PP));
         HIP_TRY(s.Cq.alloc(PP));
         HIP_TRY(s.Wq.alloc(PP));
+        HIP_TRY(s.Tq.alloc(PP));
+        HIP_TRY(s.WdT.alloc((size_t)c->NP * 16));
+        HIP_TRY(s.cs.alloc((size_t)(c->NP / 16) * (c->NP / 16) * 16));
         // stream-ordered (a null-stream memset is NOT ordered against the non-blocking slot streams)
         HIP_TRY(hipMemsetAsync(s.Cq.p, 0, sizeof(double) * PP, c->stream));
         HIP_TRY(hipMemsetAsync(s.Wq.p, 0, sizeof(double) * PP, c->stream));
@@ -1004,6 +1013,9 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
     P.band_lu = s.band_lu.p;
     P.C = s.Cq.p;
     P.W = s.Wq.p;
+    P.T = s.Tq.p;
+    P.WdT = s.WdT.p;
+    P.cs = s.cs.p;
     P.mu_out = s.mu_out.p;
     P.p_out = s.p_out.p;
     P.result = s.result.p;

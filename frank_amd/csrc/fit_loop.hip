@@ -27,10 +27,30 @@ namespace {
 #else
 #define TSTAMP(ph) do { } while (0)
 #endif
+#ifdef FIT_LOOP_TIMING
+#define FSTAMP(slot) do { if (threadIdx.x == 0) { long long n2_ = clock64(); P.timing[slot] += n2_ - f_last; f_last = n2_; } } while (0)
+#else
+#define FSTAMP(slot) do { } while (0)
+#endif
+#ifdef FIT_LOOP_TIMING
+#define ISTAMP(ph) do { if (threadIdx.x == 0) { long long now_ = clock64(); timing[ph] += now_ - t_last; t_last = now_; } } while (0)
+#else
+#define ISTAMP(ph) do { } while (0)
+#endif
+#ifdef FIT_LOOP_TIMING
+#define WSTAMP(slot) do { if (threadIdx.x == 64) { long long n2_ = clock64(); P.timing[slot] += n2_ - w_last; w_last = n2_; } } while (0)
+#else
+#define WSTAMP(slot) do { } while (0)
+#endif
 
-constexpr int KT = 1024;
+#ifndef FIT_LOOP_THREADS
+#define FIT_LOOP_THREADS 512
+#endif
+constexpr int KT = FIT_LOOP_THREADS;
 constexpr int NW = KT / 64;
+constexpr int NWK = NW - NW / 4;  // trailing-update workers: the waves that do not share wave 0's SIMD
 constexpr int PS = 17;  // LDS stride of the 16-wide panel rows (doubles)
+constexpr int PF = 2;   // operand prefetch depth (tile products) in the block-inverse phases
 
 __device__ __forceinline__ double bcast(double v, int lane) {  // wave-uniform broadcast of lane `lane`'s value
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -42,25 +62,45 @@ struct Smem {
     double *pan;   // panel / block-row staging, max(NP*PS, 16*(NP+1)) doubles
     double *lw;    // NW x 16 x PS: per-wave scratch for the diagonal-tile inverses
     double *dl;    // 16 x PS: factor of the current diagonal tile (+ reciprocal diagonal in column 16)
-    double *p, *pold, *m, *y, *tr2, *rhs, *b, *red;  // NP each (red: 3*NP scratch)
+    double *dli;   // 16 x PS: its inverse (A operand of the MFMA panel solve)
+    double *p, *pold, *m, *y, *tr2, *rhs, *b, *red;  // NP each (red: 6*NP scratch)
+    int *lst;      // tile list of the current trailing update (<= 171 entries)
     int *flag;
 };
 
-// ---- Cholesky of the 16x16 diagonal tile k by ONE wave: lane r (< 16) holds row r ---------------------------------
-__device__ __forceinline__ bool factor_diag_tile(double *C, int ld, int k, double *dl, int lane) {
+// v_rsq_f64 + one cubically convergent correction: < 1 ulp, no division, no sqrt call on the serial path
+__device__ __forceinline__ double rsqrt_f64(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
+}
+
+// ---- Cholesky of a 16x16 diagonal tile by ONE wave: every 16-lane group holds the tile, lane&15 = row -----------
+// `tile` points at element [0][0] (row stride `ts`; global A/C or the LDS copy made by the look-ahead);
+// `pdiag` (or NULL) is added to the diagonal (first touch of A).  force_c >= 0: pivot of that local column is taken
+// as 1 (the augmented row that carries b, see solve_posterior).  Writes L to Cout (global) and dl (+ 1/diag in col 16).
+__device__ __forceinline__ bool factor_diag_tile(const double *tile, int ts, const double *pdiag, int force_c,
+                                                 double *Cout, int ld, double *dl, int lane) {
     double t[16];
     const int r = lane & 15;
-    const double *src = C + (size_t)(16 * k + r) * ld + 16 * k;
+    const double *sp = tile + (size_t)r * ts;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) t[c] = (lane < 16 && c <= r) ? src[c] : 0.0;
+    for (int c = 0; c < 16; ++c) t[c] = (c <= r) ? sp[c] : 0.0;
+    if (pdiag) {
+        const double pv = pdiag[r];
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c == r) t[c] += pv;
+    }
     bool ok = true;
+    double dinv_mine = 0.0;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        const double d2 = bcast(t[c], c);
+        const double d2 = (c == force_c) ? 1.0 : bcast(t[c], c);
         ok = ok && (d2 > 0.0);
-        const double d = sqrt(d2);
-        const double dinv = 1.0 / d;
-        t[c] = (r == c) ? d : t[c] * dinv;  // rows r > c: L[r][c]; (rows < c hold zeros)
+        const double dinv = rsqrt_f64(d2);
+        t[c] = (r == c) ? d2 * dinv : t[c] * dinv;  // rows r > c: L[r][c]; (rows < c hold zeros)
+        if (r == c) dinv_mine = dinv;
         if (c < 15) {
 #pragma unroll
             for (int c2 = c + 1; c2 < 16; ++c2) {
@@ -68,189 +108,341 @@ __device__ __forceinline__ bool factor_diag_tile(double *C, int ld, int k, doubl
                 t[c2] = fma(-t[c], s, t[c2]);      // only rows r >= c2 matter
             }
         }
-        if (r == c) dl[r * PS + 16] = dinv;
     }
     if (lane < 16) {
-        double *dst = C + (size_t)(16 * k + r) * ld + 16 * k;
+        double *dst = Cout + (size_t)r * ld;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const double v = c <= r ? t[c] : 0.0;
             dl[r * PS + c] = v;
             if (c <= r) dst[c] = v;
         }
+        dl[r * PS + 16] = dinv_mine;
     }
     return ok;
 }
 
-// ---- inverse of the 16x16 lower-triangular diagonal tile I of C into W, by one wave: lane c holds column c --------
-// L_II is staged in this wave's LDS scratch `lw` (16 x PS) and read back with wave-uniform (broadcast) addresses.
-__device__ __forceinline__ void invert_diag_tile(const double *C, double *W, int ld, int I, int lane, double *lw) {
+// ---- inverse of the diagonal tile just factored (its L is in dl): W_kk = L_kk^-1 -> dli (LDS), W, WdT ----------------
+// One wave; lane c holds column c of the inverse; L is read from dl with wave-uniform (broadcast) addresses.
+__device__ __forceinline__ void invert_factored_tile(const double *dl, double *dli, double *W, double *WdT, int ld,
+                                                     int k, int lane, double *cs_kk, int rows_valid) {
     const int c = lane & 15;
-    if (lane < 16) {
-        const double *src = C + (size_t)(16 * I + c) * ld + 16 * I;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) lw[c * PS + s] = (s <= c) ? src[s] : 0.0;
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are done (single-wave hand-off)
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): dl was written by this wave
     __builtin_amdgcn_wave_barrier();
     double x[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         double a = (r == c) ? 1.0 : 0.0;
 #pragma unroll
-        for (int s = 0; s < r; ++s) a = fma(-lw[r * PS + s], x[s], a);  // L[r][s] * X[s][c]
-        x[r] = a / lw[r * PS + r];
+        for (int s = 0; s < r; ++s) a = fma(-dl[r * PS + s], x[s], a);  // L[r][s] * X[s][c]
+        x[r] = a * dl[r * PS + 16];                                     // * 1/L[r][r]
     }
     if (lane < 16) {
+        double *wt = WdT + (size_t)k * 256 + c * 16;  // WdT[k][c][r] = W_kk[r][c]
+        double ssq = 0.0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) W[(size_t)(16 * I + r) * ld + 16 * I + c] = (r >= c) ? x[r] : 0.0;
+        for (int r = 0; r < 16; ++r) {
+            const double v = (r >= c) ? x[r] : 0.0;
+            dli[r * PS + c] = v;
+            W[(size_t)(16 * k + r) * ld + 16 * k + c] = v;
+            wt[r] = v;
+            if (r < rows_valid) ssq = fma(v, v, ssq);
+        }
+        cs_kk[c] = ssq;  // column sums of squares of the diagonal tile (rows of the real system only)
     }
 }
 
+// Fragment loaders (v_mfma_f64_16x16x4_f64: lane = (cl = lane & 15, rg = lane >> 4), k-step s covers k = 4s + rg).
+// "Row form": element [k][cl] of a row-major tile -> 4 rows x 16 contiguous doubles per k-step (coalesced).
+struct Frag {
+    double v[4];
+};
+__device__ __forceinline__ Frag load_rows(const double *tile, int ld, int cl, int rg) {
+    Frag f;
+    const double *p = tile + (size_t)rg * ld + cl;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f.v[s] = p[(size_t)(4 * s) * ld];
+    return f;
+}
+__device__ __forceinline__ v4f64 mfma4(const Frag &a, const Frag &b, v4f64 acc, bool neg) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(neg ? -a.v[s] : a.v[s], b.v[s], acc, 0, 0, 0);
+    return acc;
+}
+// store a C/D-layout tile at block (I, J) and its transpose at block (J, I)
+__device__ __forceinline__ void store_tile(double *Mx, int ld, int I, int J, const v4f64 &t, int cl, int rg, bool mirror) {
+    double *p = Mx + (size_t)(16 * I + rg) * ld + 16 * J + cl;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[(size_t)(4 * r) * ld] = t[r];
+    if (mirror) {
+        double *q = Mx + (size_t)(16 * J + cl) * ld + 16 * I + rg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q[4 * r] = t[r];
+    }
+}
+
+// ---- (4) recursive block inverse as its own function: separate register allocation from the Cholesky sweep ---------
+__device__ __noinline__ void block_inverse(const double *C, double *W, double *T, const double *WdT, double *cs,
+                                           int N, int nb, int ld, long long *timing) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cl = lane & 15, rg = lane >> 4;
+#ifdef FIT_LOOP_TIMING
+    long long t_last = clock64();
+#endif
+    auto cs_ptr = [&](int I, int J) { return cs + ((size_t)I * nb + J) * 16; };
+    // (4) recursive block inverse, bottom-up: for each range [a, a+2s) split at mid = a+s:
+    //       T = L21 W11   then   W21 = -W22 T        (all tiles of a level are independent)
+    for (int s = 1; s < nb; s *= 2) {
+        // phase A: T_IJ = sum_{K=J}^{mid-1} L_IK W_KJ,  I in [mid, b), J in [a, mid)
+        int ctr = 0;
+        for (int a = 0; a + s < nb; a += 2 * s) {
+            const int mid = a + s, b = min(a + 2 * s, nb);
+            for (int I = mid; I < b; ++I)
+                for (int J = a; J < mid; ++J, ++ctr) {
+                    if ((ctr & (NW - 1)) != wave) continue;
+                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+                    // A operand L_IK from its mirror block (K, I); B operand W_KJ in place (row form both);
+                    // operands are fetched PF tile-products ahead (L2 latency ~ 4 products' worth of MFMAs)
+                    Frag ra[PF], rb[PF];
+#pragma unroll
+                    for (int d = 0; d < PF; ++d) {
+                        const int K = min(J + d, mid - 1);
+                        ra[d] = load_rows(C + (size_t)(16 * K) * ld + 16 * I, ld, cl, rg);
+                        rb[d] = load_rows(W + (size_t)(16 * K) * ld + 16 * J, ld, cl, rg);
+                    }
+                    for (int K = J; K < mid; ++K) {
+                        const Frag fa = ra[0], fb = rb[0];
+#pragma unroll
+                        for (int d = 0; d + 1 < PF; ++d) {
+                            ra[d] = ra[d + 1];
+                            rb[d] = rb[d + 1];
+                        }
+                        if (K + PF < mid) {
+                            ra[PF - 1] = load_rows(C + (size_t)(16 * (K + PF)) * ld + 16 * I, ld, cl, rg);
+                            rb[PF - 1] = load_rows(W + (size_t)(16 * (K + PF)) * ld + 16 * J, ld, cl, rg);
+                        }
+                        acc = mfma4(fa, fb, acc, false);
+                    }
+                    store_tile(T, ld, I, J, acc, cl, rg, false);
+                }
+        }
+        __syncthreads();
+        ISTAMP(5);
+        // phase B: W_IJ = -sum_{K=mid}^{I} W_IK T_KJ   (W_II from the transposed diagonal copies)
+        ctr = 0;
+        for (int a = 0; a + s < nb; a += 2 * s) {
+            const int mid = a + s, b = min(a + 2 * s, nb);
+            for (int I = mid; I < b; ++I)
+                for (int J = a; J < mid; ++J, ++ctr) {
+                    if ((ctr & (NW - 1)) != wave) continue;
+                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+                    // A operand W_IK: mirror block (K, I) for K < I, transposed diagonal copy for K == I
+                    auto load_a = [&](int K) {
+                        Frag f;
+                        if (K < I) {
+                            f = load_rows(W + (size_t)(16 * K) * ld + 16 * I, ld, cl, rg);
+                        } else {
+                            const double *wd = WdT + (size_t)I * 256 + rg * 16 + cl;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) f.v[q] = wd[64 * q];
+                        }
+                        return f;
+                    };
+                    Frag ra[PF], rb[PF];
+#pragma unroll
+                    for (int d = 0; d < PF; ++d) {
+                        const int K = min(mid + d, I);
+                        ra[d] = load_a(K);
+                        rb[d] = load_rows(T + (size_t)(16 * K) * ld + 16 * J, ld, cl, rg);
+                    }
+                    for (int K = mid; K <= I; ++K) {
+                        const Frag fa = ra[0], fb = rb[0];
+#pragma unroll
+                        for (int d = 0; d + 1 < PF; ++d) {
+                            ra[d] = ra[d + 1];
+                            rb[d] = rb[d + 1];
+                        }
+                        if (K + PF <= I) {
+                            ra[PF - 1] = load_a(K + PF);
+                            rb[PF - 1] = load_rows(T + (size_t)(16 * (K + PF)) * ld + 16 * J, ld, cl, rg);
+                        }
+                        acc = mfma4(fa, fb, acc, true);
+                    }
+                    store_tile(W, ld, I, J, acc, cl, rg, true);
+                    // column sums of squares of this (final) tile over the rows of the real system
+                    double ssq = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * I + rg + 4 * r < N) ssq = fma(acc[r], acc[r], ssq);
+                    ssq += __shfl_xor(ssq, 16);
+                    ssq += __shfl_xor(ssq, 32);
+                    if (rg == 0) cs_ptr(I, J)[cl] = ssq;
+                }
+        }
+        __syncthreads();
+        ISTAMP(6);
+    }
+
+}
+
 // ---- one posterior solve: C = A + diag(1/p) -> L -> W = L^-1 -> y = W b, m = W^T y, tr2 = colnorm2(W) --------------
-__device__ bool solve_posterior(const FitLoopParams &P, const Smem &S) {
+// Storage: C lower = L, C strictly-upper blocks = L^T (mirror); W lower = L^-1, W strictly-upper blocks = its
+// transpose; with the mirrors every MFMA operand is loaded in "row form" (4 rows x 128 contiguous bytes).
+__device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Smem &S) {
     const int N = P.N, NP = P.NP, nb = P.NP / 16, ld = P.NP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = lane & 15, rg = lane >> 4;
-    double *C = P.C, *W = P.W;
+    double *C = P.C, *W = P.W, *T = P.T, *WdT = P.WdT;
 #ifdef FIT_LOOP_TIMING
     long long t_last = clock64();
 #endif
 
-    // (1) C (lower triangle) = A + diag(1/p); padding rows/cols = identity
-    for (int i = wave; i < NP; i += NW) {
-        const double *ar = P.A + (size_t)i * ld;
-        double *cr = C + (size_t)i * ld;
-        for (int j = lane; j <= i; j += 64) {
-            double v = (i < N) ? ar[j] : 0.0;
-            if (j == i) v = (i < N) ? v + 1.0 / S.p[i] : 1.0;
-            cr[j] = v;
-        }
-    }
+    // 1/p (padding rows: 1) -- the diagonal of C = A + diag(1/p) is added when a tile is first read from A
+    for (int i = tid; i < NP; i += KT) S.y[i] = i < N ? 1.0 / S.p[i] : 1.0;  // row N (b) and padding: 1
     if (tid == 0) *S.flag = 0;
     __syncthreads();
+    const double *pinv = S.y;
     TSTAMP(0);
 
-    // (2) right-looking blocked Cholesky, 16-wide panels
+    // (2) right-looking blocked Cholesky, 16-wide panels; step 0 reads A, later steps read C.
+    //   * look-ahead: wave 0 updates tile (k+1,k+1) first, factors it AND inverts it (dl, dli) while the other waves
+    //     do the trailing update of step k.  fp64 VALU and fp64 MFMA share the DP units of a SIMD, so the waves
+    //     that share wave 0's SIMD (4, 8, 12) sit the trailing update out;
+    //   * panel: L_Ik^T = L_kk^-1 C_Ik^T on MFMAs (C_Ik^T is the mirror block (k, I)), one tile per wave.
+    // Row N of the padded system carries b:  C[N, 0:N] = b^T with the pivot of that row forced to 1, so the factor's
+    // row N is y^T = (L^-1 b)^T and row N of W = L^-1 is -(W^T y)^T = -m^T: both matvecs come for free.
+    const int aug_tile = N / 16, aug_c = N - 16 * aug_tile;
+    auto cs_ptr = [&](int I, int J) { return P.cs + ((size_t)I * nb + J) * 16; };
+    auto rows_valid = [&](int I) { return min(16, max(0, N - 16 * I)); };
+    if (wave == 0) {
+        const bool ok = factor_diag_tile(P.A, ld, pinv, aug_tile == 0 ? aug_c : -1, C, ld, S.dl, lane);
+        if (!ok && lane == 0) *S.flag = 1;
+        invert_factored_tile(S.dl, S.dli, W, WdT, ld, 0, lane, cs_ptr(0, 0), rows_valid(0));
+    }
+    __syncthreads();
+    TSTAMP(1);
     for (int k = 0; k < nb; ++k) {
-        if (wave == 0) {
-            const bool ok = factor_diag_tile(C, ld, k, S.dl, lane);
-            if (!ok && lane == 0) *S.flag = 1;
-        }
-        __syncthreads();
-        TSTAMP(1);
         if (*S.flag) return false;
-        const int r0 = 16 * (k + 1);
-        // panel: row i solves x L_kk^T = C[i, 16k:16k+16]
-        for (int i = r0 + tid; i < NP; i += KT) {
-            double *cr = C + (size_t)i * ld + 16 * k;
-            double x[16];
+        const double *src = (k == 0) ? P.A : C;
+        const int m = nb - k - 1, cnt = m * (m + 1) / 2;
+        // tile list of this step's trailing update, (I << 8) | J for k < J <= I (read after the next barrier)
+        for (int e = tid; e < cnt; e += KT) {
+            int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            while ((i + 1) * (i + 2) / 2 <= e) ++i;
+            while (i * (i + 1) / 2 > e) --i;
+            const int j = e - i * (i + 1) / 2;
+            S.lst[e] = ((k + 1 + i) << 8) | (k + 1 + j);
+        }
+        // look-ahead prefetch: wave 0 starts loading tile (k+1,k+1) now; it is complete when the panel is done
+        v4f64 la = {0.0, 0.0, 0.0, 0.0};
+        if (wave == 0 && cnt > 0) {
+            const double *c1 = src + (size_t)(16 * (k + 1) + rg) * ld + 16 * (k + 1) + cl;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) x[c] = cr[c];
+            for (int r = 0; r < 4; ++r) la[r] = c1[(size_t)(4 * r) * ld];
+        }
+        // panel: D = L_kk^-1 * (C_Ik)^T for I > k; D^T -> C (I,k), D -> C mirror (k,I), D^T -> LDS panel
+        {
+            Frag fa;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                double a = x[c];
+            for (int q = 0; q < 4; ++q) fa.v[q] = S.dli[cl * PS + 4 * q + rg];
+            for (int I = k + 1 + wave; I < nb; I += NW) {
+                const Frag fb = load_rows(src + (size_t)(16 * k) * ld + 16 * I, ld, cl, rg);
+                v4f64 d = {0.0, 0.0, 0.0, 0.0};
+                d = mfma4(fa, fb, d, false);
+                store_tile(C, ld, k, I, d, cl, rg, true);
+                double *pr = S.pan + (size_t)((I - k - 1) * 16 + cl) * PS + rg;
 #pragma unroll
-                for (int s = 0; s < c; ++s) a = fma(-x[s], S.dl[c * PS + s], a);
-                x[c] = a * S.dl[c * PS + 16];
-            }
-            double *pr = S.pan + (size_t)(i - r0) * PS;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                cr[c] = x[c];
-                pr[c] = x[c];
+                for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
             }
         }
         __syncthreads();
         TSTAMP(2);
-        // trailing update C_IJ -= L_Ik L_Jk^T for k < J <= I (tiles dealt round-robin to the waves)
-        int ctr = 0;
-        for (int I = k + 1; I < nb; ++I) {
-            for (int J = k + 1; J <= I; ++J, ++ctr) {
-                if ((ctr & (NW - 1)) != wave) continue;
-                double *ct = C + (size_t)(16 * I + rg) * ld + 16 * J + cl;
-                v4f64 acc;
+        // trailing update C_IJ = src_IJ - L_Ik L_Jk^T for k < J <= I; next tile's loads are in flight during the MFMAs
+        auto load_tile = [&](int t) {
+            v4f64 a;
+            const double *c1 = src + (size_t)(16 * (t >> 8) + rg) * ld + 16 * (t & 255) + cl;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = ct[(size_t)(4 * r) * ld];
-                const double *pa = S.pan + (size_t)((I - k - 1) * 16 + cl) * PS + rg;
-                const double *pb = S.pan + (size_t)((J - k - 1) * 16 + cl) * PS + rg;
+            for (int r = 0; r < 4; ++r) a[r] = c1[(size_t)(4 * r) * ld];
+            return a;
+        };
+        auto update_tile = [&](int t, v4f64 a) {
+            const int I1 = t >> 8, J1 = t & 255;
+            if (k == 0 && I1 == J1) {  // first touch: add diag(1/p) on diagonal tiles
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * s], pb[4 * s], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ct[(size_t)(4 * r) * ld] = acc[r];
+                for (int r = 0; r < 4; ++r)
+                    if (rg + 4 * r == cl) a[r] += pinv[16 * I1 + cl];
             }
+            const double *pa1 = S.pan + (size_t)((I1 - k - 1) * 16 + cl) * PS + rg;
+            const double *pb1 = S.pan + (size_t)((J1 - k - 1) * 16 + cl) * PS + rg;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s], pb1[4 * s], a, 0, 0, 0);
+            return a;
+        };
+        if (wave == 0) {
+            if (cnt > 0) {  // tile (k+1, k+1): update, transpose through LDS to row-per-lane, factor, invert
+#ifdef FIT_LOOP_TIMING
+                long long f_last = clock64();
+#endif
+                const int t = S.lst[0];
+                const v4f64 a = update_tile(t, la);
+                FSTAMP(8);
+                double *lw = S.lw;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lw[(rg + 4 * r) * PS + cl] = a[r];
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                const bool ok = factor_diag_tile(lw, PS, nullptr, aug_tile == k + 1 ? aug_c : -1,
+                                                 C + (size_t)(16 * (k + 1)) * ld + 16 * (k + 1), ld, S.dl, lane);
+                if (!ok && lane == 0) *S.flag = 1;
+                FSTAMP(9);
+                invert_factored_tile(S.dl, S.dli, W, WdT, ld, k + 1, lane, cs_ptr(k + 1, k + 1), rows_valid(k + 1));
+                FSTAMP(10);
+            }
+        } else if ((wave & 3) != 0) {
+            // worker waves (SIMDs other than wave 0's); tiles 1.. of the list
+            const int widx = wave - 1 - (wave >> 2);  // 0..NWK-1
+#ifdef FIT_LOOP_TIMING
+            long long w_last = clock64();
+#endif
+            int e = 1 + widx;
+            if (e < cnt) {
+                int t = S.lst[e];
+                v4f64 a = load_tile(t);
+                while (true) {
+                    const int en = e + NWK;
+                    const bool more = en < cnt;
+                    const int tn = more ? S.lst[en] : t;
+                    v4f64 an = a;
+                    if (more) an = load_tile(tn);
+                    a = update_tile(t, a);
+                    // tiles of column k+1 also feed the next panel as mirrors
+                    store_tile(C, ld, t >> 8, t & 255, a, cl, rg, (t & 255) == k + 1 && (t >> 8) != k + 1);
+                    if (!more) break;
+                    e = en;
+                    t = tn;
+                    a = an;
+                }
+            }
+            WSTAMP(11);
         }
         __syncthreads();
         TSTAMP(3);
     }
-
-    // (3) W_II = L_II^-1 for every diagonal tile
-    for (int I = wave; I < nb; I += NW) invert_diag_tile(C, W, ld, I, lane, S.lw + wave * 16 * PS);
-    __syncthreads();
+    if (*S.flag) return false;
     TSTAMP(4);
 
-    // (4) W_IJ = -W_II * sum_{K=J}^{I-1} L_IK W_KJ, block row by block row
-    const int LS = NP + 1;  // LDS stride of the staged block row of L
-    for (int I = 1; I < nb; ++I) {
-        for (int e = tid; e < 16 * 16 * I; e += KT) {
-            const int a = e / (16 * I), c = e - a * (16 * I);
-            S.pan[a * LS + c] = C[(size_t)(16 * I + a) * ld + c];
-        }
-        for (int e = tid; e < 256; e += KT) S.dl[(e >> 4) * PS + (e & 15)] = W[(size_t)(16 * I + (e >> 4)) * ld + 16 * I + (e & 15)];
-        __syncthreads();
-        TSTAMP(5);
-        for (int J = wave; J < I; J += NW) {
-            v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-            for (int K = J; K < I; ++K) {
-                const double *pa = S.pan + cl * LS + 16 * K + rg;
-                const double *wb = W + (size_t)(16 * K + rg) * ld + 16 * J + cl;
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * s], wb[(size_t)(4 * s) * ld], acc, 0, 0, 0);
-            }
-            // the accumulator tile is directly the B operand (register s = rows 4s..4s+3): out = -W_II * acc
-            v4f64 out = {0.0, 0.0, 0.0, 0.0};
-            const double *wa = S.dl + cl * PS + rg;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) out = __builtin_amdgcn_mfma_f64_16x16x4f64(-wa[4 * s], acc[s], out, 0, 0, 0);
-            double *wt = W + (size_t)(16 * I + rg) * ld + 16 * J + cl;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) wt[(size_t)(4 * r) * ld] = out[r];
-        }
-        __syncthreads();
-        TSTAMP(6);
-    }
+    block_inverse(C, W, T, WdT, P.cs, N, nb, ld, P.timing);
+#ifdef FIT_LOOP_TIMING
+    t_last = clock64();
+#endif
 
-    // (5) y = W b
-    for (int r = wave; r < N; r += NW) {
-        const double *wr = W + (size_t)r * ld;
-        double a = 0.0;
-        for (int c = lane; c <= r; c += 64) a = fma(wr[c], S.b[c], a);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off);
-        if (lane == 0) S.y[r] = a;
-    }
-    __syncthreads();
-    // (6) m_i = sum_{r>=i} W[r,i] y_r,  tr2_i = sum_{r>=i} W[r,i]^2  (three row segments, then combined)
-    {
-        const int col = tid % 320, seg = tid / 320;
-        if (seg < 3 && col < N) {
-            const int per = (N + 2) / 3;
-            const int ra = seg * per, rb = min(N, ra + per);
-            double am = 0.0, at = 0.0;
-            for (int r = max(ra, col); r < rb; ++r) {
-                const double w = W[(size_t)r * ld + col];
-                am = fma(w, S.y[r], am);
-                at = fma(w, w, at);
-            }
-            S.red[seg * 2 * NP + col] = am;
-            S.red[seg * 2 * NP + NP + col] = at;
-        }
-    }
-    __syncthreads();
+    // (5) m = -(row N of W),  tr2_i = sum over the block column of the tile column sums (fixed order)
     for (int i = tid; i < N; i += KT) {
-        S.m[i] = S.red[i] + S.red[2 * NP + i] + S.red[4 * NP + i];
-        S.tr2[i] = S.red[NP + i] + S.red[3 * NP + i] + S.red[5 * NP + i];
+        const int J = i >> 4, c = i & 15;
+        double t2 = 0.0;
+        for (int I = J; I < nb; ++I) t2 += cs_ptr(I, J)[c];
+        S.tr2[i] = t2;
+        S.m[i] = -W[(size_t)N * ld + i];
     }
     __syncthreads();
     TSTAMP(7);
@@ -262,11 +454,12 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     const int N = P.N, NP = P.NP;
     const int tid = threadIdx.x;
     Smem S;
-    const int panel_doubles = max(NP * PS, 16 * (NP + 1));
+    const int panel_doubles = max(NP * PS, 2 * NW * NP);
     S.pan = smem;
     S.lw = S.pan + panel_doubles;
     S.dl = S.lw + NW * 16 * PS;
-    S.p = S.dl + 16 * PS;
+    S.dli = S.dl + 16 * PS;
+    S.p = S.dli + 16 * PS;
     S.pold = S.p + NP;
     S.m = S.pold + NP;
     S.y = S.m + NP;
@@ -274,7 +467,8 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     S.rhs = S.tr2 + NP;
     S.b = S.rhs + NP;
     S.red = S.b + NP;  // 6*NP
-    S.flag = reinterpret_cast<int *>(S.red + 6 * NP);
+    S.lst = reinterpret_cast<int *>(S.red + 6 * NP);
+    S.flag = S.lst + 192;
     __shared__ int s_ctl[4];  // [0] stop, [1] status
 
     for (int i = tid; i < NP; i += KT) {
@@ -398,20 +592,24 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     }
 }
 
-// A <- (A + A^T)/2 on the leading N x N block of an ld-strided buffer; zero padding elsewhere.
-__global__ void symmetrize_pad_kernel(const double *Araw, int N, int NP, double *A) {
+// A <- (A + A^T)/2 on the leading N x N block of an NP-strided buffer, b in row/column N, zero elsewhere.
+__global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int N, int NP, double *A) {
     const size_t total = (size_t)NP * NP;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int i = (int)(e / NP), j = (int)(e - (size_t)i * NP);
-        A[e] = (i < N && j < N) ? 0.5 * (Araw[(size_t)i * N + j] + Araw[(size_t)j * N + i]) : 0.0;
+        double v = 0.0;
+        if (i < N && j < N) v = 0.5 * (Araw[(size_t)i * N + j] + Araw[(size_t)j * N + i]);
+        else if (i == N && j < N) v = bq[j];
+        else if (j == N && i < N) v = bq[i];
+        A[e] = v;
     }
 }
 
 }  // namespace
 
 size_t fh_k2_loop_smem_bytes(int NP) {
-    const int panel = NP * PS > 16 * (NP + 1) ? NP * PS : 16 * (NP + 1);
-    return sizeof(double) * (size_t)(panel + (NW + 1) * 16 * PS + 7 * NP + 6 * NP) + 16;
+    const int panel = NP * PS > 2 * NW * NP ? NP * PS : 2 * NW * NP;
+    return sizeof(double) * (size_t)(panel + (NW + 2) * 16 * PS + 7 * NP + 6 * NP) + 4 * 192 + 16;
 }
 
 hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s) {
@@ -427,7 +625,7 @@ hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t fh_k2_launch_symmetrize(const double *Araw, int N, int NP, double *A, hipStream_t s) {
-    hipLaunchKernelGGL(symmetrize_pad_kernel, dim3(128), dim3(256), 0, s, Araw, N, NP, A);
+hipError_t fh_k2_launch_symmetrize(const double *Araw, const double *bq, int N, int NP, double *A, hipStream_t s) {
+    hipLaunchKernelGGL(symmetrize_pad_kernel, dim3(128), dim3(256), 0, s, Araw, bq, N, NP, A);
     return hipGetLastError();
 }

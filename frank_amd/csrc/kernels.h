@@ -88,7 +88,9 @@ struct FitLoopParams {
     const double *q;        // N collocation frequencies
     const double *band_lu;  // 5N: LU factors of the pentadiagonal T + I
     const double *p_init;   // N or NULL (= ones)
-    double *C, *W;          // NP*NP work: Cholesky factor, its inverse
+    double *C, *W, *T;      // NP*NP work: Cholesky factor (+ mirror), its inverse (+ mirror), block-inverse temporary
+    double *WdT;            // (NP/16)*256: transposed inverses of the diagonal tiles
+    double *cs;             // (NP/16)^2 * 16: per-tile column sums of squares of W
     double *mu_out, *p_out; // N
     int *result;            // [0] count, [1] status
     double *diag_p, *diag_mu;
@@ -97,4 +99,4 @@ struct FitLoopParams {
 
 size_t fh_k2_loop_smem_bytes(int NP);
 hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s);
-hipError_t fh_k2_launch_symmetrize(const double *Araw, int N, int NP, double *A, hipStream_t s);
+hipError_t fh_k2_launch_symmetrize(const double *Araw, const double *bq, int N, int NP, double *A, hipStream_t s);

@@ -21,6 +21,8 @@ if os.environ.get("FRANK_AMD_LIB"):
     from frank_amd import _lib
     out=(ctypes.c_longlong*16)()
     _lib.lib.fh_debug_loop_timing(FF._DHT.context(), out)
-    names=['build C','diag factor','panel trsm','trailing','diag inverses','trtri stage','trtri compute','matvec']
+    names=['pinv','diag factor','panel trsm','trailing','(unused)','inverse phase A','inverse phase B','m, tr2 reduce']
     tot=sum(out[:8])
+
+    print('wave0: update %.1f factor %.1f invert %.1f | worker wave1 busy %.1f us/iter'%tuple(v/2.1e3/(2*nit+4) for v in out[8:12]))
     for n_,v in zip(names,out[:8]): print('%-14s %8.1f us/iter  %5.1f%%'%(n_, v/2.1e3/ (2*nit+4) , 100*v/tot))
