@@ -245,6 +245,12 @@ def main():
         flops_sym = a.nvis * (Nc * (Nc + 1) + 2 * Nc)       # SURVEY 8(d) symmetric-half figure (unique outputs)
         flops_full = a.nvis * (2 * Nc * Nc + 2 * Nc)         # SURVEY 8(d) full figure
         achieved = flops_sym / (kms * 1e-3) / 1e12
+        traffic = None
+        try:  # HBM bytes of one bin_gram launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as fh:
+                traffic = json.load(fh)["bin_gram_kernel"]["hbm_bytes_per_launch"] * (a.nvis / 1e7) if Nc == 300 else None
+        except Exception:
+            traffic = None
         out = {
             "metric": "FrankFitter solves/sec (N=%d, %.0e visibilities per fit, Normal, fp64, end-to-end)" % (Nc, a.nvis),
             "value": value, "unit": "fits/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -260,7 +266,8 @@ def main():
                              "note": "steps are pipelined: fit i's iteration (one CU) overlaps fit i+1's binning"},
             "roofline": {"kernel": "bin_gram_kernel<19>", "bound": "mfma", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "kernel_ms": kms, "kernel_ms_per_step": [round(x, 2) for x in kernel_ms],
+                         "traffic": traffic, "traffic_source": "profiles/r01_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / "
+                         "WRITE_SIZE, FETCH doubled per the gfx950 note)", "kernel_ms": kms, "kernel_ms_per_step": [round(x, 2) for x in kernel_ms],
                          "algorithmic_flops_per_vis": Nc * (Nc + 1) + 2 * Nc,
                          "achieved_full_gram_equiv": flops_full / (kms * 1e-3) / 1e12,
                          "hbm_read_GBps": 40.0 * a.nvis / (kms * 1e-3) / 1e9 * (1.0 if Nc <= 207 else 2.0)},
