@@ -41,19 +41,46 @@ FH_HD double fh_horner(const double (&c)[N], double x) {
     return a;
 }
 
-// Large-argument branch, x >= FH_J0_XSPLIT.  `ab` = FH_J0_AB ({A_k, B_k} pairs, highest power first).
+// Degree-12 polynomial sum_{k=0}^{12} c(k) x^k by Estrin's scheme: 15 DP ops instead of Horner's 12, but a
+// dependency depth of 5 instead of 12 -- the J0 chains are latency-bound on the DP pipe they share with the MFMAs.
+#define FH_ESTRIN12(res, c, x)                                                              \
+    do {                                                                                    \
+        const double x2_ = (x) * (x), x4_ = x2_ * x2_, x8_ = x4_ * x4_;                     \
+        const double p0_ = fma(c(1), (x), c(0)), p1_ = fma(c(3), (x), c(2));                \
+        const double p2_ = fma(c(5), (x), c(4)), p3_ = fma(c(7), (x), c(6));                \
+        const double p4_ = fma(c(9), (x), c(8)), p5_ = fma(c(11), (x), c(10));              \
+        const double q0_ = fma(p1_, x2_, p0_), q1_ = fma(p3_, x2_, p2_), q2_ = fma(p5_, x2_, p4_); \
+        const double r0_ = fma(q1_, x4_, q0_), r1_ = fma(c(12), x4_, q2_);                  \
+        (res) = fma(r1_, x8_, r0_);                                                         \
+    } while (0)
+// Degree-11 variant (12 coefficients)
+#define FH_ESTRIN11(res, c, x)                                                              \
+    do {                                                                                    \
+        const double x2_ = (x) * (x), x4_ = x2_ * x2_, x8_ = x4_ * x4_;                     \
+        const double p0_ = fma(c(1), (x), c(0)), p1_ = fma(c(3), (x), c(2));                \
+        const double p2_ = fma(c(5), (x), c(4)), p3_ = fma(c(7), (x), c(6));                \
+        const double p4_ = fma(c(9), (x), c(8)), p5_ = fma(c(11), (x), c(10));              \
+        const double q0_ = fma(p1_, x2_, p0_), q1_ = fma(p3_, x2_, p2_), q2_ = fma(p5_, x2_, p4_); \
+        const double r0_ = fma(q1_, x4_, q0_);                                              \
+        (res) = fma(q2_, x8_, r0_);                                                         \
+    } while (0)
+
+// Large-argument branch, x >= FH_J0_XSPLIT.  `ab` = FH_J0_AB ({A_k, B_k} pairs, highest power first) followed by
+// the cosine coefficients FH_J0_CD.
 template <typename TabPtr>
 FH_HD double fh_j0_large(double x, TabPtr ab) {
     const double y = fh_rsqrt(x);
     const double r = y * y;
     const double w = r * r;
     const double u = fma(w, FH_J0_USCALE, -1.0);
-    double a = ab[0], b = ab[1];
-#pragma unroll
-    for (int k = 1; k <= FH_J0_ADEG; ++k) {
-        a = fma(a, u, ab[2 * k]);
-        b = fma(b, u, ab[2 * k + 1]);
-    }
+    static_assert(FH_J0_ADEG == 12 && FH_J0_BDEG == 12 && FH_J0_CDEG == 11, "Estrin schemes are written for these degrees");
+    double a, b;  // ab[2k] = A_{12-k}, ab[2k+1] = B_{12-k}
+#define FH_CA(k) ab[2 * (12 - (k))]
+#define FH_CB(k) ab[2 * (12 - (k)) + 1]
+    FH_ESTRIN12(a, FH_CA, u);
+    FH_ESTRIN12(b, FH_CB, u);
+#undef FH_CA
+#undef FH_CB
     const double m = rint(fma(x, FH_INV_PI, -0.25));
     double ph = fma(-m, FH_PI1, x);
     ph = fma(-m, FH_PI2, ph);
@@ -61,7 +88,10 @@ FH_HD double fh_j0_large(double x, TabPtr ab) {
     ph = (ph - FH_PIO4_HI) - FH_PIO4_LO;
     ph = fma(r, b, ph);
     const double z = ph * ph;
-    const double c = fh_horner<FH_J0_CDEG + 1>(FH_J0_C, z);
+    double c;  // ab[NAB + k] = C_{11-k}
+#define FH_CC(k) ab[FH_J0_NAB + 11 - (k)]
+    FH_ESTRIN11(c, FH_CC, z);
+#undef FH_CC
     // (-1)^m without an integer conversion (valid for every finite m)
     const double odd = fabs(fma(-2.0, rint(0.5 * m), m));
     const double s = fma(-2.0, odd, 1.0);
@@ -75,21 +105,24 @@ FH_HD double fh_j0_small(double x, TabPtr tab) {
     idx = idx > FH_J0_NI - 1 ? FH_J0_NI - 1 : idx;
     const double t = x - ((double)idx + 0.5) * FH_J0_WIDTH;
     TabPtr row = tab + idx * FH_J0_TSTRIDE;
-    double a = row[FH_J0_TDEG];
-#pragma unroll
-    for (int k = FH_J0_TDEG - 1; k >= 0; --k) a = fma(a, t, row[k]);
+    static_assert(FH_J0_TDEG == 12, "Estrin scheme is written for degree 12");
+    double a;
+#define FH_CT(k) row[k]
+    FH_ESTRIN12(a, FH_CT, t);
+#undef FH_CT
     return a;
 }
 
-// `tab` points at FH_J0_TABLE_DOUBLES doubles: FH_J0_TAYLOR followed by FH_J0_AB.
+// `tab` points at FH_J0_TABLE_DOUBLES doubles: FH_J0_TAYLOR, FH_J0_AB, FH_J0_CD.
 template <typename TabPtr>
 FH_HD double fh_j0(double x, TabPtr tab) {
     if (x < FH_J0_XSPLIT) return fh_j0_small(x, tab);
     return fh_j0_large(x, tab + FH_J0_NI * FH_J0_TSTRIDE);
 }
 
-// Host copy of the combined table (Taylor rows, then {A,B} pairs).
+// Host copy of the combined table (Taylor rows, {A,B} pairs, cosine coefficients).
 static inline void fh_j0_fill_table(double *dst) {
     for (int i = 0; i < FH_J0_NI * FH_J0_TSTRIDE; ++i) dst[i] = FH_J0_TAYLOR[i];
     for (int i = 0; i < FH_J0_NAB; ++i) dst[FH_J0_NI * FH_J0_TSTRIDE + i] = FH_J0_AB[i];
+    for (int i = 0; i < FH_J0_NC; ++i) dst[FH_J0_NI * FH_J0_TSTRIDE + FH_J0_NAB + i] = FH_J0_CD[i];
 }
