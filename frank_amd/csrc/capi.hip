@@ -963,6 +963,69 @@ static int update_power_spectrum_rocsolver(fh_ctx *c, const double *M, const dou
     return FH_OK;
 }
 
+int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch, const double *alpha, const double *p0,
+                          const double *wsmooth, double tol, int max_iter, double *mu, double *p, int *niter,
+                          int *status) {
+    if (!c || !alpha || !p0 || !wsmooth || !mu || !p || !niter || batch < 1)
+        return fail(FH_ERR_INVALID, "fh_fit_normal_batched: bad argument");
+    if ((M == nullptr) != (j == nullptr)) return fail(FH_ERR_INVALID, "pass both M and j or neither");
+    if (!M && !c->have_device_Mj) return fail(FH_ERR_INVALID, "no device-resident M, j (run fh_stats_finalize)");
+    if (c->NP > 320) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 319", c->N);
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->N, NP = c->NP, nbk = NP / 16;
+    const size_t NN = (size_t)N * N, PP = (size_t)NP * NP;
+    if (M) {
+        HIP_TRY(hipMemcpyAsync(c->M.p, M, sizeof(double) * NN, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->j.p, j, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+        c->have_device_Mj = false;
+    }
+    int rc = prepare_qspace(c, c->Aq.p, c->bq.p);
+    if (rc) return rc;
+    // per-fit work buffers and parameters
+    DevBuf<double> Cb, Wb, Tb, WdTb, csb, mub, pb, lub, alb, p0b;
+    DevBuf<int> resb;
+    const size_t B = (size_t)batch;
+    if (Cb.alloc(B * PP) != hipSuccess || Wb.alloc(B * PP) != hipSuccess || Tb.alloc(B * PP) != hipSuccess ||
+        WdTb.alloc(B * NP * 16) != hipSuccess || csb.alloc(B * nbk * nbk * 16) != hipSuccess ||
+        mub.alloc(B * N) != hipSuccess || pb.alloc(B * N) != hipSuccess || lub.alloc(B * 5 * N) != hipSuccess ||
+        alb.alloc(B) != hipSuccess || p0b.alloc(B) != hipSuccess || resb.alloc(2 * B) != hipSuccess)
+        return fail(FH_ERR_NOMEM, "fh_fit_normal_batched: device allocation for %d fits failed", batch);
+    std::vector<double> lu_all(B * 5 * N), lu;
+    for (int b = 0; b < batch; ++b) {
+        smoothing_band_lu(*c->dht, wsmooth[b], lu);
+        memcpy(lu_all.data() + (size_t)b * 5 * N, lu.data(), sizeof(double) * 5 * N);
+    }
+    HIP_TRY(hipMemcpyAsync(lub.p, lu_all.data(), sizeof(double) * lu_all.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(alb.p, alpha, sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(p0b.p, p0, sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
+    FitLoopParams P = make_loop_params(c, FIT_MODE_FULL, 0.0, 0.0, tol, max_iter);
+    P.band_lu = lub.p;
+    P.C = Cb.p;
+    P.W = Wb.p;
+    P.T = Tb.p;
+    P.WdT = WdTb.p;
+    P.cs = csb.p;
+    P.mu_out = mub.p;
+    P.p_out = pb.p;
+    P.result = resb.p;
+    P.batch = batch;
+    P.batch_alpha = alb.p;
+    P.batch_p0 = p0b.p;
+    HIP_TRY(fh_k2_launch_loop_batched(P, batch, c->stream));
+    std::vector<int> res(2 * B);
+    HIP_TRY(hipMemcpyAsync(res.data(), resb.p, sizeof(int) * 2 * B, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(mu, mub.p, sizeof(double) * B * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(p, pb.p, sizeof(double) * B * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < batch; ++b) {
+        niter[b] = res[2 * b];
+        if (status)
+            status[b] = res[2 * b + 1] == FIT_STATUS_BAD_P ? FH_ERR_BAD_P
+                        : res[2 * b + 1] == FIT_STATUS_NOT_SPD ? FH_ERR_NOT_SPD : FH_OK;
+    }
+    return FH_OK;
+}
+
 int fh_fit_slots(void) { return kFitSlots; }
 
 int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol, int max_iter, int *ticket) {

@@ -451,6 +451,21 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
 
 __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (P.batch) {  // one workgroup per fit: per-fit hyper-parameters, work buffers and outputs; A, b shared
+        const int f = blockIdx.x;
+        const size_t PP = (size_t)P.NP * P.NP, nbk = (size_t)(P.NP / 16);
+        P.alpha = P.batch_alpha[f];
+        P.p0 = P.batch_p0[f];
+        P.band_lu += (size_t)f * 5 * P.N;
+        P.C += f * PP;
+        P.W += f * PP;
+        P.T += f * PP;
+        P.WdT += f * (size_t)P.NP * 16;
+        P.cs += f * nbk * nbk * 16;
+        P.mu_out += (size_t)f * P.N;
+        P.p_out += (size_t)f * P.N;
+        P.result += 2 * f;
+    }
     const int N = P.N, NP = P.NP;
     const int tid = threadIdx.x;
     Smem S;
@@ -610,6 +625,15 @@ __global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int 
 size_t fh_k2_loop_smem_bytes(int NP) {
     const int panel = NP * PS > 2 * NW * NP ? NP * PS : 2 * NW * NP;
     return sizeof(double) * (size_t)(panel + (NW + 2) * 16 * PS + 7 * NP + 6 * NP) + 4 * 192 + 16;
+}
+
+hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s) {
+    const size_t smem = fh_k2_loop_smem_bytes(P.NP);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fit_loop_kernel, dim3(batch), dim3(KT), smem, s, P);
+    return hipGetLastError();
 }
 
 hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s) {

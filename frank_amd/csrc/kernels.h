@@ -95,8 +95,13 @@ struct FitLoopParams {
     int *result;            // [0] count, [1] status
     double *diag_p, *diag_mu;
     long long *timing;      // debug builds (FIT_LOOP_TIMING): cycles per phase
+    // batched launch (one workgroup per fit; A, bq, Yinv, q shared): per-fit alpha / p0, band_lu[f][5N], and the
+    // work / output buffers strided by fit
+    int batch;
+    const double *batch_alpha, *batch_p0;
 };
 
 size_t fh_k2_loop_smem_bytes(int NP);
 hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s);
+hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s);
 hipError_t fh_k2_launch_symmetrize(const double *Araw, const double *bq, int N, int NP, double *A, hipStream_t s);

@@ -1,0 +1,48 @@
+"""Hyper-parameter sweeps over one mapping: the batched form of frank/fit.py:534-548 (`run_multiple_fits`).
+
+The reference re-runs the whole fit (including the visibility mapping) for every (alpha, w_smooth) point
+although M and j do not depend on them.  Here the mapping is done once (FrankFitter.preprocess_visibilities)
+and all points are iterated concurrently, one fit_loop workgroup (one compute unit) per point
+(fh_fit_normal_batched)."""
+import ctypes
+
+import numpy as np
+
+from frank_amd import _lib
+from frank_amd.radial_fitters import FrankFitter, FrankGaussianFit
+from frank_amd.statistical_models import GaussianModel, _BAD_P_MSG
+
+
+def sweep_fits(fitter, preproc_vis, alphas, weights_smooth, p_0=None, tol=1e-3, max_iter=2000):
+    """Fit `preproc_vis` (from `fitter.preprocess_visibilities`) for every (alpha[i], weights_smooth[i]).
+
+    Returns (sols, niters): FrankGaussianFit objects as FrankFitter.fit_preprocessed would return for a fitter
+    constructed with those hyper-parameters, and the iteration counts (`count`; >= max_iter means not converged).
+    """
+    if not isinstance(fitter, FrankFitter):
+        raise TypeError("fitter must be a frank_amd FrankFitter")
+    alphas = _lib.f8(np.atleast_1d(alphas))
+    ws = _lib.f8(np.atleast_1d(weights_smooth))
+    if alphas.shape != ws.shape:
+        raise ValueError("alphas and weights_smooth must have the same length")
+    B, N = alphas.size, fitter.size
+    p0 = _lib.f8(np.full(B, 1e-15 if p_0 is None else p_0))
+    fitter._build_matrices(preproc_vis)
+    M, j = _lib.f8(fitter._M), _lib.f8(fitter._j)
+    mu, p = np.empty((B, N)), np.empty((B, N))
+    niter = (ctypes.c_int * B)()
+    status = (ctypes.c_int * B)()
+    _lib.check(_lib.lib.fh_fit_normal_batched(fitter._DHT.context(), _lib.ptr(M), _lib.ptr(j), B, _lib.ptr(alphas),
+                                              _lib.ptr(p0), _lib.ptr(ws), float(tol), int(max_iter), _lib.ptr(mu),
+                                              _lib.ptr(p), niter, status))
+    sols = []
+    for b in range(B):
+        if status[b] == _lib.FH_ERR_BAD_P:
+            raise ValueError(_BAD_P_MSG)
+        if status[b] != _lib.FH_OK:
+            raise RuntimeError("fit %d of the sweep failed (status %d)" % (b, status[b]))
+        fit = GaussianModel._from_solution(fitter._DHT, fitter._M, fitter._j, p[b].copy(), mu[b].copy(),
+                                           noise_likelihood=fitter._H0)
+        info = dict(fitter._info, alpha=float(alphas[b]), wsmooth=float(ws[b]), p0=float(p0[b]))
+        sols.append(FrankGaussianFit(fitter._vis_map, fit, info, geometry=fitter._geometry.clone()))
+    return sols, [int(n) for n in niter]

@@ -139,6 +139,15 @@ int fh_fit_slots(void);
 int fh_fit_submit(fh_ctx *ctx, double alpha, double p0, double wsmooth, double tol, int max_iter, int *ticket);
 int fh_fit_collect(fh_ctx *ctx, int ticket, double *mu, double *p, int *niter);
 
+/* Batched form for hyper-parameter sweeps over ONE mapping (fit.py:534-548 re-runs the whole fit per (alpha,
+ * w_smooth) point although M, j do not depend on them): `batch` fits of the same M, j (host, or NULL for the
+ * context's device copies) with per-fit alpha[b], p0[b], wsmooth[b]; one fit_loop workgroup (one CU) per fit, all in
+ * one launch.  Outputs: mu, p (batch*N, row per fit), niter (batch), status (batch: FH_OK / FH_ERR_BAD_P /
+ * FH_ERR_NOT_SPD per fit).                                                                                      */
+int fh_fit_normal_batched(fh_ctx *ctx, const double *M, const double *j, int batch, const double *alpha,
+                          const double *p0, const double *wsmooth, double tol, int max_iter, double *mu, double *p,
+                          int *niter, int *status);
+
 /* One pass of the loop body for a caller-supplied p: fit = GaussianModel(M, j, p); p_new =
  * CriticalFilter.update_power_spectrum(fit) (filter.py:154-177).  M, j, p host; mu (N, posterior mean for p) and
  * p_new (N) host outputs, either may be NULL.                                                                */

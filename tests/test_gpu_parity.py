@@ -339,3 +339,25 @@ def test_pipelined_fits_match_synchronous(golden):
         assert rel_to_max(mu, sol.I) < 1e-9      # throughput-mode binning may order the partial sums differently
         assert rel_to_max(mu, g["I_a"]) < 1e-6
     _lib.lib.fh_vis_destroy(vis)
+
+
+def test_batched_sweep(golden):
+    """Batched hyper-parameter sweep (fh_fit_normal_batched) == one fitter per point (fit.py:534-548 semantics)."""
+    from frank_amd import FrankFitter
+    from frank_amd.sweep import sweep_fits
+    g = golden("sweep_N50_2e4.npz")
+    u, v, V, w = mock_disc_visibilities(int(g["n"]), seed=int(g["seed"]), noise_seed=int(g["noise_seed"]))
+    FF = FrankFitter(2.0, 50, geom(), verbose=False)
+    m = FF.preprocess_visibilities(u, v, V, w)
+    alphas = [float(g["alpha_a"]), float(g["alpha_b"]), 1.1, 1.2]
+    wss = [float(g["wsmooth_a"]), float(g["wsmooth_b"]), 1e-3, 1e-2]
+    sols, niters = sweep_fits(FF, m, alphas, wss)
+    assert niters[0] == int(g["niter_a"]) and niters[1] == int(g["niter_b"])
+    assert rel_to_max(sols[0].I, g["I_a"]) < 1e-6 and rel_to_max(sols[1].I, g["I_b"]) < 1e-6
+    for a, ws, sol, n in zip(alphas, wss, sols, niters):
+        F1 = FrankFitter(2.0, 50, geom(), alpha=a, weights_smooth=ws, store_iteration_diagnostics=True, verbose=False)
+        s1 = F1.fit_preprocessed(m)
+        assert F1.iteration_diagnostics["num_iterations"] == n
+        np.testing.assert_array_equal(s1.I, sol.I)
+        np.testing.assert_array_equal(s1.power_spectrum, sol.power_spectrum)
+        assert sol.info["alpha"] == a and sol.info["wsmooth"] == ws
