@@ -361,3 +361,26 @@ def test_batched_sweep(golden):
         np.testing.assert_array_equal(s1.I, sol.I)
         np.testing.assert_array_equal(s1.power_spectrum, sol.power_spectrum)
         assert sol.info["alpha"] == a and sol.info["wsmooth"] == ws
+
+
+def test_posterior_extras(golden):
+    """covariance, log-likelihoods, log prior, Laplace evidence, power-spectrum covariance and
+    predict_deprojected against the reference's values (statistical_models.py:790-883, filter.py:184-263,
+    radial_fitters.py:100-144, 892-967)."""
+    from frank_amd import FrankFitter
+    g = golden("sweep_N50_2e4.npz")
+    m = None
+    for tag in "ab":
+        FF = FrankFitter(2.0, 50, geom(), alpha=float(g["alpha_" + tag]), weights_smooth=float(g["wsmooth_" + tag]),
+                         verbose=False)
+        if m is None:
+            u, v, V, w = mock_disc_visibilities(int(g["n"]), seed=int(g["seed"]), noise_seed=int(g["noise_seed"]))
+            m = FF.preprocess_visibilities(u, v, V, w)
+        sol = FF.fit_preprocessed(m)
+        np.testing.assert_allclose(np.diag(sol.covariance), g["cov_diag_" + tag], rtol=1e-6)
+        np.testing.assert_allclose(sol.log_likelihood(), float(g["loglike_" + tag]), rtol=1e-9)
+        np.testing.assert_allclose(sol.log_likelihood(sol.I), float(g["loglike_I_" + tag]), rtol=1e-9)
+        np.testing.assert_allclose(FF.log_prior(), float(g["logprior_" + tag]), rtol=1e-8)
+        np.testing.assert_allclose(FF.log_evidence_laplace(), float(g["logevidence_" + tag]), rtol=1e-8)
+        np.testing.assert_allclose(np.diag(FF.MAP_spectrum_covariance), g["pscov_diag_" + tag], rtol=1e-5)
+        assert rel_to_max(sol.predict_deprojected(g["q_pred"]), g["Vpred_" + tag]) < 1e-7

@@ -157,6 +157,16 @@ def sweep():
         out["alpha_" + tag], out["wsmooth_" + tag] = a, ws
         out["I_" + tag], out["p_" + tag] = sol.I, sol.power_spectrum
         out["niter_" + tag] = FF.iteration_diagnostics["num_iterations"]
+        # posterior extras: covariance, likelihoods, Laplace evidence, power-spectrum covariance
+        out["cov_diag_" + tag] = np.diag(sol.covariance).copy()
+        out["loglike_" + tag] = sol.log_likelihood()
+        out["loglike_I_" + tag] = sol.log_likelihood(sol.I)
+        out["logprior_" + tag] = FF.log_prior()
+        out["logevidence_" + tag] = FF.log_evidence_laplace()
+        out["pscov_diag_" + tag] = np.diag(FF.MAP_spectrum_covariance).copy()
+        q_pred = np.array([1e4, 5e4, 2e5, 8e5, 1.9e6])
+        out["q_pred"] = q_pred
+        out["Vpred_" + tag] = sol.predict_deprojected(q_pred)
         print("    alpha=%g ws=%g niter=%d" % (a, ws, out["niter_" + tag]))
     # max_iter hit -> RuntimeError / ignore (radial_fitters.py:788-815)
     FFi = FrankFitter(RMAX, 50, geom(), max_iter=10, convergence_failure="ignore",
