@@ -301,7 +301,7 @@ class GaussianModel:
             s1 = np.where(s > 0, 1. / s, 0)
             return np.dot(V.T, np.multiply(np.dot(U.T, b).T, s1).T)
         shape = b.shape
-        B = np.ascontiguousarray(b.reshape(self.size, -1))
+        B = np.array(b.reshape(self.size, -1), dtype=np.float64, order='C')  # copy: the solve is in place
         _lib.check(_lib.lib.fh_cho_solve(self._DHT.context(), _lib.ptr(self._Dchol), _lib.ptr(B), B.shape[1]))
         return B.reshape(shape)
 
