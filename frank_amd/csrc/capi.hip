@@ -985,8 +985,13 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     DevBuf<double> Cb, Wb, Tb, WdTb, csb, mub, pb, lub, alb, p0b;
     DevBuf<int> resb;
     const size_t B = (size_t)batch;
-    if (Cb.alloc(B * PP) != hipSuccess || Wb.alloc(B * PP) != hipSuccess || Tb.alloc(B * PP) != hipSuccess ||
-        WdTb.alloc(B * NP * 16) != hipSuccess || csb.alloc(B * nbk * nbk * 16) != hipSuccess ||
+    // work buffers per resident workgroup (at most one per CU), outputs per fit
+    const size_t G = (size_t)(batch < c->num_cu ? batch : c->num_cu);
+    DevBuf<int> counter;
+    if (counter.alloc(1) != hipSuccess) return fail(FH_ERR_NOMEM, "device allocation failed");
+    HIP_TRY(hipMemsetAsync(counter.p, 0, sizeof(int), c->stream));
+    if (Cb.alloc(G * PP) != hipSuccess || Wb.alloc(G * PP) != hipSuccess || Tb.alloc(G * PP) != hipSuccess ||
+        WdTb.alloc(G * NP * 16) != hipSuccess || csb.alloc(G * nbk * nbk * 16) != hipSuccess ||
         mub.alloc(B * N) != hipSuccess || pb.alloc(B * N) != hipSuccess || lub.alloc(B * 5 * N) != hipSuccess ||
         alb.alloc(B) != hipSuccess || p0b.alloc(B) != hipSuccess || resb.alloc(2 * B) != hipSuccess)
         return fail(FH_ERR_NOMEM, "fh_fit_normal_batched: device allocation for %d fits failed", batch);
@@ -1011,7 +1016,8 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     P.batch = batch;
     P.batch_alpha = alb.p;
     P.batch_p0 = p0b.p;
-    HIP_TRY(fh_k2_launch_loop_batched(P, batch, c->stream));
+    P.batch_counter = counter.p;
+    HIP_TRY(fh_k2_launch_loop_batched(P, (int)G, c->stream));
     std::vector<int> res(2 * B);
     HIP_TRY(hipMemcpyAsync(res.data(), resb.p, sizeof(int) * 2 * B, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(mu, mub.p, sizeof(double) * B * N, hipMemcpyDeviceToHost, c->stream));

@@ -451,17 +451,27 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
 
 __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    if (P.batch) {  // one workgroup per fit: per-fit hyper-parameters, work buffers and outputs; A, b shared
-        const int f = blockIdx.x;
+    __shared__ int s_fit;
+    const FitLoopParams P0 = P;
+    // batched launch: the workgroups pull fit indices from a counter (fits of a sweep differ ~20x in iteration count)
+    for (;;) {
+    P = P0;
+    if (P.batch) {
+        if (threadIdx.x == 0) s_fit = atomicAdd(P.batch_counter, 1);
+        __syncthreads();
+        const int f = s_fit;
+        __syncthreads();
+        if (f >= P.batch) return;
         const size_t PP = (size_t)P.NP * P.NP, nbk = (size_t)(P.NP / 16);
+        const size_t slot = blockIdx.x;  // work buffers belong to the workgroup, outputs to the fit
         P.alpha = P.batch_alpha[f];
         P.p0 = P.batch_p0[f];
         P.band_lu += (size_t)f * 5 * P.N;
-        P.C += f * PP;
-        P.W += f * PP;
-        P.T += f * PP;
-        P.WdT += f * (size_t)P.NP * 16;
-        P.cs += f * nbk * nbk * 16;
+        P.C += slot * PP;
+        P.W += slot * PP;
+        P.T += slot * PP;
+        P.WdT += slot * (size_t)P.NP * 16;
+        P.cs += slot * nbk * nbk * 16;
         P.mu_out += (size_t)f * P.N;
         P.p_out += (size_t)f * P.N;
         P.result += 2 * f;
@@ -605,6 +615,9 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         P.result[0] = count;
         P.result[1] = status;
     }
+    if (!P.batch) return;
+    __syncthreads();
+    }  // next fit of the batch
 }
 
 // A <- (A + A^T)/2 on the leading N x N block of an NP-strided buffer, b in row/column N, zero elsewhere.

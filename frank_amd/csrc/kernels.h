@@ -98,6 +98,7 @@ struct FitLoopParams {
     // batched launch (one workgroup per fit; A, bq, Yinv, q shared): per-fit alpha / p0, band_lu[f][5N], and the
     // work / output buffers strided by fit
     int batch;
+    int *batch_counter;     // zeroed before the launch; workgroups pull fit indices from it
     const double *batch_alpha, *batch_p0;
 };
 

@@ -384,3 +384,32 @@ def test_posterior_extras(golden):
         np.testing.assert_allclose(FF.log_evidence_laplace(), float(g["logevidence_" + tag]), rtol=1e-8)
         np.testing.assert_allclose(np.diag(FF.MAP_spectrum_covariance), g["pscov_diag_" + tag], rtol=1e-5)
         assert rel_to_max(sol.predict_deprojected(g["q_pred"]), g["Vpred_" + tag]) < 1e-7
+
+
+def test_full_size_properties_1e7():
+    """BASELINE.json full size (N=300, 1e7 visibilities): size-independent properties of the binning pass --
+    additivity over a split, exact symmetry, positive diagonal, H0 additivity -- and one end-to-end fit whose
+    iteration count must agree between the synchronous and the pipelined entry points."""
+    import ctypes
+    from frank_amd import _lib, FrankFitter
+    n = 10_000_000
+    u, v, V, w = mock_disc_visibilities(n, seed=0, noise_seed=50)
+    FF = FrankFitter(2.0, 300, geom(), verbose=False, store_iteration_diagnostics=True)
+    full = FF.preprocess_visibilities(u, v, V, w)
+    assert np.array_equal(full["M"], full["M"].T) and np.all(np.diag(full["M"]) > 0)
+    cut = 3_333_333
+    a = FF.preprocess_visibilities(u[:cut], v[:cut], V[:cut], w[:cut])
+    b = FF.preprocess_visibilities(u[cut:], v[cut:], V[cut:], w[cut:])
+    assert rel_to_max(a["M"] + b["M"], full["M"]) < 1e-13
+    assert rel_to_max(a["j"] + b["j"], full["j"]) < 1e-12
+    assert abs(a["null_likelihood"] + b["null_likelihood"] - full["null_likelihood"]) < 1e-10 * abs(full["null_likelihood"])
+    sol = FF.fit_preprocessed(full)
+    nit = FF.iteration_diagnostics["num_iterations"]
+    assert 100 < nit < 2000 and np.all(np.isfinite(sol.I))
+    # the fit reproduces the data: chi^2 per visibility of the real parts is ~1 for noise of variance 1/w
+    up, vp = geom().deproject(u[:200000], v[:200000])
+    from frank_amd.geometry import apply_phase_shift
+    Vc = apply_phase_shift(u[:200000], v[:200000], V[:200000], MOCK_GEOMETRY["dRA"], MOCK_GEOMETRY["dDec"], inverse=True)
+    res = Vc.real - sol.predict_deprojected(np.hypot(up, vp))
+    chi2 = float(np.mean(res ** 2 * w[:200000]))
+    assert 0.97 < chi2 < 1.03, chi2
