@@ -129,13 +129,16 @@ __device__ __forceinline__ void invert_factored_tile(const double *dl, double *d
     const int c = lane & 15;
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): dl was written by this wave
     __builtin_amdgcn_wave_barrier();
+    // right-looking forward substitution: once x_s is known every later row is updated independently, so the
+    // dependency depth is 16 (not 120 as with row-by-row dot products)
     double x[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        double a = (r == c) ? 1.0 : 0.0;
+    for (int r = 0; r < 16; ++r) x[r] = (r == c) ? 1.0 : 0.0;
 #pragma unroll
-        for (int s = 0; s < r; ++s) a = fma(-dl[r * PS + s], x[s], a);  // L[r][s] * X[s][c]
-        x[r] = a * dl[r * PS + 16];                                     // * 1/L[r][r]
+    for (int s = 0; s < 16; ++s) {
+        x[s] = x[s] * dl[s * PS + 16];  // * 1/L[s][s]
+#pragma unroll
+        for (int r = s + 1; r < 16; ++r) x[r] = fma(-dl[r * PS + s], x[s], x[r]);  // L[r][s] * X[s][c]
     }
     if (lane < 16) {
         double *wt = WdT + (size_t)k * 256 + c * 16;  // WdT[k][c][r] = W_kk[r][c]
