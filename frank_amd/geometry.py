@@ -1,108 +1,96 @@
-"""Fixed source geometry -- host mirror of frank/geometry.py:41-131, 173-401.
+"""Fixed source geometry (inclination, position angle, phase centre) for the MI355X frank path.
 
-The hot path does NOT use these NumPy routines: VisibilityMapping.map_visibilities hands the raw
-(u, v, V) to the bin_gram kernel, which applies the phase shift and deprojection itself
-(csrc/bin_gram.hip::deproject_one).  They exist for callers that need deprojected coordinates on the
-host (FrankRadialFit.predict, user code) and carry the (inc, PA, dRA, dDec) the kernel reads.
-Geometry *fitting* (FitGeometryGaussian / FitGeometryFourierBessel, geometry.py:404-763) is out of scope.
+API-compatible with the fixed-geometry part of frank/geometry.py (`apply_phase_shift` :41-79, `deproject`
+:82-131, `SourceGeometry` :173-369, `FixedGeometry` :372-401).  The hot path does NOT run these NumPy
+routines: `VisibilityMapping.map_visibilities` hands the raw (u, v, V) to the GPU, where
+`deproject_kernel` (csrc/bin_gram.hip) applies the phase shift and the deprojection.  They serve callers that
+need deprojected coordinates on the host (`FrankRadialFit.predict`, user code) and carry the
+(inc, PA, dRA, dDec) that the kernels read.  Geometry *fitting* (geometry.py:404-763) is out of scope.
 """
 import numpy as np
 
 from frank_amd.constants import rad_to_arcsec, deg_to_rad
 
+_TWO_PI_PER_ARCSEC = 2. * np.pi / rad_to_arcsec
+
+
+def _phasor(u, v, dRA, dDec):
+    """exp(i * 2 pi (u dRA + v dDec)) with the offsets given in arcsec."""
+    angle = u * (dRA * _TWO_PI_PER_ARCSEC) + v * (dDec * _TWO_PI_PER_ARCSEC)
+    return np.cos(angle) + 1j * np.sin(angle)
+
 
 def apply_phase_shift(u, v, V, dRA, dDec, inverse=False):
-    """geometry.py:41-79"""
-    dRA = dRA * (2. * np.pi / rad_to_arcsec)
-    dDec = dDec * (2. * np.pi / rad_to_arcsec)
-    phi = u * dRA + v * dDec
-    if inverse:
-        return V / (np.cos(phi) + 1j * np.sin(phi))
-    return V * (np.cos(phi) + 1j * np.sin(phi))
+    """Move the source by (dRA, dDec) arcsec in the image plane; `inverse=True` moves it back."""
+    rot = _phasor(u, v, dRA, dDec)
+    return V / rot if inverse else V * rot
 
 
 def deproject(u, v, inc, PA, inverse=False):
-    """geometry.py:82-131"""
-    inc = inc * deg_to_rad
-    PA = PA * deg_to_rad
-    cos_t = np.cos(PA)
-    sin_t = np.sin(PA)
+    """Rotate the uv-plane by PA and compress u by cos(inc) (deproject), or undo that (`inverse=True`).
+
+    Deprojecting also returns the third Fourier coordinate w' = u_rot * sin(inc).
+    """
+    ci, si = np.cos(inc * deg_to_rad), np.sin(inc * deg_to_rad)
+    ct, st = np.cos(PA * deg_to_rad), np.sin(PA * deg_to_rad)
     if inverse:
-        sin_t *= -1
-        u = u / np.cos(inc)
-    up = u * cos_t - v * sin_t
-    vp = u * sin_t + v * cos_t
-    if inverse:
-        return up, vp
-    wp = up * np.sin(inc)
-    up = up * np.cos(inc)
-    return up, vp, wp
+        u = u / ci
+        st = -st
+        return u * ct - v * st, u * st + v * ct
+    ur = u * ct - v * st
+    vr = u * st + v * ct
+    return ur * ci, vr, ur * si
 
 
 class SourceGeometry(object):
-    """geometry.py:173-369 (inc, PA in degrees; dRA, dDec in arcsec)."""
+    """Geometry container + correction helpers; inc, PA in degrees, dRA, dDec in arcsec."""
 
     def __init__(self, inc=None, PA=None, dRA=None, dDec=None):
-        self._inc = inc
-        self._PA = PA
-        self._dRA = dRA
-        self._dDec = dDec
+        self._inc, self._PA, self._dRA, self._dDec = inc, PA, dRA, dDec
 
+    # -- corrections -------------------------------------------------------------------------------------
     def apply_correction(self, u, v, V, use3D=False):
-        Vp = apply_phase_shift(u, v, V, self._dRA, self._dDec, inverse=True)
-        up, vp, wp = deproject(u, v, self._inc, self._PA)
-        if use3D:
-            return up, vp, wp, Vp
-        return up, vp, Vp
+        """Centre the phase and deproject: returns (u', v'[, w'], V')."""
+        Vc = apply_phase_shift(u, v, V, self._dRA, self._dDec, inverse=True)
+        ud, vd, wd = deproject(u, v, self._inc, self._PA)
+        return (ud, vd, wd, Vc) if use3D else (ud, vd, Vc)
 
     def undo_correction(self, u, v, V):
-        up, vp = self.reproject(u, v)
-        Vp = apply_phase_shift(up, vp, V, self._dRA, self._dDec, inverse=False)
-        return up, vp, Vp
+        """Reproject deprojected points and put the phase offset back."""
+        us, vs = self.reproject(u, v)
+        return us, vs, apply_phase_shift(us, vs, V, self._dRA, self._dDec)
 
     def deproject(self, u, v, use3D=False):
-        if use3D:
-            return deproject(u, v, self._inc, self._PA)
-        return deproject(u, v, self._inc, self._PA)[:2]
+        out = deproject(u, v, self._inc, self._PA)
+        return out if use3D else out[:2]
 
     def reproject(self, u, v):
         return deproject(u, v, self._inc, self._PA, inverse=True)
 
     def fit(self, u, v, V, weights):
-        return
+        """Nothing to determine for a fixed geometry."""
+        return None
 
     def clone(self):
-        return FixedGeometry(self.inc, self.PA, self.dRA, self.dDec)
+        return FixedGeometry(self._inc, self._PA, self._dRA, self._dDec)
 
-    @property
-    def dRA(self):
-        return self._dRA
-
-    @property
-    def dDec(self):
-        return self._dDec
-
-    @property
-    def PA(self):
-        return self._PA
-
-    @property
-    def inc(self):
-        return self._inc
+    # -- parameters ----------------------------------------------------------------------------------------
+    inc = property(lambda self: self._inc, doc="inclination [deg]")
+    PA = property(lambda self: self._PA, doc="position angle, east of north [deg]")
+    dRA = property(lambda self: self._dRA, doc="phase-centre offset in right ascension [arcsec]")
+    dDec = property(lambda self: self._dDec, doc="phase-centre offset in declination [arcsec]")
 
     @property
     def rescale_factor(self):
+        """1 / cos(inc): the optically-thick flux rescaling."""
         return 1.0 / np.cos(self._inc * deg_to_rad)
 
     def __repr__(self):
-        return "SourceGeometry(inc={}, PA={}, dRA={}, dDec={})".format(self.inc, self.PA, self.dRA, self.dDec)
+        return "%s(inc=%r, PA=%r, dRA=%r, dDec=%r)" % (type(self).__name__, self._inc, self._PA, self._dRA, self._dDec)
 
 
 class FixedGeometry(SourceGeometry):
-    """geometry.py:372-401"""
+    """Known geometry: FixedGeometry(inc, PA, dRA=0, dDec=0)."""
 
     def __init__(self, inc, PA, dRA=0.0, dDec=0.0):
-        super(FixedGeometry, self).__init__(inc, PA, dRA, dDec)
-
-    def __repr__(self):
-        return "FixedGeometry(inc={}, PA={}, dRA={}, dDEC={})".format(self.inc, self.PA, self.dRA, self.dDec)
+        SourceGeometry.__init__(self, inc, PA, dRA, dDec)

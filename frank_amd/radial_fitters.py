@@ -20,6 +20,14 @@ from frank_amd.hankel import DiscreteHankelTransform
 from frank_amd.statistical_models import GaussianModel, VisibilityMapping
 
 
+def _forward(owner, attr, doc, scale=None):
+    """Read-only property returning getattr(self.<owner>, attr) (times `scale`, e.g. radians -> arcsec)."""
+    def get(self):
+        val = getattr(getattr(self, owner), attr)
+        return val if scale is None else val * scale
+    return property(get, doc=doc)
+
+
 class FrankRadialFit(metaclass=abc.ABCMeta):
     """Base class for results of frank fits (radial_fitters.py:35-219)."""
 
@@ -63,40 +71,13 @@ class FrankRadialFit(metaclass=abc.ABCMeta):
     def I(self):
         return self.MAP
 
-    @property
-    def r(self):
-        """Radius points, unit = arcsec"""
-        return self._vis_map.r
-
-    @property
-    def Rmax(self):
-        """Maximum radius, unit = arcsec"""
-        return self._vis_map.Rmax
-
-    @property
-    def q(self):
-        r"""Frequency points, unit = :math:`\lambda`"""
-        return self._vis_map.q
-
-    @property
-    def Qmax(self):
-        r"""Maximum frequency, unit = :math:`\lambda`"""
-        return self._vis_map.Qmax
-
-    @property
-    def size(self):
-        """Number of points in reconstruction"""
-        return self._vis_map.size
-
-    @property
-    def geometry(self):
-        """SourceGeometry object"""
-        return self._geometry
-
-    @property
-    def info(self):
-        """Fit quantities for reference"""
-        return self._info
+    r = _forward("_vis_map", "r", "Radius points, unit = arcsec")
+    Rmax = _forward("_vis_map", "Rmax", "Maximum radius, unit = arcsec")
+    q = _forward("_vis_map", "q", "Frequency points, unit = lambda")
+    Qmax = _forward("_vis_map", "Qmax", "Maximum frequency, unit = lambda")
+    size = _forward("_vis_map", "size", "Number of points in the reconstruction")
+    geometry = property(lambda self: self._geometry, doc="SourceGeometry used for the fit")
+    info = property(lambda self: self._info, doc="Hyper-parameters and sizes that reproduce the fit")
 
 
 class FrankGaussianFit(FrankRadialFit):
@@ -115,25 +96,10 @@ class FrankGaussianFit(FrankRadialFit):
     def solve_non_negative(self):
         return self._fit.solve_non_negative()
 
-    @property
-    def mean(self):
-        """Posterior mean, unit = Jy / sr"""
-        return self._fit.mean
-
-    @property
-    def MAP(self):
-        """Posterior maximum, unit = Jy / sr"""
-        return self.mean
-
-    @property
-    def covariance(self):
-        """Posterior covariance, unit = (Jy / sr)**2"""
-        return self._fit.covariance
-
-    @property
-    def power_spectrum(self):
-        """Power spectrum coefficients"""
-        return self._fit.power_spectrum
+    mean = _forward("_fit", "mean", "Posterior mean, unit = Jy / sr")
+    MAP = _forward("_fit", "mean", "Posterior maximum (= mean for the Gaussian model), unit = Jy / sr")
+    covariance = _forward("_fit", "covariance", "Posterior covariance, unit = (Jy / sr)**2")
+    power_spectrum = _forward("_fit", "power_spectrum", "Power spectrum coefficients")
 
 
 class FourierBesselFitter(object):
@@ -199,35 +165,12 @@ class FourierBesselFitter(object):
         self._sol = FrankGaussianFit(self._vis_map, fit, self._info, geometry=self._geometry.clone())
         return self._sol
 
-    @property
-    def r(self):
-        """Radius points, unit = arcsec"""
-        return self._DHT.r * rad_to_arcsec
-
-    @property
-    def Rmax(self):
-        """Maximum radius, unit = arcsec"""
-        return self._DHT.Rmax * rad_to_arcsec
-
-    @property
-    def q(self):
-        r"""Frequency points, unit = :math:`\lambda`"""
-        return self._DHT.q
-
-    @property
-    def Qmax(self):
-        r"""Maximum frequency, unit = :math:`\lambda`"""
-        return self._DHT.Qmax
-
-    @property
-    def size(self):
-        """Number of points in reconstruction"""
-        return self._DHT.size
-
-    @property
-    def geometry(self):
-        """Geometry object"""
-        return self._geometry
+    r = _forward("_DHT", "r", "Radius points, unit = arcsec", rad_to_arcsec)
+    Rmax = _forward("_DHT", "Rmax", "Maximum radius, unit = arcsec", rad_to_arcsec)
+    q = _forward("_DHT", "q", "Frequency points, unit = lambda")
+    Qmax = _forward("_DHT", "Qmax", "Maximum frequency, unit = lambda")
+    size = _forward("_DHT", "size", "Number of points in the reconstruction")
+    geometry = property(lambda self: self._geometry, doc="Geometry object")
 
 
 class FrankFitter(FourierBesselFitter):
@@ -293,24 +236,16 @@ class FrankFitter(FourierBesselFitter):
             self._iteration_diagnostics['power_spectrum'] = [dp[i].copy() for i in range(count)]
             self._iteration_diagnostics['MAP'] = [dm[i].copy() for i in range(count)]
 
-        # Check / report convergence (radial_fitters.py:787-815)
+        # convergence policy of radial_fitters.py:787-815: success iff count < max_iter
         if count < self._max_iter:
             if self._verbose:
-                logging.info('    Convergence criterion met at iteration {}'.format(count - 1))
+                logging.info('    Converged after {} power-spectrum iterations'.format(count))
         else:
-            if self._verbose:
-                logging.info('    Convergence criterion not met; fit stopped at'
-                             ' max_iter specified in your parameter file, {}'.format(self._max_iter))
-            msg = f'Convergence not met within {self._max_iter} '
-            msg += 'iterations.\nTry increasing max_iter, or '
-            msg += 'try increasing alpha since convergence can '
-            msg += 'be very slow for alpha close to 1.'
+            msg = ('Convergence not met within {} iterations. Increase max_iter or alpha (convergence is slow for '
+                   'alpha close to 1)'.format(self._max_iter))
             if self._convergence_failure == 'raise':
-                msg += '\nAlternatively set convergence_failure to'
-                msg += "'warn' or 'ignore' to continue despite the"
-                msg += 'failure.'
-                raise RuntimeError(msg)
-            elif self._convergence_failure == 'warn':
+                raise RuntimeError(msg + ", or set convergence_failure to 'warn' / 'ignore' to keep the last iterate.")
+            if self._convergence_failure == 'warn':
                 if logging.getLogger().isEnabledFor(logging.INFO):
                     logging.info(msg)
                 else:
@@ -356,15 +291,8 @@ class FrankFitter(FourierBesselFitter):
         sign, logdet = np.linalg.slogdet(Sigma_inv / (2 * np.pi))
         return self.log_likelihood() - 0.5 * logdet
 
-    @property
-    def MAP_solution(self):
-        """Reconstruction for the maximum a posteriori power spectrum"""
-        return self._sol
-
-    @property
-    def MAP_spectrum(self):
-        """Maximum a posteriori power spectrum"""
-        return self._ps
+    MAP_solution = property(lambda self: self._sol, doc="Reconstruction for the maximum a posteriori power spectrum")
+    MAP_spectrum = property(lambda self: self._ps, doc="Maximum a posteriori power spectrum")
 
     @property
     def MAP_spectrum_covariance(self):
@@ -373,7 +301,5 @@ class FrankFitter(FourierBesselFitter):
             self._ps_cov = self._filter.covariance_MAP(self._sol)
         return self._ps_cov
 
-    @property
-    def iteration_diagnostics(self):
-        """Power spectrum and posterior mean at each fit iteration, and number of iterations"""
-        return self._iteration_diagnostics
+    iteration_diagnostics = property(lambda self: self._iteration_diagnostics,
+                                     doc="dict: power spectrum and posterior mean of every iteration, num_iterations")
