@@ -13,7 +13,7 @@ from frank_amd.constants import rad_to_arcsec, deg_to_rad  # noqa: F401
 
 def __getattr__(name):
     # lazy: `import frank_amd.mock` / `frank_amd.constants` must work on a box without the built library
-    if name in ("FrankFitter", "FourierBesselFitter", "FrankRadialFit", "FrankGaussianFit"):
+    if name in ("FrankFitter", "FourierBesselFitter", "FrankRadialFit", "FrankGaussianFit", "FrankLogNormalFit"):
         from frank_amd import radial_fitters
         return getattr(radial_fitters, name)
     if name in ("FixedGeometry", "SourceGeometry"):
@@ -22,7 +22,7 @@ def __getattr__(name):
     if name == "DiscreteHankelTransform":
         from frank_amd.hankel import DiscreteHankelTransform
         return DiscreteHankelTransform
-    if name in ("VisibilityMapping", "GaussianModel"):
+    if name in ("VisibilityMapping", "GaussianModel", "LogNormalMAPModel"):
         from frank_amd import statistical_models
         return getattr(statistical_models, name)
     if name == "CriticalFilter":

@@ -20,6 +20,7 @@ FH_ERR_NOT_SPD = -4
 FH_ERR_NOMEM = -5
 FH_ERR_HIP = -6
 FH_ERR_UNSUPPORTED = -7
+FH_ERR_NUMERIC = -8
 
 VIS_MODELS = {"opt_thick": 0, "opt_thin": 1}
 
@@ -71,6 +72,11 @@ SIGNATURES = {
     "fh_fit_collect": (ctypes.c_int, [_vp, ctypes.c_int, _dp, _dp, ctypes.POINTER(ctypes.c_int)]),
     "fh_update_power_spectrum": (ctypes.c_int, [_vp, _dp, _dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                                 _dp, _dp]),
+    "fh_lognormal_model": (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, ctypes.c_double, _dp, _dp, ctypes.POINTER(_i64)]),
+    "fh_fit_lognormal": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                        ctypes.c_double, ctypes.c_int, ctypes.c_double, _dp, _dp,
+                                        ctypes.POINTER(ctypes.c_int), _dp, ctypes.POINTER(_i64), _dp, _dp]),
+    "fh_posterior_update": (ctypes.c_int, [_vp, _dp, _dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp]),
     "fh_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "fh_comm_create": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.POINTER(_vp)]),
@@ -94,7 +100,7 @@ def last_error():
     return lib.fh_last_error().decode("utf-8", "replace")
 
 
-def check(rc, value_error_codes=(FH_ERR_INVALID, FH_ERR_QRANGE, FH_ERR_BAD_P)):
+def check(rc, value_error_codes=(FH_ERR_INVALID, FH_ERR_QRANGE, FH_ERR_BAD_P, FH_ERR_NUMERIC)):
     """Map FH_ERR_* to the exception class the reference raises for the same condition."""
     if rc == FH_OK:
         return

@@ -110,6 +110,10 @@ struct fh_ctx {
     bool bin_timed = false;
     // scratch for coefficient / predict calls
     DevBuf<double> scratch_q, scratch_out, scratch_I;
+    // LogNormal (lognormal.hip)
+    DevBuf<double> ln_Sinv, ln_H, ln_LU, ln_s, ln_p, ln_pin, ln_guess, ln_diag_p, ln_diag_s;
+    DevBuf<int> ln_result;
+    DevBuf<long long> ln_stats;
 };
 
 struct fh_comm {
@@ -1148,6 +1152,168 @@ int fh_update_power_spectrum(fh_ctx *c, const double *M, const double *j, const 
     if (result[1] == FIT_STATUS_NOT_SPD) return fail(FH_ERR_NOT_SPD, "Cholesky of the posterior precision failed");
     if (result[1] == FIT_STATUS_BAD_P) return fail(FH_ERR_BAD_P, "Bad value in power spectrum after the update");
     return FH_OK;
+}
+
+// ---- method='LogNormal' ------------------------------------------------------------------------------------------
+static int ln_prepare(fh_ctx *c, const double *M, const double *j, LogNormalParams &P) {
+    const int N = c->N;
+    const size_t NN = (size_t)N * N;
+    if (N > 320) return fail(FH_ERR_UNSUPPORTED, "N = %d: the LogNormal kernel covers N <= 320", N);
+    if ((M == nullptr) != (j == nullptr)) return fail(FH_ERR_INVALID, "pass both M and j or neither");
+    if (!M && !c->have_device_Mj) return fail(FH_ERR_INVALID, "no device-resident M, j (run fh_stats_finalize)");
+    HIP_TRY(hipSetDevice(c->device));
+    if (M) {
+        HIP_TRY(hipMemcpyAsync(c->M.p, M, sizeof(double) * NN, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->j.p, j, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+        c->have_device_Mj = false;
+    }
+    if (!c->ln_Sinv.p) {
+        HIP_TRY(c->ln_Sinv.alloc(NN));
+        HIP_TRY(c->ln_H.alloc(NN));
+        HIP_TRY(c->ln_LU.alloc(NN));
+        HIP_TRY(c->ln_s.alloc(N));
+        HIP_TRY(c->ln_p.alloc(N));
+        HIP_TRY(c->ln_pin.alloc(N));
+        HIP_TRY(c->ln_guess.alloc(N));
+        HIP_TRY(c->ln_result.alloc(2));
+        HIP_TRY(c->ln_stats.alloc(9));
+    }
+    P = LogNormalParams{};
+    P.N = N;
+    P.max_step = 100000;  // minimizer.py:190
+    P.max_hev = 1000;
+    P.newton_tol = 1e-7;  // statistical_models.py:1141
+    const double norm = 1 / (M_PI * c->dht->Qmax * c->dht->Qmax);
+    P.pl_scale = ((2 * M_PI * c->dht->Rmax * c->dht->Rmax) / c->dht->j_nN) / (0.5 * c->dht->j_nN * norm);
+    P.M = c->M.p;
+    P.j = c->j.p;
+    P.Y = c->Y.p;
+    P.q = c->q.p;
+    P.band_lu = c->band_lu.p;
+    P.Sinv = c->ln_Sinv.p;
+    P.H = c->ln_H.p;
+    P.LU = c->ln_LU.p;
+    P.s_out = c->ln_s.p;
+    P.p_out = c->ln_p.p;
+    P.result = c->ln_result.p;
+    P.stats = c->ln_stats.p;
+    return FH_OK;
+}
+
+static int ln_finish(fh_ctx *c, double *s, double *p, double *Dinv, int64_t *stats, int result[2]) {
+    const int N = c->N;
+    long long st[9];
+    HIP_TRY(hipMemcpyAsync(result, c->ln_result.p, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(st, c->ln_stats.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    if (s) HIP_TRY(hipMemcpyAsync(s, c->ln_s.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    if (p) HIP_TRY(hipMemcpyAsync(p, c->ln_p.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    if (Dinv) HIP_TRY(hipMemcpyAsync(Dinv, c->ln_H.p, sizeof(double) * (size_t)N * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (stats)
+        for (int k = 0; k < 9; ++k) stats[k] = st[k];
+    if (result[1] == LN_STATUS_BAD_P) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (non-positive or NaN)");
+    if (result[1] == LN_STATUS_SLOPE) return fail(FH_ERR_NUMERIC, "Round off in slope calculation (LineSearch)");
+    return FH_OK;
+}
+
+int fh_lognormal_model(fh_ctx *c, const double *M, const double *j, const double *p, const double *guess, double s0,
+                       double *s_map, double *Dinv, int64_t *stats) {
+    if (!c || !p || !guess || !s_map) return fail(FH_ERR_INVALID, "fh_lognormal_model: NULL argument");
+    for (int k = 0; k < c->N; ++k)
+        if (!(p[k] > 0.0)) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (p[%d] = %g)", k, p[k]);
+    LogNormalParams P;
+    int rc = ln_prepare(c, M, j, P);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->ln_pin.p, p, sizeof(double) * c->N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ln_guess.p, guess, sizeof(double) * c->N, hipMemcpyHostToDevice, c->stream));
+    P.mode = LN_MODE_MAP;
+    P.s0 = s0;
+    P.p_in = c->ln_pin.p;
+    P.guess = c->ln_guess.p;
+    HIP_TRY(fh_ln_launch(P, 1, c->stream));
+    int result[2];
+    return ln_finish(c, s_map, nullptr, Dinv, stats, result);
+}
+
+int fh_fit_lognormal(fh_ctx *c, const double *M, const double *j, double alpha, double p0, double wsmooth, double tol,
+                     int max_iter, double I_scale, double *s_map, double *p, int *niter, double *Dinv, int64_t *stats,
+                     double *diag_p, double *diag_s) {
+    if (!c || !s_map || !p || !niter) return fail(FH_ERR_INVALID, "fh_fit_lognormal: NULL argument");
+    if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
+    if (!(I_scale > 0)) return fail(FH_ERR_INVALID, "I_scale must be positive");
+    if ((diag_p == nullptr) != (diag_s == nullptr)) return fail(FH_ERR_INVALID, "pass both diag_p and diag_s or neither");
+    if (c->NP > 320) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit kernels cover N <= 303", c->N);
+    LogNormalParams P;
+    int rc = ln_prepare(c, M, j, P);
+    if (rc) return rc;
+    const int N = c->N;
+    std::vector<double> lu;
+    smoothing_band_lu(*c->dht, wsmooth, lu);
+    HIP_TRY(hipMemcpyAsync(c->band_lu.p, lu.data(), sizeof(double) * lu.size(), hipMemcpyHostToDevice, c->stream));
+    // radial_fitters.py:744-752: the two Normal seed fits (p = 1, then the power-law guess); max_iter = -1 stops the
+    // fit_loop kernel after them
+    rc = prepare_qspace(c, c->Aq.p, c->bq.p);
+    if (rc) return rc;
+    FitLoopParams L = make_loop_params(c, FIT_MODE_FULL, alpha, p0, tol, -1);
+    HIP_TRY(fh_k2_launch_loop(L, c->stream));
+    int seed[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(seed, c->loop_result.p, sizeof seed, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (seed[1] == FIT_STATUS_NOT_SPD) return fail(FH_ERR_NOT_SPD, "Cholesky of the seed fit failed");
+    if (seed[1] == FIT_STATUS_BAD_P) return fail(FH_ERR_BAD_P, "Bad value in the seed power spectrum");
+    if (diag_p) {
+        const size_t need = (size_t)(max_iter + 1) * N;
+        if (c->ln_diag_p.n < need) HIP_TRY(c->ln_diag_p.alloc(need));
+        if (c->ln_diag_s.n < need) HIP_TRY(c->ln_diag_s.alloc(need));
+        P.diag_p = c->ln_diag_p.p;
+        P.diag_s = c->ln_diag_s.p;
+    }
+    P.mode = LN_MODE_FIT;
+    P.max_iter = max_iter;
+    P.alpha = alpha;
+    P.p0 = p0;
+    P.tol = tol;
+    P.s0 = log(I_scale);  // radial_fitters.py:712
+    P.guess = c->mu_out.p;
+    HIP_TRY(fh_ln_launch(P, 1, c->stream));
+    int result[2];
+    rc = ln_finish(c, s_map, p, Dinv, stats, result);
+    *niter = result[0];
+    if (rc) return rc;
+    const size_t nd = (size_t)result[0] * N;
+    if (diag_p && nd) {
+        HIP_TRY(hipMemcpy(diag_p, c->ln_diag_p.p, sizeof(double) * nd, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(diag_s, c->ln_diag_s.p, sizeof(double) * nd, hipMemcpyDeviceToHost));
+    }
+    return FH_OK;
+}
+
+int fh_posterior_update(fh_ctx *c, const double *map, const double *Dinv, const double *p, double alpha, double p0,
+                        double wsmooth, double *p_new) {
+    if (!c || !map || !Dinv || !p || !p_new) return fail(FH_ERR_INVALID, "fh_posterior_update: NULL argument");
+    const int N = c->N;
+    for (int k = 0; k < N; ++k)
+        if (!(p[k] > 0.0)) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (p[%d] = %g)", k, p[k]);
+    LogNormalParams P;
+    const bool keep = c->have_device_Mj;
+    c->have_device_Mj = true;  // M, j are not touched by this mode
+    int rc = ln_prepare(c, nullptr, nullptr, P);
+    c->have_device_Mj = keep;
+    if (rc) return rc;
+    std::vector<double> lu;
+    smoothing_band_lu(*c->dht, wsmooth, lu);
+    HIP_TRY(hipMemcpyAsync(c->band_lu.p, lu.data(), sizeof(double) * lu.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ln_pin.p, p, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ln_guess.p, map, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ln_H.p, Dinv, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, c->stream));
+    P.mode = LN_MODE_UPDATE;
+    P.alpha = alpha;
+    P.p0 = p0;
+    P.p_in = c->ln_pin.p;
+    P.guess = c->ln_guess.p;
+    HIP_TRY(fh_ln_launch(P, 1, c->stream));
+    int result[2];
+    return ln_finish(c, nullptr, p_new, nullptr, nullptr, result);
 }
 
 #ifdef FIT_LOOP_TIMING

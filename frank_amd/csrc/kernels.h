@@ -106,3 +106,28 @@ size_t fh_k2_loop_smem_bytes(int NP);
 hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s);
 hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s);
 hipError_t fh_k2_launch_symmetrize(const double *Araw, const double *bq, int N, int NP, double *A, hipStream_t s);
+
+// ---- LogNormal (lognormal.hip): Newton MAP of the log-brightness + the power-spectrum loop, one workgroup per fit
+enum { LN_MODE_MAP = 0, LN_MODE_FIT = 1, LN_MODE_UPDATE = 2 };
+enum { LN_STATUS_OK = 0, LN_STATUS_BAD_P = 1, LN_STATUS_SLOPE = 2 };
+
+struct LogNormalParams {
+    int N, max_iter, mode, lu_in_lds;
+    int max_step, max_hev;        // MinimizeNewton limits (minimizer.py:190-191: 10**5, 1000)
+    double newton_tol;            // 1e-7 (statistical_models.py:1141)
+    double alpha, p0, tol, s0;    // CriticalFilter hyper-parameters, loop tolerance, s0 = log(I_scale)
+    double pl_scale;              // DHT.transform(f) = pl_scale * (Y f)
+    const double *M, *j;          // normal equations (device)
+    const double *Y, *q;          // DHT.coefficients() row-major, collocation q
+    const double *band_lu;        // 5N: LU factors of the pentadiagonal T + I
+    const double *p_in;           // LN_MODE_MAP: power spectrum
+    const double *guess;          // LN_MODE_MAP: starting s;  LN_MODE_FIT: MAP of the Normal seed fit (radial_fitters.py:752)
+    double *Sinv, *H, *LU;        // N*N work: prior precision, Hessian at the MAP (output Dinv), LU factors when N > 112
+    double *s_out, *p_out;        // N
+    int *result;                  // [0] count, [1] status
+    long long *stats;             // [0] MAP solves, [1] Newton steps, [2] function evaluations, [3] Hessians, [4..8] exits 0-4
+    double *diag_p, *diag_s;      // optional (max_iter+1)*N each
+};
+
+size_t fh_ln_smem_bytes(int N, int *lu_in_lds);
+hipError_t fh_ln_launch(const LogNormalParams &P, int nblocks, hipStream_t s);

@@ -41,6 +41,13 @@ class CriticalFilter:
         """Estimate the best fit power spectrum given the current model fit (filter.py:154-177)."""
         N = self._DHT.size
         p_new = np.empty(N)
+        if hasattr(fit, '_Dinv'):
+            # a posterior that carries its own precision matrix (LogNormalMAPModel): Tr1 from fit.MAP, Tr2 from Dinv^-1
+            _lib.check(_lib.lib.fh_posterior_update(
+                self._DHT.context(), _lib.ptr(_lib.f8(fit.MAP)), _lib.ptr(_lib.f8(fit._Dinv)),
+                _lib.ptr(_lib.f8(fit.power_spectrum)), float(self._alpha), float(self._p_0),
+                float(self._weights_smooth), _lib.ptr(p_new)))
+            return p_new
         _lib.check(_lib.lib.fh_update_power_spectrum(
             self._DHT.context(), _lib.ptr(_lib.f8(fit._M)), _lib.ptr(_lib.f8(fit._j)),
             _lib.ptr(_lib.f8(fit.power_spectrum)), float(self._alpha), float(self._p_0),

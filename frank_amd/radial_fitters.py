@@ -4,6 +4,7 @@ Same constructor signatures, methods, properties, defaults and error behaviour; 
 the MI355X through libfrank_hip:
   preprocess_visibilities -> fh_map_visibilities (K1 bin_gram)
   fit_preprocessed / _fit -> fh_fit_normal       (K2: the whole power-spectrum loop on the device)
+                          -> fh_fit_lognormal    (method='LogNormal': Newton MAP + the same loop, lognormal kernel)
 Result objects hold NumPy arrays only and pickle like the reference's (io.py:190).
 """
 import abc
@@ -17,7 +18,7 @@ from frank_amd import _lib
 from frank_amd.constants import rad_to_arcsec
 from frank_amd.filter import CriticalFilter
 from frank_amd.hankel import DiscreteHankelTransform
-from frank_amd.statistical_models import GaussianModel, VisibilityMapping
+from frank_amd.statistical_models import GaussianModel, LogNormalMAPModel, VisibilityMapping
 
 
 def _forward(owner, attr, doc, scale=None):
@@ -102,6 +103,25 @@ class FrankGaussianFit(FrankRadialFit):
     power_spectrum = _forward("_fit", "power_spectrum", "Power spectrum coefficients")
 
 
+class FrankLogNormalFit(FrankRadialFit):
+    """Result of a frank fit with a log-normal brightness model (radial_fitters.py:325-403)."""
+
+    def __init__(self, DHT, fit, info={}, geometry=None):
+        FrankRadialFit.__init__(self, DHT, info, geometry)
+        self._fit = fit
+
+    def log_likelihood(self, I=None):
+        return self._fit.log_likelihood(None if I is None else np.log(I))
+
+    @property
+    def MAP(self):
+        """Posterior maximum, unit = Jy / sr"""
+        return np.exp((self._fit.MAP + self._fit.s_0) * self._fit.scale)
+
+    covariance = _forward("_fit", "covariance", "Posterior covariance of s = log I at the MAP")
+    power_spectrum = _forward("_fit", "power_spectrum", "Power spectrum coefficients")
+
+
 class FourierBesselFitter(object):
     """Fourier-Bessel series model for fitting visibilities (radial_fitters.py:405-613).
 
@@ -174,10 +194,10 @@ class FourierBesselFitter(object):
 
 
 class FrankFitter(FourierBesselFitter):
-    """Gaussian-process fit with the MAP power spectrum (radial_fitters.py:616-991), method='Normal'.
+    """Gaussian-process fit with the MAP power spectrum (radial_fitters.py:616-991), method 'Normal' or 'LogNormal'.
 
-    Same defaults as the reference: alpha=1.05, p_0=1e-15 ('Normal'), weights_smooth=1e-4, tol=1e-3,
-    max_iter=2000, convergence_failure='raise'.
+    Same defaults as the reference: alpha=1.05, p_0=1e-15 ('Normal') / 1e-35 ('LogNormal'), weights_smooth=1e-4,
+    tol=1e-3, I_scale=1e5, max_iter=2000, convergence_failure='raise'.
     """
 
     def __init__(self, Rmax, N, geometry, nu=0, block_data=True, block_size=10 ** 5, alpha=1.05, p_0=None,
@@ -186,9 +206,6 @@ class FrankFitter(FourierBesselFitter):
                  convergence_failure='raise'):
         if method not in {'Normal', 'LogNormal'}:
             raise ValueError('FrankFitter supports following mehods:\n\t{ "Normal", "LogNormal"}"')
-        if method == 'LogNormal':
-            raise NotImplementedError("method='LogNormal' (statistical_models.py:907-1295, minimizer.py) is the "
-                                      "next row of the hot-path table and is not built yet")
         self._method = method
         super(FrankFitter, self).__init__(Rmax, N, geometry, nu, block_data, assume_optically_thick, scale_height,
                                           block_size, verbose)
@@ -212,10 +229,12 @@ class FrankFitter(FourierBesselFitter):
         return '{}: {} method'.format(type(self).__name__, self._method)
 
     def _fit(self):
-        """The power-spectrum iteration (radial_fitters.py:737-832), run on the device by fh_fit_normal."""
+        """The power-spectrum iteration (radial_fitters.py:737-832), run on the device by fh_fit_normal /
+        fh_fit_lognormal; the convergence policy (:787-815) is applied to the returned `count`."""
         N = self.size
         alpha, p_0, wsmooth, tol = self._hyper
-        mu, p = np.empty(N), np.empty(N)
+        lognormal = self._method == 'LogNormal'
+        x, p = np.empty(N), np.empty(N)
         niter = ctypes.c_int(0)
         dp = dm = None
         if self._store_iteration_diagnostics:
@@ -223,9 +242,16 @@ class FrankFitter(FourierBesselFitter):
             dp = np.zeros((self._max_iter + 1, N))
             dm = np.zeros((self._max_iter + 1, N))
         M, j = _lib.f8(self._M), _lib.f8(self._j)
-        rc = _lib.lib.fh_fit_normal(self._DHT.context(), _lib.ptr(M), _lib.ptr(j), alpha, p_0, wsmooth, tol,
-                                    int(self._max_iter), _lib.ptr(mu), _lib.ptr(p), ctypes.byref(niter),
-                                    _lib.ptr(dp), _lib.ptr(dm))
+        if lognormal:
+            Dinv = np.empty((N, N))
+            stats = (ctypes.c_int64 * 9)()
+            rc = _lib.lib.fh_fit_lognormal(self._DHT.context(), _lib.ptr(M), _lib.ptr(j), alpha, p_0, wsmooth, tol,
+                                           int(self._max_iter), float(np.exp(self._s_scale)), _lib.ptr(x), _lib.ptr(p),
+                                           ctypes.byref(niter), _lib.ptr(Dinv), stats, _lib.ptr(dp), _lib.ptr(dm))
+        else:
+            rc = _lib.lib.fh_fit_normal(self._DHT.context(), _lib.ptr(M), _lib.ptr(j), alpha, p_0, wsmooth, tol,
+                                        int(self._max_iter), _lib.ptr(x), _lib.ptr(p), ctypes.byref(niter),
+                                        _lib.ptr(dp), _lib.ptr(dm))
         if rc == _lib.FH_ERR_BAD_P:
             from frank_amd.statistical_models import _BAD_P_MSG
             raise ValueError(_BAD_P_MSG)
@@ -254,8 +280,13 @@ class FrankFitter(FourierBesselFitter):
         if self._store_iteration_diagnostics:
             self._iteration_diagnostics['num_iterations'] = count
 
-        fit = GaussianModel._from_solution(self._DHT, self._M, self._j, p, mu, noise_likelihood=self._H0)
-        self._sol = FrankGaussianFit(self._vis_map, fit, self._info, geometry=self._geometry.clone())
+        if lognormal:
+            fit = LogNormalMAPModel._from_solution(self._DHT, self._M, self._j, p, x, Dinv, self._s_scale,
+                                                   noise_likelihood=self._H0, stats=tuple(stats))
+            self._sol = FrankLogNormalFit(self._vis_map, fit, self._info, geometry=self._geometry.clone())
+        else:
+            fit = GaussianModel._from_solution(self._DHT, self._M, self._j, p, x, noise_likelihood=self._H0)
+            self._sol = FrankGaussianFit(self._vis_map, fit, self._info, geometry=self._geometry.clone())
         self._ps = p
         self._ps_cov = None
         return self._sol
@@ -266,6 +297,9 @@ class FrankFitter(FourierBesselFitter):
             fit_method = self._method
         if fit_method == 'Normal':
             return GaussianModel(self._DHT, self._M, self._j, p, guess=guess, noise_likelihood=self._H0)
+        if fit_method == 'LogNormal':
+            return LogNormalMAPModel(self._DHT, self._M, self._j, p, guess=guess, s0=self._s_scale,
+                                     noise_likelihood=self._H0)
         raise ValueError('fit_method must be one of the following:\n\t{"Normal", "LogNormal"}')
 
     def draw_powerspectrum(self, Ndraw=1):

@@ -1,4 +1,4 @@
-"""VisibilityMapping and GaussianModel -- drop-ins for frank/statistical_models.py:29-904.
+"""VisibilityMapping, GaussianModel and LogNormalMAPModel -- drop-ins for frank/statistical_models.py:29-1295.
 
 Every array computation here is a call into libfrank_hip (HIP kernels, rocBLAS, rocSOLVER); the Python
 keeps the reference's signatures, attribute names, error behaviour and plain-NumPy results.
@@ -363,6 +363,182 @@ class GaussianModel:
     def power_spectrum(self):
         """Power spectrum coefficients"""
         return self._p
+
+    @property
+    def num_fields(self):
+        return self._Nfields
+
+    @property
+    def size(self):
+        """Number of points in reconstruction"""
+        return self._DHT.size
+
+
+
+class LogNormalMAPModel:
+    r"""Maximum a posteriori log-brightness, P(s|q,V,p,s0) ~ G(H exp(s+s0) - V, M) P(s|p)
+    (statistical_models.py:907-1295), for one field and one frequency with scale = 1 -- what FrankFitter builds
+    (radial_fitters.py:885-887).  The Newton minimisation (minimizer.py) runs in the lognormal kernel through
+    fh_lognormal_model; `Dsolve` applies the inverse of the Hessian at the MAP.
+    """
+
+    def __init__(self, DHT, M, j, p=None, scale=None, s0=None, guess=None, Nfields=None, full_hessian=1,
+                 noise_likelihood=0):
+        self._DHT = DHT
+        M = np.asarray(M, dtype=np.float64)
+        j = np.asarray(j, dtype=np.float64)
+        if M.ndim == 3 and M.shape[0] == 1:
+            M = M[0]
+        if j.ndim == 2 and j.shape[0] == 1:
+            j = j[0]
+        if (M.ndim != 2 or j.ndim != 1 or Nfields not in (None, 1)
+                or (scale is not None and np.any(np.asarray(scale) != 1))):
+            raise NotImplementedError("multi-frequency / multi-field LogNormalMAPModel (statistical_models.py:"
+                                      "1017-1047) is unreachable from FrankFitter and not built")
+        if full_hessian != 1:
+            raise NotImplementedError("full_hessian != 1 (statistical_models.py:1112-1120) is not built; FrankFitter "
+                                      "always uses the full Hessian")
+        if s0 is None or guess is None:
+            # the reference fails on both as well (s0.reshape / guess.reshape on None, :1058, :1124)
+            raise ValueError("LogNormalMAPModel needs s0 and guess")
+        s0 = np.atleast_1d(np.asarray(s0, dtype=np.float64))
+        if len(s0) != 1:
+            raise ValueError("Signal zero-point (s0) must have the same "
+                             "length as the number of fields or length 1")
+        self._Nfields = 1
+        self._full_hess = full_hessian
+        self._scale = np.ones([1, 1], dtype='f8')
+        self._s0 = s0.reshape(1, 1)
+        N = DHT.size
+        if p is not None:
+            p = np.asarray(p, dtype=np.float64).reshape(-1, N)
+            if np.any(p <= 0) or np.any(np.isnan(p)):  # statistical_models.py:1049-1057
+                raise ValueError(_BAD_P_MSG)
+        self._p = p
+        self._M = np.ascontiguousarray(M).reshape(1, N, N)
+        self._j = np.ascontiguousarray(j).reshape(1, N)
+        self._like_noise = noise_likelihood
+        self._Sinv_cache = None
+        self._cov = None
+        self._Dchol = None
+        self._chol_failed = False
+        self._fit(np.asarray(guess, dtype=np.float64).reshape(N))
+
+    @classmethod
+    def _from_solution(cls, DHT, M, j, p, s_map, Dinv, s0, noise_likelihood=0, stats=None):
+        """Wrap a MAP the device loop already found (fh_fit_lognormal)."""
+        self = cls.__new__(cls)
+        N = DHT.size
+        self._DHT = DHT
+        self._Nfields = 1
+        self._full_hess = 1
+        self._scale = np.ones([1, 1], dtype='f8')
+        self._s0 = np.full((1, 1), float(s0))
+        self._p = np.asarray(p, dtype=np.float64).reshape(1, N)
+        self._M = np.ascontiguousarray(M, dtype=np.float64).reshape(1, N, N)
+        self._j = np.ascontiguousarray(j, dtype=np.float64).reshape(1, N)
+        self._like_noise = noise_likelihood
+        self._Sinv_cache = None
+        self._cov = None
+        self._Dchol = None
+        self._chol_failed = False
+        self._s_MAP = np.asarray(s_map, dtype=np.float64).reshape(1, N)
+        self._Dinv = np.asarray(Dinv, dtype=np.float64)
+        self._newton_stats = stats
+        return self
+
+    def _fit(self, guess):
+        """statistical_models.py:1064-1160"""
+        N = self.size
+        s_map, Dinv = np.empty(N), np.empty((N, N))
+        stats = (ctypes.c_int64 * 9)()
+        # no prior (p=None): S^-1 = 0 (:1063) is p -> infinity
+        p = np.full(N, np.inf) if self._p is None else _lib.f8(self._p[0])
+        _lib.check(_lib.lib.fh_lognormal_model(self._DHT.context(), _lib.ptr(_lib.f8(self._M[0])),
+                                               _lib.ptr(_lib.f8(self._j[0])), _lib.ptr(p), _lib.ptr(_lib.f8(guess)),
+                                               float(self._s0[0, 0]), _lib.ptr(s_map), _lib.ptr(Dinv), stats))
+        self._s_MAP = s_map.reshape(1, N)
+        self._Dinv = Dinv
+        self._newton_stats = tuple(stats)
+        self._cov = None
+
+    @property
+    def _Sinv(self):
+        """Prior precision Y^T diag(1/p) Y, shape (1, N, N) (statistical_models.py:1060-1063)."""
+        if self._Sinv_cache is None:
+            N = self.size
+            if self._p is None:
+                self._Sinv_cache = np.zeros([1, N, N], dtype='f8')
+            else:
+                Ykm = self._DHT.coefficients()
+                self._Sinv_cache = np.einsum('ji,lj,jk->lik', Ykm, 1 / self._p, Ykm)
+        return self._Sinv_cache
+
+    def _ensure_factor(self):
+        if self._Dchol is None and not self._chol_failed:
+            N = self.size
+            mu, chol = np.empty(N), np.empty((N, N))
+            used_svd = ctypes.c_int(0)
+            sym = np.ascontiguousarray(0.5 * (self._Dinv + self._Dinv.T))
+            _lib.check(_lib.lib.fh_gaussian_model(self._DHT.context(), _lib.ptr(sym), _lib.ptr(np.zeros(N)), None,
+                                                  _lib.ptr(mu), _lib.ptr(chol), None, ctypes.byref(used_svd)))
+            if used_svd.value:
+                self._chol_failed = True
+            else:
+                self._Dchol = chol
+
+    def Dsolve(self, b):
+        r"""Compute D . b by solving D^-1 x = b, D^-1 = hess(s_MAP) (statistical_models.py:1162-1182)."""
+        self._ensure_factor()
+        b = np.asarray(b, dtype=np.float64)
+        if self._Dchol is None:
+            # the Hessian at the MAP is not positive definite: the reference's SVD route (:1150-1158), on the host
+            U, s_svd, V = np.linalg.svd(self._Dinv, full_matrices=False)
+            s1 = np.where(s_svd > 0, 1. / s_svd, 0)
+            return np.dot(V.T, np.multiply(np.dot(U.T, b).T, s1).T)
+        shape = b.shape
+        B = np.array(b.reshape(self.size, -1), dtype=np.float64, order='C')
+        _lib.check(_lib.lib.fh_cho_solve(self._DHT.context(), _lib.ptr(self._Dchol), _lib.ptr(B), B.shape[1]))
+        return B.reshape(shape)
+
+    def draw(self, N):
+        """Compute N draws from the (approximate) posterior (statistical_models.py:1184-1189; host RNG)."""
+        return np.random.multivariate_normal(self.MAP.reshape(-1), self.covariance, N)
+
+    def log_likelihood(self, s=None):
+        r"""statistical_models.py:1191-1241.  The reference's own implementation raises for every input
+        (`np.einsum('i,j->ij', self._scale, s)` with a 2-D `_scale`), so there is no behaviour to match."""
+        raise NotImplementedError("LogNormalMAPModel.log_likelihood raises in the reference as well "
+                                  "(statistical_models.py:1232)")
+
+    def solve_non_negative(self):
+        """The solution is always non-negative; provided for convenience (statistical_models.py:1243-1246)."""
+        return self.MAP
+
+    @property
+    def MAP(self):
+        """Posterior maximum of s = log(I) - s0"""
+        return self._s_MAP.reshape(self.size)
+
+    @property
+    def covariance(self):
+        """Posterior covariance at the MAP"""
+        if self._cov is None:
+            self._cov = self.Dsolve(np.eye(self.size))
+        return self._cov
+
+    @property
+    def power_spectrum(self):
+        """Power spectrum coefficients"""
+        return None if self._p is None else self._p.reshape(self.size)
+
+    @property
+    def scale(self):
+        return self._scale[:, 0]
+
+    @property
+    def s_0(self):
+        return self._s0[0]
 
     @property
     def num_fields(self):

@@ -34,6 +34,7 @@ extern "C" {
 #define FH_ERR_NOMEM (-5)
 #define FH_ERR_HIP (-6)           /* no GPU, or a HIP / rocBLAS / rocSOLVER / RCCL runtime error              */
 #define FH_ERR_UNSUPPORTED (-7)   /* e.g. nu != 0                                                             */
+#define FH_ERR_NUMERIC (-8)       /* ValueError("Round off in slope calculation"): minimizer.py:136-137         */
 
 /* vis_model: statistical_models.py:71-73, 486-496 */
 #define FH_VIS_OPT_THICK 0 /* H scaled by cos(inc) */
@@ -153,6 +154,34 @@ int fh_fit_normal_batched(fh_ctx *ctx, const double *M, const double *j, int bat
  * p_new (N) host outputs, either may be NULL.                                                                */
 int fh_update_power_spectrum(fh_ctx *ctx, const double *M, const double *j, const double *p, double alpha, double p0,
                              double wsmooth, double *mu, double *p_new);
+
+/* ---- method='LogNormal' (radial_fitters.py:754-763, statistical_models.py:907-1160, minimizer.py) -------------
+ * fh_lognormal_model: LogNormalMAPModel(DHT, M, j, p, guess=guess, s0=s0) for one field / one frequency: the MAP of
+ * s = log(I) - s0 by MinimizeNewton(H, jac, hess, guess, LineSearch(reduce_step=limit_step), tol=1e-7)
+ * (statistical_models.py:1064-1145, minimizer.py:190-283).  M, j host (or NULL, NULL for the context's device
+ * copies); p, guess (N) host.  Outputs (host): s_map (N); Dinv (N*N row-major, hess(s_MAP), statistical_models.py:
+ * 1147; may be NULL); stats (9 x int64, may be NULL): MAP solves, Newton steps, function evaluations, Hessian
+ * factorisations, then the number of MinimizeNewton exits with status 0 (converged), 1 (no improvement), 2 (max
+ * steps), 3 (max Hessians), 4 (slope round-off -> FH_ERR_NUMERIC).  As in the reference the exit status of the
+ * minimiser is otherwise ignored (statistical_models.py:1142-1145).                                             */
+int fh_lognormal_model(fh_ctx *ctx, const double *M, const double *j, const double *p, const double *guess, double s0,
+                       double *s_map, double *Dinv, int64_t *stats);
+
+/* fh_fit_lognormal: FrankFitter._fit with method='LogNormal' (radial_fitters.py:737-832): the two Normal seed fits,
+ * the log-space seed (:756-763), then `while not converged and count <= max_iter` of LogNormalMAPModel +
+ * CriticalFilter.update_power_spectrum, all device-resident.  I_scale as FrankFitter(I_scale=...) (:712).
+ * Outputs (host): s_map (N; I = exp(s_map + log I_scale), radial_fitters.py:392), p (N), niter (`count` at exit),
+ * Dinv (N*N, Hessian at the final MAP, may be NULL), stats (9 x int64 as above, may be NULL), diag_p / diag_s
+ * ((max_iter+1)*N each, both or neither): p and s of every pass (store_iteration_diagnostics).                  */
+int fh_fit_lognormal(fh_ctx *ctx, const double *M, const double *j, double alpha, double p0, double wsmooth,
+                     double tol, int max_iter, double I_scale, double *s_map, double *p, int *niter, double *Dinv,
+                     int64_t *stats, double *diag_p, double *diag_s);
+
+/* fh_posterior_update: CriticalFilter.update_power_spectrum(fit) (filter.py:154-177) for ANY posterior object the
+ * caller holds: map = fit.MAP (N), Dinv = the posterior precision (N*N row-major; fit.Dsolve applies its inverse),
+ * p = fit.power_spectrum.  The inverse is applied through a partial-pivoting LU on the device.  Output p_new (N). */
+int fh_posterior_update(fh_ctx *ctx, const double *map, const double *Dinv, const double *p, double alpha, double p0,
+                        double wsmooth, double *p_new);
 
 /* ---- multi-GPU: RCCL all-reduce of the sufficient statistics (one rank per GPU) ------------------------------
  * The reduction being distributed is `Ms[i] += ...; js[i] += ...` (statistical_models.py:210-211) and the

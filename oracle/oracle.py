@@ -193,3 +193,41 @@ def frank_fit_normal(N, Rmax, M, j, alpha=1.05, p0=1e-15, wsmooth=1e-4, tol=1e-3
     if diagnostics:
         out["diag_p"], out["diag_mu"] = dp[:niter.value], dm[:niter.value]
     return out
+
+
+def lognormal_map(dht, M, j, p, guess, s0):
+    """LogNormalMAPModel(DHT, M, j, p, guess=guess, s0=s0) (statistical_models.py:1012-1160).
+
+    Returns dict(s, Dinv, chol, Sinv, rc, stats=(status, nstep, nfev, nhess))."""
+    N = dht.N
+    Y = dht.coefficients()
+    s = np.array(guess, dtype="f8", order="C")
+    Dinv, chol, Sinv = np.empty((N, N)), np.empty((N, N)), np.empty((N, N))
+    stats = (ctypes.c_long * 4)()
+    rc = lib().fo_lognormal_map(ctypes.c_int(N), _p(Y), _p(_f8(M)), _p(_f8(j)), _p(_f8(p)), ctypes.c_double(s0),
+                                _p(s), _p(Dinv), _p(chol), _p(Sinv), stats)
+    return dict(s=s, Dinv=Dinv, chol=chol, Sinv=Sinv, rc=rc, stats=tuple(stats))
+
+
+def frank_fit_lognormal(N, Rmax, M, j, alpha=1.05, p0=1e-35, wsmooth=1e-4, tol=1e-3, max_iter=2000, I_scale=1e5,
+                        diagnostics=False):
+    """FrankFitter._fit, method='LogNormal' (radial_fitters.py:737-832). Rmax in radians.
+
+    Returns dict(s, I, p, niter, rc, Dinv, totals=(fits, nstep, nfev, nhess), status_hist[, diag_p, diag_s])."""
+    M, j = _f8(M), _f8(j)
+    s, p, Dinv = np.empty(N), np.empty(N), np.empty((N, N))
+    niter = ctypes.c_int(0)
+    totals, hist = (ctypes.c_long * 4)(), (ctypes.c_long * 5)()
+    dp = ds = None
+    if diagnostics:
+        dp, ds = np.zeros((max_iter + 1, N)), np.zeros((max_iter + 1, N))
+    s0 = float(np.log(I_scale))
+    rc = lib().fo_frank_fit_lognormal(ctypes.c_int(N), ctypes.c_double(Rmax), _p(M), _p(j), ctypes.c_double(alpha),
+                                      ctypes.c_double(p0), ctypes.c_double(wsmooth), ctypes.c_double(tol),
+                                      ctypes.c_int(max_iter), ctypes.c_double(s0), _p(s), _p(p), ctypes.byref(niter),
+                                      _p(Dinv), _p(dp), _p(ds), totals, hist)
+    out = dict(s=s, I=np.exp(s + s0), p=p, niter=niter.value, rc=rc, Dinv=Dinv, totals=tuple(totals),
+               status_hist=tuple(hist))
+    if diagnostics:
+        out["diag_p"], out["diag_s"] = dp[:niter.value], ds[:niter.value]
+    return out

@@ -413,3 +413,87 @@ def test_full_size_properties_1e7():
     res = Vc.real - sol.predict_deprojected(np.hypot(up, vp))
     chi2 = float(np.mean(res ** 2 * w[:200000]))
     assert 0.97 < chi2 < 1.03, chi2
+
+
+# ---- method='LogNormal' (a17 / a18): lognormal kernel ----------------------------------------------------------
+
+def _load_mapping(FF, g):
+    """what fit_preprocessed does after the hash check (radial_fitters.py:500-514), with the fixture's M, j"""
+    FF._M, FF._j, FF._H0 = np.array(g["M"]), np.array(g["j"]), float(g["H0"])
+
+
+@pytest.mark.parametrize("N", [40, 80])
+def test_lognormal_map_model(golden, N):
+    """LogNormalMAPModel on the device (fh_lognormal_model) vs the reference's MAP, Hessian, covariance and
+    MinimizeNewton exit on the seed power spectrum; then CriticalFilter.update_power_spectrum(fit)."""
+    from frank_amd import CriticalFilter, DiscreteHankelTransform, LogNormalMAPModel
+    g = golden("lognormal_N%d.npz" % N)
+    d = DiscreteHankelTransform(RMAX, N)
+    s0 = float(np.log(g["I_scale"]))
+    fit = LogNormalMAPModel(d, g["M"], g["j"], g["p_seed"], guess=g["s_guess"], s0=s0)
+    assert np.abs(fit.MAP - g["map_s"]).max() < 1e-9
+    assert rel_to_max(fit._Dinv, g["map_Dinv"]) < 1e-10
+    status, nstep, nfev, nhess = (int(x) for x in g["map_stats"])
+    st = fit._newton_stats
+    assert st[0] == 1 and st[4 + status] == 1 and st[3] == nhess
+    assert abs(st[1] - nstep) <= 0.01 * nstep + 2
+    np.testing.assert_allclose(np.diag(fit.covariance), g["map_cov_diag"], rtol=1e-7)
+    p_new = CriticalFilter(d, 1.3, 1e-35, 1e-2).update_power_spectrum(fit)
+    np.testing.assert_allclose(p_new, g["map_p_updated"], rtol=1e-7)
+    # error behaviour (statistical_models.py:1049-1057)
+    bad = g["p_seed"].copy()
+    bad[3] = -1.0
+    with pytest.raises(ValueError):
+        LogNormalMAPModel(d, g["M"], g["j"], bad, guess=g["s_guess"], s0=s0)
+
+
+def test_lognormal_fit_N80(golden):
+    """FrankFitter(method='LogNormal') end to end on the device, 968 passes, vs the reference (fixture) and the oracle.
+    Tolerances as in tests/test_oracle_golden.py::test_lognormal_fit_N80 (the fit is determined to the reference's own
+    round-off sensitivity, recorded in the fixture)."""
+    from frank_amd import FrankFitter, FrankLogNormalFit
+    g = golden("lognormal_N80.npz")
+    FF = FrankFitter(2.0, 80, geom(), alpha=float(g["alpha_a"]), weights_smooth=float(g["wsmooth_a"]),
+                     method="LogNormal", I_scale=float(g["I_scale"]), store_iteration_diagnostics=True, verbose=False,
+                     check_qbounds=False)
+    _load_mapping(FF, g)
+    sol = FF._fit()
+    assert isinstance(sol, FrankLogNormalFit)
+    d = FF.iteration_diagnostics
+    assert d["num_iterations"] == int(g["niter_a"])
+    for k in range(3):
+        np.testing.assert_allclose(d["power_spectrum"][k], g["diag_p_a"][k], rtol=1e-8)
+        assert np.abs(d["MAP"][k] - g["diag_s_a"][k]).max() < 1e-8
+    assert np.abs(sol.I / g["I_a"] - 1).max() < 5e-3
+    assert rel_to_max(sol.I, g["I_a"]) < 1e-3
+    np.testing.assert_allclose(sol.power_spectrum, g["p_a"], rtol=5e-3)
+    assert np.all(sol.I > 0) and sol.covariance.shape == (80, 80)
+    np.testing.assert_allclose(sol.MAP, np.exp(sol._fit.MAP + np.log(g["I_scale"])))
+    st = sol._fit._newton_stats
+    assert st[0] == d["num_iterations"] + 1 and sum(st[4:]) == st[0]
+
+
+def test_lognormal_fit_N40_and_max_iter(golden):
+    """The badly conditioned case (the reference differs from itself by ~1e-2, see the oracle test): stay inside a few
+    times the reference's own spread; and the max_iter / convergence_failure policy (radial_fitters.py:787-815)."""
+    from frank_amd import FrankFitter
+    g = golden("lognormal_N40.npz")
+    kw = dict(alpha=float(g["alpha_a"]), weights_smooth=float(g["wsmooth_a"]), method="LogNormal", verbose=False,
+              check_qbounds=False, store_iteration_diagnostics=True)
+    FF = FrankFitter(2.0, 40, geom(), **kw)
+    _load_mapping(FF, g)
+    sol = FF._fit()
+    np.testing.assert_allclose(FF.iteration_diagnostics["power_spectrum"][0], g["diag_p_a"][0], rtol=1e-8)
+    spread = abs(int(g["selfsens_niter_a"]) - int(g["niter_a"]))
+    assert abs(FF.iteration_diagnostics["num_iterations"] - int(g["niter_a"])) <= 3 * spread
+    assert rel_to_max(sol.I, g["I_a"]) < 5 * float(g["selfsens_I_relmax_a"])
+    FF3 = FrankFitter(2.0, 40, geom(), max_iter=3, **kw)
+    _load_mapping(FF3, g)
+    with pytest.raises(RuntimeError, match="Convergence not met"):
+        FF3._fit()
+    FF3i = FrankFitter(2.0, 40, geom(), max_iter=3, convergence_failure="ignore", **kw)
+    _load_mapping(FF3i, g)
+    FF3i._fit()
+    assert FF3i.iteration_diagnostics["num_iterations"] == 4
+    for k in range(4):
+        np.testing.assert_allclose(FF3i.iteration_diagnostics["power_spectrum"][k], g["diag_p_a"][k], rtol=1e-5)

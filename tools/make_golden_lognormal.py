@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Golden fixtures for the LogNormal branch (run in the BUILD container only; imports the reference).
+
+    python3 tools/make_golden_lognormal.py         # ~4 min
+
+Writes tests/golden/lognormal_N40.npz and lognormal_N80.npz:
+  * one LogNormalMAPModel solve (statistical_models.py:1012-1160) on the seed power spectrum: inputs, s_MAP,
+    Hessian at the MAP, posterior covariance diagonal, MinimizeNewton exit statistics;
+  * one CriticalFilter.update_power_spectrum from that solve (filter.py:154-177);
+  * whole FrankFitter(method='LogNormal') fits (radial_fitters.py:737-832): iteration count, final I and p, the
+    first passes' diagnostics -- and the reference's OWN sensitivity: the same fit after M is perturbed by 1e-15
+    relative (1 ulp-scale), because the Newton iteration is driven into round-off by design and the reference
+    ignores its exit status (statistical_models.py:1142-1145).  Parity tests use that spread as their scale.
+"""
+import collections
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, ".."))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+import scipy  # noqa: E402
+import frank  # noqa: E402
+import frank.statistical_models as sm  # noqa: E402
+from frank.filter import CriticalFilter  # noqa: E402
+from frank.geometry import FixedGeometry  # noqa: E402
+from frank.radial_fitters import FrankFitter  # noqa: E402
+from frank.statistical_models import GaussianModel, LogNormalMAPModel  # noqa: E402
+
+from frank_amd.mock import MOCK_GEOMETRY, mock_disc_visibilities  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+META = dict(reference_version=frank.__version__, numpy=np.__version__, scipy=scipy.__version__)
+RMAX = 2.0
+I_SCALE = 1e5
+
+_newton_stats = []
+_orig_newton = sm.MinimizeNewton
+
+
+def _recording_newton(*a, **k):
+    x, st = _orig_newton(*a, **k)
+    _newton_stats.append(st)
+    return x, st
+
+
+sm.MinimizeNewton = _recording_newton
+
+
+def fitter(N, alpha, ws, **kw):
+    # the mock's longest baselines exceed Qmax for these small N; the bounds check is not the subject here
+    return FrankFitter(RMAX, N, FixedGeometry(**MOCK_GEOMETRY), alpha=alpha, weights_smooth=ws, method="LogNormal",
+                       I_scale=I_SCALE, store_iteration_diagnostics=True, verbose=False,
+                       convergence_failure="ignore", check_qbounds=False, **kw)
+
+
+def whole_fit(N, alpha, ws, mapping, perturb_seed=0):
+    _newton_stats.clear()
+    FF = fitter(N, alpha, ws)
+    m = dict(mapping)
+    if perturb_seed:
+        rng = np.random.default_rng(perturb_seed)
+        Mp = m["M"] * (1 + 1e-15 * rng.standard_normal(m["M"].shape))
+        m["M"] = 0.5 * (Mp + Mp.T)
+    t0 = time.perf_counter()
+    sol = FF.fit_preprocessed(m)
+    dt = time.perf_counter() - t0
+    st = np.array(_newton_stats)
+    hist = collections.Counter(st[:, 0].tolist())
+    d = FF.iteration_diagnostics
+    return dict(I=sol.I, s=sol._fit.MAP, p=sol.power_spectrum, niter=d["num_iterations"], t_fit=dt,
+                diag_p=np.array(d["power_spectrum"][:6]), diag_s=np.array(d["MAP"][:6]),
+                status_hist=np.array([hist.get(k, 0) for k in range(4)]),
+                totals=np.array([len(st), st[:, 1].sum(), st[:, 2].sum(), st[:, 3].sum()]))
+
+
+def case(name, N, n, fits):
+    print("LogNormal N=%d, %d vis" % (N, n))
+    u, v, V, w = mock_disc_visibilities(n, seed=5, noise_seed=6)
+    FF = fitter(N, 1.05, 1e-4)
+    mapping = FF.preprocess_visibilities(u, v, V, w)
+    M, j = mapping["M"], mapping["j"]
+    out = dict(N=N, n=n, seed=5, noise_seed=6, Rmax=RMAX, I_scale=I_SCALE, M=M, j=j, H0=mapping["null_likelihood"])
+    D = FF._DHT
+    # seeds of FrankFitter._fit (radial_fitters.py:744-763)
+    fit = GaussianModel(D, M, j, np.ones(N), guess=np.ones(N))
+    pI = np.max(D.transform(fit.MAP) ** 2) * (D.q / D.q[0]) ** -2
+    fit = GaussianModel(D, M, j, pI)
+    s0 = np.log(I_SCALE)
+    s_guess = np.log(np.maximum(fit.MAP, 1e-3 * fit.MAP.max())) - s0
+    p_seed = np.max(D.transform(s_guess) ** 2) * (D.q / D.q[0]) ** -4
+    _newton_stats.clear()
+    ln = LogNormalMAPModel(D, M, j, p_seed, guess=s_guess.copy(), s0=s0)
+    filt = CriticalFilter(D, 1.3, 1e-35, 1e-2)
+    out.update(seed_mu=fit.MAP, s_guess=s_guess, p_seed=p_seed, map_s=ln.MAP, map_Dinv=_hess(ln),
+               map_cov_diag=np.diag(ln.covariance).copy(), map_stats=np.array(_newton_stats[-1]),
+               map_p_updated=filt.update_power_spectrum(ln))
+    print("   MAP solve exit (status, nstep, nfev, nhess) =", _newton_stats[-1])
+    for tag, (alpha, ws) in fits.items():
+        a = whole_fit(N, alpha, ws, mapping)
+        b = whole_fit(N, alpha, ws, mapping, perturb_seed=1)
+        out["alpha_" + tag], out["wsmooth_" + tag] = alpha, ws
+        for k, val in a.items():
+            out["%s_%s" % (k, tag)] = val
+        out["selfsens_I_rel_" + tag] = np.max(np.abs(b["I"] / a["I"] - 1))
+        out["selfsens_I_relmax_" + tag] = np.max(np.abs(b["I"] - a["I"])) / a["I"].max()
+        out["selfsens_niter_" + tag] = b["niter"]
+        print("   fit %s: alpha=%g ws=%g niter=%d (perturbed: %d)  %.1fs  exits=%s  self-sensitivity: %.2e elementwise, "
+              "%.2e of max" % (tag, alpha, ws, a["niter"], b["niter"], a["t_fit"], a["status_hist"],
+                               out["selfsens_I_rel_" + tag], out["selfsens_I_relmax_" + tag]))
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **out, **{"meta_" + k: v for k, v in META.items()})
+    print("  wrote %s %.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+def _hess(ln):
+    """Hessian at the MAP: what LogNormalMAPModel._fit factorises (statistical_models.py:1147-1149)."""
+    # cho_factor output holds the upper factor in the upper triangle (lower is untouched input garbage)
+    U = np.triu(ln._Dchol[0])
+    return U.T @ U
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    case("lognormal_N40.npz", 40, 5000, dict(a=(1.3, 1e-2)))
+    case("lognormal_N80.npz", 80, 20000, dict(a=(1.05, 1e-4)))
+
+
+if __name__ == "__main__":
+    main()
