@@ -111,7 +111,7 @@ struct fh_ctx {
     // scratch for coefficient / predict calls
     DevBuf<double> scratch_q, scratch_out, scratch_I;
     // LogNormal (lognormal.hip)
-    DevBuf<double> ln_Sinv, ln_H, ln_LU, ln_s, ln_p, ln_pin, ln_guess, ln_diag_p, ln_diag_s;
+    DevBuf<double> ln_Sinv, ln_H, ln_LU, ln_Hinv, ln_s, ln_p, ln_pin, ln_guess, ln_diag_p, ln_diag_s;
     DevBuf<int> ln_result;
     DevBuf<long long> ln_stats;
 };
@@ -1171,12 +1171,13 @@ static int ln_prepare(fh_ctx *c, const double *M, const double *j, LogNormalPara
         HIP_TRY(c->ln_Sinv.alloc(NN));
         HIP_TRY(c->ln_H.alloc(NN));
         HIP_TRY(c->ln_LU.alloc(NN));
+        HIP_TRY(c->ln_Hinv.alloc(NN));
         HIP_TRY(c->ln_s.alloc(N));
         HIP_TRY(c->ln_p.alloc(N));
         HIP_TRY(c->ln_pin.alloc(N));
         HIP_TRY(c->ln_guess.alloc(N));
         HIP_TRY(c->ln_result.alloc(2));
-        HIP_TRY(c->ln_stats.alloc(9));
+        HIP_TRY(c->ln_stats.alloc(17));
     }
     P = LogNormalParams{};
     P.N = N;
@@ -1193,6 +1194,7 @@ static int ln_prepare(fh_ctx *c, const double *M, const double *j, LogNormalPara
     P.Sinv = c->ln_Sinv.p;
     P.H = c->ln_H.p;
     P.LU = c->ln_LU.p;
+    P.Hinv = c->ln_Hinv.p;
     P.s_out = c->ln_s.p;
     P.p_out = c->ln_p.p;
     P.result = c->ln_result.p;
@@ -1211,6 +1213,14 @@ static int ln_finish(fh_ctx *c, double *s, double *p, double *Dinv, int64_t *sta
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (stats)
         for (int k = 0; k < 9; ++k) stats[k] = st[k];
+#ifdef LN_TIMING
+    {
+        long long cyc[8];
+        HIP_TRY(hipMemcpy(cyc, c->ln_stats.p + 9, sizeof cyc, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[ln timing, Mcycles] eval %.1f  lu %.1f  solve %.1f (fwd chain %.1f, bwd chain %.1f)  hess %.1f  newton total %.1f\n",
+                cyc[0] / 1e6, cyc[1] / 1e6, cyc[2] / 1e6, cyc[5] / 1e6, cyc[6] / 1e6, cyc[3] / 1e6, cyc[4] / 1e6);
+    }
+#endif
     if (result[1] == LN_STATUS_BAD_P) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (non-positive or NaN)");
     if (result[1] == LN_STATUS_SLOPE) return fail(FH_ERR_NUMERIC, "Round off in slope calculation (LineSearch)");
     return FH_OK;

@@ -123,6 +123,7 @@ struct LogNormalParams {
     const double *p_in;           // LN_MODE_MAP: power spectrum
     const double *guess;          // LN_MODE_MAP: starting s;  LN_MODE_FIT: MAP of the Normal seed fit (radial_fitters.py:752)
     double *Sinv, *H, *LU;        // N*N work: prior precision, Hessian at the MAP (output Dinv), LU factors when N > 112
+    double *Hinv;                 // N*N work: explicit inverse of a Hessian that keeps being re-used
     double *s_out, *p_out;        // N
     int *result;                  // [0] count, [1] status
     long long *stats;             // [0] MAP solves, [1] Newton steps, [2] function evaluations, [3] Hessians, [4..8] exits 0-4

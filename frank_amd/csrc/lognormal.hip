@@ -18,6 +18,7 @@
 // instead of a Cholesky factor (the reference falls back to an SVD inverse when the Cholesky fails,
 // statistical_models.py:1150-1158 -- the same matrix); jac(x) re-uses the products of the accepted fun(x).
 #include <hip/hip_runtime.h>
+#include <rocprim/warp/warp_reduce.hpp>
 
 #include "kernels.h"
 
@@ -25,106 +26,154 @@
 
 namespace {
 
+#ifdef LN_TIMING
+__shared__ long long ln_cyc[8];
+#define LTIC() const long long _t0 = clock64()
+#define LTOC(k) do { if (threadIdx.x == 0) ln_cyc[k] += clock64() - _t0; } while (0)
+#else
+#define LTIC() do {} while (0)
+#define LTOC(k) do {} while (0)
+#endif
+
 constexpr int LT = 512;        // threads per workgroup
 constexpr int LNW = LT / 64;   // waves
-constexpr int LN_TMAX = 5;     // 64-row register slabs of a solve vector (N <= 320)
 constexpr int LS_MAX_TRIALS = 2000;  // back-tracking guard: lam shrinks >= 10x per trial, x + lam p == x long before
 
 struct LnS {
     double *x, *xn, *I, *In, *Sx, *Sxn, *MI, *MIn, *jx, *dx, *pd, *jv, *p, *pold, *rhs, *tr2, *col, *rowk, *rdiag, *red;
+    double *part;  // 2 * LT: per-chunk partial products of ln_eval
+    double *wsol;  // LNW * N: per-wave solve vectors
     int *perm, *ipiv;
-    double *lu;  // N*N column-major: LDS or global
+    double *lu;    // N*N column-major: LDS or global
+    int redsel;
+    int row, c0, c1, slot;  // ln_eval work split: this thread sums columns [c0, c1) of output `row` into part[slot]
+    int nch;
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+// Wave reductions through DPP row operations (rocprim), result broadcast to every lane.
+template <class T, class Op>
+__device__ __forceinline__ T wave_reduce(T v, Op op) {
+    using WR = rocprim::warp_reduce<T, 64, true>;
+    typename WR::storage_type st;
+    T out;
+    WR().reduce(v, out, st, op);
+    return out;
+}
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce(v, rocprim::plus<double>()); }
+
+// Block reductions: every thread returns the same bits (wave partials combined in wave order by every thread).
+// Two partial buffers used alternately: a thread can only reach the next-but-one reduction after every thread has
+// passed the barrier of the next one, i.e. has finished reading this one -- no trailing barrier needed.
+__device__ __forceinline__ double *red_buf(LnS &S) {
+    S.redsel ^= 1;
+    return S.red + 32 * S.redsel;
 }
 
-// Block reductions: every thread returns the same bits (partials combined in wave order by every thread).
-__device__ double block_sum(LnS &S, double v) {
+__device__ __forceinline__ double block_sum(LnS &S, double v) {
+    double *red = red_buf(S);
     v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) S.red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     double r = 0.0;
 #pragma unroll
-    for (int w = 0; w < LNW; ++w) r += S.red[w];
-    __syncthreads();
+    for (int w = 0; w < LNW; ++w) r += red[w];
     return r;
 }
 
-__device__ void block_sum3(LnS &S, double &a, double &b, double &c) {
+__device__ __forceinline__ void block_sum3(LnS &S, double &a, double &b, double &c) {
+    double *red = red_buf(S);
     a = wave_sum(a);
     b = wave_sum(b);
     c = wave_sum(c);
     if ((threadIdx.x & 63) == 0) {
         const int w = threadIdx.x >> 6;
-        S.red[3 * w] = a;
-        S.red[3 * w + 1] = b;
-        S.red[3 * w + 2] = c;
+        red[3 * w] = a;
+        red[3 * w + 1] = b;
+        red[3 * w + 2] = c;
     }
     __syncthreads();
     double ra = 0.0, rb = 0.0, rc = 0.0;
 #pragma unroll
     for (int w = 0; w < LNW; ++w) {
-        ra += S.red[3 * w];
-        rb += S.red[3 * w + 1];
-        rc += S.red[3 * w + 2];
+        ra += red[3 * w];
+        rb += red[3 * w + 1];
+        rc += red[3 * w + 2];
     }
-    __syncthreads();
     a = ra;
     b = rb;
     c = rc;
 }
 
 template <bool IS_MAX>
-__device__ double block_minmax(LnS &S, double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double o = __shfl_xor(v, off);
-        v = IS_MAX ? fmax(v, o) : fmin(v, o);
-    }
-    if ((threadIdx.x & 63) == 0) S.red[threadIdx.x >> 6] = v;
+__device__ __forceinline__ double block_minmax(LnS &S, double v) {
+    double *red = red_buf(S);
+    v = IS_MAX ? wave_reduce(v, rocprim::maximum<double>()) : wave_reduce(v, rocprim::minimum<double>());
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    double r = S.red[0];
+    double r = red[0];
 #pragma unroll
-    for (int w = 1; w < LNW; ++w) r = IS_MAX ? fmax(r, S.red[w]) : fmin(r, S.red[w]);
-    __syncthreads();
+    for (int w = 1; w < LNW; ++w) r = IS_MAX ? fmax(r, red[w]) : fmin(r, red[w]);
     return r;
 }
 
-// H(s) = 1/2 s^T S^-1 s + 1/2 I^T M I - j^T I,  I = exp(s + s0)   (statistical_models.py:1075-1085)
-// leaves I, S^-1 s and M I of the point in Iv, Sxv, MIv (the gradient and the Hessian diagonal re-use them).
-__device__ double ln_eval(const LogNormalParams &P, LnS &S, const double *xv, double *Iv, double *Sxv, double *MIv) {
-    const int N = P.N, tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    for (int i = tid; i < N; i += LT) Iv[i] = exp(xv[i] + P.s0);
+// min of a and sum of b in one pass (step limiter and slope of the line search)
+__device__ __forceinline__ void block_min_sum(LnS &S, double &a, double &b) {
+    double *red = red_buf(S);
+    a = wave_reduce(a, rocprim::minimum<double>());
+    b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) {
+        red[2 * (threadIdx.x >> 6)] = a;
+        red[2 * (threadIdx.x >> 6) + 1] = b;
+    }
     __syncthreads();
-    for (int r = w; r < N; r += LNW) {
-        const double *sr = P.Sinv + (size_t)r * N, *mr = P.M + (size_t)r * N;
+    double ra = red[0], rb = red[1];
+#pragma unroll
+    for (int w = 1; w < LNW; ++w) {
+        ra = fmin(ra, red[2 * w]);
+        rb += red[2 * w + 1];
+    }
+    a = ra;
+    b = rb;
+}
+
+// H(s) = 1/2 s^T S^-1 s + 1/2 I^T M I - j^T I,  I = exp(s + s0)   (statistical_models.py:1075-1085)
+// Iv = exp(xv + s0) is the caller's; leaves S^-1 s and M I of the point in Sxv, MIv (gradient and Hessian re-use them).
+// The two matrix-vector products are split by column chunks over all threads: thread (row, chunk) walks down a
+// COLUMN of the symmetric matrices, so a wave reads consecutive addresses and nothing crosses lanes.
+__device__ __forceinline__ double ln_eval(const LogNormalParams &P, LnS &S, const double *xv, double *Iv, double *Sxv, double *MIv) {
+    const int N = P.N, tid = threadIdx.x;
+    LTIC();
+    if (S.row >= 0) {
+        const int o = S.c0 * N + S.row;
+        const double *sc = P.Sinv + o, *mc = P.M + o;
         double a = 0.0, b = 0.0;
-        for (int c = l; c < N; c += 64) {
-            a = fma(sr[c], xv[c], a);
-            b = fma(mr[c], Iv[c], b);
+#pragma unroll 8
+        for (int c = S.c0; c < S.c1; ++c, sc += N, mc += N) {
+            a = fma(*sc, xv[c], a);
+            b = fma(*mc, Iv[c], b);
         }
-        a = wave_sum(a);
-        b = wave_sum(b);
-        if (l == 0) {
-            Sxv[r] = a;
-            MIv[r] = b;
-        }
+        S.part[S.slot] = a;
+        S.part[LT + S.slot] = b;
     }
     __syncthreads();
     double A = 0.0, B = 0.0, C = 0.0;
-    for (int i = tid; i < N; i += LT) {
-        A += xv[i] * Sxv[i];
-        B += Iv[i] * MIv[i];
-        C += Iv[i] * S.jv[i];
+    if (tid < N) {
+        double a = 0.0, b = 0.0;
+        for (int ch = 0; ch < S.nch; ++ch) {
+            a += S.part[ch * N + tid];
+            b += S.part[LT + ch * N + tid];
+        }
+        Sxv[tid] = a;
+        MIv[tid] = b;
+        A = xv[tid] * a;
+        B = Iv[tid] * b;
+        C = Iv[tid] * S.jv[tid];
     }
     block_sum3(S, A, B, C);
     double f = 0.5 * A;
     f += 0.5 * B;
     f -= C;
+    LTOC(0);
     return f;
 }
 
@@ -135,155 +184,170 @@ __device__ __forceinline__ double ln_grad(const LnS &S, int i) {
 
 // hess(s) = I_a M_ab I_b + delta_ab (I_a (M I)_a - I_a j_a) + S^-1_ab   (statistical_models.py:1100-1122), at S.x,
 // written column-major into A (and into `copy` when given).  M is exactly symmetric, S^-1 to round-off.
-__device__ void build_hess(const LogNormalParams &P, LnS &S, double *A, double *copy) {
+__device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, double *A, double *copy) {
     const int N = P.N, tid = threadIdx.x;
+    LTIC();
     for (int b = tid >> 5; b < N; b += LT / 32) {
         const double Ib = S.I[b];
-        const double *mb = P.M + (size_t)b * N, *sb = P.Sinv + (size_t)b * N;
+        const double *mb = P.M + b * N, *sb = P.Sinv + b * N;
         for (int a = tid & 31; a < N; a += 32) {
             double v = S.I[a] * mb[a] * Ib;
             if (a == b) v += S.I[a] * S.MI[a] - S.I[a] * S.jv[a];
             v += sb[a];
-            A[(size_t)b * N + a] = v;
-            if (copy) copy[(size_t)a * N + b] = v;  // row-major H_ab
+            A[b * N + a] = v;
+            if (copy) copy[a * N + b] = v;  // row-major H_ab
         }
     }
     __syncthreads();
+    LTOC(3);
 }
 
-// Partial-pivoting LU in place (column-major, unit lower), three barriers per column; perm[i] = source row of row i,
-// rdiag[i] = 1 / U_ii.  A zero pivot leaves the column unscaled (LAPACK getf2 does the same and reports it).
-__device__ void lu_factor(LnS &S, int N, double *A) {
-    const int tid = threadIdx.x;
+// Partial-pivoting LU in place (column-major, unit lower); perm[i] = source row of row i, rdiag[i] = 1 / U_ii.
+// Two barriers per column: every wave finds the pivot of column k for itself (same data, same reduction, same
+// answer -- no broadcast, no barrier), then
+//   phase A: rows k <-> piv are exchanged OUTSIDE column k, the new row k and the scaled column k are staged in LDS
+//            vectors (column k itself is only read, so a wave still searching it sees the old values);
+//   phase B: the scaled column is written back and the trailing block gets its rank-1 update.
+// A zero pivot leaves the column unscaled (LAPACK getf2 does the same and reports it).
+__device__ __forceinline__ void lu_factor(LnS &S, int N, double *A) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    LTIC();
+    for (int i = tid; i < N; i += LT) S.perm[i] = i;
+    __syncthreads();
     for (int k = 0; k < N; ++k) {
-        if (tid < 64) {  // first maximum of |A[k:, k]|
-            double best = -1.0;
-            int bi = k;
-            for (int i = k + tid; i < N; i += 64) {
-                const double v = fabs(A[(size_t)k * N + i]);
-                if (v > best) {
-                    best = v;
-                    bi = i;
-                }
-            }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const double ob = __shfl_xor(best, off);
-                const int oi = __shfl_xor(bi, off);
-                if (ob > best || (ob == best && oi < bi)) {
-                    best = ob;
-                    bi = oi;
-                }
-            }
-            if (tid == 0) {
-                S.ipiv[k] = bi;
-                S.red[0] = A[(size_t)k * N + bi];
+        const double *ck = A + k * N;
+        double best = -1.0;
+        int bi = 0x7fffffff;
+        for (int i = k + lane; i < N; i += 64) {  // first maximum of |A[k:, k]|
+            const double v = fabs(ck[i]);
+            if (v > best) {
+                best = v;
+                bi = i;
             }
         }
-        __syncthreads();
-        const int piv = S.ipiv[k];
-        const double pv = S.red[0];
-        // swap rows k <-> piv outside column k, stage the new row k and the scaled column k
+        const double top = wave_reduce(best, rocprim::maximum<double>());
+        int piv = wave_reduce(best == top ? bi : 0x7fffffff, rocprim::minimum<int>());
+        if (piv >= N) piv = k;  // all-NaN column: keep the diagonal
+        const double pv = ck[piv], dkk = ck[k];
+        // phase A
         for (int j = tid; j < N; j += LT) {
             if (j == k) continue;
-            const double a = A[(size_t)j * N + k], b = A[(size_t)j * N + piv];
+            const double a = A[j * N + k], b = A[j * N + piv];
             if (piv != k) {
-                A[(size_t)j * N + k] = b;
-                A[(size_t)j * N + piv] = a;
+                A[j * N + k] = b;
+                A[j * N + piv] = a;
             }
             if (j > k) S.rowk[j] = b;
         }
         for (int i = k + 1 + tid; i < N; i += LT) {
-            const double v = (i == piv) ? A[(size_t)k * N + k] : A[(size_t)k * N + i];
-            const double lv = (pv != 0.0) ? v / pv : v;
-            A[(size_t)k * N + i] = lv;
-            S.col[i] = (pv != 0.0) ? lv : 0.0;
-            if (i == piv) A[(size_t)k * N + k] = pv;
+            const double v = (i == piv) ? dkk : ck[i];
+            S.col[i] = (pv != 0.0) ? v / pv : v;
         }
-        if (tid == 0) S.rdiag[k] = 1.0 / pv;
-        __syncthreads();
-        // trailing update A[i, j] -= l_i u_j
-        for (int j = k + 1 + (tid >> 5); j < N; j += LT / 32) {
-            const double uj = S.rowk[j];
-            double *cj = A + (size_t)j * N;
-            for (int i = k + 1 + (tid & 31); i < N; i += 32) cj[i] = fma(-S.col[i], uj, cj[i]);
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        for (int i = 0; i < N; ++i) S.perm[i] = i;
-        for (int k = 0; k < N; ++k) {
-            const int pk = S.ipiv[k];
-            if (pk != k) {
+        if (tid == LT - 1) {
+            S.rdiag[k] = 1.0 / pv;
+            if (piv != k) {
                 const int t = S.perm[k];
-                S.perm[k] = S.perm[pk];
-                S.perm[pk] = t;
+                S.perm[k] = S.perm[piv];
+                S.perm[piv] = t;
             }
         }
+        __syncthreads();
+        // phase B
+        for (int i = k + tid; i < N; i += LT) A[k * N + i] = (i == k) ? pv : S.col[i];
+        if (pv != 0.0)
+            for (int j = k + 1 + (tid >> 5); j < N; j += LT / 32) {
+                const double uj = S.rowk[j];
+                double *cj = A + j * N;
+                for (int i = k + 1 + (tid & 31); i < N; i += 32) cj[i] = fma(-S.col[i], uj, cj[i]);
+            }
+        __syncthreads();
     }
-    __syncthreads();
+    LTOC(1);
 }
 
-// One wave solves (P L U) x = sign * b; lane l keeps x[l], x[64 + l], ... in registers.
-__device__ void lu_solve_regs(const LnS &S, int N, const double *A, const double *b, double sign, double (&x)[LN_TMAX]) {
+__device__ __forceinline__ double lane_bcast(double v, int l) {  // l uniform: v_readlane, no LDS round trip
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void wave_sync() {  // LDS traffic between the lanes of ONE wave: order it, no s_barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One wave solves (P L U) x = sign * b into xs (LDS, N doubles owned by the wave).  64 rows at a time, lane = row:
+// the part of the row left of (right of, for U) the diagonal block is a dot product with the already known x, read
+// down the columns of the column-major factors (coalesced).  Inside the 64 x 64 diagonal block the substitution
+// chain runs on v_readlane broadcasts, eight columns per trip of a ROLLED loop (the kernel has to stay inside the
+// instruction cache), the next eight columns in flight while the chain of the current eight executes.
+// b == nullptr: the right-hand side is the unit vector e_unit.
+__device__ __forceinline__ void wave_solve(const LnS &S, int N, const double *A, const double *b, int unit, double sign,
+                                           double *xs) {
     const int lane = threadIdx.x & 63;
-    const int T = (N + 63) >> 6;
+    for (int jj = lane; jj < N; jj += 64) xs[jj] = b ? sign * b[S.perm[jj]] : (S.perm[jj] == unit ? sign : 0.0);
+    wave_sync();
+    for (int k0 = 0; k0 < N; k0 += 64) {  // L y = P b, unit lower
+        const int r = k0 + lane, rc = min(r, N - 1);
+        const int ng = (min(64, N - k0) + 7) >> 3;
+        double acc = (r < N) ? xs[r] : 0.0;
+#pragma unroll 8
+        for (int c = 0; c < k0; ++c) acc = fma(-A[c * N + rc], xs[c], acc);
+        double nxt[8];
 #pragma unroll
-    for (int t = 0; t < LN_TMAX; ++t) {
-        const int jj = 64 * t + lane;
-        x[t] = (jj < N) ? sign * b[S.perm[jj]] : 0.0;
-    }
+        for (int u = 0; u < 8; ++u) nxt[u] = A[min(k0 + u, N - 1) * N + rc];
+#pragma unroll 1
+        for (int g = 0; g < ng; ++g) {
+            double cur[8];
 #pragma unroll
-    for (int t = 0; t < LN_TMAX; ++t) {  // L y = b (unit lower), column by column
-        if (t >= T) break;
-        const int lim = min(64, N - 64 * t);
-        for (int l = 0; l < lim; ++l) {
-            const int i = 64 * t + l;
-            const double xi = __shfl(x[t], l);
-            const double *ci = A + (size_t)i * N;
+            for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+            if (g + 1 < ng) {
 #pragma unroll
-            for (int t2 = t; t2 < LN_TMAX; ++t2) {
-                const int jj = 64 * t2 + lane;
-                if (t2 < T && jj > i && jj < N) x[t2] = fma(-ci[jj], xi, x[t2]);
+                for (int u = 0; u < 8; ++u) nxt[u] = A[min(k0 + 8 * g + 8 + u, N - 1) * N + rc];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = 8 * g + u;  // rows below the diagonal of column k0 + c (columns past N see x = 0)
+                acc = fma(-((lane > c && r < N) ? cur[u] : 0.0), lane_bcast(acc, c), acc);
             }
         }
+        if (r < N) xs[r] = acc;
+        wave_sync();
     }
+    for (int k0 = 64 * ((N - 1) / 64); k0 >= 0; k0 -= 64) {  // U x = y
+        const int r = k0 + lane, rc = min(r, N - 1);
+        const int ng = (min(64, N - k0) + 7) >> 3;
+        double acc = (r < N) ? xs[r] : 0.0;
+#pragma unroll 8
+        for (int c = k0 + 64; c < N; ++c) acc = fma(-A[c * N + rc], xs[c], acc);
+        const double rd = (r < N) ? S.rdiag[r] : 0.0;
+        double nxt[8];
 #pragma unroll
-    for (int t = LN_TMAX - 1; t >= 0; --t) {  // U x = y
-        if (t >= T) continue;
-        const int lim = min(64, N - 64 * t);
-        for (int l = lim - 1; l >= 0; --l) {
-            const int i = 64 * t + l;
-            const double xi = __shfl(x[t], l) * S.rdiag[i];
-            if (lane == l) x[t] = xi;
-            const double *ci = A + (size_t)i * N;
+        for (int u = 0; u < 8; ++u) nxt[u] = A[min(k0 + 8 * (ng - 1) + u, N - 1) * N + rc];
+#pragma unroll 1
+        for (int g = ng - 1; g >= 0; --g) {
+            double cur[8];
 #pragma unroll
-            for (int t2 = 0; t2 <= t; ++t2) {
-                const int jj = 64 * t2 + lane;
-                if (jj < i) x[t2] = fma(-ci[jj], xi, x[t2]);
+            for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+            if (g > 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) nxt[u] = A[(k0 + 8 * g - 8 + u) * N + rc];
+            }
+#pragma unroll
+            for (int u = 7; u >= 0; --u) {
+                const int c = 8 * g + u;  // lanes past the last row carry rd = 0: their "pivot" broadcasts 0
+                const double xi = lane_bcast(acc * rd, c);
+                acc = (lane == c) ? xi : acc;
+                acc = fma(-((lane < c) ? cur[u] : 0.0), xi, acc);
             }
         }
+        if (r < N) xs[r] = acc;
+        wave_sync();
     }
 }
 
-// limit_step (statistical_models.py:1126-1130) into S.pd, and delta_f = jac . p (minimizer.py:131-134)
-__device__ double limited_step(LnS &S, int N, const double *dir) {
-    const int tid = threadIdx.x;
-    double am = INFINITY;
-    for (int i = tid; i < N; i += LT) am = fmin(am, fabs(S.x[i] / dir[i]));
-    am = block_minmax<false>(S, am);
-    double alpha = 1.1 * am;
-    if (1.0 < alpha) alpha = 1.0;
-    double df = 0.0;
-    for (int i = tid; i < N; i += LT) {
-        const double pi = alpha * dir[i];
-        S.pd[i] = pi;
-        df += S.jx[i] * pi;
-    }
-    return block_sum(S, df);
-}
-
-__device__ void accept_trial(LnS &S, int N) {
+__device__ __forceinline__ void accept_trial(LnS &S, int N) {
     for (int i = threadIdx.x; i < N; i += LT) {
         S.x[i] = S.xn[i];
         S.I[i] = S.In[i];
@@ -293,30 +357,58 @@ __device__ void accept_trial(LnS &S, int N) {
     __syncthreads();
 }
 
-// LineSearch.__call__(fun, jac, x, dir, fx, root=False)  (minimizer.py:70-187).
-// returns 0 accepted (x, fx, reduction updated), 1 failed, -1 "Round off in slope calculation".
-__device__ int line_search(const LogNormalParams &P, LnS &S, const double *dir, double &fx, int &nfev, double &reduction) {
+// One back-tracking pass along `dir` from S.x -- the single place in the Newton loop where the objective is
+// evaluated (one copy of the code in the instruction cache):
+//   fallback == false: LineSearch.__call__(fun, jac, x, dir, fx, root=False)  (minimizer.py:70-187) with
+//                      reduce_step = limit_step (statistical_models.py:1126-1130); acceptance by the Armijo rule,
+//                      quadratic / cubic model for the next step length;
+//   fallback == true : the last resort of MinimizeNewton (minimizer.py:256-267): ten trials with the step divided by
+//                      16 each time, accepted as soon as the objective decreases.
+// amin = min |x / dir| and slope = jac . dir come from the caller's reduction.
+// returns 0 accepted (x, fx updated; reduction too for the line search), 1 failed, -1 "Round off in slope calculation".
+__device__ __forceinline__ int backtrack(const LogNormalParams &P, LnS &S, const double *dir, double amin, double slope,
+                                         bool fallback, double &fx, int &nfev, double &reduction) {
     const int N = P.N, tid = threadIdx.x;
     const double armijo = 1e-4, l_min = 0.1;
     const double cost = fx;
-    const double delta_f = limited_step(S, N, dir);
-    if (delta_f > 0) return -1;
+    double alpha = 1.1 * amin;
+    if (1.0 < alpha) alpha = 1.0;
+    double delta_f = slope;  // alpha == 1: p = dir bit for bit, and jac . p is the caller's sum
+    const double *p = dir;
+    if (alpha != 1.0) {
+        double df = 0.0;
+        for (int i = tid; i < N; i += LT) {
+            const double pi = alpha * dir[i];
+            S.pd[i] = pi;
+            df += S.jx[i] * pi;
+        }
+        delta_f = block_sum(S, df);
+        p = S.pd;
+    }
+    if (!fallback && delta_f > 0) return -1;
     double lam = 1.0, cost_save = 0.0, lam_save = 0.0;
-    for (int trial = 0; trial < LS_MAX_TRIALS; ++trial) {
+    const int max_trials = fallback ? 10 : LS_MAX_TRIALS;
+    for (int trial = 0; trial < max_trials; ++trial) {
         int moved = 0;
         for (int i = tid; i < N; i += LT) {
-            const double xn = S.x[i] + lam * S.pd[i];
+            const double xn = S.x[i] + lam * p[i];
             S.xn[i] = xn;
+            S.In[i] = exp(xn + P.s0);
             moved |= (xn != S.x[i]);
         }
-        if (!__syncthreads_or(moved)) return 1;
+        moved = __syncthreads_or(moved);
+        if (!fallback && !moved) return 1;
         const double cost_new = ln_eval(P, S, S.xn, S.In, S.Sxn, S.MIn);
         ++nfev;
-        if (cost_new <= (cost + armijo * lam * delta_f)) {
-            reduction = lam;
+        if (fallback ? (cost_new < cost) : (cost_new <= (cost + armijo * lam * delta_f))) {
+            if (!fallback) reduction = lam;
             accept_trial(S, N);
             fx = cost_new;
             return 0;
+        }
+        if (fallback) {
+            lam *= 0.0625;  // dx *= 2**-4: exact, so x + lam p carries the reference's bits
+            continue;
         }
         double lam_new;
         if (lam == 1.0) {
@@ -349,74 +441,104 @@ struct NewtonExit {
 };
 
 // MinimizeNewton(H, jac, hess, S.x, LineSearch(reduce_step=limit_step), tol=1e-7)  (minimizer.py:190-283)
-__device__ NewtonExit minimize_newton(const LogNormalParams &P, LnS &S) {
+__device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, LnS &S) {
     const int N = P.N, tid = threadIdx.x;
     bool need_hess = true;
     int nfev = 1, nhess = 0;
     double reduction = NAN;  // LineSearch.reduction starts as None
+    int reuse = 0;
+    bool have_inv = false;
+    const int inv_after = max(2, N >> 3);
+    for (int i = tid; i < N; i += LT) S.I[i] = exp(S.x[i] + P.s0);
+    __syncthreads();
     double fx = ln_eval(P, S, S.x, S.I, S.Sx, S.MI);
+    for (int i = tid; i < N; i += LT) S.jx[i] = ln_grad(S, i);
+    __syncthreads();
     for (int nstep = 0; nstep < P.max_step; ++nstep) {
         if (need_hess) {
             if (nhess == P.max_hev) return {3, nstep, nfev, nhess};
             build_hess(P, S, S.lu, nullptr);
             lu_factor(S, N, S.lu);
             ++nhess;
+            reuse = 0;
+            have_inv = false;
         }
-        for (int i = tid; i < N; i += LT) S.jx[i] = ln_grad(S, i);
-        __syncthreads();
-        if (tid < 64) {
-            double xr[LN_TMAX];
-            lu_solve_regs(S, N, S.lu, S.jx, -1.0, xr);
-#pragma unroll
-            for (int t = 0; t < LN_TMAX; ++t)
-                if (64 * t + tid < N) S.dx[64 * t + tid] = xr[t];
-        }
-        __syncthreads();
-        double d = 0.0;
-        for (int i = tid; i < N; i += LT) d += S.jx[i] * S.dx[i];
-        d = block_sum(S, d);
-        int failed;
-        if (d < 0) {
-            failed = line_search(P, S, S.dx, fx, nfev, reduction);
-            if (failed < 0) return {4, nstep, nfev, nhess};
-        } else {
-            failed = 1;
-        }
-        if (failed) {  // gradient descent when Newton's direction does not improve (minimizer.py:249-271)
-            for (int i = tid; i < N; i += LT) S.dx[i] = -S.jx[i];
-            __syncthreads();
-            const int failed_descent = line_search(P, S, S.dx, fx, nfev, reduction);
-            if (failed_descent < 0) return {4, nstep, nfev, nhess};
-            if (failed_descent) {
-                (void)limited_step(S, N, S.dx);
-                bool improved = false;
-                double fn = fx;
-                for (int it = 0; it < 10; ++it) {
-                    for (int i = tid; i < N; i += LT) S.xn[i] = S.x[i] + S.pd[i];
-                    __syncthreads();
-                    fn = ln_eval(P, S, S.xn, S.In, S.Sxn, S.MIn);
-                    ++nfev;
-                    if (fn < fx) {
-                        improved = true;
-                        break;
-                    }
-                    for (int i = tid; i < N; i += LT) S.pd[i] *= 0.0625;
-                    __syncthreads();
-                }
-                if (!improved) return {1, nstep, nfev, nhess};
-                fx = fn;
-                accept_trial(S, N);
+        // S.jx = jac(x) (from the end of the previous step); dx = -hess^-1 jac.  A factorisation that keeps being
+        // re-used (reduction == 1: the Hessian is frozen, minimizer.py:273) is turned into the explicit inverse once
+        // it has served N/8 solves -- N wave-solves shared by the 8 waves cost as much as that -- and every later
+        // step is a matrix-vector product over all threads instead of a substitution chain in one wave.
+        LTIC();
+        if (!have_inv && reuse >= inv_after) {
+            for (int r = tid >> 6; r < N; r += LNW) {
+                double *xs = S.wsol + (tid >> 6) * N;
+                wave_solve(S, N, S.lu, nullptr, r, 1.0, xs);
+                for (int i = tid & 63; i < N; i += 64) P.Hinv[r * N + i] = xs[i];  // column r of hess^-1
             }
+            __syncthreads();
+            have_inv = true;
         }
+        if (have_inv) {
+            if (S.row >= 0) {
+                const double *hc = P.Hinv + (S.c0 * N + S.row);
+                double a = 0.0;
+#pragma unroll 8
+                for (int c = S.c0; c < S.c1; ++c, hc += N) a = fma(*hc, S.jx[c], a);
+                S.part[S.slot] = a;
+            }
+            __syncthreads();
+            if (tid < N) {
+                double a = 0.0;
+                for (int ch = 0; ch < S.nch; ++ch) a += S.part[ch * N + tid];
+                S.dx[tid] = -a;
+            }
+        } else if (tid < 64) {
+            wave_solve(S, N, S.lu, S.jx, -1, -1.0, S.dx);
+        }
+        ++reuse;
+        __syncthreads();
+        LTOC(2);
+        double am = INFINITY, d = 0.0;
+        for (int i = tid; i < N; i += LT) {
+            am = fmin(am, fabs(S.x[i] / S.dx[i]));
+            d += S.jx[i] * S.dx[i];
+        }
+        block_min_sum(S, am, d);
+        // attempt 0: Newton direction (only if it descends); 1: steepest descent; 2: descent, shrinking by 16
+        // (minimizer.py:243-271).  `failed` is the outcome of attempt 0, as in the reference.
+        int failed = 1, res = 1;
+        for (int attempt = (d < 0) ? 0 : 1; attempt < 3; ++attempt) {
+            if (attempt == 1) {
+                am = INFINITY;
+                d = 0.0;
+                for (int i = tid; i < N; i += LT) {
+                    const double gi = -S.jx[i];
+                    S.dx[i] = gi;
+                    am = fmin(am, fabs(S.x[i] / gi));
+                    d += S.jx[i] * gi;
+                }
+                block_min_sum(S, am, d);
+            }
+            res = backtrack(P, S, S.dx, am, d, attempt == 2, fx, nfev, reduction);
+            if (res < 0) return {4, nstep, nfev, nhess};
+            if (attempt == 0) failed = res;
+            if (res == 0) break;
+        }
+        if (res != 0) return {1, nstep, nfev, nhess};  // neither direction improves the solution
         need_hess = failed || (reduction != 1.0);
         double g = -INFINITY;
-        for (int i = tid; i < N; i += LT) g = fmax(g, fabs(ln_grad(S, i)) * fabs(S.x[i]));
+        for (int i = tid; i < N; i += LT) {
+            const double gi = ln_grad(S, i);
+            S.jx[i] = gi;
+            g = fmax(g, fabs(gi) * fabs(S.x[i]));
+        }
         g = block_minmax<true>(S, g);
         if (g < P.newton_tol * fmax(fabs(fx), 1.0)) return {0, nstep, nfev, nhess};
     }
     return {2, P.max_step - 1, nfev, nhess};
 }
 
+// LDS_LU: the LU factors live in LDS (N <= 112), else in global memory (L2)
+template <bool LDS_LU>
 __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int N = P.N, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -429,12 +551,27 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
             *v = b;
             b += N;
         }
-        S.red = b;
-        b += 64;
+        S.red = b;  // 2 x 32 reduction partials + the pivot value
+        b += 72;
+        S.part = b;
+        b += 2 * LT;
+        S.wsol = b;  // one solve vector per wave
+        b += LNW * N;
         S.perm = reinterpret_cast<int *>(b);
         S.ipiv = S.perm + N;
         b += N;  // 2N ints
-        S.lu = P.lu_in_lds ? b : P.LU;
+        S.lu = LDS_LU ? b : P.LU;
+    }
+    S.redsel = 0;
+    S.nch = min(LT / N, N);
+    S.row = -1;
+    S.c0 = S.c1 = S.slot = 0;
+    if (tid < S.nch * N) {
+        const int ch = tid / N;
+        S.row = tid - ch * N;
+        S.c0 = ch * N / S.nch;
+        S.c1 = (ch + 1) * N / S.nch;
+        S.slot = tid;
     }
     __shared__ long long s_tot[9];
     for (int i = tid; i < N; i += LT) {
@@ -442,6 +579,9 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         S.pold[i] = 0.0;  // radial_fitters.py:768
     }
     if (tid < 9) s_tot[tid] = 0;
+#ifdef LN_TIMING
+    if (tid < 8) ln_cyc[tid] = 0;
+#endif
     __syncthreads();
 
     if (P.mode == LN_MODE_FIT) {
@@ -453,7 +593,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         __syncthreads();
         double best = -INFINITY;
         for (int r = w; r < N; r += LNW) {
-            const double *yr = P.Y + (size_t)r * N;
+            const double *yr = P.Y + r * N;
             double a = 0.0;
             for (int c = lane; c < N; c += 64) a = fma(yr[c], S.x[c], a);
             a = wave_sum(a) * P.pl_scale;
@@ -485,11 +625,17 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
             for (int a = tid >> 5; a < N; a += LT / 32)  // S^-1 = Y^T diag(1/p) Y  (:1061)
                 for (int b = tid & 31; b < N; b += 32) {
                     double acc = 0.0;
-                    for (int k = 0; k < N; ++k) acc += (P.Y[(size_t)k * N + a] * S.rhs[k]) * P.Y[(size_t)k * N + b];
-                    P.Sinv[(size_t)a * N + b] = acc;
+                    for (int k = 0; k < N; ++k) acc += S.rhs[k] * (P.Y[k * N + a] * P.Y[k * N + b]);  // symmetric bit for bit
+                    P.Sinv[a * N + b] = acc;
                 }
             __syncthreads();
+#ifdef LN_TIMING
+            const long long _tn = clock64();
+#endif
             const NewtonExit ex = minimize_newton(P, S);
+#ifdef LN_TIMING
+            if (tid == 0) ln_cyc[4] += clock64() - _tn;
+#endif
             if (tid == 0) {
                 s_tot[0] += 1;
                 s_tot[1] += ex.nstep;
@@ -506,7 +652,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         } else {
             // a caller-supplied posterior: s_MAP in S.x, Dinv (row-major) in P.H
             for (int b = tid >> 5; b < N; b += LT / 32)
-                for (int a = tid & 31; a < N; a += 32) S.lu[(size_t)b * N + a] = P.H[(size_t)a * N + b];
+                for (int a = tid & 31; a < N; a += 32) S.lu[b * N + a] = P.H[a * N + b];
             __syncthreads();
         }
         lu_factor(S, N, S.lu);
@@ -514,8 +660,8 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         if (in_pass) {  // radial_fitters.py:781-785
             if (P.diag_p)
                 for (int i = tid; i < N; i += LT) {
-                    P.diag_p[(size_t)count * N + i] = S.p[i];
-                    P.diag_s[(size_t)count * N + i] = S.x[i];
+                    P.diag_p[count * N + i] = S.p[i];
+                    P.diag_s[count * N + i] = S.x[i];
                 }
             ++count;
         }
@@ -525,16 +671,14 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         if (P.mode == LN_MODE_FIT && (!bad || count > P.max_iter)) break;  // radial_fitters.py:769-770
         // ---- CriticalFilter.update_power_spectrum(fit)  (filter.py:154-177) ----
         for (int r = w; r < N; r += LNW) {
-            const double *yr = P.Y + (size_t)r * N;
+            const double *yr = P.Y + r * N;
             double a = 0.0;  // Tr1_r = (Y s)_r^2
             for (int c = lane; c < N; c += 64) a = fma(yr[c], S.x[c], a);
             a = wave_sum(a);
-            double xr[LN_TMAX];  // Tr2_r = y_r . D y_r,  D = Dinv^-1
-            lu_solve_regs(S, N, S.lu, yr, 1.0, xr);
+            double *xs = S.wsol + w * N;  // Tr2_r = y_r . D y_r,  D = Dinv^-1
+            wave_solve(S, N, S.lu, yr, -1, 1.0, xs);
             double t2 = 0.0;
-#pragma unroll
-            for (int t = 0; t < LN_TMAX; ++t)
-                if (64 * t + lane < N) t2 = fma(yr[64 * t + lane], xr[t], t2);
+            for (int c = lane; c < N; c += 64) t2 = fma(yr[c], xs[c], t2);
             t2 = wave_sum(t2);
             if (lane == 0) {
                 const double pi = S.p[r];
@@ -581,25 +725,30 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         P.result[0] = count;
         P.result[1] = status;
         for (int k = 0; k < 9; ++k) P.stats[k] = s_tot[k];
+#ifdef LN_TIMING
+        for (int k = 0; k < 8; ++k) P.stats[9 + k] = ln_cyc[k];
+#endif
     }
 }
 
 }  // namespace
 
 size_t fh_ln_smem_bytes(int N, int *lu_in_lds) {
-    size_t doubles = 19 * (size_t)N + 64 + (size_t)N;
+    size_t doubles = (19 + LNW) * N + 72 + 2 * LT + N;
     const int fits = (N <= 112);
     if (lu_in_lds) *lu_in_lds = fits;
-    if (fits) doubles += (size_t)N * N;
+    if (fits) doubles += N * N;
     return doubles * sizeof(double);
 }
 
 hipError_t fh_ln_launch(const LogNormalParams &P0, int nblocks, hipStream_t s) {
     LogNormalParams P = P0;
     const size_t smem = fh_ln_smem_bytes(P.N, &P.lu_in_lds);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lognormal_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    using Kernel = void (*)(LogNormalParams);
+    Kernel fn = P.lu_in_lds ? lognormal_kernel<true> : lognormal_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)smem);
     if (e != hipSuccess) return e;
-    lognormal_kernel<<<nblocks, LT, smem, s>>>(P);
+    fn<<<nblocks, LT, smem, s>>>(P);
     return hipGetLastError();
 }

@@ -71,5 +71,6 @@ if __name__ == "__main__":
     cases = [(40, 5000, 1.3, 1e-2), (80, 20000, 1.05, 1e-4)]
     if len(sys.argv) > 1:
         cases = [(int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3]), float(sys.argv[4]))]
+    mi = int(sys.argv[5]) if len(sys.argv) > 5 else 2000
     for c in cases:
-        run(*c)
+        run(*c, max_iter=mi)
