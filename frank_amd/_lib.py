@@ -76,6 +76,9 @@ SIGNATURES = {
     "fh_fit_lognormal": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                         ctypes.c_double, ctypes.c_int, ctypes.c_double, _dp, _dp,
                                         ctypes.POINTER(ctypes.c_int), _dp, ctypes.POINTER(_i64), _dp, _dp]),
+    "fh_fit_lognormal_batched": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, _dp, _dp, _dp, ctypes.c_double,
+                                                ctypes.c_int, ctypes.c_double, _dp, _dp, ctypes.POINTER(ctypes.c_int),
+                                                ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_i64)]),
     "fh_posterior_update": (ctypes.c_int, [_vp, _dp, _dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp]),
     "fh_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "fh_comm_create": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,

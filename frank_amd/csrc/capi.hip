@@ -1326,6 +1326,84 @@ int fh_posterior_update(fh_ctx *c, const double *map, const double *Dinv, const 
     return ln_finish(c, nullptr, p_new, nullptr, nullptr, result);
 }
 
+int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int batch, const double *alpha,
+                             const double *p0, const double *wsmooth, double tol, int max_iter, double I_scale,
+                             double *s_map, double *p, int *niter, int *status, int64_t *stats) {
+    if (!c || !alpha || !p0 || !wsmooth || !s_map || !p || !niter || batch < 1)
+        return fail(FH_ERR_INVALID, "fh_fit_lognormal_batched: bad argument");
+    if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
+    if (!(I_scale > 0)) return fail(FH_ERR_INVALID, "I_scale must be positive");
+    if (c->NP > 320) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit kernels cover N <= 303", c->N);
+    LogNormalParams P;
+    int rc = ln_prepare(c, M, j, P);
+    if (rc) return rc;
+    const int N = c->N;
+    const size_t NN = (size_t)N * N, B = (size_t)batch;
+    const size_t G = (size_t)(batch < c->num_cu ? batch : c->num_cu);
+    // the seed fits do not depend on the hyper-parameters (radial_fitters.py:744-752): once for the whole sweep
+    rc = prepare_qspace(c, c->Aq.p, c->bq.p);
+    if (rc) return rc;
+    FitLoopParams L = make_loop_params(c, FIT_MODE_FULL, 1.05, 1e-15, tol, -1);
+    HIP_TRY(fh_k2_launch_loop(L, c->stream));
+    int seed[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(seed, c->loop_result.p, sizeof seed, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (seed[1] == FIT_STATUS_NOT_SPD) return fail(FH_ERR_NOT_SPD, "Cholesky of the seed fit failed");
+    if (seed[1] == FIT_STATUS_BAD_P) return fail(FH_ERR_BAD_P, "Bad value in the seed power spectrum");
+    DevBuf<double> Sb, LUb, Hib, Hb, sb, pb, lub, alb, p0b;
+    DevBuf<int> resb, counter;
+    DevBuf<long long> stb;
+    if (Sb.alloc(G * NN) != hipSuccess || LUb.alloc(G * NN) != hipSuccess || Hib.alloc(G * NN) != hipSuccess ||
+        Hb.alloc(B * NN) != hipSuccess || sb.alloc(B * N) != hipSuccess || pb.alloc(B * N) != hipSuccess ||
+        lub.alloc(B * 5 * N) != hipSuccess || alb.alloc(B) != hipSuccess || p0b.alloc(B) != hipSuccess ||
+        resb.alloc(2 * B) != hipSuccess || counter.alloc(1) != hipSuccess || stb.alloc(17 * B) != hipSuccess)
+        return fail(FH_ERR_NOMEM, "fh_fit_lognormal_batched: device allocation for %d fits failed", batch);
+    HIP_TRY(hipMemsetAsync(counter.p, 0, sizeof(int), c->stream));
+    std::vector<double> lu_all(B * 5 * N), lu;
+    for (int b = 0; b < batch; ++b) {
+        smoothing_band_lu(*c->dht, wsmooth[b], lu);
+        memcpy(lu_all.data() + (size_t)b * 5 * N, lu.data(), sizeof(double) * 5 * N);
+    }
+    HIP_TRY(hipMemcpyAsync(lub.p, lu_all.data(), sizeof(double) * lu_all.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(alb.p, alpha, sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(p0b.p, p0, sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
+    P.mode = LN_MODE_FIT;
+    P.max_iter = max_iter;
+    P.tol = tol;
+    P.s0 = log(I_scale);
+    P.guess = c->mu_out.p;
+    P.band_lu = lub.p;
+    P.Sinv = Sb.p;
+    P.LU = LUb.p;
+    P.Hinv = Hib.p;
+    P.H = Hb.p;
+    P.s_out = sb.p;
+    P.p_out = pb.p;
+    P.result = resb.p;
+    P.stats = stb.p;
+    P.batch = batch;
+    P.batch_counter = counter.p;
+    P.batch_alpha = alb.p;
+    P.batch_p0 = p0b.p;
+    HIP_TRY(fh_ln_launch(P, (int)G, c->stream));
+    std::vector<int> res(2 * B);
+    std::vector<long long> st(17 * B);
+    HIP_TRY(hipMemcpyAsync(res.data(), resb.p, sizeof(int) * 2 * B, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(st.data(), stb.p, sizeof(long long) * 17 * B, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(s_map, sb.p, sizeof(double) * B * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(p, pb.p, sizeof(double) * B * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < batch; ++b) {
+        niter[b] = res[2 * b];
+        if (status)
+            status[b] = res[2 * b + 1] == LN_STATUS_BAD_P ? FH_ERR_BAD_P
+                        : res[2 * b + 1] == LN_STATUS_SLOPE ? FH_ERR_NUMERIC : FH_OK;
+        if (stats)
+            for (int k = 0; k < 9; ++k) stats[9 * b + k] = st[17 * (size_t)b + k];
+    }
+    return FH_OK;
+}
+
 #ifdef FIT_LOOP_TIMING
 // debug builds: cycles per phase of the fit_loop kernel accumulated since the context was created
 int fh_debug_loop_timing(fh_ctx *c, long long *out16) {

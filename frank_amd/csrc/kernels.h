@@ -128,6 +128,11 @@ struct LogNormalParams {
     int *result;                  // [0] count, [1] status
     long long *stats;             // [0] MAP solves, [1] Newton steps, [2] function evaluations, [3] Hessians, [4..8] exits 0-4
     double *diag_p, *diag_s;      // optional (max_iter+1)*N each
+    // batched launch (sweeps): M, j, Y, q and the seed shared; Sinv / LU / Hinv strided by workgroup; H, s_out, p_out,
+    // result (2), stats (17) strided by fit; per-fit alpha, p0, band_lu[f][5N]
+    int batch;
+    int *batch_counter;
+    const double *batch_alpha, *batch_p0;
 };
 
 size_t fh_ln_smem_bytes(int N, int *lu_in_lds);

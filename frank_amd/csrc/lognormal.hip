@@ -541,6 +541,31 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
 template <bool LDS_LU>
 __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int s_fit;
+    const LogNormalParams P0 = P;
+    // batched launch: the workgroups pull fit indices from a counter; work buffers belong to the workgroup, outputs to
+    // the fit (per-fit alpha, p0, band_lu)
+    for (;;) {
+    P = P0;
+    if (P.batch) {
+        if (threadIdx.x == 0) s_fit = atomicAdd(P.batch_counter, 1);
+        __syncthreads();
+        const int f = s_fit;
+        __syncthreads();
+        if (f >= P.batch) return;
+        const int NN = P.N * P.N;
+        P.alpha = P.batch_alpha[f];
+        P.p0 = P.batch_p0[f];
+        P.band_lu += (size_t)f * 5 * P.N;
+        P.Sinv += (size_t)blockIdx.x * NN;
+        P.LU += (size_t)blockIdx.x * NN;
+        P.Hinv += (size_t)blockIdx.x * NN;
+        P.H += (size_t)f * NN;
+        P.s_out += (size_t)f * P.N;
+        P.p_out += (size_t)f * P.N;
+        P.result += 2 * f;
+        P.stats += 17 * f;
+    }
     const int N = P.N, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     LnS S;
     {
@@ -729,6 +754,9 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         for (int k = 0; k < 8; ++k) P.stats[9 + k] = ln_cyc[k];
 #endif
     }
+    if (!P.batch) return;
+    __syncthreads();
+    }  // next fit of the batch
 }
 
 }  // namespace

@@ -2,22 +2,23 @@
 
 The reference re-runs the whole fit (including the visibility mapping) for every (alpha, w_smooth) point
 although M and j do not depend on them.  Here the mapping is done once (FrankFitter.preprocess_visibilities)
-and all points are iterated concurrently, one fit_loop workgroup (one compute unit) per point
-(fh_fit_normal_batched)."""
+and all points are iterated concurrently, one workgroup (one compute unit) per point: fh_fit_normal_batched
+(fit_loop kernel) for method='Normal', fh_fit_lognormal_batched (lognormal kernel) for method='LogNormal'."""
 import ctypes
 
 import numpy as np
 
 from frank_amd import _lib
-from frank_amd.radial_fitters import FrankFitter, FrankGaussianFit
-from frank_amd.statistical_models import GaussianModel, _BAD_P_MSG
+from frank_amd.radial_fitters import FrankFitter, FrankGaussianFit, FrankLogNormalFit
+from frank_amd.statistical_models import GaussianModel, LogNormalMAPModel, _BAD_P_MSG
 
 
 def sweep_fits(fitter, preproc_vis, alphas, weights_smooth, p_0=None, tol=1e-3, max_iter=2000):
     """Fit `preproc_vis` (from `fitter.preprocess_visibilities`) for every (alpha[i], weights_smooth[i]).
 
-    Returns (sols, niters): FrankGaussianFit objects as FrankFitter.fit_preprocessed would return for a fitter
-    constructed with those hyper-parameters, and the iteration counts (`count`; >= max_iter means not converged).
+    Returns (sols, niters): FrankGaussianFit (FrankLogNormalFit for a method='LogNormal' fitter) objects as
+    FrankFitter.fit_preprocessed would return for a fitter constructed with those hyper-parameters, and the iteration
+    counts (`count`; >= max_iter means not converged).
     """
     if not isinstance(fitter, FrankFitter):
         raise TypeError("fitter must be a frank_amd FrankFitter")
@@ -26,9 +27,12 @@ def sweep_fits(fitter, preproc_vis, alphas, weights_smooth, p_0=None, tol=1e-3, 
     if alphas.shape != ws.shape:
         raise ValueError("alphas and weights_smooth must have the same length")
     B, N = alphas.size, fitter.size
-    p0 = _lib.f8(np.full(B, 1e-15 if p_0 is None else p_0))
+    lognormal = fitter._method == 'LogNormal'
+    p0 = _lib.f8(np.full(B, (1e-35 if lognormal else 1e-15) if p_0 is None else p_0))
     fitter._build_matrices(preproc_vis)
     M, j = _lib.f8(fitter._M), _lib.f8(fitter._j)
+    if lognormal:
+        return _sweep_lognormal(fitter, M, j, alphas, ws, p0, tol, max_iter)
     mu, p = np.empty((B, N)), np.empty((B, N))
     niter = (ctypes.c_int * B)()
     status = (ctypes.c_int * B)()
@@ -46,3 +50,46 @@ def sweep_fits(fitter, preproc_vis, alphas, weights_smooth, p_0=None, tol=1e-3, 
         info = dict(fitter._info, alpha=float(alphas[b]), wsmooth=float(ws[b]), p0=float(p0[b]))
         sols.append(FrankGaussianFit(fitter._vis_map, fit, info, geometry=fitter._geometry.clone()))
     return sols, [int(n) for n in niter]
+
+
+def _sweep_lognormal(fitter, M, j, alphas, ws, p0, tol, max_iter):
+    B, N = alphas.size, fitter.size
+    s_map, p = np.empty((B, N)), np.empty((B, N))
+    niter = (ctypes.c_int * B)()
+    status = (ctypes.c_int * B)()
+    stats = (ctypes.c_int64 * (9 * B))()
+    _lib.check(_lib.lib.fh_fit_lognormal_batched(fitter._DHT.context(), _lib.ptr(M), _lib.ptr(j), B, _lib.ptr(alphas),
+                                                 _lib.ptr(p0), _lib.ptr(ws), float(tol), int(max_iter),
+                                                 float(np.exp(fitter._s_scale)), _lib.ptr(s_map), _lib.ptr(p), niter,
+                                                 status, stats))
+    sols = []
+    for b in range(B):
+        if status[b] == _lib.FH_ERR_BAD_P:
+            raise ValueError(_BAD_P_MSG)
+        if status[b] != _lib.FH_OK:
+            raise RuntimeError("fit %d of the sweep failed (status %d)" % (b, status[b]))
+        # the Hessian at the MAP is rebuilt on demand (covariance / Dsolve) by a one-step MAP solve from s_map
+        fit = _LazyLogNormal._from_map(fitter._DHT, fitter._M, fitter._j, p[b].copy(), s_map[b].copy(),
+                                       fitter._s_scale, fitter._H0, tuple(stats[9 * b:9 * b + 9]))
+        info = dict(fitter._info, alpha=float(alphas[b]), wsmooth=float(ws[b]), p0=float(p0[b]))
+        sols.append(FrankLogNormalFit(fitter._vis_map, fit, info, geometry=fitter._geometry.clone()))
+    return sols, [int(n) for n in niter]
+
+
+class _LazyLogNormal(LogNormalMAPModel):
+    """A sweep result: MAP and power spectrum from the batched kernel; `_Dinv` (the Hessian at the MAP, needed only by
+    covariance / Dsolve / update_power_spectrum) is obtained on first use by re-solving from the MAP itself."""
+
+    @classmethod
+    def _from_map(cls, DHT, M, j, p, s_map, s0, noise_likelihood, stats):
+        self = cls._from_solution(DHT, M, j, p, s_map, np.zeros((0, 0)), s0, noise_likelihood, stats)
+        self._lazy = True
+        return self
+
+    def __getattribute__(self, name):
+        if name == '_Dinv' and object.__getattribute__(self, '__dict__').get('_lazy'):
+            self._lazy = False
+            keep_s, keep_stats = self._s_MAP.copy(), self._newton_stats
+            self._fit(keep_s.reshape(-1))  # converges at once: starts at the MAP
+            self._s_MAP, self._newton_stats = keep_s, keep_stats
+        return object.__getattribute__(self, name)

@@ -177,6 +177,14 @@ int fh_fit_lognormal(fh_ctx *ctx, const double *M, const double *j, double alpha
                      double tol, int max_iter, double I_scale, double *s_map, double *p, int *niter, double *Dinv,
                      int64_t *stats, double *diag_p, double *diag_s);
 
+/* Batched form for hyper-parameter sweeps of LogNormal fits over ONE mapping (fit.py:534-548): `batch` fits with
+ * per-fit alpha[b], p0[b], wsmooth[b]; the Normal seed fits are shared; one lognormal workgroup (one CU) per fit, all
+ * in one launch.  Outputs: s_map, p (batch*N, row per fit), niter (batch), status (batch: FH_OK / FH_ERR_BAD_P /
+ * FH_ERR_NUMERIC; may be NULL), stats (batch*9 int64 as in fh_lognormal_model; may be NULL).                    */
+int fh_fit_lognormal_batched(fh_ctx *ctx, const double *M, const double *j, int batch, const double *alpha,
+                             const double *p0, const double *wsmooth, double tol, int max_iter, double I_scale,
+                             double *s_map, double *p, int *niter, int *status, int64_t *stats);
+
 /* fh_posterior_update: CriticalFilter.update_power_spectrum(fit) (filter.py:154-177) for ANY posterior object the
  * caller holds: map = fit.MAP (N), Dinv = the posterior precision (N*N row-major; fit.Dsolve applies its inverse),
  * p = fit.power_spectrum.  The inverse is applied through a partial-pivoting LU on the device.  Output p_new (N). */

