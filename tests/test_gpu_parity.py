@@ -525,3 +525,24 @@ def test_lognormal_sweep_batched(golden):
     assert np.all(sols[0].I > 0)
     cov = sols[0].covariance
     assert cov.shape == (80, 80) and np.all(np.diag(cov) > 0)
+
+
+def test_realdata_multi_ring(golden):
+    """FrankFitter.fit end to end on the uv-table the reference ships (54 180 visibilities, 851 iterations at N=100),
+    against the reference's M, j, H0, iteration count, profile, power spectrum and predicted visibilities."""
+    from frank_amd import FixedGeometry, FrankFitter
+    g = golden("realdata_multi_ring_N100.npz")
+    geometry = FixedGeometry(float(g["geom_inc"]), float(g["geom_PA"]), float(g["geom_dRA"]), float(g["geom_dDec"]))
+    V = g["Vre"] + 1j * g["Vim"]
+    FF = FrankFitter(2.0, 100, geometry, alpha=1.05, weights_smooth=1e-4, store_iteration_diagnostics=True,
+                     verbose=False)
+    pre = FF.preprocess_visibilities(g["u"], g["v"], V, g["w"])
+    assert rel_to_max(pre["M"], g["M"]) < 1e-12 and rel_to_max(pre["j"], g["j"]) < 1e-12
+    assert abs(pre["null_likelihood"] - float(g["H0"])) <= 1e-12 * abs(float(g["H0"]))
+    sol = FF.fit_preprocessed(pre)
+    assert FF.iteration_diagnostics["num_iterations"] == int(g["niter"]) == 851
+    assert rel_to_max(sol.I, g["I"]) < 1e-6  # north_star tolerance; the oracle itself sits at 7e-7 here (unit weights)
+    np.testing.assert_allclose(sol.power_spectrum, g["p"], rtol=1e-4)
+    np.testing.assert_allclose(FF.iteration_diagnostics["power_spectrum"][0], g["diag_p_first"][0], rtol=1e-7)
+    Vp = sol.predict_deprojected(g["q_pred"])
+    assert np.abs(Vp - g["Vpred"]).max() <= 1e-6 * np.abs(g["Vpred"]).max()
