@@ -90,6 +90,9 @@ __global__ __launch_bounds__(256) void deproject_kernel(BinParams p) {
         const double Vre = p.Vre[g];
         const double Vim = p.Vim ? p.Vim[g] : 0.0;
         const double w = p.w[p.w_scalar ? 0 : g];
+        // multiplicity of the row in a bootstrap resample (utilities.py:632-666): c copies of a row contribute
+        // c w h h^T, c w V h, c (log(w/2pi) - w V^2); rows drawn zero times drop out of min/max q as well
+        const double mult = p.mult ? (double)p.mult[g] : 1.0;
         const double phi = u * p.dRA + v * p.dDec;
         double sn, cs;
         sincos(phi, &sn, &cs);
@@ -105,13 +108,16 @@ __global__ __launch_bounds__(256) void deproject_kernel(BinParams p) {
         const double vp = u * p.sin_t + v * p.cos_t;
         up = up * p.cos_i;
         const double q = hypot(up, vp);
-        const double sw = sqrt(w);
+        const double sw = p.mult ? sqrt(mult * w) : sqrt(w);
         p.prep_s[i] = p.inv_Qmax * q;  // k * q, hankel.py:189,202
         p.prep_sw[i] = sw;
         p.prep_swV[i] = sw * re;
-        sum_logw += log(w / (2 * M_PI));  // statistical_models.py:218
-        qmin = fmin(qmin, q);
-        qmax = fmax(qmax, q);
+        if (mult > 0.0) {
+            const double lw = log(w / (2 * M_PI));  // statistical_models.py:218
+            sum_logw += p.mult ? mult * lw : lw;
+            qmin = fmin(qmin, q);
+            qmax = fmax(qmax, q);
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {

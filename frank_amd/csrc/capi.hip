@@ -71,6 +71,8 @@ struct fh_vis {
     int64_t n = 0;
     int w_scalar = 0, has_im = 0;
     DevBuf<double> u, v, Vre, Vim, w;
+    DevBuf<int> mult;  // bootstrap multiplicities (fh_vis_set_multiplicity), empty = every row once
+    bool use_mult = false;
 };
 
 struct FitSlot {
@@ -404,6 +406,20 @@ void fh_vis_destroy(fh_vis *vis) {
 }
 int64_t fh_vis_size(const fh_vis *vis) { return vis ? vis->n : 0; }
 
+int fh_vis_set_multiplicity(fh_vis *vis, const int32_t *counts) {
+    if (!vis) return fail(FH_ERR_INVALID, "fh_vis_set_multiplicity: vis is NULL");
+    if (!counts) {
+        vis->use_mult = false;
+        return FH_OK;
+    }
+    HIP_TRY(hipSetDevice(vis->device));
+    const size_t nn = (size_t)(vis->n > 0 ? vis->n : 1);
+    if (!vis->mult.p && vis->mult.alloc(nn) != hipSuccess) return fail(FH_ERR_NOMEM, "fh_vis_set_multiplicity: hipMalloc failed");
+    if (vis->n > 0) HIP_TRY(hipMemcpy(vis->mult.p, counts, sizeof(int) * (size_t)vis->n, hipMemcpyHostToDevice));
+    vis->use_mult = true;
+    return FH_OK;
+}
+
 // ---- K1 ----------------------------------------------------------------------------------------------------------
 int fh_bin_reset(fh_ctx *c) {
     if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
@@ -430,6 +446,7 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     p.Vim = vis->has_im ? vis->Vim.p : nullptr;
     p.w = vis->w.p;
     p.w_scalar = vis->w_scalar;
+    p.mult = vis->use_mult ? vis->mult.p : nullptr;
     p.first = first;
     p.count = count;
     // geometry.py:69-70 (dRA *= 2 pi / rad_to_arcsec), :111-115

@@ -6,6 +6,7 @@
 struct BinParams {
     // visibility columns (device), rows [first, first+count)
     const double *u, *v, *Vre, *Vim, *w;
+    const int *mult;  // optional per-row multiplicity (bootstrap resampling), NULL = 1
     int w_scalar;
     int64_t first, count;
     // geometry (geometry.py:69-70,111-115): dRA, dDec already multiplied by 2 pi / rad_to_arcsec

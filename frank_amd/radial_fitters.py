@@ -262,20 +262,7 @@ class FrankFitter(FourierBesselFitter):
             self._iteration_diagnostics['power_spectrum'] = [dp[i].copy() for i in range(count)]
             self._iteration_diagnostics['MAP'] = [dm[i].copy() for i in range(count)]
 
-        # convergence policy of radial_fitters.py:787-815: success iff count < max_iter
-        if count < self._max_iter:
-            if self._verbose:
-                logging.info('    Converged after {} power-spectrum iterations'.format(count))
-        else:
-            msg = ('Convergence not met within {} iterations. Increase max_iter or alpha (convergence is slow for '
-                   'alpha close to 1)'.format(self._max_iter))
-            if self._convergence_failure == 'raise':
-                raise RuntimeError(msg + ", or set convergence_failure to 'warn' / 'ignore' to keep the last iterate.")
-            if self._convergence_failure == 'warn':
-                if logging.getLogger().isEnabledFor(logging.INFO):
-                    logging.info(msg)
-                else:
-                    print(msg)
+        self._check_convergence_policy(count)
 
         if self._store_iteration_diagnostics:
             self._iteration_diagnostics['num_iterations'] = count
@@ -290,6 +277,22 @@ class FrankFitter(FourierBesselFitter):
         self._ps = p
         self._ps_cov = None
         return self._sol
+
+    def _check_convergence_policy(self, count):
+        """radial_fitters.py:787-815: success iff count < max_iter; otherwise raise / warn / ignore."""
+        if count < self._max_iter:
+            if self._verbose:
+                logging.info('    Converged after {} power-spectrum iterations'.format(count))
+            return
+        msg = ('Convergence not met within {} iterations. Increase max_iter or alpha (convergence is slow for '
+               'alpha close to 1)'.format(self._max_iter))
+        if self._convergence_failure == 'raise':
+            raise RuntimeError(msg + ", or set convergence_failure to 'warn' / 'ignore' to keep the last iterate.")
+        if self._convergence_failure == 'warn':
+            if logging.getLogger().isEnabledFor(logging.INFO):
+                logging.info(msg)
+            else:
+                print(msg)
 
     def _perform_fit(self, p, guess=None, fit_method=None):
         """Posterior for a given p (radial_fitters.py:858-890)."""

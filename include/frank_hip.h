@@ -87,6 +87,11 @@ int fh_vis_upload(int device, const double *u, const double *v, const double *Vr
                   const double *w, int64_t n_w, int64_t n, fh_vis **out);
 void fh_vis_destroy(fh_vis *vis);
 int64_t fh_vis_size(const fh_vis *vis);
+/* Bootstrap resampling without moving data: counts[i] (n int32, host) = how many times row i was drawn by
+ * draw_bootstrap_sample (utilities.py:632-666; counts = bincount(idxs)).  Subsequent fh_bin_visibilities calls weigh
+ * row i by counts[i] in M, j, H0 and leave rows with count 0 out of the q range -- the sums over the resampled table,
+ * streamed in place instead of gathered.  counts = NULL restores every row once.                                  */
+int fh_vis_set_multiplicity(fh_vis *vis, const int32_t *counts);
 
 /* ---- a5-a8: map_visibilities = K1 `bin_gram` ---------------------------------------------------------------
  * statistical_models.py:109-237 with geometry.py:69-79,111-131 and hankel.py:201-202 fused:

@@ -546,3 +546,32 @@ def test_realdata_multi_ring(golden):
     np.testing.assert_allclose(FF.iteration_diagnostics["power_spectrum"][0], g["diag_p_first"][0], rtol=1e-7)
     Vp = sol.predict_deprojected(g["q_pred"])
     assert np.abs(Vp - g["Vpred"]).max() <= 1e-6 * np.abs(g["Vpred"]).max()
+
+
+def test_bootstrap_matches_reference(golden):
+    """perform_bootstrap's loop (fit.py:731-797): same RNG seed -> same resamples; the table stays on the GPU and the
+    resample is applied as row multiplicities (fh_vis_set_multiplicity).  Profiles vs the reference's."""
+    from frank_amd import FrankFitter
+    from frank_amd.bootstrap import bootstrap_fits, draw_bootstrap_counts
+    g = golden("bootstrap_N50_2e4.npz")
+    u, v, V, w = mock_disc_visibilities(int(g["n"]), seed=int(g["seed"]), noise_seed=int(g["noise_seed"]))
+    assert sha(u, v, V, w) == str(g["input_sha256"])
+    FF = FrankFitter(2.0, 50, geom(), alpha=float(g["alpha"]), weights_smooth=float(g["wsmooth"]), verbose=False)
+    np.random.seed(int(g["rng_seed"]))
+    r, profiles = bootstrap_fits(FF, u, v, V, w, 3)
+    assert profiles.shape == g["profiles"].shape
+    for t in range(3):
+        assert rel_to_max(profiles[t], g["profiles"][t]) < 1e-6
+    # multiplicities == explicit resample (gathered copy through the ordinary path)
+    np.random.seed(7)
+    counts = draw_bootstrap_counts(u.size)
+    np.random.seed(7)
+    idxs = np.random.randint(low=0, high=u.size, size=u.size)
+    assert np.array_equal(counts, np.bincount(idxs, minlength=u.size))
+    pre = FF.preprocess_visibilities(u[idxs], v[idxs], V[idxs], w[idxs])
+    np.random.seed(7)
+    _, prof = bootstrap_fits(FF, u, v, V, w, 1)
+    assert rel_to_max(prof[0], FF.fit_preprocessed(pre).I) < 1e-9
+    # the table is left untouched for ordinary fits afterwards
+    sol = FF.fit(u, v, V, w)
+    assert np.isfinite(sol.I).all()

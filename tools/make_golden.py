@@ -177,16 +177,39 @@ def sweep():
     save("sweep_N50_2e4.npz", **out)
 
 
+def bootstrap():
+    print("bootstrap trials (fit.py:731-797, utilities.py:632-666), N=50, 2e4 vis, np.random.seed(1234)")
+    from frank.utilities import draw_bootstrap_sample
+    u, v, V, w = mock_disc_visibilities(20000, seed=5, noise_seed=6)
+    np.random.seed(1234)
+    profiles, niters = [], []
+    for _ in range(3):
+        ub, vb, Vb, wb = draw_bootstrap_sample(u, v, V, w)
+        FF = FrankFitter(RMAX, 50, geom(), alpha=1.3, weights_smooth=1e-2, store_iteration_diagnostics=True,
+                         verbose=False)
+        sol = FF.fit(ub, vb, Vb, wb)
+        profiles.append(sol.I)
+        niters.append(FF.iteration_diagnostics["num_iterations"])
+    print("    niter", niters)
+    save("bootstrap_N50_2e4.npz", N=50, n=20000, seed=5, noise_seed=6, rng_seed=1234, alpha=1.3, wsmooth=1e-2,
+         input_sha256=checksum(u, v, V, w), profiles=np.array(profiles), niters=np.array(niters))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default=None, help="run a single generator function by name")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
+    if args.only:
+        globals()[args.only]()
+        return
     dht_fixtures()
     geometry_fixture()
     map_small()
     smoothing()
     sweep()
+    bootstrap()
     fit_case("fit_N100_1e5.npz", 100, 1e5, 1.05, 1e-4, keep_M=True)
     if not args.quick:
         fit_case("fit_N300_1e6.npz", 300, 1e6, 1.05, 1e-4, keep_M=True)
