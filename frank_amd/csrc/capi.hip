@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <utility>
 #include <string>
 #include <vector>
@@ -1418,6 +1419,212 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
         if (stats)
             for (int k = 0; k < 9; ++k) stats[9 * b + k] = st[17 * (size_t)b + k];
     }
+    return FH_OK;
+}
+
+// ---- utilities.UVDataBinner -------------------------------------------------------------------------------------
+struct fh_uvbin {
+    int device = 0, num_cu = 0;
+    int64_t n = 0;
+    int nbins = 0, is_complex = 0;
+    double bin_width = 0;
+    DevBuf<double> uv, Vre, Vim, w;
+    std::vector<double> b_uv, b_Vre, b_Vim, b_w, e_re, e_im;
+    std::vector<int64_t> b_n;
+};
+
+// sums of w * qty over the bins for device-resident rows (bin_quantities, utilities.py:300-366)
+static int uvbin_sums(fh_uvbin *h, const double *d_uv, const double *d_w, const double *const qty[4], int nq, int64_t n,
+                      bool count, std::vector<double> &sums, std::vector<int64_t> *counts) {
+    const int nb = h->nbins;
+    DevBuf<double> ds;
+    DevBuf<unsigned long long> dc;
+    if (ds.alloc((size_t)nq * nb) != hipSuccess || dc.alloc((size_t)nb) != hipSuccess)
+        return fail(FH_ERR_NOMEM, "uvbin: device allocation failed");
+    HIP_TRY(hipMemset(ds.p, 0, sizeof(double) * (size_t)nq * nb));
+    HIP_TRY(hipMemset(dc.p, 0, sizeof(unsigned long long) * (size_t)nb));
+    UvBinParams p{};
+    p.uv = d_uv;
+    p.w = d_w;
+    for (int q = 0; q < 4; ++q) p.qty[q] = q < nq ? qty[q] : nullptr;
+    p.nq = nq;
+    p.count = count ? 1 : 0;
+    p.n = n;
+    p.bin_width = h->bin_width;
+    p.norm = 1 / h->bin_width;
+    p.nbins = nb;
+    p.sums = ds.p;
+    p.counts = dc.p;
+    HIP_TRY(fh_uvbin_launch_sum(p, h->num_cu, nullptr));
+    sums.resize((size_t)nq * nb);
+    HIP_TRY(hipMemcpy(sums.data(), ds.p, sizeof(double) * sums.size(), hipMemcpyDeviceToHost));
+    if (counts) {
+        std::vector<unsigned long long> cc((size_t)nb);
+        HIP_TRY(hipMemcpy(cc.data(), dc.p, sizeof(unsigned long long) * cc.size(), hipMemcpyDeviceToHost));
+        counts->assign(cc.begin(), cc.end());
+    }
+    return FH_OK;
+}
+
+int fh_uvbin_create(int device, const double *uv, const double *Vre, const double *Vim, const double *w, int64_t n,
+                    double bin_width, fh_uvbin **out) {
+    if (!out || !uv || !Vre || !w || n < 1 || !(bin_width > 0)) return fail(FH_ERR_INVALID, "fh_uvbin_create: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(FH_ERR_HIP, "no HIP device available: frank_amd has no CPU fallback for device work");
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<fh_uvbin> h(new fh_uvbin());
+    h->device = device;
+    h->n = n;
+    h->bin_width = bin_width;
+    h->is_complex = Vim ? 1 : 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    h->num_cu = prop.multiProcessorCount;
+    const size_t nn = (size_t)n, bytes = sizeof(double) * nn;
+    if (h->uv.alloc(nn) != hipSuccess || h->Vre.alloc(nn) != hipSuccess || (Vim && h->Vim.alloc(nn) != hipSuccess) ||
+        h->w.alloc(nn) != hipSuccess)
+        return fail(FH_ERR_NOMEM, "fh_uvbin_create: hipMalloc failed for %lld rows", (long long)n);
+    HIP_TRY(hipMemcpy(h->uv.p, uv, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->Vre.p, Vre, bytes, hipMemcpyHostToDevice));
+    if (Vim) HIP_TRY(hipMemcpy(h->Vim.p, Vim, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->w.p, w, bytes, hipMemcpyHostToDevice));
+    // nbins = ceil(uv.max() / bin_width), +1 if rounding left the maximum outside (utilities.py:204-208)
+    DevBuf<unsigned long long> mx;
+    if (mx.alloc(2) != hipSuccess) return fail(FH_ERR_NOMEM, "fh_uvbin_create: hipMalloc failed");
+    HIP_TRY(hipMemset(mx.p, 0, 2 * sizeof(unsigned long long)));
+    HIP_TRY(fh_uvbin_launch_max(h->uv.p, n, mx.p, h->num_cu, nullptr));
+    unsigned long long mxh[2];
+    HIP_TRY(hipMemcpy(mxh, mx.p, sizeof mxh, hipMemcpyDeviceToHost));
+    if (mxh[1]) return fail(FH_ERR_INVALID, "fh_uvbin_create: baselines must be non-negative and finite");
+    double uvmax;
+    memcpy(&uvmax, &mxh[0], sizeof uvmax);
+    double nbf = ceil(uvmax / bin_width);
+    if (nbf * bin_width < uvmax) nbf += 1;
+    if (!(nbf >= 1) || nbf > 1e8) return fail(FH_ERR_INVALID, "fh_uvbin_create: %g bins of width %g", nbf, bin_width);
+    const int nb = h->nbins = (int)nbf;
+    // weighted sums of uv, 1, Re V, Im V + counts, then the means (utilities.py:214-223)
+    const double *qty[4] = {h->uv.p, nullptr, h->Vre.p, h->Vim.p};
+    std::vector<double> sums;
+    int rc = uvbin_sums(h.get(), h->uv.p, h->w.p, qty, Vim ? 4 : 3, n, true, sums, &h->b_n);
+    if (rc) return rc;
+    h->b_uv.assign(sums.begin(), sums.begin() + nb);
+    h->b_w.assign(sums.begin() + nb, sums.begin() + 2 * nb);
+    h->b_Vre.assign(sums.begin() + 2 * nb, sums.begin() + 3 * nb);
+    h->b_Vim.assign((size_t)nb, 0.0);
+    if (Vim) h->b_Vim.assign(sums.begin() + 3 * nb, sums.begin() + 4 * nb);
+    for (int b = 0; b < nb; ++b)
+        if (h->b_n[b] > 0) {
+            h->b_uv[b] /= h->b_w[b];
+            if (Vim) {  // complex / real as NumPy does it: both parts divided
+                h->b_Vre[b] /= h->b_w[b];
+                h->b_Vim[b] /= h->b_w[b];
+            } else {
+                h->b_Vre[b] /= h->b_w[b];
+            }
+        }
+    // error of the mean (utilities.py:236-263)
+    DevBuf<double> mre, mim, es;
+    if (mre.alloc((size_t)nb) != hipSuccess || mim.alloc((size_t)nb) != hipSuccess || es.alloc(2 * (size_t)nb) != hipSuccess)
+        return fail(FH_ERR_NOMEM, "fh_uvbin_create: hipMalloc failed");
+    HIP_TRY(hipMemcpy(mre.p, h->b_Vre.data(), sizeof(double) * nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(mim.p, h->b_Vim.data(), sizeof(double) * nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(es.p, 0, sizeof(double) * 2 * nb));
+    UvBinParams p{};
+    p.uv = h->uv.p;
+    p.w = h->w.p;
+    p.qty[0] = h->Vre.p;
+    p.qty[1] = Vim ? h->Vim.p : nullptr;
+    p.n = n;
+    p.bin_width = bin_width;
+    p.norm = 1 / bin_width;
+    p.nbins = nb;
+    p.mu_re = mre.p;
+    p.mu_im = mim.p;
+    p.sums = es.p;
+    HIP_TRY(fh_uvbin_launch_err(p, h->num_cu, nullptr));
+    std::vector<double> e(2 * (size_t)nb);
+    HIP_TRY(hipMemcpy(e.data(), es.p, sizeof(double) * e.size(), hipMemcpyDeviceToHost));
+    h->e_re.assign((size_t)nb, NAN);
+    h->e_im.assign((size_t)nb, 0.0);
+    for (int b = 0; b < nb; ++b)
+        if (h->b_n[b] > 1) {
+            const double den = h->b_w[b] * h->b_w[b] * (1 - 1 / (double)h->b_n[b]);
+            h->e_re[b] = sqrt(e[b] / den);
+            if (Vim) h->e_im[b] = sqrt(e[(size_t)nb + b] / den);
+        }
+    // bins with one row: utilities.py:256-261 assigns to `.real` of a fancy-indexed copy, which leaves np.nan
+    // (nan+0j for complex V) in place -- kept, so that results match the reference
+    *out = h.release();
+    return FH_OK;
+}
+
+void fh_uvbin_destroy(fh_uvbin *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    delete h;
+}
+
+int fh_uvbin_nbins(const fh_uvbin *h) { return h ? h->nbins : 0; }
+
+int fh_uvbin_get(const fh_uvbin *h, double *uv, double *Vre, double *Vim, double *w, int64_t *count, double *err_re,
+                 double *err_im) {
+    if (!h) return fail(FH_ERR_INVALID, "fh_uvbin_get: NULL handle");
+    const size_t nb = (size_t)h->nbins;
+    if (uv) memcpy(uv, h->b_uv.data(), sizeof(double) * nb);
+    if (Vre) memcpy(Vre, h->b_Vre.data(), sizeof(double) * nb);
+    if (Vim) memcpy(Vim, h->b_Vim.data(), sizeof(double) * nb);
+    if (w) memcpy(w, h->b_w.data(), sizeof(double) * nb);
+    if (count) memcpy(count, h->b_n.data(), sizeof(int64_t) * nb);
+    if (err_re) memcpy(err_re, h->e_re.data(), sizeof(double) * nb);
+    if (err_im) memcpy(err_im, h->e_im.data(), sizeof(double) * nb);
+    return FH_OK;
+}
+
+int fh_uvbin_determine(fh_uvbin *h, const double *uv, int64_t n, int32_t *idx) {
+    if (!h || (n > 0 && (!uv || !idx)) || n < 0) return fail(FH_ERR_INVALID, "fh_uvbin_determine: bad argument");
+    if (n == 0) return FH_OK;
+    // the reference indexes bins[idx] before rejecting: baselines at or past (nbins + 1) * bin_width raise IndexError
+    for (int64_t i = 0; i < n; ++i)
+        if (!(uv[i] >= 0) || floor(uv[i] * (1 / h->bin_width)) > h->nbins)
+            return fail(FH_ERR_INVALID, "index %lld is out of bounds: baseline %g beyond the bin edges", (long long)i, uv[i]);
+    HIP_TRY(hipSetDevice(h->device));
+    DevBuf<double> d;
+    DevBuf<int> o;
+    if (d.alloc((size_t)n) != hipSuccess || o.alloc((size_t)n) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc failed");
+    HIP_TRY(hipMemcpy(d.p, uv, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(fh_uvbin_launch_lookup(d.p, n, h->bin_width, h->nbins, o.p, h->num_cu, nullptr));
+    HIP_TRY(hipMemcpy(idx, o.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    return FH_OK;
+}
+
+int fh_uvbin_quantities(fh_uvbin *h, const double *uv, const double *w, const double *qre, const double *qim, int64_t n,
+                        double *out_re, double *out_im, int64_t *counts) {
+    if (!h || !uv || !w || !qre || !out_re || n < 0 || ((qim == nullptr) != (out_im == nullptr)))
+        return fail(FH_ERR_INVALID, "fh_uvbin_quantities: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t nn = (size_t)(n > 0 ? n : 1), bytes = sizeof(double) * (size_t)n;
+    DevBuf<double> duv, dw, dre, dim;
+    if (duv.alloc(nn) != hipSuccess || dw.alloc(nn) != hipSuccess || dre.alloc(nn) != hipSuccess ||
+        (qim && dim.alloc(nn) != hipSuccess))
+        return fail(FH_ERR_NOMEM, "hipMalloc failed");
+    if (n > 0) {
+        for (int64_t i = 0; i < n; ++i)
+            if (!(uv[i] >= 0) || floor(uv[i] * (1 / h->bin_width)) > h->nbins)
+                return fail(FH_ERR_INVALID, "index out of bounds: baseline %g beyond the bin edges", uv[i]);
+        HIP_TRY(hipMemcpy(duv.p, uv, bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dw.p, w, bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dre.p, qre, bytes, hipMemcpyHostToDevice));
+        if (qim) HIP_TRY(hipMemcpy(dim.p, qim, bytes, hipMemcpyHostToDevice));
+    }
+    const double *qty[4] = {dre.p, qim ? dim.p : nullptr, nullptr, nullptr};
+    std::vector<double> sums;
+    std::vector<int64_t> cc;
+    int rc = uvbin_sums(h, duv.p, dw.p, qty, qim ? 2 : 1, n, counts != nullptr, sums, counts ? &cc : nullptr);
+    if (rc) return rc;
+    memcpy(out_re, sums.data(), sizeof(double) * (size_t)h->nbins);
+    if (qim) memcpy(out_im, sums.data() + h->nbins, sizeof(double) * (size_t)h->nbins);
+    if (counts) memcpy(counts, cc.data(), sizeof(int64_t) * (size_t)h->nbins);
     return FH_OK;
 }
 

@@ -138,3 +138,23 @@ struct LogNormalParams {
 
 size_t fh_ln_smem_bytes(int N, int *lu_in_lds);
 hipError_t fh_ln_launch(const LogNormalParams &P, int nblocks, hipStream_t s);
+
+// ---- UVDataBinner (uvbin.hip) -----------------------------------------------------------------------------------
+struct UvBinParams {
+    const double *uv, *w;   // baselines and weights of the rows (device)
+    const double *qty[4];   // up to four quantities to sum as w * qty (NULL = ones)
+    int nq;                 // number of quantities
+    int count;              // also count rows per bin
+    int64_t n;
+    double bin_width, norm; // norm = 1 / bin_width (utilities.py:211)
+    int nbins, use_lds;
+    const double *mu_re, *mu_im;  // per-bin means for the error pass
+    double *sums;                 // nq * nbins, zeroed by the caller
+    unsigned long long *counts;   // nbins, zeroed by the caller
+};
+
+hipError_t fh_uvbin_launch_max(const double *uv, int64_t n, unsigned long long *out2, int num_cu, hipStream_t s);
+hipError_t fh_uvbin_launch_sum(const UvBinParams &p, int num_cu, hipStream_t s);
+hipError_t fh_uvbin_launch_err(const UvBinParams &p, int num_cu, hipStream_t s);
+hipError_t fh_uvbin_launch_lookup(const double *uv, int64_t n, double bin_width, int nbins, int *out, int num_cu,
+                                  hipStream_t s);

@@ -1,0 +1,171 @@
+// uvbin.hip -- utilities.UVDataBinner (frank/utilities.py:180-400): weighted means of the visibilities in
+// equal-width baseline bins, the number of rows per bin and the error of the mean.
+//
+// HBM-bound streaming work: 32 B per row and pass (uv, Re V, Im V, w), a handful of flops, and a scatter into a
+// histogram of a few hundred to a few thousand bins.  Each workgroup keeps a private histogram in LDS (hardware
+// ds_add_f64 / ds_add_u64), flushes it once with global fp64 atomics; the bin INDEX of a row is integer work and
+// follows the reference's floor / edge fix-ups exactly (bit-exact indices and counts; the fp64 sums differ from
+// NumPy's sequential bincount by summation order only).
+//
+//   uvbin_index        bin_quantities   :329-341  (accumulation index, never -1)
+//   uvbin_lookup       determine_uv_bin :271-298  (-1 past the last edge)
+//   uvbin_max_kernel   __init__ :204     uv.max()
+//   uvbin_sum_kernel   bin_quantities   :300-366  sums of w*q for up to four quantities + counts
+//   uvbin_err_kernel   __init__ :239-246 sums of w^2 (V - mean[bin])^2
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int UT = 256;
+
+__device__ __forceinline__ double edge(int k, double bin_width) { return (double)k * bin_width; }  // arange * width
+
+__device__ __forceinline__ int uvbin_index(double uv, double norm, double bin_width, int nbins) {
+    int idx = (int)floor(uv * norm);
+    if (uv < edge(idx, bin_width)) idx -= 1;
+    if (idx == nbins) idx -= 1;
+    if (uv >= edge(idx + 1, bin_width) && idx + 1 != nbins) idx += 1;
+    return idx;
+}
+
+__device__ __forceinline__ int uvbin_lookup(double uv, double norm, double bin_width, int nbins) {
+    int idx = (int)floor(uv * norm);
+    if (uv < edge(idx, bin_width)) idx -= 1;
+    if (uv == edge(nbins, bin_width)) idx -= 1;
+    if (idx >= nbins) return -1;
+    if (uv >= edge(idx + 1, bin_width) && idx + 1 < nbins) idx += 1;
+    return idx;
+}
+
+__global__ __launch_bounds__(UT) void uvbin_max_kernel(const double *uv, int64_t n, unsigned long long *out) {
+    // baselines are non-negative: the IEEE bit pattern orders like the value
+    double m = 0.0;
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * UT + threadIdx.x; i < n; i += (int64_t)gridDim.x * UT) {
+        const double x = uv[i];
+        bad |= !(x >= 0.0);
+        m = fmax(m, x);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+    if (bad) atomicOr(out + 1, 1ull);
+}
+
+// sums[q * nbins + b] += w * qty_q for the given quantities, counts[b] += 1
+__global__ __launch_bounds__(UT) void uvbin_sum_kernel(UvBinParams p) {
+    extern __shared__ __attribute__((aligned(16))) double hist[];
+    const int nb = p.nbins, nq = p.nq;
+    unsigned long long *hcnt = reinterpret_cast<unsigned long long *>(hist + (size_t)nq * nb);
+    if (p.use_lds) {
+        for (int i = threadIdx.x; i < (nq + 1) * nb; i += UT) hist[i] = 0.0;  // +0.0 and 0ull share the bit pattern
+        __syncthreads();
+    }
+    double *acc = p.use_lds ? hist : p.sums;
+    unsigned long long *cnt = p.use_lds ? hcnt : p.counts;
+    for (int64_t i = (int64_t)blockIdx.x * UT + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * UT) {
+        const double x = p.uv[i], w = p.w[i];
+        const int b = uvbin_index(x, p.norm, p.bin_width, nb);
+        if (b < 0 || b >= nb) continue;  // NaN / negative baselines: reported by the max kernel
+        if (p.count) atomicAdd(cnt + b, 1ull);
+#pragma unroll 4
+        for (int q = 0; q < nq; ++q) {
+            const double *src = p.qty[q];
+            unsafeAtomicAdd(acc + (size_t)q * nb + b, w * (src ? src[i] : 1.0));
+        }
+    }
+    if (p.use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nq * nb; i += UT)
+            if (hist[i] != 0.0) unsafeAtomicAdd(p.sums + i, hist[i]);
+        if (p.count)
+            for (int i = threadIdx.x; i < nb; i += UT)
+                if (hcnt[i]) atomicAdd(p.counts + i, hcnt[i]);
+    }
+}
+
+// sums[b] += w^2 (Re V - mu_re[bin])^2, sums[nbins + b] += w^2 (Im V - mu_im[bin])^2   (utilities.py:239-246)
+__global__ __launch_bounds__(UT) void uvbin_err_kernel(UvBinParams p) {
+    extern __shared__ __attribute__((aligned(16))) double hist[];
+    const int nb = p.nbins, nq = p.qty[1] ? 2 : 1;
+    if (p.use_lds) {
+        for (int i = threadIdx.x; i < nq * nb; i += UT) hist[i] = 0.0;
+        __syncthreads();
+    }
+    double *acc = p.use_lds ? hist : p.sums;
+    for (int64_t i = (int64_t)blockIdx.x * UT + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * UT) {
+        const double x = p.uv[i], w = p.w[i];
+        const int b = uvbin_index(x, p.norm, p.bin_width, nb);
+        const int l = uvbin_lookup(x, p.norm, p.bin_width, nb);
+        if (b < 0 || b >= nb || l < 0) continue;
+        const double w2 = w * w;
+        const double dr = p.qty[0][i] - p.mu_re[l];
+        unsafeAtomicAdd(acc + b, w2 * (dr * dr));
+        if (nq == 2) {
+            const double di = p.qty[1][i] - p.mu_im[l];
+            unsafeAtomicAdd(acc + nb + b, w2 * (di * di));
+        }
+    }
+    if (p.use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nq * nb; i += UT)
+            if (hist[i] != 0.0) unsafeAtomicAdd(p.sums + i, hist[i]);
+    }
+}
+
+__global__ __launch_bounds__(UT) void uvbin_lookup_kernel(const double *uv, int64_t n, double norm, double bin_width,
+                                                          int nbins, int *out) {
+    for (int64_t i = (int64_t)blockIdx.x * UT + threadIdx.x; i < n; i += (int64_t)gridDim.x * UT)
+        out[i] = uvbin_lookup(uv[i], norm, bin_width, nbins);
+}
+
+int grid_for(int64_t n, int num_cu) {
+    const int64_t want = (n + UT - 1) / UT;
+    const int64_t cap = (int64_t)num_cu * 4;
+    return (int)(want < 1 ? 1 : (want < cap ? want : cap));
+}
+
+}  // namespace
+
+hipError_t fh_uvbin_launch_max(const double *uv, int64_t n, unsigned long long *out2, int num_cu, hipStream_t s) {
+    uvbin_max_kernel<<<grid_for(n, num_cu), UT, 0, s>>>(uv, n, out2);
+    return hipGetLastError();
+}
+
+static size_t uvbin_lds_bytes(int nq_plus, int nbins) { return (size_t)nq_plus * nbins * sizeof(double); }
+
+hipError_t fh_uvbin_launch_sum(const UvBinParams &p0, int num_cu, hipStream_t s) {
+    UvBinParams p = p0;
+    const size_t lds = uvbin_lds_bytes(p.nq + 1, p.nbins);
+    p.use_lds = lds <= 120 * 1024;
+    hipError_t e = hipSuccess;
+    if (p.use_lds)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(uvbin_sum_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+    if (e != hipSuccess) return e;
+    uvbin_sum_kernel<<<grid_for(p.n, num_cu), UT, p.use_lds ? lds : 0, s>>>(p);
+    return hipGetLastError();
+}
+
+hipError_t fh_uvbin_launch_err(const UvBinParams &p0, int num_cu, hipStream_t s) {
+    UvBinParams p = p0;
+    const size_t lds = uvbin_lds_bytes(2, p.nbins);
+    p.use_lds = lds <= 120 * 1024;
+    hipError_t e = hipSuccess;
+    if (p.use_lds)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(uvbin_err_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+    if (e != hipSuccess) return e;
+    uvbin_err_kernel<<<grid_for(p.n, num_cu), UT, p.use_lds ? lds : 0, s>>>(p);
+    return hipGetLastError();
+}
+
+hipError_t fh_uvbin_launch_lookup(const double *uv, int64_t n, double bin_width, int nbins, int *out, int num_cu,
+                                  hipStream_t s) {
+    uvbin_lookup_kernel<<<grid_for(n, num_cu), UT, 0, s>>>(uv, n, 1 / bin_width, bin_width, nbins, out);
+    return hipGetLastError();
+}

@@ -1,0 +1,156 @@
+"""UVDataBinner and estimate_weights -- drop-ins for frank/utilities.py:180-400 and :515-631.
+
+The row-wise work (bin index of every baseline, weighted sums per bin, squared deviations from the bin mean) runs in
+the uvbin kernels of libfrank_hip (LDS histograms, one streaming pass per statistic); what is left on the host is
+O(nbins): masking, and the neighbour logic of estimate_weights.
+"""
+import ctypes
+import logging
+
+import numpy as np
+
+from frank_amd import _lib
+
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+class UVDataBinner(object):
+    r"""Average uv-data into bins of equal size: the weighted mean of the visibilities in each bin
+    (utilities.py:180-400).  Same constructor and properties as the reference; empty bins are masked.
+
+    Parameters
+    ----------
+    uv : array, unit = :math:`\lambda` -- baselines of the data to bin
+    V : array, unit = Jy -- observed visibility; if complex both components are binned
+    weights : array, unit = Jy^-2 -- weights on the visibility points
+    bin_width : float, unit = :math:`\lambda`
+    """
+
+    def __init__(self, uv, V, weights, bin_width):
+        uv = _lib.f8(uv)
+        V = np.asarray(V)
+        self._complex = np.iscomplexobj(V)
+        Vre = _lib.f8(V.real)
+        Vim = _lib.f8(V.imag) if self._complex else None
+        w = _lib.f8(np.broadcast_to(weights, uv.shape))
+        if Vre.shape != uv.shape:
+            raise ValueError("uv and V must have the same length")
+        self._handle = ctypes.c_void_p()
+        _lib.check(_lib.lib.fh_uvbin_create(0, _lib.ptr(uv), _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), uv.size,
+                                            float(bin_width), ctypes.byref(self._handle)))
+        nbins = self._nbins = _lib.lib.fh_uvbin_nbins(self._handle)
+        self._bins = np.arange(nbins + 1, dtype='float64') * bin_width
+        self._norm = 1 / bin_width
+        b_uv, b_re, b_im, b_w = (np.empty(nbins) for _ in range(4))
+        e_re, e_im = np.empty(nbins), np.empty(nbins)
+        b_n = np.empty(nbins, dtype=np.int64)
+        _lib.check(_lib.lib.fh_uvbin_get(self._handle, _lib.ptr(b_uv), _lib.ptr(b_re), _lib.ptr(b_im), _lib.ptr(b_w),
+                                         b_n.ctypes.data_as(_i64p), _lib.ptr(e_re), _lib.ptr(e_im)))
+        mask = (b_n == 0)
+        b_V = (b_re + 1j * b_im) if self._complex else b_re
+        err = (e_re + 1j * e_im) if self._complex else e_re
+        err[mask] = np.nan
+        self._uv = np.ma.masked_where(mask, b_uv)
+        self._V = np.ma.masked_where(mask, b_V)
+        self._w = np.ma.masked_where(mask, b_w)
+        self._count = np.ma.masked_where(mask, b_n)
+        self._uv_left = np.ma.masked_where(mask, self._bins[:-1])
+        self._uv_right = np.ma.masked_where(mask, self._bins[1:])
+        self._Verr = np.ma.masked_where(mask, err)
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            _lib.lib.fh_uvbin_destroy(h)
+            self._handle = None
+
+    def determine_uv_bin(self, uv):
+        r"""Bin that each of the given uv points belongs to; -1 if the bin does not exist (utilities.py:271-298)."""
+        uv = _lib.f8(uv)
+        idx = np.empty(uv.shape, dtype=np.int32)
+        rc = _lib.lib.fh_uvbin_determine(self._handle, _lib.ptr(uv), uv.size, idx.ctypes.data_as(_i32p))
+        if rc == _lib.FH_ERR_INVALID:
+            raise IndexError(_lib.last_error())
+        _lib.check(rc)
+        return idx
+
+    def bin_quantities(self, uv, w, *quantities, bin_counts=False):
+        r"""Bin the given quantities according to the uv points and weights (utilities.py:300-366)."""
+        uv, w = _lib.f8(uv), _lib.f8(w)
+        nbins = self._nbins
+        results = []
+        counts = np.zeros(nbins, dtype=np.int64) if bin_counts else None
+        for k, qty in enumerate(quantities):
+            qty = np.asarray(qty)
+            cplx = np.iscomplexobj(qty)
+            qre = _lib.f8(qty.real)
+            qim = _lib.f8(qty.imag) if cplx else None
+            ore = np.empty(nbins)
+            oim = np.empty(nbins) if cplx else None
+            want = counts if (bin_counts and k == 0) else None
+            rc = _lib.lib.fh_uvbin_quantities(self._handle, _lib.ptr(uv), _lib.ptr(w), _lib.ptr(qre), _lib.ptr(qim),
+                                              uv.size, _lib.ptr(ore), _lib.ptr(oim),
+                                              None if want is None else want.ctypes.data_as(_i64p))
+            if rc == _lib.FH_ERR_INVALID:
+                raise IndexError(_lib.last_error())
+            _lib.check(rc)
+            results.append((ore + 1j * oim).astype(qty.dtype) if cplx else ore.astype(qty.dtype, copy=False))
+        if bin_counts:
+            return results + [counts]
+        if len(results) == 1:
+            return results[0]
+        return results
+
+    def __len__(self):
+        return len(self._uv)
+
+    uv = property(lambda self: self._uv, doc=r"Binned uv points, unit = :math:`\lambda`")
+    V = property(lambda self: self._V, doc="Binned visibility, unit = Jy")
+    weights = property(lambda self: self._w, doc="Binned weights, unit = Jy^-2")
+    error = property(lambda self: self._Verr, doc="Uncertainty on the binned visibilities, unit = Jy")
+    bin_counts = property(lambda self: self._count, doc="Number of points in each bin")
+    bin_edges = property(lambda self: [self._uv_left, self._uv_right], doc="Edges of the histogram bins")
+
+
+def estimate_weights(u, v=None, V=None, nbins=300, log=True, use_median=False, verbose=True):
+    r"""Estimate the weights from the variance of the binned visibilities (utilities.py:515-631); same call forms:
+    `estimate_weights(u, v, V)`, `estimate_weights(u, V)`, `estimate_weights(u, V=V)`.
+    """
+    if verbose:
+        logging.info('  Estimating visibility weights')
+    if V is None:
+        if v is None:
+            raise ValueError("The visibilities, V, must be supplied")
+        V, q = v, np.abs(u)
+    elif v is not None:
+        q = np.hypot(u, v)
+    else:
+        q = np.abs(u)
+    V = np.asarray(V)
+    if log:
+        q = np.log(q)
+        q -= q.min()
+    bin_width = (q.max() - q.min()) / nbins
+    uvBin = UVDataBinner(q, V, np.ones_like(q), bin_width)
+    if uvBin.bin_counts.max() == 1:
+        raise ValueError("No bin contains more than one uv point, can't"
+                         " estimate the variance. Use fewer bins.")
+    # as in the reference, `np.iscomplex(V.dtype)` is False for every dtype: the real-part variance is used (:589-592)
+    var = uvBin.error.real ** 2 * uvBin.bin_counts
+    if use_median:
+        if verbose:
+            logging.info('    Setting all weights as median binned visibility variance')
+        return np.full(len(u), 1 / np.ma.median(var[uvBin.bin_counts > 1]))
+    if verbose:
+        logging.info('    Setting weights according to baseline-dependent binned visibility variance')
+    single = np.argwhere(uvBin.bin_counts == 1).reshape(-1)
+    if len(single) > 0:  # bins with one point: mean of the two adjacent bins that have a variance (:606-616)
+        good = np.argwhere(uvBin.bin_counts > 1).reshape(-1)
+        loc = np.searchsorted(good, single, side='right')
+        below = good[np.maximum(loc - 1, 0)]
+        above = good[np.minimum(loc, len(good) - 1)]
+        var[single] = 0.5 * (var[below] + var[above])
+    bin_id = uvBin.determine_uv_bin(q)
+    assert np.all(bin_id != -1), "Error in binning"
+    return 1 / var[bin_id]

@@ -196,6 +196,27 @@ int fh_fit_lognormal_batched(fh_ctx *ctx, const double *M, const double *j, int 
 int fh_posterior_update(fh_ctx *ctx, const double *map, const double *Dinv, const double *p, double alpha, double p0,
                         double wsmooth, double *p_new);
 
+/* ---- utilities.UVDataBinner (utilities.py:180-400): uv-data averaged in bins of equal width ---------------------
+ * fh_uvbin_create: UVDataBinner(uv, V, weights, bin_width): uv, Vre, Vim (NULL for real V), w: n host doubles.
+ *   nbins = ceil(max(uv) / bin_width) (+1 under the rounding guard of :206-208); per bin the weighted means of uv
+ *   and V, the summed weight, the number of rows, and the error of the mean (NaN for bins with fewer than two rows,
+ *   as the reference leaves it: see the note at :256-261 in DESIGN.md).  Bin indices and counts are bit-exact.
+ * fh_uvbin_get: copies out nbins entries of each (any pointer may be NULL); empty bins hold 0 sums / NaN errors and
+ *   count 0 (the Python class masks them).
+ * fh_uvbin_determine: determine_uv_bin(uv) (:271-298): bin of each baseline, -1 exactly past the last edge;
+ *   FH_ERR_INVALID where the reference raises IndexError (baseline >= (nbins + 1) * bin_width).
+ * fh_uvbin_quantities: bin_quantities(uv, w, qty[, bin_counts]) (:300-366) for one real or complex quantity.   */
+typedef struct fh_uvbin fh_uvbin;
+int fh_uvbin_create(int device, const double *uv, const double *Vre, const double *Vim, const double *w, int64_t n,
+                    double bin_width, fh_uvbin **out);
+void fh_uvbin_destroy(fh_uvbin *h);
+int fh_uvbin_nbins(const fh_uvbin *h);
+int fh_uvbin_get(const fh_uvbin *h, double *uv, double *Vre, double *Vim, double *w, int64_t *count, double *err_re,
+                 double *err_im);
+int fh_uvbin_determine(fh_uvbin *h, const double *uv, int64_t n, int32_t *idx);
+int fh_uvbin_quantities(fh_uvbin *h, const double *uv, const double *w, const double *qre, const double *qim, int64_t n,
+                        double *out_re, double *out_im, int64_t *counts);
+
 /* ---- multi-GPU: RCCL all-reduce of the sufficient statistics (one rank per GPU) ------------------------------
  * The reduction being distributed is `Ms[i] += ...; js[i] += ...` (statistical_models.py:210-211) and the
  * sum at :218; min/max q feed _check_uv_range (:512-535).                                                    */

@@ -231,3 +231,37 @@ def frank_fit_lognormal(N, Rmax, M, j, alpha=1.05, p0=1e-35, wsmooth=1e-4, tol=1
     if diagnostics:
         out["diag_p"], out["diag_s"] = dp[:niter.value], ds[:niter.value]
     return out
+
+
+def uvbin_nbins(uv, bin_width):
+    uv = _f8(uv)
+    f = lib().fo_uvbin_nbins
+    f.restype = ctypes.c_int64
+    return int(f(_p(uv), ctypes.c_int64(uv.size), ctypes.c_double(bin_width)))
+
+
+def uvbin_determine(uv, bin_width, nbins):
+    """UVDataBinner.determine_uv_bin (utilities.py:271-298)."""
+    uv = _f8(uv)
+    out = np.empty(uv.size, dtype=np.int32)
+    lib().fo_uvbin_determine(_p(uv), ctypes.c_int64(uv.size), ctypes.c_double(bin_width), ctypes.c_int64(nbins),
+                             out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    return out
+
+
+def uvbin_build(uv, V, w, bin_width):
+    """UVDataBinner.__init__ (utilities.py:203-268). Returns dict(nbins, uv, V, w, count, err) with NaN-filled empties."""
+    uv, w = _f8(uv), _f8(w)
+    V = np.asarray(V)
+    cplx = np.iscomplexobj(V)
+    Vre = _f8(V.real)
+    Vim = _f8(V.imag) if cplx else None
+    nb = uvbin_nbins(uv, bin_width)
+    buv, bre, bim, bw = np.zeros(nb), np.zeros(nb), np.zeros(nb), np.zeros(nb)
+    ere, eim = np.zeros(nb), np.zeros(nb)
+    cnt = np.zeros(nb, dtype=np.int64)
+    lib().fo_uvbin_build(_p(uv), _p(Vre), _p(Vim), _p(w), ctypes.c_int64(uv.size), ctypes.c_double(bin_width),
+                         ctypes.c_int64(nb), _p(buv), _p(bre), _p(bim), _p(bw),
+                         cnt.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _p(ere), _p(eim))
+    return dict(nbins=nb, uv=buv, V=(bre + 1j * bim) if cplx else bre, w=bw, count=cnt,
+                err=(ere + 1j * eim) if cplx else ere)

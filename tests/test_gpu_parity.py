@@ -575,3 +575,66 @@ def test_bootstrap_matches_reference(golden):
     # the table is left untouched for ordinary fits afterwards
     sol = FF.fit(u, v, V, w)
     assert np.isfinite(sol.I).all()
+
+
+# ---- UVDataBinner / estimate_weights (next-tier row f4): HBM-bound histogram, integer bin indices ----------------
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_uvbinner(golden, tag):
+    """frank_amd.utilities.UVDataBinner vs the reference's (utilities.py:180-400): bin indices and counts BIT-EXACT,
+    masks identical, means / summed weights / errors to 1e-12 (atomic summation order), same NaN pattern."""
+    from frank_amd.utilities import UVDataBinner
+    g = golden("uvbin_3e4.npz")
+    V = g["Vre"] + 1j * g["Vim"]
+    bw = float(g["bw_" + tag])
+    b = UVDataBinner(g["q"], V, g["w"], bw)
+    assert len(b) == int(g["nbins_" + tag])
+    m = g["mask_" + tag]
+    assert np.array_equal(np.ma.getmaskarray(b.uv), m)
+    assert np.array_equal(np.ma.filled(b.bin_counts, 0), g["count_" + tag])
+    np.testing.assert_allclose(b.uv.compressed(), g["uv_" + tag][~m], rtol=1e-12)
+    np.testing.assert_allclose(b.weights.compressed(), g["w_" + tag][~m], rtol=1e-12)
+    np.testing.assert_allclose(b.V.compressed(), g["V_" + tag][~m], rtol=1e-10, atol=1e-14)
+    err, many = np.ma.filled(b.error, np.nan), g["count_" + tag] > 1
+    np.testing.assert_allclose(err[many], g["err_" + tag][many], rtol=1e-10)
+    assert np.all(np.isnan(err.real[~many]))
+    np.testing.assert_array_equal(np.ma.filled(b.bin_edges[0], np.nan)[~m], g["left_" + tag][~m])
+    np.testing.assert_array_equal(np.ma.filled(b.bin_edges[1], np.nan)[~m], g["right_" + tag][~m])
+    # determine_uv_bin incl. the edges, exactly past the last one (-1) and beyond (IndexError as in the reference)
+    assert np.array_equal(b.determine_uv_bin(g["probe_" + tag]), g["probe_idx_" + tag])
+    with pytest.raises(IndexError):
+        b.determine_uv_bin(np.array([(len(b) + 1.5) * bw]))
+    # real-valued data and bin_quantities
+    br = UVDataBinner(g["q"], g["Vre"], g["w"], bw)
+    np.testing.assert_allclose(np.ma.filled(br.error, np.nan)[many], g["err_real_" + tag][many], rtol=1e-10)
+    s_w, s_wV, cnt = b.bin_quantities(g["q"], g["w"], np.ones_like(g["q"]), V, bin_counts=True)
+    assert np.array_equal(cnt, g["count_" + tag])
+    np.testing.assert_allclose(s_w[~m], g["w_" + tag][~m], rtol=1e-12)
+    np.testing.assert_allclose(s_wV[~m] / s_w[~m], g["V_" + tag][~m], rtol=1e-10, atol=1e-14)
+    # against the CPU oracle on a bigger, different table (counts exact, sums to round-off)
+    from oracle import oracle as fo
+    rng = np.random.default_rng(5)
+    q2 = np.exp(rng.uniform(np.log(1e4), np.log(2e6), 400000))
+    V2 = rng.normal(size=q2.size) + 1j * rng.normal(size=q2.size)
+    w2 = rng.uniform(0.5, 2.0, q2.size)
+    b2, o2 = UVDataBinner(q2, V2, w2, 5e3), fo.uvbin_build(q2, V2, w2, 5e3)
+    assert np.array_equal(np.ma.filled(b2.bin_counts, 0), o2["count"])
+    ok = o2["count"] > 0
+    np.testing.assert_allclose(np.ma.filled(b2.V, 0)[ok], o2["V"][ok], rtol=1e-9, atol=1e-13)
+
+
+def test_estimate_weights(golden):
+    """utilities.estimate_weights (utilities.py:515-631) in its three call forms, median and linear-bin variants."""
+    from frank_amd.utilities import estimate_weights
+    g = golden("uvbin_3e4.npz")
+    V = g["Vre"] + 1j * g["Vim"]
+    up, vp = g["up"], g["vp"]
+    np.testing.assert_allclose(estimate_weights(up, vp, V, verbose=False), g["ew_uvV"], rtol=1e-9)
+    np.testing.assert_allclose(estimate_weights(up, V, verbose=False), g["ew_uV"], rtol=1e-9)
+    np.testing.assert_allclose(estimate_weights(up, V=V, verbose=False), g["ew_uV"], rtol=1e-9)
+    np.testing.assert_allclose(estimate_weights(up, vp, V, use_median=True, verbose=False)[:4], g["ew_median"], rtol=1e-9)
+    np.testing.assert_allclose(estimate_weights(up, vp, V, nbins=100, log=False, verbose=False), g["ew_lin_100"],
+                               rtol=1e-9)
+    np.testing.assert_allclose(estimate_weights(up, vp, g["Vre"], nbins=2000, verbose=False), g["ew_real"], rtol=1e-9)
+    with pytest.raises(ValueError):
+        estimate_weights(up)

@@ -255,3 +255,26 @@ def test_realdata_multi_ring(golden):
     # unit weights leave this problem far worse conditioned than the mock sets (there: 1e-9); the bar is north_star's 1e-6
     assert rel_to_max(out["mu"], g["I"]) < 1e-6
     np.testing.assert_allclose(out["p"], g["p"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_uvbin_oracle(golden, tag):
+    """UVDataBinner (utilities.py:180-400) restated in C: bin indices and counts bit-exact, means / weights / errors to
+    round-off, the NaN pattern of the error (bins with fewer than two rows) identical."""
+    g = golden("uvbin_3e4.npz")
+    V = g["Vre"] + 1j * g["Vim"]
+    bw = float(g["bw_" + tag])
+    o = fo.uvbin_build(g["q"], V, g["w"], bw)
+    assert o["nbins"] == int(g["nbins_" + tag])
+    assert np.array_equal(o["count"], g["count_" + tag])
+    m = g["mask_" + tag]
+    assert np.array_equal(o["count"] == 0, m)
+    np.testing.assert_allclose(o["uv"][~m], g["uv_" + tag][~m], rtol=1e-15)
+    np.testing.assert_allclose(o["w"][~m], g["w_" + tag][~m], rtol=1e-15)
+    np.testing.assert_allclose(o["V"][~m], g["V_" + tag][~m], rtol=1e-14)
+    many = g["count_" + tag] > 1
+    np.testing.assert_allclose(o["err"][many], g["err_" + tag][many], rtol=1e-13)
+    assert np.all(np.isnan(o["err"].real[~many])) and np.all(np.isnan(g["err_" + tag].real[~many]))
+    assert np.array_equal(fo.uvbin_determine(g["probe_" + tag], bw, o["nbins"]), g["probe_idx_" + tag])
+    o_real = fo.uvbin_build(g["q"], g["Vre"], g["w"], bw)
+    np.testing.assert_allclose(o_real["err"][many], g["err_real_" + tag][many], rtol=1e-13)

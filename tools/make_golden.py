@@ -177,6 +177,42 @@ def sweep():
     save("sweep_N50_2e4.npz", **out)
 
 
+def uvbin():
+    print("UVDataBinner (utilities.py:180-400)")
+    from frank.utilities import UVDataBinner
+    u, v, V, w = mock_disc_visibilities(30000, seed=21, noise_seed=22)
+    w = w * np.random.default_rng(23).uniform(0.5, 2.0, w.size)
+    up, vp = geom().deproject(u, v)
+    q = np.hypot(up, vp)
+    out = dict(q=q, Vre=V.real, Vim=V.imag, w=w)
+    for tag, bw in dict(a=2e4, b=1e3).items():
+        b = UVDataBinner(q, V, w, bw)
+        br = UVDataBinner(q, V.real, w, bw)
+        filled = lambda a, f=np.nan: np.ma.filled(a, f)  # noqa: E731
+        out.update({"bw_" + tag: bw, "nbins_" + tag: len(b), "uv_" + tag: filled(b.uv), "V_" + tag: filled(b.V),
+                    "w_" + tag: filled(b.weights), "count_" + tag: filled(b.bin_counts, 0),
+                    "err_" + tag: filled(b.error), "err_real_" + tag: filled(br.error),
+                    "mask_" + tag: np.ma.getmaskarray(b.uv), "left_" + tag: filled(b.bin_edges[0]),
+                    "right_" + tag: filled(b.bin_edges[1])})
+        # index look-ups, including the edges and past the last bin (determine_uv_bin, :271-298)
+        nb = len(b)
+        probe = np.concatenate([[0.0, bw, bw * (1 - 2 ** -53), np.nextafter(bw, 2 * bw), nb * bw, nb * bw * (1 + 1e-12),
+                                 (nb - 1) * bw], q[:200], np.arange(nb + 1) * bw])
+        out["probe_" + tag] = probe
+        out["probe_idx_" + tag] = b.determine_uv_bin(probe)
+        print("    bin_width %g: %d bins, %d empty, %d single" % (bw, nb, np.ma.getmaskarray(b.uv).sum(),
+                                                                 (filled(b.bin_counts, 0) == 1).sum()))
+    # estimate_weights (utilities.py:515-631): the three call forms + median, linear bins
+    from frank.utilities import estimate_weights
+    out["ew_uvV"] = estimate_weights(up, vp, V, verbose=False)
+    out["ew_uV"] = estimate_weights(up, V, verbose=False)
+    out["ew_median"] = estimate_weights(up, vp, V, use_median=True, verbose=False)[:4]
+    out["ew_lin_100"] = estimate_weights(up, vp, V, nbins=100, log=False, verbose=False)
+    out["ew_real"] = estimate_weights(up, vp, V.real, nbins=2000, verbose=False)  # leaves single-row bins
+    out["up"], out["vp"] = up, vp
+    save("uvbin_3e4.npz", **out)
+
+
 def bootstrap():
     print("bootstrap trials (fit.py:731-797, utilities.py:632-666), N=50, 2e4 vis, np.random.seed(1234)")
     from frank.utilities import draw_bootstrap_sample
