@@ -84,6 +84,7 @@ SIGNATURES = {
     "fh_uvbin_create": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, _dp, _i64, ctypes.c_double, ctypes.POINTER(_vp)]),
     "fh_uvbin_destroy": (None, [_vp]),
     "fh_uvbin_nbins": (ctypes.c_int, [_vp]),
+    "fh_uvbin_kernel_ms": (ctypes.c_float, [_vp]),
     "fh_uvbin_get": (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, ctypes.POINTER(_i64), _dp, _dp]),
     "fh_uvbin_determine": (ctypes.c_int, [_vp, _dp, _i64, ctypes.POINTER(ctypes.c_int32)]),
     "fh_uvbin_quantities": (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _i64, _dp, _dp, ctypes.POINTER(_i64)]),

@@ -1431,6 +1431,7 @@ struct fh_uvbin {
     DevBuf<double> uv, Vre, Vim, w;
     std::vector<double> b_uv, b_Vre, b_Vim, b_w, e_re, e_im;
     std::vector<int64_t> b_n;
+    float kernel_ms = 0;  // max + sum + error passes of the constructor (HIP events)
 };
 
 // sums of w * qty over the bins for device-resident rows (bin_quantities, utilities.py:300-366)
@@ -1455,7 +1456,18 @@ static int uvbin_sums(fh_uvbin *h, const double *d_uv, const double *d_w, const 
     p.nbins = nb;
     p.sums = ds.p;
     p.counts = dc.p;
+    hipEvent_t s0 = nullptr, s1 = nullptr;
+    HIP_TRY(hipEventCreate(&s0));
+    HIP_TRY(hipEventCreate(&s1));
+    HIP_TRY(hipEventRecord(s0, nullptr));
     HIP_TRY(fh_uvbin_launch_sum(p, h->num_cu, nullptr));
+    HIP_TRY(hipEventRecord(s1, nullptr));
+    HIP_TRY(hipEventSynchronize(s1));
+    float sms = 0;
+    HIP_TRY(hipEventElapsedTime(&sms, s0, s1));
+    (void)hipEventDestroy(s0);
+    (void)hipEventDestroy(s1);
+    h->kernel_ms = sms;
     sums.resize((size_t)nq * nb);
     HIP_TRY(hipMemcpy(sums.data(), ds.p, sizeof(double) * sums.size(), hipMemcpyDeviceToHost));
     if (counts) {
@@ -1489,11 +1501,22 @@ int fh_uvbin_create(int device, const double *uv, const double *Vre, const doubl
     HIP_TRY(hipMemcpy(h->Vre.p, Vre, bytes, hipMemcpyHostToDevice));
     if (Vim) HIP_TRY(hipMemcpy(h->Vim.p, Vim, bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->w.p, w, bytes, hipMemcpyHostToDevice));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventCreate(&ev2));
+    HIP_TRY(hipEventCreate(&ev3));
+    struct EvGuard {
+        hipEvent_t *e[4];
+        ~EvGuard() { for (auto p : e) if (*p) (void)hipEventDestroy(*p); }
+    } guard{{&ev0, &ev1, &ev2, &ev3}};
     // nbins = ceil(uv.max() / bin_width), +1 if rounding left the maximum outside (utilities.py:204-208)
     DevBuf<unsigned long long> mx;
     if (mx.alloc(2) != hipSuccess) return fail(FH_ERR_NOMEM, "fh_uvbin_create: hipMalloc failed");
     HIP_TRY(hipMemset(mx.p, 0, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipEventRecord(ev0, nullptr));
     HIP_TRY(fh_uvbin_launch_max(h->uv.p, n, mx.p, h->num_cu, nullptr));
+    HIP_TRY(hipEventRecord(ev1, nullptr));
     unsigned long long mxh[2];
     HIP_TRY(hipMemcpy(mxh, mx.p, sizeof mxh, hipMemcpyDeviceToHost));
     if (mxh[1]) return fail(FH_ERR_INVALID, "fh_uvbin_create: baselines must be non-negative and finite");
@@ -1542,7 +1565,9 @@ int fh_uvbin_create(int device, const double *uv, const double *Vre, const doubl
     p.mu_re = mre.p;
     p.mu_im = mim.p;
     p.sums = es.p;
+    HIP_TRY(hipEventRecord(ev2, nullptr));
     HIP_TRY(fh_uvbin_launch_err(p, h->num_cu, nullptr));
+    HIP_TRY(hipEventRecord(ev3, nullptr));
     std::vector<double> e(2 * (size_t)nb);
     HIP_TRY(hipMemcpy(e.data(), es.p, sizeof(double) * e.size(), hipMemcpyDeviceToHost));
     h->e_re.assign((size_t)nb, NAN);
@@ -1553,6 +1578,13 @@ int fh_uvbin_create(int device, const double *uv, const double *Vre, const doubl
             h->e_re[b] = sqrt(e[b] / den);
             if (Vim) h->e_im[b] = sqrt(e[(size_t)nb + b] / den);
         }
+    {
+        float a = 0, b2 = 0;
+        HIP_TRY(hipEventSynchronize(ev3));
+        HIP_TRY(hipEventElapsedTime(&a, ev0, ev1));
+        HIP_TRY(hipEventElapsedTime(&b2, ev2, ev3));
+        h->kernel_ms = a + b2 + h->kernel_ms;  // + the sum pass, timed inside uvbin_sums
+    }
     // bins with one row: utilities.py:256-261 assigns to `.real` of a fancy-indexed copy, which leaves np.nan
     // (nan+0j for complex V) in place -- kept, so that results match the reference
     *out = h.release();
@@ -1566,6 +1598,7 @@ void fh_uvbin_destroy(fh_uvbin *h) {
 }
 
 int fh_uvbin_nbins(const fh_uvbin *h) { return h ? h->nbins : 0; }
+float fh_uvbin_kernel_ms(const fh_uvbin *h) { return h ? h->kernel_ms : 0.0f; }
 
 int fh_uvbin_get(const fh_uvbin *h, double *uv, double *Vre, double *Vim, double *w, int64_t *count, double *err_re,
                  double *err_im) {

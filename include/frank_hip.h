@@ -211,6 +211,7 @@ int fh_uvbin_create(int device, const double *uv, const double *Vre, const doubl
                     double bin_width, fh_uvbin **out);
 void fh_uvbin_destroy(fh_uvbin *h);
 int fh_uvbin_nbins(const fh_uvbin *h);
+float fh_uvbin_kernel_ms(const fh_uvbin *h); /* HIP-event time of the three streaming passes of fh_uvbin_create */
 int fh_uvbin_get(const fh_uvbin *h, double *uv, double *Vre, double *Vim, double *w, int64_t *count, double *err_re,
                  double *err_im);
 int fh_uvbin_determine(fh_uvbin *h, const double *uv, int64_t n, int32_t *idx);
