@@ -41,8 +41,10 @@ FP64_MFMA_PEAK_TFLOPS = 78.6
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    # the timed region holds K binning passes back to back plus ONE pipeline drain (the iteration of the last fit,
+    # ~0.29 s): the default K amortises it, a small K mostly measures it
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nvis", type=int, default=N_VIS)
     ap.add_argument("--ncoll", type=int, default=N_COLL)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -266,11 +268,12 @@ def main():
             "breakdown_ms": {"single_fit_latency": 1e3 * (t_bin + t_solve), "bin_gram_pass": 1e3 * t_bin,
                              "finalize_plus_iterate": 1e3 * t_solve, "us_per_iteration": 1e6 * t_solve / max(nit, 1),
                              "bin_gram_kernel_alone": kms_alone,
-                             "note": "steps are pipelined: fit i's iteration (one CU) overlaps fit i+1's binning"},
+                             "note": "steps are pipelined: fit i's iteration (one CU) overlaps fit i+1's binning; the "
+                                     "timed region = steps x (binning + hand-over) + one drain of finalize_plus_iterate"},
             "roofline": {"kernel": "bin_gram_kernel<19>", "bound": "mfma", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": "profiles/r01_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / "
-                         "WRITE_SIZE, FETCH doubled per the gfx950 note)", "kernel_ms": kms, "kernel_ms_per_step": [round(x, 2) for x in kernel_ms],
+                         "WRITE_SIZE, FETCH doubled per the gfx950 note)", "kernel_ms": kms, "kernel_ms_min_median_max": [round(float(x), 2) for x in (np.min(kernel_ms), np.median(kernel_ms), np.max(kernel_ms))],
                          "algorithmic_flops_per_vis": Nc * (Nc + 1) + 2 * Nc,
                          "achieved_full_gram_equiv": flops_full / (kms * 1e-3) / 1e12,
                          "hbm_read_GBps": 40.0 * a.nvis / (kms * 1e-3) / 1e9 * (1.0 if Nc <= 207 else 2.0)},

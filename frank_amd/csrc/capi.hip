@@ -52,13 +52,21 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool owned = true;
     hipError_t alloc(size_t count) {
         release();
         n = count;
+        owned = true;
         return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
     }
+    void adopt(T *slice, size_t count) {  // a slice of somebody else's allocation
+        release();
+        p = slice;
+        n = count;
+        owned = false;
+    }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && owned) (void)hipFree(p);
         p = nullptr;
         n = 0;
     }
@@ -83,7 +91,11 @@ struct FitSlot {
     DevBuf<int> result;
     bool busy = false;
 };
-constexpr int kFitSlots = 32;
+// One HIP stream per slot.  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; raised to 24 below)
+// and two kernels whose streams share a queue serialise: with 32 slot streams the 25th fit queued BEHIND a running
+// one (seen in the kernel trace as a 190 ms stall).  16 slots stay one-to-one with queues and still cover the ~9
+// fits that are in flight at the binning rate (0.33 s per fit / 37 ms per pass).
+constexpr int kFitSlots = 16;
 
 struct fh_ctx {
     const fh_dht *dht = nullptr;
@@ -106,6 +118,8 @@ struct fh_ctx {
     DevBuf<double> Yinv, T1, Araw, Aq, bq, Cq, Wq, Tq, WdT, cs, mu_out, p_out, p_init;
     DevBuf<int> loop_result;
     DevBuf<long long> loop_timing;  // FIT_LOOP_TIMING debug builds only
+    DevBuf<double> slot_pool;   // backing store of every slot's buffers
+    DevBuf<int> slot_results;
     FitSlot slots[kFitSlots];
     int slots_busy = 0;
     bool have_device_Mj = false;
@@ -127,6 +141,11 @@ struct fh_comm {
     int (*destroy)(void *) = nullptr;
     const char *(*errstr)(int) = nullptr;
 };
+
+// The default of 4 hardware queues would serialise the fit_loop kernels of independent fits; this must be in the
+// environment before the HIP runtime initialises (first HIP call), so it is set when the library is loaded and never
+// overrides a value the user chose.
+__attribute__((constructor)) static void fh_raise_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 
 extern "C" {
 
@@ -1069,27 +1088,35 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
             break;
         }
     if (si < 0) return fail(FH_ERR_INVALID, "fh_fit_submit: all %d fit slots are outstanding; collect one first", kFitSlots);
-    FitSlot &s = c->slots[si];
     const int N = c->N;
     const size_t PP = (size_t)c->NP * c->NP;
-    if (!s.stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
-        HIP_TRY(s.Aq.alloc(PP));
-        HIP_TRY(s.Cq.alloc(PP));
-        HIP_TRY(s.Wq.alloc(PP));
-        HIP_TRY(s.Tq.alloc(PP));
-        HIP_TRY(s.WdT.alloc((size_t)c->NP * 16));
-        HIP_TRY(s.cs.alloc((size_t)(c->NP / 16) * (c->NP / 16) * 16));
-        // stream-ordered (a null-stream memset is NOT ordered against the non-blocking slot streams)
-        HIP_TRY(hipMemsetAsync(s.Cq.p, 0, sizeof(double) * PP, c->stream));
-        HIP_TRY(hipMemsetAsync(s.Wq.p, 0, sizeof(double) * PP, c->stream));
-        HIP_TRY(s.bq.alloc(N));
-        HIP_TRY(s.mu_out.alloc(N));
-        HIP_TRY(s.p_out.alloc(N));
-        HIP_TRY(s.band_lu.alloc(5 * (size_t)N));
-        HIP_TRY(s.result.alloc(2));
+    if (!c->slot_pool.p) {
+        // all slots at once, carved from ONE allocation: a hipMalloc per buffer costs ~0.7 ms of host time, and paying
+        // 11 of them whenever a fresh slot is first used put an 8 ms hole after every binning pass of a pipeline
+        const size_t nbk = (size_t)(c->NP / 16);
+        const size_t per_slot = 4 * PP + (size_t)c->NP * 16 + nbk * nbk * 16 + 3 * (size_t)N + 5 * (size_t)N;
+        HIP_TRY(c->slot_pool.alloc(per_slot * kFitSlots));
+        HIP_TRY(c->slot_results.alloc(2 * kFitSlots));
+        HIP_TRY(hipMemsetAsync(c->slot_pool.p, 0, sizeof(double) * per_slot * kFitSlots, c->stream));
+        for (int i = 0; i < kFitSlots; ++i) {
+            FitSlot &t = c->slots[i];
+            double *b = c->slot_pool.p + per_slot * i;
+            HIP_TRY(hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&t.ready, hipEventDisableTiming));
+            t.Aq.adopt(b, PP); b += PP;
+            t.Cq.adopt(b, PP); b += PP;
+            t.Wq.adopt(b, PP); b += PP;
+            t.Tq.adopt(b, PP); b += PP;
+            t.WdT.adopt(b, (size_t)c->NP * 16); b += (size_t)c->NP * 16;
+            t.cs.adopt(b, nbk * nbk * 16); b += nbk * nbk * 16;
+            t.bq.adopt(b, N); b += N;
+            t.mu_out.adopt(b, N); b += N;
+            t.p_out.adopt(b, N); b += N;
+            t.band_lu.adopt(b, 5 * (size_t)N);
+            t.result.adopt(c->slot_results.p + 2 * i, 2);
+        }
     }
+    FitSlot &s = c->slots[si];
     std::vector<double> lu;
     smoothing_band_lu(*c->dht, wsmooth, lu);
     HIP_TRY(hipMemcpyAsync(s.band_lu.p, lu.data(), sizeof(double) * lu.size(), hipMemcpyHostToDevice, c->stream));
