@@ -389,6 +389,70 @@ __global__ void finalize_stats_kernel(const double *stats_sum, int NBT, int N, c
     }
 }
 
+// ---- N > 303: rows to memory + rocBLAS dsyrk (the register-resident kernel cannot hold more than 190 tiles) --------
+// Xt[i, k] = sqrt(w_i) J0(s_i j_k) (k < N), Xt[i, N] = sqrt(w_i) Re V'_i, row-major with leading dimension N + 1: read
+// as a column-major (N+1) x rows matrix it is the operand of G += Xc Xc^T.
+__global__ void wide_rows_kernel(const double *prep_s, const double *prep_sw, const double *prep_swV, int64_t first,
+                                 int64_t rows, int N, const double *zeros, const double *j0_table, double *X) {
+    __shared__ double tab[FH_J0_TABLE_DOUBLES];
+    for (int i = threadIdx.x; i < FH_J0_TABLE_DOUBLES; i += blockDim.x) tab[i] = j0_table[i];
+    __syncthreads();
+    const int N1 = N + 1;
+    const int64_t total = rows * (int64_t)N1;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / N1;
+        const int k = (int)(e - i * N1);
+        const int64_t g = first + i;
+        double val;
+        if (k < N) {
+            double x;
+            {
+#pragma clang fp contract(off)
+                x = prep_s[g] * zeros[k];
+            }
+            val = prep_sw[g] * fh_j0(x, tab);
+        } else {
+            val = prep_swV[g];
+        }
+        X[e] = val;
+    }
+}
+
+// fold the per-block scalars of deproject_kernel into the running totals (the tile reducer does this for N <= 303)
+__global__ void wide_scalars_kernel(const double *partial_scalars, int blocks, double *tail, double *stats_minmax) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0.0, mn = INFINITY, mx = -INFINITY;
+        for (int b = 0; b < blocks; ++b) {
+            s += partial_scalars[b * 4 + 0];
+            mn = fmin(mn, partial_scalars[b * 4 + 1]);
+            mx = fmax(mx, partial_scalars[b * 4 + 2]);
+        }
+        tail[0] += s;
+        stats_minmax[0] = fmax(stats_minmax[0], -mn);
+        stats_minmax[1] = fmax(stats_minmax[1], mx);
+    }
+}
+
+// G is the (N+1) x (N+1) column-major Gram with the UPPER triangle valid: entry (r, c), r <= c, at G[c * (N+1) + r]
+__global__ void wide_finalize_kernel(const double *G, int N, const double *a, double *M, double *j, double *sumwV2) {
+    const int N1 = N + 1;
+    const int64_t total = (int64_t)N1 * N1;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e / N1), r = (int)(e - (int64_t)c * N1);
+        if (r > c) continue;
+        const double g = G[e];
+        if (c < N) {
+            const double m = (a[r] * a[c]) * g;
+            M[(size_t)r * N + c] = m;
+            M[(size_t)c * N + r] = m;
+        } else if (r < N) {
+            j[r] = a[r] * g;
+        } else {
+            *sumwV2 = g;
+        }
+    }
+}
+
 // a3/a7: H[i,k] = (norm*sf_k) * J0((kq*q_i) * j_k) * scale   (hankel.py:201-202, statistical_models.py:507)
 __global__ void coefficients_kernel(const double *q, int64_t n, int N, const double *zeros, const double *pref,
                                     double inv_Q, double scale, const double *j0_table, double *H) {
@@ -510,5 +574,28 @@ hipError_t fh_k1_launch_predict(const double *q, int64_t n, int N, const double 
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(predict_kernel, dim3(grid), dim3(256), 0, stream, q, n, N, zeros, pref, inv_Q, scale, I,
                        j0_table, V);
+    return hipGetLastError();
+}
+
+hipError_t fh_k1_launch_wide_rows(const BinParams &p, int64_t first, int64_t rows, double *X, hipStream_t stream) {
+    const int64_t total = rows * (int64_t)(p.N + 1);
+    int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(wide_rows_kernel, dim3(grid), dim3(256), 0, stream, p.prep_s, p.prep_sw, p.prep_swV, first, rows,
+                       p.N, p.zeros, p.j0_table, X);
+    return hipGetLastError();
+}
+
+hipError_t fh_k1_launch_wide_scalars(const double *partial_scalars, int blocks, double *tail, double *stats_minmax,
+                                     hipStream_t stream) {
+    hipLaunchKernelGGL(wide_scalars_kernel, dim3(1), dim3(64), 0, stream, partial_scalars, blocks, tail, stats_minmax);
+    return hipGetLastError();
+}
+
+hipError_t fh_k1_launch_wide_finalize(const double *G, int N, const double *a, double *M, double *j, double *sumwV2,
+                                      hipStream_t stream) {
+    const int64_t total = (int64_t)(N + 1) * (N + 1);
+    hipLaunchKernelGGL(wide_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, G, N, a, M, j,
+                       sumwV2);
     return hipGetLastError();
 }

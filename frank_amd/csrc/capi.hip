@@ -109,6 +109,11 @@ struct fh_ctx {
     DevBuf<double> partials[2], partial_scalars, stats_sum, stats_minmax, a_scale, sumwV2, prep;
     DevBuf<int> work_counter;
     int deproject_blocks = 0;
+    // N > 303: rows to memory + rocBLAS dsyrk; stats_sum then holds the dense (N+1)^2 Gram (upper triangle) + 2 scalars
+    bool wide = false;
+    size_t tail_offset = 0;      // index of sum log(w / 2 pi) in stats_sum
+    int64_t wide_rows = 0;       // rows per dsyrk chunk
+    DevBuf<double> wide_X;
     // normal equations + K2 work
     DevBuf<double> M, j, W, D, Z, p, p_old, mu, band_lu, diag_p, diag_mu;
     DevBuf<int> flags, info;
@@ -237,7 +242,7 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     HIP_TRY(hipMemcpy(c->pref_fwd.p, pf.data(), sizeof(double) * N, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->pref_bwd.p, pb.data(), sizeof(double) * N, hipMemcpyHostToDevice));
 
-    // K1 workspaces (0 => N too large for the register-resident kernel; binning then reports FH_ERR_UNSUPPORTED)
+    // K1 workspaces (0 => N too large for the register-resident kernel: the rows-to-memory + dsyrk path is used)
     c->NBT = fh_k1_nbt_for(N);
     if (c->NBT) {
         c->ntiles = fh_k1_ntiles(c->NBT);
@@ -263,6 +268,20 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
         HIP_TRY(c->stats_minmax.alloc(2));
         HIP_TRY(c->a_scale.alloc(N));
         HIP_TRY(c->sumwV2.alloc(1));
+        c->tail_offset = (size_t)c->ntiles * 256;
+    } else {
+        c->wide = true;
+        const int G = c->num_cu > 0 ? c->num_cu : 256;
+        const size_t N1 = (size_t)N + 1;
+        c->deproject_blocks = 8 * G;
+        c->wide_rows = 65536;
+        HIP_TRY(c->partial_scalars.alloc((size_t)c->deproject_blocks * 4));
+        HIP_TRY(c->stats_sum.alloc(N1 * N1 + 2));
+        HIP_TRY(c->stats_minmax.alloc(2));
+        HIP_TRY(c->a_scale.alloc(N));
+        HIP_TRY(c->sumwV2.alloc(1));
+        HIP_TRY(c->wide_X.alloc((size_t)c->wide_rows * N1));
+        c->tail_offset = N1 * N1;
     }
     // K2
     HIP_TRY(c->M.alloc(NN));
@@ -443,7 +462,6 @@ int fh_vis_set_multiplicity(fh_vis *vis, const int32_t *counts) {
 // ---- K1 ----------------------------------------------------------------------------------------------------------
 int fh_bin_reset(fh_ctx *c) {
     if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
-    if (!c->NBT) return FH_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->stats_sum.p, 0, sizeof(double) * c->stats_sum.n, c->stream));
     const double init[2] = {-INFINITY, -INFINITY};  // (-qmin, qmax) under max
@@ -455,7 +473,6 @@ int fh_bin_reset(fh_ctx *c) {
 
 int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int64_t first, int64_t count) {
     if (!c || !g || !vis) return fail(FH_ERR_INVALID, "fh_bin_visibilities: NULL argument");
-    if (!c->NBT) return fail(FH_ERR_UNSUPPORTED, "N = %d: the bin_gram kernel covers N <= 303", c->N);
     if (first < 0 || count < 0 || first + count > vis->n) return fail(FH_ERR_INVALID, "fh_bin_visibilities: bad range");
     if (vis->device != c->device) return fail(FH_ERR_INVALID, "visibility table lives on another device");
     HIP_TRY(hipSetDevice(c->device));
@@ -488,6 +505,29 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     p.prep_s = c->prep.p;
     p.prep_sw = c->prep.p + (count > 0 ? count : 1);
     p.prep_swV = c->prep.p + 2 * (size_t)(count > 0 ? count : 1);
+    if (c->wide) {
+        // N > 303: sqrt(w)-scaled rows to memory, chunk by chunk, and G += X^T X by rocBLAS (fp64 MFMA inside)
+        int dblocks = (int)((count + 255) / 256);
+        if (dblocks > c->deproject_blocks) dblocks = c->deproject_blocks;
+        if (dblocks < 1) dblocks = 1;
+        p.partial_scalars = c->partial_scalars.p;
+        HIP_TRY(fh_k1_launch_deproject(p, dblocks, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_bin0, c->stream));
+        const int N1 = c->N + 1;
+        const double one = 1.0;
+        for (int64_t r0 = 0; r0 < count; r0 += c->wide_rows) {
+            const int64_t rows = count - r0 < c->wide_rows ? count - r0 : c->wide_rows;
+            HIP_TRY(fh_k1_launch_wide_rows(p, r0, rows, c->wide_X.p, c->stream));
+            ROC_TRY(rocblas_dsyrk(c->blas, rocblas_fill_upper, rocblas_operation_none, N1, (rocblas_int)rows, &one,
+                                  c->wide_X.p, N1, &one, c->stats_sum.p, N1));
+        }
+        HIP_TRY(hipEventRecord(c->ev_bin1, c->stream));
+        c->bin_timed = true;
+        HIP_TRY(fh_k1_launch_wide_scalars(c->partial_scalars.p, dblocks, c->stats_sum.p + c->tail_offset,
+                                          c->stats_minmax.p, c->stream));
+        c->have_device_Mj = false;
+        return FH_OK;
+    }
     // throughput mode while fit_loop kernels of earlier fits hold CUs (see bin_gram.hip)
     const bool dynamic = c->slots_busy > 0;
     p.work_counter = dynamic ? c->work_counter.p : nullptr;
@@ -535,7 +575,7 @@ int fh_bin_last_kernel_ms(fh_ctx *c, float *ms) {
 }
 
 int fh_stats_device(fh_ctx *c, double **sum_stats, int64_t *n_sum, double **minmax_stats) {
-    if (!c || !c->NBT) return fail(FH_ERR_INVALID, "fh_stats_device: no binning workspace");
+    if (!c || !c->stats_sum.p) return fail(FH_ERR_INVALID, "fh_stats_device: no binning workspace");
     if (sum_stats) *sum_stats = c->stats_sum.p;
     if (n_sum) *n_sum = (int64_t)c->stats_sum.n;
     if (minmax_stats) *minmax_stats = c->stats_minmax.p;
@@ -545,7 +585,6 @@ int fh_stats_device(fh_ctx *c, double **sum_stats, int64_t *n_sum, double **minm
 int fh_stats_finalize(fh_ctx *c, const fh_geometry *g, int vis_model, int check_qbounds, double *M, double *j,
                       double *H0, double *qmin, double *qmax) {
     if (!c || !g) return fail(FH_ERR_INVALID, "fh_stats_finalize: NULL argument");
-    if (!c->NBT) return fail(FH_ERR_UNSUPPORTED, "N = %d: the bin_gram kernel covers N <= 303", c->N);
     if (vis_model != FH_VIS_OPT_THICK && vis_model != FH_VIS_OPT_THIN)
         return fail(FH_ERR_INVALID, "vis_model must be one of ['opt_thick', 'opt_thin'] here ('debris' is not built)");
     HIP_TRY(hipSetDevice(c->device));
@@ -556,9 +595,12 @@ int fh_stats_finalize(fh_ctx *c, const fh_geometry *g, int vis_model, int check_
     std::vector<double> a(N);
     for (int k = 0; k < N; ++k) a[k] = (norm * c->dht->scale_factor[k]) * scale;
     HIP_TRY(hipMemcpyAsync(c->a_scale.p, a.data(), sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(fh_k1_launch_finalize(c->stats_sum.p, c->NBT, N, c->a_scale.p, c->M.p, c->j.p, c->sumwV2.p, c->stream));
+    if (c->wide)
+        HIP_TRY(fh_k1_launch_wide_finalize(c->stats_sum.p, N, c->a_scale.p, c->M.p, c->j.p, c->sumwV2.p, c->stream));
+    else
+        HIP_TRY(fh_k1_launch_finalize(c->stats_sum.p, c->NBT, N, c->a_scale.p, c->M.p, c->j.p, c->sumwV2.p, c->stream));
     double tail[2], mm[2], swv2;
-    HIP_TRY(hipMemcpyAsync(tail, c->stats_sum.p + (size_t)c->ntiles * 256, sizeof tail, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(tail, c->stats_sum.p + c->tail_offset, sizeof tail, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(mm, c->stats_minmax.p, sizeof mm, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&swv2, c->sumwV2.p, sizeof swv2, hipMemcpyDeviceToHost, c->stream));
     if (M) HIP_TRY(hipMemcpyAsync(M, c->M.p, sizeof(double) * (size_t)N * N, hipMemcpyDeviceToHost, c->stream));
@@ -924,7 +966,8 @@ static FitLoopParams make_loop_params(fh_ctx *c, int mode, double alpha, double 
 int fh_fit_normal(fh_ctx *c, const double *M, const double *j, double alpha, double p0, double wsmooth, double tol,
                   int max_iter, double *mu, double *p, int *niter, double *diag_p, double *diag_mu) {
     if (!c || !mu || !p || !niter) return fail(FH_ERR_INVALID, "fh_fit_normal: NULL argument");
-    if (c->use_rocsolver_loop)
+    // N > 303 does not fit the LDS-resident fit_loop kernel: the library loop (rocBLAS + rocSOLVER per iteration) serves
+    if (c->use_rocsolver_loop || c->NP > 320)
         return fit_normal_rocsolver(c, M, j, alpha, p0, wsmooth, tol, max_iter, mu, p, niter, diag_p, diag_mu);
     if ((M == nullptr) != (j == nullptr)) return fail(FH_ERR_INVALID, "fh_fit_normal: pass both M and j or neither");
     if (!M && !c->have_device_Mj) return fail(FH_ERR_INVALID, "fh_fit_normal: no device-resident M, j (run fh_stats_finalize)");
@@ -1166,7 +1209,8 @@ int fh_fit_collect(fh_ctx *c, int ticket, double *mu, double *p, int *niter) {
 int fh_update_power_spectrum(fh_ctx *c, const double *M, const double *j, const double *p, double alpha, double p0,
                              double wsmooth, double *mu, double *p_new) {
     if (!c || !M || !j || !p) return fail(FH_ERR_INVALID, "fh_update_power_spectrum: NULL argument");
-    if (c->use_rocsolver_loop) return update_power_spectrum_rocsolver(c, M, j, p, alpha, p0, wsmooth, mu, p_new);
+    if (c->use_rocsolver_loop || c->NP > 320)
+        return update_power_spectrum_rocsolver(c, M, j, p, alpha, p0, wsmooth, mu, p_new);
     if (c->NP > 320) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 320", c->N);
     HIP_TRY(hipSetDevice(c->device));
     const int N = c->N;

@@ -43,6 +43,11 @@ int fh_k1_super();
 hipError_t fh_k1_launch_deproject(const BinParams &p, int blocks, hipStream_t stream);
 hipError_t fh_k1_launch_bin(int NBT, const BinParams &p, hipStream_t stream);
 hipError_t fh_k1_launch_reduce(const ReduceParams &rp, double *stats_sum, double *stats_minmax, hipStream_t stream);
+hipError_t fh_k1_launch_wide_rows(const BinParams &p, int64_t first, int64_t rows, double *X, hipStream_t stream);
+hipError_t fh_k1_launch_wide_scalars(const double *partial_scalars, int blocks, double *tail, double *stats_minmax,
+                                     hipStream_t stream);
+hipError_t fh_k1_launch_wide_finalize(const double *G, int N, const double *a, double *M, double *j, double *sumwV2,
+                                      hipStream_t stream);
 hipError_t fh_k1_launch_finalize(const double *stats_sum, int NBT, int N, const double *a, double *M, double *j,
                                  double *sumwV2, hipStream_t stream);
 hipError_t fh_k1_launch_coefficients(const double *q, int64_t n, int N, const double *zeros, const double *pref,

@@ -638,3 +638,42 @@ def test_estimate_weights(golden):
     np.testing.assert_allclose(estimate_weights(up, vp, g["Vre"], nbins=2000, verbose=False), g["ew_real"], rtol=1e-9)
     with pytest.raises(ValueError):
         estimate_weights(up)
+
+
+def test_wide_basis_N320(golden):
+    """N = 320 > 303: the register-resident Gram kernel does not apply; rows go to memory, rocBLAS dsyrk accumulates
+    them, and the iteration runs through the rocBLAS / rocSOLVER loop.  Same parity bar as the other sizes."""
+    from frank_amd import FrankFitter
+    g = golden("fit_N320_5e4.npz")
+    u, v, V, w = mock_disc_visibilities(int(g["n"]), seed=int(g["seed"]), noise_seed=int(g["noise_seed"]))
+    assert sha(u, v, V, w) == str(g["input_sha256"])
+    FF = FrankFitter(2.0, 320, geom(), store_iteration_diagnostics=True, verbose=False)
+    m = FF.preprocess_visibilities(u, v, V, w)
+    assert np.array_equal(m["M"], m["M"].T)
+    assert rel_to_max(np.diag(m["M"]), g["M_diag"]) < 5e-13
+    assert np.abs(m["M"][0] - g["M_row0"]).max() <= 5e-13 * np.abs(g["M_diag"]).max()
+    assert abs(np.linalg.norm(m["M"]) - float(g["M_fro"])) <= 1e-12 * float(g["M_fro"])
+    assert rel_to_max(m["j"], g["j"]) < 5e-13
+    assert abs(m["null_likelihood"] - float(g["H0"])) <= 1e-12 * abs(float(g["H0"]))
+    sol = FF.fit_preprocessed(m)
+    assert FF.iteration_diagnostics["num_iterations"] == int(g["niter"])
+    assert rel_to_max(sol.I, g["I"]) < 1e-6
+    np.testing.assert_allclose(sol.power_spectrum, g["p"], rtol=1e-4)
+    # binning in two calls accumulates (the RCCL-sharded path relies on it)
+    from frank_amd import _lib
+    import ctypes
+    L, ctx = _lib.lib, FF._DHT.context()
+    gm = _lib.make_geometry(FF._geometry)
+    tab = ctypes.c_void_p()
+    Vre, Vim = np.ascontiguousarray(V.real), np.ascontiguousarray(V.imag)
+    _lib.check(L.fh_vis_upload(0, _lib.ptr(u), _lib.ptr(v), _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), w.size, u.size,
+                               ctypes.byref(tab)))
+    _lib.check(L.fh_bin_reset(ctx))
+    _lib.check(L.fh_bin_visibilities(ctx, ctypes.byref(gm), tab, 0, 20000))
+    _lib.check(L.fh_bin_visibilities(ctx, ctypes.byref(gm), tab, 20000, u.size - 20000))
+    M2, j2 = np.empty((320, 320)), np.empty(320)
+    H0, a, b = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    _lib.check(L.fh_stats_finalize(ctx, ctypes.byref(gm), 0, 1, _lib.ptr(M2), _lib.ptr(j2), ctypes.byref(H0),
+                                   ctypes.byref(a), ctypes.byref(b)))
+    L.fh_vis_destroy(tab)
+    assert rel_to_max(M2, m["M"]) < 1e-13 and rel_to_max(j2, m["j"]) < 1e-13

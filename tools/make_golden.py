@@ -231,6 +231,11 @@ def bootstrap():
          input_sha256=checksum(u, v, V, w), profiles=np.array(profiles), niters=np.array(niters))
 
 
+def wide():
+    """N > 303: beyond the register-resident binning kernel (rows-to-memory + dsyrk path, rocSOLVER loop)"""
+    fit_case("fit_N320_5e4.npz", 320, 5e4, 1.05, 1e-4, keep_M=False, seed=8, noise_seed=9)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -248,6 +253,7 @@ def main():
     bootstrap()
     fit_case("fit_N100_1e5.npz", 100, 1e5, 1.05, 1e-4, keep_M=True)
     if not args.quick:
+        wide()
         fit_case("fit_N300_1e6.npz", 300, 1e6, 1.05, 1e-4, keep_M=True)
 
 
