@@ -103,3 +103,11 @@ def test_device_entry_points_fail_loudly_without_a_gpu():
     x = np.full(8, 1e5)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         FF.fit(x, x, np.ones(8) + 0j, np.ones(8))
+
+
+def test_constants_are_the_reference_doubles():
+    """frank/constants.py:23-25 evaluated as NumPy would: the same IEEE doubles."""
+    import frank_amd.constants as c
+    assert c.rad_to_arcsec == 3600 * 180 / np.pi
+    assert c.sterad_to_arcsec == (3600 * 180 / np.pi) ** 2
+    assert c.deg_to_rad == np.pi / 180
