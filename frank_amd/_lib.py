@@ -22,7 +22,7 @@ FH_ERR_HIP = -6
 FH_ERR_UNSUPPORTED = -7
 FH_ERR_NUMERIC = -8
 
-VIS_MODELS = {"opt_thick": 0, "opt_thin": 1}
+VIS_MODELS = {"opt_thick": 0, "opt_thin": 1, "debris": 2}
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _vp = ctypes.c_void_p
@@ -88,6 +88,7 @@ SIGNATURES = {
     "fh_uvbin_get": (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, ctypes.POINTER(_i64), _dp, _dp]),
     "fh_uvbin_determine": (ctypes.c_int, [_vp, _dp, _i64, ctypes.POINTER(ctypes.c_int32)]),
     "fh_uvbin_quantities": (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _i64, _dp, _dp, ctypes.POINTER(_i64)]),
+    "fh_ctx_set_scale_height": (ctypes.c_int, [_vp, _dp]),
     "fh_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "fh_comm_create": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.POINTER(_vp)]),

@@ -109,6 +109,10 @@ __global__ __launch_bounds__(256) void deproject_kernel(BinParams p) {
         up = up * p.cos_i;
         const double q = hypot(up, vp);
         const double sw = p.mult ? sqrt(mult * w) : sqrt(w);
+        if (p.prep_k2) {  // debris model: vertical uv-distance of the 3-D deprojection, wp = up sin(inc) (geometry.py:128)
+            const double wz = (u * p.cos_t - v * p.sin_t) * p.sin_i;
+            p.prep_k2[i] = wz * wz;
+        }
         p.prep_s[i] = p.inv_Qmax * q;  // k * q, hankel.py:189,202
         p.prep_sw[i] = sw;
         p.prep_swV[i] = sw * re;
@@ -392,8 +396,10 @@ __global__ void finalize_stats_kernel(const double *stats_sum, int NBT, int N, c
 // ---- N > 303: rows to memory + rocBLAS dsyrk (the register-resident kernel cannot hold more than 190 tiles) --------
 // Xt[i, k] = sqrt(w_i) J0(s_i j_k) (k < N), Xt[i, N] = sqrt(w_i) Re V'_i, row-major with leading dimension N + 1: read
 // as a column-major (N+1) x rows matrix it is the operand of G += Xc Xc^T.
-__global__ void wide_rows_kernel(const double *prep_s, const double *prep_sw, const double *prep_swV, int64_t first,
-                                 int64_t rows, int N, const double *zeros, const double *j0_table, double *X) {
+// debris model (statistical_models.py:494-496): the row is further scaled by exp(-kz_i^2 H2[k]); k2 / H2 NULL otherwise.
+__global__ void wide_rows_kernel(const double *prep_s, const double *prep_sw, const double *prep_swV, const double *k2,
+                                 const double *H2, int64_t first, int64_t rows, int N, const double *zeros,
+                                 const double *j0_table, double *X) {
     __shared__ double tab[FH_J0_TABLE_DOUBLES];
     for (int i = threadIdx.x; i < FH_J0_TABLE_DOUBLES; i += blockDim.x) tab[i] = j0_table[i];
     __syncthreads();
@@ -411,6 +417,10 @@ __global__ void wide_rows_kernel(const double *prep_s, const double *prep_sw, co
                 x = prep_s[g] * zeros[k];
             }
             val = prep_sw[g] * fh_j0(x, tab);
+            if (H2) {
+#pragma clang fp contract(off)
+                val = val * exp(-(k2[g] * H2[k]));
+            }
         } else {
             val = prep_swV[g];
         }
@@ -581,8 +591,8 @@ hipError_t fh_k1_launch_wide_rows(const BinParams &p, int64_t first, int64_t row
     const int64_t total = rows * (int64_t)(p.N + 1);
     int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(wide_rows_kernel, dim3(grid), dim3(256), 0, stream, p.prep_s, p.prep_sw, p.prep_swV, first, rows,
-                       p.N, p.zeros, p.j0_table, X);
+    hipLaunchKernelGGL(wide_rows_kernel, dim3(grid), dim3(256), 0, stream, p.prep_s, p.prep_sw, p.prep_swV, p.prep_k2,
+                       p.H2, first, rows, p.N, p.zeros, p.j0_table, X);
     return hipGetLastError();
 }
 

@@ -113,7 +113,9 @@ struct fh_ctx {
     bool wide = false;
     size_t tail_offset = 0;      // index of sum log(w / 2 pi) in stats_sum
     int64_t wide_rows = 0;       // rows per dsyrk chunk
-    DevBuf<double> wide_X;
+    DevBuf<double> wide_X, wide_G;  // wide_G: dense Gram + 2 scalars when the tile workspace exists too (debris, N <= 303)
+    DevBuf<double> debris_H2;    // vis_model 'debris': H2[k]; set by fh_ctx_set_scale_height, forces the rows + dgemm path
+    bool debris = false;
     // normal equations + K2 work
     DevBuf<double> M, j, W, D, Z, p, p_old, mu, band_lu, diag_p, diag_mu;
     DevBuf<int> flags, info;
@@ -244,6 +246,8 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
 
     // K1 workspaces (0 => N too large for the register-resident kernel: the rows-to-memory + dsyrk path is used)
     c->NBT = fh_k1_nbt_for(N);
+    if (const char *e = getenv("FRANK_AMD_K1"))  // development switch: FRANK_AMD_K1=wide forces the rows + dsyrk path
+        if (!strcmp(e, "wide")) c->NBT = 0;
     if (c->NBT) {
         c->ntiles = fh_k1_ntiles(c->NBT);
         c->nparts = fh_k1_nparts(c->NBT);
@@ -460,10 +464,42 @@ int fh_vis_set_multiplicity(fh_vis *vis, const int32_t *counts) {
 }
 
 // ---- K1 ----------------------------------------------------------------------------------------------------------
+// the rows-to-memory + dgemm path is taken for N > 303 always and for the debris model at any N
+static bool use_wide(const fh_ctx *c) { return c->wide || c->debris; }
+static double *dense_gram(fh_ctx *c) { return c->wide ? c->stats_sum.p : c->wide_G.p; }  // (N+1)^2 + 2 scalars
+static size_t dense_tail(const fh_ctx *c) { return ((size_t)c->N + 1) * ((size_t)c->N + 1); }
+
+static int ensure_wide(fh_ctx *c) {
+    if (c->wide_X.p) return FH_OK;
+    const size_t N1 = (size_t)c->N + 1;
+    c->wide_rows = 65536;
+    if (c->wide_X.alloc((size_t)c->wide_rows * N1) != hipSuccess || c->wide_G.alloc(N1 * N1 + 2) != hipSuccess)
+        return fail(FH_ERR_NOMEM, "device allocation for the rows + dgemm path failed");
+    return FH_OK;
+}
+
+int fh_ctx_set_scale_height(fh_ctx *c, const double *H2) {
+    if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!H2) {
+        c->debris = false;
+        return FH_OK;
+    }
+    for (int k = 0; k < c->N; ++k)
+        if (!(H2[k] >= 0.0)) return fail(FH_ERR_INVALID, "H2[%d] = %g: the squared scale height must be >= 0", k, H2[k]);
+    int rc = ensure_wide(c);
+    if (rc) return rc;
+    if (!c->debris_H2.p) HIP_TRY(c->debris_H2.alloc(c->N));
+    HIP_TRY(hipMemcpy(c->debris_H2.p, H2, sizeof(double) * c->N, hipMemcpyHostToDevice));
+    c->debris = true;
+    return FH_OK;
+}
+
 int fh_bin_reset(fh_ctx *c) {
     if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->stats_sum.p, 0, sizeof(double) * c->stats_sum.n, c->stream));
+    if (c->wide_G.p) HIP_TRY(hipMemsetAsync(c->wide_G.p, 0, sizeof(double) * c->wide_G.n, c->stream));
     const double init[2] = {-INFINITY, -INFINITY};  // (-qmin, qmax) under max
     HIP_TRY(hipMemcpyAsync(c->stats_minmax.p, init, sizeof init, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -493,20 +529,25 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     p.cos_t = cos(PA);
     p.sin_t = sin(PA);
     p.cos_i = cos(inc);
+    p.sin_i = sin(inc);
     p.N = c->N;
     p.inv_Qmax = 1. / c->dht->Qmax;
     p.zeros = c->zeros.p;
     p.j0_table = c->j0_table.p;
     const int64_t nsuper = (count + fh_k1_super() - 1) / fh_k1_super();
     if (nsuper > 0x7fffffff / 2) return fail(FH_ERR_UNSUPPORTED, "more than 2^39 visibilities in one call");
-    // K1a scratch: 24 B per visibility
-    const size_t need = (size_t)(count > 0 ? count : 1) * 3;
+    // K1a scratch: 24 B per visibility (32 B with the debris model's kz^2)
+    const size_t cnt1 = (size_t)(count > 0 ? count : 1);
+    const size_t need = cnt1 * (c->debris ? 4 : 3);
     if (c->prep.n < need) HIP_TRY(c->prep.alloc(need));
     p.prep_s = c->prep.p;
-    p.prep_sw = c->prep.p + (count > 0 ? count : 1);
-    p.prep_swV = c->prep.p + 2 * (size_t)(count > 0 ? count : 1);
-    if (c->wide) {
-        // N > 303: sqrt(w)-scaled rows to memory, chunk by chunk, and G += X^T X by rocBLAS (fp64 MFMA inside)
+    p.prep_sw = c->prep.p + cnt1;
+    p.prep_swV = c->prep.p + 2 * cnt1;
+    p.prep_k2 = c->debris ? c->prep.p + 3 * cnt1 : nullptr;
+    p.H2 = c->debris ? c->debris_H2.p : nullptr;
+    if (use_wide(c)) {
+        // N > 303 / debris: sqrt(w)-scaled rows to memory, chunk by chunk, and G += X^T X by rocBLAS (fp64 MFMA inside)
+        double *G = dense_gram(c);
         int dblocks = (int)((count + 255) / 256);
         if (dblocks > c->deproject_blocks) dblocks = c->deproject_blocks;
         if (dblocks < 1) dblocks = 1;
@@ -518,13 +559,19 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
         for (int64_t r0 = 0; r0 < count; r0 += c->wide_rows) {
             const int64_t rows = count - r0 < c->wide_rows ? count - r0 : c->wide_rows;
             HIP_TRY(fh_k1_launch_wide_rows(p, r0, rows, c->wide_X.p, c->stream));
-            ROC_TRY(rocblas_dsyrk(c->blas, rocblas_fill_upper, rocblas_operation_none, N1, (rocblas_int)rows, &one,
-                                  c->wide_X.p, N1, &one, c->stats_sum.p, N1));
+            if (getenv("FRANK_AMD_WIDE_SYRK")) {
+                ROC_TRY(rocblas_dsyrk(c->blas, rocblas_fill_upper, rocblas_operation_none, N1, (rocblas_int)rows, &one,
+                                      c->wide_X.p, N1, &one, G, N1));
+            } else {
+                // the full product: rocBLAS's dsyrk is ~2 orders of magnitude slower than its dgemm for this shape
+                // (n = N + 1 small, k = 65536); only the upper triangle of G is read afterwards
+                ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, N1, N1, (rocblas_int)rows,
+                                      &one, c->wide_X.p, N1, c->wide_X.p, N1, &one, G, N1));
+            }
         }
         HIP_TRY(hipEventRecord(c->ev_bin1, c->stream));
         c->bin_timed = true;
-        HIP_TRY(fh_k1_launch_wide_scalars(c->partial_scalars.p, dblocks, c->stats_sum.p + c->tail_offset,
-                                          c->stats_minmax.p, c->stream));
+        HIP_TRY(fh_k1_launch_wide_scalars(c->partial_scalars.p, dblocks, G + dense_tail(c), c->stats_minmax.p, c->stream));
         c->have_device_Mj = false;
         return FH_OK;
     }
@@ -576,8 +623,8 @@ int fh_bin_last_kernel_ms(fh_ctx *c, float *ms) {
 
 int fh_stats_device(fh_ctx *c, double **sum_stats, int64_t *n_sum, double **minmax_stats) {
     if (!c || !c->stats_sum.p) return fail(FH_ERR_INVALID, "fh_stats_device: no binning workspace");
-    if (sum_stats) *sum_stats = c->stats_sum.p;
-    if (n_sum) *n_sum = (int64_t)c->stats_sum.n;
+    if (sum_stats) *sum_stats = use_wide(c) ? dense_gram(c) : c->stats_sum.p;
+    if (n_sum) *n_sum = use_wide(c) ? (int64_t)dense_tail(c) + 2 : (int64_t)c->stats_sum.n;
     if (minmax_stats) *minmax_stats = c->stats_minmax.p;
     return FH_OK;
 }
@@ -585,8 +632,10 @@ int fh_stats_device(fh_ctx *c, double **sum_stats, int64_t *n_sum, double **minm
 int fh_stats_finalize(fh_ctx *c, const fh_geometry *g, int vis_model, int check_qbounds, double *M, double *j,
                       double *H0, double *qmin, double *qmax) {
     if (!c || !g) return fail(FH_ERR_INVALID, "fh_stats_finalize: NULL argument");
-    if (vis_model != FH_VIS_OPT_THICK && vis_model != FH_VIS_OPT_THIN)
-        return fail(FH_ERR_INVALID, "vis_model must be one of ['opt_thick', 'opt_thin'] here ('debris' is not built)");
+    if (vis_model != FH_VIS_OPT_THICK && vis_model != FH_VIS_OPT_THIN && vis_model != FH_VIS_DEBRIS)
+        return fail(FH_ERR_INVALID, "vis_model must be one of ['opt_thick', 'opt_thin', 'debris']");
+    if ((vis_model == FH_VIS_DEBRIS) != c->debris)
+        return fail(FH_ERR_INVALID, "vis_model 'debris' goes with fh_ctx_set_scale_height (and only with it)");
     HIP_TRY(hipSetDevice(c->device));
     const int N = c->N;
     // a_k = ((norm * sf_k)) * scale : hankel.py:201 and statistical_models.py:490,507
@@ -595,12 +644,13 @@ int fh_stats_finalize(fh_ctx *c, const fh_geometry *g, int vis_model, int check_
     std::vector<double> a(N);
     for (int k = 0; k < N; ++k) a[k] = (norm * c->dht->scale_factor[k]) * scale;
     HIP_TRY(hipMemcpyAsync(c->a_scale.p, a.data(), sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
-    if (c->wide)
-        HIP_TRY(fh_k1_launch_wide_finalize(c->stats_sum.p, N, c->a_scale.p, c->M.p, c->j.p, c->sumwV2.p, c->stream));
+    if (use_wide(c))
+        HIP_TRY(fh_k1_launch_wide_finalize(dense_gram(c), N, c->a_scale.p, c->M.p, c->j.p, c->sumwV2.p, c->stream));
     else
         HIP_TRY(fh_k1_launch_finalize(c->stats_sum.p, c->NBT, N, c->a_scale.p, c->M.p, c->j.p, c->sumwV2.p, c->stream));
     double tail[2], mm[2], swv2;
-    HIP_TRY(hipMemcpyAsync(tail, c->stats_sum.p + c->tail_offset, sizeof tail, hipMemcpyDeviceToHost, c->stream));
+    const double *tail_src = use_wide(c) ? dense_gram(c) + dense_tail(c) : c->stats_sum.p + c->tail_offset;
+    HIP_TRY(hipMemcpyAsync(tail, tail_src, sizeof tail, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(mm, c->stats_minmax.p, sizeof mm, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&swv2, c->sumwV2.p, sizeof swv2, hipMemcpyDeviceToHost, c->stream));
     if (M) HIP_TRY(hipMemcpyAsync(M, c->M.p, sizeof(double) * (size_t)N * N, hipMemcpyDeviceToHost, c->stream));

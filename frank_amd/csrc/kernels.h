@@ -10,7 +10,7 @@ struct BinParams {
     int w_scalar;
     int64_t first, count;
     // geometry (geometry.py:69-70,111-115): dRA, dDec already multiplied by 2 pi / rad_to_arcsec
-    double dRA, dDec, cos_t, sin_t, cos_i;
+    double dRA, dDec, cos_t, sin_t, cos_i, sin_i;
     // DHT
     int N;
     double inv_Qmax;        // k = 1./Qmax, hankel.py:189
@@ -19,6 +19,9 @@ struct BinParams {
     // outputs
     // K1a output (device, `count` entries each): s = q/Qmax, sqrt(w), sqrt(w) Re V'
     double *prep_s, *prep_sw, *prep_swV;
+    // debris model only: kz^2 per visibility (K1a output) and H2[k] = 0.5 (2 pi H(r_k))^2 (device); NULL otherwise
+    double *prep_k2;
+    const double *H2;
     // throughput mode: two ints (one per part) handing out super-chunks; NULL = static, reproducible split
     int *work_counter;
     // grid split between the tile parts (bin_gram.hip): part_blocks[0] + part_blocks[1] workgroups

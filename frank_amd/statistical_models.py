@@ -25,12 +25,9 @@ class VisibilityMapping:
         _vis_models = ['opt_thick', 'opt_thin', 'debris']
         if vis_model not in _vis_models:
             raise ValueError(f"vis_model must be one of {_vis_models}")  # statistical_models.py:71-73
-        if vis_model == 'debris':
-            if scale_height is None:
-                raise ValueError('You requested a model with a non-zero scale height'
-                                 ' but did not specify H(R) (scale_height=None)')
-            raise NotImplementedError("vis_model='debris' (statistical_models.py:494-496) is outside the "
-                                      "hot path built so far")
+        if vis_model == 'debris' and scale_height is None:
+            raise ValueError('You requested a model with a non-zero scale height'
+                             ' but did not specify H(R) (scale_height=None)')
         self._vis_model = vis_model
         self.check_qbounds = check_qbounds
         self._verbose = verbose
@@ -39,6 +36,9 @@ class VisibilityMapping:
         self._DHT = DHT
         self._geometry = geometry
         self._scale_height = None
+        if vis_model == 'debris':  # statistical_models.py:96-102
+            self._scale_height = scale_height(self.r)
+            self._H2 = 0.5 * (2 * np.pi * self._scale_height / rad_to_arcsec) ** 2
         if self._verbose:
             if vis_model == 'opt_thick':
                 logging.info('  Assuming an optically thick model (the default): '
@@ -73,6 +73,9 @@ class VisibilityMapping:
         M, j = np.empty((N, N)), np.empty(N)
         H0, qmin, qmax = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         g = _lib.make_geometry(self._geometry)
+        # geometrically thick model: the kernel needs H2[k] to scale every row by exp(-kz^2 H2[k]) (:494-496)
+        _lib.check(_lib.lib.fh_ctx_set_scale_height(
+            self._DHT.context(), _lib.ptr(_lib.f8(self._H2)) if self._vis_model == 'debris' else None))
         rc = _lib.lib.fh_map_visibilities(
             self._DHT.context(), ctypes.byref(g), _lib.VIS_MODELS[self._vis_model], 0, _lib.ptr(u), _lib.ptr(v),
             _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), w.size, n, _lib.ptr(M), _lib.ptr(j), ctypes.byref(H0),
@@ -124,6 +127,9 @@ class VisibilityMapping:
         I = _lib.f8(I)
         if I.size != self.size:
             raise ValueError("I must have one value per collocation point")
+        if self._vis_model == 'debris':
+            # H(q) from the GPU, the per-(visibility, column) factor exp(-k^2 H2) and the product on the host
+            return np.dot(self._get_mapping_coefficients(q, np.asarray(k, dtype=np.float64).reshape(-1)), I)
         V = np.empty(q.size)
         _lib.check(_lib.lib.fh_predict_visibilities(self._DHT.context(), _lib.ptr(q), q.size, _lib.ptr(I),
                                                     float(self._scale(geometry)), _lib.ptr(V)))
@@ -147,6 +153,12 @@ class VisibilityMapping:
 
     def _get_mapping_coefficients(self, qs, ks, geometry=None, inverse=False):
         """H(q) with the model's scale (statistical_models.py:483-509), built on the GPU."""
+        if self._vis_model == 'debris':
+            scale = np.exp(-np.outer(np.asarray(ks) * np.asarray(ks), self._H2))
+            if inverse:
+                return self._DHT._device_coefficients(np.asarray(qs) / rad_to_arcsec, 'backward', 1.0) * \
+                    np.atleast_1d(1 / scale).reshape(1, -1)
+            return self._DHT._device_coefficients(qs, 'forward', 1.0) * scale
         scale = self._scale(geometry)
         if inverse:
             return self._DHT._device_coefficients(np.asarray(qs) / rad_to_arcsec, 'backward', 1.0 / scale)

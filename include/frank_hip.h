@@ -39,6 +39,7 @@ extern "C" {
 /* vis_model: statistical_models.py:71-73, 486-496 */
 #define FH_VIS_OPT_THICK 0 /* H scaled by cos(inc) */
 #define FH_VIS_OPT_THIN 1  /* no scaling           */
+#define FH_VIS_DEBRIS 2    /* geometrically thick: exp(-kz^2 H2[k]) per visibility and column, see fh_ctx_set_scale_height */
 
 typedef struct fh_dht fh_dht; /* DiscreteHankelTransform, hankel.py:25-294        */
 typedef struct fh_vis fh_vis; /* a visibility table resident in HBM               */
@@ -217,6 +218,12 @@ int fh_uvbin_get(const fh_uvbin *h, double *uv, double *Vre, double *Vim, double
 int fh_uvbin_determine(fh_uvbin *h, const double *uv, int64_t n, int32_t *idx);
 int fh_uvbin_quantities(fh_uvbin *h, const double *uv, const double *w, const double *qre, const double *qim, int64_t n,
                         double *out_re, double *out_im, int64_t *counts);
+
+/* vis_model='debris' (statistical_models.py:96-102, 494-496): H2[k] = 0.5 * (2 pi scale_height(r_k) / rad_to_arcsec)^2,
+ * N host doubles.  While set, fh_bin_visibilities scales each row by exp(-kz_i^2 H2[k]) (kz = the vertical uv-distance
+ * of the 3-D deprojection, geometry.py:128) and takes the rows-to-memory + rocBLAS path; fh_stats_finalize /
+ * fh_map_visibilities must then be called with FH_VIS_DEBRIS.  H2 = NULL switches back.                             */
+int fh_ctx_set_scale_height(fh_ctx *ctx, const double *H2);
 
 /* ---- multi-GPU: RCCL all-reduce of the sufficient statistics (one rank per GPU) ------------------------------
  * The reduction being distributed is `Ms[i] += ...; js[i] += ...` (statistical_models.py:210-211) and the

@@ -260,10 +260,12 @@ void fo_apply_correction(int64_t n, const double *u, const double *v, const doub
 /* weights may be a scalar (n_w == 1) as at statistical_models.py:173.       */
 /* Returns FO_ERR_QRANGE when q_k[-1] < max(q) and check_qbounds != 0.       */
 /* ------------------------------------------------------------------------ */
-int fo_map_visibilities(int N, double Rmax, double inc_deg, double PA_deg, double dRA, double dDec, int vis_model,
-                        int check_qbounds, int64_t block_size, int64_t n, const double *u, const double *v,
-                        const double *Vre, const double *Vim, const double *w, int64_t n_w, double *M, double *j,
-                        double *H0_out, double *qmin_out, double *qmax_out) {
+/* vis_model 2 = 'debris' (optically thin, geometrically thick): scale[i,k] = exp(-kz_i^2 * H2[k]) with kz the third    */
+/* deprojected coordinate and H2 = 0.5 (2 pi H(r_k) / rad_to_arcsec)^2  [:101-102, :494-496]; H2 is ignored otherwise. */
+int fo_map_visibilities_ex(int N, double Rmax, double inc_deg, double PA_deg, double dRA, double dDec, int vis_model,
+                           int check_qbounds, int64_t block_size, int64_t n, const double *u, const double *v,
+                           const double *Vre, const double *Vim, const double *w, int64_t n_w, const double *H2,
+                           double *M, double *j, double *H0_out, double *qmin_out, double *qmax_out) {
     double *r = malloc(sizeof(double) * N), *qk = malloc(sizeof(double) * N), *jnk = malloc(sizeof(double) * N);
     double *Ykm = malloc(sizeof(double) * (size_t)N * N), *sf = malloc(sizeof(double) * N);
     double j_nN, Qmax;
@@ -271,9 +273,9 @@ int fo_map_visibilities(int N, double Rmax, double inc_deg, double PA_deg, doubl
     free(Ykm);
 
     double *up = malloc(sizeof(double) * n), *vp = malloc(sizeof(double) * n), *Vp = malloc(sizeof(double) * n);
-    double *q = malloc(sizeof(double) * n);
-    if (!up || !vp || !Vp || !q) return FO_ERR_NOMEM;
-    fo_apply_correction(n, u, v, Vre, Vim, inc_deg, PA_deg, dRA, dDec, up, vp, NULL, Vp, NULL);
+    double *q = malloc(sizeof(double) * n), *kz = malloc(sizeof(double) * n);
+    if (!up || !vp || !Vp || !q || !kz) return FO_ERR_NOMEM;
+    fo_apply_correction(n, u, v, Vre, Vim, inc_deg, PA_deg, dRA, dDec, up, vp, kz, Vp, NULL);
     double qmin = INFINITY, qmax = -INFINITY;
     for (int64_t i = 0; i < n; i++) {
         q[i] = hypot(up[i], vp[i]); /* statistical_models.py:166 */
@@ -300,7 +302,9 @@ int fo_map_visibilities(int N, double Rmax, double inc_deg, double PA_deg, doubl
                 double s = kq * q[start + i];
                 double wi = (n_w == 1) ? w[0] : w[start + i];
                 wi = 1.0 * wi; /* np.ones_like(V) * weights */
+                double kz2 = kz[start + i] * kz[start + i];
                 for (int k = 0; k < N; k++) {
+                    if (vis_model == 2) scale = exp(-(kz2 * H2[k])); /* np.exp(-np.outer(ks*ks, H2)), :496 */
                     double h = ((norm * sf[k]) * fo_j0(s * jnk[k])) * scale;
                     X[(size_t)i * N + k] = h;
                     wXT[(size_t)i * N + k] = h * wi; /* :208 */
@@ -330,8 +334,16 @@ int fo_map_visibilities(int N, double Rmax, double inc_deg, double PA_deg, doubl
         }
         *H0_out = 0.5 * acc;
     }
-    free(r); free(qk); free(jnk); free(sf); free(up); free(vp); free(Vp); free(q);
+    free(r); free(qk); free(jnk); free(sf); free(up); free(vp); free(Vp); free(q); free(kz);
     return rc;
+}
+
+int fo_map_visibilities(int N, double Rmax, double inc_deg, double PA_deg, double dRA, double dDec, int vis_model,
+                        int check_qbounds, int64_t block_size, int64_t n, const double *u, const double *v,
+                        const double *Vre, const double *Vim, const double *w, int64_t n_w, double *M, double *j,
+                        double *H0_out, double *qmin_out, double *qmax_out) {
+    return fo_map_visibilities_ex(N, Rmax, inc_deg, PA_deg, dRA, dDec, vis_model, check_qbounds, block_size, n, u, v, Vre,
+                                  Vim, w, n_w, NULL, M, j, H0_out, qmin_out, qmax_out);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -116,10 +116,11 @@ def apply_correction(u, v, V, inc, PA, dRA, dDec):
     return up, vp, wp, Vr + 1j * Vi
 
 
-def map_visibilities(N, Rmax, geom, u, v, V, w, vis_model=0, check_qbounds=True, block_size=10 ** 5):
+def map_visibilities(N, Rmax, geom, u, v, V, w, vis_model=0, check_qbounds=True, block_size=10 ** 5, H2=None):
     """VisibilityMapping.map_visibilities (statistical_models.py:109-237), single channel.
 
-    geom = (inc_deg, PA_deg, dRA_arcsec, dDec_arcsec); Rmax in radians.
+    geom = (inc_deg, PA_deg, dRA_arcsec, dDec_arcsec); Rmax in radians.  vis_model 2 ('debris') needs
+    H2 = 0.5 * (2 pi scale_height(r) / rad_to_arcsec)**2 (:101-102).
     Returns dict(M, j, null_likelihood, qmin, qmax, rc).
     """
     u, v = _f8(u), _f8(v)
@@ -130,12 +131,12 @@ def map_visibilities(N, Rmax, geom, u, v, V, w, vis_model=0, check_qbounds=True,
     n = u.size
     M, j = np.zeros((N, N)), np.zeros(N)
     H0, qmin, qmax = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-    rc = lib().fo_map_visibilities(
+    rc = lib().fo_map_visibilities_ex(
         ctypes.c_int(N), ctypes.c_double(Rmax), ctypes.c_double(geom[0]), ctypes.c_double(geom[1]),
         ctypes.c_double(geom[2]), ctypes.c_double(geom[3]), ctypes.c_int(vis_model),
         ctypes.c_int(1 if check_qbounds else 0), ctypes.c_int64(block_size), ctypes.c_int64(n), _p(u), _p(v),
-        _p(Vre), _p(Vim), _p(w), ctypes.c_int64(w.size), _p(M), _p(j), ctypes.byref(H0), ctypes.byref(qmin),
-        ctypes.byref(qmax))
+        _p(Vre), _p(Vim), _p(w), ctypes.c_int64(w.size), _p(None if H2 is None else _f8(H2)), _p(M), _p(j),
+        ctypes.byref(H0), ctypes.byref(qmin), ctypes.byref(qmax))
     return dict(M=M, j=j, null_likelihood=H0.value, qmin=qmin.value, qmax=qmax.value, rc=rc)
 
 

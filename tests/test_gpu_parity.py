@@ -677,3 +677,29 @@ def test_wide_basis_N320(golden):
                                    ctypes.byref(a), ctypes.byref(b)))
     L.fh_vis_destroy(tab)
     assert rel_to_max(M2, m["M"]) < 1e-13 and rel_to_max(j2, m["j"]) < 1e-13
+
+
+def test_debris_model(golden):
+    """FrankFitter(assume_optically_thick=False, scale_height=H): the geometrically thick model -- mapping through the
+    rows + rocBLAS path with the exp(-kz^2 H2) factor, fit, and sky-plane prediction with the vertical coordinate."""
+    from frank_amd import FrankFitter
+    g = golden("debris_N40.npz")
+    u, v, V, w = mock_disc_visibilities(int(g["n"]), seed=int(g["seed"]), noise_seed=int(g["noise_seed"]))
+    assert sha(u, v, V, w) == str(g["input_sha256"])
+    FF = FrankFitter(2.0, 40, geom(), alpha=float(g["alpha"]), weights_smooth=float(g["wsmooth"]),
+                     assume_optically_thick=False, scale_height=lambda r: 0.02 + 0.05 * r, check_qbounds=False,
+                     store_iteration_diagnostics=True, verbose=False)
+    np.testing.assert_allclose(FF._vis_map.scale_height, g["H"], rtol=1e-14)
+    m = FF.preprocess_visibilities(u, v, V, w)
+    assert rel_to_max(m["M"], g["M"]) < 5e-13 and rel_to_max(m["j"], g["j"]) < 5e-13
+    assert abs(m["null_likelihood"] - float(g["H0"])) <= 1e-12 * abs(float(g["H0"]))
+    sol = FF.fit_preprocessed(m)
+    assert FF.iteration_diagnostics["num_iterations"] == int(g["niter"])
+    assert rel_to_max(sol.I, g["I"]) < 1e-6
+    Vp = sol.predict(g["u_pred"], g["v_pred"])
+    assert np.abs(Vp - g["V_pred"]).max() <= 1e-6 * np.abs(g["V_pred"]).max()
+    # the same context goes back to the thin model afterwards
+    FT = FrankFitter(2.0, 40, geom(), assume_optically_thick=False, check_qbounds=False, verbose=False)
+    FT._DHT = FF._DHT
+    with pytest.raises(ValueError):
+        FrankFitter(2.0, 40, geom(), scale_height=lambda r: 0.1 * r, verbose=False)  # thick + scale height

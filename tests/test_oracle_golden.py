@@ -278,3 +278,17 @@ def test_uvbin_oracle(golden, tag):
     assert np.array_equal(fo.uvbin_determine(g["probe_" + tag], bw, o["nbins"]), g["probe_idx_" + tag])
     o_real = fo.uvbin_build(g["q"], g["Vre"], g["w"], bw)
     np.testing.assert_allclose(o_real["err"][many], g["err_real_" + tag][many], rtol=1e-13)
+
+
+def test_debris_mapping(golden):
+    """vis_model='debris': rows scaled by exp(-kz^2 H2[k]) (statistical_models.py:96-102, 494-496)."""
+    g = golden("debris_N40.npz")
+    u, v, V, w = mock_disc_visibilities(int(g["n"]), seed=int(g["seed"]), noise_seed=int(g["noise_seed"]))
+    H2 = 0.5 * (2 * np.pi * g["H"] / rad_to_arcsec) ** 2
+    m = fo.map_visibilities(40, RMAX, GEOM, u, v, V, w, vis_model=2, check_qbounds=False, H2=H2)
+    assert m["rc"] == 0
+    assert rel_to_max(m["M"], g["M"]) < 1e-12 and rel_to_max(m["j"], g["j"]) < 1e-12
+    assert abs(m["null_likelihood"] - float(g["H0"])) <= 1e-12 * abs(float(g["H0"]))
+    out = fo.frank_fit_normal(40, RMAX, m["M"], m["j"], alpha=float(g["alpha"]), wsmooth=float(g["wsmooth"]))
+    assert out["niter"] == int(g["niter"])
+    assert rel_to_max(out["mu"], g["I"]) < 1e-6

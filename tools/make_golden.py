@@ -231,6 +231,26 @@ def bootstrap():
          input_sha256=checksum(u, v, V, w), profiles=np.array(profiles), niters=np.array(niters))
 
 
+def debris():
+    print("debris model: vis_model='debris', exp(-kz^2 H2) scale (statistical_models.py:96-102, 494-496), N=40")
+    u, v, V, w = mock_disc_visibilities(3000, seed=31, noise_seed=32)
+    FF = FrankFitter(RMAX, 40, geom(), alpha=1.3, weights_smooth=1e-2, assume_optically_thick=False,
+                     scale_height=_debris_H, check_qbounds=False, store_iteration_diagnostics=True, verbose=False)
+    m = FF.preprocess_visibilities(u, v, V, w)
+    sol = FF.fit_preprocessed(m)
+    nit = FF.iteration_diagnostics["num_iterations"]
+    print("    niter", nit)
+    save("debris_N40.npz", N=40, n=3000, seed=31, noise_seed=32, alpha=1.3, wsmooth=1e-2,
+         input_sha256=checksum(u, v, V, w), M=m["M"], j=m["j"], H0=m["null_likelihood"], I=sol.I,
+         p=sol.power_spectrum, niter=nit, H=FF._vis_map.scale_height, u_pred=u[:64], v_pred=v[:64],
+         V_pred=sol.predict(u[:64], v[:64]))
+
+
+def _debris_H(r):
+    """scale height in arcsec at radius r [arcsec]: a flared belt"""
+    return 0.02 + 0.05 * r
+
+
 def wide():
     """N > 303: beyond the register-resident binning kernel (rows-to-memory + dsyrk path, rocSOLVER loop)"""
     fit_case("fit_N320_5e4.npz", 320, 5e4, 1.05, 1e-4, keep_M=False, seed=8, noise_seed=9)
