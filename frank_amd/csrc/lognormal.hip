@@ -147,7 +147,7 @@ __device__ __forceinline__ double ln_eval(const LogNormalParams &P, LnS &S, cons
         const int o = S.c0 * N + S.row;
         const double *sc = P.Sinv + o, *mc = P.M + o;
         double a = 0.0, b = 0.0;
-#pragma unroll 8
+#pragma unroll 16
         for (int c = S.c0; c < S.c1; ++c, sc += N, mc += N) {
             a = fma(*sc, xv[c], a);
             b = fma(*mc, Iv[c], b);
@@ -481,7 +481,7 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
             if (S.row >= 0) {
                 const double *hc = P.Hinv + (S.c0 * N + S.row);
                 double a = 0.0;
-#pragma unroll 8
+#pragma unroll 16
                 for (int c = S.c0; c < S.c1; ++c, hc += N) a = fma(*hc, S.jx[c], a);
                 S.part[S.slot] = a;
             }
