@@ -52,7 +52,14 @@ __global__ __launch_bounds__(UT) void uvbin_max_kernel(const double *uv, int64_t
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+    __shared__ double wmax[UT / 64];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one contended atomic per workgroup, not per wave
+#pragma unroll
+        for (int w = 1; w < UT / 64; ++w) m = fmax(m, wmax[w]);
+        atomicMax(out, (unsigned long long)__double_as_longlong(m));
+    }
     if (bad) atomicOr(out + 1, 1ull);
 }
 
