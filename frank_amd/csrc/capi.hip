@@ -255,9 +255,15 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
         if (c->nparts == 1) {
             c->part_blocks[0] = G;
             c->part_blocks[1] = 0;
-        } else {  // split the CUs in proportion to the parts' tile counts (equal MFMA time per workgroup)
+        } else {
+            // split the CUs in proportion to the parts' work per visibility: their tiles (MFMA) plus the J0 column blocks
+            // they have to evaluate (part 0 all 19, part 1 the last 12).  A block of 16 J0 columns weighs about as much
+            // as 13 tile updates -- from a sweep of the split at N = 300: 151 workgroups (tiles only) 30.5 ms, 155
+            // 30.1 ms, 159 31.3 ms.
             const int t0 = fh_k1_part_ntiles(c->NBT, 0), t1 = fh_k1_part_ntiles(c->NBT, 1);
-            int g0 = (int)llround((double)G * t0 / (t0 + t1));
+            const double w0 = t0 + 13.0 * c->NBT, w1 = t1 + 13.0 * (c->NBT - 7);
+            int g0 = (int)llround((double)G * w0 / (w0 + w1));
+            if (const char *e = getenv("FRANK_AMD_K1_SPLIT")) g0 = atoi(e);  // development: workgroups of part 0
             if (g0 < 1) g0 = 1;
             if (g0 > G - 1) g0 = G - 1;
             c->part_blocks[0] = g0;
