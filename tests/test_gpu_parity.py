@@ -703,3 +703,36 @@ def test_debris_model(golden):
     FT._DHT = FF._DHT
     with pytest.raises(ValueError):
         FrankFitter(2.0, 40, geom(), scale_height=lambda r: 0.1 * r, verbose=False)  # thick + scale height
+
+
+def test_lognormal_large_basis_against_oracle():
+    """N = 128 > 112: the LU factors no longer fit in LDS (lognormal_kernel<false>, factors in L2) and the solve vector
+    spans two 64-row blocks.  No reference fixture at this size (minutes of CPU): the pinned oracle is the referee."""
+    from frank_amd import DiscreteHankelTransform, FrankFitter, LogNormalMAPModel
+    from oracle import oracle as fo
+    N = 128
+    u, v, V, w = mock_disc_visibilities(30000, seed=41, noise_seed=42)
+    m = fo.map_visibilities(N, RMAX, GEOM, u, v, V, w)
+    assert m["rc"] == 0
+    D = fo.DHT(RMAX, N)
+    s0 = float(np.log(1e5))
+    mu, _, _, _ = fo.gaussian_model(D, m["M"], m["j"], np.ones(N))
+    pI = np.max(D.transform(mu) ** 2) * (D.q / D.q[0]) ** -2
+    mu, _, _, _ = fo.gaussian_model(D, m["M"], m["j"], pI)
+    s_guess = np.log(np.maximum(mu, 1e-3 * mu.max())) - s0
+    p_seed = np.max(D.transform(s_guess) ** 2) * (D.q / D.q[0]) ** -4
+    ref = fo.lognormal_map(D, m["M"], m["j"], p_seed, s_guess, s0)
+    fit = LogNormalMAPModel(DiscreteHankelTransform(RMAX, N), m["M"], m["j"], p_seed, guess=s_guess, s0=s0)
+    assert np.abs(fit.MAP - ref["s"]).max() < 1e-8
+    assert rel_to_max(fit._Dinv, ref["Dinv"]) < 1e-10
+    assert fit._newton_stats[4 + ref["stats"][0]] == 1 and abs(fit._newton_stats[1] - ref["stats"][1]) <= 0.01 * ref["stats"][1] + 2
+    # a few passes of the whole loop
+    FF = FrankFitter(2.0, N, geom(), method="LogNormal", max_iter=3, convergence_failure="ignore",
+                     store_iteration_diagnostics=True, verbose=False)
+    FF._M, FF._j, FF._H0 = m["M"], m["j"], m["null_likelihood"]
+    FF._fit()
+    o = fo.frank_fit_lognormal(N, RMAX, m["M"], m["j"], max_iter=3, diagnostics=True)
+    assert FF.iteration_diagnostics["num_iterations"] == o["niter"] == 4
+    for k in range(4):
+        np.testing.assert_allclose(FF.iteration_diagnostics["power_spectrum"][k], o["diag_p"][k], rtol=1e-6)
+        assert np.abs(FF.iteration_diagnostics["MAP"][k] - o["diag_s"][k]).max() < 1e-6
