@@ -308,6 +308,13 @@ __device__ __forceinline__ void wave_main(const BinParams &p, double *smem, int 
 template <int NBT, int P>
 __device__ __forceinline__ void part_main(const BinParams &p, double *smem, int part_block, int part_nblocks) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef K1_ICACHE_TEST  // experiment only (wrong results): every wave runs ONE specialisation -> 1/8 of the hot code
+    if (wave >= 0) {
+        if (wave & 4) wave_main<NBT, P, 4>(p, smem, part_block, part_nblocks);
+        else wave_main<NBT, P, 0>(p, smem, part_block, part_nblocks);
+        return;
+    }
+#endif
     switch (wave) {
         case 0: wave_main<NBT, P, 0>(p, smem, part_block, part_nblocks); break;
         case 1: wave_main<NBT, P, 1>(p, smem, part_block, part_nblocks); break;
