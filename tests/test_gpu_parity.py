@@ -736,3 +736,22 @@ def test_lognormal_large_basis_against_oracle():
     for k in range(4):
         np.testing.assert_allclose(FF.iteration_diagnostics["power_spectrum"][k], o["diag_p"][k], rtol=1e-6)
         assert np.abs(FF.iteration_diagnostics["MAP"][k] - o["diag_s"][k]).max() < 1e-6
+
+
+def test_bootstrap_lognormal_equals_gathered_copy():
+    """bootstrap_fits with a method='LogNormal' fitter: multiplicities in the binning pre-pass + fh_fit_lognormal on the
+    device-resident M, j must equal the ordinary fit of the explicitly resampled table (few passes: before the
+    round-off sensitivity of the Newton iteration matters)."""
+    from frank_amd import FrankFitter
+    from frank_amd.bootstrap import bootstrap_fits
+    u, v, V, w = mock_disc_visibilities(20000, seed=5, noise_seed=6)
+    FF = FrankFitter(2.0, 50, geom(), alpha=1.3, weights_smooth=1e-2, method="LogNormal", max_iter=4,
+                     convergence_failure="ignore", verbose=False)
+    np.random.seed(11)
+    _, prof = bootstrap_fits(FF, u, v, V, w, 2)
+    np.random.seed(11)
+    for t in range(2):
+        idxs = np.random.randint(low=0, high=u.size, size=u.size)
+        sol = FF.fit(u[idxs], v[idxs], V[idxs], w[idxs])
+        assert rel_to_max(prof[t], sol.I) < 1e-6
+        assert np.all(prof[t] > 0)
