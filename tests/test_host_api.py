@@ -103,6 +103,17 @@ def test_device_entry_points_fail_loudly_without_a_gpu():
     x = np.full(8, 1e5)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         FF.fit(x, x, np.ones(8) + 0j, np.ones(8))
+    # the other entry families: LogNormal, uv-binner, bootstrap
+    from frank_amd.utilities import UVDataBinner
+    from frank_amd.bootstrap import bootstrap_fits
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        UVDataBinner(x, np.ones(8) + 0j, np.ones(8), 1e4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        bootstrap_fits(FF, x, x, np.ones(8) + 0j, np.ones(8), 1)
+    FL = FrankFitter(2.0, 20, FixedGeometry(30.0, 40.0), method="LogNormal", verbose=False)
+    assert FL._info["p0"] == 1e-35 and FL.fit_method() == "FrankFitter: LogNormal method"
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        FL.fit(x, x, np.ones(8) + 0j, np.ones(8))
 
 
 def test_constants_are_the_reference_doubles():
