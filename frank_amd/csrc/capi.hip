@@ -1583,6 +1583,10 @@ static int uvbin_sums(fh_uvbin *h, const double *d_uv, const double *d_w, const 
     p.nbins = nb;
     p.sums = ds.p;
     p.counts = dc.p;
+    DevBuf<double> scratch;
+    if ((size_t)(nq + 1) * nb * sizeof(double) <= 120 * 1024 &&
+        scratch.alloc(fh_uvbin_scratch_doubles(nq + 1, nb, n, h->num_cu)) == hipSuccess)
+        p.scratch = scratch.p;
     hipEvent_t s0 = nullptr, s1 = nullptr;
     HIP_TRY(hipEventCreate(&s0));
     HIP_TRY(hipEventCreate(&s1));
@@ -1692,6 +1696,10 @@ int fh_uvbin_create(int device, const double *uv, const double *Vre, const doubl
     p.mu_re = mre.p;
     p.mu_im = mim.p;
     p.sums = es.p;
+    DevBuf<double> escratch;
+    if ((size_t)2 * nb * sizeof(double) <= 120 * 1024 &&
+        escratch.alloc(fh_uvbin_scratch_doubles(2, nb, n, h->num_cu)) == hipSuccess)
+        p.scratch = escratch.p;
     HIP_TRY(hipEventRecord(ev2, nullptr));
     HIP_TRY(fh_uvbin_launch_err(p, h->num_cu, nullptr));
     HIP_TRY(hipEventRecord(ev3, nullptr));

@@ -157,11 +157,13 @@ struct UvBinParams {
     double bin_width, norm; // norm = 1 / bin_width (utilities.py:211)
     int nbins, use_lds;
     const double *mu_re, *mu_im;  // per-bin means for the error pass
+    double *scratch;              // per-workgroup slabs (fh_uvbin_scratch_doubles); NULL: global atomics into sums
     double *sums;                 // nq * nbins, zeroed by the caller
     unsigned long long *counts;   // nbins, zeroed by the caller
 };
 
 hipError_t fh_uvbin_launch_max(const double *uv, int64_t n, unsigned long long *out2, int num_cu, hipStream_t s);
+size_t fh_uvbin_scratch_doubles(int nq_plus, int nbins, int64_t n, int num_cu);
 hipError_t fh_uvbin_launch_sum(const UvBinParams &p, int num_cu, hipStream_t s);
 hipError_t fh_uvbin_launch_err(const UvBinParams &p, int num_cu, hipStream_t s);
 hipError_t fh_uvbin_launch_lookup(const double *uv, int64_t n, double bin_width, int nbins, int *out, int num_cu,
