@@ -59,7 +59,8 @@ __device__ __forceinline__ double bcast(double v, int lane) {  // wave-uniform b
 }
 
 struct Smem {
-    double *pan;   // panel / block-row staging, max(NP*PS, 16*(NP+1)) doubles
+    double *pan;   // panel / block-row staging, max(NP*PS, 16*(NP+1)) doubles (also stage 0 of row_inverse)
+    double *stage1;  // second stage buffer of row_inverse: (NP/16) * 256 doubles
     double *lw;    // NW x 16 x PS: per-wave scratch for the diagonal-tile inverses
     double *dl;    // 16 x PS: factor of the current diagonal tile (+ reciprocal diagonal in column 16)
     double *dli;   // 16 x PS: its inverse (A operand of the MFMA panel solve)
@@ -288,6 +289,79 @@ __device__ __noinline__ void block_inverse(const double *C, double *W, double *T
 
 }
 
+// ---- (4') row-by-row inverse: W_IJ = -W_II * sum_{K=J}^{I-1} L_IK W_KJ, one block row at a time ------------------------
+// One CU pulls only ~13 B/clk from L2, and the recursive form above moves ~8 MB per iteration (T is written and read
+// back at every level).  Here a row's L tiles are staged once in LDS (the next row's while this row computes), the sum
+// is accumulated in registers, and the accumulator -- already in the layout of an MFMA B operand -- is multiplied by
+// W_II without touching memory: ~3.5 MB per iteration, one barrier per block row.  W's mirror blocks are not needed.
+__device__ __noinline__ void row_inverse(const double *C, double *W, const double *WdT, double *cs, double *stage0,
+                                         double *stage1, int N, int nb, int ld, long long *timing) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cl = lane & 15, rg = lane >> 4;
+#ifdef FIT_LOOP_TIMING
+    long long t_last = clock64();
+#endif
+    auto cs_ptr = [&](int I, int J) { return cs + ((size_t)I * nb + J) * 16; };
+    // stage[K][k][i] = L_IK[i][k] (the mirror block (K, I) of C, row-major): fragment s of lane (cl, rg) is
+    // stage[K * 256 + (4 s + rg) * 16 + cl]
+    auto stage_row = [&](int I, double *stage) {
+        for (int e = tid; e < I * 256; e += KT) {
+            const int K = e >> 8, r = (e >> 4) & 15, c = e & 15;
+            stage[e] = C[(size_t)(16 * K + r) * ld + 16 * I + c];
+        }
+    };
+    if (nb > 1) stage_row(1, stage0);
+    __syncthreads();
+    constexpr int PFR = PF;  // W tiles in flight per chain (4 deep and a register-held stage were tried: spills, slower)
+    for (int I = 1; I < nb; ++I) {
+        double *stage = (I & 1) ? stage0 : stage1;
+        if (I + 1 < nb) stage_row(I + 1, (I & 1) ? stage1 : stage0);
+        Frag fw;  // A operand W_II: rows of its transpose
+        {
+            const double *wd = WdT + (size_t)I * 256 + rg * 16 + cl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fw.v[q] = wd[64 * q];
+        }
+        // columns in snake order over the waves: the chain of column J has I - J products
+        for (int idx = 0; idx < I; ++idx) {
+            const int slot = idx & (NW - 1);
+            if ((((idx / NW) & 1) ? NW - 1 - slot : slot) != wave) continue;
+            const int J = idx;
+            v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+            Frag rb[PFR];
+#pragma unroll
+            for (int d = 0; d < PFR; ++d) rb[d] = load_rows(W + (size_t)(16 * min(J + d, I - 1)) * ld + 16 * J, ld, cl, rg);
+            for (int K = J; K < I; ++K) {
+                Frag fa;
+                const double *sp = stage + K * 256 + rg * 16 + cl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fa.v[q] = sp[64 * q];
+                const Frag fb = rb[0];
+#pragma unroll
+                for (int d = 0; d + 1 < PFR; ++d) rb[d] = rb[d + 1];
+                if (K + PFR < I) rb[PFR - 1] = load_rows(W + (size_t)(16 * (K + PFR)) * ld + 16 * J, ld, cl, rg);
+                acc = mfma4(fa, fb, acc, false);
+            }
+            // the C/D layout of acc (row = rg + 4 r, col = cl) is the B-operand layout (k = 4 s + rg, j = cl)
+            Frag fs;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fs.v[q] = acc[q];
+            v4f64 w = {0.0, 0.0, 0.0, 0.0};
+            w = mfma4(fw, fs, w, true);
+            store_tile(W, ld, I, J, w, cl, rg, false);
+            double ssq = 0.0;  // column sums of squares of this (final) tile over the rows of the real system
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * I + rg + 4 * r < N) ssq = fma(w[r], w[r], ssq);
+            ssq += __shfl_xor(ssq, 16);
+            ssq += __shfl_xor(ssq, 32);
+            if (rg == 0) cs_ptr(I, J)[cl] = ssq;
+        }
+        __syncthreads();  // row I of W is complete (row I + 1 reads it) and the next row's L tiles are staged
+    }
+    ISTAMP(5);
+}
+
 // ---- one posterior solve: C = A + diag(1/p) -> L -> W = L^-1 -> y = W b, m = W^T y, tr2 = colnorm2(W) --------------
 // Storage: C lower = L, C strictly-upper blocks = L^T (mirror); W lower = L^-1, W strictly-upper blocks = its
 // transpose; with the mirrors every MFMA operand is loaded in "row form" (4 rows x 128 contiguous bytes).
@@ -434,7 +508,11 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
     if (*S.flag) return false;
     TSTAMP(4);
 
+#ifdef FIT_INVERSE_BLOCKED
     block_inverse(C, W, T, WdT, P.cs, N, nb, ld, P.timing);
+#else
+    row_inverse(C, W, WdT, P.cs, S.pan, S.stage1, N, nb, ld, P.timing);
+#endif
 #ifdef FIT_LOOP_TIMING
     t_last = clock64();
 #endif
@@ -495,7 +573,8 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     S.rhs = S.tr2 + NP;
     S.b = S.rhs + NP;
     S.red = S.b + NP;  // 6*NP
-    S.lst = reinterpret_cast<int *>(S.red + 6 * NP);
+    S.stage1 = S.red + 6 * NP;
+    S.lst = reinterpret_cast<int *>(S.stage1 + (NP / 16) * 256);
     S.flag = S.lst + 192;
     __shared__ int s_ctl[4];  // [0] stop, [1] status
 
@@ -640,7 +719,7 @@ __global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int 
 
 size_t fh_k2_loop_smem_bytes(int NP) {
     const int panel = NP * PS > 2 * NW * NP ? NP * PS : 2 * NW * NP;
-    return sizeof(double) * (size_t)(panel + (NW + 2) * 16 * PS + 7 * NP + 6 * NP) + 4 * 192 + 16;
+    return sizeof(double) * (size_t)(panel + (NW + 2) * 16 * PS + 7 * NP + 6 * NP + (NP / 16) * 256) + 4 * 192 + 16;
 }
 
 hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s) {
