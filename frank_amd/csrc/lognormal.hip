@@ -7,11 +7,13 @@
 //   CriticalFilter.update_power_spectrum  frank/filter.py:154-177
 //
 // The algorithm is a serial chain of small dense operations (N <= 320): ~1e5 Newton steps, ~1e6 function evaluations
-// and ~1e4 LU factorisations per fit, each depending on the last.  Nothing here is bandwidth- or MFMA-bound; the
-// cost is latency, so the whole chain lives in ONE workgroup: state in LDS, the LU factors in LDS when they fit
-// (N <= 112) or in L2 otherwise, every reduction in a fixed order so that all lanes take the same branch, no host
-// round trip until the fit is done.  Throughput comes from running independent fits (sweeps, bootstraps) on the
-// other 255 CUs, not from splitting one fit.
+// and ~1e4 LU factorisations per fit, each depending on the last.  Nothing here is MFMA-bound: for small N the cost is
+// latency, from N ~ 100 it is what one CU can stream from L2 (three N x N matrices per Newton step at ~13 B/clk).  The
+// whole chain lives in ONE workgroup: state in LDS, the LU factors in LDS when they fit (N <= 112) or in L2 otherwise,
+// every reduction in a fixed order so that all lanes take the same branch, no host round trip until the fit is done.
+// A factorisation that keeps being re-used is turned into the explicit inverse (minimize_newton).  Throughput comes
+// from running independent fits (sweeps, bootstraps) on the other 255 CUs: the batched launch pulls fits from a queue.
+// The hot loop has to stay inside the 64 KB instruction cache (one evaluation site, rolled substitution chains).
 //
 // Differences from the reference that do not change the mathematics: scipy's lu_factor (LAPACK getrf) is an
 // unblocked partial-pivoting LU here; the posterior covariance D = hess(s_MAP)^-1 is applied through that LU
