@@ -734,49 +734,33 @@ static int solve_posterior(fh_ctx *c, const FitState &st, bool with_prior, bool 
     return FH_OK;
 }
 
-// Host SVD pseudo-inverse solve, the reference's route when cho_factor raises (statistical_models.py:747-755).
-static void svd_pinv_solve(int n, const std::vector<double> &A, const std::vector<double> &b, std::vector<double> &x) {
-    std::vector<double> W(A), V((size_t)n * n, 0.0);
-    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {  // one-sided Jacobi (Hestenes)
-        double off = 0;
-        for (int p = 0; p < n - 1; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                double al = 0, be = 0, ga = 0;
-                for (int i = 0; i < n; ++i) {
-                    const double a = W[(size_t)i * n + p], d = W[(size_t)i * n + q];
-                    al += a * a;
-                    be += d * d;
-                    ga += a * d;
-                }
-                if (ga == 0 || fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
-                off += fabs(ga) / sqrt(al * be);
-                const double zeta = (be - al) / (2 * ga);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
-                const double cs = 1 / sqrt(1 + t * t), sn = cs * t;
-                for (int i = 0; i < n; ++i) {
-                    double a = W[(size_t)i * n + p], d = W[(size_t)i * n + q];
-                    W[(size_t)i * n + p] = cs * a - sn * d;
-                    W[(size_t)i * n + q] = sn * a + cs * d;
-                    a = V[(size_t)i * n + p];
-                    d = V[(size_t)i * n + q];
-                    V[(size_t)i * n + p] = cs * a - sn * d;
-                    V[(size_t)i * n + q] = sn * a + cs * d;
-                }
-            }
-        if (off < 1e-15) break;
-    }
-    x.assign(n, 0.0);
-    for (int k = 0; k < n; ++k) {
-        double s2 = 0, wb = 0;
-        for (int i = 0; i < n; ++i) {
-            s2 += W[(size_t)i * n + k] * W[(size_t)i * n + k];
-            wb += W[(size_t)i * n + k] * b[i];
-        }
-        if (s2 > 0)
-            for (int i = 0; i < n; ++i) x[i] += V[(size_t)i * n + k] * (wb / s2);
-    }
+// SVD pseudo-inverse solve on the device, the reference's route when cho_factor raises (statistical_models.py:747-755,
+// 1150-1158):  U, s, V = svd(A);  X = V^T diag(where(s > 0, 1/s, 0)) U^T B.   A_dev: N*N row-major (destroyed),
+// B_dev: N*nrhs row-major, overwritten with X.  rocSOLVER factorises the column-major view A^T = U' S Vt', so
+// pinv(A) = U' S^+ Vt' and, on the column-major view of B (nrhs x N), X^T = B^T Vt'^T S^+ U'^T.
+static int svd_pinv_solve_device(fh_ctx *c, double *A_dev, double *B_dev, int nrhs) {
+    const int N = c->N;
+    const size_t NN = (size_t)N * N;
+    DevBuf<double> S, U, Vt, E, T;
+    if (S.alloc(2 * (size_t)N) != hipSuccess || U.alloc(NN) != hipSuccess || Vt.alloc(NN) != hipSuccess ||
+        E.alloc((size_t)N) != hipSuccess || T.alloc((size_t)N * nrhs) != hipSuccess)
+        return fail(FH_ERR_NOMEM, "svd_pinv_solve: device allocation failed");
+    ROC_TRY(rocsolver_dgesvd(c->blas, rocblas_svect_all, rocblas_svect_all, N, N, A_dev, N, S.p, U.p, N, Vt.p, N, E.p,
+                             rocblas_outofplace, c->info.p));
+    int info = 0;
+    HIP_TRY(hipMemcpyAsync(&info, c->info.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (info != 0) return fail(FH_ERR_NOT_SPD, "SVD did not converge (info %d)", info);
+    HIP_TRY(fh_k2_launch_pinv_scale(S.p, N, S.p + N, c->stream));
+    const double one = 1.0, zero = 0.0;
+    ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, nrhs, N, N, &one, B_dev, nrhs, Vt.p,
+                          N, &zero, T.p, nrhs));
+    ROC_TRY(rocblas_ddgmm(c->blas, rocblas_side_right, nrhs, N, T.p, nrhs, S.p + N, 1, T.p, nrhs));
+    ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, nrhs, N, N, &one, T.p, nrhs, U.p, N,
+                          &zero, B_dev, nrhs));
+    return FH_OK;
 }
+
 
 int fh_gaussian_model(fh_ctx *c, const double *M, const double *j, const double *p, double *mu, double *chol,
                       double *Sinv, int *used_svd) {
@@ -813,22 +797,20 @@ int fh_gaussian_model(fh_ctx *c, const double *M, const double *j, const double 
     if (chol) HIP_TRY(hipMemcpyAsync(chol, c->D.p, sizeof(double) * NN, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (info != 0) {
-        // not positive definite: rebuild Dinv and take the SVD route on the host, as the reference does
-        std::vector<double> Dinv(NN), bj(j, j + N), x;
+        // not positive definite: rebuild Dinv and take the SVD route, as the reference does (rocSOLVER gesvd)
         if (p) {
             const double one = 1.0;
             HIP_TRY(fh_k2_launch_prep(st, c->stream));
             ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, N, N, N, &one, c->Y.p,
                                   N, c->W.p, N, &one, c->D.p, N));
-            HIP_TRY(hipMemcpyAsync(Dinv.data(), c->D.p, sizeof(double) * NN, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            for (int i = 0; i < N; ++i)  // the dgemm result is symmetric only to rounding; use the upper triangle
-                for (int k = 0; k < i; ++k) Dinv[(size_t)i * N + k] = Dinv[(size_t)k * N + i];
         } else {
-            memcpy(Dinv.data(), M, sizeof(double) * NN);
+            HIP_TRY(hipMemcpyAsync(c->D.p, c->M.p, sizeof(double) * NN, hipMemcpyDeviceToDevice, c->stream));
         }
-        svd_pinv_solve(N, Dinv, bj, x);
-        if (mu) memcpy(mu, x.data(), sizeof(double) * N);
+        HIP_TRY(hipMemcpyAsync(c->mu.p, c->j.p, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
+        rc = svd_pinv_solve_device(c, c->D.p, c->mu.p, 1);
+        if (rc) return rc;
+        if (mu) HIP_TRY(hipMemcpyAsync(mu, c->mu.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
         if (used_svd) *used_svd = 1;
     }
     return FH_OK;
@@ -848,6 +830,21 @@ int fh_cho_solve(fh_ctx *c, const double *chol, double *B, int nrhs) {
                           rocblas_diagonal_non_unit, nrhs, N, &one, c->D.p, N, c->scratch_out.p, nrhs));
     ROC_TRY(rocblas_dtrsm(c->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none,
                           rocblas_diagonal_non_unit, nrhs, N, &one, c->D.p, N, c->scratch_out.p, nrhs));
+    HIP_TRY(hipMemcpyAsync(B, c->scratch_out.p, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
+int fh_svd_solve(fh_ctx *c, const double *A, double *B, int nrhs) {
+    if (!c || !A || !B || nrhs < 1) return fail(FH_ERR_INVALID, "fh_svd_solve: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->N;
+    const size_t NN = (size_t)N * N, nb = (size_t)N * nrhs;
+    if (c->scratch_out.n < nb) HIP_TRY(c->scratch_out.alloc(nb));
+    HIP_TRY(hipMemcpyAsync(c->D.p, A, sizeof(double) * NN, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->scratch_out.p, B, sizeof(double) * nb, hipMemcpyHostToDevice, c->stream));
+    int rc = svd_pinv_solve_device(c, c->D.p, c->scratch_out.p, nrhs);
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(B, c->scratch_out.p, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return FH_OK;

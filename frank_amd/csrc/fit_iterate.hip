@@ -176,3 +176,15 @@ hipError_t fh_k2_launch_record(const FitState &st, hipStream_t s) {
     hipLaunchKernelGGL(fit_record_kernel, dim3(1), dim3(256), 0, s, st);
     return hipGetLastError();
 }
+
+// s1 = where(s > 0, 1 / s, 0): the cut of the SVD pseudo-inverse (statistical_models.py:751, :1155)
+__global__ void pinv_scale_kernel(const double *s, int n, double *s1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) s1[i] = s[i] > 0 ? 1.0 / s[i] : 0.0;
+}
+
+hipError_t fh_k2_launch_pinv_scale(const double *s, int n, double *s1, hipStream_t st) {
+    hipLaunchKernelGGL(pinv_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s, n, s1);
+    return hipGetLastError();
+}
+

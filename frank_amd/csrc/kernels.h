@@ -82,6 +82,7 @@ hipError_t fh_k2_launch_prep(const FitState &st, hipStream_t s);
 hipError_t fh_k2_launch_powerlaw(const FitState &st, hipStream_t s);
 hipError_t fh_k2_launch_update(const FitState &st, hipStream_t s);
 hipError_t fh_k2_launch_record(const FitState &st, hipStream_t s);
+hipError_t fh_k2_launch_pinv_scale(const double *s, int n, double *s1, hipStream_t st);
 
 // ---- K2 v2: single persistent kernel (fit_loop.hip) ---------------------------------------------------------
 enum { FIT_MODE_FULL = 0, FIT_MODE_STEP = 1, FIT_MODE_SOLVE = 2 };

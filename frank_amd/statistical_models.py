@@ -307,11 +307,9 @@ class GaussianModel:
         self._ensure_factor()
         b = np.asarray(b, dtype=np.float64)
         if self._Dchol is None:
-            # Cholesky failed for this Dinv: same route as the reference (:779-781), on the host
+            # Cholesky failed for this Dinv: the reference's SVD route (:779-781), rocSOLVER gesvd on the device
             Dinv = self._M + (self._sinv() if self._p is not None else 0)
-            U, s, V = np.linalg.svd(Dinv, full_matrices=False)
-            s1 = np.where(s > 0, 1. / s, 0)
-            return np.dot(V.T, np.multiply(np.dot(U.T, b).T, s1).T)
+            return _svd_solve(self._DHT, Dinv, b)
         shape = b.shape
         B = np.array(b.reshape(self.size, -1), dtype=np.float64, order='C')  # copy: the solve is in place
         _lib.check(_lib.lib.fh_cho_solve(self._DHT.context(), _lib.ptr(self._Dchol), _lib.ptr(B), B.shape[1]))
@@ -385,6 +383,15 @@ class GaussianModel:
         """Number of points in reconstruction"""
         return self._DHT.size
 
+
+
+def _svd_solve(DHT, Dinv, b):
+    """V^T diag(where(s > 0, 1/s, 0)) U^T b with U, s, V = svd(Dinv): fh_svd_solve (rocSOLVER gesvd + rocBLAS)."""
+    b = np.asarray(b, dtype=np.float64)
+    N = DHT.size
+    B = np.array(b.reshape(N, -1), dtype=np.float64, order='C')
+    _lib.check(_lib.lib.fh_svd_solve(DHT.context(), _lib.ptr(_lib.f8(Dinv)), _lib.ptr(B), B.shape[1]))
+    return B.reshape(b.shape)
 
 
 class LogNormalMAPModel:
@@ -504,10 +511,8 @@ class LogNormalMAPModel:
         self._ensure_factor()
         b = np.asarray(b, dtype=np.float64)
         if self._Dchol is None:
-            # the Hessian at the MAP is not positive definite: the reference's SVD route (:1150-1158), on the host
-            U, s_svd, V = np.linalg.svd(self._Dinv, full_matrices=False)
-            s1 = np.where(s_svd > 0, 1. / s_svd, 0)
-            return np.dot(V.T, np.multiply(np.dot(U.T, b).T, s1).T)
+            # the Hessian at the MAP is not positive definite: the reference's SVD route (:1150-1158), on the device
+            return _svd_solve(self._DHT, self._Dinv, b)
         shape = b.shape
         B = np.array(b.reshape(self.size, -1), dtype=np.float64, order='C')
         _lib.check(_lib.lib.fh_cho_solve(self._DHT.context(), _lib.ptr(self._Dchol), _lib.ptr(B), B.shape[1]))

@@ -125,6 +125,11 @@ int fh_gaussian_model(fh_ctx *ctx, const double *M, const double *j, const doubl
 /* Dsolve(b) with a previously returned factor (statistical_models.py:762-781). B: N*nrhs row-major, in place. */
 int fh_cho_solve(fh_ctx *ctx, const double *chol, double *B, int nrhs);
 
+/* The reference's route when cho_factor raises (statistical_models.py:747-755, 779-781, 1150-1158, 1181-1182):
+ * U, s, V = svd(A); X = V^T diag(where(s > 0, 1/s, 0)) U^T B, on the device (rocSOLVER gesvd + rocBLAS).
+ * A: N*N row-major host; B: N*nrhs row-major host, overwritten with X.                                          */
+int fh_svd_solve(fh_ctx *ctx, const double *A, double *B, int nrhs);
+
 /* ---- a10/a14/a15/a16: the power-spectrum iteration = K2 `fit_iterate` --------------------------------------
  * FrankFitter._fit, method='Normal' (radial_fitters.py:737-832) with CriticalFilter.update_power_spectrum /
  * check_convergence (filter.py:154-181), spectral_smoothing_matrix (filter.py:23-62) and GaussianModel

@@ -755,3 +755,25 @@ def test_bootstrap_lognormal_equals_gathered_copy():
         sol = FF.fit(u[idxs], v[idxs], V[idxs], w[idxs])
         assert rel_to_max(prof[t], sol.I) < 1e-6
         assert np.all(prof[t] > 0)
+
+
+def test_svd_route_when_cholesky_fails(golden):
+    """cho_factor raises on an indefinite Dinv and the reference switches to an SVD pseudo-inverse
+    (statistical_models.py:742-755, 779-781): here rocSOLVER gesvd (fh_svd_solve), checked against NumPy's SVD."""
+    from frank_amd import DiscreteHankelTransform, GaussianModel
+    g = golden("map_small.npz")
+    N = int(g["N"])
+    M = np.array(g["M"])
+    M = 0.5 * (M + M.T) - 0.05 * np.diag(np.diag(M))        # push the small eigenvalues below zero
+    assert np.linalg.eigvalsh(M).min() < 0
+    j = np.array(g["j"])
+    fit = GaussianModel(DiscreteHankelTransform(RMAX, N), M, j)   # no prior: Dinv = M
+    assert fit._used_svd
+    U, s, V = np.linalg.svd(M, full_matrices=False)
+    s1 = np.where(s > 0, 1. / s, 0)
+    expect = np.dot(V.T, s1 * np.dot(U.T, j))
+    assert rel_to_max(fit.mean, expect) < 1e-7
+    B = np.random.default_rng(3).normal(size=(N, 3))
+    X = fit.Dsolve(B)
+    assert rel_to_max(X, np.dot(V.T, (s1 * np.dot(U.T, B).T).T)) < 1e-7
+    assert fit.covariance.shape == (N, N)
