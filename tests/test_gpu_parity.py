@@ -777,3 +777,20 @@ def test_svd_route_when_cholesky_fails(golden):
     X = fit.Dsolve(B)
     assert rel_to_max(X, np.dot(V.T, (s1 * np.dot(U.T, B).T).T)) < 1e-7
     assert fit.covariance.shape == (N, N)
+
+
+@pytest.mark.parametrize("n,N", [(30, 100), (50, 300)])
+def test_fewer_visibilities_than_basis_functions(n, N):
+    """n < N: M is rank-deficient and only the prior keeps M + S^-1 positive definite.  The reference stays on the
+    Cholesky route there (no SVD call observed), and so must the q-space formulation of the device loop."""
+    from frank_amd import FrankFitter
+    from oracle import oracle as fo
+    u, v, V, w = mock_disc_visibilities(n, seed=3, noise_seed=4)
+    FF = FrankFitter(2.0, N, geom(), verbose=False, store_iteration_diagnostics=True, convergence_failure="ignore",
+                     max_iter=300, check_qbounds=False)
+    sol = FF.fit(u, v, V, w)
+    m = fo.map_visibilities(N, RMAX, GEOM, u, v, V, w, check_qbounds=False)
+    ref = fo.frank_fit_normal(N, RMAX, m["M"], m["j"], max_iter=300)
+    assert ref["rc"] == 0 and ref["n_svd"] == 0
+    assert FF.iteration_diagnostics["num_iterations"] == ref["niter"]
+    assert rel_to_max(sol.I, ref["mu"]) < 1e-6
