@@ -581,15 +581,24 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
         c->have_device_Mj = false;
         return FH_OK;
     }
-    // throughput mode while fit_loop kernels of earlier fits hold CUs (see bin_gram.hip)
-    const bool dynamic = c->slots_busy > 0;
+    // fit_loop kernels of earlier fits that are still RUNNING each hold a CU (a slot stays "busy" until it is collected,
+    // long after its kernel has finished: counting those would leave CUs idle)
+    int running = 0;
+    if (c->slots_busy > 0)
+        for (auto &sl : c->slots)
+            if (sl.busy && sl.stream && hipStreamQuery(sl.stream) == hipErrorNotReady) ++running;
+    (void)hipGetLastError();  // hipErrorNotReady is not an error here
+    // throughput mode while such kernels hold CUs (see bin_gram.hip)
+    const bool dynamic = running > 0 || getenv("FRANK_AMD_K1_DYNAMIC") != nullptr;  // env: development switch
     p.work_counter = dynamic ? c->work_counter.p : nullptr;
     if (dynamic) HIP_TRY(hipMemsetAsync(c->work_counter.p, 0, 2 * sizeof(int), c->stream));
     ReduceParams rp{};
     rp.nparts = c->nparts;
     rp.ntiles = c->ntiles;
     // leave one CU per outstanding fit_loop kernel (each occupies a whole CU) so every bin_gram workgroup is resident
-    const int reserve = c->slots_busy < c->num_cu / 4 ? c->slots_busy : c->num_cu / 4;
+    int reserve = running;
+    if (const char *e = getenv("FRANK_AMD_K1_RESERVE_MULT")) reserve = (int)(running * atof(e));  // development switch
+    if (reserve > c->num_cu / 4) reserve = c->num_cu / 4;
     const int G = c->part_blocks[0] + c->part_blocks[1];
     for (int P = 0; P < 2; ++P) {
         int blocks = c->part_blocks[P];
