@@ -14,15 +14,16 @@
 // The DHT scaling a_k (~1e-14) is applied once afterwards in fp64 (finalize kernel): the Gram has O(1) entries.
 //
 // Work decomposition of K1b (DESIGN.md "K1"):
-//   * one 512-thread workgroup per CU = 8 waves, two per SIMD: while one wave of a SIMD waits on the
-//     matrix pipe the other issues the J0 polynomial work (VALU); waves 4-7 run half a chunk out of phase;
+//   * one 768-thread workgroup per CU = 12 waves, three per SIMD (K1_WAVES; the first design had 8): while a wave
+//     of a SIMD waits on the matrix pipe or on LDS the others issue J0 polynomial work (VALU) or their own MFMAs;
+//     the waves of a SIMD produce their J0 row at different k-steps of the chunk;
 //   * the upper triangle of the NBT x NBT grid of 16x16 output tiles (190 tiles at N = 300) stays in
 //     accumulator registers for the whole visibility stream.  190 tiles x 8 registers do not fit one CU
 //     beside the J0 temporaries, so for NBT = 19 the triangle is cut row-aligned into two PARTS (tile rows
 //     0-6: 112 tiles, rows 7-18: 78 tiles); the grid is split between the parts in proportion to their tile
 //     counts and every part streams ALL visibilities, evaluating only the J0 columns it needs (1.68x J0);
-//   * visibilities are streamed in super-chunks of 512 and chunks of 16 rows; a chunk's rows are written to
-//     LDS (double-buffered) by all eight waves and read back as MFMA fragments (the A-fragment of block I is
+//   * visibilities are streamed in super-chunks of 768 and chunks of 12 rows; a chunk's rows are written to
+//     LDS (double-buffered), one row per wave, and read back as MFMA fragments (the A-fragment of block I is
 //     the B-fragment of block I).  The loop is specialised per wave (static accumulator registers), with the J0
 //     evaluation rolled over the column groups so that a part's eight specialisations fit the I-cache;
 //   * super-chunks are handed out either statically (block b takes b, b+G, ...: bitwise reproducible, the
@@ -41,11 +42,19 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kThreads = 512;
-constexpr int kWaves = 8;
-constexpr int kSuper = 512;  // visibilities per super-chunk (one LDS row of scalars per thread)
-constexpr int kChunk = 16;   // rows per LDS buffer = 4 MFMA k-steps; 2 rows produced per wave
+// K1_WAVES = 12 (default): three waves per SIMD (168 VGPRs), 12-row chunks, one J0 row per wave and chunk: 28.6 ms.
+// K1_WAVES = 8: two waves per SIMD, 16-row chunks, two J0 rows per wave and chunk: 30.2 ms (the first design).
+// K1_WAVES = 16: four per SIMD would need <= 128 VGPRs: 167 spilled registers, not viable.
+#ifndef K1_WAVES
+#define K1_WAVES 12
+#endif
+constexpr int kWaves = K1_WAVES;
+constexpr int kThreads = 64 * kWaves;
+constexpr int kSuper = kThreads;          // visibilities per super-chunk (one LDS row of scalars per thread)
+constexpr int kChunk = kWaves == 8 ? 16 : kWaves;  // rows per LDS buffer = kChunk / 4 MFMA k-steps
+constexpr int kRowsPerWave = kChunk / kWaves;  // J0 rows a wave produces per chunk
 constexpr int kChunksPerSuper = kSuper / kChunk;
+static_assert(kChunk % 4 == 0 && kChunk % kWaves == 0 && kSuper % kChunk == 0, "chunk geometry");
 
 constexpr int xstride(int NBT) {  // LDS row stride in doubles, == 16 (mod 32): conflict-free fragment reads
     return (NBT * 16) % 32 == 16 ? NBT * 16 : NBT * 16 + 16;
@@ -159,7 +168,7 @@ __device__ __forceinline__ void mfma_one(v4f64 &acc, const double (&f)[NBT]) {
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f[I], f[J], acc, 0, 0, 0);
 }
 template <int NBT, int P, int W, int TPW, int... Ts>
-__device__ __forceinline__ void mfma_all(v4f64 (&acc)[TPW], const double (&f)[NBT],
+__device__ __forceinline__ void mfma_all(v4f64 (&acc)[TPW > 0 ? TPW : 1], const double (&f)[NBT],
                                          std::integer_sequence<int, Ts...>) {
     (mfma_one<NBT, P, W, Ts>(acc[Ts], f), ...);
 }
@@ -175,7 +184,8 @@ __device__ __forceinline__ void wave_main(const BinParams &p, double *smem, int 
     constexpr int C0 = B0 * 16;                           // first column
     constexpr int NCG = (NC - C0 + 63) / 64;              // column groups of 64 lanes
     constexpr bool kSkew = W >= 4;                        // second wave of each SIMD: half a chunk out of phase
-    static_assert(TPW >= 1, "every wave owns at least one tile");
+    constexpr int kPhase = W / 4;                         // position among the waves of this SIMD (12-wave layout)
+    constexpr int TPWA = TPW > 0 ? TPW : 1;               // (with 12 waves the small bases leave some waves without tiles)
 
     double *tab = smem;                                                      // FH_J0_TABLE_DOUBLES
     double *vs_s = tab + FH_J0_TABLE_DOUBLES;                                // [2][kSuper] each
@@ -193,7 +203,7 @@ __device__ __forceinline__ void wave_main(const BinParams &p, double *smem, int 
 
     for (int c = tid; c < NCG * 64; c += kThreads) jkl[c] = (C0 + c) < N ? p.zeros[C0 + c] : 0.0;  // J0(0) = 1 beyond N
 
-    v4f64 acc[TPW];
+    v4f64 acc[TPWA];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
 
@@ -221,7 +231,7 @@ __device__ __forceinline__ void wave_main(const BinParams &p, double *smem, int 
     };
     // ---- one J0 row: this wave produces rows 2W, 2W+1 of every chunk, one 64-column group at a time -----------
     auto produce_row = [&](int sbuf, int ch, int xbuf, int rr) {
-        const int row = W * 2 + rr;
+        const int row = W * kRowsPerWave + rr;
         const int vi = sbuf * kSuper + ch * kChunk + row;
         const double s = vs_s[vi], sw = vs_sw[vi], swV = vs_swV[vi];
         double *xr = X + (xbuf * kChunk + row) * XS + C0;
@@ -242,10 +252,11 @@ __device__ __forceinline__ void wave_main(const BinParams &p, double *smem, int 
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    // ---- MFMAs of two k-steps (8 rows) of X[xbuf] ---------------------------------------------------------
-    auto consume2 = [&](int xbuf, int ks0) {
+    // ---- MFMAs of `NKS` k-steps (4 rows each) of X[xbuf] ------------------------------------------------------
+    auto consume = [&](int xbuf, int ks0, auto nks_tag) {
+        constexpr int NKS = decltype(nks_tag)::value;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
             const double *xb = X + (xbuf * kChunk + (ks0 + ks) * 4 + kk) * XS + ii;
             double f[NBT];
 #pragma unroll
@@ -254,14 +265,16 @@ __device__ __forceinline__ void wave_main(const BinParams &p, double *smem, int 
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    auto consume2 = [&](int xbuf, int ks0) { consume(xbuf, ks0, std::integral_constant<int, 2>{}); };
+    auto consume1 = [&](int xbuf, int ks0) { consume(xbuf, ks0, std::integral_constant<int, 1>{}); };
 
     // ---- main loop --------------------------------------------------------------------------------------------
     int sbuf = 0, xbuf = 0;
     if (cur < nsup) {
         load_scalars(cur, 0);
         __syncthreads();
-        produce_row(0, 0, 0, 0);
-        produce_row(0, 0, 0, 1);
+#pragma unroll
+        for (int rr = 0; rr < kRowsPerWave; ++rr) produce_row(0, 0, 0, rr);
         __syncthreads();
     }
     int qslot = 0;
@@ -275,16 +288,24 @@ __device__ __forceinline__ void wave_main(const BinParams &p, double *smem, int 
             const int nsb = last ? (sbuf ^ 1) : sbuf;
             const int nch = last ? 0 : ch + 1;
             // J0 rows of chunk c+1 (VALU) against the MFMAs of chunk c (matrix pipe)
-            if (!kSkew) {
-                if (more) produce_row(nsb, nch, xbuf ^ 1, 0);
-                consume2(xbuf, 0);
-                if (more) produce_row(nsb, nch, xbuf ^ 1, 1);
-                consume2(xbuf, 2);
-            } else {
-                consume2(xbuf, 0);
-                if (more) produce_row(nsb, nch, xbuf ^ 1, 0);
-                consume2(xbuf, 2);
-                if (more) produce_row(nsb, nch, xbuf ^ 1, 1);
+            if constexpr (kWaves == 8) {
+                if (!kSkew) {
+                    if (more) produce_row(nsb, nch, xbuf ^ 1, 0);
+                    consume2(xbuf, 0);
+                    if (more) produce_row(nsb, nch, xbuf ^ 1, 1);
+                    consume2(xbuf, 2);
+                } else {
+                    consume2(xbuf, 0);
+                    if (more) produce_row(nsb, nch, xbuf ^ 1, 0);
+                    consume2(xbuf, 2);
+                    if (more) produce_row(nsb, nch, xbuf ^ 1, 1);
+                }
+            } else {  // three / four waves per SIMD: the one J0 row of a wave slides through the k-steps
+#pragma unroll
+                for (int ks = 0; ks < kChunk / 4; ++ks) {
+                    if (kPhase == ks && more) produce_row(nsb, nch, xbuf ^ 1, 0);
+                    consume1(xbuf, ks);
+                }
             }
             __syncthreads();
             xbuf ^= 1;
@@ -323,12 +344,28 @@ __device__ __forceinline__ void part_main(const BinParams &p, double *smem, int 
         case 4: wave_main<NBT, P, 4>(p, smem, part_block, part_nblocks); break;
         case 5: wave_main<NBT, P, 5>(p, smem, part_block, part_nblocks); break;
         case 6: wave_main<NBT, P, 6>(p, smem, part_block, part_nblocks); break;
+#if K1_WAVES == 8
         default: wave_main<NBT, P, 7>(p, smem, part_block, part_nblocks); break;
+#else
+        case 7: wave_main<NBT, P, 7>(p, smem, part_block, part_nblocks); break;
+        case 8: wave_main<NBT, P, 8>(p, smem, part_block, part_nblocks); break;
+        case 9: wave_main<NBT, P, 9>(p, smem, part_block, part_nblocks); break;
+        case 10: wave_main<NBT, P, 10>(p, smem, part_block, part_nblocks); break;
+#if K1_WAVES == 12
+        default: wave_main<NBT, P, 11>(p, smem, part_block, part_nblocks); break;
+#else
+        case 11: wave_main<NBT, P, 11>(p, smem, part_block, part_nblocks); break;
+        case 12: wave_main<NBT, P, 12>(p, smem, part_block, part_nblocks); break;
+        case 13: wave_main<NBT, P, 13>(p, smem, part_block, part_nblocks); break;
+        case 14: wave_main<NBT, P, 14>(p, smem, part_block, part_nblocks); break;
+        default: wave_main<NBT, P, 15>(p, smem, part_block, part_nblocks); break;
+#endif
+#endif
     }
 }
 
 template <int NBT>
-__global__ __launch_bounds__(kThreads, 2) void bin_gram_kernel(BinParams p) {
+__global__ __launch_bounds__(kThreads, kWaves / 4) void bin_gram_kernel(BinParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     for (int i = threadIdx.x; i < FH_J0_TABLE_DOUBLES; i += kThreads) smem[i] = p.j0_table[i];
     __syncthreads();
