@@ -41,8 +41,42 @@ FH_HD double fh_horner(const double (&c)[N], double x) {
     return a;
 }
 
-// Degree-12 polynomial sum_{k=0}^{12} c(k) x^k by Estrin's scheme: 15 DP ops instead of Horner's 12, but a
-// dependency depth of 5 instead of 12 -- the J0 chains are latency-bound on the DP pipe they share with the MFMAs.
+// Degree-12 polynomial sum_{k=0}^{12} c(k) x^k.  Estrin's scheme (default): 15 DP ops instead of Horner's 12, but a
+// dependency depth of 5 instead of 12.  FH_J0_HORNER selects Horner: fewer operations and far fewer live registers
+// (coefficients are consumed as they arrive), for kernels that hide the chain latency with more resident waves.
+#ifdef FH_J0_HORNER
+#define FH_ESTRIN12(res, c, x)                                  \
+    do {                                                        \
+        double h_ = c(12);                                      \
+        h_ = fma(h_, (x), c(11));                               \
+        h_ = fma(h_, (x), c(10));                               \
+        h_ = fma(h_, (x), c(9));                                \
+        h_ = fma(h_, (x), c(8));                                \
+        h_ = fma(h_, (x), c(7));                                \
+        h_ = fma(h_, (x), c(6));                                \
+        h_ = fma(h_, (x), c(5));                                \
+        h_ = fma(h_, (x), c(4));                                \
+        h_ = fma(h_, (x), c(3));                                \
+        h_ = fma(h_, (x), c(2));                                \
+        h_ = fma(h_, (x), c(1));                                \
+        (res) = fma(h_, (x), c(0));                             \
+    } while (0)
+#define FH_ESTRIN11(res, c, x)                                  \
+    do {                                                        \
+        double h_ = c(11);                                      \
+        h_ = fma(h_, (x), c(10));                               \
+        h_ = fma(h_, (x), c(9));                                \
+        h_ = fma(h_, (x), c(8));                                \
+        h_ = fma(h_, (x), c(7));                                \
+        h_ = fma(h_, (x), c(6));                                \
+        h_ = fma(h_, (x), c(5));                                \
+        h_ = fma(h_, (x), c(4));                                \
+        h_ = fma(h_, (x), c(3));                                \
+        h_ = fma(h_, (x), c(2));                                \
+        h_ = fma(h_, (x), c(1));                                \
+        (res) = fma(h_, (x), c(0));                             \
+    } while (0)
+#else
 #define FH_ESTRIN12(res, c, x)                                                              \
     do {                                                                                    \
         const double x2_ = (x) * (x), x4_ = x2_ * x2_, x8_ = x4_ * x4_;                     \
@@ -64,6 +98,7 @@ FH_HD double fh_horner(const double (&c)[N], double x) {
         const double r0_ = fma(q1_, x4_, q0_);                                              \
         (res) = fma(q2_, x8_, r0_);                                                         \
     } while (0)
+#endif
 
 // Large-argument branch, x >= FH_J0_XSPLIT.  `ab` = FH_J0_AB ({A_k, B_k} pairs, highest power first) followed by
 // the cosine coefficients FH_J0_CD.

@@ -35,6 +35,10 @@
 
 #include <utility>
 
+// Horner form of the J0 polynomials: with three waves per SIMD hiding the chain latency, the 9 DP operations fewer per
+// large-argument evaluation are worth more than Estrin's shorter dependency depth (28.5 -> 28.0 ms); max |error| vs
+// 40-digit mpmath on [0, 1000]: 1.1e-16 (Estrin form: 2.2e-16).
+#define FH_J0_HORNER 1
 #include "bessel.h"
 #include "kernels.h"
 
