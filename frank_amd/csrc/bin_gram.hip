@@ -46,7 +46,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-// K1_WAVES = 12 (default): three waves per SIMD (168 VGPRs), 12-row chunks, one J0 row per wave and chunk: 28.6 ms.
+// K1_WAVES = 12 (default): three waves per SIMD (166 VGPRs), 24-row chunks, two J0 rows per wave and chunk: 27.3 ms.
 // K1_WAVES = 8: two waves per SIMD, 16-row chunks, two J0 rows per wave and chunk: 30.2 ms (the first design).
 // K1_WAVES = 16: four per SIMD would need <= 128 VGPRs: 167 spilled registers, not viable.
 #ifndef K1_WAVES
@@ -55,7 +55,10 @@ namespace {
 constexpr int kWaves = K1_WAVES;
 constexpr int kThreads = 64 * kWaves;
 constexpr int kSuper = kThreads;          // visibilities per super-chunk (one LDS row of scalars per thread)
-constexpr int kChunk = kWaves == 8 ? 16 : kWaves;  // rows per LDS buffer = kChunk / 4 MFMA k-steps
+#ifndef K1_CHUNK
+#define K1_CHUNK (K1_WAVES == 8 ? 16 : 2 * K1_WAVES)  // 24 rows: half the barriers of 12 (28.1 -> 27.3 ms), 158 KB of LDS
+#endif
+constexpr int kChunk = K1_CHUNK;  // rows per LDS buffer = kChunk / 4 MFMA k-steps
 constexpr int kRowsPerWave = kChunk / kWaves;  // J0 rows a wave produces per chunk
 constexpr int kChunksPerSuper = kSuper / kChunk;
 static_assert(kChunk % 4 == 0 && kChunk % kWaves == 0 && kSuper % kChunk == 0, "chunk geometry");
@@ -304,10 +307,12 @@ __device__ __forceinline__ void wave_main(const BinParams &p, double *smem, int 
                     consume2(xbuf, 2);
                     if (more) produce_row(nsb, nch, xbuf ^ 1, 1);
                 }
-            } else {  // three / four waves per SIMD: the one J0 row of a wave slides through the k-steps
+            } else {  // three waves per SIMD: a wave's J0 rows slide through the k-steps according to its position
 #pragma unroll
                 for (int ks = 0; ks < kChunk / 4; ++ks) {
-                    if (kPhase == ks && more) produce_row(nsb, nch, xbuf ^ 1, 0);
+#pragma unroll
+                    for (int rr = 0; rr < kRowsPerWave; ++rr)
+                        if (ks == kPhase * kRowsPerWave + rr && more) produce_row(nsb, nch, xbuf ^ 1, rr);
                     consume1(xbuf, ks);
                 }
             }

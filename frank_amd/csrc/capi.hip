@@ -257,11 +257,11 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
             c->part_blocks[1] = 0;
         } else {
             // split the CUs in proportion to the parts' work per visibility: their tiles (MFMA) plus the J0 column blocks
-            // they have to evaluate (part 0 all 19, part 1 the last 12).  A block of 16 J0 columns weighs about as much
-            // as 13 tile updates -- from a sweep of the split at N = 300: 151 workgroups (tiles only) 30.5 ms, 155
-            // 30.1 ms, 159 31.3 ms.
+            // they have to evaluate (part 0 all 19, part 1 the last 12).  The weight of a block of 16 J0 columns comes
+            // from sweeps of the split at N = 300 (12-wave layout, Horner J0): 149 workgroups 27.8 ms, 153 27.1 ms,
+            // 157 28.0 ms -- about 3.3 tile updates; the optimum is flat to +-2 workgroups.
             const int t0 = fh_k1_part_ntiles(c->NBT, 0), t1 = fh_k1_part_ntiles(c->NBT, 1);
-            const double w0 = t0 + 13.0 * c->NBT, w1 = t1 + 13.0 * (c->NBT - 7);
+            const double w0 = t0 + 3.3 * c->NBT, w1 = t1 + 3.3 * (c->NBT - 7);
             int g0 = (int)llround((double)G * w0 / (w0 + w1));
             if (const char *e = getenv("FRANK_AMD_K1_SPLIT")) g0 = atoi(e);  // development: workgroups of part 0
             if (g0 < 1) g0 = 1;
