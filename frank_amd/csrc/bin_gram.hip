@@ -311,7 +311,7 @@ __device__ __forceinline__ void wave_main(const BinParams &p, double *smem, int 
 #pragma unroll
                 for (int ks = 0; ks < kChunk / 4; ++ks) {
 #pragma unroll
-                    for (int rr = 0; rr < kRowsPerWave; ++rr)
+                    for (int rr = 0; rr < kRowsPerWave; ++rr)  // (rows half a chunk apart instead: no difference)
                         if (ks == kPhase * kRowsPerWave + rr && more) produce_row(nsb, nch, xbuf ^ 1, rr);
                     consume1(xbuf, ks);
                 }
