@@ -391,30 +391,64 @@ constexpr size_t bin_smem_bytes() {
     return sizeof(double) * (FH_J0_TABLE_DOUBLES + 3 * 2 * kSuper + 2 * kChunk * xstride(NBT) + ((NBT * 16 + 63) / 64) * 64 + 2);
 }
 
-// Sum the per-workgroup slabs of every part in block order and add into the running statistics.
-__global__ void reduce_partials_kernel(ReduceParams rp, double *stats_sum, double *stats_minmax) {
+// Sum the per-workgroup slabs of every part and add into the running statistics -- in a FIXED order (bitwise
+// reproducible), in two levels so that the ~50 MB of slabs are read by thousands of threads instead of 190 serial
+// chains: level 1, group g of kReduceGroups sums its contiguous range of slabs in block order into scratch[g][e];
+// level 2 adds the groups in order.
+constexpr int kReduceGroups = 8;
+__global__ void reduce_partials_level1(ReduceParams rp, double *scratch) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ne = (int64_t)rp.ntiles * 256;
+    if (e >= ne) return;
+    const int g = blockIdx.y;
+    const int part = (rp.nparts > 1 && e >= (int64_t)rp.part_tile0[1] * 256) ? 1 : 0;
+    const int64_t pe = e - (int64_t)rp.part_tile0[part] * 256;
+    const int64_t stride = (int64_t)rp.part_ntiles[part] * 256;
+    const double *src = rp.partials[part];
+    const int nb = rp.part_blocks[part], per = (nb + kReduceGroups - 1) / kReduceGroups;
+    const int b0 = g * per, b1 = min(nb, b0 + per);
+    double s = 0.0;
+#pragma unroll 8
+    for (int b = b0; b < b1; ++b) s += src[(size_t)b * stride + pe];
+    scratch[(size_t)g * ne + e] = s;
+}
+__global__ void reduce_partials_kernel(ReduceParams rp, const double *scratch, double *stats_sum, double *stats_minmax) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t ne = (int64_t)rp.ntiles * 256;
     if (e < ne) {
-        const int part = (rp.nparts > 1 && e >= (int64_t)rp.part_tile0[1] * 256) ? 1 : 0;
-        const int64_t pe = e - (int64_t)rp.part_tile0[part] * 256;
-        const int64_t stride = (int64_t)rp.part_ntiles[part] * 256;
-        const double *src = rp.partials[part];
         double s = 0.0;
-        for (int b = 0; b < rp.part_blocks[part]; ++b) s += src[(size_t)b * stride + pe];
+#pragma unroll
+        for (int g = 0; g < kReduceGroups; ++g) s += scratch[(size_t)g * ne + e];
         stats_sum[e] += s;
     }
-    if (e == 0) {
+    if (blockIdx.x == 0) {
+        // the per-block scalars of deproject_kernel (up to 2048 of them): strided partial sums, then a fixed tree
+        __shared__ double rs[256], rmn[256], rmx[256];
+        const int t = threadIdx.x;
         double s = 0.0, mn = INFINITY, mx = -INFINITY;
-        for (int b = 0; b < rp.scalar_blocks; ++b) {
+        for (int b = t; b < rp.scalar_blocks; b += 256) {
             s += rp.partial_scalars[b * 4 + 0];
             mn = fmin(mn, rp.partial_scalars[b * 4 + 1]);
             mx = fmax(mx, rp.partial_scalars[b * 4 + 2]);
         }
-        stats_sum[ne + 0] += s;
-        // min/max are kept as (-qmin, qmax) so that one max-all-reduce serves both
-        stats_minmax[0] = fmax(stats_minmax[0], -mn);
-        stats_minmax[1] = fmax(stats_minmax[1], mx);
+        rs[t] = s;
+        rmn[t] = mn;
+        rmx[t] = mx;
+        __syncthreads();
+        for (int h = 128; h >= 1; h >>= 1) {
+            if (t < h) {
+                rs[t] += rs[t + h];
+                rmn[t] = fmin(rmn[t], rmn[t + h]);
+                rmx[t] = fmax(rmx[t], rmx[t + h]);
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            stats_sum[ne + 0] += rs[0];
+            // min/max are kept as (-qmin, qmax) so that one max-all-reduce serves both
+            stats_minmax[0] = fmax(stats_minmax[0], -rmn[0]);
+            stats_minmax[1] = fmax(stats_minmax[1], rmx[0]);
+        }
     }
 }
 
@@ -607,7 +641,9 @@ hipError_t fh_k1_launch_bin(int NBT, const BinParams &p, hipStream_t stream) {
 hipError_t fh_k1_launch_reduce(const ReduceParams &rp, double *stats_sum, double *stats_minmax,
                                hipStream_t stream) {
     const int64_t ne = (int64_t)rp.ntiles * 256;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, rp,
+    hipLaunchKernelGGL(reduce_partials_level1, dim3((unsigned)((ne + 255) / 256), kReduceGroups), dim3(256), 0, stream, rp,
+                       rp.scratch);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, rp, rp.scratch,
                        stats_sum, stats_minmax);
     return hipGetLastError();
 }

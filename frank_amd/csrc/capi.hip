@@ -106,7 +106,7 @@ struct fh_ctx {
     DevBuf<double> zeros, j0_table, Y, Ykm, q, pref_fwd, pref_bwd;
     // K1
     int part_blocks[2] = {0, 0};
-    DevBuf<double> partials[2], partial_scalars, stats_sum, stats_minmax, a_scale, sumwV2, prep;
+    DevBuf<double> partials[2], partial_scalars, stats_sum, stats_minmax, a_scale, sumwV2, prep, reduce_scratch;
     DevBuf<int> work_counter;
     int deproject_blocks = 0;
     // N > 303: rows to memory + rocBLAS dsyrk; stats_sum then holds the dense (N+1)^2 Gram (upper triangle) + 2 scalars
@@ -275,6 +275,7 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
         HIP_TRY(c->partial_scalars.alloc((size_t)c->deproject_blocks * 4));
         HIP_TRY(c->work_counter.alloc(2));
         HIP_TRY(c->stats_sum.alloc((size_t)c->ntiles * 256 + 2));
+        HIP_TRY(c->reduce_scratch.alloc(8 * (size_t)c->ntiles * 256));
         HIP_TRY(c->stats_minmax.alloc(2));
         HIP_TRY(c->a_scale.alloc(N));
         HIP_TRY(c->sumwV2.alloc(1));
@@ -614,6 +615,7 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     }
     p.partial_scalars = c->partial_scalars.p;
     rp.partial_scalars = c->partial_scalars.p;
+    rp.scratch = c->reduce_scratch.p;
     int dblocks = (int)((count + 255) / 256);
     if (dblocks > c->deproject_blocks) dblocks = c->deproject_blocks;
     if (dblocks < 1) dblocks = 1;

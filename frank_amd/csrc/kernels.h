@@ -35,6 +35,7 @@ struct ReduceParams {
     int part_blocks[2], part_tile0[2], part_ntiles[2];
     const double *partials[2];
     const double *partial_scalars;
+    double *scratch;  // 8 * ntiles * 256 doubles: level-1 sums of the slab reduction
 };
 
 int fh_k1_nbt_for(int N);
