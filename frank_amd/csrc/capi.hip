@@ -89,6 +89,7 @@ struct FitSlot {
     hipEvent_t ready = nullptr;
     DevBuf<double> Aq, bq, Cq, Wq, Tq, WdT, cs, mu_out, p_out, band_lu;
     DevBuf<int> result;
+    std::vector<double> lu_host;  // stays alive while the asynchronous copy of the band LU may still read it
     bool busy = false;
 };
 // One HIP stream per slot.  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; raised to 24 below)
@@ -507,9 +508,9 @@ int fh_bin_reset(fh_ctx *c) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->stats_sum.p, 0, sizeof(double) * c->stats_sum.n, c->stream));
     if (c->wide_G.p) HIP_TRY(hipMemsetAsync(c->wide_G.p, 0, sizeof(double) * c->wide_G.n, c->stream));
-    const double init[2] = {-INFINITY, -INFINITY};  // (-qmin, qmax) under max
-    HIP_TRY(hipMemcpyAsync(c->stats_minmax.p, init, sizeof init, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // (-qmin, qmax) under max start at -infinity: 0xFFF0000000000000 is not a byte pattern, but 0xFFFFFFFF words are a
+    // NaN, and fmax(NaN, x) = x -- the same neutral element, set without a host-side source buffer or a wait
+    HIP_TRY(hipMemsetAsync(c->stats_minmax.p, 0xFF, 2 * sizeof(double), c->stream));
     c->have_device_Mj = false;
     return FH_OK;
 }
@@ -675,6 +676,8 @@ int fh_stats_finalize(fh_ctx *c, const fh_geometry *g, int vis_model, int check_
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_device_Mj = true;
     if (H0) *H0 = 0.5 * (tail[0] - swv2);  // statistical_models.py:218
+    if (mm[0] != mm[0]) mm[0] = -INFINITY;  // nothing binned since the reset (the reset leaves the NaN neutral element)
+    if (mm[1] != mm[1]) mm[1] = -INFINITY;
     const double qmn = -mm[0], qmx = mm[1];
     if (qmin) *qmin = qmn;
     if (qmax) *qmax = qmx;
@@ -1224,10 +1227,8 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
         }
     }
     FitSlot &s = c->slots[si];
-    std::vector<double> lu;
-    smoothing_band_lu(*c->dht, wsmooth, lu);
-    HIP_TRY(hipMemcpyAsync(s.band_lu.p, lu.data(), sizeof(double) * lu.size(), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // `lu` is pageable host memory: make the copy complete before it dies
+    smoothing_band_lu(*c->dht, wsmooth, s.lu_host);  // the slot owns the host copy: no wait for the copy here
+    HIP_TRY(hipMemcpyAsync(s.band_lu.p, s.lu_host.data(), sizeof(double) * s.lu_host.size(), hipMemcpyHostToDevice, c->stream));
     int rc = prepare_qspace(c, s.Aq.p, s.bq.p);  // on the context's stream, after the finalize that produced M, j
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s.ready, c->stream));
