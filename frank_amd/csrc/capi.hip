@@ -1371,8 +1371,8 @@ static int ln_finish(fh_ctx *c, double *s, double *p, double *Dinv, int64_t *sta
     {
         long long cyc[8];
         HIP_TRY(hipMemcpy(cyc, c->ln_stats.p + 9, sizeof cyc, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[ln timing, Mcycles] eval %.1f  lu %.1f  solve %.1f (fwd chain %.1f, bwd chain %.1f)  hess %.1f  newton total %.1f\n",
-                cyc[0] / 1e6, cyc[1] / 1e6, cyc[2] / 1e6, cyc[5] / 1e6, cyc[6] / 1e6, cyc[3] / 1e6, cyc[4] / 1e6);
+        fprintf(stderr, "[ln timing, Mcycles] eval %.1f  lu %.1f (panel %.1f, write-back+swaps %.1f, U12+trailing %.1f)  solve %.1f  hess %.1f  newton total %.1f\n",
+                cyc[0] / 1e6, cyc[1] / 1e6, cyc[5] / 1e6, cyc[6] / 1e6, cyc[7] / 1e6, cyc[2] / 1e6, cyc[3] / 1e6, cyc[4] / 1e6);
     }
 #endif
     if (result[1] == LN_STATUS_BAD_P) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (non-positive or NaN)");

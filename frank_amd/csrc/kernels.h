@@ -123,7 +123,7 @@ enum { LN_MODE_MAP = 0, LN_MODE_FIT = 1, LN_MODE_UPDATE = 2 };
 enum { LN_STATUS_OK = 0, LN_STATUS_BAD_P = 1, LN_STATUS_SLOPE = 2 };
 
 struct LogNormalParams {
-    int N, max_iter, mode, lu_in_lds;
+    int N, max_iter, mode, lu_in_lds, lu_nb;  // lu_nb: panel width of the blocked LU (set by fh_ln_launch)
     int max_step, max_hev;        // MinimizeNewton limits (minimizer.py:190-191: 10**5, 1000)
     double newton_tol;            // 1e-7 (statistical_models.py:1141)
     double alpha, p0, tol, s0;    // CriticalFilter hyper-parameters, loop tolerance, s0 = log(I_scale)
@@ -146,7 +146,7 @@ struct LogNormalParams {
     const double *batch_alpha, *batch_p0;
 };
 
-size_t fh_ln_smem_bytes(int N, int *lu_in_lds);
+size_t fh_ln_smem_bytes(int N, int *lu_in_lds, int *lu_nb);
 hipError_t fh_ln_launch(const LogNormalParams &P, int nblocks, hipStream_t s);
 
 // ---- UVDataBinner (uvbin.hip) -----------------------------------------------------------------------------------

@@ -47,6 +47,8 @@ struct LnS {
     double *wsol;  // LNW * N: per-wave solve vectors
     int *perm, *ipiv;
     double *lu;    // N*N column-major: LDS or global
+    double *pan, *ut;  // global-LU kernels: LDS panel (N * lu_nb) and one 64-column tile of U12 (lu_nb * 64)
+    int lu_nb;
     int redsel;
     int row, c0, c1, slot;  // ln_eval work split: this thread sums columns [c0, c1) of output `row` into part[slot]
     int nch;
@@ -267,6 +269,158 @@ __device__ __forceinline__ void lu_factor(LnS &S, int N, double *A) {
     LTOC(1);
 }
 
+// Blocked right-looking LU with partial pivoting for factors that live in global memory (N > 112).  One CU streams
+// only ~13 B/clk from L2, and the unblocked sweep above rewrites the whole trailing matrix once per COLUMN: 144 MB and
+// 5.8 ms per factorisation at N = 300.  Here a panel of NB columns is factorised in LDS, its row swaps are applied to
+// the other columns, U12 = L11^-1 A12 is formed 64 columns at a time in LDS, and the trailing matrix is rewritten once
+// per PANEL with the panel's row of L in registers.  Pivots and every floating-point operation are those of the
+// unblocked algorithm in the same order (rank-1 updates become NB successive fmas on the same element).
+constexpr int LU_NB_MAX = 32;
+__device__ __forceinline__ void lu_factor_blocked(LnS &S, int N, double *A) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int NB = S.lu_nb;
+    double *pan = S.pan, *ut = S.ut;
+    LTIC();
+    for (int i = tid; i < N; i += LT) S.perm[i] = i;
+    __syncthreads();
+    for (int k0 = 0; k0 < N; k0 += NB) {
+        const int nb = min(NB, N - k0), m = N - k0;
+#ifdef LN_TIMING
+        long long _tp = clock64();
+#endif
+        for (int c = 0; c < nb; ++c)  // panel (rows k0.., columns k0..k0+nb) -> LDS, column-major with ld = m
+            for (int r = tid; r < m; r += LT) pan[c * m + r] = A[(k0 + c) * N + k0 + r];
+        __syncthreads();
+        for (int j = 0; j < nb; ++j) {  // unblocked factorisation of the panel, two barriers per column
+            const double *cj = pan + j * m;
+            double best = -1.0;
+            int bi = 0x7fffffff;
+            for (int r = j + lane; r < m; r += 64) {
+                const double v = fabs(cj[r]);
+                if (v > best) {
+                    best = v;
+                    bi = r;
+                }
+            }
+            const double top = wave_reduce(best, rocprim::maximum<double>());
+            int piv = wave_reduce(best == top ? bi : 0x7fffffff, rocprim::minimum<int>());
+            if (piv >= m) piv = j;
+            const double pv = cj[piv], djj = cj[j];
+            for (int c = tid; c < nb; c += LT) {  // rows j <-> piv in the other panel columns; stage the new row j
+                if (c == j) continue;
+                const double a = pan[c * m + j], b = pan[c * m + piv];
+                if (piv != j) {
+                    pan[c * m + j] = b;
+                    pan[c * m + piv] = a;
+                }
+                if (c > j) S.rowk[c] = b;
+            }
+            for (int r = j + 1 + tid; r < m; r += LT) {
+                const double v = (r == piv) ? djj : cj[r];
+                S.col[r] = (pv != 0.0) ? v / pv : v;
+            }
+            if (tid == LT - 1) {
+                S.ipiv[k0 + j] = k0 + piv;
+                S.rdiag[k0 + j] = 1.0 / pv;
+                if (piv != j) {
+                    const int t = S.perm[k0 + j];
+                    S.perm[k0 + j] = S.perm[k0 + piv];
+                    S.perm[k0 + piv] = t;
+                }
+            }
+            __syncthreads();
+            for (int r = j + tid; r < m; r += LT) pan[j * m + r] = (r == j) ? pv : S.col[r];
+            if (pv != 0.0)
+                for (int c = j + 1 + (tid >> 6); c < nb; c += LNW) {
+                    const double uj = S.rowk[c];
+                    double *cc = pan + c * m;
+                    for (int r = j + 1 + lane; r < m; r += 64) cc[r] = fma(-S.col[r], uj, cc[r]);
+                }
+            __syncthreads();
+        }
+#ifdef LN_TIMING
+        if (tid == 0) { const long long n_ = clock64(); ln_cyc[5] += n_ - _tp; _tp = n_; }
+#endif
+        for (int c = 0; c < nb; ++c)  // panel back to global
+            for (int r = tid; r < m; r += LT) A[(k0 + c) * N + k0 + r] = pan[c * m + r];
+        for (int c = tid; c < N; c += LT) {  // the panel's row swaps in every other column, in pivot order
+            if (c >= k0 && c < k0 + nb) continue;
+            double *col = A + c * N;
+            for (int j = 0; j < nb; ++j) {
+                const int p = S.ipiv[k0 + j];
+                if (p != k0 + j) {
+                    const double t = col[k0 + j];
+                    col[k0 + j] = col[p];
+                    col[p] = t;
+                }
+            }
+        }
+        __syncthreads();
+#ifdef LN_TIMING
+        if (tid == 0) { const long long n_ = clock64(); ln_cyc[6] += n_ - _tp; _tp = n_; }
+#endif
+        const int mr = m - nb;  // rows below the panel's diagonal block
+        for (int c0 = k0 + nb; c0 < N; c0 += 64) {
+            const int tc = min(64, N - c0);
+            if (tid < tc) {  // U12 column c0 + tid: forward substitution with the unit-lower L11 of the panel
+                double x[LU_NB_MAX];
+                double *col = A + (c0 + tid) * N + k0;
+#pragma unroll
+                for (int i = 0; i < LU_NB_MAX; ++i) x[i] = (i < nb) ? col[i] : 0.0;
+#pragma unroll
+                for (int i = 1; i < LU_NB_MAX; ++i) {
+                    if (i < nb) {
+#pragma unroll
+                        for (int j = 0; j < i; ++j) x[i] = fma(-pan[j * m + i], x[j], x[i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < LU_NB_MAX; ++i)
+                    if (i < nb) {
+                        col[i] = x[i];
+                        ut[i * 64 + tid] = x[i];
+                    }
+            }
+            __syncthreads();
+            if (mr > 0) {  // A22[:, tile] -= L21 U12[:, tile]: a thread keeps its row of L21 in registers
+                const int groups = max(1, LT / mr);
+                for (int e = tid; e < mr * groups; e += LT) {
+                    const int g = e / mr, r = nb + (e - g * mr);
+                    double l[LU_NB_MAX];
+#pragma unroll
+                    for (int j = 0; j < LU_NB_MAX; ++j) l[j] = (j < nb) ? pan[j * m + r] : 0.0;
+                    // eight columns at a time: their loads are issued together (the compiler will not move a load
+                    // across the previous column's store), one L2 latency per batch instead of per column
+                    for (int cb = g; cb < tc; cb += 8 * groups) {
+                        double a[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int c = cb + q * groups;
+                            a[q] = (c < tc) ? A[(c0 + c) * N + k0 + r] : 0.0;
+                        }
+#pragma unroll
+                        for (int j = 0; j < LU_NB_MAX; ++j)
+                            if (j < nb) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) a[q] = fma(-l[j], ut[j * 64 + min(cb + q * groups, 63)], a[q]);
+                            }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int c = cb + q * groups;
+                            if (c < tc) A[(c0 + c) * N + k0 + r] = a[q];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+#ifdef LN_TIMING
+        if (tid == 0) { const long long n_ = clock64(); ln_cyc[7] += n_ - _tp; _tp = n_; }
+#endif
+    }
+    LTOC(1);
+}
+
 __device__ __forceinline__ double lane_bcast(double v, int l) {  // l uniform: v_readlane, no LDS round trip
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -460,7 +614,8 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
         if (need_hess) {
             if (nhess == P.max_hev) return {3, nstep, nfev, nhess};
             build_hess(P, S, S.lu, nullptr);
-            lu_factor(S, N, S.lu);
+            if (S.lu_nb > 0) lu_factor_blocked(S, N, S.lu);
+            else lu_factor(S, N, S.lu);
             ++nhess;
             reuse = 0;
             have_inv = false;
@@ -588,6 +743,9 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         S.ipiv = S.perm + N;
         b += N;  // 2N ints
         S.lu = LDS_LU ? b : P.LU;
+        S.lu_nb = LDS_LU ? 0 : P.lu_nb;  // blocked factorisation only for factors in global memory
+        S.pan = b;                       // (global-LU kernels: panel and U12 tile follow the int arrays)
+        S.ut = b + N * (LDS_LU ? 0 : P.lu_nb);
     }
     S.redsel = 0;
     S.nch = min(LT / N, N);
@@ -682,7 +840,8 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
                 for (int a = tid & 31; a < N; a += 32) S.lu[b * N + a] = P.H[a * N + b];
             __syncthreads();
         }
-        lu_factor(S, N, S.lu);
+        if (S.lu_nb > 0) lu_factor_blocked(S, N, S.lu);
+        else lu_factor(S, N, S.lu);
         if (P.mode == LN_MODE_MAP) break;
         if (in_pass) {  // radial_fitters.py:781-785
             if (P.diag_p)
@@ -763,17 +922,27 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
 
 }  // namespace
 
-size_t fh_ln_smem_bytes(int N, int *lu_in_lds) {
+// lu_nb: panel width of the blocked LU (0: factors in LDS, unblocked): the widest of 32, 24, 16, 8 that fits 160 KB
+size_t fh_ln_smem_bytes(int N, int *lu_in_lds, int *lu_nb) {
     size_t doubles = (19 + LNW) * N + 72 + 2 * LT + N;
     const int fits = (N <= 112);
     if (lu_in_lds) *lu_in_lds = fits;
-    if (fits) doubles += N * N;
+    int nb = 0;
+    if (fits) {
+        doubles += N * N;
+    } else {
+        const size_t budget = (160 * 1024 - 1024) / sizeof(double);
+        for (nb = LU_NB_MAX; nb > 8; nb -= 8)
+            if (doubles + (size_t)N * nb + (size_t)nb * 64 <= budget) break;
+        doubles += (size_t)N * nb + (size_t)nb * 64;
+    }
+    if (lu_nb) *lu_nb = nb;
     return doubles * sizeof(double);
 }
 
 hipError_t fh_ln_launch(const LogNormalParams &P0, int nblocks, hipStream_t s) {
     LogNormalParams P = P0;
-    const size_t smem = fh_ln_smem_bytes(P.N, &P.lu_in_lds);
+    const size_t smem = fh_ln_smem_bytes(P.N, &P.lu_in_lds, &P.lu_nb);
     using Kernel = void (*)(LogNormalParams);
     Kernel fn = P.lu_in_lds ? lognormal_kernel<true> : lognormal_kernel<false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
