@@ -26,6 +26,8 @@
 
 #pragma clang fp contract(off)
 
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
 namespace {
 
 #ifdef LN_TIMING
@@ -39,6 +41,13 @@ __shared__ long long ln_cyc[8];
 
 constexpr int LT = 512;        // threads per workgroup
 constexpr int LNW = LT / 64;   // waves
+#ifndef LN_EVB
+#define LN_EVB 8
+#endif
+#ifndef LN_HVB
+#define LN_HVB 16
+#endif
+constexpr int EVB = LN_EVB, HVB = LN_HVB;  // columns per load batch of the two evaluation products / the inverse product
 constexpr int LS_MAX_TRIALS = 2000;  // back-tracking guard: lam shrinks >= 10x per trial, x + lam p == x long before
 
 struct LnS {
@@ -151,8 +160,21 @@ __device__ __forceinline__ double ln_eval(const LogNormalParams &P, LnS &S, cons
         const int o = S.c0 * N + S.row;
         const double *sc = P.Sinv + o, *mc = P.M + o;
         double a = 0.0, b = 0.0;
-#pragma unroll 16
-        for (int c = S.c0; c < S.c1; ++c, sc += N, mc += N) {
+        int c = S.c0;
+        for (; c + EVB <= S.c1; c += EVB, sc += EVB * N, mc += EVB * N) {  // 2 x EVB loads in flight, explicitly (see the Hinv loop)
+            double vs[EVB], vm[EVB];
+#pragma unroll
+            for (int u = 0; u < EVB; ++u) {
+                vs[u] = sc[u * N];
+                vm[u] = mc[u * N];
+            }
+#pragma unroll
+            for (int u = 0; u < EVB; ++u) {
+                a = fma(vs[u], xv[c + u], a);
+                b = fma(vm[u], Iv[c + u], b);
+            }
+        }
+        for (; c < S.c1; ++c, sc += N, mc += N) {
             a = fma(*sc, xv[c], a);
             b = fma(*mc, Iv[c], b);
         }
@@ -362,52 +384,45 @@ __device__ __forceinline__ void lu_factor_blocked(LnS &S, int N, double *A) {
         const int mr = m - nb;  // rows below the panel's diagonal block
         for (int c0 = k0 + nb; c0 < N; c0 += 64) {
             const int tc = min(64, N - c0);
-            if (tid < tc) {  // U12 column c0 + tid: forward substitution with the unit-lower L11 of the panel
-                double x[LU_NB_MAX];
+            if (tid < tc) {  // U12 column c0 + tid: forward substitution with the unit-lower L11 of the panel; the column
+                             // lives in its own slot of the LDS tile (no register array: the kernel is at the VGPR limit)
                 double *col = A + (c0 + tid) * N + k0;
-#pragma unroll
-                for (int i = 0; i < LU_NB_MAX; ++i) x[i] = (i < nb) ? col[i] : 0.0;
-#pragma unroll
-                for (int i = 1; i < LU_NB_MAX; ++i) {
-                    if (i < nb) {
-#pragma unroll
-                        for (int j = 0; j < i; ++j) x[i] = fma(-pan[j * m + i], x[j], x[i]);
-                    }
+                for (int i = 0; i < nb; ++i) ut[i * 64 + tid] = col[i];
+                for (int i = 1; i < nb; ++i) {
+                    double xi = ut[i * 64 + tid];
+                    for (int j = 0; j < i; ++j) xi = fma(-pan[j * m + i], ut[j * 64 + tid], xi);
+                    ut[i * 64 + tid] = xi;
                 }
-#pragma unroll
-                for (int i = 0; i < LU_NB_MAX; ++i)
-                    if (i < nb) {
-                        col[i] = x[i];
-                        ut[i * 64 + tid] = x[i];
-                    }
+                for (int i = 0; i < nb; ++i) col[i] = ut[i * 64 + tid];
             }
             __syncthreads();
-            if (mr > 0) {  // A22[:, tile] -= L21 U12[:, tile]: a thread keeps its row of L21 in registers
-                const int groups = max(1, LT / mr);
-                for (int e = tid; e < mr * groups; e += LT) {
-                    const int g = e / mr, r = nb + (e - g * mr);
-                    double l[LU_NB_MAX];
+            if (mr > 0) {
+                // A22[:, tile] -= L21 U12[:, tile] on the matrix pipe: 16 x 16 output tiles, k = nb in steps of 4; the A
+                // fragments come from the LDS panel, the B fragments from the LDS U12 tile, C/D from / to global memory
+                // (lane = (cl: column, rg: row group), rows rg + 4 q).  One wave per block of 16 rows.
+                const int cl = lane & 15, rg = lane >> 4, wv = tid >> 6;
+                const int nrb = (mr + 15) >> 4, ncb = (tc + 15) >> 4, ks = (nb + 3) >> 2;
+                for (int rb = wv; rb < nrb; rb += LNW) {
+                    const int r0 = nb + 16 * rb;  // panel row of the block's first row
+                    const int rr = min(r0 + cl, m - 1);
+                    const bool rok = r0 + cl < m;
+                    for (int cb = 0; cb < ncb; ++cb) {
+                        const int cc = 16 * cb + cl;  // column within the tile
+                        v4f64 acc;
+                        double *cp = A + (c0 + min(cc, tc - 1)) * N + k0 + r0 + rg;
 #pragma unroll
-                    for (int j = 0; j < LU_NB_MAX; ++j) l[j] = (j < nb) ? pan[j * m + r] : 0.0;
-                    // eight columns at a time: their loads are issued together (the compiler will not move a load
-                    // across the previous column's store), one L2 latency per batch instead of per column
-                    for (int cb = g; cb < tc; cb += 8 * groups) {
-                        double a[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int c = cb + q * groups;
-                            a[q] = (c < tc) ? A[(c0 + c) * N + k0 + r] : 0.0;
+                        for (int q = 0; q < 4; ++q) acc[q] = (r0 + rg + 4 * q < m) ? cp[4 * q] : 0.0;
+                        for (int s4 = 0; s4 < ks; ++s4) {  // (fragments re-read from LDS per tile: the kernel has no registers to spare)
+                            const int kk = min(4 * s4 + rg, nb - 1);
+                            const bool kok = 4 * s4 + rg < nb;
+                            const double af = (kok && rok) ? -pan[kk * m + rr] : 0.0;
+                            const double bf = kok ? ut[kk * 64 + min(cc, 63)] : 0.0;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
                         }
+                        if (cc < tc) {
 #pragma unroll
-                        for (int j = 0; j < LU_NB_MAX; ++j)
-                            if (j < nb) {
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) a[q] = fma(-l[j], ut[j * 64 + min(cb + q * groups, 63)], a[q]);
-                            }
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int c = cb + q * groups;
-                            if (c < tc) A[(c0 + c) * N + k0 + r] = a[q];
+                            for (int q = 0; q < 4; ++q)
+                                if (r0 + rg + 4 * q < m) cp[4 * q] = acc[q];
                         }
                     }
                 }
@@ -638,8 +653,17 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
             if (S.row >= 0) {
                 const double *hc = P.Hinv + (S.c0 * N + S.row);
                 double a = 0.0;
-#pragma unroll 16
-                for (int c = S.c0; c < S.c1; ++c, hc += N) a = fma(*hc, S.jx[c], a);
+                int c = S.c0;
+                // the loads of 16 columns are issued as one batch: what a single CU can pull from L2 is set by the
+                // number of requests in flight, and the compiler does not always keep an unrolled loop's loads together
+                for (; c + HVB <= S.c1; c += HVB, hc += HVB * N) {
+                    double vh[HVB];
+#pragma unroll
+                    for (int u = 0; u < HVB; ++u) vh[u] = hc[u * N];
+#pragma unroll
+                    for (int u = 0; u < HVB; ++u) a = fma(vh[u], S.jx[c + u], a);
+                }
+                for (; c < S.c1; ++c, hc += N) a = fma(*hc, S.jx[c], a);
                 S.part[S.slot] = a;
             }
             __syncthreads();
