@@ -27,6 +27,8 @@
 #pragma clang fp contract(off)
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -54,9 +56,9 @@ struct LnS {
     double *x, *xn, *I, *In, *Sx, *Sxn, *MI, *MIn, *jx, *dx, *pd, *jv, *p, *pold, *rhs, *tr2, *col, *rowk, *rdiag, *red;
     double *part;  // 2 * LT: per-chunk partial products of ln_eval
     double *wsol;  // LNW * N: per-wave solve vectors
-    int *perm, *ipiv;
+    int *perm;
     double *lu;    // N*N column-major: LDS or global
-    double *pan, *ut;  // global-LU kernels: LDS panel (N * lu_nb) and one 64-column tile of U12 (lu_nb * 64)
+    double *pan;   // global-LU kernels: LDS panel of the blocked factorisation (N * LU_NB)
     int lu_nb;
     int redsel;
     int row, c0, c1, slot;  // ln_eval work split: this thread sums columns [c0, c1) of output `row` into part[slot]
@@ -72,6 +74,9 @@ __device__ __forceinline__ T wave_reduce(T v, Op op) {
     WR().reduce(v, out, st, op);
     return out;
 }
+struct FMax {  // operands never NaN
+    __device__ __forceinline__ double operator()(double a, double b) const { return __builtin_fmax(a, b); }
+};
 __device__ __forceinline__ double wave_sum(double v) { return wave_reduce(v, rocprim::plus<double>()); }
 
 // Block reductions: every thread returns the same bits (wave partials combined in wave order by every thread).
@@ -291,89 +296,243 @@ __device__ __forceinline__ void lu_factor(LnS &S, int N, double *A) {
     LTOC(1);
 }
 
-// Blocked right-looking LU with partial pivoting for factors that live in global memory (N > 112).  One CU streams
-// only ~13 B/clk from L2, and the unblocked sweep above rewrites the whole trailing matrix once per COLUMN: 144 MB and
-// 5.8 ms per factorisation at N = 300.  Here a panel of NB columns is factorised in LDS, its row swaps are applied to
-// the other columns, U12 = L11^-1 A12 is formed 64 columns at a time in LDS, and the trailing matrix is rewritten once
-// per PANEL with the panel's row of L in registers.  Pivots and every floating-point operation are those of the
-// unblocked algorithm in the same order (rank-1 updates become NB successive fmas on the same element).
-constexpr int LU_NB_MAX = 32;
+// Blocked right-looking LU with partial pivoting for factors that live in global memory (N > 112), panels of 32
+// columns.  The unblocked sweep above rewrites the whole trailing matrix once per COLUMN (144 MB per factorisation at
+// N = 300); here it is rewritten once per PANEL, on the matrix pipe.
+//   panel   one thread per row keeps its 32 panel entries in REGISTERS for all 32 column steps.  Rows never move: a
+//           thread tracks the position its row would have after LAPACK's swaps (`lpos`); the pivot of a step is the
+//           largest |a_j| among the rows not yet chosen, first position on ties.  One barrier per column: every wave
+//           finds its best row (DPP max + ballot) and publishes that row before the barrier, afterwards every thread
+//           picks the winner among the wave maxima and eliminates with 31 register fmas whose destination is the next
+//           slot (the frame shifts one column per step, so the step loop is rolled with static register indices).
+//           Measured per column step at N = 300: 7 k cycles (the LDS-panel version with two barriers: 6.5 k; a fully
+//           unrolled 32-step version: 7.5 k) -- the step is a chain of ~15 dependent LDS round trips and DPP stages.
+//   swaps   the rows that changed position (<= 64) form a (source, destination) list; a wave moves one outside column
+//           with a single gather / scatter pair, several columns in flight.
+//   U12     = L11^-1 A12 per block of 16 columns on MFMAs: the two 16 x 16 diagonal blocks of L11 are inverted by 32
+//           threads in registers, and U_top = A^-1 T0, U_bot = C^-1 (T1 - B U_top) chains through the accumulator
+//           layout (the C/D layout of a 16 x 16 tile is the B-operand layout of its four k-steps).
+//   trailing  A22 -= L21 U12, 16 x 16 tiles shared evenly among the waves, L21 fragments from the LDS panel, U12 tiles
+//           loaded once per block column, the next tile's load in flight during the 8 MFMAs of this one.
+// Same pivots and the same elimination arithmetic as the unblocked algorithm inside a panel; U12 goes through the
+// explicit block inverses (differences at round-off level).
+constexpr int LU_NB = 32;
 __device__ __forceinline__ void lu_factor_blocked(LnS &S, int N, double *A) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int NB = S.lu_nb;
-    double *pan = S.pan, *ut = S.ut;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cl = lane & 15, rg = lane >> 4;
+    double *pan = S.pan;
+    double *linv = S.part;                               // two 16 x 16 inverse blocks, k-major: [blk][k][i]
+    double *pred = S.part + 512;                         // 2 x LNW wave maxima
+    int *pidx = reinterpret_cast<int *>(S.part + 528);   // 2 x LNW positions of the wave maxima
+    int *mv = reinterpret_cast<int *>(S.part + 540);     // [0]: count, [1..64]: src | dst << 16 of the moved rows
+    // candidate pivot rows, 2 (steps) x LNW (waves) x 32, in the solve vectors' space: 16-byte aligned for ds_read_b128
+    v2f64 *rowv = reinterpret_cast<v2f64 *>(__builtin_assume_aligned(S.wsol, 16));
     LTIC();
     for (int i = tid; i < N; i += LT) S.perm[i] = i;
     __syncthreads();
-    for (int k0 = 0; k0 < N; k0 += NB) {
-        const int nb = min(NB, N - k0), m = N - k0;
+    for (int k0 = 0; k0 < N; k0 += LU_NB) {
+        const int nb = min(LU_NB, N - k0), m = N - k0;
 #ifdef LN_TIMING
         long long _tp = clock64();
 #endif
-        for (int c = 0; c < nb; ++c)  // panel (rows k0.., columns k0..k0+nb) -> LDS, column-major with ld = m
-            for (int r = tid; r < m; r += LT) pan[c * m + r] = A[(k0 + c) * N + k0 + r];
-        __syncthreads();
-        for (int j = 0; j < nb; ++j) {  // unblocked factorisation of the panel, two barriers per column
-            const double *cj = pan + j * m;
-            double best = -1.0;
-            int bi = 0x7fffffff;
-            for (int r = j + lane; r < m; r += 64) {
-                const double v = fabs(cj[r]);
-                if (v > best) {
-                    best = v;
-                    bi = r;
-                }
-            }
-            const double top = wave_reduce(best, rocprim::maximum<double>());
-            int piv = wave_reduce(best == top ? bi : 0x7fffffff, rocprim::minimum<int>());
-            if (piv >= m) piv = j;
-            const double pv = cj[piv], djj = cj[j];
-            for (int c = tid; c < nb; c += LT) {  // rows j <-> piv in the other panel columns; stage the new row j
-                if (c == j) continue;
-                const double a = pan[c * m + j], b = pan[c * m + piv];
-                if (piv != j) {
-                    pan[c * m + j] = b;
-                    pan[c * m + piv] = a;
-                }
-                if (c > j) S.rowk[c] = b;
-            }
-            for (int r = j + 1 + tid; r < m; r += LT) {
-                const double v = (r == piv) ? djj : cj[r];
-                S.col[r] = (pv != 0.0) ? v / pv : v;
-            }
-            if (tid == LT - 1) {
-                S.ipiv[k0 + j] = k0 + piv;
-                S.rdiag[k0 + j] = 1.0 / pv;
-                if (piv != j) {
-                    const int t = S.perm[k0 + j];
-                    S.perm[k0 + j] = S.perm[k0 + piv];
-                    S.perm[k0 + piv] = t;
-                }
-            }
-            __syncthreads();
-            for (int r = j + tid; r < m; r += LT) pan[j * m + r] = (r == j) ? pv : S.col[r];
-            if (pv != 0.0)
-                for (int c = j + 1 + (tid >> 6); c < nb; c += LNW) {
-                    const double uj = S.rowk[c];
-                    double *cc = pan + c * m;
-                    for (int r = j + 1 + lane; r < m; r += 64) cc[r] = fma(-S.col[r], uj, cc[r]);
-                }
-            __syncthreads();
+        // ---- panel ----------------------------------------------------------------------------------------------
+        // a[c] is the row's entry in panel column j + c: the frame shifts by one column per step (the shift is the
+        // destination of the elimination fma), so the step loop stays ROLLED with static register indices -- unrolled
+        // it is ~60 KB of straight-line code and runs at instruction-fetch speed (7.5 k cycles per column, measured).
+        const bool mine = tid < m;
+        double a[LU_NB];
+        {
+            const double *src = A + (size_t)k0 * N + k0 + (mine ? tid : 0);
+#pragma unroll
+            for (int c = 0; c < LU_NB; ++c) a[c] = (c < nb) ? src[(size_t)c * N] : 0.0;
         }
+        int lpos = tid;
+        bool live = mine;  // not yet chosen as a pivot row
+        if (tid == 0) mv[0] = 0;
+        // The step is bound by the CU's LDS instruction rate (measured: 16-byte broadcast reads cost their full 8
+        // cycles each), so waves that hold no rows of this panel only keep the barrier count (the last one also does the
+        // bookkeeping), and only the part of a row that is still inside the panel is published / read.
+        const bool wactive = wv * 64 < m;
+        if (!wactive && lane == 0) {
+            pred[wv] = pred[LNW + wv] = -1.0;
+            pidx[wv] = pidx[LNW + wv] = 0x7fffffff;
+        }
+        // winner among the wave maxima: all partials in flight at once, branch-free selection
+        auto combine = [&](int j, double &top, int &piv, int &pw) {
+            v2f64 tv2[LNW / 2];
+            v4i32 ti4[LNW / 4];
+            const v2f64 *prv = reinterpret_cast<const v2f64 *>(__builtin_assume_aligned(pred + (j & 1) * LNW, 16));
+            const v4i32 *piv4 = reinterpret_cast<const v4i32 *>(__builtin_assume_aligned(pidx + (j & 1) * LNW, 16));
+#pragma unroll
+            for (int w = 0; w < LNW / 2; ++w) tv2[w] = prv[w];
+#pragma unroll
+            for (int w = 0; w < LNW / 4; ++w) ti4[w] = piv4[w];
+            top = -1.0;
+            piv = 0x7fffffff;
+            pw = -1;
+#pragma unroll
+            for (int w = 0; w < LNW; ++w) {
+                const double tv = tv2[w >> 1][w & 1];
+                const int ti = ti4[w >> 2][w & 3];
+                const bool better = tv > top || (tv == top && ti < piv);
+                top = better ? tv : top;
+                piv = better ? ti : piv;
+                pw = better ? w : pw;
+            }
+            if (pw < 0) {  // all-NaN column: keep the diagonal; nothing is eliminated (every candidate entry is NaN)
+                piv = j;
+                pw = 0;
+            }
+        };
+        if (!wactive) {
+            for (int j = 0; j < nb; ++j) {
+                __syncthreads();
+                if (wv == LNW - 1) {  // bookkeeping off the critical path (wave 7 holds no rows for N <= 448)
+                    double top;
+                    int piv, pw;
+                    combine(j, top, piv, pw);
+                    const double pv = reinterpret_cast<const double *>(rowv + (j & 1) * (LNW * LU_NB / 2) + pw * (LU_NB / 2))[0];
+                    if (tid == LT - 1) {
+                        S.rdiag[k0 + j] = 1.0 / pv;
+                        if (piv != j) {
+                            const int t = S.perm[k0 + j];
+                            S.perm[k0 + j] = S.perm[k0 + piv];
+                            S.perm[k0 + piv] = t;
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int j = 0; j < nb; ++j) {
+                // ONE barrier per column: every wave's best row is published before the barrier (candidate rows double
+                // buffered), afterwards every thread picks the winner among the wave maxima and eliminates with its row.
+                const int rem = nb - j;  // columns of the frame still inside the panel
+                double v = fabs(a[0]);
+                const bool ok = live && v == v;  // a NaN never wins
+                if (!ok) v = -1.0;
+                const double wtop = wave_reduce(v, FMax());
+                // position of the maximum: one lane in all but exceptional cases (ties go to the first position)
+                const unsigned long long tie = __ballot(ok && v == wtop);
+                int wpos = 0x7fffffff;
+                if (tie != 0) {
+                    if ((tie & (tie - 1)) == 0) wpos = __builtin_amdgcn_readlane(lpos, __ffsll((long long)tie) - 1);
+                    else wpos = wave_reduce((ok && v == wtop) ? lpos : 0x7fffffff, rocprim::minimum<int>());
+                }
+                v2f64 *rows = rowv + (j & 1) * (LNW * LU_NB / 2);
+                if (ok && lpos == wpos) {  // this wave's candidate (at most one lane)
+                    pred[(j & 1) * LNW + wv] = wtop;
+                    pidx[(j & 1) * LNW + wv] = wpos;
+                    v2f64 *rw = rows + wv * (LU_NB / 2);
+#pragma unroll
+                    for (int c = 0; c < LU_NB; c += 2)
+                        if (c < rem) rw[c >> 1] = v2f64{a[c], a[c + 1]};
+                } else if (lane == 0 && tie == 0) {
+                    pred[(j & 1) * LNW + wv] = -1.0;
+                    pidx[(j & 1) * LNW + wv] = wpos;
+                }
+                __syncthreads();
+                double top;
+                int piv, pw;
+                combine(j, top, piv, pw);
+                const bool nopiv = top < 0.0;
+                const v2f64 *rw = rows + pw * (LU_NB / 2);
+                v2f64 r2 = rw[0];
+                const double pv = nopiv ? a[0] : r2[0];
+                if (mine) {
+                    if (lpos == piv) {
+                        lpos = j;
+                        live = false;
+                    } else if (lpos == j) {
+                        lpos = piv;
+                    }
+                }
+                if (tid == LT - 1) {  // (only when the last wave holds rows)
+                    S.rdiag[k0 + j] = 1.0 / pv;
+                    if (piv != j) {
+                        const int t = S.perm[k0 + j];
+                        S.perm[k0 + j] = S.perm[k0 + piv];
+                        S.perm[k0 + piv] = t;
+                    }
+                }
+                // the entry of column j: the multiplier for a live row, the U entry for a row chosen now or earlier (its
+                // frame keeps shifting with l = 0)
+                double l = 0.0;
+                if (live && !nopiv) {
+                    l = (pv != 0.0) ? a[0] / pv : a[0];
+                    pan[j * m + tid] = l;
+                    if (pv == 0.0) l = 0.0;  // zero pivot: column left unscaled, no elimination (getf2 does the same)
+                } else if (mine) {
+                    pan[j * m + tid] = a[0];
+                }
+                a[0] = fma(-l, r2[1], a[1]);
+#pragma unroll
+                for (int c = 2; c < LU_NB; c += 2) {  // (unconditional: the 15 reads stay in flight together; slots at
+                                                      // and beyond rem hold stale values that never move back inside)
+                    r2 = rw[c >> 1];
+                    a[c - 1] = fma(-l, r2[0], a[c]);
+                    a[c] = fma(-l, r2[1], a[c + 1 < LU_NB ? c + 1 : c]);
+                }
+            }
+        }
+        // (every row now sits in the LDS panel at its ORIGINAL position: pivot rows wrote themselves, the others their
+        // multipliers step by step)  moved rows to their final positions, then the panel back to the factor
+        const bool moved = mine && lpos != tid;
+        if (moved) mv[1 + atomicAdd(&mv[0], 1)] = tid | (lpos << 16);
+        __syncthreads();
+        if (moved) {
+#pragma unroll
+            for (int c = 0; c < LU_NB; ++c) a[c] = pan[min(c, nb - 1) * m + tid];
+        }
+        __syncthreads();
+        if (moved) {
+#pragma unroll
+            for (int c = 0; c < LU_NB; ++c)
+                if (c < nb) pan[c * m + lpos] = a[c];
+        }
+        __syncthreads();
+        if (mine) {
+            double *dst = A + (size_t)k0 * N + k0 + tid;
+#pragma unroll 8
+            for (int c = 0; c < nb; ++c) dst[(size_t)c * N] = pan[c * m + tid];
+        }
+        __syncthreads();
 #ifdef LN_TIMING
         if (tid == 0) { const long long n_ = clock64(); ln_cyc[5] += n_ - _tp; _tp = n_; }
 #endif
-        for (int c = 0; c < nb; ++c)  // panel back to global
-            for (int r = tid; r < m; r += LT) A[(k0 + c) * N + k0 + r] = pan[c * m + r];
-        for (int c = tid; c < N; c += LT) {  // the panel's row swaps in every other column, in pivot order
-            if (c >= k0 && c < k0 + nb) continue;
-            double *col = A + c * N;
-            for (int j = 0; j < nb; ++j) {
-                const int p = S.ipiv[k0 + j];
-                if (p != k0 + j) {
-                    const double t = col[k0 + j];
-                    col[k0 + j] = col[p];
-                    col[p] = t;
+        // ---- row moves in the columns outside the panel; wave 0 first inverts the diagonal blocks of L11 ----------
+        const bool trailing = k0 + LU_NB < N;
+        if (trailing && tid < 32) {
+            const int blk = tid >> 4, jj = tid & 15;
+            const double *L = pan + (16 * blk) * m + 16 * blk;  // L[i][k] = L[k * m + i]
+            double x[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = (i == jj) ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 1; i < 16; ++i)
+#pragma unroll
+                for (int k = 0; k < i; ++k) x[i] = fma(-L[k * m + i], x[k], x[i]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) linv[blk * 256 + jj * 16 + i] = x[i];
+        }
+        {
+            const int cnt = mv[0];
+            if (cnt > 0) {
+                const int pr = lane < cnt ? mv[1 + lane] : 0;
+                const int so = pr & 0xffff, dd = pr >> 16;
+                const bool on = lane < cnt;
+                const int nout = N - nb;  // outside columns, in order: 0 .. k0-1, k0+nb .. N-1
+                for (int ci = wv; ci < nout; ci += 4 * LNW) {
+                    double vv[4];
+                    double *cp[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c1 = min(ci + u * LNW, nout - 1);
+                        cp[u] = A + (size_t)(c1 < k0 ? c1 : c1 + nb) * N + k0;
+                        vv[u] = on ? cp[u][so] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (on && ci + u * LNW < nout) cp[u][dd] = vv[u];
                 }
             }
         }
@@ -381,50 +540,85 @@ __device__ __forceinline__ void lu_factor_blocked(LnS &S, int N, double *A) {
 #ifdef LN_TIMING
         if (tid == 0) { const long long n_ = clock64(); ln_cyc[6] += n_ - _tp; _tp = n_; }
 #endif
-        const int mr = m - nb;  // rows below the panel's diagonal block
-        for (int c0 = k0 + nb; c0 < N; c0 += 64) {
-            const int tc = min(64, N - c0);
-            if (tid < tc) {  // U12 column c0 + tid: forward substitution with the unit-lower L11 of the panel; the column
-                             // lives in its own slot of the LDS tile (no register array: the kernel is at the VGPR limit)
-                double *col = A + (c0 + tid) * N + k0;
-                for (int i = 0; i < nb; ++i) ut[i * 64 + tid] = col[i];
-                for (int i = 1; i < nb; ++i) {
-                    double xi = ut[i * 64 + tid];
-                    for (int j = 0; j < i; ++j) xi = fma(-pan[j * m + i], ut[j * 64 + tid], xi);
-                    ut[i * 64 + tid] = xi;
+        if (trailing) {
+            const int c0 = k0 + LU_NB, mr = m - LU_NB;     // first trailing column; trailing rows (= trailing columns)
+            const int nblk = (mr + 15) >> 4;                // block rows = block columns
+            // U12: one wave per block of 16 columns
+            for (int cb = wv; cb < nblk; cb += LNW) {
+                const int cc = c0 + 16 * cb + cl;
+                const bool cok = cc < N;
+                double *cp = A + (size_t)min(cc, N - 1) * N + k0 + rg;
+                v4f64 t0, t1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    t0[q] = cp[4 * q];
+                    t1[q] = cp[16 + 4 * q];
                 }
-                for (int i = 0; i < nb; ++i) col[i] = ut[i * 64 + tid];
+                v4f64 u0 = {0.0, 0.0, 0.0, 0.0}, u1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+                    u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(linv[(4 * s4 + rg) * 16 + cl], t0[s4], u0, 0, 0, 0);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+                    t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pan[(4 * s4 + rg) * m + 16 + cl], u0[s4], t1, 0, 0, 0);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+                    u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(linv[256 + (4 * s4 + rg) * 16 + cl], t1[s4], u1, 0, 0, 0);
+                if (cok) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        cp[4 * q] = u0[q];
+                        cp[16 + 4 * q] = u1[q];
+                    }
+                }
             }
             __syncthreads();
-            if (mr > 0) {
-                // A22[:, tile] -= L21 U12[:, tile] on the matrix pipe: 16 x 16 output tiles, k = nb in steps of 4; the A
-                // fragments come from the LDS panel, the B fragments from the LDS U12 tile, C/D from / to global memory
-                // (lane = (cl: column, rg: row group), rows rg + 4 q).  One wave per block of 16 rows.
-                const int cl = lane & 15, rg = lane >> 4, wv = tid >> 6;
-                const int nrb = (mr + 15) >> 4, ncb = (tc + 15) >> 4, ks = (nb + 3) >> 2;
-                for (int rb = wv; rb < nrb; rb += LNW) {
-                    const int r0 = nb + 16 * rb;  // panel row of the block's first row
-                    const int rr = min(r0 + cl, m - 1);
-                    const bool rok = r0 + cl < m;
-                    for (int cb = 0; cb < ncb; ++cb) {
-                        const int cc = 16 * cb + cl;  // column within the tile
-                        v4f64 acc;
-                        double *cp = A + (c0 + min(cc, tc - 1)) * N + k0 + r0 + rg;
+            // trailing update: tiles in block-column-major order, an equal share per wave
+            const int T = nblk * nblk, per = (T + LNW - 1) / LNW;
+            const int tb = wv * per, te = min(T, tb + per);
+            auto tile_ptr = [&](int t) {
+                const int cb = t / nblk, rb = t - cb * nblk;
+                return A + (size_t)min(c0 + 16 * cb + cl, N - 1) * N + k0 + LU_NB + 16 * rb + rg;
+            };
+            auto tile_load = [&](int t) {
+                const int cb = t / nblk, rb = t - cb * nblk;
+                const double *tp = tile_ptr(t);
+                v4f64 r;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[q] = (r0 + rg + 4 * q < m) ? cp[4 * q] : 0.0;
-                        for (int s4 = 0; s4 < ks; ++s4) {  // (fragments re-read from LDS per tile: the kernel has no registers to spare)
-                            const int kk = min(4 * s4 + rg, nb - 1);
-                            const bool kok = 4 * s4 + rg < nb;
-                            const double af = (kok && rok) ? -pan[kk * m + rr] : 0.0;
-                            const double bf = kok ? ut[kk * 64 + min(cc, 63)] : 0.0;
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
-                        }
-                        if (cc < tc) {
+                for (int q = 0; q < 4; ++q) r[q] = (16 * rb + rg + 4 * q < mr) ? tp[4 * q] : 0.0;
+                return r;
+            };
+            if (tb < te) {
+                int curb = -1;
+                v4f64 u0 = {0.0, 0.0, 0.0, 0.0}, u1 = {0.0, 0.0, 0.0, 0.0};
+                v4f64 acc = tile_load(tb);
+                for (int t = tb; t < te; ++t) {
+                    const int cb = t / nblk, rb = t - cb * nblk;
+                    if (cb != curb) {
+                        const double *up = A + (size_t)min(c0 + 16 * cb + cl, N - 1) * N + k0 + rg;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (r0 + rg + 4 * q < m) cp[4 * q] = acc[q];
+                        for (int q = 0; q < 4; ++q) {
+                            u0[q] = up[4 * q];
+                            u1[q] = up[16 + 4 * q];
                         }
+                        curb = cb;
                     }
+                    v4f64 nxt = acc;
+                    if (t + 1 < te) nxt = tile_load(t + 1);
+                    const double *lp = pan + rg * m + min(LU_NB + 16 * rb + cl, m - 1);  // -L21[row cl][k = 4 s + rg]
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lp[(4 * s4) * m], u0[s4], acc, 0, 0, 0);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lp[(16 + 4 * s4) * m], u1[s4], acc, 0, 0, 0);
+                    if (c0 + 16 * cb + cl < N) {
+                        double *tp = tile_ptr(t);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (16 * rb + rg + 4 * q < mr) tp[4 * q] = acc[q];
+                    }
+                    acc = nxt;
                 }
             }
             __syncthreads();
@@ -751,25 +945,23 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
     LnS S;
     {
         double *b = smem;
+        S.red = b;  // 2 x 32 reduction partials + the pivot value
+        b += 72;
+        S.part = b;  // (fixed-size arrays first: part and wsol start on 16-byte boundaries for every N)
+        b += 2 * LT;
+        S.wsol = b;  // one solve vector per wave
+        b += LNW * N;
         double **vecs[] = {&S.x,  &S.xn, &S.I, &S.In,   &S.Sx,  &S.Sxn, &S.MI,  &S.MIn,  &S.jx,   &S.dx,
                            &S.pd, &S.jv, &S.p, &S.pold, &S.rhs, &S.tr2, &S.col, &S.rowk, &S.rdiag};
         for (auto v : vecs) {
             *v = b;
             b += N;
         }
-        S.red = b;  // 2 x 32 reduction partials + the pivot value
-        b += 72;
-        S.part = b;
-        b += 2 * LT;
-        S.wsol = b;  // one solve vector per wave
-        b += LNW * N;
         S.perm = reinterpret_cast<int *>(b);
-        S.ipiv = S.perm + N;
         b += N;  // 2N ints
         S.lu = LDS_LU ? b : P.LU;
         S.lu_nb = LDS_LU ? 0 : P.lu_nb;  // blocked factorisation only for factors in global memory
-        S.pan = b;                       // (global-LU kernels: panel and U12 tile follow the int arrays)
-        S.ut = b + N * (LDS_LU ? 0 : P.lu_nb);
+        S.pan = b;                       // (global-LU kernels: the panel follows the int arrays)
     }
     S.redsel = 0;
     S.nch = min(LT / N, N);
@@ -946,7 +1138,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
 
 }  // namespace
 
-// lu_nb: panel width of the blocked LU (0: factors in LDS, unblocked): the widest of 32, 24, 16, 8 that fits 160 KB
+// lu_nb: panel width of the blocked LU (0: factors in LDS, unblocked); N = 320 with a 32-column panel takes 159 KB
 size_t fh_ln_smem_bytes(int N, int *lu_in_lds, int *lu_nb) {
     size_t doubles = (19 + LNW) * N + 72 + 2 * LT + N;
     const int fits = (N <= 112);
@@ -955,10 +1147,8 @@ size_t fh_ln_smem_bytes(int N, int *lu_in_lds, int *lu_nb) {
     if (fits) {
         doubles += N * N;
     } else {
-        const size_t budget = (160 * 1024 - 1024) / sizeof(double);
-        for (nb = LU_NB_MAX; nb > 8; nb -= 8)
-            if (doubles + (size_t)N * nb + (size_t)nb * 64 <= budget) break;
-        doubles += (size_t)N * nb + (size_t)nb * 64;
+        nb = LU_NB;
+        doubles += (size_t)N * nb;
     }
     if (lu_nb) *lu_nb = nb;
     return doubles * sizeof(double);
