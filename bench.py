@@ -280,7 +280,7 @@ def main():
         }
         if sharded:
             out["sharded_fit"] = sharded
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:  # the CPU leg is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(a.ncoll, a.nvis, nit)
         print(json.dumps(out))
     if dist is not None:

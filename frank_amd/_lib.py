@@ -25,6 +25,7 @@ FH_ERR_NUMERIC = -8
 VIS_MODELS = {"opt_thick": 0, "opt_thin": 1, "debris": 2}
 
 _dp = ctypes.POINTER(ctypes.c_double)
+_fp = ctypes.POINTER(ctypes.c_float)
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
 
@@ -50,6 +51,7 @@ SIGNATURES = {
     "fh_dht_coefficients": (ctypes.c_int, [_vp, _dp, _i64, ctypes.c_int, ctypes.c_double, _dp]),
     "fh_predict_visibilities": (ctypes.c_int, [_vp, _dp, _i64, _dp, ctypes.c_double, _dp]),
     "fh_vis_upload": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _i64, _i64, ctypes.POINTER(_vp)]),
+    "fh_vis_upload_f32": (ctypes.c_int, [ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _i64, _i64, ctypes.POINTER(_vp)]),
     "fh_vis_destroy": (None, [_vp]),
     "fh_vis_size": (_i64, [_vp]),
     "fh_vis_set_multiplicity": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
@@ -131,6 +133,21 @@ def f8(a):
 
 def ptr(a):
     return None if a is None else a.ctypes.data_as(_dp)
+
+
+def f4(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def fptr(a):
+    return None if a is None else a.ctypes.data_as(_fp)
+
+
+def all_float32(u, v, V, weights):
+    """True when the whole table is single precision: float32 u, v, weights and complex64 / float32 V."""
+    dts = [np.asarray(x).dtype for x in (u, v, weights)]
+    vd = np.asarray(V).dtype
+    return all(d == np.float32 for d in dts) and vd in (np.dtype(np.complex64), np.dtype(np.float32))
 
 
 def device_count():

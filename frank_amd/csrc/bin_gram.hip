@@ -102,10 +102,20 @@ __global__ __launch_bounds__(256) void deproject_kernel(BinParams p) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + tid; i < p.count; i += (int64_t)gridDim.x * blockDim.x) {
 #pragma clang fp contract(off)
         const int64_t g = p.first + i;
-        const double u = p.u[g], v = p.v[g];
-        const double Vre = p.Vre[g];
-        const double Vim = p.Vim ? p.Vim[g] : 0.0;
-        const double w = p.w[p.w_scalar ? 0 : g];
+        double u, v, Vre, Vim, w;
+        if (p.u32) {  // fp32 table: widened here, everything after it is the fp64 path
+            u = (double)p.u32[g];
+            v = (double)p.v32[g];
+            Vre = (double)p.Vre32[g];
+            Vim = p.Vim32 ? (double)p.Vim32[g] : 0.0;
+            w = (double)p.w32[p.w_scalar ? 0 : g];
+        } else {
+            u = p.u[g];
+            v = p.v[g];
+            Vre = p.Vre[g];
+            Vim = p.Vim ? p.Vim[g] : 0.0;
+            w = p.w[p.w_scalar ? 0 : g];
+        }
         // multiplicity of the row in a bootstrap resample (utilities.py:632-666): c copies of a row contribute
         // c w h h^T, c w V h, c (log(w/2pi) - w V^2); rows drawn zero times drop out of min/max q as well
         const double mult = p.mult ? (double)p.mult[g] : 1.0;

@@ -80,6 +80,8 @@ struct fh_vis {
     int64_t n = 0;
     int w_scalar = 0, has_im = 0;
     DevBuf<double> u, v, Vre, Vim, w;
+    DevBuf<float> u32, v32, Vre32, Vim32, w32;  // fh_vis_upload_f32: the same columns in fp32
+    bool f32 = false;
     DevBuf<int> mult;  // bootstrap multiplicities (fh_vis_set_multiplicity), empty = every row once
     bool use_mult = false;
 };
@@ -450,6 +452,45 @@ int fh_vis_upload(int device, const double *u, const double *v, const double *Vr
     *out = t;
     return FH_OK;
 }
+int fh_vis_upload_f32(int device, const float *u, const float *v, const float *Vre, const float *Vim, const float *w,
+                      int64_t n_w, int64_t n, fh_vis **out) {
+    if (!out || n < 0 || (n > 0 && (!u || !v || !Vre || !w))) return fail(FH_ERR_INVALID, "fh_vis_upload_f32: bad argument");
+    if (n_w != 1 && n_w != n) return fail(FH_ERR_INVALID, "fh_vis_upload_f32: weights must have 1 or n entries");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(FH_ERR_HIP, "no HIP device available: frank_amd has no CPU fallback for device work");
+    HIP_TRY(hipSetDevice(device));
+    fh_vis *t = new fh_vis();
+    t->device = device;
+    t->n = n;
+    t->f32 = true;
+    t->w_scalar = (n_w == 1 && n != 1) ? 1 : 0;
+    t->has_im = Vim ? 1 : 0;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    hipError_t e = t->u32.alloc(nn);
+    if (e == hipSuccess) e = t->v32.alloc(nn);
+    if (e == hipSuccess) e = t->Vre32.alloc(nn);
+    if (e == hipSuccess && Vim) e = t->Vim32.alloc(nn);
+    if (e == hipSuccess) e = t->w32.alloc(t->w_scalar ? 1 : nn);
+    if (e != hipSuccess) {
+        delete t;
+        return fail(FH_ERR_NOMEM, "fh_vis_upload_f32: hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    if (n > 0) {
+        const size_t b = sizeof(float) * (size_t)n;
+        e = hipMemcpy(t->u32.p, u, b, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(t->v32.p, v, b, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(t->Vre32.p, Vre, b, hipMemcpyHostToDevice);
+        if (e == hipSuccess && Vim) e = hipMemcpy(t->Vim32.p, Vim, b, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(t->w32.p, w, t->w_scalar ? sizeof(float) : b, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            delete t;
+            return fail(FH_ERR_HIP, "fh_vis_upload_f32: copy failed: %s", hipGetErrorString(e));
+        }
+    }
+    *out = t;
+    return FH_OK;
+}
 void fh_vis_destroy(fh_vis *vis) {
     if (!vis) return;
     (void)hipSetDevice(vis->device);
@@ -526,6 +567,13 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     p.Vre = vis->Vre.p;
     p.Vim = vis->has_im ? vis->Vim.p : nullptr;
     p.w = vis->w.p;
+    if (vis->f32) {
+        p.u32 = vis->u32.p;
+        p.v32 = vis->v32.p;
+        p.Vre32 = vis->Vre32.p;
+        p.Vim32 = vis->has_im ? vis->Vim32.p : nullptr;
+        p.w32 = vis->w32.p;
+    }
     p.w_scalar = vis->w_scalar;
     p.mult = vis->use_mult ? vis->mult.p : nullptr;
     p.first = first;

@@ -6,6 +6,9 @@
 struct BinParams {
     // visibility columns (device), rows [first, first+count)
     const double *u, *v, *Vre, *Vim, *w;
+    // the same columns stored as fp32 (fh_vis_upload_f32: 20 B / visibility, widened to fp64 as they are read);
+    // non-NULL u32 selects them
+    const float *u32, *v32, *Vre32, *Vim32, *w32;
     const int *mult;  // optional per-row multiplicity (bootstrap resampling), NULL = 1
     int w_scalar;
     int64_t first, count;

@@ -61,26 +61,45 @@ class VisibilityMapping:
             geometry = self._geometry
         if self._verbose:
             logging.info('    Building visibility matrices M and j')
-        u, v = _lib.f8(u), _lib.f8(v)
         V = np.asarray(V)
-        Vre = _lib.f8(V.real)
-        Vim = _lib.f8(V.imag) if np.iscomplexobj(V) else None
-        w = _lib.f8(np.atleast_1d(weights))
-        n = u.size
-        if v.size != n or Vre.size != n or w.size not in (1, n):
-            raise ValueError("u, v, V (and weights) must have matching lengths")
+        f32 = _lib.all_float32(u, v, V, weights)
         N = self.size
         M, j = np.empty((N, N)), np.empty(N)
         H0, qmin, qmax = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         g = _lib.make_geometry(self._geometry)
+        ctx = self._DHT.context()
         # geometrically thick model: the kernel needs H2[k] to scale every row by exp(-kz^2 H2[k]) (:494-496)
         _lib.check(_lib.lib.fh_ctx_set_scale_height(
-            self._DHT.context(), _lib.ptr(_lib.f8(self._H2)) if self._vis_model == 'debris' else None))
-        rc = _lib.lib.fh_map_visibilities(
-            self._DHT.context(), ctypes.byref(g), _lib.VIS_MODELS[self._vis_model], 0, _lib.ptr(u), _lib.ptr(v),
-            _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), w.size, n, _lib.ptr(M), _lib.ptr(j), ctypes.byref(H0),
-            ctypes.byref(qmin), ctypes.byref(qmax))
-        _lib.check(rc)
+            ctx, _lib.ptr(_lib.f8(self._H2)) if self._vis_model == 'debris' else None))
+        model = _lib.VIS_MODELS[self._vis_model]
+        conv = _lib.f4 if f32 else _lib.f8
+        u, v = conv(u), conv(v)
+        Vre = conv(V.real)
+        Vim = conv(V.imag) if np.iscomplexobj(V) else None
+        w = conv(np.atleast_1d(weights))
+        n = u.size
+        if v.size != n or Vre.size != n or w.size not in (1, n):
+            raise ValueError("u, v, V (and weights) must have matching lengths")
+        if f32:
+            # a table handed over in single precision (float32 u, v, weights, complex64 / float32 V) is stored and
+            # streamed as fp32, 20 B per visibility, and widened in the pre-pass: the arithmetic is the fp64 path, as the
+            # reference's is whatever dtype it gets (NumPy promotes in geometry.py:69-79)
+            vis = ctypes.c_void_p()
+            _lib.check(_lib.lib.fh_vis_upload_f32(0, _lib.fptr(u), _lib.fptr(v), _lib.fptr(Vre), _lib.fptr(Vim),
+                                                  _lib.fptr(w), w.size, n, ctypes.byref(vis)))
+            try:
+                _lib.check(_lib.lib.fh_bin_reset(ctx))
+                _lib.check(_lib.lib.fh_bin_visibilities(ctx, ctypes.byref(g), vis, 0, n))
+                _lib.check(_lib.lib.fh_stats_finalize(ctx, ctypes.byref(g), model, 0, _lib.ptr(M), _lib.ptr(j),
+                                                      ctypes.byref(H0), ctypes.byref(qmin), ctypes.byref(qmax)))
+            finally:
+                _lib.lib.fh_vis_destroy(vis)
+        else:
+            rc = _lib.lib.fh_map_visibilities(
+                ctx, ctypes.byref(g), model, 0, _lib.ptr(u), _lib.ptr(v),
+                _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), w.size, n, _lib.ptr(M), _lib.ptr(j), ctypes.byref(H0),
+                ctypes.byref(qmin), ctypes.byref(qmax))
+            _lib.check(rc)
         self._check_uv_range(qmin.value, qmax.value)
         return {
             'mult_freq': False,

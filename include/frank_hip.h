@@ -86,6 +86,12 @@ int fh_predict_visibilities(fh_ctx *ctx, const double *q, int64_t n, const doubl
  * n_w == 1 broadcasts a scalar weight (statistical_models.py:173).                                         */
 int fh_vis_upload(int device, const double *u, const double *v, const double *Vre, const double *Vim,
                   const double *w, int64_t n_w, int64_t n, fh_vis **out);
+/* The same table stored as five fp32 columns (20 B / visibility; BASELINE configs with fp32 data).  The columns are
+ * widened to fp64 as the pre-pass reads them and everything downstream is the fp64 path: the result equals that of
+ * fh_vis_upload on the widened values bit for bit (the reference also computes in fp64 whatever dtype it is handed:
+ * NumPy promotes in geometry.py:69-79, 111-131).                                                              */
+int fh_vis_upload_f32(int device, const float *u, const float *v, const float *Vre, const float *Vim,
+                      const float *w, int64_t n_w, int64_t n, fh_vis **out);
 void fh_vis_destroy(fh_vis *vis);
 int64_t fh_vis_size(const fh_vis *vis);
 /* Bootstrap resampling without moving data: counts[i] (n int32, host) = how many times row i was drawn by

@@ -794,3 +794,34 @@ def test_fewer_visibilities_than_basis_functions(n, N):
     assert ref["rc"] == 0 and ref["n_svd"] == 0
     assert FF.iteration_diagnostics["num_iterations"] == ref["niter"]
     assert rel_to_max(sol.I, ref["mu"]) < 1e-6
+
+
+def test_fp32_visibility_table():
+    """A table handed over in single precision is stored as fp32 (fh_vis_upload_f32, 20 B / visibility) and widened in
+    the pre-pass: (i) identical, bit for bit, to the fp64 table holding the widened values -- which is what the
+    reference computes for float32 input, NumPy promoting to double; (ii) against the oracle on the widened values the
+    fp64 bar; (iii) against the fit of the original double-precision data the 1e-3 bar BASELINE.json states for fp32."""
+    from frank_amd import FrankFitter, VisibilityMapping, DiscreteHankelTransform
+    from oracle import oracle as fo
+    N, n = 100, 100000
+    u, v, V, w = mock_disc_visibilities(n, seed=11, noise_seed=12)
+    w = np.full(n, w) if np.ndim(w) == 0 else w
+    u4, v4, V4, w4 = u.astype(np.float32), v.astype(np.float32), V.astype(np.complex64), w.astype(np.float32)
+    vm = VisibilityMapping(DiscreteHankelTransform(RMAX, N), geom())
+    m4 = vm.map_visibilities(u4, v4, V4, w4)
+    m8 = vm.map_visibilities(u4.astype(np.float64), v4.astype(np.float64), V4.astype(np.complex128), w4.astype(np.float64))
+    assert np.array_equal(m4["M"], m8["M"]) and np.array_equal(m4["j"], m8["j"])
+    assert m4["null_likelihood"] == m8["null_likelihood"]
+    mo = fo.map_visibilities(N, RMAX, GEOM, u4.astype(np.float64), v4.astype(np.float64), V4.astype(np.complex128),
+                             w4.astype(np.float64))
+    assert rel_to_max(m4["M"], mo["M"]) < 1e-11 and rel_to_max(m4["j"], mo["j"]) < 1e-11
+    FF = FrankFitter(2.0, N, geom(), verbose=False, store_iteration_diagnostics=True)
+    sol4 = FF.fit(u4, v4, V4, w4)
+    ref = fo.frank_fit_normal(N, RMAX, mo["M"], mo["j"])
+    assert FF.iteration_diagnostics["num_iterations"] == ref["niter"]
+    assert rel_to_max(sol4.I, ref["mu"]) < 1e-6
+    sol8 = FF.fit(u, v, V, w)
+    assert rel_to_max(sol4.I, sol8.I) < 1e-3
+    # a scalar float32 weight broadcasts like the fp64 one (statistical_models.py:173)
+    m4s = vm.map_visibilities(u4, v4, V4, np.float32(w4[0]))
+    assert rel_to_max(m4s["M"], m4["M"]) < 1e-13
