@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
+#include <cstdlib>
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
@@ -731,8 +732,36 @@ hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStrea
     return hipGetLastError();
 }
 
+// Development experiment (FRANK_AMD_K2_DUMMY=<milliseconds>): a workgroup that occupies a CU exactly like the fit loop
+// (threads, LDS) but only spins -- separates what co-running fit loops cost bin_gram through the CU they hold from what
+// they cost through the memory system.  Results are garbage.
+__global__ __launch_bounds__(KT) void fit_loop_dummy_kernel(long long cycles, int *result) {
+    extern __shared__ double dsm[];
+    const long long t0 = clock64();
+    double acc = 0.0;
+    while (clock64() - t0 < cycles) {
+        acc += dsm[threadIdx.x];
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (threadIdx.x == 0) {
+        result[0] = 1 + (acc == 12345.678);
+        result[1] = 0;
+    }
+}
+
 hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s) {
     const size_t smem = fh_k2_loop_smem_bytes(P.NP);
+    if (const char *e = getenv("FRANK_AMD_K2_DUMMY")) {
+        static bool attr = false;
+        if (!attr) {
+            hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_dummy_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (er != hipSuccess) return er;
+            attr = true;
+        }
+        hipLaunchKernelGGL(fit_loop_dummy_kernel, dim3(1), dim3(KT), smem, s, (long long)(atof(e) * 2.4e6), P.result);
+        return hipGetLastError();
+    }
     static size_t attr_for = 0;
     if (smem > attr_for) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_kernel),
