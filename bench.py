@@ -134,6 +134,7 @@ class Fitter:
             pending.append(self.submit())
             if kernel_ms is not None:
                 kernel_ms.append(self.kernel_ms())
+        L.check(L.lib.fh_fit_flush(self.ctx))  # the last, partly filled launch
         for t in pending:
             nit = self.collect(t)
         return nit

@@ -71,6 +71,7 @@ SIGNATURES = {
     "fh_fit_normal_batched": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, _dp, _dp, _dp, ctypes.c_double, ctypes.c_int,
                                              _dp, _dp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "fh_fit_slots": (ctypes.c_int, []),
+    "fh_fit_flush": (ctypes.c_int, [_vp]),
     "fh_fit_submit": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                      ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "fh_fit_collect": (ctypes.c_int, [_vp, ctypes.c_int, _dp, _dp, ctypes.POINTER(ctypes.c_int)]),

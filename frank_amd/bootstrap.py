@@ -94,6 +94,7 @@ def bootstrap_fits(fitter, u, v, vis, weights, ntrials, nonnegative=False):
             ticket = ctypes.c_int(-1)
             _lib.check(L.fh_fit_submit(ctx, alpha, p_0, wsmooth, tol, int(fitter._max_iter), ctypes.byref(ticket)))
             pending.append((t, ticket.value, Mj))
+        _lib.check(L.fh_fit_flush(ctx))  # launch the last, partly filled batch before waiting for the earlier ones
         while pending:
             collect(pending.pop(0))
     finally:

@@ -87,18 +87,34 @@ struct fh_vis {
 };
 
 struct FitSlot {
-    hipStream_t stream = nullptr;
-    hipEvent_t ready = nullptr;
     DevBuf<double> Aq, bq, Cq, Wq, Tq, WdT, cs, mu_out, p_out, band_lu;
     DevBuf<int> result;
     std::vector<double> lu_host;  // stays alive while the asynchronous copy of the band LU may still read it
     bool busy = false;
+    int batch = -1;               // the launch this fit belongs to
 };
-// One HIP stream per slot.  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; raised to 24 below)
-// and two kernels whose streams share a queue serialise: with 32 slot streams the 25th fit queued BEHIND a running
-// one (seen in the kernel trace as a 190 ms stall).  16 slots stay one-to-one with queues and still cover the ~9
-// fits that are in flight at the binning rate (0.33 s per fit / 37 ms per pass).
-constexpr int kFitSlots = 16;
+// Pipelined fits are launched in BATCHES: one fit_loop launch with one workgroup per fit (kernels.h: slot launch).
+//  * A single dispatch deals its workgroups evenly over the XCDs and their shader engines; fit loops started one by one
+//    land wherever the dispatcher's pointers happen to be, and bin_gram, whose one-per-CU workgroups are dealt IN ORDER,
+//    stops at the first engine without a free CU: 0.40 ms of bin_gram time per co-running fit loop started singly, 0.25 ms
+//    in a batch of 16 (tools/k1_with_batch.py).
+//  * The fits in flight are no longer limited by the hardware queues (one stream per launch, not per fit): 64 slots, so
+//    that a pipeline over small tables (bootstrap resamples, 1e6-visibility sweeps: binning << 0.26 s of iteration) can
+//    keep ~64 fit loops resident instead of 16.
+// HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; raised to 24 below) and two kernels whose streams
+// share a queue serialise (seen in the kernel trace as 190 ms stalls with 32 streams): 12 launch streams stay one-to-one.
+constexpr int kFitSlots = 64;
+constexpr int kFitBatchMax = 16;
+constexpr int kFitBatches = 12;
+struct FitBatch {
+    hipStream_t stream = nullptr;
+    hipEvent_t ready = nullptr;
+    unsigned char slots[kFitBatchMax];
+    int n = 0, outstanding = 0;
+    bool active = false, launched = false;
+    double alpha = 0, p0 = 0, tol = 0;
+    int max_iter = 0;
+};
 
 struct fh_ctx {
     const fh_dht *dht = nullptr;
@@ -131,6 +147,10 @@ struct fh_ctx {
     DevBuf<double> slot_pool;   // backing store of every slot's buffers
     DevBuf<int> slot_results;
     FitSlot slots[kFitSlots];
+    FitBatch batches[kFitBatches];
+    int pending_batch = -1;  // batch that is still collecting submissions (not launched)
+    int fit_batch = kFitBatchMax;
+    size_t slot_stride = 0;
     int slots_busy = 0;
     bool have_device_Mj = false;
     hipEvent_t ev_bin0 = nullptr, ev_bin1 = nullptr;
@@ -352,12 +372,12 @@ void fh_ctx_destroy(fh_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto &s : c->slots) {
-        if (s.stream) {
-            (void)hipStreamSynchronize(s.stream);
-            (void)hipStreamDestroy(s.stream);
+    for (auto &b : c->batches) {
+        if (b.stream) {
+            (void)hipStreamSynchronize(b.stream);
+            (void)hipStreamDestroy(b.stream);
         }
-        if (s.ready) (void)hipEventDestroy(s.ready);
+        if (b.ready) (void)hipEventDestroy(b.ready);
     }
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev_bin0) (void)hipEventDestroy(c->ev_bin0);
@@ -635,8 +655,8 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     // long after its kernel has finished: counting those would leave CUs idle)
     int running = 0;
     if (c->slots_busy > 0)
-        for (auto &sl : c->slots)
-            if (sl.busy && sl.stream && hipStreamQuery(sl.stream) == hipErrorNotReady) ++running;
+        for (auto &b : c->batches)
+            if (b.active && b.launched && hipStreamQuery(b.stream) == hipErrorNotReady) running += b.n;
     (void)hipGetLastError();  // hipErrorNotReady is not an error here
     // throughput mode while such kernels hold CUs (see bin_gram.hip)
     const bool dynamic = running > 0 || getenv("FRANK_AMD_K1_DYNAMIC") != nullptr;  // env: development switch
@@ -1231,7 +1251,52 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     return FH_OK;
 }
 
-int fh_fit_slots(void) { return kFitSlots; }
+static int fit_batch_size() {  // fit loops per launch: 16, or FRANK_AMD_FIT_BATCH = 1 (launch at once) .. 16
+    int b = kFitBatchMax;
+    if (const char *e = getenv("FRANK_AMD_FIT_BATCH")) b = atoi(e);
+    return b < 1 ? 1 : (b > kFitBatchMax ? kFitBatchMax : b);
+}
+int fh_fit_slots(void) {  // fits that may be outstanding: bounded by the slots and by the launches in flight
+    const int by_launch = kFitBatches * fit_batch_size();
+    return by_launch < kFitSlots ? by_launch : kFitSlots;
+}
+
+// launch the batch that is collecting submissions (no-op if there is none)
+static int flush_pending_batch(fh_ctx *c) {
+    if (c->pending_batch < 0) return FH_OK;
+    FitBatch &b = c->batches[c->pending_batch];
+    c->pending_batch = -1;
+    if (b.n == 0) {
+        b.active = false;
+        return FH_OK;
+    }
+    HIP_TRY(hipEventRecord(b.ready, c->stream));  // the operands of its fits were prepared on the context's stream
+    HIP_TRY(hipStreamWaitEvent(b.stream, b.ready, 0));
+    FitLoopParams P = make_loop_params(c, FIT_MODE_FULL, b.alpha, b.p0, b.tol, b.max_iter);
+    const FitSlot &s0 = c->slots[0];
+    P.A = s0.Aq.p;
+    P.bq = s0.bq.p;
+    P.band_lu = s0.band_lu.p;
+    P.C = s0.Cq.p;
+    P.W = s0.Wq.p;
+    P.T = s0.Tq.p;
+    P.WdT = s0.WdT.p;
+    P.cs = s0.cs.p;
+    P.mu_out = s0.mu_out.p;
+    P.p_out = s0.p_out.p;
+    P.result = s0.result.p;
+    P.slot_stride = c->slot_stride;
+    for (int i = 0; i < b.n; ++i) P.slot_ids[i] = b.slots[i];
+    HIP_TRY(fh_k2_launch_loop_slots(P, b.n, b.stream));
+    b.launched = true;
+    return FH_OK;
+}
+
+int fh_fit_flush(fh_ctx *c) {
+    if (!c) return fail(FH_ERR_INVALID, "fh_fit_flush: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return flush_pending_batch(c);
+}
 
 int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol, int max_iter, int *ticket) {
     if (!c || !ticket) return fail(FH_ERR_INVALID, "fh_fit_submit: NULL argument");
@@ -1256,11 +1321,10 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
         HIP_TRY(c->slot_pool.alloc(per_slot * kFitSlots));
         HIP_TRY(c->slot_results.alloc(2 * kFitSlots));
         HIP_TRY(hipMemsetAsync(c->slot_pool.p, 0, sizeof(double) * per_slot * kFitSlots, c->stream));
+        c->slot_stride = per_slot;
         for (int i = 0; i < kFitSlots; ++i) {
             FitSlot &t = c->slots[i];
             double *b = c->slot_pool.p + per_slot * i;
-            HIP_TRY(hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&t.ready, hipEventDisableTiming));
             t.Aq.adopt(b, PP); b += PP;
             t.Cq.adopt(b, PP); b += PP;
             t.Wq.adopt(b, PP); b += PP;
@@ -1273,30 +1337,51 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
             t.band_lu.adopt(b, 5 * (size_t)N);
             t.result.adopt(c->slot_results.p + 2 * i, 2);
         }
+        for (auto &bt : c->batches) {
+            HIP_TRY(hipStreamCreateWithFlags(&bt.stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&bt.ready, hipEventDisableTiming));
+        }
+        c->fit_batch = fit_batch_size();
+    }
+    // a launch carries ONE set of (alpha, p0, tol, max_iter); w_smooth is per fit (the band LU is a slot operand)
+    if (c->pending_batch >= 0) {
+        const FitBatch &pb = c->batches[c->pending_batch];
+        if (pb.alpha != alpha || pb.p0 != p0 || pb.tol != tol || pb.max_iter != max_iter) {
+            int rc = flush_pending_batch(c);
+            if (rc) return rc;
+        }
+    }
+    if (c->pending_batch < 0) {
+        int bi = -1;
+        for (int i = 0; i < kFitBatches; ++i)
+            if (!c->batches[i].active) {
+                bi = i;
+                break;
+            }
+        if (bi < 0) return fail(FH_ERR_INVALID, "fh_fit_submit: all %d launches are outstanding; collect first", kFitBatches);
+        FitBatch &nb = c->batches[bi];
+        nb.active = true;
+        nb.launched = false;
+        nb.n = nb.outstanding = 0;
+        nb.alpha = alpha;
+        nb.p0 = p0;
+        nb.tol = tol;
+        nb.max_iter = max_iter;
+        c->pending_batch = bi;
     }
     FitSlot &s = c->slots[si];
     smoothing_band_lu(*c->dht, wsmooth, s.lu_host);  // the slot owns the host copy: no wait for the copy here
     HIP_TRY(hipMemcpyAsync(s.band_lu.p, s.lu_host.data(), sizeof(double) * s.lu_host.size(), hipMemcpyHostToDevice, c->stream));
     int rc = prepare_qspace(c, s.Aq.p, s.bq.p);  // on the context's stream, after the finalize that produced M, j
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(s.ready, c->stream));
-    HIP_TRY(hipStreamWaitEvent(s.stream, s.ready, 0));
-    FitLoopParams P = make_loop_params(c, FIT_MODE_FULL, alpha, p0, tol, max_iter);
-    P.A = s.Aq.p;
-    P.bq = s.bq.p;
-    P.band_lu = s.band_lu.p;
-    P.C = s.Cq.p;
-    P.W = s.Wq.p;
-    P.T = s.Tq.p;
-    P.WdT = s.WdT.p;
-    P.cs = s.cs.p;
-    P.mu_out = s.mu_out.p;
-    P.p_out = s.p_out.p;
-    P.result = s.result.p;
-    HIP_TRY(fh_k2_launch_loop(P, s.stream));
+    FitBatch &b = c->batches[c->pending_batch];
+    b.slots[b.n++] = (unsigned char)si;
+    ++b.outstanding;
+    s.batch = c->pending_batch;
     s.busy = true;
     ++c->slots_busy;
     *ticket = si;
+    if (b.n >= c->fit_batch) return flush_pending_batch(c);
     return FH_OK;
 }
 
@@ -1305,14 +1390,21 @@ int fh_fit_collect(fh_ctx *c, int ticket, double *mu, double *p, int *niter) {
         return fail(FH_ERR_INVALID, "fh_fit_collect: bad ticket %d", ticket);
     HIP_TRY(hipSetDevice(c->device));
     FitSlot &s = c->slots[ticket];
+    FitBatch &b = c->batches[s.batch];
+    if (!b.launched) {  // its launch is still collecting submissions: send it now
+        int rc = flush_pending_batch(c);
+        if (rc) return rc;
+    }
     const int N = c->N;
     int result[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(result, s.result.p, sizeof result, hipMemcpyDeviceToHost, s.stream));
-    if (mu) HIP_TRY(hipMemcpyAsync(mu, s.mu_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, s.stream));
-    if (p) HIP_TRY(hipMemcpyAsync(p, s.p_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, s.stream));
-    HIP_TRY(hipStreamSynchronize(s.stream));
+    HIP_TRY(hipMemcpyAsync(result, s.result.p, sizeof result, hipMemcpyDeviceToHost, b.stream));
+    if (mu) HIP_TRY(hipMemcpyAsync(mu, s.mu_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, b.stream));
+    if (p) HIP_TRY(hipMemcpyAsync(p, s.p_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, b.stream));
+    HIP_TRY(hipStreamSynchronize(b.stream));
     s.busy = false;
+    s.batch = -1;
     --c->slots_busy;
+    if (--b.outstanding == 0) b.active = false;
     if (niter) *niter = result[0];
     if (result[1] == FIT_STATUS_BAD_P) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (non-positive or NaN)");
     if (result[1] == FIT_STATUS_NOT_SPD) return fail(FH_ERR_NOT_SPD, "Cholesky of the posterior precision failed");

@@ -558,6 +558,21 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         P.p_out += (size_t)f * P.N;
         P.result += 2 * f;
     }
+    if (P.slot_stride) {
+        const int sl = P.slot_ids[blockIdx.x];
+        const size_t off = (size_t)sl * P.slot_stride;
+        P.A += off;
+        P.bq += off;
+        P.band_lu += off;
+        P.C += off;
+        P.W += off;
+        P.T += off;
+        P.WdT += off;
+        P.cs += off;
+        P.mu_out += off;
+        P.p_out += off;
+        P.result += 2 * sl;
+    }
     const int N = P.N, NP = P.NP;
     const int tid = threadIdx.x;
     Smem S;
@@ -770,6 +785,22 @@ hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s) {
         attr_for = smem;
     }
     hipLaunchKernelGGL(fit_loop_kernel, dim3(1), dim3(KT), smem, s, P);
+    return hipGetLastError();
+}
+
+hipError_t fh_k2_launch_loop_slots(const FitLoopParams &P, int nslots, hipStream_t s) {
+    const size_t smem = fh_k2_loop_smem_bytes(P.NP);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    if (const char *d = getenv("FRANK_AMD_K2_DUMMY")) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_dummy_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fit_loop_dummy_kernel, dim3(nslots), dim3(KT), smem, s, (long long)(atof(d) * 2.4e6), P.result);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(fit_loop_kernel, dim3(nslots), dim3(KT), smem, s, P);
     return hipGetLastError();
 }
 

@@ -114,10 +114,15 @@ struct FitLoopParams {
     int batch;
     int *batch_counter;     // zeroed before the launch; workgroups pull fit indices from it
     const double *batch_alpha, *batch_p0;
+    // slot launch (pipelined fits, one workgroup per fit, every operand per fit): the pointers above are those of slot 0,
+    // slot i lives slot_stride doubles further (results: 2 ints further); workgroup b runs slot slot_ids[b]
+    size_t slot_stride;
+    unsigned char slot_ids[16];
 };
 
 size_t fh_k2_loop_smem_bytes(int NP);
 hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s);
+hipError_t fh_k2_launch_loop_slots(const FitLoopParams &P, int nslots, hipStream_t s);
 hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s);
 hipError_t fh_k2_launch_symmetrize(const double *Araw, const double *bq, int N, int NP, double *A, hipStream_t s);
 

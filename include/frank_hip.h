@@ -148,13 +148,16 @@ int fh_fit_normal(fh_ctx *ctx, const double *M, const double *j, double alpha, d
                   double tol, int max_iter, double *mu, double *p, int *niter, double *diag_p, double *diag_mu);
 
 /* Pipelined form for independent fits (hyper-parameter sweeps, bootstraps, many sources -- fit.py:534-548,
- * 770-782 call the fitter in a plain loop): fh_fit_submit enqueues the iteration of the context's device-resident
- * M, j (from fh_stats_finalize) on one of the context's fit slots and returns at once; the fit_loop kernel occupies
- * ONE compute unit, so the next fh_bin_visibilities overlaps with it.  fh_fit_collect waits for that fit and
- * returns mu, p, niter exactly as fh_fit_normal does.  Tickets are collected in any order; at most
- * fh_fit_slots() fits may be outstanding.                                                                     */
+ * 770-782 call the fitter in a plain loop): fh_fit_submit stages the iteration of the context's device-resident
+ * M, j (from fh_stats_finalize) in one of the context's fit slots and returns at once; a fit_loop workgroup occupies
+ * ONE compute unit, so the following fh_bin_visibilities calls overlap with it.  Submissions are launched in batches
+ * (16 fit loops per launch by default; a launch carries one alpha / p0 / tol / max_iter, w_smooth is per fit):
+ * fh_fit_flush launches what has been staged so far -- call it after the last submission; fh_fit_collect on a fit
+ * whose launch is still open does the same.  fh_fit_collect waits for that fit and returns mu, p, niter exactly as
+ * fh_fit_normal does.  Tickets are collected in any order; at most fh_fit_slots() fits may be outstanding.     */
 int fh_fit_slots(void);
 int fh_fit_submit(fh_ctx *ctx, double alpha, double p0, double wsmooth, double tol, int max_iter, int *ticket);
+int fh_fit_flush(fh_ctx *ctx);
 int fh_fit_collect(fh_ctx *ctx, int ticket, double *mu, double *p, int *niter);
 
 /* Batched form for hyper-parameter sweeps over ONE mapping (fit.py:534-548 re-runs the whole fit per (alpha,
