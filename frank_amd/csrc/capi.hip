@@ -103,9 +103,9 @@ struct FitSlot {
 //    keep ~64 fit loops resident instead of 16.
 // HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; raised to 24 below) and two kernels whose streams
 // share a queue serialise (seen in the kernel trace as 190 ms stalls with 32 streams): 12 launch streams stay one-to-one.
-constexpr int kFitSlots = 64;
+constexpr int kFitSlots = 128;
 constexpr int kFitBatchMax = 16;
-constexpr int kFitBatches = 12;
+constexpr int kFitBatches = 16;
 struct FitBatch {
     hipStream_t stream = nullptr;
     hipEvent_t ready = nullptr;
