@@ -66,6 +66,7 @@ struct Smem {
     double *dl;    // 16 x PS: factor of the current diagonal tile (+ reciprocal diagonal in column 16)
     double *dli;   // 16 x PS: its inverse (A operand of the MFMA panel solve)
     double *p, *pold, *m, *y, *tr2, *rhs, *b, *red;  // NP each (red: 6*NP scratch)
+    double *band;  // 5 NP: LU factors of the pentadiagonal T + I, staged once per fit
     int *lst;      // tile list of the current trailing update (<= 171 entries)
     int *flag;
 };
@@ -590,10 +591,13 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     S.b = S.rhs + NP;
     S.red = S.b + NP;  // 6*NP
     S.stage1 = S.red + 6 * NP;
-    S.lst = reinterpret_cast<int *>(S.stage1 + (NP / 16) * 256);
+    S.band = S.stage1 + (NP / 16) * 256;
+    S.lst = reinterpret_cast<int *>(S.band + 5 * NP);
     S.flag = S.lst + 192;
     __shared__ int s_ctl[4];  // [0] stop, [1] status
 
+    if (P.band_lu)
+        for (int i = tid; i < 5 * N; i += KT) S.band[i] = P.band_lu[i];
     for (int i = tid; i < NP; i += KT) {
         S.b[i] = i < N ? P.bq[i] : 0.0;
         S.p[i] = i < N ? (P.p_init ? P.p_init[i] : 1.0) : 1.0;  // radial_fitters.py:744 (p = 1)
@@ -661,26 +665,53 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
             S.pold[i] = pi;
         }
         __syncthreads();
-        if (tid == 0) {  // banded LU solve with the host-prepared factors; the recurrence lives in registers
-            const double *f1 = P.band_lu, *f2 = f1 + N, *d0 = f2 + N, *u1 = d0 + N, *u2 = u1 + N;
+        if (tid == 0) {  // banded LU solve with the host-prepared factors (staged in LDS once per fit); the recurrence
+                         // lives in registers and the operands of 8 steps are fetched together, so that a step costs its
+                         // two dependent fmas (and the division on the way back), not an LDS round trip
+            const double *f1 = S.band, *f2 = f1 + N, *d0 = f2 + N, *u1 = d0 + N, *u2 = u1 + N;
             double x1 = S.rhs[0], x2 = 0.0;  // x_{i-1}, x_{i-2}
-            for (int i = 1; i < N; ++i) {
-                double xi = S.rhs[i];
-                xi = fma(-f2[i], x2, xi);
-                xi = fma(-f1[i], x1, xi);
-                S.rhs[i] = xi;
-                x2 = x1;
-                x1 = xi;
+            for (int i0 = 1; i0 < N; i0 += 8) {
+                double r[8], a1[8], a2[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = min(i0 + k, N - 1);
+                    r[k] = S.rhs[i];
+                    a1[k] = f1[i];
+                    a2[k] = f2[i];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (i0 + k < N) {
+                        double xi = r[k];
+                        xi = fma(-a2[k], x2, xi);
+                        xi = fma(-a1[k], x1, xi);
+                        S.rhs[i0 + k] = xi;
+                        x2 = x1;
+                        x1 = xi;
+                    }
             }
             double y1 = 0.0, y2 = 0.0;  // x_{i+1}, x_{i+2}
-            for (int i = N - 1; i >= 0; --i) {
-                double t = S.rhs[i];
-                t = fma(-u1[i], y1, t);
-                t = fma(-u2[i], y2, t);
-                t = t / d0[i];
-                S.rhs[i] = t;
-                y2 = y1;
-                y1 = t;
+            for (int i0 = N - 1; i0 >= 0; i0 -= 8) {
+                double r[8], b1[8], b2[8], dd[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = max(i0 - k, 0);
+                    r[k] = S.rhs[i];
+                    b1[k] = u1[i];
+                    b2[k] = u2[i];
+                    dd[k] = d0[i];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (i0 - k >= 0) {
+                        double t = r[k];
+                        t = fma(-b1[k], y1, t);
+                        t = fma(-b2[k], y2, t);
+                        t = t / dd[k];
+                        S.rhs[i0 - k] = t;
+                        y2 = y1;
+                        y1 = t;
+                    }
             }
         }
         __syncthreads();
@@ -735,7 +766,7 @@ __global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int 
 
 size_t fh_k2_loop_smem_bytes(int NP) {
     const int panel = NP * PS > 2 * NW * NP ? NP * PS : 2 * NW * NP;
-    return sizeof(double) * (size_t)(panel + (NW + 2) * 16 * PS + 7 * NP + 6 * NP + (NP / 16) * 256) + 4 * 192 + 16;
+    return sizeof(double) * (size_t)(panel + (NW + 2) * 16 * PS + 7 * NP + 6 * NP + (NP / 16) * 256 + 5 * NP) + 4 * 192 + 16;
 }
 
 hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s) {
