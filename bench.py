@@ -42,7 +42,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # the timed region holds K binning passes back to back plus ONE pipeline drain (the iteration of the last fit,
-    # ~0.29 s): the default K amortises it, a small K mostly measures it
+    # ~0.24 s): the default K amortises it, a small K mostly measures it
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nvis", type=int, default=N_VIS)
