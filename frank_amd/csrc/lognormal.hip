@@ -256,8 +256,12 @@ __device__ __forceinline__ void lu_factor(LnS &S, int N, double *A) {
                 bi = i;
             }
         }
-        const double top = wave_reduce(best, rocprim::maximum<double>());
-        int piv = wave_reduce(best == top ? bi : 0x7fffffff, rocprim::minimum<int>());
+        const double top = wave_reduce(best, FMax());  // (best is never NaN: a NaN entry fails `v > best`)
+        // the row of the maximum: one lane in all but exceptional cases (ties go to the first row)
+        const unsigned long long tie = __ballot(best == top);
+        int piv;
+        if ((tie & (tie - 1)) == 0) piv = __builtin_amdgcn_readlane(bi, __ffsll((long long)tie) - 1);
+        else piv = wave_reduce(best == top ? bi : 0x7fffffff, rocprim::minimum<int>());
         if (piv >= N) piv = k;  // all-NaN column: keep the diagonal
         const double pv = ck[piv], dkk = ck[k];
         // phase A
