@@ -1319,7 +1319,7 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
         // all slots at once, carved from ONE allocation: a hipMalloc per buffer costs ~0.7 ms of host time, and paying
         // 11 of them whenever a fresh slot is first used put an 8 ms hole after every binning pass of a pipeline
         const size_t nbk = (size_t)(c->NP / 16);
-        const size_t per_slot = 4 * PP + (size_t)c->NP * 16 + nbk * nbk * 16 + 3 * (size_t)N + 5 * (size_t)N;
+        const size_t per_slot = 4 * PP + (size_t)c->NP * 16 + nbk * nbk * 16 + 3 * (size_t)N + 5 * (size_t)N + 2;
         HIP_TRY(c->slot_pool.alloc(per_slot * kFitSlots));
         HIP_TRY(c->slot_results.alloc(2 * kFitSlots));
         HIP_TRY(hipMemsetAsync(c->slot_pool.p, 0, sizeof(double) * per_slot * kFitSlots, c->stream));
@@ -1336,7 +1336,7 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
             t.bq.adopt(b, N); b += N;
             t.mu_out.adopt(b, N); b += N;
             t.p_out.adopt(b, N); b += N;
-            t.band_lu.adopt(b, 5 * (size_t)N);
+            t.band_lu.adopt(b, 5 * (size_t)N + 2);  // + alpha, p0 of the fit (read by the slot launch)
             t.result.adopt(c->slot_results.p + 2 * i, 2);
         }
         for (auto &bt : c->batches) {
@@ -1345,10 +1345,10 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
         }
         c->fit_batch = fit_batch_size();
     }
-    // a launch carries ONE set of (alpha, p0, tol, max_iter); w_smooth is per fit (the band LU is a slot operand)
+    // a launch carries ONE (tol, max_iter); alpha, p0 and w_smooth are per fit (they travel with the slot's band LU)
     if (c->pending_batch >= 0) {
         const FitBatch &pb = c->batches[c->pending_batch];
-        if (pb.alpha != alpha || pb.p0 != p0 || pb.tol != tol || pb.max_iter != max_iter) {
+        if (pb.tol != tol || pb.max_iter != max_iter) {
             int rc = flush_pending_batch(c);
             if (rc) return rc;
         }
@@ -1373,6 +1373,9 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
     }
     FitSlot &s = c->slots[si];
     smoothing_band_lu(*c->dht, wsmooth, s.lu_host);  // the slot owns the host copy: no wait for the copy here
+    s.lu_host.resize(5 * (size_t)N);
+    s.lu_host.push_back(alpha);
+    s.lu_host.push_back(p0);
     HIP_TRY(hipMemcpyAsync(s.band_lu.p, s.lu_host.data(), sizeof(double) * s.lu_host.size(), hipMemcpyHostToDevice, c->stream));
     int rc = prepare_qspace(c, s.Aq.p, s.bq.p);  // on the context's stream, after the finalize that produced M, j
     if (rc) return rc;

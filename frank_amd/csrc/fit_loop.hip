@@ -573,6 +573,8 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         P.mu_out += off;
         P.p_out += off;
         P.result += 2 * sl;
+        P.alpha = P.band_lu[5 * P.N];  // per-fit hyper-parameters travel behind the slot's band LU
+        P.p0 = P.band_lu[5 * P.N + 1];
     }
     const int N = P.N, NP = P.NP;
     const int tid = threadIdx.x;

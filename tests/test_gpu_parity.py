@@ -825,3 +825,41 @@ def test_fp32_visibility_table():
     # a scalar float32 weight broadcasts like the fp64 one (statistical_models.py:173)
     m4s = vm.map_visibilities(u4, v4, V4, np.float32(w4[0]))
     assert rel_to_max(m4s["M"], m4["M"]) < 1e-13
+
+
+def test_pipelined_fits_with_per_fit_hyperparameters():
+    """One batched launch carries fits with different alpha / w_smooth (they travel with the slot): each equals the
+    synchronous fit with those hyper-parameters (the per-point fits of a sweep over distinct tables)."""
+    import ctypes
+    from frank_amd import _lib, FrankFitter
+    N, n = 60, 20000
+    u, v, V, w = mock_disc_visibilities(n, seed=31, noise_seed=32)
+    hyper = [(1.05, 1e-4), (1.2, 1e-3), (1.3, 1e-2), (1.05, 1e-1)]
+    sync = []
+    for a, ws in hyper:
+        FF = FrankFitter(2.0, N, geom(), alpha=a, weights_smooth=ws, verbose=False, store_iteration_diagnostics=True)
+        sol = FF.fit(u, v, V, w)
+        sync.append((sol.I.copy(), FF.iteration_diagnostics["num_iterations"]))
+    ctx = FF._DHT.context()
+    vis = ctypes.c_void_p()
+    Vre, Vim = np.ascontiguousarray(V.real), np.ascontiguousarray(V.imag)
+    _lib.check(_lib.lib.fh_vis_upload(0, _lib.ptr(u), _lib.ptr(v), _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), w.size,
+                                      u.size, ctypes.byref(vis)))
+    gm = _lib.make_geometry(geom())
+    tickets = []
+    for a, ws in hyper:
+        _lib.check(_lib.lib.fh_bin_reset(ctx))
+        _lib.check(_lib.lib.fh_bin_visibilities(ctx, ctypes.byref(gm), vis, 0, u.size))
+        H0, q0, q1 = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(_lib.lib.fh_stats_finalize(ctx, ctypes.byref(gm), 0, 1, None, None, ctypes.byref(H0),
+                                              ctypes.byref(q0), ctypes.byref(q1)))
+        t = ctypes.c_int(-1)
+        _lib.check(_lib.lib.fh_fit_submit(ctx, a, 1e-15, ws, 1e-3, 2000, ctypes.byref(t)))
+        tickets.append(t.value)
+    _lib.check(_lib.lib.fh_fit_flush(ctx))
+    for t, (I_ref, nit) in zip(tickets, sync):
+        mu, p, k = np.empty(N), np.empty(N), ctypes.c_int()
+        _lib.check(_lib.lib.fh_fit_collect(ctx, t, _lib.ptr(mu), _lib.ptr(p), ctypes.byref(k)))
+        assert k.value == nit
+        assert rel_to_max(mu, I_ref) < 1e-9
+    _lib.lib.fh_vis_destroy(vis)
