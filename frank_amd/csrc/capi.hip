@@ -87,7 +87,7 @@ struct fh_vis {
 };
 
 struct FitSlot {
-    DevBuf<double> Aq, bq, Cq, Wq, Tq, WdT, cs, mu_out, p_out, band_lu;
+    DevBuf<double> Aq, bq, Cq, Wq, WdT, cs, mu_out, p_out, band_lu;
     DevBuf<int> result;
     std::vector<double> lu_host;  // stays alive while the asynchronous copy of the band LU may still read it
     bool busy = false;
@@ -141,7 +141,7 @@ struct fh_ctx {
     // K2 v2 (fit_loop): q-space operands and work buffers
     int NP = 0;
     bool use_rocsolver_loop = false;
-    DevBuf<double> Yinv, T1, Araw, Aq, bq, Cq, Wq, Tq, WdT, cs, mu_out, p_out, p_init;
+    DevBuf<double> Yinv, T1, Araw, Aq, bq, Cq, Wq, WdT, cs, mu_out, p_out, p_init;
     DevBuf<int> loop_result;
     DevBuf<long long> loop_timing;  // FIT_LOOP_TIMING debug builds only
     DevBuf<double> slot_pool;   // backing store of every slot's buffers
@@ -351,7 +351,6 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
         HIP_TRY(c->Aq.alloc(PP));
         HIP_TRY(c->Cq.alloc(PP));
         HIP_TRY(c->Wq.alloc(PP));
-        HIP_TRY(c->Tq.alloc(PP));
         HIP_TRY(c->WdT.alloc((size_t)c->NP * 16));
         HIP_TRY(c->cs.alloc((size_t)(c->NP / 16) * (c->NP / 16) * 16));
         HIP_TRY(hipMemsetAsync(c->Cq.p, 0, sizeof(double) * PP, c->stream));
@@ -1087,7 +1086,6 @@ static FitLoopParams make_loop_params(fh_ctx *c, int mode, double alpha, double 
     P.p_init = nullptr;
     P.C = c->Cq.p;
     P.W = c->Wq.p;
-    P.T = c->Tq.p;
     P.WdT = c->WdT.p;
     P.cs = c->cs.p;
     P.mu_out = c->mu_out.p;
@@ -1203,7 +1201,7 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     int rc = prepare_qspace(c, c->Aq.p, c->bq.p);
     if (rc) return rc;
     // per-fit work buffers and parameters
-    DevBuf<double> Cb, Wb, Tb, WdTb, csb, mub, pb, lub, alb, p0b;
+    DevBuf<double> Cb, Wb, WdTb, csb, mub, pb, lub, alb, p0b;
     DevBuf<int> resb;
     const size_t B = (size_t)batch;
     // work buffers per resident workgroup (at most one per CU), outputs per fit
@@ -1211,7 +1209,7 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     DevBuf<int> counter;
     if (counter.alloc(1) != hipSuccess) return fail(FH_ERR_NOMEM, "device allocation failed");
     HIP_TRY(hipMemsetAsync(counter.p, 0, sizeof(int), c->stream));
-    if (Cb.alloc(G * PP) != hipSuccess || Wb.alloc(G * PP) != hipSuccess || Tb.alloc(G * PP) != hipSuccess ||
+    if (Cb.alloc(G * PP) != hipSuccess || Wb.alloc(G * PP) != hipSuccess ||
         WdTb.alloc(G * NP * 16) != hipSuccess || csb.alloc(G * nbk * nbk * 16) != hipSuccess ||
         mub.alloc(B * N) != hipSuccess || pb.alloc(B * N) != hipSuccess || lub.alloc(B * 5 * N) != hipSuccess ||
         alb.alloc(B) != hipSuccess || p0b.alloc(B) != hipSuccess || resb.alloc(2 * B) != hipSuccess)
@@ -1228,7 +1226,6 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     P.band_lu = lub.p;
     P.C = Cb.p;
     P.W = Wb.p;
-    P.T = Tb.p;
     P.WdT = WdTb.p;
     P.cs = csb.p;
     P.mu_out = mub.p;
@@ -1281,7 +1278,6 @@ static int flush_pending_batch(fh_ctx *c) {
     P.band_lu = s0.band_lu.p;
     P.C = s0.Cq.p;
     P.W = s0.Wq.p;
-    P.T = s0.Tq.p;
     P.WdT = s0.WdT.p;
     P.cs = s0.cs.p;
     P.mu_out = s0.mu_out.p;
@@ -1319,7 +1315,7 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
         // all slots at once, carved from ONE allocation: a hipMalloc per buffer costs ~0.7 ms of host time, and paying
         // 11 of them whenever a fresh slot is first used put an 8 ms hole after every binning pass of a pipeline
         const size_t nbk = (size_t)(c->NP / 16);
-        const size_t per_slot = 4 * PP + (size_t)c->NP * 16 + nbk * nbk * 16 + 3 * (size_t)N + 5 * (size_t)N + 2;
+        const size_t per_slot = 3 * PP + (size_t)c->NP * 16 + nbk * nbk * 16 + 3 * (size_t)N + 5 * (size_t)N + 2;
         HIP_TRY(c->slot_pool.alloc(per_slot * kFitSlots));
         HIP_TRY(c->slot_results.alloc(2 * kFitSlots));
         HIP_TRY(hipMemsetAsync(c->slot_pool.p, 0, sizeof(double) * per_slot * kFitSlots, c->stream));
@@ -1330,7 +1326,6 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
             t.Aq.adopt(b, PP); b += PP;
             t.Cq.adopt(b, PP); b += PP;
             t.Wq.adopt(b, PP); b += PP;
-            t.Tq.adopt(b, PP); b += PP;
             t.WdT.adopt(b, (size_t)c->NP * 16); b += (size_t)c->NP * 16;
             t.cs.adopt(b, nbk * nbk * 16); b += nbk * nbk * 16;
             t.bq.adopt(b, N); b += N;

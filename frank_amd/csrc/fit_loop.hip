@@ -51,7 +51,7 @@ constexpr int KT = FIT_LOOP_THREADS;
 constexpr int NW = KT / 64;
 constexpr int NWK = NW - NW / 4;  // trailing-update workers: the waves that do not share wave 0's SIMD
 constexpr int PS = 17;  // LDS stride of the 16-wide panel rows (doubles)
-constexpr int PF = 2;   // operand prefetch depth (tile products) in the block-inverse phases
+constexpr int PF = 2;   // W tiles in flight per chain of the row-by-row inverse
 
 __device__ __forceinline__ double bcast(double v, int lane) {  // wave-uniform broadcast of lane `lane`'s value
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -187,113 +187,9 @@ __device__ __forceinline__ void store_tile(double *Mx, int ld, int I, int J, con
     }
 }
 
-// ---- (4) recursive block inverse as its own function: separate register allocation from the Cholesky sweep ---------
-__device__ __noinline__ void block_inverse(const double *C, double *W, double *T, const double *WdT, double *cs,
-                                           int N, int nb, int ld, long long *timing) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cl = lane & 15, rg = lane >> 4;
-#ifdef FIT_LOOP_TIMING
-    long long t_last = clock64();
-#endif
-    auto cs_ptr = [&](int I, int J) { return cs + ((size_t)I * nb + J) * 16; };
-    // (4) recursive block inverse, bottom-up: for each range [a, a+2s) split at mid = a+s:
-    //       T = L21 W11   then   W21 = -W22 T        (all tiles of a level are independent)
-    for (int s = 1; s < nb; s *= 2) {
-        // phase A: T_IJ = sum_{K=J}^{mid-1} L_IK W_KJ,  I in [mid, b), J in [a, mid)
-        int ctr = 0;
-        for (int a = 0; a + s < nb; a += 2 * s) {
-            const int mid = a + s, b = min(a + 2 * s, nb);
-            for (int I = mid; I < b; ++I)
-                for (int J = a; J < mid; ++J, ++ctr) {
-                    if ((ctr & (NW - 1)) != wave) continue;
-                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-                    // A operand L_IK from its mirror block (K, I); B operand W_KJ in place (row form both);
-                    // operands are fetched PF tile-products ahead (L2 latency ~ 4 products' worth of MFMAs)
-                    Frag ra[PF], rb[PF];
-#pragma unroll
-                    for (int d = 0; d < PF; ++d) {
-                        const int K = min(J + d, mid - 1);
-                        ra[d] = load_rows(C + (size_t)(16 * K) * ld + 16 * I, ld, cl, rg);
-                        rb[d] = load_rows(W + (size_t)(16 * K) * ld + 16 * J, ld, cl, rg);
-                    }
-                    for (int K = J; K < mid; ++K) {
-                        const Frag fa = ra[0], fb = rb[0];
-#pragma unroll
-                        for (int d = 0; d + 1 < PF; ++d) {
-                            ra[d] = ra[d + 1];
-                            rb[d] = rb[d + 1];
-                        }
-                        if (K + PF < mid) {
-                            ra[PF - 1] = load_rows(C + (size_t)(16 * (K + PF)) * ld + 16 * I, ld, cl, rg);
-                            rb[PF - 1] = load_rows(W + (size_t)(16 * (K + PF)) * ld + 16 * J, ld, cl, rg);
-                        }
-                        acc = mfma4(fa, fb, acc, false);
-                    }
-                    store_tile(T, ld, I, J, acc, cl, rg, false);
-                }
-        }
-        __syncthreads();
-        ISTAMP(5);
-        // phase B: W_IJ = -sum_{K=mid}^{I} W_IK T_KJ   (W_II from the transposed diagonal copies)
-        ctr = 0;
-        for (int a = 0; a + s < nb; a += 2 * s) {
-            const int mid = a + s, b = min(a + 2 * s, nb);
-            for (int I = mid; I < b; ++I)
-                for (int J = a; J < mid; ++J, ++ctr) {
-                    if ((ctr & (NW - 1)) != wave) continue;
-                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-                    // A operand W_IK: mirror block (K, I) for K < I, transposed diagonal copy for K == I
-                    auto load_a = [&](int K) {
-                        Frag f;
-                        if (K < I) {
-                            f = load_rows(W + (size_t)(16 * K) * ld + 16 * I, ld, cl, rg);
-                        } else {
-                            const double *wd = WdT + (size_t)I * 256 + rg * 16 + cl;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) f.v[q] = wd[64 * q];
-                        }
-                        return f;
-                    };
-                    Frag ra[PF], rb[PF];
-#pragma unroll
-                    for (int d = 0; d < PF; ++d) {
-                        const int K = min(mid + d, I);
-                        ra[d] = load_a(K);
-                        rb[d] = load_rows(T + (size_t)(16 * K) * ld + 16 * J, ld, cl, rg);
-                    }
-                    for (int K = mid; K <= I; ++K) {
-                        const Frag fa = ra[0], fb = rb[0];
-#pragma unroll
-                        for (int d = 0; d + 1 < PF; ++d) {
-                            ra[d] = ra[d + 1];
-                            rb[d] = rb[d + 1];
-                        }
-                        if (K + PF <= I) {
-                            ra[PF - 1] = load_a(K + PF);
-                            rb[PF - 1] = load_rows(T + (size_t)(16 * (K + PF)) * ld + 16 * J, ld, cl, rg);
-                        }
-                        acc = mfma4(fa, fb, acc, true);
-                    }
-                    store_tile(W, ld, I, J, acc, cl, rg, true);
-                    // column sums of squares of this (final) tile over the rows of the real system
-                    double ssq = 0.0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (16 * I + rg + 4 * r < N) ssq = fma(acc[r], acc[r], ssq);
-                    ssq += __shfl_xor(ssq, 16);
-                    ssq += __shfl_xor(ssq, 32);
-                    if (rg == 0) cs_ptr(I, J)[cl] = ssq;
-                }
-        }
-        __syncthreads();
-        ISTAMP(6);
-    }
-
-}
-
-// ---- (4') row-by-row inverse: W_IJ = -W_II * sum_{K=J}^{I-1} L_IK W_KJ, one block row at a time ------------------------
-// One CU pulls only ~13 B/clk from L2, and the recursive form above moves ~8 MB per iteration (T is written and read
-// back at every level).  Here a row's L tiles are staged once in LDS (the next row's while this row computes), the sum
+// ---- (4) row-by-row inverse: W_IJ = -W_II * sum_{K=J}^{I-1} L_IK W_KJ, one block row at a time ------------------------
+// The first design was a recursive, GEMM-shaped block inverse whose temporary T was written and read back at every
+// level: ~8 MB of L2 traffic per iteration, 156 us.  Here a row's L tiles are staged once in LDS (the next row's while this row computes), the sum
 // is accumulated in registers, and the accumulator -- already in the layout of an MFMA B operand -- is multiplied by
 // W_II without touching memory: ~3.5 MB per iteration, one barrier per block row.  W's mirror blocks are not needed.
 __device__ __noinline__ void row_inverse(const double *C, double *W, const double *WdT, double *cs, double *stage0,
@@ -371,7 +267,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
     const int N = P.N, NP = P.NP, nb = P.NP / 16, ld = P.NP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = lane & 15, rg = lane >> 4;
-    double *C = P.C, *W = P.W, *T = P.T, *WdT = P.WdT;
+    double *C = P.C, *W = P.W, *WdT = P.WdT;
 #ifdef FIT_LOOP_TIMING
     long long t_last = clock64();
 #endif
@@ -510,11 +406,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
     if (*S.flag) return false;
     TSTAMP(4);
 
-#ifdef FIT_INVERSE_BLOCKED
-    block_inverse(C, W, T, WdT, P.cs, N, nb, ld, P.timing);
-#else
     row_inverse(C, W, WdT, P.cs, S.pan, S.stage1, N, nb, ld, P.timing);
-#endif
 #ifdef FIT_LOOP_TIMING
     t_last = clock64();
 #endif
@@ -552,7 +444,6 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         P.band_lu += (size_t)f * 5 * P.N;
         P.C += slot * PP;
         P.W += slot * PP;
-        P.T += slot * PP;
         P.WdT += slot * (size_t)P.NP * 16;
         P.cs += slot * nbk * nbk * 16;
         P.mu_out += (size_t)f * P.N;
@@ -567,7 +458,6 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         P.band_lu += off;
         P.C += off;
         P.W += off;
-        P.T += off;
         P.WdT += off;
         P.cs += off;
         P.mu_out += off;

@@ -102,7 +102,7 @@ struct FitLoopParams {
     const double *q;        // N collocation frequencies
     const double *band_lu;  // 5N: LU factors of the pentadiagonal T + I
     const double *p_init;   // N or NULL (= ones)
-    double *C, *W, *T;      // NP*NP work: Cholesky factor (+ mirror), its inverse (+ mirror), block-inverse temporary
+    double *C, *W;          // NP*NP work: Cholesky factor (+ mirror), its inverse
     double *WdT;            // (NP/16)*256: transposed inverses of the diagonal tiles
     double *cs;             // (NP/16)^2 * 16: per-tile column sums of squares of W
     double *mu_out, *p_out; // N
