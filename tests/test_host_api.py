@@ -103,6 +103,9 @@ def test_device_entry_points_fail_loudly_without_a_gpu():
     x = np.full(8, 1e5)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         FF.fit(x, x, np.ones(8) + 0j, np.ones(8))
+    x4 = x.astype(np.float32)  # single-precision tables take the fp32 upload: the same loud failure
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        FF.fit(x4, x4, (np.ones(8) + 0j).astype(np.complex64), np.ones(8, dtype=np.float32))
     # the other entry families: LogNormal, uv-binner, bootstrap
     from frank_amd.utilities import UVDataBinner
     from frank_amd.bootstrap import bootstrap_fits
