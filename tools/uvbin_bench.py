@@ -5,7 +5,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from frank_amd.utilities import UVDataBinner
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10 ** 7
