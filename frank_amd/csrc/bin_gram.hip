@@ -92,6 +92,46 @@ constexpr int part_row1(int NBT, int P) { return (NBT > 13 && P == 0) ? 7 : NBT;
 constexpr int part_tile0(int NBT, int P) { return row_first_tile(NBT, part_row0(NBT, P)); }
 constexpr int part_tile1(int NBT, int P) { return row_first_tile(NBT, part_row1(NBT, P)); }
 
+
+// Which tiles a wave owns.  The accumulation of a tile does not depend on its owner, so any assignment gives the same
+// bits; what it changes is how many distinct 16-column fragments a wave reads from LDS per k-step (the union of the row
+// and column blocks of its tiles).  Round-robin over the row-major triangle: 13 fragments per wave in part 0, 9-10 in
+// part 1.  For NBT = 19 with 12 waves the tiles are dealt as compact rectangles (two block rows x <= 5 block columns):
+// 5-8 fragments in part 0, 3-6 in part 1 -- half the fragment reads -- with the same <= 10 tiles per wave and 28 (19-20)
+// tiles per SIMD (waves W, W+4, W+8 share SIMD W % 4).  Tables: tools/gen_k1_tile_tables.py.
+constexpr short kTiles19P0[12][10] = {
+    {5, 6, 7, 8, 9, 23, 24, 25, 26, 27},        {42, 43, 44, 45, 46, 58, 59, 60, 61, 62},
+    {75, 76, 77, 78, 79, 89, 90, 91, 92, 93},   {80, 81, 82, 83, 84, 94, 95, 96, 97, 98},
+    {10, 11, 12, 13, 14, 28, 29, 30, 31, 32},   {47, 48, 49, 50, 51, 63, 64, 65, 66, 67},
+    {0, 1, 2, 3, 4, 19, 20, 21, 22, -1},        {70, 71, 72, 73, 74, 85, 86, 87, 88, -1},
+    {15, 16, 17, 18, 33, 34, 35, 36, -1, -1},   {99, 100, 101, 102, 103, 104, 105, 106, -1, -1},
+    {37, 38, 39, 40, 41, 54, 55, 56, 57, -1},   {52, 53, 68, 69, 107, 108, 109, 110, 111, -1},
+};
+constexpr short kTiles19P1[12][10] = {
+    {180, 181, 182, 183, 184, 185, 186, 187, 188, 189}, {158, 159, 160, 161, 165, 166, 167, 168, -1, -1},
+    {112, 113, 114, 115, 124, 125, 126, -1, -1, -1},    {154, 155, 156, 157, 162, 163, 164, -1, -1, -1},
+    {169, 170, 171, 175, 176, -1, -1, -1, -1, -1},      {116, 117, 118, 127, 128, 129, -1, -1, -1, -1},
+    {135, 136, 137, 138, 145, 146, 147, -1, -1, -1},    {142, 143, 144, 151, 152, 153, -1, -1, -1, -1},
+    {122, 123, 133, 134, -1, -1, -1, -1, -1, -1},       {119, 120, 121, 130, 131, 132, -1, -1, -1, -1},
+    {139, 140, 141, 148, 149, 150, -1, -1, -1, -1},     {172, 173, 174, 177, 178, 179, -1, -1, -1, -1},
+};
+#ifdef K1_ROUND_ROBIN_TILES
+constexpr bool kCompactTiles = false;
+#else
+constexpr bool kCompactTiles = (kWaves == 12);
+#endif
+// global index of the T-th tile of wave W in part P (-1: none)
+constexpr int wave_tile(int NBT, int P, int W, int T) {
+    if (kCompactTiles && NBT == 19 && nparts(NBT) == 2) return T < 10 ? (P == 0 ? kTiles19P0[W][T] : kTiles19P1[W][T]) : -1;
+    const int tt = part_tile0(NBT, P) + W + T * kWaves;
+    return tt < part_tile1(NBT, P) ? tt : -1;
+}
+constexpr int wave_ntiles(int NBT, int P, int W) {
+    int n = 0;
+    while (n < 64 && wave_tile(NBT, P, W, n) >= 0) ++n;
+    return n;
+}
+
 // ---- K1a ----------------------------------------------------------------------------------------------------
 // geometry.py:69-79 (inverse phase shift, NumPy's Smith complex division), :111-131 (deproject),
 // statistical_models.py:166 (hypot).  Every product/sum rounds separately, as the NumPy expressions do.
@@ -179,7 +219,7 @@ __global__ __launch_bounds__(256) void deproject_kernel(BinParams p) {
 // ---- K1b ----------------------------------------------------------------------------------------------------
 template <int NBT, int P, int W, int T>
 __device__ __forceinline__ void mfma_one(v4f64 &acc, const double (&f)[NBT]) {
-    constexpr int tt = part_tile0(NBT, P) + W + T * kWaves;
+    constexpr int tt = wave_tile(NBT, P, W, T);
     constexpr int I = tile_I(NBT, tt), J = tile_J(NBT, tt);
     // A[i][k] = Xt[k][16I+i] and B[k][j] = Xt[k][16J+j] share one fragment layout: lane -> (k = lane>>4, i|j = lane&15)
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f[I], f[J], acc, 0, 0, 0);
@@ -196,7 +236,7 @@ __device__ __forceinline__ void wave_main(const BinParams &p, double *smem, int 
     constexpr int XS = xstride(NBT);
     constexpr int T0 = part_tile0(NBT, P), T1 = part_tile1(NBT, P);
     constexpr int NTP = T1 - T0;                          // tiles of this part
-    constexpr int TPW = (NTP - W + kWaves - 1) / kWaves;  // tiles of this wave: T0 + W, T0 + W + 8, ...
+    constexpr int TPW = wave_ntiles(NBT, P, W);           // tiles of this wave (wave_tile)
     constexpr int B0 = part_row0(NBT, P);                 // first column block this part needs
     constexpr int C0 = B0 * 16;                           // first column
     constexpr int NCG = (NC - C0 + 63) / 64;              // column groups of 64 lanes
@@ -339,7 +379,7 @@ __device__ __forceinline__ void wave_main(const BinParams &p, double *smem, int 
     double *slab = p.partials[P] + (size_t)part_block * NTP * 256;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int tl = W + t * kWaves;
+        const int tl = wave_tile(NBT, P, W, t) - T0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) slab[(size_t)tl * 256 + r * 64 + lane] = acc[t][r];
     }
