@@ -125,3 +125,19 @@ def test_constants_are_the_reference_doubles():
     assert c.rad_to_arcsec == 3600 * 180 / np.pi
     assert c.sterad_to_arcsec == (3600 * 180 / np.pi) ** 2
     assert c.deg_to_rad == np.pi / 180
+
+
+def test_bin_gram_tile_tables_cover_the_triangle_once():
+    """The tile-ownership tables of bin_gram_kernel<19> (kTiles19P0 / kTiles19P1) are a partition of the 190 upper-triangle
+    tiles: part 0 the block rows 0-6 (tiles 0..111), part 1 the rest; at most 10 tiles per wave; equal (+-1) tile counts
+    per SIMD (waves W, W+4, W+8)."""
+    src = open(os.path.join(ROOT, "frank_amd", "csrc", "bin_gram.hip")).read()
+    for name, lo, hi in (("kTiles19P0", 0, 112), ("kTiles19P1", 112, 190)):
+        body = re.search(r"constexpr short %s\[12\]\[10\] = \{(.*?)\n\};" % name, src, flags=re.S).group(1)
+        rows = re.findall(r"\{([^{}]*)\}", body)
+        assert len(rows) == 12
+        waves = [[int(x) for x in r.split(",") if int(x) >= 0] for r in rows]
+        assert all(1 <= len(w) <= 10 for w in waves)
+        assert sorted(t for w in waves for t in w) == list(range(lo, hi))
+        per_simd = [sum(len(waves[w]) for w in (s, s + 4, s + 8)) for s in range(4)]
+        assert max(per_simd) - min(per_simd) <= 1
