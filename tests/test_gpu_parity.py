@@ -863,3 +863,56 @@ def test_pipelined_fits_with_per_fit_hyperparameters():
         assert k.value == nit
         assert rel_to_max(mu, I_ref) < 1e-9
     _lib.lib.fh_vis_destroy(vis)
+
+
+def test_pipeline_bookkeeping_many_fits_out_of_order():
+    """150 pipelined fits (more than the 128 slots, so slots and launches are recycled), collected out of order and with a
+    partly filled last launch: every one equals the synchronous fit of its w_smooth."""
+    import ctypes
+    from frank_amd import _lib, FrankFitter
+    N, n = 50, 5000
+    u, v, V, w = mock_disc_visibilities(n, seed=41, noise_seed=42)
+    wss = [1e-4, 1e-3, 1e-2]
+    sync = {}
+    for ws in wss:
+        FF = FrankFitter(2.0, N, geom(), weights_smooth=ws, verbose=False, store_iteration_diagnostics=True,
+                         check_qbounds=False)
+        sol = FF.fit(u, v, V, w)
+        sync[ws] = (sol.I.copy(), FF.iteration_diagnostics["num_iterations"])
+    ctx = FF._DHT.context()
+    vis = ctypes.c_void_p()
+    Vre, Vim = np.ascontiguousarray(V.real), np.ascontiguousarray(V.imag)
+    _lib.check(_lib.lib.fh_vis_upload(0, _lib.ptr(u), _lib.ptr(v), _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), w.size,
+                                      u.size, ctypes.byref(vis)))
+    gm = _lib.make_geometry(geom())
+    slots = _lib.lib.fh_fit_slots()
+    assert slots >= 16
+    pending, done = [], 0
+    rng = np.random.default_rng(5)
+
+    def collect(entry):
+        t, ws = entry
+        mu, p, k = np.empty(N), np.empty(N), ctypes.c_int()
+        _lib.check(_lib.lib.fh_fit_collect(ctx, t, _lib.ptr(mu), _lib.ptr(p), ctypes.byref(k)))
+        assert k.value == sync[ws][1]
+        assert rel_to_max(mu, sync[ws][0]) < 1e-9
+
+    for i in range(150):
+        if len(pending) == slots:
+            collect(pending.pop(int(rng.integers(len(pending)))))  # any ticket, not the oldest
+            done += 1
+        ws = wss[i % 3]
+        _lib.check(_lib.lib.fh_bin_reset(ctx))
+        _lib.check(_lib.lib.fh_bin_visibilities(ctx, ctypes.byref(gm), vis, 0, u.size))
+        H0, q0, q1 = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(_lib.lib.fh_stats_finalize(ctx, ctypes.byref(gm), 0, 0, None, None, ctypes.byref(H0),
+                                              ctypes.byref(q0), ctypes.byref(q1)))
+        t = ctypes.c_int(-1)
+        _lib.check(_lib.lib.fh_fit_submit(ctx, 1.05, 1e-15, ws, 1e-3, 2000, ctypes.byref(t)))
+        pending.append((t.value, ws))
+    _lib.check(_lib.lib.fh_fit_flush(ctx))
+    while pending:
+        collect(pending.pop(int(rng.integers(len(pending)))))
+        done += 1
+    assert done == 150
+    _lib.lib.fh_vis_destroy(vis)
