@@ -66,6 +66,7 @@ SIGNATURES = {
     "fh_gaussian_model": (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, ctypes.POINTER(ctypes.c_int)]),
     "fh_cho_solve": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int]),
     "fh_svd_solve": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int]),
+    "fh_svd_solve_as_reference": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int]),
     "fh_fit_normal": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                      ctypes.c_double, ctypes.c_int, _dp, _dp, ctypes.POINTER(ctypes.c_int), _dp, _dp]),
     "fh_fit_normal_batched": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, _dp, _dp, _dp, ctypes.c_double, ctypes.c_int,

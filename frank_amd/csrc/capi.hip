@@ -821,7 +821,7 @@ static int solve_posterior(fh_ctx *c, const FitState &st, bool with_prior, bool 
 // 1150-1158):  U, s, V = svd(A);  X = V^T diag(where(s > 0, 1/s, 0)) U^T B.   A_dev: N*N row-major (destroyed),
 // B_dev: N*nrhs row-major, overwritten with X.  rocSOLVER factorises the column-major view A^T = U' S Vt', so
 // pinv(A) = U' S^+ Vt' and, on the column-major view of B (nrhs x N), X^T = B^T Vt'^T S^+ U'^T.
-static int svd_pinv_solve_device(fh_ctx *c, double *A_dev, double *B_dev, int nrhs) {
+static int svd_pinv_solve_device(fh_ctx *c, double *A_dev, double *B_dev, int nrhs, bool last_axis_scaling = false) {
     const int N = c->N;
     const size_t NN = (size_t)N * N;
     DevBuf<double> S, U, Vt, E, T;
@@ -838,7 +838,11 @@ static int svd_pinv_solve_device(fh_ctx *c, double *A_dev, double *B_dev, int nr
     const double one = 1.0, zero = 0.0;
     ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, nrhs, N, N, &one, B_dev, nrhs, Vt.p,
                           N, &zero, T.p, nrhs));
-    ROC_TRY(rocblas_ddgmm(c->blas, rocblas_side_right, nrhs, N, T.p, nrhs, S.p + N, 1, T.p, nrhs));
+    // T (nrhs x N column-major) = (U^T B)^T.  The pseudo-inverse scales singular direction i (a column here) by s1[i];
+    // the reference's `(U^T b) * s1` broadcasts s1 over the LAST axis of an N x N right-hand side instead, i.e. scales
+    // right-hand side c (a row here) by s1[c] (fh_svd_solve_as_reference)
+    if (last_axis_scaling && nrhs == N) ROC_TRY(rocblas_ddgmm(c->blas, rocblas_side_left, nrhs, N, T.p, nrhs, S.p + N, 1, T.p, nrhs));
+    else ROC_TRY(rocblas_ddgmm(c->blas, rocblas_side_right, nrhs, N, T.p, nrhs, S.p + N, 1, T.p, nrhs));
     ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, nrhs, N, N, &one, T.p, nrhs, U.p, N,
                           &zero, B_dev, nrhs));
     return FH_OK;
@@ -927,6 +931,23 @@ int fh_svd_solve(fh_ctx *c, const double *A, double *B, int nrhs) {
     HIP_TRY(hipMemcpyAsync(c->D.p, A, sizeof(double) * NN, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->scratch_out.p, B, sizeof(double) * nb, hipMemcpyHostToDevice, c->stream));
     int rc = svd_pinv_solve_device(c, c->D.p, c->scratch_out.p, nrhs);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(B, c->scratch_out.p, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
+int fh_svd_solve_as_reference(fh_ctx *c, const double *A, double *B, int nrhs) {
+    if (!c || !A || !B || nrhs < 1) return fail(FH_ERR_INVALID, "fh_svd_solve_as_reference: bad argument");
+    if (nrhs != 1 && nrhs != c->N)
+        return fail(FH_ERR_INVALID, "operands could not be broadcast together with shapes (%d,%d) (%d,)", c->N, nrhs, c->N);
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->N;
+    const size_t NN = (size_t)N * N, nb = (size_t)N * nrhs;
+    if (c->scratch_out.n < nb) HIP_TRY(c->scratch_out.alloc(nb));
+    HIP_TRY(hipMemcpyAsync(c->D.p, A, sizeof(double) * NN, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->scratch_out.p, B, sizeof(double) * nb, hipMemcpyHostToDevice, c->stream));
+    int rc = svd_pinv_solve_device(c, c->D.p, c->scratch_out.p, nrhs, true);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(B, c->scratch_out.p, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -48,11 +48,28 @@ class CriticalFilter:
                 _lib.ptr(_lib.f8(fit.power_spectrum)), float(self._alpha), float(self._p_0),
                 float(self._weights_smooth), _lib.ptr(p_new)))
             return p_new
-        _lib.check(_lib.lib.fh_update_power_spectrum(
+        rc = _lib.lib.fh_update_power_spectrum(
             self._DHT.context(), _lib.ptr(_lib.f8(fit._M)), _lib.ptr(_lib.f8(fit._j)),
             _lib.ptr(_lib.f8(fit.power_spectrum)), float(self._alpha), float(self._p_0),
-            float(self._weights_smooth), None, _lib.ptr(p_new)))
+            float(self._weights_smooth), None, _lib.ptr(p_new))
+        if rc == _lib.FH_ERR_NOT_SPD:
+            return self._update_through_dsolve(fit)
+        _lib.check(rc)
         return p_new
+
+    def _update_through_dsolve(self, fit):
+        """filter.py:154-177 spelled out with the posterior's own solves -- taken when the Cholesky of M + S^-1 fails and
+        `fit` went through the SVD pseudo-inverse (statistical_models.py:747-755): Tr1 = (Y mu)^2, Tr2_i = sum_j Y_ij
+        [D Y^T]_ji with D.b from fit.Dsolve (device SVD route), then the pentadiagonal solve on the host (O(N^3) dense
+        here: this path is the exception, not the loop)."""
+        Ykm = self._DHT.coefficients()
+        pi = fit.power_spectrum
+        Tr1 = np.dot(Ykm, fit.MAP) ** 2
+        Tr2 = np.einsum('ij,ji->i', Ykm, fit.Dsolve(Ykm.T))
+        beta = (self._p_0 + 0.5 * (Tr1 + Tr2)) / pi - (self._alpha - 1.0 + 0.5 * 1.0)
+        Tij_pI = np.asarray(self._Tij) + np.eye(self._DHT.size)
+        tau = np.linalg.solve(Tij_pI, beta + np.log(pi))
+        return np.exp(tau)
 
     def check_convergence(self, pi_new, pi_old):
         """filter.py:179-181"""

@@ -405,11 +405,17 @@ class GaussianModel:
 
 
 def _svd_solve(DHT, Dinv, b):
-    """V^T diag(where(s > 0, 1/s, 0)) U^T b with U, s, V = svd(Dinv): fh_svd_solve (rocSOLVER gesvd + rocBLAS)."""
+    """np.dot(V.T, np.multiply(np.dot(U.T, b), s1)) with U, s, V = svd(Dinv), s1 = where(s > 0, 1/s, 0), as the
+    reference writes it (statistical_models.py:779-781): rocSOLVER gesvd + rocBLAS on the device.  For a vector that is
+    the pseudo-inverse solve; for an N x N `b` NumPy broadcasts s1 over the last axis (column c times s1[c]) and the
+    reference's power-spectrum iteration runs on exactly that, so it is reproduced (fh_svd_solve_as_reference)."""
     b = np.asarray(b, dtype=np.float64)
     N = DHT.size
     B = np.array(b.reshape(N, -1), dtype=np.float64, order='C')
-    _lib.check(_lib.lib.fh_svd_solve(DHT.context(), _lib.ptr(_lib.f8(Dinv)), _lib.ptr(B), B.shape[1]))
+    if b.ndim > 1 and B.shape[1] != N:
+        raise ValueError("operands could not be broadcast together with shapes (%d,%d) (%d,) " % (N, B.shape[1], N))
+    entry = _lib.lib.fh_svd_solve if b.ndim == 1 else _lib.lib.fh_svd_solve_as_reference
+    _lib.check(entry(DHT.context(), _lib.ptr(_lib.f8(Dinv)), _lib.ptr(B), B.shape[1]))
     return B.reshape(b.shape)
 
 

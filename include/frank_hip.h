@@ -135,6 +135,12 @@ int fh_cho_solve(fh_ctx *ctx, const double *chol, double *B, int nrhs);
  * U, s, V = svd(A); X = V^T diag(where(s > 0, 1/s, 0)) U^T B, on the device (rocSOLVER gesvd + rocBLAS).
  * A: N*N row-major host; B: N*nrhs row-major host, overwritten with X.                                          */
 int fh_svd_solve(fh_ctx *ctx, const double *A, double *B, int nrhs);
+/* Dsolve(b) of a posterior whose Cholesky failed, EXACTLY as the reference evaluates it (statistical_models.py:779-781,
+ * 1181-1182): np.dot(V.T, np.multiply(np.dot(U.T, b), s1)).  NumPy broadcasts s1 over the LAST axis: for a vector b
+ * (nrhs = 1) this is fh_svd_solve; for the N x N right-hand side of update_power_spectrum (filter.py:168) it scales
+ * right-hand side c by s1[c] instead of singular direction k by s1[k] -- and the reference's iteration runs on that.
+ * Other widths cannot be broadcast: FH_ERR_INVALID (the reference raises ValueError).                            */
+int fh_svd_solve_as_reference(fh_ctx *ctx, const double *A, double *B, int nrhs);
 
 /* ---- a10/a14/a15/a16: the power-spectrum iteration = K2 `fit_iterate` --------------------------------------
  * FrankFitter._fit, method='Normal' (radial_fitters.py:737-832) with CriticalFilter.update_power_spectrum /

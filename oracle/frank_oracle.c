@@ -389,13 +389,13 @@ void fo_cho_solve_upper(int n, const double *U, double *B, int nrhs) {
     }
 }
 
-/* One-sided Jacobi SVD pseudo-inverse solve: the reference's fallback when cho_factor raises LinAlgError
- * [statistical_models.py:747-755]: U,s,V = svd(Dinv); mu = V^T ((U^T j) * where(s>0, 1/s, 0)).          */
-static void fo_svd_pinv_solve(int n, const double *A, const double *b, double *x) {
-    double *W = malloc(sizeof(double) * (size_t)n * n), *V = malloc(sizeof(double) * (size_t)n * n);
+/* One-sided Jacobi SVD, A = U diag(s) V^T with the singular values in DESCENDING order (LAPACK's convention, which
+ * the broadcasting quirk below makes observable).  Us = U diag(s) (n*n), V (n*n), s2[k] = s_k^2. */
+static void fo_svd_jacobi(int n, const double *A, double *Us, double *V, double *s2) {
+    double *W = malloc(sizeof(double) * (size_t)n * n), *Vw = malloc(sizeof(double) * (size_t)n * n);
     memcpy(W, A, sizeof(double) * (size_t)n * n);
     for (int i = 0; i < n; i++)
-        for (int k = 0; k < n; k++) V[(size_t)i * n + k] = (i == k);
+        for (int k = 0; k < n; k++) Vw[(size_t)i * n + k] = (i == k);
     for (int sweep = 0; sweep < 60; sweep++) {
         double off = 0;
         for (int p = 0; p < n - 1; p++)
@@ -409,30 +409,76 @@ static void fo_svd_pinv_solve(int n, const double *A, const double *b, double *x
                 off += fabs(ga) / sqrt(al * be);
                 double zeta = (be - al) / (2 * ga);
                 double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
-                double c = 1 / sqrt(1 + t * t), s = c * t;
+                double c = 1 / sqrt(1 + t * t), sn = c * t;
                 for (int i = 0; i < n; i++) {
                     double a = W[(size_t)i * n + p], d = W[(size_t)i * n + q];
-                    W[(size_t)i * n + p] = c * a - s * d; W[(size_t)i * n + q] = s * a + c * d;
-                    a = V[(size_t)i * n + p]; d = V[(size_t)i * n + q];
-                    V[(size_t)i * n + p] = c * a - s * d; V[(size_t)i * n + q] = s * a + c * d;
+                    W[(size_t)i * n + p] = c * a - sn * d; W[(size_t)i * n + q] = sn * a + c * d;
+                    a = Vw[(size_t)i * n + p]; d = Vw[(size_t)i * n + q];
+                    Vw[(size_t)i * n + p] = c * a - sn * d; Vw[(size_t)i * n + q] = sn * a + c * d;
                 }
             }
         if (off < 1e-15) break;
     }
-    /* A = W V^T with W = U diag(s): x = V diag(1/s) U^T b = sum_k V[:,k] (W[:,k].b)/s_k^2 */
-    for (int i = 0; i < n; i++) x[i] = 0;
-    double smax = 0;
+    int *ord = malloc(sizeof(int) * n);
+    double *raw = malloc(sizeof(double) * n);
     for (int k = 0; k < n; k++) {
-        double s2 = 0;
-        for (int i = 0; i < n; i++) s2 += W[(size_t)i * n + k] * W[(size_t)i * n + k];
-        if (s2 > smax) smax = s2;
+        double t = 0;
+        for (int i = 0; i < n; i++) t += W[(size_t)i * n + k] * W[(size_t)i * n + k];
+        raw[k] = t;
+        ord[k] = k;
+    }
+    for (int a = 1; a < n; a++) { /* insertion sort, descending, stable */
+        int o = ord[a], b = a - 1;
+        while (b >= 0 && raw[ord[b]] < raw[o]) { ord[b + 1] = ord[b]; b--; }
+        ord[b + 1] = o;
     }
     for (int k = 0; k < n; k++) {
-        double s2 = 0, wb = 0;
-        for (int i = 0; i < n; i++) { s2 += W[(size_t)i * n + k] * W[(size_t)i * n + k]; wb += W[(size_t)i * n + k] * b[i]; }
-        if (s2 > 0) for (int i = 0; i < n; i++) x[i] += V[(size_t)i * n + k] * (wb / s2);
+        s2[k] = raw[ord[k]];
+        for (int i = 0; i < n; i++) {
+            Us[(size_t)i * n + k] = W[(size_t)i * n + ord[k]];
+            V[(size_t)i * n + k] = Vw[(size_t)i * n + ord[k]];
+        }
     }
-    free(W); free(V);
+    free(W); free(Vw); free(ord); free(raw);
+}
+
+/* The reference's route when cho_factor raises LinAlgError [statistical_models.py:747-755, 779-781]:
+ *   U, s, V = svd(Dinv);  s1 = where(s > 0, 1/s, 0);  x = V^T ((U^T b) * s1).
+ * B: n*nrhs row-major, overwritten.  `*` is NumPy's element-wise product: s1 broadcasts over the LAST axis.  For a
+ * vector b that is diag(s1) (U^T b), the pseudo-inverse solve.  For the N x N right-hand side of
+ * CriticalFilter.update_power_spectrum (fit.Dsolve(Ykm.T), filter.py:168) it multiplies COLUMN c of U^T b by s1[c]
+ * -- not row k by s1[k] -- and that is what the reference's loop then iterates on; `as_reference` != 0 reproduces it
+ * (nrhs must be n), 0 gives the pseudo-inverse solve for every column. */
+void fo_svd_solve(int n, const double *A, double *B, int nrhs, int as_reference) {
+    size_t nn = (size_t)n * n;
+    double *Us = malloc(sizeof(double) * nn), *V = malloc(sizeof(double) * nn), *s2 = malloc(sizeof(double) * n);
+    double *T = malloc(sizeof(double) * (size_t)n * nrhs);
+    fo_svd_jacobi(n, A, Us, V, s2);
+    for (int k = 0; k < n; k++) { /* T = U^T B, U[:,k] = Us[:,k] / s_k */
+        double sk = sqrt(s2[k]);
+        for (int c = 0; c < nrhs; c++) {
+            double a = 0;
+            for (int i = 0; i < n; i++) a += Us[(size_t)i * n + k] * B[(size_t)i * nrhs + c];
+            T[(size_t)k * nrhs + c] = sk > 0 ? a / sk : 0.0;
+        }
+    }
+    for (int k = 0; k < n; k++)
+        for (int c = 0; c < nrhs; c++) {
+            double sv = sqrt(s2[(as_reference && nrhs > 1) ? c : k]);
+            T[(size_t)k * nrhs + c] *= sv > 0 ? 1.0 / sv : 0.0;
+        }
+    for (int i = 0; i < n; i++) /* x = V T  (scipy's V is V^T here) */
+        for (int c = 0; c < nrhs; c++) {
+            double a = 0;
+            for (int k = 0; k < n; k++) a += V[(size_t)i * n + k] * T[(size_t)k * nrhs + c];
+            B[(size_t)i * nrhs + c] = a;
+        }
+    free(Us); free(V); free(s2); free(T);
+}
+
+static void fo_svd_pinv_solve(int n, const double *A, const double *b, double *x) {
+    memcpy(x, b, sizeof(double) * n);
+    fo_svd_solve(n, A, x, 1, 0);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -441,7 +487,7 @@ static void fo_svd_pinv_solve(int n, const double *A, const double *b, double *x
 /*   chol (upper) is returned in `chol` (N*N, upper triangle valid); p may   */
 /*   be NULL (no prior, as FourierBesselFitter._fit, radial_fitters.py:576). */
 /* Returns FO_OK, FO_ERR_BAD_P, or FO_ERR_NOT_SPD (mu then from the SVD      */
-/* pseudo-inverse and chol is not valid).                                    */
+/* pseudo-inverse; `chol` then holds Dinv itself, for the SVD-route Dsolve). */
 /* ------------------------------------------------------------------------ */
 int fo_gaussian_model(int N, const double *Y, const double *M, const double *j, const double *p, double *mu,
                       double *chol, double *Sinv_out) {
@@ -478,6 +524,7 @@ int fo_gaussian_model(int N, const double *Y, const double *M, const double *j, 
         return FO_OK;
     }
     fo_svd_pinv_solve(N, keep, j, mu);
+    memcpy(chol, keep, sizeof(double) * NN); /* the SVD route works on Dinv itself: hand it back */
     free(keep);
     return FO_ERR_NOT_SPD;
 }
@@ -551,8 +598,8 @@ void fo_penta_solve(int N, const double *band, const double *rhs, double *x) {
 /* CriticalFilter.update_power_spectrum  [filter.py:154-177]                 */
 /*   needs the posterior of the current fit: mu, upper Cholesky of Dinv.     */
 /* ------------------------------------------------------------------------ */
-void fo_update_power_spectrum(int N, const double *Y, const double *band, double alpha, double p0, const double *p,
-                              const double *mu, const double *chol, double *p_new) {
+void fo_update_power_spectrum_ex(int N, const double *Y, const double *band, double alpha, double p0, const double *p,
+                                 const double *mu, const double *chol, int svd_route, double *p_new) {
     size_t NN = (size_t)N * N;
     double *Tr1 = malloc(sizeof(double) * N), *Tr2 = malloc(sizeof(double) * N);
     double *Z = malloc(sizeof(double) * NN), *rhs = malloc(sizeof(double) * N), *tau = malloc(sizeof(double) * N);
@@ -563,7 +610,8 @@ void fo_update_power_spectrum(int N, const double *Y, const double *band, double
     }
     for (int i = 0; i < N; i++) /* Z = Y^T */
         for (int k = 0; k < N; k++) Z[(size_t)k * N + i] = Y[(size_t)i * N + k];
-    fo_cho_solve_upper(N, chol, Z, N); /* Dsolve(Ykm.T), :168 */
+    if (svd_route) fo_svd_solve(N, chol, Z, N, 1); /* Dsolve(Ykm.T) of a fit whose Cholesky failed: chol = Dinv */
+    else fo_cho_solve_upper(N, chol, Z, N);      /* Dsolve(Ykm.T), :168 */
     for (int i = 0; i < N; i++) {
         double a = 0;
         for (int k = 0; k < N; k++) a += Y[(size_t)i * N + k] * Z[(size_t)k * N + i];
@@ -577,6 +625,11 @@ void fo_update_power_spectrum(int N, const double *Y, const double *band, double
     fo_penta_solve(N, band, rhs, tau);
     for (int i = 0; i < N; i++) p_new[i] = exp(tau[i]); /* :177 */
     free(Tr1); free(Tr2); free(Z); free(rhs); free(tau);
+}
+
+void fo_update_power_spectrum(int N, const double *Y, const double *band, double alpha, double p0, const double *p,
+                              const double *mu, const double *chol, double *p_new) {
+    fo_update_power_spectrum_ex(N, Y, band, alpha, p0, p, mu, chol, 0, p_new);
 }
 
 /* CriticalFilter.check_convergence  [filter.py:179-181] */
@@ -617,17 +670,18 @@ int fo_frank_fit_normal(int N, double Rmax, const double *M, const double *j, do
     for (int k = 0; k < N; k++) { double t = tmp[k] * tmp[k]; if (t > pmax) pmax = t; }
     for (int k = 0; k < N; k++) pI[k] = pmax * pow(q[k] / q[0], -2.0); /* :750 */
     rc = fo_gaussian_model(N, Y, M, j, pI, mu, chol, NULL); /* :752 */
-    if (rc == FO_ERR_NOT_SPD) { nsvd++; rc = FO_OK; }
+    int svd_now = 0; /* the current fit went through the SVD (its Dsolve does too, :779-781) */
+    if (rc == FO_ERR_NOT_SPD) { nsvd++; svd_now = 1; rc = FO_OK; }
     if (rc != FO_OK) goto done;
 
     int count = 0;
     for (int k = 0; k < N; k++) pold[k] = 0.0; /* :768 pi_old = 0 */
     while (!fo_check_convergence(N, pI, pold, tol) && count <= max_iter) { /* :769-770 */
         memcpy(pold, pI, sizeof(double) * N);
-        if (nsvd) { rc = FO_ERR_NOT_SPD; goto done; } /* Dsolve through the SVD is not restated */
-        fo_update_power_spectrum(N, Y, band, alpha, p0, pold, mu, chol, pI); /* :777 */
-        rc = fo_gaussian_model(N, Y, M, j, pI, mu, chol, NULL);                /* :779 */
-        if (rc == FO_ERR_NOT_SPD) { nsvd++; rc = FO_OK; }
+        fo_update_power_spectrum_ex(N, Y, band, alpha, p0, pold, mu, chol, svd_now, pI); /* :777 */
+        rc = fo_gaussian_model(N, Y, M, j, pI, mu, chol, NULL);                            /* :779 */
+        svd_now = 0;
+        if (rc == FO_ERR_NOT_SPD) { nsvd++; svd_now = 1; rc = FO_OK; }
         if (rc != FO_OK) goto done;
         if (diag_p) memcpy(diag_p + (size_t)count * N, pI, sizeof(double) * N);
         if (diag_mu) memcpy(diag_mu + (size_t)count * N, mu, sizeof(double) * N);

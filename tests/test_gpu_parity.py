@@ -773,10 +773,14 @@ def test_svd_route_when_cholesky_fails(golden):
     s1 = np.where(s > 0, 1. / s, 0)
     expect = np.dot(V.T, s1 * np.dot(U.T, j))
     assert rel_to_max(fit.mean, expect) < 1e-7
-    B = np.random.default_rng(3).normal(size=(N, 3))
+    # a matrix right-hand side goes through NumPy's broadcasting exactly as the reference writes it (:781): s1 runs
+    # over the LAST axis, so an N x N `b` has column c scaled by s1[c], and any other width cannot be broadcast
+    B = np.random.default_rng(3).normal(size=(N, N))
     X = fit.Dsolve(B)
-    assert rel_to_max(X, np.dot(V.T, (s1 * np.dot(U.T, B).T).T)) < 1e-7
-    assert fit.covariance.shape == (N, N)
+    assert rel_to_max(X, np.dot(V.T, np.multiply(np.dot(U.T, B), s1))) < 1e-7
+    with pytest.raises(ValueError):
+        fit.Dsolve(B[:, :3])
+    assert rel_to_max(fit.covariance, np.dot(V.T, np.multiply(np.dot(U.T, np.eye(N)), s1))) < 1e-7
 
 
 @pytest.mark.parametrize("n,N", [(30, 100), (50, 300)])
@@ -916,3 +920,23 @@ def test_pipeline_bookkeeping_many_fits_out_of_order():
         done += 1
     assert done == 150
     _lib.lib.fh_vis_destroy(vis)
+
+
+def test_loop_continues_through_the_svd_route(golden):
+    """An indefinite M makes every Cholesky of the loop fail; the reference carries on through the SVD pseudo-inverse
+    (statistical_models.py:747-755, fixture: 28 SVD solves, 26 passes at max_iter=25).  The fused device loop reports
+    the failure and the fit continues one posterior at a time (device SVD solves): same pass count, same spectrum."""
+    from frank_amd import FrankFitter
+    g = golden("svd_loop_N24.npz")
+    N = int(g["N"])
+    FF = FrankFitter(2.0, N, geom(), store_iteration_diagnostics=True, verbose=False, max_iter=int(g["max_iter"]),
+                     convergence_failure="ignore", check_qbounds=False)
+    m = {'mult_freq': False, 'channels': None, 'M': g["M"], 'j': g["j"], 'null_likelihood': float(g["H0"]),
+         'hash': [False, FF._DHT, FF._geometry, 'opt_thick', None]}
+    sol = FF.fit_preprocessed(m)
+    d = FF.iteration_diagnostics
+    assert d["num_iterations"] == int(g["niter"])
+    assert rel_to_max(np.array(d["power_spectrum"][0]), g["diag_p"][0]) < 1e-6
+    assert rel_to_max(np.array(d["MAP"][0]), g["diag_mu"][0]) < 1e-6
+    assert rel_to_max(sol.I, g["I"]) < 1e-5
+    assert np.max(np.abs(np.log(sol.power_spectrum / g["p"]))) < 1e-4

@@ -292,3 +292,17 @@ def test_debris_mapping(golden):
     out = fo.frank_fit_normal(40, RMAX, m["M"], m["j"], alpha=float(g["alpha"]), wsmooth=float(g["wsmooth"]))
     assert out["niter"] == int(g["niter"])
     assert rel_to_max(out["mu"], g["I"]) < 1e-6
+
+
+def test_oracle_loop_through_the_svd_route(golden):
+    """An indefinite M: every cho_factor of the loop raises and the reference iterates through its SVD route, whose Dsolve
+    of the N x N right-hand side broadcasts 1/s over the last axis (statistical_models.py:747-755, 779-781; fixture
+    tools/make_golden.py::svd_loop, 28 SVD solves).  The oracle restates exactly that."""
+    from oracle import oracle as fo
+    from frank_amd.constants import rad_to_arcsec
+    g = golden("svd_loop_N24.npz")
+    N = int(g["N"])
+    out = fo.frank_fit_normal(N, 2.0 / rad_to_arcsec, g["M"], g["j"], max_iter=int(g["max_iter"]))
+    assert out["rc"] == 0 and out["niter"] == int(g["niter"]) and out["n_svd"] == int(g["n_svd"])
+    assert np.max(np.abs(np.log(out["p"] / g["p"]))) < 1e-9
+    assert np.max(np.abs(out["mu"] - g["I"])) < 1e-9 * np.max(np.abs(g["I"]))

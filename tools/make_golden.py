@@ -256,6 +256,43 @@ def wide():
     fit_case("fit_N320_5e4.npz", 320, 5e4, 1.05, 1e-4, keep_M=False, seed=8, noise_seed=9)
 
 
+def svd_loop():
+    """The iteration when the Cholesky of M + S^-1 fails (statistical_models.py:747-755, 779-781): an indefinite M (one
+    eigenvalue of a real M flipped) sends every solve of the loop through the SVD pseudo-inverse."""
+    import warnings
+    N, n, max_iter = 24, 4000, 25
+    print("FrankFitter loop on an indefinite M: N=%d, %d iterations through the SVD route" % (N, max_iter))
+    u, v, V, w = mock_disc_visibilities(n, seed=61, noise_seed=62)
+    FF = FrankFitter(RMAX, N, geom(), store_iteration_diagnostics=True, verbose=False, max_iter=max_iter,
+                     convergence_failure="ignore", check_qbounds=False)
+    m = FF.preprocess_visibilities(u, v, V, w)
+    lam, vec = np.linalg.eigh(m["M"])
+    k = N - 1  # the largest: M + S^-1 stays indefinite while the power spectrum settles
+    M2 = m["M"] - 2.0 * lam[k] * np.outer(vec[:, k], vec[:, k])   # eigenvalue k -> -lam[k]
+    M2 = 0.5 * (M2 + M2.T)
+    m2 = dict(m)
+    m2["M"] = M2
+    ncalls = [0]
+    import frank.statistical_models as sm
+    orig = sm.scipy.linalg.svd
+
+    def counting_svd(*a, **kw):
+        ncalls[0] += 1
+        return orig(*a, **kw)
+    sm.scipy.linalg.svd = counting_svd
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sol = FF.fit_preprocessed(m2)
+    finally:
+        sm.scipy.linalg.svd = orig
+    d = FF.iteration_diagnostics
+    print("    num_iterations=%d, svd calls=%d, min eig(M2)=%.3e" % (d["num_iterations"], ncalls[0], np.linalg.eigvalsh(M2).min()))
+    save("svd_loop_N24.npz", N=N, n=n, max_iter=max_iter, M=M2, j=m["j"], H0=m["null_likelihood"], I=sol.I,
+         p=sol.power_spectrum, niter=d["num_iterations"], n_svd=ncalls[0], diag_p=np.array(d["power_spectrum"]),
+         diag_mu=np.array(d["MAP"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
