@@ -43,6 +43,10 @@ def sweep_fits(fitter, preproc_vis, alphas, weights_smooth, p_0=None, tol=1e-3, 
     for b in range(B):
         if status[b] == _lib.FH_ERR_BAD_P:
             raise ValueError(_BAD_P_MSG)
+        if status[b] == _lib.FH_ERR_NOT_SPD:
+            # a Cholesky of this point's loop failed: continue it the way the reference does, through the SVD route
+            sols.append(_refit_through_svd_route(fitter, float(alphas[b]), float(p0[b]), float(ws[b]), tol, max_iter, niter, b))
+            continue
         if status[b] != _lib.FH_OK:
             raise RuntimeError("fit %d of the sweep failed (status %d)" % (b, status[b]))
         fit = GaussianModel._from_solution(fitter._DHT, fitter._M, fitter._j, p[b].copy(), mu[b].copy(),
@@ -50,6 +54,22 @@ def sweep_fits(fitter, preproc_vis, alphas, weights_smooth, p_0=None, tol=1e-3, 
         info = dict(fitter._info, alpha=float(alphas[b]), wsmooth=float(ws[b]), p0=float(p0[b]))
         sols.append(FrankGaussianFit(fitter._vis_map, fit, info, geometry=fitter._geometry.clone()))
     return sols, [int(n) for n in niter]
+
+
+def _refit_through_svd_route(fitter, alpha, p_0, wsmooth, tol, max_iter, niter, b):
+    """One point of a sweep whose device loop hit a failed Cholesky: FrankFitter._fit_one_posterior_at_a_time with this
+    point's hyper-parameters (statistical_models.py:747-755 semantics)."""
+    import copy
+    from frank_amd.filter import CriticalFilter
+    sub = copy.copy(fitter)
+    sub._filter = CriticalFilter(fitter._DHT, alpha, p_0, wsmooth, tol)
+    sub._max_iter = int(max_iter)
+    sub._info = dict(fitter._info, alpha=alpha, wsmooth=wsmooth, p0=p_0)
+    sub._store_iteration_diagnostics = True
+    sub._convergence_failure = 'ignore'  # the sweep reports iteration counts; its caller applies the policy
+    sol = sub._fit_one_posterior_at_a_time()
+    niter[b] = sub._iteration_diagnostics['num_iterations']
+    return sol
 
 
 def _sweep_lognormal(fitter, M, j, alphas, ws, p0, tol, max_iter):

@@ -940,3 +940,25 @@ def test_loop_continues_through_the_svd_route(golden):
     assert rel_to_max(np.array(d["MAP"][0]), g["diag_mu"][0]) < 1e-6
     assert rel_to_max(sol.I, g["I"]) < 1e-5
     assert np.max(np.abs(np.log(sol.power_spectrum / g["p"]))) < 1e-4
+
+
+def test_sweep_point_continues_through_the_svd_route(golden):
+    """A sweep over the indefinite-M fixture: every point's device loop stops at a failed Cholesky and is continued through
+    the SVD route, giving what the single fit of that point gives (and the reference's result for its own point)."""
+    from frank_amd import FrankFitter
+    from frank_amd.sweep import sweep_fits
+    g = golden("svd_loop_N24.npz")
+    N = int(g["N"])
+    FF = FrankFitter(2.0, N, geom(), verbose=False, max_iter=int(g["max_iter"]), convergence_failure="ignore",
+                     check_qbounds=False)
+    m = {'mult_freq': False, 'channels': None, 'M': g["M"], 'j': g["j"], 'null_likelihood': float(g["H0"]),
+         'hash': [False, FF._DHT, FF._geometry, 'opt_thick', None]}
+    sols, nits = sweep_fits(FF, m, [1.05, 1.3], [1e-4, 1e-2], max_iter=int(g["max_iter"]))
+    assert nits[0] == int(g["niter"])
+    assert rel_to_max(sols[0].I, g["I"]) < 1e-5
+    FF2 = FrankFitter(2.0, N, geom(), alpha=1.3, weights_smooth=1e-2, verbose=False, max_iter=int(g["max_iter"]),
+                      convergence_failure="ignore", check_qbounds=False, store_iteration_diagnostics=True)
+    m2 = dict(m, hash=[False, FF2._DHT, FF2._geometry, 'opt_thick', None])
+    ref = FF2.fit_preprocessed(m2)
+    assert nits[1] == FF2.iteration_diagnostics["num_iterations"]
+    assert rel_to_max(sols[1].I, ref.I) < 1e-9
