@@ -13,10 +13,18 @@ Nothing is cached between steps.  `value` = fits completed by all ranks / max-ov
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Multi-GPU: fits are independent objects, so each rank fits its own 1e7-visibility dataset (weak
-scaling, no data-path collective).  The sharded-visibility path with the RCCL all-reduce of the
-(N^2+N)-sized sufficient statistics (BASELINE.json configs[3]) is timed separately and reported under
-"sharded_fit".  torch is used ONLY for the rendezvous / barrier / max-over-ranks (gloo, CPU tensors);
-the data path is libfrank_hip + RCCL.
+scaling, no data-path collective): that is `value`.  Whenever WORLD_SIZE > 1 the sharded-visibility path
+(BASELINE.json configs[3]: ONE fit of 1e8 visibilities sharded over the ranks, RCCL all-reduce over xGMI of
+the packed (N^2+N)-sized sufficient statistics) is timed after the headline region and reported under
+"sharded_fit" -- inside a watchdog, so that a collective problem costs that key, never the headline line.
+torch is used ONLY for the rendezvous / barrier / max-over-ranks (gloo, CPU tensors); the data path is
+libfrank_hip + RCCL.
+
+Rank 0 at N=1 also reports, outside the timed region and bounded to about a minute in total:
+  extra.lognormal_fullsize   BASELINE configs[2] (N=300, 1e7 visibilities, LogNormal) on the resident table
+  extra.sweep512             BASELINE configs[4] on one GPU (512 fits of one 1e6-visibility mapping)
+  extra.uvbin                UVDataBinner streaming passes at 1e7 rows (HBM roofline)
+  cpu_baseline               the CPU oracle on one core and on all host cores (independent fits per core)
 """
 import argparse
 import ctypes
@@ -36,6 +44,7 @@ RMAX_ARCSEC = 2.0
 HYPER = dict(alpha=1.05, p0=1e-15, wsmooth=1e-4, tol=1e-3, max_iter=2000)
 # roofline constants: MI355X fp64 matrix peak (AMD CDNA4 datasheet; the microarch guide lists no fp64 MFMA row)
 FP64_MFMA_PEAK_TFLOPS = 78.6
+K1_KERNEL_NAME = "bin_gram_kernel<19>"
 
 
 def parse():
@@ -48,9 +57,12 @@ def parse():
     ap.add_argument("--nvis", type=int, default=N_VIS)
     ap.add_argument("--ncoll", type=int, default=N_COLL)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sharded", action="store_true",
-                    help="also time BASELINE configs[3] (one fit sharded over the ranks, RCCL all-reduce); opt-in so "
-                         "that a collective problem can never cost the headline line")
+    ap.add_argument("--no-sharded", action="store_true",
+                    help="skip the BASELINE configs[3] leg (one fit sharded over the ranks, RCCL all-reduce) that "
+                         "otherwise runs whenever WORLD_SIZE > 1")
+    ap.add_argument("--sharded-total", type=float, default=1e8, help="visibilities of the sharded fit (all ranks)")
+    ap.add_argument("--sharded-cap", type=float, default=2.5e7, help="most visibilities one rank generates / holds")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (extra.*)")
     return ap.parse_args()
 
 
@@ -72,6 +84,7 @@ class Fitter:
         self.niter = ctypes.c_int(0)
         self.vis = None
         self.n = 0
+        self.nfit = 0
 
     def upload(self, u, v, V, w):
         L = self.L
@@ -80,11 +93,14 @@ class Fitter:
         L.check(L.lib.fh_vis_upload(self.device, L.ptr(u), L.ptr(v), L.ptr(Vre), L.ptr(Vim), L.ptr(w), w.size, u.size,
                                     ctypes.byref(vis)))
         self.vis, self.n = vis, u.size
+        if not getattr(self, "nfit", 0):
+            self.nfit = u.size  # rows of one headline fit (the table may hold more, for the sharded leg)
 
-    def bin(self):
+    def bin(self, count=None):
         L = self.L
         L.check(L.lib.fh_bin_reset(self.ctx))
-        L.check(L.lib.fh_bin_visibilities(self.ctx, ctypes.byref(self.geom), self.vis, 0, self.n))
+        L.check(L.lib.fh_bin_visibilities(self.ctx, ctypes.byref(self.geom), self.vis, 0,
+                                          self.nfit if count is None else count))
 
     def kernel_ms(self):
         ms = ctypes.c_float(0)
@@ -143,29 +159,180 @@ class Fitter:
         self.L.check(self.L.lib.fh_ctx_synchronize(self.ctx))
 
 
-def cpu_baseline(ncoll, nvis, gpu_niter):
-    """The CPU oracle (oracle/frank_oracle.c, a single-threaded port of the reference path) on a bounded sample."""
+def _cpu_leg(args):
+    """One worker of the CPU baseline: the oracle's map_visibilities on `ns` visibilities and `it` power-spectrum
+    iterations, timed separately.  Runs in a fresh interpreter (spawn): no GPU state, imports only numpy + oracle."""
+    ncoll, ns, it, seed = args
     from frank_amd.constants import rad_to_arcsec
     from frank_amd.mock import MOCK_GEOMETRY, mock_disc_visibilities
     from oracle import oracle as fo
     g = MOCK_GEOMETRY
     geom = (g["inc"], g["PA"], g["dRA"], g["dDec"])
-    ns = min(nvis, 100_000 if ncoll >= 200 else 400_000)
-    u, v, V, w = mock_disc_visibilities(ns, seed=0, noise_seed=50)
+    u, v, V, w = mock_disc_visibilities(ns, seed=seed, noise_seed=50 + seed)
     t0 = time.perf_counter()
     m = fo.map_visibilities(ncoll, RMAX_ARCSEC / rad_to_arcsec, geom, u, v, V, w)
     t_map = time.perf_counter() - t0
-    it = 150
     t0 = time.perf_counter()
     out = fo.frank_fit_normal(ncoll, RMAX_ARCSEC / rad_to_arcsec, m["M"], m["j"], max_iter=it, **{
         k: HYPER[k] for k in ("alpha", "p0", "wsmooth", "tol")})
     t_it = (time.perf_counter() - t0) / max(out["niter"], 1)
-    t_fit_total = t_map * (nvis / ns) + t_it * gpu_niter
-    return {"value": 1.0 / t_fit_total, "unit": "fits/s", "cores": 1, "kind": "port",
-            "sample": "oracle map_visibilities on %d of %d visibilities (%.1f s, scaled linearly) + %d of the %d "
-                      "power-spectrum iterations (%.1f ms/iteration, scaled)" % (ns, nvis, t_map, out["niter"],
-                                                                               gpu_niter, 1e3 * t_it),
-            "s_per_fit": t_fit_total}
+    return t_map, t_it, out["niter"]
+
+
+def cpu_baseline(ncoll, nvis, gpu_niter):
+    """The CPU oracle (oracle/frank_oracle.c, a single-threaded port of the reference path) on a bounded sample of the
+    same workload: first alone on one core, then one copy on every host core at once (independent fits are the unit of
+    work, so a node's CPU throughput is cores / seconds-per-fit with all cores loaded)."""
+    ns = min(nvis, 100_000 if ncoll >= 200 else 400_000)
+    it = 150
+    t_map, t_it, nit = _cpu_leg((ncoll, ns, it, 0))
+    t_fit = t_map * (nvis / ns) + t_it * gpu_niter
+    out = {"value": 1.0 / t_fit, "unit": "fits/s", "cores": 1, "kind": "port",
+           "sample": "oracle map_visibilities on %d of %d visibilities (%.1f s, scaled linearly) + %d of the %d "
+                     "power-spectrum iterations (%.1f ms/iteration, scaled)" % (ns, nvis, t_map, nit, gpu_niter, 1e3 * t_it),
+           "s_per_fit": t_fit,
+           "reference_s_per_fit": 196.0,
+           "reference_note": "the reference itself (NumPy/SciPy + BLAS, 1 thread) measured in the build container: "
+                             "196 s/fit (BASELINE.md); the naive-loop C port is slower than that, quote 196 s"}
+    try:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        cores = os.cpu_count() or 1
+        workers = max(1, min(cores, 256))
+        with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as pool:
+            res = list(pool.map(_cpu_leg, [(ncoll, ns, it, 1 + k) for k in range(workers)]))
+        tm = float(np.median([r[0] for r in res]))
+        ti = float(np.median([r[1] for r in res]))
+        t_loaded = tm * (nvis / ns) + ti * gpu_niter
+        out["all_cores"] = {"value": workers / t_loaded, "unit": "fits/s", "cores": workers, "host_cpus": cores,
+                            "s_per_fit_per_core_loaded": t_loaded,
+                            "sample": "%d concurrent single-thread copies of the sample above (median %.1f s map, "
+                                      "%.1f ms/iteration), one independent fit per core" % (workers, tm, 1e3 * ti)}
+    except Exception as e:  # the one-core figure stands on its own
+        out["all_cores"] = {"error": repr(e)}
+    return out
+
+
+def extras(f, L, a):
+    """Secondary workloads on rank 0 at N=1, after the timed region (bounded: ~16 s LogNormal + ~2 s sweep + ~2 s)."""
+    ex = {}
+    N = a.ncoll
+    h = HYPER
+    H0, qmn, qmx = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+
+    def finalize():
+        L.check(L.lib.fh_stats_finalize(f.ctx, ctypes.byref(f.geom), 0, 1, None, None, ctypes.byref(H0),
+                                        ctypes.byref(qmn), ctypes.byref(qmx)))
+    # -- BASELINE configs[2]: LogNormal fit (alpha = 1.3, w_smooth = 1e-2 as the reference's own LogNormal test,
+    #    tests.py:350) of the resident table, end to end
+    try:
+        s_map, p = np.empty(N), np.empty(N)
+        nit = ctypes.c_int(0)
+        stats = (ctypes.c_int64 * 9)()
+        t0 = time.perf_counter()
+        f.bin()
+        finalize()
+        t1 = time.perf_counter()
+        L.check(L.lib.fh_fit_lognormal(f.ctx, None, None, 1.3, 1e-35, 1e-2, h["tol"], h["max_iter"], 1e5, L.ptr(s_map),
+                                       L.ptr(p), ctypes.byref(nit), None, stats, None, None))
+        t2 = time.perf_counter()
+        I = np.exp(s_map + np.log(1e5))
+        ex["lognormal_fullsize"] = {"workload": "BASELINE configs[2]: N=%d, %d visibilities, LogNormal, alpha=1.3, "
+                                                "w_smooth=1e-2, fp64 arithmetic" % (N, f.nfit),
+                                    "s_per_fit": t2 - t0, "bin_s": t1 - t0, "fit_s": t2 - t1,
+                                    "power_spectrum_iterations": nit.value, "newton_steps": int(stats[1]),
+                                    "hessian_factorisations": int(stats[3]), "I_min": float(I.min()),
+                                    "I_max": float(I.max()), "finite": bool(np.all(np.isfinite(I)))}
+    except Exception as e:
+        ex["lognormal_fullsize"] = {"error": repr(e)}
+    # -- BASELINE configs[4] on one GPU: 512 fits (32 alpha x 16 w_smooth) of ONE mapping of 1e6 visibilities
+    try:
+        al, ws = np.meshgrid(np.linspace(1.01, 1.5, 32), np.logspace(-4, -1, 16))
+        al, ws = np.ascontiguousarray(al.ravel()), np.ascontiguousarray(ws.ravel())
+        B = al.size
+        p0 = np.full(B, h["p0"])
+        mu, pp = np.empty((B, N)), np.empty((B, N))
+        niter = (ctypes.c_int * B)()
+        status = (ctypes.c_int * B)()
+        nv = min(f.n, 1_000_000)
+        t0 = time.perf_counter()
+        f.bin(nv)
+        finalize()
+        L.check(L.lib.fh_fit_normal_batched(f.ctx, None, None, B, L.ptr(al), L.ptr(p0), L.ptr(ws), h["tol"],
+                                            h["max_iter"], L.ptr(mu), L.ptr(pp), niter, status))
+        dt = time.perf_counter() - t0
+        its = np.array(list(niter))
+        ex["sweep512"] = {"workload": "BASELINE configs[4] on ONE GPU: %d fits (alpha x w_smooth grid), N=%d, %d "
+                                      "visibilities, shared (M, j) as fit.py:534-548" % (B, N, nv),
+                          "fits_per_s": B / dt, "s_total": dt,
+                          "iterations_min_median_max": [int(its.min()), int(np.median(its)), int(its.max())],
+                          "failed": int(np.sum(np.array(list(status)) != 0)),
+                          "not_converged": int(np.sum(its >= h["max_iter"]))}
+    except Exception as e:
+        ex["sweep512"] = {"error": repr(e)}
+    # -- UVDataBinner (next-tier row f4): three streaming passes, 72 algorithmic bytes per row
+    try:
+        from frank_amd.utilities import UVDataBinner
+        n = 10_000_000
+        rng = np.random.default_rng(0)
+        q = np.exp(rng.uniform(np.log(1e4), np.log(2e6), n))
+        V = rng.normal(size=n) + 1j * rng.normal(size=n)
+        w = rng.uniform(0.5, 2.0, n)
+        best = None
+        for _ in range(3):
+            b = UVDataBinner(q, V, w, 2e4)
+            k = float(L.lib.fh_uvbin_kernel_ms(b._handle))
+            best = k if best is None else min(best, k)
+        gbps = 72.0 * n / best / 1e6
+        ex["uvbin"] = {"workload": "UVDataBinner, %d rows, %d bins" % (n, len(b)), "kernels_ms": best,
+                       "roofline": {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s",
+                                    "frac": gbps / 8000.0, "algorithmic_bytes_per_row": 72}}
+    except Exception as e:
+        ex["uvbin"] = {"error": repr(e)}
+    return ex
+
+
+def sharded_leg(f, L, a, dist, rank, world, local_rank, barrier, out):
+    """BASELINE configs[3]: ONE fit whose visibilities are sharded over the ranks (contiguous slabs, SURVEY 8(e));
+    every rank bins its slab, ONE RCCL all-reduce sums the packed upper-triangle Gram + scalars (and a 2-double
+    max-reduce the baseline range), then every rank holds M, j and solves (rank 0's solve is the fit)."""
+    import torch
+    from frank_amd.distributed import RcclComm
+
+    def bcast(ident):
+        t = torch.tensor(list(ident if ident is not None else bytes(128)), dtype=torch.uint8)
+        dist.broadcast(t, 0)
+        return bytes(t.tolist())
+    comm = RcclComm(rank, world, f.device, bcast)
+    shard = f.n_shard
+    times, ar_ms, bin_ms = [], [], []
+    nit_s = 0
+    for i in range(4):  # the first pass warms RCCL's channels up and is not reported
+        barrier()
+        t0 = time.perf_counter()
+        f.bin(shard)
+        comm.allreduce_stats(f.ctx)
+        nit_s = f.solve()
+        f.sync()
+        barrier()
+        if i:
+            times.append(time.perf_counter() - t0)
+            ar_ms.append(comm.last_allreduce_ms())
+            bin_ms.append(f.kernel_ms())
+    t = torch.tensor([min(times)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    payload = ctypes.c_int64(0)
+    L.check(L.lib.fh_stats_device(f.ctx, None, ctypes.byref(payload), None))
+    out.update({"workload": "BASELINE configs[3]: one N=%d fit of %d visibilities sharded over %d ranks "
+                            "(%d per rank)" % (a.ncoll, shard * world, world, shard),
+                "nvis_total": shard * world, "nvis_per_rank": shard, "rccl_ranks": comm.size(),
+                "s_per_fit": float(t.item()), "fits_per_s": 1.0 / float(t.item()),
+                "vis_per_s": shard * world / float(t.item()),
+                "allreduce_us": 1e3 * float(np.median(ar_ms)), "bin_gram_ms": float(np.median(bin_ms)),
+                "iterations": nit_s,
+                "collective": "ncclAllReduce(sum) of %d doubles (%.0f KB) + ncclAllReduce(max) of 2 doubles, on the "
+                              "context's stream" % (payload.value, payload.value * 8 / 1024.0)})
+    comm.close()
 
 
 def main():
@@ -193,7 +360,11 @@ def main():
 
     ndev = max(L.device_count(), 1)
     f = Fitter(L, a.ncoll, local_rank % ndev)  # (more ranks than GPUs only happens in the 1-GPU smoke run of this path)
-    u, v, V, w = mock_disc_visibilities(a.nvis, seed=1000 * rank, noise_seed=50 + rank)
+    do_shard = world > 1 and not a.no_sharded
+    f.nfit = a.nvis
+    f.n_shard = int(min(-(-int(a.sharded_total) // world), int(a.sharded_cap))) if do_shard else 0
+    nrows = max(a.nvis, f.n_shard)
+    u, v, V, w = mock_disc_visibilities(nrows, seed=1000 * rank, noise_seed=50 + rank)
     f.upload(u, v, V, w)
     del u, v, V, w
 
@@ -218,30 +389,23 @@ def main():
     kms_alone = f.kernel_ms()
 
     sharded = None
-    if world > 1 and a.sharded:
-        # BASELINE configs[3]: ONE fit whose visibilities are sharded over the ranks; RCCL all-reduce of the packed
-        # upper-triangle Gram + scalars, then every rank holds M, j (rank 0's solve is the fit).
-        import torch
-        from frank_amd.distributed import RcclComm
+    hung = False
+    if do_shard:
+        # in a watchdog thread: an RCCL failure or hang must cost this key, never the headline line
+        import threading
+        sharded = {}
 
-        def bcast(ident):
-            t = torch.tensor(list(ident if ident is not None else bytes(128)), dtype=torch.uint8)
-            dist.broadcast(t, 0)
-            return bytes(t.tolist())
-        comm = RcclComm(rank, world, local_rank, bcast)
-        times = []
-        for i in range(3):
-            barrier()
-            t0 = time.perf_counter()
-            f.bin()
-            comm.allreduce_stats(f.ctx)
-            nit_s = f.solve()
-            f.sync()
-            barrier()
-            times.append(time.perf_counter() - t0)
-        sharded = {"nvis_total": a.nvis * world, "s_per_fit": min(times), "iterations": nit_s,
-                   "collective": "RCCL all-reduce, %d doubles" % (190 * 256 + 2 if a.ncoll > 207 else 0)}
-        comm.close()
+        def leg():
+            try:
+                sharded_leg(f, L, a, dist, rank, world, local_rank, barrier, sharded)
+            except BaseException as e:  # noqa: BLE001
+                sharded["error"] = repr(e)
+        th = threading.Thread(target=leg, daemon=True)
+        th.start()
+        th.join(timeout=240.0)
+        if th.is_alive():
+            hung = True
+            sharded = {"error": "sharded leg did not finish within 240 s (rank %d)" % rank}
 
     if rank == 0:
         fits = a.steps * world
@@ -251,12 +415,15 @@ def main():
         flops_sym = a.nvis * (Nc * (Nc + 1) + 2 * Nc)       # SURVEY 8(d) symmetric-half figure (unique outputs)
         flops_full = a.nvis * (2 * Nc * Nc + 2 * Nc)         # SURVEY 8(d) full figure
         achieved = flops_sym / (kms * 1e-3) / 1e12
-        traffic = None
-        try:  # HBM bytes of one bin_gram launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as fh:
-                traffic = json.load(fh)["bin_gram_kernel"]["hbm_bytes_per_launch"] * (a.nvis / 1e7) if Nc == 300 else None
-        except Exception:
-            traffic = None
+        traffic, traffic_src = None, None
+        for prof in ("r02_pmc_hbm.json", "r01_pmc_hbm.json"):
+            try:  # HBM bytes of one bin_gram launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+                with open(os.path.join(ROOT, "profiles", prof)) as fh:
+                    traffic = json.load(fh)["bin_gram_kernel"]["hbm_bytes_per_launch"] * (a.nvis / 1e7) if Nc == 300 else None
+                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)" % prof
+                break
+            except Exception:
+                traffic = None
         out = {
             "metric": "FrankFitter solves/sec (N=%d, %.0e visibilities per fit, Normal, fp64, end-to-end)" % (Nc, a.nvis),
             "value": value, "unit": "fits/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -271,20 +438,25 @@ def main():
                              "bin_gram_kernel_alone": kms_alone,
                              "note": "steps are pipelined: fit i's iteration (one CU) overlaps fit i+1's binning; the "
                                      "timed region = steps x (binning + hand-over) + one drain of finalize_plus_iterate"},
-            "roofline": {"kernel": "bin_gram_kernel<19>", "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": K1_KERNEL_NAME, "bound": "mfma", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic, "traffic_source": "profiles/r01_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / "
-                         "WRITE_SIZE, FETCH doubled per the gfx950 note)", "kernel_ms": kms, "kernel_ms_min_median_max": [round(float(x), 2) for x in (np.min(kernel_ms), np.median(kernel_ms), np.max(kernel_ms))],
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kms,
+                         "kernel_ms_min_median_max": [round(float(x), 2) for x in (np.min(kernel_ms), np.median(kernel_ms), np.max(kernel_ms))],
                          "algorithmic_flops_per_vis": Nc * (Nc + 1) + 2 * Nc,
                          "achieved_full_gram_equiv": flops_full / (kms * 1e-3) / 1e12,
-                         "hbm_read_GBps": 40.0 * a.nvis / (kms * 1e-3) / 1e9 * (1.0 if Nc <= 207 else 2.0)},
+                         "hbm_read_GBps": 40.0 * a.nvis / (kms * 1e-3) / 1e9},
         }
-        if sharded:
+        if sharded is not None:
             out["sharded_fit"] = sharded
+        if world == 1 and not a.no_extras:
+            out["extra"] = extras(f, L, a)
         if not a.no_cpu_baseline and world == 1:  # the CPU leg is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(a.ncoll, a.nvis, nit)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if hung:
+        os._exit(0)  # a collective that never returned cannot be torn down cleanly
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -99,6 +99,8 @@ SIGNATURES = {
                                       ctypes.POINTER(_vp)]),
     "fh_comm_destroy": (None, [_vp]),
     "fh_comm_allreduce_stats": (ctypes.c_int, [_vp, _vp]),
+    "fh_comm_last_allreduce_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    "fh_comm_size": (ctypes.c_int, [_vp]),
 }
 
 if not os.path.exists(LIB_PATH):

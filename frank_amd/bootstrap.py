@@ -44,7 +44,7 @@ def bootstrap_fits(fitter, u, v, vis, weights, ntrials, nonnegative=False):
     alpha, p_0, wsmooth, tol = fitter._hyper
     lognormal = fitter._method == 'LogNormal'
     table = ctypes.c_void_p()
-    _lib.check(L.fh_vis_upload(0, _lib.ptr(u), _lib.ptr(v), _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), w.size, n,
+    _lib.check(L.fh_vis_upload(fitter._DHT.device, _lib.ptr(u), _lib.ptr(v), _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), w.size, n,
                                ctypes.byref(table)))
     profiles = np.empty((ntrials, N))
     slots = L.fh_fit_slots()
@@ -57,6 +57,17 @@ def bootstrap_fits(fitter, u, v, vis, weights, ntrials, nonnegative=False):
         rc = L.fh_fit_collect(ctx, ticket, _lib.ptr(mu), _lib.ptr(p), ctypes.byref(niter))
         if rc == _lib.FH_ERR_BAD_P:
             raise ValueError(_BAD_P_MSG)
+        if rc == _lib.FH_ERR_NOT_SPD and Mj[0] is not None:
+            # a Cholesky of this trial's loop failed: carry on as the reference does, through the SVD pseudo-inverse
+            # (statistical_models.py:747-755), one posterior at a time on this trial's M, j
+            keep = fitter._M, fitter._j
+            fitter._M, fitter._j = Mj
+            try:
+                sol = fitter._fit_one_posterior_at_a_time()
+            finally:
+                fitter._M, fitter._j = keep
+            profiles[t] = sol._fit.solve_non_negative() if nonnegative else sol.I
+            return
         _lib.check(rc)
         fitter._check_convergence_policy(niter.value)
         if nonnegative:
@@ -98,5 +109,12 @@ def bootstrap_fits(fitter, u, v, vis, weights, ntrials, nonnegative=False):
         while pending:
             collect(pending.pop(0))
     finally:
+        # an exception above (convergence policy, q range, bad spectrum ...) must not leave tickets outstanding: their
+        # fit slots would stay busy on the fitter's long-lived context and starve the next pipeline
+        if pending:
+            L.fh_fit_flush(ctx)
+            scratch_mu, scratch_p, scratch_n = np.empty(N), np.empty(N), ctypes.c_int(0)
+            for _t, ticket, _Mj in pending:
+                L.fh_fit_collect(ctx, ticket, _lib.ptr(scratch_mu), _lib.ptr(scratch_p), ctypes.byref(scratch_n))
         L.fh_vis_destroy(table)
     return fitter.r, profiles

@@ -661,12 +661,10 @@ int fh_k1_super() { return kSuper; }
 template <int NBT>
 static hipError_t launch_bin(const BinParams &p, hipStream_t stream) {
     constexpr size_t smem = bin_smem_bytes<NBT>();
-    static bool attr_set = false;
-    if (!attr_set) {
+    {  // per launch (cheap): the attribute is per device, and contexts on several devices share this code
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_gram_kernel<NBT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const int grid = p.part_blocks[0] + (nparts(NBT) > 1 ? p.part_blocks[1] : 0);
     hipLaunchKernelGGL(bin_gram_kernel<NBT>, dim3(grid), dim3(kThreads), smem, stream, p);

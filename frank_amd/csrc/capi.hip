@@ -55,9 +55,14 @@ struct DevBuf {
     bool owned = true;
     hipError_t alloc(size_t count) {
         release();
-        n = count;
         owned = true;
-        return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e != hipSuccess) {  // leave the buffer empty so that a later grow-on-demand check allocates again
+            p = nullptr;
+            return e;
+        }
+        n = count;
+        return e;
     }
     void adopt(T *slice, size_t count) {  // a slice of somebody else's allocation
         release();
@@ -166,7 +171,9 @@ struct fh_ctx {
 struct fh_comm {
     void *lib = nullptr;
     void *comm = nullptr;
-    int rank = 0, world = 1;
+    int rank = 0, world = 1, device = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the most recent all-reduce, on the context's stream
+    bool timed = false;
     int (*allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*destroy)(void *) = nullptr;
     const char *(*errstr)(int) = nullptr;
@@ -228,7 +235,9 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
         return fail(FH_ERR_HIP, "no HIP device available: frank_amd has no CPU fallback for device work");
     if (device < 0 || device >= ndev) return fail(FH_ERR_INVALID, "fh_ctx_create: device %d of %d", device, ndev);
     HIP_TRY(hipSetDevice(device));
-    fh_ctx *c = new fh_ctx();
+    // released to the caller only on success: every early return below destroys what has been created so far
+    std::unique_ptr<fh_ctx, void (*)(fh_ctx *)> guard(new fh_ctx(), fh_ctx_destroy);
+    fh_ctx *c = guard.get();
     c->dht = dht;
     c->device = device;
     const int N = c->N = dht->N;
@@ -363,8 +372,10 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
         const char *env = getenv("FRANK_AMD_K2");
         c->use_rocsolver_loop = env && strcmp(env, "rocsolver") == 0;
     }
-    *out = c;
-    return fh_bin_reset(c);
+    const int rc = fh_bin_reset(c);
+    if (rc != FH_OK) return rc;
+    *out = guard.release();
+    return FH_OK;
 }
 
 void fh_ctx_destroy(fh_ctx *c) {
@@ -2021,6 +2032,11 @@ int fh_comm_create(const char id[128], int rank, int world, int device, fh_comm 
     fh_comm *cm = new fh_comm();
     cm->rank = rank;
     cm->world = world;
+    cm->device = device;
+    if (hipEventCreate(&cm->ev0) != hipSuccess || hipEventCreate(&cm->ev1) != hipSuccess) {
+        delete cm;
+        return fail(FH_ERR_HIP, "fh_comm_create: hipEventCreate failed");
+    }
     UniqueId uid;
     memcpy(uid.internal, id, 128);
     // ncclResult_t ncclCommInitRank(ncclComm_t*, int nranks, ncclUniqueId commId, int rank): the id travels by value
@@ -2037,19 +2053,41 @@ int fh_comm_create(const char id[128], int rank, int world, int device, fh_comm 
 
 void fh_comm_destroy(fh_comm *cm) {
     if (!cm) return;
+    (void)hipSetDevice(cm->device);
     if (cm->comm && g_rccl.destroy) g_rccl.destroy(cm->comm);
+    if (cm->ev0) (void)hipEventDestroy(cm->ev0);
+    if (cm->ev1) (void)hipEventDestroy(cm->ev1);
     delete cm;
 }
 
 int fh_comm_allreduce_stats(fh_comm *cm, fh_ctx *c) {
-    if (!cm || !c || !c->NBT) return fail(FH_ERR_INVALID, "fh_comm_allreduce_stats: bad argument");
+    if (!cm || !c || !c->stats_sum.p) return fail(FH_ERR_INVALID, "fh_comm_allreduce_stats: bad argument");
+    if (c->device != cm->device) return fail(FH_ERR_INVALID, "fh_comm_allreduce_stats: context and communicator live on different devices");
     HIP_TRY(hipSetDevice(c->device));
     enum { kFloat64 = 8, kSum = 0, kMax = 2 };  // ncclDataType_t / ncclRedOp_t values (rccl.h)
-    int s = g_rccl.allreduce(c->stats_sum.p, c->stats_sum.p, c->stats_sum.n, kFloat64, kSum, cm->comm, c->stream);
+    // the buffer fh_stats_finalize reads: the packed tile triangle, or the dense (N+1)^2 Gram of the rows + dgemm path
+    // (N > 303: it lives in stats_sum; debris model at N <= 303: in wide_G) -- always with its two trailing scalars
+    double *buf = use_wide(c) ? dense_gram(c) : c->stats_sum.p;
+    const size_t len = use_wide(c) ? dense_tail(c) + 2 : c->stats_sum.n;
+    HIP_TRY(hipEventRecord(cm->ev0, c->stream));
+    int s = g_rccl.allreduce(buf, buf, len, kFloat64, kSum, cm->comm, c->stream);
     if (s == 0) s = g_rccl.allreduce(c->stats_minmax.p, c->stats_minmax.p, 2, kFloat64, kMax, cm->comm, c->stream);
     if (s != 0) return fail(FH_ERR_HIP, "ncclAllReduce: %s", g_rccl.errstr ? g_rccl.errstr(s) : "?");
+    HIP_TRY(hipEventRecord(cm->ev1, c->stream));
+    cm->timed = true;
     c->have_device_Mj = false;
     return FH_OK;
 }
+
+int fh_comm_last_allreduce_ms(fh_comm *cm, float *ms) {
+    if (!cm || !ms) return fail(FH_ERR_INVALID, "fh_comm_last_allreduce_ms: NULL argument");
+    if (!cm->timed) return fail(FH_ERR_INVALID, "no all-reduce recorded yet");
+    HIP_TRY(hipSetDevice(cm->device));
+    HIP_TRY(hipEventSynchronize(cm->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, cm->ev0, cm->ev1));
+    return FH_OK;
+}
+
+int fh_comm_size(const fh_comm *cm) { return cm ? cm->world : 0; }
 
 }  // extern "C"

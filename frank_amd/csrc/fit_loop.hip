@@ -700,12 +700,10 @@ hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s) {
         hipLaunchKernelGGL(fit_loop_dummy_kernel, dim3(1), dim3(KT), smem, s, (long long)(atof(e) * 2.4e6), P.result);
         return hipGetLastError();
     }
-    static size_t attr_for = 0;
-    if (smem > attr_for) {
+    {  // per launch (cheap): the attribute is per device, and contexts on several devices share this code
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        attr_for = smem;
     }
     hipLaunchKernelGGL(fit_loop_kernel, dim3(1), dim3(KT), smem, s, P);
     return hipGetLastError();

@@ -52,7 +52,18 @@ class RcclComm:
         _lib.check(_lib.lib.fh_comm_create(ident, rank, world, device, ctypes.byref(self.handle)))
 
     def allreduce_stats(self, ctx):
+        """Sum the context's device-resident statistics over the ranks (asynchronous on the context's stream)."""
         self._lib.check(self._lib.lib.fh_comm_allreduce_stats(self.handle, ctx))
+
+    def last_allreduce_ms(self):
+        """Device time of the most recent allreduce_stats (HIP events on the context's stream)."""
+        import ctypes
+        ms = ctypes.c_float(0)
+        self._lib.check(self._lib.lib.fh_comm_last_allreduce_ms(self.handle, ctypes.byref(ms)))
+        return ms.value
+
+    def size(self):
+        return self._lib.lib.fh_comm_size(self.handle)
 
     def close(self):
         if self.handle:

@@ -5,10 +5,16 @@ Set-up (collocation points, Ykm, scale factors: hankel.py:55-93) is done by the 
 (fh_dht_coefficients).  Instances hold a native handle but pickle as plain numbers (it is rebuilt).
 """
 import ctypes
+import os
 
 import numpy as np
 
 from frank_amd import _lib
+
+
+def default_device():
+    """The HIP device used when none is named: $FRANK_AMD_DEVICE, else 0."""
+    return int(os.environ.get("FRANK_AMD_DEVICE", "0"))
 
 
 class DiscreteHankelTransform(object):
@@ -22,14 +28,18 @@ class DiscreteHankelTransform(object):
         Number of terms to use in the series
     nu : integer, default = 0
         Order of the Bessel function; only nu = 0 is built.
+    device : integer, optional (not in the reference)
+        HIP device that carries this transform's GPU work.  Default: $FRANK_AMD_DEVICE, else 0.  One process
+        may hold transforms on several devices (frank_amd.sweep.sweep_fits(..., devices=[...])).
     """
 
-    def __init__(self, Rmax, N, nu=0):
+    def __init__(self, Rmax, N, nu=0, device=None):
         if nu != 0:
             raise NotImplementedError("frank_amd builds the nu = 0 transform only (hankel.py:58-66)")
         self._N = int(N)
         self._nu = nu
         self._Rmax = float(Rmax)
+        self._device = default_device() if device is None else int(device)
         self._handle = None
         self._ctx = None
         self._build()
@@ -51,19 +61,30 @@ class DiscreteHankelTransform(object):
         self._j_nk, self._j_nN = zeros[:-1].copy(), float(zeros[-1])
         self._Qmax = Qmax.value
 
-    def context(self, device=0):
-        """The fh_ctx (device buffers + stream) bound to this transform; created on first GPU use."""
-        if self._ctx is None or self._ctx[0] != device:
-            self._drop_ctx()
+    @property
+    def device(self):
+        """HIP device of this transform's GPU work"""
+        return self._device
+
+    def context(self, device=None):
+        """The fh_ctx (device buffers + stream) of this transform on `device` (default: its own device); created
+        on first use.  A transform keeps one context per device it has been used on."""
+        device = self._device if device is None else int(device)
+        if self._ctx is None:
+            self._ctx = {}
+        c = self._ctx.get(device)
+        if c is None:
             c = ctypes.c_void_p()
             _lib.check(_lib.lib.fh_ctx_create(self._handle, device, ctypes.byref(c)))
-            self._ctx = (device, c)
-        return self._ctx[1]
+            self._ctx[device] = c
+        return c
 
     def _drop_ctx(self):
-        if getattr(self, "_ctx", None) is not None:
-            _lib.lib.fh_ctx_destroy(self._ctx[1])
-            self._ctx = None
+        ctxs = getattr(self, "_ctx", None)
+        if ctxs:
+            for c in ctxs.values():
+                _lib.lib.fh_ctx_destroy(c)
+        self._ctx = None
 
     def __del__(self):
         try:
@@ -75,10 +96,11 @@ class DiscreteHankelTransform(object):
             pass
 
     def __getstate__(self):
-        return dict(Rmax=self._Rmax, N=self._N, nu=self._nu)
+        return dict(Rmax=self._Rmax, N=self._N, nu=self._nu, device=self._device)
 
     def __setstate__(self, state):
         self._Rmax, self._N, self._nu = state["Rmax"], state["N"], state["nu"]
+        self._device = state.get("device", default_device())
         self._handle = None
         self._ctx = None
         self._build()

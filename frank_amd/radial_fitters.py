@@ -129,10 +129,11 @@ class FourierBesselFitter(object):
     """
 
     def __init__(self, Rmax, N, geometry, nu=0, block_data=True, assume_optically_thick=True, scale_height=None,
-                 block_size=10 ** 5, verbose=True):
+                 block_size=10 ** 5, verbose=True, device=None):
         Rmax /= rad_to_arcsec
         self._geometry = geometry
-        self._DHT = DiscreteHankelTransform(Rmax, N, nu)
+        # `device` (not in the reference): HIP device of this fitter's GPU work, default $FRANK_AMD_DEVICE or 0
+        self._DHT = DiscreteHankelTransform(Rmax, N, nu, device=device)
         if assume_optically_thick:
             if scale_height is not None:
                 raise ValueError("Optically thick models must have zero scale-height")
@@ -203,12 +204,12 @@ class FrankFitter(FourierBesselFitter):
     def __init__(self, Rmax, N, geometry, nu=0, block_data=True, block_size=10 ** 5, alpha=1.05, p_0=None,
                  weights_smooth=1e-4, tol=1e-3, method='Normal', I_scale=1e5, max_iter=2000, check_qbounds=True,
                  store_iteration_diagnostics=False, assume_optically_thick=True, scale_height=None, verbose=True,
-                 convergence_failure='raise'):
+                 convergence_failure='raise', device=None):
         if method not in {'Normal', 'LogNormal'}:
             raise ValueError('FrankFitter supports following mehods:\n\t{ "Normal", "LogNormal"}"')
         self._method = method
         super(FrankFitter, self).__init__(Rmax, N, geometry, nu, block_data, assume_optically_thick, scale_height,
-                                          block_size, verbose)
+                                          block_size, verbose, device=device)
         # Reinstate the bounds check: FourierBesselFitter does not check bounds (radial_fitters.py:706-707)
         self._vis_map.check_qbounds = check_qbounds
         if p_0 is None:

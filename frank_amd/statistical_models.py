@@ -85,7 +85,7 @@ class VisibilityMapping:
             # streamed as fp32, 20 B per visibility, and widened in the pre-pass: the arithmetic is the fp64 path, as the
             # reference's is whatever dtype it gets (NumPy promotes in geometry.py:69-79)
             vis = ctypes.c_void_p()
-            _lib.check(_lib.lib.fh_vis_upload_f32(0, _lib.fptr(u), _lib.fptr(v), _lib.fptr(Vre), _lib.fptr(Vim),
+            _lib.check(_lib.lib.fh_vis_upload_f32(self._DHT.device, _lib.fptr(u), _lib.fptr(v), _lib.fptr(Vre), _lib.fptr(Vim),
                                                   _lib.fptr(w), w.size, n, ctypes.byref(vis)))
             try:
                 _lib.check(_lib.lib.fh_bin_reset(ctx))

@@ -13,12 +13,24 @@ from frank_amd.radial_fitters import FrankFitter, FrankGaussianFit, FrankLogNorm
 from frank_amd.statistical_models import GaussianModel, LogNormalMAPModel, _BAD_P_MSG
 
 
-def sweep_fits(fitter, preproc_vis, alphas, weights_smooth, p_0=None, tol=1e-3, max_iter=2000):
+def split_grid(npoints, ndevices):
+    """Contiguous, near-equal index ranges [(first, count), ...] of `npoints` sweep points for `ndevices` devices
+    (broadcast (M, j), split the fits evenly, no further communication)."""
+    from frank_amd.distributed import shard_range
+    return [shard_range(npoints, d, ndevices) for d in range(ndevices)]
+
+
+def sweep_fits(fitter, preproc_vis, alphas, weights_smooth, p_0=None, tol=1e-3, max_iter=2000, devices=None):
     """Fit `preproc_vis` (from `fitter.preprocess_visibilities`) for every (alpha[i], weights_smooth[i]).
 
     Returns (sols, niters): FrankGaussianFit (FrankLogNormalFit for a method='LogNormal' fitter) objects as
     FrankFitter.fit_preprocessed would return for a fitter constructed with those hyper-parameters, and the iteration
     counts (`count`; >= max_iter means not converged).
+
+    devices : list of HIP device indices, optional.  The grid is split evenly over them (split_grid), M and j go to
+        every device once (the only transfer), and each device iterates its points concurrently with the others: no
+        communication between devices.  Default: the fitter's own device.  The results do not depend on the split
+        (every point is one workgroup running the same arithmetic wherever it is placed).
     """
     if not isinstance(fitter, FrankFitter):
         raise TypeError("fitter must be a frank_amd FrankFitter")
@@ -31,14 +43,23 @@ def sweep_fits(fitter, preproc_vis, alphas, weights_smooth, p_0=None, tol=1e-3, 
     p0 = _lib.f8(np.full(B, (1e-35 if lognormal else 1e-15) if p_0 is None else p_0))
     fitter._build_matrices(preproc_vis)
     M, j = _lib.f8(fitter._M), _lib.f8(fitter._j)
+    devices = [fitter._DHT.device] if not devices else [int(d) for d in devices]
     if lognormal:
-        return _sweep_lognormal(fitter, M, j, alphas, ws, p0, tol, max_iter)
+        return _sweep_lognormal(fitter, M, j, alphas, ws, p0, tol, max_iter, devices)
     mu, p = np.empty((B, N)), np.empty((B, N))
-    niter = (ctypes.c_int * B)()
-    status = (ctypes.c_int * B)()
-    _lib.check(_lib.lib.fh_fit_normal_batched(fitter._DHT.context(), _lib.ptr(M), _lib.ptr(j), B, _lib.ptr(alphas),
-                                              _lib.ptr(p0), _lib.ptr(ws), float(tol), int(max_iter), _lib.ptr(mu),
-                                              _lib.ptr(p), niter, status))
+    niter = np.zeros(B, dtype=np.intc)
+    status = np.zeros(B, dtype=np.intc)
+    ip = ctypes.POINTER(ctypes.c_int)
+
+    def run(dev, first, count):
+        if count == 0:
+            return
+        sl = slice(first, first + count)
+        _lib.check(_lib.lib.fh_fit_normal_batched(
+            fitter._DHT.context(dev), _lib.ptr(M), _lib.ptr(j), count, _lib.ptr(alphas[sl]), _lib.ptr(p0[sl]),
+            _lib.ptr(ws[sl]), float(tol), int(max_iter), _lib.ptr(mu[sl]), _lib.ptr(p[sl]),
+            niter[sl].ctypes.data_as(ip), status[sl].ctypes.data_as(ip)))
+    _on_devices(run, devices, B)
     sols = []
     for b in range(B):
         if status[b] == _lib.FH_ERR_BAD_P:
@@ -54,6 +75,28 @@ def sweep_fits(fitter, preproc_vis, alphas, weights_smooth, p_0=None, tol=1e-3, 
         info = dict(fitter._info, alpha=float(alphas[b]), wsmooth=float(ws[b]), p0=float(p0[b]))
         sols.append(FrankGaussianFit(fitter._vis_map, fit, info, geometry=fitter._geometry.clone()))
     return sols, [int(n) for n in niter]
+
+
+def _on_devices(run, devices, npoints):
+    """run(device, first, count) for every slice of split_grid.  Slices of different devices run concurrently (one host
+    thread per device; ctypes drops the GIL for the duration of a call, and a context's work is confined to its own
+    device and stream); slices that name the same device share its context and run one after the other."""
+    parts = split_grid(npoints, len(devices))
+    by_dev = {}
+    for d, part in zip(devices, parts):
+        by_dev.setdefault(d, []).append(part)
+
+    def run_all(d):
+        for first, count in by_dev[d]:
+            run(d, first, count)
+    if len(by_dev) == 1:
+        run_all(devices[0])
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(by_dev)) as pool:
+        futs = [pool.submit(run_all, d) for d in by_dev]
+        for fu in futs:
+            fu.result()
 
 
 def _refit_through_svd_route(fitter, alpha, p_0, wsmooth, tol, max_iter, niter, b):
@@ -72,16 +115,24 @@ def _refit_through_svd_route(fitter, alpha, p_0, wsmooth, tol, max_iter, niter, 
     return sol
 
 
-def _sweep_lognormal(fitter, M, j, alphas, ws, p0, tol, max_iter):
+def _sweep_lognormal(fitter, M, j, alphas, ws, p0, tol, max_iter, devices):
     B, N = alphas.size, fitter.size
     s_map, p = np.empty((B, N)), np.empty((B, N))
-    niter = (ctypes.c_int * B)()
-    status = (ctypes.c_int * B)()
-    stats = (ctypes.c_int64 * (9 * B))()
-    _lib.check(_lib.lib.fh_fit_lognormal_batched(fitter._DHT.context(), _lib.ptr(M), _lib.ptr(j), B, _lib.ptr(alphas),
-                                                 _lib.ptr(p0), _lib.ptr(ws), float(tol), int(max_iter),
-                                                 float(np.exp(fitter._s_scale)), _lib.ptr(s_map), _lib.ptr(p), niter,
-                                                 status, stats))
+    niter = np.zeros(B, dtype=np.intc)
+    status = np.zeros(B, dtype=np.intc)
+    stats = np.zeros(9 * B, dtype=np.int64)
+    ip, lp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)
+
+    def run(dev, first, count):
+        if count == 0:
+            return
+        sl = slice(first, first + count)
+        _lib.check(_lib.lib.fh_fit_lognormal_batched(
+            fitter._DHT.context(dev), _lib.ptr(M), _lib.ptr(j), count, _lib.ptr(alphas[sl]), _lib.ptr(p0[sl]),
+            _lib.ptr(ws[sl]), float(tol), int(max_iter), float(np.exp(fitter._s_scale)), _lib.ptr(s_map[sl]),
+            _lib.ptr(p[sl]), niter[sl].ctypes.data_as(ip), status[sl].ctypes.data_as(ip),
+            stats[9 * first:9 * (first + count)].ctypes.data_as(lp)))
+    _on_devices(run, devices, B)
     sols = []
     for b in range(B):
         if status[b] == _lib.FH_ERR_BAD_P:

@@ -10,6 +10,7 @@ import logging
 import numpy as np
 
 from frank_amd import _lib
+from frank_amd.hankel import default_device
 
 _i32p = ctypes.POINTER(ctypes.c_int32)
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -37,7 +38,7 @@ class UVDataBinner(object):
         if Vre.shape != uv.shape:
             raise ValueError("uv and V must have the same length")
         self._handle = ctypes.c_void_p()
-        _lib.check(_lib.lib.fh_uvbin_create(0, _lib.ptr(uv), _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), uv.size,
+        _lib.check(_lib.lib.fh_uvbin_create(default_device(), _lib.ptr(uv), _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), uv.size,
                                             float(bin_width), ctypes.byref(self._handle)))
         nbins = self._nbins = _lib.lib.fh_uvbin_nbins(self._handle)
         self._bins = np.arange(nbins + 1, dtype='float64') * bin_width

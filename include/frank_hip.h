@@ -251,7 +251,13 @@ int fh_ctx_set_scale_height(fh_ctx *ctx, const double *H2);
 int fh_comm_unique_id(char id[128]);
 int fh_comm_create(const char id[128], int rank, int world, int device, fh_comm **out);
 void fh_comm_destroy(fh_comm *comm);
+/* Sums the context's statistics over the ranks in place, asynchronously on the context's stream: the packed tile
+ * triangle (N <= 303) or the dense (N+1)^2 Gram of the composed path (N > 303, or the debris model), each with its two
+ * scalars, plus a 2-double max-reduce of (-qmin, qmax).  fh_stats_finalize afterwards yields the unsharded M, j, H0. */
 int fh_comm_allreduce_stats(fh_comm *comm, fh_ctx *ctx);
+/* Device time (ms, HIP events on the context's stream) of the most recent fh_comm_allreduce_stats. */
+int fh_comm_last_allreduce_ms(fh_comm *comm, float *ms);
+int fh_comm_size(const fh_comm *comm); /* number of ranks */
 
 #ifdef __cplusplus
 }

@@ -141,3 +141,23 @@ def test_bin_gram_tile_tables_cover_the_triangle_once():
         assert sorted(t for w in waves for t in w) == list(range(lo, hi))
         per_simd = [sum(len(waves[w]) for w in (s, s + 4, s + 8)) for s in range(4)]
         assert max(per_simd) - min(per_simd) <= 1
+
+
+def test_split_grid_and_device_argument():
+    """Host logic of the multi-GPU paths: the sweep grid is dealt in contiguous near-equal slices, and the
+    `device` of a transform survives pickling (result objects hold no native handles)."""
+    import pickle
+    from frank_amd import DiscreteHankelTransform
+    from frank_amd.sweep import split_grid
+    assert split_grid(512, 8) == [(64 * d, 64) for d in range(8)]
+    assert split_grid(7, 3) == [(0, 3), (3, 2), (5, 2)]
+    assert split_grid(2, 4) == [(0, 1), (1, 1), (2, 0), (2, 0)]
+    d = DiscreteHankelTransform(1e-5, 12, device=5)
+    assert d.device == 5
+    d2 = pickle.loads(pickle.dumps(d))
+    assert d2.device == 5 and np.array_equal(d2.q, d.q)
+    os.environ["FRANK_AMD_DEVICE"] = "2"
+    try:
+        assert DiscreteHankelTransform(1e-5, 12).device == 2
+    finally:
+        del os.environ["FRANK_AMD_DEVICE"]

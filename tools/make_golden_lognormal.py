@@ -2,6 +2,7 @@
 """Golden fixtures for the LogNormal branch (run in the BUILD container only; imports the reference).
 
     python3 tools/make_golden_lognormal.py         # ~4 min
+    python3 tools/make_golden_lognormal.py N300    # lognormal_N300.npz: the seed MAP solve at N = 300 only
 
 Writes tests/golden/lognormal_N40.npz and lognormal_N80.npz:
   * one LogNormalMAPModel solve (statistical_models.py:1012-1160) on the seed power spectrum: inputs, s_MAP,
@@ -127,6 +128,11 @@ def _hess(ln):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "N300":
+        # BASELINE configs[2]'s basis size: ONE LogNormalMAPModel seed solve + one update_power_spectrum (the blocked-LU
+        # and 64-row-block solve geometry of the device kernel); no whole fit (hours in the reference)
+        case("lognormal_N300.npz", 300, 200000, dict())
+        return
     case("lognormal_N40.npz", 40, 5000, dict(a=(1.3, 1e-2)))
     case("lognormal_N80.npz", 80, 20000, dict(a=(1.05, 1e-4)))
 
