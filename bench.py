@@ -159,6 +159,31 @@ class Fitter:
         self.L.check(self.L.lib.fh_ctx_synchronize(self.ctx))
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container on a 256-thread
+    host is often given a few cores; oversubscribing them 30x is what a naive os.cpu_count() pool does)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                        n = min(n, max(1, q // int(fh.read())))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def _cpu_leg(args):
     """One worker of the CPU baseline: the oracle's map_visibilities on `ns` visibilities and `it` power-spectrum
     iterations, timed separately.  Runs in a fresh interpreter (spawn): no GPU state, imports only numpy + oracle."""
@@ -197,14 +222,14 @@ def cpu_baseline(ncoll, nvis, gpu_niter):
     try:
         import multiprocessing as mp
         from concurrent.futures import ProcessPoolExecutor
-        cores = os.cpu_count() or 1
-        workers = max(1, min(cores, 256))
+        cores = usable_cpus()
+        workers = max(1, min(cores, 64))  # bounded: the sample is per core, more copies add nothing
         with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as pool:
             res = list(pool.map(_cpu_leg, [(ncoll, ns, it, 1 + k) for k in range(workers)]))
         tm = float(np.median([r[0] for r in res]))
         ti = float(np.median([r[1] for r in res]))
         t_loaded = tm * (nvis / ns) + ti * gpu_niter
-        out["all_cores"] = {"value": workers / t_loaded, "unit": "fits/s", "cores": workers, "host_cpus": cores,
+        out["all_cores"] = {"value": workers / t_loaded, "unit": "fits/s", "cores": workers, "usable_cpus": cores, "host_cpus": os.cpu_count(),
                             "s_per_fit_per_core_loaded": t_loaded,
                             "sample": "%d concurrent single-thread copies of the sample above (median %.1f s map, "
                                       "%.1f ms/iteration), one independent fit per core" % (workers, tm, 1e3 * ti)}

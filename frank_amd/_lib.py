@@ -44,6 +44,7 @@ SIGNATURES = {
     "fh_dht_destroy": (None, [_vp]),
     "fh_dht_size": (ctypes.c_int, [_vp]),
     "fh_dht_get": (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "fh_dht_bucket_tables": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _dp, _dp]),
     "fh_ctx_create": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_vp)]),
     "fh_ctx_destroy": (None, [_vp]),
     "fh_ctx_synchronize": (ctypes.c_int, [_vp]),
@@ -58,6 +59,8 @@ SIGNATURES = {
     "fh_bin_reset": (ctypes.c_int, [_vp]),
     "fh_bin_visibilities": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), _vp, _i64, _i64]),
     "fh_bin_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    "fh_bin_last_prepass_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    "fh_ctx_set_reproducible": (ctypes.c_int, [_vp, ctypes.c_int]),
     "fh_stats_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64), ctypes.POINTER(_vp)]),
     "fh_stats_finalize": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), ctypes.c_int, ctypes.c_int, _dp, _dp, _dp,
                                          _dp, _dp]),

@@ -451,7 +451,9 @@ __global__ void reduce_partials_level1(ReduceParams rp, double *scratch) {
     const int64_t ne = (int64_t)rp.ntiles * 256;
     if (e >= ne) return;
     const int g = blockIdx.y;
-    const int part = (rp.nparts > 1 && e >= (int64_t)rp.part_tile0[1] * 256) ? 1 : 0;
+    int part = 0;
+    for (int q = 1; q < rp.nparts; ++q)
+        if (e >= (int64_t)rp.part_tile0[q] * 256) part = q;
     const int64_t pe = e - (int64_t)rp.part_tile0[part] * 256;
     const int64_t stride = (int64_t)rp.part_ntiles[part] * 256;
     const double *src = rp.partials[part];

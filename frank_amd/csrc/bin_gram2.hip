@@ -1,0 +1,523 @@
+// K1 `bin_gram` v2: the Bessel design block is GENERATED ON THE MATRIX PIPE, then the weighted Gram as before.
+//
+// Replaces the chunk loop of VisibilityMapping.map_visibilities (statistical_models.py:165-218) with
+// DHT.coefficients (hankel.py:201-202) fused in; the deprojection pre-pass (geometry.py:69-79, 111-131) is
+// deproject_kernel of bin_gram.hip.
+//
+// v1 evaluated J0(s_i j_k) with ~55 fp64 VALU instructions per 64 entries; on MI355X fp64 VALU and fp64 MFMA share
+// the DP units, and the J0 temporaries forced the 190-tile triangle into two workgroup specialisations that each
+// re-evaluated most columns (1.9x the J0 work): matrix pipe 46 % busy, 26.6 ms per 1e7 visibilities at N = 300.
+//
+// v2 (j0_buckets.h): visibilities are sorted into buckets of s = q/Qmax of width Delta = 2h/j_N, h = 1/4.  Inside
+// bucket b, with tau = (s - s0_b)/(Delta/2) in [-1, 1],
+//     sqrt(w) J0(s j_k) = sum_{n<12} [sqrt(w) tau^n] * C_b[n][k],     C_b[n][k] = a_n(s0_b j_k) (j_k Delta/2)^n,
+// so a 16-visibility x 16-column tile of the design block is P (16 x 12) times C_b (12 x 16): THREE
+// v_mfma_f64_16x16x4_f64.  Register r of the result (C/D layout: column = lane & 15, row = (lane >> 4) + 4 r) is
+// exactly the A/B operand fragment of Gram k-step r (rows 4r .. 4r+3), so the tile goes to LDS in the layout the
+// consumers read, no transposition.  19 column blocks x 3 MFMAs per 16 visibilities against 190 x 4 for the Gram
+// (+7.5 %); the J0 VALU work is gone, and with it the register pressure: ONE workgroup specialisation holds all
+// 190 tiles (8 waves x 24 tiles x 8 accumulator registers, two waves per SIMD) and nothing is evaluated twice.
+//
+//   bucket_hist / bucket_scan / bucket_starts / bucket_scatter   stable (deterministic) counting sort of the K1a
+//                          output by bucket; bucket starts aligned to 16 rows (padding rows have sqrt(w) = 0);
+//                          32 B per sorted row: tau, sqrt(w), sqrt(w) Re V', -
+//   bin_gram2_kernel       per 16-row chunk: generate the chunk's tiles (each wave 2-3 column blocks) into the other
+//                          LDS buffer while the Gram MFMAs of the current chunk run; one barrier per chunk.
+//   N > 303                the triangle is cut into row-aligned PARTS of <= 192 tiles; a part's workgroups generate
+//                          only the column blocks its tiles touch (cheap now), so the fused path reaches N = 511.
+#include <hip/hip_runtime.h>
+
+#include <utility>
+
+#include "j0_buckets.h"
+#include "k1v2_tiles.h"
+#include "kernels.h"
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kWaves = 8;
+constexpr int kThreads = 64 * kWaves;
+constexpr int kCap = 24;              // tiles per wave (kTiles* tables)
+constexpr int kRows = 16;             // rows per chunk = one generated tile = 4 Gram k-steps
+constexpr int kTerms = FH_K1_TERMS;   // 12
+constexpr int kRun = 48;              // chunks per dynamic hand-out
+
+constexpr int xstride(int NBT) {  // LDS row stride in doubles, == 16 (mod 32): conflict-free fragment reads / writes
+    return (NBT * 16) % 32 == 16 ? NBT * 16 : NBT * 16 + 16;
+}
+constexpr int ntiles(int NBT) { return NBT * (NBT + 1) / 2; }
+constexpr int nparts(int NBT) { return NBT <= 19 ? 1 : (NBT == 24 ? 2 : 3); }
+constexpr int wave_tile(int NBT, int P, int W, int T) {
+    return NBT == 4    ? kTiles4[0][W][T]
+           : NBT == 8  ? kTiles8[0][W][T]
+           : NBT == 13 ? kTiles13[0][W][T]
+           : NBT == 19 ? kTiles19[0][W][T]
+           : NBT == 24 ? kTiles24[P < 2 ? P : 0][W][T]
+                       : kTiles32[P < 3 ? P : 0][W][T];
+}
+constexpr int tile_I(int NBT, int t) {
+    int I = 0;
+    while (t >= NBT - I) {
+        t -= NBT - I;
+        ++I;
+    }
+    return I;
+}
+constexpr int tile_J(int NBT, int t) {
+    int I = 0;
+    while (t >= NBT - I) {
+        t -= NBT - I;
+        ++I;
+    }
+    return I + t;
+}
+constexpr int wave_ntiles(int NBT, int P, int W) {
+    int n = 0;
+    while (n < kCap && wave_tile(NBT, P, W, n) >= 0) ++n;
+    return n;
+}
+// first / one-past-last tile (row-major triangle numbering) of a part: parts are contiguous, row-aligned
+constexpr int part_tile0(int NBT, int P) {
+    int m = 1 << 30;
+    for (int W = 0; W < kWaves; ++W)
+        for (int T = 0; T < kCap; ++T) {
+            const int t = wave_tile(NBT, P, W, T);
+            if (t >= 0 && t < m) m = t;
+        }
+    return m;
+}
+constexpr int part_tile1(int NBT, int P) {
+    int m = -1;
+    for (int W = 0; W < kWaves; ++W)
+        for (int T = 0; T < kCap; ++T) {
+            const int t = wave_tile(NBT, P, W, T);
+            if (t > m) m = t;
+        }
+    return m + 1;
+}
+constexpr int part_block0(int NBT, int P) { return tile_I(NBT, part_tile0(NBT, P)); }  // first column block needed
+constexpr bool wave_needs(int NBT, int P, int W, int B) {
+    for (int T = 0; T < kCap; ++T) {
+        const int t = wave_tile(NBT, P, W, T);
+        if (t >= 0 && (tile_I(NBT, t) == B || tile_J(NBT, t) == B)) return true;
+    }
+    return false;
+}
+
+// ---- counting sort by bucket ------------------------------------------------------------------------------------
+__device__ __forceinline__ int bucket_of(double s, double inv_delta, int nb) {
+    int b = (int)(s * inv_delta);  // s >= 0
+    return b < nb - 1 ? b : nb - 1;
+}
+
+// hist[block][bucket]: rows i = block * 256 + tid + k * grid * 256 (the SAME mapping as bucket_scatter_kernel)
+__global__ __launch_bounds__(256) void bucket_hist_kernel(const double *s, int64_t n, double inv_delta, int nb, int *hist) {
+    extern __shared__ int lh[];
+    for (int b = threadIdx.x; b < nb; b += 256) lh[b] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        atomicAdd(&lh[bucket_of(s[i], inv_delta, nb)], 1);
+    __syncthreads();
+    int *row = hist + (size_t)blockIdx.x * nb;
+    for (int b = threadIdx.x; b < nb; b += 256) row[b] = lh[b];
+}
+
+// per bucket: exclusive prefix over the blocks (in place) and the bucket's total
+__global__ void bucket_scan_blocks_kernel(int *hist, int nblocks, int nb, int *totals) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    int run = 0;
+#pragma unroll 8
+    for (int k = 0; k < nblocks; ++k) {
+        const int v = hist[(size_t)k * nb + b];
+        hist[(size_t)k * nb + b] = run;
+        run += v;
+    }
+    totals[b] = run;
+}
+
+struct Row32 {
+    double tau, sw, swV, pad;
+};
+
+// starts[b] = first sorted row of bucket b (a multiple of 16), starts[nb] = padded length; info[0] = chunks;
+// the padding rows behind each bucket are zeroed.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void bucket_starts_kernel(const int *totals, int nb, int *starts, int *info, Row32 *rows) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    const int b0 = t * per, b1 = min(nb, b0 + per);
+    int sum = 0;
+    for (int b = b0; b < b1; ++b) sum += (totals[b] + 15) & ~15;
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - sum;
+    for (int b = b0; b < b1; ++b) {
+        starts[b] = run;
+        const int tot = totals[b], pad = (tot + 15) & ~15;
+        for (int r = tot; r < pad; ++r) rows[(size_t)run + r] = Row32{0.0, 0.0, 0.0, 0.0};
+        run += pad;
+    }
+    if (t == 1023) {
+        starts[nb] = part[1023];
+        info[0] = part[1023] / kRows;
+    }
+}
+
+// bucket of every 16-row chunk (binary search in starts; empty buckets have equal starts)
+__global__ void chunk_bucket_kernel(const int *starts, int nb, const int *info, int *chunk_bucket) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= info[0]) return;
+    const int row = c * kRows;
+    int lo = 0, hi = nb;  // largest b with starts[b] <= row and starts[b + 1] > row
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (starts[mid] <= row) lo = mid;
+        else hi = mid;
+    }
+    chunk_bucket[c] = lo;
+}
+
+// Stable scatter: a row's position is bucket start + rows of that bucket in earlier blocks (hist, scanned) + rows of
+// that bucket earlier in this block, counted in (iteration, wave, lane) order -- no atomics, the same position in
+// every run.  Per 64 rows the lanes of equal bucket find each other with one ballot per bucket-index bit.
+__global__ __launch_bounds__(256) void bucket_scatter_kernel(const double *s, const double *sw, const double *swV, int64_t n,
+                                                             double inv_delta, double delta, int nb, int nbits,
+                                                             const int *hist, const int *starts, Row32 *rows) {
+    extern __shared__ int cnt[];
+    const int *row = hist + (size_t)blockIdx.x * nb;
+    for (int b = threadIdx.x; b < nb; b += 256) cnt[b] = starts[b] + row[b];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double inv_half = 2.0 * inv_delta;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t iters = (n + stride - 1) / stride;
+    for (int64_t k = 0; k < iters; ++k) {
+        const int64_t i = k * stride + (int64_t)blockIdx.x * 256 + threadIdx.x;
+        const bool active = i < n;
+        const double si = active ? s[i] : 0.0;
+        const int b = bucket_of(si, inv_delta, nb);
+        unsigned long long peers = __ballot(active);
+        for (int bit = 0; bit < nbits; ++bit) {
+            const bool one = (b >> bit) & 1;
+            const unsigned long long m = __ballot(one);
+            peers &= one ? m : ~m;
+        }
+        const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+        const int leader_lane = __ffsll((long long)peers) - 1;
+        int base = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w && active && rank == 0) {
+                base = cnt[b];
+                cnt[b] = base + __popcll(peers);
+            }
+            __syncthreads();
+        }
+        base = __shfl(base, leader_lane < 0 ? 0 : leader_lane);
+        if (active) {
+            double tau;
+            {
+#pragma clang fp contract(off)
+                tau = (si - ((double)b + 0.5) * delta) * inv_half;  // fh_k1_bucket_centre, the table's expansion point
+            }
+            rows[(size_t)base + rank] = Row32{tau, sw[i], swV[i], 0.0};
+        }
+    }
+}
+
+// ---- K1b v2 ---------------------------------------------------------------------------------------------------
+template <int NBT, int P, int W, int T>
+__device__ __forceinline__ void mfma_one(v4f64 &acc, const double (&f)[NBT]) {
+    constexpr int tt = wave_tile(NBT, P, W, T);
+    constexpr int I = tile_I(NBT, tt), J = tile_J(NBT, tt);
+    // A[i][k] = Xt[k][16I+i] and B[k][j] = Xt[k][16J+j] share one fragment layout: lane -> (k = lane>>4, i|j = lane&15)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f[I], f[J], acc, 0, 0, 0);
+}
+template <int NBT, int P, int W, int TPW, int... Ts>
+__device__ __forceinline__ void mfma_all(v4f64 (&acc)[TPW > 0 ? TPW : 1], const double (&f)[NBT],
+                                         std::integer_sequence<int, Ts...>) {
+    (mfma_one<NBT, P, W, Ts>(acc[Ts], f), ...);
+}
+template <int NBT, int P, int W, int B>
+__device__ __forceinline__ void load_frag(double (&f)[NBT], const double *xb) {
+    if constexpr (wave_needs(NBT, P, W, B)) f[B] = xb[B * 16];
+}
+template <int NBT, int P, int W, int... Bs>
+__device__ __forceinline__ void load_frags(double (&f)[NBT], const double *xb, std::integer_sequence<int, Bs...>) {
+    (load_frag<NBT, P, W, Bs>(f, xb), ...);
+}
+
+template <int NBT, int P, int W>
+__device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int part_block, int part_nblocks) {
+    constexpr int XS = xstride(NBT);
+    constexpr int T0 = part_tile0(NBT, P), T1 = part_tile1(NBT, P);
+    constexpr int NTP = T1 - T0;
+    constexpr int TPW = wave_ntiles(NBT, P, W);
+    constexpr int TPWA = TPW > 0 ? TPW : 1;
+    constexpr int B0 = part_block0(NBT, P);            // first column block this part needs
+    constexpr int NGEN = (NBT - B0 - W + kWaves - 1) / kWaves > 0 ? (NBT - B0 - W + kWaves - 1) / kWaves : 0;  // blocks B0+W+8g
+
+    double *Ctab = smem;                    // [kTerms][XS]
+    double *X = Ctab + kTerms * XS;         // [2][kRows][XS]
+    int *sq = reinterpret_cast<int *>(X + 2 * kRows * XS);  // [4] run queue (dynamic hand-out)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int kk = lane >> 4, ii = lane & 15;
+    const int N = p.N;
+    const int JN = N >> 4, jn = N & 15;     // the data column sqrt(w) Re V' lives at column N
+    const int nchunks = p.info[0];
+
+    v4f64 acc[TPWA];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
+
+    // ---- rows of one chunk: lane (kk, ii) holds row ii ----------------------------------------------------------
+    struct RowRegs {
+        double tau, sw, swV;
+    };
+    auto load_row = [&](int chunk) -> RowRegs {
+        const double *rp = p.rows + ((size_t)chunk * kRows + ii) * 4;
+        return RowRegs{rp[0], rp[1], rp[2]};
+    };
+    // ---- the Taylor table of one bucket into LDS (all threads) ---------------------------------------------------
+    auto load_table = [&](int bucket) {
+        const double *src = p.table + (size_t)bucket * kTerms * XS;
+        for (int e = tid; e < kTerms * XS; e += kThreads) Ctab[e] = src[e];
+    };
+    // ---- generate this wave's column blocks of one chunk into X[xbuf] -------------------------------------------
+    // A operand P[i][n] = sqrt(w_i) tau_i^n : lane (k = kk, i = ii) of k-step t holds n = 4t + kk
+    auto gen_one = [&](const RowRegs &r, int xbuf, int J, double a0, double a1, double a2) {
+        const double *cb = Ctab + kk * XS + J * 16 + ii;
+        v4f64 d = v4f64{0.0, 0.0, 0.0, 0.0};
+        d = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, cb[8 * XS], d, 0, 0, 0);  // smallest terms first
+        d = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, cb[4 * XS], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, cb[0], d, 0, 0, 0);
+        if (J == JN) {  // column N: sqrt(w) Re V' of row 4 reg + kk (held by lane 4 reg + kk); columns beyond: table zeros
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const double v = __shfl(r.swV, 4 * reg + kk);
+                if (ii == jn) d[reg] = v;
+            }
+        }
+        double *xw = X + ((size_t)xbuf * kRows + kk) * XS + J * 16 + ii;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) xw[reg * 4 * XS] = d[reg];
+    };
+    auto powers = [&](const RowRegs &r, double &a0, double &a1, double &a2) {
+        const double t2 = r.tau * r.tau;
+        const double pk = kk == 0 ? 1.0 : (kk == 1 ? r.tau : (kk == 2 ? t2 : t2 * r.tau));
+        const double t4 = t2 * t2;
+        a0 = r.sw * pk;
+        a1 = a0 * t4;
+        a2 = a1 * t4;
+    };
+    // ---- Gram MFMAs of k-step ks (rows 4 ks .. 4 ks + 3) of X[xbuf] ------------------------------------------------
+    auto gram = [&](int xbuf, int ks) {
+        const double *xb = X + ((size_t)xbuf * kRows + ks * 4 + kk) * XS + ii;
+        double f[NBT];
+        load_frags<NBT, P, W>(f, xb, std::make_integer_sequence<int, NBT>{});
+        mfma_all<NBT, P, W, TPW>(acc, f, std::make_integer_sequence<int, TPW>{});
+    };
+
+    // ---- work hand-out: contiguous chunk ranges (static, bitwise reproducible) or runs from an atomic counter ----
+    int *counter = p.work_counter ? p.work_counter + P : nullptr;
+    int c0, c1;
+    if (!counter) {
+        const int per = (nchunks + part_nblocks - 1) / part_nblocks;
+        c0 = part_block * per;
+        c1 = min(nchunks, c0 + per);
+    } else {
+        if (tid == 0) sq[0] = atomicAdd(counter, 1);
+        __syncthreads();
+        c0 = sq[0] * kRun;
+        c1 = min(nchunks, c0 + kRun);
+    }
+    int qslot = 0;
+    int cur_bucket = -1;
+    while (c0 < c1) {
+        if (counter && tid == 0) sq[qslot ^ 1] = atomicAdd(counter, 1);  // the run after this one
+        // prologue of a range: table + first chunk.  Row scalars and bucket ids are fetched TWO chunks ahead of their
+        // use (a dependent global load at the top of every chunk would stall the wave for a microsecond of each five)
+        RowRegs rnext = load_row(c0);
+        int bnext = c0 + 1 < c1 ? p.chunk_bucket[c0 + 1] : 0;  // bucket of the chunk generated in the first iteration
+        {
+            const int b = p.chunk_bucket[c0];
+            if (b != cur_bucket) {
+                __syncthreads();
+                load_table(b);
+                cur_bucket = b;
+            }
+            __syncthreads();
+            double a0, a1, a2;
+            powers(rnext, a0, a1, a2);
+#pragma unroll
+            for (int g = 0; g < NGEN; ++g) gen_one(rnext, 0, B0 + W + kWaves * g, a0, a1, a2);
+            if (c0 + 1 < c1) rnext = load_row(c0 + 1);
+            __syncthreads();
+        }
+        int xbuf = 0;
+#pragma unroll 1
+        for (int c = c0; c < c1; ++c) {
+            const bool more = c + 1 < c1;
+            const RowRegs rgen = rnext;
+            const int bgen = bnext;
+            if (c + 2 < c1) {
+                rnext = load_row(c + 2);
+                bnext = p.chunk_bucket[c + 2];
+            }
+            if (more && bgen != cur_bucket) {  // uniform: nobody reads Ctab between the closing barrier of a chunk and here
+                load_table(bgen);
+                cur_bucket = bgen;
+                __syncthreads();
+            }
+            double a0 = 0, a1 = 0, a2 = 0;
+            if (more) powers(rgen, a0, a1, a2);
+            // this wave's generated blocks of chunk c+1 (matrix pipe + LDS writes) between the Gram k-steps of chunk c
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < NGEN && more) gen_one(rgen, xbuf ^ 1, B0 + W + kWaves * ks, a0, a1, a2);
+                gram(xbuf, ks);
+            }
+            static_assert(NGEN <= 4, "a wave generates at most four column blocks per chunk");
+            __syncthreads();
+            xbuf ^= 1;
+        }
+        if (!counter) break;
+        c0 = sq[qslot ^ 1] * kRun;
+        c1 = min(nchunks, c0 + kRun);
+        qslot ^= 1;
+    }
+
+    // ---- write this workgroup's partial tiles: slab[part_block][tile - T0][reg][lane] --------------------------
+    double *slab = p.partials[P] + (size_t)part_block * NTP * 256;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tl = wave_tile(NBT, P, W, t) - T0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(size_t)tl * 256 + r * 64 + lane] = acc[t][r];
+    }
+}
+
+template <int NBT, int P>
+__device__ __forceinline__ void part_main(const Bin2Params &p, double *smem, int part_block, int part_nblocks) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    switch (wave) {
+        case 0: wave_main<NBT, P, 0>(p, smem, part_block, part_nblocks); break;
+        case 1: wave_main<NBT, P, 1>(p, smem, part_block, part_nblocks); break;
+        case 2: wave_main<NBT, P, 2>(p, smem, part_block, part_nblocks); break;
+        case 3: wave_main<NBT, P, 3>(p, smem, part_block, part_nblocks); break;
+        case 4: wave_main<NBT, P, 4>(p, smem, part_block, part_nblocks); break;
+        case 5: wave_main<NBT, P, 5>(p, smem, part_block, part_nblocks); break;
+        case 6: wave_main<NBT, P, 6>(p, smem, part_block, part_nblocks); break;
+        default: wave_main<NBT, P, 7>(p, smem, part_block, part_nblocks); break;
+    }
+}
+
+template <int NBT>
+__global__ __launch_bounds__(kThreads, 2) void bin_gram2_kernel(Bin2Params p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x;
+    if (nparts(NBT) == 1 || b < p.part_blocks[0]) {
+        part_main<NBT, 0>(p, smem, b, p.part_blocks[0]);
+    } else if (nparts(NBT) == 2 || b < p.part_blocks[0] + p.part_blocks[1]) {
+        part_main<NBT, nparts(NBT) >= 2 ? 1 : 0>(p, smem, b - p.part_blocks[0], p.part_blocks[1]);
+    } else {
+        part_main<NBT, nparts(NBT) >= 3 ? 2 : 0>(p, smem, b - p.part_blocks[0] - p.part_blocks[1], p.part_blocks[2]);
+    }
+}
+
+template <int NBT>
+constexpr size_t bin2_smem_bytes() {
+    return sizeof(double) * ((size_t)kTerms * xstride(NBT) + 2 * kRows * xstride(NBT)) + 4 * sizeof(int);
+}
+
+template <int NBT>
+hipError_t launch_bin2(const Bin2Params &p, hipStream_t stream) {
+    constexpr size_t smem = bin2_smem_bytes<NBT>();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_gram2_kernel<NBT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    const int grid = p.part_blocks[0] + p.part_blocks[1] + p.part_blocks[2];
+    hipLaunchKernelGGL(bin_gram2_kernel<NBT>, dim3(grid), dim3(kThreads), smem, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+static int nbt_for(int N) {
+    const int nb = (N + 1 + 15) / 16;
+    if (nb <= 4) return 4;
+    if (nb <= 8) return 8;
+    if (nb <= 13) return 13;
+    if (nb <= 19) return 19;
+    if (nb <= 24) return 24;
+    return 0;  // N > 383: not covered yet (NBT = 32 needs a single-buffered X to fit 160 KB of LDS)
+}
+int fh_k1v2_nbt_for(int N) { return nbt_for(N); }
+int fh_k1v2_xstride(int NBT) { return xstride(NBT); }
+int fh_k1v2_ntiles(int NBT) { return ntiles(NBT); }
+int fh_k1v2_nparts(int NBT) { return nparts(NBT); }
+int fh_k1v2_part_tile0(int NBT, int P) {
+    switch (NBT) {
+        case 4: return part_tile0(4, 0);
+        case 8: return part_tile0(8, 0);
+        case 13: return part_tile0(13, 0);
+        case 19: return part_tile0(19, 0);
+        case 24: return P == 0 ? part_tile0(24, 0) : part_tile0(24, 1);
+    }
+    return 0;
+}
+int fh_k1v2_part_ntiles(int NBT, int P) {
+    switch (NBT) {
+        case 4: return part_tile1(4, 0) - part_tile0(4, 0);
+        case 8: return part_tile1(8, 0) - part_tile0(8, 0);
+        case 13: return part_tile1(13, 0) - part_tile0(13, 0);
+        case 19: return part_tile1(19, 0) - part_tile0(19, 0);
+        case 24: return P == 0 ? part_tile1(24, 0) - part_tile0(24, 0) : part_tile1(24, 1) - part_tile0(24, 1);
+    }
+    return 0;
+}
+int fh_k1v2_part_block0(int NBT, int P) {
+    switch (NBT) {
+        case 24: return P == 0 ? part_block0(24, 0) : part_block0(24, 1);
+    }
+    return 0;
+}
+
+hipError_t fh_k1v2_launch_sort(const SortParams &sp, hipStream_t stream) {
+    const size_t lds = sizeof(int) * (size_t)sp.nb;
+    int nbits = 0;
+    while ((1 << nbits) < sp.nb) ++nbits;
+    hipLaunchKernelGGL(bucket_hist_kernel, dim3(sp.blocks), dim3(256), lds, stream, sp.s, sp.n, sp.inv_delta, sp.nb, sp.hist);
+    hipLaunchKernelGGL(bucket_scan_blocks_kernel, dim3((sp.nb + 255) / 256), dim3(256), 0, stream, sp.hist, sp.blocks, sp.nb,
+                       sp.totals);
+    hipLaunchKernelGGL(bucket_starts_kernel, dim3(1), dim3(1024), 0, stream, sp.totals, sp.nb, sp.starts, sp.info,
+                       reinterpret_cast<Row32 *>(sp.rows));
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(sp.blocks), dim3(256), lds, stream, sp.s, sp.sw, sp.swV, sp.n, sp.inv_delta,
+                       sp.delta, sp.nb, nbits, sp.hist, sp.starts, reinterpret_cast<Row32 *>(sp.rows));
+    const int64_t max_chunks = (sp.n + (int64_t)kRows * sp.nb) / kRows + 1;
+    hipLaunchKernelGGL(chunk_bucket_kernel, dim3((unsigned)((max_chunks + 255) / 256)), dim3(256), 0, stream, sp.starts,
+                       sp.nb, sp.info, sp.chunk_bucket);
+    return hipGetLastError();
+}
+
+hipError_t fh_k1v2_launch_bin(int NBT, const Bin2Params &p, hipStream_t stream) {
+    switch (NBT) {
+        case 4: return launch_bin2<4>(p, stream);
+        case 8: return launch_bin2<8>(p, stream);
+        case 13: return launch_bin2<13>(p, stream);
+        case 19: return launch_bin2<19>(p, stream);
+        case 24: return launch_bin2<24>(p, stream);
+    }
+    return hipErrorInvalidValue;
+}

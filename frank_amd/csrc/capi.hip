@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <utility>
 #include <string>
 #include <vector>
@@ -17,6 +19,7 @@
 #include "../../include/frank_hip.h"
 #include "bessel.h"
 #include "dht_host.h"
+#include "j0_buckets.h"
 #include "kernels.h"
 
 namespace {
@@ -129,10 +132,19 @@ struct fh_ctx {
     // DHT constants on the device
     DevBuf<double> zeros, j0_table, Y, Ykm, q, pref_fwd, pref_bwd;
     // K1
-    int part_blocks[2] = {0, 0};
-    DevBuf<double> partials[2], partial_scalars, stats_sum, stats_minmax, a_scale, sumwV2, prep, reduce_scratch;
+    int part_blocks[3] = {0, 0, 0};
+    DevBuf<double> partials[3], partial_scalars, stats_sum, stats_minmax, a_scale, sumwV2, prep, reduce_scratch;
     DevBuf<int> work_counter;
     int deproject_blocks = 0;
+    // K1 v2 (bin_gram2.hip): bucket sort workspaces and the Taylor tables of the buckets seen so far
+    bool v2 = false, force_static = false;
+    int XS = 0, k1_nb_built = 0, sort_blocks = 0;
+    double k1_delta = 0;
+    DevBuf<double> k1_table, k1_rows;
+    DevBuf<int> k1_hist, k1_totals, k1_starts, k1_info, k1_chunk_bucket;
+    std::vector<double> k1_scalars_host;
+    hipEvent_t ev_pre0 = nullptr;
+    float last_prepass_ms = 0.f;
     // N > 303: rows to memory + rocBLAS dsyrk; stats_sum then holds the dense (N+1)^2 Gram (upper triangle) + 2 scalars
     bool wide = false;
     size_t tail_offset = 0;      // index of sum log(w / 2 pi) in stats_sum
@@ -227,6 +239,14 @@ int fh_dht_get(const fh_dht *d, double *r, double *q, double *zeros, double *Ykm
     return FH_OK;
 }
 
+int fh_dht_bucket_tables(const fh_dht *d, int b0, int b1, double *table, double *delta) {
+    if (!d || b0 < 0 || b1 < b0) return fail(FH_ERR_INVALID, "fh_dht_bucket_tables: bad argument");
+    if (delta) *delta = fh_k1_bucket_width(d->zeros.data(), d->N);
+    if (table && fh_k1_bucket_table(d->zeros.data(), d->N, d->N, b0, b1, table) != 0)
+        return fail(FH_ERR_INVALID, "fh_dht_bucket_tables: table construction failed");
+    return FH_OK;
+}
+
 // ---- contexts -------------------------------------------------------------------------------------------------
 int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     if (!dht || !out) return fail(FH_ERR_INVALID, "fh_ctx_create: NULL argument");
@@ -276,36 +296,60 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     HIP_TRY(hipMemcpy(c->pref_fwd.p, pf.data(), sizeof(double) * N, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->pref_bwd.p, pb.data(), sizeof(double) * N, hipMemcpyHostToDevice));
 
-    // K1 workspaces (0 => N too large for the register-resident kernel: the rows-to-memory + dsyrk path is used)
-    c->NBT = fh_k1_nbt_for(N);
-    if (const char *e = getenv("FRANK_AMD_K1"))  // development switch: FRANK_AMD_K1=wide forces the rows + dsyrk path
-        if (!strcmp(e, "wide")) c->NBT = 0;
+    // K1 workspaces.  v2 (bin_gram2.hip, design block generated on the matrix pipe) covers N <= 383; beyond that, and
+    // for the debris model, rows go to memory and rocBLAS forms the Gram.  Development switches: FRANK_AMD_K1=v1 selects
+    // the first kernel (J0 on the vector ALU, N <= 303), FRANK_AMD_K1=wide forces the rows + dgemm path.
+    const char *k1env = getenv("FRANK_AMD_K1");
+    const bool want_v1 = k1env && !strcmp(k1env, "v1"), want_wide = k1env && !strcmp(k1env, "wide");
+    c->v2 = !want_v1 && !want_wide && fh_k1v2_nbt_for(N) != 0;
+    c->NBT = want_wide ? 0 : (c->v2 ? fh_k1v2_nbt_for(N) : fh_k1_nbt_for(N));
+    HIP_TRY(hipEventCreate(&c->ev_pre0));
     if (c->NBT) {
-        c->ntiles = fh_k1_ntiles(c->NBT);
-        c->nparts = fh_k1_nparts(c->NBT);
         const int G = c->num_cu > 0 ? c->num_cu : 256;
-        if (c->nparts == 1) {
-            c->part_blocks[0] = G;
-            c->part_blocks[1] = 0;
+        if (c->v2) {
+            c->ntiles = fh_k1v2_ntiles(c->NBT);
+            c->nparts = fh_k1v2_nparts(c->NBT);
+            c->XS = fh_k1v2_xstride(c->NBT);
+            c->k1_delta = fh_k1_bucket_width(dht->zeros.data(), N);
+            // split the CUs over the parts by their MFMA work per 16 rows: 4 per tile + 3 per generated column block
+            double wsum = 0, wp[3] = {0, 0, 0};
+            for (int P = 0; P < c->nparts; ++P)
+                wsum += wp[P] = 4.0 * fh_k1v2_part_ntiles(c->NBT, P) + 3.0 * (c->NBT - fh_k1v2_part_block0(c->NBT, P));
+            int left = G;
+            for (int P = 0; P < c->nparts; ++P) {
+                int g = P == c->nparts - 1 ? left : (int)llround(G * wp[P] / wsum);
+                if (g < 1) g = 1;
+                if (g > left - (c->nparts - 1 - P)) g = left - (c->nparts - 1 - P);
+                c->part_blocks[P] = g;
+                left -= g;
+            }
+            for (int P = 0; P < c->nparts; ++P)
+                HIP_TRY(c->partials[P].alloc((size_t)c->part_blocks[P] * fh_k1v2_part_ntiles(c->NBT, P) * 256));
+            HIP_TRY(c->k1_info.alloc(4));
         } else {
-            // split the CUs in proportion to the parts' work per visibility: their tiles (MFMA) plus the J0 column blocks
-            // they have to evaluate (part 0 all 19, part 1 the last 12).  The weight of a block of 16 J0 columns comes
-            // from sweeps of the split at N = 300 (12-wave layout, Horner J0): 149 workgroups 27.8 ms, 153 27.1 ms,
-            // 157 28.0 ms -- about 3.3 tile updates; the optimum is flat to +-2 workgroups.
-            const int t0 = fh_k1_part_ntiles(c->NBT, 0), t1 = fh_k1_part_ntiles(c->NBT, 1);
-            const double w0 = t0 + 3.3 * c->NBT, w1 = t1 + 3.3 * (c->NBT - 7);
-            int g0 = (int)llround((double)G * w0 / (w0 + w1));
-            if (const char *e = getenv("FRANK_AMD_K1_SPLIT")) g0 = atoi(e);  // development: workgroups of part 0
-            if (g0 < 1) g0 = 1;
-            if (g0 > G - 1) g0 = G - 1;
-            c->part_blocks[0] = g0;
-            c->part_blocks[1] = G - g0;
+            c->ntiles = fh_k1_ntiles(c->NBT);
+            c->nparts = fh_k1_nparts(c->NBT);
+            if (c->nparts == 1) {
+                c->part_blocks[0] = G;
+                c->part_blocks[1] = 0;
+            } else {
+                // split the CUs in proportion to the parts' work per visibility: their tiles (MFMA) plus the J0 column
+                // blocks they have to evaluate (part 0 all 19, part 1 the last 12); block weight from sweeps at N = 300
+                const int t0 = fh_k1_part_ntiles(c->NBT, 0), t1 = fh_k1_part_ntiles(c->NBT, 1);
+                const double w0 = t0 + 3.3 * c->NBT, w1 = t1 + 3.3 * (c->NBT - 7);
+                int g0 = (int)llround((double)G * w0 / (w0 + w1));
+                if (const char *e = getenv("FRANK_AMD_K1_SPLIT")) g0 = atoi(e);  // development: workgroups of part 0
+                if (g0 < 1) g0 = 1;
+                if (g0 > G - 1) g0 = G - 1;
+                c->part_blocks[0] = g0;
+                c->part_blocks[1] = G - g0;
+            }
+            for (int P = 0; P < c->nparts; ++P)
+                HIP_TRY(c->partials[P].alloc((size_t)c->part_blocks[P] * fh_k1_part_ntiles(c->NBT, P) * 256));
         }
-        for (int P = 0; P < c->nparts; ++P)
-            HIP_TRY(c->partials[P].alloc((size_t)c->part_blocks[P] * fh_k1_part_ntiles(c->NBT, P) * 256));
         c->deproject_blocks = 8 * G;
         HIP_TRY(c->partial_scalars.alloc((size_t)c->deproject_blocks * 4));
-        HIP_TRY(c->work_counter.alloc(2));
+        HIP_TRY(c->work_counter.alloc(4));
         HIP_TRY(c->stats_sum.alloc((size_t)c->ntiles * 256 + 2));
         HIP_TRY(c->reduce_scratch.alloc(8 * (size_t)c->ntiles * 256));
         HIP_TRY(c->stats_minmax.alloc(2));
@@ -392,6 +436,7 @@ void fh_ctx_destroy(fh_ctx *c) {
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev_bin0) (void)hipEventDestroy(c->ev_bin0);
     if (c->ev_bin1) (void)hipEventDestroy(c->ev_bin1);
+    if (c->ev_pre0) (void)hipEventDestroy(c->ev_pre0);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -574,6 +619,51 @@ int fh_ctx_set_scale_height(fh_ctx *c, const double *H2) {
     return FH_OK;
 }
 
+// ---- K1 v2: Taylor tables of the buckets (j0_buckets.h) ------------------------------------------------------------
+// The host copy is shared by every context of the same basis size in the process (the zeros depend on N only) and only
+// ever grows; a context's device copy is re-uploaded when a table with more buckets is needed.
+namespace {
+struct K1TableCache {
+    std::mutex mu;
+    std::map<std::pair<int, int>, std::shared_ptr<std::vector<double>>> tabs;  // (N, XS) -> [nb][12][XS]
+} g_k1_tables;
+}  // namespace
+
+static int k1v2_ensure_table(fh_ctx *c, int nb_needed) {
+    if (nb_needed <= c->k1_nb_built) return FH_OK;
+    const size_t per = (size_t)FH_K1_TERMS * c->XS;
+    // 25 % headroom so that fits of similar tables do not rebuild; bounded so that one absurd baseline cannot ask for
+    // an absurd table (s = q/Qmax < 1 whenever the q-range check of statistical_models.py:526 would pass)
+    int nb_new = nb_needed + nb_needed / 4 + 8;
+    const size_t cap_bytes = (size_t)4 << 30;
+    if ((size_t)nb_needed * per * sizeof(double) > cap_bytes)
+        return fail(FH_ERR_UNSUPPORTED, "baselines reach %.1f x Qmax: the bucket tables of bin_gram would need %.1f GB",
+                    nb_needed * c->k1_delta, nb_needed * per * 8e-9);
+    if ((size_t)nb_new * per * sizeof(double) > cap_bytes) nb_new = nb_needed;
+    std::shared_ptr<std::vector<double>> tab;
+    {
+        std::lock_guard<std::mutex> lk(g_k1_tables.mu);
+        auto &slot = g_k1_tables.tabs[{c->N, c->XS}];
+        if (!slot) slot = std::make_shared<std::vector<double>>();
+        const int have = (int)(slot->size() / per);
+        if (have < nb_new) {
+            // a NEW vector (readers of the old one keep their shared_ptr): old buckets copied, new ones computed
+            auto grown = std::make_shared<std::vector<double>>((size_t)nb_new * per);
+            if (have) memcpy(grown->data(), slot->data(), sizeof(double) * (size_t)have * per);
+            if (fh_k1_bucket_table(c->dht->zeros.data(), c->N, c->XS, have, nb_new, grown->data() + (size_t)have * per) != 0)
+                return fail(FH_ERR_INVALID, "fh_k1_bucket_table failed");
+            slot = grown;
+        }
+        tab = slot;
+    }
+    const int nb_up = (int)(tab->size() / per);
+    HIP_TRY(hipStreamSynchronize(c->stream));  // nothing in flight may still read the old device table
+    if (c->k1_table.alloc((size_t)nb_up * per) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc of the bucket tables failed");
+    HIP_TRY(hipMemcpy(c->k1_table.p, tab->data(), sizeof(double) * (size_t)nb_up * per, hipMemcpyHostToDevice));
+    c->k1_nb_built = nb_up;
+    return FH_OK;
+}
+
 int fh_bin_reset(fh_ctx *c) {
     if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
@@ -582,6 +672,115 @@ int fh_bin_reset(fh_ctx *c) {
     // (-qmin, qmax) under max start at -infinity: 0xFFF0000000000000 is not a byte pattern, but 0xFFFFFFFF words are a
     // NaN, and fmax(NaN, x) = x -- the same neutral element, set without a host-side source buffer or a wait
     HIP_TRY(hipMemsetAsync(c->stats_minmax.p, 0xFF, 2 * sizeof(double), c->stream));
+    c->have_device_Mj = false;
+    return FH_OK;
+}
+
+// fit_loop kernels of earlier fits that are still RUNNING each hold a CU (a slot stays "busy" until it is collected, long
+// after its kernel has finished: counting those would leave CUs idle)
+static int running_fit_loops(fh_ctx *c) {
+    int running = 0;
+    if (c->slots_busy > 0)
+        for (auto &b : c->batches)
+            if (b.active && b.launched && hipStreamQuery(b.stream) == hipErrorNotReady) running += b.n;
+    (void)hipGetLastError();  // hipErrorNotReady is not an error here
+    return running;
+}
+
+// K1 v2: deproject -> (host: baseline range, bucket tables) -> bucket sort -> bin_gram2 -> slab reduction.
+// The one host round trip (64 KB of per-block scalars) is what _check_uv_range needs before any binning in the reference
+// too (statistical_models.py:166-169); it costs the stream ~20 us of idle time per call.
+static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count) {
+    if (count > 0x7fffffff - 16 * 65536) return fail(FH_ERR_UNSUPPORTED, "more than 2^31 visibilities in one call: split it");
+    int dblocks = (int)((count + 255) / 256);
+    if (dblocks > c->deproject_blocks) dblocks = c->deproject_blocks;
+    if (dblocks < 1) dblocks = 1;
+    p.partial_scalars = c->partial_scalars.p;
+    HIP_TRY(hipEventRecord(c->ev_pre0, c->stream));
+    HIP_TRY(fh_k1_launch_deproject(p, dblocks, c->stream));
+    c->k1_scalars_host.resize((size_t)dblocks * 4);
+    HIP_TRY(hipMemcpyAsync(c->k1_scalars_host.data(), c->partial_scalars.p, sizeof(double) * (size_t)dblocks * 4,
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double qmax = 0.0;
+    for (int b = 0; b < dblocks; ++b) {
+        const double m = c->k1_scalars_host[(size_t)b * 4 + 2];
+        if (m > qmax) qmax = m;  // (-inf for blocks without rows; NaN baselines never win)
+    }
+    if (!(qmax < INFINITY)) return fail(FH_ERR_INVALID, "non-finite baseline in the visibility table");
+    const double delta = c->k1_delta, inv_delta = 1.0 / delta;
+    const double smax = qmax * p.inv_Qmax;
+    if (smax * inv_delta > 2.0e9) return fail(FH_ERR_UNSUPPORTED, "baselines reach %.3g x Qmax", smax);
+    const int nb = (int)(smax * inv_delta) + 2;  // one spare bucket: the device recomputes s * inv_delta itself
+    int rc = k1v2_ensure_table(c, nb);
+    if (rc) return rc;
+    // sort workspaces (grow on demand)
+    int sblocks = (int)((count + 255) / 256);
+    if (sblocks > 512) sblocks = 512;
+    if (sblocks < 1) sblocks = 1;
+    const size_t nrows = (size_t)count + 16 * (size_t)nb + 16, nchunks_max = nrows / 16 + 1;
+    if (c->k1_rows.n < nrows * 4 && c->k1_rows.alloc(nrows * 4) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc (sorted rows) failed");
+    if (c->k1_chunk_bucket.n < nchunks_max && c->k1_chunk_bucket.alloc(nchunks_max) != hipSuccess)
+        return fail(FH_ERR_NOMEM, "hipMalloc (chunk map) failed");
+    if (c->k1_hist.n < (size_t)sblocks * nb && c->k1_hist.alloc((size_t)sblocks * nb + 1024) != hipSuccess)
+        return fail(FH_ERR_NOMEM, "hipMalloc (histograms) failed");
+    if (c->k1_totals.n < (size_t)nb && c->k1_totals.alloc((size_t)nb + 256) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc failed");
+    if (c->k1_starts.n < (size_t)nb + 1 && c->k1_starts.alloc((size_t)nb + 257) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc failed");
+    SortParams sp{};
+    sp.s = p.prep_s;
+    sp.sw = p.prep_sw;
+    sp.swV = p.prep_swV;
+    sp.n = count;
+    sp.inv_delta = inv_delta;
+    sp.delta = delta;
+    sp.nb = nb;
+    sp.blocks = sblocks;
+    sp.hist = c->k1_hist.p;
+    sp.totals = c->k1_totals.p;
+    sp.starts = c->k1_starts.p;
+    sp.info = c->k1_info.p;
+    sp.rows = c->k1_rows.p;
+    sp.chunk_bucket = c->k1_chunk_bucket.p;
+    HIP_TRY(fh_k1v2_launch_sort(sp, c->stream));
+
+    const int running = running_fit_loops(c);
+    // throughput mode while fit_loop kernels hold CUs (a workgroup that starts late simply takes fewer runs); fits of a
+    // pipeline are run-dependent in their last bits anyway; synchronous fits stay static = bitwise reproducible
+    const bool dynamic = (running > 0 || c->slots_busy > 0 || getenv("FRANK_AMD_K1_DYNAMIC") != nullptr) && !c->force_static;
+    Bin2Params bp{};
+    bp.N = c->N;
+    bp.rows = c->k1_rows.p;
+    bp.chunk_bucket = c->k1_chunk_bucket.p;
+    bp.info = c->k1_info.p;
+    bp.table = c->k1_table.p;
+    bp.work_counter = dynamic ? c->work_counter.p : nullptr;
+    if (dynamic) HIP_TRY(hipMemsetAsync(c->work_counter.p, 0, 4 * sizeof(int), c->stream));
+    ReduceParams rp{};
+    rp.nparts = c->nparts;
+    rp.ntiles = c->ntiles;
+    int reserve = running;
+    if (reserve > c->num_cu / 4) reserve = c->num_cu / 4;
+    int G = 0;
+    for (int P = 0; P < c->nparts; ++P) G += c->part_blocks[P];
+    for (int P = 0; P < 3; ++P) {
+        int blocks = P < c->nparts ? c->part_blocks[P] : 0;
+        if (P < c->nparts && reserve > 0 && G > 0) blocks -= (reserve * c->part_blocks[P] + G - 1) / G;
+        if (P < c->nparts && blocks < 1) blocks = 1;
+        bp.part_blocks[P] = blocks;
+        bp.partials[P] = c->partials[P].p;
+        rp.part_blocks[P] = blocks;
+        rp.part_tile0[P] = P < c->nparts ? fh_k1v2_part_tile0(c->NBT, P) : 0;
+        rp.part_ntiles[P] = P < c->nparts ? fh_k1v2_part_ntiles(c->NBT, P) : 0;
+        rp.partials[P] = c->partials[P].p;
+    }
+    rp.partial_scalars = c->partial_scalars.p;
+    rp.scratch = c->reduce_scratch.p;
+    rp.scalar_blocks = dblocks;
+    HIP_TRY(hipEventRecord(c->ev_bin0, c->stream));
+    HIP_TRY(fh_k1v2_launch_bin(c->NBT, bp, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_bin1, c->stream));
+    c->bin_timed = true;
+    HIP_TRY(fh_k1_launch_reduce(rp, c->stats_sum.p, c->stats_minmax.p, c->stream));
     c->have_device_Mj = false;
     return FH_OK;
 }
@@ -661,6 +860,7 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
         c->have_device_Mj = false;
         return FH_OK;
     }
+    if (c->v2) return bin_visibilities_v2(c, p, count);
     // fit_loop kernels of earlier fits that are still RUNNING each hold a CU (a slot stays "busy" until it is collected,
     // long after its kernel has finished: counting those would leave CUs idle)
     int running = 0;
@@ -671,7 +871,7 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     // throughput mode while such kernels hold CUs (see bin_gram.hip)
     // (also while fits of a pipeline are merely outstanding: the dynamic hand-out is 2 % faster even on an empty GPU,
     // 26.7 vs 27.2 ms, and a pipeline's sums are run-dependent in their last bits anyway; synchronous fits stay static)
-    const bool dynamic = running > 0 || c->slots_busy > 0 || getenv("FRANK_AMD_K1_DYNAMIC") != nullptr;
+    const bool dynamic = (running > 0 || c->slots_busy > 0 || getenv("FRANK_AMD_K1_DYNAMIC") != nullptr) && !c->force_static;
     p.work_counter = dynamic ? c->work_counter.p : nullptr;
     if (dynamic) HIP_TRY(hipMemsetAsync(c->work_counter.p, 0, 2 * sizeof(int), c->stream));
     ReduceParams rp{};
@@ -716,6 +916,20 @@ int fh_bin_last_kernel_ms(fh_ctx *c, float *ms) {
     if (!c->bin_timed) return fail(FH_ERR_INVALID, "no bin_gram launch recorded yet");
     HIP_TRY(hipEventSynchronize(c->ev_bin1));
     HIP_TRY(hipEventElapsedTime(ms, c->ev_bin0, c->ev_bin1));
+    return FH_OK;
+}
+
+int fh_bin_last_prepass_ms(fh_ctx *c, float *ms) {
+    if (!c || !ms) return fail(FH_ERR_INVALID, "fh_bin_last_prepass_ms: NULL argument");
+    if (!c->bin_timed || !c->v2) return fail(FH_ERR_INVALID, "no bin_gram (v2) launch recorded yet");
+    HIP_TRY(hipEventSynchronize(c->ev_bin0));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev_pre0, c->ev_bin0));
+    return FH_OK;
+}
+
+int fh_ctx_set_reproducible(fh_ctx *c, int on) {
+    if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
+    c->force_static = on != 0;
     return FH_OK;
 }
 

@@ -35,11 +35,44 @@ struct BinParams {
 
 struct ReduceParams {
     int nparts, ntiles, scalar_blocks;
-    int part_blocks[2], part_tile0[2], part_ntiles[2];
-    const double *partials[2];
+    int part_blocks[3], part_tile0[3], part_ntiles[3];
+    const double *partials[3];
     const double *partial_scalars;
     double *scratch;  // 8 * ntiles * 256 doubles: level-1 sums of the slab reduction
 };
+
+// ---- K1 v2 (bin_gram2.hip): bucket sort + design block generated on the matrix pipe ------------------------------
+struct SortParams {
+    const double *s, *sw, *swV;  // K1a output, n rows
+    int64_t n;
+    double inv_delta, delta;     // bucket width in s (j0_buckets.h)
+    int nb, blocks;              // buckets; workgroups of the histogram / scatter passes
+    int *hist;                   // [blocks][nb]
+    int *totals;                 // [nb]
+    int *starts;                 // [nb + 1]
+    int *info;                   // [0] = number of 16-row chunks of the sorted table
+    double *rows;                // sorted table, 4 doubles per row (tau, sqrt(w), sqrt(w) Re V', -), n + 16 nb rows
+    int *chunk_bucket;           // bucket of every chunk
+};
+struct Bin2Params {
+    int N;
+    const double *rows;
+    const int *chunk_bucket;
+    const int *info;
+    const double *table;         // [bucket][12][xstride]: Taylor tables (fh_k1_bucket_table)
+    int *work_counter;           // NULL = static contiguous ranges (bitwise reproducible); else one int per part
+    int part_blocks[3];
+    double *partials[3];         // per part: [part_blocks][part_ntiles][256]
+};
+int fh_k1v2_nbt_for(int N);
+int fh_k1v2_xstride(int NBT);
+int fh_k1v2_ntiles(int NBT);
+int fh_k1v2_nparts(int NBT);
+int fh_k1v2_part_tile0(int NBT, int P);
+int fh_k1v2_part_ntiles(int NBT, int P);
+int fh_k1v2_part_block0(int NBT, int P);
+hipError_t fh_k1v2_launch_sort(const SortParams &sp, hipStream_t stream);
+hipError_t fh_k1v2_launch_bin(int NBT, const Bin2Params &p, hipStream_t stream);
 
 int fh_k1_nbt_for(int N);
 int fh_k1_ntiles(int NBT);

@@ -65,6 +65,13 @@ int fh_dht_size(const fh_dht *dht);
 int fh_dht_get(const fh_dht *dht, double *r, double *q, double *zeros, double *Ykm, double *scale_factor,
                double *Qmax, double *Rmax);
 
+/* The Taylor tables behind bin_gram's evaluation of J0((q/Qmax) j_k) (hankel.py:201-202), for inspection and tests
+ * (host only, no GPU needed).  Visibilities are grouped into buckets of s = q/Qmax of width *delta = 1/(2 j_N); in
+ * bucket b, with tau = (s - (b + 1/2) delta) / (delta / 2) in [-1, 1],
+ *     J0(s j_k) = sum_{n < 12} table[(b - b0) * 12 * N + n * N + k] * tau^n        (truncation error 1.2e-16).
+ * table: (b1 - b0) * 12 * N doubles, or NULL to query delta only.                                                    */
+int fh_dht_bucket_tables(const fh_dht *dht, int b0, int b1, double *table, double *delta);
+
 /* ---- contexts ------------------------------------------------------------------------------------------- */
 int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out);
 void fh_ctx_destroy(fh_ctx *ctx);
@@ -114,6 +121,15 @@ int fh_bin_reset(fh_ctx *ctx);
 int fh_bin_visibilities(fh_ctx *ctx, const fh_geometry *geom, const fh_vis *vis, int64_t first, int64_t count);
 /* Device time (ms, HIP events on the context's stream) of the most recent bin_gram launch alone. */
 int fh_bin_last_kernel_ms(fh_ctx *ctx, float *ms);
+/* Time (ms) from the start of the deprojection pre-pass to the start of that bin_gram launch: deprojection, the host's
+ * look at the baseline range (the _check_uv_range input, statistical_models.py:166-169) and the bucket sort.          */
+int fh_bin_last_prepass_ms(fh_ctx *ctx, float *ms);
+/* Work hand-out of bin_gram.  By default a synchronous fit deals contiguous ranges of the sorted table to the workgroups
+ * (the sums come out bit for bit the same in every run) and a pipeline of fits (fh_fit_submit outstanding) lets the
+ * workgroups pull work from a counter, which is faster while fit loops occupy compute units but makes the last bits
+ * depend on the run.  on != 0 forces the first, reproducible hand-out everywhere, as the reference's single-threaded
+ * sums are (statistical_models.py:200-214).                                                                          */
+int fh_ctx_set_reproducible(fh_ctx *ctx, int on);
 int fh_stats_device(fh_ctx *ctx, double **sum_stats, int64_t *n_sum, double **minmax_stats);
 int fh_stats_finalize(fh_ctx *ctx, const fh_geometry *geom, int vis_model, int check_qbounds, double *M, double *j,
                       double *H0, double *qmin, double *qmax);

@@ -161,3 +161,44 @@ def test_split_grid_and_device_argument():
         assert DiscreteHankelTransform(1e-5, 12).device == 2
     finally:
         del os.environ["FRANK_AMD_DEVICE"]
+
+
+@pytest.mark.parametrize("N", [20, 300])
+def test_bucket_tables_reproduce_j0(N):
+    """The Taylor tables bin_gram multiplies on the matrix pipe (fh_dht_bucket_tables, host long double) against
+    scipy.special.j0 and mpmath at random points of random buckets: |error| <= 2.5e-16 (Cephes itself is 4e-16 .. 1.3e-15
+    off the true J0 in this range), for the first bucket (expansion point next to the singular point of Bessel's
+    equation), the buckets of the bench workload and the last bucket of the q range."""
+    import mpmath
+    from scipy.special import j0
+    from frank_amd import _lib
+    d = ctypes.c_void_p()
+    _lib.check(_lib.lib.fh_dht_create(RMAX, N, 0, ctypes.byref(d)))
+    zeros = np.empty(N + 1)
+    _lib.check(_lib.lib.fh_dht_get(d, None, None, _lib.ptr(zeros), None, None, None, None))
+    delta = ctypes.c_double()
+    _lib.check(_lib.lib.fh_dht_bucket_tables(d, 0, 0, None, ctypes.byref(delta)))
+    assert delta.value == 0.5 / zeros[N - 1]
+    nb = int(1.0 / delta.value) + 1
+    rng = np.random.default_rng(7)
+    worst_mp = 0.0
+    for b in [0, 1, 2, nb // 7, nb // 2, nb - 1]:
+        tab = np.empty((12, N))
+        _lib.check(_lib.lib.fh_dht_bucket_tables(d, b, b + 1, _lib.ptr(tab), None))
+        s0 = (b + 0.5) * delta.value
+        tau = rng.uniform(-1, 1, 64)
+        tau[:2] = (-1.0, 1.0)
+        P = tau[:, None] ** np.arange(12)[None, :]
+        X = np.zeros((64, N))
+        for n in range(11, -1, -1):  # small terms first, as the kernel accumulates
+            X += P[:, n:n + 1] * tab[n][None, :]
+        s = s0 + tau * (delta.value / 2)
+        ref = j0(np.outer(s, zeros[:N]))
+        # scipy's own error (4e-16 .. 1.3e-15) plus the rounding of its argument fl(s * j_k), up to 1e-13 * |J1| at x ~ 1e3
+        assert np.abs(X - ref).max() < 1e-14
+        mpmath.mp.dps = 30
+        for i, k in ((0, 0), (1, N - 1), (5, N // 3), (9, N // 2), (17, 1)):
+            x = (mpmath.mpf(s0) + mpmath.mpf(float(tau[i])) * mpmath.mpf(delta.value / 2)) * mpmath.mpf(float(zeros[k]))
+            worst_mp = max(worst_mp, abs(float(mpmath.besselj(0, x) - mpmath.mpf(float(X[i, k])))))
+    assert worst_mp < 2.5e-16
+    _lib.lib.fh_dht_destroy(d)

@@ -206,6 +206,28 @@ def test_lognormal_map_solve(golden, N):
     np.testing.assert_allclose(p_new, g["map_p_updated"], rtol=1e-7)
 
 
+def test_lognormal_map_solve_N300(golden):
+    """The same solve at the basis size of BASELINE configs[2].  Here the reference itself is determined only to its
+    recorded self-sensitivity (1.6e-4 in s in the faint outer disc, 1e-7 of max I, after a 1e-15 perturbation of M:
+    MinimizeNewton's tol = 1e-7 stop), which scales the assertions."""
+    g = golden("lognormal_N300.npz")
+    d = fo.DHT(RMAX, 300)
+    s0 = float(np.log(g["I_scale"]))
+    out = fo.lognormal_map(d, g["M"], g["j"], g["p_seed"], g["s_guess"], s0)
+    assert out["rc"] == 0
+    sens_s = float(g["map_selfsens_s"])
+    assert np.abs(out["s"] - g["map_s"]).max() < 5 * sens_s
+    I, Iref = np.exp(out["s"] + s0), np.exp(g["map_s"] + s0)
+    assert np.abs(I - Iref).max() / Iref.max() < 1e-6
+    assert rel_to_max(out["Dinv"], g["map_Dinv"]) < 1e-7
+    status, nstep, nfev, nhess = (int(x) for x in g["map_stats"])
+    assert out["stats"][0] == status and out["stats"][3] == nhess
+    assert abs(out["stats"][1] - nstep) <= 3 * abs(int(g["map_selfsens_nstep"]) - nstep) + 0.01 * nstep
+    _, band = fo.smoothing_matrix(d, 1e-2)
+    p_new = fo.update_power_spectrum(d, band, 1.3, 1e-35, g["p_seed"], out["s"], out["chol"])
+    np.testing.assert_allclose(p_new, g["map_p_updated"], rtol=2e-4)
+
+
 def test_lognormal_fit_N80(golden):
     """FrankFitter(method='LogNormal') (radial_fitters.py:737-832), alpha=1.05, w_smooth=1e-4, 968 passes.
     The Newton solves end in round-off (exit 1 / 3 dominate and are ignored by the reference), so the fit is

@@ -102,6 +102,16 @@ def case(name, N, n, fits):
                map_cov_diag=np.diag(ln.covariance).copy(), map_stats=np.array(_newton_stats[-1]),
                map_p_updated=filt.update_power_spectrum(ln))
     print("   MAP solve exit (status, nstep, nfev, nhess) =", _newton_stats[-1])
+    # the reference's OWN sensitivity of this solve to a 1e-15 relative perturbation of M: at N = 300 the faint outer
+    # disc is loosely held by MinimizeNewton's tol = 1e-7 stop (1.6e-4 in s there), the profile to 1e-7 of its maximum
+    rng = np.random.default_rng(1)
+    Mp = M * (1 + 1e-15 * rng.standard_normal(M.shape))
+    ln2 = LogNormalMAPModel(D, 0.5 * (Mp + Mp.T), j, p_seed, guess=s_guess.copy(), s0=s0)
+    I1, I2 = np.exp(ln.MAP + s0), np.exp(ln2.MAP + s0)
+    out.update(map_selfsens_s=np.max(np.abs(ln2.MAP - ln.MAP)), map_selfsens_I_relmax=np.max(np.abs(I2 - I1)) / I1.max(),
+               map_selfsens_nstep=_newton_stats[-1][1])
+    print("   self-sensitivity of the MAP solve: %.2e in s, %.2e of max I, nstep %d" % (
+        out["map_selfsens_s"], out["map_selfsens_I_relmax"], out["map_selfsens_nstep"]))
     for tag, (alpha, ws) in fits.items():
         a = whole_fit(N, alpha, ws, mapping)
         b = whole_fit(N, alpha, ws, mapping, perturb_seed=1)
