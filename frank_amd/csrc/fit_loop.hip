@@ -49,7 +49,13 @@ namespace {
 #endif
 constexpr int KT = FIT_LOOP_THREADS;
 constexpr int NW = KT / 64;
-constexpr int NWK = NW - NW / 4;  // trailing-update workers: the waves that do not share wave 0's SIMD
+// Trailing-update workers.  At first the waves that share wave 0's SIMD sat the trailing update out (fp64 VALU and MFMA
+// share a SIMD's DP units and wave 0's serial chain was the critical path); with the rows of the inverse merged into the
+// steps the workers are the longer side, so every wave but wave 0 works (K2_ALL_WORK 0 restores the old split).
+#ifndef K2_ALL_WORK
+#define K2_ALL_WORK 1
+#endif
+constexpr int NWK = K2_ALL_WORK ? NW - 1 : NW - NW / 4;
 constexpr int PS = 17;  // LDS stride of the 16-wide panel rows (doubles)
 constexpr int PF = 2;   // W tiles in flight per chain of the row-by-row inverse
 
@@ -187,77 +193,46 @@ __device__ __forceinline__ void store_tile(double *Mx, int ld, int I, int J, con
     }
 }
 
-// ---- (4) row-by-row inverse: W_IJ = -W_II * sum_{K=J}^{I-1} L_IK W_KJ, one block row at a time ------------------------
+// ---- (4) row-by-row inverse: W_IJ = -W_II * sum_{K=J}^{I-1} L_IK W_KJ --------------------------------------------------
 // The first design was a recursive, GEMM-shaped block inverse whose temporary T was written and read back at every
-// level: ~8 MB of L2 traffic per iteration, 156 us.  Here a row's L tiles are staged once in LDS (the next row's while this row computes), the sum
-// is accumulated in registers, and the accumulator -- already in the layout of an MFMA B operand -- is multiplied by
-// W_II without touching memory: ~3.5 MB per iteration, one barrier per block row.  W's mirror blocks are not needed.
-__device__ __noinline__ void row_inverse(const double *C, double *W, const double *WdT, double *cs, double *stage0,
-                                         double *stage1, int N, int nb, int ld, long long *timing) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cl = lane & 15, rg = lane >> 4;
-#ifdef FIT_LOOP_TIMING
-    long long t_last = clock64();
-#endif
-    auto cs_ptr = [&](int I, int J) { return cs + ((size_t)I * nb + J) * 16; };
-    // stage[K][k][i] = L_IK[i][k] (the mirror block (K, I) of C, row-major): fragment s of lane (cl, rg) is
-    // stage[K * 256 + (4 s + rg) * 16 + cl]
-    auto stage_row = [&](int I, double *stage) {
-        for (int e = tid; e < I * 256; e += KT) {
-            const int K = e >> 8, r = (e >> 4) & 15, c = e & 15;
-            stage[e] = C[(size_t)(16 * K + r) * ld + 16 * I + c];
-        }
-    };
-    if (nb > 1) stage_row(1, stage0);
-    __syncthreads();
-    constexpr int PFR = PF;  // W tiles in flight per chain (4 deep and a register-held stage were tried: spills, slower)
-    for (int I = 1; I < nb; ++I) {
-        double *stage = (I & 1) ? stage0 : stage1;
-        if (I + 1 < nb) stage_row(I + 1, (I & 1) ? stage1 : stage0);
-        Frag fw;  // A operand W_II: rows of its transpose
-        {
-            const double *wd = WdT + (size_t)I * 256 + rg * 16 + cl;
+// level (~8 MB of L2 traffic per iteration, 156 us); the second computed the rows one after the other BEHIND the
+// factorisation (a row's L tiles staged in LDS, the sum kept in registers and multiplied by W_II straight from the
+// accumulator, 123 us).  Row I only needs rows <= I of L and rows < I of W, so it is now computed DURING step I of the
+// factorisation: the trailing update shrinks quadratically with the step while the rows of the inverse grow, and the
+// two together keep the waves about evenly busy (the factorisation alone left them idle for most of its second half).
+// One tile W_IJ: `stage` holds row I of L (stage[K][k][i] = L_IK[i][k], fragment s of lane (cl, rg) at
+// stage[K * 256 + (4 s + rg) * 16 + cl]); `fw` is the A operand W_II (rows of its transpose).
+__device__ __forceinline__ void inverse_tile(const double *stage, const Frag &fw, double *W, double *cs_IJ, int I, int J,
+                                             int N, int ld, int cl, int rg) {
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    Frag rb[PF];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) fw.v[q] = wd[64 * q];
-        }
-        // columns in snake order over the waves: the chain of column J has I - J products
-        for (int idx = 0; idx < I; ++idx) {
-            const int slot = idx & (NW - 1);
-            if ((((idx / NW) & 1) ? NW - 1 - slot : slot) != wave) continue;
-            const int J = idx;
-            v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-            Frag rb[PFR];
+    for (int d = 0; d < PF; ++d) rb[d] = load_rows(W + (size_t)(16 * min(J + d, I - 1)) * ld + 16 * J, ld, cl, rg);
+    for (int K = J; K < I; ++K) {
+        Frag fa;
+        const double *sp = stage + K * 256 + rg * 16 + cl;
 #pragma unroll
-            for (int d = 0; d < PFR; ++d) rb[d] = load_rows(W + (size_t)(16 * min(J + d, I - 1)) * ld + 16 * J, ld, cl, rg);
-            for (int K = J; K < I; ++K) {
-                Frag fa;
-                const double *sp = stage + K * 256 + rg * 16 + cl;
+        for (int q = 0; q < 4; ++q) fa.v[q] = sp[64 * q];
+        const Frag fb = rb[0];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) fa.v[q] = sp[64 * q];
-                const Frag fb = rb[0];
-#pragma unroll
-                for (int d = 0; d + 1 < PFR; ++d) rb[d] = rb[d + 1];
-                if (K + PFR < I) rb[PFR - 1] = load_rows(W + (size_t)(16 * (K + PFR)) * ld + 16 * J, ld, cl, rg);
-                acc = mfma4(fa, fb, acc, false);
-            }
-            // the C/D layout of acc (row = rg + 4 r, col = cl) is the B-operand layout (k = 4 s + rg, j = cl)
-            Frag fs;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) fs.v[q] = acc[q];
-            v4f64 w = {0.0, 0.0, 0.0, 0.0};
-            w = mfma4(fw, fs, w, true);
-            store_tile(W, ld, I, J, w, cl, rg, false);
-            double ssq = 0.0;  // column sums of squares of this (final) tile over the rows of the real system
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (16 * I + rg + 4 * r < N) ssq = fma(w[r], w[r], ssq);
-            ssq += __shfl_xor(ssq, 16);
-            ssq += __shfl_xor(ssq, 32);
-            if (rg == 0) cs_ptr(I, J)[cl] = ssq;
-        }
-        __syncthreads();  // row I of W is complete (row I + 1 reads it) and the next row's L tiles are staged
+        for (int d = 0; d + 1 < PF; ++d) rb[d] = rb[d + 1];
+        if (K + PF < I) rb[PF - 1] = load_rows(W + (size_t)(16 * (K + PF)) * ld + 16 * J, ld, cl, rg);
+        acc = mfma4(fa, fb, acc, false);
     }
-    ISTAMP(5);
+    // the C/D layout of acc (row = rg + 4 r, col = cl) is the B-operand layout (k = 4 s + rg, j = cl)
+    Frag fs;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fs.v[q] = acc[q];
+    v4f64 w = {0.0, 0.0, 0.0, 0.0};
+    w = mfma4(fw, fs, w, true);
+    store_tile(W, ld, I, J, w, cl, rg, false);
+    double ssq = 0.0;  // column sums of squares of this (final) tile over the rows of the real system
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (16 * I + rg + 4 * r < N) ssq = fma(w[r], w[r], ssq);
+    ssq += __shfl_xor(ssq, 16);
+    ssq += __shfl_xor(ssq, 32);
+    if (rg == 0) cs_IJ[cl] = ssq;
 }
 
 // ---- one posterior solve: C = A + diag(1/p) -> L -> W = L^-1 -> y = W b, m = W^T y, tr2 = colnorm2(W) --------------
@@ -308,6 +283,18 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             const int j = e - i * (i + 1) / 2;
             S.lst[e] = ((k + 1 + i) << 8) | (k + 1 + j);
         }
+        // row k of L (final since the panels of steps < k) for row k of the inverse, computed beside this step's trailing
+        // update; its columns are handed out from a counter, longest chain (J = 0) first
+        // (loads issued here, written to LDS behind the panel: the panel's MFMAs cover their latency)
+        constexpr int kStageMax = (20 * 256 + KT - 1) / KT;  // NP <= 336
+        double sv[kStageMax];
+#pragma unroll
+        for (int i = 0; i < kStageMax; ++i) {
+            const int e = tid + i * KT;
+            const int K = e >> 8, r = (e >> 4) & 15, c = e & 15;
+            sv[i] = e < k * 256 ? C[(size_t)(16 * K + r) * ld + 16 * k + c] : 0.0;
+        }
+        if (tid == 0) S.flag[1] = 0;
         // look-ahead prefetch: wave 0 starts loading tile (k+1,k+1) now; it is complete when the panel is done
         v4f64 la = {0.0, 0.0, 0.0, 0.0};
         if (wave == 0 && cnt > 0) {
@@ -329,6 +316,11 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
             }
+        }
+#pragma unroll
+        for (int i = 0; i < kStageMax; ++i) {
+            const int e = tid + i * KT;
+            if (e < k * 256) S.stage1[e] = sv[i];
         }
         __syncthreads();
         TSTAMP(2);
@@ -353,7 +345,23 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             for (int s = 0; s < 4; ++s) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s], pb1[4 * s], a, 0, 0, 0);
             return a;
         };
+        // columns of row k of the inverse, pulled from the LDS counter (which wave computes a tile does not change its bits)
+        auto inverse_columns = [&]() {
+            if (k < 1) return;
+            Frag fw;  // A operand W_kk: rows of its transpose
+            const double *wd = WdT + (size_t)k * 256 + rg * 16 + cl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fw.v[q] = wd[64 * q];
+            for (;;) {
+                int J = 0;
+                if (lane == 0) J = atomicAdd(&S.flag[1], 1);
+                J = __builtin_amdgcn_readfirstlane(J);
+                if (J >= k) break;
+                inverse_tile(S.stage1, fw, W, cs_ptr(k, J), k, J, N, ld, cl, rg);
+            }
+        };
         if (wave == 0) {
+            if (cnt == 0) inverse_columns();  // last step: no look-ahead tile, wave 0 joins the last row of the inverse
             if (cnt > 0) {  // tile (k+1, k+1): update, transpose through LDS to row-per-lane, factor, invert
 #ifdef FIT_LOOP_TIMING
                 long long f_last = clock64();
@@ -372,10 +380,11 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 FSTAMP(9);
                 invert_factored_tile(S.dl, S.dli, W, WdT, ld, k + 1, lane, cs_ptr(k + 1, k + 1), rows_valid(k + 1));
                 FSTAMP(10);
+                inverse_columns();  // whatever is left of the row when the chain is done
             }
-        } else if ((wave & 3) != 0) {
-            // worker waves (SIMDs other than wave 0's); tiles 1.. of the list
-            const int widx = wave - 1 - (wave >> 2);  // 0..NWK-1
+        } else if (K2_ALL_WORK || (wave & 3) != 0) {
+            // worker waves; tiles 1.. of the list
+            const int widx = K2_ALL_WORK ? wave - 1 : wave - 1 - (wave >> 2);  // 0..NWK-1
 #ifdef FIT_LOOP_TIMING
             long long w_last = clock64();
 #endif
@@ -399,17 +408,18 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 }
             }
             WSTAMP(11);
+            inverse_columns();
+            WSTAMP(12);
+        } else {
+            // the waves that share wave 0's SIMD sit the trailing update out (fp64 VALU and MFMA share the DP units and
+            // wave 0's serial chain is the critical path of a step); the inverse row they do take part in, last in line
+            inverse_columns();
         }
         __syncthreads();
         TSTAMP(3);
     }
     if (*S.flag) return false;
     TSTAMP(4);
-
-    row_inverse(C, W, WdT, P.cs, S.pan, S.stage1, N, nb, ld, P.timing);
-#ifdef FIT_LOOP_TIMING
-    t_last = clock64();
-#endif
 
     // (5) m = -(row N of W),  tr2_i = sum over the block column of the tile column sums (fixed order)
     for (int i = tid; i < N; i += KT) {
@@ -485,7 +495,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     S.stage1 = S.red + 6 * NP;
     S.band = S.stage1 + (NP / 16) * 256;
     S.lst = reinterpret_cast<int *>(S.band + 5 * NP);
-    S.flag = S.lst + 192;
+    S.flag = S.lst + 192;  // [0] not positive definite, [1] column counter of the inverse row
     __shared__ int s_ctl[4];  // [0] stop, [1] status
 
     if (P.band_lu)
@@ -658,7 +668,7 @@ __global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int 
 
 size_t fh_k2_loop_smem_bytes(int NP) {
     const int panel = NP * PS > 2 * NW * NP ? NP * PS : 2 * NW * NP;
-    return sizeof(double) * (size_t)(panel + (NW + 2) * 16 * PS + 7 * NP + 6 * NP + (NP / 16) * 256 + 5 * NP) + 4 * 192 + 16;
+    return sizeof(double) * (size_t)(panel + (NW + 2) * 16 * PS + 7 * NP + 6 * NP + (NP / 16) * 256 + 5 * NP) + 4 * 192 + 32;
 }
 
 hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s) {

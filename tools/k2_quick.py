@@ -24,5 +24,5 @@ if os.environ.get("FRANK_AMD_LIB"):
     names=['pinv','diag factor','panel trsm','trailing','(unused)','inverse phase A','inverse phase B','m, tr2 reduce']
     tot=sum(out[:8])
 
-    print('wave0: update %.1f factor %.1f invert %.1f | worker wave1 busy %.1f us/iter'%tuple(v/2.1e3/(2*nit+4) for v in out[8:12]))
+    print('wave0: update %.1f factor %.1f invert %.1f | worker wave1: trailing %.1f, inverse row %.1f us/iter'%tuple(v/2.1e3/(2*nit+4) for v in out[8:13]))
     for n_,v in zip(names,out[:8]): print('%-14s %8.1f us/iter  %5.1f%%'%(n_, v/2.1e3/ (2*nit+4) , 100*v/tot))
