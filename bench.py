@@ -270,6 +270,39 @@ def extras(f, L, a):
                                     "I_max": float(I.max()), "finite": bool(np.all(np.isfinite(I)))}
     except Exception as e:
         ex["lognormal_fullsize"] = {"error": repr(e)}
+    # -- the same workload with single-precision binning (fh_ctx_set_arithmetic): kernel time beside the fp64 one
+    try:
+        L.check(L.lib.fh_ctx_set_arithmetic(f.ctx, 1))
+        ms = []
+        for _ in range(3):
+            f.bin()
+            f.sync()
+            ms.append(f.kernel_ms())
+        finalize()
+        mu32, p32, n32 = np.empty(N), np.empty(N), ctypes.c_int(0)
+        L.check(L.lib.fh_fit_normal(f.ctx, None, None, h["alpha"], h["p0"], h["wsmooth"], h["tol"], h["max_iter"],
+                                    L.ptr(mu32), L.ptr(p32), ctypes.byref(n32), None, None))
+        L.check(L.lib.fh_ctx_set_arithmetic(f.ctx, 0))
+        f.bin()
+        finalize()
+        mu64, p64, n64 = np.empty(N), np.empty(N), ctypes.c_int(0)
+        L.check(L.lib.fh_fit_normal(f.ctx, None, None, h["alpha"], h["p0"], h["wsmooth"], h["tol"], h["max_iter"],
+                                    L.ptr(mu64), L.ptr(p64), ctypes.byref(n64), None, None))
+        k32 = float(np.median(ms))
+        fl = f.nfit * (N * (N + 1) + 2 * N)
+        ex["fp32_binning"] = {"workload": "bin_gram with single-precision design block / tile products (fp64 argument "
+                                          "reduction and block accumulation), N=%d, %d visibilities" % (N, f.nfit),
+                              "kernel_ms": k32, "iterations_fp32_vs_fp64": [n32.value, n64.value],
+                              "profile_max_abs_diff_over_max": float(np.abs(mu32 - mu64).max() / np.abs(mu64).max()),
+                              "roofline": {"bound": "mfma", "achieved": fl / (k32 * 1e-3) / 1e12, "peak": 157.3,
+                                           "unit": "TFLOP/s", "frac": fl / (k32 * 1e-3) / 1e12 / 157.3,
+                                           "peak_source": "MI355X fp32 matrix peak, MI355X_MICROARCH.md"}}
+    except Exception as e:
+        ex["fp32_binning"] = {"error": repr(e)}
+        try:
+            L.lib.fh_ctx_set_arithmetic(f.ctx, 0)
+        except Exception:
+            pass
     # -- BASELINE configs[4] on one GPU: 512 fits (32 alpha x 16 w_smooth) of ONE mapping of 1e6 visibilities
     try:
         al, ws = np.meshgrid(np.linspace(1.01, 1.5, 32), np.logspace(-4, -1, 16))

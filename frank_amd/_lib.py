@@ -60,6 +60,7 @@ SIGNATURES = {
     "fh_bin_visibilities": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), _vp, _i64, _i64]),
     "fh_bin_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "fh_bin_last_prepass_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    "fh_ctx_set_arithmetic": (ctypes.c_int, [_vp, ctypes.c_int]),
     "fh_ctx_set_reproducible": (ctypes.c_int, [_vp, ctypes.c_int]),
     "fh_stats_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64), ctypes.POINTER(_vp)]),
     "fh_stats_finalize": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), ctypes.c_int, ctypes.c_int, _dp, _dp, _dp,

@@ -234,29 +234,56 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const double *s, co
 }
 
 // ---- K1b v2 ---------------------------------------------------------------------------------------------------
-template <int NBT, int P, int W, int T>
-__device__ __forceinline__ void mfma_one(v4f64 &acc, const double (&f)[NBT]) {
-    constexpr int tt = wave_tile(NBT, P, W, T);
+// Element type T of the design block and the Gram MFMAs.
+//   double  v_mfma_f64_16x16x4_f64, 64 cycles per SIMD; the result stays in registers for the whole stream.
+//   float   v_mfma_f32_16x16x4_f32, 32 cycles per SIMD (BASELINE configs[2], "fp32"): tau, the bucket centre and hence
+//           the argument of J0 are still formed in fp64 (bucket sort), only the Taylor tail sum_n C[n] tau^n, the
+//           design rows and the tile products are single precision; the single-precision accumulators are added into
+//           the workgroup's fp64 slab every kFlush rows (block accumulation), so the sums over millions of rows are fp64.
+template <typename T>
+struct Mx;
+template <>
+struct Mx<double> {
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ v4 mfma(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    // C/D layout: column = lane & 15, row = (lane >> 4) + 4 reg
+    static __device__ __forceinline__ int row_of(int kk, int reg) { return kk + 4 * reg; }
+};
+template <>
+struct Mx<float> {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ v4 mfma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    // C/D layout: column = lane & 15, row = 4 (lane >> 4) + reg.  Register r as an A/B operand of a Gram k-step then
+    // pairs rows {r, 4 + r, 8 + r, 12 + r}: any partition of the 16 rows into k-steps gives the same Gram.
+    static __device__ __forceinline__ int row_of(int kk, int reg) { return 4 * kk + reg; }
+};
+constexpr int kFlush = 64;  // fp32: chunks (of 16 rows) between two additions into the fp64 slab
+
+template <typename T, int NBT, int P, int W, int Tt>
+__device__ __forceinline__ void mfma_one(typename Mx<T>::v4 &acc, const T (&f)[NBT]) {
+    constexpr int tt = wave_tile(NBT, P, W, Tt);
     constexpr int I = tile_I(NBT, tt), J = tile_J(NBT, tt);
     // A[i][k] = Xt[k][16I+i] and B[k][j] = Xt[k][16J+j] share one fragment layout: lane -> (k = lane>>4, i|j = lane&15)
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f[I], f[J], acc, 0, 0, 0);
+    acc = Mx<T>::mfma(f[I], f[J], acc);
 }
-template <int NBT, int P, int W, int TPW, int... Ts>
-__device__ __forceinline__ void mfma_all(v4f64 (&acc)[TPW > 0 ? TPW : 1], const double (&f)[NBT],
+template <typename T, int NBT, int P, int W, int TPW, int... Ts>
+__device__ __forceinline__ void mfma_all(typename Mx<T>::v4 (&acc)[TPW > 0 ? TPW : 1], const T (&f)[NBT],
                                          std::integer_sequence<int, Ts...>) {
-    (mfma_one<NBT, P, W, Ts>(acc[Ts], f), ...);
+    (mfma_one<T, NBT, P, W, Ts>(acc[Ts], f), ...);
 }
-template <int NBT, int P, int W, int B>
-__device__ __forceinline__ void load_frag(double (&f)[NBT], const double *xb) {
+template <typename T, int NBT, int P, int W, int B>
+__device__ __forceinline__ void load_frag(T (&f)[NBT], const T *xb) {
     if constexpr (wave_needs(NBT, P, W, B)) f[B] = xb[B * 16];
 }
-template <int NBT, int P, int W, int... Bs>
-__device__ __forceinline__ void load_frags(double (&f)[NBT], const double *xb, std::integer_sequence<int, Bs...>) {
-    (load_frag<NBT, P, W, Bs>(f, xb), ...);
+template <typename T, int NBT, int P, int W, int... Bs>
+__device__ __forceinline__ void load_frags(T (&f)[NBT], const T *xb, std::integer_sequence<int, Bs...>) {
+    (load_frag<T, NBT, P, W, Bs>(f, xb), ...);
 }
 
-template <int NBT, int P, int W>
+template <typename T, int NBT, int P, int W>
 __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int part_block, int part_nblocks) {
+    typedef typename Mx<T>::v4 v4;
+    constexpr bool kF32 = sizeof(T) == 4;
     constexpr int XS = xstride(NBT);
     constexpr int T0 = part_tile0(NBT, P), T1 = part_tile1(NBT, P);
     constexpr int NTP = T1 - T0;
@@ -265,8 +292,8 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
     constexpr int B0 = part_block0(NBT, P);            // first column block this part needs
     constexpr int NGEN = (NBT - B0 - W + kWaves - 1) / kWaves > 0 ? (NBT - B0 - W + kWaves - 1) / kWaves : 0;  // blocks B0+W+8g
 
-    double *Ctab = smem;                    // [kTerms][XS]
-    double *X = Ctab + kTerms * XS;         // [2][kRows][XS]
+    T *Ctab = reinterpret_cast<T *>(smem);  // [kTerms][XS]
+    T *X = Ctab + kTerms * XS;              // [2][kRows][XS]
     int *sq = reinterpret_cast<int *>(X + 2 * kRows * XS);  // [4] run queue (dynamic hand-out)
 
     const int tid = threadIdx.x;
@@ -276,9 +303,30 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
     const int JN = N >> 4, jn = N & 15;     // the data column sqrt(w) Re V' lives at column N
     const int nchunks = p.info[0];
 
-    v4f64 acc[TPWA];
+    v4 acc[TPWA];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < TPW; ++t) acc[t] = v4{0, 0, 0, 0};
+    double *slab = p.partials[P] + (size_t)part_block * NTP * 256;
+    // fp32: add the single-precision accumulators into the fp64 slab ([tile][lane][reg]: 32 contiguous bytes per lane)
+    // and clear them; `first`: the slab holds nothing yet
+    auto flush = [&](bool first) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            double *sp = slab + ((size_t)(wave_tile(NBT, P, W, t) - T0) * 64 + lane) * 4;
+            double o[4] = {0.0, 0.0, 0.0, 0.0};
+            if (!first) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = sp[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sp[r] = o[r] + (double)acc[t][r];
+                acc[t][r] = 0;
+            }
+        }
+    };
+    bool flushed = false;
+    int since_flush = 0;
 
     // ---- rows of one chunk: lane (kk, ii) holds row ii ----------------------------------------------------------
     struct RowRegs {
@@ -290,42 +338,49 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
     };
     // ---- the Taylor table of one bucket into LDS (all threads) ---------------------------------------------------
     auto load_table = [&](int bucket) {
-        const double *src = p.table + (size_t)bucket * kTerms * XS;
-        for (int e = tid; e < kTerms * XS; e += kThreads) Ctab[e] = src[e];
+        if constexpr (kF32) {
+            const float *src = p.table32 + (size_t)bucket * kTerms * XS;
+            for (int e = tid; e < kTerms * XS; e += kThreads) Ctab[e] = src[e];
+        } else {
+            const double *src = p.table + (size_t)bucket * kTerms * XS;
+            for (int e = tid; e < kTerms * XS; e += kThreads) Ctab[e] = src[e];
+        }
     };
     // ---- generate this wave's column blocks of one chunk into X[xbuf] -------------------------------------------
     // A operand P[i][n] = sqrt(w_i) tau_i^n : lane (k = kk, i = ii) of k-step t holds n = 4t + kk
-    auto gen_one = [&](const RowRegs &r, int xbuf, int J, double a0, double a1, double a2) {
-        const double *cb = Ctab + kk * XS + J * 16 + ii;
-        v4f64 d = v4f64{0.0, 0.0, 0.0, 0.0};
-        d = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, cb[8 * XS], d, 0, 0, 0);  // smallest terms first
-        d = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, cb[4 * XS], d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, cb[0], d, 0, 0, 0);
-        if (J == JN) {  // column N: sqrt(w) Re V' of row 4 reg + kk (held by lane 4 reg + kk); columns beyond: table zeros
+    auto gen_one = [&](const RowRegs &r, int xbuf, int J, T a0, T a1, T a2) {
+        const T *cb = Ctab + kk * XS + J * 16 + ii;
+        v4 d = v4{0, 0, 0, 0};
+        d = Mx<T>::mfma(a2, cb[8 * XS], d);  // smallest terms first
+        d = Mx<T>::mfma(a1, cb[4 * XS], d);
+        d = Mx<T>::mfma(a0, cb[0], d);
+        if (J == JN) {  // column N: sqrt(w) Re V' of the row this register holds; columns beyond: table zeros
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const double v = __shfl(r.swV, 4 * reg + kk);
-                if (ii == jn) d[reg] = v;
+                const double v = __shfl(r.swV, Mx<T>::row_of(kk, reg));  // lane q < 16 holds row q
+                if (ii == jn) d[reg] = (T)v;
             }
         }
-        double *xw = X + ((size_t)xbuf * kRows + kk) * XS + J * 16 + ii;
+        // register `reg` goes where Gram k-step `reg` reads its fragment: position 4 reg + kk of the chunk
+        T *xw = X + ((size_t)xbuf * kRows + kk) * XS + J * 16 + ii;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) xw[reg * 4 * XS] = d[reg];
     };
-    auto powers = [&](const RowRegs &r, double &a0, double &a1, double &a2) {
+    auto powers = [&](const RowRegs &r, T &a0, T &a1, T &a2) {
         const double t2 = r.tau * r.tau;
         const double pk = kk == 0 ? 1.0 : (kk == 1 ? r.tau : (kk == 2 ? t2 : t2 * r.tau));
         const double t4 = t2 * t2;
-        a0 = r.sw * pk;
-        a1 = a0 * t4;
-        a2 = a1 * t4;
+        const double b0 = r.sw * pk, b1 = b0 * t4;
+        a0 = (T)b0;
+        a1 = (T)b1;
+        a2 = (T)(b1 * t4);
     };
-    // ---- Gram MFMAs of k-step ks (rows 4 ks .. 4 ks + 3) of X[xbuf] ------------------------------------------------
+    // ---- Gram MFMAs of k-step ks (positions 4 ks .. 4 ks + 3) of X[xbuf] -------------------------------------------
     auto gram = [&](int xbuf, int ks) {
-        const double *xb = X + ((size_t)xbuf * kRows + ks * 4 + kk) * XS + ii;
-        double f[NBT];
-        load_frags<NBT, P, W>(f, xb, std::make_integer_sequence<int, NBT>{});
-        mfma_all<NBT, P, W, TPW>(acc, f, std::make_integer_sequence<int, TPW>{});
+        const T *xb = X + ((size_t)xbuf * kRows + ks * 4 + kk) * XS + ii;
+        T f[NBT];
+        load_frags<T, NBT, P, W>(f, xb, std::make_integer_sequence<int, NBT>{});
+        mfma_all<T, NBT, P, W, TPW>(acc, f, std::make_integer_sequence<int, TPW>{});
     };
 
     // ---- work hand-out: contiguous chunk ranges (static, bitwise reproducible) or runs from an atomic counter ----
@@ -357,7 +412,7 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
                 cur_bucket = b;
             }
             __syncthreads();
-            double a0, a1, a2;
+            T a0, a1, a2;
             powers(rnext, a0, a1, a2);
 #pragma unroll
             for (int g = 0; g < NGEN; ++g) gen_one(rnext, 0, B0 + W + kWaves * g, a0, a1, a2);
@@ -379,7 +434,7 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
                 cur_bucket = bgen;
                 __syncthreads();
             }
-            double a0 = 0, a1 = 0, a2 = 0;
+            T a0 = 0, a1 = 0, a2 = 0;
             if (more) powers(rgen, a0, a1, a2);
             // this wave's generated blocks of chunk c+1 (matrix pipe + LDS writes) between the Gram k-steps of chunk c
 #pragma unroll
@@ -388,6 +443,13 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
                 gram(xbuf, ks);
             }
             static_assert(NGEN <= 4, "a wave generates at most four column blocks per chunk");
+            if constexpr (kF32) {
+                if (++since_flush == kFlush) {
+                    flush(!flushed);
+                    flushed = true;
+                    since_flush = 0;
+                }
+            }
             __syncthreads();
             xbuf ^= 1;
         }
@@ -397,58 +459,74 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
         qslot ^= 1;
     }
 
-    // ---- write this workgroup's partial tiles: slab[part_block][tile - T0][reg][lane] --------------------------
-    double *slab = p.partials[P] + (size_t)part_block * NTP * 256;
+    // ---- write this workgroup's partial tiles ------------------------------------------------------------------------
+    if constexpr (kF32) {
+        flush(!flushed);  // slab[part_block][tile - T0][lane][reg], fp64
+    } else {              // slab[part_block][tile - T0][reg][lane]
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int tl = wave_tile(NBT, P, W, t) - T0;
+        for (int t = 0; t < TPW; ++t) {
+            const int tl = wave_tile(NBT, P, W, t) - T0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) slab[(size_t)tl * 256 + r * 64 + lane] = acc[t][r];
+            for (int r = 0; r < 4; ++r) slab[(size_t)tl * 256 + r * 64 + lane] = acc[t][r];
+        }
     }
 }
 
-template <int NBT, int P>
+template <typename T, int NBT, int P>
 __device__ __forceinline__ void part_main(const Bin2Params &p, double *smem, int part_block, int part_nblocks) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch (wave) {
-        case 0: wave_main<NBT, P, 0>(p, smem, part_block, part_nblocks); break;
-        case 1: wave_main<NBT, P, 1>(p, smem, part_block, part_nblocks); break;
-        case 2: wave_main<NBT, P, 2>(p, smem, part_block, part_nblocks); break;
-        case 3: wave_main<NBT, P, 3>(p, smem, part_block, part_nblocks); break;
-        case 4: wave_main<NBT, P, 4>(p, smem, part_block, part_nblocks); break;
-        case 5: wave_main<NBT, P, 5>(p, smem, part_block, part_nblocks); break;
-        case 6: wave_main<NBT, P, 6>(p, smem, part_block, part_nblocks); break;
-        default: wave_main<NBT, P, 7>(p, smem, part_block, part_nblocks); break;
+        case 0: wave_main<T, NBT, P, 0>(p, smem, part_block, part_nblocks); break;
+        case 1: wave_main<T, NBT, P, 1>(p, smem, part_block, part_nblocks); break;
+        case 2: wave_main<T, NBT, P, 2>(p, smem, part_block, part_nblocks); break;
+        case 3: wave_main<T, NBT, P, 3>(p, smem, part_block, part_nblocks); break;
+        case 4: wave_main<T, NBT, P, 4>(p, smem, part_block, part_nblocks); break;
+        case 5: wave_main<T, NBT, P, 5>(p, smem, part_block, part_nblocks); break;
+        case 6: wave_main<T, NBT, P, 6>(p, smem, part_block, part_nblocks); break;
+        default: wave_main<T, NBT, P, 7>(p, smem, part_block, part_nblocks); break;
     }
 }
 
-template <int NBT>
+template <typename T, int NBT>
 __global__ __launch_bounds__(kThreads, 2) void bin_gram2_kernel(Bin2Params p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     if (nparts(NBT) == 1 || b < p.part_blocks[0]) {
-        part_main<NBT, 0>(p, smem, b, p.part_blocks[0]);
+        part_main<T, NBT, 0>(p, smem, b, p.part_blocks[0]);
     } else if (nparts(NBT) == 2 || b < p.part_blocks[0] + p.part_blocks[1]) {
-        part_main<NBT, nparts(NBT) >= 2 ? 1 : 0>(p, smem, b - p.part_blocks[0], p.part_blocks[1]);
+        part_main<T, NBT, nparts(NBT) >= 2 ? 1 : 0>(p, smem, b - p.part_blocks[0], p.part_blocks[1]);
     } else {
-        part_main<NBT, nparts(NBT) >= 3 ? 2 : 0>(p, smem, b - p.part_blocks[0] - p.part_blocks[1], p.part_blocks[2]);
+        part_main<T, NBT, nparts(NBT) >= 3 ? 2 : 0>(p, smem, b - p.part_blocks[0] - p.part_blocks[1], p.part_blocks[2]);
     }
 }
 
-template <int NBT>
+template <typename T, int NBT>
 constexpr size_t bin2_smem_bytes() {
-    return sizeof(double) * ((size_t)kTerms * xstride(NBT) + 2 * kRows * xstride(NBT)) + 4 * sizeof(int);
+    return sizeof(T) * ((size_t)kTerms * xstride(NBT) + 2 * kRows * xstride(NBT)) + 4 * sizeof(int);
 }
 
-template <int NBT>
+template <typename T, int NBT>
 hipError_t launch_bin2(const Bin2Params &p, hipStream_t stream) {
-    constexpr size_t smem = bin2_smem_bytes<NBT>();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_gram2_kernel<NBT>),
+    constexpr size_t smem = bin2_smem_bytes<T, NBT>();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_gram2_kernel<T, NBT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
     const int grid = p.part_blocks[0] + p.part_blocks[1] + p.part_blocks[2];
-    hipLaunchKernelGGL(bin_gram2_kernel<NBT>, dim3(grid), dim3(kThreads), smem, stream, p);
+    hipLaunchKernelGGL((bin_gram2_kernel<T, NBT>), dim3(grid), dim3(kThreads), smem, stream, p);
     return hipGetLastError();
+}
+
+// the fp32 slabs are [tile][lane][reg]; bring them to the [tile][reg][lane] order of the fp64 path (in place per tile)
+__global__ __launch_bounds__(256) void slab_transpose_kernel(double *slab, size_t ntile_slabs) {
+    __shared__ double t[256];
+    for (size_t s = blockIdx.x; s < ntile_slabs; s += gridDim.x) {
+        double *sp = slab + s * 256;
+        const int lane = threadIdx.x >> 2, reg = threadIdx.x & 3;
+        t[reg * 64 + lane] = sp[threadIdx.x];  // element (lane, reg) sits at lane * 4 + reg
+        __syncthreads();
+        sp[threadIdx.x] = t[threadIdx.x];
+        __syncthreads();
+    }
 }
 
 }  // namespace
@@ -512,12 +590,30 @@ hipError_t fh_k1v2_launch_sort(const SortParams &sp, hipStream_t stream) {
 }
 
 hipError_t fh_k1v2_launch_bin(int NBT, const Bin2Params &p, hipStream_t stream) {
+    if (p.table32) {  // single-precision design block and tile products, fp64 block accumulation
+        hipError_t e = hipErrorInvalidValue;
+        switch (NBT) {
+            case 4: e = launch_bin2<float, 4>(p, stream); break;
+            case 8: e = launch_bin2<float, 8>(p, stream); break;
+            case 13: e = launch_bin2<float, 13>(p, stream); break;
+            case 19: e = launch_bin2<float, 19>(p, stream); break;
+            case 24: e = launch_bin2<float, 24>(p, stream); break;
+        }
+        if (e != hipSuccess) return e;
+        for (int P = 0; P < 3; ++P)
+            if (p.part_blocks[P] > 0) {
+                const size_t n = (size_t)p.part_blocks[P] * fh_k1v2_part_ntiles(NBT, P);
+                hipLaunchKernelGGL(slab_transpose_kernel, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(256), 0, stream,
+                                   p.partials[P], n);
+            }
+        return hipGetLastError();
+    }
     switch (NBT) {
-        case 4: return launch_bin2<4>(p, stream);
-        case 8: return launch_bin2<8>(p, stream);
-        case 13: return launch_bin2<13>(p, stream);
-        case 19: return launch_bin2<19>(p, stream);
-        case 24: return launch_bin2<24>(p, stream);
+        case 4: return launch_bin2<double, 4>(p, stream);
+        case 8: return launch_bin2<double, 8>(p, stream);
+        case 13: return launch_bin2<double, 13>(p, stream);
+        case 19: return launch_bin2<double, 19>(p, stream);
+        case 24: return launch_bin2<double, 24>(p, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -141,6 +141,9 @@ struct fh_ctx {
     int XS = 0, k1_nb_built = 0, sort_blocks = 0;
     double k1_delta = 0;
     DevBuf<double> k1_table, k1_rows;
+    DevBuf<float> k1_table32;       // the tables rounded to fp32 (fh_ctx_set_arithmetic)
+    int k1_nb_built32 = 0;
+    bool arith32 = false;
     DevBuf<int> k1_hist, k1_totals, k1_starts, k1_info, k1_chunk_bucket;
     std::vector<double> k1_scalars_host;
     hipEvent_t ev_pre0 = nullptr;
@@ -629,8 +632,18 @@ struct K1TableCache {
 } g_k1_tables;
 }  // namespace
 
+static int k1v2_upload_table32(fh_ctx *c, const std::vector<double> &tab, int nb) {
+    const size_t n = (size_t)nb * FH_K1_TERMS * c->XS;
+    std::vector<float> t32(n);
+    for (size_t i = 0; i < n; ++i) t32[i] = (float)tab[i];
+    if (c->k1_table32.alloc(n) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc of the fp32 bucket tables failed");
+    HIP_TRY(hipMemcpy(c->k1_table32.p, t32.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    c->k1_nb_built32 = nb;
+    return FH_OK;
+}
+
 static int k1v2_ensure_table(fh_ctx *c, int nb_needed) {
-    if (nb_needed <= c->k1_nb_built) return FH_OK;
+    if (nb_needed <= c->k1_nb_built && (!c->arith32 || nb_needed <= c->k1_nb_built32)) return FH_OK;
     const size_t per = (size_t)FH_K1_TERMS * c->XS;
     // 25 % headroom so that fits of similar tables do not rebuild; bounded so that one absurd baseline cannot ask for
     // an absurd table (s = q/Qmax < 1 whenever the q-range check of statistical_models.py:526 would pass)
@@ -661,6 +674,7 @@ static int k1v2_ensure_table(fh_ctx *c, int nb_needed) {
     if (c->k1_table.alloc((size_t)nb_up * per) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc of the bucket tables failed");
     HIP_TRY(hipMemcpy(c->k1_table.p, tab->data(), sizeof(double) * (size_t)nb_up * per, hipMemcpyHostToDevice));
     c->k1_nb_built = nb_up;
+    if (c->arith32) return k1v2_upload_table32(c, *tab, nb_up);
     return FH_OK;
 }
 
@@ -753,6 +767,7 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count) {
     bp.chunk_bucket = c->k1_chunk_bucket.p;
     bp.info = c->k1_info.p;
     bp.table = c->k1_table.p;
+    bp.table32 = c->arith32 ? c->k1_table32.p : nullptr;
     bp.work_counter = dynamic ? c->work_counter.p : nullptr;
     if (dynamic) HIP_TRY(hipMemsetAsync(c->work_counter.p, 0, 4 * sizeof(int), c->stream));
     ReduceParams rp{};
@@ -924,6 +939,13 @@ int fh_bin_last_prepass_ms(fh_ctx *c, float *ms) {
     if (!c->bin_timed || !c->v2) return fail(FH_ERR_INVALID, "no bin_gram (v2) launch recorded yet");
     HIP_TRY(hipEventSynchronize(c->ev_bin0));
     HIP_TRY(hipEventElapsedTime(ms, c->ev_pre0, c->ev_bin0));
+    return FH_OK;
+}
+
+int fh_ctx_set_arithmetic(fh_ctx *c, int fp32) {
+    if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
+    if (fp32 && !c->v2) return fail(FH_ERR_UNSUPPORTED, "single-precision binning exists for the fused kernel only (N <= 383)");
+    c->arith32 = fp32 != 0;
     return FH_OK;
 }
 

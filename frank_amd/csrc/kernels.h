@@ -60,6 +60,7 @@ struct Bin2Params {
     const int *chunk_bucket;
     const int *info;
     const double *table;         // [bucket][12][xstride]: Taylor tables (fh_k1_bucket_table)
+    const float *table32;        // the same tables rounded to fp32; non-NULL selects the single-precision kernel
     int *work_counter;           // NULL = static contiguous ranges (bitwise reproducible); else one int per part
     int part_blocks[3];
     double *partials[3];         // per part: [part_blocks][part_ntiles][256]

@@ -129,7 +129,7 @@ class FourierBesselFitter(object):
     """
 
     def __init__(self, Rmax, N, geometry, nu=0, block_data=True, assume_optically_thick=True, scale_height=None,
-                 block_size=10 ** 5, verbose=True, device=None):
+                 block_size=10 ** 5, verbose=True, device=None, arithmetic='fp64'):
         Rmax /= rad_to_arcsec
         self._geometry = geometry
         # `device` (not in the reference): HIP device of this fitter's GPU work, default $FRANK_AMD_DEVICE or 0
@@ -142,7 +142,7 @@ class FourierBesselFitter(object):
             model = 'debris'
         else:
             model = 'opt_thin'
-        self._vis_map = VisibilityMapping(self._DHT, geometry, model, scale_height=scale_height,
+        self._vis_map = VisibilityMapping(self._DHT, geometry, model, scale_height=scale_height, arithmetic=arithmetic,
                                           block_data=block_data, block_size=block_size, check_qbounds=False,
                                           verbose=verbose)
         self._info = {'Rmax': self._DHT.Rmax * rad_to_arcsec, 'N': self._DHT.size}
@@ -204,12 +204,12 @@ class FrankFitter(FourierBesselFitter):
     def __init__(self, Rmax, N, geometry, nu=0, block_data=True, block_size=10 ** 5, alpha=1.05, p_0=None,
                  weights_smooth=1e-4, tol=1e-3, method='Normal', I_scale=1e5, max_iter=2000, check_qbounds=True,
                  store_iteration_diagnostics=False, assume_optically_thick=True, scale_height=None, verbose=True,
-                 convergence_failure='raise', device=None):
+                 convergence_failure='raise', device=None, arithmetic='fp64'):
         if method not in {'Normal', 'LogNormal'}:
             raise ValueError('FrankFitter supports following mehods:\n\t{ "Normal", "LogNormal"}"')
         self._method = method
         super(FrankFitter, self).__init__(Rmax, N, geometry, nu, block_data, assume_optically_thick, scale_height,
-                                          block_size, verbose, device=device)
+                                          block_size, verbose, device=device, arithmetic=arithmetic)
         # Reinstate the bounds check: FourierBesselFitter does not check bounds (radial_fitters.py:706-707)
         self._vis_map.check_qbounds = check_qbounds
         if p_0 is None:

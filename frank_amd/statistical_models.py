@@ -21,8 +21,16 @@ class VisibilityMapping:
     """
 
     def __init__(self, DHT, geometry, vis_model='opt_thick', scale_height=None, block_data=True,
-                 block_size=10 ** 5, check_qbounds=True, verbose=True):
+                 block_size=10 ** 5, check_qbounds=True, verbose=True, arithmetic='fp64'):
         _vis_models = ['opt_thick', 'opt_thin', 'debris']
+        if arithmetic not in ('fp64', 'fp32'):
+            raise ValueError("arithmetic must be 'fp64' or 'fp32'")
+        if arithmetic == 'fp32' and vis_model == 'debris':
+            raise ValueError("single-precision binning is not built for the debris model")
+        # (not in the reference) 'fp32': the table is stored in single precision and the Bessel design block and the
+        # tile products of the Gram run in single precision on the matrix pipe, with fp64 argument reduction and fp64
+        # block accumulation (fh_ctx_set_arithmetic); M, j and the fit stay fp64
+        self._arithmetic = arithmetic
         if vis_model not in _vis_models:
             raise ValueError(f"vis_model must be one of {_vis_models}")  # statistical_models.py:71-73
         if vis_model == 'debris' and scale_height is None:
@@ -62,7 +70,7 @@ class VisibilityMapping:
         if self._verbose:
             logging.info('    Building visibility matrices M and j')
         V = np.asarray(V)
-        f32 = _lib.all_float32(u, v, V, weights)
+        f32 = _lib.all_float32(u, v, V, weights) or self._arithmetic == 'fp32'
         N = self.size
         M, j = np.empty((N, N)), np.empty(N)
         H0, qmin, qmax = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
@@ -71,6 +79,7 @@ class VisibilityMapping:
         # geometrically thick model: the kernel needs H2[k] to scale every row by exp(-kz^2 H2[k]) (:494-496)
         _lib.check(_lib.lib.fh_ctx_set_scale_height(
             ctx, _lib.ptr(_lib.f8(self._H2)) if self._vis_model == 'debris' else None))
+        _lib.check(_lib.lib.fh_ctx_set_arithmetic(ctx, 1 if self._arithmetic == 'fp32' else 0))
         model = _lib.VIS_MODELS[self._vis_model]
         conv = _lib.f4 if f32 else _lib.f8
         u, v = conv(u), conv(v)

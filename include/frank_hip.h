@@ -124,6 +124,13 @@ int fh_bin_last_kernel_ms(fh_ctx *ctx, float *ms);
 /* Time (ms) from the start of the deprojection pre-pass to the start of that bin_gram launch: deprojection, the host's
  * look at the baseline range (the _check_uv_range input, statistical_models.py:166-169) and the bucket sort.          */
 int fh_bin_last_prepass_ms(fh_ctx *ctx, float *ms);
+/* Arithmetic of bin_gram (BASELINE configs[2], "fp32").  fp32 != 0: the Bessel design block and the tile products of the
+ * Gram run in single precision on the matrix pipe (v_mfma_f32_16x16x4_f32, twice the fp64 rate), with the argument of
+ * J0 still reduced in fp64 (bucket centre + offset) and the single-precision accumulators added into fp64 sums every
+ * 1024 visibilities; everything downstream (M, j, the fit) is fp64.  The reference has no such mode (NumPy promotes to
+ * fp64, geometry.py:69-79): the brightness profile then agrees with the fp64 path to ~1e-5 of its maximum, inside the
+ * 1e-3 BASELINE.json states for fp32.  Default 0 (fp64 arithmetic whatever the storage type of the table).           */
+int fh_ctx_set_arithmetic(fh_ctx *ctx, int fp32);
 /* Work hand-out of bin_gram.  By default a synchronous fit deals contiguous ranges of the sorted table to the workgroups
  * (the sums come out bit for bit the same in every run) and a pipeline of fits (fh_fit_submit outstanding) lets the
  * workgroups pull work from a counter, which is faster while fit loops occupy compute units but makes the last bits

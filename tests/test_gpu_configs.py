@@ -211,3 +211,57 @@ def test_two_device_rccl_allreduce(case):
         assert rel_to_max(r["M"], single["M"]) < 1e-13
         assert rel_to_max(r["j"], single["j"]) < 1e-13
         assert abs(r["H0"] - single["null_likelihood"]) <= 1e-12 * abs(single["null_likelihood"])
+
+
+# ---- fp32 arithmetic (BASELINE configs[2], north_star "1e-3 fp32") ---------------------------------------------------
+@pytest.mark.parametrize("name,N", [("fit_N100_1e5.npz", 100), ("fit_N300_1e6.npz", 300)])
+def test_fp32_arithmetic_binning(golden, name, N):
+    """arithmetic='fp32': design block and Gram tile products in single precision on the matrix pipe (fp64 argument
+    reduction by the bucket sort, fp64 block accumulation every 1024 rows), against the reference's fp64 fixture:
+    M, j to ~1e-6, the brightness profile to the 1e-3 BASELINE.json states for fp32 (measured ~1e-5), the iteration
+    count within the drift SURVEY.md measured for fp32 input (527 -> 612, 16 %)."""
+    from frank_amd import FrankFitter
+    g = golden(name)
+    u, v, V, w = mock_disc_visibilities(int(g["n"]), seed=int(g["seed"]), noise_seed=int(g["noise_seed"]))
+    FF = FrankFitter(2.0, N, geom(), store_iteration_diagnostics=True, verbose=False, arithmetic="fp32")
+    m = FF.preprocess_visibilities(u, v, V, w)
+    assert rel_to_max(m["M"], g["M"]) < 1e-5 and rel_to_max(m["j"], g["j"]) < 1e-5
+    assert not np.array_equal(m["M"], g["M"])  # it really is another arithmetic
+    sol = FF.fit_preprocessed(m)
+    assert rel_to_max(sol.I, g["I"]) < 1e-3
+    nit, ref = FF.iteration_diagnostics["num_iterations"], int(g["niter"])
+    assert abs(nit - ref) <= 0.16 * ref
+    # the fp64 path of the same fitter class is untouched by the switch on another instance
+    F8 = FrankFitter(2.0, N, geom(), verbose=False)
+    m8 = F8.preprocess_visibilities(u, v, V, w)
+    assert rel_to_max(m8["M"], g["M"]) < 5e-13
+
+
+def test_bucket_tables_grow_with_the_baseline_range():
+    """The Taylor tables cover the buckets the data reach and grow on demand: a second table with three times longer
+    baselines (check_qbounds off: s = q/Qmax > 1, where the reference simply evaluates J0 at larger arguments) on the
+    same context, then the first table again -- each against the oracle."""
+    from frank_amd import DiscreteHankelTransform, VisibilityMapping
+    from oracle import oracle as fo
+    N = 40
+    GEOM = (MOCK_GEOMETRY["inc"], MOCK_GEOMETRY["PA"], MOCK_GEOMETRY["dRA"], MOCK_GEOMETRY["dDec"])
+    vm = VisibilityMapping(DiscreteHankelTransform(RMAX, N), geom(), check_qbounds=False, verbose=False)
+    u, v, V, w = mock_disc_visibilities(3000, seed=5, noise_seed=6, qmax=6e5)
+    u2, v2, V2, w2 = mock_disc_visibilities(3000, seed=7, noise_seed=8, qmax=6e5)
+    u2, v2 = 9.0 * u2, 9.0 * v2  # up to 5.4e6 lambda: 2.6 x Qmax at N = 40
+    for (a, b, c, d) in ((u, v, V, w), (u2, v2, V2, w2), (u, v, V, w)):
+        m = vm.map_visibilities(a, b, c, d)
+        o = fo.map_visibilities(N, RMAX, GEOM, a, b, c, d, check_qbounds=False)
+        assert rel_to_max(m["M"], o["M"]) < 1e-12 and rel_to_max(m["j"], o["j"]) < 1e-12
+
+
+def test_generated_design_block_equals_vector_alu_j0(monkeypatch):
+    """Two independent evaluations of the same Gram: the Taylor / matrix-pipe design block of bin_gram2 and the first
+    kernel's polynomial J0 on the vector ALU (FRANK_AMD_K1=v1, kept as a cross-check): M agrees to 2e-14."""
+    from frank_amd import DiscreteHankelTransform, VisibilityMapping
+    u, v, V, w = mock_disc_visibilities(200000, seed=3, noise_seed=4)
+    m2 = VisibilityMapping(DiscreteHankelTransform(RMAX, 300), geom(), verbose=False).map_visibilities(u, v, V, w)
+    monkeypatch.setenv("FRANK_AMD_K1", "v1")
+    m1 = VisibilityMapping(DiscreteHankelTransform(RMAX, 300), geom(), verbose=False).map_visibilities(u, v, V, w)
+    assert rel_to_max(m1["M"], m2["M"]) < 2e-14 and rel_to_max(m1["j"], m2["j"]) < 2e-14
+    assert abs(m1["null_likelihood"] - m2["null_likelihood"]) <= 1e-13 * abs(m2["null_likelihood"])
