@@ -516,13 +516,16 @@ hipError_t launch_bin2(const Bin2Params &p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// the fp32 slabs are [tile][lane][reg]; bring them to the [tile][reg][lane] order of the fp64 path (in place per tile)
-__global__ __launch_bounds__(256) void slab_transpose_kernel(double *slab, size_t ntile_slabs) {
+// The fp32 kernel leaves its fp64 slabs as [tile][lane][reg] in the C/D layout of v_mfma_f32_16x16x4_f32 (row = 4 (lane >> 4)
+// + reg, column = lane & 15); the reduction and finalize kernels expect [tile][reg'][lane'] in the fp64 layout (row =
+// (lane' >> 4) + 4 reg').  Element (kk, ii, reg) -> row 4 kk + reg -> reg' = kk, lane' = 16 reg + ii.  In place per tile.
+__global__ __launch_bounds__(256) void slab_relayout_kernel(double *slab, size_t ntile_slabs) {
     __shared__ double t[256];
     for (size_t s = blockIdx.x; s < ntile_slabs; s += gridDim.x) {
         double *sp = slab + s * 256;
         const int lane = threadIdx.x >> 2, reg = threadIdx.x & 3;
-        t[reg * 64 + lane] = sp[threadIdx.x];  // element (lane, reg) sits at lane * 4 + reg
+        const int kk = lane >> 4, ii = lane & 15;
+        t[kk * 64 + reg * 16 + ii] = sp[threadIdx.x];  // element (lane, reg) sits at lane * 4 + reg
         __syncthreads();
         sp[threadIdx.x] = t[threadIdx.x];
         __syncthreads();
@@ -603,7 +606,7 @@ hipError_t fh_k1v2_launch_bin(int NBT, const Bin2Params &p, hipStream_t stream) 
         for (int P = 0; P < 3; ++P)
             if (p.part_blocks[P] > 0) {
                 const size_t n = (size_t)p.part_blocks[P] * fh_k1v2_part_ntiles(NBT, P);
-                hipLaunchKernelGGL(slab_transpose_kernel, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(256), 0, stream,
+                hipLaunchKernelGGL(slab_relayout_kernel, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(256), 0, stream,
                                    p.partials[P], n);
             }
         return hipGetLastError();
