@@ -1717,6 +1717,8 @@ int fh_update_power_spectrum(fh_ctx *c, const double *M, const double *j, const 
 }
 
 // ---- method='LogNormal' ------------------------------------------------------------------------------------------
+static int ln_np(int N) { return 16 * ((N + 15) / 16); }
+
 static int ln_prepare(fh_ctx *c, const double *M, const double *j, LogNormalParams &P) {
     const int N = c->N;
     const size_t NN = (size_t)N * N;
@@ -1732,7 +1734,7 @@ static int ln_prepare(fh_ctx *c, const double *M, const double *j, LogNormalPara
     if (!c->ln_Sinv.p) {
         HIP_TRY(c->ln_Sinv.alloc(NN));
         HIP_TRY(c->ln_H.alloc(NN));
-        HIP_TRY(c->ln_LU.alloc(NN));
+        HIP_TRY(c->ln_LU.alloc(NN + (size_t)ln_np(N) * ln_np(N)));
         HIP_TRY(c->ln_Hinv.alloc(NN));
         HIP_TRY(c->ln_s.alloc(N));
         HIP_TRY(c->ln_p.alloc(N));
@@ -1743,6 +1745,7 @@ static int ln_prepare(fh_ctx *c, const double *M, const double *j, LogNormalPara
     }
     P = LogNormalParams{};
     P.N = N;
+    P.NP = ln_np(N);
     P.max_step = 100000;  // minimizer.py:190
     P.max_hev = 1000;
     P.newton_tol = 1e-7;  // statistical_models.py:1141
@@ -1915,7 +1918,7 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
     DevBuf<double> Sb, LUb, Hib, Hb, sb, pb, lub, alb, p0b;
     DevBuf<int> resb, counter;
     DevBuf<long long> stb;
-    if (Sb.alloc(G * NN) != hipSuccess || LUb.alloc(G * NN) != hipSuccess || Hib.alloc(G * NN) != hipSuccess ||
+    if (Sb.alloc(G * NN) != hipSuccess || LUb.alloc(G * (NN + (size_t)ln_np(N) * ln_np(N))) != hipSuccess || Hib.alloc(G * NN) != hipSuccess ||
         Hb.alloc(B * NN) != hipSuccess || sb.alloc(B * N) != hipSuccess || pb.alloc(B * N) != hipSuccess ||
         lub.alloc(B * 5 * N) != hipSuccess || alb.alloc(B) != hipSuccess || p0b.alloc(B) != hipSuccess ||
         resb.alloc(2 * B) != hipSuccess || counter.alloc(1) != hipSuccess || stb.alloc(17 * B) != hipSuccess)

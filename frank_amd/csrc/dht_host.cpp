@@ -11,6 +11,7 @@
 
 #include "../../include/frank_hip.h"
 #include "bessel.h"
+#include "j0_zeros_table.h"
 
 namespace {
 
@@ -66,7 +67,9 @@ int fh_dht_build(double Rmax_rad, int N, fh_dht *out) {
             x += dx;
             if (fabsl(dx) < 1e-19L * x) break;
         }
-        d.zeros[k - 1] = (double)x;
+        // the reference's grid is built from SciPy's zeros (0.74 ulp from the true ones): use exactly those values where
+        // the table has them, so that r_k, q_k, Qmax are bit-identical with hankel.py:72-78; the Newton root only beyond
+        d.zeros[k - 1] = k <= FH_J0_ZEROS_TABLE ? FH_J0_ZEROS[k - 1] : (double)x;
         long double f, g;
         bessel_j01_miller((long double)d.zeros[k - 1], &f, &g);  // J1 at the fp64 zero, as j1(j_nk) does
         J1z[k - 1] = g;

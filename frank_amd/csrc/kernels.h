@@ -176,6 +176,8 @@ struct LogNormalParams {
     const double *p_in;           // LN_MODE_MAP: power spectrum
     const double *guess;          // LN_MODE_MAP: starting s;  LN_MODE_FIT: MAP of the Normal seed fit (radial_fitters.py:752)
     double *Sinv, *H, *LU;        // N*N work: prior precision, Hessian at the MAP (output Dinv), LU factors when N > 112
+    int NP;                       // N rounded up to a multiple of 16; behind the N*N doubles of LU (per workgroup) follow NP*NP
+                                  // doubles: the padded copy of the Hessian that the tiled Cholesky factors in place
     double *Hinv;                 // N*N work: explicit inverse of a Hessian that keeps being re-used
     double *s_out, *p_out;        // N
     int *result;                  // [0] count, [1] status

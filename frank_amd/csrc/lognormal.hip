@@ -23,10 +23,10 @@
 #include <rocprim/warp/warp_reduce.hpp>
 
 #include "kernels.h"
+#include "tile_chol.h"
 
 #pragma clang fp contract(off)
 
-typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
@@ -215,7 +215,9 @@ __device__ __forceinline__ double ln_grad(const LnS &S, int i) {
 
 // hess(s) = I_a M_ab I_b + delta_ab (I_a (M I)_a - I_a j_a) + S^-1_ab   (statistical_models.py:1100-1122), at S.x,
 // written column-major into A (and into `copy` when given).  M is exactly symmetric, S^-1 to round-off.
-__device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, double *A, double *copy) {
+// `padded` (or NULL): the same symmetric matrix with leading dimension P.NP for the tiled Cholesky (its padding rows and
+// columns hold the identity: written once per kernel, the factorisation leaves them as they are)
+__device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, double *A, double *copy, double *padded = nullptr) {
     const int N = P.N, tid = threadIdx.x;
     LTIC();
     for (int b = tid >> 5; b < N; b += LT / 32) {
@@ -227,10 +229,102 @@ __device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, dou
             v += sb[a];
             A[b * N + a] = v;
             if (copy) copy[a * N + b] = v;  // row-major H_ab
+            if (padded) padded[b * P.NP + a] = v;
         }
     }
     __syncthreads();
     LTOC(3);
+}
+
+// ---- Cholesky first ------------------------------------------------------------------------------------------------
+// scipy's lu_factor (minimizer.py:238) costs the blocked LU below 3.3 M cycles at N = 300, two thirds of it in the 300
+// pivot-search steps of the panels.  Near the MAP the Hessian diag(I) M diag(I) + diag(.) + S^-1 is positive definite
+// (it is what LogNormalMAPModel._fit hands to cho_factor, statistical_models.py:1147-1149), so it is first factored as
+// H = L L^T with the 16 x 16 MFMA tile primitives of the fit loop (tile_chol.h), no pivot search at all, and rewritten
+// as the unit-lower / upper pair the solves expect: H = (L D^-1)(D L^T), D = diag(L), identity permutation -- the LU
+// factorisation WITHOUT pivoting, which is what partial pivoting would also choose for a diagonally dominant matrix and
+// equally backward stable for a positive definite one.  A non-positive pivot leaves S.lu untouched and the pivoted LU
+// runs as before.  Cp: the padded copy (row-major, symmetric, leading dimension NP), factored in place: lower blocks = L,
+// strictly-upper blocks = L^T (mirror).
+__device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S, double *Cp) {
+    using namespace tilechol;
+    const int N = P.N, NP = P.NP, nb = NP / 16, ld = NP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cl = lane & 15, rg = lane >> 4;
+    double *pan = S.pan;                 // NP x PS panel (the LU panel's space: N * LU_NB doubles)
+    double *dl = pan + NP * PS, *dli = dl + 16 * PS, *lw = dli + 16 * PS;
+    int *flag = reinterpret_cast<int *>(lw + 16 * PS);
+    LTIC();
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    for (int k = 0; k < nb; ++k) {
+        if (wave == 0) {  // diagonal tile: factor (row per lane, v_readlane broadcasts) and invert
+            const bool ok = factor_diag_tile(Cp + (size_t)(16 * k) * ld + 16 * k, ld, nullptr, -1,
+                                             Cp + (size_t)(16 * k) * ld + 16 * k, ld, dl, lane);
+            if (!ok && lane == 0) *flag = 1;
+            invert_factored_tile(dl, dli, nullptr, nullptr, ld, k, lane, nullptr, 16);
+        }
+        __syncthreads();
+        if (*flag) return false;
+        // panel: D = L_kk^-1 (C_Ik)^T for I > k; D^T -> (I,k), D -> mirror (k,I), D^T -> LDS panel
+        {
+            Frag fa;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fa.v[q] = dli[cl * PS + 4 * q + rg];
+            for (int I = k + 1 + wave; I < nb; I += LNW) {
+                const Frag fb = load_rows(Cp + (size_t)(16 * k) * ld + 16 * I, ld, cl, rg);
+                v4f64 d = {0.0, 0.0, 0.0, 0.0};
+                d = mfma4(fa, fb, d, false);
+                store_tile(Cp, ld, k, I, d, cl, rg, true);
+                double *pr = pan + (size_t)((I - k - 1) * 16 + cl) * PS + rg;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
+            }
+        }
+        __syncthreads();
+        // trailing update C_IJ -= L_Ik L_Jk^T for k < J <= I (tiles dealt to the waves; the tiles of column k + 1 also
+        // feed the next panel as mirrors)
+        const int m = nb - k - 1, cnt = m * (m + 1) / 2;
+        for (int e = wave; e < cnt; e += LNW) {
+            int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            while ((i + 1) * (i + 2) / 2 <= e) ++i;
+            while (i * (i + 1) / 2 > e) --i;
+            const int I1 = k + 1 + i, J1 = k + 1 + (e - i * (i + 1) / 2);
+            v4f64 a;
+            const double *c1 = Cp + (size_t)(16 * I1 + rg) * ld + 16 * J1 + cl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = c1[(size_t)(4 * r) * ld];
+            const double *pa1 = pan + (size_t)((I1 - k - 1) * 16 + cl) * PS + rg;
+            const double *pb1 = pan + (size_t)((J1 - k - 1) * 16 + cl) * PS + rg;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s2], pb1[4 * s2], a, 0, 0, 0);
+            store_tile(Cp, ld, I1, J1, a, cl, rg, J1 == k + 1 && I1 != k + 1);
+        }
+        __syncthreads();
+    }
+    // H = (L D^-1)(D L^T): column-major unit-lower / upper factors, identity permutation, rdiag = 1 / U_ii = 1 / L_ii^2
+    double *dg = pan;  // N diagonal entries of L
+    for (int i = tid; i < N; i += LT) {
+        const double d = Cp[(size_t)i * ld + i];
+        dg[i] = d;
+        S.rdiag[i] = 1.0 / (d * d);
+        S.perm[i] = i;
+    }
+    __syncthreads();
+    for (int e = tid; e < N * N; e += LT) {
+        const int j = e / N, i = e - j * N;  // element (i, j) of the column-major N x N factors
+        double v;
+        if (i > j) {  // L_ij / L_jj: the mirror block holds L_ij contiguous in i; inside a diagonal tile there is no mirror
+            const double l = ((i >> 4) != (j >> 4)) ? Cp[(size_t)j * ld + i] : Cp[(size_t)i * ld + j];
+            v = l / dg[j];
+        } else {      // U_ij = L_ii L_ji
+            v = dg[i] * Cp[(size_t)j * ld + i];
+        }
+        S.lu[e] = v;
+    }
+    __syncthreads();
+    LTOC(1);
+    return true;
 }
 
 // Partial-pivoting LU in place (column-major, unit lower); perm[i] = source row of row i, rdiag[i] = 1 / U_ii.
@@ -826,9 +920,13 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
     for (int nstep = 0; nstep < P.max_step; ++nstep) {
         if (need_hess) {
             if (nhess == P.max_hev) return {3, nstep, nfev, nhess};
-            build_hess(P, S, S.lu, nullptr);
-            if (S.lu_nb > 0) lu_factor_blocked(S, N, S.lu);
-            else lu_factor(S, N, S.lu);
+            double *Cp = S.lu_nb > 0 ? P.LU + N * N : nullptr;
+            build_hess(P, S, S.lu, nullptr, Cp);
+            if (S.lu_nb > 0) {
+                if (!cholesky_as_lu(P, S, Cp)) lu_factor_blocked(S, N, S.lu);
+            } else {
+                lu_factor(S, N, S.lu);
+            }
             ++nhess;
             reuse = 0;
             have_inv = false;
@@ -937,7 +1035,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         P.p0 = P.batch_p0[f];
         P.band_lu += (size_t)f * 5 * P.N;
         P.Sinv += (size_t)blockIdx.x * NN;
-        P.LU += (size_t)blockIdx.x * NN;
+        P.LU += (size_t)blockIdx.x * (NN + P.NP * P.NP);
         P.Hinv += (size_t)blockIdx.x * NN;
         P.H += (size_t)f * NN;
         P.s_out += (size_t)f * P.N;
@@ -966,6 +1064,13 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         S.lu = LDS_LU ? b : P.LU;
         S.lu_nb = LDS_LU ? 0 : P.lu_nb;  // blocked factorisation only for factors in global memory
         S.pan = b;                       // (global-LU kernels: the panel follows the int arrays)
+    }
+    if (!LDS_LU) {  // identity in the padding rows / columns of the Cholesky's copy of the Hessian (see build_hess)
+        double *Cp = P.LU + N * N;
+        for (int e = tid; e < P.NP * P.NP; e += LT) {
+            const int i = e / P.NP, j = e - i * P.NP;
+            if (i >= N || j >= N) Cp[e] = (i == j) ? 1.0 : 0.0;
+        }
     }
     S.redsel = 0;
     S.nch = min(LT / N, N);
