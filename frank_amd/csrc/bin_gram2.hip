@@ -48,6 +48,9 @@ constexpr int xstride(int NBT) {  // LDS row stride in doubles, == 16 (mod 32): 
     return (NBT * 16) % 32 == 16 ? NBT * 16 : NBT * 16 + 16;
 }
 constexpr int ntiles(int NBT) { return NBT * (NBT + 1) / 2; }
+// NBT = 32 (N <= 511): table (12 rows) + two buffers of design rows would need 186 KB of LDS; with ONE buffer the chunk
+// is generated behind the Gram k-steps of its predecessor instead of beside them (two barriers per chunk)
+constexpr bool double_buffered(int NBT) { return NBT <= 24; }
 constexpr int nparts(int NBT) { return NBT <= 19 ? 1 : (NBT == 24 ? 2 : 3); }
 constexpr int wave_tile(int NBT, int P, int W, int T) {
     return NBT == 4    ? kTiles4[0][W][T]
@@ -293,8 +296,9 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
     constexpr int NGEN = (NBT - B0 - W + kWaves - 1) / kWaves > 0 ? (NBT - B0 - W + kWaves - 1) / kWaves : 0;  // blocks B0+W+8g
 
     T *Ctab = reinterpret_cast<T *>(smem);  // [kTerms][XS]
-    T *X = Ctab + kTerms * XS;              // [2][kRows][XS]
-    int *sq = reinterpret_cast<int *>(X + 2 * kRows * XS);  // [4] run queue (dynamic hand-out)
+    constexpr bool kDB = double_buffered(NBT);
+    T *X = Ctab + kTerms * XS;              // [2][kRows][XS] (one buffer when !kDB)
+    int *sq = reinterpret_cast<int *>(X + (kDB ? 2 : 1) * kRows * XS);  // [4] run queue (dynamic hand-out)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -436,13 +440,23 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
             }
             T a0 = 0, a1 = 0, a2 = 0;
             if (more) powers(rgen, a0, a1, a2);
-            // this wave's generated blocks of chunk c+1 (matrix pipe + LDS writes) between the Gram k-steps of chunk c
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks < NGEN && more) gen_one(rgen, xbuf ^ 1, B0 + W + kWaves * ks, a0, a1, a2);
-                gram(xbuf, ks);
-            }
             static_assert(NGEN <= 4, "a wave generates at most four column blocks per chunk");
+            if constexpr (kDB) {
+                // this wave's generated blocks of chunk c+1 (matrix pipe + LDS writes) between the Gram k-steps of chunk c
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks < NGEN && more) gen_one(rgen, xbuf ^ 1, B0 + W + kWaves * ks, a0, a1, a2);
+                    gram(xbuf, ks);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) gram(0, ks);
+                __syncthreads();  // everybody has read chunk c: its buffer takes chunk c+1
+                if (more) {
+#pragma unroll
+                    for (int g = 0; g < NGEN; ++g) gen_one(rgen, 0, B0 + W + kWaves * g, a0, a1, a2);
+                }
+            }
             if constexpr (kF32) {
                 if (++since_flush == kFlush) {
                     flush(!flushed);
@@ -451,7 +465,7 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
                 }
             }
             __syncthreads();
-            xbuf ^= 1;
+            if constexpr (kDB) xbuf ^= 1;
         }
         if (!counter) break;
         c0 = sq[qslot ^ 1] * kRun;
@@ -502,7 +516,7 @@ __global__ __launch_bounds__(kThreads, 2) void bin_gram2_kernel(Bin2Params p) {
 
 template <typename T, int NBT>
 constexpr size_t bin2_smem_bytes() {
-    return sizeof(T) * ((size_t)kTerms * xstride(NBT) + 2 * kRows * xstride(NBT)) + 4 * sizeof(int);
+    return sizeof(T) * ((size_t)kTerms * xstride(NBT) + (double_buffered(NBT) ? 2 : 1) * kRows * xstride(NBT)) + 4 * sizeof(int);
 }
 
 template <typename T, int NBT>
@@ -542,7 +556,8 @@ static int nbt_for(int N) {
     if (nb <= 13) return 13;
     if (nb <= 19) return 19;
     if (nb <= 24) return 24;
-    return 0;  // N > 383: not covered yet (NBT = 32 needs a single-buffered X to fit 160 KB of LDS)
+    if (nb <= 32) return 32;
+    return 0;  // N > 511
 }
 int fh_k1v2_nbt_for(int N) { return nbt_for(N); }
 int fh_k1v2_xstride(int NBT) { return xstride(NBT); }
@@ -555,6 +570,7 @@ int fh_k1v2_part_tile0(int NBT, int P) {
         case 13: return part_tile0(13, 0);
         case 19: return part_tile0(19, 0);
         case 24: return P == 0 ? part_tile0(24, 0) : part_tile0(24, 1);
+        case 32: return P == 0 ? part_tile0(32, 0) : (P == 1 ? part_tile0(32, 1) : part_tile0(32, 2));
     }
     return 0;
 }
@@ -565,12 +581,16 @@ int fh_k1v2_part_ntiles(int NBT, int P) {
         case 13: return part_tile1(13, 0) - part_tile0(13, 0);
         case 19: return part_tile1(19, 0) - part_tile0(19, 0);
         case 24: return P == 0 ? part_tile1(24, 0) - part_tile0(24, 0) : part_tile1(24, 1) - part_tile0(24, 1);
+        case 32:
+            return P == 0 ? part_tile1(32, 0) - part_tile0(32, 0)
+                          : (P == 1 ? part_tile1(32, 1) - part_tile0(32, 1) : part_tile1(32, 2) - part_tile0(32, 2));
     }
     return 0;
 }
 int fh_k1v2_part_block0(int NBT, int P) {
     switch (NBT) {
         case 24: return P == 0 ? part_block0(24, 0) : part_block0(24, 1);
+        case 32: return P == 0 ? part_block0(32, 0) : (P == 1 ? part_block0(32, 1) : part_block0(32, 2));
     }
     return 0;
 }
@@ -601,6 +621,7 @@ hipError_t fh_k1v2_launch_bin(int NBT, const Bin2Params &p, hipStream_t stream) 
             case 13: e = launch_bin2<float, 13>(p, stream); break;
             case 19: e = launch_bin2<float, 19>(p, stream); break;
             case 24: e = launch_bin2<float, 24>(p, stream); break;
+            case 32: e = launch_bin2<float, 32>(p, stream); break;
         }
         if (e != hipSuccess) return e;
         for (int P = 0; P < 3; ++P)
@@ -617,6 +638,7 @@ hipError_t fh_k1v2_launch_bin(int NBT, const Bin2Params &p, hipStream_t stream) 
         case 13: return launch_bin2<double, 13>(p, stream);
         case 19: return launch_bin2<double, 19>(p, stream);
         case 24: return launch_bin2<double, 24>(p, stream);
+        case 32: return launch_bin2<double, 32>(p, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -264,3 +264,20 @@ def test_generated_design_block_equals_vector_alu_j0(monkeypatch):
     m1 = VisibilityMapping(DiscreteHankelTransform(RMAX, 300), geom(), verbose=False).map_visibilities(u, v, V, w)
     assert rel_to_max(m1["M"], m2["M"]) < 2e-14 and rel_to_max(m1["j"], m2["j"]) < 2e-14
     assert abs(m1["null_likelihood"] - m2["null_likelihood"]) <= 1e-13 * abs(m2["null_likelihood"])
+
+
+@pytest.mark.parametrize("N", [340, 400, 511])
+def test_fused_gram_beyond_N303_against_oracle(N):
+    """The fused bin_gram covers N <= 511: the tile triangle is cut into two (N <= 383) or three row-aligned parts whose
+    workgroups generate only the column blocks they touch; N = 400, 511 run the single-buffered variant (LDS).  No
+    reference fixture at these sizes (fit_N320 is the reference's): the pinned oracle is the referee for M, j, H0."""
+    from frank_amd import DiscreteHankelTransform, VisibilityMapping
+    from oracle import oracle as fo
+    GEOM = (MOCK_GEOMETRY["inc"], MOCK_GEOMETRY["PA"], MOCK_GEOMETRY["dRA"], MOCK_GEOMETRY["dDec"])
+    u, v, V, w = mock_disc_visibilities(20011, seed=31, noise_seed=32)
+    vm = VisibilityMapping(DiscreteHankelTransform(RMAX, N), geom(), verbose=False)
+    m = vm.map_visibilities(u, v, V, w)
+    o = fo.map_visibilities(N, RMAX, GEOM, u, v, V, w)
+    assert rel_to_max(m["M"], o["M"]) < 1e-12 and rel_to_max(m["j"], o["j"]) < 1e-12
+    assert abs(m["null_likelihood"] - o["null_likelihood"]) <= 1e-12 * abs(o["null_likelihood"])
+    assert np.array_equal(m["M"], m["M"].T)
