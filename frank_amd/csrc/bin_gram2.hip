@@ -192,9 +192,10 @@ __global__ void chunk_bucket_kernel(const int *starts, int nb, const int *info, 
 // Stable scatter: a row's position is bucket start + rows of that bucket in earlier blocks (hist, scanned) + rows of
 // that bucket earlier in this block, counted in (iteration, wave, lane) order -- no atomics, the same position in
 // every run.  Per 64 rows the lanes of equal bucket find each other with one ballot per bucket-index bit.
-__global__ __launch_bounds__(256) void bucket_scatter_kernel(const double *s, const double *sw, const double *swV, int64_t n,
-                                                             double inv_delta, double delta, int nb, int nbits,
-                                                             const int *hist, const int *starts, Row32 *rows) {
+__global__ __launch_bounds__(256) void bucket_scatter_kernel(const double *s, const double *sw, const double *swV,
+                                                             const double *k2, int64_t n, double inv_delta, double delta,
+                                                             int nb, int nbits, const int *hist, const int *starts,
+                                                             Row32 *rows) {
     extern __shared__ int cnt[];
     const int *row = hist + (size_t)blockIdx.x * nb;
     for (int b = threadIdx.x; b < nb; b += 256) cnt[b] = starts[b] + row[b];
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const double *s, co
 #pragma clang fp contract(off)
                 tau = (si - ((double)b + 0.5) * delta) * inv_half;  // fh_k1_bucket_centre, the table's expansion point
             }
-            rows[(size_t)base + rank] = Row32{tau, sw[i], swV[i], 0.0};
+            rows[(size_t)base + rank] = Row32{tau, sw[i], swV[i], k2 ? k2[i] : 0.0};  // (debris model: kz^2 of the row)
         }
     }
 }
@@ -283,7 +284,9 @@ __device__ __forceinline__ void load_frags(T (&f)[NBT], const T *xb, std::intege
     (load_frag<T, NBT, P, W, Bs>(f, xb), ...);
 }
 
-template <typename T, int NBT, int P, int W>
+// DEB: vis_model = 'debris' (statistical_models.py:494-496): every generated entry is further scaled by
+// exp(-kz_i^2 H2[k]) (kz^2 travels in the fourth slot of the sorted row, H2 sits in LDS, zero beyond column N - 1)
+template <typename T, int NBT, int P, int W, bool DEB>
 __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int part_block, int part_nblocks) {
     typedef typename Mx<T>::v4 v4;
     constexpr bool kF32 = sizeof(T) == 4;
@@ -299,6 +302,7 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
     constexpr bool kDB = double_buffered(NBT);
     T *X = Ctab + kTerms * XS;              // [2][kRows][XS] (one buffer when !kDB)
     int *sq = reinterpret_cast<int *>(X + (kDB ? 2 : 1) * kRows * XS);  // [4] run queue (dynamic hand-out)
+    double *H2s = reinterpret_cast<double *>(sq + 4);                   // [NBT * 16] (DEB only)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -334,12 +338,16 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
 
     // ---- rows of one chunk: lane (kk, ii) holds row ii ----------------------------------------------------------
     struct RowRegs {
-        double tau, sw, swV;
+        double tau, sw, swV, k2;
     };
     auto load_row = [&](int chunk) -> RowRegs {
         const double *rp = p.rows + ((size_t)chunk * kRows + ii) * 4;
-        return RowRegs{rp[0], rp[1], rp[2]};
+        return RowRegs{rp[0], rp[1], rp[2], DEB ? rp[3] : 0.0};
     };
+    if constexpr (DEB) {
+        for (int c = threadIdx.x; c < NBT * 16; c += kThreads) H2s[c] = c < p.N ? p.H2[c] : 0.0;
+        __syncthreads();
+    }
     // ---- the Taylor table of one bucket into LDS (all threads) ---------------------------------------------------
     auto load_table = [&](int bucket) {
         if constexpr (kF32) {
@@ -358,6 +366,15 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
         d = Mx<T>::mfma(a2, cb[8 * XS], d);  // smallest terms first
         d = Mx<T>::mfma(a1, cb[4 * XS], d);
         d = Mx<T>::mfma(a0, cb[0], d);
+        if constexpr (DEB) {
+            const double h2 = H2s[J * 16 + ii];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+#pragma clang fp contract(off)
+                const double kz2 = __shfl(r.k2, Mx<T>::row_of(kk, reg));
+                d[reg] = (T)((double)d[reg] * exp(-(kz2 * h2)));
+            }
+        }
         if (J == JN) {  // column N: sqrt(w) Re V' of the row this register holds; columns beyond: table zeros
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
@@ -486,47 +503,48 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
     }
 }
 
-template <typename T, int NBT, int P>
+template <typename T, int NBT, int P, bool DEB>
 __device__ __forceinline__ void part_main(const Bin2Params &p, double *smem, int part_block, int part_nblocks) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch (wave) {
-        case 0: wave_main<T, NBT, P, 0>(p, smem, part_block, part_nblocks); break;
-        case 1: wave_main<T, NBT, P, 1>(p, smem, part_block, part_nblocks); break;
-        case 2: wave_main<T, NBT, P, 2>(p, smem, part_block, part_nblocks); break;
-        case 3: wave_main<T, NBT, P, 3>(p, smem, part_block, part_nblocks); break;
-        case 4: wave_main<T, NBT, P, 4>(p, smem, part_block, part_nblocks); break;
-        case 5: wave_main<T, NBT, P, 5>(p, smem, part_block, part_nblocks); break;
-        case 6: wave_main<T, NBT, P, 6>(p, smem, part_block, part_nblocks); break;
-        default: wave_main<T, NBT, P, 7>(p, smem, part_block, part_nblocks); break;
+        case 0: wave_main<T, NBT, P, 0, DEB>(p, smem, part_block, part_nblocks); break;
+        case 1: wave_main<T, NBT, P, 1, DEB>(p, smem, part_block, part_nblocks); break;
+        case 2: wave_main<T, NBT, P, 2, DEB>(p, smem, part_block, part_nblocks); break;
+        case 3: wave_main<T, NBT, P, 3, DEB>(p, smem, part_block, part_nblocks); break;
+        case 4: wave_main<T, NBT, P, 4, DEB>(p, smem, part_block, part_nblocks); break;
+        case 5: wave_main<T, NBT, P, 5, DEB>(p, smem, part_block, part_nblocks); break;
+        case 6: wave_main<T, NBT, P, 6, DEB>(p, smem, part_block, part_nblocks); break;
+        default: wave_main<T, NBT, P, 7, DEB>(p, smem, part_block, part_nblocks); break;
     }
 }
 
-template <typename T, int NBT>
+template <typename T, int NBT, bool DEB>
 __global__ __launch_bounds__(kThreads, 2) void bin_gram2_kernel(Bin2Params p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     if (nparts(NBT) == 1 || b < p.part_blocks[0]) {
-        part_main<T, NBT, 0>(p, smem, b, p.part_blocks[0]);
+        part_main<T, NBT, 0, DEB>(p, smem, b, p.part_blocks[0]);
     } else if (nparts(NBT) == 2 || b < p.part_blocks[0] + p.part_blocks[1]) {
-        part_main<T, NBT, nparts(NBT) >= 2 ? 1 : 0>(p, smem, b - p.part_blocks[0], p.part_blocks[1]);
+        part_main<T, NBT, nparts(NBT) >= 2 ? 1 : 0, DEB>(p, smem, b - p.part_blocks[0], p.part_blocks[1]);
     } else {
-        part_main<T, NBT, nparts(NBT) >= 3 ? 2 : 0>(p, smem, b - p.part_blocks[0] - p.part_blocks[1], p.part_blocks[2]);
+        part_main<T, NBT, nparts(NBT) >= 3 ? 2 : 0, DEB>(p, smem, b - p.part_blocks[0] - p.part_blocks[1], p.part_blocks[2]);
     }
 }
 
 template <typename T, int NBT>
-constexpr size_t bin2_smem_bytes() {
-    return sizeof(T) * ((size_t)kTerms * xstride(NBT) + (double_buffered(NBT) ? 2 : 1) * kRows * xstride(NBT)) + 4 * sizeof(int);
+constexpr size_t bin2_smem_bytes() {  // (+ 8-byte alignment slack and the debris model's H2 row)
+    return sizeof(T) * ((size_t)kTerms * xstride(NBT) + (double_buffered(NBT) ? 2 : 1) * kRows * xstride(NBT)) + 4 * sizeof(int) +
+           8 + sizeof(double) * NBT * 16;
 }
 
-template <typename T, int NBT>
+template <typename T, int NBT, bool DEB>
 hipError_t launch_bin2(const Bin2Params &p, hipStream_t stream) {
     constexpr size_t smem = bin2_smem_bytes<T, NBT>();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_gram2_kernel<T, NBT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_gram2_kernel<T, NBT, DEB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
     const int grid = p.part_blocks[0] + p.part_blocks[1] + p.part_blocks[2];
-    hipLaunchKernelGGL((bin_gram2_kernel<T, NBT>), dim3(grid), dim3(kThreads), smem, stream, p);
+    hipLaunchKernelGGL((bin_gram2_kernel<T, NBT, DEB>), dim3(grid), dim3(kThreads), smem, stream, p);
     return hipGetLastError();
 }
 
@@ -604,8 +622,8 @@ hipError_t fh_k1v2_launch_sort(const SortParams &sp, hipStream_t stream) {
                        sp.totals);
     hipLaunchKernelGGL(bucket_starts_kernel, dim3(1), dim3(1024), 0, stream, sp.totals, sp.nb, sp.starts, sp.info,
                        reinterpret_cast<Row32 *>(sp.rows));
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(sp.blocks), dim3(256), lds, stream, sp.s, sp.sw, sp.swV, sp.n, sp.inv_delta,
-                       sp.delta, sp.nb, nbits, sp.hist, sp.starts, reinterpret_cast<Row32 *>(sp.rows));
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(sp.blocks), dim3(256), lds, stream, sp.s, sp.sw, sp.swV, sp.k2, sp.n,
+                       sp.inv_delta, sp.delta, sp.nb, nbits, sp.hist, sp.starts, reinterpret_cast<Row32 *>(sp.rows));
     const int64_t max_chunks = (sp.n + (int64_t)kRows * sp.nb) / kRows + 1;
     hipLaunchKernelGGL(chunk_bucket_kernel, dim3((unsigned)((max_chunks + 255) / 256)), dim3(256), 0, stream, sp.starts,
                        sp.nb, sp.info, sp.chunk_bucket);
@@ -613,15 +631,15 @@ hipError_t fh_k1v2_launch_sort(const SortParams &sp, hipStream_t stream) {
 }
 
 hipError_t fh_k1v2_launch_bin(int NBT, const Bin2Params &p, hipStream_t stream) {
-    if (p.table32) {  // single-precision design block and tile products, fp64 block accumulation
+    if (p.table32 && !p.H2) {  // single-precision design block and tile products, fp64 block accumulation
         hipError_t e = hipErrorInvalidValue;
         switch (NBT) {
-            case 4: e = launch_bin2<float, 4>(p, stream); break;
-            case 8: e = launch_bin2<float, 8>(p, stream); break;
-            case 13: e = launch_bin2<float, 13>(p, stream); break;
-            case 19: e = launch_bin2<float, 19>(p, stream); break;
-            case 24: e = launch_bin2<float, 24>(p, stream); break;
-            case 32: e = launch_bin2<float, 32>(p, stream); break;
+            case 4: e = launch_bin2<float, 4, false>(p, stream); break;
+            case 8: e = launch_bin2<float, 8, false>(p, stream); break;
+            case 13: e = launch_bin2<float, 13, false>(p, stream); break;
+            case 19: e = launch_bin2<float, 19, false>(p, stream); break;
+            case 24: e = launch_bin2<float, 24, false>(p, stream); break;
+            case 32: e = launch_bin2<float, 32, false>(p, stream); break;
         }
         if (e != hipSuccess) return e;
         for (int P = 0; P < 3; ++P)
@@ -632,13 +650,24 @@ hipError_t fh_k1v2_launch_bin(int NBT, const Bin2Params &p, hipStream_t stream) 
             }
         return hipGetLastError();
     }
+    if (p.H2) {  // debris model: the scaled design block (fp64 only)
+        switch (NBT) {
+            case 4: return launch_bin2<double, 4, true>(p, stream);
+            case 8: return launch_bin2<double, 8, true>(p, stream);
+            case 13: return launch_bin2<double, 13, true>(p, stream);
+            case 19: return launch_bin2<double, 19, true>(p, stream);
+            case 24: return launch_bin2<double, 24, true>(p, stream);
+            case 32: return launch_bin2<double, 32, true>(p, stream);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (NBT) {
-        case 4: return launch_bin2<double, 4>(p, stream);
-        case 8: return launch_bin2<double, 8>(p, stream);
-        case 13: return launch_bin2<double, 13>(p, stream);
-        case 19: return launch_bin2<double, 19>(p, stream);
-        case 24: return launch_bin2<double, 24>(p, stream);
-        case 32: return launch_bin2<double, 32>(p, stream);
+        case 4: return launch_bin2<double, 4, false>(p, stream);
+        case 8: return launch_bin2<double, 8, false>(p, stream);
+        case 13: return launch_bin2<double, 13, false>(p, stream);
+        case 19: return launch_bin2<double, 19, false>(p, stream);
+        case 24: return launch_bin2<double, 24, false>(p, stream);
+        case 32: return launch_bin2<double, 32, false>(p, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -592,7 +592,7 @@ int fh_vis_set_multiplicity(fh_vis *vis, const int32_t *counts) {
 
 // ---- K1 ----------------------------------------------------------------------------------------------------------
 // the rows-to-memory + dgemm path is taken for N > 303 always and for the debris model at any N
-static bool use_wide(const fh_ctx *c) { return c->wide || c->debris; }
+static bool use_wide(const fh_ctx *c) { return c->wide || (c->debris && !c->v2); }
 static double *dense_gram(fh_ctx *c) { return c->wide ? c->stats_sum.p : c->wide_G.p; }  // (N+1)^2 + 2 scalars
 static size_t dense_tail(const fh_ctx *c) { return ((size_t)c->N + 1) * ((size_t)c->N + 1); }
 
@@ -614,8 +614,10 @@ int fh_ctx_set_scale_height(fh_ctx *c, const double *H2) {
     }
     for (int k = 0; k < c->N; ++k)
         if (!(H2[k] >= 0.0)) return fail(FH_ERR_INVALID, "H2[%d] = %g: the squared scale height must be >= 0", k, H2[k]);
-    int rc = ensure_wide(c);
-    if (rc) return rc;
+    if (!c->v2) {  // the fused kernel scales its generated design block itself; otherwise rows go to memory + rocBLAS
+        int rc = ensure_wide(c);
+        if (rc) return rc;
+    }
     if (!c->debris_H2.p) HIP_TRY(c->debris_H2.alloc(c->N));
     HIP_TRY(hipMemcpy(c->debris_H2.p, H2, sizeof(double) * c->N, hipMemcpyHostToDevice));
     c->debris = true;
@@ -744,6 +746,7 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count) {
     sp.s = p.prep_s;
     sp.sw = p.prep_sw;
     sp.swV = p.prep_swV;
+    sp.k2 = c->debris ? p.prep_k2 : nullptr;
     sp.n = count;
     sp.inv_delta = inv_delta;
     sp.delta = delta;
@@ -768,6 +771,7 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count) {
     bp.info = c->k1_info.p;
     bp.table = c->k1_table.p;
     bp.table32 = c->arith32 ? c->k1_table32.p : nullptr;
+    bp.H2 = c->debris ? c->debris_H2.p : nullptr;
     bp.work_counter = dynamic ? c->work_counter.p : nullptr;
     if (dynamic) HIP_TRY(hipMemsetAsync(c->work_counter.p, 0, 4 * sizeof(int), c->stream));
     ReduceParams rp{};

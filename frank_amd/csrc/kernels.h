@@ -44,6 +44,7 @@ struct ReduceParams {
 // ---- K1 v2 (bin_gram2.hip): bucket sort + design block generated on the matrix pipe ------------------------------
 struct SortParams {
     const double *s, *sw, *swV;  // K1a output, n rows
+    const double *k2;            // debris model: kz^2 of every row (K1a output), else NULL
     int64_t n;
     double inv_delta, delta;     // bucket width in s (j0_buckets.h)
     int nb, blocks;              // buckets; workgroups of the histogram / scatter passes
@@ -61,6 +62,7 @@ struct Bin2Params {
     const int *info;
     const double *table;         // [bucket][12][xstride]: Taylor tables (fh_k1_bucket_table)
     const float *table32;        // the same tables rounded to fp32; non-NULL selects the single-precision kernel
+    const double *H2;            // debris model: H2[k] (N doubles); non-NULL selects the kernel that scales by exp(-kz^2 H2[k])
     int *work_counter;           // NULL = static contiguous ranges (bitwise reproducible); else one int per part
     int part_blocks[3];
     double *partials[3];         // per part: [part_blocks][part_ntiles][256]
