@@ -143,9 +143,15 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
     auto cs_ptr = [&](int I, int J) { return P.cs + ((size_t)I * nb + J) * 16; };
     auto rows_valid = [&](int I) { return min(16, max(0, N - 16 * I)); };
     if (wave == 0) {
-        const bool ok = factor_diag_tile(P.A, ld, pinv, aug_tile == 0 ? aug_c : -1, C, ld, S.dl, lane);
+        v4f64 t0, x0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rg + 4 * r;
+            t0[r] = P.A[(size_t)row * ld + cl] + (row == cl ? pinv[cl] : 0.0);
+        }
+        const bool ok = chol_inv_tile_acc(t0, x0, lane, aug_tile == 0 ? aug_c : -1);
         if (!ok && lane == 0) *S.flag = 1;
-        invert_factored_tile(S.dl, S.dli, W, WdT, ld, 0, lane, cs_ptr(0, 0), rows_valid(0));
+        store_factored_tile(t0, x0, C, ld, S.dli, W, WdT, cs_ptr(0, 0), rows_valid(0), lane);
     }
     __syncthreads();
     TSTAMP(1);
@@ -245,18 +251,15 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 long long f_last = clock64();
 #endif
                 const int t = S.lst[0];
-                const v4f64 a = update_tile(t, la);
+                v4f64 a = update_tile(t, la), xi;
                 FSTAMP(8);
-                double *lw = S.lw;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) lw[(rg + 4 * r) * PS + cl] = a[r];
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                const bool ok = factor_diag_tile(lw, PS, nullptr, aug_tile == k + 1 ? aug_c : -1,
-                                                 C + (size_t)(16 * (k + 1)) * ld + 16 * (k + 1), ld, S.dl, lane);
+                // factor and invert in the accumulator layout (DPP row broadcasts, no LDS round trip, no transposition)
+                const bool ok = chol_inv_tile_acc(a, xi, lane, aug_tile == k + 1 ? aug_c : -1);
                 if (!ok && lane == 0) *S.flag = 1;
                 FSTAMP(9);
-                invert_factored_tile(S.dl, S.dli, W, WdT, ld, k + 1, lane, cs_ptr(k + 1, k + 1), rows_valid(k + 1));
+                const size_t dblk = (size_t)(16 * (k + 1)) * ld + 16 * (k + 1);
+                store_factored_tile(a, xi, C + dblk, ld, S.dli, W + dblk, WdT + (size_t)(k + 1) * 256, cs_ptr(k + 1, k + 1),
+                                    rows_valid(k + 1), lane);
                 FSTAMP(10);
                 inverse_columns();  // whatever is left of the row when the chain is done
             }

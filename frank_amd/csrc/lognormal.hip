@@ -258,11 +258,14 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
     if (tid == 0) *flag = 0;
     __syncthreads();
     for (int k = 0; k < nb; ++k) {
-        if (wave == 0) {  // diagonal tile: factor (row per lane, v_readlane broadcasts) and invert
-            const bool ok = factor_diag_tile(Cp + (size_t)(16 * k) * ld + 16 * k, ld, nullptr, -1,
-                                             Cp + (size_t)(16 * k) * ld + 16 * k, ld, dl, lane);
+        if (wave == 0) {  // diagonal tile: factor and invert in the accumulator layout (tile_chol.h)
+            double *blk = Cp + (size_t)(16 * k) * ld + 16 * k;
+            v4f64 t, x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = blk[(size_t)(rg + 4 * r) * ld + cl];
+            const bool ok = chol_inv_tile_acc(t, x, lane, -1);
             if (!ok && lane == 0) *flag = 1;
-            invert_factored_tile(dl, dli, nullptr, nullptr, ld, k, lane, nullptr, 16);
+            store_factored_tile(t, x, blk, ld, dli, nullptr, nullptr, nullptr, 16, lane);
         }
         __syncthreads();
         if (*flag) return false;

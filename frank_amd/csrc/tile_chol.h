@@ -6,6 +6,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 namespace tilechol {
@@ -25,83 +27,90 @@ __device__ __forceinline__ double rsqrt_f64(double x) {
     return fma(y * e, fma(0.375, e, 0.5), y);
 }
 
-// ---- Cholesky of a 16x16 diagonal tile by ONE wave: every 16-lane group holds the tile, lane&15 = row -----------
-// `tile` points at element [0][0] (row stride `ts`; global A/C or the LDS copy made by the look-ahead);
-// `pdiag` (or NULL) is added to the diagonal (first touch of A).  force_c >= 0: pivot of that local column is taken
-// as 1 (the augmented row that carries b, see solve_posterior).  Writes L to Cout (global) and dl (+ 1/diag in col 16).
-__device__ __forceinline__ bool factor_diag_tile(const double *tile, int ts, const double *pdiag, int force_c,
-                                                 double *Cout, int ld, double *dl, int lane) {
-    double t[16];
-    const int r = lane & 15;
-    const double *sp = tile + (size_t)r * ts;
+// ---- factor AND invert a diagonal tile held in the MFMA accumulator layout, without leaving the registers ---------------
+// T (in/out): the symmetric positive definite tile, register r of lane (rg = lane >> 4, cl = lane & 15) = element
+// (row rg + 4 r, column cl); on return its lower triangle holds L (T = L L^T), zeros above.  X (out) = L^-1, same layout.
+// Right-looking, one column per step, both recurrences in the same 16 steps:
+//   * L[i][c] for a lane's own rows comes from its own 16-lane DPP row (row_newbcast:c, two full-rate movs per double);
+//   * L[cl][c] = T[c][cl] dinv (symmetry) and the finished row c of X cross DPP rows: one ds_bpermute pair each;
+//   * the pivot is read with v_readlane (two SGPRs, transient).
+// No LDS storage, no per-lane register arrays of 16, no SGPR arrays: the first version (row per lane, v_readlane
+// broadcasts, inverse from an LDS copy) cost 4 + 4 us per tile, most of it spilled SGPRs and serialised LDS reads.
+template <int C>
+__device__ __forceinline__ double dpp_row_bcast_c(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + C, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + C, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// One column step.  Registers above the pivot's register (r < R) are finished; registers below it (r > R) take the updates
+// unconditionally; only register R itself needs lane-dependent selects (its four rows straddle the pivot row).  The rank-1
+// update of T is applied to EVERY entry of the unfinished registers: entries left of / above the pivot become garbage
+// that no later step reads (later steps read row C' and column C' of the trailing square only).
+template <int C>
+__device__ __forceinline__ void chol_inv_step(v4f64 &T, v4f64 &Lo, v4f64 &X, int rg, int cl, int force_c, bool &ok) {
+    constexpr int R = C >> 2, Q = C & 3;  // element (C, j) lives in register R of lane (Q, j)
+    double d = bcast(T[R], Q * 16 + C);
+    d = (C == force_c) ? 1.0 : d;
+    ok = ok && (d > 0.0);
+    const double dinv = rsqrt_f64(d);
+    const double b = __shfl(T[R], Q * 16 + cl) * dinv;   // L[cl][C] for cl >= C (garbage for cl < C: unread)
+    const double xs = __shfl(X[R], Q * 16 + cl) * dinv;  // row C of X, final
+    const bool colC = cl == C;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) t[c] = (c <= r) ? sp[c] : 0.0;
-    if (pdiag) {
-        const double pv = pdiag[r];
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (c == r) t[c] += pv;
+    for (int r = R; r < 4; ++r) {
+        const double a = dpp_row_bcast_c<C>(T[r]) * dinv;  // L[row][C] for row >= C (row == C: sqrt(d))
+        T[r] = fma(-a, b, T[r]);
+        if (r > R) {
+            Lo[r] = colC ? a : Lo[r];
+            X[r] = fma(-a, xs, X[r]);
+        } else {  // the pivot's own register: rows rg + 4 R, pivot row at rg == Q
+            Lo[r] = (colC && rg >= Q) ? a : Lo[r];
+            const double xu = fma(-a, xs, X[r]);
+            double x = (rg > Q) ? xu : X[r];
+            x = (rg == Q) ? xs : x;
+            X[r] = x;
+        }
     }
+}
+template <int... Cs>
+__device__ __forceinline__ void chol_inv_steps(v4f64 &T, v4f64 &Lo, v4f64 &X, int rg, int cl, int force_c, bool &ok,
+                                               std::integer_sequence<int, Cs...>) {
+    (chol_inv_step<Cs>(T, Lo, X, rg, cl, force_c, ok), ...);
+}
+// T: in = the tile, out = its factor L (lower triangle, zeros above).
+__device__ __forceinline__ bool chol_inv_tile_acc(v4f64 &T, v4f64 &X, int lane, int force_c) {
+    int rg = lane >> 4, cl = lane & 15;
+    asm volatile("" : "+v"(rg), "+v"(cl));  // (keeps the lane-index selects out of the enclosing loops' prologue)
+    v4f64 Lo = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[r] = (rg + 4 * r == cl) ? 1.0 : 0.0;
     bool ok = true;
-    double dinv_mine = 0.0;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const double d2 = (c == force_c) ? 1.0 : bcast(t[c], c);
-        ok = ok && (d2 > 0.0);
-        const double dinv = rsqrt_f64(d2);
-        t[c] = (r == c) ? d2 * dinv : t[c] * dinv;  // rows r > c: L[r][c]; (rows < c hold zeros)
-        if (r == c) dinv_mine = dinv;
-        if (c < 15) {
-#pragma unroll
-            for (int c2 = c + 1; c2 < 16; ++c2) {
-                const double s = bcast(t[c], c2);  // L[c2][c]
-                t[c2] = fma(-t[c], s, t[c2]);      // only rows r >= c2 matter
-            }
-        }
-    }
-    if (lane < 16) {
-        double *dst = Cout + (size_t)r * ld;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const double v = c <= r ? t[c] : 0.0;
-            dl[r * PS + c] = v;
-            if (c <= r) dst[c] = v;
-        }
-        dl[r * PS + 16] = dinv_mine;
-    }
+    chol_inv_steps(T, Lo, X, rg, cl, force_c, ok, std::make_integer_sequence<int, 16>{});
+    T = Lo;
     return ok;
 }
 
-// ---- inverse of the diagonal tile just factored (its L is in dl): W_kk = L_kk^-1 -> dli (LDS), W, WdT ----------------
-// One wave; lane c holds column c of the inverse; L is read from dl with wave-uniform (broadcast) addresses.
-__device__ __forceinline__ void invert_factored_tile(const double *dl, double *dli, double *W, double *WdT, int ld,
-                                                     int k, int lane, double *cs_kk, int rows_valid) {
-    const int c = lane & 15;
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): dl was written by this wave
-    __builtin_amdgcn_wave_barrier();
-    // right-looking forward substitution: once x_s is known every later row is updated independently, so the
-    // dependency depth is 16 (not 120 as with row-by-row dot products)
-    double x[16];
+// Outputs of a factored + inverted diagonal tile (both in the accumulator layout): L into the row-major matrix block
+// `Cblk` (leading dimension ld; NULL: skip), X = L^-1 into the LDS panel-solve operand dli (stride PS), into the row-major
+// block `Wblk` and, transposed, into WdT_k (256 doubles: WdT_k[c][r] = X[r][c]); cs[c] = sum over the first rows_valid rows
+// of X[r][c]^2.  Any of Wblk, WdT_k, cs may be NULL.
+__device__ __forceinline__ void store_factored_tile(const v4f64 &L, const v4f64 &X, double *Cblk, int ld, double *dli,
+                                                    double *Wblk, double *WdT_k, double *cs, int rows_valid, int lane) {
+    const int rg = lane >> 4, cl = lane & 15;
+    double ssq = 0.0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        x[s] = x[s] * dl[s * PS + 16];  // * 1/L[s][s]
-#pragma unroll
-        for (int r = s + 1; r < 16; ++r) x[r] = fma(-dl[r * PS + s], x[s], x[r]);  // L[r][s] * X[s][c]
+    for (int r = 0; r < 4; ++r) {
+        const int row = rg + 4 * r;
+        if (Cblk) Cblk[(size_t)row * ld + cl] = L[r];
+        dli[row * PS + cl] = X[r];
+        if (Wblk) Wblk[(size_t)row * ld + cl] = X[r];
+        if (WdT_k) WdT_k[cl * 16 + row] = X[r];
+        if (row < rows_valid) ssq = fma(X[r], X[r], ssq);
     }
-    if (lane < 16) {
-        double *wt = WdT ? WdT + (size_t)k * 256 + c * 16 : nullptr;  // WdT[k][c][r] = W_kk[r][c]
-        double ssq = 0.0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const double v = (r >= c) ? x[r] : 0.0;
-            dli[r * PS + c] = v;
-            if (W) W[(size_t)(16 * k + r) * ld + 16 * k + c] = v;
-            if (wt) wt[r] = v;
-            if (r < rows_valid) ssq = fma(v, v, ssq);
-        }
-        if (cs_kk) cs_kk[c] = ssq;  // column sums of squares of the diagonal tile (rows of the real system only)
+    if (cs) {
+        ssq += __shfl_xor(ssq, 16);
+        ssq += __shfl_xor(ssq, 32);
+        if (rg == 0) cs[cl] = ssq;
     }
 }
 
