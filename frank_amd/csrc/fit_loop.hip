@@ -57,7 +57,6 @@ constexpr int NW = KT / 64;
 #define K2_ALL_WORK 1
 #endif
 constexpr int NWK = K2_ALL_WORK ? NW - 1 : NW - NW / 4;
-constexpr int PF = 2;   // W tiles in flight per chain of the row-by-row inverse
 
 struct Smem {
     double *pan;   // panel / block-row staging, max(NP*PS, 16*(NP+1)) doubles (also stage 0 of row_inverse)
@@ -82,28 +81,36 @@ struct Smem {
 // stage[K * 256 + (4 s + rg) * 16 + cl]); `fw` is the A operand W_II (rows of its transpose).
 __device__ __forceinline__ void inverse_tile(const double *stage, const Frag &fw, double *W, double *cs_IJ, int I, int J,
                                              int N, int ld, int cl, int rg) {
+    const gdouble *Wg = as_global(W) + 16 * J;  // block column J
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-    Frag rb[PF];
-#pragma unroll
-    for (int d = 0; d < PF; ++d) rb[d] = load_rows(W + (size_t)(16 * min(J + d, I - 1)) * ld + 16 * J, ld, cl, rg);
-    for (int K = J; K < I; ++K) {
+    auto lfrag = [&](int K) {  // A operand: L_IK from the staged row
         Frag fa;
         const double *sp = stage + K * 256 + rg * 16 + cl;
 #pragma unroll
         for (int q = 0; q < 4; ++q) fa.v[q] = sp[64 * q];
-        const Frag fb = rb[0];
-#pragma unroll
-        for (int d = 0; d + 1 < PF; ++d) rb[d] = rb[d + 1];
-        if (K + PF < I) rb[PF - 1] = load_rows(W + (size_t)(16 * (K + PF)) * ld + 16 * J, ld, cl, rg);
-        acc = mfma4(fa, fb, acc, false);
+        return fa;
+    };
+    // two W tiles in flight, in two named register sets (a rotating array made the compiler copy the sets and wait for
+    // EVERY outstanding load at the top of each trip: one full L2 latency per product)
+    Frag b0 = load_rows(Wg + (size_t)(16 * J) * ld, ld, cl, rg), b1 = b0;
+    if (J + 1 < I) b1 = load_rows(Wg + (size_t)(16 * (J + 1)) * ld, ld, cl, rg);
+    int K = J;
+    for (; K + 1 < I; K += 2) {
+        const Frag a0 = lfrag(K), a1 = lfrag(K + 1);
+        const Frag c0 = b0, c1 = b1;
+        if (K + 2 < I) b0 = load_rows(Wg + (size_t)(16 * (K + 2)) * ld, ld, cl, rg);
+        if (K + 3 < I) b1 = load_rows(Wg + (size_t)(16 * (K + 3)) * ld, ld, cl, rg);
+        acc = mfma4(a0, c0, acc, false);
+        acc = mfma4(a1, c1, acc, false);
     }
+    if (K < I) acc = mfma4(lfrag(K), b0, acc, false);
     // the C/D layout of acc (row = rg + 4 r, col = cl) is the B-operand layout (k = 4 s + rg, j = cl)
     Frag fs;
 #pragma unroll
     for (int q = 0; q < 4; ++q) fs.v[q] = acc[q];
     v4f64 w = {0.0, 0.0, 0.0, 0.0};
     w = mfma4(fw, fs, w, true);
-    store_tile(W, ld, I, J, w, cl, rg, false);
+    store_tile(as_global(W), ld, I, J, w, cl, rg, false);
     double ssq = 0.0;  // column sums of squares of this (final) tile over the rows of the real system
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -192,10 +199,10 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
 #pragma unroll
             for (int q = 0; q < 4; ++q) fa.v[q] = S.dli[cl * PS + 4 * q + rg];
             for (int I = k + 1 + wave; I < nb; I += NW) {
-                const Frag fb = load_rows(src + (size_t)(16 * k) * ld + 16 * I, ld, cl, rg);
+                const Frag fb = load_rows(as_global(src) + (size_t)(16 * k) * ld + 16 * I, ld, cl, rg);
                 v4f64 d = {0.0, 0.0, 0.0, 0.0};
                 d = mfma4(fa, fb, d, false);
-                store_tile(C, ld, k, I, d, cl, rg, true);
+                store_tile(as_global(C), ld, k, I, d, cl, rg, true);
                 double *pr = S.pan + (size_t)((I - k - 1) * 16 + cl) * PS + rg;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
@@ -209,9 +216,11 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
         __syncthreads();
         TSTAMP(2);
         // trailing update C_IJ = src_IJ - L_Ik L_Jk^T for k < J <= I; next tile's loads are in flight during the MFMAs
+        const gdouble *srcg = as_global(src);
+        gdouble *Cg = as_global(C);
         auto load_tile = [&](int t) {
             v4f64 a;
-            const double *c1 = src + (size_t)(16 * (t >> 8) + rg) * ld + 16 * (t & 255) + cl;
+            const gdouble *c1 = srcg + (size_t)(16 * (t >> 8) + rg) * ld + 16 * (t & 255) + cl;
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] = c1[(size_t)(4 * r) * ld];
             return a;
@@ -269,23 +278,44 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
 #ifdef FIT_LOOP_TIMING
             long long w_last = clock64();
 #endif
+            // two tiles in flight, in two named register sets (ta/a and tb/b): the loads of the tile after next are issued
+            // before the four dependent MFMAs of the current one
+            auto finish = [&](int t, v4f64 a) {
+                a = update_tile(t, a);
+                // tiles of column k+1 also feed the next panel as mirrors
+                store_tile(Cg, ld, t >> 8, t & 255, a, cl, rg, (t & 255) == k + 1 && (t >> 8) != k + 1);
+            };
             int e = 1 + widx;
             if (e < cnt) {
-                int t = S.lst[e];
-                v4f64 a = load_tile(t);
-                while (true) {
-                    const int en = e + NWK;
-                    const bool more = en < cnt;
-                    const int tn = more ? S.lst[en] : t;
-                    v4f64 an = a;
-                    if (more) an = load_tile(tn);
-                    a = update_tile(t, a);
-                    // tiles of column k+1 also feed the next panel as mirrors
-                    store_tile(C, ld, t >> 8, t & 255, a, cl, rg, (t & 255) == k + 1 && (t >> 8) != k + 1);
-                    if (!more) break;
-                    e = en;
-                    t = tn;
-                    a = an;
+                int ta = S.lst[e], tb = 0;
+                v4f64 a = load_tile(ta), b = a;
+                bool hb = e + NWK < cnt;
+                if (hb) {
+                    tb = S.lst[e + NWK];
+                    b = load_tile(tb);
+                }
+                e += 2 * NWK;
+                for (;;) {
+                    // current: (ta, a); next: (tb, b) if hb
+                    const int tc = ta;
+                    const v4f64 c = a;
+                    const bool ha = e < cnt;
+                    if (ha) {
+                        ta = S.lst[e];
+                        a = load_tile(ta);
+                    }
+                    finish(tc, c);
+                    if (!hb) break;
+                    const int td = tb;
+                    const v4f64 d = b;
+                    hb = e + NWK < cnt;
+                    if (hb) {
+                        tb = S.lst[e + NWK];
+                        b = load_tile(tb);
+                    }
+                    finish(td, d);
+                    if (!ha) break;
+                    e += 2 * NWK;
                 }
             }
             WSTAMP(11);

@@ -12,6 +12,13 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 namespace tilechol {
 
+// Pointers into HBM / L2 as GLOBAL address-space pointers: kernel-argument structs that are copied and offset lose the
+// address space in the optimiser's eyes and every access becomes a flat_load / flat_store (which also ties up the LDS
+// counter, so that "wait for my LDS read" waits for memory too).
+typedef __attribute__((address_space(1))) double gdouble;
+__device__ __forceinline__ gdouble *as_global(double *p) { return (gdouble *)p; }
+__device__ __forceinline__ const gdouble *as_global(const double *p) { return (const gdouble *)p; }
+
 constexpr int PS = 17;  // LDS stride of the 16-wide panel rows (doubles)
 
 __device__ __forceinline__ double bcast(double v, int lane) {  // wave-uniform broadcast of lane `lane`'s value
@@ -119,9 +126,10 @@ __device__ __forceinline__ void store_factored_tile(const v4f64 &L, const v4f64 
 struct Frag {
     double v[4];
 };
-__device__ __forceinline__ Frag load_rows(const double *tile, int ld, int cl, int rg) {
+template <typename Ptr>
+__device__ __forceinline__ Frag load_rows(Ptr tile, int ld, int cl, int rg) {
     Frag f;
-    const double *p = tile + (size_t)rg * ld + cl;
+    const auto p = tile + (size_t)rg * ld + cl;
 #pragma unroll
     for (int s = 0; s < 4; ++s) f.v[s] = p[(size_t)(4 * s) * ld];
     return f;
@@ -132,12 +140,13 @@ __device__ __forceinline__ v4f64 mfma4(const Frag &a, const Frag &b, v4f64 acc, 
     return acc;
 }
 // store a C/D-layout tile at block (I, J) and its transpose at block (J, I)
-__device__ __forceinline__ void store_tile(double *Mx, int ld, int I, int J, const v4f64 &t, int cl, int rg, bool mirror) {
-    double *p = Mx + (size_t)(16 * I + rg) * ld + 16 * J + cl;
+template <typename Ptr>
+__device__ __forceinline__ void store_tile(Ptr Mx, int ld, int I, int J, const v4f64 &t, int cl, int rg, bool mirror) {
+    auto p = Mx + (size_t)(16 * I + rg) * ld + 16 * J + cl;
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[(size_t)(4 * r) * ld] = t[r];
     if (mirror) {
-        double *q = Mx + (size_t)(16 * J + cl) * ld + 16 * I + rg;
+        auto q = Mx + (size_t)(16 * J + cl) * ld + 16 * I + rg;
 #pragma unroll
         for (int r = 0; r < 4; ++r) q[4 * r] = t[r];
     }
