@@ -51,6 +51,12 @@ int fail(int code, const char *fmt, ...) {
 const double kRadToArcsec = 3600.0 * 180.0 / M_PI;  // frank/constants.py:23
 const double kDegToRad = M_PI / 180.0;              // frank/constants.py:25
 
+// Functions that queue copies into CALLER memory must not return (on an error path) while those copies are in flight.
+struct SyncOnExit {
+    hipStream_t s;
+    ~SyncOnExit() { (void)hipStreamSynchronize(s); }
+};
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -138,6 +144,8 @@ struct fh_ctx {
     int deproject_blocks = 0;
     // K1 v2 (bin_gram2.hip): bucket sort workspaces and the Taylor tables of the buckets seen so far
     bool v2 = false, force_static = false;
+    bool check_q_before_bin = false;  // fh_map_visibilities(check_qbounds): _check_uv_range before any binning, as the reference
+    double prepass_qmin = 0, prepass_qmax = 0;
     int XS = 0, k1_nb_built = 0, sort_blocks = 0;
     double k1_delta = 0;
     DevBuf<double> k1_table, k1_rows;
@@ -718,16 +726,25 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count) {
     HIP_TRY(hipMemcpyAsync(c->k1_scalars_host.data(), c->partial_scalars.p, sizeof(double) * (size_t)dblocks * 4,
                            hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    double qmax = 0.0;
+    double qmax = 0.0, qmin = INFINITY;
     for (int b = 0; b < dblocks; ++b) {
-        const double m = c->k1_scalars_host[(size_t)b * 4 + 2];
+        const double m = c->k1_scalars_host[(size_t)b * 4 + 2], mn = c->k1_scalars_host[(size_t)b * 4 + 1];
         if (m > qmax) qmax = m;  // (-inf for blocks without rows; NaN baselines never win)
+        if (mn < qmin) qmin = mn;
     }
     if (!(qmax < INFINITY)) return fail(FH_ERR_INVALID, "non-finite baseline in the visibility table");
+    c->prepass_qmin = qmin;
+    c->prepass_qmax = qmax;
+    // statistical_models.py:166-169: the range check comes BEFORE the chunk loop -- nothing is binned for a table that fails it
+    if (c->check_q_before_bin && c->dht->q[c->N - 1] < qmax)
+        return fail(FH_ERR_QRANGE, "last collocation point %.3e < longest deprojected baseline %.3e", c->dht->q[c->N - 1], qmax);
     const double delta = c->k1_delta, inv_delta = 1.0 / delta;
     const double smax = qmax * p.inv_Qmax;
     if (smax * inv_delta > 2.0e9) return fail(FH_ERR_UNSUPPORTED, "baselines reach %.3g x Qmax", smax);
     const int nb = (int)(smax * inv_delta) + 2;  // one spare bucket: the device recomputes s * inv_delta itself
+    if (nb > 16000)  // the sort keeps one counter per bucket in 64 KB of LDS
+        return fail(FH_ERR_UNSUPPORTED, "baselines reach %.1f x Qmax (%d buckets of J0 arguments): cut the (u, v) distribution or "
+                    "raise N", smax, nb);
     int rc = k1v2_ensure_table(c, nb);
     if (rc) return rc;
     // sort workspaces (grow on demand)
@@ -1014,9 +1031,18 @@ int fh_map_visibilities(fh_ctx *c, const fh_geometry *g, int vis_model, int chec
     int rc = fh_vis_upload(c->device, u, v, Vre, Vim, w, n_w, n, &vis);
     if (rc) return rc;
     rc = fh_bin_reset(c);
+    c->check_q_before_bin = check_qbounds != 0;
     if (!rc) rc = fh_bin_visibilities(c, g, vis, 0, n);
-    if (!rc) rc = fh_stats_finalize(c, g, vis_model, check_qbounds, M, j, H0, qmin, qmax);
-    else (void)hipStreamSynchronize(c->stream);
+    c->check_q_before_bin = false;
+    if (!rc) {
+        rc = fh_stats_finalize(c, g, vis_model, check_qbounds, M, j, H0, qmin, qmax);
+    } else {
+        (void)hipStreamSynchronize(c->stream);
+        if (rc == FH_ERR_QRANGE) {  // stopped before the binning: the range is what the caller's message needs
+            if (qmin) *qmin = c->prepass_qmin;
+            if (qmax) *qmax = c->prepass_qmax;
+        }
+    }
     fh_vis_destroy(vis);
     return rc;
 }
@@ -1103,6 +1129,7 @@ static int svd_pinv_solve_device(fh_ctx *c, double *A_dev, double *B_dev, int nr
 int fh_gaussian_model(fh_ctx *c, const double *M, const double *j, const double *p, double *mu, double *chol,
                       double *Sinv, int *used_svd) {
     if (!c || !M || !j) return fail(FH_ERR_INVALID, "fh_gaussian_model: NULL argument");
+    SyncOnExit drain{c->stream};
     HIP_TRY(hipSetDevice(c->device));
     const int N = c->N;
     const size_t NN = (size_t)N * N;

@@ -105,10 +105,11 @@ class VisibilityMapping:
                 _lib.lib.fh_vis_destroy(vis)
         else:
             rc = _lib.lib.fh_map_visibilities(
-                ctx, ctypes.byref(g), model, 0, _lib.ptr(u), _lib.ptr(v),
+                ctx, ctypes.byref(g), model, 1 if self.check_qbounds else 0, _lib.ptr(u), _lib.ptr(v),
                 _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), w.size, n, _lib.ptr(M), _lib.ptr(j), ctypes.byref(H0),
                 ctypes.byref(qmin), ctypes.byref(qmax))
-            _lib.check(rc)
+            if rc != _lib.FH_ERR_QRANGE:  # (that one: stopped before the binning; the reference's message is raised below)
+                _lib.check(rc)
         self._check_uv_range(qmin.value, qmax.value)
         return {
             'mult_freq': False,

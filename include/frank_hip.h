@@ -140,7 +140,9 @@ int fh_ctx_set_reproducible(fh_ctx *ctx, int on);
 int fh_stats_device(fh_ctx *ctx, double **sum_stats, int64_t *n_sum, double **minmax_stats);
 int fh_stats_finalize(fh_ctx *ctx, const fh_geometry *geom, int vis_model, int check_qbounds, double *M, double *j,
                       double *H0, double *qmin, double *qmax);
-/* One-shot convenience with host arrays (what VisibilityMapping.map_visibilities binds to). */
+/* One-shot convenience with host arrays (what VisibilityMapping.map_visibilities binds to).  With check_qbounds the
+ * baseline range is checked BEFORE any binning, as _check_uv_range is in the reference (statistical_models.py:166-169):
+ * FH_ERR_QRANGE is returned after the deprojection pre-pass, qmin / qmax are set, M, j, H0 are not.                     */
 int fh_map_visibilities(fh_ctx *ctx, const fh_geometry *geom, int vis_model, int check_qbounds, const double *u,
                         const double *v, const double *Vre, const double *Vim, const double *w, int64_t n_w,
                         int64_t n, double *M, double *j, double *H0, double *qmin, double *qmax);
