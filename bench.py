@@ -44,7 +44,7 @@ RMAX_ARCSEC = 2.0
 HYPER = dict(alpha=1.05, p0=1e-15, wsmooth=1e-4, tol=1e-3, max_iter=2000)
 # roofline constants: MI355X fp64 matrix peak (AMD CDNA4 datasheet; the microarch guide lists no fp64 MFMA row)
 FP64_MFMA_PEAK_TFLOPS = 78.6
-K1_KERNEL_NAME = "bin_gram2_kernel<19>"
+K1_KERNEL_NAME = "bin_gram2_kernel<double, 19, false>"
 
 
 def parse():

@@ -17,6 +17,6 @@ done
 cd $ROOT
 python3 tools/pmc_summary.py $OUT/pmc_hbm.json $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 python3 tools/pmc_summary.py $OUT/pmc_compute.json $OUT/pmc_SQ_* $OUT/pmc_GRBM_GUI_ACTIVE
-find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+python3 tools/pmc_summary.py --stats $(find $OUT/stats -name "*_results.db" | head -1) $OUT/kernel_stats.csv  # (times in microseconds)
 # keep the merge small: drop the raw traces
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +8M -delete
