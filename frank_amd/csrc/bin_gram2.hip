@@ -37,6 +37,9 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#ifndef K1_STAGGER
+#define K1_STAGGER 1
+#endif
 constexpr int kWaves = 8;
 constexpr int kThreads = 64 * kWaves;
 constexpr int kCap = 24;              // tiles per wave (kTiles* tables)
@@ -462,8 +465,16 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
                 // this wave's generated blocks of chunk c+1 (matrix pipe + LDS writes) between the Gram k-steps of chunk c
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    if (ks < NGEN && more) gen_one(rgen, xbuf ^ 1, B0 + W + kWaves * ks, a0, a1, a2);
-                    gram(xbuf, ks);
+                    // K1_STAGGER: the second wave of each SIMD (W >= 4) generates behind its Gram k-steps instead of in
+                    // front of them, so that the two waves of a SIMD are not in the same phase of the chunk
+                    const int g = (K1_STAGGER && W >= 4) ? ks - (4 - NGEN) : ks;
+                    if (!(K1_STAGGER && W >= 4)) {
+                        if (g >= 0 && g < NGEN && more) gen_one(rgen, xbuf ^ 1, B0 + W + kWaves * g, a0, a1, a2);
+                        gram(xbuf, ks);
+                    } else {
+                        gram(xbuf, K1_STAGGER == 2 ? (ks + 2) & 3 : ks);
+                        if (g >= 0 && g < NGEN && more) gen_one(rgen, xbuf ^ 1, B0 + W + kWaves * g, a0, a1, a2);
+                    }
                 }
             } else {
 #pragma unroll
