@@ -61,8 +61,13 @@ struct LnS {
     double *pan;   // global-LU kernels: LDS panel of the blocked factorisation (N * LU_NB)
     int lu_nb;
     int redsel;
-    int row, c0, c1, slot;  // ln_eval work split: this thread sums columns [c0, c1) of output `row` into part[slot]
+    int row, c0, c1, slot;  // ln_eval work split: this thread sums columns [c0, c1) of output `row` into pbuf[slot]
     int nch;
+    // pair mode (N even, 256 < N: one chunk of N threads would leave 40 % of the workgroup idle and read 8 B per lane): a
+    // thread owns rows `row`, `row + 1` (one 16-byte load per column and matrix) and one of nch column chunks; the
+    // partials then need 2 * nch * N doubles and live in the solve vectors' space (idle during the products)
+    int pair, pstride;
+    double *pbuf;
 };
 
 // Wave reductions through DPP row operations (rocprim), result broadcast to every lane.
@@ -161,7 +166,40 @@ __device__ __forceinline__ void block_min_sum(LnS &S, double &a, double &b) {
 __device__ __forceinline__ double ln_eval(const LogNormalParams &P, LnS &S, const double *xv, double *Iv, double *Sxv, double *MIv) {
     const int N = P.N, tid = threadIdx.x;
     LTIC();
-    if (S.row >= 0) {
+    if (S.row >= 0 && S.pair) {
+        const int o = S.c0 * N + S.row, N2 = N >> 1;
+        const v2f64 *sc = reinterpret_cast<const v2f64 *>(__builtin_assume_aligned(P.Sinv + o, 16));
+        const v2f64 *mc = reinterpret_cast<const v2f64 *>(__builtin_assume_aligned(P.M + o, 16));
+        v2f64 a = {0.0, 0.0}, b = {0.0, 0.0};
+        int c = S.c0;
+        for (; c + EVB <= S.c1; c += EVB, sc += EVB * N2, mc += EVB * N2) {
+            v2f64 vs[EVB], vm[EVB];
+#pragma unroll
+            for (int u = 0; u < EVB; ++u) {
+                vs[u] = sc[u * N2];
+                vm[u] = mc[u * N2];
+            }
+#pragma unroll
+            for (int u = 0; u < EVB; ++u) {
+                const double xc = xv[c + u], ic = Iv[c + u];
+                a[0] = fma(vs[u][0], xc, a[0]);
+                a[1] = fma(vs[u][1], xc, a[1]);
+                b[0] = fma(vm[u][0], ic, b[0]);
+                b[1] = fma(vm[u][1], ic, b[1]);
+            }
+        }
+        for (; c < S.c1; ++c, sc += N2, mc += N2) {
+            const v2f64 vs = *sc, vm = *mc;
+            a[0] = fma(vs[0], xv[c], a[0]);
+            a[1] = fma(vs[1], xv[c], a[1]);
+            b[0] = fma(vm[0], Iv[c], b[0]);
+            b[1] = fma(vm[1], Iv[c], b[1]);
+        }
+        S.pbuf[S.slot] = a[0];
+        S.pbuf[S.slot + 1] = a[1];
+        S.pbuf[S.pstride + S.slot] = b[0];
+        S.pbuf[S.pstride + S.slot + 1] = b[1];
+    } else if (S.row >= 0) {
         const int o = S.c0 * N + S.row;
         const double *sc = P.Sinv + o, *mc = P.M + o;
         double a = 0.0, b = 0.0;
@@ -183,16 +221,16 @@ __device__ __forceinline__ double ln_eval(const LogNormalParams &P, LnS &S, cons
             a = fma(*sc, xv[c], a);
             b = fma(*mc, Iv[c], b);
         }
-        S.part[S.slot] = a;
-        S.part[LT + S.slot] = b;
+        S.pbuf[S.slot] = a;
+        S.pbuf[S.pstride + S.slot] = b;
     }
     __syncthreads();
     double A = 0.0, B = 0.0, C = 0.0;
     if (tid < N) {
         double a = 0.0, b = 0.0;
         for (int ch = 0; ch < S.nch; ++ch) {
-            a += S.part[ch * N + tid];
-            b += S.part[LT + ch * N + tid];
+            a += S.pbuf[ch * N + tid];
+            b += S.pbuf[S.pstride + ch * N + tid];
         }
         Sxv[tid] = a;
         MIv[tid] = b;
@@ -227,9 +265,9 @@ __device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, dou
             double v = S.I[a] * mb[a] * Ib;
             if (a == b) v += S.I[a] * S.MI[a] - S.I[a] * S.jv[a];
             v += sb[a];
-            A[b * N + a] = v;
+            if (padded) padded[b * P.NP + a] = v;  // (the Cholesky attempt works on this copy and writes the factors into A)
+            else A[b * N + a] = v;
             if (copy) copy[a * N + b] = v;  // row-major H_ab
-            if (padded) padded[b * P.NP + a] = v;
         }
     }
     __syncthreads();
@@ -252,80 +290,106 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = lane & 15, rg = lane >> 4;
     double *pan = S.pan;                 // NP x PS panel (the LU panel's space: N * LU_NB doubles)
-    double *dl = pan + NP * PS, *dli = dl + 16 * PS, *lw = dli + 16 * PS;
-    int *flag = reinterpret_cast<int *>(lw + 16 * PS);
+    double *dli = pan + NP * PS, *dvec = dli + 16 * PS;  // inverse of the current diagonal tile; diag(L), NP entries
+    int *flag = reinterpret_cast<int *>(dvec + NP);
+    gdouble *Cg = as_global(Cp);
+    gdouble *lu = as_global(S.lu);       // the factors go straight to their final place: column-major N x N, unit-lower L D^-1
+                                         // below the diagonal, D L^T on and above it (both scalings need the diagonal of block
+                                         // column k only, known when its tile is factored)
     LTIC();
     if (tid == 0) *flag = 0;
+    // factor + invert diagonal tile k (held in `t`, accumulator layout); write its part of the factors
+    auto diag_tile = [&](int k, v4f64 t) {
+        v4f64 x;
+        const bool ok = chol_inv_tile_acc(t, x, lane, -1);
+        if (!ok && lane == 0) *flag = 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dli[(rg + 4 * r) * PS + cl] = x[r];
+            if (rg + 4 * r == cl) dvec[16 * k + cl] = t[r];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const double dc = dvec[16 * k + cl];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * k + rg + 4 * r, j = 16 * k + cl;  // element (i, j) of L, i >= j holds data
+            if (i < N && j < N && i >= j) {
+                if (i > j) {
+                    lu[(size_t)j * N + i] = t[r] / dc;   // L_ij / L_jj
+                    lu[(size_t)i * N + j] = dc * t[r];   // U_ji = L_jj L_ij
+                } else {
+                    lu[(size_t)i * N + i] = dc * dc;
+                    S.rdiag[i] = 1.0 / (dc * dc);
+                    S.perm[i] = i;
+                }
+            }
+        }
+    };
+    auto load_acc = [&](int I, int J) {
+        v4f64 a;
+        const gdouble *c1 = Cg + (size_t)(16 * I + rg) * ld + 16 * J + cl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = c1[(size_t)(4 * r) * ld];
+        return a;
+    };
+    if (wave == 0) diag_tile(0, load_acc(0, 0));
     __syncthreads();
     for (int k = 0; k < nb; ++k) {
-        if (wave == 0) {  // diagonal tile: factor and invert in the accumulator layout (tile_chol.h)
-            double *blk = Cp + (size_t)(16 * k) * ld + 16 * k;
-            v4f64 t, x;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t[r] = blk[(size_t)(rg + 4 * r) * ld + cl];
-            const bool ok = chol_inv_tile_acc(t, x, lane, -1);
-            if (!ok && lane == 0) *flag = 1;
-            store_factored_tile(t, x, blk, ld, dli, nullptr, nullptr, nullptr, 16, lane);
-        }
-        __syncthreads();
         if (*flag) return false;
-        // panel: D = L_kk^-1 (C_Ik)^T for I > k; D^T -> (I,k), D -> mirror (k,I), D^T -> LDS panel
+        // panel: D = L_kk^-1 (C_Ik)^T = L_Ik^T for I > k -> LDS panel (unscaled, for the trailing update) and, scaled, into
+        // the factors: element (a, b) of D is L[16 I + b][16 k + a]
         {
             Frag fa;
 #pragma unroll
             for (int q = 0; q < 4; ++q) fa.v[q] = dli[cl * PS + 4 * q + rg];
             for (int I = k + 1 + wave; I < nb; I += LNW) {
-                const Frag fb = load_rows(Cp + (size_t)(16 * k) * ld + 16 * I, ld, cl, rg);
+                const Frag fb = load_rows(Cg + (size_t)(16 * k) * ld + 16 * I, ld, cl, rg);
                 v4f64 d = {0.0, 0.0, 0.0, 0.0};
                 d = mfma4(fa, fb, d, false);
-                store_tile(Cp, ld, k, I, d, cl, rg, true);
                 double *pr = pan + (size_t)((I - k - 1) * 16 + cl) * PS + rg;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
+                for (int r = 0; r < 4; ++r) {
+                    pr[4 * r] = d[r];
+                    const int a = 16 * k + rg + 4 * r, b = 16 * I + cl;
+                    if (a < N && b < N) {
+                        const double da = dvec[a];
+                        lu[(size_t)a * N + b] = d[r] / da;  // (L D^-1)[b][a]
+                        lu[(size_t)b * N + a] = da * d[r];  // (D L^T)[a][b]
+                    }
+                }
             }
         }
         __syncthreads();
-        // trailing update C_IJ -= L_Ik L_Jk^T for k < J <= I (tiles dealt to the waves; the tiles of column k + 1 also
-        // feed the next panel as mirrors)
+        // trailing update C_IJ -= L_Ik L_Jk^T for k < J <= I.  Wave 0 takes tile (k+1, k+1) first and goes on to factor and
+        // invert it while the other waves update the rest (look-ahead); the tiles of column k + 1 also feed the next panel
+        // as mirrors.
         const int m = nb - k - 1, cnt = m * (m + 1) / 2;
-        for (int e = wave; e < cnt; e += LNW) {
-            int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-            while ((i + 1) * (i + 2) / 2 <= e) ++i;
-            while (i * (i + 1) / 2 > e) --i;
-            const int I1 = k + 1 + i, J1 = k + 1 + (e - i * (i + 1) / 2);
-            v4f64 a;
-            const double *c1 = Cp + (size_t)(16 * I1 + rg) * ld + 16 * J1 + cl;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = c1[(size_t)(4 * r) * ld];
+        auto updated = [&](int I1, int J1) {
+            v4f64 a = load_acc(I1, J1);
             const double *pa1 = pan + (size_t)((I1 - k - 1) * 16 + cl) * PS + rg;
             const double *pb1 = pan + (size_t)((J1 - k - 1) * 16 + cl) * PS + rg;
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s2], pb1[4 * s2], a, 0, 0, 0);
-            store_tile(Cp, ld, I1, J1, a, cl, rg, J1 == k + 1 && I1 != k + 1);
+            return a;
+        };
+        if (wave == 0) {
+            if (cnt > 0) diag_tile(k + 1, updated(k + 1, k + 1));
+        } else {
+            // (prefetching the next tile before the MFMAs of the current one was measured: 11 % slower -- the compiler
+            //  rotates the register sets with copies and waits for every outstanding load)
+            for (int e = wave; e < cnt; e += LNW - 1) {
+                int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                while ((i + 1) * (i + 2) / 2 <= e) ++i;
+                while (i * (i + 1) / 2 > e) --i;
+                const int I1 = k + 1 + i, J1 = k + 1 + (e - i * (i + 1) / 2);
+                const v4f64 a = updated(I1, J1);
+                store_tile(Cg, ld, I1, J1, a, cl, rg, J1 == k + 1 && I1 != k + 1);
+            }
         }
         __syncthreads();
     }
-    // H = (L D^-1)(D L^T): column-major unit-lower / upper factors, identity permutation, rdiag = 1 / U_ii = 1 / L_ii^2
-    double *dg = pan;  // N diagonal entries of L
-    for (int i = tid; i < N; i += LT) {
-        const double d = Cp[(size_t)i * ld + i];
-        dg[i] = d;
-        S.rdiag[i] = 1.0 / (d * d);
-        S.perm[i] = i;
-    }
-    __syncthreads();
-    for (int e = tid; e < N * N; e += LT) {
-        const int j = e / N, i = e - j * N;  // element (i, j) of the column-major N x N factors
-        double v;
-        if (i > j) {  // L_ij / L_jj: the mirror block holds L_ij contiguous in i; inside a diagonal tile there is no mirror
-            const double l = ((i >> 4) != (j >> 4)) ? Cp[(size_t)j * ld + i] : Cp[(size_t)i * ld + j];
-            v = l / dg[j];
-        } else {      // U_ij = L_ii L_ji
-            v = dg[i] * Cp[(size_t)j * ld + i];
-        }
-        S.lu[e] = v;
-    }
-    __syncthreads();
+    if (*flag) return false;
     LTOC(1);
     return true;
 }
@@ -813,6 +877,109 @@ __device__ __forceinline__ void wave_solve(const LnS &S, int N, const double *A,
     }
 }
 
+// The same solve for ONE right-hand side with the whole workgroup: the part of a 64-row block that lies left of (right
+// of, for U) its diagonal block is a 64 x k0 matrix-vector product -- 90 % of the loads of a solve at N = 300 -- and is
+// split by column ranges over the 8 waves (partials through LDS); wave 0 then runs the substitution chain of the diagonal
+// block as wave_solve does.  wave_solve leaves seven waves idle for ~130 us per Newton step.  xs: LDS, N doubles.
+__device__ __forceinline__ void block_solve(LnS &S, int N, const double *A, const double *b, double sign, double *xs) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double *part = S.part;  // LNW x 64 partial sums
+    for (int jj = tid; jj < N; jj += LT) xs[jj] = sign * b[S.perm[jj]];
+    __syncthreads();
+    for (int k0 = 0; k0 < N; k0 += 64) {  // L y = P b, unit lower
+        const int r = k0 + lane, rc = min(r, N - 1);
+        {
+            const int c0 = wv * k0 / LNW, c1 = (wv + 1) * k0 / LNW;
+            double acc = 0.0;
+            int c = c0;
+            for (; c + 8 <= c1; c += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = A[(c + u) * N + rc];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = fma(v[u], xs[c + u], acc);
+            }
+            for (; c < c1; ++c) acc = fma(A[c * N + rc], xs[c], acc);
+            part[wv * 64 + lane] = acc;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            const int ng = (min(64, N - k0) + 7) >> 3;
+            double acc = (r < N) ? xs[r] : 0.0;
+#pragma unroll
+            for (int w = 0; w < LNW; ++w) acc -= part[w * 64 + lane];
+            double nxt[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) nxt[u] = A[min(k0 + u, N - 1) * N + rc];
+#pragma unroll 1
+            for (int g = 0; g < ng; ++g) {
+                double cur[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+                if (g + 1 < ng) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) nxt[u] = A[min(k0 + 8 * g + 8 + u, N - 1) * N + rc];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = 8 * g + u;
+                    acc = fma(-((lane > c && r < N) ? cur[u] : 0.0), lane_bcast(acc, c), acc);
+                }
+            }
+            if (r < N) xs[r] = acc;
+        }
+        __syncthreads();
+    }
+    for (int k0 = 64 * ((N - 1) / 64); k0 >= 0; k0 -= 64) {  // U x = y
+        const int r = k0 + lane, rc = min(r, N - 1);
+        {
+            const int lo = min(N, k0 + 64), span = N - lo;
+            const int c0 = lo + wv * span / LNW, c1 = lo + (wv + 1) * span / LNW;
+            double acc = 0.0;
+            int c = c0;
+            for (; c + 8 <= c1; c += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = A[(c + u) * N + rc];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = fma(v[u], xs[c + u], acc);
+            }
+            for (; c < c1; ++c) acc = fma(A[c * N + rc], xs[c], acc);
+            part[wv * 64 + lane] = acc;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            const int ng = (min(64, N - k0) + 7) >> 3;
+            double acc = (r < N) ? xs[r] : 0.0;
+#pragma unroll
+            for (int w = 0; w < LNW; ++w) acc -= part[w * 64 + lane];
+            const double rd = (r < N) ? S.rdiag[r] : 0.0;
+            double nxt[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) nxt[u] = A[min(k0 + 8 * (ng - 1) + u, N - 1) * N + rc];
+#pragma unroll 1
+            for (int g = ng - 1; g >= 0; --g) {
+                double cur[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+                if (g > 0) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) nxt[u] = A[(k0 + 8 * g - 8 + u) * N + rc];
+                }
+#pragma unroll
+                for (int u = 7; u >= 0; --u) {
+                    const int c = 8 * g + u;
+                    const double xi = lane_bcast(acc * rd, c);
+                    acc = (lane == c) ? xi : acc;
+                    acc = fma(-((lane < c) ? cur[u] : 0.0), xi, acc);
+                }
+            }
+            if (r < N) xs[r] = acc;
+        }
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ void accept_trial(LnS &S, int N) {
     for (int i = threadIdx.x; i < N; i += LT) {
         S.x[i] = S.xn[i];
@@ -926,7 +1093,10 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
             double *Cp = S.lu_nb > 0 ? P.LU + N * N : nullptr;
             build_hess(P, S, S.lu, nullptr, Cp);
             if (S.lu_nb > 0) {
-                if (!cholesky_as_lu(P, S, Cp)) lu_factor_blocked(S, N, S.lu);
+                if (!cholesky_as_lu(P, S, Cp)) {  // not positive definite: the attempt has written into S.lu -- build again
+                    build_hess(P, S, S.lu, nullptr, nullptr);
+                    lu_factor_blocked(S, N, S.lu);
+                }
             } else {
                 lu_factor(S, N, S.lu);
             }
@@ -949,7 +1119,29 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
             have_inv = true;
         }
         if (have_inv) {
-            if (S.row >= 0) {
+            if (S.row >= 0 && S.pair) {
+                const int N2 = N >> 1;
+                const v2f64 *hc = reinterpret_cast<const v2f64 *>(__builtin_assume_aligned(P.Hinv + (S.c0 * N + S.row), 16));
+                v2f64 a = {0.0, 0.0};
+                int c = S.c0;
+                for (; c + HVB <= S.c1; c += HVB, hc += HVB * N2) {
+                    v2f64 vh[HVB];
+#pragma unroll
+                    for (int u = 0; u < HVB; ++u) vh[u] = hc[u * N2];
+#pragma unroll
+                    for (int u = 0; u < HVB; ++u) {
+                        a[0] = fma(vh[u][0], S.jx[c + u], a[0]);
+                        a[1] = fma(vh[u][1], S.jx[c + u], a[1]);
+                    }
+                }
+                for (; c < S.c1; ++c, hc += N2) {
+                    const v2f64 vh = *hc;
+                    a[0] = fma(vh[0], S.jx[c], a[0]);
+                    a[1] = fma(vh[1], S.jx[c], a[1]);
+                }
+                S.pbuf[S.slot] = a[0];
+                S.pbuf[S.slot + 1] = a[1];
+            } else if (S.row >= 0) {
                 const double *hc = P.Hinv + (S.c0 * N + S.row);
                 double a = 0.0;
                 int c = S.c0;
@@ -963,14 +1155,16 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
                     for (int u = 0; u < HVB; ++u) a = fma(vh[u], S.jx[c + u], a);
                 }
                 for (; c < S.c1; ++c, hc += N) a = fma(*hc, S.jx[c], a);
-                S.part[S.slot] = a;
+                S.pbuf[S.slot] = a;
             }
             __syncthreads();
             if (tid < N) {
                 double a = 0.0;
-                for (int ch = 0; ch < S.nch; ++ch) a += S.part[ch * N + tid];
+                for (int ch = 0; ch < S.nch; ++ch) a += S.pbuf[ch * N + tid];
                 S.dx[tid] = -a;
             }
+        } else if (S.lu_nb > 0) {
+            block_solve(S, N, S.lu, S.jx, -1.0, S.dx);  // factors in L2: every wave streams its share of them
         } else if (tid < 64) {
             wave_solve(S, N, S.lu, S.jx, -1, -1.0, S.dx);
         }
@@ -1079,7 +1273,22 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
     S.nch = min(LT / N, N);
     S.row = -1;
     S.c0 = S.c1 = S.slot = 0;
-    if (tid < S.nch * N) {
+    S.pair = (S.nch == 1 && (N & 1) == 0 && 2 * (LT / (N / 2)) * N <= LNW * N) ? 1 : 0;
+    S.pbuf = S.part;
+    S.pstride = LT;
+    if (S.pair) {
+        const int N2 = N / 2;
+        S.nch = LT / N2;  // 3 at N = 300
+        S.pbuf = S.wsol;
+        S.pstride = S.nch * N;
+        if (tid < S.nch * N2) {
+            const int ch = tid / N2;
+            S.row = 2 * (tid - ch * N2);
+            S.c0 = ch * N / S.nch;
+            S.c1 = (ch + 1) * N / S.nch;
+            S.slot = ch * N + S.row;
+        }
+    } else if (tid < S.nch * N) {
         const int ch = tid / N;
         S.row = tid - ch * N;
         S.c0 = ch * N / S.nch;
