@@ -198,14 +198,25 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             Frag fa;
 #pragma unroll
             for (int q = 0; q < 4; ++q) fa.v[q] = S.dli[cl * PS + 4 * q + rg];
-            for (int I = k + 1 + wave; I < nb; I += NW) {
-                const Frag fb = load_rows(as_global(src) + (size_t)(16 * k) * ld + 16 * I, ld, cl, rg);
-                v4f64 d = {0.0, 0.0, 0.0, 0.0};
-                d = mfma4(fa, fb, d, false);
-                store_tile(as_global(C), ld, k, I, d, cl, rg, true);
-                double *pr = S.pan + (size_t)((I - k - 1) * 16 + cl) * PS + rg;
+            // a wave's (up to three) panel tiles: all loads first, then the products -- one L2 latency per step, not per tile
+            constexpr int kPanelMax = 3;  // ceil((NP / 16 - 1) / NW) for NP <= 400
+            Frag fb[kPanelMax];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
+            for (int u = 0; u < kPanelMax; ++u) {
+                const int I = k + 1 + wave + u * NW;
+                if (I < nb) fb[u] = load_rows(as_global(src) + (size_t)(16 * k) * ld + 16 * I, ld, cl, rg);
+            }
+#pragma unroll
+            for (int u = 0; u < kPanelMax; ++u) {
+                const int I = k + 1 + wave + u * NW;
+                if (I < nb) {
+                    v4f64 d = {0.0, 0.0, 0.0, 0.0};
+                    d = mfma4(fa, fb[u], d, false);
+                    store_tile(as_global(C), ld, k, I, d, cl, rg, true);
+                    double *pr = S.pan + (size_t)((I - k - 1) * 16 + cl) * PS + rg;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
+                }
             }
         }
 #pragma unroll
