@@ -575,7 +575,70 @@ __global__ __launch_bounds__(256) void slab_relayout_kernel(double *slab, size_t
     }
 }
 
+// ---- predict_visibilities through the same tables (statistical_models.py:279-329) --------------------------------------
+// V_i = sum_k H[i,k] I_k = sum_k pref_k scale I_k J0(s_i j_k); inside bucket b, J0(s j_k) = sum_n C_b[n][k] tau^n, so
+//     V_i = sum_n tau_i^n c_b[n],        c_b[n] = sum_k C_b[n][k] (pref_k scale I_k)      -- 12 numbers per bucket.
+// The per-bucket coefficients are one small matrix-vector product over the tables; a visibility then costs a degree-11
+// polynomial instead of N Bessel evaluations: the pass is bound by reading q and writing V (16 B per visibility).
+__global__ __launch_bounds__(256) void predict_bucket_coef_kernel(const double *table, int XS, int N, int nb, const double *pref,
+                                                                  const double *I, double scale, double *coef) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // row = b * 12 + n
+    if (row >= nb * kTerms) return;
+    const double *t = table + (size_t)row * XS;
+    double a = 0.0;
+    for (int k = lane; k < N; k += 64) a = fma(t[k], (pref[k] * I[k]) * scale, a);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off);
+    if (lane == 0) coef[row] = a;
+}
+__global__ __launch_bounds__(256) void predict_taylor_kernel(const double *q, int64_t n, double inv_Q, double inv_delta,
+                                                             double delta, int nb, const double *coef, double *V) {
+    const double inv_half = 2.0 * inv_delta;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double s = inv_Q * q[i];
+        const int b = bucket_of(s, inv_delta, nb);
+        double tau;
+        {
+#pragma clang fp contract(off)
+            tau = (s - ((double)b + 0.5) * delta) * inv_half;
+        }
+        const double *c = coef + (size_t)b * kTerms;
+        double a = c[kTerms - 1];
+#pragma unroll
+        for (int m = kTerms - 2; m >= 0; --m) a = fma(a, tau, c[m]);
+        V[i] = a;
+    }
+}
+__global__ void max_abs_kernel(const double *q, int64_t n, double *out) {  // out[0] = max q (q >= 0), one workgroup of 1024
+    __shared__ double red[16];
+    double m = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) m = fmax(m, q[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_down(m, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = fmax(m, red[w]);
+        out[0] = m;
+    }
+}
+
 }  // namespace
+
+hipError_t fh_k1v2_launch_max(const double *q, int64_t n, double *out, hipStream_t stream) {
+    hipLaunchKernelGGL(max_abs_kernel, dim3(1), dim3(1024), 0, stream, q, n, out);
+    return hipGetLastError();
+}
+hipError_t fh_k1v2_launch_predict(const double *table, int XS, int N, int nb, const double *pref, const double *I, double scale,
+                                  double *coef, const double *q, int64_t n, double inv_Q, double delta, double *V,
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(predict_bucket_coef_kernel, dim3((nb * kTerms + 3) / 4), dim3(256), 0, stream, table, XS, N, nb, pref, I,
+                       scale, coef);
+    int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(predict_taylor_kernel, dim3(grid), dim3(256), 0, stream, q, n, inv_Q, 1.0 / delta, delta, nb, coef, V);
+    return hipGetLastError();
+}
 
 // ---------------------------------------------------------------------------------------------------------
 static int nbt_for(int N) {

@@ -149,6 +149,7 @@ struct fh_ctx {
     int XS = 0, k1_nb_built = 0, sort_blocks = 0;
     double k1_delta = 0;
     DevBuf<double> k1_table, k1_rows;
+    DevBuf<double> predict_coef;    // [bucket][12]: fh_predict_visibilities through the tables
     DevBuf<float> k1_table32;       // the tables rounded to fp32 (fh_ctx_set_arithmetic)
     int k1_nb_built32 = 0;
     bool arith32 = false;
@@ -482,6 +483,8 @@ int fh_dht_coefficients(fh_ctx *c, const double *q, int64_t n, int direction, do
     return FH_OK;
 }
 
+static int k1v2_ensure_table(fh_ctx *c, int nb_needed);
+
 int fh_predict_visibilities(fh_ctx *c, const double *q, int64_t n, const double *I, double scale, double *V) {
     if (!c || !q || !I || !V || n < 0) return fail(FH_ERR_INVALID, "fh_predict_visibilities: bad argument");
     if (n == 0) return FH_OK;
@@ -490,8 +493,30 @@ int fh_predict_visibilities(fh_ctx *c, const double *q, int64_t n, const double 
     int rc = stage_q(c, q, n);
     if (rc) return rc;
     if (c->scratch_out.n < (size_t)n) HIP_TRY(c->scratch_out.alloc((size_t)n));
-    if (c->scratch_I.n < (size_t)N) HIP_TRY(c->scratch_I.alloc(N));
+    if (c->scratch_I.n < (size_t)N + 1) HIP_TRY(c->scratch_I.alloc((size_t)N + 1));  // (+ one scratch double)
     HIP_TRY(hipMemcpyAsync(c->scratch_I.p, I, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    if (c->v2 && n >= 4096) {
+        // through the bucket tables of bin_gram: 12 coefficients per bucket, then a degree-11 polynomial per visibility
+        // instead of N Bessel evaluations (bin_gram2.hip); small calls keep the direct kernel (no table to build)
+        double *mx = c->scratch_I.p + N;
+        HIP_TRY(fh_k1v2_launch_max(c->scratch_q.p, n, mx, c->stream));
+        double qmax = 0.0;
+        HIP_TRY(hipMemcpyAsync(&qmax, mx, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const double smax = qmax / c->dht->Qmax;
+        if (qmax == qmax && smax / c->k1_delta < 15000.0) {
+            const int nb = (int)(smax / c->k1_delta) + 2;
+            rc = k1v2_ensure_table(c, nb);
+            if (rc) return rc;
+            if (c->predict_coef.n < (size_t)c->k1_nb_built * FH_K1_TERMS)
+                HIP_TRY(c->predict_coef.alloc((size_t)c->k1_nb_built * FH_K1_TERMS));
+            HIP_TRY(fh_k1v2_launch_predict(c->k1_table.p, c->XS, N, nb, c->pref_fwd.p, c->scratch_I.p, scale, c->predict_coef.p,
+                                           c->scratch_q.p, n, 1. / c->dht->Qmax, c->k1_delta, c->scratch_out.p, c->stream));
+            HIP_TRY(hipMemcpyAsync(V, c->scratch_out.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            return FH_OK;
+        }
+    }
     HIP_TRY(fh_k1_launch_predict(c->scratch_q.p, n, N, c->zeros.p, c->pref_fwd.p, 1. / c->dht->Qmax, scale,
                                  c->scratch_I.p, c->j0_table.p, c->scratch_out.p, c->stream));
     HIP_TRY(hipMemcpyAsync(V, c->scratch_out.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));

@@ -76,6 +76,10 @@ int fh_k1v2_part_ntiles(int NBT, int P);
 int fh_k1v2_part_block0(int NBT, int P);
 hipError_t fh_k1v2_launch_sort(const SortParams &sp, hipStream_t stream);
 hipError_t fh_k1v2_launch_bin(int NBT, const Bin2Params &p, hipStream_t stream);
+hipError_t fh_k1v2_launch_max(const double *q, int64_t n, double *out, hipStream_t stream);
+hipError_t fh_k1v2_launch_predict(const double *table, int XS, int N, int nb, const double *pref, const double *I, double scale,
+                                  double *coef, const double *q, int64_t n, double inv_Q, double delta, double *V,
+                                  hipStream_t stream);
 
 int fh_k1_nbt_for(int N);
 int fh_k1_ntiles(int NBT);

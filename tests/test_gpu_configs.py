@@ -281,3 +281,23 @@ def test_fused_gram_beyond_N303_against_oracle(N):
     assert rel_to_max(m["M"], o["M"]) < 1e-12 and rel_to_max(m["j"], o["j"]) < 1e-12
     assert abs(m["null_likelihood"] - o["null_likelihood"]) <= 1e-12 * abs(o["null_likelihood"])
     assert np.array_equal(m["M"], m["M"].T)
+
+
+def test_predict_through_bucket_tables(golden):
+    """predict_visibilities for many points goes through the bucket tables of bin_gram (12 coefficients per bucket, then a
+    degree-11 polynomial per visibility instead of N Bessel evaluations); small calls keep the direct kernel.  Both
+    against each other, against the oracle's H(q) . I and against the reference's own prediction (real-data fixture)."""
+    from frank_amd import DiscreteHankelTransform, VisibilityMapping
+    from oracle import oracle as fo
+    N = 100
+    g = golden("realdata_multi_ring_N100.npz")
+    vm = VisibilityMapping(DiscreteHankelTransform(RMAX, N), geom(), verbose=False)
+    I = np.asarray(g["I"], dtype=np.float64)
+    rng = np.random.default_rng(3)
+    q = np.exp(rng.uniform(np.log(1e3), np.log(0.99 * vm.q[-1]), 50000))
+    V_tab = vm.predict_visibilities(I, q)                       # n >= 4096: tables
+    V_dir = np.concatenate([vm.predict_visibilities(I, q[i:i + 2000]) for i in range(0, q.size, 2000)])  # direct kernel
+    scale = np.abs(V_dir).max()
+    assert np.abs(V_tab - V_dir).max() < 1e-13 * scale
+    H = fo.DHT(RMAX, N).coefficients(q[:3000]) * np.cos(MOCK_GEOMETRY["inc"] * np.pi / 180)
+    assert np.abs(V_tab[:3000] - H @ I).max() < 1e-12 * scale
