@@ -249,11 +249,13 @@ def extras(f, L, a):
         L.check(L.lib.fh_stats_finalize(f.ctx, ctypes.byref(f.geom), 0, 1, None, None, ctypes.byref(H0),
                                         ctypes.byref(qmn), ctypes.byref(qmx)))
     # -- BASELINE configs[2]: LogNormal fit (alpha = 1.3, w_smooth = 1e-2 as the reference's own LogNormal test,
-    #    tests.py:350) of the resident table, end to end
-    try:
+    #    tests.py:350) of the resident table, end to end; with the default line search (S^-1 (x + lam p) by linearity) and
+    #    with the reference's arithmetic (every trial point multiplied out) -- include/frank_hip.h
+    def lognormal(reference_products):
         s_map, p = np.empty(N), np.empty(N)
         nit = ctypes.c_int(0)
         stats = (ctypes.c_int64 * 9)()
+        L.check(L.lib.fh_ctx_set_lognormal_linesearch(f.ctx, reference_products))
         t0 = time.perf_counter()
         f.bin()
         finalize()
@@ -261,21 +263,26 @@ def extras(f, L, a):
         L.check(L.lib.fh_fit_lognormal(f.ctx, None, None, 1.3, 1e-35, 1e-2, h["tol"], h["max_iter"], 1e5, L.ptr(s_map),
                                        L.ptr(p), ctypes.byref(nit), None, stats, None, None))
         t2 = time.perf_counter()
+        L.check(L.lib.fh_ctx_set_lognormal_linesearch(f.ctx, 0))
         I = np.exp(s_map + np.log(1e5))
-        ex["lognormal_fullsize"] = {"workload": "BASELINE configs[2]: N=%d, %d visibilities, LogNormal, alpha=1.3, "
-                                                "w_smooth=1e-2, fp64 arithmetic" % (N, f.nfit),
-                                    "s_per_fit": t2 - t0, "bin_s": t1 - t0, "fit_s": t2 - t1,
-                                    "power_spectrum_iterations": nit.value, "newton_steps": int(stats[1]),
-                                    "function_evaluations": int(stats[2]),
-                                    "hessian_factorisations": int(stats[3]),
-                                    "ms_per_hessian_all_in": 1e3 * (t2 - t1) / max(int(stats[3]), 1),
-                                    "note": "the Newton solves end in round-off by design (the reference ignores their exit "
-                                            "status), so the number of Hessians -- and the seconds per fit -- depend on "
-                                            "1e-16-level changes of M; ms_per_hessian_all_in is the comparable figure",
-                                    "I_min": float(I.min()),
-                                    "I_max": float(I.max()), "finite": bool(np.all(np.isfinite(I)))}
+        return {"workload": "BASELINE configs[2]: N=%d, %d visibilities, LogNormal, alpha=1.3, w_smooth=1e-2, fp64 "
+                            "arithmetic" % (N, f.nfit),
+                "linesearch": "reference" if reference_products else "linear",
+                "s_per_fit": t2 - t0, "bin_s": t1 - t0, "fit_s": t2 - t1,
+                "power_spectrum_iterations": nit.value, "newton_steps": int(stats[1]),
+                "function_evaluations": int(stats[2]), "hessian_factorisations": int(stats[3]),
+                "ms_per_power_spectrum_iteration": 1e3 * (t2 - t1) / max(nit.value, 1),
+                "I_min": float(I.min()), "I_max": float(I.max()), "finite": bool(np.all(np.isfinite(I)))}, I
+    try:
+        ex["lognormal_fullsize"], I_lin = lognormal(0)
+        ex["lognormal_fullsize_reference_linesearch"], I_ref = lognormal(1)
+        ex["lognormal_fullsize_reference_linesearch"]["note"] = (
+            "the reference's Newton solves end in round-off (it ignores their exit status): the number of steps and "
+            "Hessians, and with them the seconds, depend on 1e-16-level changes of M")
+        ex["lognormal_fullsize"]["profile_vs_reference_linesearch_max_abs_diff_over_max"] = float(
+            np.abs(I_lin - I_ref).max() / np.abs(I_ref).max())
     except Exception as e:
-        ex["lognormal_fullsize"] = {"error": repr(e)}
+        ex.setdefault("lognormal_fullsize", {})["error"] = repr(e)
     # -- the same workload with single-precision binning (fh_ctx_set_arithmetic): kernel time beside the fp64 one
     try:
         L.check(L.lib.fh_ctx_set_arithmetic(f.ctx, 1))

@@ -62,6 +62,7 @@ SIGNATURES = {
     "fh_bin_last_prepass_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "fh_ctx_set_arithmetic": (ctypes.c_int, [_vp, ctypes.c_int]),
     "fh_ctx_set_reproducible": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "fh_ctx_set_lognormal_linesearch": (ctypes.c_int, [_vp, ctypes.c_int]),
     "fh_stats_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64), ctypes.POINTER(_vp)]),
     "fh_stats_finalize": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), ctypes.c_int, ctypes.c_int, _dp, _dp, _dp,
                                          _dp, _dp]),
@@ -167,3 +168,14 @@ def device_count():
 def make_geometry(geometry):
     """fh_geometry from any object with inc / PA / dRA / dDec attributes (degrees, arcsec)."""
     return fh_geometry(float(geometry.inc), float(geometry.PA), float(geometry.dRA), float(geometry.dDec))
+
+
+LOGNORMAL_LINESEARCH = ("linear", "reference")
+
+
+def set_lognormal_linesearch(ctx, mode):
+    """'linear': S^-1 (x + lam p) by linearity along a line search (default); 'reference': every trial point multiplied
+    out as minimizer.py / statistical_models.py:1075-1085 do (include/frank_hip.h, fh_ctx_set_lognormal_linesearch)."""
+    if mode not in LOGNORMAL_LINESEARCH:
+        raise ValueError("lognormal_linesearch must be one of %r, not %r" % (LOGNORMAL_LINESEARCH, mode))
+    check(lib.fh_ctx_set_lognormal_linesearch(ctx, 1 if mode == "reference" else 0))

@@ -91,6 +91,7 @@ def bootstrap_fits(fitter, u, v, vis, weights, ntrials, nonnegative=False):
             if lognormal:
                 s, p = np.empty(N), np.empty(N)
                 niter = ctypes.c_int(0)
+                _lib.set_lognormal_linesearch(ctx, fitter._lognormal_linesearch)
                 rc = L.fh_fit_lognormal(ctx, None, None, alpha, p_0, wsmooth, tol, int(fitter._max_iter),
                                         float(np.exp(fitter._s_scale)), _lib.ptr(s), _lib.ptr(p), ctypes.byref(niter),
                                         None, None, None, None)

@@ -153,6 +153,7 @@ struct fh_ctx {
     DevBuf<float> k1_table32;       // the tables rounded to fp32 (fh_ctx_set_arithmetic)
     int k1_nb_built32 = 0;
     bool arith32 = false;
+    bool ln_fresh_products = false;  // fh_ctx_set_lognormal_linesearch
     DevBuf<int> k1_hist, k1_totals, k1_starts, k1_info, k1_chunk_bucket;
     std::vector<double> k1_scalars_host;
     hipEvent_t ev_pre0 = nullptr;
@@ -995,6 +996,12 @@ int fh_ctx_set_arithmetic(fh_ctx *c, int fp32) {
     return FH_OK;
 }
 
+int fh_ctx_set_lognormal_linesearch(fh_ctx *c, int reference_products) {
+    if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
+    c->ln_fresh_products = reference_products != 0;
+    return FH_OK;
+}
+
 int fh_ctx_set_reproducible(fh_ctx *c, int on) {
     if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
     c->force_static = on != 0;
@@ -1790,7 +1797,7 @@ static int ln_prepare(fh_ctx *c, const double *M, const double *j, LogNormalPara
     if (!c->ln_Sinv.p) {
         HIP_TRY(c->ln_Sinv.alloc(NN));
         HIP_TRY(c->ln_H.alloc(NN));
-        HIP_TRY(c->ln_LU.alloc(NN + (size_t)ln_np(N) * ln_np(N)));
+        HIP_TRY(c->ln_LU.alloc(fh_ln_lu_doubles(N, ln_np(N))));
         HIP_TRY(c->ln_Hinv.alloc(NN));
         HIP_TRY(c->ln_s.alloc(N));
         HIP_TRY(c->ln_p.alloc(N));
@@ -1802,6 +1809,7 @@ static int ln_prepare(fh_ctx *c, const double *M, const double *j, LogNormalPara
     P = LogNormalParams{};
     P.N = N;
     P.NP = ln_np(N);
+    P.fresh_products = c->ln_fresh_products ? 1 : 0;
     P.max_step = 100000;  // minimizer.py:190
     P.max_hev = 1000;
     P.newton_tol = 1e-7;  // statistical_models.py:1141
@@ -1838,7 +1846,7 @@ static int ln_finish(fh_ctx *c, double *s, double *p, double *Dinv, int64_t *sta
     {
         long long cyc[8];
         HIP_TRY(hipMemcpy(cyc, c->ln_stats.p + 9, sizeof cyc, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[ln timing, Mcycles] eval %.1f  lu %.1f (panel %.1f, write-back+swaps %.1f, U12+trailing %.1f)  solve %.1f  hess %.1f  newton total %.1f\n",
+        fprintf(stderr, "[ln timing, Mcycles] eval %.1f  lu %.1f (pivoted LU: panel %.1f, fallbacks %.6f M, rest %.1f)  solve %.1f  hess %.1f  newton total %.1f\n",
                 cyc[0] / 1e6, cyc[1] / 1e6, cyc[5] / 1e6, cyc[6] / 1e6, cyc[7] / 1e6, cyc[2] / 1e6, cyc[3] / 1e6, cyc[4] / 1e6);
     }
 #endif
@@ -1974,7 +1982,7 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
     DevBuf<double> Sb, LUb, Hib, Hb, sb, pb, lub, alb, p0b;
     DevBuf<int> resb, counter;
     DevBuf<long long> stb;
-    if (Sb.alloc(G * NN) != hipSuccess || LUb.alloc(G * (NN + (size_t)ln_np(N) * ln_np(N))) != hipSuccess || Hib.alloc(G * NN) != hipSuccess ||
+    if (Sb.alloc(G * NN) != hipSuccess || LUb.alloc(G * fh_ln_lu_doubles(N, ln_np(N))) != hipSuccess || Hib.alloc(G * NN) != hipSuccess ||
         Hb.alloc(B * NN) != hipSuccess || sb.alloc(B * N) != hipSuccess || pb.alloc(B * N) != hipSuccess ||
         lub.alloc(B * 5 * N) != hipSuccess || alb.alloc(B) != hipSuccess || p0b.alloc(B) != hipSuccess ||
         resb.alloc(2 * B) != hipSuccess || counter.alloc(1) != hipSuccess || stb.alloc(17 * B) != hipSuccess)

@@ -59,10 +59,8 @@ constexpr int NW = KT / 64;
 constexpr int NWK = K2_ALL_WORK ? NW - 1 : NW - NW / 4;
 
 struct Smem {
-    double *pan;   // panel / block-row staging, max(NP*PS, 16*(NP+1)) doubles (also stage 0 of row_inverse)
+    double *pan;   // panel of the current block column: NP x PS doubles
     double *stage1;  // second stage buffer of row_inverse: (NP/16) * 256 doubles
-    double *lw;    // NW x 16 x PS: per-wave scratch for the diagonal-tile inverses
-    double *dl;    // 16 x PS: factor of the current diagonal tile (+ reciprocal diagonal in column 16)
     double *dli;   // 16 x PS: its inverse (A operand of the MFMA panel solve)
     double *p, *pold, *m, *y, *tr2, *rhs, *b, *red;  // NP each (red: 6*NP scratch)
     double *band;  // 5 NP: LU factors of the pentadiagonal T + I, staged once per fit
@@ -401,11 +399,8 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     const int N = P.N, NP = P.NP;
     const int tid = threadIdx.x;
     Smem S;
-    const int panel_doubles = max(NP * PS, 2 * NW * NP);
     S.pan = smem;
-    S.lw = S.pan + panel_doubles;
-    S.dl = S.lw + NW * 16 * PS;
-    S.dli = S.dl + 16 * PS;
+    S.dli = S.pan + NP * PS;
     S.p = S.dli + 16 * PS;
     S.pold = S.p + NP;
     S.m = S.pold + NP;
@@ -589,8 +584,7 @@ __global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int 
 }  // namespace
 
 size_t fh_k2_loop_smem_bytes(int NP) {
-    const int panel = NP * PS > 2 * NW * NP ? NP * PS : 2 * NW * NP;
-    return sizeof(double) * (size_t)(panel + (NW + 2) * 16 * PS + 7 * NP + 6 * NP + (NP / 16) * 256 + 5 * NP) + 4 * 192 + 32;
+    return sizeof(double) * (size_t)(NP * PS + 16 * PS + 7 * NP + 6 * NP + (NP / 16) * 256 + 5 * NP) + 4 * 192 + 32;
 }
 
 hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s) {

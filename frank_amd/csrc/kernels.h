@@ -182,8 +182,12 @@ struct LogNormalParams {
     const double *p_in;           // LN_MODE_MAP: power spectrum
     const double *guess;          // LN_MODE_MAP: starting s;  LN_MODE_FIT: MAP of the Normal seed fit (radial_fitters.py:752)
     double *Sinv, *H, *LU;        // N*N work: prior precision, Hessian at the MAP (output Dinv), LU factors when N > 112
-    int NP;                       // N rounded up to a multiple of 16; behind the N*N doubles of LU (per workgroup) follow NP*NP
-                                  // doubles: the padded copy of the Hessian that the tiled Cholesky factors in place
+    int NP;                       // N rounded up to a multiple of 16.  LU holds fh_ln_lu_doubles(N, NP) doubles per workgroup:
+                                  // [N*N] factors, [NP*NP] the padded copy of the Hessian that the tiled Cholesky factors in
+                                  // place, [NP*NP] the solved tiles of the Tr2 triangular solve, [16*NP] inverses of the
+                                  // diagonal tiles
+    int fresh_products;           // 1: every trial point of the line search gets its own S^-1 x product, as the reference's
+                                  // H(x) evaluates it (statistical_models.py:1075-1085); 0: S^-1 (x + lam p) by linearity
     double *Hinv;                 // N*N work: explicit inverse of a Hessian that keeps being re-used
     double *s_out, *p_out;        // N
     int *result;                  // [0] count, [1] status
@@ -196,6 +200,7 @@ struct LogNormalParams {
     const double *batch_alpha, *batch_p0;
 };
 
+constexpr size_t fh_ln_lu_doubles(int N, int NP) { return (size_t)N * N + 2 * (size_t)NP * NP + 16 * (size_t)NP; }
 size_t fh_ln_smem_bytes(int N, int *lu_in_lds, int *lu_nb);
 hipError_t fh_ln_launch(const LogNormalParams &P, int nblocks, hipStream_t s);
 

@@ -163,76 +163,119 @@ __device__ __forceinline__ void block_min_sum(LnS &S, double &a, double &b) {
 // Iv = exp(xv + s0) is the caller's; leaves S^-1 s and M I of the point in Sxv, MIv (gradient and Hessian re-use them).
 // The two matrix-vector products are split by column chunks over all threads: thread (row, chunk) walks down a
 // COLUMN of the symmetric matrices, so a wave reads consecutive addresses and nothing crosses lanes.
-__device__ __forceinline__ double ln_eval(const LogNormalParams &P, LnS &S, const double *xv, double *Iv, double *Sxv, double *MIv) {
+//
+// One CU pulls ~60 GB/s out of L2, so an evaluation costs what its matrix bytes cost, and the back-tracking line search
+// evaluates ~15 points x + lam p per Newton step at full size.  S^-1 is linear: the first trial of a search multiplies
+// S^-1 with the DIRECTION (sv = p, sdst = S^-1 p) and every trial forms S^-1 (x + lam p) = S^-1 x + lam S^-1 p from the
+// cached S^-1 x (along = true); later trials (sv = NULL) read M only.  M exp(.) is recomputed for every point.
+//   sv    vector multiplied with S^-1 (NULL: none), its product goes to sdst
+//   along S^-1 xv = S.Sx + lam * S.col   (S.col: S^-1 p of this search; the unblocked LU's scratch, idle here)
+__device__ __forceinline__ double ln_eval(const LogNormalParams &P, LnS &S, const double *xv, double *Iv, double *Sxv, double *MIv,
+                                          const double *sv, double *sdst, bool along, double lam) {
     const int N = P.N, tid = threadIdx.x;
     LTIC();
     if (S.row >= 0 && S.pair) {
         const int o = S.c0 * N + S.row, N2 = N >> 1;
-        const v2f64 *sc = reinterpret_cast<const v2f64 *>(__builtin_assume_aligned(P.Sinv + o, 16));
         const v2f64 *mc = reinterpret_cast<const v2f64 *>(__builtin_assume_aligned(P.M + o, 16));
         v2f64 a = {0.0, 0.0}, b = {0.0, 0.0};
         int c = S.c0;
-        for (; c + EVB <= S.c1; c += EVB, sc += EVB * N2, mc += EVB * N2) {
-            v2f64 vs[EVB], vm[EVB];
+        if (sv) {
+            const v2f64 *sc = reinterpret_cast<const v2f64 *>(__builtin_assume_aligned(P.Sinv + o, 16));
+            for (; c + EVB <= S.c1; c += EVB, sc += EVB * N2, mc += EVB * N2) {
+                v2f64 vs[EVB], vm[EVB];
 #pragma unroll
-            for (int u = 0; u < EVB; ++u) {
-                vs[u] = sc[u * N2];
-                vm[u] = mc[u * N2];
+                for (int u = 0; u < EVB; ++u) {
+                    vs[u] = sc[u * N2];
+                    vm[u] = mc[u * N2];
+                }
+#pragma unroll
+                for (int u = 0; u < EVB; ++u) {
+                    const double xc = sv[c + u], ic = Iv[c + u];
+                    a[0] = fma(vs[u][0], xc, a[0]);
+                    a[1] = fma(vs[u][1], xc, a[1]);
+                    b[0] = fma(vm[u][0], ic, b[0]);
+                    b[1] = fma(vm[u][1], ic, b[1]);
+                }
             }
+            for (; c < S.c1; ++c, sc += N2, mc += N2) {
+                const v2f64 vs = *sc, vm = *mc;
+                a[0] = fma(vs[0], sv[c], a[0]);
+                a[1] = fma(vs[1], sv[c], a[1]);
+                b[0] = fma(vm[0], Iv[c], b[0]);
+                b[1] = fma(vm[1], Iv[c], b[1]);
+            }
+            S.pbuf[S.slot] = a[0];
+            S.pbuf[S.slot + 1] = a[1];
+        } else {
+            for (; c + 2 * EVB <= S.c1; c += 2 * EVB, mc += 2 * EVB * N2) {
+                v2f64 vm[2 * EVB];
 #pragma unroll
-            for (int u = 0; u < EVB; ++u) {
-                const double xc = xv[c + u], ic = Iv[c + u];
-                a[0] = fma(vs[u][0], xc, a[0]);
-                a[1] = fma(vs[u][1], xc, a[1]);
-                b[0] = fma(vm[u][0], ic, b[0]);
-                b[1] = fma(vm[u][1], ic, b[1]);
+                for (int u = 0; u < 2 * EVB; ++u) vm[u] = mc[u * N2];
+#pragma unroll
+                for (int u = 0; u < 2 * EVB; ++u) {
+                    const double ic = Iv[c + u];
+                    b[0] = fma(vm[u][0], ic, b[0]);
+                    b[1] = fma(vm[u][1], ic, b[1]);
+                }
+            }
+            for (; c < S.c1; ++c, mc += N2) {
+                const v2f64 vm = *mc;
+                b[0] = fma(vm[0], Iv[c], b[0]);
+                b[1] = fma(vm[1], Iv[c], b[1]);
             }
         }
-        for (; c < S.c1; ++c, sc += N2, mc += N2) {
-            const v2f64 vs = *sc, vm = *mc;
-            a[0] = fma(vs[0], xv[c], a[0]);
-            a[1] = fma(vs[1], xv[c], a[1]);
-            b[0] = fma(vm[0], Iv[c], b[0]);
-            b[1] = fma(vm[1], Iv[c], b[1]);
-        }
-        S.pbuf[S.slot] = a[0];
-        S.pbuf[S.slot + 1] = a[1];
         S.pbuf[S.pstride + S.slot] = b[0];
         S.pbuf[S.pstride + S.slot + 1] = b[1];
     } else if (S.row >= 0) {
         const int o = S.c0 * N + S.row;
-        const double *sc = P.Sinv + o, *mc = P.M + o;
+        const double *mc = P.M + o;
         double a = 0.0, b = 0.0;
         int c = S.c0;
-        for (; c + EVB <= S.c1; c += EVB, sc += EVB * N, mc += EVB * N) {  // 2 x EVB loads in flight, explicitly (see the Hinv loop)
-            double vs[EVB], vm[EVB];
+        if (sv) {
+            const double *sc = P.Sinv + o;
+            for (; c + EVB <= S.c1; c += EVB, sc += EVB * N, mc += EVB * N) {  // 2 x EVB loads in flight, explicitly (see the Hinv loop)
+                double vs[EVB], vm[EVB];
 #pragma unroll
-            for (int u = 0; u < EVB; ++u) {
-                vs[u] = sc[u * N];
-                vm[u] = mc[u * N];
-            }
+                for (int u = 0; u < EVB; ++u) {
+                    vs[u] = sc[u * N];
+                    vm[u] = mc[u * N];
+                }
 #pragma unroll
-            for (int u = 0; u < EVB; ++u) {
-                a = fma(vs[u], xv[c + u], a);
-                b = fma(vm[u], Iv[c + u], b);
+                for (int u = 0; u < EVB; ++u) {
+                    a = fma(vs[u], sv[c + u], a);
+                    b = fma(vm[u], Iv[c + u], b);
+                }
             }
+            for (; c < S.c1; ++c, sc += N, mc += N) {
+                a = fma(*sc, sv[c], a);
+                b = fma(*mc, Iv[c], b);
+            }
+            S.pbuf[S.slot] = a;
+        } else {
+            for (; c + 2 * EVB <= S.c1; c += 2 * EVB, mc += 2 * EVB * N) {
+                double vm[2 * EVB];
+#pragma unroll
+                for (int u = 0; u < 2 * EVB; ++u) vm[u] = mc[u * N];
+#pragma unroll
+                for (int u = 0; u < 2 * EVB; ++u) b = fma(vm[u], Iv[c + u], b);
+            }
+            for (; c < S.c1; ++c, mc += N) b = fma(*mc, Iv[c], b);
         }
-        for (; c < S.c1; ++c, sc += N, mc += N) {
-            a = fma(*sc, xv[c], a);
-            b = fma(*mc, Iv[c], b);
-        }
-        S.pbuf[S.slot] = a;
         S.pbuf[S.pstride + S.slot] = b;
     }
     __syncthreads();
     double A = 0.0, B = 0.0, C = 0.0;
     if (tid < N) {
         double a = 0.0, b = 0.0;
-        for (int ch = 0; ch < S.nch; ++ch) {
-            a += S.pbuf[ch * N + tid];
-            b += S.pbuf[S.pstride + ch * N + tid];
+        if (sv) {
+            for (int ch = 0; ch < S.nch; ++ch) a += S.pbuf[ch * N + tid];
+            sdst[tid] = a;
         }
-        Sxv[tid] = a;
+        for (int ch = 0; ch < S.nch; ++ch) b += S.pbuf[S.pstride + ch * N + tid];
+        if (along) {
+            a = fma(lam, S.col[tid], S.Sx[tid]);
+            Sxv[tid] = a;
+        }
         MIv[tid] = b;
         A = xv[tid] * a;
         B = Iv[tid] * b;
@@ -251,23 +294,75 @@ __device__ __forceinline__ double ln_grad(const LnS &S, int i) {
     return S.Sx[i] + (S.I[i] * S.MI[i] - S.I[i] * S.jv[i]);
 }
 
-// hess(s) = I_a M_ab I_b + delta_ab (I_a (M I)_a - I_a j_a) + S^-1_ab   (statistical_models.py:1100-1122), at S.x,
-// written column-major into A (and into `copy` when given).  M is exactly symmetric, S^-1 to round-off.
-// `padded` (or NULL): the same symmetric matrix with leading dimension P.NP for the tiled Cholesky (its padding rows and
-// columns hold the identity: written once per kernel, the factorisation leaves them as they are)
-__device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, double *A, double *copy, double *padded = nullptr) {
+// hess(s) = I_a M_ab I_b + delta_ab (I_a (M I)_a - I_a j_a) + S^-1_ab   (statistical_models.py:1100-1122), at S.x.
+// M and S^-1 are symmetric bit for bit, the product I_a M_ab I_b is not (two roundings, in an order): out[b * ld + a] is
+// (I_a M_ab) I_b -- the column-major Hessian the factorisations work on -- or, with outer_first, (I_b M_ba) I_a: the same
+// bits as element [a][b] of the former, i.e. its row-major image (the Dinv handed to the host), written along rows too.
+// ld = P.NP: the padded copy for the tiled Cholesky (its padding rows and columns hold the identity: written once per
+// kernel, the factorisation leaves them as they are).
+__device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, double *out, int ld, bool outer_first) {
     const int N = P.N, tid = threadIdx.x;
     LTIC();
-    for (int b = tid >> 5; b < N; b += LT / 32) {
-        const double Ib = S.I[b];
-        const double *mb = P.M + b * N, *sb = P.Sinv + b * N;
-        for (int a = tid & 31; a < N; a += 32) {
-            double v = S.I[a] * mb[a] * Ib;
-            if (a == b) v += S.I[a] * S.MI[a] - S.I[a] * S.jv[a];
-            v += sb[a];
-            if (padded) padded[b * P.NP + a] = v;  // (the Cholesky attempt works on this copy and writes the factors into A)
-            else A[b * N + a] = v;
-            if (copy) copy[a * N + b] = v;  // row-major H_ab
+    if ((N & 1) == 0) {
+        // one wave per row, 16 bytes per lane and matrix, the loads of TWO rows issued before the first store: a single CU
+        // streams from L2 at the rate its requests in flight allow (8-byte loads interleaved with stores: 131 us per
+        // Hessian at N = 300; this: ~40 us, which is what 2.2 MB cost one CU)
+        constexpr int HB = 3;  // 64 * HB pairs per pass: one pass for N <= 384
+        const int lane = tid & 63, N2 = N >> 1;
+        for (int b0 = tid >> 6; b0 < N; b0 += 2 * LNW) {
+            for (int a0 = 0; a0 < N2; a0 += 64 * HB) {
+                v2f64 vm[2][HB], vs[2][HB];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int b = b0 + h * LNW;
+                    if (b < N) {
+                        const v2f64 *mb = reinterpret_cast<const v2f64 *>(__builtin_assume_aligned(P.M + b * N, 16));
+                        const v2f64 *sb = reinterpret_cast<const v2f64 *>(__builtin_assume_aligned(P.Sinv + b * N, 16));
+#pragma unroll
+                        for (int u = 0; u < HB; ++u) {
+                            const int idx = a0 + 64 * u + lane;
+                            if (idx < N2) {
+                                vm[h][u] = mb[idx];
+                                vs[h][u] = sb[idx];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int b = b0 + h * LNW;
+                    if (b < N) {
+                        const double Ib = S.I[b];
+#pragma unroll
+                        for (int u = 0; u < HB; ++u) {
+                            const int idx = a0 + 64 * u + lane;
+                            if (idx < N2) {
+                                v2f64 v;
+#pragma unroll
+                                for (int e = 0; e < 2; ++e) {
+                                    const int a = 2 * idx + e;
+                                    double t = outer_first ? Ib * vm[h][u][e] * S.I[a] : S.I[a] * vm[h][u][e] * Ib;
+                                    if (a == b) t += S.I[a] * S.MI[a] - S.I[a] * S.jv[a];
+                                    t += vs[h][u][e];
+                                    v[e] = t;
+                                }
+                                *reinterpret_cast<v2f64 *>(__builtin_assume_aligned(out + (size_t)b * ld + 2 * idx, 16)) = v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        for (int b = tid >> 5; b < N; b += LT / 32) {
+            const double Ib = S.I[b];
+            const double *mb = P.M + b * N, *sb = P.Sinv + b * N;
+            for (int a = tid & 31; a < N; a += 32) {
+                double v = outer_first ? Ib * mb[a] * S.I[a] : S.I[a] * mb[a] * Ib;
+                if (a == b) v += S.I[a] * S.MI[a] - S.I[a] * S.jv[a];
+                v += sb[a];
+                out[(size_t)b * ld + a] = v;
+            }
         }
     }
     __syncthreads();
@@ -284,14 +379,15 @@ __device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, dou
 // equally backward stable for a positive definite one.  A non-positive pivot leaves S.lu untouched and the pivoted LU
 // runs as before.  Cp: the padded copy (row-major, symmetric, leading dimension NP), factored in place: lower blocks = L,
 // strictly-upper blocks = L^T (mirror).
-__device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S, double *Cp) {
+__device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S, double *Cp, double *Xd = nullptr) {
     using namespace tilechol;
     const int N = P.N, NP = P.NP, nb = NP / 16, ld = NP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = lane & 15, rg = lane >> 4;
     double *pan = S.pan;                 // NP x PS panel (the LU panel's space: N * LU_NB doubles)
-    double *dli = pan + NP * PS, *dvec = dli + 16 * PS;  // inverse of the current diagonal tile; diag(L), NP entries
-    int *flag = reinterpret_cast<int *>(dvec + NP);
+    double *dli = pan + NP * PS, *dvec = dli + 16 * PS, *rdv = dvec + NP;  // inverse of the current diagonal tile; diag(L), 1 / diag(L)
+    int *flag = reinterpret_cast<int *>(rdv + NP);
+    int *lst = flag + 2;                 // tile list of the current trailing update: nb (nb - 1) / 2 entries at most
     gdouble *Cg = as_global(Cp);
     gdouble *lu = as_global(S.lu);       // the factors go straight to their final place: column-major N x N, unit-lower L D^-1
                                          // below the diagonal, D L^T on and above it (both scalings need the diagonal of block
@@ -306,21 +402,25 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             dli[(rg + 4 * r) * PS + cl] = x[r];
-            if (rg + 4 * r == cl) dvec[16 * k + cl] = t[r];
+            if (Xd) Xd[k * 256 + (rg + 4 * r) * 16 + cl] = x[r];  // L_kk^-1, row-major (the Tr2 solve's A operand)
+            if (rg + 4 * r == cl) {
+                dvec[16 * k + cl] = t[r];
+                rdv[16 * k + cl] = 1.0 / t[r];
+            }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        const double dc = dvec[16 * k + cl];
+        const double dc = dvec[16 * k + cl], rdc = rdv[16 * k + cl];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 16 * k + rg + 4 * r, j = 16 * k + cl;  // element (i, j) of L, i >= j holds data
             if (i < N && j < N && i >= j) {
                 if (i > j) {
-                    lu[(size_t)j * N + i] = t[r] / dc;   // L_ij / L_jj
+                    lu[(size_t)j * N + i] = t[r] * rdc;  // L_ij / L_jj
                     lu[(size_t)i * N + j] = dc * t[r];   // U_ji = L_jj L_ij
                 } else {
                     lu[(size_t)i * N + i] = dc * dc;
-                    S.rdiag[i] = 1.0 / (dc * dc);
+                    S.rdiag[i] = rdc * rdc;
                     S.perm[i] = i;
                 }
             }
@@ -337,25 +437,50 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
     __syncthreads();
     for (int k = 0; k < nb; ++k) {
         if (*flag) return false;
+        const int m = nb - k - 1, cnt = m * (m + 1) / 2;
+        // tile list of this step's trailing update, (I << 8) | J for k < J <= I (read after the next barrier)
+        for (int e = tid; e < cnt; e += LT) {
+            int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            while ((i + 1) * (i + 2) / 2 <= e) ++i;
+            while (i * (i + 1) / 2 > e) --i;
+            lst[e] = ((k + 1 + i) << 8) | (k + 1 + (e - i * (i + 1) / 2));
+        }
+        // look-ahead: wave 0 starts loading tile (k+1, k+1) now; it is there when the panel is done
+        v4f64 la = {0.0, 0.0, 0.0, 0.0};
+        if (wave == 0 && cnt > 0) la = load_acc(k + 1, k + 1);
         // panel: D = L_kk^-1 (C_Ik)^T = L_Ik^T for I > k -> LDS panel (unscaled, for the trailing update) and, scaled, into
-        // the factors: element (a, b) of D is L[16 I + b][16 k + a]
+        // the factors.  Element (a, b) of D is L[16 I + b][16 k + a]: its store runs along a column of the unit-lower part;
+        // the upper part wants the transposed tile, which is the same product with the operands exchanged (the B fragment
+        // of C_kI is the A fragment of C_Ik, the A fragment of X the B fragment of X^T): four more MFMAs instead of 64
+        // scattered 8-byte stores per tile.
         {
             Frag fa;
 #pragma unroll
             for (int q = 0; q < 4; ++q) fa.v[q] = dli[cl * PS + 4 * q + rg];
-            for (int I = k + 1 + wave; I < nb; I += LNW) {
-                const Frag fb = load_rows(Cg + (size_t)(16 * k) * ld + 16 * I, ld, cl, rg);
-                v4f64 d = {0.0, 0.0, 0.0, 0.0};
-                d = mfma4(fa, fb, d, false);
-                double *pr = pan + (size_t)((I - k - 1) * 16 + cl) * PS + rg;
+            // a wave's (up to three) panel tiles: all loads first, then the products -- one L2 latency per step, not per tile
+            constexpr int kPanelMax = 3;  // ceil((NP / 16 - 1) / LNW) for NP <= 400
+            Frag fb[kPanelMax];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pr[4 * r] = d[r];
-                    const int a = 16 * k + rg + 4 * r, b = 16 * I + cl;
-                    if (a < N && b < N) {
-                        const double da = dvec[a];
-                        lu[(size_t)a * N + b] = d[r] / da;  // (L D^-1)[b][a]
-                        lu[(size_t)b * N + a] = da * d[r];  // (D L^T)[a][b]
+            for (int u = 0; u < kPanelMax; ++u) {
+                const int I = k + 1 + wave + u * LNW;
+                if (I < nb) fb[u] = load_rows(Cg + (size_t)(16 * k) * ld + 16 * I, ld, cl, rg);
+            }
+            const double dck = dvec[16 * k + cl];
+#pragma unroll
+            for (int u = 0; u < kPanelMax; ++u) {
+                const int I = k + 1 + wave + u * LNW;
+                if (I < nb) {
+                    const v4f64 z = {0.0, 0.0, 0.0, 0.0};
+                    const v4f64 d = mfma4(fa, fb[u], z, false);
+                    const v4f64 dt = mfma4(fb[u], fa, z, false);
+                    double *pr = pan + (size_t)((I - k - 1) * 16 + cl) * PS + rg;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pr[4 * r] = d[r];
+                        const int a = 16 * k + rg + 4 * r, b = 16 * I + cl;
+                        if (a < N && b < N) lu[(size_t)a * N + b] = d[r] * rdv[a];  // (L D^-1)[b][a]
+                        const int bt = 16 * I + rg + 4 * r, at = 16 * k + cl;
+                        if (at < N && bt < N) lu[(size_t)bt * N + at] = dck * dt[r];  // (D L^T)[at][bt]
                     }
                 }
             }
@@ -364,27 +489,55 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
         // trailing update C_IJ -= L_Ik L_Jk^T for k < J <= I.  Wave 0 takes tile (k+1, k+1) first and goes on to factor and
         // invert it while the other waves update the rest (look-ahead); the tiles of column k + 1 also feed the next panel
         // as mirrors.
-        const int m = nb - k - 1, cnt = m * (m + 1) / 2;
-        auto updated = [&](int I1, int J1) {
-            v4f64 a = load_acc(I1, J1);
-            const double *pa1 = pan + (size_t)((I1 - k - 1) * 16 + cl) * PS + rg;
-            const double *pb1 = pan + (size_t)((J1 - k - 1) * 16 + cl) * PS + rg;
+        auto load_tile = [&](int t) { return load_acc(t >> 8, t & 255); };
+        auto update_tile = [&](int t, v4f64 a) {
+            const double *pa1 = pan + (size_t)(((t >> 8) - k - 1) * 16 + cl) * PS + rg;
+            const double *pb1 = pan + (size_t)(((t & 255) - k - 1) * 16 + cl) * PS + rg;
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s2], pb1[4 * s2], a, 0, 0, 0);
             return a;
         };
         if (wave == 0) {
-            if (cnt > 0) diag_tile(k + 1, updated(k + 1, k + 1));
+            if (cnt > 0) diag_tile(k + 1, update_tile(lst[0], la));
         } else {
-            // (prefetching the next tile before the MFMAs of the current one was measured: 11 % slower -- the compiler
-            //  rotates the register sets with copies and waits for every outstanding load)
-            for (int e = wave; e < cnt; e += LNW - 1) {
-                int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-                while ((i + 1) * (i + 2) / 2 <= e) ++i;
-                while (i * (i + 1) / 2 > e) --i;
-                const int I1 = k + 1 + i, J1 = k + 1 + (e - i * (i + 1) / 2);
-                const v4f64 a = updated(I1, J1);
-                store_tile(Cg, ld, I1, J1, a, cl, rg, J1 == k + 1 && I1 != k + 1);
+            // two tiles in flight, in two named register sets (ta/a and tb/b): the loads of the tile after next are issued
+            // before the four dependent MFMAs of the current one (the fit loop's scheme, fit_loop.hip)
+            constexpr int NWK = LNW - 1;
+            auto finish = [&](int t, v4f64 a) {
+                a = update_tile(t, a);
+                store_tile(Cg, ld, t >> 8, t & 255, a, cl, rg, (t & 255) == k + 1 && (t >> 8) != k + 1);
+            };
+            int e = wave;  // tiles 1.. of the list
+            if (e < cnt) {
+                int ta = lst[e], tb = 0;
+                v4f64 a = load_tile(ta), b = a;
+                bool hb = e + NWK < cnt;
+                if (hb) {
+                    tb = lst[e + NWK];
+                    b = load_tile(tb);
+                }
+                e += 2 * NWK;
+                for (;;) {
+                    const int tc = ta;
+                    const v4f64 c = a;
+                    const bool ha = e < cnt;
+                    if (ha) {
+                        ta = lst[e];
+                        a = load_tile(ta);
+                    }
+                    finish(tc, c);
+                    if (!hb) break;
+                    const int td = tb;
+                    const v4f64 d = b;
+                    hb = e + NWK < cnt;
+                    if (hb) {
+                        tb = lst[e + NWK];
+                        b = load_tile(tb);
+                    }
+                    finish(td, d);
+                    if (!ha) break;
+                    e += 2 * NWK;
+                }
             }
         }
         __syncthreads();
@@ -703,7 +856,7 @@ __device__ __forceinline__ void lu_factor_blocked(LnS &S, int N, double *A) {
         }
         __syncthreads();
 #ifdef LN_TIMING
-        if (tid == 0) { const long long n_ = clock64(); ln_cyc[6] += n_ - _tp; _tp = n_; }
+        if (tid == 0) { const long long n_ = clock64(); ln_cyc[7] += n_ - _tp; _tp = n_; }  // (slot 6 counts the fallbacks)
 #endif
         if (trailing) {
             const int c0 = k0 + LU_NB, mr = m - LU_NB;     // first trailing column; trailing rows (= trailing columns)
@@ -1031,7 +1184,10 @@ __device__ __forceinline__ int backtrack(const LogNormalParams &P, LnS &S, const
         }
         moved = __syncthreads_or(moved);
         if (!fallback && !moved) return 1;
-        const double cost_new = ln_eval(P, S, S.xn, S.In, S.Sxn, S.MIn);
+        // (fresh_products: S^-1 x_n multiplied out for every trial point, the reference's arithmetic)
+        const bool fresh = P.fresh_products != 0;
+        const double *sv = fresh ? S.xn : (trial == 0 ? p : nullptr);
+        const double cost_new = ln_eval(P, S, S.xn, S.In, S.Sxn, S.MIn, sv, fresh ? S.Sxn : S.col, !fresh, lam);
         ++nfev;
         if (fallback ? (cost_new < cost) : (cost_new <= (cost + armijo * lam * delta_f))) {
             if (!fallback) reduction = lam;
@@ -1084,20 +1240,24 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
     const int inv_after = max(2, N >> 3);
     for (int i = tid; i < N; i += LT) S.I[i] = exp(S.x[i] + P.s0);
     __syncthreads();
-    double fx = ln_eval(P, S, S.x, S.I, S.Sx, S.MI);
+    double fx = ln_eval(P, S, S.x, S.I, S.Sx, S.MI, S.x, S.Sx, false, 0.0);
     for (int i = tid; i < N; i += LT) S.jx[i] = ln_grad(S, i);
     __syncthreads();
     for (int nstep = 0; nstep < P.max_step; ++nstep) {
         if (need_hess) {
             if (nhess == P.max_hev) return {3, nstep, nfev, nhess};
             double *Cp = S.lu_nb > 0 ? P.LU + N * N : nullptr;
-            build_hess(P, S, S.lu, nullptr, Cp);
             if (S.lu_nb > 0) {
-                if (!cholesky_as_lu(P, S, Cp)) {  // not positive definite: the attempt has written into S.lu -- build again
-                    build_hess(P, S, S.lu, nullptr, nullptr);
+                build_hess(P, S, Cp, P.NP, false);
+                if (!cholesky_as_lu(P, S, Cp)) {  // not positive definite: the attempt has written into S.lu
+#ifdef LN_TIMING
+                    if (tid == 0) ln_cyc[6] += 1;
+#endif
+                    build_hess(P, S, S.lu, N, false);
                     lu_factor_blocked(S, N, S.lu);
                 }
             } else {
+                build_hess(P, S, S.lu, N, false);
                 lu_factor(S, N, S.lu);
             }
             ++nhess;
@@ -1211,6 +1371,180 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
     return {2, P.max_step - 1, nfev, nhess};
 }
 
+// S^-1 = Y^T diag(1/p) Y  (statistical_models.py:1061) on the matrix cores: tile (I, J) = sum_k (Y_k,I / p_k)^T Y_k,J, the
+// A fragment of k-step s being rows 4s..4s+3 of Y's block column I scaled by 1/p, the B fragment the same rows of block
+// column J.  A wave owns a 2 x 2 group of tiles on or below the block diagonal (four fragment loads feed four MFMAs);
+// the upper triangle is the mirror image, so S^-1 is symmetric bit for bit: the transposed tile comes from four more
+// MFMAs against the identity (the accumulator registers of a tile ARE the A fragments of its transpose) and both are
+// stored along rows.  rk: LDS, 1 / p.  (The scalar loop this replaces took 6 ms per power-spectrum iteration at N = 300
+// -- two strided 8-byte loads per multiply-add on one CU; this takes ~0.2 ms.)
+__device__ __forceinline__ void build_sinv(const LogNormalParams &P, const double *rk) {
+    using namespace tilechol;
+    const int N = P.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cl = lane & 15, rg = lane >> 4;
+    const int nbt = (N + 15) >> 4, G = (nbt + 1) >> 1, ngroups = G * (G + 1) / 2;
+    const int ksteps = (N + 3) >> 2;
+    const gdouble *Y = as_global(P.Y);
+    gdouble *out = as_global(P.Sinv);
+    double ident[4];  // B fragments of the 16 x 16 identity
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ident[q] = (4 * q + rg == cl) ? 1.0 : 0.0;
+    for (int g = wave; g < ngroups; g += LNW) {
+        int gi = (int)((sqrtf(8.0f * (float)g + 1.0f) - 1.0f) * 0.5f);
+        while ((gi + 1) * (gi + 2) / 2 <= g) ++gi;
+        while (gi * (gi + 1) / 2 > g) --gi;
+        const int gj = g - gi * (gi + 1) / 2;
+        const int I0 = 2 * gi, J0 = 2 * gj;
+        // columns past N are clamped: they only reach tile elements that are never stored
+        const int ca0 = min(16 * I0 + cl, N - 1), ca1 = min(16 * I0 + 16 + cl, N - 1);
+        const int cb0 = min(16 * J0 + cl, N - 1), cb1 = min(16 * J0 + 16 + cl, N - 1);
+        v4f64 d00 = {0.0, 0.0, 0.0, 0.0}, d01 = d00, d10 = d00, d11 = d00;
+        constexpr int KU = 4;  // k-steps per batch: 16 loads in flight, then 16 MFMAs
+        for (int s0 = 0; s0 < ksteps; s0 += KU) {
+            double fa0[KU], fa1[KU], fb0[KU], fb1[KU];
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int k = 4 * (s0 + u) + rg, kc = min(k, N - 1);
+                const gdouble *row = Y + (size_t)kc * N;
+                fa0[u] = row[ca0];
+                fa1[u] = row[ca1];
+                fb0[u] = row[cb0];
+                fb1[u] = row[cb1];
+            }
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int k = 4 * (s0 + u) + rg;
+                const double r = (k < N) ? rk[k] : 0.0;  // rows past N (and k-steps past the last one) contribute nothing
+                const double a0 = fa0[u] * r, a1 = fa1[u] * r;
+                d00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, fb0[u], d00, 0, 0, 0);
+                d01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, fb1[u], d01, 0, 0, 0);
+                d10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, fb0[u], d10, 0, 0, 0);
+                d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, fb1[u], d11, 0, 0, 0);
+            }
+        }
+        auto put = [&](int I, int J, const v4f64 &d) {
+            if (I >= nbt || J > I) return;
+            v4f64 t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t = __builtin_amdgcn_mfma_f64_16x16x4f64(d[q], ident[q], t, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int lr = rg + 4 * q;  // element (lr, cl) of the tile: d = D[lr][cl], t = D[cl][lr]
+                const int a = 16 * I + lr, b = 16 * J + cl;
+                if (I == J) {
+                    if (a < N && b < N) out[(size_t)a * N + b] = (lr >= cl) ? d[q] : t[q];
+                } else {
+                    if (a < N && b < N) out[(size_t)a * N + b] = d[q];
+                    const int at = 16 * J + lr, bt = 16 * I + cl;  // element (lr, cl) of the mirror tile (J, I)
+                    if (at < N && bt < N) out[(size_t)at * N + bt] = t[q];
+                }
+            }
+        };
+        put(I0, J0, d00);
+        put(I0, J0 + 1, d01);
+        put(I0 + 1, J0, d10);
+        put(I0 + 1, J0 + 1, d11);
+    }
+}
+
+// Tr2_r = y_r^T Dinv^-1 y_r for every row y_r of Y (filter.py:168-170) from the Cholesky factors of Dinv = L L^T:
+// Tr2_r = |L^-1 y_r|^2, a triangular solve with N right-hand sides on the matrix cores.  The right-hand sides are taken 16
+// at a time (block column c = rows 16c.. of Y); a wave owns up to three block columns and walks down the block rows:
+//     Z_I = L_II^-1 (Y^T_I - sum_{J<I} L'_IJ W_J),   W_J = D_J Z_J,   L' = L D^-1 (the unit-lower factor in S.lu)
+// The accumulator registers of a tile are the B fragments of the same tile, so W_J goes to a lane-private scratch (Wsc)
+// and comes back as an operand without any reshuffling; L_II^-1 was kept by the factorisation (Xd); the transposed tile
+// of Y comes from four MFMAs against the identity.  No barriers: the block columns are independent.  The substitution
+// by waves this replaces (wave_solve per row) took 6.5 ms per power-spectrum iteration at N = 300.
+__device__ __forceinline__ void tr2_solve(const LogNormalParams &P, LnS &S, const double *Xd, double *Wsc, double *tr2) {
+    using namespace tilechol;
+    const int N = P.N, NP = P.NP, nb = NP / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cl = lane & 15, rg = lane >> 4;
+    const double *dvec = S.pan + NP * PS + 16 * PS;  // diag(L), left in LDS by cholesky_as_lu
+    const gdouble *lu = as_global(S.lu), *Y = as_global(P.Y), *X = as_global(Xd);
+    gdouble *W = as_global(Wsc);
+    constexpr int NC = 3;  // block columns per wave: nb <= 24
+    double ident[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ident[q] = (4 * q + rg == cl) ? 1.0 : 0.0;
+    v4f64 ss[NC];
+#pragma unroll
+    for (int u = 0; u < NC; ++u) ss[u] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int I = 0; I < nb; ++I) {
+        v4f64 acc[NC];
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+            const int c = wave + u * LNW;
+            acc[u] = v4f64{0.0, 0.0, 0.0, 0.0};
+            if (c < nb) {
+                double t[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = 16 * c + rg + 4 * q, col = 16 * I + cl;
+                    t[q] = (row < N && col < N) ? Y[(size_t)row * N + col] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(t[q], ident[q], acc[u], 0, 0, 0);
+            }
+        }
+        const int lrow = 16 * I + cl;
+        const bool lvalid = lrow < N;
+        const gdouble *la = lu + min(lrow, N - 1);
+#pragma unroll 2
+        for (int J = 0; J < I; ++J) {
+            double fa[4], fb[NC][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fa[q] = la[(size_t)(16 * J + 4 * q + rg) * N];
+#pragma unroll
+            for (int u = 0; u < NC; ++u) {
+                const int c = wave + u * LNW;
+                if (c < nb) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) fb[u][q] = W[((size_t)(c * nb + J) * 4 + q) * 64 + lane];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fa[q] = lvalid ? -fa[q] : 0.0;
+#pragma unroll
+            for (int u = 0; u < NC; ++u) {
+                const int c = wave + u * LNW;
+                if (c < nb) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q], fb[u][q], acc[u], 0, 0, 0);
+                }
+            }
+        }
+        double fx[4], dI[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            fx[q] = X[I * 256 + cl * 16 + 4 * q + rg];
+            dI[q] = dvec[16 * I + rg + 4 * q];
+        }
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+            const int c = wave + u * LNW;
+            if (c < nb) {
+                v4f64 z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z = __builtin_amdgcn_mfma_f64_16x16x4f64(fx[q], acc[u][q], z, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ss[u][q] = fma(z[q], z[q], ss[u][q]);
+                    W[((size_t)(c * nb + I) * 4 + q) * 64 + lane] = z[q] * dI[q];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+        const int c = wave + u * LNW;
+        double t = (ss[u][0] + ss[u][1]) + (ss[u][2] + ss[u][3]);
+        t += __shfl_xor(t, 16);
+        t += __shfl_xor(t, 32);
+        if (c < nb && rg == 0 && 16 * c + cl < N) tr2[16 * c + cl] = t;
+    }
+}
+
 // LDS_LU: the LU factors live in LDS (N <= 112), else in global memory (L2)
 template <bool LDS_LU>
 __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
@@ -1232,7 +1566,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         P.p0 = P.batch_p0[f];
         P.band_lu += (size_t)f * 5 * P.N;
         P.Sinv += (size_t)blockIdx.x * NN;
-        P.LU += (size_t)blockIdx.x * (NN + P.NP * P.NP);
+        P.LU += (size_t)blockIdx.x * fh_ln_lu_doubles(P.N, P.NP);
         P.Hinv += (size_t)blockIdx.x * NN;
         P.H += (size_t)f * NN;
         P.s_out += (size_t)f * P.N;
@@ -1344,12 +1678,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
             }
             for (int i = tid; i < N; i += LT) S.rhs[i] = 1 / S.p[i];
             __syncthreads();
-            for (int a = tid >> 5; a < N; a += LT / 32)  // S^-1 = Y^T diag(1/p) Y  (:1061)
-                for (int b = tid & 31; b < N; b += 32) {
-                    double acc = 0.0;
-                    for (int k = 0; k < N; ++k) acc += S.rhs[k] * (P.Y[k * N + a] * P.Y[k * N + b]);  // symmetric bit for bit
-                    P.Sinv[a * N + b] = acc;
-                }
+            build_sinv(P, S.rhs);
             __syncthreads();
 #ifdef LN_TIMING
             const long long _tn = clock64();
@@ -1369,17 +1698,38 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
                 status = LN_STATUS_SLOPE;
                 break;
             }
-            // Dinv = hess(s_MAP) (:1147); its LU stands in for cho_factor / the SVD fallback
-            build_hess(P, S, S.lu, P.H);
-        } else {
-            // a caller-supplied posterior: s_MAP in S.x, Dinv (row-major) in P.H
-            for (int b = tid >> 5; b < N; b += LT / 32)
-                for (int a = tid & 31; a < N; a += 32) S.lu[b * N + a] = P.H[a * N + b];
-            __syncthreads();
+            // Dinv = hess(s_MAP) (:1147), row-major for the host
+            build_hess(P, S, P.H, N, true);
         }
-        if (S.lu_nb > 0) lu_factor_blocked(S, N, S.lu);
-        else lu_factor(S, N, S.lu);
         if (P.mode == LN_MODE_MAP) break;
+        // Factors of Dinv for Tr2 (filter.py:168-170 solves with the model's cho_factor / SVD fallback,
+        // statistical_models.py:1147-1158): tiled Cholesky first -- Dinv is positive definite at a MAP -- and the
+        // pivoted LU when a pivot is not positive.
+        // (P.H of a caller-supplied posterior is row-major Dinv; the Hessian of this kernel is rebuilt in the layout
+        //  each factorisation wants)
+        bool chol = false;
+        double *const Cp = P.LU + N * N, *const Wsc = Cp + P.NP * P.NP, *const Xd = Wsc + P.NP * P.NP;
+        if (S.lu_nb > 0) {
+            if (P.mode != LN_MODE_UPDATE) {
+                build_hess(P, S, Cp, P.NP, false);
+            } else {
+                for (int b = tid >> 5; b < N; b += LT / 32)
+                    for (int a = tid & 31; a < N; a += 32) Cp[b * P.NP + a] = P.H[a * N + b];
+                __syncthreads();
+            }
+            chol = cholesky_as_lu(P, S, Cp, Xd);
+        }
+        if (!chol) {
+            if (P.mode != LN_MODE_UPDATE) {
+                build_hess(P, S, S.lu, N, false);
+            } else {
+                for (int b = tid >> 5; b < N; b += LT / 32)
+                    for (int a = tid & 31; a < N; a += 32) S.lu[b * N + a] = P.H[a * N + b];
+                __syncthreads();
+            }
+            if (S.lu_nb > 0) lu_factor_blocked(S, N, S.lu);
+            else lu_factor(S, N, S.lu);
+        }
         if (in_pass) {  // radial_fitters.py:781-785
             if (P.diag_p)
                 for (int i = tid; i < N; i += LT) {
@@ -1393,16 +1743,25 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         bad = __syncthreads_or(bad);
         if (P.mode == LN_MODE_FIT && (!bad || count > P.max_iter)) break;  // radial_fitters.py:769-770
         // ---- CriticalFilter.update_power_spectrum(fit)  (filter.py:154-177) ----
+        if (chol) {
+            tr2_solve(P, S, Xd, Wsc, S.tr2);
+            __syncthreads();
+        }
         for (int r = w; r < N; r += LNW) {
             const double *yr = P.Y + r * N;
             double a = 0.0;  // Tr1_r = (Y s)_r^2
             for (int c = lane; c < N; c += 64) a = fma(yr[c], S.x[c], a);
             a = wave_sum(a);
-            double *xs = S.wsol + w * N;  // Tr2_r = y_r . D y_r,  D = Dinv^-1
-            wave_solve(S, N, S.lu, yr, -1, 1.0, xs);
-            double t2 = 0.0;
-            for (int c = lane; c < N; c += 64) t2 = fma(yr[c], xs[c], t2);
-            t2 = wave_sum(t2);
+            double t2;       // Tr2_r = y_r . D y_r,  D = Dinv^-1
+            if (chol) {
+                t2 = S.tr2[r];
+            } else {
+                double *xs = S.wsol + w * N;
+                wave_solve(S, N, S.lu, yr, -1, 1.0, xs);
+                t2 = 0.0;
+                for (int c = lane; c < N; c += 64) t2 = fma(yr[c], xs[c], t2);
+                t2 = wave_sum(t2);
+            }
             if (lane == 0) {
                 const double pi = S.p[r];
                 const double beta = (P.p0 + 0.5 * (a * a + t2)) / pi - (P.alpha - 1.0 + 0.5 * 1.0);

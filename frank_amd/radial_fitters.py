@@ -204,10 +204,14 @@ class FrankFitter(FourierBesselFitter):
     def __init__(self, Rmax, N, geometry, nu=0, block_data=True, block_size=10 ** 5, alpha=1.05, p_0=None,
                  weights_smooth=1e-4, tol=1e-3, method='Normal', I_scale=1e5, max_iter=2000, check_qbounds=True,
                  store_iteration_diagnostics=False, assume_optically_thick=True, scale_height=None, verbose=True,
-                 convergence_failure='raise', device=None, arithmetic='fp64'):
+                 convergence_failure='raise', device=None, arithmetic='fp64', lognormal_linesearch='linear'):
         if method not in {'Normal', 'LogNormal'}:
             raise ValueError('FrankFitter supports following mehods:\n\t{ "Normal", "LogNormal"}"')
+        if lognormal_linesearch not in _lib.LOGNORMAL_LINESEARCH:
+            raise ValueError("lognormal_linesearch must be one of %r, not %r" % (_lib.LOGNORMAL_LINESEARCH,
+                                                                                  lognormal_linesearch))
         self._method = method
+        self._lognormal_linesearch = lognormal_linesearch
         super(FrankFitter, self).__init__(Rmax, N, geometry, nu, block_data, assume_optically_thick, scale_height,
                                           block_size, verbose, device=device, arithmetic=arithmetic)
         # Reinstate the bounds check: FourierBesselFitter does not check bounds (radial_fitters.py:706-707)
@@ -246,6 +250,7 @@ class FrankFitter(FourierBesselFitter):
         if lognormal:
             Dinv = np.empty((N, N))
             stats = (ctypes.c_int64 * 9)()
+            _lib.set_lognormal_linesearch(self._DHT.context(), self._lognormal_linesearch)
             rc = _lib.lib.fh_fit_lognormal(self._DHT.context(), _lib.ptr(M), _lib.ptr(j), alpha, p_0, wsmooth, tol,
                                            int(self._max_iter), float(np.exp(self._s_scale)), _lib.ptr(x), _lib.ptr(p),
                                            ctypes.byref(niter), _lib.ptr(Dinv), stats, _lib.ptr(dp), _lib.ptr(dm))
@@ -337,7 +342,7 @@ class FrankFitter(FourierBesselFitter):
             return GaussianModel(self._DHT, self._M, self._j, p, guess=guess, noise_likelihood=self._H0)
         if fit_method == 'LogNormal':
             return LogNormalMAPModel(self._DHT, self._M, self._j, p, guess=guess, s0=self._s_scale,
-                                     noise_likelihood=self._H0)
+                                     noise_likelihood=self._H0, linesearch=self._lognormal_linesearch)
         raise ValueError('fit_method must be one of the following:\n\t{"Normal", "LogNormal"}')
 
     def draw_powerspectrum(self, Ndraw=1):

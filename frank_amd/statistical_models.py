@@ -437,7 +437,12 @@ class LogNormalMAPModel:
     """
 
     def __init__(self, DHT, M, j, p=None, scale=None, s0=None, guess=None, Nfields=None, full_hessian=1,
-                 noise_likelihood=0):
+                 noise_likelihood=0, linesearch='linear'):
+        # linesearch (not in the reference): 'linear' forms S^-1 (x + lam p) from S^-1 x and S^-1 p along a line search,
+        # 'reference' multiplies every trial point out as minimizer.py does (include/frank_hip.h)
+        if linesearch not in _lib.LOGNORMAL_LINESEARCH:
+            raise ValueError("linesearch must be one of %r, not %r" % (_lib.LOGNORMAL_LINESEARCH, linesearch))
+        self._linesearch = linesearch
         self._DHT = DHT
         M = np.asarray(M, dtype=np.float64)
         j = np.asarray(j, dtype=np.float64)
@@ -484,6 +489,7 @@ class LogNormalMAPModel:
         self = cls.__new__(cls)
         N = DHT.size
         self._DHT = DHT
+        self._linesearch = 'linear'
         self._Nfields = 1
         self._full_hess = 1
         self._scale = np.ones([1, 1], dtype='f8')
@@ -508,6 +514,7 @@ class LogNormalMAPModel:
         stats = (ctypes.c_int64 * 9)()
         # no prior (p=None): S^-1 = 0 (:1063) is p -> infinity
         p = np.full(N, np.inf) if self._p is None else _lib.f8(self._p[0])
+        _lib.set_lognormal_linesearch(self._DHT.context(), self._linesearch)
         _lib.check(_lib.lib.fh_lognormal_model(self._DHT.context(), _lib.ptr(_lib.f8(self._M[0])),
                                                _lib.ptr(_lib.f8(self._j[0])), _lib.ptr(p), _lib.ptr(_lib.f8(guess)),
                                                float(self._s0[0, 0]), _lib.ptr(s_map), _lib.ptr(Dinv), stats))

@@ -127,6 +127,7 @@ def _sweep_lognormal(fitter, M, j, alphas, ws, p0, tol, max_iter, devices):
         if count == 0:
             return
         sl = slice(first, first + count)
+        _lib.set_lognormal_linesearch(fitter._DHT.context(dev), fitter._lognormal_linesearch)
         _lib.check(_lib.lib.fh_fit_lognormal_batched(
             fitter._DHT.context(dev), _lib.ptr(M), _lib.ptr(j), count, _lib.ptr(alphas[sl]), _lib.ptr(p0[sl]),
             _lib.ptr(ws[sl]), float(tol), int(max_iter), float(np.exp(fitter._s_scale)), _lib.ptr(s_map[sl]),

@@ -131,6 +131,17 @@ int fh_bin_last_prepass_ms(fh_ctx *ctx, float *ms);
  * fp64, geometry.py:69-79): the brightness profile then agrees with the fp64 path to ~1e-5 of its maximum, inside the
  * 1e-3 BASELINE.json states for fp32.  Default 0 (fp64 arithmetic whatever the storage type of the table).           */
 int fh_ctx_set_arithmetic(fh_ctx *ctx, int fp32);
+/* Line search of the LogNormal Newton solves (minimizer.py:70-187 evaluates H(x + lam p) afresh for every trial step).
+ * The prior precision S^-1 = Y^T diag(1/p) Y has entries ~1/p_0 = 1e35 that cancel in S^-1 x, so a freshly multiplied
+ * S^-1 (x + lam p) carries round-off far above that of the objective itself and the Armijo test of the reference mostly
+ * compares noise: ~15 trial points per Newton step, most MAP solves end with "neither direction improves".
+ *   reference_products == 0 (default): S^-1 (x + lam p) = S^-1 x + lam S^-1 p along a search (S^-1 is linear; one product
+ *       per search instead of one per trial).  The round-off of S^-1 x is then the same at every trial point, the
+ *       searches accept the Newton step, the solves converge in ~10 steps.  The profile differs from the reference's by
+ *       no more than the reference's own fit moves when M is perturbed by 1e-15 (tests/test_gpu_configs.py).
+ *   reference_products != 0: every trial point multiplied out, the reference's arithmetic; Newton step and evaluation
+ *       counts then track the reference's (tests/golden/lognormal_*.npz), at ~8x the time.                              */
+int fh_ctx_set_lognormal_linesearch(fh_ctx *ctx, int reference_products);
 /* Work hand-out of bin_gram.  By default a synchronous fit deals contiguous ranges of the sorted table to the workgroups
  * (the sums come out bit for bit the same in every run) and a pipeline of fits (fh_fit_submit outstanding) lets the
  * workgroups pull work from a counter, which is faster while fit loops occupy compute units but makes the last bits

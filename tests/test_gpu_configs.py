@@ -32,19 +32,24 @@ def _load_mapping(FF, g):
 
 
 # ---- configs[2] -----------------------------------------------------------------------------------------------------
-def test_lognormal_map_model_N300(golden):
+@pytest.mark.parametrize("linesearch", ["linear", "reference"])
+def test_lognormal_map_model_N300(golden, linesearch):
     """The device LogNormalMAPModel at the basis size of BASELINE configs[2] (blocked LU with factors in L2, five 64-row
     solve blocks) against the reference's own solve on the seed power spectrum (tools/make_golden_lognormal.py N300).
 
     At N = 300 this solve is no longer determined to 1e-9: MinimizeNewton stops on a 1e-7 relative improvement and the
     faint outer disc is held loosely -- the reference moves by 1.6e-4 in s (1e-7 of max I, 1571 -> 1591 steps) when M is
-    perturbed by 1e-15 relative; the fixture records that (map_selfsens_*), and it is the scale of the assertions."""
+    perturbed by 1e-15 relative; the fixture records that (map_selfsens_*), and it is the scale of the assertions.
+
+    linesearch='reference' multiplies S^-1 x out at every trial point as the reference does and reproduces its step count;
+    the default ('linear') reaches the same MAP inside the same band (here in as many steps: this solve runs on a frozen
+    Hessian whose steps are accepted at the first trial either way)."""
     from frank_amd import CriticalFilter, DiscreteHankelTransform, LogNormalMAPModel
     g = golden("lognormal_N300.npz")
     N = 300
     d = DiscreteHankelTransform(RMAX, N)
     s0 = float(np.log(g["I_scale"]))
-    fit = LogNormalMAPModel(d, g["M"], g["j"], g["p_seed"], guess=g["s_guess"], s0=s0)
+    fit = LogNormalMAPModel(d, g["M"], g["j"], g["p_seed"], guess=g["s_guess"], s0=s0, linesearch=linesearch)
     sens_s, sens_I = float(g["map_selfsens_s"]), float(g["map_selfsens_I_relmax"])
     assert 1e-5 < sens_s < 1e-3 and sens_I < 1e-6
     assert np.abs(fit.MAP - g["map_s"]).max() < 5 * sens_s
@@ -55,8 +60,12 @@ def test_lognormal_map_model_N300(golden):
     assert rel_to_max(fit._Dinv, g["map_Dinv"]) < 1e-7
     status, nstep, nfev, nhess = (int(x) for x in g["map_stats"])
     st = fit._newton_stats
-    assert st[0] == 1 and st[4 + status] == 1 and st[3] == nhess
-    assert abs(st[1] - nstep) <= 3 * abs(int(g["map_selfsens_nstep"]) - nstep) + 0.01 * nstep
+    if linesearch == "reference":
+        assert st[0] == 1 and st[4 + status] == 1 and st[3] == nhess
+        assert abs(st[1] - nstep) <= 3 * abs(int(g["map_selfsens_nstep"]) - nstep) + 0.01 * nstep
+    else:
+        assert st[0] == 1 and st[4] == 1  # converged (exit 0); what the searches save shows in the evaluations per step
+        assert st[2] < 1.5 * st[1]
     p_new = CriticalFilter(d, 1.3, 1e-35, 1e-2).update_power_spectrum(fit)
     np.testing.assert_allclose(p_new, g["map_p_updated"], rtol=2e-4)
 

@@ -16,7 +16,7 @@ for name,N in (('sweep_N50_2e4.npz',50),('fit_N100_1e5.npz',100),('fit_N300_1e6.
     nit=FF.iteration_diagnostics['num_iterations']
     print(N,'niter',nit,ni,'rel',np.abs(sol.I-I).max()/np.abs(I).max(),'time %.1f ms  %.1f us/iter'%(1e3*dt,1e6*dt/nit))
 
-if os.environ.get("FRANK_AMD_LIB"):
+if "timing" in os.environ.get("FRANK_AMD_LIB", ""):
     import ctypes
     from frank_amd import _lib
     out=(ctypes.c_longlong*16)()
