@@ -30,6 +30,11 @@ using namespace tilechol;
 #define TSTAMP(ph) do { } while (0)
 #endif
 #ifdef FIT_LOOP_TIMING
+#define OSTAMP(slot) do { if (threadIdx.x == 0) { long long n3_ = clock64(); P.timing[slot] += n3_ - o_last; o_last = n3_; } } while (0)
+#else
+#define OSTAMP(slot) do { } while (0)
+#endif
+#ifdef FIT_LOOP_TIMING
 #define FSTAMP(slot) do { if (threadIdx.x == 0) { long long n2_ = clock64(); P.timing[slot] += n2_ - f_last; f_last = n2_; } } while (0)
 #else
 #define FSTAMP(slot) do { } while (0)
@@ -57,14 +62,16 @@ constexpr int NW = KT / 64;
 #define K2_ALL_WORK 1
 #endif
 constexpr int NWK = K2_ALL_WORK ? NW - 1 : NW - NW / 4;
+constexpr int kMaxTiles = 210;  // tiles of the largest trailing triangle: NP / 16 - 1 = 20 block rows (NP <= 336)
 
 struct Smem {
     double *pan;   // panel of the current block column: NP x PS doubles
-    double *stage1;  // second stage buffer of row_inverse: (NP/16) * 256 doubles
     double *dli;   // 16 x PS: its inverse (A operand of the MFMA panel solve)
     double *p, *pold, *m, *y, *tr2, *rhs, *b, *red;  // NP each (red: 6*NP scratch)
-    double *band;  // 5 NP: LU factors of the pentadiagonal T + I, staged once per fit
-    int *lst;      // tile list of the current trailing update (<= 171 entries)
+    double *band;  // 6 NP: LU factors of the pentadiagonal T + I (five bands) and the reciprocal pivots, staged once per fit
+    uint4 *rec;    // tile e = i (i + 1) / 2 + j of the trailing triangle (block (k+1+i, k+1+j) at step k), built once per launch:
+                   // x = byte offset of the tile relative to block (k+1, k+1) | bit 0: column k+1 (also stored as mirror) | bit 1:
+                   // diagonal tile; y, z = byte offsets of panel row blocks i, j; w = offset of the mirror tile | i
     int *flag;
 };
 
@@ -75,40 +82,55 @@ struct Smem {
 // accumulator, 123 us).  Row I only needs rows <= I of L and rows < I of W, so it is now computed DURING step I of the
 // factorisation: the trailing update shrinks quadratically with the step while the rows of the inverse grow, and the
 // two together keep the waves about evenly busy (the factorisation alone left them idle for most of its second half).
-// One tile W_IJ: `stage` holds row I of L (stage[K][k][i] = L_IK[i][k], fragment s of lane (cl, rg) at
-// stage[K * 256 + (4 s + rg) * 16 + cl]); `fw` is the A operand W_II (rows of its transpose).
-__device__ __forceinline__ void inverse_tile(const double *stage, const Frag &fw, double *W, double *cs_IJ, int I, int J,
+// One tile W_IJ.  The A operand L_IK is read from its mirror block (K, I) of C in row form (4 rows x 128 contiguous
+// bytes), like every other operand; a first version staged row I of L in LDS, transposed, once per step: the staging loads
+// sat in front of the panel (their registers and the in-order vmcnt tied them to the spill reloads: ~1 us per step) and
+// took 39 KB of LDS.  `fw` is the A operand W_II (rows of its transpose).  All addresses: uniform base + 32-bit offset.
+__device__ __forceinline__ void inverse_tile(const gdouble *Cu, const Frag &fw, gdouble *Wu, double *cs_IJ, int I, int J,
                                              int N, int ld, int cl, int rg) {
-    const gdouble *Wg = as_global(W) + 16 * J;  // block column J
+    const unsigned row4 = (unsigned)(4 * ld * 8), blk = (unsigned)(16 * ld * 8);
+    unsigned oa = (unsigned)(((16 * J + rg) * ld + 16 * I + cl) * 8);  // fragment of block (K, I) of C, K = J
+    unsigned ob = (unsigned)(((16 * J + rg) * ld + 16 * J + cl) * 8);  // fragment of block (K, J) of W
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-    auto lfrag = [&](int K) {  // A operand: L_IK from the staged row
-        Frag fa;
-        const double *sp = stage + K * 256 + rg * 16 + cl;
+    auto frag = [&](const gdouble *base, unsigned o) {
+        Frag f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) fa.v[q] = sp[64 * q];
-        return fa;
+        for (int q = 0; q < 4; ++q) f.v[q] = ld_off(base, o + q * row4);
+        return f;
     };
-    // two W tiles in flight, in two named register sets (a rotating array made the compiler copy the sets and wait for
+    // two products in flight, in two named register sets (a rotating array made the compiler copy the sets and wait for
     // EVERY outstanding load at the top of each trip: one full L2 latency per product)
-    Frag b0 = load_rows(Wg + (size_t)(16 * J) * ld, ld, cl, rg), b1 = b0;
-    if (J + 1 < I) b1 = load_rows(Wg + (size_t)(16 * (J + 1)) * ld, ld, cl, rg);
+    Frag a0 = frag(Cu, oa), b0 = frag(Wu, ob), a1 = a0, b1 = b0;
+    if (J + 1 < I) {
+        a1 = frag(Cu, oa + blk);
+        b1 = frag(Wu, ob + blk);
+    }
     int K = J;
     for (; K + 1 < I; K += 2) {
-        const Frag a0 = lfrag(K), a1 = lfrag(K + 1);
-        const Frag c0 = b0, c1 = b1;
-        if (K + 2 < I) b0 = load_rows(Wg + (size_t)(16 * (K + 2)) * ld, ld, cl, rg);
-        if (K + 3 < I) b1 = load_rows(Wg + (size_t)(16 * (K + 3)) * ld, ld, cl, rg);
-        acc = mfma4(a0, c0, acc, false);
-        acc = mfma4(a1, c1, acc, false);
+        const Frag ca0 = a0, cb0 = b0, ca1 = a1, cb1 = b1;
+        oa += 2 * blk;
+        ob += 2 * blk;
+        if (K + 2 < I) {
+            a0 = frag(Cu, oa);
+            b0 = frag(Wu, ob);
+        }
+        if (K + 3 < I) {
+            a1 = frag(Cu, oa + blk);
+            b1 = frag(Wu, ob + blk);
+        }
+        acc = mfma4(ca0, cb0, acc, false);
+        acc = mfma4(ca1, cb1, acc, false);
     }
-    if (K < I) acc = mfma4(lfrag(K), b0, acc, false);
+    if (K < I) acc = mfma4(a0, b0, acc, false);
     // the C/D layout of acc (row = rg + 4 r, col = cl) is the B-operand layout (k = 4 s + rg, j = cl)
     Frag fs;
 #pragma unroll
     for (int q = 0; q < 4; ++q) fs.v[q] = acc[q];
     v4f64 w = {0.0, 0.0, 0.0, 0.0};
     w = mfma4(fw, fs, w, true);
-    store_tile(as_global(W), ld, I, J, w, cl, rg, false);
+    const unsigned ow = (unsigned)(((16 * I + rg) * ld + 16 * J + cl) * 8);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st_off(Wu, ow + r * row4, w[r]);
     double ssq = 0.0;  // column sums of squares of this (final) tile over the rows of the real system
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -123,7 +145,7 @@ __device__ __forceinline__ void inverse_tile(const double *stage, const Frag &fw
 // transpose; with the mirrors every MFMA operand is loaded in "row form" (4 rows x 128 contiguous bytes).
 __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Smem &S) {
     const int N = P.N, NP = P.NP, nb = P.NP / 16, ld = P.NP;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
     const int cl = lane & 15, rg = lane >> 4;
     double *C = P.C, *W = P.W, *WdT = P.WdT;
 #ifdef FIT_LOOP_TIMING
@@ -163,26 +185,10 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
     for (int k = 0; k < nb; ++k) {
         if (*S.flag) return false;
         const double *src = (k == 0) ? P.A : C;
-        const int m = nb - k - 1, cnt = m * (m + 1) / 2;
-        // tile list of this step's trailing update, (I << 8) | J for k < J <= I (read after the next barrier)
-        for (int e = tid; e < cnt; e += KT) {
-            int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-            while ((i + 1) * (i + 2) / 2 <= e) ++i;
-            while (i * (i + 1) / 2 > e) --i;
-            const int j = e - i * (i + 1) / 2;
-            S.lst[e] = ((k + 1 + i) << 8) | (k + 1 + j);
-        }
-        // row k of L (final since the panels of steps < k) for row k of the inverse, computed beside this step's trailing
-        // update; its columns are handed out from a counter, longest chain (J = 0) first
-        // (loads issued here, written to LDS behind the panel: the panel's MFMAs cover their latency)
-        constexpr int kStageMax = (20 * 256 + KT - 1) / KT;  // NP <= 336
-        double sv[kStageMax];
-#pragma unroll
-        for (int i = 0; i < kStageMax; ++i) {
-            const int e = tid + i * KT;
-            const int K = e >> 8, r = (e >> 4) & 15, c = e & 15;
-            sv[i] = e < k * 256 ? C[(size_t)(16 * K + r) * ld + 16 * k + c] : 0.0;
-        }
+        const int m = nb - k - 1, cnt = __builtin_amdgcn_readfirstlane(m * (m + 1) / 2);
+        TSTAMP(5);
+        // row k of the inverse is computed beside this step's trailing update (row k of L is final since the panels of
+        // steps < k); its columns are handed out from a counter, longest chain (J = 0) first
         if (tid == 0) S.flag[1] = 0;
         // look-ahead prefetch: wave 0 starts loading tile (k+1,k+1) now; it is complete when the panel is done
         v4f64 la = {0.0, 0.0, 0.0, 0.0};
@@ -191,6 +197,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
 #pragma unroll
             for (int r = 0; r < 4; ++r) la[r] = c1[(size_t)(4 * r) * ld];
         }
+        TSTAMP(6);
         // panel: D = L_kk^-1 * (C_Ik)^T for I > k; D^T -> C (I,k), D -> C mirror (k,I), D^T -> LDS panel
         {
             Frag fa;
@@ -216,11 +223,6 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                     for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
                 }
             }
-        }
-#pragma unroll
-        for (int i = 0; i < kStageMax; ++i) {
-            const int e = tid + i * KT;
-            if (e < k * 256) S.stage1[e] = sv[i];
         }
         __syncthreads();
         TSTAMP(2);
@@ -248,6 +250,8 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             return a;
         };
         // columns of row k of the inverse, pulled from the LDS counter (which wave computes a tile does not change its bits)
+        const gdouble *C_inv = as_global(uniform_ptr(C));
+        gdouble *W_inv = as_global(uniform_ptr(W));
         auto inverse_columns = [&]() {
             if (k < 1) return;
             Frag fw;  // A operand W_kk: rows of its transpose
@@ -259,7 +263,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 if (lane == 0) J = atomicAdd(&S.flag[1], 1);
                 J = __builtin_amdgcn_readfirstlane(J);
                 if (J >= k) break;
-                inverse_tile(S.stage1, fw, W, cs_ptr(k, J), k, J, N, ld, cl, rg);
+                inverse_tile(C_inv, fw, W_inv, cs_ptr(k, J), k, J, N, ld, cl, rg);
             }
         };
         if (wave == 0) {
@@ -268,7 +272,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
 #ifdef FIT_LOOP_TIMING
                 long long f_last = clock64();
 #endif
-                const int t = S.lst[0];
+                const int t = ((k + 1) << 8) | (k + 1);
                 v4f64 a = update_tile(t, la), xi;
                 FSTAMP(8);
                 // factor and invert in the accumulator layout (DPP row broadcasts, no LDS round trip, no transposition)
@@ -287,44 +291,76 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
 #ifdef FIT_LOOP_TIMING
             long long w_last = clock64();
 #endif
-            // two tiles in flight, in two named register sets (ta/a and tb/b): the loads of the tile after next are issued
-            // before the four dependent MFMAs of the current one
-            auto finish = [&](int t, v4f64 a) {
-                a = update_tile(t, a);
-                // tiles of column k+1 also feed the next panel as mirrors
-                store_tile(Cg, ld, t >> 8, t & 255, a, cl, rg, (t & 255) == k + 1 && (t >> 8) != k + 1);
+            // Per tile: 4 MFMAs (256 cycles of the matrix pipe) against, at first, ~90 other instructions, most of them 64-bit
+            // address arithmetic.  Every address is now a uniform base + a 32-bit byte offset (one v_add per row), the offsets
+            // of tile e relative to block (k+1, k+1) come from a table built once per launch (S.rec: the tiles of step k are
+            // the first cnt entries of ONE row-wise enumeration of the triangle), and THREE named register sets rotate through
+            // an unrolled trip: the loads of the tile after next are issued before the stores of the current one (vmcnt counts
+            // loads and stores in order -- a load issued behind a store would wait for the store's acknowledgement) without
+            // a register copy.  (2 x 2 groups of tiles with four interleaved MFMA chains were measured too: no faster --
+            // the phase is bound by the number of dependent round trips per step, not by MFMA issue.)
+            const unsigned base_k = (unsigned)(16 * (k + 1) * (ld + 1) * 8);
+            const unsigned lane_c = base_k + (unsigned)((rg * ld + cl) * 8), row4 = (unsigned)(4 * ld * 8);
+            const unsigned lane_m = base_k + (unsigned)((cl * ld + rg) * 8);
+            const unsigned lane_p = (unsigned)((cl * PS + rg) * 8);
+            const char *pan_b = reinterpret_cast<const char *>(S.pan);
+            const gdouble *src_u = as_global(uniform_ptr(src));
+            gdouble *C_u = as_global(uniform_ptr(C));
+            auto ldt = [&](const uint4 &t) {
+                v4f64 a;
+                const unsigned o = (t.x & ~127u) + lane_c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = ld_off(src_u, o + r * row4);
+                return a;
             };
-            int e = 1 + widx;
-            if (e < cnt) {
-                int ta = S.lst[e], tb = 0;
-                v4f64 a = load_tile(ta), b = a;
-                bool hb = e + NWK < cnt;
-                if (hb) {
-                    tb = S.lst[e + NWK];
-                    b = load_tile(tb);
+            auto fin = [&](const uint4 &t, v4f64 a) {
+                if (k == 0 && (t.x & 2u)) {  // first touch: add diag(1/p) on diagonal tiles
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (rg + 4 * r == cl) a[r] += pinv[16 * (1 + (t.w & 127u)) + cl];
                 }
-                e += 2 * NWK;
+                const double *pa1 = reinterpret_cast<const double *>(pan_b + t.y + lane_p);
+                const double *pb1 = reinterpret_cast<const double *>(pan_b + t.z + lane_p);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s], pb1[4 * s], a, 0, 0, 0);
+                const unsigned o = (t.x & ~127u) + lane_c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st_off(C_u, o + r * row4, a[r]);
+                if (t.x & 1u) {  // column k + 1: also as the mirror block that feeds the next panel
+                    const unsigned m2 = (t.w & ~127u) + lane_m;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st_off(C_u, m2 + 32 * r, a[r]);
+                }
+            };
+            int e = 1 + widx;  // tiles 1.. of the enumeration, every NWK-th
+            if (e < cnt) {
+                uint4 ta = S.rec[e], tb = ta, tc = ta;
+                v4f64 a = ldt(ta), b = a, c = a;
+                if (e + NWK < cnt) {
+                    tb = S.rec[e + NWK];
+                    b = ldt(tb);
+                }
                 for (;;) {
-                    // current: (ta, a); next: (tb, b) if hb
-                    const int tc = ta;
-                    const v4f64 c = a;
-                    const bool ha = e < cnt;
-                    if (ha) {
-                        ta = S.lst[e];
-                        a = load_tile(ta);
+                    // sets in flight: a (current), b (next); c is free
+                    if (e + 2 * NWK < cnt) {
+                        tc = S.rec[e + 2 * NWK];
+                        c = ldt(tc);
                     }
-                    finish(tc, c);
-                    if (!hb) break;
-                    const int td = tb;
-                    const v4f64 d = b;
-                    hb = e + NWK < cnt;
-                    if (hb) {
-                        tb = S.lst[e + NWK];
-                        b = load_tile(tb);
+                    fin(ta, a);
+                    if (e + NWK >= cnt) break;
+                    if (e + 3 * NWK < cnt) {
+                        ta = S.rec[e + 3 * NWK];
+                        a = ldt(ta);
                     }
-                    finish(td, d);
-                    if (!ha) break;
-                    e += 2 * NWK;
+                    fin(tb, b);
+                    if (e + 2 * NWK >= cnt) break;
+                    if (e + 4 * NWK < cnt) {
+                        tb = S.rec[e + 4 * NWK];
+                        b = ldt(tb);
+                    }
+                    fin(tc, c);
+                    if (e + 3 * NWK >= cnt) break;
+                    e += 3 * NWK;
                 }
             }
             WSTAMP(11);
@@ -409,14 +445,28 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     S.rhs = S.tr2 + NP;
     S.b = S.rhs + NP;
     S.red = S.b + NP;  // 6*NP
-    S.stage1 = S.red + 6 * NP;
-    S.band = S.stage1 + (NP / 16) * 256;
-    S.lst = reinterpret_cast<int *>(S.band + 5 * NP);
-    S.flag = S.lst + 192;  // [0] not positive definite, [1] column counter of the inverse row
+    S.band = S.red + 6 * NP;
+    S.rec = reinterpret_cast<uint4 *>(S.band + 6 * NP);  // (16-byte aligned: every region before it is an even number of doubles)
+    S.flag = reinterpret_cast<int *>(S.rec + kMaxTiles);  // [0] not positive definite, [1] column counter of the inverse row
+    for (int e = tid; e < kMaxTiles; e += KT) {
+        int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        while ((i + 1) * (i + 2) / 2 <= e) ++i;
+        while (i * (i + 1) / 2 > e) --i;
+        const int j = e - i * (i + 1) / 2;
+        S.rec[e] = make_uint4((unsigned)((16 * i * NP + 16 * j) * 8) | ((j == 0 && i != 0) ? 1u : 0u) | (i == j ? 2u : 0u),
+                              (unsigned)(i * 16 * PS * 8), (unsigned)(j * 16 * PS * 8),
+                              (unsigned)((16 * j * NP + 16 * i) * 8) | (unsigned)i);
+    }
     __shared__ int s_ctl[4];  // [0] stop, [1] status
 
     if (P.band_lu)
-        for (int i = tid; i < 5 * N; i += KT) S.band[i] = P.band_lu[i];
+        for (int i = tid; i < 5 * NP; i += KT) {  // five bands of NP entries (padding: unit pivots, zero bands) + reciprocal pivots
+            const int bnd = i / NP, c = i - bnd * NP;
+            double v = (c < N) ? P.band_lu[bnd * N + c] : (bnd == 2 ? 1.0 : 0.0);
+            if (c == 0 && bnd < 2) v = 0.0;  // no sub-diagonal entries in row 0
+            S.band[i] = v;
+            if (bnd == 2) S.band[5 * NP + c] = 1.0 / v;
+        }
     for (int i = tid; i < NP; i += KT) {
         S.b[i] = i < N ? P.bq[i] : 0.0;
         S.p[i] = i < N ? (P.p_init ? P.p_init[i] : 1.0) : 1.0;  // radial_fitters.py:744 (p = 1)
@@ -432,7 +482,11 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     // guess (:749-752); phase 2: the loop of :769-785 (FIT_MODE_STEP: exactly one pass, FIT_MODE_SOLVE: none).
     int phase = (P.mode == FIT_MODE_FULL) ? 0 : 2;
     bool in_pass = false;
+#ifdef FIT_LOOP_TIMING
+    long long o_last = clock64();
+#endif
     for (;;) {
+        OSTAMP(14);
         if (!solve_posterior(P, S)) {
             status = FIT_STATUS_NOT_SPD;
             break;
@@ -456,10 +510,11 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
             phase = 1;
             continue;
         }
+        OSTAMP(13);
         phase = 2;
         if (in_pass) {
             if (P.diag_mu) {  // MAP of this pass: mu = Y^-1 m   (radial_fitters.py:783)
-                for (int r = tid >> 6; r < N; r += NW) {
+                for (int r = __builtin_amdgcn_readfirstlane(tid >> 6); r < N; r += NW) {
                     const double *yr = P.Yinv + (size_t)r * N;
                     double a = 0.0;
                     for (int c = tid & 63; c < N; c += 64) a = fma(yr[c], S.m[c], a);
@@ -477,62 +532,78 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         bad = __syncthreads_or(bad);
         if (!bad || count > P.max_iter) break;  // radial_fitters.py:769-770
         // beta and the right-hand side of (T + I) tau = beta + log p   (filter.py:172-175)
-        for (int i = tid; i < N; i += KT) {
-            const double pi = S.p[i], mi = S.m[i];
-            const double beta = (P.p0 + 0.5 * (mi * mi + S.tr2[i])) / pi - (P.alpha - 1.0 + 0.5 * 1.0);
-            S.rhs[i] = beta + log(pi);
-            S.pold[i] = pi;
+        for (int i = tid; i < NP; i += KT) {
+            if (i < N) {
+                const double pi = S.p[i], mi = S.m[i];
+                const double beta = (P.p0 + 0.5 * (mi * mi + S.tr2[i])) / pi - (P.alpha - 1.0 + 0.5 * 1.0);
+                S.rhs[i] = beta + log(pi);
+                S.pold[i] = pi;
+            } else {
+                S.rhs[i] = 0.0;  // padding rows of the banded system
+            }
         }
         __syncthreads();
-        if (tid == 0) {  // banded LU solve with the host-prepared factors (staged in LDS once per fit); the recurrence
-                         // lives in registers and the operands of 8 steps are fetched together, so that a step costs its
-                         // two dependent fmas (and the division on the way back), not an LDS round trip
-            const double *f1 = S.band, *f2 = f1 + N, *d0 = f2 + N, *u1 = d0 + N, *u2 = u1 + N;
-            double x1 = S.rhs[0], x2 = 0.0;  // x_{i-1}, x_{i-2}
-            for (int i0 = 1; i0 < N; i0 += 8) {
-                double r[8], a1[8], a2[8];
+        OSTAMP(14);
+        if (tid == 0) {
+            // Banded LU solve with the host-prepared factors (staged in LDS once per fit, padded to NP with unit pivots and
+            // zero bands).  One thread, a chain of 2 N dependent steps: a step must cost its two dependent fmas (and the
+            // three-operation division on the way back) and little else -- 16-byte LDS accesses for the operands and the
+            // results of eight steps, no per-step predicate (the padding rows solve to 0), everything in registers.
+            // (per step it was ~200 cycles, 50 us per pass: 14 scalar-width LDS instructions and an exec-mask update)
+            const v2f64 *f1 = reinterpret_cast<const v2f64 *>(S.band), *f2 = f1 + NP / 2, *d0 = f2 + NP / 2, *u1 = d0 + NP / 2,
+                        *u2 = u1 + NP / 2, *rd0 = u2 + NP / 2;
+            v2f64 *rv = reinterpret_cast<v2f64 *>(S.rhs);
+            double x1 = 0.0, x2 = 0.0;  // x_{i-1}, x_{i-2}  (f1[0] = f2[0] = 0: x_0 = rhs_0 exactly)
+            for (int h = 0; h < NP / 2; h += 4) {
+                v2f64 r[4], a1[4], a2[4];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int i = min(i0 + k, N - 1);
-                    r[k] = S.rhs[i];
-                    a1[k] = f1[i];
-                    a2[k] = f2[i];
+                for (int k = 0; k < 4; ++k) {
+                    r[k] = rv[h + k];
+                    a1[k] = f1[h + k];
+                    a2[k] = f2[h + k];
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (i0 + k < N) {
-                        double xi = r[k];
-                        xi = fma(-a2[k], x2, xi);
-                        xi = fma(-a1[k], x1, xi);
-                        S.rhs[i0 + k] = xi;
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        double xi = r[k][e];
+                        xi = fma(-a2[k][e], x2, xi);
+                        xi = fma(-a1[k][e], x1, xi);
+                        r[k][e] = xi;
                         x2 = x1;
                         x1 = xi;
                     }
+                    rv[h + k] = r[k];
+                }
             }
             double y1 = 0.0, y2 = 0.0;  // x_{i+1}, x_{i+2}
-            for (int i0 = N - 1; i0 >= 0; i0 -= 8) {
-                double r[8], b1[8], b2[8], dd[8];
+            for (int h = NP / 2 - 4; h >= 0; h -= 4) {
+                v2f64 r[4], b1[4], b2[4], dd[4], rr[4];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int i = max(i0 - k, 0);
-                    r[k] = S.rhs[i];
-                    b1[k] = u1[i];
-                    b2[k] = u2[i];
-                    dd[k] = d0[i];
+                for (int k = 0; k < 4; ++k) {
+                    r[k] = rv[h + k];
+                    b1[k] = u1[h + k];
+                    b2[k] = u2[h + k];
+                    dd[k] = d0[h + k];
+                    rr[k] = rd0[h + k];
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (i0 - k >= 0) {
-                        double t = r[k];
-                        t = fma(-b1[k], y1, t);
-                        t = fma(-b2[k], y2, t);
-                        t = t / dd[k];
-                        S.rhs[i0 - k] = t;
+                for (int k = 3; k >= 0; --k) {
+#pragma unroll
+                    for (int e = 1; e >= 0; --e) {
+                        double t = r[k][e];
+                        t = fma(-b1[k][e], y1, t);
+                        t = fma(-b2[k][e], y2, t);
+                        t = div_rn(t, dd[k][e], rr[k][e]);  // (the division itself: ~12 dependent operations per step)
+                        r[k][e] = t;
                         y2 = y1;
                         y1 = t;
                     }
+                    rv[h + k] = r[k];
+                }
             }
         }
+        OSTAMP(15);
         __syncthreads();
         int badp = 0;
         for (int i = tid; i < N; i += KT) {
@@ -550,7 +621,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     }
 
     // outputs: mu = Y^-1 m, p, count, status
-    for (int r = tid >> 6; r < N; r += NW) {
+    for (int r = __builtin_amdgcn_readfirstlane(tid >> 6); r < N; r += NW) {
         const double *yr = P.Yinv + (size_t)r * N;
         double a = 0.0;
         for (int c = tid & 63; c < N; c += 64) a = fma(yr[c], S.m[c], a);
@@ -584,7 +655,7 @@ __global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int 
 }  // namespace
 
 size_t fh_k2_loop_smem_bytes(int NP) {
-    return sizeof(double) * (size_t)(NP * PS + 16 * PS + 7 * NP + 6 * NP + (NP / 16) * 256 + 5 * NP) + 4 * 192 + 32;
+    return sizeof(double) * (size_t)(NP * PS + 16 * PS + 7 * NP + 6 * NP + 6 * NP) + 16 * kMaxTiles + 32;
 }
 
 hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s) {

@@ -309,7 +309,7 @@ __device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, dou
         // Hessian at N = 300; this: ~40 us, which is what 2.2 MB cost one CU)
         constexpr int HB = 3;  // 64 * HB pairs per pass: one pass for N <= 384
         const int lane = tid & 63, N2 = N >> 1;
-        for (int b0 = tid >> 6; b0 < N; b0 += 2 * LNW) {
+        for (int b0 = __builtin_amdgcn_readfirstlane(tid >> 6); b0 < N; b0 += 2 * LNW) {
             for (int a0 = 0; a0 < N2; a0 += 64 * HB) {
                 v2f64 vm[2][HB], vs[2][HB];
 #pragma unroll
@@ -382,7 +382,7 @@ __device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, dou
 __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S, double *Cp, double *Xd = nullptr) {
     using namespace tilechol;
     const int N = P.N, NP = P.NP, nb = NP / 16, ld = NP;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
     const int cl = lane & 15, rg = lane >> 4;
     double *pan = S.pan;                 // NP x PS panel (the LU panel's space: N * LU_NB doubles)
     double *dli = pan + NP * PS, *dvec = dli + 16 * PS, *rdv = dvec + NP;  // inverse of the current diagonal tile; diag(L), 1 / diag(L)
@@ -437,7 +437,7 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
     __syncthreads();
     for (int k = 0; k < nb; ++k) {
         if (*flag) return false;
-        const int m = nb - k - 1, cnt = m * (m + 1) / 2;
+        const int m = nb - k - 1, cnt = __builtin_amdgcn_readfirstlane(m * (m + 1) / 2);
         // tile list of this step's trailing update, (I << 8) | J for k < J <= I (read after the next barrier)
         for (int e = tid; e < cnt; e += LT) {
             int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
@@ -636,7 +636,7 @@ __device__ __forceinline__ void lu_factor(LnS &S, int N, double *A) {
 // explicit block inverses (differences at round-off level).
 constexpr int LU_NB = 32;
 __device__ __forceinline__ void lu_factor_blocked(LnS &S, int N, double *A) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = lane & 15, rg = lane >> 4;
     double *pan = S.pan;
     double *linv = S.part;                               // two 16 x 16 inverse blocks, k-major: [blk][k][i]
@@ -1035,7 +1035,7 @@ __device__ __forceinline__ void wave_solve(const LnS &S, int N, const double *A,
 // split by column ranges over the 8 waves (partials through LDS); wave 0 then runs the substitution chain of the diagonal
 // block as wave_solve does.  wave_solve leaves seven waves idle for ~130 us per Newton step.  xs: LDS, N doubles.
 __device__ __forceinline__ void block_solve(LnS &S, int N, const double *A, const double *b, double sign, double *xs) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *part = S.part;  // LNW x 64 partial sums
     for (int jj = tid; jj < N; jj += LT) xs[jj] = sign * b[S.perm[jj]];
     __syncthreads();
@@ -1270,7 +1270,7 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
         // step is a matrix-vector product over all threads instead of a substitution chain in one wave.
         LTIC();
         if (!have_inv && reuse >= inv_after) {
-            for (int r = tid >> 6; r < N; r += LNW) {
+            for (int r = __builtin_amdgcn_readfirstlane(tid >> 6); r < N; r += LNW) {
                 double *xs = S.wsol + (tid >> 6) * N;
                 wave_solve(S, N, S.lu, nullptr, r, 1.0, xs);
                 for (int i = tid & 63; i < N; i += 64) P.Hinv[r * N + i] = xs[i];  // column r of hess^-1
@@ -1380,7 +1380,7 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
 // -- two strided 8-byte loads per multiply-add on one CU; this takes ~0.2 ms.)
 __device__ __forceinline__ void build_sinv(const LogNormalParams &P, const double *rk) {
     using namespace tilechol;
-    const int N = P.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = P.N, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
     const int cl = lane & 15, rg = lane >> 4;
     const int nbt = (N + 15) >> 4, G = (nbt + 1) >> 1, ngroups = G * (G + 1) / 2;
     const int ksteps = (N + 3) >> 2;
@@ -1458,7 +1458,7 @@ __device__ __forceinline__ void build_sinv(const LogNormalParams &P, const doubl
 __device__ __forceinline__ void tr2_solve(const LogNormalParams &P, LnS &S, const double *Xd, double *Wsc, double *tr2) {
     using namespace tilechol;
     const int N = P.N, NP = P.NP, nb = NP / 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
     const int cl = lane & 15, rg = lane >> 4;
     const double *dvec = S.pan + NP * PS + 16 * PS;  // diag(L), left in LDS by cholesky_as_lu
     const gdouble *lu = as_global(S.lu), *Y = as_global(P.Y), *X = as_global(Xd);
@@ -1574,7 +1574,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         P.result += 2 * f;
         P.stats += 17 * f;
     }
-    const int N = P.N, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int N = P.N, tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     LnS S;
     {
         double *b = smem;
@@ -1770,26 +1770,54 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         }
         __syncthreads();
         for (int i = tid; i < N; i += LT) S.pold[i] = S.p[i];
-        if (tid == 0) {  // (T + I) tau = beta + log p with the host-factorised bands
+        if (tid == 0) {  // (T + I) tau = beta + log p with the host-factorised bands: the recurrences live in registers, the
+                         // operands of 8 steps are fetched together (the bands are in L2: one round trip per batch, not per step)
             const double *f1 = P.band_lu, *f2 = f1 + N, *d0 = f2 + N, *u1 = d0 + N, *u2 = u1 + N;
             double x1 = S.rhs[0], x2 = 0.0;
-            for (int i = 1; i < N; ++i) {
-                double xi = S.rhs[i];
-                xi = fma(-f2[i], x2, xi);
-                xi = fma(-f1[i], x1, xi);
-                S.rhs[i] = xi;
-                x2 = x1;
-                x1 = xi;
+            for (int i0 = 1; i0 < N; i0 += 8) {
+                double r[8], a1[8], a2[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = min(i0 + k, N - 1);
+                    r[k] = S.rhs[i];
+                    a1[k] = f1[i];
+                    a2[k] = f2[i];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (i0 + k < N) {
+                        double xi = r[k];
+                        xi = fma(-a2[k], x2, xi);
+                        xi = fma(-a1[k], x1, xi);
+                        S.rhs[i0 + k] = xi;
+                        x2 = x1;
+                        x1 = xi;
+                    }
             }
             double y1 = 0.0, y2 = 0.0;
-            for (int i = N - 1; i >= 0; --i) {
-                double t = S.rhs[i];
-                t = fma(-u1[i], y1, t);
-                t = fma(-u2[i], y2, t);
-                t = t / d0[i];
-                S.rhs[i] = t;
-                y2 = y1;
-                y1 = t;
+            for (int i0 = N - 1; i0 >= 0; i0 -= 8) {
+                double r[8], b1[8], b2[8], dd[8], rr[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = max(i0 - k, 0);
+                    r[k] = S.rhs[i];
+                    b1[k] = u1[i];
+                    b2[k] = u2[i];
+                    dd[k] = d0[i];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) rr[k] = 1.0 / dd[k];  // (off the recurrence: eight independent divisions)
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (i0 - k >= 0) {
+                        double t = r[k];
+                        t = fma(-b1[k], y1, t);
+                        t = fma(-b2[k], y2, t);
+                        t = tilechol::div_rn(t, dd[k], rr[k]);
+                        S.rhs[i0 - k] = t;
+                        y2 = y1;
+                        y1 = t;
+                    }
             }
         }
         __syncthreads();

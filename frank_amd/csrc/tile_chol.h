@@ -9,6 +9,7 @@
 #include <utility>
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
 
 namespace tilechol {
 
@@ -123,6 +124,33 @@ __device__ __forceinline__ void store_factored_tile(const v4f64 &L, const v4f64 
 
 // Fragment loaders (v_mfma_f64_16x16x4_f64: lane = (cl = lane & 15, rg = lane >> 4), k-step s covers k = 4s + rg).
 // "Row form": element [k][cl] of a row-major tile -> 4 rows x 16 contiguous doubles per k-step (coalesced).
+// t / d from a precomputed rd = RN(1 / d): quotient estimate, exact remainder (fma), one correction -- three dependent
+// operations instead of the ~12 of the compiler's division (v_div_scale, v_rcp, two Newton steps, v_div_fmas, v_div_fixup).
+// The result is the correctly rounded quotient (Markstein) except for operands whose quotient falls within a hair of a
+// rounding boundary; serial recurrences (the pentadiagonal back-substitution) pay the division on every step.
+__device__ __forceinline__ double div_rn(double t, double d, double rd) {
+    const double q = t * rd;
+    const double r = __builtin_fma(-q, d, t);
+    return __builtin_fma(r, rd, q);
+}
+
+// uniform base + 32-bit byte offset: the global_load / global_store "saddr" form, one 32-bit add per address
+__device__ __forceinline__ double ld_off(const gdouble *base, unsigned byte_off) {
+    return *reinterpret_cast<const gdouble *>(reinterpret_cast<const __attribute__((address_space(1))) char *>(base) + byte_off);
+}
+__device__ __forceinline__ void st_off(gdouble *base, unsigned byte_off, double v) {
+    *reinterpret_cast<gdouble *>(reinterpret_cast<__attribute__((address_space(1))) char *>(base) + byte_off) = v;
+}
+
+// a pointer the compiler can keep in scalar registers (a select between two kernel arguments otherwise ends up in VGPRs and
+// every access pays a 64-bit vector add)
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+
 struct Frag {
     double v[4];
 };

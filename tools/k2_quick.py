@@ -4,7 +4,9 @@ from frank_amd import FrankFitter, FixedGeometry
 from frank_amd.mock import MOCK_GEOMETRY
 from frank_amd.constants import rad_to_arcsec
 import os
+only = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 for name,N in (('sweep_N50_2e4.npz',50),('fit_N100_1e5.npz',100),('fit_N300_1e6.npz',300)):
+    if only and N != only: continue
     g=np.load('/root/repo/tests/golden/'+name)
     kw={}
     if N==50: kw=dict(alpha=float(g['alpha_a']),weights_smooth=float(g['wsmooth_a']))
@@ -21,8 +23,9 @@ if "timing" in os.environ.get("FRANK_AMD_LIB", ""):
     from frank_amd import _lib
     out=(ctypes.c_longlong*16)()
     _lib.lib.fh_debug_loop_timing(FF._DHT.context(), out)
-    names=['pinv','diag factor','panel trsm','trailing','(unused)','inverse phase A','inverse phase B','m, tr2 reduce']
+    names=['pinv','diag factor','panel trsm','trailing','(unused)','lists (panel phase)','stage row loads','m, tr2 reduce']
     tot=sum(out[:8])
 
     print('wave0: update %.1f factor %.1f invert %.1f | worker wave1: trailing %.1f, inverse row %.1f us/iter'%tuple(v/2.1e3/(2*nit+4) for v in out[8:13]))
+    print('outer loop: solve_posterior %.1f, beta/convergence/exp %.1f, banded solve (thread 0) %.1f us/iter' % tuple(v/2.1e3/(2*nit+4) for v in out[13:16]))
     for n_,v in zip(names,out[:8]): print('%-14s %8.1f us/iter  %5.1f%%'%(n_, v/2.1e3/ (2*nit+4) , 100*v/tot))
