@@ -65,13 +65,13 @@ constexpr int NWK = K2_ALL_WORK ? NW - 1 : NW - NW / 4;
 constexpr int kMaxTiles = 210;  // tiles of the largest trailing triangle: NP / 16 - 1 = 20 block rows (NP <= 336)
 
 struct Smem {
-    double *pan;   // panel of the current block column: NP x PS doubles
+    double *pan;   // panels of the current and the next block column: 2 x NP x PS doubles
     double *dli;   // 16 x PS: its inverse (A operand of the MFMA panel solve)
     double *p, *pold, *m, *y, *tr2, *rhs, *b, *red;  // NP each (red: 6*NP scratch)
     double *band;  // 6 NP: LU factors of the pentadiagonal T + I (five bands) and the reciprocal pivots, staged once per fit
-    uint4 *rec;    // tile e = i (i + 1) / 2 + j of the trailing triangle (block (k+1+i, k+1+j) at step k), built once per launch:
-                   // x = byte offset of the tile relative to block (k+1, k+1) | bit 0: column k+1 (also stored as mirror) | bit 1:
-                   // diagonal tile; y, z = byte offsets of panel row blocks i, j; w = offset of the mirror tile | i
+    uint4 *rec;    // tile e = (i - 1) i / 2 + (j - 1), 1 <= j <= i, of the trailing triangle right of its first column (block
+                   // (k+1+i, k+1+j) at step k), built once per launch: x = byte offset of the tile relative to block (k+1, k+1) |
+                   // bit 1: diagonal tile; y, z = byte offsets of panel row blocks i, j; w = i
     int *flag;
 };
 
@@ -154,7 +154,11 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
 
     // 1/p (padding rows: 1) -- the diagonal of C = A + diag(1/p) is added when a tile is first read from A
     for (int i = tid; i < NP; i += KT) S.y[i] = i < N ? 1.0 / S.p[i] : 1.0;  // row N (b) and padding: 1
-    if (tid == 0) *S.flag = 0;
+    if (tid == 0) {
+        S.flag[0] = 0;  // not positive definite
+        S.flag[1] = S.flag[2] = 0;  // column counters of the inverse rows (even / odd steps)
+        S.flag[3] = 0;  // index of the last diagonal tile whose inverse is in LDS
+    }
     __syncthreads();
     const double *pinv = S.y;
     TSTAMP(0);
@@ -182,98 +186,93 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
     }
     __syncthreads();
     TSTAMP(1);
+    // Panel 0 from memory: D = L_00^-1 (C_I0)^T for I > 0; D -> block (0, I), D^T -> block (I, 0), D -> LDS panel 0.  The
+    // panels of the later steps are produced INSIDE the trailing update of the step before (below): one barrier per step.
+    {
+        Frag fa;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fa.v[q] = S.dli[cl * PS + 4 * q + rg];
+        constexpr int kPanelMax = 3;  // ceil((NP / 16 - 1) / NW) for NP <= 400
+        Frag fb[kPanelMax];
+#pragma unroll
+        for (int u = 0; u < kPanelMax; ++u) {
+            const int I = 1 + wave + u * NW;
+            if (I < nb) fb[u] = load_rows(as_global(P.A) + 16 * I, ld, cl, rg);
+        }
+#pragma unroll
+        for (int u = 0; u < kPanelMax; ++u) {
+            const int I = 1 + wave + u * NW;
+            if (I < nb) {
+                v4f64 d = {0.0, 0.0, 0.0, 0.0};
+                d = mfma4(fa, fb[u], d, false);
+                store_tile(as_global(C), ld, 0, I, d, cl, rg, true);
+                double *pr = S.pan + (size_t)((I - 1) * 16 + cl) * PS + rg;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
+            }
+        }
+    }
+    __syncthreads();
+    TSTAMP(2);
+    const gdouble *C_inv = as_global(uniform_ptr(C));
+    gdouble *W_inv = as_global(uniform_ptr(W));
+    gdouble *C_u = as_global(uniform_ptr(C));
+    double ident[4];  // B fragments of the 16 x 16 identity
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ident[q] = (4 * q + rg == cl) ? 1.0 : 0.0;
     for (int k = 0; k < nb; ++k) {
         if (*S.flag) return false;
         const double *src = (k == 0) ? P.A : C;
-        const int m = nb - k - 1, cnt = __builtin_amdgcn_readfirstlane(m * (m + 1) / 2);
-        TSTAMP(5);
-        // row k of the inverse is computed beside this step's trailing update (row k of L is final since the panels of
-        // steps < k); its columns are handed out from a counter, longest chain (J = 0) first
-        if (tid == 0) S.flag[1] = 0;
-        // look-ahead prefetch: wave 0 starts loading tile (k+1,k+1) now; it is complete when the panel is done
-        v4f64 la = {0.0, 0.0, 0.0, 0.0};
-        if (wave == 0 && cnt > 0) {
-            const double *c1 = src + (size_t)(16 * (k + 1) + rg) * ld + 16 * (k + 1) + cl;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) la[r] = c1[(size_t)(4 * r) * ld];
-        }
-        TSTAMP(6);
-        // panel: D = L_kk^-1 * (C_Ik)^T for I > k; D^T -> C (I,k), D -> C mirror (k,I), D^T -> LDS panel
-        {
-            Frag fa;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) fa.v[q] = S.dli[cl * PS + 4 * q + rg];
-            // a wave's (up to three) panel tiles: all loads first, then the products -- one L2 latency per step, not per tile
-            constexpr int kPanelMax = 3;  // ceil((NP / 16 - 1) / NW) for NP <= 400
-            Frag fb[kPanelMax];
-#pragma unroll
-            for (int u = 0; u < kPanelMax; ++u) {
-                const int I = k + 1 + wave + u * NW;
-                if (I < nb) fb[u] = load_rows(as_global(src) + (size_t)(16 * k) * ld + 16 * I, ld, cl, rg);
-            }
-#pragma unroll
-            for (int u = 0; u < kPanelMax; ++u) {
-                const int I = k + 1 + wave + u * NW;
-                if (I < nb) {
-                    v4f64 d = {0.0, 0.0, 0.0, 0.0};
-                    d = mfma4(fa, fb[u], d, false);
-                    store_tile(as_global(C), ld, k, I, d, cl, rg, true);
-                    double *pr = S.pan + (size_t)((I - k - 1) * 16 + cl) * PS + rg;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
-                }
-            }
-        }
-        __syncthreads();
-        TSTAMP(2);
-        // trailing update C_IJ = src_IJ - L_Ik L_Jk^T for k < J <= I; next tile's loads are in flight during the MFMAs
-        const gdouble *srcg = as_global(src);
-        gdouble *Cg = as_global(C);
-        auto load_tile = [&](int t) {
-            v4f64 a;
-            const gdouble *c1 = srcg + (size_t)(16 * (t >> 8) + rg) * ld + 16 * (t & 255) + cl;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = c1[(size_t)(4 * r) * ld];
-            return a;
-        };
-        auto update_tile = [&](int t, v4f64 a) {
-            const int I1 = t >> 8, J1 = t & 255;
-            if (k == 0 && I1 == J1) {  // first touch: add diag(1/p) on diagonal tiles
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (rg + 4 * r == cl) a[r] += pinv[16 * I1 + cl];
-            }
-            const double *pa1 = S.pan + (size_t)((I1 - k - 1) * 16 + cl) * PS + rg;
-            const double *pb1 = S.pan + (size_t)((J1 - k - 1) * 16 + cl) * PS + rg;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s], pb1[4 * s], a, 0, 0, 0);
-            return a;
-        };
-        // columns of row k of the inverse, pulled from the LDS counter (which wave computes a tile does not change its bits)
-        const gdouble *C_inv = as_global(uniform_ptr(C));
-        gdouble *W_inv = as_global(uniform_ptr(W));
-        auto inverse_columns = [&]() {
-            if (k < 1) return;
+        const gdouble *src_u = as_global(uniform_ptr(src));
+        const int m = nb - k - 1;
+        const int cntA = __builtin_amdgcn_readfirstlane(m * (m - 1) / 2);  // tiles with k + 1 < J <= I
+        const int ncol = __builtin_amdgcn_readfirstlane(max(m - 1, 0));     // tiles (I, k + 1), I > k + 1
+        double *pan_cur = S.pan + (size_t)(k & 1) * NP * PS, *pan_nxt = S.pan + (size_t)((k + 1) & 1) * NP * PS;
+        int *ctr_cur = S.flag + 1 + (k & 1);
+        if (tid == 0) S.flag[1 + ((k + 1) & 1)] = 0;  // column counter of the NEXT step's inverse row (nobody reads it now)
+        const unsigned base_k = (unsigned)(16 * (k + 1) * (ld + 1) * 8);
+        const unsigned lane_c = base_k + (unsigned)((rg * ld + cl) * 8), row4 = (unsigned)(4 * ld * 8);
+        const unsigned lane_p = (unsigned)((cl * PS + rg) * 8);
+        const char *pan_b = reinterpret_cast<const char *>(pan_cur);
+        // columns of row k of the inverse, pulled from an LDS counter, longest chain (J = 0) first (which wave computes a tile
+        // does not change its bits); row k of L is final since the panel of step k - 1
+        auto load_fw = [&]() {
             Frag fw;  // A operand W_kk: rows of its transpose
             const double *wd = WdT + (size_t)k * 256 + rg * 16 + cl;
 #pragma unroll
             for (int q = 0; q < 4; ++q) fw.v[q] = wd[64 * q];
-            for (;;) {
-                int J = 0;
-                if (lane == 0) J = atomicAdd(&S.flag[1], 1);
-                J = __builtin_amdgcn_readfirstlane(J);
-                if (J >= k) break;
-                inverse_tile(C_inv, fw, W_inv, cs_ptr(k, J), k, J, N, ld, cl, rg);
+            return fw;
+        };
+        auto inverse_one = [&](const Frag &fw) {
+            int J = 0;
+            if (lane == 0) J = atomicAdd(ctr_cur, 1);
+            J = __builtin_amdgcn_readfirstlane(J);
+            if (J >= k) return false;
+            inverse_tile(C_inv, fw, W_inv, cs_ptr(k, J), k, J, N, ld, cl, rg);
+            return true;
+        };
+        auto inverse_columns = [&]() {
+            if (k < 1) return;
+            const Frag fw = load_fw();
+            while (inverse_one(fw)) {
             }
         };
         if (wave == 0) {
-            if (cnt == 0) inverse_columns();  // last step: no look-ahead tile, wave 0 joins the last row of the inverse
-            if (cnt > 0) {  // tile (k+1, k+1): update, transpose through LDS to row-per-lane, factor, invert
+            if (m > 0) {  // look-ahead: tile (k+1, k+1) updated, factored and inverted while the other waves update the rest
 #ifdef FIT_LOOP_TIMING
                 long long f_last = clock64();
 #endif
-                const int t = ((k + 1) << 8) | (k + 1);
-                v4f64 a = update_tile(t, la), xi;
+                v4f64 a, xi;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = ld_off(src_u, lane_c + r * row4);
+                if (k == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (rg + 4 * r == cl) a[r] += pinv[16 + cl];
+                }
+                const double *pa1 = reinterpret_cast<const double *>(pan_b + lane_p);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s], pa1[4 * s], a, 0, 0, 0);
                 FSTAMP(8);
                 // factor and invert in the accumulator layout (DPP row broadcasts, no LDS round trip, no transposition)
                 const bool ok = chol_inv_tile_acc(a, xi, lane, aug_tile == k + 1 ? aug_c : -1);
@@ -282,35 +281,36 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 const size_t dblk = (size_t)(16 * (k + 1)) * ld + 16 * (k + 1);
                 store_factored_tile(a, xi, C + dblk, ld, S.dli, W + dblk, WdT + (size_t)(k + 1) * 256, cs_ptr(k + 1, k + 1),
                                     rows_valid(k + 1), lane);
+                // L_{k+1,k+1}^-1 is in LDS: the waves holding tiles of column k + 1 may now turn them into panel k + 1
+                __hip_atomic_store(&S.flag[3], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 FSTAMP(10);
-                inverse_columns();  // whatever is left of the row when the chain is done
             }
-        } else if (K2_ALL_WORK || (wave & 3) != 0) {
-            // worker waves; tiles 1.. of the list
-            const int widx = K2_ALL_WORK ? wave - 1 : wave - 1 - (wave >> 2);  // 0..NWK-1
+            inverse_columns();
+        } else {
+            const int widx = wave - 1;  // 0..NWK-1
 #ifdef FIT_LOOP_TIMING
             long long w_last = clock64();
 #endif
+            // ---- trailing update of the tiles right of column k + 1 ----
             // Per tile: 4 MFMAs (256 cycles of the matrix pipe) against, at first, ~90 other instructions, most of them 64-bit
             // address arithmetic.  Every address is now a uniform base + a 32-bit byte offset (one v_add per row), the offsets
             // of tile e relative to block (k+1, k+1) come from a table built once per launch (S.rec: the tiles of step k are
-            // the first cnt entries of ONE row-wise enumeration of the triangle), and THREE named register sets rotate through
-            // an unrolled trip: the loads of the tile after next are issued before the stores of the current one (vmcnt counts
-            // loads and stores in order -- a load issued behind a store would wait for the store's acknowledgement) without
-            // a register copy.  (2 x 2 groups of tiles with four interleaved MFMA chains were measured too: no faster --
-            // the phase is bound by the number of dependent round trips per step, not by MFMA issue.)
-            const unsigned base_k = (unsigned)(16 * (k + 1) * (ld + 1) * 8);
-            const unsigned lane_c = base_k + (unsigned)((rg * ld + cl) * 8), row4 = (unsigned)(4 * ld * 8);
-            const unsigned lane_m = base_k + (unsigned)((cl * ld + rg) * 8);
-            const unsigned lane_p = (unsigned)((cl * PS + rg) * 8);
-            const char *pan_b = reinterpret_cast<const char *>(S.pan);
-            const gdouble *src_u = as_global(uniform_ptr(src));
-            gdouble *C_u = as_global(uniform_ptr(C));
+            // the first cntA entries of ONE row-wise enumeration), and THREE named register sets rotate through an unrolled
+            // trip: the loads of the tile after next are issued before the stores of the current one (vmcnt counts loads and
+            // stores in order -- a load issued behind a store would wait for the store's acknowledgement) without a register
+            // copy.  (2 x 2 groups of tiles with four interleaved MFMA chains were measured too: no faster.)
             auto ldt = [&](const uint4 &t) {
                 v4f64 a;
                 const unsigned o = (t.x & ~127u) + lane_c;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a[r] = ld_off(src_u, o + r * row4);
+                return a;
+            };
+            auto upd = [&](unsigned pa, unsigned pb, v4f64 a) {
+                const double *pa1 = reinterpret_cast<const double *>(pan_b + pa + lane_p);
+                const double *pb1 = reinterpret_cast<const double *>(pan_b + pb + lane_p);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s], pb1[4 * s], a, 0, 0, 0);
                 return a;
             };
             auto fin = [&](const uint4 &t, v4f64 a) {
@@ -319,57 +319,103 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                     for (int r = 0; r < 4; ++r)
                         if (rg + 4 * r == cl) a[r] += pinv[16 * (1 + (t.w & 127u)) + cl];
                 }
-                const double *pa1 = reinterpret_cast<const double *>(pan_b + t.y + lane_p);
-                const double *pb1 = reinterpret_cast<const double *>(pan_b + t.z + lane_p);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s], pb1[4 * s], a, 0, 0, 0);
+                a = upd(t.y, t.z, a);
                 const unsigned o = (t.x & ~127u) + lane_c;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) st_off(C_u, o + r * row4, a[r]);
-                if (t.x & 1u) {  // column k + 1: also as the mirror block that feeds the next panel
-                    const unsigned m2 = (t.w & ~127u) + lane_m;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) st_off(C_u, m2 + 32 * r, a[r]);
-                }
             };
-            int e = 1 + widx;  // tiles 1.. of the enumeration, every NWK-th
-            if (e < cnt) {
+            int e = widx;  // every NWK-th tile of the enumeration
+            if (e < cntA) {
                 uint4 ta = S.rec[e], tb = ta, tc = ta;
                 v4f64 a = ldt(ta), b = a, c = a;
-                if (e + NWK < cnt) {
+                if (e + NWK < cntA) {
                     tb = S.rec[e + NWK];
                     b = ldt(tb);
                 }
                 for (;;) {
                     // sets in flight: a (current), b (next); c is free
-                    if (e + 2 * NWK < cnt) {
+                    if (e + 2 * NWK < cntA) {
                         tc = S.rec[e + 2 * NWK];
                         c = ldt(tc);
                     }
                     fin(ta, a);
-                    if (e + NWK >= cnt) break;
-                    if (e + 3 * NWK < cnt) {
+                    if (e + NWK >= cntA) break;
+                    if (e + 3 * NWK < cntA) {
                         ta = S.rec[e + 3 * NWK];
                         a = ldt(ta);
                     }
                     fin(tb, b);
-                    if (e + 2 * NWK >= cnt) break;
-                    if (e + 4 * NWK < cnt) {
+                    if (e + 2 * NWK >= cntA) break;
+                    if (e + 4 * NWK < cntA) {
                         tb = S.rec[e + 4 * NWK];
                         b = ldt(tb);
                     }
                     fin(tc, c);
-                    if (e + 3 * NWK >= cnt) break;
+                    if (e + 3 * NWK >= cntA) break;
                     e += 3 * NWK;
                 }
             }
             WSTAMP(11);
+            // ---- column k + 1: update, then the panel of step k + 1 straight from the registers ----
+            // (the round-robin deal of the tiles goes on where the enumeration above stopped)
+            int cfirst = widx - cntA % NWK;
+            if (cfirst < 0) cfirst += NWK;
+            if (cfirst < ncol) {
+                // L_{k+1,k+1}^-1 comes from wave 0's chain (~5 us into the step): inverse columns fill the wait
+                if (k >= 1) {
+                    const Frag fw = load_fw();
+                    int spins = 0;
+                    while (__hip_atomic_load(&S.flag[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) {
+                        if (!inverse_one(fw)) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > (1 << 22)) {  // (never observed; a stuck flag must not hang the device)
+                                if (lane == 0) *S.flag = 1;
+                                break;
+                            }
+                        }
+                    }
+                } else {
+                    int spins = 0;
+                    while (__hip_atomic_load(&S.flag[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1 << 22)) {
+                            if (lane == 0) *S.flag = 1;
+                            break;
+                        }
+                    }
+                }
+                Frag fx;  // L_{k+1,k+1}^-1: as A operand X, as B operand X^T
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[cl * PS + 4 * q + rg];
+                for (int c = cfirst; c < ncol; c += NWK) {
+                    const int i = c + 1;  // block row I = k + 1 + i
+                    const unsigned o = lane_c + (unsigned)(16 * i * ld * 8);
+                    v4f64 t;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] = ld_off(src_u, o + r * row4);
+                    t = upd((unsigned)(i * 16 * PS * 8), 0u, t);  // T = C_{I,k+1} - L_Ik L_{k+1,k}^T, rows of block I
+                    // its transpose in the accumulator layout (the registers of a tile are the A fragments of its transpose)
+                    v4f64 tt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tt = __builtin_amdgcn_mfma_f64_16x16x4f64(t[q], ident[q], tt, 0, 0, 0);
+                    Frag ft;  // as B operand: T^T; as A operand: T
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ft.v[q] = tt[q];
+                    const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
+                    const v4f64 d = mfma4(fx, ft, z4, false);   // D = X T^T = L_{I,k+1}^T  (what the panel from memory computes)
+                    const v4f64 dt = mfma4(ft, fx, z4, false);  // D^T = T X^T = L_{I,k+1}
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st_off(C_u, o + r * row4, dt[r]);  // block (I, k+1)
+                    const unsigned om = lane_c + (unsigned)(16 * i * 8);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st_off(C_u, om + r * row4, d[r]);  // mirror block (k+1, I)
+                    double *pr = pan_nxt + (size_t)((i - 1) * 16 + cl) * PS + rg;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
+                }
+            }
             inverse_columns();
             WSTAMP(12);
-        } else {
-            // the waves that share wave 0's SIMD sit the trailing update out (fp64 VALU and MFMA share the DP units and
-            // wave 0's serial chain is the critical path of a step); the inverse row they do take part in, last in line
-            inverse_columns();
         }
         __syncthreads();
         TSTAMP(3);
@@ -436,7 +482,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     const int tid = threadIdx.x;
     Smem S;
     S.pan = smem;
-    S.dli = S.pan + NP * PS;
+    S.dli = S.pan + 2 * NP * PS;
     S.p = S.dli + 16 * PS;
     S.pold = S.p + NP;
     S.m = S.pold + NP;
@@ -448,14 +494,14 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     S.band = S.red + 6 * NP;
     S.rec = reinterpret_cast<uint4 *>(S.band + 6 * NP);  // (16-byte aligned: every region before it is an even number of doubles)
     S.flag = reinterpret_cast<int *>(S.rec + kMaxTiles);  // [0] not positive definite, [1] column counter of the inverse row
-    for (int e = tid; e < kMaxTiles; e += KT) {
+    for (int e = tid; e < kMaxTiles; e += KT) {  // tile e = (i - 1) i / 2 + (j - 1), 1 <= j <= i
         int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while ((i + 1) * (i + 2) / 2 <= e) ++i;
         while (i * (i + 1) / 2 > e) --i;
-        const int j = e - i * (i + 1) / 2;
-        S.rec[e] = make_uint4((unsigned)((16 * i * NP + 16 * j) * 8) | ((j == 0 && i != 0) ? 1u : 0u) | (i == j ? 2u : 0u),
-                              (unsigned)(i * 16 * PS * 8), (unsigned)(j * 16 * PS * 8),
-                              (unsigned)((16 * j * NP + 16 * i) * 8) | (unsigned)i);
+        const int j = e - i * (i + 1) / 2 + 1;
+        ++i;
+        S.rec[e] = make_uint4((unsigned)((16 * i * NP + 16 * j) * 8) | (i == j ? 2u : 0u), (unsigned)(i * 16 * PS * 8),
+                              (unsigned)(j * 16 * PS * 8), (unsigned)i);
     }
     __shared__ int s_ctl[4];  // [0] stop, [1] status
 
@@ -655,7 +701,7 @@ __global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int 
 }  // namespace
 
 size_t fh_k2_loop_smem_bytes(int NP) {
-    return sizeof(double) * (size_t)(NP * PS + 16 * PS + 7 * NP + 6 * NP + 6 * NP) + 16 * kMaxTiles + 32;
+    return sizeof(double) * (size_t)(2 * NP * PS + 16 * PS + 7 * NP + 6 * NP + 6 * NP) + 16 * kMaxTiles + 32;
 }
 
 hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s) {
