@@ -35,6 +35,12 @@ using namespace tilechol;
 #define OSTAMP(slot) do { } while (0)
 #endif
 #ifdef FIT_LOOP_TIMING
+// per-wave time stamps of ONE pass behind timing[16] (tools/k2_quick.py prints the timeline of the steps)
+#define TRACE(slot) do { if (P.trace_on && lane == 0 && k < 20) P.timing[16 + (wave * 20 + k) * 6 + (slot)] = clock64(); } while (0)
+#else
+#define TRACE(slot) do { } while (0)
+#endif
+#ifdef FIT_LOOP_TIMING
 #define FSTAMP(slot) do { if (threadIdx.x == 0) { long long n2_ = clock64(); P.timing[slot] += n2_ - f_last; f_last = n2_; } } while (0)
 #else
 #define FSTAMP(slot) do { } while (0)
@@ -257,6 +263,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             while (inverse_one(fw)) {
             }
         };
+        TRACE(0);
         if (wave == 0) {
             if (m > 0) {  // look-ahead: tile (k+1, k+1) updated, factored and inverted while the other waves update the rest
 #ifdef FIT_LOOP_TIMING
@@ -284,8 +291,10 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 // L_{k+1,k+1}^-1 is in LDS: the waves holding tiles of column k + 1 may now turn them into panel k + 1
                 __hip_atomic_store(&S.flag[3], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 FSTAMP(10);
+                TRACE(5);
             }
             inverse_columns();
+            TRACE(4);
         } else {
             const int widx = wave - 1;  // 0..NWK-1
 #ifdef FIT_LOOP_TIMING
@@ -356,6 +365,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 }
             }
             WSTAMP(11);
+            TRACE(1);
             // ---- column k + 1: update, then the panel of step k + 1 straight from the registers ----
             // (the round-robin deal of the tiles goes on where the enumeration above stopped)
             int cfirst = widx - cntA % NWK;
@@ -384,6 +394,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                         }
                     }
                 }
+                TRACE(2);
                 Frag fx;  // L_{k+1,k+1}^-1: as A operand X, as B operand X^T
 #pragma unroll
                 for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[cl * PS + 4 * q + rg];
@@ -414,7 +425,9 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                     for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
                 }
             }
+            TRACE(3);
             inverse_columns();
+            TRACE(4);
             WSTAMP(12);
         }
         __syncthreads();
@@ -533,6 +546,9 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
 #endif
     for (;;) {
         OSTAMP(14);
+#ifdef FIT_LOOP_TIMING
+        P.trace_on = (count == 5);
+#endif
         if (!solve_posterior(P, S)) {
             status = FIT_STATUS_NOT_SPD;
             break;

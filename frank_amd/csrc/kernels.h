@@ -149,6 +149,7 @@ struct FitLoopParams {
     int *result;            // [0] count, [1] status
     double *diag_p, *diag_mu;
     long long *timing;      // debug builds (FIT_LOOP_TIMING): cycles per phase
+    int trace_on;           // debug builds: record per-wave time stamps of this pass behind timing[16]
     // batched launch (one workgroup per fit; A, bq, Yinv, q shared): per-fit alpha / p0, band_lu[f][5N], and the
     // work / output buffers strided by fit
     int batch;

@@ -29,3 +29,15 @@ if "timing" in os.environ.get("FRANK_AMD_LIB", ""):
     print('wave0: update %.1f factor %.1f invert %.1f | worker wave1: trailing %.1f, inverse row %.1f us/iter'%tuple(v/2.1e3/(2*nit+4) for v in out[8:13]))
     print('outer loop: solve_posterior %.1f, beta/convergence/exp %.1f, banded solve (thread 0) %.1f us/iter' % tuple(v/2.1e3/(2*nit+4) for v in out[13:16]))
     for n_,v in zip(names,out[:8]): print('%-14s %8.1f us/iter  %5.1f%%'%(n_, v/2.1e3/ (2*nit+4) , 100*v/tot))
+
+    tr=(ctypes.c_longlong*1024)()
+    _lib.lib.fh_debug_loop_trace(FF._DHT.context(), tr)
+    t=np.array(tr[:960],dtype=np.int64).reshape(8,20,6)
+    t0=t[:,:,0][t[:,:,0]>0].min()
+    us=lambda v: (v-t0)/2.4e3
+    print('step | start (w0) | w0: flag set, done | workers: trailing done (min..max), flag seen (max), column done (max), all done (max)')
+    for k in range(19):
+        w=t[1:,k,:]
+        f=lambda a: us(a[a>0]).max() if (a>0).any() else float('nan')
+        g=lambda a: us(a[a>0]).min() if (a>0).any() else float('nan')
+        print('%2d  %7.2f | %7.2f %7.2f | %7.2f..%7.2f  %7.2f  %7.2f  %7.2f' % (k, us(t[0,k,0]), us(t[0,k,5]) if t[0,k,5]>0 else float('nan'), us(t[0,k,4]), g(w[:,1]), f(w[:,1]), f(w[:,2]), f(w[:,3]), f(w[:,4])))
