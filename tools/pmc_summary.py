@@ -84,7 +84,8 @@ def main():
                    "dispatch; hbm_bytes_per_launch = 2 x FETCH_SIZE KB + WRITE_SIZE KB (gfx950 FETCH_SIZE correction)")
     with open(out_path, "w") as fh:
         json.dump(res, fh, indent=1)
-    print("wrote", out_path, "kernels:", ", ".join(k for k in res if not k.startswith("_")))
+    names = [k for k in res if not k.startswith("_")]
+    print("wrote", out_path, len(names), "kernels:", ", ".join(k for k in names if len(k) < 60)[:600])
 
 
 if __name__ == "__main__":
