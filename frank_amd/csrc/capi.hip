@@ -1810,6 +1810,10 @@ static int ln_prepare(fh_ctx *c, const double *M, const double *j, LogNormalPara
     P.N = N;
     P.NP = ln_np(N);
     P.fresh_products = c->ln_fresh_products ? 1 : 0;
+    {
+        const char *e = getenv("FRANK_AMD_LN_PIVOTED");
+        P.no_cholesky = (e && e[0] == '1') ? 1 : 0;
+    }
     P.max_step = 100000;  // minimizer.py:190
     P.max_hev = 1000;
     P.newton_tol = 1e-7;  // statistical_models.py:1141

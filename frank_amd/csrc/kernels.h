@@ -187,6 +187,8 @@ struct LogNormalParams {
                                   // [N*N] factors, [NP*NP] the padded copy of the Hessian that the tiled Cholesky factors in
                                   // place, [NP*NP] the solved tiles of the Tr2 triangular solve, [16*NP] inverses of the
                                   // diagonal tiles
+    int no_cholesky;              // 1: skip the tiled Cholesky attempts, always the pivoted LU (FRANK_AMD_LN_PIVOTED=1: the route a
+                                  // non-positive pivot takes, kept testable)
     int fresh_products;           // 1: every trial point of the line search gets its own S^-1 x product, as the reference's
                                   // H(x) evaluates it (statistical_models.py:1075-1085); 0: S^-1 (x + lam p) by linearity
     double *Hinv;                 // N*N work: explicit inverse of a Hessian that keeps being re-used

@@ -1248,8 +1248,8 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
             if (nhess == P.max_hev) return {3, nstep, nfev, nhess};
             double *Cp = S.lu_nb > 0 ? P.LU + N * N : nullptr;
             if (S.lu_nb > 0) {
-                build_hess(P, S, Cp, P.NP, false);
-                if (!cholesky_as_lu(P, S, Cp)) {  // not positive definite: the attempt has written into S.lu
+                if (!P.no_cholesky) build_hess(P, S, Cp, P.NP, false);
+                if (P.no_cholesky || !cholesky_as_lu(P, S, Cp)) {  // not positive definite: the attempt has written into S.lu
 #ifdef LN_TIMING
                     if (tid == 0) ln_cyc[6] += 1;
 #endif
@@ -1709,7 +1709,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         //  each factorisation wants)
         bool chol = false;
         double *const Cp = P.LU + N * N, *const Wsc = Cp + P.NP * P.NP, *const Xd = Wsc + P.NP * P.NP;
-        if (S.lu_nb > 0) {
+        if (S.lu_nb > 0 && !P.no_cholesky) {
             if (P.mode != LN_MODE_UPDATE) {
                 build_hess(P, S, Cp, P.NP, false);
             } else {
