@@ -23,6 +23,15 @@
 //                          32 B per sorted row: tau, sqrt(w), sqrt(w) Re V', -
 //   bin_gram2_kernel       per 16-row chunk: generate the chunk's tiles (each wave 2-3 column blocks) into the other
 //                          LDS buffer while the Gram MFMAs of the current chunk run; one barrier per chunk.
+//   bucket_compress        (v3) the rows of a bucket enter the Gram only through 12 x 12 moments: with P_i = sqrt(w_i) [1, tau_i,
+//                          .., tau_i^11], sum_i X_i^T X_i = C_b^T (sum_i P_i^T P_i) C_b = C_b^T H_b C_b, H_b[n][m] = sum_i w_i
+//                          tau_i^(n+m).  The data column rides along: the 13 x 13 matrix [[H, nu], [nu^T, eta]], nu_n = sum_i
+//                          w_i V_i tau_i^n, eta = sum_i w_i V_i^2, is the Gram matrix of (1, tau, .., tau^11, V) -- positive
+//                          semi-definite -- and its Cholesky factor R (R^T R = H_aug up to a backward error of a few ulp of
+//                          its entries, whatever its condition) gives 13 VIRTUAL rows per bucket that the Gram kernel
+//                          cannot tell from visibilities: row r has P = R[r][0..11] and the data column R[r][12].  One
+//                          16-row chunk per bucket instead of one per 16 visibilities: 1e7 visibilities in ~1.6e4
+//                          buckets are 39x fewer chunks.  Buckets of <= 16 rows keep their rows.
 //   N > 303                the triangle is cut into row-aligned PARTS of <= 192 tiles; a part's workgroups generate
 //                          only the column blocks its tiles touch (cheap now), so the fused path reaches N = 511.
 #include <hip/hip_runtime.h>
@@ -240,6 +249,152 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const double *s, co
     }
 }
 
+// ---- bucket compression (v3) ----------------------------------------------------------------------------------
+// cidx[b] = number of non-empty buckets before b; info[1] = their total.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void bucket_compact_kernel(const int *totals, int nb, int *cidx, int *info) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    const int b0 = t * per, b1 = min(nb, b0 + per);
+    int sum = 0;
+    for (int b = b0; b < b1; ++b) sum += totals[b] > 0;
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - sum;
+    for (int b = b0; b < b1; ++b) {
+        cidx[b] = run;
+        run += totals[b] > 0;
+    }
+    if (t == 1023) info[1] = part[1023];
+}
+
+constexpr int kMom = 2 * kTerms - 1;  // moments 0 .. 22 of tau
+constexpr int kMomAll = kMom + kTerms + 1;  // + nu_0 .. nu_11 + eta
+// Partial moments: wave (b, part) sums the rows of the part-th slice of bucket b (slices of whole 16-row chunks; fixed
+// order: lane l takes rows l, l + 64, .. of the slice, then a butterfly across the lanes) into partial[b][part][36].
+// The buckets are very unequal (a (u, v) distribution piles up at short baselines): one wave per bucket took 10 ms.
+__global__ __launch_bounds__(256) void bucket_moments_kernel(const Row32 *rows, const int *starts, const int *totals, int nb,
+                                                             int parts, double *partial) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = wid / parts, part = wid - b * parts;
+    if (b >= nb) return;
+    const int tot = totals[b];
+    if (tot <= 16) return;  // such a bucket keeps its rows (bucket_factor_kernel)
+    const int chunks = (tot + 15) >> 4, per = (chunks + parts - 1) / parts;
+    const int r0 = min(tot, part * per * 16), r1 = min(tot, (part + 1) * per * 16);
+    const Row32 *rb = rows + starts[b];
+    double mu[kMom], nu[kTerms], eta = 0.0;
+#pragma unroll
+    for (int m = 0; m < kMom; ++m) mu[m] = 0.0;
+#pragma unroll
+    for (int n = 0; n < kTerms; ++n) nu[n] = 0.0;
+    for (int i = r0 + lane; i < r1; i += 64) {
+        const Row32 r = rb[i];
+        const double w = r.sw * r.sw, wv = r.sw * r.swV;
+        double pw = 1.0;
+#pragma unroll
+        for (int m = 0; m < kMom; ++m) {
+            mu[m] = fma(w, pw, mu[m]);
+            if (m < kTerms) nu[m] = fma(wv, pw, nu[m]);
+            pw *= r.tau;
+        }
+        eta = fma(r.swV, r.swV, eta);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int m = 0; m < kMom; ++m) mu[m] += __shfl_xor(mu[m], off);
+#pragma unroll
+        for (int n = 0; n < kTerms; ++n) nu[n] += __shfl_xor(nu[n], off);
+        eta += __shfl_xor(eta, off);
+    }
+    if (lane == 0) {
+        double *o = partial + ((size_t)b * parts + part) * kMomAll;
+#pragma unroll
+        for (int m = 0; m < kMom; ++m) o[m] = mu[m];
+#pragma unroll
+        for (int n = 0; n < kTerms; ++n) o[kMom + n] = nu[n];
+        o[kMom + kTerms] = eta;
+    }
+}
+
+// One wave per bucket.  <= 16 rows: the P rows of the visibilities themselves.  More: the partial moments are added in the
+// order of the parts, then the Cholesky factor of the augmented moment matrix with lane c holding column c (right-looking,
+// 13 steps of one broadcast, one square root and <= 12 fmas per lane).  A pivot that is not positive beyond the round-off
+// of its own formation ends the factorisation of that row: its contribution is below that round-off (for a positive
+// semi-definite matrix the rest of the row is bounded by the pivot).
+__global__ __launch_bounds__(256) void bucket_factor_kernel(const Row32 *rows, const int *starts, const int *totals,
+                                                            const int *cidx, int nb, int parts, const double *partial,
+                                                            double *vrows, int *vbucket) {
+    __shared__ double mom[4][kMomAll];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= nb) return;
+    const int tot = totals[b];
+    if (tot == 0) return;
+    const int c = cidx[b];
+    if (lane == 0) vbucket[c] = b;
+    double *out = vrows + (size_t)c * 256;
+    if (tot <= 16) {
+        if (lane < 16) {
+            const Row32 r = rows[starts[b] + lane];  // (rows past the bucket's last one are zero rows)
+            double pw = r.sw;
+#pragma unroll
+            for (int n = 0; n < kTerms; ++n) {
+                out[lane * 16 + n] = pw;
+                pw *= r.tau;
+            }
+            out[lane * 16 + 12] = r.swV;
+            out[lane * 16 + 13] = out[lane * 16 + 14] = out[lane * 16 + 15] = 0.0;
+        }
+        return;
+    }
+    if (lane < kMomAll) {
+        const double *pp = partial + (size_t)b * parts * kMomAll + lane;
+        double v = 0.0;
+        for (int k = 0; k < parts; ++k) v += pp[(size_t)k * kMomAll];
+        mom[wave][lane] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // column cc of the augmented matrix: H_aug[i][cc], i = 0 .. 12
+    constexpr int NA = kTerms + 1;
+    const int cc = lane < NA ? lane : NA - 1;
+    double col[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int idx = (cc < kTerms) ? (i < kTerms ? i + cc : kMom + cc) : (i < kTerms ? kMom + i : kMom + kTerms);
+        col[i] = mom[wave][idx];
+    }
+#pragma unroll
+    for (int r = 0; r < NA; ++r) {
+        const double h0 = mom[wave][r < kTerms ? 2 * r : kMom + kTerms];  // the diagonal entry before any update
+        const double piv = __shfl(col[r], r);
+        const bool ok = piv > 1.5e-14 * h0;
+        const double inv = ok ? 1.0 / sqrt(piv) : 0.0;
+        const double Rrc = (cc >= r) ? col[r] * inv : 0.0;
+        if (lane < NA) out[r * 16 + lane] = Rrc;
+#pragma unroll
+        for (int i = r + 1; i < NA; ++i) {
+            const double Rri = __shfl(Rrc, i);
+            col[i] = fma(-Rri, Rrc, col[i]);
+        }
+    }
+    // columns 13 .. 15 of rows 0 .. 12, and rows 13 .. 15
+    for (int e = lane; e < 256; e += 64) {
+        const int r = e >> 4, c2 = e & 15;
+        if (r >= NA || c2 >= NA) out[e] = 0.0;
+    }
+}
+
 // ---- K1b v2 ---------------------------------------------------------------------------------------------------
 // Element type T of the design block and the Gram MFMAs.
 //   double  v_mfma_f64_16x16x4_f64, 64 cycles per SIMD; the result stays in registers for the whole stream.
@@ -289,7 +444,7 @@ __device__ __forceinline__ void load_frags(T (&f)[NBT], const T *xb, std::intege
 
 // DEB: vis_model = 'debris' (statistical_models.py:494-496): every generated entry is further scaled by
 // exp(-kz_i^2 H2[k]) (kz^2 travels in the fourth slot of the sorted row, H2 sits in LDS, zero beyond column N - 1)
-template <typename T, int NBT, int P, int W, bool DEB>
+template <typename T, int NBT, int P, int W, bool DEB, bool VR>
 __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int part_block, int part_nblocks) {
     typedef typename Mx<T>::v4 v4;
     constexpr bool kF32 = sizeof(T) == 4;
@@ -344,8 +499,13 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
         double tau, sw, swV, k2;
     };
     auto load_row = [&](int chunk) -> RowRegs {
-        const double *rp = p.rows + ((size_t)chunk * kRows + ii) * 4;
-        return RowRegs{rp[0], rp[1], rp[2], DEB ? rp[3] : 0.0};
+        if constexpr (VR) {  // compressed rows: the A operands themselves (tau, sw, k2 carry k-steps 0, 1, 2) and the data column
+            const double *rp = p.rows + ((size_t)chunk * kRows + ii) * 16;
+            return RowRegs{rp[kk], rp[4 + kk], rp[12], rp[8 + kk]};
+        } else {
+            const double *rp = p.rows + ((size_t)chunk * kRows + ii) * 4;
+            return RowRegs{rp[0], rp[1], rp[2], DEB ? rp[3] : 0.0};
+        }
     };
     if constexpr (DEB) {
         for (int c = threadIdx.x; c < NBT * 16; c += kThreads) H2s[c] = c < p.N ? p.H2[c] : 0.0;
@@ -391,6 +551,12 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
         for (int reg = 0; reg < 4; ++reg) xw[reg * 4 * XS] = d[reg];
     };
     auto powers = [&](const RowRegs &r, T &a0, T &a1, T &a2) {
+        if constexpr (VR) {
+            a0 = (T)r.tau;
+            a1 = (T)r.sw;
+            a2 = (T)r.k2;
+            return;
+        }
         const double t2 = r.tau * r.tau;
         const double pk = kk == 0 ? 1.0 : (kk == 1 ? r.tau : (kk == 2 ? t2 : t2 * r.tau));
         const double t4 = t2 * t2;
@@ -409,6 +575,7 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
 
     // ---- work hand-out: contiguous chunk ranges (static, bitwise reproducible) or runs from an atomic counter ----
     int *counter = p.work_counter ? p.work_counter + P : nullptr;
+    constexpr int run = VR ? 4 : kRun;  // (compressed: ~1.6e4 chunks in all)
     int c0, c1;
     if (!counter) {
         const int per = (nchunks + part_nblocks - 1) / part_nblocks;
@@ -417,8 +584,8 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
     } else {
         if (tid == 0) sq[0] = atomicAdd(counter, 1);
         __syncthreads();
-        c0 = sq[0] * kRun;
-        c1 = min(nchunks, c0 + kRun);
+        c0 = sq[0] * run;
+        c1 = min(nchunks, c0 + run);
     }
     int qslot = 0;
     int cur_bucket = -1;
@@ -496,8 +663,8 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
             if constexpr (kDB) xbuf ^= 1;
         }
         if (!counter) break;
-        c0 = sq[qslot ^ 1] * kRun;
-        c1 = min(nchunks, c0 + kRun);
+        c0 = sq[qslot ^ 1] * run;
+        c1 = min(nchunks, c0 + run);
         qslot ^= 1;
     }
 
@@ -514,31 +681,31 @@ __device__ __forceinline__ void wave_main(const Bin2Params &p, double *smem, int
     }
 }
 
-template <typename T, int NBT, int P, bool DEB>
+template <typename T, int NBT, int P, bool DEB, bool VR>
 __device__ __forceinline__ void part_main(const Bin2Params &p, double *smem, int part_block, int part_nblocks) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch (wave) {
-        case 0: wave_main<T, NBT, P, 0, DEB>(p, smem, part_block, part_nblocks); break;
-        case 1: wave_main<T, NBT, P, 1, DEB>(p, smem, part_block, part_nblocks); break;
-        case 2: wave_main<T, NBT, P, 2, DEB>(p, smem, part_block, part_nblocks); break;
-        case 3: wave_main<T, NBT, P, 3, DEB>(p, smem, part_block, part_nblocks); break;
-        case 4: wave_main<T, NBT, P, 4, DEB>(p, smem, part_block, part_nblocks); break;
-        case 5: wave_main<T, NBT, P, 5, DEB>(p, smem, part_block, part_nblocks); break;
-        case 6: wave_main<T, NBT, P, 6, DEB>(p, smem, part_block, part_nblocks); break;
-        default: wave_main<T, NBT, P, 7, DEB>(p, smem, part_block, part_nblocks); break;
+        case 0: wave_main<T, NBT, P, 0, DEB, VR>(p, smem, part_block, part_nblocks); break;
+        case 1: wave_main<T, NBT, P, 1, DEB, VR>(p, smem, part_block, part_nblocks); break;
+        case 2: wave_main<T, NBT, P, 2, DEB, VR>(p, smem, part_block, part_nblocks); break;
+        case 3: wave_main<T, NBT, P, 3, DEB, VR>(p, smem, part_block, part_nblocks); break;
+        case 4: wave_main<T, NBT, P, 4, DEB, VR>(p, smem, part_block, part_nblocks); break;
+        case 5: wave_main<T, NBT, P, 5, DEB, VR>(p, smem, part_block, part_nblocks); break;
+        case 6: wave_main<T, NBT, P, 6, DEB, VR>(p, smem, part_block, part_nblocks); break;
+        default: wave_main<T, NBT, P, 7, DEB, VR>(p, smem, part_block, part_nblocks); break;
     }
 }
 
-template <typename T, int NBT, bool DEB>
+template <typename T, int NBT, bool DEB, bool VR = false>
 __global__ __launch_bounds__(kThreads, 2) void bin_gram2_kernel(Bin2Params p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     if (nparts(NBT) == 1 || b < p.part_blocks[0]) {
-        part_main<T, NBT, 0, DEB>(p, smem, b, p.part_blocks[0]);
+        part_main<T, NBT, 0, DEB, VR>(p, smem, b, p.part_blocks[0]);
     } else if (nparts(NBT) == 2 || b < p.part_blocks[0] + p.part_blocks[1]) {
-        part_main<T, NBT, nparts(NBT) >= 2 ? 1 : 0, DEB>(p, smem, b - p.part_blocks[0], p.part_blocks[1]);
+        part_main<T, NBT, nparts(NBT) >= 2 ? 1 : 0, DEB, VR>(p, smem, b - p.part_blocks[0], p.part_blocks[1]);
     } else {
-        part_main<T, NBT, nparts(NBT) >= 3 ? 2 : 0, DEB>(p, smem, b - p.part_blocks[0] - p.part_blocks[1], p.part_blocks[2]);
+        part_main<T, NBT, nparts(NBT) >= 3 ? 2 : 0, DEB, VR>(p, smem, b - p.part_blocks[0] - p.part_blocks[1], p.part_blocks[2]);
     }
 }
 
@@ -548,14 +715,14 @@ constexpr size_t bin2_smem_bytes() {  // (+ 8-byte alignment slack and the debri
            8 + sizeof(double) * NBT * 16;
 }
 
-template <typename T, int NBT, bool DEB>
+template <typename T, int NBT, bool DEB, bool VR = false>
 hipError_t launch_bin2(const Bin2Params &p, hipStream_t stream) {
     constexpr size_t smem = bin2_smem_bytes<T, NBT>();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_gram2_kernel<T, NBT, DEB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_gram2_kernel<T, NBT, DEB, VR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
     const int grid = p.part_blocks[0] + p.part_blocks[1] + p.part_blocks[2];
-    hipLaunchKernelGGL((bin_gram2_kernel<T, NBT, DEB>), dim3(grid), dim3(kThreads), smem, stream, p);
+    hipLaunchKernelGGL((bin_gram2_kernel<T, NBT, DEB, VR>), dim3(grid), dim3(kThreads), smem, stream, p);
     return hipGetLastError();
 }
 
@@ -704,6 +871,17 @@ hipError_t fh_k1v2_launch_sort(const SortParams &sp, hipStream_t stream) {
     return hipGetLastError();
 }
 
+int fh_k1v2_moment_doubles() { return kMomAll; }
+hipError_t fh_k1v2_launch_compress(const CompressParams &cp, hipStream_t stream) {
+    hipLaunchKernelGGL(bucket_compact_kernel, dim3(1), dim3(1024), 0, stream, cp.totals, cp.nb, cp.cidx, cp.info);
+    const long long waves = (long long)cp.nb * cp.parts;
+    hipLaunchKernelGGL(bucket_moments_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream,
+                       reinterpret_cast<const Row32 *>(cp.rows), cp.starts, cp.totals, cp.nb, cp.parts, cp.partial);
+    hipLaunchKernelGGL(bucket_factor_kernel, dim3((cp.nb + 3) / 4), dim3(256), 0, stream, reinterpret_cast<const Row32 *>(cp.rows),
+                       cp.starts, cp.totals, cp.cidx, cp.nb, cp.parts, cp.partial, cp.vrows, cp.vbucket);
+    return hipGetLastError();
+}
+
 hipError_t fh_k1v2_launch_bin(int NBT, const Bin2Params &p, hipStream_t stream) {
     if (p.table32 && !p.H2) {  // single-precision design block and tile products, fp64 block accumulation
         hipError_t e = hipErrorInvalidValue;
@@ -732,6 +910,17 @@ hipError_t fh_k1v2_launch_bin(int NBT, const Bin2Params &p, hipStream_t stream) 
             case 19: return launch_bin2<double, 19, true>(p, stream);
             case 24: return launch_bin2<double, 24, true>(p, stream);
             case 32: return launch_bin2<double, 32, true>(p, stream);
+        }
+        return hipErrorInvalidValue;
+    }
+    if (p.virtual_rows) {
+        switch (NBT) {
+            case 4: return launch_bin2<double, 4, false, true>(p, stream);
+            case 8: return launch_bin2<double, 8, false, true>(p, stream);
+            case 13: return launch_bin2<double, 13, false, true>(p, stream);
+            case 19: return launch_bin2<double, 19, false, true>(p, stream);
+            case 24: return launch_bin2<double, 24, false, true>(p, stream);
+            case 32: return launch_bin2<double, 32, false, true>(p, stream);
         }
         return hipErrorInvalidValue;
     }

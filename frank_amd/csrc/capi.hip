@@ -155,6 +155,10 @@ struct fh_ctx {
     bool arith32 = false;
     bool ln_fresh_products = false;  // fh_ctx_set_lognormal_linesearch
     DevBuf<int> k1_hist, k1_totals, k1_starts, k1_info, k1_chunk_bucket;
+    DevBuf<double> k1_partial;      // partial moments of the bucket slices
+    DevBuf<double> k1_vrows;        // compressed rows (fh_k1v2_launch_compress): one 16 x 16 chunk per non-empty bucket
+    DevBuf<int> k1_cidx, k1_vbucket;
+    bool k1_moments = true;         // FRANK_AMD_K1=rows: bin the visibilities themselves (the v2 path, kept for cross-checks)
     std::vector<double> k1_scalars_host;
     hipEvent_t ev_pre0 = nullptr;
     float last_prepass_ms = 0.f;
@@ -315,6 +319,7 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     const char *k1env = getenv("FRANK_AMD_K1");
     const bool want_v1 = k1env && !strcmp(k1env, "v1"), want_wide = k1env && !strcmp(k1env, "wide");
     c->v2 = !want_v1 && !want_wide && fh_k1v2_nbt_for(N) != 0;
+    c->k1_moments = !(k1env && !strcmp(k1env, "rows"));  // FRANK_AMD_K1=rows: the v2 kernel on the visibilities themselves
     c->NBT = want_wide ? 0 : (c->v2 ? fh_k1v2_nbt_for(N) : fh_k1_nbt_for(N));
     HIP_TRY(hipEventCreate(&c->ev_pre0));
     if (c->NBT) {
@@ -803,6 +808,33 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count) {
     sp.chunk_bucket = c->k1_chunk_bucket.p;
     HIP_TRY(fh_k1v2_launch_sort(sp, c->stream));
 
+    // v3: the rows of a bucket enter the Gram through 12 x 12 moments (bin_gram2.hip); not for the debris model (its design
+    // block is not a product of a row factor and a column factor) and not in single precision
+    const bool moments = c->k1_moments && !c->debris && !c->arith32;
+    if (moments) {
+        if (c->k1_vrows.n < (size_t)nb * 256 && c->k1_vrows.alloc((size_t)nb * 256 + 4096) != hipSuccess)
+            return fail(FH_ERR_NOMEM, "hipMalloc (compressed rows) failed");
+        if (c->k1_cidx.n < (size_t)nb && c->k1_cidx.alloc((size_t)nb + 256) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc failed");
+        if (c->k1_vbucket.n < (size_t)nb && c->k1_vbucket.alloc((size_t)nb + 256) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc failed");
+        // slices per bucket: ~256 rows per wave on average, at most 64
+        int parts = (int)((count + (int64_t)nb * 256 - 1) / ((int64_t)nb * 256));
+        parts = parts < 1 ? 1 : (parts > 64 ? 64 : parts);
+        const size_t npart = (size_t)nb * parts * fh_k1v2_moment_doubles();
+        if (c->k1_partial.n < npart && c->k1_partial.alloc(npart + 4096) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc (moments) failed");
+        CompressParams cp{};
+        cp.parts = parts;
+        cp.partial = c->k1_partial.p;
+        cp.rows = c->k1_rows.p;
+        cp.starts = c->k1_starts.p;
+        cp.totals = c->k1_totals.p;
+        cp.nb = nb;
+        cp.cidx = c->k1_cidx.p;
+        cp.info = c->k1_info.p;
+        cp.vrows = c->k1_vrows.p;
+        cp.vbucket = c->k1_vbucket.p;
+        HIP_TRY(fh_k1v2_launch_compress(cp, c->stream));
+    }
+
     const int running = running_fit_loops(c);
     // throughput mode while fit_loop kernels hold CUs (a workgroup that starts late simply takes fewer runs); fits of a
     // pipeline are run-dependent in their last bits anyway; synchronous fits stay static = bitwise reproducible
@@ -815,6 +847,12 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count) {
     bp.table = c->k1_table.p;
     bp.table32 = c->arith32 ? c->k1_table32.p : nullptr;
     bp.H2 = c->debris ? c->debris_H2.p : nullptr;
+    if (moments) {
+        bp.virtual_rows = 1;
+        bp.rows = c->k1_vrows.p;
+        bp.chunk_bucket = c->k1_vbucket.p;
+        bp.info = c->k1_info.p + 1;
+    }
     bp.work_counter = dynamic ? c->work_counter.p : nullptr;
     if (dynamic) HIP_TRY(hipMemsetAsync(c->work_counter.p, 0, 4 * sizeof(int), c->stream));
     ReduceParams rp{};

@@ -64,6 +64,8 @@ struct Bin2Params {
     const float *table32;        // the same tables rounded to fp32; non-NULL selects the single-precision kernel
     const double *H2;            // debris model: H2[k] (N doubles); non-NULL selects the kernel that scales by exp(-kz^2 H2[k])
     int *work_counter;           // NULL = static contiguous ranges (bitwise reproducible); else one int per part
+    int virtual_rows;            // rows = the compressed rows of fh_k1v2_launch_compress: [chunk][16][16] doubles, P[0..11] and
+                                 // the data column at [12]; chunk_bucket = bucket of each compressed chunk, info[0] = their number
     int part_blocks[3];
     double *partials[3];         // per part: [part_blocks][part_ntiles][256]
 };
@@ -76,6 +78,20 @@ int fh_k1v2_part_ntiles(int NBT, int P);
 int fh_k1v2_part_block0(int NBT, int P);
 hipError_t fh_k1v2_launch_sort(const SortParams &sp, hipStream_t stream);
 hipError_t fh_k1v2_launch_bin(int NBT, const Bin2Params &p, hipStream_t stream);
+// Bucket compression (bin_gram2.hip): one 16-row chunk per non-empty bucket.
+struct CompressParams {
+    const double *rows;   // sorted rows (Row32), bucket starts aligned to 16 rows
+    const int *starts, *totals;
+    int nb;
+    int *cidx;            // [nb] index of the bucket among the non-empty ones
+    int *info;            // info[1] = number of non-empty buckets
+    double *vrows;        // [non-empty bucket][16][16]
+    int *vbucket;         // [non-empty bucket]
+    int parts;            // slices per bucket of the moment sums
+    double *partial;      // [nb][parts][fh_k1v2_moment_doubles()]
+};
+int fh_k1v2_moment_doubles();
+hipError_t fh_k1v2_launch_compress(const CompressParams &cp, hipStream_t stream);
 hipError_t fh_k1v2_launch_max(const double *q, int64_t n, double *out, hipStream_t stream);
 hipError_t fh_k1v2_launch_predict(const double *table, int XS, int N, int nb, const double *pref, const double *I, double scale,
                                   double *coef, const double *q, int64_t n, double inv_Q, double delta, double *V,
