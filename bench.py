@@ -44,7 +44,10 @@ RMAX_ARCSEC = 2.0
 HYPER = dict(alpha=1.05, p0=1e-15, wsmooth=1e-4, tol=1e-3, max_iter=2000)
 # roofline constants: MI355X fp64 matrix peak (AMD CDNA4 datasheet; the microarch guide lists no fp64 MFMA row)
 FP64_MFMA_PEAK_TFLOPS = 78.6
-K1_KERNEL_NAME = "bin_gram2_kernel<double, 19, false>"
+K2_KERNEL_NAME = "fit_loop_kernel"
+K1_KERNEL_NAME = "bin_gram2_kernel<double, 19, false, true>"  # the Gram kernel of the binning pass (on compressed rows)
+N_CU = 256
+HBM_PEAK_GBPS = 8000.0
 
 
 def parse():
@@ -105,6 +108,16 @@ class Fitter:
     def kernel_ms(self):
         ms = ctypes.c_float(0)
         self.L.check(self.L.lib.fh_bin_last_kernel_ms(self.ctx, ctypes.byref(ms)))
+        return ms.value
+
+    def prepass_ms(self):
+        ms = ctypes.c_float(0)
+        self.L.check(self.L.lib.fh_bin_last_prepass_ms(self.ctx, ctypes.byref(ms)))
+        return ms.value
+
+    def loop_kernel_ms(self):
+        ms = ctypes.c_float(0)
+        self.L.check(self.L.lib.fh_fit_last_kernel_ms(self.ctx, ctypes.byref(ms)))
         return ms.value
 
     def solve(self):
@@ -466,6 +479,8 @@ def main():
     t0 = time.perf_counter(); f.bin(); f.sync(); t_bin = time.perf_counter() - t0
     t0 = time.perf_counter(); f.solve(); f.sync(); t_solve = time.perf_counter() - t0
     kms_alone = f.kernel_ms()
+    pre_alone = f.prepass_ms()
+    loop_ms = f.loop_kernel_ms()
 
     sharded = None
     hung = False
@@ -491,18 +506,27 @@ def main():
         value = fits / elapsed
         kms = float(np.mean(kernel_ms))
         Nc = a.ncoll
-        flops_sym = a.nvis * (Nc * (Nc + 1) + 2 * Nc)       # SURVEY 8(d) symmetric-half figure (unique outputs)
-        flops_full = a.nvis * (2 * Nc * Nc + 2 * Nc)         # SURVEY 8(d) full figure
-        achieved = flops_sym / (kms * 1e-3) / 1e12
+        # -- the dominant kernel: fit_loop_kernel, ONE workgroup = one CU per fit.  Algorithmic flops of a pass (DESIGN.md
+        #    K2): Cholesky of the (N+1) x (N+1) augmented precision, n^3 / 3, + inverse of the triangular factor, n^3 / 3;
+        #    the kernel makes iterations + 2 passes (the two seed solves of radial_fitters.py:744-752)
+        n_aug = Nc + 1
+        flops_pass = 2.0 * n_aug ** 3 / 3.0
+        flops_fit = flops_pass * (nit + 2)
+        achieved = flops_fit / (loop_ms * 1e-3) / 1e12
+        peak_cu = FP64_MFMA_PEAK_TFLOPS / N_CU
         traffic, traffic_src = None, None
-        for prof in ("r02_pmc_hbm.json", "r01_pmc_hbm.json"):
-            try:  # HBM bytes of one bin_gram launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
-                with open(os.path.join(ROOT, "profiles", prof)) as fh:
-                    traffic = json.load(fh)["bin_gram_kernel"]["hbm_bytes_per_launch"] * (a.nvis / 1e7) if Nc == 300 else None
-                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)" % prof
-                break
-            except Exception:
-                traffic = None
+        try:  # HBM bytes of one fit_loop launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_fit_loop.json")) as fh:
+                traffic = json.load(fh)["fit_loop_kernel"]["hbm_bytes_per_launch"] if Nc == 300 else None
+            traffic_src = ("profiles/r02_pmc_fit_loop.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on one fit, FETCH "
+                           "doubled per the gfx950 note)")
+        except Exception:
+            traffic = None
+        # -- the binning pass (deproject .. sort .. moments .. Gram of the compressed rows), HBM-bound: 40 B per visibility
+        #    (u, v, Re V, Im V, w) over the time of the whole pass, by events
+        pass_ms = pre_alone + kms_alone
+        bin_GBps = 40.0 * a.nvis / (pass_ms * 1e-3) / 1e9
+        flops_sym = a.nvis * (Nc * (Nc + 1) + 2 * Nc)       # what binning the visibilities row by row costs
         out = {
             "metric": "FrankFitter solves/sec (N=%d, %.0e visibilities per fit, Normal, fp64, end-to-end)" % (Nc, a.nvis),
             "value": value, "unit": "fits/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -514,16 +538,24 @@ def main():
                        "iterations_to_converge": nit, "parallelism": "independent fits x%d" % world},
             "breakdown_ms": {"single_fit_latency": 1e3 * (t_bin + t_solve), "bin_gram_pass": 1e3 * t_bin,
                              "finalize_plus_iterate": 1e3 * t_solve, "us_per_iteration": 1e6 * t_solve / max(nit, 1),
-                             "bin_gram_kernel_alone": kms_alone,
+                             "binning_pass_by_events": pre_alone + kms_alone, "fit_loop_kernel": loop_ms,
                              "note": "steps are pipelined: fit i's iteration (one CU) overlaps fit i+1's binning; the "
                                      "timed region = steps x (binning + hand-over) + one drain of finalize_plus_iterate"},
-            "roofline": {"kernel": K1_KERNEL_NAME, "bound": "mfma", "achieved": achieved,
-                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kms,
-                         "kernel_ms_min_median_max": [round(float(x), 2) for x in (np.min(kernel_ms), np.median(kernel_ms), np.max(kernel_ms))],
-                         "algorithmic_flops_per_vis": Nc * (Nc + 1) + 2 * Nc,
-                         "achieved_full_gram_equiv": flops_full / (kms * 1e-3) / 1e12,
-                         "hbm_read_GBps": 40.0 * a.nvis / (kms * 1e-3) / 1e9},
+            "roofline": {"kernel": K2_KERNEL_NAME, "bound": "mfma", "achieved": achieved, "peak": peak_cu, "unit": "TFLOP/s",
+                         "frac": achieved / peak_cu, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel_ms": loop_ms, "passes": nit + 2, "algorithmic_flops_per_pass": flops_pass,
+                         "peak_note": "the kernel is one workgroup: peak = one CU's share (1/256) of the 78.6 TFLOP/s "
+                                      "fp64 matrix peak; a pipeline of fits keeps one CU per outstanding fit busy",
+                         "why_this_kernel": "96 % of the GPU time of the timed region (profiles/r02_kernel_stats.csv)"},
+            "roofline_binning": {"kernel": "binning pass: deproject, bucket sort (hist/scan/scatter), bucket moments + factor, "
+                                           + K1_KERNEL_NAME + ", reduce",
+                                 "bound": "hbm", "achieved": bin_GBps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": bin_GBps / HBM_PEAK_GBPS, "pass_ms": pass_ms, "gram_kernel_ms": kms_alone,
+                                 "algorithmic_bytes_per_vis": 40,
+                                 "row_by_row_equivalent_TFLOPs": flops_sym / (pass_ms * 1e-3) / 1e12,
+                                 "note": "the rows of a J0 bucket enter the Gram through 12 x 12 moments, so the pass is "
+                                         "memory-bound; row_by_row_equivalent is what binning every visibility on the "
+                                         "matrix pipe (the v2 kernel, 15.2 ms = 0.76 of the fp64 matrix peak) would need"},
         }
         if sharded is not None:
             out["sharded_fit"] = sharded

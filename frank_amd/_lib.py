@@ -60,6 +60,7 @@ SIGNATURES = {
     "fh_bin_visibilities": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), _vp, _i64, _i64]),
     "fh_bin_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "fh_bin_last_prepass_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    "fh_fit_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "fh_ctx_set_arithmetic": (ctypes.c_int, [_vp, ctypes.c_int]),
     "fh_ctx_set_reproducible": (ctypes.c_int, [_vp, ctypes.c_int]),
     "fh_ctx_set_lognormal_linesearch": (ctypes.c_int, [_vp, ctypes.c_int]),

@@ -161,6 +161,8 @@ struct fh_ctx {
     bool k1_moments = true;         // FRANK_AMD_K1=rows: bin the visibilities themselves (the v2 path, kept for cross-checks)
     std::vector<double> k1_scalars_host;
     hipEvent_t ev_pre0 = nullptr;
+    hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;  // around the fit_loop kernel of the last fh_fit_normal
+    bool loop_timed = false;
     float last_prepass_ms = 0.f;
     // N > 303: rows to memory + rocBLAS dsyrk; stats_sum then holds the dense (N+1)^2 Gram (upper triangle) + 2 scalars
     bool wide = false;
@@ -322,6 +324,8 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     c->k1_moments = !(k1env && !strcmp(k1env, "rows"));  // FRANK_AMD_K1=rows: the v2 kernel on the visibilities themselves
     c->NBT = want_wide ? 0 : (c->v2 ? fh_k1v2_nbt_for(N) : fh_k1_nbt_for(N));
     HIP_TRY(hipEventCreate(&c->ev_pre0));
+    HIP_TRY(hipEventCreate(&c->ev_loop0));
+    HIP_TRY(hipEventCreate(&c->ev_loop1));
     if (c->NBT) {
         const int G = c->num_cu > 0 ? c->num_cu : 256;
         if (c->v2) {
@@ -455,6 +459,8 @@ void fh_ctx_destroy(fh_ctx *c) {
     if (c->ev_bin0) (void)hipEventDestroy(c->ev_bin0);
     if (c->ev_bin1) (void)hipEventDestroy(c->ev_bin1);
     if (c->ev_pre0) (void)hipEventDestroy(c->ev_pre0);
+    if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);
+    if (c->ev_loop1) (void)hipEventDestroy(c->ev_loop1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1027,6 +1033,14 @@ int fh_bin_last_prepass_ms(fh_ctx *c, float *ms) {
     return FH_OK;
 }
 
+int fh_fit_last_kernel_ms(fh_ctx *c, float *ms) {
+    if (!c || !ms) return fail(FH_ERR_INVALID, "fh_fit_last_kernel_ms: NULL argument");
+    if (!c->loop_timed) return fail(FH_ERR_INVALID, "no fit_loop launch of fh_fit_normal recorded yet");
+    HIP_TRY(hipEventSynchronize(c->ev_loop1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev_loop0, c->ev_loop1));
+    return FH_OK;
+}
+
 int fh_ctx_set_arithmetic(fh_ctx *c, int fp32) {
     if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
     if (fp32 && !c->v2) return fail(FH_ERR_UNSUPPORTED, "single-precision binning exists for the fused kernel only (N <= 383)");
@@ -1499,7 +1513,10 @@ int fh_fit_normal(fh_ctx *c, const double *M, const double *j, double alpha, dou
     FitLoopParams P = make_loop_params(c, FIT_MODE_FULL, alpha, p0, tol, max_iter);
     P.diag_p = want_diag ? c->diag_p.p : nullptr;
     P.diag_mu = want_diag ? c->diag_mu.p : nullptr;
+    HIP_TRY(hipEventRecord(c->ev_loop0, c->stream));
     HIP_TRY(fh_k2_launch_loop(P, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_loop1, c->stream));
+    c->loop_timed = true;
     int result[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(result, c->loop_result.p, sizeof result, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(mu, c->mu_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));

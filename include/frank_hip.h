@@ -124,6 +124,8 @@ int fh_bin_last_kernel_ms(fh_ctx *ctx, float *ms);
 /* Time (ms) from the start of the deprojection pre-pass to the start of that bin_gram launch: deprojection, the host's
  * look at the baseline range (the _check_uv_range input, statistical_models.py:166-169) and the bucket sort.          */
 int fh_bin_last_prepass_ms(fh_ctx *ctx, float *ms);
+/* Duration of the fit_loop kernel of the last fh_fit_normal call, by HIP events on the context's stream (bench.py). */
+int fh_fit_last_kernel_ms(fh_ctx *ctx, float *ms);
 /* Arithmetic of bin_gram (BASELINE configs[2], "fp32").  fp32 != 0: the Bessel design block and the tile products of the
  * Gram run in single precision on the matrix pipe (v_mfma_f32_16x16x4_f32, twice the fp64 rate), with the argument of
  * J0 still reduced in fp64 (bucket centre + offset) and the single-precision accumulators added into fp64 sums every

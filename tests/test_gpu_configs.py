@@ -275,6 +275,65 @@ def test_generated_design_block_equals_vector_alu_j0(monkeypatch):
     assert abs(m1["null_likelihood"] - m2["null_likelihood"]) <= 1e-13 * abs(m2["null_likelihood"])
 
 
+@pytest.mark.parametrize("n", [3000, 1000000, 10000000])
+def test_moment_path_equals_row_path(monkeypatch, n):
+    """bin_gram v3 against v2: the rows of a J0 bucket entering the Gram through the Cholesky factor of their 13 x 13
+    moment matrix (13 virtual rows per bucket) must give the M, j, H0 of binning the visibilities themselves
+    (FRANK_AMD_K1=rows).  n = 3000: every bucket holds <= 16 rows (kept as they are); 1e6 / 1e7: ~500 / ~5000 rows per bucket
+    with the short baselines piled up; the 1e7 pass also runs the whole fit on both mappings."""
+    from frank_amd import DiscreteHankelTransform, FrankFitter, VisibilityMapping
+    u, v, V, w = mock_disc_visibilities(n, seed=0, noise_seed=50)
+    m3 = VisibilityMapping(DiscreteHankelTransform(RMAX, 300), geom(), verbose=False).map_visibilities(u, v, V, w)
+    monkeypatch.setenv("FRANK_AMD_K1", "rows")
+    m2 = VisibilityMapping(DiscreteHankelTransform(RMAX, 300), geom(), verbose=False).map_visibilities(u, v, V, w)
+    monkeypatch.delenv("FRANK_AMD_K1")
+    assert rel_to_max(m3["M"], m2["M"]) < 1e-13 and rel_to_max(m3["j"], m2["j"]) < 1e-13
+    assert abs(m3["null_likelihood"] - m2["null_likelihood"]) <= 1e-12 * abs(m2["null_likelihood"])
+    assert np.array_equal(m3["M"], m3["M"].T)
+    if n == 10000000:
+        sols = []
+        for m in (m3, m2):
+            FF = FrankFitter(2.0, 300, geom(), verbose=False, store_iteration_diagnostics=True)
+            FF._M, FF._j, FF._H0 = m["M"], m["j"], m["null_likelihood"]
+            sols.append((FF._fit(), FF.iteration_diagnostics["num_iterations"]))
+        assert sols[0][1] == sols[1][1]
+        assert rel_to_max(sols[0][0].I, sols[1][0].I) < 1e-9
+
+
+def test_moment_path_degenerate_buckets():
+    """Buckets whose moment matrix is singular: (i) every baseline has the same length (one bucket, one value of tau:
+    rank 1, plus the data column); (ii) two lengths in one bucket; (iii) a bucket of 17 rows -- the smallest that is
+    compressed -- among buckets that keep their rows.  The pivots that vanish end their rows of the factorisation; M, j
+    must still be those of the oracle."""
+    from frank_amd import DiscreteHankelTransform, VisibilityMapping
+    from oracle import oracle as fo
+    N = 100
+    rng = np.random.default_rng(12)
+    dht = DiscreteHankelTransform(RMAX, N)
+    face_on = dict(inc=0.0, PA=0.0, dRA=0.0, dDec=0.0)
+    from frank_amd import FixedGeometry
+    vm = VisibilityMapping(dht, FixedGeometry(**face_on), verbose=False)
+
+    def ring(q, k):
+        phi = rng.uniform(0, 2 * np.pi, k)
+        return q * np.cos(phi), q * np.sin(phi)
+    cases = []
+    u, v = ring(3.0e5, 400)
+    cases.append((u, v))
+    ua, va = ring(3.0e5, 300)
+    ub, vb = ring(3.0e5 * (1 + 2e-5), 300)
+    cases.append((np.concatenate([ua, ub]), np.concatenate([va, vb])))
+    parts = [ring(4.0e5, 17)] + [ring(q, 3) for q in np.linspace(5e4, 9e5, 40)]
+    cases.append((np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])))
+    for u, v in cases:
+        V = rng.normal(size=u.size) + 1j * rng.normal(size=u.size)
+        w = rng.uniform(0.5, 2.0, u.size)
+        m = vm.map_visibilities(u, v, V, w)
+        o = fo.map_visibilities(N, RMAX, (0.0, 0.0, 0.0, 0.0), u, v, V, w)
+        assert rel_to_max(m["M"], o["M"]) < 1e-12 and rel_to_max(m["j"], o["j"]) < 1e-12
+        assert abs(m["null_likelihood"] - o["null_likelihood"]) <= 1e-12 * abs(o["null_likelihood"])
+
+
 @pytest.mark.parametrize("N", [340, 400, 511])
 def test_fused_gram_beyond_N303_against_oracle(N):
     """The fused bin_gram covers N <= 511: the tile triangle is cut into two (N <= 383) or three row-aligned parts whose
