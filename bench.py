@@ -138,9 +138,9 @@ class Fitter:
         """bin_gram on the main stream, then hand the iteration to a fit slot (fit_loop kernel on its own stream)."""
         L = self.L
         self.bin()
-        H0, qmn, qmx = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-        L.check(L.lib.fh_stats_finalize(self.ctx, ctypes.byref(self.geom), 0, 1, None, None, ctypes.byref(H0),
-                                        ctypes.byref(qmn), ctypes.byref(qmx)))
+        # nothing is asked back from the finalisation (M, j stay on the device; the baseline range was checked by the
+        # synchronous fit of the warm-up): the call does not wait for the binning pass
+        L.check(L.lib.fh_stats_finalize(self.ctx, ctypes.byref(self.geom), 0, 0, None, None, None, None, None))
         h = HYPER
         t = ctypes.c_int(-1)
         L.check(L.lib.fh_fit_submit(self.ctx, h["alpha"], h["p0"], h["wsmooth"], h["tol"], h["max_iter"],

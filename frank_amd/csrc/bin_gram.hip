@@ -150,11 +150,12 @@ __global__ __launch_bounds__(256) void deproject_kernel(BinParams p) {
             Vim = p.Vim32 ? (double)p.Vim32[g] : 0.0;
             w = (double)p.w32[p.w_scalar ? 0 : g];
         } else {
-            u = p.u[g];
-            v = p.v[g];
-            Vre = p.Vre[g];
-            Vim = p.Vim ? p.Vim[g] : 0.0;
-            w = p.w[p.w_scalar ? 0 : g];
+            // (streamed once: non-temporal, so that the pass does not push the fit loops' working sets out of L2)
+            u = __builtin_nontemporal_load(&p.u[g]);
+            v = __builtin_nontemporal_load(&p.v[g]);
+            Vre = __builtin_nontemporal_load(&p.Vre[g]);
+            Vim = p.Vim ? __builtin_nontemporal_load(&p.Vim[g]) : 0.0;
+            w = p.w_scalar ? p.w[0] : __builtin_nontemporal_load(&p.w[g]);
         }
         // multiplicity of the row in a bootstrap resample (utilities.py:632-666): c copies of a row contribute
         // c w h h^T, c w V h, c (log(w/2pi) - w V^2); rows drawn zero times drop out of min/max q as well

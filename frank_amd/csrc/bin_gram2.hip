@@ -296,7 +296,11 @@ __global__ __launch_bounds__(256) void bucket_moments_kernel(const Row32 *rows, 
 #pragma unroll
     for (int n = 0; n < kTerms; ++n) nu[n] = 0.0;
     for (int i = r0 + lane; i < r1; i += 64) {
-        const Row32 r = rb[i];
+        const double *rp = reinterpret_cast<const double *>(rb + i);
+        Row32 r;
+        r.tau = __builtin_nontemporal_load(rp);
+        r.sw = __builtin_nontemporal_load(rp + 1);
+        r.swV = __builtin_nontemporal_load(rp + 2);
         const double w = r.sw * r.sw, wv = r.sw * r.swV;
         double pw = 1.0;
 #pragma unroll

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -89,7 +90,9 @@ struct DevBuf {
 
 }  // namespace
 
+static std::atomic<unsigned long long> g_vis_serial{1};
 struct fh_vis {
+    unsigned long long serial = g_vis_serial.fetch_add(1);  // identifies the table in the baseline-range cache of a context
     int device = 0;
     int64_t n = 0;
     int w_scalar = 0, has_im = 0;
@@ -158,6 +161,15 @@ struct fh_ctx {
     DevBuf<double> k1_partial;      // partial moments of the bucket slices
     DevBuf<double> k1_vrows;        // compressed rows (fh_k1v2_launch_compress): one 16 x 16 chunk per non-empty bucket
     DevBuf<int> k1_cidx, k1_vbucket;
+    // baseline range of the last pre-pass, keyed by (table, row range, geometry): binning the same rows under the same geometry
+    // again (bootstrap draws, pipelines of fits, sweeps) needs no second look at the range before the sort is sized
+    unsigned long long range_vis = 0;
+    int64_t range_first = -1, range_count = -1;
+    double range_geom[6] = {0, 0, 0, 0, 0, 0};
+    bool range_valid = false;
+    std::vector<double> a_host;      // finalize scale vector (stays alive behind an asynchronous copy)
+    bool a_scale_valid = false;
+    double a_scale_value = 0.0;
     bool k1_moments = true;         // FRANK_AMD_K1=rows: bin the visibilities themselves (the v2 path, kept for cross-checks)
     std::vector<double> k1_scalars_host;
     hipEvent_t ev_pre0 = nullptr;
@@ -751,7 +763,7 @@ static int running_fit_loops(fh_ctx *c) {
 // K1 v2: deproject -> (host: baseline range, bucket tables) -> bucket sort -> bin_gram2 -> slab reduction.
 // The one host round trip (64 KB of per-block scalars) is what _check_uv_range needs before any binning in the reference
 // too (statistical_models.py:166-169); it costs the stream ~20 us of idle time per call.
-static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count) {
+static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned long long vis_serial) {
     if (count > 0x7fffffff - 16 * 65536) return fail(FH_ERR_UNSUPPORTED, "more than 2^31 visibilities in one call: split it");
     int dblocks = (int)((count + 255) / 256);
     if (dblocks > c->deproject_blocks) dblocks = c->deproject_blocks;
@@ -759,19 +771,32 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count) {
     p.partial_scalars = c->partial_scalars.p;
     HIP_TRY(hipEventRecord(c->ev_pre0, c->stream));
     HIP_TRY(fh_k1_launch_deproject(p, dblocks, c->stream));
-    c->k1_scalars_host.resize((size_t)dblocks * 4);
-    HIP_TRY(hipMemcpyAsync(c->k1_scalars_host.data(), c->partial_scalars.p, sizeof(double) * (size_t)dblocks * 4,
-                           hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    const double gkey[6] = {p.dRA, p.dDec, p.cos_t, p.sin_t, p.cos_i, p.sin_i};
+    const bool known = c->range_valid && c->range_vis == vis_serial && c->range_first == p.first && c->range_count == count &&
+                       memcmp(gkey, c->range_geom, sizeof gkey) == 0 && !getenv("FRANK_AMD_NO_RANGE_CACHE");
     double qmax = 0.0, qmin = INFINITY;
-    for (int b = 0; b < dblocks; ++b) {
-        const double m = c->k1_scalars_host[(size_t)b * 4 + 2], mn = c->k1_scalars_host[(size_t)b * 4 + 1];
-        if (m > qmax) qmax = m;  // (-inf for blocks without rows; NaN baselines never win)
-        if (mn < qmin) qmin = mn;
+    if (known) {  // same rows, same geometry: the range is the one read back last time, no host round trip
+        qmin = c->prepass_qmin;
+        qmax = c->prepass_qmax;
+    } else {
+        c->k1_scalars_host.resize((size_t)dblocks * 4);
+        HIP_TRY(hipMemcpyAsync(c->k1_scalars_host.data(), c->partial_scalars.p, sizeof(double) * (size_t)dblocks * 4,
+                               hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int b = 0; b < dblocks; ++b) {
+            const double m = c->k1_scalars_host[(size_t)b * 4 + 2], mn = c->k1_scalars_host[(size_t)b * 4 + 1];
+            if (m > qmax) qmax = m;  // (-inf for blocks without rows; NaN baselines never win)
+            if (mn < qmin) qmin = mn;
+        }
     }
     if (!(qmax < INFINITY)) return fail(FH_ERR_INVALID, "non-finite baseline in the visibility table");
     c->prepass_qmin = qmin;
     c->prepass_qmax = qmax;
+    c->range_vis = vis_serial;
+    c->range_first = p.first;
+    c->range_count = count;
+    memcpy(c->range_geom, gkey, sizeof gkey);
+    c->range_valid = true;
     // statistical_models.py:166-169: the range check comes BEFORE the chunk loop -- nothing is binned for a table that fails it
     if (c->check_q_before_bin && c->dht->q[c->N - 1] < qmax)
         return fail(FH_ERR_QRANGE, "last collocation point %.3e < longest deprojected baseline %.3e", c->dht->q[c->N - 1], qmax);
@@ -966,7 +991,7 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
         c->have_device_Mj = false;
         return FH_OK;
     }
-    if (c->v2) return bin_visibilities_v2(c, p, count);
+    if (c->v2) return bin_visibilities_v2(c, p, count, vis->serial);
     // fit_loop kernels of earlier fits that are still RUNNING each hold a CU (a slot stays "busy" until it is collected,
     // long after its kernel has finished: counting those would leave CUs idle)
     int running = 0;
@@ -1080,13 +1105,23 @@ int fh_stats_finalize(fh_ctx *c, const fh_geometry *g, int vis_model, int check_
     // a_k = ((norm * sf_k)) * scale : hankel.py:201 and statistical_models.py:490,507
     const double scale = vis_model == FH_VIS_OPT_THICK ? cos(g->inc_deg * kDegToRad) : 1.0;
     const double norm = 1 / (M_PI * c->dht->Qmax * c->dht->Qmax);
-    std::vector<double> a(N);
-    for (int k = 0; k < N; ++k) a[k] = (norm * c->dht->scale_factor[k]) * scale;
-    HIP_TRY(hipMemcpyAsync(c->a_scale.p, a.data(), sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    if (!(c->a_scale_valid && c->a_scale_value == scale)) {  // (the vector on the device depends on `scale` only)
+        std::vector<double> &a = c->a_host;
+        HIP_TRY(hipStreamSynchronize(c->stream));  // an earlier asynchronous copy may still read the host vector
+        a.resize(N);
+        for (int k = 0; k < N; ++k) a[k] = (norm * c->dht->scale_factor[k]) * scale;
+        HIP_TRY(hipMemcpyAsync(c->a_scale.p, a.data(), sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+        c->a_scale_valid = true;
+        c->a_scale_value = scale;
+    }
     if (use_wide(c))
         HIP_TRY(fh_k1_launch_wide_finalize(dense_gram(c), N, c->a_scale.p, c->M.p, c->j.p, c->sumwV2.p, c->stream));
     else
         HIP_TRY(fh_k1_launch_finalize(c->stats_sum.p, c->NBT, N, c->a_scale.p, c->M.p, c->j.p, c->sumwV2.p, c->stream));
+    if (!M && !j && !H0 && !qmin && !qmax && !check_qbounds) {  // nothing asked for on the host: M, j stay on the device, no wait
+        c->have_device_Mj = true;
+        return FH_OK;
+    }
     double tail[2], mm[2], swv2;
     const double *tail_src = use_wide(c) ? dense_gram(c) + dense_tail(c) : c->stats_sum.p + c->tail_offset;
     HIP_TRY(hipMemcpyAsync(tail, tail_src, sizeof tail, hipMemcpyDeviceToHost, c->stream));

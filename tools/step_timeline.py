@@ -33,8 +33,7 @@ for i in range(steps):
     L.check(L.lib.fh_bin_reset(f.ctx))
     L.check(L.lib.fh_bin_visibilities(f.ctx, ctypes.byref(f.geom), f.vis, 0, f.nfit))
     t2 = time.perf_counter()
-    L.check(L.lib.fh_stats_finalize(f.ctx, ctypes.byref(f.geom), 0, 1, None, None, ctypes.byref(H0), ctypes.byref(qmn),
-                                    ctypes.byref(qmx)))
+    L.check(L.lib.fh_stats_finalize(f.ctx, ctypes.byref(f.geom), 0, 0, None, None, None, None, None))
     t3 = time.perf_counter()
     t = ctypes.c_int(-1)
     L.check(L.lib.fh_fit_submit(f.ctx, h["alpha"], h["p0"], h["wsmooth"], h["tol"], h["max_iter"], ctypes.byref(t)))
