@@ -112,10 +112,16 @@ int fh_vis_set_multiplicity(fh_vis *vis, const int32_t *counts);
  * phase-centre + deproject each visibility, q = hypot(u', v'), J0((q/Qmax) j_k) for all k, and accumulate the
  * Bessel Gram G = X^T diag(w) X, g = X^T diag(w) Re V', sum w V'^2, sum log w, min/max q on the device.
  *   fh_bin_reset      zero the context's sufficient statistics
- *   fh_bin_visibilities  add rows [first, first+count) of `vis` (asynchronous on the context's stream)
+ *   fh_bin_visibilities  add rows [first, first+count) of `vis`.  The pre-pass reads the baseline range back once (it
+ *                     sizes the bucket sort, and it is what _check_uv_range needs before any binning,
+ *                     statistical_models.py:166-169); binning the SAME rows of the SAME table under the SAME geometry again
+ *                     (bootstrap draws, pipelines, sweeps) re-uses that range and the call does not wait for the device
+ *                     (FRANK_AMD_NO_RANGE_CACHE=1 switches this off)
  *   fh_stats_device   device pointer / length (doubles) of the packed statistics, for an RCCL all-reduce
  *   fh_stats_finalize apply the DHT scaling, unpack to M (N*N), j (N), H0, qmin, qmax (host, any may be NULL);
- *                     the device copies of M and j stay in the context for fh_fit_normal(M = NULL).
+ *                     the device copies of M and j stay in the context for fh_fit_normal(M = NULL).  With every output
+ *                     NULL and check_qbounds == 0 the call only queues the finalisation and returns (pipelines:
+ *                     fh_fit_submit takes M, j on the device).
  *                     Returns FH_ERR_QRANGE iff check_qbounds and q_k[-1] < qmax (outputs are still written). */
 int fh_bin_reset(fh_ctx *ctx);
 int fh_bin_visibilities(fh_ctx *ctx, const fh_geometry *geom, const fh_vis *vis, int64_t first, int64_t count);
