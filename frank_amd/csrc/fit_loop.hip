@@ -94,15 +94,17 @@ struct Smem {
 // sat in front of the panel (their registers and the in-order vmcnt tied them to the spill reloads: ~1 us per step) and
 // took 39 KB of LDS.  `fw` is the A operand W_II (rows of its transpose).  All addresses: uniform base + 32-bit offset.
 __device__ __forceinline__ void inverse_tile(const gdouble *Cu, const Frag &fw, gdouble *Wu, double *cs_IJ, int I, int J,
-                                             int N, int ld, int cl, int rg) {
-    const unsigned row4 = (unsigned)(4 * ld * 8), blk = (unsigned)(16 * ld * 8);
-    unsigned oa = (unsigned)(((16 * J + rg) * ld + 16 * I + cl) * 8);  // fragment of block (K, I) of C, K = J
-    unsigned ob = (unsigned)(((16 * J + rg) * ld + 16 * J + cl) * 8);  // fragment of block (K, J) of W
+                                             int N, int nb, int lane) {
+    const int rg = lane >> 4;
+    const unsigned blk = (unsigned)(nb * 2048);                 // one block row further, packed tiles
+    unsigned oa = (unsigned)((J * nb + I) * 2048);              // tile (K, I) of C (the mirror, L_IK^T), K = J
+    unsigned ob = (unsigned)((J * nb + J) * 2048);              // tile (K, J) of W
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
     auto frag = [&](const gdouble *base, unsigned o) {
+        const v4f64 t = ld_pk(base, o, lane);
         Frag f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) f.v[q] = ld_off(base, o + q * row4);
+        for (int q = 0; q < 4; ++q) f.v[q] = t[q];
         return f;
     };
     // two products in flight, in two named register sets (a rotating array made the compiler copy the sets and wait for
@@ -135,21 +137,20 @@ __device__ __forceinline__ void inverse_tile(const gdouble *Cu, const Frag &fw, 
     for (int q = 0; q < 4; ++q) fs.v[q] = acc[q];
     v4f64 w = {0.0, 0.0, 0.0, 0.0};
     w = mfma4(fw, fs, w, true);
-    const unsigned ow = (unsigned)(((16 * I + rg) * ld + 16 * J + cl) * 8);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) st_off(Wu, ow + r * row4, w[r]);
+    st_pk(Wu, (unsigned)((I * nb + J) * 2048), lane, w);
     double ssq = 0.0;  // column sums of squares of this (final) tile over the rows of the real system
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (16 * I + rg + 4 * r < N) ssq = fma(w[r], w[r], ssq);
     ssq += __shfl_xor(ssq, 16);
     ssq += __shfl_xor(ssq, 32);
-    if (rg == 0) cs_IJ[cl] = ssq;
+    if (rg == 0) cs_IJ[lane & 15] = ssq;
 }
 
 // ---- one posterior solve: C = A + diag(1/p) -> L -> W = L^-1 -> y = W b, m = W^T y, tr2 = colnorm2(W) --------------
 // Storage: C lower = L, C strictly-upper blocks = L^T (mirror); W lower = L^-1, W strictly-upper blocks = its
-// transpose; with the mirrors every MFMA operand is loaded in "row form" (4 rows x 128 contiguous bytes).
+// transpose.  C and W are stored as PACKED tiles (tile_chol.h): a tile is two contiguous 1 KB accesses; only the input A
+// (first touch of every tile in step 0) is row-major.
 __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Smem &S) {
     const int N = P.N, NP = P.NP, nb = P.NP / 16, ld = P.NP;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
@@ -189,7 +190,8 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
         }
         const bool ok = chol_inv_tile_acc(t0, x0, lane, aug_tile == 0 ? aug_c : -1);
         if (!ok && lane == 0) *S.flag = 1;
-        store_factored_tile(t0, x0, C, ld, S.dli, W, WdT, cs_ptr(0, 0), rows_valid(0), lane);
+        store_factored_tile(t0, x0, nullptr, ld, S.dli, nullptr, WdT, cs_ptr(0, 0), rows_valid(0), lane);
+        st_pk(as_global(W), 0u, lane, x0);  // W_00
     }
     __syncthreads();
     TSTAMP(1);
@@ -212,7 +214,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             if (I < nb) {
                 v4f64 d = {0.0, 0.0, 0.0, 0.0};
                 d = mfma4(fa, fb[u], d, false);
-                store_tile(as_global(C), ld, 0, I, d, cl, rg, true);
+                st_pk(as_global(C), (unsigned)(I * 2048), lane, d);  // tile (0, I) = L_I0^T (what the inverse reads)
                 double *pr = S.pan + (size_t)((I - 1) * 16 + cl) * PS + rg;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
@@ -237,7 +239,8 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
         double *pan_cur = S.pan + (size_t)(k & 1) * NP * PS, *pan_nxt = S.pan + (size_t)((k + 1) & 1) * NP * PS;
         int *ctr_cur = S.flag + 1 + (k & 1);
         if (tid == 0) S.flag[1 + ((k + 1) & 1)] = 0;  // column counter of the NEXT step's inverse row (nobody reads it now)
-        const unsigned base_k = (unsigned)(16 * (k + 1) * (ld + 1) * 8);
+        const unsigned base_k = (unsigned)(16 * (k + 1) * (ld + 1) * 8);  // block (k+1, k+1) of the row-major A
+        const unsigned base_pk = (unsigned)((k + 1) * (nb + 1) * 2048);   // tile (k+1, k+1), packed
         const unsigned lane_c = base_k + (unsigned)((rg * ld + cl) * 8), row4 = (unsigned)(4 * ld * 8);
         const unsigned lane_p = (unsigned)((cl * PS + rg) * 8);
         const char *pan_b = reinterpret_cast<const char *>(pan_cur);
@@ -255,7 +258,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             if (lane == 0) J = atomicAdd(ctr_cur, 1);
             J = __builtin_amdgcn_readfirstlane(J);
             if (J >= k) return false;
-            inverse_tile(C_inv, fw, W_inv, cs_ptr(k, J), k, J, N, ld, cl, rg);
+            inverse_tile(C_inv, fw, W_inv, cs_ptr(k, J), k, J, N, nb, lane);
             return true;
         };
         auto inverse_columns = [&]() {
@@ -271,8 +274,12 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 long long f_last = clock64();
 #endif
                 v4f64 a, xi;
+                if (k == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[r] = ld_off(src_u, lane_c + r * row4);
+                    for (int r = 0; r < 4; ++r) a[r] = ld_off(src_u, lane_c + r * row4);
+                } else {
+                    a = ld_pk(C_u, base_pk, lane);
+                }
                 if (k == 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -286,9 +293,9 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 const bool ok = chol_inv_tile_acc(a, xi, lane, aug_tile == k + 1 ? aug_c : -1);
                 if (!ok && lane == 0) *S.flag = 1;
                 FSTAMP(9);
-                const size_t dblk = (size_t)(16 * (k + 1)) * ld + 16 * (k + 1);
-                store_factored_tile(a, xi, C + dblk, ld, S.dli, W + dblk, WdT + (size_t)(k + 1) * 256, cs_ptr(k + 1, k + 1),
+                store_factored_tile(a, xi, nullptr, ld, S.dli, nullptr, WdT + (size_t)(k + 1) * 256, cs_ptr(k + 1, k + 1),
                                     rows_valid(k + 1), lane);
+                st_pk(as_global(uniform_ptr(W)), base_pk, lane, xi);  // W_{k+1,k+1}
                 // L_{k+1,k+1}^-1 is in LDS: the waves holding tiles of column k + 1 may now turn them into panel k + 1
                 __hip_atomic_store(&S.flag[3], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 FSTAMP(10);
@@ -310,7 +317,8 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             // stores in order -- a load issued behind a store would wait for the store's acknowledgement) without a register
             // copy.  (2 x 2 groups of tiles with four interleaved MFMA chains were measured too: no faster.)
             auto ldt = [&](const uint4 &t) {
-                v4f64 a;
+                if (k != 0) return ld_pk(C_u, base_pk + (t.w & ~2047u), lane);
+                v4f64 a;  // first touch: the row-major input
                 const unsigned o = (t.x & ~127u) + lane_c;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a[r] = ld_off(src_u, o + r * row4);
@@ -327,12 +335,10 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 if (k == 0 && (t.x & 2u)) {  // first touch: add diag(1/p) on diagonal tiles
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (rg + 4 * r == cl) a[r] += pinv[16 * (1 + (t.w & 127u)) + cl];
+                        if (rg + 4 * r == cl) a[r] += pinv[16 * (1 + (t.w & 127u)) + cl];  // (w: packed offset | i)
                 }
                 a = upd(t.y, t.z, a);
-                const unsigned o = (t.x & ~127u) + lane_c;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) st_off(C_u, o + r * row4, a[r]);
+                st_pk(C_u, base_pk + (t.w & ~2047u), lane, a);
             };
             int e = widx;  // every NWK-th tile of the enumeration
             if (e < cntA) {
@@ -401,26 +407,26 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[cl * PS + 4 * q + rg];
                 for (int c = cfirst; c < ncol; c += NWK) {
                     const int i = c + 1;  // block row I = k + 1 + i
-                    const unsigned o = lane_c + (unsigned)(16 * i * ld * 8);
                     v4f64 t;
+                    if (k == 0) {
+                        const unsigned o = lane_c + (unsigned)(16 * i * ld * 8);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) t[r] = ld_off(src_u, o + r * row4);
+                        for (int r = 0; r < 4; ++r) t[r] = ld_off(src_u, o + r * row4);
+                    } else {
+                        t = ld_pk(C_u, base_pk + (unsigned)(i * nb * 2048), lane);
+                    }
                     t = upd((unsigned)(i * 16 * PS * 8), 0u, t);  // T = C_{I,k+1} - L_Ik L_{k+1,k}^T, rows of block I
                     // its transpose in the accumulator layout (the registers of a tile are the A fragments of its transpose)
                     v4f64 tt = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) tt = __builtin_amdgcn_mfma_f64_16x16x4f64(t[q], ident[q], tt, 0, 0, 0);
-                    Frag ft;  // as B operand: T^T; as A operand: T
+                    Frag ft;  // as B operand: T^T
 #pragma unroll
                     for (int q = 0; q < 4; ++q) ft.v[q] = tt[q];
                     const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
-                    const v4f64 d = mfma4(fx, ft, z4, false);   // D = X T^T = L_{I,k+1}^T  (what the panel from memory computes)
-                    const v4f64 dt = mfma4(ft, fx, z4, false);  // D^T = T X^T = L_{I,k+1}
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) st_off(C_u, o + r * row4, dt[r]);  // block (I, k+1)
-                    const unsigned om = lane_c + (unsigned)(16 * i * 8);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) st_off(C_u, om + r * row4, d[r]);  // mirror block (k+1, I)
+                    const v4f64 d = mfma4(fx, ft, z4, false);  // D = X T^T = L_{I,k+1}^T  (what the panel from memory computes)
+                    // tile (k+1, I): the block the inverse reads; L_{I,k+1} itself (block (I, k+1)) has no reader
+                    st_pk(C_u, base_pk + (unsigned)(i * 2048), lane, d);
                     double *pr = pan_nxt + (size_t)((i - 1) * 16 + cl) * PS + rg;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
@@ -443,7 +449,10 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
         double t2 = 0.0;
         for (int I = J; I < nb; ++I) t2 += cs_ptr(I, J)[c];
         S.tr2[i] = t2;
-        S.m[i] = -W[(size_t)N * ld + i];
+        {   // row N of W, packed: tile (aug_tile, J), element (N - 16 aug_tile, c)
+            const int rr = N - 16 * aug_tile, q = rr >> 2, ln = (rr & 3) * 16 + c;
+            S.m[i] = -W[((size_t)aug_tile * nb + J) * 256 + (q >> 1) * 128 + ln * 2 + (q & 1)];
+        }
     }
     __syncthreads();
     TSTAMP(7);
@@ -620,7 +629,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         const int j = e - i * (i + 1) / 2 + 1;
         ++i;
         S.rec[e] = make_uint4((unsigned)((16 * i * NP + 16 * j) * 8) | (i == j ? 2u : 0u), (unsigned)(i * 16 * PS * 8),
-                              (unsigned)(j * 16 * PS * 8), (unsigned)i);
+                              (unsigned)(j * 16 * PS * 8), (unsigned)((i * (NP / 16) + j) * 2048) | (unsigned)i);
     }
     __shared__ int s_ctl[4];  // [0] stop, [1] status
 

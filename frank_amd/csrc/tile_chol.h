@@ -142,6 +142,25 @@ __device__ __forceinline__ void st_off(gdouble *base, unsigned byte_off, double 
     *reinterpret_cast<gdouble *>(reinterpret_cast<__attribute__((address_space(1))) char *>(base) + byte_off) = v;
 }
 
+// PACKED tiles: the work matrices of the fit loop are stored tile by tile (2 KB each, tile (I, J) at (I nb + J) * 256 doubles) in
+// the register layout of the matrix instructions: a lane's four values (accumulator registers 0..3 = fragments of k-steps 0..3:
+// element (row 4 q + rg, column cl)) sit in two 16-byte pairs, [q >> 1][lane][q & 1].  A tile is then TWO fully contiguous
+// 1 KB accesses of 16 bytes per lane instead of four of 8 bytes over four 128-byte rows of a row-major matrix -- the vector
+// memory pipe of the one CU a fit runs on is what its tile products wait for.
+typedef double gv2f64 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v4f64 ld_pk(const gdouble *base, unsigned tile_byte_off, int lane) {
+    const auto *p = reinterpret_cast<const __attribute__((address_space(1))) gv2f64 *>(
+        reinterpret_cast<const __attribute__((address_space(1))) char *>(base) + tile_byte_off + (unsigned)lane * 16u);
+    const gv2f64 lo = p[0], hi = p[64];
+    return v4f64{lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ void st_pk(gdouble *base, unsigned tile_byte_off, int lane, const v4f64 &v) {
+    auto *p = reinterpret_cast<__attribute__((address_space(1))) gv2f64 *>(
+        reinterpret_cast<__attribute__((address_space(1))) char *>(base) + tile_byte_off + (unsigned)lane * 16u);
+    p[0] = gv2f64{v[0], v[1]};
+    p[64] = gv2f64{v[2], v[3]};
+}
+
 // a pointer the compiler can keep in scalar registers (a select between two kernel arguments otherwise ends up in VGPRs and
 // every access pays a 64-bit vector add)
 template <typename T>
