@@ -149,8 +149,7 @@ __device__ __forceinline__ void inverse_tile(const gdouble *Cu, const Frag &fw, 
 
 // ---- one posterior solve: C = A + diag(1/p) -> L -> W = L^-1 -> y = W b, m = W^T y, tr2 = colnorm2(W) --------------
 // Storage: C lower = L, C strictly-upper blocks = L^T (mirror); W lower = L^-1, W strictly-upper blocks = its
-// transpose.  C and W are stored as PACKED tiles (tile_chol.h): a tile is two contiguous 1 KB accesses; only the input A
-// (first touch of every tile in step 0) is row-major.
+// transpose.  A, C and W are stored as PACKED tiles (tile_chol.h): a tile is two contiguous 1 KB accesses.
 __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Smem &S) {
     const int N = P.N, NP = P.NP, nb = P.NP / 16, ld = P.NP;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
@@ -182,12 +181,10 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
     auto cs_ptr = [&](int I, int J) { return P.cs + ((size_t)I * nb + J) * 16; };
     auto rows_valid = [&](int I) { return min(16, max(0, N - 16 * I)); };
     if (wave == 0) {
-        v4f64 t0, x0;
+        v4f64 t0 = ld_pk(as_global(P.A), 0u, lane), x0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = rg + 4 * r;
-            t0[r] = P.A[(size_t)row * ld + cl] + (row == cl ? pinv[cl] : 0.0);
-        }
+        for (int r = 0; r < 4; ++r)
+            if (rg + 4 * r == cl) t0[r] += pinv[cl];
         const bool ok = chol_inv_tile_acc(t0, x0, lane, aug_tile == 0 ? aug_c : -1);
         if (!ok && lane == 0) *S.flag = 1;
         store_factored_tile(t0, x0, nullptr, ld, S.dli, nullptr, WdT, cs_ptr(0, 0), rows_valid(0), lane);
@@ -206,7 +203,11 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
 #pragma unroll
         for (int u = 0; u < kPanelMax; ++u) {
             const int I = 1 + wave + u * NW;
-            if (I < nb) fb[u] = load_rows(as_global(P.A) + 16 * I, ld, cl, rg);
+            if (I < nb) {
+                const v4f64 t = ld_pk(as_global(P.A), (unsigned)(I * 2048), lane);  // tile (0, I) = (A_I0)^T: A is symmetric
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fb[u].v[q] = t[q];
+            }
         }
 #pragma unroll
         for (int u = 0; u < kPanelMax; ++u) {
@@ -239,9 +240,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
         double *pan_cur = S.pan + (size_t)(k & 1) * NP * PS, *pan_nxt = S.pan + (size_t)((k + 1) & 1) * NP * PS;
         int *ctr_cur = S.flag + 1 + (k & 1);
         if (tid == 0) S.flag[1 + ((k + 1) & 1)] = 0;  // column counter of the NEXT step's inverse row (nobody reads it now)
-        const unsigned base_k = (unsigned)(16 * (k + 1) * (ld + 1) * 8);  // block (k+1, k+1) of the row-major A
         const unsigned base_pk = (unsigned)((k + 1) * (nb + 1) * 2048);   // tile (k+1, k+1), packed
-        const unsigned lane_c = base_k + (unsigned)((rg * ld + cl) * 8), row4 = (unsigned)(4 * ld * 8);
         const unsigned lane_p = (unsigned)((cl * PS + rg) * 8);
         const char *pan_b = reinterpret_cast<const char *>(pan_cur);
         // columns of row k of the inverse, pulled from an LDS counter, longest chain (J = 0) first (which wave computes a tile
@@ -274,12 +273,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 long long f_last = clock64();
 #endif
                 v4f64 a, xi;
-                if (k == 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) a[r] = ld_off(src_u, lane_c + r * row4);
-                } else {
-                    a = ld_pk(C_u, base_pk, lane);
-                }
+                a = ld_pk(src_u, base_pk, lane);
                 if (k == 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -317,12 +311,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             // stores in order -- a load issued behind a store would wait for the store's acknowledgement) without a register
             // copy.  (2 x 2 groups of tiles with four interleaved MFMA chains were measured too: no faster.)
             auto ldt = [&](const uint4 &t) {
-                if (k != 0) return ld_pk(C_u, base_pk + (t.w & ~2047u), lane);
-                v4f64 a;  // first touch: the row-major input
-                const unsigned o = (t.x & ~127u) + lane_c;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a[r] = ld_off(src_u, o + r * row4);
-                return a;
+                return ld_pk(src_u, base_pk + (t.w & ~2047u), lane);
             };
             auto upd = [&](unsigned pa, unsigned pb, v4f64 a) {
                 const double *pa1 = reinterpret_cast<const double *>(pan_b + pa + lane_p);
@@ -407,14 +396,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[cl * PS + 4 * q + rg];
                 for (int c = cfirst; c < ncol; c += NWK) {
                     const int i = c + 1;  // block row I = k + 1 + i
-                    v4f64 t;
-                    if (k == 0) {
-                        const unsigned o = lane_c + (unsigned)(16 * i * ld * 8);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) t[r] = ld_off(src_u, o + r * row4);
-                    } else {
-                        t = ld_pk(C_u, base_pk + (unsigned)(i * nb * 2048), lane);
-                    }
+                    v4f64 t = ld_pk(src_u, base_pk + (unsigned)(i * nb * 2048), lane);
                     t = upd((unsigned)(i * 16 * PS * 8), 0u, t);  // T = C_{I,k+1} - L_Ik L_{k+1,k}^T, rows of block I
                     // its transpose in the accumulator layout (the registers of a tile are the A fragments of its transpose)
                     v4f64 tt = {0.0, 0.0, 0.0, 0.0};
@@ -827,11 +809,16 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     }  // next fit of the batch
 }
 
-// A <- (A + A^T)/2 on the leading N x N block of an NP-strided buffer, b in row/column N, zero elsewhere.
+// A <- (A + A^T)/2 on the leading N x N block, b in row/column N, zero elsewhere -- written as PACKED tiles (tile_chol.h): the
+// fit loop is the only reader.
 __global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int N, int NP, double *A) {
     const size_t total = (size_t)NP * NP;
+    const int nb = NP / 16;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int i = (int)(e / NP), j = (int)(e - (size_t)i * NP);
+        // e enumerates the PACKED positions: tile, pair index h, lane, element of the pair
+        const int tile = (int)(e >> 8), w = (int)(e & 255), h = w >> 7, ln = (w >> 1) & 63, e2 = w & 1;
+        const int I = tile / nb, J = tile - I * nb;
+        const int i = 16 * I + 4 * (2 * h + e2) + (ln >> 4), j = 16 * J + (ln & 15);
         double v = 0.0;
         if (i < N && j < N) v = 0.5 * (Araw[(size_t)i * N + j] + Araw[(size_t)j * N + i]);
         else if (i == N && j < N) v = bq[j];
