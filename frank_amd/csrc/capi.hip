@@ -1677,7 +1677,9 @@ static int fit_batch_size() {  // fit loops per launch: 16, or FRANK_AMD_FIT_BAT
     return b < 1 ? 1 : (b > kFitBatchMax ? kFitBatchMax : b);
 }
 int fh_fit_slots(void) {  // fits that may be outstanding: bounded by the slots and by the launches in flight
-    const int by_launch = kFitBatches * fit_batch_size();
+    // (a launch is free again when ALL its fits are collected: with first-in first-out collection one launch may be
+    //  partly collected)
+    const int by_launch = (kFitBatches - 1) * fit_batch_size() + 1;
     return by_launch < kFitSlots ? by_launch : kFitSlots;
 }
 
