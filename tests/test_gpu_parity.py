@@ -814,6 +814,24 @@ def test_lognormal_pivoted_route_equals_cholesky_route(monkeypatch):
         assert np.abs(out[0]["MAP"][k] - out[1]["MAP"][k]).max() < 1e-7
 
 
+@pytest.mark.parametrize("N", [17, 47, 130, 287])
+def test_fit_at_other_basis_sizes_against_oracle(N):
+    """The whole Normal fit (bucket moments -> Gram -> fit loop with packed tiles, fused panels, wave-scan band solve) at
+    basis sizes between the fixtures': 2, 3, 9 and 18 block rows, the last tile mostly padding (N = 17: 15 of 16 rows).  The
+    pinned oracle is the referee: same iteration count, profile to 1e-8 of its maximum, M to 1e-13."""
+    from frank_amd import FrankFitter
+    from oracle import oracle as fo
+    u, v, V, w = mock_disc_visibilities(40000, seed=100 + N, noise_seed=7)
+    FF = FrankFitter(2.0, N, geom(), verbose=False, store_iteration_diagnostics=True, check_qbounds=False)
+    sol = FF.fit(u, v, V, w)
+    m = fo.map_visibilities(N, RMAX, GEOM, u, v, V, w, check_qbounds=False)
+    o = fo.frank_fit_normal(N, RMAX, m["M"], m["j"])
+    assert o["rc"] == 0
+    assert rel_to_max(FF._M, m["M"]) < 1e-13 and rel_to_max(FF._j, m["j"]) < 1e-13
+    assert FF.iteration_diagnostics["num_iterations"] == o["niter"]
+    assert rel_to_max(sol.I, o["mu"]) < 1e-8
+
+
 def test_bootstrap_lognormal_equals_gathered_copy():
     """bootstrap_fits with a method='LogNormal' fitter: multiplicities in the binning pre-pass + fh_fit_lognormal on the
     device-resident M, j must equal the ordinary fit of the explicitly resampled table (few passes: before the
