@@ -2407,7 +2407,22 @@ struct UniqueId {
 RcclApi g_rccl;
 int load_rccl() {
     if (g_rccl.lib) return FH_OK;
-    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // The RCCL that sits BESIDE the HIP runtime this process runs on.  A process can hold two ROCm stacks (this library
+    // loaded first, on /opt/rocm; then `import torch`, which brings its bundled librccl / libhsa-runtime64): a bare
+    // dlopen("librccl.so.1") then returns the bundled RCCL, which opens the bundled -- never initialised -- HSA runtime and
+    // ncclCommInitRank fails with "no ROCm-capable device is detected".
+    void *lib = nullptr;
+    Dl_info hip_rt{};
+    if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &hip_rt) && hip_rt.dli_fname) {
+        std::string dir(hip_rt.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+            dir.resize(slash);
+            lib = dlopen((dir + "/librccl.so.1").c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (!lib) lib = dlopen((dir + "/librccl.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+        }
+    }
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) return fail(FH_ERR_HIP, "cannot load librccl: %s", dlerror());
     g_rccl.get_unique_id = (int (*)(void *))dlsym(lib, "ncclGetUniqueId");

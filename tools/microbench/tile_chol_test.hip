@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "tile_chol.h"
@@ -72,6 +73,13 @@ int main() {
             }
         if (!ok[b]) printf("tile %d not ok\n", b);
     }
+    unsigned long long hsh = 1469598103934665603ULL;
+    for (int i = 0; i < nt * 256; ++i) {
+        unsigned long long a, b;
+        memcpy(&a, &L[i], 8); memcpy(&b, &X[i], 8);
+        hsh = (hsh ^ a) * 1099511628211ULL; hsh = (hsh ^ b) * 1099511628211ULL;
+    }
+    printf("bits of L and X: %016llx\n", hsh);
     printf("max |L L^T - A| / max|A| = %.2e   max |L X - I| = %.2e   max upper = %.2e   cycles per tile (s_memtime) = %lld\n", worstL, worstX,
            worstU, cyc[0]);
     return !(worstL < 1e-13 && worstX < 1e-9 && worstU == 0.0);
