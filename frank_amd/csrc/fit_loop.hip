@@ -77,8 +77,9 @@ struct Smem {
     double *scanQ; // transfer matrices of the banded recurrences at the six levels of the wave scan (per fit)
     double *band;  // 6 NP: LU factors of the pentadiagonal T + I (five bands) and the reciprocal pivots, staged once per fit
     uint4 *rec;    // tile e = (i - 1) i / 2 + (j - 1), 1 <= j <= i, of the trailing triangle right of its first column (block
-                   // (k+1+i, k+1+j) at step k), built once per launch: x = byte offset of the tile relative to block (k+1, k+1) |
-                   // bit 1: diagonal tile; y, z = byte offsets of panel row blocks i, j; w = i
+                   // (k+1+i, k+1+j) at step k), built once per launch: x = packed byte offset of the MIRROR tile (j, i) relative
+                   // to block (k+1, k+1) (step 0 reads the transposes from A) | bit 1: diagonal tile; y, z = byte offsets of
+                   // panel row blocks j, i (A and B operand of the transposed update); w = packed offset of tile (i, j) | i
     int *flag;
 };
 
@@ -148,8 +149,10 @@ __device__ __forceinline__ void inverse_tile(const gdouble *Cu, const Frag &fw, 
 }
 
 // ---- one posterior solve: C = A + diag(1/p) -> L -> W = L^-1 -> y = W b, m = W^T y, tr2 = colnorm2(W) --------------
-// Storage: C lower = L, C strictly-upper blocks = L^T (mirror); W lower = L^-1, W strictly-upper blocks = its
-// transpose.  A, C and W are stored as PACKED tiles (tile_chol.h): a tile is two contiguous 1 KB accesses.
+// Storage: C strictly-upper blocks = L^T (the mirror tiles (K, I) = L_IK^T: what the inverse reads); the lower tiles of C
+// hold the trailing matrix in progress, every tile TRANSPOSED (tile (I, J) holds T_IJ^T: the update swaps its operands, and
+// the tiles of column k + 1 are then the B operands of D = L_{k+1,k+1}^-1 T^T as they stand -- no transposition on the
+// way into the panel); W lower = L^-1.  A, C and W are stored as PACKED tiles (tile_chol.h): two contiguous 1 KB accesses.
 __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Smem &S) {
     const int N = P.N, NP = P.NP, nb = P.NP / 16, ld = P.NP;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
@@ -227,9 +230,6 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
     const gdouble *C_inv = as_global(uniform_ptr(C));
     gdouble *W_inv = as_global(uniform_ptr(W));
     gdouble *C_u = as_global(uniform_ptr(C));
-    double ident[4];  // B fragments of the 16 x 16 identity
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ident[q] = (4 * q + rg == cl) ? 1.0 : 0.0;
     for (int k = 0; k < nb; ++k) {
         if (*S.flag) return false;
         const double *src = (k == 0) ? P.A : C;
@@ -310,8 +310,8 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             // trip: the loads of the tile after next are issued before the stores of the current one (vmcnt counts loads and
             // stores in order -- a load issued behind a store would wait for the store's acknowledgement) without a register
             // copy.  (2 x 2 groups of tiles with four interleaved MFMA chains were measured too: no faster.)
-            auto ldt = [&](const uint4 &t) {
-                return ld_pk(src_u, base_pk + (t.w & ~2047u), lane);
+            auto ldt = [&](const uint4 &t) {  // (step 0 reads A: the transpose of tile (I, J) is its tile (J, I))
+                return ld_pk(src_u, base_pk + ((k == 0 ? t.x : t.w) & ~2047u), lane);
             };
             auto upd = [&](unsigned pa, unsigned pb, v4f64 a) {
                 const double *pa1 = reinterpret_cast<const double *>(pan_b + pa + lane_p);
@@ -396,15 +396,11 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[cl * PS + 4 * q + rg];
                 for (int c = cfirst; c < ncol; c += NWK) {
                     const int i = c + 1;  // block row I = k + 1 + i
-                    v4f64 t = ld_pk(src_u, base_pk + (unsigned)(i * nb * 2048), lane);
-                    t = upd((unsigned)(i * 16 * PS * 8), 0u, t);  // T = C_{I,k+1} - L_Ik L_{k+1,k}^T, rows of block I
-                    // its transpose in the accumulator layout (the registers of a tile are the A fragments of its transpose)
-                    v4f64 tt = {0.0, 0.0, 0.0, 0.0};
+                    v4f64 t = ld_pk(src_u, base_pk + (unsigned)(k == 0 ? i * 2048 : i * nb * 2048), lane);
+                    t = upd(0u, (unsigned)(i * 16 * PS * 8), t);  // T^T = C_{I,k+1}^T - L_{k+1,k} L_Ik^T: the tile is kept transposed
+                    Frag ft;  // as B operand: T^T (the accumulator registers of a matrix are its B fragments)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) tt = __builtin_amdgcn_mfma_f64_16x16x4f64(t[q], ident[q], tt, 0, 0, 0);
-                    Frag ft;  // as B operand: T^T
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) ft.v[q] = tt[q];
+                    for (int q = 0; q < 4; ++q) ft.v[q] = t[q];
                     const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
                     const v4f64 d = mfma4(fx, ft, z4, false);  // D = X T^T = L_{I,k+1}^T  (what the panel from memory computes)
                     // tile (k+1, I): the block the inverse reads; L_{I,k+1} itself (block (I, k+1)) has no reader
@@ -610,8 +606,8 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         while (i * (i + 1) / 2 > e) --i;
         const int j = e - i * (i + 1) / 2 + 1;
         ++i;
-        S.rec[e] = make_uint4((unsigned)((16 * i * NP + 16 * j) * 8) | (i == j ? 2u : 0u), (unsigned)(i * 16 * PS * 8),
-                              (unsigned)(j * 16 * PS * 8), (unsigned)((i * (NP / 16) + j) * 2048) | (unsigned)i);
+        S.rec[e] = make_uint4((unsigned)((j * (NP / 16) + i) * 2048) | (i == j ? 2u : 0u), (unsigned)(j * 16 * PS * 8),
+                              (unsigned)(i * 16 * PS * 8), (unsigned)((i * (NP / 16) + j) * 2048) | (unsigned)i);
     }
     __shared__ int s_ctl[4];  // [0] stop, [1] status
 
