@@ -56,8 +56,13 @@ using namespace tilechol;
 #define WSTAMP(slot) do { } while (0)
 #endif
 
+// Twelve waves, three per SIMD (168 registers each): the worker waves wait for L2 round trips (~850 cycles per tile load against
+// 4 x 64 cycles of matrix pipe per product) with the operands of two products in flight each, so what a pass needs is more of
+// them.  Eight waves (256 registers): 164 us per pass at N = 300; twelve: 153; sixteen (128 registers, 105 of them spilled): 153.
+// Below ~N = 100 the three agree to 1 %.  What made more than eight waves pay: the parameter struct out of scratch memory
+// (see the slot index below) and the scan's addresses formed where they are used.
 #ifndef FIT_LOOP_THREADS
-#define FIT_LOOP_THREADS 512
+#define FIT_LOOP_THREADS 768
 #endif
 constexpr int KT = FIT_LOOP_THREADS;
 constexpr int NW = KT / 64;
@@ -68,6 +73,12 @@ constexpr int NW = KT / 64;
 #define K2_ALL_WORK 1
 #endif
 constexpr int NWK = K2_ALL_WORK ? NW - 1 : NW - NW / 4;
+// The wave that runs the serial factor-and-invert chain (any: with twelve waves every SIMD holds three; with 11 waves, 704
+// threads, wave 3 shares its SIMD with one mate instead of two -- measured, 4 % slower than twelve waves all the same).
+#ifndef K2_CHAIN_WAVE
+#define K2_CHAIN_WAVE 3
+#endif
+constexpr int kChain = K2_CHAIN_WAVE;
 constexpr int kMaxTiles = 210;  // tiles of the largest trailing triangle: NP / 16 - 1 = 20 block rows (NP <= 336)
 
 struct Smem {
@@ -270,7 +281,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             }
         };
         TRACE(0);
-        if (wave == 0) {
+        if (wave == kChain) {
             if (m > 0) {  // look-ahead: tile (k+1, k+1) updated, factored and inverted while the other waves update the rest
 #ifdef FIT_LOOP_TIMING
                 long long f_last = clock64();
@@ -301,7 +312,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             inverse_columns();
             TRACE(4);
         } else {
-            const int widx = wave - 1;  // 0..NWK-1
+            const int widx = wave < kChain ? wave : wave - 1;  // 0..NWK-1
 #ifdef FIT_LOOP_TIMING
             long long w_last = clock64();
 #endif
@@ -571,7 +582,15 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         P.result += 2 * f;
     }
     if (P.slot_stride) {
-        const int sl = P.slot_ids[blockIdx.x];
+        // (constant indices only: a dynamic index into the by-value parameter struct forces the WHOLE struct into scratch
+        // memory, every later P.field a scratch load and the prologue 256 bytes of scratch stores)
+        unsigned long long ids_lo = 0, ids_hi = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            ids_lo |= (unsigned long long)P.slot_ids[i] << (8 * i);
+            ids_hi |= (unsigned long long)P.slot_ids[8 + i] << (8 * i);
+        }
+        const int sl = (int)(((blockIdx.x < 8 ? ids_lo : ids_hi) >> (8 * (blockIdx.x & 7))) & 0xffull);
         const size_t off = (size_t)sl * P.slot_stride;
         P.A += off;
         P.bq += off;
@@ -708,8 +727,12 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         OSTAMP(14);
 #ifndef K2_SERIAL_BAND
         if (tid < 64) {  // wave 0: both substitutions as wave scans (see scan_solve); LDS traffic of one wave only, in order
-            scan_solve(S.band, NP, S.scanQ, S.rhs, 0, tid);
-            scan_solve(S.band, NP, S.scanQ, S.rhs, 1, tid);
+            // (the lane index goes through an opaque move: the LDS addresses of the scan are then formed HERE, a few integer
+            // operations, instead of being hoisted out of the pass loop, kept alive across the factorisation and spilled)
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            scan_solve(S.band, NP, S.scanQ, S.rhs, 0, t);
+            scan_solve(S.band, NP, S.scanQ, S.rhs, 1, t);
         }
 #else
         if (tid == 0) {
