@@ -1510,7 +1510,7 @@ static FitLoopParams make_loop_params(fh_ctx *c, int mode, double alpha, double 
     P.p_out = c->p_out.p;
     P.result = c->loop_result.p;
 #ifdef FIT_LOOP_TIMING
-    if (!c->loop_timing.p && c->loop_timing.alloc(16 + 1024) == hipSuccess) (void)hipMemset(c->loop_timing.p, 0, (16 + 1024) * sizeof(long long));
+    if (!c->loop_timing.p && c->loop_timing.alloc(16 + 2048) == hipSuccess) (void)hipMemset(c->loop_timing.p, 0, (16 + 2048) * sizeof(long long));
     P.timing = c->loop_timing.p;
 #endif
     return P;
@@ -2385,9 +2385,9 @@ int fh_debug_loop_timing(fh_ctx *c, long long *out16) {
     return FH_OK;
 }
 // per-wave time stamps of one pass (8 waves x 20 steps x 6 stamps), FIT_LOOP_TIMING builds
-int fh_debug_loop_trace(fh_ctx *c, long long *out1024) {
+int fh_debug_loop_trace(fh_ctx *c, long long *out2048) {  // [wave][step < 20][6 stamps], up to 16 waves
     if (!c || !c->loop_timing.p) return FH_ERR_INVALID;
-    HIP_TRY(hipMemcpy(out1024, c->loop_timing.p + 16, 1024 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out2048, c->loop_timing.p + 16, 2048 * sizeof(long long), hipMemcpyDeviceToHost));
     return FH_OK;
 }
 #endif

@@ -75,6 +75,10 @@ constexpr int NW = KT / 64;
 constexpr int NWK = K2_ALL_WORK ? NW - 1 : NW - NW / 4;
 // The wave that runs the serial factor-and-invert chain (any: with twelve waves every SIMD holds three; with 11 waves, 704
 // threads, wave 3 shares its SIMD with one mate instead of two -- measured, 4 % slower than twelve waves all the same).
+// inverse tiles with at least this many products go through the ring of hand-issued loads (>= 3)
+#ifndef K2_RING_MIN
+#define K2_RING_MIN 3
+#endif
 #ifndef K2_CHAIN_WAVE
 #define K2_CHAIN_WAVE 3
 #endif
@@ -112,37 +116,64 @@ __device__ __forceinline__ void inverse_tile(const gdouble *Cu, const Frag &fw, 
     unsigned oa = (unsigned)((J * nb + I) * 2048);              // tile (K, I) of C (the mirror, L_IK^T), K = J
     unsigned ob = (unsigned)((J * nb + J) * 2048);              // tile (K, J) of W
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-    auto frag = [&](const gdouble *base, unsigned o) {
-        const v4f64 t = ld_pk(base, o, lane);
-        Frag f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) f.v[q] = t[q];
-        return f;
+    // A ring of four register sets, three products in flight behind the one being multiplied.  The loads are issued and
+    // waited for by hand (uniform base + 32-bit offset; vmcnt counts in issue order: product p is complete when at most
+    // 4 x (products issued after it) loads are outstanding): the compiler's version -- two named sets, copied at the top of
+    // every trip behind a vmcnt(0) -- had one L2 round trip per two products on the path of a chain of up to nb - 1 of them,
+    // and the late steps of a pass wait for exactly that chain.  Same order of summation, same bits.
+    struct Operands {
+        v2f64 alo, ahi, blo, bhi;
     };
-    // two products in flight, in two named register sets (a rotating array made the compiler copy the sets and wait for
-    // EVERY outstanding load at the top of each trip: one full L2 latency per product)
-    Frag a0 = frag(Cu, oa), b0 = frag(Wu, ob), a1 = a0, b1 = b0;
-    if (J + 1 < I) {
-        a1 = frag(Cu, oa + blk);
-        b1 = frag(Wu, ob + blk);
-    }
-    int K = J;
-    for (; K + 1 < I; K += 2) {
-        const Frag ca0 = a0, cb0 = b0, ca1 = a1, cb1 = b1;
-        oa += 2 * blk;
-        ob += 2 * blk;
-        if (K + 2 < I) {
-            a0 = frag(Cu, oa);
-            b0 = frag(Wu, ob);
+    const int n = I - J;  // products
+    const unsigned lane_o = (unsigned)lane * 16u;
+    auto issue = [&](Operands &r, int p) {
+        const unsigned pa = oa + (unsigned)p * blk + lane_o, pb = ob + (unsigned)p * blk + lane_o;
+        asm volatile(
+            "global_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %4, %6 offset:1024\n\t"
+            "global_load_dwordx4 %2, %5, %7\n\tglobal_load_dwordx4 %3, %5, %7 offset:1024"
+            : "=&v"(r.alo), "=&v"(r.ahi), "=&v"(r.blo), "=&v"(r.bhi)
+            : "v"(pa), "v"(pb), "s"(Cu), "s"(Wu)
+            : "memory");
+    };
+    auto consume = [&](Operands &r, int p) {
+        switch (min(3, n - 1 - p)) {  // products issued after p
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
         }
-        if (K + 3 < I) {
-            a1 = frag(Cu, oa + blk);
-            b1 = frag(Wu, ob + blk);
+        asm volatile("" : "+v"(r.alo), "+v"(r.ahi), "+v"(r.blo), "+v"(r.bhi));  // (used behind the wait)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(r.alo[0], r.blo[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(r.alo[1], r.blo[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(r.ahi[0], r.bhi[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(r.ahi[1], r.bhi[1], acc, 0, 0, 0);
+    };
+    if (n <= K2_RING_MIN - 1) {  // short chains: plain loads, the compiler's waits (nothing to pipeline)
+        for (int p = 0; p < n; ++p) {
+            const v4f64 ta = ld_pk(Cu, oa + (unsigned)p * blk, lane), tb = ld_pk(Wu, ob + (unsigned)p * blk, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[q], tb[q], acc, 0, 0, 0);
         }
-        acc = mfma4(ca0, cb0, acc, false);
-        acc = mfma4(ca1, cb1, acc, false);
+    } else {
+        Operands s0, s1, s2, s3;
+        issue(s0, 0);
+        issue(s1, 1);
+        issue(s2, 2);
+        for (int p = 0;; p += 4) {
+            if (p + 3 < n) issue(s3, p + 3);
+            consume(s0, p);
+            if (p + 1 >= n) break;
+            if (p + 4 < n) issue(s0, p + 4);
+            consume(s1, p + 1);
+            if (p + 2 >= n) break;
+            if (p + 5 < n) issue(s1, p + 5);
+            consume(s2, p + 2);
+            if (p + 3 >= n) break;
+            if (p + 6 < n) issue(s2, p + 6);
+            consume(s3, p + 3);
+            if (p + 4 >= n) break;
+        }
     }
-    if (K < I) acc = mfma4(a0, b0, acc, false);
     // the C/D layout of acc (row = rg + 4 r, col = cl) is the B-operand layout (k = 4 s + rg, j = cl)
     Frag fs;
 #pragma unroll

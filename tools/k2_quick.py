@@ -30,14 +30,16 @@ if "timing" in os.environ.get("FRANK_AMD_LIB", ""):
     print('outer loop: solve_posterior %.1f, beta/convergence/exp %.1f, banded solve (thread 0) %.1f us/iter' % tuple(v/2.1e3/(2*nit+4) for v in out[13:16]))
     for n_,v in zip(names,out[:8]): print('%-14s %8.1f us/iter  %5.1f%%'%(n_, v/2.1e3/ (2*nit+4) , 100*v/tot))
 
-    tr=(ctypes.c_longlong*1024)()
+    nw=12
+    tr=(ctypes.c_longlong*2048)()
     _lib.lib.fh_debug_loop_trace(FF._DHT.context(), tr)
-    t=np.array(tr[:960],dtype=np.int64).reshape(8,20,6)
+    t=np.array(tr[:nw*120],dtype=np.int64).reshape(nw,20,6)
+    cw=int(np.argmax((t[:,:,5]>0).sum(axis=1)))  # the wave that runs the chain
     t0=t[:,:,0][t[:,:,0]>0].min()
     us=lambda v: (v-t0)/2.4e3
     print('step | start (w0) | w0: flag set, done | workers: trailing done (min..max), flag seen (max), column done (max), all done (max)')
     for k in range(19):
-        w=t[1:,k,:]
+        w=np.delete(t,cw,axis=0)[:,k,:]
         f=lambda a: us(a[a>0]).max() if (a>0).any() else float('nan')
         g=lambda a: us(a[a>0]).min() if (a>0).any() else float('nan')
-        print('%2d  %7.2f | %7.2f %7.2f | %7.2f..%7.2f  %7.2f  %7.2f  %7.2f' % (k, us(t[0,k,0]), us(t[0,k,5]) if t[0,k,5]>0 else float('nan'), us(t[0,k,4]), g(w[:,1]), f(w[:,1]), f(w[:,2]), f(w[:,3]), f(w[:,4])))
+        print('%2d  %7.2f | %7.2f %7.2f | %7.2f..%7.2f  %7.2f  %7.2f  %7.2f' % (k, us(t[cw,k,0]), us(t[cw,k,5]) if t[cw,k,5]>0 else float('nan'), us(t[cw,k,4]), g(w[:,1]), f(w[:,1]), f(w[:,2]), f(w[:,3]), f(w[:,4])))
