@@ -139,18 +139,32 @@ __global__ __launch_bounds__(256) void bucket_hist_kernel(const double *s, int64
     for (int b = threadIdx.x; b < nb; b += 256) row[b] = lh[b];
 }
 
-// per bucket: exclusive prefix over the blocks (in place) and the bucket's total
-__global__ void bucket_scan_blocks_kernel(int *hist, int nblocks, int nb, int *totals) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    int run = 0;
+// per bucket: exclusive prefix over the blocks (in place) and the bucket's total.  A workgroup takes 64 buckets (one per
+// lane: the rows of `hist` are read 256 bytes at a time) and its 16 waves 16 contiguous groups of blocks: sum of the group,
+// the sums of the groups before it through LDS, then the group's prefixes.  (One thread per bucket over all 512 blocks --
+// 8 000 threads on the whole device -- took 60 us of the 0.7 ms binning pass.)
+__global__ __launch_bounds__(1024) void bucket_scan_blocks_kernel(int *hist, int nblocks, int nb, int *totals) {
+    __shared__ int part[16][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int b = blockIdx.x * 64 + lane;
+    const int per = (nblocks + 15) / 16, k0 = min(nblocks, g * per), k1 = min(nblocks, k0 + per);
+    int sum = 0;
+    if (b < nb) {
 #pragma unroll 8
-    for (int k = 0; k < nblocks; ++k) {
+        for (int k = k0; k < k1; ++k) sum += hist[(size_t)k * nb + b];
+    }
+    part[g][lane] = sum;
+    __syncthreads();
+    int run = 0;
+    for (int h = 0; h < g; ++h) run += part[h][lane];
+    if (b >= nb) return;
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k) {
         const int v = hist[(size_t)k * nb + b];
         hist[(size_t)k * nb + b] = run;
         run += v;
     }
-    totals[b] = run;
+    if (g == 15) totals[b] = run;
 }
 
 struct Row32 {
@@ -863,7 +877,7 @@ hipError_t fh_k1v2_launch_sort(const SortParams &sp, hipStream_t stream) {
     int nbits = 0;
     while ((1 << nbits) < sp.nb) ++nbits;
     hipLaunchKernelGGL(bucket_hist_kernel, dim3(sp.blocks), dim3(256), lds, stream, sp.s, sp.n, sp.inv_delta, sp.nb, sp.hist);
-    hipLaunchKernelGGL(bucket_scan_blocks_kernel, dim3((sp.nb + 255) / 256), dim3(256), 0, stream, sp.hist, sp.blocks, sp.nb,
+    hipLaunchKernelGGL(bucket_scan_blocks_kernel, dim3((sp.nb + 63) / 64), dim3(1024), 0, stream, sp.hist, sp.blocks, sp.nb,
                        sp.totals);
     hipLaunchKernelGGL(bucket_starts_kernel, dim3(1), dim3(1024), 0, stream, sp.totals, sp.nb, sp.starts, sp.info,
                        reinterpret_cast<Row32 *>(sp.rows));
