@@ -814,10 +814,11 @@ def test_lognormal_pivoted_route_equals_cholesky_route(monkeypatch):
         assert np.abs(out[0]["MAP"][k] - out[1]["MAP"][k]).max() < 1e-7
 
 
-@pytest.mark.parametrize("N", [17, 47, 130, 287])
+@pytest.mark.parametrize("N", [3, 16, 17, 33, 47, 130, 287])
 def test_fit_at_other_basis_sizes_against_oracle(N):
     """The whole Normal fit (bucket moments -> Gram -> fit loop with packed tiles, fused panels, wave-scan band solve) at
-    basis sizes between the fixtures': 2, 3, 9 and 18 block rows, the last tile mostly padding (N = 17: 15 of 16 rows).  The
+    basis sizes between and below the fixtures': one block row (N = 3: no factorisation step at all; N = 16: the right-hand-side row
+    alone in the second), 2, 3, 9 and 18 block rows, the last tile mostly padding (N = 17, 33: 14 of 16 rows).  The
     pinned oracle is the referee: same iteration count, profile to 1e-8 of its maximum, M to 1e-13."""
     from frank_amd import FrankFitter
     from oracle import oracle as fo
