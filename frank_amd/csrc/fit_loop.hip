@@ -75,9 +75,14 @@ constexpr int NW = KT / 64;
 constexpr int NWK = K2_ALL_WORK ? NW - 1 : NW - NW / 4;
 // The wave that runs the serial factor-and-invert chain (any: with twelve waves every SIMD holds three; with 11 waves, 704
 // threads, wave 3 shares its SIMD with one mate instead of two -- measured, 4 % slower than twelve waves all the same).
-// inverse tiles with at least this many products go through the ring of hand-issued loads (>= 3)
+// inverse tiles with at least this many products go through the ring of hand-issued loads (>= K2_RING_SETS)
 #ifndef K2_RING_MIN
-#define K2_RING_MIN 3
+#define K2_RING_MIN 2
+#endif
+// register sets of that ring (2 or 3): 4 sets 97.4 ms per fit, 3 sets 94.0, 2 sets 92.2 -- what pays is the exact wait and the
+// missing register copies, not the depth; every register the inverse tiles do not hold is worth more than a load in flight
+#ifndef K2_RING_SETS
+#define K2_RING_SETS 2
 #endif
 #ifndef K2_CHAIN_WAVE
 #define K2_CHAIN_WAVE 3
@@ -116,11 +121,11 @@ __device__ __forceinline__ void inverse_tile(const gdouble *Cu, const Frag &fw, 
     unsigned oa = (unsigned)((J * nb + I) * 2048);              // tile (K, I) of C (the mirror, L_IK^T), K = J
     unsigned ob = (unsigned)((J * nb + J) * 2048);              // tile (K, J) of W
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-    // A ring of four register sets, three products in flight behind the one being multiplied.  The loads are issued and
-    // waited for by hand (uniform base + 32-bit offset; vmcnt counts in issue order: product p is complete when at most
-    // 4 x (products issued after it) loads are outstanding): the compiler's version -- two named sets, copied at the top of
-    // every trip behind a vmcnt(0) -- had one L2 round trip per two products on the path of a chain of up to nb - 1 of them,
-    // and the late steps of a pass wait for exactly that chain.  Same order of summation, same bits.
+    // A ring of register sets (K2_RING_SETS, two by default: one product in flight behind the one being multiplied).  The
+    // loads are issued and waited for by hand (uniform base + 32-bit offset; vmcnt counts in issue order: product p is complete
+    // when at most 4 x (products issued after it) loads are outstanding): the compiler's version -- two named sets, copied at
+    // the top of every trip behind a vmcnt(0) -- had one L2 round trip and 32 register moves per two products on the path of a
+    // chain of up to nb - 1 of them, and the late steps of a pass wait for exactly that chain.  Same order of summation, same bits.
     struct Operands {
         v2f64 alo, ahi, blo, bhi;
     };
@@ -136,7 +141,7 @@ __device__ __forceinline__ void inverse_tile(const gdouble *Cu, const Frag &fw, 
             : "memory");
     };
     auto consume = [&](Operands &r, int p) {
-        switch (min(3, n - 1 - p)) {  // products issued after p
+        switch (min(K2_RING_SETS - 1, n - 1 - p)) {  // products issued after p
             case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
             case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
             case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
@@ -155,24 +160,33 @@ __device__ __forceinline__ void inverse_tile(const gdouble *Cu, const Frag &fw, 
             for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[q], tb[q], acc, 0, 0, 0);
         }
     } else {
-        Operands s0, s1, s2, s3;
+#if K2_RING_SETS == 2
+        Operands s0, s1;
         issue(s0, 0);
-        issue(s1, 1);
-        issue(s2, 2);
-        for (int p = 0;; p += 4) {
-            if (p + 3 < n) issue(s3, p + 3);
+        for (int p = 0;; p += 2) {
+            if (p + 1 < n) issue(s1, p + 1);
             consume(s0, p);
             if (p + 1 >= n) break;
-            if (p + 4 < n) issue(s0, p + 4);
+            if (p + 2 < n) issue(s0, p + 2);
             consume(s1, p + 1);
             if (p + 2 >= n) break;
-            if (p + 5 < n) issue(s1, p + 5);
+        }
+#else
+        Operands s0, s1, s2;
+        issue(s0, 0);
+        issue(s1, 1);
+        for (int p = 0;; p += 3) {
+            if (p + 2 < n) issue(s2, p + 2);
+            consume(s0, p);
+            if (p + 1 >= n) break;
+            if (p + 3 < n) issue(s0, p + 3);
+            consume(s1, p + 1);
+            if (p + 2 >= n) break;
+            if (p + 4 < n) issue(s1, p + 4);
             consume(s2, p + 2);
             if (p + 3 >= n) break;
-            if (p + 6 < n) issue(s2, p + 6);
-            consume(s3, p + 3);
-            if (p + 4 >= n) break;
         }
+#endif
     }
     // the C/D layout of acc (row = rg + 4 r, col = cl) is the B-operand layout (k = 4 s + rg, j = cl)
     Frag fs;
