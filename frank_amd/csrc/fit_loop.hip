@@ -114,7 +114,7 @@ struct Smem {
 // bytes), like every other operand; a first version staged row I of L in LDS, transposed, once per step: the staging loads
 // sat in front of the panel (their registers and the in-order vmcnt tied them to the spill reloads: ~1 us per step) and
 // took 39 KB of LDS.  `fw` is the A operand W_II (rows of its transpose).  All addresses: uniform base + 32-bit offset.
-__device__ __forceinline__ void inverse_tile(const gdouble *Cu, const Frag &fw, gdouble *Wu, double *cs_IJ, int I, int J,
+__device__ __forceinline__ void inverse_tile(const gdouble *Cu, const double *dli_I, gdouble *Wu, double *cs_IJ, int I, int J,
                                              int N, int nb, int lane) {
     const int rg = lane >> 4;
     const unsigned blk = (unsigned)(nb * 2048);                 // one block row further, packed tiles
@@ -192,6 +192,12 @@ __device__ __forceinline__ void inverse_tile(const gdouble *Cu, const Frag &fw, 
     Frag fs;
 #pragma unroll
     for (int q = 0; q < 4; ++q) fs.v[q] = acc[q];
+    Frag fw;  // A operand W_II = L_II^-1, read from LDS only now: eight registers less across the chain
+    {
+        const int cl = lane & 15;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fw.v[q] = dli_I[cl * PS + 4 * q + rg];
+    }
     v4f64 w = {0.0, 0.0, 0.0, 0.0};
     w = mfma4(fw, fs, w, true);
     st_pk(Wu, (unsigned)((I * nb + J) * 2048), lane, w);
@@ -216,7 +222,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
     // W = L^-1 lives in the LOWER tiles of C: tile (k, J), J < k, of the trailing matrix is dead once column J has been
     // processed (its factor is the mirror tile (J, k)), the diagonal tile once wave 0 has it in registers; row k of W is
     // written at step k > J.  One matrix less in the working set of a pass (1.5 -> 1.1 MB: three loops per 4 MB L2).
-    double *C = P.C, *W = P.C, *WdT = P.WdT;
+    double *C = P.C, *W = P.C;
 #ifdef FIT_LOOP_TIMING
     long long t_last = clock64();
 #endif
@@ -249,7 +255,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             if (rg + 4 * r == cl) t0[r] += pinv[cl];
         const bool ok = chol_inv_tile_acc(t0, x0, lane, aug_tile == 0 ? aug_c : -1);
         if (!ok && lane == 0) *S.flag = 1;
-        store_factored_tile(t0, x0, nullptr, ld, S.dli, nullptr, WdT, cs_ptr(0, 0), rows_valid(0), lane);
+        store_factored_tile(t0, x0, nullptr, ld, S.dli, nullptr, nullptr, cs_ptr(0, 0), rows_valid(0), lane);  // L_00^-1 -> dli[0]
         st_pk(as_global(W), 0u, lane, x0);  // W_00
     }
     __syncthreads();
@@ -304,25 +310,18 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
         const char *pan_b = reinterpret_cast<const char *>(pan_cur);
         // columns of row k of the inverse, pulled from an LDS counter, longest chain (J = 0) first (which wave computes a tile
         // does not change its bits); row k of L is final since the panel of step k - 1
-        auto load_fw = [&]() {
-            Frag fw;  // A operand W_kk: rows of its transpose
-            const double *wd = WdT + (size_t)k * 256 + rg * 16 + cl;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) fw.v[q] = wd[64 * q];
-            return fw;
-        };
-        auto inverse_one = [&](const Frag &fw) {
+        const double *dli_k = S.dli + (k & 1) * 16 * PS;  // L_kk^-1 = W_kk, left there by the chain of step k - 1
+        auto inverse_one = [&]() {
             int J = 0;
             if (lane == 0) J = atomicAdd(ctr_cur, 1);
             J = __builtin_amdgcn_readfirstlane(J);
             if (J >= k) return false;
-            inverse_tile(C_inv, fw, W_inv, cs_ptr(k, J), k, J, N, nb, lane);
+            inverse_tile(C_inv, dli_k, W_inv, cs_ptr(k, J), k, J, N, nb, lane);
             return true;
         };
         auto inverse_columns = [&]() {
             if (k < 1) return;
-            const Frag fw = load_fw();
-            while (inverse_one(fw)) {
+            while (inverse_one()) {
             }
         };
         TRACE(0);
@@ -346,7 +345,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 const bool ok = chol_inv_tile_acc(a, xi, lane, aug_tile == k + 1 ? aug_c : -1);
                 if (!ok && lane == 0) *S.flag = 1;
                 FSTAMP(9);
-                store_factored_tile(a, xi, nullptr, ld, S.dli, nullptr, WdT + (size_t)(k + 1) * 256, cs_ptr(k + 1, k + 1),
+                store_factored_tile(a, xi, nullptr, ld, S.dli + ((k + 1) & 1) * 16 * PS, nullptr, nullptr, cs_ptr(k + 1, k + 1),
                                     rows_valid(k + 1), lane);
                 st_pk(as_global(uniform_ptr(W)), base_pk, lane, xi);  // W_{k+1,k+1}
                 // L_{k+1,k+1}^-1 is in LDS: the waves holding tiles of column k + 1 may now turn them into panel k + 1
@@ -428,10 +427,9 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             if (cfirst < ncol) {
                 // L_{k+1,k+1}^-1 comes from wave 0's chain (~5 us into the step): inverse columns fill the wait
                 if (k >= 1) {
-                    const Frag fw = load_fw();
                     int spins = 0;
                     while (__hip_atomic_load(&S.flag[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) {
-                        if (!inverse_one(fw)) {
+                        if (!inverse_one()) {
                             __builtin_amdgcn_s_sleep(2);
                             if (++spins > (1 << 22)) {  // (never observed; a stuck flag must not hang the device)
                                 if (lane == 0) *S.flag = 1;
@@ -452,7 +450,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 TRACE(2);
                 Frag fx;  // L_{k+1,k+1}^-1: as A operand X, as B operand X^T
 #pragma unroll
-                for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[cl * PS + 4 * q + rg];
+                for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[((k + 1) & 1) * 16 * PS + cl * PS + 4 * q + rg];
                 for (int c = cfirst; c < ncol; c += NWK) {
                     const int i = c + 1;  // block row I = k + 1 + i
                     v4f64 t = ld_pk(src_u, base_pk + (unsigned)(k == 0 ? i * 2048 : i * nb * 2048), lane);
@@ -655,7 +653,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     Smem S;
     S.pan = smem;
     S.dli = S.pan + 2 * NP * PS;
-    S.p = S.dli + 16 * PS;
+    S.p = S.dli + 2 * 16 * PS;
     S.pold = S.p + NP;
     S.m = S.pold + NP;
     S.y = S.m + NP;
@@ -897,7 +895,7 @@ __global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int 
 }  // namespace
 
 size_t fh_k2_loop_smem_bytes(int NP) {
-    return sizeof(double) * (size_t)(2 * NP * PS + 16 * PS + 7 * NP + NP + 6 * NP + 2 * 6 * 4 * 64) + 16 * kMaxTiles + 32;
+    return sizeof(double) * (size_t)(2 * NP * PS + 2 * 16 * PS + 7 * NP + NP + 6 * NP + 2 * 6 * 4 * 64) + 16 * kMaxTiles + 32;
 }
 
 hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s) {
