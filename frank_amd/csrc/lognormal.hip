@@ -43,6 +43,14 @@ __shared__ long long ln_cyc[8];
 
 constexpr int LT = 512;        // threads per workgroup
 constexpr int LNW = LT / 64;   // waves
+// The thread index through an opaque move: every routine of this (one, very large) kernel forms its per-thread addresses where
+// it uses them.  Taken from threadIdx.x directly they are all invariants of the outer loops: hoisted to the top of the kernel,
+// kept alive across every phase and spilled (262 registers), with reloads inside the row loops.
+__device__ __forceinline__ int ln_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
 #ifndef LN_EVB
 #define LN_EVB 8
 #endif
@@ -172,7 +180,7 @@ __device__ __forceinline__ void block_min_sum(LnS &S, double &a, double &b) {
 //   along S^-1 xv = S.Sx + lam * S.col   (S.col: S^-1 p of this search; the unblocked LU's scratch, idle here)
 __device__ __forceinline__ double ln_eval(const LogNormalParams &P, LnS &S, const double *xv, double *Iv, double *Sxv, double *MIv,
                                           const double *sv, double *sdst, bool along, double lam) {
-    const int N = P.N, tid = threadIdx.x;
+    const int N = P.N, tid = ln_tid();
     LTIC();
     if (S.row >= 0 && S.pair) {
         const int o = S.c0 * N + S.row, N2 = N >> 1;
@@ -301,7 +309,7 @@ __device__ __forceinline__ double ln_grad(const LnS &S, int i) {
 // ld = P.NP: the padded copy for the tiled Cholesky (its padding rows and columns hold the identity: written once per
 // kernel, the factorisation leaves them as they are).
 __device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, double *out, int ld, bool outer_first) {
-    const int N = P.N, tid = threadIdx.x;
+    const int N = P.N, tid = ln_tid();
     LTIC();
     if ((N & 1) == 0) {
         // one wave per row, 16 bytes per lane and matrix, the loads of TWO rows issued before the first store: a single CU
@@ -382,7 +390,7 @@ __device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, dou
 __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S, double *Cp, double *Xd = nullptr) {
     using namespace tilechol;
     const int N = P.N, NP = P.NP, nb = NP / 16, ld = NP;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
+    const int tid = ln_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
     const int cl = lane & 15, rg = lane >> 4;
     double *pan = S.pan;                 // NP x PS panel (the LU panel's space: N * LU_NB doubles)
     double *dli = pan + NP * PS, *dvec = dli + 16 * PS, *rdv = dvec + NP;  // inverse of the current diagonal tile; diag(L), 1 / diag(L)
@@ -555,7 +563,7 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
 //   phase B: the scaled column is written back and the trailing block gets its rank-1 update.
 // A zero pivot leaves the column unscaled (LAPACK getf2 does the same and reports it).
 __device__ __forceinline__ void lu_factor(LnS &S, int N, double *A) {
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = ln_tid(), lane = tid & 63;
     LTIC();
     for (int i = tid; i < N; i += LT) S.perm[i] = i;
     __syncthreads();
@@ -636,7 +644,7 @@ __device__ __forceinline__ void lu_factor(LnS &S, int N, double *A) {
 // explicit block inverses (differences at round-off level).
 constexpr int LU_NB = 32;
 __device__ __forceinline__ void lu_factor_blocked(LnS &S, int N, double *A) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = ln_tid(), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = lane & 15, rg = lane >> 4;
     double *pan = S.pan;
     double *linv = S.part;                               // two 16 x 16 inverse blocks, k-major: [blk][k][i]
@@ -968,7 +976,7 @@ __device__ __forceinline__ void wave_sync() {  // LDS traffic between the lanes 
 // b == nullptr: the right-hand side is the unit vector e_unit.
 __device__ __forceinline__ void wave_solve(const LnS &S, int N, const double *A, const double *b, int unit, double sign,
                                            double *xs) {
-    const int lane = threadIdx.x & 63;
+    const int lane = ln_tid() & 63;
     for (int jj = lane; jj < N; jj += 64) xs[jj] = b ? sign * b[S.perm[jj]] : (S.perm[jj] == unit ? sign : 0.0);
     wave_sync();
     for (int k0 = 0; k0 < N; k0 += 64) {  // L y = P b, unit lower
@@ -1035,7 +1043,7 @@ __device__ __forceinline__ void wave_solve(const LnS &S, int N, const double *A,
 // split by column ranges over the 8 waves (partials through LDS); wave 0 then runs the substitution chain of the diagonal
 // block as wave_solve does.  wave_solve leaves seven waves idle for ~130 us per Newton step.  xs: LDS, N doubles.
 __device__ __forceinline__ void block_solve(LnS &S, int N, const double *A, const double *b, double sign, double *xs) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = ln_tid(), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *part = S.part;  // LNW x 64 partial sums
     for (int jj = tid; jj < N; jj += LT) xs[jj] = sign * b[S.perm[jj]];
     __syncthreads();
@@ -1134,7 +1142,7 @@ __device__ __forceinline__ void block_solve(LnS &S, int N, const double *A, cons
 }
 
 __device__ __forceinline__ void accept_trial(LnS &S, int N) {
-    for (int i = threadIdx.x; i < N; i += LT) {
+    for (int i = ln_tid(); i < N; i += LT) {
         S.x[i] = S.xn[i];
         S.I[i] = S.In[i];
         S.Sx[i] = S.Sxn[i];
@@ -1154,7 +1162,7 @@ __device__ __forceinline__ void accept_trial(LnS &S, int N) {
 // returns 0 accepted (x, fx updated; reduction too for the line search), 1 failed, -1 "Round off in slope calculation".
 __device__ __forceinline__ int backtrack(const LogNormalParams &P, LnS &S, const double *dir, double amin, double slope,
                                          bool fallback, double &fx, int &nfev, double &reduction) {
-    const int N = P.N, tid = threadIdx.x;
+    const int N = P.N, tid = ln_tid();
     const double armijo = 1e-4, l_min = 0.1;
     const double cost = fx;
     double alpha = 1.1 * amin;
@@ -1231,7 +1239,7 @@ struct NewtonExit {
 
 // MinimizeNewton(H, jac, hess, S.x, LineSearch(reduce_step=limit_step), tol=1e-7)  (minimizer.py:190-283)
 __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, LnS &S) {
-    const int N = P.N, tid = threadIdx.x;
+    const int N = P.N, tid = ln_tid();
     bool need_hess = true;
     int nfev = 1, nhess = 0;
     double reduction = NAN;  // LineSearch.reduction starts as None
@@ -1380,7 +1388,7 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
 // -- two strided 8-byte loads per multiply-add on one CU; this takes ~0.2 ms.)
 __device__ __forceinline__ void build_sinv(const LogNormalParams &P, const double *rk) {
     using namespace tilechol;
-    const int N = P.N, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
+    const int N = P.N, tid = ln_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
     const int cl = lane & 15, rg = lane >> 4;
     const int nbt = (N + 15) >> 4, G = (nbt + 1) >> 1, ngroups = G * (G + 1) / 2;
     const int ksteps = (N + 3) >> 2;
@@ -1458,7 +1466,7 @@ __device__ __forceinline__ void build_sinv(const LogNormalParams &P, const doubl
 __device__ __forceinline__ void tr2_solve(const LogNormalParams &P, LnS &S, const double *Xd, double *Wsc, double *tr2) {
     using namespace tilechol;
     const int N = P.N, NP = P.NP, nb = NP / 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
+    const int tid = ln_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
     const int cl = lane & 15, rg = lane >> 4;
     const double *dvec = S.pan + NP * PS + 16 * PS;  // diag(L), left in LDS by cholesky_as_lu
     const gdouble *lu = as_global(S.lu), *Y = as_global(P.Y), *X = as_global(Xd);
@@ -1574,7 +1582,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         P.result += 2 * f;
         P.stats += 17 * f;
     }
-    const int N = P.N, tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int N = P.N, tid = ln_tid(), w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     LnS S;
     {
         double *b = smem;
