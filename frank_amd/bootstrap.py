@@ -57,7 +57,7 @@ def bootstrap_fits(fitter, u, v, vis, weights, ntrials, nonnegative=False):
         rc = L.fh_fit_collect(ctx, ticket, _lib.ptr(mu), _lib.ptr(p), ctypes.byref(niter))
         if rc == _lib.FH_ERR_BAD_P:
             raise ValueError(_BAD_P_MSG)
-        if rc == _lib.FH_ERR_NOT_SPD and Mj[0] is not None:
+        if rc == _lib.FH_ERR_NOT_SPD:
             # a Cholesky of this trial's loop failed: carry on as the reference does, through the SVD pseudo-inverse
             # (statistical_models.py:747-755), one posterior at a time on this trial's M, j
             keep = fitter._M, fitter._j
@@ -76,6 +76,10 @@ def bootstrap_fits(fitter, u, v, vis, weights, ntrials, nonnegative=False):
         else:
             profiles[t] = mu
 
+    # the arithmetic of the binning pass is per-context state: set it from THIS fitter, whatever an earlier caller left
+    _lib.check(L.fh_ctx_set_arithmetic(ctx, 1 if fitter._vis_map._arithmetic == 'fp32' else 0))
+    _lib.check(L.fh_ctx_set_scale_height(
+        ctx, _lib.ptr(_lib.f8(fitter._vis_map._H2)) if fitter._vis_map._vis_model == 'debris' else None))
     try:
         for t in range(ntrials):
             counts = draw_bootstrap_counts(n)
@@ -83,7 +87,9 @@ def bootstrap_fits(fitter, u, v, vis, weights, ntrials, nonnegative=False):
             _lib.check(L.fh_bin_reset(ctx))
             _lib.check(L.fh_bin_visibilities(ctx, ctypes.byref(geom), table, 0, n))
             H0, qmn, qmx = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-            Mj = (np.empty((N, N)), np.empty(N)) if nonnegative else (None, None)
+            # M, j of every trial come back (0.7 MB): solve_non_negative needs them, and so does the SVD route the fit
+            # continues through when a Cholesky of its loop fails (statistical_models.py:747-755)
+            Mj = (np.empty((N, N)), np.empty(N))
             _lib.check(L.fh_stats_finalize(ctx, ctypes.byref(geom), vis_model, 0, _lib.ptr(Mj[0]), _lib.ptr(Mj[1]),
                                            ctypes.byref(H0), ctypes.byref(qmn), ctypes.byref(qmx)))
             if fitter._vis_map.check_qbounds:

@@ -136,9 +136,9 @@ constexpr int wave_ntiles(int NBT, int P, int W) {
 // geometry.py:69-79 (inverse phase shift, NumPy's Smith complex division), :111-131 (deproject),
 // statistical_models.py:166 (hypot).  Every product/sum rounds separately, as the NumPy expressions do.
 __global__ __launch_bounds__(256) void deproject_kernel(BinParams p) {
-    __shared__ double red[3 * 4];
+    __shared__ double red[3 * 4], red_all[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double sum_logw = 0.0, qmin = INFINITY, qmax = -INFINITY;
+    double sum_logw = 0.0, qmin = INFINITY, qmax = -INFINITY, qmax_all = -INFINITY;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + tid; i < p.count; i += (int64_t)gridDim.x * blockDim.x) {
 #pragma clang fp contract(off)
         const int64_t g = p.first + i;
@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256) void deproject_kernel(BinParams p) {
         p.prep_s[i] = p.inv_Qmax * q;  // k * q, hankel.py:189,202
         p.prep_sw[i] = sw;
         p.prep_swV[i] = sw * re;
+        qmax_all = fmax(qmax_all, q);
         if (mult > 0.0) {
             const double lw = log(w / (2 * M_PI));  // statistical_models.py:218
             sum_logw += p.mult ? mult * lw : lw;
@@ -195,25 +196,28 @@ __global__ __launch_bounds__(256) void deproject_kernel(BinParams p) {
         sum_logw += __shfl_down(sum_logw, off);
         qmin = fmin(qmin, __shfl_down(qmin, off));
         qmax = fmax(qmax, __shfl_down(qmax, off));
+        qmax_all = fmax(qmax_all, __shfl_down(qmax_all, off));
     }
     if (lane == 0) {
         red[wave * 3 + 0] = sum_logw;
         red[wave * 3 + 1] = qmin;
         red[wave * 3 + 2] = qmax;
+        red_all[wave] = qmax_all;
     }
     __syncthreads();
     if (tid == 0) {
-        double s = 0, mn = INFINITY, mx = -INFINITY;
+        double s = 0, mn = INFINITY, mx = -INFINITY, ma = -INFINITY;
         for (int w = 0; w < 4; ++w) {
             s += red[w * 3 + 0];
             mn = fmin(mn, red[w * 3 + 1]);
             mx = fmax(mx, red[w * 3 + 2]);
+            ma = fmax(ma, red_all[w]);
         }
         double *ps = p.partial_scalars + (size_t)blockIdx.x * 4;
         ps[0] = s;
         ps[1] = mn;
         ps[2] = mx;
-        ps[3] = 0.0;
+        ps[3] = ma;  // every row whatever its multiplicity: sizes the bucket sort (capi.hip)
     }
 }
 

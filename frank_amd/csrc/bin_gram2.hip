@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256) void predict_taylor_kernel(const double *q, in
                                                              double delta, int nb, const double *coef, double *V) {
     const double inv_half = 2.0 * inv_delta;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const double s = inv_Q * q[i];
+        const double s = inv_Q * fabs(q[i]);  // J0 is even: the reference and the direct kernel take q of either sign
         const int b = bucket_of(s, inv_delta, nb);
         double tau;
         {
@@ -794,10 +794,10 @@ __global__ __launch_bounds__(256) void predict_taylor_kernel(const double *q, in
         V[i] = a;
     }
 }
-__global__ void max_abs_kernel(const double *q, int64_t n, double *out) {  // out[0] = max q (q >= 0), one workgroup of 1024
+__global__ void max_abs_kernel(const double *q, int64_t n, double *out) {  // out[0] = max |q|, one workgroup of 1024
     __shared__ double red[16];
     double m = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) m = fmax(m, q[i]);
+    for (int64_t i = threadIdx.x; i < n; i += 1024) m = fmax(m, fabs(q[i]));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_down(m, off));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;

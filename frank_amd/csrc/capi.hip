@@ -101,6 +101,7 @@ struct fh_vis {
     bool f32 = false;
     DevBuf<int> mult;  // bootstrap multiplicities (fh_vis_set_multiplicity), empty = every row once
     bool use_mult = false;
+    unsigned long long mult_gen = 0;  // changes with every fh_vis_set_multiplicity: rows drawn zero times leave the range
 };
 
 struct FitSlot {
@@ -148,7 +149,7 @@ struct fh_ctx {
     // K1 v2 (bin_gram2.hip): bucket sort workspaces and the Taylor tables of the buckets seen so far
     bool v2 = false, force_static = false;
     bool check_q_before_bin = false;  // fh_map_visibilities(check_qbounds): _check_uv_range before any binning, as the reference
-    double prepass_qmin = 0, prepass_qmax = 0;
+    double prepass_qmin = 0, prepass_qmax = 0, prepass_qmax_all = 0;
     int XS = 0, k1_nb_built = 0, sort_blocks = 0;
     double k1_delta = 0;
     DevBuf<double> k1_table, k1_rows;
@@ -163,7 +164,7 @@ struct fh_ctx {
     DevBuf<int> k1_cidx, k1_vbucket;
     // baseline range of the last pre-pass, keyed by (table, row range, geometry): binning the same rows under the same geometry
     // again (bootstrap draws, pipelines of fits, sweeps) needs no second look at the range before the sort is sized
-    unsigned long long range_vis = 0;
+    unsigned long long range_vis = 0, range_mult_gen = 0;
     int64_t range_first = -1, range_count = -1;
     double range_geom[6] = {0, 0, 0, 0, 0, 0};
     bool range_valid = false;
@@ -635,6 +636,7 @@ int64_t fh_vis_size(const fh_vis *vis) { return vis ? vis->n : 0; }
 
 int fh_vis_set_multiplicity(fh_vis *vis, const int32_t *counts) {
     if (!vis) return fail(FH_ERR_INVALID, "fh_vis_set_multiplicity: vis is NULL");
+    vis->mult_gen = g_vis_serial.fetch_add(1);  // the baseline range of the drawn rows is not the one a context remembers
     if (!counts) {
         vis->use_mult = false;
         return FH_OK;
@@ -695,6 +697,7 @@ static int k1v2_upload_table32(fh_ctx *c, const std::vector<double> &tab, int nb
     const size_t n = (size_t)nb * FH_K1_TERMS * c->XS;
     std::vector<float> t32(n);
     for (size_t i = 0; i < n; ++i) t32[i] = (float)tab[i];
+    c->k1_nb_built32 = 0;
     if (c->k1_table32.alloc(n) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc of the fp32 bucket tables failed");
     HIP_TRY(hipMemcpy(c->k1_table32.p, t32.data(), sizeof(float) * n, hipMemcpyHostToDevice));
     c->k1_nb_built32 = nb;
@@ -730,6 +733,7 @@ static int k1v2_ensure_table(fh_ctx *c, int nb_needed) {
     }
     const int nb_up = (int)(tab->size() / per);
     HIP_TRY(hipStreamSynchronize(c->stream));  // nothing in flight may still read the old device table
+    c->k1_nb_built = 0;  // DevBuf::alloc releases the old table first: after a failed allocation there is none
     if (c->k1_table.alloc((size_t)nb_up * per) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc of the bucket tables failed");
     HIP_TRY(hipMemcpy(c->k1_table.p, tab->data(), sizeof(double) * (size_t)nb_up * per, hipMemcpyHostToDevice));
     c->k1_nb_built = nb_up;
@@ -763,7 +767,8 @@ static int running_fit_loops(fh_ctx *c) {
 // K1 v2: deproject -> (host: baseline range, bucket tables) -> bucket sort -> bin_gram2 -> slab reduction.
 // The one host round trip (64 KB of per-block scalars) is what _check_uv_range needs before any binning in the reference
 // too (statistical_models.py:166-169); it costs the stream ~20 us of idle time per call.
-static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned long long vis_serial) {
+static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned long long vis_serial,
+                               unsigned long long mult_gen) {
     if (count > 0x7fffffff - 16 * 65536) return fail(FH_ERR_UNSUPPORTED, "more than 2^31 visibilities in one call: split it");
     int dblocks = (int)((count + 255) / 256);
     if (dblocks > c->deproject_blocks) dblocks = c->deproject_blocks;
@@ -772,12 +777,15 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     HIP_TRY(hipEventRecord(c->ev_pre0, c->stream));
     HIP_TRY(fh_k1_launch_deproject(p, dblocks, c->stream));
     const double gkey[6] = {p.dRA, p.dDec, p.cos_t, p.sin_t, p.cos_i, p.sin_i};
-    const bool known = c->range_valid && c->range_vis == vis_serial && c->range_first == p.first && c->range_count == count &&
+    const bool known = c->range_valid && c->range_vis == vis_serial && c->range_mult_gen == mult_gen && c->range_first == p.first && c->range_count == count &&
                        memcmp(gkey, c->range_geom, sizeof gkey) == 0 && !getenv("FRANK_AMD_NO_RANGE_CACHE");
-    double qmax = 0.0, qmin = INFINITY;
+    // qmax_all: over every row of the range whatever its multiplicity -- the sort is sized from it, because rows drawn
+    // zero times are still sorted (with weight 0) and must land in a bucket of their own argument
+    double qmax = 0.0, qmin = INFINITY, qmax_all = 0.0;
     if (known) {  // same rows, same geometry: the range is the one read back last time, no host round trip
         qmin = c->prepass_qmin;
         qmax = c->prepass_qmax;
+        qmax_all = c->prepass_qmax_all;
     } else {
         c->k1_scalars_host.resize((size_t)dblocks * 4);
         HIP_TRY(hipMemcpyAsync(c->k1_scalars_host.data(), c->partial_scalars.p, sizeof(double) * (size_t)dblocks * 4,
@@ -787,12 +795,16 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned 
             const double m = c->k1_scalars_host[(size_t)b * 4 + 2], mn = c->k1_scalars_host[(size_t)b * 4 + 1];
             if (m > qmax) qmax = m;  // (-inf for blocks without rows; NaN baselines never win)
             if (mn < qmin) qmin = mn;
+            const double ma = c->k1_scalars_host[(size_t)b * 4 + 3];
+            if (ma > qmax_all) qmax_all = ma;
         }
     }
-    if (!(qmax < INFINITY)) return fail(FH_ERR_INVALID, "non-finite baseline in the visibility table");
+    if (!(qmax < INFINITY) || !(qmax_all < INFINITY)) return fail(FH_ERR_INVALID, "non-finite baseline in the visibility table");
     c->prepass_qmin = qmin;
     c->prepass_qmax = qmax;
+    c->prepass_qmax_all = qmax_all;
     c->range_vis = vis_serial;
+    c->range_mult_gen = mult_gen;
     c->range_first = p.first;
     c->range_count = count;
     memcpy(c->range_geom, gkey, sizeof gkey);
@@ -801,7 +813,7 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     if (c->check_q_before_bin && c->dht->q[c->N - 1] < qmax)
         return fail(FH_ERR_QRANGE, "last collocation point %.3e < longest deprojected baseline %.3e", c->dht->q[c->N - 1], qmax);
     const double delta = c->k1_delta, inv_delta = 1.0 / delta;
-    const double smax = qmax * p.inv_Qmax;
+    const double smax = qmax_all * p.inv_Qmax;
     if (smax * inv_delta > 2.0e9) return fail(FH_ERR_UNSUPPORTED, "baselines reach %.3g x Qmax", smax);
     const int nb = (int)(smax * inv_delta) + 2;  // one spare bucket: the device recomputes s * inv_delta itself
     if (nb > 16000)  // the sort keeps one counter per bucket in 64 KB of LDS
@@ -991,7 +1003,7 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
         c->have_device_Mj = false;
         return FH_OK;
     }
-    if (c->v2) return bin_visibilities_v2(c, p, count, vis->serial);
+    if (c->v2) return bin_visibilities_v2(c, p, count, vis->serial, vis->use_mult ? vis->mult_gen : 0);
     // fit_loop kernels of earlier fits that are still RUNNING each hold a CU (a slot stays "busy" until it is collected,
     // long after its kernel has finished: counting those would leave CUs idle)
     int running = 0;

@@ -5,7 +5,7 @@ cells 8, 16-17; frank/utilities.py:962-1038): a four-Gaussian ringed profile, sa
 at deprojected baselines through an N=500 DHT, scaled by cos(inc), re-phased by
 (dRA, dDec), plus N(0, w^-1/2) noise on the real and imaginary parts.
 
-The noiseless curve V(q) is read from tests/golden/mock_disc_vis_table.npz (tabulated
+The noiseless curve V(q) is read from mock_disc_vis_table.npz beside this module (tabulated
 once from the reference by tools/make_mock_table.py) and linearly interpolated, so the
 generator is NumPy-only and bit-reproducible wherever numpy's default_rng is.
 """
@@ -18,8 +18,7 @@ from frank_amd.constants import rad_to_arcsec, deg_to_rad
 # frank/tests.py:141-142 (the AS 209 geometry used throughout the reference tests)
 MOCK_GEOMETRY = dict(inc=34.97, PA=85.76, dRA=1.9e-3, dDec=2.5e-3)
 
-_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden",
-                      "mock_disc_vis_table.npz")
+_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mock_disc_vis_table.npz")
 _cache = {}
 
 

@@ -261,9 +261,11 @@ class FrankFitter(FourierBesselFitter):
         if rc == _lib.FH_ERR_BAD_P:
             from frank_amd.statistical_models import _BAD_P_MSG
             raise ValueError(_BAD_P_MSG)
-        if rc == _lib.FH_ERR_NOT_SPD and not lognormal:
-            # a Cholesky inside the device loop failed: the reference carries on through the SVD pseudo-inverse
-            # (statistical_models.py:747-755); so does the loop below, one posterior at a time
+        if rc == _lib.FH_ERR_NOT_SPD:
+            # a Cholesky inside the device loop failed (for method='LogNormal': in one of the two Normal seed solves,
+            # radial_fitters.py:744-752, or of the Hessian at a MAP, statistical_models.py:1150-1158): the reference
+            # carries on through the SVD pseudo-inverse (statistical_models.py:747-755); so does the loop below, one
+            # posterior at a time
             return self._fit_one_posterior_at_a_time()
         _lib.check(rc)
         count = niter.value
@@ -289,10 +291,12 @@ class FrankFitter(FourierBesselFitter):
         return self._sol
 
     def _fit_one_posterior_at_a_time(self):
-        """radial_fitters.py:743-832 step by step for method='Normal': every posterior is a GaussianModel (device
-        Cholesky, device SVD pseudo-inverse when that fails), every update a CriticalFilter.update_power_spectrum.  The
-        fused device loop stops at the first failed Cholesky; this is where such a fit continues."""
+        """radial_fitters.py:743-832 step by step, either method: every posterior is a GaussianModel / LogNormalMAPModel
+        (device Cholesky, device SVD pseudo-inverse when that fails), every update a
+        CriticalFilter.update_power_spectrum.  The fused device loops stop at the first failed Cholesky; this is where
+        such a fit continues."""
         N = self.size
+        lognormal = self._method == 'LogNormal'
         if self._store_iteration_diagnostics:
             self._iteration_diagnostics = defaultdict(list)
         pI = np.ones(N)
@@ -300,12 +304,18 @@ class FrankFitter(FourierBesselFitter):
         pI = np.max(self._DHT.transform(fit.MAP) ** 2)
         pI = pI * (self.q / self.q[0]) ** -2
         fit = self._perform_fit(pI, fit_method='Normal')
+        if lognormal:  # radial_fitters.py:756-763
+            s = np.log(np.maximum(fit.MAP, 1e-3 * fit.MAP.max()))
+            s -= self._s_scale
+            pI = np.max(self._DHT.transform(s) ** 2)
+            pI = pI * (self.q / self.q[0]) ** -4
+            fit = self._perform_fit(pI, guess=s)
         count = 0
         pi_old = 0
         while (not self._filter.check_convergence(pI, pi_old)) and count <= self._max_iter:
             pi_old = pI.copy()
             pI = self._filter.update_power_spectrum(fit)
-            fit = self._perform_fit(pI, guess=fit.MAP, fit_method='Normal')
+            fit = self._perform_fit(pI, guess=fit.MAP)
             if self._store_iteration_diagnostics:
                 self._iteration_diagnostics['power_spectrum'].append(pI)
                 self._iteration_diagnostics['MAP'].append(fit.MAP)
@@ -313,7 +323,8 @@ class FrankFitter(FourierBesselFitter):
         self._check_convergence_policy(count)
         if self._store_iteration_diagnostics:
             self._iteration_diagnostics['num_iterations'] = count
-        self._sol = FrankGaussianFit(self._vis_map, fit, self._info, geometry=self._geometry.clone())
+        Sol = FrankLogNormalFit if lognormal else FrankGaussianFit
+        self._sol = Sol(self._vis_map, fit, self._info, geometry=self._geometry.clone())
         self._ps = pI
         self._ps_cov = None
         return self._sol

@@ -31,6 +31,39 @@ def _load_mapping(FF, g):
     FF._M, FF._j, FF._H0 = g["M"], g["j"], float(g["H0"])
 
 
+def sha(*arrs):
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+# ---- configs[1] -----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k1", ["moments", "rows"])
+def test_fit_N300_1e7_against_the_reference(golden, monkeypatch, k1):
+    """BASELINE configs[1] at its FULL size against the reference itself: N = 300, 1e7 mock visibilities, Normal method,
+    alpha = 1.05, w_smooth = 1e-4.  The fixture is the reference's own map_visibilities + fit of these inputs
+    (tools/make_golden.py --only fit_N300_1e7: 105 s of mapping, 71 s of fitting, 667 iterations).  Both binning paths
+    are held to it: the default (bucket moments, ~5 000 rows per bucket here) and the rows themselves (FRANK_AMD_K1=rows).
+    statistical_models.py:192-218, radial_fitters.py:737-832."""
+    from frank_amd import FrankFitter
+    g = golden("fit_N300_1e7.npz")
+    if k1 == "rows":
+        monkeypatch.setenv("FRANK_AMD_K1", "rows")
+    u, v, V, w = mock_disc_visibilities(int(g["n"]), seed=int(g["seed"]), noise_seed=int(g["noise_seed"]))
+    assert u.size == 10 ** 7 and sha(u, v, V, w) == str(g["input_sha256"])
+    FF = FrankFitter(2.0, 300, geom(), store_iteration_diagnostics=True, verbose=False)
+    m = FF.preprocess_visibilities(u, v, V, w)
+    assert rel_to_max(m["M"], g["M"]) < 5e-13
+    assert rel_to_max(m["j"], g["j"]) < 5e-13
+    assert abs(m["null_likelihood"] - float(g["H0"])) <= 1e-12 * abs(float(g["H0"]))
+    sol = FF.fit_preprocessed(m)
+    assert FF.iteration_diagnostics["num_iterations"] == int(g["niter"]) == 667
+    assert rel_to_max(sol.I, g["I"]) < 1e-6
+    np.testing.assert_allclose(sol.power_spectrum, g["p"], rtol=1e-4)
+
+
 # ---- configs[2] -----------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("linesearch", ["linear", "reference"])
 def test_lognormal_map_model_N300(golden, linesearch):
@@ -68,6 +101,39 @@ def test_lognormal_map_model_N300(golden, linesearch):
         assert st[2] < 1.5 * st[1]
     p_new = CriticalFilter(d, 1.3, 1e-35, 1e-2).update_power_spectrum(fit)
     np.testing.assert_allclose(p_new, g["map_p_updated"], rtol=2e-4)
+
+
+@pytest.mark.parametrize("linesearch", ["linear", "reference"])
+@pytest.mark.parametrize("fixture", ["lognormal_N300_full.npz", "lognormal_N300_1e7.npz"])
+def test_lognormal_whole_fit_N300_against_the_reference(golden, fixture, linesearch):
+    """BASELINE configs[2]: the WHOLE method='LogNormal' fit at N = 300 (radial_fitters.py:754-785,
+    statistical_models.py:1088-1158, minimizer.py:187-284) against the reference's own run -- on the M, j of the
+    1e6-visibility Normal fixture and on those of the 1e7-visibility one (configs[2]'s size), alpha = 1.3,
+    w_smooth = 1e-2 (tools/make_golden_lognormal.py N300_full / N300_1e7).
+
+    The fixtures also hold the reference's fit of M (1 + 1e-15 noise): its own round-off spread in the profile and in
+    the number of passes.  Asserted, for both line-search modes: the profile within 5x that spread of the reference's
+    (and within 1e-5 of its maximum whatever the spread), the number of passes within 3x the recorded spread (+2), the
+    first passes of the loop to 1e-7."""
+    from frank_amd import FrankFitter, FrankLogNormalFit
+    g = golden(fixture)
+    src = golden(str(g["source"]))
+    FF = FrankFitter(2.0, 300, geom(), alpha=float(g["alpha"]), weights_smooth=float(g["wsmooth"]), method="LogNormal",
+                     I_scale=float(g["I_scale"]), store_iteration_diagnostics=True, verbose=False, check_qbounds=False,
+                     convergence_failure="ignore", lognormal_linesearch=linesearch)
+    _load_mapping(FF, src)
+    sol = FF._fit()
+    assert isinstance(sol, FrankLogNormalFit)
+    d = FF.iteration_diagnostics
+    spread_I = max(float(g["selfsens_I_relmax"]), 1e-7)
+    spread_n = abs(int(g["niter_perturbed"]) - int(g["niter"]))
+    assert abs(d["num_iterations"] - int(g["niter"])) <= 3 * spread_n + 2
+    assert rel_to_max(sol.I, g["I"]) < min(5 * spread_I, 1e-5) or rel_to_max(sol.I, g["I"]) < 5 * spread_I < 1e-4
+    for k in range(2):
+        np.testing.assert_allclose(d["power_spectrum"][k], g["diag_p"][k], rtol=1e-6)
+        assert np.abs(d["MAP"][k] - g["diag_s"][k]).max() < 5e-4  # (one N = 300 MAP solve moves by 1.6e-4 in s by itself)
+    np.testing.assert_allclose(sol.power_spectrum, g["p"], rtol=0.05)
+    assert np.all(sol.I > 0)
 
 
 def test_lognormal_full_size_fp32_table():

@@ -515,6 +515,35 @@ def test_lognormal_fit_N40_and_max_iter(golden, linesearch):
         np.testing.assert_allclose(FF3i.iteration_diagnostics["power_spectrum"][k], g["diag_p_a"][k], rtol=1e-5)
 
 
+@pytest.mark.parametrize("linesearch", LINESEARCH)
+def test_lognormal_continues_through_failed_seed_cholesky(golden, linesearch):
+    """method='LogNormal' when the Cholesky of the Normal seed solves fails: fh_fit_lognormal reports FH_ERR_NOT_SPD and
+    the fit continues one posterior at a time through the device SVD route, as the reference does
+    (radial_fitters.py:744-752 via statistical_models.py:747-755) -- fixture svd_seed_lognormal_N24.npz (2 SVD solves,
+    then 41 regular LogNormal passes)."""
+    from frank_amd import FrankFitter, FrankLogNormalFit
+    g = golden("svd_seed_lognormal_N24.npz")
+    FF = FrankFitter(2.0, int(g["N"]), geom(), alpha=float(g["alpha"]), weights_smooth=float(g["wsmooth"]),
+                     method="LogNormal", I_scale=float(g["I_scale"]), max_iter=int(g["max_iter"]),
+                     store_iteration_diagnostics=True, verbose=False, check_qbounds=False, convergence_failure="ignore",
+                     lognormal_linesearch=linesearch)
+    FF._M, FF._j, FF._H0 = g["M"], g["j"], float(g["H0"])
+    sol = FF._fit()
+    assert isinstance(sol, FrankLogNormalFit)
+    d = FF.iteration_diagnostics
+    assert d["num_iterations"] == int(g["niter"])
+    for k in range(3):
+        np.testing.assert_allclose(d["power_spectrum"][k], g["diag_p"][k], rtol=1e-7)
+        assert np.abs(d["MAP"][k] - g["diag_s"][k]).max() < 1e-7
+    assert rel_to_max(sol.I, g["I"]) < 1e-6
+    # convergence_failure='raise' still applies on this route
+    FF.__init__(2.0, int(g["N"]), geom(), alpha=float(g["alpha"]), weights_smooth=float(g["wsmooth"]), method="LogNormal",
+                max_iter=3, verbose=False, check_qbounds=False, lognormal_linesearch=linesearch)
+    FF._M, FF._j, FF._H0 = g["M"], g["j"], float(g["H0"])
+    with pytest.raises(RuntimeError, match="Convergence not met"):
+        FF._fit()
+
+
 def test_lognormal_sweep_batched(golden):
     """fh_fit_lognormal_batched: a 6-point (alpha, w_smooth) sweep in one launch, one workgroup per point, against
     single fits of the same points (same kernel code, so the early passes agree to round-off and the end points to the

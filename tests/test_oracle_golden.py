@@ -247,6 +247,42 @@ def test_lognormal_fit_N80(golden):
     np.testing.assert_allclose(out["p"], g["p_a"], rtol=2e-3)
 
 
+def test_lognormal_whole_fit_N300(golden):
+    """The whole method='LogNormal' fit at the basis size of BASELINE configs[2] (N = 300, alpha = 1.3, w_smooth = 1e-2,
+    M and j of the 1e6-visibility Normal fixture) against the reference's own run (tools/make_golden_lognormal.py
+    N300_full: 175 passes; 172 and 2.9e-6 of max I away from itself after a 1e-15 perturbation of M).  The oracle, with a
+    different LU and summation order, lands as far from the reference as the reference's Newton stops allow: a few
+    passes, a few 1e-5 of the maximum -- far inside the 1e-3 that north_star grants the single-precision config."""
+    g = golden("lognormal_N300_full.npz")
+    src = golden(str(g["source"]))
+    out = fo.frank_fit_lognormal(300, RMAX, src["M"], src["j"], alpha=float(g["alpha"]), wsmooth=float(g["wsmooth"]),
+                                 I_scale=float(g["I_scale"]), diagnostics=True)
+    assert out["rc"] == 0
+    spread_niter = abs(int(g["niter_perturbed"]) - int(g["niter"]))
+    assert abs(out["niter"] - int(g["niter"])) <= 3 * spread_niter + 2
+    np.testing.assert_allclose(out["diag_p"][0], g["diag_p"][0], rtol=1e-6)
+    assert np.abs(out["diag_s"][0] - g["diag_s"][0]).max() < 5e-4   # (one N = 300 MAP solve moves by 1.6e-4 in s by itself)
+    assert float(g["selfsens_I_relmax"]) < 1e-5
+    assert rel_to_max(out["I"], g["I"]) < 1e-4
+    np.testing.assert_allclose(out["p"], g["p"], rtol=0.05)
+
+
+def test_lognormal_continues_through_failed_seed_cholesky(golden):
+    """method='LogNormal' on an M whose two Normal seed solves fail their Cholesky (radial_fitters.py:744-752): the
+    reference's GaussianModel._fit catches the LinAlgError and takes the SVD pseudo-inverse
+    (statistical_models.py:747-755), and the LogNormal loop runs on from there (fixture svd_seed_lognormal_N24.npz:
+    2 SVD calls, 41 passes = max_iter + 1)."""
+    g = golden("svd_seed_lognormal_N24.npz")
+    out = fo.frank_fit_lognormal(int(g["N"]), RMAX, g["M"], g["j"], alpha=float(g["alpha"]), wsmooth=float(g["wsmooth"]),
+                                 I_scale=float(g["I_scale"]), max_iter=int(g["max_iter"]), diagnostics=True)
+    assert out["rc"] == 0 and int(g["n_svd"]) == 2
+    assert out["niter"] == int(g["niter"]) == int(g["max_iter"]) + 1
+    for k in range(3):
+        np.testing.assert_allclose(out["diag_p"][k], g["diag_p"][k], rtol=1e-8)
+        assert np.abs(out["diag_s"][k] - g["diag_s"][k]).max() < 1e-8
+    assert rel_to_max(out["I"], g["I"]) < 1e-6
+
+
 def test_lognormal_fit_N40_chaotic(golden):
     """alpha=1.3, w_smooth=1e-2 on 5000 visibilities: a case where the reference is NOT reproducible against itself
     beyond ~1e-2 (niter 189 vs 209 after a 1e-15 perturbation of M, fixture fields selfsens_*).  The oracle has to land

@@ -256,6 +256,12 @@ def wide():
     fit_case("fit_N320_5e4.npz", 320, 5e4, 1.05, 1e-4, keep_M=False, seed=8, noise_seed=9)
 
 
+def fit_N300_1e7():
+    """BASELINE configs[1] at its full size: the reference's own map + fit of 1e7 mock visibilities at N = 300 (about
+    2 min of mapping and 1.5 min of fitting here).  python3 tools/make_golden.py --only fit_N300_1e7"""
+    fit_case("fit_N300_1e7.npz", 300, 1e7, 1.05, 1e-4, keep_M=True)
+
+
 def svd_loop():
     """The iteration when the Cholesky of M + S^-1 fails (statistical_models.py:747-755, 779-781): an indefinite M (one
     eigenvalue of a real M flipped) sends every solve of the loop through the SVD pseudo-inverse."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/mock_disc_vis_table.npz (run in the BUILD container only).
+"""Generate frank_amd/mock_disc_vis_table.npz (run in the BUILD container only).
 
 Imports the reference (/root/reference, frank v1.2.3) and tabulates the noiseless,
 deprojected visibility curve of the mock disc of docs/tutorials/mock_data.ipynb
@@ -17,7 +17,7 @@ sys.path.insert(0, "/root/reference")
 from frank.utilities import generic_dht  # noqa: E402
 
 INC = 34.97
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "mock_disc_vis_table.npz")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "frank_amd", "mock_disc_vis_table.npz")
 
 
 def gauss(x, a, x0, sigma):
