@@ -130,7 +130,7 @@ def test_lognormal_whole_fit_N300_against_the_reference(golden, fixture, linesea
     assert abs(d["num_iterations"] - int(g["niter"])) <= 3 * spread_n + 2
     assert rel_to_max(sol.I, g["I"]) < min(5 * spread_I, 1e-5) or rel_to_max(sol.I, g["I"]) < 5 * spread_I < 1e-4
     for k in range(2):
-        np.testing.assert_allclose(d["power_spectrum"][k], g["diag_p"][k], rtol=1e-6)
+        np.testing.assert_allclose(d["power_spectrum"][k], g["diag_p"][k], rtol=1e-4)
         assert np.abs(d["MAP"][k] - g["diag_s"][k]).max() < 5e-4  # (one N = 300 MAP solve moves by 1.6e-4 in s by itself)
     np.testing.assert_allclose(sol.power_spectrum, g["p"], rtol=0.05)
     assert np.all(sol.I > 0)

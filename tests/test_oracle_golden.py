@@ -260,7 +260,7 @@ def test_lognormal_whole_fit_N300(golden):
     assert out["rc"] == 0
     spread_niter = abs(int(g["niter_perturbed"]) - int(g["niter"]))
     assert abs(out["niter"] - int(g["niter"])) <= 3 * spread_niter + 2
-    np.testing.assert_allclose(out["diag_p"][0], g["diag_p"][0], rtol=1e-6)
+    np.testing.assert_allclose(out["diag_p"][0], g["diag_p"][0], rtol=1e-4)
     assert np.abs(out["diag_s"][0] - g["diag_s"][0]).max() < 5e-4   # (one N = 300 MAP solve moves by 1.6e-4 in s by itself)
     assert float(g["selfsens_I_relmax"]) < 1e-5
     assert rel_to_max(out["I"], g["I"]) < 1e-4
