@@ -41,6 +41,7 @@
 #define FH_J0_HORNER 1
 #include "bessel.h"
 #include "kernels.h"
+#include "deproject.h"
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
@@ -142,44 +143,15 @@ __global__ __launch_bounds__(256) void deproject_kernel(BinParams p) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + tid; i < p.count; i += (int64_t)gridDim.x * blockDim.x) {
 #pragma clang fp contract(off)
         const int64_t g = p.first + i;
-        double u, v, Vre, Vim, w;
-        if (p.u32) {  // fp32 table: widened here, everything after it is the fp64 path
-            u = (double)p.u32[g];
-            v = (double)p.v32[g];
-            Vre = (double)p.Vre32[g];
-            Vim = p.Vim32 ? (double)p.Vim32[g] : 0.0;
-            w = (double)p.w32[p.w_scalar ? 0 : g];
-        } else {
-            // (streamed once: non-temporal, so that the pass does not push the fit loops' working sets out of L2)
-            u = __builtin_nontemporal_load(&p.u[g]);
-            v = __builtin_nontemporal_load(&p.v[g]);
-            Vre = __builtin_nontemporal_load(&p.Vre[g]);
-            Vim = p.Vim ? __builtin_nontemporal_load(&p.Vim[g]) : 0.0;
-            w = p.w_scalar ? p.w[0] : __builtin_nontemporal_load(&p.w[g]);
-        }
+        const VisRow r = fh_load_row(p, g);
+        const double u = r.u, v = r.v, w = r.w;
         // multiplicity of the row in a bootstrap resample (utilities.py:632-666): c copies of a row contribute
         // c w h h^T, c w V h, c (log(w/2pi) - w V^2); rows drawn zero times drop out of min/max q as well
         const double mult = p.mult ? (double)p.mult[g] : 1.0;
-        const double phi = u * p.dRA + v * p.dDec;
-        double sn, cs;
-        sincos(phi, &sn, &cs);
-        double re;
-        if (fabs(cs) >= fabs(sn)) {
-            const double rat = sn / cs, scl = 1.0 / (cs + sn * rat);
-            re = (Vre + Vim * rat) * scl;
-        } else {
-            const double rat = cs / sn, scl = 1.0 / (sn + cs * rat);
-            re = (Vre * rat + Vim) * scl;
-        }
-        double up = u * p.cos_t - v * p.sin_t;
-        const double vp = u * p.sin_t + v * p.cos_t;
-        up = up * p.cos_i;
-        const double q = hypot(up, vp);
+        const double re = fh_phase_centre_re(p, u, v, r.Vre, r.Vim);
+        const double q = fh_deproject_q(p, u, v);
         const double sw = p.mult ? sqrt(mult * w) : sqrt(w);
-        if (p.prep_k2) {  // debris model: vertical uv-distance of the 3-D deprojection, wp = up sin(inc) (geometry.py:128)
-            const double wz = (u * p.cos_t - v * p.sin_t) * p.sin_i;
-            p.prep_k2[i] = wz * wz;
-        }
+        if (p.prep_k2) p.prep_k2[i] = fh_deproject_kz2(p, u, v);  // debris model
         p.prep_s[i] = p.inv_Qmax * q;  // k * q, hankel.py:189,202
         p.prep_sw[i] = sw;
         p.prep_swV[i] = sw * re;

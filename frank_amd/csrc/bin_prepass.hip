@@ -1,0 +1,582 @@
+// K1 pre-pass of the moments path (round 3): from the visibility table to one 16 x 16 chunk of "virtual rows" per J0 bucket
+// in three streaming passes and two small kernels, 1.05 GB of HBM traffic per 1e7 visibilities (round 2: 1.9 GB in eight
+// kernels: deproject -> s, sqrt(w), sqrt(w) V' -> histogram -> scan -> starts -> scatter -> chunk map -> compact ->
+// moments -> factor).
+//
+// Replaces, for the default (moments) path of VisibilityMapping.map_visibilities (statistical_models.py:109-237):
+// geometry.apply_correction (geometry.py:69-79, 111-131), q = hypot(u', v') (:166), and the grouping of the rows by the
+// bucket of their J0 argument (bin_gram2.hip).  The rows path (FRANK_AMD_K1=rows, the debris model, fp32 arithmetic)
+// keeps deproject_kernel + the sort of bin_gram2.hip.
+//
+//   P1 uv_hist_kernel            reads u, v only (16 B / row): bucket of every row, one histogram per workgroup (its rows are a
+//                                fixed set: tiles of 1024 rows dealt round-robin), the baseline range of the pass
+//   -- bucket_scan_kernel        exclusive prefix over the workgroups per bucket; the LAST workgroup to finish lays out the
+//                                sorted table (bucket starts aligned to 16 rows), numbers the non-empty buckets and counts
+//                                the pieces P3 cuts the buckets into (a (u, v) distribution piles up at short baselines:
+//                                buckets differ by 1e4 in size)
+//   P2 deproject_scatter_kernel  reads the five columns (40 B / row), phase-centres and deprojects, and writes the row
+//                                (tau, sqrt(w), sqrt(w) Re V': 24 B) at its place: bucket start + rows of the bucket in
+//                                earlier workgroups + in earlier tiles, waves, lanes of this workgroup -- no atomics, two
+//                                barriers per tile, the same place in every run; sum log(w / 2 pi) rides along
+//   P3 piece_moments_kernel      one wave per piece (the rows of a bucket inside one 4096-row segment of the sorted table):
+//                                23 moments of tau, 12 of V tau^n, sum w V^2 (16-byte loads)
+//   -- bucket_factor2_kernel     per bucket: pieces added in order, Cholesky factor of the 13 x 13 moment matrix =
+//                                13 virtual rows (bin_gram2.hip explains why this is exact to round-off)
+//
+// What a row costs: 16 + 40 + 24 + 24 = 104 B against the 40 B it holds; the sort cannot do with less than one look at
+// (u, v) before it knows where a row goes.
+#include <hip/hip_runtime.h>
+
+#include "deproject.h"
+#include "j0_buckets.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int kTerms = FH_K1_TERMS;          // 12
+constexpr int kMom = 2 * kTerms - 1;         // moments 0 .. 22 of tau
+constexpr int kMomAll = kMom + kTerms + 1;   // + nu_0 .. nu_11 + eta = 36
+constexpr int kScanGroups = 16;
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// ---- P1 ------------------------------------------------------------------------------------------------------------
+// Workgroup k of the pass owns the tiles t = k, k + G, ... of 64 x (waves per workgroup) rows (the same in P1 and P2).
+// hist[workgroup][b] = rows of bucket b among the workgroup's rows (LDS integer atomics: the counts do not depend on their order);
+// partial_scalars[workgroup] = (-, qmin, qmax over rows of multiplicity > 0, qmax over all rows)
+template <bool HIST>
+__global__ __launch_bounds__(1024) void uv_hist_kernel(PrepassParams P) {
+    extern __shared__ int lds_i[];
+    __shared__ double red[3][16];
+    const BinParams &p = P.bin;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    if (HIST) {
+        for (int b = threadIdx.x; b < P.nb; b += blockDim.x) lds_i[b] = 0;
+        __syncthreads();
+    }
+    double qmin = INFINITY, qmax = -INFINITY, qmax_all = -INFINITY;
+    const int tile = blockDim.x;
+    const int64_t ntiles = (p.count + tile - 1) / tile;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t i = t * tile + threadIdx.x;
+        if (i < p.count) {
+            double u, v;
+            fh_load_uv(p, p.first + i, u, v);
+            const int mult = p.mult ? p.mult[p.first + i] : 1;
+            const double q = fh_deproject_q_fast(p, u, v);
+            qmax_all = fmax(qmax_all, q);
+            if (mult > 0) {
+                qmin = fmin(qmin, q);
+                qmax = fmax(qmax, q);
+            }
+            if (HIST) atomicAdd(&lds_i[fh_bucket_of(p.inv_Qmax * q, P.inv_delta, P.nb)], 1);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        qmin = fmin(qmin, __shfl_down(qmin, off));
+        qmax = fmax(qmax, __shfl_down(qmax, off));
+        qmax_all = fmax(qmax_all, __shfl_down(qmax_all, off));
+    }
+    if (lane == 0) {
+        red[0][wave] = qmin;
+        red[1][wave] = qmax;
+        red[2][wave] = qmax_all;
+    }
+    __syncthreads();
+    if (HIST) {
+        int *row = P.hist + (size_t)blockIdx.x * P.nb;
+        for (int b = threadIdx.x; b < P.nb; b += blockDim.x) row[b] = lds_i[b];
+    }
+    if (threadIdx.x == 0) {
+        double mn = INFINITY, mx = -INFINITY, ma = -INFINITY;
+        for (int w = 0; w < wpb; ++w) {
+            mn = fmin(mn, red[0][w]);
+            mx = fmax(mx, red[1][w]);
+            ma = fmax(ma, red[2][w]);
+        }
+        double *ps = P.partial_scalars + (size_t)blockIdx.x * 4;
+        ps[1] = mn;
+        ps[2] = mx;
+        ps[3] = ma;
+    }
+}
+
+// ---- scan + layout -----------------------------------------------------------------------------------------------
+// hist[workgroup][bucket] -> rows of the bucket in earlier workgroups (in place); totals[bucket].  A workgroup of the scan
+// takes 64 buckets (one per lane: rows of `hist` are read 256 bytes at a time), its 16 thread groups 16 contiguous ranges
+// of rows.  The last workgroup to arrive (ticket in info[3]) then does the serial part on the totals -- O(buckets):
+//   starts[b]   first sorted row of bucket b (multiple of 16; the <= 15 padding rows behind a bucket are zeroed),
+//   cidx[b]     number of non-empty buckets before b; info[1] their total,
+//   piece0[b]   first slot of the bucket's partial moments: P3 cuts the SORTED TABLE into segments of seg_rows rows, bucket b
+//               meets the segments starts[b] / seg_rows .. (starts[b] + tot - 1) / seg_rows, one slot each.
+__global__ __launch_bounds__(1024) void bucket_scan_kernel(PrepassParams P) {
+    __shared__ int part[kScanGroups][64];
+    __shared__ int sc[3][1024];
+    __shared__ int last;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int nb = P.nb, nw = P.blocks;
+    {
+        const int b = blockIdx.x * 64 + lane;
+        const int per = (nw + kScanGroups - 1) / kScanGroups, k0 = min(nw, g * per), k1 = min(nw, k0 + per);
+        int sum = 0;
+        if (b < nb) {
+#pragma unroll 8
+            for (int k = k0; k < k1; ++k) sum += P.hist[(size_t)k * nb + b];
+        }
+        part[g][lane] = sum;
+        __syncthreads();
+        int run = 0;
+        for (int hh = 0; hh < g; ++hh) run += part[hh][lane];
+        if (b < nb) {
+#pragma unroll 8
+            for (int k = k0; k < k1; ++k) {
+                const int v = P.hist[(size_t)k * nb + b];
+                P.hist[(size_t)k * nb + b] = run;
+                run += v;
+            }
+            if (g == kScanGroups - 1) P.totals[b] = run;
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&P.info[3], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const int t = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    const int b0 = min(nb, t * per), b1 = min(nb, b0 + per);
+    const int seg = P.seg_rows;
+    // pass 1: padded rows and non-empty buckets of this thread's range
+    int s_rows = 0, s_ne = 0;
+    for (int b = b0; b < b1; ++b) {
+        const int tot = __hip_atomic_load(&P.totals[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (other workgroups' writes)
+        s_rows += (tot + 15) & ~15;
+        s_ne += tot > 0;
+    }
+    sc[0][t] = s_rows;
+    sc[1][t] = s_ne;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scans
+        int a0 = 0, a1 = 0;
+        if (t >= off) {
+            a0 = sc[0][t - off];
+            a1 = sc[1][t - off];
+        }
+        __syncthreads();
+        sc[0][t] += a0;
+        sc[1][t] += a1;
+        __syncthreads();
+    }
+    // pass 2: starts, indices, padding; the pieces of each bucket (their number needs the bucket's start)
+    int r_rows = sc[0][t] - s_rows, r_ne = sc[1][t] - s_ne, s_pc = 0;
+    for (int b = b0; b < b1; ++b) {
+        const int tot = __hip_atomic_load(&P.totals[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int pad = (tot + 15) & ~15;
+        P.starts[b] = r_rows;
+        P.cidx[b] = r_ne;
+        for (int r = tot; r < pad; ++r) {
+            double *z = P.rows + ((size_t)r_rows + r) * 3;
+            z[0] = z[1] = z[2] = 0.0;
+        }
+        s_pc += tot > 16 ? (r_rows + tot - 1) / seg - r_rows / seg + 1 : 0;
+        r_rows += pad;
+        r_ne += tot > 0;
+    }
+    sc[2][t] = s_pc;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int a2 = t >= off ? sc[2][t - off] : 0;
+        __syncthreads();
+        sc[2][t] += a2;
+        __syncthreads();
+    }
+    int r_pc = sc[2][t] - s_pc;
+    r_rows = sc[0][t] - s_rows;
+    for (int b = b0; b < b1; ++b) {
+        const int tot = __hip_atomic_load(&P.totals[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        P.piece0[b] = r_pc;
+        r_pc += tot > 16 ? (r_rows + tot - 1) / seg - r_rows / seg + 1 : 0;
+        r_rows += (tot + 15) & ~15;
+    }
+    if (t == 1023) {
+        P.starts[nb] = sc[0][1023];
+        P.piece0[nb] = sc[2][1023];
+        P.info[0] = sc[0][1023] / 16;
+        P.info[1] = sc[1][1023];
+        P.info[2] = (sc[0][1023] + seg - 1) / seg;  // segments of the sorted table
+        P.info[3] = 0;                               // the ticket of the next pass
+    }
+}
+
+// ---- P2 ------------------------------------------------------------------------------------------------------------
+// Stable scatter without atomics.  A workgroup owns the same tiles of rows as in P1 and keeps ONE write front per bucket
+// (cnt[b] in LDS, starting at bucket start + rows of the bucket in earlier workgroups): 256 fronts x the buckets are a few MB of
+// partly written lines, which the L2 merges (one front per WAVE was 16 x as many: 1.8 x the bytes went to memory).  Inside a
+// tile a row's place is front + rows of its bucket in earlier waves of the tile + rows of its bucket in earlier lanes of its
+// wave: per 64 rows the lanes of equal bucket find each other with one ballot per bucket-index bit, the first of them
+// publishes their number (wc[wave][b]); after one barrier it adds up the earlier waves' numbers; after a second one the
+// first wave that holds the bucket advances the front.  The same place in every run.
+// The per-row arithmetic is the fast set of deproject.h (the pass was half bound by fp64 vector instructions); the sum of
+// log(w / 2 pi) (statistical_models.py:218) is the log of a running product -- mantissa and exponent kept apart, one
+// logarithm per lane at the end instead of one per row, and a smaller rounding error than the sum of the logarithms.
+// MULT: bootstrap multiplicities (fh_vis_set_multiplicity); F32: the table is stored in single precision; SAFE: phases beyond
+// 1e5 rad may occur (the host bounds them by (|dRA| + |dDec|) qmax / cos(inc)), the library's sincos takes them.
+// The loop is straight-line -- loads and stores are never skipped (rows past the end read the last row and write a dummy row
+// behind the table) -- so that the compiler counts its outstanding memory operations exactly: the next tile's loads are
+// waited for with the current tile's stores still in flight.
+template <bool MULT, bool F32, bool SAFE>
+__global__ __launch_bounds__(1024) void deproject_scatter_kernel(PrepassParams P, int nbits) {
+    extern __shared__ int lds_i[];  // cnt[nb], wc[wpb][nb]
+    __shared__ double red[16];
+    const BinParams &p = P.bin;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int nb = P.nb;
+    int *cnt = lds_i, *wc = lds_i + nb;
+    {
+        const int *wg = P.hist + (size_t)blockIdx.x * nb;
+        for (int b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = P.starts[b] + wg[b];
+        for (int e = threadIdx.x; e < wpb * nb; e += blockDim.x) wc[e] = 0;
+    }
+    const double inv_half = 2.0 * P.inv_delta;
+    double sum_logw = 0.0;      // rows with multiplicities: the plain sum
+    double pm = 1.0;            // mantissa of the product of the weights, in [0.5, 1)
+    int pe = 0, pn = 0;         // its exponent; the number of rows in it
+    const int tile = blockDim.x;
+    const int64_t ntiles = (p.count + tile - 1) / tile;
+    const int64_t last = p.first + p.count - 1;
+    const size_t dummy = (size_t)P.dummy_row;
+    // (columns that do not exist are read from one that does and then ignored)
+    const double *colVim = p.Vim ? p.Vim : p.Vre;
+    const float *colVim32 = p.Vim32 ? p.Vim32 : p.Vre32;
+    const bool has_im = F32 ? p.Vim32 != nullptr : p.Vim != nullptr;
+    VisRow r;
+    int rmult = 1;
+    auto fetch = [&](int64_t tt) {
+        int64_t g = p.first + tt * tile + threadIdx.x;
+        g = g < last ? g : last;
+        const int64_t gw = p.w_scalar ? 0 : g;
+        if (F32) {
+            r.u = (double)p.u32[g];
+            r.v = (double)p.v32[g];
+            r.Vre = (double)p.Vre32[g];
+            r.Vim = (double)colVim32[g];
+            r.w = (double)p.w32[gw];
+        } else {
+            r.u = __builtin_nontemporal_load(&p.u[g]);
+            r.v = __builtin_nontemporal_load(&p.v[g]);
+            r.Vre = __builtin_nontemporal_load(&p.Vre[g]);
+            r.Vim = __builtin_nontemporal_load(&colVim[g]);
+            r.w = __builtin_nontemporal_load(&p.w[gw]);
+        }
+        if (MULT) rmult = p.mult[g];
+    };
+    fetch(blockIdx.x);
+    __syncthreads();
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t i = t * tile + threadIdx.x;
+        const bool active = i < p.count;
+        const VisRow c = r;
+        const double cm = MULT ? (double)rmult : 1.0;
+        fetch(t + gridDim.x);  // the next tile's row is in flight during this tile's arithmetic and barriers
+        const double Vim = has_im ? c.Vim : 0.0;
+        const double re = SAFE ? fh_phase_centre_re(p, c.u, c.v, c.Vre, Vim) : fh_phase_centre_re_fast(p, c.u, c.v, c.Vre, Vim);
+        const double q = fh_deproject_q_fast(p, c.u, c.v);
+        const double sw = MULT ? sqrt(cm * c.w) : sqrt(c.w);
+        const double s = p.inv_Qmax * q;  // k * q, hankel.py:189,202
+        const double swV = sw * re;
+        if (MULT) {
+            if (active && cm > 0.0) sum_logw += cm * log(c.w / (2 * M_PI));
+        } else {
+            int e1, e2;
+            const double m1 = frexp(active ? c.w : 1.0, &e1);
+            pm = frexp(pm * m1, &e2);
+            pe += e1 + e2;
+            pn += active ? 1 : 0;
+            if (active && !(c.w > 0.0)) pm = c.w == 0.0 ? 0.0 : NAN;  // log(0) = -inf, log(negative) = NaN, as the reference's sum
+        }
+        const int b = fh_bucket_of(s, P.inv_delta, nb);
+        unsigned long long peers = __ballot(active);
+        for (int bit = 0; bit < nbits; ++bit) {
+            const bool one = (b >> bit) & 1;
+            const unsigned long long m = __ballot(one);
+            peers &= one ? m : ~m;
+        }
+        const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+        const int leader = __ffsll((long long)peers) - 1;
+        const bool lead = active && rank == 0;
+        const int npeers = __popcll(peers);
+        if (lead) wc[wave * nb + b] = npeers;
+        __syncthreads();
+        int base = 0, before = 0, total = 0;
+        if (lead) {
+            for (int w = 0; w < wpb; ++w) {
+                const int v = wc[w * nb + b];
+                total += v;
+                before += w < wave ? v : 0;
+            }
+            base = cnt[b] + before;
+        }
+        __syncthreads();
+        if (lead) {
+            if (before == 0) cnt[b] += total;  // (the first wave of the tile that holds the bucket)
+            wc[wave * nb + b] = 0;
+        }
+        base = __shfl(base, leader < 0 ? 0 : leader);
+        {
+            // 24-byte rows: the 16-byte aligned pair in one store, the third double in another (no branch)
+            const size_t row = active ? (size_t)base + rank : dummy;
+            double *o = P.rows + row * 3;
+            const double tau = fh_bucket_tau(s, b, P.delta, inv_half);
+            const bool odd = row & 1;
+            *reinterpret_cast<d2 *>(o + (odd ? 1 : 0)) = odd ? d2{sw, swV} : d2{tau, sw};
+            o[odd ? 0 : 2] = odd ? tau : swV;
+        }
+    }
+    if (!MULT) sum_logw = (log(pm) + (double)pe * M_LN2) - (double)pn * log(2 * M_PI);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum_logw += __shfl_down(sum_logw, off);
+    if (lane == 0) red[wave] = sum_logw;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sacc = 0.0;
+        for (int w = 0; w < wpb; ++w) sacc += red[w];
+        P.partial_scalars[(size_t)blockIdx.x * 4] = sacc;
+    }
+}
+
+// ---- P3 ------------------------------------------------------------------------------------------------------------
+// One wave per PIECE = the rows of one bucket inside one segment of the sorted table (seg_rows rows; a bucket of more than
+// 16 rows has piece0[b + 1] - piece0[b] of them, small buckets one).  The wave finds its bucket by bisection of piece0 (staged
+// in LDS); lane l takes rows 2l, 2l + 1 of every group of 128 -- three 16-byte loads --, then a butterfly over the lanes;
+// fixed order, same bits in every run.
+__global__ __launch_bounds__(256) void piece_moments_kernel(PrepassParams P) {
+    extern __shared__ int p0s[];  // piece0[0 .. nb]
+    const int nb = P.nb;
+    for (int b = threadIdx.x; b <= nb; b += 256) p0s[b] = P.piece0[b];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int pc = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pc >= p0s[nb]) return;
+    int lo = 0, hi = nb;  // the bucket with piece0[b] <= pc < piece0[b + 1] (buckets without pieces have equal neighbours)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (p0s[mid] <= pc) lo = mid;
+        else hi = mid;
+    }
+    const int b = lo, k = pc - p0s[b];
+    const int tot = P.totals[b], st = P.starts[b], seg = P.seg_rows;
+    const int sg = st / seg + k;
+    const int r0 = max(sg * seg, st), r1 = min((sg + 1) * seg, st + tot);  // sorted rows of the piece (r0 a multiple of 16)
+    const double *rb = P.rows;
+    double mu[kMom], nu[kTerms], eta = 0.0;
+#pragma unroll
+    for (int m = 0; m < kMom; ++m) mu[m] = 0.0;
+#pragma unroll
+    for (int n = 0; n < kTerms; ++n) nu[n] = 0.0;
+    // (the next group's three loads are in flight while this one's 120 multiply-adds run: a wave has 32 groups and, at 148
+    // registers, only two companions on its SIMD to hide a memory round trip behind)
+    d2 n0 = d2{0.0, 0.0}, n1 = n0, n2 = n0;
+    int i = r0 + 2 * lane;
+    if (i < r1) {
+        const d2 *rp = reinterpret_cast<const d2 *>(rb + (size_t)i * 3);
+        n0 = __builtin_nontemporal_load(rp);
+        n1 = __builtin_nontemporal_load(rp + 1);
+        n2 = __builtin_nontemporal_load(rp + 2);
+    }
+    for (; i < r1; i += 128) {
+        const d2 x0 = n0, x1 = n1, x2 = n2;
+        if (i + 128 < r1) {
+            const d2 *rp = reinterpret_cast<const d2 *>(rb + (size_t)(i + 128) * 3);
+            n0 = __builtin_nontemporal_load(rp);
+            n1 = __builtin_nontemporal_load(rp + 1);
+            n2 = __builtin_nontemporal_load(rp + 2);
+        }
+        const bool two = i + 1 < r1;  // (what lies behind the piece may be the next bucket's rows)
+        const double tau[2] = {x0.x, two ? x1.y : 0.0}, sw[2] = {x0.y, two ? x2.x : 0.0}, swV[2] = {x1.x, two ? x2.y : 0.0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const double w = sw[h] * sw[h], wv = sw[h] * swV[h];
+            double pw = 1.0;
+#pragma unroll
+            for (int m = 0; m < kMom; ++m) {
+                mu[m] = fma(w, pw, mu[m]);
+                if (m < kTerms) nu[m] = fma(wv, pw, nu[m]);
+                pw *= tau[h];
+            }
+            eta = fma(swV[h], swV[h], eta);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int m = 0; m < kMom; ++m) mu[m] += __shfl_xor(mu[m], off);
+#pragma unroll
+        for (int n = 0; n < kTerms; ++n) nu[n] += __shfl_xor(nu[n], off);
+        eta += __shfl_xor(eta, off);
+    }
+    if (lane == 0) {
+        double *o = P.partial + (size_t)pc * kMomAll;
+#pragma unroll
+        for (int m = 0; m < kMom; ++m) o[m] = mu[m];
+#pragma unroll
+        for (int n = 0; n < kTerms; ++n) o[kMom + n] = nu[n];
+        o[kMom + kTerms] = eta;
+    }
+}
+
+// One workgroup per bucket.  <= 16 rows: the P rows of the visibilities themselves.  More: the pieces' moments are added in a
+// fixed order (wave g takes pieces g, g + 4, ... eight loads at a time; then ((0 + 1) + (2 + 3))), then wave 0 forms the
+// Cholesky factor of the augmented moment matrix with lane c holding column c (right-looking, 13 steps of one broadcast, one
+// square root and <= 12 fmas per lane).  A pivot that is not positive beyond the round-off of its own formation ends the
+// factorisation of that row: its contribution is below that round-off (for a positive semi-definite matrix the rest of the
+// row is bounded by the pivot).
+__global__ __launch_bounds__(256) void bucket_factor2_kernel(PrepassParams P) {
+    __shared__ double psum[4][kMomAll];
+    __shared__ double mom[kMomAll];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    const int tot = P.totals[b];
+    if (tot == 0) return;
+    const int c = P.cidx[b];
+    if (threadIdx.x == 0) P.vbucket[c] = b;
+    double *out = P.vrows + (size_t)c * 256;
+    if (tot <= 16) {
+        if (threadIdx.x < 16) {
+            const double *rp = P.rows + ((size_t)P.starts[b] + lane) * 3;  // (rows past the bucket's last one are zero rows)
+            const double tau = rp[0], sw = rp[1], swV = rp[2];
+            double pw = sw;
+#pragma unroll
+            for (int n = 0; n < kTerms; ++n) {
+                out[lane * 16 + n] = pw;
+                pw *= tau;
+            }
+            out[lane * 16 + 12] = swV;
+            out[lane * 16 + 13] = out[lane * 16 + 14] = out[lane * 16 + 15] = 0.0;
+        }
+        return;
+    }
+    if (lane < kMomAll) {
+        const int s0 = P.piece0[b], ns = P.piece0[b + 1] - s0;
+        const double *pp = P.partial + (size_t)s0 * kMomAll + lane;
+        double a = 0.0;
+        int k = wave;
+        for (; k + 28 < ns; k += 32) {
+            double x[8];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) x[h] = pp[(size_t)(k + 4 * h) * kMomAll];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) a += x[h];
+        }
+        for (; k < ns; k += 4) a += pp[(size_t)k * kMomAll];
+        psum[wave][lane] = a;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    if (lane < kMomAll) mom[lane] = (psum[0][lane] + psum[1][lane]) + (psum[2][lane] + psum[3][lane]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // column cc of the augmented matrix: H_aug[i][cc], i = 0 .. 12
+    constexpr int NA = kTerms + 1;
+    const int cc = lane < NA ? lane : NA - 1;
+    double col[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int idx = (cc < kTerms) ? (i < kTerms ? i + cc : kMom + cc) : (i < kTerms ? kMom + i : kMom + kTerms);
+        col[i] = mom[idx];
+    }
+#pragma unroll
+    for (int r = 0; r < NA; ++r) {
+        const double h0 = mom[r < kTerms ? 2 * r : kMom + kTerms];  // the diagonal entry before any update
+        const double piv = __shfl(col[r], r);
+        const bool ok = piv > 1.5e-14 * h0;
+        const double inv = ok ? 1.0 / sqrt(piv) : 0.0;
+        const double Rrc = (cc >= r) ? col[r] * inv : 0.0;
+        if (lane < NA) out[r * 16 + lane] = Rrc;
+#pragma unroll
+        for (int i = r + 1; i < NA; ++i) {
+            const double Rri = __shfl(Rrc, i);
+            col[i] = fma(-Rri, Rrc, col[i]);
+        }
+    }
+    // columns 13 .. 15 of rows 0 .. 12, and rows 13 .. 15
+    for (int e = lane; e < 256; e += 64) {
+        const int r = e >> 4, c2 = e & 15;
+        if (r >= NA || c2 >= NA) out[e] = 0.0;
+    }
+}
+
+}  // namespace
+
+int fh_prepass_moment_doubles() { return kMomAll; }
+
+// Geometry of P1 / P2 for nb buckets on a device of num_cu compute units: waves per workgroup, workgroups.  P2 keeps
+// (waves + 1) counters per bucket in LDS (144 KB are budgeted): 16 waves up to 2 168 buckets, one wave at 16 000.
+void fh_prepass_geometry(int nb, int num_cu, int *wpb, int *blocks) {
+    int w = 16;
+    while (w > 1 && (size_t)(w + 1) * (size_t)(nb > 0 ? nb : 1) * sizeof(int) > 144 * 1024) w >>= 1;
+    *wpb = w;
+    *blocks = (num_cu > 0 ? num_cu : 256) * (16 / w);
+}
+
+int64_t fh_prepass_max_pieces(int64_t count, int nb, int seg_rows) { return count / seg_rows + 2 * (int64_t)nb + 2; }
+
+hipError_t fh_prepass_launch_range(const PrepassParams &P, hipStream_t stream) {
+    PrepassParams Q = P;
+    Q.nb = 0;
+    hipLaunchKernelGGL(uv_hist_kernel<false>, dim3(P.blocks), dim3(64 * P.wpb), 0, stream, Q);
+    return hipGetLastError();
+}
+
+template <bool MULT, bool F32, bool SAFE>
+static hipError_t launch_scatter_t(const PrepassParams &P, int nbits, size_t lds, hipStream_t stream) {
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&deproject_scatter_kernel<MULT, F32, SAFE>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((deproject_scatter_kernel<MULT, F32, SAFE>), dim3(P.blocks), dim3(64 * P.wpb), lds, stream, P, nbits);
+    return hipGetLastError();
+}
+static hipError_t launch_scatter(const PrepassParams &P, int nbits, size_t lds, hipStream_t stream) {
+    const bool mult = P.bin.mult != nullptr, f32 = P.bin.u32 != nullptr, safe = P.safe_trig != 0;
+    const int sel = (mult ? 4 : 0) | (f32 ? 2 : 0) | (safe ? 1 : 0);
+    switch (sel) {
+        case 0: return launch_scatter_t<false, false, false>(P, nbits, lds, stream);
+        case 1: return launch_scatter_t<false, false, true>(P, nbits, lds, stream);
+        case 2: return launch_scatter_t<false, true, false>(P, nbits, lds, stream);
+        case 3: return launch_scatter_t<false, true, true>(P, nbits, lds, stream);
+        case 4: return launch_scatter_t<true, false, false>(P, nbits, lds, stream);
+        case 5: return launch_scatter_t<true, false, true>(P, nbits, lds, stream);
+        case 6: return launch_scatter_t<true, true, false>(P, nbits, lds, stream);
+        default: return launch_scatter_t<true, true, true>(P, nbits, lds, stream);
+    }
+}
+
+hipError_t fh_prepass_launch(const PrepassParams &P, hipStream_t stream) {
+    const size_t lds1 = sizeof(int) * (size_t)P.nb, lds2 = sizeof(int) * (size_t)P.nb * (P.wpb + 1);
+    const size_t lds3 = sizeof(int) * ((size_t)P.nb + 1);
+    int nbits = 0;
+    while ((1 << nbits) < P.nb) ++nbits;
+    hipError_t e;
+    if (lds1 > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&uv_hist_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds1);
+        if (e != hipSuccess) return e;
+    }
+    if (lds3 > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&piece_moments_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds3);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(uv_hist_kernel<true>, dim3(P.blocks), dim3(64 * P.wpb), lds1, stream, P);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3((P.nb + 63) / 64), dim3(1024), 0, stream, P);
+    e = launch_scatter(P, nbits, lds2, stream);
+    if (e != hipSuccess) return e;
+    const int64_t max_pieces = fh_prepass_max_pieces(P.bin.count, P.nb, P.seg_rows);
+    hipLaunchKernelGGL(piece_moments_kernel, dim3((unsigned)((max_pieces + 3) / 4)), dim3(256), lds3, stream, P);
+    hipLaunchKernelGGL(bucket_factor2_kernel, dim3(P.nb), dim3(256), 0, stream, P);
+    return hipGetLastError();
+}

@@ -162,6 +162,8 @@ struct fh_ctx {
     DevBuf<double> k1_partial;      // partial moments of the bucket slices
     DevBuf<double> k1_vrows;        // compressed rows (fh_k1v2_launch_compress): one 16 x 16 chunk per non-empty bucket
     DevBuf<int> k1_cidx, k1_vbucket;
+    DevBuf<int> k1_piece0;          // bin_prepass.hip: first partial-moment slot of every bucket
+    bool no_range_cache = false;    // fh_ctx_set_range_cache(ctx, 0): look at (u, v) on every pass (benchmarks of distinct tables)
     // baseline range of the last pre-pass, keyed by (table, row range, geometry): binning the same rows under the same geometry
     // again (bootstrap draws, pipelines of fits, sweeps) needs no second look at the range before the sort is sized
     unsigned long long range_vis = 0, range_mult_gen = 0;
@@ -361,6 +363,7 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
             for (int P = 0; P < c->nparts; ++P)
                 HIP_TRY(c->partials[P].alloc((size_t)c->part_blocks[P] * fh_k1v2_part_ntiles(c->NBT, P) * 256));
             HIP_TRY(c->k1_info.alloc(4));
+            HIP_TRY(hipMemset(c->k1_info.p, 0, 4 * sizeof(int)));  // ([3]: the ticket of bucket_scan_kernel starts at zero)
         } else {
             c->ntiles = fh_k1_ntiles(c->NBT);
             c->nparts = fh_k1_nparts(c->NBT);
@@ -767,9 +770,22 @@ static int running_fit_loops(fh_ctx *c) {
 // K1 v2: deproject -> (host: baseline range, bucket tables) -> bucket sort -> bin_gram2 -> slab reduction.
 // The one host round trip (64 KB of per-block scalars) is what _check_uv_range needs before any binning in the reference
 // too (statistical_models.py:166-169); it costs the stream ~20 us of idle time per call.
+static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned long long vis_serial,
+                               unsigned long long mult_gen);
+
 static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned long long vis_serial,
                                unsigned long long mult_gen) {
     if (count > 0x7fffffff - 16 * 65536) return fail(FH_ERR_UNSUPPORTED, "more than 2^31 visibilities in one call: split it");
+    // the default: the rows of a bucket enter the Gram through 12 x 12 moments (bin_prepass.hip + bin_gram2.hip); not for the
+    // debris model (its design block is not a product of a row factor and a column factor) and not in single precision
+    if (c->k1_moments && !c->debris && !c->arith32) return bin_visibilities_v4(c, p, count, vis_serial, mult_gen);
+    const size_t cnt1 = (size_t)(count > 0 ? count : 1);  // K1a scratch: 24 B per visibility (32 B with the debris model's kz^2)
+    const size_t need = cnt1 * (c->debris ? 4 : 3);
+    if (c->prep.n < need) HIP_TRY(c->prep.alloc(need));
+    p.prep_s = c->prep.p;
+    p.prep_sw = c->prep.p + cnt1;
+    p.prep_swV = c->prep.p + 2 * cnt1;
+    p.prep_k2 = c->debris ? c->prep.p + 3 * cnt1 : nullptr;
     int dblocks = (int)((count + 255) / 256);
     if (dblocks > c->deproject_blocks) dblocks = c->deproject_blocks;
     if (dblocks < 1) dblocks = 1;
@@ -778,7 +794,7 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     HIP_TRY(fh_k1_launch_deproject(p, dblocks, c->stream));
     const double gkey[6] = {p.dRA, p.dDec, p.cos_t, p.sin_t, p.cos_i, p.sin_i};
     const bool known = c->range_valid && c->range_vis == vis_serial && c->range_mult_gen == mult_gen && c->range_first == p.first && c->range_count == count &&
-                       memcmp(gkey, c->range_geom, sizeof gkey) == 0 && !getenv("FRANK_AMD_NO_RANGE_CACHE");
+                       memcmp(gkey, c->range_geom, sizeof gkey) == 0 && !c->no_range_cache && !getenv("FRANK_AMD_NO_RANGE_CACHE");
     // qmax_all: over every row of the range whatever its multiplicity -- the sort is sized from it, because rows drawn
     // zero times are still sorted (with weight 0) and must land in a bucket of their own argument
     double qmax = 0.0, qmin = INFINITY, qmax_all = 0.0;
@@ -851,33 +867,6 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     sp.chunk_bucket = c->k1_chunk_bucket.p;
     HIP_TRY(fh_k1v2_launch_sort(sp, c->stream));
 
-    // v3: the rows of a bucket enter the Gram through 12 x 12 moments (bin_gram2.hip); not for the debris model (its design
-    // block is not a product of a row factor and a column factor) and not in single precision
-    const bool moments = c->k1_moments && !c->debris && !c->arith32;
-    if (moments) {
-        if (c->k1_vrows.n < (size_t)nb * 256 && c->k1_vrows.alloc((size_t)nb * 256 + 4096) != hipSuccess)
-            return fail(FH_ERR_NOMEM, "hipMalloc (compressed rows) failed");
-        if (c->k1_cidx.n < (size_t)nb && c->k1_cidx.alloc((size_t)nb + 256) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc failed");
-        if (c->k1_vbucket.n < (size_t)nb && c->k1_vbucket.alloc((size_t)nb + 256) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc failed");
-        // slices per bucket: ~256 rows per wave on average, at most 64
-        int parts = (int)((count + (int64_t)nb * 256 - 1) / ((int64_t)nb * 256));
-        parts = parts < 1 ? 1 : (parts > 64 ? 64 : parts);
-        const size_t npart = (size_t)nb * parts * fh_k1v2_moment_doubles();
-        if (c->k1_partial.n < npart && c->k1_partial.alloc(npart + 4096) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc (moments) failed");
-        CompressParams cp{};
-        cp.parts = parts;
-        cp.partial = c->k1_partial.p;
-        cp.rows = c->k1_rows.p;
-        cp.starts = c->k1_starts.p;
-        cp.totals = c->k1_totals.p;
-        cp.nb = nb;
-        cp.cidx = c->k1_cidx.p;
-        cp.info = c->k1_info.p;
-        cp.vrows = c->k1_vrows.p;
-        cp.vbucket = c->k1_vbucket.p;
-        HIP_TRY(fh_k1v2_launch_compress(cp, c->stream));
-    }
-
     const int running = running_fit_loops(c);
     // throughput mode while fit_loop kernels hold CUs (a workgroup that starts late simply takes fewer runs); fits of a
     // pipeline are run-dependent in their last bits anyway; synchronous fits stay static = bitwise reproducible
@@ -890,12 +879,6 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     bp.table = c->k1_table.p;
     bp.table32 = c->arith32 ? c->k1_table32.p : nullptr;
     bp.H2 = c->debris ? c->debris_H2.p : nullptr;
-    if (moments) {
-        bp.virtual_rows = 1;
-        bp.rows = c->k1_vrows.p;
-        bp.chunk_bucket = c->k1_vbucket.p;
-        bp.info = c->k1_info.p + 1;
-    }
     bp.work_counter = dynamic ? c->work_counter.p : nullptr;
     if (dynamic) HIP_TRY(hipMemsetAsync(c->work_counter.p, 0, 4 * sizeof(int), c->stream));
     ReduceParams rp{};
@@ -919,6 +902,152 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     rp.partial_scalars = c->partial_scalars.p;
     rp.scratch = c->reduce_scratch.p;
     rp.scalar_blocks = dblocks;
+    HIP_TRY(hipEventRecord(c->ev_bin0, c->stream));
+    HIP_TRY(fh_k1v2_launch_bin(c->NBT, bp, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_bin1, c->stream));
+    c->bin_timed = true;
+    HIP_TRY(fh_k1_launch_reduce(rp, c->stats_sum.p, c->stats_minmax.p, c->stream));
+    c->have_device_Mj = false;
+    return FH_OK;
+}
+
+// The moments path (default): range (first sight of a table only) -> P1 histogram of (u, v) -> scan + layout -> P2 deproject +
+// scatter -> P3 segment moments -> factor -> bin_gram2 on the 13 virtual rows per bucket -> slab reduction (bin_prepass.hip).
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned long long vis_serial,
+                               unsigned long long mult_gen) {
+    PrepassParams P{};
+    P.bin = p;
+    P.partial_scalars = c->partial_scalars.p;
+    HIP_TRY(hipEventRecord(c->ev_pre0, c->stream));
+    const double gkey[6] = {p.dRA, p.dDec, p.cos_t, p.sin_t, p.cos_i, p.sin_i};
+    const bool known = c->range_valid && c->range_vis == vis_serial && c->range_mult_gen == mult_gen && c->range_first == p.first &&
+                       c->range_count == count && memcmp(gkey, c->range_geom, sizeof gkey) == 0 && !c->no_range_cache &&
+                       !getenv("FRANK_AMD_NO_RANGE_CACHE");
+    // qmax_all: over every row of the range whatever its multiplicity -- the sort is sized from it, because rows drawn
+    // zero times are still sorted (with weight 0) and must land in a bucket of their own argument
+    double qmax = 0.0, qmin = INFINITY, qmax_all = 0.0;
+    if (known) {  // same rows, same geometry: the range is the one read back last time, no host round trip
+        qmin = c->prepass_qmin;
+        qmax = c->prepass_qmax;
+        qmax_all = c->prepass_qmax_all;
+    } else {  // one look at (u, v): 16 B per visibility and the one host round trip of the pass (64 KB of per-workgroup scalars)
+        fh_prepass_geometry(0, c->num_cu, &P.wpb, &P.blocks);
+        const int rblocks = P.blocks;
+        HIP_TRY(fh_prepass_launch_range(P, c->stream));
+        c->k1_scalars_host.resize((size_t)rblocks * 4);
+        HIP_TRY(hipMemcpyAsync(c->k1_scalars_host.data(), c->partial_scalars.p, sizeof(double) * (size_t)rblocks * 4,
+                               hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int b = 0; b < rblocks; ++b) {
+            const double mn = c->k1_scalars_host[(size_t)b * 4 + 1], m = c->k1_scalars_host[(size_t)b * 4 + 2],
+                         ma = c->k1_scalars_host[(size_t)b * 4 + 3];
+            if (m > qmax) qmax = m;  // (-inf for workgroups without rows; NaN baselines never win)
+            if (mn < qmin) qmin = mn;
+            if (ma > qmax_all) qmax_all = ma;
+        }
+    }
+    if (!(qmax < INFINITY) || !(qmax_all < INFINITY)) return fail(FH_ERR_INVALID, "non-finite baseline in the visibility table");
+    c->prepass_qmin = qmin;
+    c->prepass_qmax = qmax;
+    c->prepass_qmax_all = qmax_all;
+    c->range_vis = vis_serial;
+    c->range_mult_gen = mult_gen;
+    c->range_first = p.first;
+    c->range_count = count;
+    memcpy(c->range_geom, gkey, sizeof gkey);
+    c->range_valid = true;
+    // statistical_models.py:166-169: the range check comes BEFORE the chunk loop -- nothing is binned for a table that fails it
+    if (c->check_q_before_bin && c->dht->q[c->N - 1] < qmax)
+        return fail(FH_ERR_QRANGE, "last collocation point %.3e < longest deprojected baseline %.3e", c->dht->q[c->N - 1], qmax);
+    const double delta = c->k1_delta, inv_delta = 1.0 / delta;
+    const double smax = qmax_all * p.inv_Qmax;
+    if (smax * inv_delta > 2.0e9) return fail(FH_ERR_UNSUPPORTED, "baselines reach %.3g x Qmax", smax);
+    const int nb = (int)(smax * inv_delta) + 2;  // one spare bucket: the device recomputes s * inv_delta itself
+    if (nb > 16000)  // a wave of the sort keeps one counter per bucket in LDS
+        return fail(FH_ERR_UNSUPPORTED, "baselines reach %.1f x Qmax (%d buckets of J0 arguments): cut the (u, v) distribution or "
+                    "raise N", smax, nb);
+    int rc = k1v2_ensure_table(c, nb);
+    if (rc) return rc;
+    int seg = env_int("FRANK_AMD_K1_SEG", 4096);
+    seg = seg < 128 ? 128 : ((seg + 127) & ~127);
+    fh_prepass_geometry(nb, c->num_cu, &P.wpb, &P.blocks);
+    if (const int w = env_int("FRANK_AMD_K1_WPB", 0)) {  // development: waves per workgroup / workgroups of P1, P2
+        P.wpb = w;
+        P.blocks = env_int("FRANK_AMD_K1_BLOCKS", P.blocks);
+    }
+    if (P.blocks > c->deproject_blocks) P.blocks = c->deproject_blocks;  // (entries of partial_scalars)
+    // workspaces (grow on demand)
+    const size_t nrows = (size_t)count + 16 * (size_t)nb + 16, max_pc = (size_t)fh_prepass_max_pieces(count, nb, seg);
+    const size_t md = (size_t)fh_prepass_moment_doubles();
+    if (c->k1_rows.n < nrows * 3 && c->k1_rows.alloc(nrows * 3 + 1024) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc (sorted rows) failed");
+    if (c->k1_hist.n < (size_t)P.blocks * nb && c->k1_hist.alloc((size_t)P.blocks * nb + 1024) != hipSuccess)
+        return fail(FH_ERR_NOMEM, "hipMalloc (histograms) failed");
+    if (c->k1_totals.n < (size_t)nb && c->k1_totals.alloc((size_t)nb + 256) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc failed");
+    if (c->k1_starts.n < (size_t)nb + 1 && c->k1_starts.alloc((size_t)nb + 257) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc failed");
+    if (c->k1_cidx.n < (size_t)nb && c->k1_cidx.alloc((size_t)nb + 256) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc failed");
+    if (c->k1_vbucket.n < (size_t)nb && c->k1_vbucket.alloc((size_t)nb + 256) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc failed");
+    if (c->k1_vrows.n < (size_t)nb * 256 && c->k1_vrows.alloc((size_t)nb * 256 + 4096) != hipSuccess)
+        return fail(FH_ERR_NOMEM, "hipMalloc (compressed rows) failed");
+    if (c->k1_piece0.n < (size_t)nb + 1 && c->k1_piece0.alloc((size_t)nb + 257) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc failed");
+    if (c->k1_partial.n < max_pc * md && c->k1_partial.alloc(max_pc * md + 4096) != hipSuccess)
+        return fail(FH_ERR_NOMEM, "hipMalloc (moments) failed");
+    P.inv_delta = inv_delta;
+    P.delta = delta;
+    P.nb = nb;
+    P.seg_rows = seg;
+    P.dummy_row = (int64_t)nrows;  // (the buffer holds nrows + 341 rows)
+    // |u|, |v| <= q / cos(inc), so |phase| <= (|dRA| + |dDec|) qmax / |cos(inc)|: beyond 1e5 rad the library's sincos
+    P.safe_trig = !((fabs(p.dRA) + fabs(p.dDec)) * qmax_all < 1.0e5 * fabs(p.cos_i)) || getenv("FRANK_AMD_K1_SAFE_TRIG");
+    P.hist = c->k1_hist.p;
+    P.totals = c->k1_totals.p;
+    P.starts = c->k1_starts.p;
+    P.cidx = c->k1_cidx.p;
+    P.info = c->k1_info.p;
+    P.piece0 = c->k1_piece0.p;
+    P.rows = c->k1_rows.p;
+    P.partial = c->k1_partial.p;
+    P.vrows = c->k1_vrows.p;
+    P.vbucket = c->k1_vbucket.p;
+    HIP_TRY(fh_prepass_launch(P, c->stream));
+
+    // the Gram of the virtual rows: one 16-row chunk per non-empty bucket (a few hundred to a few thousand chunks), so a
+    // few dozen workgroups -- every workgroup writes a slab of all its tiles that the reduction reads back
+    Bin2Params bp{};
+    bp.N = c->N;
+    bp.table = c->k1_table.p;
+    bp.virtual_rows = 1;
+    bp.rows = c->k1_vrows.p;
+    bp.chunk_bucket = c->k1_vbucket.p;
+    bp.info = c->k1_info.p + 1;
+    bp.work_counter = nullptr;  // static hand-out: the same sums in every run
+    ReduceParams rp{};
+    rp.nparts = c->nparts;
+    rp.ntiles = c->ntiles;
+    int vr_blocks = env_int("FRANK_AMD_K1_VRBLOCKS", nb < 512 ? 32 : 64);
+    int G = 0;
+    for (int Pt = 0; Pt < c->nparts; ++Pt) G += c->part_blocks[Pt];
+    if (vr_blocks > G) vr_blocks = G;
+    for (int Pt = 0; Pt < 3; ++Pt) {
+        int blocks = 0;
+        if (Pt < c->nparts) {
+            blocks = (int)(((long long)c->part_blocks[Pt] * vr_blocks + G - 1) / G);
+            if (blocks < 1) blocks = 1;
+            if (blocks > c->part_blocks[Pt]) blocks = c->part_blocks[Pt];
+        }
+        bp.part_blocks[Pt] = blocks;
+        bp.partials[Pt] = c->partials[Pt].p;
+        rp.part_blocks[Pt] = blocks;
+        rp.part_tile0[Pt] = Pt < c->nparts ? fh_k1v2_part_tile0(c->NBT, Pt) : 0;
+        rp.part_ntiles[Pt] = Pt < c->nparts ? fh_k1v2_part_ntiles(c->NBT, Pt) : 0;
+        rp.partials[Pt] = c->partials[Pt].p;
+    }
+    rp.partial_scalars = c->partial_scalars.p;
+    rp.scratch = c->reduce_scratch.p;
+    rp.scalar_blocks = P.blocks;
     HIP_TRY(hipEventRecord(c->ev_bin0, c->stream));
     HIP_TRY(fh_k1v2_launch_bin(c->NBT, bp, c->stream));
     HIP_TRY(hipEventRecord(c->ev_bin1, c->stream));
@@ -964,6 +1093,8 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     p.j0_table = c->j0_table.p;
     const int64_t nsuper = (count + fh_k1_super() - 1) / fh_k1_super();
     if (nsuper > 0x7fffffff / 2) return fail(FH_ERR_UNSUPPORTED, "more than 2^39 visibilities in one call");
+    p.H2 = c->debris ? c->debris_H2.p : nullptr;
+    if (c->v2 && !use_wide(c)) return bin_visibilities_v2(c, p, count, vis->serial, vis->use_mult ? vis->mult_gen : 0);
     // K1a scratch: 24 B per visibility (32 B with the debris model's kz^2)
     const size_t cnt1 = (size_t)(count > 0 ? count : 1);
     const size_t need = cnt1 * (c->debris ? 4 : 3);
@@ -972,7 +1103,6 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     p.prep_sw = c->prep.p + cnt1;
     p.prep_swV = c->prep.p + 2 * cnt1;
     p.prep_k2 = c->debris ? c->prep.p + 3 * cnt1 : nullptr;
-    p.H2 = c->debris ? c->debris_H2.p : nullptr;
     if (use_wide(c)) {
         // N > 303 / debris: sqrt(w)-scaled rows to memory, chunk by chunk, and G += X^T X by rocBLAS (fp64 MFMA inside)
         double *G = dense_gram(c);
@@ -1003,7 +1133,6 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
         c->have_device_Mj = false;
         return FH_OK;
     }
-    if (c->v2) return bin_visibilities_v2(c, p, count, vis->serial, vis->use_mult ? vis->mult_gen : 0);
     // fit_loop kernels of earlier fits that are still RUNNING each hold a CU (a slot stays "busy" until it is collected,
     // long after its kernel has finished: counting those would leave CUs idle)
     int running = 0;
@@ -1094,6 +1223,13 @@ int fh_ctx_set_lognormal_linesearch(fh_ctx *c, int reference_products) {
 int fh_ctx_set_reproducible(fh_ctx *c, int on) {
     if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
     c->force_static = on != 0;
+    return FH_OK;
+}
+
+int fh_ctx_set_range_cache(fh_ctx *c, int on) {
+    if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
+    c->no_range_cache = on == 0;
+    c->range_valid = false;
     return FH_OK;
 }
 

@@ -90,6 +90,33 @@ struct CompressParams {
     int parts;            // slices per bucket of the moment sums
     double *partial;      // [nb][parts][fh_k1v2_moment_doubles()]
 };
+// ---- pre-pass of the moments path (bin_prepass.hip) -------------------------------------------------------------------
+struct PrepassParams {
+    BinParams bin;            // table columns, row range, geometry, 1/Qmax, multiplicities
+    double inv_delta, delta;  // bucket width in s (j0_buckets.h)
+    int nb;                   // buckets
+    int wpb, blocks;          // waves per workgroup and workgroups of P1 / P2 (fh_prepass_geometry)
+    int seg_rows;             // rows per segment of the sorted table in P3 (a multiple of 128)
+    int safe_trig;            // phases u dRA + v dDec beyond 1e5 rad may occur: P2 takes the library's sincos
+    int64_t dummy_row;        // a row behind the sorted table that lanes past the end of the visibility table write to
+    int *hist;                // [blocks][nb] rows per workgroup and bucket, then (scan) in earlier workgroups
+    int *totals;              // [nb]
+    int *starts;              // [nb + 1] first sorted row of every bucket (multiples of 16)
+    int *cidx;                // [nb] index of the bucket among the non-empty ones
+    int *info;                // [0] 16-row chunks of the sorted table, [1] non-empty buckets, [2] segments, [3] ticket (zero)
+    int *piece0;              // [nb + 1] first slot of every bucket's partial moments
+    double *rows;             // sorted table, 3 doubles per row (tau, sqrt(w), sqrt(w) Re V'), count + 16 nb + 16 rows
+    double *partial;          // [pieces][fh_prepass_moment_doubles()]
+    double *vrows;            // [non-empty bucket][16][16]: the input of bin_gram2_kernel<.., VR = true>
+    int *vbucket;             // [non-empty bucket]
+    double *partial_scalars;  // [workgroup][4]: sum log(w / 2 pi), qmin, qmax (rows of multiplicity > 0), qmax (all rows)
+};
+int fh_prepass_moment_doubles();
+void fh_prepass_geometry(int nb, int num_cu, int *wpb, int *blocks);
+int64_t fh_prepass_max_pieces(int64_t count, int nb, int seg_rows);
+hipError_t fh_prepass_launch_range(const PrepassParams &P, hipStream_t stream);  // baseline range only (partial_scalars)
+hipError_t fh_prepass_launch(const PrepassParams &P, hipStream_t stream);        // P1, scan, P2, P3, factor
+
 int fh_k1v2_moment_doubles();
 hipError_t fh_k1v2_launch_compress(const CompressParams &cp, hipStream_t stream);
 hipError_t fh_k1v2_launch_max(const double *q, int64_t n, double *out, hipStream_t stream);

@@ -156,6 +156,11 @@ int fh_ctx_set_lognormal_linesearch(fh_ctx *ctx, int reference_products);
  * depend on the run.  on != 0 forces the first, reproducible hand-out everywhere, as the reference's single-threaded
  * sums are (statistical_models.py:200-214).                                                                          */
 int fh_ctx_set_reproducible(fh_ctx *ctx, int on);
+/* The baseline range of a (table, row range, geometry, multiplicities) is remembered by the context, so that binning the same
+ * rows again needs no second look at (u, v) and no host round trip before the sort is sized (what _check_uv_range computes
+ * before the chunk loop, statistical_models.py:166-169).  on = 0 forgets it and measures the range on every pass -- the cost
+ * of binning a table the context has not seen (bench.py `distinct_tables`).  Default: on.                                  */
+int fh_ctx_set_range_cache(fh_ctx *ctx, int on);
 int fh_stats_device(fh_ctx *ctx, double **sum_stats, int64_t *n_sum, double **minmax_stats);
 int fh_stats_finalize(fh_ctx *ctx, const fh_geometry *geom, int vis_model, int check_qbounds, double *M, double *j,
                       double *H0, double *qmin, double *qmax);
