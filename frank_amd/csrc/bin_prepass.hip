@@ -27,6 +27,8 @@
 // (u, v) before it knows where a row goes.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "deproject.h"
 #include "j0_buckets.h"
 #include "kernels.h"
@@ -55,10 +57,11 @@ __global__ __launch_bounds__(1024) void uv_hist_kernel(PrepassParams P) {
         __syncthreads();
     }
     double qmin = INFINITY, qmax = -INFINITY, qmax_all = -INFINITY;
-    const int tile = blockDim.x;
+    const int tile = blockDim.x * P.unroll;
     const int64_t ntiles = (p.count + tile - 1) / tile;
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int64_t i = t * tile + threadIdx.x;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x)
+      for (int j = 0; j < P.unroll; ++j) {
+        const int64_t i = t * tile + j * blockDim.x + threadIdx.x;
         if (i < p.count) {
             double u, v;
             fh_load_uv(p, p.first + i, u, v);
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(1024) void uv_hist_kernel(PrepassParams P) {
             }
             if (HIST) atomicAdd(&lds_i[fh_bucket_of(p.inv_Qmax * q, P.inv_delta, P.nb)], 1);
         }
-    }
+      }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         qmin = fmin(qmin, __shfl_down(qmin, off));
@@ -222,12 +225,16 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(PrepassParams P) {
 // log(w / 2 pi) (statistical_models.py:218) is the log of a running product -- mantissa and exponent kept apart, one
 // logarithm per lane at the end instead of one per row, and a smaller rounding error than the sum of the logarithms.
 // MULT: bootstrap multiplicities (fh_vis_set_multiplicity); F32: the table is stored in single precision; SAFE: phases beyond
-// 1e5 rad may occur (the host bounds them by (|dRA| + |dDec|) qmax / cos(inc)), the library's sincos takes them.
-// The loop is straight-line -- loads and stores are never skipped (rows past the end read the last row and write a dummy row
-// behind the table) -- so that the compiler counts its outstanding memory operations exactly: the next tile's loads are
-// waited for with the current tile's stores still in flight.
-template <bool MULT, bool F32, bool SAFE>
-__global__ __launch_bounds__(1024) void deproject_scatter_kernel(PrepassParams P, int nbits) {
+// 1e5 rad may occur (the host bounds them by (|dRA| + |dDec|) qmax / cos(inc)), the library's sincos takes them; U: rows
+// per lane and tile (a tile = 64 U rows per wave; wave w of the workgroup holds rows [64 U w, 64 U (w + 1)) of it).
+// The loop over the full tiles is straight-line -- no lane is ever idle in it, the last, partial tile is peeled off -- so
+// that the compiler counts its outstanding memory operations exactly: the next tile's loads are waited for with the current
+// tile's stores still in flight.
+// Rank of a row among the rows of its bucket in its wave: the value an LDS atomic add on the wave's counter of that bucket
+// returns.  Lanes that meet in one instruction are served in a fixed order, and the U instructions of a tile in program
+// order, so the ranks -- and with them the place of every row -- are the same in every run.
+template <bool MULT, bool F32, bool SAFE, int U>
+__global__ __launch_bounds__(1024) void deproject_scatter_kernel(PrepassParams P) {
     extern __shared__ int lds_i[];  // cnt[nb], wc[wpb][nb]
     __shared__ double red[16];
     const BinParams &p = P.bin;
@@ -239,101 +246,138 @@ __global__ __launch_bounds__(1024) void deproject_scatter_kernel(PrepassParams P
         for (int b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = P.starts[b] + wg[b];
         for (int e = threadIdx.x; e < wpb * nb; e += blockDim.x) wc[e] = 0;
     }
+    int *wcw = wc + wave * nb;
     const double inv_half = 2.0 * P.inv_delta;
     double sum_logw = 0.0;      // rows with multiplicities: the plain sum
     double pm = 1.0;            // mantissa of the product of the weights, in [0.5, 1)
     int pe = 0, pn = 0;         // its exponent; the number of rows in it
-    const int tile = blockDim.x;
-    const int64_t ntiles = (p.count + tile - 1) / tile;
+    double w_prev = -1.0, sw_prev = 0.0;
+    const int tile = blockDim.x * U;
+    const int64_t ntiles = (p.count + tile - 1) / tile, nfull = p.count / tile;
     const int64_t last = p.first + p.count - 1;
-    const size_t dummy = (size_t)P.dummy_row;
     // (columns that do not exist are read from one that does and then ignored)
     const double *colVim = p.Vim ? p.Vim : p.Vre;
     const float *colVim32 = p.Vim32 ? p.Vim32 : p.Vre32;
     const bool has_im = F32 ? p.Vim32 != nullptr : p.Vim != nullptr;
-    VisRow r;
-    int rmult = 1;
+    VisRow r[U];
+    int rmult[U];
     auto fetch = [&](int64_t tt) {
-        int64_t g = p.first + tt * tile + threadIdx.x;
-        g = g < last ? g : last;
-        const int64_t gw = p.w_scalar ? 0 : g;
-        if (F32) {
-            r.u = (double)p.u32[g];
-            r.v = (double)p.v32[g];
-            r.Vre = (double)p.Vre32[g];
-            r.Vim = (double)colVim32[g];
-            r.w = (double)p.w32[gw];
-        } else {
-            r.u = __builtin_nontemporal_load(&p.u[g]);
-            r.v = __builtin_nontemporal_load(&p.v[g]);
-            r.Vre = __builtin_nontemporal_load(&p.Vre[g]);
-            r.Vim = __builtin_nontemporal_load(&colVim[g]);
-            r.w = __builtin_nontemporal_load(&p.w[gw]);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            int64_t g = p.first + tt * tile + (wave * U + j) * 64 + lane;
+            g = g < last ? g : last;
+            const int64_t gw = p.w_scalar ? 0 : g;
+            if (F32) {
+                r[j].u = (double)p.u32[g];
+                r[j].v = (double)p.v32[g];
+                r[j].Vre = (double)p.Vre32[g];
+                r[j].Vim = (double)colVim32[g];
+                r[j].w = (double)p.w32[gw];
+            } else {
+                r[j].u = __builtin_nontemporal_load(&p.u[g]);
+                r[j].v = __builtin_nontemporal_load(&p.v[g]);
+                r[j].Vre = __builtin_nontemporal_load(&p.Vre[g]);
+                r[j].Vim = __builtin_nontemporal_load(&colVim[g]);
+                r[j].w = __builtin_nontemporal_load(&p.w[gw]);
+            }
+            if (MULT) rmult[j] = p.mult[g];
         }
-        if (MULT) rmult = p.mult[g];
+    };
+    // one tile; FULL: every lane holds a row of the table
+    auto process = [&](int64_t t, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        VisRow c[U];
+        double cm[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            c[j] = r[j];
+            cm[j] = MULT ? (double)rmult[j] : 1.0;
+        }
+        fetch(t + gridDim.x);  // the next tile's rows are in flight during this tile's arithmetic and barriers
+        double tau[U], sw[U], swV[U];
+        int bk[U], rank[U];
+        bool active[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            active[j] = FULL || t * tile + (wave * U + j) * 64 + lane < p.count;
+            const double Vim = has_im ? c[j].Vim : 0.0;
+            const double re = SAFE ? fh_phase_centre_re(p, c[j].u, c[j].v, c[j].Vre, Vim)
+                                   : fh_phase_centre_re_fast(p, c[j].u, c[j].v, c[j].Vre, Vim);
+            const double q = fh_deproject_q_fast(p, c[j].u, c[j].v);
+            const double wj = MULT ? cm[j] * c[j].w : c[j].w;
+            if (__all(wj == w_prev)) {  // (tables of constant weight: the square root of the row before)
+                sw[j] = sw_prev;
+            } else {
+                sw[j] = sqrt(wj);
+                w_prev = wj;
+                sw_prev = sw[j];
+            }
+            const double s = p.inv_Qmax * q;  // k * q, hankel.py:189,202
+            swV[j] = sw[j] * re;
+            if (MULT) {
+                if (active[j] && cm[j] > 0.0) sum_logw += cm[j] * log(c[j].w / (2 * M_PI));  // statistical_models.py:218
+            } else {
+                // mantissa and exponent of w by integer arithmetic; anything but a positive normal number takes frexp
+                const double w1 = active[j] ? c[j].w : 1.0;
+                const unsigned long long bits = __double_as_longlong(w1);
+                const int ex = (int)((bits >> 52) & 0x7ff);
+                double m1 = __longlong_as_double((bits & 0x800fffffffffffffull) | 0x3fe0000000000000ull);
+                int e1 = ex - 1022;
+                if (__builtin_expect(__any(ex == 0 || ex == 0x7ff || (long long)bits < 0), 0)) {
+                    m1 = frexp(w1, &e1);
+                    if (!(w1 > 0.0)) m1 = w1 == 0.0 ? 0.0 : NAN;  // log(0) = -inf, log(negative) = NaN, as the reference's sum
+                }
+                pm *= m1;  // in [0.25, 1): back to [0.5, 1)
+                const unsigned long long pb = __double_as_longlong(pm);
+                const int e2 = (int)((pb >> 52) & 0x7ff) - 1022;  // 0 or -1 (0, NaN: whatever, the product stays what it is)
+                if (pm > 0.0) {
+                    pm = __longlong_as_double((pb & 0x800fffffffffffffull) | 0x3fe0000000000000ull);
+                    pe += e1 + e2;
+                }
+                pn += active[j] ? 1 : 0;
+            }
+            bk[j] = fh_bucket_of(s, P.inv_delta, nb);
+            tau[j] = fh_bucket_tau(s, bk[j], P.delta, inv_half);
+            rank[j] = 0;
+            if (active[j]) rank[j] = atomicAdd(&wcw[bk[j]], 1);  // (ds_add_rtn_u32)
+        }
+        __syncthreads();
+        int base[U], before[U], total[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            before[j] = total[j] = 0;
+            for (int w = 0; w < wpb; ++w) {
+                const int v = wc[w * nb + bk[j]];
+                total[j] += v;
+                before[j] += w < wave ? v : 0;
+            }
+            base[j] = cnt[bk[j]] + before[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            // the first row of a bucket in the tile advances the workgroup's front; the first in a wave clears the wave's counter
+            // (with U > 1 the same bucket may come up again at j + 1: its rank is then > 0)
+            if (active[j] && rank[j] == 0) {
+                if (before[j] == 0) cnt[bk[j]] += total[j];
+                wcw[bk[j]] = 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            // 24-byte rows: the 16-byte aligned pair in one store, the third double in another (no branch)
+            const size_t row = active[j] ? (size_t)base[j] + rank[j] : (size_t)P.dummy_row;
+            double *o = P.rows + row * 3;
+            const bool odd = row & 1;
+            *reinterpret_cast<d2 *>(o + (odd ? 1 : 0)) = odd ? d2{sw[j], swV[j]} : d2{tau[j], sw[j]};
+            o[odd ? 0 : 2] = odd ? tau[j] : swV[j];
+        }
     };
     fetch(blockIdx.x);
     __syncthreads();
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int64_t i = t * tile + threadIdx.x;
-        const bool active = i < p.count;
-        const VisRow c = r;
-        const double cm = MULT ? (double)rmult : 1.0;
-        fetch(t + gridDim.x);  // the next tile's row is in flight during this tile's arithmetic and barriers
-        const double Vim = has_im ? c.Vim : 0.0;
-        const double re = SAFE ? fh_phase_centre_re(p, c.u, c.v, c.Vre, Vim) : fh_phase_centre_re_fast(p, c.u, c.v, c.Vre, Vim);
-        const double q = fh_deproject_q_fast(p, c.u, c.v);
-        const double sw = MULT ? sqrt(cm * c.w) : sqrt(c.w);
-        const double s = p.inv_Qmax * q;  // k * q, hankel.py:189,202
-        const double swV = sw * re;
-        if (MULT) {
-            if (active && cm > 0.0) sum_logw += cm * log(c.w / (2 * M_PI));
-        } else {
-            int e1, e2;
-            const double m1 = frexp(active ? c.w : 1.0, &e1);
-            pm = frexp(pm * m1, &e2);
-            pe += e1 + e2;
-            pn += active ? 1 : 0;
-            if (active && !(c.w > 0.0)) pm = c.w == 0.0 ? 0.0 : NAN;  // log(0) = -inf, log(negative) = NaN, as the reference's sum
-        }
-        const int b = fh_bucket_of(s, P.inv_delta, nb);
-        unsigned long long peers = __ballot(active);
-        for (int bit = 0; bit < nbits; ++bit) {
-            const bool one = (b >> bit) & 1;
-            const unsigned long long m = __ballot(one);
-            peers &= one ? m : ~m;
-        }
-        const int rank = __popcll(peers & ((1ull << lane) - 1ull));
-        const int leader = __ffsll((long long)peers) - 1;
-        const bool lead = active && rank == 0;
-        const int npeers = __popcll(peers);
-        if (lead) wc[wave * nb + b] = npeers;
-        __syncthreads();
-        int base = 0, before = 0, total = 0;
-        if (lead) {
-            for (int w = 0; w < wpb; ++w) {
-                const int v = wc[w * nb + b];
-                total += v;
-                before += w < wave ? v : 0;
-            }
-            base = cnt[b] + before;
-        }
-        __syncthreads();
-        if (lead) {
-            if (before == 0) cnt[b] += total;  // (the first wave of the tile that holds the bucket)
-            wc[wave * nb + b] = 0;
-        }
-        base = __shfl(base, leader < 0 ? 0 : leader);
-        {
-            // 24-byte rows: the 16-byte aligned pair in one store, the third double in another (no branch)
-            const size_t row = active ? (size_t)base + rank : dummy;
-            double *o = P.rows + row * 3;
-            const double tau = fh_bucket_tau(s, b, P.delta, inv_half);
-            const bool odd = row & 1;
-            *reinterpret_cast<d2 *>(o + (odd ? 1 : 0)) = odd ? d2{sw, swV} : d2{tau, sw};
-            o[odd ? 0 : 2] = odd ? tau : swV;
-        }
-    }
+    int64_t t = blockIdx.x;
+    for (; t < nfull; t += gridDim.x) process(t, std::true_type{});
+    if (t < ntiles) process(t, std::false_type{});  // (at most one workgroup)
     if (!MULT) sum_logw = (log(pm) + (double)pe * M_LN2) - (double)pn * log(2 * M_PI);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sum_logw += __shfl_down(sum_logw, off);
@@ -508,15 +552,144 @@ __global__ __launch_bounds__(256) void bucket_factor2_kernel(PrepassParams P) {
     }
 }
 
+// ---- Gram of the virtual rows ----------------------------------------------------------------------------------------------
+// G = sum_b X_b^T X_b over the non-empty buckets, X_b = R_b C_b: the 16 virtual rows of bucket b (bucket_factor2_kernel: P in
+// columns 0 .. 11, the data column in 12) times the bucket's Taylor table (12 x N).  A few hundred to a few thousand chunks
+// of 16 rows: bin_gram2_kernel (built to stream 1e7 rows: every workgroup holds all 190 tiles and writes a slab of them)
+// needed 85 us on 32 workgroups or 100 MB of slabs on 256.  Here a workgroup owns ONE output tile (I, J) and its waves split
+// the chunks: per chunk a wave generates the two 16 x 16 blocks X_I, X_J it needs -- three matrix instructions each; register r
+// of the result is the operand fragment of Gram k-step r, so nothing goes through LDS -- and adds X_I^T X_J in four more.
+// No slabs: the waves' tiles are added in LDS in wave order, the `split` workgroups of a tile through `scratch` in
+// vr_finish_kernel.  Same arithmetic per chunk as bin_gram2_kernel<.., VR>; the order over the chunks is fixed.
+typedef double v4d __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(1024) void vr_gram_kernel(VrGramParams G) {
+    __shared__ double red[16][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int kk = lane >> 4, ii = lane & 15;
+    const int t = blockIdx.x / G.split, sp = blockIdx.x - t * G.split;
+    int I = 0, tt = t;
+    while (tt >= G.NBT - I) {
+        tt -= G.NBT - I;
+        ++I;
+    }
+    const int J = I + tt;
+    const int JN = G.N >> 4, jn = G.N & 15;  // the data column sqrt(w) Re V' lives at column N
+    const int nchunks = G.info[0];
+    const int stride = nwaves * G.split;
+    v4d acc = v4d{0, 0, 0, 0};
+    // operands of one chunk: 9 doubles per lane (+ 4 of the data column for the tiles of the last block column); the next
+    // chunk's are in flight while this one's ten matrix instructions run, its bucket id one chunk further ahead
+    struct Ops {
+        double a0, a1, a2, i0, i1, i2, j0, j1, j2, dc[4];
+    };
+    auto load_ops = [&](int c, int b) {
+        Ops o;
+        const double *rp = G.vrows + (size_t)c * 256 + ii * 16;
+        const double *cb = G.table + ((size_t)b * kTerms + kk) * G.XS + ii;
+        const double *cI = cb + I * 16, *cJ = cb + J * 16;
+        o.a0 = rp[kk];
+        o.a1 = rp[4 + kk];
+        o.a2 = rp[8 + kk];
+        o.i0 = cI[0];
+        o.i1 = cI[4 * G.XS];
+        o.i2 = cI[8 * G.XS];
+        o.j0 = cJ[0];
+        o.j1 = cJ[4 * G.XS];
+        o.j2 = cJ[8 * G.XS];
+        if (J == JN) {
+            const double *dc = G.vrows + (size_t)c * 256 + 12;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) o.dc[reg] = dc[(kk + 4 * reg) * 16];
+        }
+        return o;
+    };
+    int c = sp * nwaves + wave;
+    Ops nxt{};
+    int bn = 0;
+    if (c < nchunks) nxt = load_ops(c, G.vbucket[c]);
+    if (c + stride < nchunks) bn = G.vbucket[c + stride];
+    for (; c < nchunks; c += stride) {
+        const Ops o = nxt;
+        if (c + stride < nchunks) nxt = load_ops(c + stride, bn);
+        if (c + 2 * stride < nchunks) bn = G.vbucket[c + 2 * stride];
+        v4d dI = v4d{0, 0, 0, 0}, dJ = v4d{0, 0, 0, 0};
+        dI = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a2, o.i2, dI, 0, 0, 0);  // smallest terms first
+        dJ = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a2, o.j2, dJ, 0, 0, 0);
+        dI = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1, o.i1, dI, 0, 0, 0);
+        dJ = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1, o.j1, dJ, 0, 0, 0);
+        dI = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0, o.i0, dI, 0, 0, 0);
+        dJ = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0, o.j0, dJ, 0, 0, 0);
+        if (J == JN) {  // column N: the data column of the row this register holds (row kk + 4 reg); columns beyond: table zeros
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                if (ii == jn) {
+                    dJ[reg] = o.dc[reg];
+                    if (I == JN) dI[reg] = o.dc[reg];
+                }
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dI[reg], dJ[reg], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) red[wave][reg * 64 + lane] = acc[reg];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        double sum = 0.0;
+        for (int w = 0; w < nwaves; ++w) sum += red[w][threadIdx.x];
+        G.scratch[((size_t)sp * G.ntiles + t) * 256 + threadIdx.x] = sum;
+    }
+}
+
+// stats_sum += the splits of every tile in order; workgroup 0 also folds the per-workgroup scalars of the pre-pass
+// (sum log(w / 2 pi), baseline range): strided partial sums, then a fixed tree
+__global__ __launch_bounds__(256) void vr_finish_kernel(VrGramParams G, double *stats_sum, double *stats_minmax) {
+    const int t = threadIdx.x;
+    const size_t e = (size_t)blockIdx.x * 256 + t, ne = (size_t)G.ntiles * 256;
+    double sum = 0.0;
+    for (int k = 0; k < G.split; ++k) sum += G.scratch[(size_t)k * ne + e];
+    stats_sum[e] += sum;
+    if (blockIdx.x == 0) {
+        __shared__ double rs[256], rmn[256], rmx[256];
+        double sl = 0.0, mn = INFINITY, mx = -INFINITY;
+        for (int b = t; b < G.scalar_blocks; b += 256) {
+            sl += G.partial_scalars[b * 4 + 0];
+            mn = fmin(mn, G.partial_scalars[b * 4 + 1]);
+            mx = fmax(mx, G.partial_scalars[b * 4 + 2]);
+        }
+        rs[t] = sl;
+        rmn[t] = mn;
+        rmx[t] = mx;
+        __syncthreads();
+        for (int h = 128; h >= 1; h >>= 1) {
+            if (t < h) {
+                rs[t] += rs[t + h];
+                rmn[t] = fmin(rmn[t], rmn[t + h]);
+                rmx[t] = fmax(rmx[t], rmx[t + h]);
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            stats_sum[ne] += rs[0];
+            // min/max are kept as (-qmin, qmax) so that one max-all-reduce serves both
+            stats_minmax[0] = fmax(stats_minmax[0], -rmn[0]);
+            stats_minmax[1] = fmax(stats_minmax[1], rmx[0]);
+        }
+    }
+}
+
 }  // namespace
 
 int fh_prepass_moment_doubles() { return kMomAll; }
 
 // Geometry of P1 / P2 for nb buckets on a device of num_cu compute units: waves per workgroup, workgroups.  P2 keeps
-// (waves + 1) counters per bucket in LDS (144 KB are budgeted): 16 waves up to 2 168 buckets, one wave at 16 000.
+// (waves + 1) counters per bucket in LDS; two workgroups of eight waves per compute unit (one's barriers and stores beside the
+// other's arithmetic: 154 against 189 us per 1e7 rows for one of sixteen) while that fits 72 KB each -- 2 048 buckets --,
+// fewer waves per workgroup beyond (one at 9 000 buckets and more: 128 KB at the 16 000 the sort admits).
 void fh_prepass_geometry(int nb, int num_cu, int *wpb, int *blocks) {
-    int w = 16;
-    while (w > 1 && (size_t)(w + 1) * (size_t)(nb > 0 ? nb : 1) * sizeof(int) > 144 * 1024) w >>= 1;
+    int w = 8;
+    const size_t n = (size_t)(nb > 0 ? nb : 1);
+    while (w > 1 && (size_t)(w + 1) * n * sizeof(int) > (w == 1 ? 144 : 72) * 1024) w >>= 1;
     *wpb = w;
     *blocks = (num_cu > 0 ? num_cu : 256) * (16 / w);
 }
@@ -530,36 +703,38 @@ hipError_t fh_prepass_launch_range(const PrepassParams &P, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <bool MULT, bool F32, bool SAFE>
-static hipError_t launch_scatter_t(const PrepassParams &P, int nbits, size_t lds, hipStream_t stream) {
+template <bool MULT, bool F32, bool SAFE, int U>
+static hipError_t launch_scatter_t(const PrepassParams &P, size_t lds, hipStream_t stream) {
     if (lds > 48 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&deproject_scatter_kernel<MULT, F32, SAFE>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&deproject_scatter_kernel<MULT, F32, SAFE, U>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((deproject_scatter_kernel<MULT, F32, SAFE>), dim3(P.blocks), dim3(64 * P.wpb), lds, stream, P, nbits);
+    hipLaunchKernelGGL((deproject_scatter_kernel<MULT, F32, SAFE, U>), dim3(P.blocks), dim3(64 * P.wpb), lds, stream, P);
     return hipGetLastError();
 }
-static hipError_t launch_scatter(const PrepassParams &P, int nbits, size_t lds, hipStream_t stream) {
+template <int U>
+static hipError_t launch_scatter_u(const PrepassParams &P, size_t lds, hipStream_t stream) {
     const bool mult = P.bin.mult != nullptr, f32 = P.bin.u32 != nullptr, safe = P.safe_trig != 0;
     const int sel = (mult ? 4 : 0) | (f32 ? 2 : 0) | (safe ? 1 : 0);
     switch (sel) {
-        case 0: return launch_scatter_t<false, false, false>(P, nbits, lds, stream);
-        case 1: return launch_scatter_t<false, false, true>(P, nbits, lds, stream);
-        case 2: return launch_scatter_t<false, true, false>(P, nbits, lds, stream);
-        case 3: return launch_scatter_t<false, true, true>(P, nbits, lds, stream);
-        case 4: return launch_scatter_t<true, false, false>(P, nbits, lds, stream);
-        case 5: return launch_scatter_t<true, false, true>(P, nbits, lds, stream);
-        case 6: return launch_scatter_t<true, true, false>(P, nbits, lds, stream);
-        default: return launch_scatter_t<true, true, true>(P, nbits, lds, stream);
+        case 0: return launch_scatter_t<false, false, false, U>(P, lds, stream);
+        case 1: return launch_scatter_t<false, false, true, U>(P, lds, stream);
+        case 2: return launch_scatter_t<false, true, false, U>(P, lds, stream);
+        case 3: return launch_scatter_t<false, true, true, U>(P, lds, stream);
+        case 4: return launch_scatter_t<true, false, false, U>(P, lds, stream);
+        case 5: return launch_scatter_t<true, false, true, U>(P, lds, stream);
+        case 6: return launch_scatter_t<true, true, false, U>(P, lds, stream);
+        default: return launch_scatter_t<true, true, true, U>(P, lds, stream);
     }
+}
+static hipError_t launch_scatter(const PrepassParams &P, size_t lds, hipStream_t stream) {
+    return P.unroll == 2 ? launch_scatter_u<2>(P, lds, stream) : launch_scatter_u<1>(P, lds, stream);
 }
 
 hipError_t fh_prepass_launch(const PrepassParams &P, hipStream_t stream) {
     const size_t lds1 = sizeof(int) * (size_t)P.nb, lds2 = sizeof(int) * (size_t)P.nb * (P.wpb + 1);
     const size_t lds3 = sizeof(int) * ((size_t)P.nb + 1);
-    int nbits = 0;
-    while ((1 << nbits) < P.nb) ++nbits;
     hipError_t e;
     if (lds1 > 48 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&uv_hist_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -573,10 +748,16 @@ hipError_t fh_prepass_launch(const PrepassParams &P, hipStream_t stream) {
     }
     hipLaunchKernelGGL(uv_hist_kernel<true>, dim3(P.blocks), dim3(64 * P.wpb), lds1, stream, P);
     hipLaunchKernelGGL(bucket_scan_kernel, dim3((P.nb + 63) / 64), dim3(1024), 0, stream, P);
-    e = launch_scatter(P, nbits, lds2, stream);
+    e = launch_scatter(P, lds2, stream);
     if (e != hipSuccess) return e;
     const int64_t max_pieces = fh_prepass_max_pieces(P.bin.count, P.nb, P.seg_rows);
     hipLaunchKernelGGL(piece_moments_kernel, dim3((unsigned)((max_pieces + 3) / 4)), dim3(256), lds3, stream, P);
     hipLaunchKernelGGL(bucket_factor2_kernel, dim3(P.nb), dim3(256), 0, stream, P);
+    return hipGetLastError();
+}
+
+hipError_t fh_vr_gram_launch(const VrGramParams &G, double *stats_sum, double *stats_minmax, hipStream_t stream) {
+    hipLaunchKernelGGL(vr_gram_kernel, dim3(G.ntiles * G.split), dim3(64 * G.waves), 0, stream, G);
+    hipLaunchKernelGGL(vr_finish_kernel, dim3(G.ntiles), dim3(256), 0, stream, G, stats_sum, stats_minmax);
     return hipGetLastError();
 }

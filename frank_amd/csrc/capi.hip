@@ -922,6 +922,7 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     PrepassParams P{};
     P.bin = p;
     P.partial_scalars = c->partial_scalars.p;
+    P.unroll = env_int("FRANK_AMD_K1_UNROLL", 2) == 2 ? 2 : 1;
     HIP_TRY(hipEventRecord(c->ev_pre0, c->stream));
     const double gkey[6] = {p.dRA, p.dDec, p.cos_t, p.sin_t, p.cos_i, p.sin_i};
     const bool known = c->range_valid && c->range_vis == vis_serial && c->range_mult_gen == mult_gen && c->range_first == p.first &&
@@ -1014,6 +1015,34 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     P.vbucket = c->k1_vbucket.p;
     HIP_TRY(fh_prepass_launch(P, c->stream));
 
+    // the Gram of the virtual rows: one 16-row chunk per non-empty bucket (a few hundred to a few thousand chunks); one
+    // workgroup (or a few) per output tile, no slabs (vr_gram_kernel).  FRANK_AMD_K1_VR=slabs keeps bin_gram2_kernel<.., VR>.
+    const char *vrenv = getenv("FRANK_AMD_K1_VR");
+    if (!(vrenv && !strcmp(vrenv, "slabs"))) {
+        VrGramParams G{};
+        G.N = c->N;
+        G.NBT = c->NBT;
+        G.XS = c->XS;
+        G.ntiles = c->ntiles;
+        // eight workgroups per tile -- workgroup ids go round the eight XCDs, so an XCD's L2 holds one eighth of the tables
+        // (7 MB at N = 300: read once per workgroup they came from memory, 42 us) -- of eight waves each
+        G.waves = env_int("FRANK_AMD_K1_VRWAVES", 8);
+        int split = env_int("FRANK_AMD_K1_VRSPLIT", 8);
+        G.split = split < 1 ? 1 : (split > 8 ? 8 : split);
+        G.vrows = c->k1_vrows.p;
+        G.vbucket = c->k1_vbucket.p;
+        G.info = c->k1_info.p + 1;
+        G.table = c->k1_table.p;
+        G.scratch = c->reduce_scratch.p;
+        G.partial_scalars = c->partial_scalars.p;
+        G.scalar_blocks = P.blocks;
+        HIP_TRY(hipEventRecord(c->ev_bin0, c->stream));
+        HIP_TRY(fh_vr_gram_launch(G, c->stats_sum.p, c->stats_minmax.p, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_bin1, c->stream));
+        c->bin_timed = true;
+        c->have_device_Mj = false;
+        return FH_OK;
+    }
     // the Gram of the virtual rows: one 16-row chunk per non-empty bucket (a few hundred to a few thousand chunks), so a
     // few dozen workgroups -- every workgroup writes a slab of all its tiles that the reduction reads back
     Bin2Params bp{};

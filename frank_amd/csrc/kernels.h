@@ -96,6 +96,7 @@ struct PrepassParams {
     double inv_delta, delta;  // bucket width in s (j0_buckets.h)
     int nb;                   // buckets
     int wpb, blocks;          // waves per workgroup and workgroups of P1 / P2 (fh_prepass_geometry)
+    int unroll;               // rows per lane and tile in P1 / P2 (1 or 2): a tile is 64 x wpb x unroll rows
     int seg_rows;             // rows per segment of the sorted table in P3 (a multiple of 128)
     int safe_trig;            // phases u dRA + v dDec beyond 1e5 rad may occur: P2 takes the library's sincos
     int64_t dummy_row;        // a row behind the sorted table that lanes past the end of the visibility table write to
@@ -111,6 +112,19 @@ struct PrepassParams {
     int *vbucket;             // [non-empty bucket]
     double *partial_scalars;  // [workgroup][4]: sum log(w / 2 pi), qmin, qmax (rows of multiplicity > 0), qmax (all rows)
 };
+// Gram of the virtual rows, one workgroup (x split) per output tile (bin_prepass.hip)
+struct VrGramParams {
+    int N, NBT, XS, ntiles;
+    int split, waves;         // workgroups per tile (<= 8: scratch), waves per workgroup (<= 16): the chunks are dealt to split x waves
+    const double *vrows;      // [chunk][16][16]
+    const int *vbucket;       // [chunk]
+    const int *info;          // info[0] = chunks
+    const double *table;      // [bucket][12][XS]
+    double *scratch;          // [split][ntiles * 256]
+    const double *partial_scalars;
+    int scalar_blocks;
+};
+hipError_t fh_vr_gram_launch(const VrGramParams &G, double *stats_sum, double *stats_minmax, hipStream_t stream);
 int fh_prepass_moment_doubles();
 void fh_prepass_geometry(int nb, int num_cu, int *wpb, int *blocks);
 int64_t fh_prepass_max_pieces(int64_t count, int nb, int seg_rows);

@@ -15,7 +15,7 @@ if [ -f "$f" ]; then
   python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-keep = ("uv_hist", "bucket_scan", "deproject_scatter", "piece_moments", "segment_moments", "bucket_factor", "bin_gram2", "reduce_partials", "deproject_kernel", "bucket_")
+keep = ("vr_gram", "vr_finish", "uv_hist", "bucket_scan", "deproject_scatter", "piece_moments", "segment_moments", "bucket_factor", "bin_gram2", "reduce_partials", "deproject_kernel", "bucket_")
 tot = 0.0
 for r in rows:
     if any(k in r["Name"] for k in keep) and int(r["Calls"]) >= 30:
