@@ -6,7 +6,11 @@ A "step" is ONE complete fit, end to end on the device, of the configuration the
 resident in HBM, Normal GP fit, fp64:
     bin_gram (deproject + J0 design block + Gram)  ->  [RCCL all-reduce in --mode shard]
     ->  scale/unpack M, j  ->  the full power-spectrum iteration to convergence (tol 1e-3).
-Nothing is cached between steps.  `value` = fits completed by all ranks / max-over-ranks wall time.
+Every step streams the whole table and runs the whole iteration; the one thing a context remembers between steps is the
+baseline range (qmin, qmax) of a (table, rows, geometry) it has binned before, which saves the host round trip that sizes
+the bucket sort (extra.distinct_tables measures the pipeline without it: a ring of different tables, range cache off).
+`value` = fits completed by all ranks / max-over-ranks wall time.  The timed region holds `steps` binning passes and ONE
+drain of the last fits' iterations (~0.09 s), so `value` grows with --steps; extra.steady_state is the rate of a >= 2 s run.
 
     python bench.py                                  # 1 GPU, defaults finish in a few minutes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -20,8 +24,15 @@ the packed (N^2+N)-sized sufficient statistics) is timed after the headline regi
 torch is used ONLY for the rendezvous / barrier / max-over-ranks (gloo, CPU tensors); the data path is
 libfrank_hip + RCCL.
 
+Whenever WORLD_SIZE > 1 "sweep512_multi" (BASELINE configs[4]: 512 fits of one 1e6-visibility mapping split over the ranks,
+the packed statistics handed to every rank by one RCCL all-reduce) runs in the same watchdog.  NOTE: the builder has one
+GPU; no N > 1 value has been measured by the builder, the scaling curve is the driver's.
+
 Rank 0 at N=1 also reports, outside the timed region and bounded to about a minute in total:
+  extra.steady_state         fits/s of the same pipeline over a >= 2 s run (the drain is < 5 % of it), fit loops resident
+  extra.distinct_tables      the same with every step binning a different table of a ring of four, range cache off
   extra.lognormal_fullsize   BASELINE configs[2] (N=300, 1e7 visibilities, LogNormal) on the resident table
+  extra.fp32_table           the same table stored in single precision (configs[2]'s "fp32": 20 B per visibility)
   extra.sweep512             BASELINE configs[4] on one GPU (512 fits of one 1e6-visibility mapping)
   extra.uvbin                UVDataBinner streaming passes at 1e7 rows (HBM roofline)
   cpu_baseline               the CPU oracle on one core and on all host cores (independent fits per core)
@@ -45,7 +56,7 @@ HYPER = dict(alpha=1.05, p0=1e-15, wsmooth=1e-4, tol=1e-3, max_iter=2000)
 # roofline constants: MI355X fp64 matrix peak (AMD CDNA4 datasheet; the microarch guide lists no fp64 MFMA row)
 FP64_MFMA_PEAK_TFLOPS = 78.6
 K2_KERNEL_NAME = "fit_loop_kernel"
-K1_KERNEL_NAME = "bin_gram2_kernel<double, 19, false, true>"  # the Gram kernel of the binning pass (on compressed rows)
+K1_KERNEL_NAME = "vr_gram_kernel"  # the Gram kernel of the binning pass (on the virtual rows of the buckets)
 N_CU = 256
 HBM_PEAK_GBPS = 8000.0
 
@@ -86,6 +97,7 @@ class Fitter:
         self.mu, self.p = np.empty(ncoll), np.empty(ncoll)
         self.niter = ctypes.c_int(0)
         self.vis = None
+        self.tables = []
         self.n = 0
         self.nfit = 0
 
@@ -96,13 +108,14 @@ class Fitter:
         L.check(L.lib.fh_vis_upload(self.device, L.ptr(u), L.ptr(v), L.ptr(Vre), L.ptr(Vim), L.ptr(w), w.size, u.size,
                                     ctypes.byref(vis)))
         self.vis, self.n = vis, u.size
+        self.tables.append(vis)
         if not getattr(self, "nfit", 0):
             self.nfit = u.size  # rows of one headline fit (the table may hold more, for the sharded leg)
 
-    def bin(self, count=None):
+    def bin(self, count=None, vis=None):
         L = self.L
         L.check(L.lib.fh_bin_reset(self.ctx))
-        L.check(L.lib.fh_bin_visibilities(self.ctx, ctypes.byref(self.geom), self.vis, 0,
+        L.check(L.lib.fh_bin_visibilities(self.ctx, ctypes.byref(self.geom), self.vis if vis is None else vis, 0,
                                           self.nfit if count is None else count))
 
     def kernel_ms(self):
@@ -134,10 +147,10 @@ class Fitter:
         self.bin()
         return self.solve()
 
-    def submit(self):
+    def submit(self, vis=None):
         """bin_gram on the main stream, then hand the iteration to a fit slot (fit_loop kernel on its own stream)."""
         L = self.L
-        self.bin()
+        self.bin(vis=vis)
         # nothing is asked back from the finalisation (M, j stay on the device; the baseline range was checked by the
         # synchronous fit of the warm-up): the call does not wait for the binning pass
         L.check(L.lib.fh_stats_finalize(self.ctx, ctypes.byref(self.geom), 0, 0, None, None, None, None, None))
@@ -152,15 +165,16 @@ class Fitter:
         L.check(L.lib.fh_fit_collect(self.ctx, ticket, L.ptr(self.mu), L.ptr(self.p), ctypes.byref(self.niter)))
         return self.niter.value
 
-    def run_steps(self, k, kernel_ms=None):
-        """k independent end-to-end fits, pipelined: the iteration of fit i overlaps the binning of fit i+1."""
+    def run_steps(self, k, kernel_ms=None, ring=None):
+        """k independent end-to-end fits, pipelined: the iteration of fit i overlaps the binning of fit i+1.
+        ring: tables to take turns with (default: the one resident table)."""
         L = self.L
         slots = L.lib.fh_fit_slots()
         pending, nit = [], 0
-        for _ in range(k):
+        for i in range(k):
             if len(pending) == slots:
                 nit = self.collect(pending.pop(0))
-            pending.append(self.submit())
+            pending.append(self.submit(None if not ring else ring[i % len(ring)]))
             if kernel_ms is not None:
                 kernel_ms.append(self.kernel_ms())
         L.check(L.lib.fh_fit_flush(self.ctx))  # the last, partly filled launch
@@ -170,6 +184,43 @@ class Fitter:
 
     def sync(self):
         self.L.check(self.L.lib.fh_ctx_synchronize(self.ctx))
+
+
+def steady_state(f, L, steps=0, ring=0, min_seconds=2.0):
+    """fits/s of the pipeline over a run of at least `min_seconds` (the one drain of the last iterations, ~0.1 s, is then
+    < 5 % of it).  ring > 0: every step bins a different table of a ring of `ring` resident tables with the range cache of
+    the context off -- what a stream of tables the context has never seen costs (one look at (u, v) and one host round trip
+    per step more)."""
+    from frank_amd.mock import mock_disc_visibilities
+    tables = None
+    if ring:
+        while len(f.tables) < ring:
+            k = len(f.tables)
+            u, v, V, w = mock_disc_visibilities(f.nfit, seed=7000 + k, noise_seed=7100 + k)
+            keep = f.vis
+            f.upload(u, v, V, w)
+            f.vis = keep
+        tables = f.tables[:ring]
+        L.check(L.lib.fh_ctx_set_range_cache(f.ctx, 0))
+    try:
+        k = steps if steps else 400
+        while True:
+            f.run_steps(8, ring=tables)
+            f.sync()
+            t0 = time.perf_counter()
+            nit = f.run_steps(k, ring=tables)
+            f.sync()
+            dt = time.perf_counter() - t0
+            if dt >= min_seconds or steps:
+                break
+            k = int(k * max(1.3 * min_seconds / dt, 1.5))
+    finally:
+        if ring:
+            L.check(L.lib.fh_ctx_set_range_cache(f.ctx, 1))
+    return {"fits_per_s": k / dt, "steps": k, "seconds": dt, "ms_per_step": 1e3 * dt / k, "fit_slots": L.lib.fh_fit_slots(),
+            "iterations_of_the_last_fit": nit,
+            "workload": ("the headline step, %d times back to back" % k) if not ring else
+                        ("the headline step on a ring of %d different resident tables, baseline-range cache off" % ring)}
 
 
 def usable_cpus():
@@ -257,6 +308,15 @@ def extras(f, L, a):
     N = a.ncoll
     h = HYPER
     H0, qmn, qmx = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    # -- what the pipeline of the headline does at steady state (>= 2 s runs), and on tables it has never seen
+    try:
+        ex["steady_state"] = steady_state(f, L)
+        ex["distinct_tables"] = steady_state(f, L, ring=4)
+        for t in f.tables[1:]:
+            L.lib.fh_vis_destroy(t)
+        del f.tables[1:]
+    except Exception as e:
+        ex.setdefault("steady_state", {})["error"] = repr(e)
 
     def finalize():
         L.check(L.lib.fh_stats_finalize(f.ctx, ctypes.byref(f.geom), 0, 1, None, None, ctypes.byref(H0),
@@ -296,47 +356,44 @@ def extras(f, L, a):
             np.abs(I_lin - I_ref).max() / np.abs(I_ref).max())
     except Exception as e:
         ex.setdefault("lognormal_fullsize", {})["error"] = repr(e)
-    # -- the same workload with single-precision binning (fh_ctx_set_arithmetic): kernel time beside the fp64 one
+    # -- "fp32" of BASELINE configs[2] = single-precision STORAGE: the table handed over as float32 / complex64 (20 B per
+    #    visibility, fh_vis_upload_f32) is widened as the pre-pass reads it and binned by the same fp64 moments pass.
+    #    (Single-precision ARITHMETIC of the design block exists for tables up to 2e6 rows -- fh_ctx_set_arithmetic,
+    #    8.8 ms per 1e7 rows and a Gram that is no longer positive definite at that size: measured in round 2, retired here)
     try:
-        L.check(L.lib.fh_ctx_set_arithmetic(f.ctx, 1))
-        ms = []
-        for _ in range(3):
-            f.bin()
-            f.sync()
-            ms.append(f.kernel_ms())
-        finalize()
-        k32 = float(np.median(ms))
-        fl = f.nfit * (N * (N + 1) + 2 * N)
-        e32 = {"workload": "bin_gram with single-precision design block / tile products (fp64 argument reduction and "
-                           "block accumulation), N=%d, %d visibilities" % (N, f.nfit),
-               "kernel_ms": k32,
-               "roofline": {"bound": "mfma", "achieved": fl / (k32 * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                            "frac": fl / (k32 * 1e-3) / 1e12 / 157.3,
-                            "peak_source": "MI355X fp32 matrix peak, MI355X_MICROARCH.md"}}
-        ex["fp32_binning"] = e32
-        mu32, p32, n32 = np.empty(N), np.empty(N), ctypes.c_int(0)
-        rc = L.lib.fh_fit_normal(f.ctx, None, None, h["alpha"], h["p0"], h["wsmooth"], h["tol"], h["max_iter"],
-                                 L.ptr(mu32), L.ptr(p32), ctypes.byref(n32), None, None)
-        L.check(L.lib.fh_ctx_set_arithmetic(f.ctx, 0))
-        if rc != 0:
-            e32["fit"] = {"status": rc, "note": L.last_error() + " -- the single-precision Gram is off by ~1e-8 of its "
-                          "largest entry, which at this many visibilities exceeds the unit prior precision of the "
-                          "first seed solve (p = 1, radial_fitters.py:744): the fused loop stops and FrankFitter "
-                          "continues through the reference's SVD route"}
-        else:
+        from frank_amd.mock import mock_disc_visibilities
+        u, v, V, w = mock_disc_visibilities(f.nfit, seed=0, noise_seed=50)
+        f4 = [np.ascontiguousarray(x, dtype=np.float32) for x in (u, v, V.real, V.imag, w)]
+        del u, v, V, w
+        vis32 = ctypes.c_void_p()
+        L.check(L.lib.fh_vis_upload_f32(f.device, L.fptr(f4[0]), L.fptr(f4[1]), L.fptr(f4[2]), L.fptr(f4[3]), L.fptr(f4[4]),
+                                        f4[4].size, f4[0].size, ctypes.byref(vis32)))
+        del f4
+        try:
+            ms = []
+            for _ in range(4):
+                f.bin(vis=vis32)
+                f.sync()
+                ms.append(f.prepass_ms() + f.kernel_ms())
+            finalize()
+            mu32, p32, n32 = np.empty(N), np.empty(N), ctypes.c_int(0)
+            L.check(L.lib.fh_fit_normal(f.ctx, None, None, h["alpha"], h["p0"], h["wsmooth"], h["tol"], h["max_iter"],
+                                        L.ptr(mu32), L.ptr(p32), ctypes.byref(n32), None, None))
             f.bin()
             finalize()
             mu64, p64, n64 = np.empty(N), np.empty(N), ctypes.c_int(0)
             L.check(L.lib.fh_fit_normal(f.ctx, None, None, h["alpha"], h["p0"], h["wsmooth"], h["tol"], h["max_iter"],
                                         L.ptr(mu64), L.ptr(p64), ctypes.byref(n64), None, None))
-            e32["fit"] = {"status": 0, "iterations_fp32_vs_fp64": [n32.value, n64.value],
-                          "profile_max_abs_diff_over_max": float(np.abs(mu32 - mu64).max() / np.abs(mu64).max())}
+            pm = float(np.median(ms[1:]))
+            ex["fp32_table"] = {"workload": "the headline table stored in single precision (20 B per visibility), fp64 arithmetic",
+                                "binning_pass_ms": pm, "GBps_of_20B_per_vis": 20.0 * f.nfit / (pm * 1e-3) / 1e9,
+                                "iterations_fp32_table_vs_fp64_table": [n32.value, n64.value],
+                                "profile_max_abs_diff_over_max": float(np.abs(mu32 - mu64).max() / np.abs(mu64).max()),
+                                "north_star_tolerance_fp32": 1e-3}
+        finally:
+            L.lib.fh_vis_destroy(vis32)
     except Exception as e:
-        ex.setdefault("fp32_binning", {})["error"] = repr(e)
-        try:
-            L.lib.fh_ctx_set_arithmetic(f.ctx, 0)
-        except Exception:
-            pass
+        ex["fp32_table"] = {"error": repr(e)}
     # -- BASELINE configs[4] on one GPU: 512 fits (32 alpha x 16 w_smooth) of ONE mapping of 1e6 visibilities
     try:
         al, ws = np.meshgrid(np.linspace(1.01, 1.5, 32), np.logspace(-4, -1, 16))
@@ -384,7 +441,7 @@ def extras(f, L, a):
     return ex
 
 
-def sharded_leg(f, L, a, dist, rank, world, local_rank, barrier, out):
+def sharded_leg(f, L, a, dist, rank, world, local_rank, barrier, out, out2):
     """BASELINE configs[3]: ONE fit whose visibilities are sharded over the ranks (contiguous slabs, SURVEY 8(e));
     every rank bins its slab, ONE RCCL all-reduce sums the packed upper-triangle Gram + scalars (and a 2-double
     max-reduce the baseline range), then every rank holds M, j and solves (rank 0's solve is the fit)."""
@@ -410,20 +467,78 @@ def sharded_leg(f, L, a, dist, rank, world, local_rank, barrier, out):
         if i:
             times.append(time.perf_counter() - t0)
             ar_ms.append(comm.last_allreduce_ms())
-            bin_ms.append(f.kernel_ms())
+            bin_ms.append(f.prepass_ms() + f.kernel_ms())
     t = torch.tensor([min(times)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    pass_ms = torch.tensor([float(np.median(bin_ms))], dtype=torch.float64)
+    pass_all = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(pass_all, pass_ms)
     payload = ctypes.c_int64(0)
     L.check(L.lib.fh_stats_device(f.ctx, None, ctypes.byref(payload), None))
+    nbytes = payload.value * 8
     out.update({"workload": "BASELINE configs[3]: one N=%d fit of %d visibilities sharded over %d ranks "
                             "(%d per rank)" % (a.ncoll, shard * world, world, shard),
                 "nvis_total": shard * world, "nvis_per_rank": shard, "rccl_ranks": comm.size(),
                 "s_per_fit": float(t.item()), "fits_per_s": 1.0 / float(t.item()),
                 "vis_per_s": shard * world / float(t.item()),
-                "allreduce_us": 1e3 * float(np.median(ar_ms)), "bin_gram_ms": float(np.median(bin_ms)),
+                "allreduce_us": 1e3 * float(np.median(ar_ms)),
+                # the payload over the seven xGMI links of a GPU in one shot, plus the latency of a hop
+                "allreduce_bound_us": {"payload_bytes": nbytes, "one_shot_over_7_links_us": nbytes / (7 * 153e9) * 1e6,
+                                       "note": "%.0f KB is latency-bound: a ring all-reduce makes 2 (ranks - 1) hops of "
+                                               "a few microseconds each" % (nbytes / 1024.0)},
+                "binning_pass_ms_per_rank": [float(x.item()) for x in pass_all],
                 "iterations": nit_s,
                 "collective": "ncclAllReduce(sum) of %d doubles (%.0f KB) + ncclAllReduce(max) of 2 doubles, on the "
-                              "context's stream" % (payload.value, payload.value * 8 / 1024.0)})
+                              "context's stream" % (payload.value, nbytes / 1024.0)})
+    # -- BASELINE configs[4] over the ranks: 512 fits (32 alpha x 16 w_smooth) of ONE mapping of 1e6 visibilities.  Rank 0
+    #    bins the table; the packed statistics (380 KB) reach every rank through the same all-reduce (the other ranks
+    #    contribute zeros); every rank runs its contiguous slice of the grid in one batched launch, no further communication
+    #    (the reference's loop: frank/fit.py:534-548)
+    try:
+        h = HYPER
+        al, ws = np.meshgrid(np.linspace(1.01, 1.5, 32), np.logspace(-4, -1, 16))
+        al, ws = np.ascontiguousarray(al.ravel()), np.ascontiguousarray(ws.ravel())
+        B = al.size
+        from frank_amd.distributed import shard_range
+        first, count = shard_range(B, rank, world)
+        nv = min(f.n, 1_000_000)
+        mu, pp = np.empty((max(count, 1), a.ncoll)), np.empty((max(count, 1), a.ncoll))
+        niter = (ctypes.c_int * max(count, 1))()
+        status = (ctypes.c_int * max(count, 1))()
+        best, per_rank = None, None
+        for i in range(2):
+            barrier()
+            t0 = time.perf_counter()
+            L.check(L.lib.fh_bin_reset(f.ctx))
+            if rank == 0:
+                L.check(L.lib.fh_bin_visibilities(f.ctx, ctypes.byref(f.geom), f.vis, 0, nv))
+            comm.allreduce_stats(f.ctx)
+            L.check(L.lib.fh_stats_finalize(f.ctx, ctypes.byref(f.geom), 0, 0, None, None, None, None, None))
+            if count:
+                p0 = np.full(count, h["p0"])
+                L.check(L.lib.fh_fit_normal_batched(f.ctx, None, None, count, L.ptr(np.ascontiguousarray(al[first:first + count])),
+                                                    L.ptr(p0), L.ptr(np.ascontiguousarray(ws[first:first + count])), h["tol"],
+                                                    h["max_iter"], L.ptr(mu), L.ptr(pp), niter, status))
+            f.sync()
+            mine = time.perf_counter() - t0
+            barrier()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            if best is None or float(dt.item()) < best:
+                best = float(dt.item())
+                mt = torch.tensor([mine], dtype=torch.float64)
+                allm = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(allm, mt)
+                per_rank = [float(x.item()) for x in allm]
+        bad = torch.tensor([int(np.sum(np.array(list(status))[:count] != 0))], dtype=torch.int64)
+        dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+        out2.update({"workload": "BASELINE configs[4]: %d fits (alpha x w_smooth grid), N=%d, one mapping of %d visibilities "
+                                 "binned on rank 0, statistics to all ranks by one RCCL all-reduce, %d fits per rank"
+                                 % (B, a.ncoll, nv, -(-B // world)),
+                     "fits_per_s": B / best, "s_total": best, "per_rank_s": per_rank, "rccl_ranks": comm.size(),
+                     "failed": int(bad.item())})
+    except BaseException as e:  # noqa: BLE001
+        out2["error"] = repr(e)
     comm.close()
 
 
@@ -482,24 +597,26 @@ def main():
     pre_alone = f.prepass_ms()
     loop_ms = f.loop_kernel_ms()
 
-    sharded = None
+    sharded = sweep_multi = None
     hung = False
     if do_shard:
         # in a watchdog thread: an RCCL failure or hang must cost this key, never the headline line
         import threading
-        sharded = {}
+        sharded, sweep_multi = {}, {}
 
         def leg():
             try:
-                sharded_leg(f, L, a, dist, rank, world, local_rank, barrier, sharded)
+                sharded_leg(f, L, a, dist, rank, world, local_rank, barrier, sharded, sweep_multi)
             except BaseException as e:  # noqa: BLE001
                 sharded["error"] = repr(e)
+                sweep_multi.setdefault("error", "the sharded leg before it failed: " + repr(e))
         th = threading.Thread(target=leg, daemon=True)
         th.start()
         th.join(timeout=240.0)
         if th.is_alive():
             hung = True
             sharded = {"error": "sharded leg did not finish within 240 s (rank %d)" % rank}
+            sweep_multi = {"error": "not reached"}
 
     if rank == 0:
         fits = a.steps * world
@@ -514,14 +631,33 @@ def main():
         flops_fit = flops_pass * (nit + 2)
         achieved = flops_fit / (loop_ms * 1e-3) / 1e12
         peak_cu = FP64_MFMA_PEAK_TFLOPS / N_CU
-        traffic, traffic_src = None, None
-        try:  # HBM bytes of one fit_loop launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_fit_loop.json")) as fh:
+        # HBM bytes per launch: STATIC values, read from the PMC summaries committed under profiles/ (rocprofv3 cannot run inside
+        # bench.py); they describe the build the profile was taken from, named in the *_source fields
+        traffic, traffic_src, bin_traffic, bin_traffic_src = None, None, None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_fit_loop.json")) as fh:
                 traffic = json.load(fh)["fit_loop_kernel"]["hbm_bytes_per_launch"] if Nc == 300 else None
-            traffic_src = ("profiles/r02_pmc_fit_loop.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on one fit, FETCH "
-                           "doubled per the gfx950 note)")
+            traffic_src = ("static: profiles/r03_pmc_fit_loop.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on one fit, FETCH "
+                           "doubled per the gfx950 note); not measured in this run")
         except Exception:
             traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_binning.json")) as fh:
+                pm = json.load(fh)
+            if Nc == 300 and a.nvis == N_VIS:
+                bin_traffic = {k: int(e["hbm_bytes_per_launch"]) for k, e in pm.items() if "hbm_bytes_per_launch" in e}
+                bin_traffic["total"] = int(sum(bin_traffic.values()))
+            bin_traffic_src = ("static: profiles/r03_pmc_binning.json (one pass of 1e7 visibilities at N = 300, per kernel; "
+                               "2 x FETCH_SIZE + WRITE_SIZE); not measured in this run")
+        except Exception:
+            bin_traffic = None
+        # the reference's own run of this very input (tests/golden/fit_N300_1e7.npz: 667 iterations) -- rank 0, default sizes
+        ref_iters = None
+        try:
+            if Nc == 300 and a.nvis == N_VIS:
+                ref_iters = int(np.load(os.path.join(ROOT, "tests", "golden", "fit_N300_1e7.npz"))["niter"])
+        except Exception:
+            ref_iters = None
         # -- the binning pass (deproject .. sort .. moments .. Gram of the compressed rows), HBM-bound: 40 B per visibility
         #    (u, v, Re V, Im V, w) over the time of the whole pass, by events
         pass_ms = pre_alone + kms_alone
@@ -535,7 +671,9 @@ def main():
             "config": {"workload": "BASELINE configs[1]: N=%d, %d mock-disc visibilities resident in HBM, Normal GP "
                                    "fit, one independent fit per GPU per step" % (Nc, a.nvis),
                        "alpha": HYPER["alpha"], "wsmooth": HYPER["wsmooth"], "tol": HYPER["tol"],
-                       "iterations_to_converge": nit, "parallelism": "independent fits x%d" % world},
+                       "iterations_to_converge": nit, "iterations_of_the_reference_on_this_input": ref_iters,
+                       "iterations_match_the_reference": (nit == ref_iters) if ref_iters is not None else None,
+                       "parallelism": "independent fits x%d" % world},
             "breakdown_ms": {"single_fit_latency": 1e3 * (t_bin + t_solve), "bin_gram_pass": 1e3 * t_bin,
                              "finalize_plus_iterate": 1e3 * t_solve, "us_per_iteration": 1e6 * t_solve / max(nit, 1),
                              "binning_pass_by_events": pre_alone + kms_alone, "fit_loop_kernel": loop_ms,
@@ -546,19 +684,27 @@ def main():
                          "kernel_ms": loop_ms, "passes": nit + 2, "algorithmic_flops_per_pass": flops_pass,
                          "peak_note": "the kernel is one workgroup: peak = one CU's share (1/256) of the 78.6 TFLOP/s "
                                       "fp64 matrix peak; a pipeline of fits keeps one CU per outstanding fit busy",
-                         "why_this_kernel": "96 % of the GPU time of the timed region (profiles/r02_kernel_stats.csv)"},
-            "roofline_binning": {"kernel": "binning pass: deproject, bucket sort (hist/scan/scatter), bucket moments + factor, "
-                                           + K1_KERNEL_NAME + ", reduce",
+                         "why_this_kernel": "most of the GPU time of the timed region (profiles/r03_kernel_stats.csv)"},
+            "roofline_binning": {"kernel": "binning pass: uv_hist, bucket_scan, deproject_scatter, piece_moments, bucket_factor2, "
+                                           + K1_KERNEL_NAME + ", vr_finish (bin_prepass.hip)",
                                  "bound": "hbm", "achieved": bin_GBps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                  "frac": bin_GBps / HBM_PEAK_GBPS, "pass_ms": pass_ms, "gram_kernel_ms": kms_alone,
-                                 "algorithmic_bytes_per_vis": 40,
+                                 "algorithmic_bytes_per_vis": 40, "traffic": bin_traffic, "traffic_source": bin_traffic_src,
+                                 "achieved_on_traffic_GBps": (bin_traffic["total"] / (pass_ms * 1e-3) / 1e9) if bin_traffic else None,
                                  "row_by_row_equivalent_TFLOPs": flops_sym / (pass_ms * 1e-3) / 1e12,
                                  "note": "the rows of a J0 bucket enter the Gram through 12 x 12 moments, so the pass is "
                                          "memory-bound; row_by_row_equivalent is what binning every visibility on the "
-                                         "matrix pipe (the v2 kernel, 15.2 ms = 0.76 of the fp64 matrix peak) would need"},
+                                         "matrix pipe (the rows kernel, 15.2 ms = 0.76 of the fp64 matrix peak) would need; "
+                                         "what the pass moves: 16 B (u, v) + 40 B (all columns) + 24 B written + 24 B read = "
+                                         "104 B per visibility"},
         }
+        if ref_iters is not None and nit != ref_iters:
+            out["parity_error"] = "the fit took %d iterations, the reference %d on the same input" % (nit, ref_iters)
         if sharded is not None:
             out["sharded_fit"] = sharded
+            out["sweep512_multi"] = sweep_multi
+            out["multi_gpu_note"] = ("the builder's box has one GPU: no N > 1 value of this line was ever measured by the "
+                                     "builder; the scaling curve is the driver's")
         if world == 1 and not a.no_extras:
             out["extra"] = extras(f, L, a)
         if not a.no_cpu_baseline and world == 1:  # the CPU leg is timed at N=1 only

@@ -64,6 +64,7 @@ SIGNATURES = {
     "fh_ctx_set_arithmetic": (ctypes.c_int, [_vp, ctypes.c_int]),
     "fh_ctx_set_reproducible": (ctypes.c_int, [_vp, ctypes.c_int]),
     "fh_ctx_set_range_cache": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "fh_ctx_set_cu_partition": (ctypes.c_int, [_vp, ctypes.c_int]),
     "fh_ctx_set_lognormal_linesearch": (ctypes.c_int, [_vp, ctypes.c_int]),
     "fh_stats_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64), ctypes.POINTER(_vp)]),
     "fh_stats_finalize": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), ctypes.c_int, ctypes.c_int, _dp, _dp, _dp,

@@ -121,7 +121,7 @@ struct FitSlot {
 //    keep ~64 fit loops resident instead of 16.
 // HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; raised to 24 below) and two kernels whose streams
 // share a queue serialise (seen in the kernel trace as 190 ms stalls with 32 streams): 12 launch streams stay one-to-one.
-constexpr int kFitSlots = 128;
+constexpr int kFitSlots = 240;  // capacity; fh_fit_slots() is what a context hands out at a time (FRANK_AMD_FIT_SLOTS)
 constexpr int kFitBatchMax = 16;
 constexpr int kFitBatches = 16;
 struct FitBatch {
@@ -163,6 +163,7 @@ struct fh_ctx {
     DevBuf<double> k1_vrows;        // compressed rows (fh_k1v2_launch_compress): one 16 x 16 chunk per non-empty bucket
     DevBuf<int> k1_cidx, k1_vbucket;
     DevBuf<int> k1_piece0;          // bin_prepass.hip: first partial-moment slot of every bucket
+    int bin_cus = 0;                // fh_ctx_set_cu_partition
     bool no_range_cache = false;    // fh_ctx_set_range_cache(ctx, 0): look at (u, v) on every pass (benchmarks of distinct tables)
     // baseline range of the last pre-pass, keyed by (table, row range, geometry): binning the same rows under the same geometry
     // again (bootstrap draws, pipelines of fits, sweeps) needs no second look at the range before the sort is sized
@@ -213,6 +214,12 @@ struct fh_ctx {
     DevBuf<int> ln_result;
     DevBuf<long long> ln_stats;
 };
+
+// bits [first, last) of a 256-bit compute-unit mask
+static void cu_mask(int first, int last, uint32_t mask[8]) {
+    for (int w = 0; w < 8; ++w) mask[w] = 0;
+    for (int b = first; b < last && b < 256; ++b) mask[b >> 5] |= 1u << (b & 31);
+}
 
 struct fh_comm {
     void *lib = nullptr;
@@ -1090,6 +1097,14 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     if (!c || !g || !vis) return fail(FH_ERR_INVALID, "fh_bin_visibilities: NULL argument");
     if (first < 0 || count < 0 || first + count > vis->n) return fail(FH_ERR_INVALID, "fh_bin_visibilities: bad range");
     if (vis->device != c->device) return fail(FH_ERR_INVALID, "visibility table lives on another device");
+    // single-precision arithmetic of the design block (fh_ctx_set_arithmetic): its Gram is off by ~1e-8 of the largest entry and,
+    // measured, no longer positive definite at 1e7 rows (the first seed solve has unit prior precision, radial_fitters.py:744);
+    // it is also 25 x slower than the fp64 moments pass.  Kept for tables up to 2e6 rows, refused beyond: hand the table over
+    // in single precision instead (fh_vis_upload_f32 -- 20 B per visibility, fp64 arithmetic).
+    if (c->arith32 && count > 2000000)
+        return fail(FH_ERR_UNSUPPORTED, "arithmetic='fp32' covers tables up to 2e6 visibilities (%lld given): beyond, the "
+                    "single-precision Gram loses positive definiteness; pass float32 arrays (fp32 storage, fp64 arithmetic) "
+                    "or use the default arithmetic", (long long)count);
     HIP_TRY(hipSetDevice(c->device));
     BinParams p{};
     p.u = vis->u.p;
@@ -1252,6 +1267,28 @@ int fh_ctx_set_lognormal_linesearch(fh_ctx *c, int reference_products) {
 int fh_ctx_set_reproducible(fh_ctx *c, int on) {
     if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
     c->force_static = on != 0;
+    return FH_OK;
+}
+
+// Compute-unit partition of a pipeline of fits.  A fit loop holds one compute unit for the ~0.1 s of its iteration; the binning
+// passes of the following fits would otherwise put their workgroups on the same units (a fit loop leaves registers and LDS
+// free) and take instruction slots and L1 lines from it.  bin_cus > 0: the context's stream -- every kernel of the binning
+// pass -- is confined to the first bin_cus units of the mask (the bits go round the eight XCDs, so every XCD gives the same
+// share), the streams of the fit loops to the rest.  Call before the first fh_fit_submit of the context.
+int fh_ctx_set_cu_partition(fh_ctx *c, int bin_cus) {
+    if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
+    if (c->slot_pool.p) return fail(FH_ERR_INVALID, "fh_ctx_set_cu_partition: the fit slots of this context exist already");
+    if (bin_cus < 8 || bin_cus > c->num_cu - 8) return fail(FH_ERR_INVALID, "fh_ctx_set_cu_partition: %d of %d compute units", bin_cus, c->num_cu);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint32_t mask[8];
+    cu_mask(0, bin_cus, mask);
+    hipStream_t st = nullptr;
+    HIP_TRY(hipExtStreamCreateWithCUMask(&st, 8, mask));
+    ROC_TRY(rocblas_set_stream(c->blas, st));
+    (void)hipStreamDestroy(c->stream);
+    c->stream = st;
+    c->bin_cus = bin_cus;
     return FH_OK;
 }
 
@@ -1853,11 +1890,16 @@ static int fit_batch_size() {  // fit loops per launch: 16, or FRANK_AMD_FIT_BAT
     if (const char *e = getenv("FRANK_AMD_FIT_BATCH")) b = atoi(e);
     return b < 1 ? 1 : (b > kFitBatchMax ? kFitBatchMax : b);
 }
+static int fit_slots_wanted() {  // fit loops in flight: every one holds a compute unit for the ~0.1 s of its iteration
+    int n = 128;
+    if (const char *e = getenv("FRANK_AMD_FIT_SLOTS")) n = atoi(e);
+    return n < 1 ? 1 : (n > kFitSlots ? kFitSlots : n);
+}
 int fh_fit_slots(void) {  // fits that may be outstanding: bounded by the slots and by the launches in flight
     // (a launch is free again when ALL its fits are collected: with first-in first-out collection one launch may be
     //  partly collected)
-    const int by_launch = (kFitBatches - 1) * fit_batch_size() + 1;
-    return by_launch < kFitSlots ? by_launch : kFitSlots;
+    const int by_launch = (kFitBatches - 1) * fit_batch_size() + 1, want = fit_slots_wanted();
+    return by_launch < want ? by_launch : want;
 }
 
 // launch the batch that is collecting submissions (no-op if there is none)
@@ -1935,7 +1977,13 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
             t.result.adopt(c->slot_results.p + 2 * i, 2);
         }
         for (auto &bt : c->batches) {
-            HIP_TRY(hipStreamCreateWithFlags(&bt.stream, hipStreamNonBlocking));
+            if (c->bin_cus > 0) {  // fh_ctx_set_cu_partition: the fit loops keep to the compute units the binning pass leaves alone
+                uint32_t mask[8];
+                cu_mask(c->bin_cus, c->num_cu, mask);
+                HIP_TRY(hipExtStreamCreateWithCUMask(&bt.stream, 8, mask));
+            } else {
+                HIP_TRY(hipStreamCreateWithFlags(&bt.stream, hipStreamNonBlocking));
+            }
             HIP_TRY(hipEventCreateWithFlags(&bt.ready, hipEventDisableTiming));
         }
         c->fit_batch = fit_batch_size();

@@ -199,6 +199,21 @@ class FrankFitter(FourierBesselFitter):
 
     Same defaults as the reference: alpha=1.05, p_0=1e-15 ('Normal') / 1e-35 ('LogNormal'), weights_smooth=1e-4,
     tol=1e-3, I_scale=1e5, max_iter=2000, convergence_failure='raise'.
+
+    Three arguments the reference does not have:
+      device                 GPU of the fit (default $FRANK_AMD_DEVICE or 0).
+      arithmetic             'fp64' (default).  'fp32': single-precision design block and tile products in the binning
+                             pass, for tables of at most 2e6 visibilities (RuntimeError beyond: the single-precision
+                             Gram loses positive definiteness).  float32 / complex64 input arrays are a different
+                             thing: they are STORED in single precision (20 B per visibility) and binned in fp64.
+      lognormal_linesearch   method='LogNormal' only.  NOTE: the default, 'linear', is NOT the reference's line-search
+                             arithmetic: it forms S^-1 (x + lam p) as S^-1 x + lam S^-1 p instead of multiplying every
+                             trial point out (minimizer.py:74-184, statistical_models.py:1088-1113).  Same minimiser,
+                             same exit tests, but the Armijo test no longer trips over the round-off of the 1e35-sized
+                             entries of S^-1: ~3 x fewer Newton steps and ~8 x less time, a brightness profile within
+                             ~1e-5 of its maximum of the reference's -- as far as the reference is from itself after
+                             a 1e-15 perturbation of M (tests/golden/lognormal_N300_*.npz).  'reference' reproduces the
+                             reference's arithmetic, Newton counters included.
     """
 
     def __init__(self, Rmax, N, geometry, nu=0, block_data=True, block_size=10 ** 5, alpha=1.05, p_0=None,

@@ -137,7 +137,11 @@ int fh_fit_last_kernel_ms(fh_ctx *ctx, float *ms);
  * J0 still reduced in fp64 (bucket centre + offset) and the single-precision accumulators added into fp64 sums every
  * 1024 visibilities; everything downstream (M, j, the fit) is fp64.  The reference has no such mode (NumPy promotes to
  * fp64, geometry.py:69-79): the brightness profile then agrees with the fp64 path to ~1e-5 of its maximum, inside the
- * 1e-3 BASELINE.json states for fp32.  Default 0 (fp64 arithmetic whatever the storage type of the table).           */
+ * 1e-3 BASELINE.json states for fp32.  Default 0 (fp64 arithmetic whatever the storage type of the table).
+ * Limited to tables of at most 2e6 visibilities: fh_bin_visibilities returns FH_ERR_UNSUPPORTED beyond (measured: at 1e7 rows the
+ * single-precision Gram is no longer positive definite, and the pass is 25 x slower than the fp64 moments pass).  What
+ * BASELINE configs[2] calls "fp32" at full size is single-precision STORAGE: fh_vis_upload_f32, 20 B per visibility, binned
+ * by the fp64 path.                                                                                                      */
 int fh_ctx_set_arithmetic(fh_ctx *ctx, int fp32);
 /* Line search of the LogNormal Newton solves (minimizer.py:70-187 evaluates H(x + lam p) afresh for every trial step).
  * The prior precision S^-1 = Y^T diag(1/p) Y has entries ~1/p_0 = 1e35 that cancel in S^-1 x, so a freshly multiplied
@@ -161,6 +165,10 @@ int fh_ctx_set_reproducible(fh_ctx *ctx, int on);
  * before the chunk loop, statistical_models.py:166-169).  on = 0 forgets it and measures the range on every pass -- the cost
  * of binning a table the context has not seen (bench.py `distinct_tables`).  Default: on.                                  */
 int fh_ctx_set_range_cache(fh_ctx *ctx, int on);
+/* Pipelines of fits (fh_fit_submit): confine the binning pass to the first bin_cus compute units and the fit loops to the
+ * others, so that a fit loop -- one workgroup that holds a compute unit for the whole iteration (radial_fitters.py:765-785) --
+ * does not share its unit with the workgroups of the passes that follow.  Before the first fh_fit_submit of the context.     */
+int fh_ctx_set_cu_partition(fh_ctx *ctx, int bin_cus);
 int fh_stats_device(fh_ctx *ctx, double **sum_stats, int64_t *n_sum, double **minmax_stats);
 int fh_stats_finalize(fh_ctx *ctx, const fh_geometry *geom, int vis_model, int check_qbounds, double *M, double *j,
                       double *H0, double *qmin, double *qmax);

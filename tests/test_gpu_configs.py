@@ -167,6 +167,56 @@ def test_lognormal_full_size_fp32_table():
     assert abs(flux(sol.I) / flux(sn.I) - 1) < 0.02
 
 
+# ---- the launcher the driver uses for N > 1 ---------------------------------------------------------------------------
+def test_bench_under_the_multi_rank_launcher(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` on whatever this box has: argument
+    parsing, shard sizing (--sharded-total / --sharded-cap), the gloo rendezvous, the max-over-ranks timing and the ONE
+    JSON line of rank 0 with the keys of both multi-rank legs.  With two devices the legs run (RCCL over xGMI); on a
+    one-GPU box both ranks sit on device 0, RCCL refuses the duplicate device, and the legs must report that under
+    "error" while the headline line still prints (a collective problem costs those keys, never the line)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--nvis", "200000", "--ncoll", "100", "--sharded-total", "3e5", "--sharded-cap", "1e5", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "independent fits x2"
+    for key in ("sharded_fit", "sweep512_multi"):
+        leg = d[key]
+        assert ("error" in leg) or (leg["rccl_ranks"] == 2 and leg["fits_per_s"] > 0), leg
+    if "error" not in d["sharded_fit"]:
+        assert d["sharded_fit"]["nvis_per_rank"] == 100000 and d["sharded_fit"]["nvis_total"] == 200000
+        assert d["sweep512_multi"]["failed"] == 0
+    assert "ever measured by the builder" in d["multi_gpu_note"]
+
+
+def test_fp32_arithmetic_refuses_large_tables():
+    """arithmetic='fp32' (single-precision design block) is limited to 2e6 visibilities: beyond, a message instead of a Gram
+    that is no longer positive definite (include/frank_hip.h, fh_ctx_set_arithmetic); float32 INPUT of any size is fine."""
+    from frank_amd import FrankFitter
+    n = 2_100_000
+    u, v, V, w = mock_disc_visibilities(n, seed=2, noise_seed=3)
+    FF = FrankFitter(2.0, 100, geom(), verbose=False, arithmetic="fp32", check_qbounds=False)
+    with pytest.raises(RuntimeError, match="fp32"):
+        FF.fit(u, v, V, w)
+    F2 = FrankFitter(2.0, 100, geom(), verbose=False, check_qbounds=False)
+    s32 = F2.fit(u.astype(np.float32), v.astype(np.float32), V.astype(np.complex64), w.astype(np.float32))
+    s64 = FrankFitter(2.0, 100, geom(), verbose=False, check_qbounds=False).fit(u, v, V, w)
+    assert rel_to_max(s32.I, s64.I) < 1e-3
+
+
 # ---- configs[4] -----------------------------------------------------------------------------------------------------
 def test_sweep_512_points_work_queue():
     """The configs[4] grid (32 alpha x 16 w_smooth = 512 fits, N = 300) on a 1e6-visibility mapping in ONE launch: with
