@@ -148,6 +148,7 @@ struct fh_ctx {
     int deproject_blocks = 0;
     // K1 v2 (bin_gram2.hip): bucket sort workspaces and the Taylor tables of the buckets seen so far
     bool v2 = false, force_static = false;
+    bool rows_ok = true;             // false: 511 < N <= 1023, only the moments path of the fused kernels exists
     bool check_q_before_bin = false;  // fh_map_visibilities(check_qbounds): _check_uv_range before any binning, as the reference
     double prepass_qmin = 0, prepass_qmax = 0, prepass_qmax_all = 0;
     int XS = 0, k1_nb_built = 0, sort_blocks = 0;
@@ -342,15 +343,27 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     // the first kernel (J0 on the vector ALU, N <= 303), FRANK_AMD_K1=wide forces the rows + dgemm path.
     const char *k1env = getenv("FRANK_AMD_K1");
     const bool want_v1 = k1env && !strcmp(k1env, "v1"), want_wide = k1env && !strcmp(k1env, "wide");
-    c->v2 = !want_v1 && !want_wide && fh_k1v2_nbt_for(N) != 0;
+    // 511 < N <= 1023: the moments path has no register-resident kernel in it (bin_prepass.hip: one workgroup per output
+    // tile), so it runs at any basis size; what cannot go through moments there (debris model, FRANK_AMD_K1=rows) takes the
+    // rows-to-memory + rocBLAS path
+    const bool generic = !want_v1 && !want_wide && fh_k1v2_nbt_for(N) == 0 && N <= 1023;
+    c->v2 = !want_v1 && !want_wide && (fh_k1v2_nbt_for(N) != 0 || generic);
+    c->rows_ok = !generic;
     c->k1_moments = !(k1env && !strcmp(k1env, "rows"));  // FRANK_AMD_K1=rows: the v2 kernel on the visibilities themselves
-    c->NBT = want_wide ? 0 : (c->v2 ? fh_k1v2_nbt_for(N) : fh_k1_nbt_for(N));
+    c->NBT = want_wide ? 0 : (generic ? (N + 1 + 15) / 16 : (c->v2 ? fh_k1v2_nbt_for(N) : fh_k1_nbt_for(N)));
     HIP_TRY(hipEventCreate(&c->ev_pre0));
     HIP_TRY(hipEventCreate(&c->ev_loop0));
     HIP_TRY(hipEventCreate(&c->ev_loop1));
     if (c->NBT) {
         const int G = c->num_cu > 0 ? c->num_cu : 256;
-        if (c->v2) {
+        if (generic) {
+            c->ntiles = c->NBT * (c->NBT + 1) / 2;
+            c->nparts = 1;
+            c->XS = fh_k1v2_xstride(c->NBT);
+            c->k1_delta = fh_k1_bucket_width(dht->zeros.data(), N);
+            HIP_TRY(c->k1_info.alloc(4));
+            HIP_TRY(hipMemset(c->k1_info.p, 0, 4 * sizeof(int)));
+        } else if (c->v2) {
             c->ntiles = fh_k1v2_ntiles(c->NBT);
             c->nparts = fh_k1v2_nparts(c->NBT);
             c->XS = fh_k1v2_xstride(c->NBT);
@@ -661,7 +674,9 @@ int fh_vis_set_multiplicity(fh_vis *vis, const int32_t *counts) {
 
 // ---- K1 ----------------------------------------------------------------------------------------------------------
 // the rows-to-memory + dgemm path is taken for N > 303 always and for the debris model at any N
-static bool use_wide(const fh_ctx *c) { return c->wide || (c->debris && !c->v2); }
+static bool use_wide(const fh_ctx *c) {
+    return c->wide || (c->debris && !c->v2) || (c->v2 && !c->rows_ok && (c->debris || !c->k1_moments));
+}
 static double *dense_gram(fh_ctx *c) { return c->wide ? c->stats_sum.p : c->wide_G.p; }  // (N+1)^2 + 2 scalars
 static size_t dense_tail(const fh_ctx *c) { return ((size_t)c->N + 1) * ((size_t)c->N + 1); }
 
@@ -671,6 +686,7 @@ static int ensure_wide(fh_ctx *c) {
     c->wide_rows = 65536;
     if (c->wide_X.alloc((size_t)c->wide_rows * N1) != hipSuccess || c->wide_G.alloc(N1 * N1 + 2) != hipSuccess)
         return fail(FH_ERR_NOMEM, "device allocation for the rows + dgemm path failed");
+    HIP_TRY(hipMemsetAsync(c->wide_G.p, 0, sizeof(double) * c->wide_G.n, c->stream));  // (fh_bin_reset came before it existed)
     return FH_OK;
 }
 
@@ -1138,7 +1154,13 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     const int64_t nsuper = (count + fh_k1_super() - 1) / fh_k1_super();
     if (nsuper > 0x7fffffff / 2) return fail(FH_ERR_UNSUPPORTED, "more than 2^39 visibilities in one call");
     p.H2 = c->debris ? c->debris_H2.p : nullptr;
+    if (c->arith32 && !c->rows_ok)
+        return fail(FH_ERR_UNSUPPORTED, "arithmetic='fp32' exists for N <= 511 (N = %d)", c->N);
     if (c->v2 && !use_wide(c)) return bin_visibilities_v2(c, p, count, vis->serial, vis->use_mult ? vis->mult_gen : 0);
+    if (use_wide(c)) {
+        const int rcw = ensure_wide(c);
+        if (rcw) return rcw;
+    }
     // K1a scratch: 24 B per visibility (32 B with the debris model's kz^2)
     const size_t cnt1 = (size_t)(count > 0 ? count : 1);
     const size_t need = cnt1 * (c->debris ? 4 : 3);

@@ -162,7 +162,7 @@ hipError_t fh_k1_launch_predict(const double *q, int64_t n, int N, const double 
                                 hipStream_t stream);
 
 // ---- K2 ------------------------------------------------------------------------------------------------
-#define FIT_MAX_N 512
+#define FIT_MAX_N 1024
 enum { FIT_FLAG_DONE = 0, FIT_FLAG_COUNT = 1, FIT_FLAG_BAD_P = 2, FIT_FLAG_NOT_SPD = 3, FIT_FLAG_INFO = 4, FIT_NFLAGS = 8 };
 
 struct FitState {

@@ -455,6 +455,97 @@ def test_moment_path_degenerate_buckets():
         assert abs(m["null_likelihood"] - o["null_likelihood"]) <= 1e-12 * abs(o["null_likelihood"])
 
 
+@pytest.mark.parametrize("N", [512, 640, 1000])
+def test_moments_path_beyond_N511_against_oracle(N):
+    """The reference has no limit on the basis size (frank/hankel.py:70-78).  Beyond N = 511 no register-resident kernel
+    exists; the moments path (bin_prepass.hip: bucket moments + one workgroup per 16 x 16 output tile) does not need one and
+    covers N <= 1023.  No reference fixture at these sizes: the pinned oracle is the referee for M, j, H0."""
+    from frank_amd import DiscreteHankelTransform, VisibilityMapping
+    from oracle import oracle as fo
+    n = 30000
+    u, v, V, w = mock_disc_visibilities(n, seed=21, noise_seed=22)
+    w = w * np.random.default_rng(23).uniform(0.5, 2.0, n)
+    m = VisibilityMapping(DiscreteHankelTransform(RMAX, N), geom(), verbose=False).map_visibilities(u, v, V, w)
+    g = MOCK_GEOMETRY
+    o = fo.map_visibilities(N, RMAX, (g["inc"], g["PA"], g["dRA"], g["dDec"]), u, v, V, w)
+    assert rel_to_max(m["M"], o["M"]) < 5e-13 and rel_to_max(m["j"], o["j"]) < 5e-13
+    assert abs(m["null_likelihood"] - o["null_likelihood"]) <= 1e-12 * abs(o["null_likelihood"])
+    assert np.array_equal(m["M"], m["M"].T)
+
+
+def test_fit_N512_first_iterations_against_oracle():
+    """A whole FrankFitter pass at N = 512 (moments binning + the library-based iteration that covers 320 < N <= 1024): the
+    first 25 power-spectrum iterations against the oracle's (radial_fitters.py:737-832; the full 1e3-iteration fit would
+    take the single-threaded oracle a quarter of an hour)."""
+    from frank_amd import FrankFitter
+    from oracle import oracle as fo
+    N, n, it = 512, 40000, 25
+    u, v, V, w = mock_disc_visibilities(n, seed=24, noise_seed=25)
+    FF = FrankFitter(2.0, N, geom(), verbose=False, max_iter=it, convergence_failure="ignore",
+                     store_iteration_diagnostics=True)
+    sol = FF.fit(u, v, V, w)
+    g = MOCK_GEOMETRY
+    o = fo.map_visibilities(N, RMAX, (g["inc"], g["PA"], g["dRA"], g["dDec"]), u, v, V, w)
+    ref = fo.frank_fit_normal(N, RMAX, o["M"], o["j"], max_iter=it)
+    assert ref["rc"] == 0 and FF.iteration_diagnostics["num_iterations"] == ref["niter"] == it + 1
+    assert rel_to_max(sol.I, ref["mu"]) < 1e-6
+    np.testing.assert_allclose(sol.power_spectrum, ref["p"], rtol=1e-6)
+
+
+def test_moment_path_under_hostile_uv_coverage(monkeypatch):
+    """Where real (u, v) coverage hurts a moment-compressed bucket (statistical_models.py:192-214 is a plain sum and does not
+    care): (i) weights spanning twelve orders of magnitude inside one bucket; (ii) 1e5 copies of one baseline plus a few
+    distinct ones in the same bucket (a moment matrix that is rank one to 1e-5); (iii) baselines exactly on bucket edges,
+    one ulp either side of them, and q = 0; (iv) one bucket holding 90 % of 1e6 rows.  M, j within 1e-12 of the oracle's
+    row-by-row sums (i-iii) and of the rows path (iv, and all of them): the pivot cut of the bucket factorisation
+    (bin_prepass.hip, 1.5e-14 of the diagonal) never drops more than round-off."""
+    import ctypes
+    from frank_amd import DiscreteHankelTransform, FixedGeometry, VisibilityMapping, _lib
+    from oracle import oracle as fo
+    N = 100
+    rng = np.random.default_rng(31)
+    dht = DiscreteHankelTransform(RMAX, N)
+    delta = ctypes.c_double(0)
+    _lib.check(_lib.lib.fh_dht_bucket_tables(dht._handle, 0, 0, None, ctypes.byref(delta)))
+    width = delta.value * dht.Qmax  # bucket width in wavelengths
+    assert 0 < width < dht.Qmax / 100
+
+    def ring(q):
+        phi = rng.uniform(0, 2 * np.pi, np.size(q))
+        return q * np.cos(phi), q * np.sin(phi)
+    cases = {}
+    # (i) one bucket (number 40), weights 1e-6 .. 1e6
+    q = (40 + rng.uniform(0.02, 0.98, 20000)) * width
+    cases["weights"] = (*ring(q), 10.0 ** rng.uniform(-6, 6, q.size))
+    # (ii) 1e5 copies of one baseline + 5 distinct ones, same bucket
+    q = np.concatenate([np.full(100000, 57.3 * width), (57 + np.array([0.05, 0.2, 0.5, 0.8, 0.95])) * width])
+    u, v = ring(q)
+    u[:100000], v[:100000] = u[0], v[0]
+    cases["repeated"] = (u, v, rng.uniform(0.5, 2.0, q.size))
+    # (iii) bucket edges, their neighbours one ulp away, and the origin
+    e = np.arange(1, 200) * width
+    q = np.concatenate([e, np.nextafter(e, 0), np.nextafter(e, np.inf), [0.0, 0.0, width / 3]])
+    u, v = np.zeros(q.size), q.copy()  # (u = 0 exactly: the deprojected baseline IS q)
+    cases["edges"] = (u, v, rng.uniform(0.5, 2.0, q.size))
+    # (iv) 90 % of 1e6 rows in one bucket
+    n = 1_000_000
+    q = np.where(rng.uniform(size=n) < 0.9, (12 + rng.uniform(0, 1, n)) * width, np.exp(rng.uniform(np.log(2e4), np.log(2e6), n)))
+    cases["crowded"] = (*ring(q), rng.uniform(0.5, 2.0, n))
+    geom0 = FixedGeometry(inc=0.0, PA=0.0, dRA=0.0, dDec=0.0)
+    for name, (u, v, w) in cases.items():
+        V = rng.normal(size=u.size) + 1j * rng.normal(size=u.size)
+        m = VisibilityMapping(DiscreteHankelTransform(RMAX, N), geom0, verbose=False).map_visibilities(u, v, V, w)
+        monkeypatch.setenv("FRANK_AMD_K1", "rows")
+        r = VisibilityMapping(DiscreteHankelTransform(RMAX, N), geom0, verbose=False).map_visibilities(u, v, V, w)
+        monkeypatch.delenv("FRANK_AMD_K1")
+        assert rel_to_max(m["M"], r["M"]) < 1e-12 and rel_to_max(m["j"], r["j"]) < 1e-12, name
+        assert abs(m["null_likelihood"] - r["null_likelihood"]) <= 1e-12 * abs(r["null_likelihood"]), name
+        if u.size <= 200000:
+            o = fo.map_visibilities(N, RMAX, (0.0, 0.0, 0.0, 0.0), u, v, V, w)
+            assert rel_to_max(m["M"], o["M"]) < 1e-12 and rel_to_max(m["j"], o["j"]) < 1e-12, name
+            assert abs(m["null_likelihood"] - o["null_likelihood"]) <= 1e-12 * abs(o["null_likelihood"]), name
+
+
 @pytest.mark.parametrize("N", [340, 400, 511])
 def test_fused_gram_beyond_N303_against_oracle(N):
     """The fused bin_gram covers N <= 511: the tile triangle is cut into two (N <= 383) or three row-aligned parts whose
