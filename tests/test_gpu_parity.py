@@ -622,6 +622,55 @@ def test_bootstrap_matches_reference(golden):
     assert np.isfinite(sol.I).all()
 
 
+def test_multiplicities_that_drop_the_longest_baseline_do_not_poison_the_range():
+    """A bootstrap draw leaves the longest baseline out with probability 1/e: the baseline range of THAT draw must not size the
+    bucket sort of the next one (rows beyond the remembered range would be pushed into the last bucket and evaluated outside
+    it: M, j silently wrong).  The sort is sized from the range of all rows, and the remembered range is keyed on the draw."""
+    import ctypes
+    from frank_amd import DiscreteHankelTransform, VisibilityMapping, _lib
+    from oracle import oracle as fo
+    L = _lib.lib
+    N, n = 100, 20000
+    rng = np.random.default_rng(77)
+    q = np.exp(rng.uniform(np.log(2e4), np.log(4e5), n))
+    q[123] = 3.9e6  # one row ten times further out than all the others
+    phi = rng.uniform(0, 2 * np.pi, n)
+    u, v = q * np.cos(phi), q * np.sin(phi)
+    V = rng.normal(size=n) + 1j * rng.normal(size=n)
+    w = rng.uniform(0.5, 2.0, n)
+    dht = DiscreteHankelTransform(RMAX, N)
+    ctx = dht.context()
+    geom0 = _lib.fh_geometry(0.0, 0.0, 0.0, 0.0)
+    table = ctypes.c_void_p()
+    Vre, Vim = np.ascontiguousarray(V.real), np.ascontiguousarray(V.imag)
+    _lib.check(L.fh_vis_upload(dht.device, _lib.ptr(u), _lib.ptr(v), _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), n, n,
+                               ctypes.byref(table)))
+    try:
+        def bin_with(counts):
+            _lib.check(L.fh_vis_set_multiplicity(table, None if counts is None else counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+            _lib.check(L.fh_bin_reset(ctx))
+            _lib.check(L.fh_bin_visibilities(ctx, ctypes.byref(geom0), table, 0, n))
+            M, j = np.empty((N, N)), np.empty(N)
+            H0, qmn, qmx = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            _lib.check(L.fh_stats_finalize(ctx, ctypes.byref(geom0), 0, 0, _lib.ptr(M), _lib.ptr(j), ctypes.byref(H0),
+                                           ctypes.byref(qmn), ctypes.byref(qmx)))
+            return M, j, qmx.value
+        c1 = np.ones(n, dtype=np.int32)
+        c1[123] = 0                      # the draw that misses the long baseline
+        c2 = np.ones(n, dtype=np.int32)
+        c2[123] = 3                      # the next one draws it three times
+        M1, j1, qmax1 = bin_with(c1)
+        M2, j2, qmax2 = bin_with(c2)
+        M3, j3, qmax3 = bin_with(None)   # and multiplicities off again
+        assert qmax1 < 5e5 < qmax2 == qmax3
+        for counts, (M, j) in ((c1, (M1, j1)), (c2, (M2, j2)), (np.ones(n, dtype=np.int32), (M3, j3))):
+            idx = np.repeat(np.arange(n), counts)
+            o = fo.map_visibilities(N, RMAX, (0.0, 0.0, 0.0, 0.0), u[idx], v[idx], V[idx], w[idx], check_qbounds=False)
+            assert rel_to_max(M, o["M"]) < 1e-12 and rel_to_max(j, o["j"]) < 1e-12
+    finally:
+        L.fh_vis_destroy(table)
+
+
 # ---- UVDataBinner / estimate_weights (next-tier row f4): HBM-bound histogram, integer bin indices ----------------
 
 @pytest.mark.parametrize("tag", ["a", "b"])
