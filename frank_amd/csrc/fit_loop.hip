@@ -11,7 +11,7 @@
 // W = L^-1 (N^3/6) -- Tr2_i = sum_r W[r,i]^2 and m = W^T (W b) -- instead of the reference's 13 N^3/6.
 // The brightness mu = Y^-1 m is formed once at the end (and per iteration only for the diagnostics).
 // The iteration is sequential and tiny (1.8e7 flop), so it is latency-bound: everything runs inside one
-// 1024-thread workgroup (16 waves, s_barrier only), matrices stay in L2, the 16x16 tile products run on
+// 768-thread workgroup (12 waves, s_barrier only), matrices stay in L2, the 16x16 tile products run on
 // v_mfma_f64_16x16x4_f64.  One launch per fit, no host round trip; fits are independent, so many of these
 // kernels run concurrently (one CU each) beside the bin_gram kernel of the next fit.
 #include <hip/hip_runtime.h>

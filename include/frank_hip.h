@@ -298,8 +298,9 @@ int fh_uvbin_quantities(fh_uvbin *h, const double *uv, const double *w, const do
 
 /* vis_model='debris' (statistical_models.py:96-102, 494-496): H2[k] = 0.5 * (2 pi scale_height(r_k) / rad_to_arcsec)^2,
  * N host doubles.  While set, fh_bin_visibilities scales each row by exp(-kz_i^2 H2[k]) (kz = the vertical uv-distance
- * of the 3-D deprojection, geometry.py:128) and takes the rows-to-memory + rocBLAS path; fh_stats_finalize /
- * fh_map_visibilities must then be called with FH_VIS_DEBRIS.  H2 = NULL switches back.                             */
+ * of the 3-D deprojection, geometry.py:128): on the fused rows kernel for N <= 511 (the generated design block is scaled in
+ * registers; the bucket moments do not apply, the factor does not split into row x column), through rows-to-memory + rocBLAS
+ * beyond; fh_stats_finalize / fh_map_visibilities must then be called with FH_VIS_DEBRIS.  H2 = NULL switches back.          */
 int fh_ctx_set_scale_height(fh_ctx *ctx, const double *H2);
 
 /* ---- multi-GPU: RCCL all-reduce of the sufficient statistics (one rank per GPU) ------------------------------
@@ -309,7 +310,7 @@ int fh_comm_unique_id(char id[128]);
 int fh_comm_create(const char id[128], int rank, int world, int device, fh_comm **out);
 void fh_comm_destroy(fh_comm *comm);
 /* Sums the context's statistics over the ranks in place, asynchronously on the context's stream: the packed tile
- * triangle (N <= 303) or the dense (N+1)^2 Gram of the composed path (N > 303, or the debris model), each with its two
+ * triangle (the fused paths: N <= 1023 by default) or the dense (N+1)^2 Gram of the rows + rocBLAS path, each with its two
  * scalars, plus a 2-double max-reduce of (-qmin, qmax).  fh_stats_finalize afterwards yields the unsharded M, j, H0. */
 int fh_comm_allreduce_stats(fh_comm *comm, fh_ctx *ctx);
 /* Device time (ms, HIP events on the context's stream) of the most recent fh_comm_allreduce_stats. */
