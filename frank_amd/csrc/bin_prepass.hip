@@ -419,26 +419,38 @@ __global__ __launch_bounds__(256) void piece_moments_kernel(PrepassParams P) {
     for (int m = 0; m < kMom; ++m) mu[m] = 0.0;
 #pragma unroll
     for (int n = 0; n < kTerms; ++n) nu[n] = 0.0;
-    // (the next group's three loads are in flight while this one's 120 multiply-adds run: a wave has 32 groups and, at 148
-    // registers, only two companions on its SIMD to hide a memory round trip behind)
+    // A group of 128 rows is 3 KB.  Lane l wants rows 2l, 2l + 1 = bytes 48 l .. 48 l + 47, but three 16-byte loads at a stride of
+    // 48 bytes make every load instruction touch all 24 lines of the group: three times the L2 requests (the kernel sat at the
+    // request rate of the L2, ~1e11 per second, at 3.4 TB/s).  So the wave loads the group as three fully coalesced 1 KB
+    // pieces (lane l: bytes 16 l of each), passes them through its own 3 KB of LDS and reads its 48 bytes back.
+    // The next group's loads are in flight while this one's 120 multiply-adds run.
+    __shared__ __attribute__((aligned(16))) d2 stage[4][192];
+    d2 *lds3 = stage[threadIdx.x >> 6];
     d2 n0 = d2{0.0, 0.0}, n1 = n0, n2 = n0;
-    int i = r0 + 2 * lane;
-    if (i < r1) {
-        const d2 *rp = reinterpret_cast<const d2 *>(rb + (size_t)i * 3);
-        n0 = __builtin_nontemporal_load(rp);
-        n1 = __builtin_nontemporal_load(rp + 1);
-        n2 = __builtin_nontemporal_load(rp + 2);
-    }
-    for (; i < r1; i += 128) {
-        const d2 x0 = n0, x1 = n1, x2 = n2;
-        if (i + 128 < r1) {
-            const d2 *rp = reinterpret_cast<const d2 *>(rb + (size_t)(i + 128) * 3);
-            n0 = __builtin_nontemporal_load(rp);
-            n1 = __builtin_nontemporal_load(rp + 1);
-            n2 = __builtin_nontemporal_load(rp + 2);
-        }
-        const bool two = i + 1 < r1;  // (what lies behind the piece may be the next bucket's rows)
-        const double tau[2] = {x0.x, two ? x1.y : 0.0}, sw[2] = {x0.y, two ? x2.x : 0.0}, swV[2] = {x1.x, two ? x2.y : 0.0};
+    const int r0a = r0;  // (a multiple of 16 rows: 384 bytes)
+    auto issue = [&](int g0) {  // rows g0 .. g0 + 127; whole 16-byte pieces inside the sorted table (its tail is padded)
+        const d2 *gp = reinterpret_cast<const d2 *>(rb + (size_t)g0 * 3) + lane;
+        n0 = __builtin_nontemporal_load(gp);
+        n1 = __builtin_nontemporal_load(gp + 64);
+        n2 = __builtin_nontemporal_load(gp + 128);
+    };
+    int g0 = r0a;
+    if (g0 < r1) issue(g0);
+    for (; g0 < r1; g0 += 128) {
+        lds3[lane] = n0;
+        lds3[64 + lane] = n1;
+        lds3[128 + lane] = n2;
+        if (g0 + 128 < r1) issue(g0 + 128);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const d2 x0 = lds3[3 * lane], x1 = lds3[3 * lane + 1], x2 = lds3[3 * lane + 2];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int i = g0 + 2 * lane;
+        const bool one = i < r1, two = i + 1 < r1;  // (what lies behind the piece may be the next bucket's rows)
+        const double tau[2] = {one ? x0.x : 0.0, two ? x1.y : 0.0}, sw[2] = {one ? x0.y : 0.0, two ? x2.x : 0.0},
+                     swV[2] = {one ? x1.x : 0.0, two ? x2.y : 0.0};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const double w = sw[h] * sw[h], wv = sw[h] * swV[h];
