@@ -87,9 +87,8 @@ __global__ __launch_bounds__(1024) void uv_hist_kernel(PrepassParams P) {
         red[2][wave] = qmax_all;
     }
     __syncthreads();
-    if (HIST) {
-        int *row = P.hist + (size_t)blockIdx.x * P.nb;
-        for (int b = threadIdx.x; b < P.nb; b += blockDim.x) row[b] = lds_i[b];
+    if (HIST) {  // bucket-major: hist[b][workgroup]
+        for (int b = threadIdx.x; b < P.nb; b += blockDim.x) P.hist[(size_t)b * P.hist_stride + blockIdx.x] = lds_i[b];
     }
     if (threadIdx.x == 0) {
         double mn = INFINITY, mx = -INFINITY, ma = -INFINITY;
@@ -106,47 +105,74 @@ __global__ __launch_bounds__(1024) void uv_hist_kernel(PrepassParams P) {
 }
 
 // ---- scan + layout -----------------------------------------------------------------------------------------------
-// hist[workgroup][bucket] -> rows of the bucket in earlier workgroups (in place); totals[bucket].  A workgroup of the scan
-// takes 64 buckets (one per lane: rows of `hist` are read 256 bytes at a time), its 16 thread groups 16 contiguous ranges
-// of rows.  The last workgroup to arrive (ticket in info[3]) then does the serial part on the totals -- O(buckets):
+// hist[bucket][workgroup] (bucket-major: a bucket's counts are contiguous) -> rows of the bucket in earlier workgroups (in
+// place); totals[bucket].  One WAVE per bucket: eight counts per lane in two 16-byte loads, a prefix inside the lane, a scan
+// over the lanes.  (The first version -- workgroup-major histograms, a workgroup per 64 buckets, 16 thread groups walking down
+// the rows -- was four workgroups for the 243 buckets of the bench: 24 us of dependent L2 round trips.)
+// The last workgroup to arrive (ticket in info[3]) then does the serial part on the totals -- O(buckets):
 //   starts[b]   first sorted row of bucket b (multiple of 16; the <= 15 padding rows behind a bucket are zeroed),
 //   cidx[b]     number of non-empty buckets before b; info[1] their total,
 //   piece0[b]   first slot of the bucket's partial moments: P3 cuts the SORTED TABLE into segments of seg_rows rows, bucket b
 //               meets the segments starts[b] / seg_rows .. (starts[b] + tot - 1) / seg_rows, one slot each.
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+// exclusive prefix of `v` over the 1024 threads of the workgroup (thread order); *total = the sum.  Two barriers.
+__device__ __forceinline__ int block_exclusive_scan(int v, int *wsum /* [16] */, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int inc = wave_inclusive_scan(v, lane);
+    __syncthreads();  // (wsum may still be read from the scan before)
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int before = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+        const int x = wsum[w];
+        before += w < wave ? x : 0;
+        tot += x;
+    }
+    *total = tot;
+    return before + inc - v;
+}
 __global__ __launch_bounds__(1024) void bucket_scan_kernel(PrepassParams P) {
-    __shared__ int part[kScanGroups][64];
-    __shared__ int sc[3][1024];
+    __shared__ int wsum[16];
     __shared__ int last;
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int nb = P.nb, nw = P.blocks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nb = P.nb, G = P.blocks;
     {
-        const int b = blockIdx.x * 64 + lane;
-        const int per = (nw + kScanGroups - 1) / kScanGroups, k0 = min(nw, g * per), k1 = min(nw, k0 + per);
-        int sum = 0;
+        const int b = blockIdx.x * 16 + wave;
         if (b < nb) {
-#pragma unroll 8
-            for (int k = k0; k < k1; ++k) sum += P.hist[(size_t)k * nb + b];
-        }
-        part[g][lane] = sum;
-        __syncthreads();
-        int run = 0;
-        for (int hh = 0; hh < g; ++hh) run += part[hh][lane];
-        if (b < nb) {
-#pragma unroll 8
-            for (int k = k0; k < k1; ++k) {
-                const int v = P.hist[(size_t)k * nb + b];
-                P.hist[(size_t)k * nb + b] = run;
-                run += v;
+            int *row = P.hist + (size_t)b * P.hist_stride;
+            // lane l holds the counts of workgroups [per l, per (l + 1)): per = a multiple of 4, rows are padded to it
+            const int per = P.hist_stride / 64;
+            int run = 0;
+            for (int k = 0; k < per; ++k) run += lane * per + k < G ? row[lane * per + k] : 0;  // (the padding holds whatever)
+            const int inc = wave_inclusive_scan(run, lane);
+            int pre = inc - run;
+            for (int k = 0; k < per; ++k) {
+                if (lane * per + k < G) {
+                    const int v = row[lane * per + k];
+                    row[lane * per + k] = pre;
+                    pre += v;
+                }
             }
-            if (g == kScanGroups - 1) P.totals[b] = run;
+            if (lane == 63) P.totals[b] = inc;
         }
     }
-    __threadfence();
+    // (one fence per workgroup: on this multi-die part an agent-scope release writes the XCD's L2 back -- with every one of the
+    //  16 x 1024 threads fencing, the kernel took 25 us; the barrier orders the other threads' stores before thread 0's fence.
+    //  The last workgroup reads the totals with agent-scope atomic loads, which do not go through its L1.)
     __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(&P.info[3], 1) == (int)gridDim.x - 1;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(&P.info[3], 1) == (int)gridDim.x - 1;
+    }
     __syncthreads();
     if (!last) return;
-    __threadfence();
     const int t = threadIdx.x;
     const int per = (nb + 1023) / 1024;
     const int b0 = min(nb, t * per), b1 = min(nb, b0 + per);
@@ -158,22 +184,11 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(PrepassParams P) {
         s_rows += (tot + 15) & ~15;
         s_ne += tot > 0;
     }
-    sc[0][t] = s_rows;
-    sc[1][t] = s_ne;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scans
-        int a0 = 0, a1 = 0;
-        if (t >= off) {
-            a0 = sc[0][t - off];
-            a1 = sc[1][t - off];
-        }
-        __syncthreads();
-        sc[0][t] += a0;
-        sc[1][t] += a1;
-        __syncthreads();
-    }
+    int tot_rows, tot_ne, tot_pc;
+    const int e_rows = block_exclusive_scan(s_rows, wsum, &tot_rows);
+    const int e_ne = block_exclusive_scan(s_ne, wsum, &tot_ne);
     // pass 2: starts, indices, padding; the pieces of each bucket (their number needs the bucket's start)
-    int r_rows = sc[0][t] - s_rows, r_ne = sc[1][t] - s_ne, s_pc = 0;
+    int r_rows = e_rows, r_ne = e_ne, s_pc = 0;
     for (int b = b0; b < b1; ++b) {
         const int tot = __hip_atomic_load(&P.totals[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int pad = (tot + 15) & ~15;
@@ -187,16 +202,8 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(PrepassParams P) {
         r_rows += pad;
         r_ne += tot > 0;
     }
-    sc[2][t] = s_pc;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int a2 = t >= off ? sc[2][t - off] : 0;
-        __syncthreads();
-        sc[2][t] += a2;
-        __syncthreads();
-    }
-    int r_pc = sc[2][t] - s_pc;
-    r_rows = sc[0][t] - s_rows;
+    int r_pc = block_exclusive_scan(s_pc, wsum, &tot_pc);
+    r_rows = e_rows;
     for (int b = b0; b < b1; ++b) {
         const int tot = __hip_atomic_load(&P.totals[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         P.piece0[b] = r_pc;
@@ -204,12 +211,12 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(PrepassParams P) {
         r_rows += (tot + 15) & ~15;
     }
     if (t == 1023) {
-        P.starts[nb] = sc[0][1023];
-        P.piece0[nb] = sc[2][1023];
-        P.info[0] = sc[0][1023] / 16;
-        P.info[1] = sc[1][1023];
-        P.info[2] = (sc[0][1023] + seg - 1) / seg;  // segments of the sorted table
-        P.info[3] = 0;                               // the ticket of the next pass
+        P.starts[nb] = tot_rows;
+        P.piece0[nb] = tot_pc;
+        P.info[0] = tot_rows / 16;
+        P.info[1] = tot_ne;
+        P.info[2] = (tot_rows + seg - 1) / seg;  // segments of the sorted table
+        P.info[3] = 0;                             // the ticket of the next pass
     }
 }
 
@@ -242,8 +249,7 @@ __global__ __launch_bounds__(1024) void deproject_scatter_kernel(PrepassParams P
     const int nb = P.nb;
     int *cnt = lds_i, *wc = lds_i + nb;
     {
-        const int *wg = P.hist + (size_t)blockIdx.x * nb;
-        for (int b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = P.starts[b] + wg[b];
+        for (int b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = P.starts[b] + P.hist[(size_t)b * P.hist_stride + blockIdx.x];
         for (int e = threadIdx.x; e < wpb * nb; e += blockDim.x) wc[e] = 0;
     }
     int *wcw = wc + wave * nb;
@@ -759,7 +765,7 @@ hipError_t fh_prepass_launch(const PrepassParams &P, hipStream_t stream) {
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(uv_hist_kernel<true>, dim3(P.blocks), dim3(64 * P.wpb), lds1, stream, P);
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3((P.nb + 63) / 64), dim3(1024), 0, stream, P);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3((P.nb + 15) / 16), dim3(1024), 0, stream, P);
     e = launch_scatter(P, lds2, stream);
     if (e != hipSuccess) return e;
     const int64_t max_pieces = fh_prepass_max_pieces(P.bin.count, P.nb, P.seg_rows);

@@ -1008,8 +1008,11 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     const size_t nrows = (size_t)count + 16 * (size_t)nb + 16, max_pc = (size_t)fh_prepass_max_pieces(count, nb, seg);
     const size_t md = (size_t)fh_prepass_moment_doubles();
     if (c->k1_rows.n < nrows * 3 && c->k1_rows.alloc(nrows * 3 + 1024) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc (sorted rows) failed");
-    if (c->k1_hist.n < (size_t)P.blocks * nb && c->k1_hist.alloc((size_t)P.blocks * nb + 1024) != hipSuccess)
-        return fail(FH_ERR_NOMEM, "hipMalloc (histograms) failed");
+    P.hist_stride = (P.blocks + 255) & ~255;
+    if (c->k1_hist.n < (size_t)P.hist_stride * nb) {
+        if (c->k1_hist.alloc((size_t)P.hist_stride * nb + 1024) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc (histograms) failed");
+        HIP_TRY(hipMemsetAsync(c->k1_hist.p, 0, sizeof(int) * c->k1_hist.n, c->stream));  // (the padding of the rows stays zero)
+    }
     if (c->k1_totals.n < (size_t)nb && c->k1_totals.alloc((size_t)nb + 256) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc failed");
     if (c->k1_starts.n < (size_t)nb + 1 && c->k1_starts.alloc((size_t)nb + 257) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc failed");
     if (c->k1_cidx.n < (size_t)nb && c->k1_cidx.alloc((size_t)nb + 256) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc failed");

@@ -100,7 +100,8 @@ struct PrepassParams {
     int seg_rows;             // rows per segment of the sorted table in P3 (a multiple of 128)
     int safe_trig;            // phases u dRA + v dDec beyond 1e5 rad may occur: P2 takes the library's sincos
     int64_t dummy_row;        // a row behind the sorted table that lanes past the end of the visibility table write to
-    int *hist;                // [blocks][nb] rows per workgroup and bucket, then (scan) in earlier workgroups
+    int *hist;                // [nb][hist_stride] rows per bucket and workgroup (zero beyond `blocks`), then (scan) in earlier workgroups
+    int hist_stride;          // blocks rounded up to a multiple of 256 (four counts per lane and 16-byte alignment in the scan)
     int *totals;              // [nb]
     int *starts;              // [nb + 1] first sorted row of every bucket (multiples of 16)
     int *cidx;                // [nb] index of the bucket among the non-empty ones
