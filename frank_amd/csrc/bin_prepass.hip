@@ -272,6 +272,7 @@ __global__ __launch_bounds__(1024) void deproject_scatter_kernel(PrepassParams P
         for (int j = 0; j < U; ++j) {
             int64_t g = p.first + tt * tile + (wave * U + j) * 64 + lane;
             g = g < last ? g : last;
+            if (p.count == 0) g = 0;  // (an empty range: a table holds at least one element)
             const int64_t gw = p.w_scalar ? 0 : g;
             if (F32) {
                 r[j].u = (double)p.u32[g];
