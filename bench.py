@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--sharded-total", type=float, default=1e8, help="visibilities of the sharded fit (all ranks)")
     ap.add_argument("--sharded-cap", type=float, default=2.5e7, help="most visibilities one rank generates / holds")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (extra.*)")
+    ap.add_argument("--force-legs", action="store_true",
+                    help="run the two multi-rank legs (sharded_fit, sweep512_multi) even at WORLD_SIZE = 1, over a one-rank "
+                         "RCCL communicator: every line of them on a one-GPU box (tests)")
     return ap.parse_args()
 
 
@@ -556,9 +559,12 @@ def main():
     from frank_amd.mock import mock_disc_visibilities
 
     dist = None
-    if world > 1:
+    if world > 1 or a.force_legs:
         import torch
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
@@ -567,7 +573,7 @@ def main():
 
     ndev = max(L.device_count(), 1)
     f = Fitter(L, a.ncoll, local_rank % ndev)  # (more ranks than GPUs only happens in the 1-GPU smoke run of this path)
-    do_shard = world > 1 and not a.no_sharded
+    do_shard = (world > 1 or a.force_legs) and not a.no_sharded
     f.nfit = a.nvis
     f.n_shard = int(min(-(-int(a.sharded_total) // world), int(a.sharded_cap))) if do_shard else 0
     nrows = max(a.nvis, f.n_shard)

@@ -202,6 +202,30 @@ def test_bench_under_the_multi_rank_launcher(tmp_path):
     assert "ever measured by the builder" in d["multi_gpu_note"]
 
 
+def test_multi_rank_legs_over_a_one_rank_communicator():
+    """Both multi-rank legs of bench.py (configs[3]: sharded fit + RCCL all-reduce of the packed statistics; configs[4]: the
+    512-point sweep split over the ranks) run end to end on ONE GPU over a one-rank RCCL communicator (--force-legs): every
+    line of them executes before the driver's first 8-GPU run does, and with one rank the sharded fit must be the plain fit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--nvis", "300000", "--ncoll", "100",
+           "--sharded-total", "3e5", "--sharded-cap", "3e5", "--no-cpu-baseline", "--no-extras", "--force-legs"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    d = json.loads(lines[0])
+    sh, sw = d["sharded_fit"], d["sweep512_multi"]
+    assert "error" not in sh, sh
+    assert "error" not in sw, sw
+    assert sh["rccl_ranks"] == 1 and sh["nvis_total"] == 300000 and sh["iterations"] == d["config"]["iterations_to_converge"]
+    assert sh["allreduce_us"] > 0 and len(sh["binning_pass_ms_per_rank"]) == 1 and sh["binning_pass_ms_per_rank"][0] > 0
+    assert sw["rccl_ranks"] == 1 and sw["failed"] == 0 and sw["fits_per_s"] > 0 and len(sw["per_rank_s"]) == 1
+
+
 def test_fp32_arithmetic_refuses_large_tables():
     """arithmetic='fp32' (single-precision design block) is limited to 2e6 visibilities: beyond, a message instead of a Gram
     that is no longer positive definite (include/frank_hip.h, fh_ctx_set_arithmetic); float32 INPUT of any size is fine."""
