@@ -422,6 +422,33 @@ def extras(f, L, a):
                           "not_converged": int(np.sum(its >= h["max_iter"]))}
     except Exception as e:
         ex["sweep512"] = {"error": repr(e)}
+    # -- LogNormal fits in one launch, one compute unit each (fh_fit_lognormal_batched): 64 points of an (alpha, w_smooth) grid
+    #    over the same 1e6-visibility mapping, default line search
+    try:
+        al, ws = np.meshgrid(np.linspace(1.1, 1.5, 8), np.logspace(-3, -1, 8))
+        al, ws = np.ascontiguousarray(al.ravel()), np.ascontiguousarray(ws.ravel())
+        B = al.size
+        p0 = np.full(B, 1e-35)
+        s_map, pp = np.empty((B, N)), np.empty((B, N))
+        niter = (ctypes.c_int * B)()
+        status = (ctypes.c_int * B)()
+        stats = (ctypes.c_int64 * (9 * B))()
+        nv = min(f.n, 1_000_000)
+        L.check(L.lib.fh_ctx_set_lognormal_linesearch(f.ctx, 0))
+        t0 = time.perf_counter()
+        f.bin(nv)
+        finalize()
+        L.check(L.lib.fh_fit_lognormal_batched(f.ctx, None, None, B, L.ptr(al), L.ptr(p0), L.ptr(ws), h["tol"], h["max_iter"],
+                                               1e5, L.ptr(s_map), L.ptr(pp), niter, status, stats))
+        dt = time.perf_counter() - t0
+        its = np.array(list(niter))
+        ex["lognormal_batched64"] = {"workload": "%d LogNormal fits (alpha x w_smooth grid) of one mapping of %d visibilities, "
+                                                 "N=%d, one compute unit each, one launch" % (B, nv, N),
+                                     "linesearch": "linear", "fits_per_s": B / dt, "s_total": dt,
+                                     "iterations_min_median_max": [int(its.min()), int(np.median(its)), int(its.max())],
+                                     "failed": int(np.sum(np.array(list(status)) != 0))}
+    except Exception as e:
+        ex["lognormal_batched64"] = {"error": repr(e)}
     # -- UVDataBinner (next-tier row f4): three streaming passes, 72 algorithmic bytes per row
     try:
         from frank_amd.utilities import UVDataBinner
