@@ -622,6 +622,63 @@ def test_bootstrap_matches_reference(golden):
     assert np.isfinite(sol.I).all()
 
 
+@pytest.mark.parametrize("safe", [False, True])
+@pytest.mark.parametrize("kind", ["f64", "f32", "mult"])
+def test_prepass_instances_against_oracle(monkeypatch, kind, safe):
+    """The eight instances of the fused deproject + scatter kernel (bin_prepass.hip: bootstrap multiplicities x single-precision
+    table x library sincos for large phases) on three geometries -- face-on at the phase centre, the AS 209 geometry, and an 80
+    degree inclination with arcsecond offsets -- against the oracle's row-by-row NumPy-order arithmetic (geometry.py:69-79,
+    111-131; statistical_models.py:200-218)."""
+    import ctypes
+    from frank_amd import DiscreteHankelTransform, _lib
+    from oracle import oracle as fo
+    if safe:
+        monkeypatch.setenv("FRANK_AMD_K1_SAFE_TRIG", "1")
+    L = _lib.lib
+    N, n = 64, 30011
+    rng = np.random.default_rng(5)
+    for gi, (inc, PA, dRA, dDec) in enumerate([(0.0, 0.0, 0.0, 0.0), GEOM, (80.0, -33.0, 1.3, -0.7)]):
+        q = np.exp(rng.uniform(np.log(2e4), np.log(6e5), n))
+        phi = rng.uniform(0, 2 * np.pi, n)
+        u, v = q * np.cos(phi), q * np.sin(phi)
+        V = rng.normal(size=n) + 1j * rng.normal(size=n)
+        w = rng.uniform(0.5, 2.0, n)
+        counts = None
+        if kind == "f32":
+            u, v, w = (x.astype(np.float32).astype(np.float64) for x in (u, v, w))
+            V = V.astype(np.complex64).astype(np.complex128)
+        if kind == "mult":
+            counts = rng.integers(0, 4, n).astype(np.int32)
+        dht = DiscreteHankelTransform(RMAX, N)
+        ctx = dht.context()
+        g = _lib.fh_geometry(inc, PA, dRA, dDec)
+        table = ctypes.c_void_p()
+        Vre, Vim = np.ascontiguousarray(V.real), np.ascontiguousarray(V.imag)
+        if kind == "f32":
+            a = [np.ascontiguousarray(x, dtype=np.float32) for x in (u, v, Vre, Vim, w)]
+            _lib.check(L.fh_vis_upload_f32(dht.device, _lib.fptr(a[0]), _lib.fptr(a[1]), _lib.fptr(a[2]), _lib.fptr(a[3]),
+                                           _lib.fptr(a[4]), n, n, ctypes.byref(table)))
+        else:
+            _lib.check(L.fh_vis_upload(dht.device, _lib.ptr(u), _lib.ptr(v), _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), n, n,
+                                       ctypes.byref(table)))
+        try:
+            if counts is not None:
+                _lib.check(L.fh_vis_set_multiplicity(table, counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+            _lib.check(L.fh_bin_reset(ctx))
+            _lib.check(L.fh_bin_visibilities(ctx, ctypes.byref(g), table, 0, n))
+            M, j = np.empty((N, N)), np.empty(N)
+            H0, qmn, qmx = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            _lib.check(L.fh_stats_finalize(ctx, ctypes.byref(g), 0, 0, _lib.ptr(M), _lib.ptr(j), ctypes.byref(H0),
+                                           ctypes.byref(qmn), ctypes.byref(qmx)))
+        finally:
+            L.fh_vis_destroy(table)
+        idx = np.arange(n) if counts is None else np.repeat(np.arange(n), counts)
+        o = fo.map_visibilities(N, RMAX, (inc, PA, dRA, dDec), u[idx], v[idx], V[idx], w[idx], check_qbounds=False)
+        assert rel_to_max(M, o["M"]) < 1e-12 and rel_to_max(j, o["j"]) < 1e-12, (kind, safe, gi)
+        assert abs(H0.value - o["null_likelihood"]) <= 1e-12 * abs(o["null_likelihood"]), (kind, safe, gi)
+        assert abs(qmx.value - o["qmax"]) <= 1e-15 * o["qmax"] * 4 if "qmax" in o else True
+
+
 def test_multiplicities_that_drop_the_longest_baseline_do_not_poison_the_range():
     """A bootstrap draw leaves the longest baseline out with probability 1/e: the baseline range of THAT draw must not size the
     bucket sort of the next one (rows beyond the remembered range would be pushed into the last bucket and evaluated outside
