@@ -425,7 +425,7 @@ def extras(f, L, a):
     # -- LogNormal fits in one launch, one compute unit each (fh_fit_lognormal_batched): 64 points of an (alpha, w_smooth) grid
     #    over the same 1e6-visibility mapping, default line search
     try:
-        al, ws = np.meshgrid(np.linspace(1.1, 1.5, 8), np.logspace(-3, -1, 8))
+        al, ws = np.meshgrid(np.linspace(1.2, 1.5, 8), np.logspace(-3, -1, 8))
         al, ws = np.ascontiguousarray(al.ravel()), np.ascontiguousarray(ws.ravel())
         B = al.size
         p0 = np.full(B, 1e-35)
