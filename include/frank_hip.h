@@ -114,9 +114,12 @@ int fh_vis_set_multiplicity(fh_vis *vis, const int32_t *counts);
  *   fh_bin_reset      zero the context's sufficient statistics
  *   fh_bin_visibilities  add rows [first, first+count) of `vis`.  The pre-pass reads the baseline range back once (it
  *                     sizes the bucket sort, and it is what _check_uv_range needs before any binning,
- *                     statistical_models.py:166-169); binning the SAME rows of the SAME table under the SAME geometry again
- *                     (bootstrap draws, pipelines, sweeps) re-uses that range and the call does not wait for the device
- *                     (FRANK_AMD_NO_RANGE_CACHE=1 switches this off)
+ *                     statistical_models.py:166-169); binning the SAME rows of the SAME table under the SAME geometry and the
+ *                     SAME multiplicities again (pipelines, sweeps) re-uses that range and the call does not wait for the
+ *                     device (fh_ctx_set_range_cache(ctx, 0) or FRANK_AMD_NO_RANGE_CACHE=1 switches this off).
+ *                     Default path (bin_prepass.hip): the rows of a J0 bucket enter the Gram through their 13 x 13 moment
+ *                     matrix; N <= 1023.  Rows path (debris model, single-precision arithmetic, FRANK_AMD_K1=rows): every
+ *                     visibility through the design-block + Gram kernel (N <= 511), rows-to-memory + rocBLAS beyond
  *   fh_stats_device   device pointer / length (doubles) of the packed statistics, for an RCCL all-reduce
  *   fh_stats_finalize apply the DHT scaling, unpack to M (N*N), j (N), H0, qmin, qmax (host, any may be NULL);
  *                     the device copies of M and j stay in the context for fh_fit_normal(M = NULL).  With every output
@@ -127,8 +130,9 @@ int fh_bin_reset(fh_ctx *ctx);
 int fh_bin_visibilities(fh_ctx *ctx, const fh_geometry *geom, const fh_vis *vis, int64_t first, int64_t count);
 /* Device time (ms, HIP events on the context's stream) of the most recent bin_gram launch alone. */
 int fh_bin_last_kernel_ms(fh_ctx *ctx, float *ms);
-/* Time (ms) from the start of the deprojection pre-pass to the start of that bin_gram launch: deprojection, the host's
- * look at the baseline range (the _check_uv_range input, statistical_models.py:166-169) and the bucket sort.          */
+/* Time (ms) from the start of the binning pass to the start of its Gram kernel: the host's look at the baseline range when the
+ * context has not seen the rows before (the _check_uv_range input, statistical_models.py:166-169), the (u, v) histogram, the
+ * fused deprojection + bucket sort and the bucket moments (default path), or deprojection + bucket sort (rows path).       */
 int fh_bin_last_prepass_ms(fh_ctx *ctx, float *ms);
 /* Duration of the fit_loop kernel of the last fh_fit_normal call, by HIP events on the context's stream (bench.py). */
 int fh_fit_last_kernel_ms(fh_ctx *ctx, float *ms);
