@@ -89,6 +89,14 @@ constexpr int NWK = K2_ALL_WORK ? NW - 1 : NW - NW / 4;
 #endif
 constexpr int kChain = K2_CHAIN_WAVE;
 constexpr int kMaxTiles = 210;  // tiles of the largest trailing triangle: NP / 16 - 1 = 20 block rows (NP <= 336)
+// WIDE (336 < NP <= 480, N <= 478): two panels of NP x 17 doubles no longer fit the 160 KB of LDS beside the vectors and the scan
+// tables.  ONE panel then: the tiles of column k + 1 are computed into registers, a second barrier of the step lets everybody
+// finish reading panel k, and only then panel k + 1 overwrites it.  Two barriers per step instead of one; N <= 320 is untouched
+// (its own instantiation).  Before this, 320 < N <= 512 ran the library loop: ~8 x the time per pass at N = 321.
+constexpr int kMaxTilesWide = 435;  // 29 block rows
+constexpr int kWideMinNP = 337, kWideMaxNP = 480;
+template <bool WIDE> constexpr int max_tiles() { return WIDE ? kMaxTilesWide : kMaxTiles; }
+template <bool WIDE> constexpr int npanels() { return WIDE ? 1 : 2; }
 
 struct Smem {
     double *pan;   // panels of the current and the next block column: 2 x NP x PS doubles
@@ -215,6 +223,7 @@ __device__ __forceinline__ void inverse_tile(const gdouble *Cu, const double *dl
 // hold the trailing matrix in progress, every tile TRANSPOSED (tile (I, J) holds T_IJ^T: the update swaps its operands, and
 // the tiles of column k + 1 are then the B operands of D = L_{k+1,k+1}^-1 T^T as they stand -- no transposition on the
 // way into the panel); W lower = L^-1.  A, C and W are stored as PACKED tiles (tile_chol.h): two contiguous 1 KB accesses.
+template <bool WIDE>
 __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Smem &S) {
     const int N = P.N, NP = P.NP, nb = P.NP / 16, ld = P.NP;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
@@ -302,7 +311,8 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
         const int m = nb - k - 1;
         const int cntA = __builtin_amdgcn_readfirstlane(m * (m - 1) / 2);  // tiles with k + 1 < J <= I
         const int ncol = __builtin_amdgcn_readfirstlane(max(m - 1, 0));     // tiles (I, k + 1), I > k + 1
-        double *pan_cur = S.pan + (size_t)(k & 1) * NP * PS, *pan_nxt = S.pan + (size_t)((k + 1) & 1) * NP * PS;
+        double *pan_cur = S.pan + (WIDE ? (size_t)0 : (size_t)(k & 1) * NP * PS);
+        double *pan_nxt = S.pan + (WIDE ? (size_t)0 : (size_t)((k + 1) & 1) * NP * PS);
         int *ctr_cur = S.flag + 1 + (k & 1);
         if (tid == 0) S.flag[1 + ((k + 1) & 1)] = 0;  // column counter of the NEXT step's inverse row (nobody reads it now)
         const unsigned base_pk = (unsigned)((k + 1) * (nb + 1) * 2048);   // tile (k+1, k+1), packed
@@ -353,6 +363,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 FSTAMP(10);
                 TRACE(5);
             }
+            if constexpr (WIDE) __syncthreads();  // (everybody has read panel k: the column tiles may overwrite it)
             inverse_columns();
             TRACE(4);
         } else {
@@ -424,6 +435,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             // (the round-robin deal of the tiles goes on where the enumeration above stopped)
             int cfirst = widx - cntA % NWK;
             if (cfirst < 0) cfirst += NWK;
+            v4f64 dcol[WIDE ? 3 : 1];  // (WIDE: ncol <= 28 = 3 x NWK - 5)
             if (cfirst < ncol) {
                 // L_{k+1,k+1}^-1 comes from wave 0's chain (~5 us into the step): inverse columns fill the wait
                 if (k >= 1) {
@@ -451,20 +463,52 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 Frag fx;  // L_{k+1,k+1}^-1: as A operand X, as B operand X^T
 #pragma unroll
                 for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[((k + 1) & 1) * 16 * PS + cl * PS + 4 * q + rg];
-                for (int c = cfirst; c < ncol; c += NWK) {
-                    const int i = c + 1;  // block row I = k + 1 + i
-                    v4f64 t = ld_pk(src_u, base_pk + (unsigned)(k == 0 ? i * 2048 : i * nb * 2048), lane);
-                    t = upd(0u, (unsigned)(i * 16 * PS * 8), t);  // T^T = C_{I,k+1}^T - L_{k+1,k} L_Ik^T: the tile is kept transposed
-                    Frag ft;  // as B operand: T^T (the accumulator registers of a matrix are its B fragments)
+                if constexpr (!WIDE) {
+                    for (int c = cfirst; c < ncol; c += NWK) {
+                        const int i = c + 1;  // block row I = k + 1 + i
+                        v4f64 t = ld_pk(src_u, base_pk + (unsigned)(k == 0 ? i * 2048 : i * nb * 2048), lane);
+                        t = upd(0u, (unsigned)(i * 16 * PS * 8), t);  // T^T = C_{I,k+1}^T - L_{k+1,k} L_Ik^T: the tile is kept transposed
+                        Frag ft;  // as B operand: T^T (the accumulator registers of a matrix are its B fragments)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) ft.v[q] = t[q];
-                    const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
-                    const v4f64 d = mfma4(fx, ft, z4, false);  // D = X T^T = L_{I,k+1}^T  (what the panel from memory computes)
-                    // tile (k+1, I): the block the inverse reads; L_{I,k+1} itself (block (I, k+1)) has no reader
-                    st_pk(C_u, base_pk + (unsigned)(i * 2048), lane, d);
-                    double *pr = pan_nxt + (size_t)((i - 1) * 16 + cl) * PS + rg;
+                        for (int q = 0; q < 4; ++q) ft.v[q] = t[q];
+                        const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
+                        const v4f64 d = mfma4(fx, ft, z4, false);  // D = X T^T = L_{I,k+1}^T  (what the panel from memory computes)
+                        // tile (k+1, I): the block the inverse reads; L_{I,k+1} itself (block (I, k+1)) has no reader
+                        st_pk(C_u, base_pk + (unsigned)(i * 2048), lane, d);
+                        double *pr = pan_nxt + (size_t)((i - 1) * 16 + cl) * PS + rg;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
+                        for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
+                    }
+                } else {
+                    // one panel: the tiles stay in registers until everybody has read panel k (the barrier below)
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const int c = cfirst + u * NWK;
+                        if (c < ncol) {
+                            const int i = c + 1;
+                            v4f64 t = ld_pk(src_u, base_pk + (unsigned)(k == 0 ? i * 2048 : i * nb * 2048), lane);
+                            t = upd(0u, (unsigned)(i * 16 * PS * 8), t);
+                            Frag ft;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) ft.v[q] = t[q];
+                            const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
+                            dcol[u] = mfma4(fx, ft, z4, false);
+                        }
+                    }
+                }
+            }
+            if constexpr (WIDE) {
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int c = cfirst + u * NWK;
+                    if (c < ncol) {
+                        const int i = c + 1;
+                        st_pk(C_u, base_pk + (unsigned)(i * 2048), lane, dcol[u]);
+                        double *pr = pan_nxt + (size_t)((i - 1) * 16 + cl) * PS + rg;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pr[4 * r] = dcol[u][r];
+                    }
                 }
             }
             TRACE(3);
@@ -504,7 +548,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
 // vectors: 2 x 5 recurrence steps and 6 x (2 shuffles + 4 fmas) per lane and direction instead of 2 N dependent steps of
 // one thread (16 us per pass, 50 us before its LDS traffic was trimmed).  dir 0: forward, coefficients f1, f2; dir 1: backward
 // over reversed rows, coefficients u1 / d, u2 / d, right-hand side r / d.
-constexpr int kScanB = 6;  // rows per lane: 64 * 6 = 384 >= NP
+template <bool WIDE> constexpr int scan_rows() { return WIDE ? 8 : 6; }  // rows per lane: 64 * 6 = 384, 64 * 8 = 512 >= NP
 __device__ __forceinline__ double shfl_up_f64(double v, int off) { return __shfl_up(v, off); }
 __device__ __forceinline__ void scan_coef(const double *band, int NP, int dir, int row, double &a1, double &a2, double &rs) {
     // row: position along the direction of the recurrence; rows past NP - 1 are the identity recurrence x = 0
@@ -525,7 +569,9 @@ __device__ __forceinline__ void scan_coef(const double *band, int NP, int dir, i
         rs = rd;
     }
 }
+template <bool WIDE>
 __device__ __forceinline__ void scan_tables(const double *band, int NP, double *Q, int lane) {
+    constexpr int kScanB = scan_rows<WIDE>();
     for (int dir = 0; dir < 2; ++dir) {
         double A00 = 1.0, A01 = 0.0, A10 = 0.0, A11 = 1.0;  // product of the block's M_i, latest on the left
 #pragma unroll
@@ -560,7 +606,9 @@ __device__ __forceinline__ void scan_tables(const double *band, int NP, double *
     }
 }
 // one direction of the solve, by wave 0 (all 64 lanes); rhs: NP entries in LDS, solved in place
+template <bool WIDE>
 __device__ __forceinline__ void scan_solve(const double *band, int NP, const double *Q, double *rhs, int dir, int lane) {
+    constexpr int kScanB = scan_rows<WIDE>();
     double a1[kScanB], a2[kScanB], r[kScanB];
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -598,6 +646,7 @@ __device__ __forceinline__ void scan_solve(const double *band, int NP, const dou
     }
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_fit;
@@ -652,7 +701,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     const int tid = threadIdx.x;
     Smem S;
     S.pan = smem;
-    S.dli = S.pan + 2 * NP * PS;
+    S.dli = S.pan + npanels<WIDE>() * NP * PS;
     S.p = S.dli + 2 * 16 * PS;
     S.pold = S.p + NP;
     S.m = S.pold + NP;
@@ -664,8 +713,8 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     S.band = S.red + NP;
     S.scanQ = S.band + 6 * NP;  // [2 directions][6 levels][4 entries][64 lanes]
     S.rec = reinterpret_cast<uint4 *>(S.scanQ + 2 * 6 * 4 * 64);  // (16-byte aligned: every region before it is an even number of doubles)
-    S.flag = reinterpret_cast<int *>(S.rec + kMaxTiles);  // [0] not positive definite, [1] column counter of the inverse row
-    for (int e = tid; e < kMaxTiles; e += KT) {  // tile e = (i - 1) i / 2 + (j - 1), 1 <= j <= i
+    S.flag = reinterpret_cast<int *>(S.rec + max_tiles<WIDE>());  // [0] not positive definite, [1] column counter of the inverse row
+    for (int e = tid; e < max_tiles<WIDE>(); e += KT) {  // tile e = (i - 1) i / 2 + (j - 1), 1 <= j <= i
         int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while ((i + 1) * (i + 2) / 2 <= e) ++i;
         while (i * (i + 1) / 2 > e) --i;
@@ -686,7 +735,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         }
     if (P.band_lu) {
         __syncthreads();
-        if (tid < 64) scan_tables(S.band, NP, S.scanQ, tid);
+        if (tid < 64) scan_tables<WIDE>(S.band, NP, S.scanQ, tid);
     }
     for (int i = tid; i < NP; i += KT) {
         S.b[i] = i < N ? P.bq[i] : 0.0;
@@ -711,7 +760,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
 #ifdef FIT_LOOP_TIMING
         P.trace_on = (count == 5);
 #endif
-        if (!solve_posterior(P, S)) {
+        if (!solve_posterior<WIDE>(P, S)) {
             status = FIT_STATUS_NOT_SPD;
             break;
         }
@@ -774,8 +823,8 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
             // operations, instead of being hoisted out of the pass loop, kept alive across the factorisation and spilled)
             int t = tid;
             asm volatile("" : "+v"(t));
-            scan_solve(S.band, NP, S.scanQ, S.rhs, 0, t);
-            scan_solve(S.band, NP, S.scanQ, S.rhs, 1, t);
+            scan_solve<WIDE>(S.band, NP, S.scanQ, S.rhs, 0, t);
+            scan_solve<WIDE>(S.band, NP, S.scanQ, S.rhs, 1, t);
         }
 #else
         if (tid == 0) {
@@ -894,17 +943,12 @@ __global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int 
 
 }  // namespace
 
+static bool loop_is_wide(int NP) { return NP >= kWideMinNP; }
+int fh_k2_loop_max_np() { return kWideMaxNP; }
 size_t fh_k2_loop_smem_bytes(int NP) {
-    return sizeof(double) * (size_t)(2 * NP * PS + 2 * 16 * PS + 7 * NP + NP + 6 * NP + 2 * 6 * 4 * 64) + 16 * kMaxTiles + 32;
-}
-
-hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s) {
-    const size_t smem = fh_k2_loop_smem_bytes(P.NP);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fit_loop_kernel, dim3(batch), dim3(KT), smem, s, P);
-    return hipGetLastError();
+    const bool wide = loop_is_wide(NP);
+    return sizeof(double) * (size_t)((wide ? 1 : 2) * NP * PS + 2 * 16 * PS + 7 * NP + NP + 6 * NP + 2 * 6 * 4 * 64) +
+           16 * (size_t)(wide ? kMaxTilesWide : kMaxTiles) + 32;
 }
 
 // Development experiment (FRANK_AMD_K2_DUMMY=<milliseconds>): a workgroup that occupies a CU exactly like the fit loop
@@ -924,43 +968,35 @@ __global__ __launch_bounds__(KT) void fit_loop_dummy_kernel(long long cycles, in
     }
 }
 
-hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s) {
+// one launch of `blocks` workgroups of the instantiation that covers P.NP
+static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s) {
     const size_t smem = fh_k2_loop_smem_bytes(P.NP);
-    if (const char *e = getenv("FRANK_AMD_K2_DUMMY")) {
-        static bool attr = false;
-        if (!attr) {
-            hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_dummy_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (er != hipSuccess) return er;
-            attr = true;
-        }
-        hipLaunchKernelGGL(fit_loop_dummy_kernel, dim3(1), dim3(KT), smem, s, (long long)(atof(e) * 2.4e6), P.result);
-        return hipGetLastError();
-    }
-    {  // per launch (cheap): the attribute is per device, and contexts on several devices share this code
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_kernel),
+    if (P.NP > kWideMaxNP) return hipErrorInvalidValue;
+    if (const char *d = getenv("FRANK_AMD_K2_DUMMY")) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_dummy_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fit_loop_dummy_kernel, dim3(blocks), dim3(KT), smem, s, (long long)(atof(d) * 2.4e6), P.result);
+        return hipGetLastError();
     }
-    hipLaunchKernelGGL(fit_loop_kernel, dim3(1), dim3(KT), smem, s, P);
+    // the attribute per launch (cheap): it is per device, and contexts on several devices share this code
+    if (loop_is_wide(P.NP)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fit_loop_kernel<true>, dim3(blocks), dim3(KT), smem, s, P);
+    } else {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fit_loop_kernel<false>, dim3(blocks), dim3(KT), smem, s, P);
+    }
     return hipGetLastError();
 }
 
-hipError_t fh_k2_launch_loop_slots(const FitLoopParams &P, int nslots, hipStream_t s) {
-    const size_t smem = fh_k2_loop_smem_bytes(P.NP);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    if (const char *d = getenv("FRANK_AMD_K2_DUMMY")) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_dummy_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fit_loop_dummy_kernel, dim3(nslots), dim3(KT), smem, s, (long long)(atof(d) * 2.4e6), P.result);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(fit_loop_kernel, dim3(nslots), dim3(KT), smem, s, P);
-    return hipGetLastError();
-}
+hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s) { return launch_loop(P, batch, s); }
+hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s) { return launch_loop(P, 1, s); }
+hipError_t fh_k2_launch_loop_slots(const FitLoopParams &P, int nslots, hipStream_t s) { return launch_loop(P, nslots, s); }
 
 hipError_t fh_k2_launch_symmetrize(const double *Araw, const double *bq, int N, int NP, double *A, hipStream_t s) {
     hipLaunchKernelGGL(symmetrize_pad_kernel, dim3(128), dim3(256), 0, s, Araw, bq, N, NP, A);

@@ -497,6 +497,41 @@ def test_moments_path_beyond_N511_against_oracle(N):
     assert np.array_equal(m["M"], m["M"].T)
 
 
+@pytest.mark.parametrize("N", [340, 400, 478])
+def test_wide_fit_loop_against_the_library_loop(monkeypatch, N):
+    """320 < N <= 478: the persistent fit loop with ONE LDS panel (fit_loop.hip, WIDE) against the library loop (rocBLAS +
+    rocSOLVER per iteration, FRANK_AMD_K2=rocsolver) that used to serve these sizes -- whole fits to convergence: the same
+    number of iterations, profiles to 1e-8 of the maximum -- and, at N = 400, the first 20 iterations against the oracle
+    (radial_fitters.py:737-832)."""
+    from frank_amd import FrankFitter
+    from oracle import oracle as fo
+    n = 60000
+    u, v, V, w = mock_disc_visibilities(n, seed=31, noise_seed=32)
+    kw = dict(alpha=1.3, weights_smooth=1e-2, verbose=False, store_iteration_diagnostics=True)
+    FF = FrankFitter(2.0, N, geom(), **kw)
+    pre = FF.preprocess_visibilities(u, v, V, w)
+    sol = FF.fit_preprocessed(pre)
+    nit = FF.iteration_diagnostics["num_iterations"]
+    monkeypatch.setenv("FRANK_AMD_K2", "rocsolver")
+    FL = FrankFitter(2.0, N, geom(), **kw)
+    sol_l = FL.fit_preprocessed(dict(pre, hash=[False, FL._DHT, FL._geometry, "opt_thick", None]))
+    monkeypatch.delenv("FRANK_AMD_K2")
+    assert nit == FL.iteration_diagnostics["num_iterations"] and 10 < nit < 2000
+    assert rel_to_max(sol.I, sol_l.I) < 1e-8
+    np.testing.assert_allclose(sol.power_spectrum, sol_l.power_spectrum, rtol=1e-7)
+    if N == 400:
+        F2 = FrankFitter(2.0, N, geom(), max_iter=20, convergence_failure="ignore", **kw)
+        s2 = F2.fit_preprocessed(dict(pre, hash=[False, F2._DHT, F2._geometry, "opt_thick", None]))
+        ref = fo.frank_fit_normal(N, RMAX, pre["M"], pre["j"], alpha=1.3, wsmooth=1e-2, max_iter=20)
+        assert ref["niter"] == F2.iteration_diagnostics["num_iterations"] == 21
+        assert rel_to_max(s2.I, ref["mu"]) < 1e-6
+        np.testing.assert_allclose(s2.power_spectrum, ref["p"], rtol=1e-6)
+        # the batched (sweep) launch and the pipeline go through the same kernel
+        from frank_amd.sweep import sweep_fits
+        sols, its = sweep_fits(FF, pre, np.array([1.3, 1.2]), np.array([1e-2, 1e-1]))
+        assert its[0] == nit and rel_to_max(sols[0].I, sol.I) < 1e-12
+
+
 def test_fit_N512_first_iterations_against_oracle():
     """A whole FrankFitter pass at N = 512 (moments binning + the library-based iteration that covers 320 < N <= 1024): the
     first 25 power-spectrum iterations against the oracle's (radial_fitters.py:737-832; the full 1e3-iteration fit would
