@@ -38,7 +38,6 @@ namespace {
 constexpr int kTerms = FH_K1_TERMS;          // 12
 constexpr int kMom = 2 * kTerms - 1;         // moments 0 .. 22 of tau
 constexpr int kMomAll = kMom + kTerms + 1;   // + nu_0 .. nu_11 + eta = 36
-constexpr int kScanGroups = 16;
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
