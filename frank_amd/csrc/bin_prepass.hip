@@ -105,8 +105,8 @@ __global__ __launch_bounds__(1024) void uv_hist_kernel(PrepassParams P) {
 
 // ---- scan + layout -----------------------------------------------------------------------------------------------
 // hist[bucket][workgroup] (bucket-major: a bucket's counts are contiguous) -> rows of the bucket in earlier workgroups (in
-// place); totals[bucket].  One WAVE per bucket: eight counts per lane in two 16-byte loads, a prefix inside the lane, a scan
-// over the lanes.  (The first version -- workgroup-major histograms, a workgroup per 64 buckets, 16 thread groups walking down
+// place); totals[bucket].  One WAVE per bucket: a few consecutive counts per lane, a prefix inside the lane, a scan over the
+// lanes.  (The first version -- workgroup-major histograms, a workgroup per 64 buckets, 16 thread groups walking down
 // the rows -- was four workgroups for the 243 buckets of the bench: 24 us of dependent L2 round trips.)
 // The last workgroup to arrive (ticket in info[3]) then does the serial part on the totals -- O(buckets):
 //   starts[b]   first sorted row of bucket b (multiple of 16; the <= 15 padding rows behind a bucket are zeroed),
@@ -223,10 +223,9 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(PrepassParams P) {
 // Stable scatter without atomics.  A workgroup owns the same tiles of rows as in P1 and keeps ONE write front per bucket
 // (cnt[b] in LDS, starting at bucket start + rows of the bucket in earlier workgroups): 256 fronts x the buckets are a few MB of
 // partly written lines, which the L2 merges (one front per WAVE was 16 x as many: 1.8 x the bytes went to memory).  Inside a
-// tile a row's place is front + rows of its bucket in earlier waves of the tile + rows of its bucket in earlier lanes of its
-// wave: per 64 rows the lanes of equal bucket find each other with one ballot per bucket-index bit, the first of them
-// publishes their number (wc[wave][b]); after one barrier it adds up the earlier waves' numbers; after a second one the
-// first wave that holds the bucket advances the front.  The same place in every run.
+// tile a row's place is front + rows of its bucket in earlier waves of the tile + its rank among the rows of its bucket in its
+// own wave (an LDS atomic add on the wave's counter wc[wave][b], below); after one barrier every lane adds up the earlier waves'
+// counters; after a second one the first row of a bucket in the tile advances the front.  The same place in every run.
 // The per-row arithmetic is the fast set of deproject.h (the pass was half bound by fp64 vector instructions); the sum of
 // log(w / 2 pi) (statistical_models.py:218) is the log of a running product -- mantissa and exponent kept apart, one
 // logarithm per lane at the end instead of one per row, and a smaller rounding error than the sum of the logarithms.
