@@ -740,6 +740,11 @@ def main():
                                      "builder; the scaling curve is the driver's")
         if world == 1 and not a.no_extras:
             out["extra"] = extras(f, L, a)
+            ss = out["extra"].get("steady_state", {})
+            if "fits_per_s" in ss:  # the same algorithmic flops against the WHOLE chip, at the rate the pipeline sustains
+                out["roofline"]["chip_fraction_at_steady_state"] = ss["fits_per_s"] * flops_fit / 1e12 / FP64_MFMA_PEAK_TFLOPS
+                out["roofline"]["chip_note"] = ("one fit loop is one CU: frac above is against 1/256 of the chip; %d loops "
+                                                "resident at steady state" % ss.get("fit_slots", 0))
         if not a.no_cpu_baseline and world == 1:  # the CPU leg is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(a.ncoll, a.nvis, nit)
         print(json.dumps(out), flush=True)
