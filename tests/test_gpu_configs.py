@@ -213,7 +213,11 @@ def test_multi_rank_legs_over_a_one_rank_communicator():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--nvis", "300000", "--ncoll", "100",
            "--sharded-total", "3e5", "--sharded-cap", "3e5", "--no-cpu-baseline", "--no-extras", "--force-legs"]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
