@@ -212,7 +212,8 @@ struct fh_ctx {
     DevBuf<double> scratch_q, scratch_out, scratch_I;
     // LogNormal (lognormal.hip)
     DevBuf<double> ln_Sinv, ln_H, ln_LU, ln_Hinv, ln_s, ln_p, ln_pin, ln_guess, ln_diag_p, ln_diag_s;
-    DevBuf<int> ln_result;
+    DevBuf<int> ln_result, ln_ctl;
+    DevBuf<double> ln_cluster_vecs;  // 1 / p, diag(L), Tr2: what the helper workgroups of a cluster exchange with the first
     DevBuf<long long> ln_stats;
 };
 
@@ -2198,6 +2199,9 @@ static int ln_finish(fh_ctx *c, double *s, double *p, double *Dinv, int64_t *sta
 #endif
     if (result[1] == LN_STATUS_BAD_P) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (non-positive or NaN)");
     if (result[1] == LN_STATUS_SLOPE) return fail(FH_ERR_NUMERIC, "Round off in slope calculation (LineSearch)");
+    if (result[1] == LN_STATUS_CLUSTER)
+        return fail(FH_ERR_HIP, "the helper workgroups of the LogNormal cluster did not answer within 2 s (FRANK_AMD_LN_CLUSTER=1 "
+                    "runs the fit on one workgroup)");
     return FH_OK;
 }
 
@@ -2260,6 +2264,22 @@ int fh_fit_lognormal(fh_ctx *c, const double *M, const double *j, double alpha, 
     P.tol = tol;
     P.s0 = log(I_scale);  // radial_fitters.py:712
     P.guess = c->mu_out.p;
+    {   // a cluster of workgroups for the parallel pieces of a pass (lognormal.hip): FRANK_AMD_LN_CLUSTER workgroups (default 4
+        // from N = 160 on, where S^-1 and the Tr2 solve are worth a hand-over; 1 = off)
+        int cl = env_int("FRANK_AMD_LN_CLUSTER", N >= 160 ? 4 : 1);
+        cl = cl < 1 ? 1 : (cl > 8 ? 8 : cl);
+        if (cl > 1) {
+            const size_t nv = (size_t)2 * N + P.NP;
+            if (!c->ln_ctl.p) HIP_TRY(c->ln_ctl.alloc(8));
+            if (c->ln_cluster_vecs.n < nv) HIP_TRY(c->ln_cluster_vecs.alloc(nv));
+            HIP_TRY(hipMemsetAsync(c->ln_ctl.p, 0, 8 * sizeof(int), c->stream));
+            P.cluster = cl;
+            P.ctl = c->ln_ctl.p;
+            P.rk_g = c->ln_cluster_vecs.p;
+            P.tr2_g = c->ln_cluster_vecs.p + N;
+            P.dvec_g = c->ln_cluster_vecs.p + 2 * N;
+        }
+    }
     HIP_TRY(fh_ln_launch(P, 1, c->stream));
     int result[2];
     rc = ln_finish(c, s_map, p, Dinv, stats, result);

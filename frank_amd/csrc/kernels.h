@@ -228,7 +228,7 @@ hipError_t fh_k2_launch_symmetrize(const double *Araw, const double *bq, int N, 
 
 // ---- LogNormal (lognormal.hip): Newton MAP of the log-brightness + the power-spectrum loop, one workgroup per fit
 enum { LN_MODE_MAP = 0, LN_MODE_FIT = 1, LN_MODE_UPDATE = 2 };
-enum { LN_STATUS_OK = 0, LN_STATUS_BAD_P = 1, LN_STATUS_SLOPE = 2 };
+enum { LN_STATUS_OK = 0, LN_STATUS_BAD_P = 1, LN_STATUS_SLOPE = 2, LN_STATUS_CLUSTER = 3 };
 
 struct LogNormalParams {
     int N, max_iter, mode, lu_in_lds, lu_nb;  // lu_nb: panel width of the blocked LU (set by fh_ln_launch)
@@ -260,6 +260,11 @@ struct LogNormalParams {
     int batch;
     int *batch_counter;
     const double *batch_alpha, *batch_p0;
+    // cluster (single fits, N > 112): `cluster` workgroups share the two per-pass pieces that are plain parallel work -- S^-1 =
+    // Y^T diag(1/p) Y and the Tr2 triangular solve -- through flags in global memory; the first of them runs everything else
+    int cluster;                  // workgroups of the cluster (1: none)
+    int *ctl;                     // [0] sequence number, [1] command, [2] helpers done, [3] helpers alive, [4] disbanded (zeroed per launch)
+    double *rk_g, *dvec_g, *tr2_g;  // N: 1 / p; NP: diagonal of the Cholesky factor; N: Tr2 -- the operands the helpers cannot read from the first workgroup's LDS
 };
 
 constexpr size_t fh_ln_lu_doubles(int N, int NP) { return (size_t)N * N + 2 * (size_t)NP * NP + 16 * (size_t)NP; }

@@ -1386,7 +1386,7 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
 // MFMAs against the identity (the accumulator registers of a tile ARE the A fragments of its transpose) and both are
 // stored along rows.  rk: LDS, 1 / p.  (The scalar loop this replaces took 6 ms per power-spectrum iteration at N = 300
 // -- two strided 8-byte loads per multiply-add on one CU; this takes ~0.2 ms.)
-__device__ __forceinline__ void build_sinv(const LogNormalParams &P, const double *rk) {
+__device__ __forceinline__ void build_sinv(const LogNormalParams &P, const double *rk, int part = 0, int nparts = 1) {
     using namespace tilechol;
     const int N = P.N, tid = ln_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
     const int cl = lane & 15, rg = lane >> 4;
@@ -1397,7 +1397,7 @@ __device__ __forceinline__ void build_sinv(const LogNormalParams &P, const doubl
     double ident[4];  // B fragments of the 16 x 16 identity
 #pragma unroll
     for (int q = 0; q < 4; ++q) ident[q] = (4 * q + rg == cl) ? 1.0 : 0.0;
-    for (int g = wave; g < ngroups; g += LNW) {
+    for (int g = part * LNW + wave; g < ngroups; g += nparts * LNW) {  // (a cluster deals the tile groups to its workgroups)
         int gi = (int)((sqrtf(8.0f * (float)g + 1.0f) - 1.0f) * 0.5f);
         while ((gi + 1) * (gi + 2) / 2 <= g) ++gi;
         while (gi * (gi + 1) / 2 > g) --gi;
@@ -1463,13 +1463,16 @@ __device__ __forceinline__ void build_sinv(const LogNormalParams &P, const doubl
 // and comes back as an operand without any reshuffling; L_II^-1 was kept by the factorisation (Xd); the transposed tile
 // of Y comes from four MFMAs against the identity.  No barriers: the block columns are independent.  The substitution
 // by waves this replaces (wave_solve per row) took 6.5 ms per power-spectrum iteration at N = 300.
-__device__ __forceinline__ void tr2_solve(const LogNormalParams &P, LnS &S, const double *Xd, double *Wsc, double *tr2) {
+// (lu: the factors in global memory; dvec: diag(L) -- LDS for the workgroup that factored, a global copy for the helpers of a
+//  cluster; part / nparts: the block columns are dealt to the nparts x LNW waves of the cluster)
+__device__ __forceinline__ void tr2_solve(const LogNormalParams &P, const double *lu_p, const double *dvec, const double *Xd,
+                                          double *Wsc, double *tr2, int part = 0, int nparts = 1) {
     using namespace tilechol;
     const int N = P.N, NP = P.NP, nb = NP / 16;
     const int tid = ln_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
     const int cl = lane & 15, rg = lane >> 4;
-    const double *dvec = S.pan + NP * PS + 16 * PS;  // diag(L), left in LDS by cholesky_as_lu
-    const gdouble *lu = as_global(S.lu), *Y = as_global(P.Y), *X = as_global(Xd);
+    const int cw = part * LNW + wave, cstride = nparts * LNW;  // this wave's first block column, the stride to its next
+    const gdouble *lu = as_global(lu_p), *Y = as_global(P.Y), *X = as_global(Xd);
     gdouble *W = as_global(Wsc);
     constexpr int NC = 3;  // block columns per wave: nb <= 24
     double ident[4];
@@ -1482,7 +1485,7 @@ __device__ __forceinline__ void tr2_solve(const LogNormalParams &P, LnS &S, cons
         v4f64 acc[NC];
 #pragma unroll
         for (int u = 0; u < NC; ++u) {
-            const int c = wave + u * LNW;
+            const int c = cw + u * cstride;
             acc[u] = v4f64{0.0, 0.0, 0.0, 0.0};
             if (c < nb) {
                 double t[4];
@@ -1505,7 +1508,7 @@ __device__ __forceinline__ void tr2_solve(const LogNormalParams &P, LnS &S, cons
             for (int q = 0; q < 4; ++q) fa[q] = la[(size_t)(16 * J + 4 * q + rg) * N];
 #pragma unroll
             for (int u = 0; u < NC; ++u) {
-                const int c = wave + u * LNW;
+                const int c = cw + u * cstride;
                 if (c < nb) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) fb[u][q] = W[((size_t)(c * nb + J) * 4 + q) * 64 + lane];
@@ -1515,7 +1518,7 @@ __device__ __forceinline__ void tr2_solve(const LogNormalParams &P, LnS &S, cons
             for (int q = 0; q < 4; ++q) fa[q] = lvalid ? -fa[q] : 0.0;
 #pragma unroll
             for (int u = 0; u < NC; ++u) {
-                const int c = wave + u * LNW;
+                const int c = cw + u * cstride;
                 if (c < nb) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q], fb[u][q], acc[u], 0, 0, 0);
@@ -1530,7 +1533,7 @@ __device__ __forceinline__ void tr2_solve(const LogNormalParams &P, LnS &S, cons
         }
 #pragma unroll
         for (int u = 0; u < NC; ++u) {
-            const int c = wave + u * LNW;
+            const int c = cw + u * cstride;
             if (c < nb) {
                 v4f64 z = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1545,11 +1548,116 @@ __device__ __forceinline__ void tr2_solve(const LogNormalParams &P, LnS &S, cons
     }
 #pragma unroll
     for (int u = 0; u < NC; ++u) {
-        const int c = wave + u * LNW;
+        const int c = cw + u * cstride;
         double t = (ss[u][0] + ss[u][1]) + (ss[u][2] + ss[u][3]);
         t += __shfl_xor(t, 16);
         t += __shfl_xor(t, 32);
         if (c < nb && rg == 0 && 16 * c + cl < N) tr2[16 * c + cl] = t;
+    }
+}
+
+// ---- cluster: a few workgroups on one fit ---------------------------------------------------------------------------------
+// One CU computes the two per-pass pieces that are plain parallel work -- S^-1 = Y^T diag(1/p) Y (N^3 multiply-adds, 0.2 ms at
+// N = 300) and the Tr2 triangular solve with N right-hand sides (0.25 ms) -- at its matrix-pipe rate; together they are a fifth
+// of a default-mode fit.  A cluster is `cluster` workgroups of ONE launch: workgroup ids 0, 8, 16, ... (ids go round the eight
+// XCDs, so these share an L2; the ids between them return at once).  The first runs the fit; the others wait for commands:
+//   ctl[0] sequence number (bumped by the first workgroup per command), ctl[1] the command, ctl[2] helpers done with it,
+//   ctl[3] helpers that have started, ctl[4] disbanded, ctl[5] the XCDs the workgroups sit on (bit mask), ctl[6] all on one.
+// Hand-over = a release fence by thread 0 behind a barrier + an agent-scope atomic; the receiver's acquire fence invalidates its
+// L1.  Every wait is bounded (wall clock): a cluster whose helpers do not all show up within 200 us is disbanded and the first
+// workgroup runs alone; a helper that hears nothing for 20 s leaves; a command that the helpers do not finish within 2 s ends
+// the fit with LN_STATUS_CLUSTER.  Nothing can hang.
+enum { LN_CMD_NONE = 0, LN_CMD_SINV = 1, LN_CMD_TR2 = 2, LN_CMD_EXIT = 3 };
+__device__ __forceinline__ int ctl_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ctl_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf; }  // HW_REG_XCC_ID
+// Release of everything this workgroup has stored (called by thread 0 behind a barrier).  An agent-scope release writes the
+// XCD's L2 back (tens of microseconds with megabytes of dirty Hessian in it); when every workgroup of the cluster sits on the
+// SAME XCD -- checked at start-up from the hardware register, ctl[6] -- the L2 is shared and it is enough that the stores have
+// left this CU (the L1 is write-through: the barrier's wait for their acknowledgement) before the flag, an agent-scope atomic
+// executed in that L2, is raised.
+__device__ __forceinline__ void cluster_release(bool same_xcd) {
+    if (same_xcd) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    else __threadfence();
+}
+// Acquire before reading what another workgroup wrote: invalidates this CU's L1 (and, across XCDs, what the L2 holds of it)
+__device__ __forceinline__ void cluster_acquire(bool same_xcd) {
+    if (same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    else __threadfence();
+}
+// first workgroup, all threads: publish a command (everything written so far becomes visible to the helpers)
+__device__ __forceinline__ void cluster_dispatch(const LogNormalParams &P, int cmd, bool same_xcd) {
+    __syncthreads();
+    if (ln_tid() == 0) {
+        ctl_store(&P.ctl[2], 0);
+        ctl_store(&P.ctl[1], cmd);
+        cluster_release(same_xcd);
+        __hip_atomic_fetch_add(&P.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// first workgroup, all threads: wait for the helpers; false on a timeout
+__device__ __forceinline__ bool cluster_wait(const LogNormalParams &P, int *s_flag, bool same_xcd) {
+    __syncthreads();
+    if (ln_tid() == 0) {
+        const long long t0 = wall_clock64();
+        int ok = 1;
+        while (ctl_load(&P.ctl[2]) < P.cluster - 1) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > 200000000ll) {  // 2 s at 100 MHz
+                ok = 0;
+                break;
+            }
+        }
+        cluster_acquire(same_xcd);
+        *s_flag = ok;
+    }
+    __syncthreads();
+    return *s_flag != 0;
+}
+// a helper workgroup (member 1 .. cluster - 1): serve commands until told to leave
+__device__ __forceinline__ void cluster_helper(const LogNormalParams &P, int member, int *s_cmd) {
+    const int tid = ln_tid();
+    if (tid == 0) {
+        __hip_atomic_fetch_or(&P.ctl[5], 1 << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&P.ctl[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int seen = 0;
+    for (;;) {
+        if (tid == 0) {
+            const long long t0 = wall_clock64();
+            int cmd = LN_CMD_EXIT;
+            for (;;) {
+                if (ctl_load(&P.ctl[4])) break;            // disbanded
+                const int seq = ctl_load(&P.ctl[0]);
+                if (seq != seen) {
+                    seen = seq;
+                    cmd = ctl_load(&P.ctl[1]);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() - t0 > 2000000000ll) break;  // 20 s of silence
+            }
+            const bool same = ctl_load(&P.ctl[6]) != 0;
+            cluster_acquire(same);  // (what the first workgroup wrote before the command)
+            s_cmd[0] = cmd;
+            s_cmd[1] = same;
+        }
+        __syncthreads();
+        const int cmd = s_cmd[0];
+        const bool same_xcd = s_cmd[1] != 0;
+        __syncthreads();
+        if (cmd == LN_CMD_EXIT || cmd == LN_CMD_NONE) return;
+        if (cmd == LN_CMD_SINV) {
+            build_sinv(P, P.rk_g, member, P.cluster);
+        } else if (cmd == LN_CMD_TR2) {
+            double *const Cp = P.LU + P.N * P.N, *const Wsc = Cp + P.NP * P.NP, *const Xd = Wsc + P.NP * P.NP;
+            tr2_solve(P, P.LU, P.dvec_g, Xd, Wsc, P.tr2_g, member, P.cluster);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            cluster_release(same_xcd);
+            __hip_atomic_fetch_add(&P.ctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -1558,6 +1666,39 @@ template <bool LDS_LU>
 __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_fit;
+    __shared__ int s_cl[2];  // cluster: command / flag hand-over inside the workgroup
+    int cluster = 1;         // workgroups that share this fit's parallel pieces (1: this one alone)
+    bool same_xcd = false;
+    if (!LDS_LU && P.cluster > 1) {
+        if (blockIdx.x & 7) return;  // (ids 0, 8, 16, ..: one XCD when the dispatcher deals a fresh launch round-robin)
+        const int member = blockIdx.x >> 3;
+        if (member > 0) {
+            cluster_helper(P, member, s_cl);
+            return;
+        }
+        // the helpers have 200 us to show up; otherwise this workgroup runs alone and they leave when they see the flag
+        if (threadIdx.x == 0) {
+            const long long t0 = wall_clock64();
+            int ok = 1;
+            while (ctl_load(&P.ctl[3]) < P.cluster - 1) {
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() - t0 > 20000) {
+                    ok = 0;
+                    ctl_store(&P.ctl[4], 1);
+                    break;
+                }
+            }
+            const int xccs = ctl_load(&P.ctl[5]) | (1 << xcc_id());
+            const int one = ok && (xccs & (xccs - 1)) == 0;
+            ctl_store(&P.ctl[6], one);
+            s_cl[0] = ok;
+            s_cl[1] = one;
+        }
+        __syncthreads();
+        cluster = s_cl[0] ? P.cluster : 1;
+        same_xcd = s_cl[1] != 0;
+        __syncthreads();
+    }
     const LogNormalParams P0 = P;
     // batched launch: the workgroups pull fit indices from a counter; work buffers belong to the workgroup, outputs to
     // the fit (per-fit alpha, p0, band_lu)
@@ -1686,7 +1827,17 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
             }
             for (int i = tid; i < N; i += LT) S.rhs[i] = 1 / S.p[i];
             __syncthreads();
-            build_sinv(P, S.rhs);
+            if (cluster > 1) {
+                for (int i = tid; i < N; i += LT) P.rk_g[i] = S.rhs[i];
+                cluster_dispatch(P, LN_CMD_SINV, same_xcd);
+                build_sinv(P, S.rhs, 0, cluster);
+                if (!cluster_wait(P, s_cl, same_xcd)) {
+                    status = LN_STATUS_CLUSTER;
+                    break;
+                }
+            } else {
+                build_sinv(P, S.rhs);
+            }
             __syncthreads();
 #ifdef LN_TIMING
             const long long _tn = clock64();
@@ -1752,7 +1903,19 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         if (P.mode == LN_MODE_FIT && (!bad || count > P.max_iter)) break;  // radial_fitters.py:769-770
         // ---- CriticalFilter.update_power_spectrum(fit)  (filter.py:154-177) ----
         if (chol) {
-            tr2_solve(P, S, Xd, Wsc, S.tr2);
+            const double *dvec = S.pan + P.NP * tilechol::PS + 16 * tilechol::PS;  // diag(L), left in LDS by cholesky_as_lu
+            if (cluster > 1) {
+                for (int i = tid; i < P.NP; i += LT) P.dvec_g[i] = dvec[i];
+                cluster_dispatch(P, LN_CMD_TR2, same_xcd);
+                tr2_solve(P, S.lu, dvec, Xd, Wsc, P.tr2_g, 0, cluster);
+                if (!cluster_wait(P, s_cl, same_xcd)) {
+                    status = LN_STATUS_CLUSTER;
+                    break;
+                }
+                for (int i = tid; i < N; i += LT) S.tr2[i] = P.tr2_g[i];
+            } else {
+                tr2_solve(P, S.lu, dvec, Xd, Wsc, S.tr2);
+            }
             __syncthreads();
         }
         for (int r = w; r < N; r += LNW) {
@@ -1847,6 +2010,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         for (int k = 0; k < 8; ++k) P.stats[9 + k] = ln_cyc[k];
 #endif
     }
+    if (cluster > 1) cluster_dispatch(P, LN_CMD_EXIT, same_xcd);
     if (!P.batch) return;
     __syncthreads();
     }  // next fit of the batch
@@ -1878,6 +2042,9 @@ hipError_t fh_ln_launch(const LogNormalParams &P0, int nblocks, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)smem);
     if (e != hipSuccess) return e;
-    fn<<<nblocks, LT, smem, s>>>(P);
+    // a cluster: workgroup ids 0, 8, 16, .. of one launch (single fits with the factors in global memory only)
+    const int grid = (P.cluster > 1 && !P.batch && !P.lu_in_lds) ? 8 * (P.cluster - 1) + 1 : nblocks;
+    if (grid == nblocks) P.cluster = 1;
+    fn<<<grid, LT, smem, s>>>(P);
     return hipGetLastError();
 }

@@ -141,6 +141,26 @@ def test_lognormal_whole_fit_N300_against_the_reference(golden, fixture, linesea
     assert np.all(sol.I > 0)
 
 
+def test_lognormal_cluster_equals_single_workgroup(golden, monkeypatch):
+    """A LogNormal fit with its parallel pieces (S^-1 = Y^T diag(1/p) Y, the Tr2 triangular solve) shared by a cluster of four
+    workgroups (lognormal.hip; default from N = 160) against the same fit on one workgroup (FRANK_AMD_LN_CLUSTER=1): the same
+    arithmetic per tile and per block column wherever it runs, so the same bits."""
+    from frank_amd import FrankFitter
+    src = golden("fit_N300_1e6.npz")
+    out = {}
+    for cl in ("1", "4", "8"):
+        monkeypatch.setenv("FRANK_AMD_LN_CLUSTER", cl)
+        FF = FrankFitter(2.0, 300, geom(), alpha=1.3, weights_smooth=1e-2, method="LogNormal", max_iter=12, verbose=False,
+                         check_qbounds=False, convergence_failure="ignore", store_iteration_diagnostics=True)
+        _load_mapping(FF, src)
+        sol = FF._fit()
+        out[cl] = (sol.I.copy(), sol.power_spectrum.copy(), FF.iteration_diagnostics["num_iterations"], sol._fit._newton_stats)
+    monkeypatch.delenv("FRANK_AMD_LN_CLUSTER")
+    for cl in ("4", "8"):
+        assert out[cl][2] == out["1"][2] == 13 and tuple(out[cl][3]) == tuple(out["1"][3])
+        assert np.array_equal(out[cl][0], out["1"][0]) and np.array_equal(out[cl][1], out["1"][1])
+
+
 def test_lognormal_full_size_fp32_table():
     """BASELINE configs[2] as stated: N = 300, 1e7 visibilities handed over in single precision, method='LogNormal'
     (alpha = 1.3, w_smooth = 1e-2 as in the reference's LogNormal test, frank/tests.py:350).  No reference run exists at
