@@ -488,13 +488,13 @@ __global__ __launch_bounds__(256) void piece_moments_kernel(PrepassParams P) {
 }
 
 // One workgroup per bucket.  <= 16 rows: the P rows of the visibilities themselves.  More: the pieces' moments are added in a
-// fixed order (wave g takes pieces g, g + 4, ... eight loads at a time; then ((0 + 1) + (2 + 3))), then wave 0 forms the
+// fixed order (wave g of sixteen takes pieces g, g + 16, ... eight loads at a time; then a fixed tree), then wave 0 forms the
 // Cholesky factor of the augmented moment matrix with lane c holding column c (right-looking, 13 steps of one broadcast, one
 // square root and <= 12 fmas per lane).  A pivot that is not positive beyond the round-off of its own formation ends the
 // factorisation of that row: its contribution is below that round-off (for a positive semi-definite matrix the rest of the
 // row is bounded by the pivot).
-__global__ __launch_bounds__(256) void bucket_factor2_kernel(PrepassParams P) {
-    __shared__ double psum[4][kMomAll];
+__global__ __launch_bounds__(1024) void bucket_factor2_kernel(PrepassParams P) {
+    __shared__ double psum[16][kMomAll];
     __shared__ double mom[kMomAll];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x;
@@ -518,24 +518,29 @@ __global__ __launch_bounds__(256) void bucket_factor2_kernel(PrepassParams P) {
         }
         return;
     }
-    if (lane < kMomAll) {
-        const int s0 = P.piece0[b], ns = P.piece0[b + 1] - s0;
+    const int s0 = P.piece0[b], ns = P.piece0[b + 1] - s0;
+    if (lane < kMomAll) {  // wave g takes pieces g, g + 16, ..: eight loads at a time
         const double *pp = P.partial + (size_t)s0 * kMomAll + lane;
         double a = 0.0;
         int k = wave;
-        for (; k + 28 < ns; k += 32) {
+        for (; k + 16 * 7 < ns; k += 16 * 8) {
             double x[8];
 #pragma unroll
-            for (int h = 0; h < 8; ++h) x[h] = pp[(size_t)(k + 4 * h) * kMomAll];
+            for (int h = 0; h < 8; ++h) x[h] = pp[(size_t)(k + 16 * h) * kMomAll];
 #pragma unroll
             for (int h = 0; h < 8; ++h) a += x[h];
         }
-        for (; k < ns; k += 4) a += pp[(size_t)k * kMomAll];
+        for (; k < ns; k += 16) a += pp[(size_t)k * kMomAll];
         psum[wave][lane] = a;
     }
     __syncthreads();
     if (wave != 0) return;
-    if (lane < kMomAll) mom[lane] = (psum[0][lane] + psum[1][lane]) + (psum[2][lane] + psum[3][lane]);
+    if (lane < kMomAll) {
+        double t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = (psum[4 * q][lane] + psum[4 * q + 1][lane]) + (psum[4 * q + 2][lane] + psum[4 * q + 3][lane]);
+        mom[lane] = (t[0] + t[1]) + (t[2] + t[3]);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -769,7 +774,7 @@ hipError_t fh_prepass_launch(const PrepassParams &P, hipStream_t stream) {
     if (e != hipSuccess) return e;
     const int64_t max_pieces = fh_prepass_max_pieces(P.bin.count, P.nb, P.seg_rows);
     hipLaunchKernelGGL(piece_moments_kernel, dim3((unsigned)((max_pieces + 3) / 4)), dim3(256), lds3, stream, P);
-    hipLaunchKernelGGL(bucket_factor2_kernel, dim3(P.nb), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(bucket_factor2_kernel, dim3(P.nb), dim3(1024), 0, stream, P);
     return hipGetLastError();
 }
 
