@@ -210,7 +210,7 @@ class FrankFitter(FourierBesselFitter):
                              arithmetic: it forms S^-1 (x + lam p) as S^-1 x + lam S^-1 p instead of multiplying every
                              trial point out (minimizer.py:74-184, statistical_models.py:1088-1113).  Same minimiser,
                              same exit tests, but the Armijo test no longer trips over the round-off of the 1e35-sized
-                             entries of S^-1: ~3 x fewer Newton steps and ~8 x less time, a brightness profile within
+                             entries of S^-1: ~3 x fewer Newton steps and ~10 x less time, a brightness profile within
                              ~1e-5 of its maximum of the reference's -- as far as the reference is from itself after
                              a 1e-15 perturbation of M (tests/golden/lognormal_N300_*.npz).  'reference' reproduces the
                              reference's arithmetic, Newton counters included.
