@@ -381,8 +381,7 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
                 c->part_blocks[P] = g;
                 left -= g;
             }
-            for (int P = 0; P < c->nparts; ++P)
-                HIP_TRY(c->partials[P].alloc((size_t)c->part_blocks[P] * fh_k1v2_part_ntiles(c->NBT, P) * 256));
+            // (the per-workgroup Gram slabs -- 100 MB at N = 300 -- are allocated when the rows path first runs: ensure_slabs)
             HIP_TRY(c->k1_info.alloc(4));
             HIP_TRY(hipMemset(c->k1_info.p, 0, 4 * sizeof(int)));  // ([3]: the ticket of bucket_scan_kernel starts at zero)
         } else {
@@ -681,6 +680,16 @@ static bool use_wide(const fh_ctx *c) {
 static double *dense_gram(fh_ctx *c) { return c->wide ? c->stats_sum.p : c->wide_G.p; }  // (N+1)^2 + 2 scalars
 static size_t dense_tail(const fh_ctx *c) { return ((size_t)c->N + 1) * ((size_t)c->N + 1); }
 
+// slabs of the rows path (bin_gram2_kernel: every workgroup holds all tiles of its part), on first use
+static int ensure_slabs(fh_ctx *c) {
+    if (!c->v2) return FH_OK;
+    for (int P = 0; P < c->nparts; ++P)
+        if (!c->partials[P].p &&
+            c->partials[P].alloc((size_t)c->part_blocks[P] * fh_k1v2_part_ntiles(c->NBT, P) * 256) != hipSuccess)
+            return fail(FH_ERR_NOMEM, "hipMalloc of the Gram slabs failed");
+    return FH_OK;
+}
+
 static int ensure_wide(fh_ctx *c) {
     if (c->wide_X.p) return FH_OK;
     const size_t N1 = (size_t)c->N + 1;
@@ -860,6 +869,8 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned 
         return fail(FH_ERR_UNSUPPORTED, "baselines reach %.1f x Qmax (%d buckets of J0 arguments): cut the (u, v) distribution or "
                     "raise N", smax, nb);
     int rc = k1v2_ensure_table(c, nb);
+    if (rc) return rc;
+    rc = ensure_slabs(c);
     if (rc) return rc;
     // sort workspaces (grow on demand)
     int sblocks = (int)((count + 255) / 256);
@@ -1045,7 +1056,7 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     // the Gram of the virtual rows: one 16-row chunk per non-empty bucket (a few hundred to a few thousand chunks); one
     // workgroup (or a few) per output tile, no slabs (vr_gram_kernel).  FRANK_AMD_K1_VR=slabs keeps bin_gram2_kernel<.., VR>.
     const char *vrenv = getenv("FRANK_AMD_K1_VR");
-    if (!(vrenv && !strcmp(vrenv, "slabs"))) {
+    if (!(vrenv && !strcmp(vrenv, "slabs") && c->rows_ok)) {  // (bin_gram2_kernel's tile maps stop at N = 511)
         VrGramParams G{};
         G.N = c->N;
         G.NBT = c->NBT;
@@ -1072,6 +1083,8 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     }
     // the Gram of the virtual rows: one 16-row chunk per non-empty bucket (a few hundred to a few thousand chunks), so a
     // few dozen workgroups -- every workgroup writes a slab of all its tiles that the reduction reads back
+    rc = ensure_slabs(c);
+    if (rc) return rc;
     Bin2Params bp{};
     bp.N = c->N;
     bp.table = c->k1_table.p;
