@@ -2277,9 +2277,10 @@ int fh_fit_lognormal(fh_ctx *c, const double *M, const double *j, double alpha, 
     P.tol = tol;
     P.s0 = log(I_scale);  // radial_fitters.py:712
     P.guess = c->mu_out.p;
-    {   // a cluster of workgroups for the parallel pieces of a pass (lognormal.hip): FRANK_AMD_LN_CLUSTER workgroups (default 4
-        // from N = 160 on, where S^-1 and the Tr2 solve are worth a hand-over; 1 = off)
-        int cl = env_int("FRANK_AMD_LN_CLUSTER", N >= 160 ? 4 : 1);
+    {   // a cluster of workgroups for the parallel pieces of a pass (lognormal.hip): FRANK_AMD_LN_CLUSTER workgroups (default 8
+        // -- one XCD's worth of workgroup ids 0, 8, .., 56 -- from N = 160 on, where S^-1 and the Tr2 solve are worth a
+        // hand-over; 1 = off.  Full size: 0.66 s alone, 0.495 with four, 0.469 with eight)
+        int cl = env_int("FRANK_AMD_LN_CLUSTER", N >= 160 ? 8 : 1);
         cl = cl < 1 ? 1 : (cl > 8 ? 8 : cl);
         if (cl > 1) {
             const size_t nv = (size_t)2 * N + P.NP;

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/warp/warp_reduce.hpp>
 
+#include "band_scan.h"
 #include "kernels.h"
 #include "tile_chol.h"
 
@@ -33,7 +34,7 @@ typedef int v4i32 __attribute__((ext_vector_type(4)));
 namespace {
 
 #ifdef LN_TIMING
-__shared__ long long ln_cyc[8];
+__shared__ long long ln_cyc[12];  // 0 eval, 1 factorisations, 2 solves, 3 Hessians, 4 Newton, 5-7 pivoted LU, 8 S^-1, 9 Tr2, 10 Tr1, 11 bands + exp
 #define LTIC() const long long _t0 = clock64()
 #define LTOC(k) do { if (threadIdx.x == 0) ln_cyc[k] += clock64() - _t0; } while (0)
 #else
@@ -1465,71 +1466,138 @@ __device__ __forceinline__ void build_sinv(const LogNormalParams &P, const doubl
 // by waves this replaces (wave_solve per row) took 6.5 ms per power-spectrum iteration at N = 300.
 // (lu: the factors in global memory; dvec: diag(L) -- LDS for the workgroup that factored, a global copy for the helpers of a
 //  cluster; part / nparts: the block columns are dealt to the nparts x LNW waves of the cluster)
-__device__ __forceinline__ void tr2_solve(const LogNormalParams &P, const double *lu_p, const double *dvec, const double *Xd,
-                                          double *Wsc, double *tr2, int part = 0, int nparts = 1) {
+// NC: block columns per wave; JB: products per column whose operands are loaded as one batch.  A lone column per wave (the
+// cluster) is a chain of nb (nb + 1) / 2 products: with the operands of one product in flight it waited for an L2 round trip per
+// product (285 k cycles per pass on four workgroups against 523 k on one); the sums run over J in the same order either way.
+template <int NC, int JB>
+__device__ __forceinline__ void tr2_solve_t(const LogNormalParams &P, const double *lu_p, const double *dvec, const double *Xd,
+                                            double *Wsc, double *tr2, int part, int nparts) {
     using namespace tilechol;
     const int N = P.N, NP = P.NP, nb = NP / 16;
     const int tid = ln_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
     const int cl = lane & 15, rg = lane >> 4;
-    const int cw = part * LNW + wave, cstride = nparts * LNW;  // this wave's first block column, the stride to its next
+    const int cw = wave * nparts + part, cstride = nparts * LNW;  // this wave's first block column (dealt round the workgroups:
+                                                                  // each gets as many busy waves as the others), the stride to its next
     const gdouble *lu = as_global(lu_p), *Y = as_global(P.Y), *X = as_global(Xd);
     gdouble *W = as_global(Wsc);
-    constexpr int NC = 3;  // block columns per wave: nb <= 24
     double ident[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) ident[q] = (4 * q + rg == cl) ? 1.0 : 0.0;
     v4f64 ss[NC];
 #pragma unroll
     for (int u = 0; u < NC; ++u) ss[u] = v4f64{0.0, 0.0, 0.0, 0.0};
+    // the tiles of Y one block row ahead (Y was last read at the start of the pass: these loads miss the L2, ~5 k cycles, and
+    // sat at the top of every row of a chain that is nb rows long)
+    double ty[NC][4];
+    auto load_y = [&](int I) {
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+            const int c = cw + u * cstride;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = 16 * c + rg + 4 * q, col = 16 * I + cl;
+                ty[u][q] = (c < nb && row < N && col < N) ? Y[(size_t)row * N + col] : 0.0;
+            }
+        }
+    };
+    load_y(0);
     for (int I = 0; I < nb; ++I) {
         v4f64 acc[NC];
 #pragma unroll
         for (int u = 0; u < NC; ++u) {
-            const int c = cw + u * cstride;
             acc[u] = v4f64{0.0, 0.0, 0.0, 0.0};
-            if (c < nb) {
-                double t[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = 16 * c + rg + 4 * q, col = 16 * I + cl;
-                    t[q] = (row < N && col < N) ? Y[(size_t)row * N + col] : 0.0;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(t[q], ident[q], acc[u], 0, 0, 0);
-            }
+            for (int q = 0; q < 4; ++q) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ty[u][q], ident[q], acc[u], 0, 0, 0);
         }
+        load_y(min(I + 1, nb - 1));
         const int lrow = 16 * I + cl;
         const bool lvalid = lrow < N;
         const gdouble *la = lu + min(lrow, N - 1);
-#pragma unroll 2
-        for (int J = 0; J < I; ++J) {
-            double fa[4], fb[NC][4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) fa[q] = la[(size_t)(16 * J + 4 * q + rg) * N];
-#pragma unroll
-            for (int u = 0; u < NC; ++u) {
-                const int c = cw + u * cstride;
-                if (c < nb) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) fb[u][q] = W[((size_t)(c * nb + J) * 4 + q) * 64 + lane];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) fa[q] = lvalid ? -fa[q] : 0.0;
-#pragma unroll
-            for (int u = 0; u < NC; ++u) {
-                const int c = cw + u * cstride;
-                if (c < nb) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q], fb[u][q], acc[u], 0, 0, 0);
-                }
-            }
-        }
-        double fx[4], dI[4];
+        double fx[4], dI[4];  // (the operands of the row's last product: in flight while the sum over J runs)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             fx[q] = X[I * 256 + cl * 16 + 4 * q + rg];
             dI[q] = dvec[16 * I + rg + 4 * q];
+        }
+        if constexpr (JB == 0) {
+#pragma unroll 2
+            for (int J = 0; J < I; ++J) {
+                double fa[4], fb[NC][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fa[q] = la[(size_t)(16 * J + 4 * q + rg) * N];
+#pragma unroll
+                for (int u = 0; u < NC; ++u) {
+                    const int c = cw + u * cstride;
+                    if (c < nb) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) fb[u][q] = W[((size_t)(c * nb + J) * 4 + q) * 64 + lane];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fa[q] = lvalid ? -fa[q] : 0.0;
+#pragma unroll
+                for (int u = 0; u < NC; ++u) {
+                    const int c = cw + u * cstride;
+                    if (c < nb) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q], fb[u][q], acc[u], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            // batches of JB products whose operands are loaded together; the rest one by one
+            constexpr int JBB = JB > 0 ? JB : 1;
+            int J = 0;
+            for (; J + JBB <= I; J += JBB) {
+                double fa[JBB][4], fb[JBB][NC][4];
+#pragma unroll
+                for (int jb = 0; jb < JBB; ++jb) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) fa[jb][q] = la[(size_t)(16 * (J + jb) + 4 * q + rg) * N];
+#pragma unroll
+                    for (int u = 0; u < NC; ++u) {
+                        const int c = cw + u * cstride;
+                        if (c < nb) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) fb[jb][u][q] = W[((size_t)(c * nb + J + jb) * 4 + q) * 64 + lane];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int jb = 0; jb < JBB; ++jb) {
+#pragma unroll
+                    for (int u = 0; u < NC; ++u) {
+                        const int c = cw + u * cstride;
+                        if (c < nb) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(lvalid ? -fa[jb][q] : 0.0, fb[jb][u][q], acc[u], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            for (; J < I; ++J) {
+                double fa[4], fb[NC][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fa[q] = la[(size_t)(16 * J + 4 * q + rg) * N];
+#pragma unroll
+                for (int u = 0; u < NC; ++u) {
+                    const int c = cw + u * cstride;
+                    if (c < nb) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) fb[u][q] = W[((size_t)(c * nb + J) * 4 + q) * 64 + lane];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NC; ++u) {
+                    const int c = cw + u * cstride;
+                    if (c < nb) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(lvalid ? -fa[q] : 0.0, fb[u][q], acc[u], 0, 0, 0);
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < NC; ++u) {
@@ -1554,6 +1622,12 @@ __device__ __forceinline__ void tr2_solve(const LogNormalParams &P, const double
         t += __shfl_xor(t, 32);
         if (c < nb && rg == 0 && 16 * c + cl < N) tr2[16 * c + cl] = t;
     }
+}
+
+__device__ __forceinline__ void tr2_solve(const LogNormalParams &P, const double *lu_p, const double *dvec, const double *Xd,
+                                          double *Wsc, double *tr2, int part = 0, int nparts = 1) {
+    if (P.NP / 16 <= nparts * LNW) tr2_solve_t<1, 4>(P, lu_p, dvec, Xd, Wsc, tr2, part, nparts);  // a column per wave at most
+    else tr2_solve_t<3, 0>(P, lu_p, dvec, Xd, Wsc, tr2, part, nparts);                            // up to three: nb <= 24
 }
 
 // ---- cluster: a few workgroups on one fit ---------------------------------------------------------------------------------
@@ -1651,7 +1725,8 @@ __device__ __forceinline__ void cluster_helper(const LogNormalParams &P, int mem
             build_sinv(P, P.rk_g, member, P.cluster);
         } else if (cmd == LN_CMD_TR2) {
             double *const Cp = P.LU + P.N * P.N, *const Wsc = Cp + P.NP * P.NP, *const Xd = Wsc + P.NP * P.NP;
-            tr2_solve(P, P.LU, P.dvec_g, Xd, Wsc, P.tr2_g, member, P.cluster);
+            if (P.cluster > 2) tr2_solve(P, P.LU, P.dvec_g, Xd, Wsc, P.tr2_g, member - 1, P.cluster - 1);  // (the helpers alone)
+            else tr2_solve(P, P.LU, P.dvec_g, Xd, Wsc, P.tr2_g, member, P.cluster);
         }
         __syncthreads();
         if (tid == 0) {
@@ -1745,6 +1820,20 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         S.lu_nb = LDS_LU ? 0 : P.lu_nb;  // blocked factorisation only for factors in global memory
         S.pan = b;                       // (global-LU kernels: the panel follows the int arrays)
     }
+    // bands of the factorised T + I with the reciprocal pivots behind them, and the tables of the wave scans that solve with
+    // them (band_scan.h), in this workgroup's scratch: formed once per fit, read by wave 0 once per pass
+    double *const band_g = P.LU + (size_t)N * N + 2 * (size_t)P.NP * P.NP + 16 * (size_t)P.NP, *const scan_g = band_g + 6 * P.NP;
+    if (P.band_lu) {
+        for (int i = tid; i < 5 * N; i += LT) {
+            const int bnd = i / N, c = i - bnd * N;
+            double v = P.band_lu[i];
+            if (c == 0 && bnd < 2) v = 0.0;  // no sub-diagonal entries in row 0
+            band_g[i] = v;
+            if (bnd == 2) band_g[5 * N + c] = 1.0 / v;
+        }
+        __syncthreads();
+        if (tid < 64) bandscan::scan_tables<6>(band_g, N, scan_g, tid);  // (6 rows per lane: N <= 320 < 384)
+    }
     if (!LDS_LU) {  // identity in the padding rows / columns of the Cholesky's copy of the Hessian (see build_hess)
         double *Cp = P.LU + N * N;
         for (int e = tid; e < P.NP * P.NP; e += LT) {
@@ -1785,7 +1874,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
     }
     if (tid < 9) s_tot[tid] = 0;
 #ifdef LN_TIMING
-    if (tid < 8) ln_cyc[tid] = 0;
+    if (tid < 12) ln_cyc[tid] = 0;
 #endif
     __syncthreads();
 
@@ -1827,6 +1916,9 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
             }
             for (int i = tid; i < N; i += LT) S.rhs[i] = 1 / S.p[i];
             __syncthreads();
+#ifdef LN_TIMING
+            const long long _ts = clock64();
+#endif
             if (cluster > 1) {
                 for (int i = tid; i < N; i += LT) P.rk_g[i] = S.rhs[i];
                 cluster_dispatch(P, LN_CMD_SINV, same_xcd);
@@ -1840,6 +1932,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
             }
             __syncthreads();
 #ifdef LN_TIMING
+            if (tid == 0) ln_cyc[8] += clock64() - _ts;
             const long long _tn = clock64();
 #endif
             const NewtonExit ex = minimize_newton(P, S);
@@ -1902,12 +1995,45 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         bad = __syncthreads_or(bad);
         if (P.mode == LN_MODE_FIT && (!bad || count > P.max_iter)) break;  // radial_fitters.py:769-770
         // ---- CriticalFilter.update_power_spectrum(fit)  (filter.py:154-177) ----
+#ifdef LN_TIMING
+        long long _tu = clock64();
+#endif
+        // (Y s)_r into S.rhs: a wave takes rows w, w + 8, ...; the loads of four rows are issued together (a row at a time the
+        // wave waited for one L2 round trip per row), the sums are formed in the same order
+        auto tr1_sums = [&]() {
+            constexpr int RB = 4, CB = 5;  // N <= 320: five column chunks of 64
+            double xs[CB];
+#pragma unroll
+            for (int cc = 0; cc < CB; ++cc) xs[cc] = (lane + 64 * cc < N) ? S.x[lane + 64 * cc] : 0.0;
+            for (int r0 = w; r0 < N; r0 += RB * LNW) {
+                double y[RB][CB];
+#pragma unroll
+                for (int k = 0; k < RB; ++k) {
+                    const int r = min(r0 + k * LNW, N - 1);
+                    const double *yr = P.Y + r * N;
+#pragma unroll
+                    for (int cc = 0; cc < CB; ++cc) y[k][cc] = yr[min(lane + 64 * cc, N - 1)];
+                }
+#pragma unroll
+                for (int k = 0; k < RB; ++k) {
+                    const int r = r0 + k * LNW;
+                    double a = 0.0;
+#pragma unroll
+                    for (int cc = 0; cc < CB; ++cc)
+                        if (lane + 64 * cc < N) a = fma(y[k][cc], xs[cc], a);
+                    a = wave_sum(a);
+                    if (lane == 0 && r < N) S.rhs[r] = a;
+                }
+            }
+        };
+        const bool tr1_early = chol && cluster > 2;  // formed while the helpers solve for Tr2
         if (chol) {
             const double *dvec = S.pan + P.NP * tilechol::PS + 16 * tilechol::PS;  // diag(L), left in LDS by cholesky_as_lu
             if (cluster > 1) {
                 for (int i = tid; i < P.NP; i += LT) P.dvec_g[i] = dvec[i];
                 cluster_dispatch(P, LN_CMD_TR2, same_xcd);
-                tr2_solve(P, S.lu, dvec, Xd, Wsc, P.tr2_g, 0, cluster);
+                if (cluster > 2) tr1_sums();  // (three helpers and more take the Tr2 columns among themselves)
+                else tr2_solve(P, S.lu, dvec, Xd, Wsc, P.tr2_g, 0, cluster);
                 if (!cluster_wait(P, s_cl, same_xcd)) {
                     status = LN_STATUS_CLUSTER;
                     break;
@@ -1918,7 +2044,23 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
             }
             __syncthreads();
         }
-        for (int r = w; r < N; r += LNW) {
+#ifdef LN_TIMING
+        if (tid == 0) ln_cyc[9] += clock64() - _tu;
+        _tu = clock64();
+#endif
+        // Tr1_r = (Y s)_r^2
+        if (chol) {
+            if (!tr1_early) tr1_sums();
+            __syncthreads();
+            // (the division and the logarithm of a row by all threads at once: on lane 0 of the row's wave, row after row,
+            //  they were most of this phase -- 150 k cycles per pass)
+            for (int r = tid; r < N; r += LT) {
+                const double a = S.rhs[r], pi = S.p[r];
+                const double beta = (P.p0 + 0.5 * (a * a + S.tr2[r])) / pi - (P.alpha - 1.0 + 0.5 * 1.0);
+                S.rhs[r] = beta + log(pi);
+            }
+        }
+        for (int r = w; r < N && !chol; r += LNW) {
             const double *yr = P.Y + r * N;
             double a = 0.0;  // Tr1_r = (Y s)_r^2
             for (int c = lane; c < N; c += 64) a = fma(yr[c], S.x[c], a);
@@ -1941,59 +2083,23 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         }
         __syncthreads();
         for (int i = tid; i < N; i += LT) S.pold[i] = S.p[i];
-        if (tid == 0) {  // (T + I) tau = beta + log p with the host-factorised bands: the recurrences live in registers, the
-                         // operands of 8 steps are fetched together (the bands are in L2: one round trip per batch, not per step)
-            const double *f1 = P.band_lu, *f2 = f1 + N, *d0 = f2 + N, *u1 = d0 + N, *u2 = u1 + N;
-            double x1 = S.rhs[0], x2 = 0.0;
-            for (int i0 = 1; i0 < N; i0 += 8) {
-                double r[8], a1[8], a2[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int i = min(i0 + k, N - 1);
-                    r[k] = S.rhs[i];
-                    a1[k] = f1[i];
-                    a2[k] = f2[i];
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (i0 + k < N) {
-                        double xi = r[k];
-                        xi = fma(-a2[k], x2, xi);
-                        xi = fma(-a1[k], x1, xi);
-                        S.rhs[i0 + k] = xi;
-                        x2 = x1;
-                        x1 = xi;
-                    }
-            }
-            double y1 = 0.0, y2 = 0.0;
-            for (int i0 = N - 1; i0 >= 0; i0 -= 8) {
-                double r[8], b1[8], b2[8], dd[8], rr[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int i = max(i0 - k, 0);
-                    r[k] = S.rhs[i];
-                    b1[k] = u1[i];
-                    b2[k] = u2[i];
-                    dd[k] = d0[i];
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) rr[k] = 1.0 / dd[k];  // (off the recurrence: eight independent divisions)
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (i0 - k >= 0) {
-                        double t = r[k];
-                        t = fma(-b1[k], y1, t);
-                        t = fma(-b2[k], y2, t);
-                        t = tilechol::div_rn(t, dd[k], rr[k]);
-                        S.rhs[i0 - k] = t;
-                        y2 = y1;
-                        y1 = t;
-                    }
-            }
+#ifdef LN_TIMING
+        if (tid == 0) ln_cyc[10] += clock64() - _tu;
+        _tu = clock64();
+#endif
+        if (tid < 64) {  // (T + I) tau = beta + log p with the host-factorised bands: both substitutions as wave scans of wave 0
+                         // (one thread took 2 N dependent steps with its operands in L2: 70 us of a 1.2 ms pass at N = 300)
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            bandscan::scan_solve<6>(band_g, N, scan_g, S.rhs, 0, t);
+            bandscan::scan_solve<6>(band_g, N, scan_g, S.rhs, 1, t);
         }
         __syncthreads();
         for (int i = tid; i < N; i += LT) S.p[i] = exp(S.rhs[i]);  // filter.py:177
         __syncthreads();
+#ifdef LN_TIMING
+        if (tid == 0) ln_cyc[11] += clock64() - _tu;
+#endif
         if (P.mode == LN_MODE_UPDATE) break;
         in_pass = true;
     }
@@ -2008,6 +2114,8 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         for (int k = 0; k < 9; ++k) P.stats[k] = s_tot[k];
 #ifdef LN_TIMING
         for (int k = 0; k < 8; ++k) P.stats[9 + k] = ln_cyc[k];
+        printf("[ln timing, Mcycles] S^-1 %.1f  Tr2 %.1f  Tr1 %.1f  bands + exp %.1f\n", ln_cyc[8] / 1e6, ln_cyc[9] / 1e6, ln_cyc[10] / 1e6,
+               ln_cyc[11] / 1e6);
 #endif
     }
     if (cluster > 1) cluster_dispatch(P, LN_CMD_EXIT, same_xcd);
