@@ -1951,7 +1951,8 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
                 break;
             }
             // Dinv = hess(s_MAP) (:1147), row-major for the host
-            build_hess(P, S, P.H, N, true);
+            // (a whole fit hands out the Dinv of its last pass only: built behind the loop; 72 k cycles of every pass)
+            if (P.mode != LN_MODE_FIT) build_hess(P, S, P.H, N, true);
         }
         if (P.mode == LN_MODE_MAP) break;
         // Factors of Dinv for Tr2 (filter.py:168-170 solves with the model's cho_factor / SVD fallback,
@@ -2103,6 +2104,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         if (P.mode == LN_MODE_UPDATE) break;
         in_pass = true;
     }
+    if (P.mode == LN_MODE_FIT && status == LN_STATUS_OK) build_hess(P, S, P.H, N, true);  // Dinv = hess(s_MAP) (:1147), row-major
 
     for (int i = tid; i < N; i += LT) {
         P.s_out[i] = S.x[i];
