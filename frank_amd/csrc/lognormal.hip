@@ -1408,28 +1408,43 @@ __device__ __forceinline__ void build_sinv(const LogNormalParams &P, const doubl
         const int ca0 = min(16 * I0 + cl, N - 1), ca1 = min(16 * I0 + 16 + cl, N - 1);
         const int cb0 = min(16 * J0 + cl, N - 1), cb1 = min(16 * J0 + 16 + cl, N - 1);
         v4f64 d00 = {0.0, 0.0, 0.0, 0.0}, d01 = d00, d10 = d00, d11 = d00;
-        constexpr int KU = 4;  // k-steps per batch: 16 loads in flight, then 16 MFMAs
-        for (int s0 = 0; s0 < ksteps; s0 += KU) {
-            double fa0[KU], fa1[KU], fb0[KU], fb1[KU];
+        // k-steps in batches of KU through two named register sets: the loads of the next batch are in flight while the
+        // sixteen MFMAs of the current one issue (every load unconditional, rows clamped: the waits stay exact counts)
+        constexpr int KU = 4;
+        struct Frags {
+            double fa0[KU], fa1[KU], fb0[KU], fb1[KU], r[KU];
+        };
+        auto load_frags = [&](Frags &f, int s0) {
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
-                const int k = 4 * (s0 + u) + rg, kc = min(k, N - 1);
+                const int kc = min(4 * (s0 + u) + rg, N - 1);
                 const gdouble *row = Y + (size_t)kc * N;
-                fa0[u] = row[ca0];
-                fa1[u] = row[ca1];
-                fb0[u] = row[cb0];
-                fb1[u] = row[cb1];
+                f.fa0[u] = row[ca0];
+                f.fa1[u] = row[ca1];
+                f.fb0[u] = row[cb0];
+                f.fb1[u] = row[cb1];
+                f.r[u] = rk[kc];
             }
+        };
+        auto mul_frags = [&](const Frags &f, int s0) {
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 const int k = 4 * (s0 + u) + rg;
-                const double r = (k < N) ? rk[k] : 0.0;  // rows past N (and k-steps past the last one) contribute nothing
-                const double a0 = fa0[u] * r, a1 = fa1[u] * r;
-                d00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, fb0[u], d00, 0, 0, 0);
-                d01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, fb1[u], d01, 0, 0, 0);
-                d10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, fb0[u], d10, 0, 0, 0);
-                d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, fb1[u], d11, 0, 0, 0);
+                const double r = (k < N) ? f.r[u] : 0.0;  // rows past N (and k-steps past the last one) contribute nothing
+                const double a0 = f.fa0[u] * r, a1 = f.fa1[u] * r;
+                d00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, f.fb0[u], d00, 0, 0, 0);
+                d01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, f.fb1[u], d01, 0, 0, 0);
+                d10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, f.fb0[u], d10, 0, 0, 0);
+                d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, f.fb1[u], d11, 0, 0, 0);
             }
+        };
+        Frags A, B;
+        load_frags(A, 0);
+        for (int s0 = 0; s0 < ksteps; s0 += 2 * KU) {
+            load_frags(B, s0 + KU);
+            mul_frags(A, s0);
+            load_frags(A, s0 + 2 * KU);
+            mul_frags(B, s0 + KU);  // (k-steps past the last one: r = 0, the products add exact zeros)
         }
         auto put = [&](int I, int J, const v4f64 &d) {
             if (I >= nbt || J > I) return;
@@ -1480,6 +1495,7 @@ __device__ __forceinline__ void tr2_solve_t(const LogNormalParams &P, const doub
                                                                   // each gets as many busy waves as the others), the stride to its next
     const gdouble *lu = as_global(lu_p), *Y = as_global(P.Y), *X = as_global(Xd);
     gdouble *W = as_global(Wsc);
+    if (NC == 1 && cw >= nb) return;  // (no barriers in here: the block columns are independent)
     double ident[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) ident[q] = (4 * q + rg == cl) ? 1.0 : 0.0;
@@ -1545,58 +1561,42 @@ __device__ __forceinline__ void tr2_solve_t(const LogNormalParams &P, const doub
                 }
             }
         } else {
-            // batches of JB products whose operands are loaded together; the rest one by one
+            // A column per wave: a chain of nb (nb + 1) / 2 products.  The operands of JB products are one batch; two named
+            // register sets, the next batch in flight while the current one multiplies; every load is issued (clamped to
+            // the last product of the row), never predicated, so that the waits stay exact counts.
+            static_assert(JB == 0 || NC == 1, "batches: one column per wave");
             constexpr int JBB = JB > 0 ? JB : 1;
-            int J = 0;
-            for (; J + JBB <= I; J += JBB) {
-                double fa[JBB][4], fb[JBB][NC][4];
+            struct OperandSet {
+                double fa[JBB][4], fb[JBB][4];
+            };
+            const int jlast = max(I - 1, 0);
+            auto load_set = [&](OperandSet &o, int J0) {
 #pragma unroll
                 for (int jb = 0; jb < JBB; ++jb) {
+                    const int Jc = min(J0 + jb, jlast);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) fa[jb][q] = la[(size_t)(16 * (J + jb) + 4 * q + rg) * N];
+                    for (int q = 0; q < 4; ++q) o.fa[jb][q] = la[(size_t)(16 * Jc + 4 * q + rg) * N];
 #pragma unroll
-                    for (int u = 0; u < NC; ++u) {
-                        const int c = cw + u * cstride;
-                        if (c < nb) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) fb[jb][u][q] = W[((size_t)(c * nb + J + jb) * 4 + q) * 64 + lane];
-                        }
-                    }
+                    for (int q = 0; q < 4; ++q) o.fb[jb][q] = W[((size_t)(cw * nb + Jc) * 4 + q) * 64 + lane];
                 }
+            };
+            auto mul_set = [&](const OperandSet &o, int J0) {
 #pragma unroll
                 for (int jb = 0; jb < JBB; ++jb) {
-#pragma unroll
-                    for (int u = 0; u < NC; ++u) {
-                        const int c = cw + u * cstride;
-                        if (c < nb) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(lvalid ? -fa[jb][q] : 0.0, fb[jb][u][q], acc[u], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-            for (; J < I; ++J) {
-                double fa[4], fb[NC][4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) fa[q] = la[(size_t)(16 * J + 4 * q + rg) * N];
-#pragma unroll
-                for (int u = 0; u < NC; ++u) {
-                    const int c = cw + u * cstride;
-                    if (c < nb) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) fb[u][q] = W[((size_t)(c * nb + J) * 4 + q) * 64 + lane];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < NC; ++u) {
-                    const int c = cw + u * cstride;
-                    if (c < nb) {
+                    if (J0 + jb < I) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(lvalid ? -fa[q] : 0.0, fb[u][q], acc[u], 0, 0, 0);
+                            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(lvalid ? -o.fa[jb][q] : 0.0, o.fb[jb][q], acc[0], 0, 0, 0);
                     }
                 }
+            };
+            OperandSet A, B;
+            load_set(A, 0);
+            for (int J0 = 0; J0 < I; J0 += 2 * JBB) {
+                load_set(B, J0 + JBB);
+                mul_set(A, J0);
+                load_set(A, J0 + 2 * JBB);
+                mul_set(B, J0 + JBB);
             }
         }
 #pragma unroll
@@ -1626,7 +1626,7 @@ __device__ __forceinline__ void tr2_solve_t(const LogNormalParams &P, const doub
 
 __device__ __forceinline__ void tr2_solve(const LogNormalParams &P, const double *lu_p, const double *dvec, const double *Xd,
                                           double *Wsc, double *tr2, int part = 0, int nparts = 1) {
-    if (P.NP / 16 <= nparts * LNW) tr2_solve_t<1, 4>(P, lu_p, dvec, Xd, Wsc, tr2, part, nparts);  // a column per wave at most
+    if (P.NP / 16 <= nparts * LNW) tr2_solve_t<1, 2>(P, lu_p, dvec, Xd, Wsc, tr2, part, nparts);  // a column per wave at most
     else tr2_solve_t<3, 0>(P, lu_p, dvec, Xd, Wsc, tr2, part, nparts);                            // up to three: nb <= 24
 }
 
