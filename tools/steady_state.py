@@ -19,6 +19,8 @@ ring = int(sys.argv[sys.argv.index("--distinct") + 1]) if "--distinct" in sys.ar
 f = bench.Fitter(L, 300, 0)
 if os.environ.get("BIN_CUS"):
     L.check(L.lib.fh_ctx_set_cu_partition(f.ctx, int(os.environ["BIN_CUS"])))
-f.upload(*mock_disc_visibilities(10_000_000, seed=0, noise_seed=50))
+nvis = int(float(os.environ.get("NVIS", "1e7")))  # (development: a smaller table, to separate the cost of the binning traffic)
+f.nfit = nvis
+f.upload(*mock_disc_visibilities(nvis, seed=0, noise_seed=50))
 f.fit()
 print("slots", os.environ.get("FRANK_AMD_FIT_SLOTS", "default"), "bin_cus", os.environ.get("BIN_CUS"), bench.steady_state(f, L, steps, ring))
