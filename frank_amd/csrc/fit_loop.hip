@@ -42,7 +42,7 @@ using namespace tilechol;
 #define TRACE(slot) do { } while (0)
 #endif
 #ifdef FIT_LOOP_TIMING
-#define FSTAMP(slot) do { if (threadIdx.x == 0) { long long n2_ = clock64(); P.timing[slot] += n2_ - f_last; f_last = n2_; } } while (0)
+#define FSTAMP(slot) do { if (threadIdx.x == 64 * K2_CHAIN_WAVE) { long long n2_ = clock64(); P.timing[slot] += n2_ - f_last; f_last = n2_; } } while (0)
 #else
 #define FSTAMP(slot) do { } while (0)
 #endif
@@ -685,13 +685,32 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         phase = 2;
         if (in_pass) {
             if (P.diag_mu) {  // MAP of this pass: mu = Y^-1 m   (radial_fitters.py:783)
-                for (int r = __builtin_amdgcn_readfirstlane(tid >> 6); r < N; r += NW) {
-                    const double *yr = P.Yinv + (size_t)r * N;
-                    double a = 0.0;
-                    for (int c = tid & 63; c < N; c += 64) a = fma(yr[c], S.m[c], a);
+                // (the loads of four rows are issued together: a row at a time the wave waited for one L2 round trip per row,
+                //  24 us of a 160 us pass with store_iteration_diagnostics on; the sums are formed in the same order)
+                constexpr int RB = 4, CB = WIDE ? 8 : 6;  // column chunks of 64: N < 336, N <= 478
+                const int ln = tid & 63;
+                double ms[CB];
 #pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off);
-                    if ((tid & 63) == 0) P.diag_mu[(size_t)count * N + r] = a;
+                for (int cc = 0; cc < CB; ++cc) ms[cc] = (ln + 64 * cc < N) ? S.m[ln + 64 * cc] : 0.0;
+                for (int r0 = __builtin_amdgcn_readfirstlane(tid >> 6); r0 < N; r0 += RB * NW) {
+                    double y[RB][CB];
+#pragma unroll
+                    for (int k = 0; k < RB; ++k) {
+                        const double *yr = P.Yinv + (size_t)min(r0 + k * NW, N - 1) * N;
+#pragma unroll
+                        for (int cc = 0; cc < CB; ++cc) y[k][cc] = yr[min(ln + 64 * cc, N - 1)];
+                    }
+#pragma unroll
+                    for (int k = 0; k < RB; ++k) {
+                        const int r = r0 + k * NW;
+                        double a = 0.0;
+#pragma unroll
+                        for (int cc = 0; cc < CB; ++cc)
+                            if (ln + 64 * cc < N) a = fma(y[k][cc], ms[cc], a);
+#pragma unroll
+                        for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off);
+                        if (ln == 0 && r < N) P.diag_mu[(size_t)count * N + r] = a;
+                    }
                 }
             }
             ++count;

@@ -26,7 +26,7 @@ if "timing" in os.environ.get("FRANK_AMD_LIB", ""):
     names=['pinv','diag factor','panel trsm','trailing','(unused)','lists (panel phase)','stage row loads','m, tr2 reduce']
     tot=sum(out[:8])
 
-    print('wave0: update %.1f factor %.1f invert %.1f | worker wave1: trailing %.1f, inverse row %.1f us/iter'%tuple(v/2.1e3/(2*nit+4) for v in out[8:13]))
+    print('chain wave: load + update %.1f, factor and invert %.1f, store + flag %.1f | worker wave1: trailing %.1f, inverse row %.1f us/iter'%tuple(v/2.35e3/(nit+2) for v in out[8:13]))
     print('outer loop: solve_posterior %.1f, beta/convergence/exp %.1f, banded solve (thread 0) %.1f us/iter' % tuple(v/2.1e3/(2*nit+4) for v in out[13:16]))
     for n_,v in zip(names,out[:8]): print('%-14s %8.1f us/iter  %5.1f%%'%(n_, v/2.1e3/ (2*nit+4) , 100*v/tot))
 
