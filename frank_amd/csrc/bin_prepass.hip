@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256) void vr_finish_kernel(VrGramParams G, double *
     const size_t e = (size_t)blockIdx.x * 256 + t, ne = (size_t)G.ntiles * 256;
     double sum = 0.0;
     for (int k = 0; k < G.split; ++k) sum += G.scratch[(size_t)k * ne + e];
-    stats_sum[e] += sum;
+    stats_sum[e] = (G.fresh ? 0.0 : stats_sum[e]) + sum;  // (0.0 + sum: the bits of an addition to zeroed memory)
     if (blockIdx.x == 0) {
         __shared__ double rs[256], rmn[256], rmx[256];
         double sl = 0.0, mn = INFINITY, mx = -INFINITY;
@@ -692,10 +692,11 @@ __global__ __launch_bounds__(256) void vr_finish_kernel(VrGramParams G, double *
             __syncthreads();
         }
         if (t == 0) {
-            stats_sum[ne] += rs[0];
-            // min/max are kept as (-qmin, qmax) so that one max-all-reduce serves both
-            stats_minmax[0] = fmax(stats_minmax[0], -rmn[0]);
-            stats_minmax[1] = fmax(stats_minmax[1], rmx[0]);
+            stats_sum[ne] = (G.fresh ? 0.0 : stats_sum[ne]) + rs[0];
+            if (G.fresh) stats_sum[ne + 1] = 0.0;
+            // min/max are kept as (-qmin, qmax) so that one max-all-reduce serves both (a fresh pair is NaN: fmax(NaN, x) = x)
+            stats_minmax[0] = G.fresh ? fmax(__builtin_nan(""), -rmn[0]) : fmax(stats_minmax[0], -rmn[0]);
+            stats_minmax[1] = G.fresh ? fmax(__builtin_nan(""), rmx[0]) : fmax(stats_minmax[1], rmx[0]);
         }
     }
 }

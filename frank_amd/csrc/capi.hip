@@ -108,6 +108,8 @@ struct FitSlot {
     DevBuf<double> Aq, bq, Cq, Wq, WdT, cs, mu_out, p_out, band_lu;
     DevBuf<int> result;
     std::vector<double> lu_host;  // stays alive while the asynchronous copy of the band LU may still read it
+    double lu_key[3] = {0, 0, 0};  // (w_smooth, alpha, p0) of the factors the device copy holds
+    bool lu_valid = false;
     bool busy = false;
     int batch = -1;               // the launch this fit belongs to
 };
@@ -184,6 +186,8 @@ struct fh_ctx {
     // N > 303: rows to memory + rocBLAS dsyrk; stats_sum then holds the dense (N+1)^2 Gram (upper triangle) + 2 scalars
     bool wide = false;
     size_t tail_offset = 0;      // index of sum log(w / 2 pi) in stats_sum
+    bool stats_reset_pending = false;  // fh_bin_reset came, its two fills have not run: the moments path's last kernel then
+                                       // STORES its sums (settle_reset() runs the fills for everybody else)
     int64_t wide_rows = 0;       // rows per dsyrk chunk
     DevBuf<double> wide_X, wide_G;  // wide_G: dense Gram + 2 scalars when the tile workspace exists too (debris, N <= 303)
     DevBuf<double> debris_H2;    // vis_model 'debris': H2[k]; set by fh_ctx_set_scale_height, forces the rows + dgemm path
@@ -309,8 +313,8 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&c->ev_bin0));
-    HIP_TRY(hipEventCreate(&c->ev_bin1));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_bin0, hipEventDisableSystemFence));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_bin1, hipEventDisableSystemFence));
     ROC_TRY(rocblas_create_handle(&c->blas));
     ROC_TRY(rocblas_set_stream(c->blas, c->stream));
     ROC_TRY(rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host));
@@ -352,9 +356,9 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     c->rows_ok = !generic;
     c->k1_moments = !(k1env && !strcmp(k1env, "rows"));  // FRANK_AMD_K1=rows: the v2 kernel on the visibilities themselves
     c->NBT = want_wide ? 0 : (generic ? (N + 1 + 15) / 16 : (c->v2 ? fh_k1v2_nbt_for(N) : fh_k1_nbt_for(N)));
-    HIP_TRY(hipEventCreate(&c->ev_pre0));
-    HIP_TRY(hipEventCreate(&c->ev_loop0));
-    HIP_TRY(hipEventCreate(&c->ev_loop1));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_pre0, hipEventDisableSystemFence));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_loop0, hipEventDisableSystemFence));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_loop1, hipEventDisableSystemFence));
     if (c->NBT) {
         const int G = c->num_cu > 0 ? c->num_cu : 256;
         if (generic) {
@@ -777,14 +781,26 @@ static int k1v2_ensure_table(fh_ctx *c, int nb_needed) {
     return FH_OK;
 }
 
-int fh_bin_reset(fh_ctx *c) {
-    if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
-    HIP_TRY(hipSetDevice(c->device));
+// The two fills of fh_bin_reset.  On a device whose other compute units run fit loops every kernel boundary of the binning
+// stream costs ~40 us (the L2 write-backs between dependent kernels find the caches full of the loops' dirty tiles): a step of
+// the pipeline was sixteen kernels, two of them these fills.  fh_bin_reset only notes that the sums are to start from
+// zero; the last kernel of the moments path (vr_finish_kernel) then stores instead of adding; every other reader or writer
+// of the sums calls settle_reset() first.
+static int settle_reset(fh_ctx *c) {
+    if (!c->stats_reset_pending) return FH_OK;
+    c->stats_reset_pending = false;
     HIP_TRY(hipMemsetAsync(c->stats_sum.p, 0, sizeof(double) * c->stats_sum.n, c->stream));
-    if (c->wide_G.p) HIP_TRY(hipMemsetAsync(c->wide_G.p, 0, sizeof(double) * c->wide_G.n, c->stream));
     // (-qmin, qmax) under max start at -infinity: 0xFFF0000000000000 is not a byte pattern, but 0xFFFFFFFF words are a
     // NaN, and fmax(NaN, x) = x -- the same neutral element, set without a host-side source buffer or a wait
     HIP_TRY(hipMemsetAsync(c->stats_minmax.p, 0xFF, 2 * sizeof(double), c->stream));
+    return FH_OK;
+}
+
+int fh_bin_reset(fh_ctx *c) {
+    if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    c->stats_reset_pending = true;
+    if (c->wide_G.p) HIP_TRY(hipMemsetAsync(c->wide_G.p, 0, sizeof(double) * c->wide_G.n, c->stream));
     c->have_device_Mj = false;
     return FH_OK;
 }
@@ -812,6 +828,10 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     // the default: the rows of a bucket enter the Gram through 12 x 12 moments (bin_prepass.hip + bin_gram2.hip); not for the
     // debris model (its design block is not a product of a row factor and a column factor) and not in single precision
     if (c->k1_moments && !c->debris && !c->arith32) return bin_visibilities_v4(c, p, count, vis_serial, mult_gen);
+    {
+        const int rcs = settle_reset(c);
+        if (rcs) return rcs;
+    }
     const size_t cnt1 = (size_t)(count > 0 ? count : 1);  // K1a scratch: 24 B per visibility (32 B with the debris model's kz^2)
     const size_t need = cnt1 * (c->debris ? 4 : 3);
     if (c->prep.n < need) HIP_TRY(c->prep.alloc(need));
@@ -1074,6 +1094,8 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
         G.scratch = c->reduce_scratch.p;
         G.partial_scalars = c->partial_scalars.p;
         G.scalar_blocks = P.blocks;
+        G.fresh = c->stats_reset_pending ? 1 : 0;  // (the sums start here: vr_finish_kernel stores them, the fills of fh_bin_reset never run)
+        c->stats_reset_pending = false;
         HIP_TRY(hipEventRecord(c->ev_bin0, c->stream));
         HIP_TRY(fh_vr_gram_launch(G, c->stats_sum.p, c->stats_minmax.p, c->stream));
         HIP_TRY(hipEventRecord(c->ev_bin1, c->stream));
@@ -1084,6 +1106,8 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     // the Gram of the virtual rows: one 16-row chunk per non-empty bucket (a few hundred to a few thousand chunks), so a
     // few dozen workgroups -- every workgroup writes a slab of all its tiles that the reduction reads back
     rc = ensure_slabs(c);
+    if (rc) return rc;
+    rc = settle_reset(c);
     if (rc) return rc;
     Bin2Params bp{};
     bp.N = c->N;
@@ -1174,6 +1198,10 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     if (c->arith32 && !c->rows_ok)
         return fail(FH_ERR_UNSUPPORTED, "arithmetic='fp32' exists for N <= 511 (N = %d)", c->N);
     if (c->v2 && !use_wide(c)) return bin_visibilities_v2(c, p, count, vis->serial, vis->use_mult ? vis->mult_gen : 0);
+    {
+        const int rcs = settle_reset(c);
+        if (rcs) return rcs;
+    }
     if (use_wide(c)) {
         const int rcw = ensure_wide(c);
         if (rcw) return rcw;
@@ -1340,6 +1368,10 @@ int fh_ctx_set_range_cache(fh_ctx *c, int on) {
 
 int fh_stats_device(fh_ctx *c, double **sum_stats, int64_t *n_sum, double **minmax_stats) {
     if (!c || !c->stats_sum.p) return fail(FH_ERR_INVALID, "fh_stats_device: no binning workspace");
+    {
+        const int rcs = settle_reset(c);
+        if (rcs) return rcs;
+    }
     if (sum_stats) *sum_stats = use_wide(c) ? dense_gram(c) : c->stats_sum.p;
     if (n_sum) *n_sum = use_wide(c) ? (int64_t)dense_tail(c) + 2 : (int64_t)c->stats_sum.n;
     if (minmax_stats) *minmax_stats = c->stats_minmax.p;
@@ -1354,6 +1386,10 @@ int fh_stats_finalize(fh_ctx *c, const fh_geometry *g, int vis_model, int check_
     if ((vis_model == FH_VIS_DEBRIS) != c->debris)
         return fail(FH_ERR_INVALID, "vis_model 'debris' goes with fh_ctx_set_scale_height (and only with it)");
     HIP_TRY(hipSetDevice(c->device));
+    {
+        const int rcs = settle_reset(c);  // (a reset that no binning pass followed)
+        if (rcs) return rcs;
+    }
     const int N = c->N;
     // a_k = ((norm * sf_k)) * scale : hankel.py:201 and statistical_models.py:490,507
     const double scale = vis_model == FH_VIS_OPT_THICK ? cos(g->inc_deg * kDegToRad) : 1.0;
@@ -2023,7 +2059,7 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
             } else {
                 HIP_TRY(hipStreamCreateWithFlags(&bt.stream, hipStreamNonBlocking));
             }
-            HIP_TRY(hipEventCreateWithFlags(&bt.ready, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&bt.ready, hipEventDisableTiming | hipEventReleaseToDevice));  // (same device: no system-scope write-back)
         }
         c->fit_batch = fit_batch_size();
     }
@@ -2054,11 +2090,20 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
         c->pending_batch = bi;
     }
     FitSlot &s = c->slots[si];
-    smoothing_band_lu(*c->dht, wsmooth, s.lu_host);  // the slot owns the host copy: no wait for the copy here
-    s.lu_host.resize(5 * (size_t)N);
-    s.lu_host.push_back(alpha);
-    s.lu_host.push_back(p0);
-    HIP_TRY(hipMemcpyAsync(s.band_lu.p, s.lu_host.data(), sizeof(double) * s.lu_host.size(), hipMemcpyHostToDevice, c->stream));
+    // (the factors of T + I depend on the hyper-parameters only: a slot that already holds them -- every slot of a pipeline
+    //  over one set of hyper-parameters, once it has been round -- skips the copy, one kernel boundary of the step less)
+    if (!(s.lu_valid && s.lu_key[0] == wsmooth && s.lu_key[1] == alpha && s.lu_key[2] == p0)) {
+        s.lu_valid = false;
+        smoothing_band_lu(*c->dht, wsmooth, s.lu_host);  // the slot owns the host copy: no wait for the copy here
+        s.lu_host.resize(5 * (size_t)N);
+        s.lu_host.push_back(alpha);
+        s.lu_host.push_back(p0);
+        HIP_TRY(hipMemcpyAsync(s.band_lu.p, s.lu_host.data(), sizeof(double) * s.lu_host.size(), hipMemcpyHostToDevice, c->stream));
+        s.lu_key[0] = wsmooth;
+        s.lu_key[1] = alpha;
+        s.lu_key[2] = p0;
+        s.lu_valid = true;
+    }
     int rc = prepare_qspace(c, s.Aq.p, s.bq.p);  // on the context's stream, after the finalize that produced M, j
     if (rc) return rc;
     FitBatch &b = c->batches[c->pending_batch];
@@ -2766,6 +2811,10 @@ void fh_comm_destroy(fh_comm *cm) {
 
 int fh_comm_allreduce_stats(fh_comm *cm, fh_ctx *c) {
     if (!cm || !c || !c->stats_sum.p) return fail(FH_ERR_INVALID, "fh_comm_allreduce_stats: bad argument");
+    {
+        const int rcs = settle_reset(c);
+        if (rcs) return rcs;
+    }
     if (c->device != cm->device) return fail(FH_ERR_INVALID, "fh_comm_allreduce_stats: context and communicator live on different devices");
     HIP_TRY(hipSetDevice(c->device));
     enum { kFloat64 = 8, kSum = 0, kMax = 2 };  // ncclDataType_t / ncclRedOp_t values (rccl.h)

@@ -124,6 +124,7 @@ struct VrGramParams {
     double *scratch;          // [split][ntiles * 256]
     const double *partial_scalars;
     int scalar_blocks;
+    int fresh;                // 1: the sums start with this launch (store, do not add: fh_bin_reset's fills were deferred)
 };
 hipError_t fh_vr_gram_launch(const VrGramParams &G, double *stats_sum, double *stats_minmax, hipStream_t stream);
 int fh_prepass_moment_doubles();
