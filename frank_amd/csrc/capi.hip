@@ -115,20 +115,25 @@ struct FitSlot {
 };
 // Pipelined fits are launched in BATCHES: one fit_loop launch with one workgroup per fit (kernels.h: slot launch).
 //  * A single dispatch deals its workgroups evenly over the XCDs and their shader engines; fit loops started one by one
-//    land wherever the dispatcher's pointers happen to be, and bin_gram, whose one-per-CU workgroups are dealt IN ORDER,
-//    stops at the first engine without a free CU: 0.40 ms of bin_gram time per co-running fit loop started singly, 0.25 ms
-//    in a batch of 16 (tools/k1_with_batch.py).
-//  * The fits in flight are no longer limited by the hardware queues (one stream per launch, not per fit): 64 slots, so
-//    that a pipeline over small tables (bootstrap resamples, 1e6-visibility sweeps: binning << 0.26 s of iteration) can
-//    keep ~64 fit loops resident instead of 16.
-// HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; raised to 24 below) and two kernels whose streams
-// share a queue serialise (seen in the kernel trace as 190 ms stalls with 32 streams): 12 launch streams stay one-to-one.
+//    land wherever the dispatcher's pointers happen to be, and the binning kernels, whose workgroups are dealt IN ORDER,
+//    stop at the first engine without a free CU (round 1: 0.40 ms of binning time per co-running fit loop started singly,
+//    0.25 ms in a batch of 16).
+//  * The fits in flight are not limited by the hardware queues (a stream per launch, not per fit).
+// HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; raised to 24 below, so that the streams of several
+// contexts never share one) and two kernels whose streams share a queue serialise (seen in the kernel trace as 190 ms
+// stalls with 32 streams).  But the command processor SERVES about four queues at a time: see FitBatch below.
 constexpr int kFitSlots = 240;  // capacity; fh_fit_slots() is what a context hands out at a time (FRANK_AMD_FIT_SLOTS)
-constexpr int kFitBatchMax = 16;
+constexpr int kFitBatchMax = FIT_MAX_BATCH;
 constexpr int kFitBatches = 16;
+constexpr int kLaunchStreamsMax = 8;
+// The launches of the pipeline share a FEW streams (four by default): the command processor serves four hardware queues at a
+// time; with eight launches of sixteen fit loops on eight queues an empty kernel on the binning stream took 31 us instead of 3
+// and a 10 us kernel 75 (tools/microbench/boundary_cost.hip) -- every one of the ~16 kernels of a pipelined step paid that.
+// Launch i goes to stream i mod 3 and starts when launch i - 3 has ended; its completion is an event, its results land in
+// pinned host memory, so collecting a fit waits for ITS launch only and puts nothing on any stream.
 struct FitBatch {
-    hipStream_t stream = nullptr;
-    hipEvent_t ready = nullptr;
+    hipStream_t stream = nullptr;  // (one of the context's launch streams; not owned)
+    hipEvent_t ready = nullptr, done = nullptr;
     unsigned char slots[kFitBatchMax];
     int n = 0, outstanding = 0;
     bool active = false, launched = false;
@@ -205,6 +210,11 @@ struct fh_ctx {
     DevBuf<int> slot_results;
     FitSlot slots[kFitSlots];
     FitBatch batches[kFitBatches];
+    hipStream_t launch_streams[kLaunchStreamsMax] = {};
+    int n_launch_streams = 0;
+    unsigned long long launches = 0;      // launches so far (stream of the next one: launches mod n_launch_streams)
+    double *slot_out_host = nullptr;      // pinned: [slot][mu (N), p (N)]
+    int *slot_result_host = nullptr;      // pinned: [slot][count, status]
     int pending_batch = -1;  // batch that is still collecting submissions (not launched)
     int fit_batch = kFitBatchMax;
     size_t slot_stride = 0;
@@ -488,13 +498,16 @@ void fh_ctx_destroy(fh_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto &b : c->batches) {
-        if (b.stream) {
-            (void)hipStreamSynchronize(b.stream);
-            (void)hipStreamDestroy(b.stream);
-        }
-        if (b.ready) (void)hipEventDestroy(b.ready);
+    for (int i = 0; i < c->n_launch_streams; ++i) {
+        (void)hipStreamSynchronize(c->launch_streams[i]);
+        (void)hipStreamDestroy(c->launch_streams[i]);
     }
+    for (auto &b : c->batches) {
+        if (b.ready) (void)hipEventDestroy(b.ready);
+        if (b.done) (void)hipEventDestroy(b.done);
+    }
+    if (c->slot_out_host) (void)hipHostFree(c->slot_out_host);
+    if (c->slot_result_host) (void)hipHostFree(c->slot_result_host);
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev_bin0) (void)hipEventDestroy(c->ev_bin0);
     if (c->ev_bin1) (void)hipEventDestroy(c->ev_bin1);
@@ -811,7 +824,7 @@ static int running_fit_loops(fh_ctx *c) {
     int running = 0;
     if (c->slots_busy > 0)
         for (auto &b : c->batches)
-            if (b.active && b.launched && hipStreamQuery(b.stream) == hipErrorNotReady) running += b.n;
+            if (b.active && b.launched && hipEventQuery(b.done) == hipErrorNotReady) running += b.n;
     (void)hipGetLastError();  // hipErrorNotReady is not an error here
     return running;
 }
@@ -1249,7 +1262,7 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     int running = 0;
     if (c->slots_busy > 0)
         for (auto &b : c->batches)
-            if (b.active && b.launched && hipStreamQuery(b.stream) == hipErrorNotReady) running += b.n;
+            if (b.active && b.launched && hipEventQuery(b.done) == hipErrorNotReady) running += b.n;
     (void)hipGetLastError();  // hipErrorNotReady is not an error here
     // throughput mode while such kernels hold CUs (see bin_gram.hip)
     // (also while fits of a pipeline are merely outstanding: the dynamic hand-out is 2 % faster even on an empty GPU,
@@ -1960,13 +1973,21 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     return FH_OK;
 }
 
-static int fit_batch_size() {  // fit loops per launch: 16, or FRANK_AMD_FIT_BATCH = 1 (launch at once) .. 16
-    int b = kFitBatchMax;
+// Defaults from a sweep of (streams, fits per launch, slots) at the headline size, fits/s at steady state: 3/32/128 825,
+// 3/43/172 858, 3/64/192 931, 3/64/240 929, 4/32/160 920, 4/48/240 905, 5/32/192 919, **4/64/240 966**; the sixteen launches of
+// sixteen on sixteen streams this replaces: 711-740.
+static int fit_launch_streams() {  // streams the launches take turns on (FRANK_AMD_FIT_STREAMS, 1 .. 8)
+    int n = 4;
+    if (const char *e = getenv("FRANK_AMD_FIT_STREAMS")) n = atoi(e);
+    return n < 1 ? 1 : (n > kLaunchStreamsMax ? kLaunchStreamsMax : n);
+}
+static int fit_batch_size() {  // fit loops per launch (FRANK_AMD_FIT_BATCH = 1 (launch at once) .. 64)
+    int b = 64;
     if (const char *e = getenv("FRANK_AMD_FIT_BATCH")) b = atoi(e);
     return b < 1 ? 1 : (b > kFitBatchMax ? kFitBatchMax : b);
 }
 static int fit_slots_wanted() {  // fit loops in flight: every one holds a compute unit for the ~0.1 s of its iteration
-    int n = 128;
+    int n = 240;
     if (const char *e = getenv("FRANK_AMD_FIT_SLOTS")) n = atoi(e);
     return n < 1 ? 1 : (n > kFitSlots ? kFitSlots : n);
 }
@@ -1986,6 +2007,7 @@ static int flush_pending_batch(fh_ctx *c) {
         b.active = false;
         return FH_OK;
     }
+    b.stream = c->launch_streams[c->launches++ % (unsigned long long)c->n_launch_streams];
     HIP_TRY(hipEventRecord(b.ready, c->stream));  // the operands of its fits were prepared on the context's stream
     HIP_TRY(hipStreamWaitEvent(b.stream, b.ready, 0));
     FitLoopParams P = make_loop_params(c, FIT_MODE_FULL, b.alpha, b.p0, b.tol, b.max_iter);
@@ -2001,8 +2023,12 @@ static int flush_pending_batch(fh_ctx *c) {
     P.p_out = s0.p_out.p;
     P.result = s0.result.p;
     P.slot_stride = c->slot_stride;
-    for (int i = 0; i < b.n; ++i) P.slot_ids[i] = b.slots[i];
+    for (int i = 0; i < 8; ++i) P.slot_words[i] = 0;
+    for (int i = 0; i < b.n; ++i) P.slot_words[i >> 3] |= (unsigned long long)b.slots[i] << (8 * (i & 7));
+    P.out_host = c->slot_out_host;
+    P.result_host = c->slot_result_host;
     HIP_TRY(fh_k2_launch_loop_slots(P, b.n, b.stream));
+    HIP_TRY(hipEventRecord(b.done, b.stream));
     b.launched = true;
     return FH_OK;
 }
@@ -2051,16 +2077,22 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
             t.band_lu.adopt(b, 5 * (size_t)N + 2);  // + alpha, p0 of the fit (read by the slot launch)
             t.result.adopt(c->slot_results.p + 2 * i, 2);
         }
-        for (auto &bt : c->batches) {
+        c->n_launch_streams = fit_launch_streams();
+        for (int i = 0; i < c->n_launch_streams; ++i) {
             if (c->bin_cus > 0) {  // fh_ctx_set_cu_partition: the fit loops keep to the compute units the binning pass leaves alone
                 uint32_t mask[8];
                 cu_mask(c->bin_cus, c->num_cu, mask);
-                HIP_TRY(hipExtStreamCreateWithCUMask(&bt.stream, 8, mask));
+                HIP_TRY(hipExtStreamCreateWithCUMask(&c->launch_streams[i], 8, mask));
             } else {
-                HIP_TRY(hipStreamCreateWithFlags(&bt.stream, hipStreamNonBlocking));
+                HIP_TRY(hipStreamCreateWithFlags(&c->launch_streams[i], hipStreamNonBlocking));
             }
-            HIP_TRY(hipEventCreateWithFlags(&bt.ready, hipEventDisableTiming | hipEventReleaseToDevice));  // (same device: no system-scope write-back)
         }
+        for (auto &bt : c->batches) {
+            HIP_TRY(hipEventCreateWithFlags(&bt.ready, hipEventDisableTiming | hipEventReleaseToDevice));  // (same device: no system-scope write-back)
+            HIP_TRY(hipEventCreateWithFlags(&bt.done, hipEventDisableTiming));  // (system-scope release: the host reads the mirrors)
+        }
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->slot_out_host), sizeof(double) * 2 * (size_t)N * kFitSlots, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->slot_result_host), sizeof(int) * 2 * kFitSlots, hipHostMallocDefault));
         c->fit_batch = fit_batch_size();
     }
     // a launch carries ONE (tol, max_iter); alpha, p0 and w_smooth are per fit (they travel with the slot's band LU)
@@ -2128,11 +2160,11 @@ int fh_fit_collect(fh_ctx *c, int ticket, double *mu, double *p, int *niter) {
         if (rc) return rc;
     }
     const int N = c->N;
-    int result[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(result, s.result.p, sizeof result, hipMemcpyDeviceToHost, b.stream));
-    if (mu) HIP_TRY(hipMemcpyAsync(mu, s.mu_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, b.stream));
-    if (p) HIP_TRY(hipMemcpyAsync(p, s.p_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, b.stream));
-    HIP_TRY(hipStreamSynchronize(b.stream));
+    HIP_TRY(hipEventSynchronize(b.done));  // this fit's launch (later launches on the same stream are not waited for)
+    const int result[2] = {c->slot_result_host[2 * ticket], c->slot_result_host[2 * ticket + 1]};
+    const double *out = c->slot_out_host + (size_t)ticket * 2 * N;
+    if (mu) memcpy(mu, out, sizeof(double) * N);
+    if (p) memcpy(p, out + N, sizeof(double) * N);
     s.busy = false;
     s.batch = -1;
     --c->slots_busy;

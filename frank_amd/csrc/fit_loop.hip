@@ -574,13 +574,16 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     if (P.slot_stride) {
         // (constant indices only: a dynamic index into the by-value parameter struct forces the WHOLE struct into scratch
         // memory, every later P.field a scratch load and the prologue 256 bytes of scratch stores)
-        unsigned long long ids_lo = 0, ids_hi = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            ids_lo |= (unsigned long long)P.slot_ids[i] << (8 * i);
-            ids_hi |= (unsigned long long)P.slot_ids[8 + i] << (8 * i);
-        }
-        const int sl = (int)(((blockIdx.x < 8 ? ids_lo : ids_hi) >> (8 * (blockIdx.x & 7))) & 0xffull);
+        const int g = blockIdx.x >> 3;  // (uniform selects between constant indices)
+        unsigned long long wsel = P.slot_words[0];
+        if (g == 1) wsel = P.slot_words[1];
+        if (g == 2) wsel = P.slot_words[2];
+        if (g == 3) wsel = P.slot_words[3];
+        if (g == 4) wsel = P.slot_words[4];
+        if (g == 5) wsel = P.slot_words[5];
+        if (g == 6) wsel = P.slot_words[6];
+        if (g == 7) wsel = P.slot_words[7];
+        const int sl = (int)((wsel >> (8 * (blockIdx.x & 7))) & 0xffull);
         const size_t off = (size_t)sl * P.slot_stride;
         P.A += off;
         P.bq += off;
@@ -592,6 +595,10 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         P.mu_out += off;
         P.p_out += off;
         P.result += 2 * sl;
+        if (P.out_host) {
+            P.out_host += (size_t)sl * 2 * P.N;
+            P.result_host += 2 * sl;
+        }
         P.alpha = P.band_lu[5 * P.N];  // per-fit hyper-parameters travel behind the slot's band LU
         P.p0 = P.band_lu[5 * P.N + 1];
     }
@@ -828,12 +835,22 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         for (int c = tid & 63; c < N; c += 64) a = fma(yr[c], S.m[c], a);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off);
-        if ((tid & 63) == 0) P.mu_out[r] = a;
+        if ((tid & 63) == 0) {
+            P.mu_out[r] = a;
+            if (P.out_host) P.out_host[r] = a;
+        }
     }
-    for (int i = tid; i < N; i += KT) P.p_out[i] = S.p[i];
+    for (int i = tid; i < N; i += KT) {
+        P.p_out[i] = S.p[i];
+        if (P.out_host) P.out_host[N + i] = S.p[i];
+    }
     if (tid == 0) {
         P.result[0] = count;
         P.result[1] = status;
+        if (P.result_host) {
+            P.result_host[0] = count;
+            P.result_host[1] = status;
+        }
     }
     if (!P.batch) return;
     __syncthreads();
