@@ -743,8 +743,9 @@ def main():
             ss = out["extra"].get("steady_state", {})
             if "fits_per_s" in ss:  # the same algorithmic flops against the WHOLE chip, at the rate the pipeline sustains
                 out["roofline"]["chip_fraction_at_steady_state"] = ss["fits_per_s"] * flops_fit / 1e12 / FP64_MFMA_PEAK_TFLOPS
-                out["roofline"]["chip_note"] = ("one fit loop is one CU: frac above is against 1/256 of the chip; %d loops "
-                                                "resident at steady state" % ss.get("fit_slots", 0))
+                out["roofline"]["chip_note"] = ("one fit loop is one CU: frac above is against 1/256 of the chip; at steady state up "
+                                                "to %d fits are outstanding, in launches of up to 64 fit loops on four streams "
+                                                "(~190 loops resident)" % ss.get("fit_slots", 0))
         if not a.no_cpu_baseline and world == 1:  # the CPU leg is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(a.ncoll, a.nvis, nit)
         print(json.dumps(out), flush=True)

@@ -1100,8 +1100,9 @@ def test_pipelined_fits_with_per_fit_hyperparameters():
 
 
 def test_pipeline_bookkeeping_many_fits_out_of_order():
-    """150 pipelined fits (more than the 128 slots, so slots and launches are recycled), collected out of order and with a
-    partly filled last launch: every one equals the synchronous fit of its w_smooth."""
+    """300 pipelined fits (more than the 240 slots, so slots and launches are recycled, and several launches of up to 64 fits
+    queue on the same launch stream), collected out of order and with a partly filled last launch: every one equals the
+    synchronous fit of its w_smooth."""
     import ctypes
     from frank_amd import _lib, FrankFitter
     N, n = 50, 5000
@@ -1131,7 +1132,7 @@ def test_pipeline_bookkeeping_many_fits_out_of_order():
         assert k.value == sync[ws][1]
         assert rel_to_max(mu, sync[ws][0]) < 1e-9
 
-    for i in range(150):
+    for i in range(300):
         if len(pending) == slots:
             collect(pending.pop(int(rng.integers(len(pending)))))  # any ticket, not the oldest
             done += 1
@@ -1148,7 +1149,7 @@ def test_pipeline_bookkeeping_many_fits_out_of_order():
     while pending:
         collect(pending.pop(int(rng.integers(len(pending)))))
         done += 1
-    assert done == 150
+    assert done == 300
     _lib.lib.fh_vis_destroy(vis)
 
 
