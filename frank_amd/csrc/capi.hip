@@ -1974,14 +1974,14 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
 }
 
 // Defaults from a sweep of (streams, fits per launch, slots) at the headline size, fits/s at steady state: 3/32/128 825,
-// 3/43/172 858, 3/64/192 931, 3/64/240 929, 4/32/160 920, 4/48/240 905, 5/32/192 919, **4/64/240 966**; the sixteen launches of
+// 3/43/172 858, 3/64/192 931, 3/64/240 929, 4/32/160 920, 4/48/240 905, 5/32/192 919, 2/120/240 1024, **4/64/240 966-1001**; the sixteen launches of
 // sixteen on sixteen streams this replaces: 711-740.
 static int fit_launch_streams() {  // streams the launches take turns on (FRANK_AMD_FIT_STREAMS, 1 .. 8)
     int n = 4;
     if (const char *e = getenv("FRANK_AMD_FIT_STREAMS")) n = atoi(e);
     return n < 1 ? 1 : (n > kLaunchStreamsMax ? kLaunchStreamsMax : n);
 }
-static int fit_batch_size() {  // fit loops per launch (FRANK_AMD_FIT_BATCH = 1 (launch at once) .. 64)
+static int fit_batch_size() {  // fit loops per launch (FRANK_AMD_FIT_BATCH = 1 (launch at once) .. 128)
     int b = 64;
     if (const char *e = getenv("FRANK_AMD_FIT_BATCH")) b = atoi(e);
     return b < 1 ? 1 : (b > kFitBatchMax ? kFitBatchMax : b);
@@ -2023,7 +2023,7 @@ static int flush_pending_batch(fh_ctx *c) {
     P.p_out = s0.p_out.p;
     P.result = s0.result.p;
     P.slot_stride = c->slot_stride;
-    for (int i = 0; i < 8; ++i) P.slot_words[i] = 0;
+    for (int i = 0; i < FIT_MAX_BATCH / 8; ++i) P.slot_words[i] = 0;
     for (int i = 0; i < b.n; ++i) P.slot_words[i >> 3] |= (unsigned long long)b.slots[i] << (8 * (i & 7));
     P.out_host = c->slot_out_host;
     P.result_host = c->slot_result_host;

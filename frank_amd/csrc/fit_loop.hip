@@ -583,6 +583,14 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         if (g == 5) wsel = P.slot_words[5];
         if (g == 6) wsel = P.slot_words[6];
         if (g == 7) wsel = P.slot_words[7];
+        if (g == 8) wsel = P.slot_words[8];
+        if (g == 9) wsel = P.slot_words[9];
+        if (g == 10) wsel = P.slot_words[10];
+        if (g == 11) wsel = P.slot_words[11];
+        if (g == 12) wsel = P.slot_words[12];
+        if (g == 13) wsel = P.slot_words[13];
+        if (g == 14) wsel = P.slot_words[14];
+        if (g == 15) wsel = P.slot_words[15];
         const int sl = (int)((wsel >> (8 * (blockIdx.x & 7))) & 0xffull);
         const size_t off = (size_t)sl * P.slot_stride;
         P.A += off;
