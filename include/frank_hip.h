@@ -218,7 +218,8 @@ int fh_fit_normal(fh_ctx *ctx, const double *M, const double *j, double alpha, d
  * 770-782 call the fitter in a plain loop): fh_fit_submit stages the iteration of the context's device-resident
  * M, j (from fh_stats_finalize) in one of the context's fit slots and returns at once; a fit_loop workgroup occupies
  * ONE compute unit, so the following fh_bin_visibilities calls overlap with it.  Submissions are launched in batches
- * (16 fit loops per launch by default; a launch carries one tol / max_iter, alpha, p0 and w_smooth are per fit):
+ * (up to 64 fit loops per launch by default, the launches taking turns on four streams; a launch carries one tol /
+ * max_iter, alpha, p0 and w_smooth are per fit):
  * fh_fit_flush launches what has been staged so far -- call it after the last submission; fh_fit_collect on a fit
  * whose launch is still open does the same.  fh_fit_collect waits for that fit and returns mu, p, niter exactly as
  * fh_fit_normal does.  Tickets are collected in any order; at most fh_fit_slots() fits may be outstanding.     */
