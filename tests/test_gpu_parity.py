@@ -679,6 +679,59 @@ def test_prepass_instances_against_oracle(monkeypatch, kind, safe):
         assert abs(qmx.value - o["qmax"]) <= 1e-15 * o["qmax"] * 4 if "qmax" in o else True
 
 
+def test_deferred_reset_keeps_the_accumulate_semantics():
+    """fh_bin_reset only NOTES that the sums start from zero (the moments path's last kernel then stores instead of adding, the
+    two fills never run): a reset followed by two binning calls still accumulates both, a second reset forgets them, a reset
+    that no binning call follows finalises to zeros, and the statistics read back through fh_stats_device are the settled ones."""
+    import ctypes
+    from frank_amd import DiscreteHankelTransform, _lib
+    L = _lib.lib
+    N, n = 60, 30000
+    u, v, V, w = mock_disc_visibilities(n, seed=5, noise_seed=6)
+    dht = DiscreteHankelTransform(RMAX, N)
+    ctx = dht.context()
+    gm = _lib.make_geometry(geom())
+    table = ctypes.c_void_p()
+    Vre, Vim = np.ascontiguousarray(V.real), np.ascontiguousarray(V.imag)
+    _lib.check(L.fh_vis_upload(dht.device, _lib.ptr(u), _lib.ptr(v), _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), n, n,
+                               ctypes.byref(table)))
+
+    def finalize():
+        M, j = np.empty((N, N)), np.empty(N)
+        H0, qmn, qmx = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(L.fh_stats_finalize(ctx, ctypes.byref(gm), 0, 0, _lib.ptr(M), _lib.ptr(j), ctypes.byref(H0),
+                                       ctypes.byref(qmn), ctypes.byref(qmx)))
+        return M, j, H0.value
+
+    try:
+        h = n // 3
+        _lib.check(L.fh_bin_reset(ctx))
+        _lib.check(L.fh_bin_visibilities(ctx, ctypes.byref(gm), table, 0, n))
+        Mf, jf, Hf = finalize()
+        _lib.check(L.fh_bin_reset(ctx))
+        _lib.check(L.fh_bin_visibilities(ctx, ctypes.byref(gm), table, 0, h))
+        _lib.check(L.fh_bin_visibilities(ctx, ctypes.byref(gm), table, h, n - h))
+        M2, j2, H2 = finalize()
+        assert rel_to_max(M2, Mf) < 1e-13 and rel_to_max(j2, jf) < 1e-12 and abs(H2 - Hf) <= 1e-11 * abs(Hf)
+        # two resets in a row, then ONE part: nothing of the runs before is left
+        _lib.check(L.fh_bin_reset(ctx))
+        _lib.check(L.fh_bin_reset(ctx))
+        _lib.check(L.fh_bin_visibilities(ctx, ctypes.byref(gm), table, 0, h))
+        Ma, ja, Ha = finalize()
+        _lib.check(L.fh_bin_reset(ctx))
+        _lib.check(L.fh_bin_visibilities(ctx, ctypes.byref(gm), table, h, n - h))
+        Mb, jb, Hb = finalize()
+        assert rel_to_max(Ma + Mb, Mf) < 1e-13 and rel_to_max(ja + jb, jf) < 1e-12
+        # the device statistics after a reset with nothing binned: zeros (the fills run when somebody looks)
+        _lib.check(L.fh_bin_reset(ctx))
+        sums, nsum, mm = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_void_p()
+        _lib.check(L.fh_stats_device(ctx, ctypes.byref(sums), ctypes.byref(nsum), ctypes.byref(mm)))
+        M0, j0, _ = finalize()
+        assert not M0.any() and not j0.any()
+    finally:
+        L.fh_vis_destroy(table)
+
+
 def test_multiplicities_that_drop_the_longest_baseline_do_not_poison_the_range():
     """A bootstrap draw leaves the longest baseline out with probability 1/e: the baseline range of THAT draw must not size the
     bucket sort of the next one (rows beyond the remembered range would be pushed into the last bucket and evaluated outside
