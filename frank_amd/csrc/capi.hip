@@ -802,6 +802,7 @@ static int k1v2_ensure_table(fh_ctx *c, int nb_needed) {
 static int settle_reset(fh_ctx *c) {
     if (!c->stats_reset_pending) return FH_OK;
     c->stats_reset_pending = false;
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->stats_sum.p, 0, sizeof(double) * c->stats_sum.n, c->stream));
     // (-qmin, qmax) under max start at -infinity: 0xFFF0000000000000 is not a byte pattern, but 0xFFFFFFFF words are a
     // NaN, and fmax(NaN, x) = x -- the same neutral element, set without a host-side source buffer or a wait
