@@ -77,7 +77,15 @@ struct LnS {
     // partials then need 2 * nch * N doubles and live in the solve vectors' space (idle during the products)
     int pair, pstride;
     double *pbuf;
+    // cluster (see "cluster: a few workgroups on one fit" below): workgroups sharing this fit's parallel pieces, whether they
+    // sit on one XCD, the flag word of the hand-overs
+    int cluster;
+    bool same_xcd;
+    int *s_cl;
 };
+enum { LN_CMD_NONE = 0, LN_CMD_SINV = 1, LN_CMD_TR2 = 2, LN_CMD_EXIT = 3, LN_CMD_HESS = 4 };
+__device__ __forceinline__ void cluster_dispatch(const LogNormalParams &P, int cmd, bool same_xcd);
+__device__ __forceinline__ bool cluster_wait(const LogNormalParams &P, int *s_flag, bool same_xcd);
 
 // Wave reductions through DPP row operations (rocprim), result broadcast to every lane.
 template <class T, class Op>
@@ -309,21 +317,24 @@ __device__ __forceinline__ double ln_grad(const LnS &S, int i) {
 // bits as element [a][b] of the former, i.e. its row-major image (the Dinv handed to the host), written along rows too.
 // ld = P.NP: the padded copy for the tiled Cholesky (its padding rows and columns hold the identity: written once per
 // kernel, the factorisation leaves them as they are).
-__device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, double *out, int ld, bool outer_first) {
+// (rows part, part + nparts, ... of the wave-by-wave deal: the cluster's workgroups build disjoint rows, bit for bit what one
+//  workgroup builds; Iv, MIv, jv: I, M I and j -- LDS for the workgroup that runs the fit, global copies for its helpers)
+__device__ __forceinline__ void build_hess_rows(const LogNormalParams &P, const double *Iv, const double *MIv, const double *jv,
+                                                double *out, int ld, bool outer_first, int part, int nparts) {
     const int N = P.N, tid = ln_tid();
-    LTIC();
     if ((N & 1) == 0) {
         // one wave per row, 16 bytes per lane and matrix, the loads of TWO rows issued before the first store: a single CU
         // streams from L2 at the rate its requests in flight allow (8-byte loads interleaved with stores: 131 us per
         // Hessian at N = 300; this: ~40 us, which is what 2.2 MB cost one CU)
         constexpr int HB = 3;  // 64 * HB pairs per pass: one pass for N <= 384
         const int lane = tid & 63, N2 = N >> 1;
-        for (int b0 = __builtin_amdgcn_readfirstlane(tid >> 6); b0 < N; b0 += 2 * LNW) {
+        const int rstride = LNW * nparts;
+        for (int b0 = part * LNW + __builtin_amdgcn_readfirstlane(tid >> 6); b0 < N; b0 += 2 * rstride) {
             for (int a0 = 0; a0 < N2; a0 += 64 * HB) {
                 v2f64 vm[2][HB], vs[2][HB];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int b = b0 + h * LNW;
+                    const int b = b0 + h * rstride;
                     if (b < N) {
                         const v2f64 *mb = reinterpret_cast<const v2f64 *>(__builtin_assume_aligned(P.M + b * N, 16));
                         const v2f64 *sb = reinterpret_cast<const v2f64 *>(__builtin_assume_aligned(P.Sinv + b * N, 16));
@@ -339,9 +350,9 @@ __device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, dou
                 }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int b = b0 + h * LNW;
+                    const int b = b0 + h * rstride;
                     if (b < N) {
-                        const double Ib = S.I[b];
+                        const double Ib = Iv[b];
 #pragma unroll
                         for (int u = 0; u < HB; ++u) {
                             const int idx = a0 + 64 * u + lane;
@@ -350,8 +361,8 @@ __device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, dou
 #pragma unroll
                                 for (int e = 0; e < 2; ++e) {
                                     const int a = 2 * idx + e;
-                                    double t = outer_first ? Ib * vm[h][u][e] * S.I[a] : S.I[a] * vm[h][u][e] * Ib;
-                                    if (a == b) t += S.I[a] * S.MI[a] - S.I[a] * S.jv[a];
+                                    double t = outer_first ? Ib * vm[h][u][e] * Iv[a] : Iv[a] * vm[h][u][e] * Ib;
+                                    if (a == b) t += Iv[a] * MIv[a] - Iv[a] * jv[a];
                                     t += vs[h][u][e];
                                     v[e] = t;
                                 }
@@ -363,18 +374,44 @@ __device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, dou
             }
         }
     } else {
-        for (int b = tid >> 5; b < N; b += LT / 32) {
-            const double Ib = S.I[b];
+        for (int b = part * (LT / 32) + (tid >> 5); b < N; b += (LT / 32) * nparts) {
+            const double Ib = Iv[b];
             const double *mb = P.M + b * N, *sb = P.Sinv + b * N;
             for (int a = tid & 31; a < N; a += 32) {
-                double v = outer_first ? Ib * mb[a] * S.I[a] : S.I[a] * mb[a] * Ib;
-                if (a == b) v += S.I[a] * S.MI[a] - S.I[a] * S.jv[a];
+                double v = outer_first ? Ib * mb[a] * Iv[a] : Iv[a] * mb[a] * Ib;
+                if (a == b) v += Iv[a] * MIv[a] - Iv[a] * jv[a];
                 v += sb[a];
                 out[(size_t)b * ld + a] = v;
             }
         }
     }
+}
+__device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, double *out, int ld, bool outer_first) {
+    LTIC();
+    build_hess_rows(P, S.I, S.MI, S.jv, out, ld, outer_first, 0, 1);
     __syncthreads();
+    LTOC(3);
+}
+// The padded copy the tiled Cholesky factors, built by the whole cluster (single fits): I and M I go to the helpers through the
+// two global vectors that S^-1 and Tr2 use at other times; a cluster that does not answer is disbanded and the copy rebuilt here.
+__device__ __forceinline__ void build_hess_padded(const LogNormalParams &P, LnS &S, double *Cp) {
+    if (S.cluster <= 1) {
+        build_hess(P, S, Cp, P.NP, false);
+        return;
+    }
+    LTIC();
+    for (int i = ln_tid(); i < P.N; i += LT) {
+        P.rk_g[i] = S.I[i];
+        P.tr2_g[i] = S.MI[i];
+    }
+    cluster_dispatch(P, LN_CMD_HESS, S.same_xcd);
+    build_hess_rows(P, S.I, S.MI, S.jv, Cp, P.NP, false, 0, S.cluster);
+    if (!cluster_wait(P, S.s_cl, S.same_xcd)) {
+        if (ln_tid() == 0) __hip_atomic_store(&P.ctl[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // disbanded
+        S.cluster = 1;
+        build_hess_rows(P, S.I, S.MI, S.jv, Cp, P.NP, false, 0, 1);
+        __syncthreads();
+    }
     LTOC(3);
 }
 
@@ -1257,7 +1294,7 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
             if (nhess == P.max_hev) return {3, nstep, nfev, nhess};
             double *Cp = S.lu_nb > 0 ? P.LU + N * N : nullptr;
             if (S.lu_nb > 0) {
-                if (!P.no_cholesky) build_hess(P, S, Cp, P.NP, false);
+                if (!P.no_cholesky) build_hess_padded(P, S, Cp);
                 if (P.no_cholesky || !cholesky_as_lu(P, S, Cp)) {  // not positive definite: the attempt has written into S.lu
 #ifdef LN_TIMING
                     if (tid == 0) ln_cyc[6] += 1;
@@ -1641,7 +1678,6 @@ __device__ __forceinline__ void tr2_solve(const LogNormalParams &P, const double
 // L1.  Every wait is bounded (wall clock): a cluster whose helpers do not all show up within 200 us is disbanded and the first
 // workgroup runs alone; a helper that hears nothing for 20 s leaves; a command that the helpers do not finish within 2 s ends
 // the fit with LN_STATUS_CLUSTER.  Nothing can hang.
-enum { LN_CMD_NONE = 0, LN_CMD_SINV = 1, LN_CMD_TR2 = 2, LN_CMD_EXIT = 3 };
 __device__ __forceinline__ int ctl_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ctl_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf; }  // HW_REG_XCC_ID
@@ -1723,6 +1759,8 @@ __device__ __forceinline__ void cluster_helper(const LogNormalParams &P, int mem
         if (cmd == LN_CMD_EXIT || cmd == LN_CMD_NONE) return;
         if (cmd == LN_CMD_SINV) {
             build_sinv(P, P.rk_g, member, P.cluster);
+        } else if (cmd == LN_CMD_HESS) {
+            build_hess_rows(P, P.rk_g, P.tr2_g, P.j, P.LU + P.N * P.N, P.NP, false, member, P.cluster);
         } else if (cmd == LN_CMD_TR2) {
             double *const Cp = P.LU + P.N * P.N, *const Wsc = Cp + P.NP * P.NP, *const Xd = Wsc + P.NP * P.NP;
             if (P.cluster > 2) tr2_solve(P, P.LU, P.dvec_g, Xd, Wsc, P.tr2_g, member - 1, P.cluster - 1);  // (the helpers alone)
@@ -1816,6 +1854,9 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         }
         S.perm = reinterpret_cast<int *>(b);
         b += N;  // 2N ints
+        S.cluster = cluster;
+        S.same_xcd = same_xcd;
+        S.s_cl = s_cl;
         S.lu = LDS_LU ? b : P.LU;
         S.lu_nb = LDS_LU ? 0 : P.lu_nb;  // blocked factorisation only for factors in global memory
         S.pan = b;                       // (global-LU kernels: the panel follows the int arrays)
@@ -1919,10 +1960,10 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
 #ifdef LN_TIMING
             const long long _ts = clock64();
 #endif
-            if (cluster > 1) {
+            if (S.cluster > 1) {
                 for (int i = tid; i < N; i += LT) P.rk_g[i] = S.rhs[i];
                 cluster_dispatch(P, LN_CMD_SINV, same_xcd);
-                build_sinv(P, S.rhs, 0, cluster);
+                build_sinv(P, S.rhs, 0, S.cluster);
                 if (!cluster_wait(P, s_cl, same_xcd)) {
                     status = LN_STATUS_CLUSTER;
                     break;
@@ -1964,7 +2005,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         double *const Cp = P.LU + N * N, *const Wsc = Cp + P.NP * P.NP, *const Xd = Wsc + P.NP * P.NP;
         if (S.lu_nb > 0 && !P.no_cholesky) {
             if (P.mode != LN_MODE_UPDATE) {
-                build_hess(P, S, Cp, P.NP, false);
+                build_hess_padded(P, S, Cp);
             } else {
                 for (int b = tid >> 5; b < N; b += LT / 32)
                     for (int a = tid & 31; a < N; a += 32) Cp[b * P.NP + a] = P.H[a * N + b];
@@ -2027,14 +2068,14 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
                 }
             }
         };
-        const bool tr1_early = chol && cluster > 2;  // formed while the helpers solve for Tr2
+        const bool tr1_early = chol && S.cluster > 2;  // formed while the helpers solve for Tr2
         if (chol) {
             const double *dvec = S.pan + P.NP * tilechol::PS + 16 * tilechol::PS;  // diag(L), left in LDS by cholesky_as_lu
-            if (cluster > 1) {
+            if (S.cluster > 1) {
                 for (int i = tid; i < P.NP; i += LT) P.dvec_g[i] = dvec[i];
                 cluster_dispatch(P, LN_CMD_TR2, same_xcd);
-                if (cluster > 2) tr1_sums();  // (three helpers and more take the Tr2 columns among themselves)
-                else tr2_solve(P, S.lu, dvec, Xd, Wsc, P.tr2_g, 0, cluster);
+                if (S.cluster > 2) tr1_sums();  // (three helpers and more take the Tr2 columns among themselves)
+                else tr2_solve(P, S.lu, dvec, Xd, Wsc, P.tr2_g, 0, S.cluster);
                 if (!cluster_wait(P, s_cl, same_xcd)) {
                     status = LN_STATUS_CLUSTER;
                     break;
@@ -2120,7 +2161,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
                ln_cyc[11] / 1e6);
 #endif
     }
-    if (cluster > 1) cluster_dispatch(P, LN_CMD_EXIT, same_xcd);
+    if (S.cluster > 1) cluster_dispatch(P, LN_CMD_EXIT, same_xcd);
     if (!P.batch) return;
     __syncthreads();
     }  // next fit of the batch
