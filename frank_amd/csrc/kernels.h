@@ -251,7 +251,8 @@ struct LogNormalParams {
     int NP;                       // N rounded up to a multiple of 16.  LU holds fh_ln_lu_doubles(N, NP) doubles per workgroup:
                                   // [N*N] factors, [NP*NP] the padded copy of the Hessian that the tiled Cholesky factors in
                                   // place, [NP*NP] the solved tiles of the Tr2 triangular solve, [16*NP] inverses of the
-                                  // diagonal tiles, [6*NP + 3072] bands and scan tables of the pentadiagonal solve (band_scan.h)
+                                  // diagonal tiles, [6*NP + 3072] bands and scan tables of the pentadiagonal solve (band_scan.h), [2*NP + NP*NP/8] vectors and
+                                  // partial sums of the objective evaluations
     int no_cholesky;              // 1: skip the tiled Cholesky attempts, always the pivoted LU (FRANK_AMD_LN_PIVOTED=1: the route a
                                   // non-positive pivot takes, kept testable)
     int fresh_products;           // 1: every trial point of the line search gets its own S^-1 x product, as the reference's
@@ -274,7 +275,8 @@ struct LogNormalParams {
 };
 
 constexpr size_t fh_ln_lu_doubles(int N, int NP) {
-    return (size_t)N * N + 2 * (size_t)NP * NP + 16 * (size_t)NP + 6 * (size_t)NP + 3072;  // (3072: bandscan::kTableDoubles)
+    return (size_t)N * N + 2 * (size_t)NP * NP + 16 * (size_t)NP + 6 * (size_t)NP + 3072  // (3072: bandscan::kTableDoubles)
+           + 2 * (size_t)NP + 2 * ((size_t)NP / 16) * NP;  // two vectors and [2][NP / 16][NP] partial sums of the evaluations
 }
 size_t fh_ln_smem_bytes(int N, int *lu_in_lds, int *lu_nb);
 hipError_t fh_ln_launch(const LogNormalParams &P, int nblocks, hipStream_t s);

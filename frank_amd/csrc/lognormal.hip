@@ -83,7 +83,7 @@ struct LnS {
     bool same_xcd;
     int *s_cl;
 };
-enum { LN_CMD_NONE = 0, LN_CMD_SINV = 1, LN_CMD_TR2 = 2, LN_CMD_EXIT = 3, LN_CMD_HESS = 4 };
+enum { LN_CMD_NONE = 0, LN_CMD_SINV = 1, LN_CMD_TR2 = 2, LN_CMD_EXIT = 3, LN_CMD_HESS = 4, LN_CMD_EVAL = 5 };
 __device__ __forceinline__ void cluster_dispatch(const LogNormalParams &P, int cmd, bool same_xcd);
 __device__ __forceinline__ bool cluster_wait(const LogNormalParams &P, int *s_flag, bool same_xcd);
 
@@ -187,108 +187,129 @@ __device__ __forceinline__ void block_min_sum(LnS &S, double &a, double &b) {
 // cached S^-1 x (along = true); later trials (sv = NULL) read M only.  M exp(.) is recomputed for every point.
 //   sv    vector multiplied with S^-1 (NULL: none), its product goes to sdst
 //   along S^-1 xv = S.Sx + lam * S.col   (S.col: S^-1 p of this search; the unblocked LU's scratch, idle here)
+// The work of the two products is cut into ITEMS -- a row unit (two rows for even N: one 16-byte load per column and matrix) x a
+// chunk of 16 columns -- whose partial sums go to a scratch in global memory, [matrix][chunk][row]; a row's sum is the sum of
+// its chunks in order.  One decomposition whoever computes the items: a workgroup alone takes them all (thread t: items t,
+// t + 512, ...), a cluster deals them round its workgroups -- the same bits (test_lognormal_cluster_equals_single_workgroup).
+// Before, a thread walked a third of a column (100 matrix entries, a dozen L2 round trips one behind the other) and one CU
+// pulled both matrices alone: 30 k cycles per evaluation at N = 300, a sixth of a default-mode fit, half of a reference-mode one.
+constexpr int EVW = 16;  // columns per item
+// scratch behind the factors (fh_ln_lu_doubles): bands and scan tables of the pentadiagonal solve, the two vectors and the
+// partial sums of the evaluations
+__device__ __forceinline__ double *ln_band_scratch(const LogNormalParams &P) {
+    return P.LU + (size_t)P.N * P.N + 2 * (size_t)P.NP * P.NP + 16 * (size_t)P.NP;
+}
+__device__ __forceinline__ double *ln_eval_vecs(const LogNormalParams &P) { return ln_band_scratch(P) + 6 * P.NP + bandscan::kTableDoubles; }
+__device__ __forceinline__ double *ln_eval_parts(const LogNormalParams &P) { return ln_eval_vecs(P) + 2 * P.NP; }
+// items gthread, gthread + gstride, ...; svv: the vector S^-1 multiplies (NULL: that product is not wanted), Ivv: I -- both
+// in LDS (the multipliers are read there, at a uniform address, as the sums are formed).  The 16 columns of an item are loaded
+// in two batches of eight per matrix (sixteen at once held 190 registers, and the kernel spilled elsewhere for it).
+__device__ __forceinline__ void ln_eval_items(const LogNormalParams &P, const double *svv, const double *Ivv, int gthread, int gstride) {
+    const int N = P.N, NP = P.NP, nch = (N + EVW - 1) / EVW;
+    constexpr int EVH = EVW / 2;
+    double *part_s = ln_eval_parts(P), *part_m = part_s + (size_t)nch * NP;
+    if ((N & 1) == 0) {
+        const int RU = N >> 1, N2 = N >> 1, items = RU * nch;
+        for (int id = gthread; id < items; id += gstride) {
+            const int ch = id / RU, ru = id - ch * RU, c0 = ch * EVW;
+            const v2f64 *mc = reinterpret_cast<const v2f64 *>(__builtin_assume_aligned(P.M + (size_t)c0 * N + 2 * ru, 16));
+            const v2f64 *sc = reinterpret_cast<const v2f64 *>(__builtin_assume_aligned(P.Sinv + (size_t)c0 * N + 2 * ru, 16));
+            v2f64 a = {0.0, 0.0}, b = {0.0, 0.0};
+#pragma unroll 1
+            for (int h = 0; h < EVW; h += EVH) {
+                v2f64 vm[EVH], vs[EVH];
+#pragma unroll
+                for (int u = 0; u < EVH; ++u) {  // (every load issued: columns past N are clamped and multiplied by zero)
+                    const int cu = min(c0 + h + u, N - 1) - c0;
+                    vm[u] = mc[cu * N2];
+                    if (svv) vs[u] = sc[cu * N2];
+                }
+#pragma unroll
+                for (int u = 0; u < EVH; ++u) {
+                    const int c = c0 + h + u;
+                    const double xi = (c < N) ? Ivv[min(c, N - 1)] : 0.0;
+                    b[0] = fma(vm[u][0], xi, b[0]);
+                    b[1] = fma(vm[u][1], xi, b[1]);
+                    if (svv) {
+                        const double xs = (c < N) ? svv[min(c, N - 1)] : 0.0;
+                        a[0] = fma(vs[u][0], xs, a[0]);
+                        a[1] = fma(vs[u][1], xs, a[1]);
+                    }
+                }
+            }
+            if (svv) *reinterpret_cast<v2f64 *>(__builtin_assume_aligned(part_s + (size_t)ch * NP + 2 * ru, 16)) = a;
+            *reinterpret_cast<v2f64 *>(__builtin_assume_aligned(part_m + (size_t)ch * NP + 2 * ru, 16)) = b;
+        }
+    } else {
+        const int items = N * nch;
+        for (int id = gthread; id < items; id += gstride) {
+            const int ch = id / N, r = id - ch * N, c0 = ch * EVW;
+            const double *mc = P.M + (size_t)c0 * N + r, *sc = P.Sinv + (size_t)c0 * N + r;
+            double a = 0.0, b = 0.0;
+#pragma unroll 1
+            for (int h = 0; h < EVW; h += EVH) {
+                double vm[EVH], vs[EVH];
+#pragma unroll
+                for (int u = 0; u < EVH; ++u) {
+                    const int cu = min(c0 + h + u, N - 1) - c0;
+                    vm[u] = mc[cu * N];
+                    if (svv) vs[u] = sc[cu * N];
+                }
+#pragma unroll
+                for (int u = 0; u < EVH; ++u) {
+                    const int c = c0 + h + u;
+                    b = fma(vm[u], (c < N) ? Ivv[min(c, N - 1)] : 0.0, b);
+                    if (svv) a = fma(vs[u], (c < N) ? svv[min(c, N - 1)] : 0.0, a);
+                }
+            }
+            if (svv) part_s[(size_t)ch * NP + r] = a;
+            part_m[(size_t)ch * NP + r] = b;
+        }
+    }
+}
 __device__ __forceinline__ double ln_eval(const LogNormalParams &P, LnS &S, const double *xv, double *Iv, double *Sxv, double *MIv,
                                           const double *sv, double *sdst, bool along, double lam) {
-    const int N = P.N, tid = ln_tid();
+    const int N = P.N, NP = P.NP, tid = ln_tid(), nch = (N + EVW - 1) / EVW;
     LTIC();
-    if (S.row >= 0 && S.pair) {
-        const int o = S.c0 * N + S.row, N2 = N >> 1;
-        const v2f64 *mc = reinterpret_cast<const v2f64 *>(__builtin_assume_aligned(P.M + o, 16));
-        v2f64 a = {0.0, 0.0}, b = {0.0, 0.0};
-        int c = S.c0;
-        if (sv) {
-            const v2f64 *sc = reinterpret_cast<const v2f64 *>(__builtin_assume_aligned(P.Sinv + o, 16));
-            for (; c + EVB <= S.c1; c += EVB, sc += EVB * N2, mc += EVB * N2) {
-                v2f64 vs[EVB], vm[EVB];
-#pragma unroll
-                for (int u = 0; u < EVB; ++u) {
-                    vs[u] = sc[u * N2];
-                    vm[u] = mc[u * N2];
-                }
-#pragma unroll
-                for (int u = 0; u < EVB; ++u) {
-                    const double xc = sv[c + u], ic = Iv[c + u];
-                    a[0] = fma(vs[u][0], xc, a[0]);
-                    a[1] = fma(vs[u][1], xc, a[1]);
-                    b[0] = fma(vm[u][0], ic, b[0]);
-                    b[1] = fma(vm[u][1], ic, b[1]);
-                }
-            }
-            for (; c < S.c1; ++c, sc += N2, mc += N2) {
-                const v2f64 vs = *sc, vm = *mc;
-                a[0] = fma(vs[0], sv[c], a[0]);
-                a[1] = fma(vs[1], sv[c], a[1]);
-                b[0] = fma(vm[0], Iv[c], b[0]);
-                b[1] = fma(vm[1], Iv[c], b[1]);
-            }
-            S.pbuf[S.slot] = a[0];
-            S.pbuf[S.slot + 1] = a[1];
-        } else {
-            for (; c + 2 * EVB <= S.c1; c += 2 * EVB, mc += 2 * EVB * N2) {
-                v2f64 vm[2 * EVB];
-#pragma unroll
-                for (int u = 0; u < 2 * EVB; ++u) vm[u] = mc[u * N2];
-#pragma unroll
-                for (int u = 0; u < 2 * EVB; ++u) {
-                    const double ic = Iv[c + u];
-                    b[0] = fma(vm[u][0], ic, b[0]);
-                    b[1] = fma(vm[u][1], ic, b[1]);
-                }
-            }
-            for (; c < S.c1; ++c, mc += N2) {
-                const v2f64 vm = *mc;
-                b[0] = fma(vm[0], Iv[c], b[0]);
-                b[1] = fma(vm[1], Iv[c], b[1]);
-            }
+    bool shared = false;
+    if (S.cluster > 1) {  // the helpers read the two vectors from global memory; P.ctl[7]: whether S^-1 is multiplied
+        double *vecs = ln_eval_vecs(P);
+        for (int i = tid; i < N; i += LT) {
+            if (sv) vecs[i] = sv[i];
+            vecs[NP + i] = Iv[i];
         }
-        S.pbuf[S.pstride + S.slot] = b[0];
-        S.pbuf[S.pstride + S.slot + 1] = b[1];
-    } else if (S.row >= 0) {
-        const int o = S.c0 * N + S.row;
-        const double *mc = P.M + o;
-        double a = 0.0, b = 0.0;
-        int c = S.c0;
-        if (sv) {
-            const double *sc = P.Sinv + o;
-            for (; c + EVB <= S.c1; c += EVB, sc += EVB * N, mc += EVB * N) {  // 2 x EVB loads in flight, explicitly (see the Hinv loop)
-                double vs[EVB], vm[EVB];
-#pragma unroll
-                for (int u = 0; u < EVB; ++u) {
-                    vs[u] = sc[u * N];
-                    vm[u] = mc[u * N];
-                }
-#pragma unroll
-                for (int u = 0; u < EVB; ++u) {
-                    a = fma(vs[u], sv[c + u], a);
-                    b = fma(vm[u], Iv[c + u], b);
-                }
-            }
-            for (; c < S.c1; ++c, sc += N, mc += N) {
-                a = fma(*sc, sv[c], a);
-                b = fma(*mc, Iv[c], b);
-            }
-            S.pbuf[S.slot] = a;
-        } else {
-            for (; c + 2 * EVB <= S.c1; c += 2 * EVB, mc += 2 * EVB * N) {
-                double vm[2 * EVB];
-#pragma unroll
-                for (int u = 0; u < 2 * EVB; ++u) vm[u] = mc[u * N];
-#pragma unroll
-                for (int u = 0; u < 2 * EVB; ++u) b = fma(vm[u], Iv[c + u], b);
-            }
-            for (; c < S.c1; ++c, mc += N) b = fma(*mc, Iv[c], b);
+        if (tid == 0) __hip_atomic_store(&P.ctl[7], sv ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cluster_dispatch(P, LN_CMD_EVAL, S.same_xcd);
+        ln_eval_items(P, sv, Iv, tid, S.cluster * LT);
+        shared = cluster_wait(P, S.s_cl, S.same_xcd);
+        if (!shared) {  // the helpers did not answer: disband, and take every item here
+            if (tid == 0) __hip_atomic_store(&P.ctl[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            S.cluster = 1;
         }
-        S.pbuf[S.pstride + S.slot] = b;
     }
+    if (!shared) ln_eval_items(P, sv, Iv, tid, LT);
     __syncthreads();
     double A = 0.0, B = 0.0, C = 0.0;
     if (tid < N) {
-        double a = 0.0, b = 0.0;
+        const double *part_s = ln_eval_parts(P), *part_m = part_s + (size_t)nch * NP;
+        // (the chunks of a row are loaded as one batch -- clamped, never predicated -- and added in order: one L2 round trip,
+        //  not one per chunk)
+        constexpr int MAXCH = 20;  // N <= 320
+        double a = 0.0, b = 0.0, pm[MAXCH];
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ++ch) pm[ch] = part_m[(size_t)min(ch, nch - 1) * NP + tid];
         if (sv) {
-            for (int ch = 0; ch < S.nch; ++ch) a += S.pbuf[ch * N + tid];
+            double ps[MAXCH];
+#pragma unroll
+            for (int ch = 0; ch < MAXCH; ++ch) ps[ch] = part_s[(size_t)min(ch, nch - 1) * NP + tid];
+#pragma unroll
+            for (int ch = 0; ch < MAXCH; ++ch)
+                if (ch < nch) a += ps[ch];
             sdst[tid] = a;
         }
-        for (int ch = 0; ch < S.nch; ++ch) b += S.pbuf[S.pstride + ch * N + tid];
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ++ch)
+            if (ch < nch) b += pm[ch];
         if (along) {
             a = fma(lam, S.col[tid], S.Sx[tid]);
             Sxv[tid] = a;
@@ -1759,6 +1780,16 @@ __device__ __forceinline__ void cluster_helper(const LogNormalParams &P, int mem
         if (cmd == LN_CMD_EXIT || cmd == LN_CMD_NONE) return;
         if (cmd == LN_CMD_SINV) {
             build_sinv(P, P.rk_g, member, P.cluster);
+        } else if (cmd == LN_CMD_EVAL) {
+            extern __shared__ __attribute__((aligned(16))) double smem[];  // (a helper's LDS is otherwise unused)
+            const double *vecs = ln_eval_vecs(P);
+            const bool with_s = ctl_load(&P.ctl[7]) != 0;
+            for (int i = tid; i < P.N; i += LT) {
+                if (with_s) smem[i] = vecs[i];
+                smem[P.NP + i] = vecs[P.NP + i];
+            }
+            __syncthreads();
+            ln_eval_items(P, with_s ? smem : nullptr, smem + P.NP, member * LT + tid, P.cluster * LT);
         } else if (cmd == LN_CMD_HESS) {
             build_hess_rows(P, P.rk_g, P.tr2_g, P.j, P.LU + P.N * P.N, P.NP, false, member, P.cluster);
         } else if (cmd == LN_CMD_TR2) {
@@ -1863,7 +1894,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
     }
     // bands of the factorised T + I with the reciprocal pivots behind them, and the tables of the wave scans that solve with
     // them (band_scan.h), in this workgroup's scratch: formed once per fit, read by wave 0 once per pass
-    double *const band_g = P.LU + (size_t)N * N + 2 * (size_t)P.NP * P.NP + 16 * (size_t)P.NP, *const scan_g = band_g + 6 * P.NP;
+    double *const band_g = ln_band_scratch(P), *const scan_g = band_g + 6 * P.NP;
     if (P.band_lu) {
         for (int i = tid; i < 5 * N; i += LT) {
             const int bnd = i / N, c = i - bnd * N;
