@@ -52,13 +52,10 @@ __device__ __forceinline__ int ln_tid() {
     asm volatile("" : "+v"(t));
     return t;
 }
-#ifndef LN_EVB
-#define LN_EVB 8
-#endif
 #ifndef LN_HVB
 #define LN_HVB 16
 #endif
-constexpr int EVB = LN_EVB, HVB = LN_HVB;  // columns per load batch of the two evaluation products / the inverse product
+constexpr int HVB = LN_HVB;  // columns per load batch of the inverse product
 constexpr int LS_MAX_TRIALS = 2000;  // back-tracking guard: lam shrinks >= 10x per trial, x + lam p == x long before
 
 struct LnS {
