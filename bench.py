@@ -578,8 +578,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
-    # Every outstanding fit_loop kernel lives on its own HIP stream; HIP multiplexes streams onto
-    # GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels sharing a queue serialise.
+    # The launches of the fit loops take turns on four HIP streams beside the binning stream; HIP multiplexes streams onto
+    # GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels sharing a queue serialise: more queues than streams, so that the
+    # streams of the several contexts of this script never share one (the library sets the same default when it is loaded).
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
     # load the HIP library BEFORE torch so that ROCm's own runtime libraries serve the process
     from frank_amd import _lib as L
