@@ -1822,13 +1822,13 @@ static FitLoopParams make_loop_params(fh_ctx *c, int mode, double alpha, double 
 int fh_fit_normal(fh_ctx *c, const double *M, const double *j, double alpha, double p0, double wsmooth, double tol,
                   int max_iter, double *mu, double *p, int *niter, double *diag_p, double *diag_mu) {
     if (!c || !mu || !p || !niter) return fail(FH_ERR_INVALID, "fh_fit_normal: NULL argument");
-    // N > 478 does not fit the LDS-resident fit_loop kernel: the library loop (rocBLAS + rocSOLVER per iteration) serves
+    // N > 511 does not fit the LDS-resident fit_loop kernel: the library loop (rocBLAS + rocSOLVER per iteration) serves
     if (c->use_rocsolver_loop || c->NP > fh_k2_loop_max_np())
         return fit_normal_rocsolver(c, M, j, alpha, p0, wsmooth, tol, max_iter, mu, p, niter, diag_p, diag_mu);
     if ((M == nullptr) != (j == nullptr)) return fail(FH_ERR_INVALID, "fh_fit_normal: pass both M and j or neither");
     if (!M && !c->have_device_Mj) return fail(FH_ERR_INVALID, "fh_fit_normal: no device-resident M, j (run fh_stats_finalize)");
     if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
-    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 478", c->N);
+    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 511", c->N);
     HIP_TRY(hipSetDevice(c->device));
     const int N = c->N;
     const size_t NN = (size_t)N * N;
@@ -1913,7 +1913,7 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
         return fail(FH_ERR_INVALID, "fh_fit_normal_batched: bad argument");
     if ((M == nullptr) != (j == nullptr)) return fail(FH_ERR_INVALID, "pass both M and j or neither");
     if (!M && !c->have_device_Mj) return fail(FH_ERR_INVALID, "no device-resident M, j (run fh_stats_finalize)");
-    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 478", c->N);
+    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 511", c->N);
     HIP_TRY(hipSetDevice(c->device));
     const int N = c->N, NP = c->NP, nbk = NP / 16;
     const size_t NN = (size_t)N * N, PP = (size_t)NP * NP;
@@ -2043,7 +2043,7 @@ int fh_fit_flush(fh_ctx *c) {
 int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol, int max_iter, int *ticket) {
     if (!c || !ticket) return fail(FH_ERR_INVALID, "fh_fit_submit: NULL argument");
     if (!c->have_device_Mj) return fail(FH_ERR_INVALID, "fh_fit_submit: no device-resident M, j (run fh_stats_finalize)");
-    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 478", c->N);
+    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 511", c->N);
     if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
     HIP_TRY(hipSetDevice(c->device));
     int si = -1;
@@ -2181,7 +2181,7 @@ int fh_update_power_spectrum(fh_ctx *c, const double *M, const double *j, const 
     if (!c || !M || !j || !p) return fail(FH_ERR_INVALID, "fh_update_power_spectrum: NULL argument");
     if (c->use_rocsolver_loop || c->NP > fh_k2_loop_max_np())
         return update_power_spectrum_rocsolver(c, M, j, p, alpha, p0, wsmooth, mu, p_new);
-    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 478", c->N);
+    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 511", c->N);
     HIP_TRY(hipSetDevice(c->device));
     const int N = c->N;
     for (int k = 0; k < N; ++k)

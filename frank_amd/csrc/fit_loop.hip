@@ -90,12 +90,12 @@ constexpr int NWK = K2_ALL_WORK ? NW - 1 : NW - NW / 4;
 #endif
 constexpr int kChain = K2_CHAIN_WAVE;
 constexpr int kMaxTiles = 210;  // tiles of the largest trailing triangle: NP / 16 - 1 = 20 block rows (NP <= 336)
-// WIDE (336 < NP <= 480, N <= 478): two panels of NP x 17 doubles no longer fit the 160 KB of LDS beside the vectors and the scan
+// WIDE (336 < NP <= 512, N <= 511): two panels of NP x 17 doubles no longer fit the 160 KB of LDS beside the vectors and the scan
 // tables.  ONE panel then: the tiles of column k + 1 are computed into registers, a second barrier of the step lets everybody
 // finish reading panel k, and only then panel k + 1 overwrites it.  Two barriers per step instead of one; N <= 320 is untouched
 // (its own instantiation).  Before this, 320 < N <= 512 ran the library loop: ~8 x the time per pass at N = 321.
-constexpr int kMaxTilesWide = 435;  // 29 block rows
-constexpr int kWideMinNP = 337, kWideMaxNP = 480;
+constexpr int kMaxTilesWide = 496;  // 31 block rows
+constexpr int kWideMinNP = 337, kWideMaxNP = 512;
 template <bool WIDE> constexpr int max_tiles() { return WIDE ? kMaxTilesWide : kMaxTiles; }
 template <bool WIDE> constexpr int npanels() { return WIDE ? 1 : 2; }
 
@@ -623,9 +623,18 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     S.rhs = S.tr2 + NP;
     S.b = S.rhs + NP;
     S.red = S.b + NP;  // NP (block reductions use NW entries)
-    S.band = S.red + NP;
-    S.scanQ = S.band + 6 * NP;  // [2 directions][6 levels][4 entries][64 lanes]
-    S.rec = reinterpret_cast<uint4 *>(S.scanQ + 2 * 6 * 4 * 64);  // (16-byte aligned: every region before it is an even number of doubles)
+    if constexpr (WIDE) {
+        // the band factors and the scan tables (48 KB at NP = 512) in global memory -- the workgroup's W buffer, unused since
+        // W lives in the dead tiles of C --: wave 0 reads them once per pass (band_scan.h takes either address space), and
+        // the one panel, the vectors and the tile table of NP = 512 fit the LDS beside nothing else
+        S.band = P.W;
+        S.scanQ = P.W + 6 * NP;
+        S.rec = reinterpret_cast<uint4 *>(S.red + NP);
+    } else {
+        S.band = S.red + NP;
+        S.scanQ = S.band + 6 * NP;  // [2 directions][6 levels][4 entries][64 lanes]
+        S.rec = reinterpret_cast<uint4 *>(S.scanQ + 2 * 6 * 4 * 64);  // (16-byte aligned: every region before it is an even number of doubles)
+    }
     S.flag = reinterpret_cast<int *>(S.rec + max_tiles<WIDE>());  // [0] not positive definite, [1] column counter of the inverse row
     for (int e = tid; e < max_tiles<WIDE>(); e += KT) {  // tile e = (i - 1) i / 2 + (j - 1), 1 <= j <= i
         int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
@@ -702,7 +711,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
             if (P.diag_mu) {  // MAP of this pass: mu = Y^-1 m   (radial_fitters.py:783)
                 // (the loads of four rows are issued together: a row at a time the wave waited for one L2 round trip per row,
                 //  24 us of a 160 us pass with store_iteration_diagnostics on; the sums are formed in the same order)
-                constexpr int RB = 4, CB = WIDE ? 8 : 6;  // column chunks of 64: N < 336, N <= 478
+                constexpr int RB = 4, CB = WIDE ? 8 : 6;  // column chunks of 64: N < 336, N <= 511
                 const int ln = tid & 63;
                 double ms[CB];
 #pragma unroll
@@ -889,7 +898,7 @@ static bool loop_is_wide(int NP) { return NP >= kWideMinNP; }
 int fh_k2_loop_max_np() { return kWideMaxNP; }
 size_t fh_k2_loop_smem_bytes(int NP) {
     const bool wide = loop_is_wide(NP);
-    return sizeof(double) * (size_t)((wide ? 1 : 2) * NP * PS + 2 * 16 * PS + 7 * NP + NP + 6 * NP + 2 * 6 * 4 * 64) +
+    return sizeof(double) * (size_t)((wide ? 1 : 2) * NP * PS + 2 * 16 * PS + 7 * NP + NP + (wide ? 0 : 6 * NP + 2 * 6 * 4 * 64)) +
            16 * (size_t)(wide ? kMaxTilesWide : kMaxTiles) + 32;
 }
 
