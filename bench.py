@@ -9,6 +9,8 @@ resident in HBM, Normal GP fit, fp64:
 Every step streams the whole table and runs the whole iteration; the one thing a context remembers between steps is the
 baseline range (qmin, qmax) of a (table, rows, geometry) it has binned before, which saves the host round trip that sizes
 the bucket sort (extra.distinct_tables measures the pipeline without it: a ring of different tables, range cache off).
+Nothing of the data is remembered otherwise; a fit slot keeps the band factors of the smoothing matrix T + I for the
+hyper-parameters it last ran (they depend on (w_smooth, alpha, p0) and the collocation points only).
 `value` = fits completed by all ranks / max-over-ranks wall time.  The timed region holds `steps` binning passes and ONE
 drain of the last fits' iterations (~0.09 s), so `value` grows with --steps; extra.steady_state is the rate of a >= 2 s run.
 
