@@ -460,18 +460,44 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     {
         c->NP = 16 * ((N + 1 + 15) / 16);  // at least one padding row: row N carries b (fit_loop.hip)
         const size_t PP = (size_t)c->NP * c->NP;
-        // Y^-1 by LU on the device (in place; the inverse of the column-major view is the row-major inverse)
+        // Y^-1 by LU on the device (the inverse of the column-major view is the row-major inverse): getrf, then getrs on the
+        // identity.  NOT getri: rocSOLVER 3.32 (ROCm 7.2) returns a wrong inverse -- |inv A - I| = 1 with info = 0 -- for every
+        // N = 127 mod 128 from 255 on (255, 383, 511, 639; checked on random matrices, round 3), which made the q-space
+        // operands garbage, the first seed Cholesky "fail" and every fit of those sizes fall back to the slow route, silently.
+        // The residual of the inverse is checked once, here, so that a library misbehaving at some other size cannot do that again.
         DevBuf<rocblas_int> ipiv;
+        DevBuf<double> lu_y;
         HIP_TRY(ipiv.alloc(N));
+        HIP_TRY(lu_y.alloc(NN));
         HIP_TRY(c->Yinv.alloc(NN));
-        HIP_TRY(hipMemcpy(c->Yinv.p, Y.data(), sizeof(double) * NN, hipMemcpyHostToDevice));
-        ROC_TRY(rocsolver_dgetrf(c->blas, N, N, c->Yinv.p, N, ipiv.p, c->info.p));
-        ROC_TRY(rocsolver_dgetri(c->blas, N, c->Yinv.p, N, ipiv.p, c->info.p));
+        HIP_TRY(c->T1.alloc(NN));
+        HIP_TRY(hipMemcpy(lu_y.p, Y.data(), sizeof(double) * NN, hipMemcpyHostToDevice));
+        {
+            std::vector<double> eye(NN, 0.0);
+            for (int k = 0; k < N; ++k) eye[(size_t)k * N + k] = 1.0;
+            HIP_TRY(hipMemcpy(c->Yinv.p, eye.data(), sizeof(double) * NN, hipMemcpyHostToDevice));
+        }
+        ROC_TRY(rocsolver_dgetrf(c->blas, N, N, lu_y.p, N, ipiv.p, c->info.p));
         int inv_info = 0;
         HIP_TRY(hipMemcpyAsync(&inv_info, c->info.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (inv_info != 0) return fail(FH_ERR_INVALID, "DHT coefficient matrix is singular (getri info %d)", inv_info);
-        HIP_TRY(c->T1.alloc(NN));
+        if (inv_info != 0) return fail(FH_ERR_INVALID, "DHT coefficient matrix is singular (getrf info %d)", inv_info);
+        ROC_TRY(rocsolver_dgetrs(c->blas, rocblas_operation_none, N, N, lu_y.p, N, ipiv.p, c->Yinv.p, N));
+        {   // residual: (Y^-1 Y - I) in the row-major reading == the column-major product Y_buf * Yinv_buf
+            const double one = 1.0, zero = 0.0;
+            HIP_TRY(hipStreamSynchronize(c->stream));  // (the solve still reads the factors in lu_y)
+            HIP_TRY(hipMemcpy(lu_y.p, Y.data(), sizeof(double) * NN, hipMemcpyHostToDevice));
+            ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, N, N, N, &one, lu_y.p, N, c->Yinv.p, N, &zero,
+                                  c->T1.p, N));
+            std::vector<double> r(NN);
+            HIP_TRY(hipMemcpyAsync(r.data(), c->T1.p, sizeof(double) * NN, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            double worst = 0.0;
+            for (int a = 0; a < N; ++a)
+                for (int b = 0; b < N; ++b) worst = std::max(worst, std::fabs(r[(size_t)a * N + b] - (a == b ? 1.0 : 0.0)));
+            if (!(worst < 1e-9))
+                return fail(FH_ERR_HIP, "the device inverse of the DHT coefficient matrix is wrong (|Y^-1 Y - I| = %.3g at N = %d)", worst, N);
+        }
         HIP_TRY(c->Araw.alloc(NN));
         HIP_TRY(c->Aq.alloc(PP));
         HIP_TRY(c->Cq.alloc(PP));
@@ -1822,13 +1848,13 @@ static FitLoopParams make_loop_params(fh_ctx *c, int mode, double alpha, double 
 int fh_fit_normal(fh_ctx *c, const double *M, const double *j, double alpha, double p0, double wsmooth, double tol,
                   int max_iter, double *mu, double *p, int *niter, double *diag_p, double *diag_mu) {
     if (!c || !mu || !p || !niter) return fail(FH_ERR_INVALID, "fh_fit_normal: NULL argument");
-    // N > 511 does not fit the LDS-resident fit_loop kernel: the library loop (rocBLAS + rocSOLVER per iteration) serves
+    // N > 639 does not fit the LDS-resident fit_loop kernel: the library loop (rocBLAS + rocSOLVER per iteration) serves
     if (c->use_rocsolver_loop || c->NP > fh_k2_loop_max_np())
         return fit_normal_rocsolver(c, M, j, alpha, p0, wsmooth, tol, max_iter, mu, p, niter, diag_p, diag_mu);
     if ((M == nullptr) != (j == nullptr)) return fail(FH_ERR_INVALID, "fh_fit_normal: pass both M and j or neither");
     if (!M && !c->have_device_Mj) return fail(FH_ERR_INVALID, "fh_fit_normal: no device-resident M, j (run fh_stats_finalize)");
     if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
-    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 511", c->N);
+    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 639", c->N);
     HIP_TRY(hipSetDevice(c->device));
     const int N = c->N;
     const size_t NN = (size_t)N * N;
@@ -1913,7 +1939,7 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
         return fail(FH_ERR_INVALID, "fh_fit_normal_batched: bad argument");
     if ((M == nullptr) != (j == nullptr)) return fail(FH_ERR_INVALID, "pass both M and j or neither");
     if (!M && !c->have_device_Mj) return fail(FH_ERR_INVALID, "no device-resident M, j (run fh_stats_finalize)");
-    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 511", c->N);
+    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 639", c->N);
     HIP_TRY(hipSetDevice(c->device));
     const int N = c->N, NP = c->NP, nbk = NP / 16;
     const size_t NN = (size_t)N * N, PP = (size_t)NP * NP;
@@ -2043,7 +2069,7 @@ int fh_fit_flush(fh_ctx *c) {
 int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol, int max_iter, int *ticket) {
     if (!c || !ticket) return fail(FH_ERR_INVALID, "fh_fit_submit: NULL argument");
     if (!c->have_device_Mj) return fail(FH_ERR_INVALID, "fh_fit_submit: no device-resident M, j (run fh_stats_finalize)");
-    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 511", c->N);
+    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 639", c->N);
     if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
     HIP_TRY(hipSetDevice(c->device));
     int si = -1;
@@ -2181,7 +2207,7 @@ int fh_update_power_spectrum(fh_ctx *c, const double *M, const double *j, const 
     if (!c || !M || !j || !p) return fail(FH_ERR_INVALID, "fh_update_power_spectrum: NULL argument");
     if (c->use_rocsolver_loop || c->NP > fh_k2_loop_max_np())
         return update_power_spectrum_rocsolver(c, M, j, p, alpha, p0, wsmooth, mu, p_new);
-    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 511", c->N);
+    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 639", c->N);
     HIP_TRY(hipSetDevice(c->device));
     const int N = c->N;
     for (int k = 0; k < N; ++k)

@@ -90,12 +90,12 @@ constexpr int NWK = K2_ALL_WORK ? NW - 1 : NW - NW / 4;
 #endif
 constexpr int kChain = K2_CHAIN_WAVE;
 constexpr int kMaxTiles = 210;  // tiles of the largest trailing triangle: NP / 16 - 1 = 20 block rows (NP <= 336)
-// WIDE (336 < NP <= 512, N <= 511): two panels of NP x 17 doubles no longer fit the 160 KB of LDS beside the vectors and the scan
+// WIDE (336 < NP <= 640, N <= 639): two panels of NP x 17 doubles no longer fit the 160 KB of LDS beside the vectors and the scan
 // tables.  ONE panel then: the tiles of column k + 1 are computed into registers, a second barrier of the step lets everybody
 // finish reading panel k, and only then panel k + 1 overwrites it.  Two barriers per step instead of one; N <= 320 is untouched
 // (its own instantiation).  Before this, 320 < N <= 512 ran the library loop: ~8 x the time per pass at N = 321.
-constexpr int kMaxTilesWide = 496;  // 31 block rows
-constexpr int kWideMinNP = 337, kWideMaxNP = 512;
+constexpr int kMaxTilesWide = 780;  // 39 block rows
+constexpr int kWideMinNP = 337, kWideMaxNP = 640;
 template <bool WIDE> constexpr int max_tiles() { return WIDE ? kMaxTilesWide : kMaxTiles; }
 template <bool WIDE> constexpr int npanels() { return WIDE ? 1 : 2; }
 
@@ -276,7 +276,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
         Frag fa;
 #pragma unroll
         for (int q = 0; q < 4; ++q) fa.v[q] = S.dli[cl * PS + 4 * q + rg];
-        constexpr int kPanelMax = 3;  // ceil((NP / 16 - 1) / NW) for NP <= 400
+        constexpr int kPanelMax = WIDE ? 4 : 3;  // ceil((NP / 16 - 1) / NW): 4 for NP <= 640
         Frag fb[kPanelMax];
 #pragma unroll
         for (int u = 0; u < kPanelMax; ++u) {
@@ -436,7 +436,8 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             // (the round-robin deal of the tiles goes on where the enumeration above stopped)
             int cfirst = widx - cntA % NWK;
             if (cfirst < 0) cfirst += NWK;
-            v4f64 dcol[WIDE ? 3 : 1];  // (WIDE: ncol <= 28 = 3 x NWK - 5)
+            constexpr int kColMax = 4;  // (WIDE: ncol <= 38 <= 4 x NWK)
+            v4f64 dcol[WIDE ? kColMax : 1];
             if (cfirst < ncol) {
                 // L_{k+1,k+1}^-1 comes from wave 0's chain (~5 us into the step): inverse columns fill the wait
                 if (k >= 1) {
@@ -483,7 +484,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 } else {
                     // one panel: the tiles stay in registers until everybody has read panel k (the barrier below)
 #pragma unroll
-                    for (int u = 0; u < 3; ++u) {
+                    for (int u = 0; u < kColMax; ++u) {
                         const int c = cfirst + u * NWK;
                         if (c < ncol) {
                             const int i = c + 1;
@@ -501,7 +502,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             if constexpr (WIDE) {
                 __syncthreads();
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
+                for (int u = 0; u < kColMax; ++u) {
                     const int c = cfirst + u * NWK;
                     if (c < ncol) {
                         const int i = c + 1;
@@ -540,7 +541,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
 }
 
 // ---- (T + I) tau = rhs by a wave scan: band_scan.h ----
-template <bool WIDE> constexpr int scan_rows() { return WIDE ? 8 : 6; }  // rows per lane: 64 * 6 = 384, 64 * 8 = 512 >= NP
+template <bool WIDE> constexpr int scan_rows() { return WIDE ? 10 : 6; }  // rows per lane: 64 * 6 = 384, 64 * 10 = 640 >= NP
 using bandscan::scan_solve;
 using bandscan::scan_tables;
 
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
             if (P.diag_mu) {  // MAP of this pass: mu = Y^-1 m   (radial_fitters.py:783)
                 // (the loads of four rows are issued together: a row at a time the wave waited for one L2 round trip per row,
                 //  24 us of a 160 us pass with store_iteration_diagnostics on; the sums are formed in the same order)
-                constexpr int RB = 4, CB = WIDE ? 8 : 6;  // column chunks of 64: N < 336, N <= 511
+                constexpr int RB = 4, CB = WIDE ? 10 : 6;  // column chunks of 64: N < 336, N <= 639
                 const int ln = tid & 63;
                 double ms[CB];
 #pragma unroll

@@ -226,7 +226,7 @@ struct FitLoopParams {
 #define FIT_MAX_BATCH 128
 
 size_t fh_k2_loop_smem_bytes(int NP);
-int fh_k2_loop_max_np();  // largest padded size NP the persistent fit loop covers (512: N <= 511)
+int fh_k2_loop_max_np();  // largest padded size NP the persistent fit loop covers (640: N <= 639)
 hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s);
 hipError_t fh_k2_launch_loop_slots(const FitLoopParams &P, int nslots, hipStream_t s);
 hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s);

@@ -679,6 +679,34 @@ def test_prepass_instances_against_oracle(monkeypatch, kind, safe):
         assert abs(qmx.value - o["qmax"]) <= 1e-15 * o["qmax"] * 4 if "qmax" in o else True
 
 
+@pytest.mark.parametrize("N", [255, 383, 511, 639])
+def test_fused_loop_where_the_library_inverse_is_wrong(monkeypatch, N):
+    """rocSOLVER 3.32's getri returns a wrong inverse (|inv A - I| = 1, info = 0) for every N = 127 mod 128 from 255 on.  Y^-1
+    of the q-space reformulation came from it: at these sizes the operands of the fit loop were garbage, its first seed
+    Cholesky "failed" and every fit fell back to the one-posterior-at-a-time route -- right results, ten times slower, and
+    nothing said so.  Y^-1 now comes from getrf + getrs on the identity and its residual is checked when the context is made.
+    Here: the fused loop itself (fh_fit_normal, no fallback) returns FH_OK at these sizes and agrees with the library loop."""
+    import ctypes
+    from frank_amd import FrankFitter, _lib
+    u, v, V, w = mock_disc_visibilities(60000, seed=31, noise_seed=32)
+    kw = dict(alpha=1.3, weights_smooth=1e-2, verbose=False)
+    FF = FrankFitter(2.0, N, geom(), **kw)
+    pre = FF.preprocess_visibilities(u, v, V, w)
+    M, j = np.ascontiguousarray(pre["M"]), np.ascontiguousarray(pre["j"])
+
+    def run(F):
+        mu, p, nit = np.empty(N), np.empty(N), ctypes.c_int()
+        rc = _lib.lib.fh_fit_normal(F._DHT.context(), _lib.ptr(M), _lib.ptr(j), 1.3, 1e-15, 1e-2, 1e-3, 2000, _lib.ptr(mu),
+                                    _lib.ptr(p), ctypes.byref(nit), None, None)
+        return rc, nit.value, mu
+
+    rc, nit, mu = run(FF)
+    monkeypatch.setenv("FRANK_AMD_K2", "rocsolver")
+    rc_l, nit_l, mu_l = run(FrankFitter(2.0, N, geom(), **kw))
+    assert rc == 0 and rc_l == 0 and nit == nit_l and 10 < nit < 2000
+    assert rel_to_max(mu, mu_l) < 1e-7
+
+
 def test_deferred_reset_keeps_the_accumulate_semantics():
     """fh_bin_reset only NOTES that the sums start from zero (the moments path's last kernel then stores instead of adding, the
     two fills never run): a reset followed by two binning calls still accumulates both, a second reset forgets them, a reset

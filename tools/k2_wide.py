@@ -12,7 +12,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from frank_amd import FixedGeometry, FrankFitter
     from frank_amd.mock import MOCK_GEOMETRY, mock_disc_visibilities
     u, v, V, w = mock_disc_visibilities(100000, seed=31, noise_seed=32)
-    for N in (300, 320, 340, 400, 478, 500):
+    for N in (300, 320, 340, 400, 478, 511, 600, 639):
         FF = FrankFitter(2.0, N, FixedGeometry(**MOCK_GEOMETRY), alpha=1.3, weights_smooth=1e-2, verbose=False,
                          store_iteration_diagnostics=True)
         pre = FF.preprocess_visibilities(u, v, V, w)
