@@ -280,7 +280,10 @@ class FrankFitter(FourierBesselFitter):
             # a Cholesky inside the device loop failed (for method='LogNormal': in one of the two Normal seed solves,
             # radial_fitters.py:744-752, or of the Hessian at a MAP, statistical_models.py:1150-1158): the reference
             # carries on through the SVD pseudo-inverse (statistical_models.py:747-755); so does the loop below, one
-            # posterior at a time
+            # posterior at a time.  (Logged: it is ~10 x slower than the fused loop, and a fit that takes this route for
+            # no numerical reason -- it once did, at the sizes where a library inverse was wrong -- should be noticed.)
+            logging.info('    A Cholesky factorisation failed inside the device loop: continuing one posterior at a '
+                         'time through the SVD route (as the reference does; slower)')
             return self._fit_one_posterior_at_a_time()
         _lib.check(rc)
         count = niter.value
