@@ -398,7 +398,12 @@ __global__ __launch_bounds__(256) void bucket_factor_kernel(const Row32 *rows, c
         const double piv = __shfl(col[r], r);
         const bool ok = piv > 1.5e-14 * h0;
         const double inv = ok ? 1.0 / sqrt(piv) : 0.0;
-        const double Rrc = (cc >= r) ? col[r] * inv : 0.0;
+        double Rrc = (cc >= r) ? col[r] * inv : 0.0;
+        if (r < NA - 1 && cc == NA - 1) {  // (the data column never takes more than is left of its own diagonal entry:
+                                            //  bucket_factor2_kernel, bin_prepass.hip)
+            const double lim = sqrt(fmax(col[NA - 1], 0.0));
+            Rrc = fmin(fmax(Rrc, -lim), lim);
+        }
         if (lane < NA) out[r * 16 + lane] = Rrc;
 #pragma unroll
         for (int i = r + 1; i < NA; ++i) {

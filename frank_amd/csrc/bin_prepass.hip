@@ -559,7 +559,17 @@ __global__ __launch_bounds__(1024) void bucket_factor2_kernel(PrepassParams P) {
         const double piv = __shfl(col[r], r);
         const bool ok = piv > 1.5e-14 * h0;
         const double inv = ok ? 1.0 / sqrt(piv) : 0.0;
-        const double Rrc = (cc >= r) ? col[r] * inv : 0.0;
+        double Rrc = (cc >= r) ? col[r] * inv : 0.0;
+        // The data column of a row whose pivot is all but cancelled: for a positive semi-definite matrix |R[r][12]|^2 cannot exceed
+        // what is left of the data column's own diagonal entry; an entry beyond that is the round-off of H[r][12] divided by the
+        // square root of a pivot of ~1e-14 H_rr.  Left alone it drove the last pivot negative -- dropped, i.e. taken as zero -- and
+        // the bucket's sum of w V^2 came out too LARGE by what had been subtracted once too often (M and j do not notice: the
+        // row's other entries are ~sqrt(pivot)): H0 off by 1.8e-3 at N = 38 and 5e-6 at N = 57 for one table, right at 507 other
+        // sizes (tools/size_sweep_binning.py).  The clamp is inactive for every entry that obeys the bound: same bits elsewhere.
+        if (r < NA - 1 && cc == NA - 1) {
+            const double lim = sqrt(fmax(col[NA - 1], 0.0));
+            Rrc = fmin(fmax(Rrc, -lim), lim);
+        }
         if (lane < NA) out[r * 16 + lane] = Rrc;
 #pragma unroll
         for (int i = r + 1; i < NA; ++i) {

@@ -679,6 +679,25 @@ def test_prepass_instances_against_oracle(monkeypatch, kind, safe):
         assert abs(qmx.value - o["qmax"]) <= 1e-15 * o["qmax"] * 4 if "qmax" in o else True
 
 
+@pytest.mark.parametrize("N", [38, 57])
+def test_null_likelihood_of_the_moments_path_at_sizes_that_lost_it(N):
+    """The sum of w V'^2 (the data-data entry of a bucket's moment matrix) through the Cholesky factor of that matrix: with a
+    pivot all but cancelled (the monomial moments of a bucket are as ill-conditioned as a Hilbert matrix) the round-off of
+    H[r][12] over the square root of the pivot could exceed what is left of the data column's diagonal; the last pivot then
+    went negative, was dropped, and the bucket's sum came out too large -- H0 off by 1.8e-3 at N = 38 and 5e-6 at N = 57 for this
+    table (M and j right), found by tools/size_sweep_binning.py over N = 3 .. 511.  Referee: the oracle."""
+    from frank_amd import FourierBesselFitter
+    from oracle import oracle as fo
+    u, v, V, w = mock_disc_visibilities(40000, seed=3, noise_seed=4)
+    FB = FourierBesselFitter(2.0, N, geom(), verbose=False)
+    FB._vis_map.check_qbounds = False
+    m = FB.preprocess_visibilities(u, v, V, w)
+    g = geom()
+    o = fo.map_visibilities(N, RMAX, (g.inc, g.PA, g.dRA, g.dDec), u, v, V, w, check_qbounds=False)
+    assert abs(m["null_likelihood"] - o["null_likelihood"]) <= 1e-12 * abs(o["null_likelihood"])
+    assert rel_to_max(m["M"], o["M"]) < 1e-12 and rel_to_max(m["j"], o["j"]) < 1e-12
+
+
 @pytest.mark.parametrize("N", [255, 383, 511, 639])
 def test_fused_loop_where_the_library_inverse_is_wrong(monkeypatch, N):
     """rocSOLVER 3.32's getri returns a wrong inverse (|inv A - I| = 1, info = 0) for every N = 127 mod 128 from 255 on.  Y^-1
