@@ -1125,6 +1125,7 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
         // eight workgroups per tile -- workgroup ids go round the eight XCDs, so an XCD's L2 holds one eighth of the tables
         // (7 MB at N = 300: read once per workgroup they came from memory, 42 us) -- of eight waves each
         G.waves = env_int("FRANK_AMD_K1_VRWAVES", 8);
+        G.waves = G.waves < 4 ? 4 : (G.waves > 16 ? 16 : G.waves);  // (the tile is folded by the workgroup's first 256 threads)
         int split = env_int("FRANK_AMD_K1_VRSPLIT", 8);
         G.split = split < 1 ? 1 : (split > 8 ? 8 : split);
         G.vrows = c->k1_vrows.p;
