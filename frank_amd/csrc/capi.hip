@@ -2349,7 +2349,8 @@ int fh_fit_lognormal(fh_ctx *c, const double *M, const double *j, double alpha, 
     if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
     if (!(I_scale > 0)) return fail(FH_ERR_INVALID, "I_scale must be positive");
     if ((diag_p == nullptr) != (diag_s == nullptr)) return fail(FH_ERR_INVALID, "pass both diag_p and diag_s or neither");
-    if (c->NP > 320) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit kernels cover N <= 303", c->N);
+    if (c->N > 320 || c->NP > fh_k2_loop_max_np())  // (the two Normal seed fits run on the fit loop)
+        return fail(FH_ERR_UNSUPPORTED, "N = %d: the LogNormal kernel covers N <= 320", c->N);
     LogNormalParams P;
     int rc = ln_prepare(c, M, j, P);
     if (rc) return rc;
@@ -2447,7 +2448,8 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
         return fail(FH_ERR_INVALID, "fh_fit_lognormal_batched: bad argument");
     if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
     if (!(I_scale > 0)) return fail(FH_ERR_INVALID, "I_scale must be positive");
-    if (c->NP > 320) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit kernels cover N <= 303", c->N);
+    if (c->N > 320 || c->NP > fh_k2_loop_max_np())  // (the two Normal seed fits run on the fit loop)
+        return fail(FH_ERR_UNSUPPORTED, "N = %d: the LogNormal kernel covers N <= 320", c->N);
     LogNormalParams P;
     int rc = ln_prepare(c, M, j, P);
     if (rc) return rc;
