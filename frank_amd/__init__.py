@@ -16,9 +16,12 @@ def __getattr__(name):
     if name in ("FrankFitter", "FourierBesselFitter", "FrankRadialFit", "FrankGaussianFit", "FrankLogNormalFit"):
         from frank_amd import radial_fitters
         return getattr(radial_fitters, name)
-    if name in ("FixedGeometry", "SourceGeometry"):
+    if name in ("FixedGeometry", "SourceGeometry", "FitGeometryGaussian", "FitGeometryFourierBessel"):
         from frank_amd import geometry
         return getattr(geometry, name)
+    if name in ("FrankDebrisFitter", "FourierBesselDebrisFitter"):
+        from frank_amd import debris_fitters
+        return getattr(debris_fitters, name)
     if name == "DiscreteHankelTransform":
         from frank_amd.hankel import DiscreteHankelTransform
         return DiscreteHankelTransform

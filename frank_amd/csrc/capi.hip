@@ -102,6 +102,7 @@ struct fh_vis {
     DevBuf<int> mult;  // bootstrap multiplicities (fh_vis_set_multiplicity), empty = every row once
     bool use_mult = false;
     unsigned long long mult_gen = 0;  // changes with every fh_vis_set_multiplicity: rows drawn zero times leave the range
+    mutable DevBuf<double> resid;     // geometry fits: residuals (2 n), Jacobian (12 n), partial sums -- grown on first use
 };
 
 struct FitSlot {
@@ -1191,20 +1192,8 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     return FH_OK;
 }
 
-int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int64_t first, int64_t count) {
-    if (!c || !g || !vis) return fail(FH_ERR_INVALID, "fh_bin_visibilities: NULL argument");
-    if (first < 0 || count < 0 || first + count > vis->n) return fail(FH_ERR_INVALID, "fh_bin_visibilities: bad range");
-    if (vis->device != c->device) return fail(FH_ERR_INVALID, "visibility table lives on another device");
-    // single-precision arithmetic of the design block (fh_ctx_set_arithmetic): its Gram is off by ~1e-8 of the largest entry and,
-    // measured, no longer positive definite at 1e7 rows (the first seed solve has unit prior precision, radial_fitters.py:744);
-    // it is also 25 x slower than the fp64 moments pass.  Kept for tables up to 2e6 rows, refused beyond: hand the table over
-    // in single precision instead (fh_vis_upload_f32 -- 20 B per visibility, fp64 arithmetic).
-    if (c->arith32 && count > 2000000)
-        return fail(FH_ERR_UNSUPPORTED, "arithmetic='fp32' covers tables up to 2e6 visibilities (%lld given): beyond, the "
-                    "single-precision Gram loses positive definiteness; pass float32 arrays (fp32 storage, fp64 arithmetic) "
-                    "or use the default arithmetic", (long long)count);
-    HIP_TRY(hipSetDevice(c->device));
-    BinParams p{};
+// columns and row range of a resident table, as every kernel that streams it takes them
+static void table_columns(BinParams &p, const fh_vis *vis, int64_t first, int64_t count) {
     p.u = vis->u.p;
     p.v = vis->v.p;
     p.Vre = vis->Vre.p;
@@ -1221,6 +1210,23 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     p.mult = vis->use_mult ? vis->mult.p : nullptr;
     p.first = first;
     p.count = count;
+}
+
+int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int64_t first, int64_t count) {
+    if (!c || !g || !vis) return fail(FH_ERR_INVALID, "fh_bin_visibilities: NULL argument");
+    if (first < 0 || count < 0 || first + count > vis->n) return fail(FH_ERR_INVALID, "fh_bin_visibilities: bad range");
+    if (vis->device != c->device) return fail(FH_ERR_INVALID, "visibility table lives on another device");
+    // single-precision arithmetic of the design block (fh_ctx_set_arithmetic): its Gram is off by ~1e-8 of the largest entry and,
+    // measured, no longer positive definite at 1e7 rows (the first seed solve has unit prior precision, radial_fitters.py:744);
+    // it is also 25 x slower than the fp64 moments pass.  Kept for tables up to 2e6 rows, refused beyond: hand the table over
+    // in single precision instead (fh_vis_upload_f32 -- 20 B per visibility, fp64 arithmetic).
+    if (c->arith32 && count > 2000000)
+        return fail(FH_ERR_UNSUPPORTED, "arithmetic='fp32' covers tables up to 2e6 visibilities (%lld given): beyond, the "
+                    "single-precision Gram loses positive definiteness; pass float32 arrays (fp32 storage, fp64 arithmetic) "
+                    "or use the default arithmetic", (long long)count);
+    HIP_TRY(hipSetDevice(c->device));
+    BinParams p{};
+    table_columns(p, vis, first, count);
     // geometry.py:69-70 (dRA *= 2 pi / rad_to_arcsec), :111-115
     p.dRA = g->dRA_arcsec * (2. * M_PI / kRadToArcsec);
     p.dDec = g->dDec_arcsec * (2. * M_PI / kRadToArcsec);
@@ -2579,6 +2585,102 @@ static int uvbin_sums(fh_uvbin *h, const double *d_uv, const double *d_w, const 
     }
     return FH_OK;
 }
+
+// ---- geometry fits: the residual functions of geometry.py:404-763 on the resident table ---------------------------------
+static int residual_scratch(const fh_vis *vis, size_t doubles, double **partial, double **sumsq) {
+    const size_t need = doubles + (size_t)fh_residual_max_blocks() + 1;
+    if (vis->resid.n < need) HIP_TRY(vis->resid.alloc(need));
+    *partial = vis->resid.p + doubles;
+    *sumsq = *partial + fh_residual_max_blocks();
+    return FH_OK;
+}
+
+int fh_vis_residuals(fh_ctx *c, const fh_geometry *g, int vis_model, const fh_vis *vis, int64_t first, int64_t count,
+                     const double *I, double *out, double *sumsq) {
+    if (!c || !g || !vis || !I) return fail(FH_ERR_INVALID, "fh_vis_residuals: NULL argument");
+    if (first < 0 || count < 0 || first + count > vis->n) return fail(FH_ERR_INVALID, "fh_vis_residuals: bad range");
+    if (vis->device != c->device) return fail(FH_ERR_INVALID, "visibility table lives on another device");
+    if (vis_model != FH_VIS_OPT_THICK && vis_model != FH_VIS_OPT_THIN && vis_model != FH_VIS_DEBRIS)
+        return fail(FH_ERR_INVALID, "vis_model must be one of ['opt_thick', 'opt_thin', 'debris']");
+    if ((vis_model == FH_VIS_DEBRIS) != c->debris)
+        return fail(FH_ERR_INVALID, "vis_model 'debris' goes with fh_ctx_set_scale_height (and only with it)");
+    if (count == 0) {
+        if (sumsq) *sumsq = 0.0;
+        return FH_OK;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->N;
+    VisResidualParams P{};
+    table_columns(P.b, vis, first, count);
+    P.b.dRA = g->dRA_arcsec * (2. * M_PI / kRadToArcsec);
+    P.b.dDec = g->dDec_arcsec * (2. * M_PI / kRadToArcsec);
+    const double inc = g->inc_deg * kDegToRad, PA = g->PA_deg * kDegToRad;
+    P.b.cos_t = cos(PA);
+    P.b.sin_t = sin(PA);
+    P.b.cos_i = cos(inc);
+    P.b.sin_i = sin(inc);
+    P.b.N = N;
+    P.b.inv_Qmax = 1. / c->dht->Qmax;
+    P.b.zeros = c->zeros.p;
+    P.b.j0_table = c->j0_table.p;
+    P.b.H2 = c->debris ? c->debris_H2.p : nullptr;
+    P.pref = c->pref_fwd.p;
+    P.scale = vis_model == FH_VIS_OPT_THICK ? cos(inc) : 1.0;
+    double *d_sumsq = nullptr;
+    int rc = residual_scratch(vis, out ? 2 * (size_t)count : 0, &P.partial, &d_sumsq);
+    if (rc) return rc;
+    P.out = out ? vis->resid.p : nullptr;
+    if (c->scratch_I.n < (size_t)N + 1) HIP_TRY(c->scratch_I.alloc((size_t)N + 1));
+    HIP_TRY(hipMemcpyAsync(c->scratch_I.p, I, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    P.I = c->scratch_I.p;
+    HIP_TRY(fh_launch_vis_residual(P, d_sumsq, c->stream));
+    if (out) HIP_TRY(hipMemcpyAsync(out, vis->resid.p, sizeof(double) * 2 * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    double ss = 0.0;
+    HIP_TRY(hipMemcpyAsync(&ss, d_sumsq, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (sumsq) *sumsq = ss;
+    return FH_OK;
+}
+
+int fh_gauss_residuals(const fh_vis *vis, const double *params, int fit_inc_pa, int fit_phase, double *fun, double *jac,
+                       double *sumsq) {
+    if (!vis || !params) return fail(FH_ERR_INVALID, "fh_gauss_residuals: NULL argument");
+    const int64_t n = vis->n;
+    if (n == 0) {
+        if (sumsq) *sumsq = 0.0;
+        return FH_OK;
+    }
+    HIP_TRY(hipSetDevice(vis->device));
+    GaussResidualParams P{};
+    table_columns(P.b, vis, 0, n);
+    P.fac = 2. * M_PI / kRadToArcsec;
+    P.rad_to_arcsec = kRadToArcsec;
+    P.b.cos_i = cos(params[0]);
+    P.b.sin_i = sin(params[0]);
+    P.b.cos_t = cos(params[1]);
+    P.b.sin_t = sin(params[1]);
+    P.b.dRA = params[2] * P.fac;
+    P.b.dDec = params[3] * P.fac;
+    P.norm = params[4];
+    P.scal = params[5];
+    P.fit_inc_pa = fit_inc_pa;
+    P.fit_phase = fit_phase;
+    const size_t nf = fun ? 2 * (size_t)n : 0, nj = jac ? 12 * (size_t)n : 0;
+    double *d_sumsq = nullptr;
+    int rc = residual_scratch(vis, nf + nj, &P.partial, &d_sumsq);
+    if (rc) return rc;
+    P.fun = fun ? vis->resid.p : nullptr;
+    P.jac = jac ? vis->resid.p + nf : nullptr;
+    hipStream_t st = nullptr;  // (the table has no context: the null stream, synchronous copies)
+    HIP_TRY(fh_launch_gauss_residual(P, d_sumsq, st));
+    if (fun) HIP_TRY(hipMemcpy(fun, P.fun, sizeof(double) * nf, hipMemcpyDeviceToHost));
+    if (jac) HIP_TRY(hipMemcpy(jac, P.jac, sizeof(double) * nj, hipMemcpyDeviceToHost));
+    double ss = 0.0;
+    HIP_TRY(hipMemcpy(&ss, d_sumsq, sizeof(double), hipMemcpyDeviceToHost));
+    if (sumsq) *sumsq = ss;
+    return FH_OK;
+}
+
 
 int fh_uvbin_create(int device, const double *uv, const double *Vre, const double *Vim, const double *w, int64_t n,
                     double bin_width, fh_uvbin **out) {

@@ -281,6 +281,28 @@ constexpr size_t fh_ln_lu_doubles(int N, int NP) {
 size_t fh_ln_smem_bytes(int N, int *lu_in_lds, int *lu_nb);
 hipError_t fh_ln_launch(const LogNormalParams &P, int nblocks, hipStream_t s);
 
+// ---- geometry fits (vis_residual.hip) ----------------------------------------------------------------------------
+// b: table columns, row range and the trial geometry as the binning pass takes them (zeros, j0_table, inv_Qmax, H2 too)
+struct VisResidualParams {
+    BinParams b;
+    const double *pref;  // norm * scale_factor[k] of the forward transform (hankel.py:201)
+    const double *I;     // brightness profile, N entries (device)
+    double scale;        // cos(inc) for the optically thick model, 1 otherwise (statistical_models.py:486-490)
+    double *out;         // [2 count]: real parts, then imaginary parts; NULL = sum of squares only
+    double *partial;     // one sum of squares per workgroup (fh_residual_max_blocks())
+};
+struct GaussResidualParams {
+    BinParams b;         // table + (cos, sin) of PA and inc in cos_t, sin_t, cos_i, sin_i; dRA, dDec in radians per wavelength
+    double norm, scal, rad_to_arcsec, fac;  // fac = 2 pi / rad_to_arcsec
+    int fit_inc_pa, fit_phase;              // which Jacobian columns are filled (geometry.py:556-577)
+    double *fun;         // [2 count] or NULL
+    double *jac;         // [2 count][6] row-major or NULL
+    double *partial;
+};
+int fh_residual_max_blocks();
+hipError_t fh_launch_vis_residual(const VisResidualParams &P, double *sumsq, hipStream_t stream);
+hipError_t fh_launch_gauss_residual(const GaussResidualParams &P, double *sumsq, hipStream_t stream);
+
 // ---- UVDataBinner (uvbin.hip) -----------------------------------------------------------------------------------
 struct UvBinParams {
     const double *uv, *w;   // baselines and weights of the rows (device)

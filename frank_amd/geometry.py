@@ -1,12 +1,21 @@
-"""Fixed source geometry (inclination, position angle, phase centre) for the MI355X frank path.
+"""Source geometry (inclination, position angle, phase centre) for the MI355X frank path.
 
-API-compatible with the fixed-geometry part of frank/geometry.py (`apply_phase_shift` :41-79, `deproject`
-:82-131, `SourceGeometry` :173-369, `FixedGeometry` :372-401).  The hot path does NOT run these NumPy
-routines: `VisibilityMapping.map_visibilities` hands the raw (u, v, V) to the GPU, where
-`deproject_kernel` (csrc/bin_gram.hip) applies the phase shift and the deprojection.  They serve callers that
-need deprojected coordinates on the host (`FrankRadialFit.predict`, user code) and carry the
-(inc, PA, dRA, dDec) that the kernels read.  Geometry *fitting* (geometry.py:404-763) is out of scope.
+API-compatible with frank/geometry.py: `apply_phase_shift` :41-79, `deproject` :82-131, `SourceGeometry` :173-369,
+`FixedGeometry` :372-401, and the two geometry fits, `FitGeometryGaussian` :404-497 and `FitGeometryFourierBessel`
+:600-763.  The hot path does NOT run the NumPy routines at the top of this file: `VisibilityMapping.map_visibilities`
+hands the raw (u, v, V) to the GPU, where the pre-pass applies the phase shift and the deprojection.  They serve callers
+that need deprojected coordinates on the host (`FrankRadialFit.predict`, user code) and carry the (inc, PA, dRA, dDec)
+that the kernels read.
+
+The geometry fits are CALLERS of the hot path: the reference hands a residual function over the whole table to
+scipy.optimize.least_squares(method='lm'), and for the non-parametric fit every evaluation of it is a binning pass, a
+solve and a prediction under a trial geometry.  Here the table is uploaded once and stays in HBM; a residual evaluation is
+fh_bin_visibilities + fh_gaussian_model + fh_vis_residuals (csrc/vis_residual.hip) under the trial geometry, or
+fh_gauss_residuals for the Gaussian; the optimiser is the same SciPy routine with the same arguments.
 """
+import ctypes
+import logging
+
 import numpy as np
 
 from frank_amd.constants import rad_to_arcsec, deg_to_rad
@@ -94,3 +103,208 @@ class FixedGeometry(SourceGeometry):
 
     def __init__(self, inc, PA, dRA=0.0, dDec=0.0):
         SourceGeometry.__init__(self, inc, PA, dRA, dDec)
+
+
+def _fix_inc_and_PA_ranges(inc, PA):
+    """Fold a fitted inclination into [0, 90] and a position angle into [0, 180) degrees (geometry.py:33-39)."""
+    inc, PA = inc % 180, PA % 180
+    return (180 - inc if inc > 90 else inc), PA
+
+
+class _ResidentTable(object):
+    """The (u, v, V, weights) of a geometry fit in HBM for as long as the optimiser runs (fh_vis_upload)."""
+
+    def __init__(self, device, u, v, V, weights):
+        from frank_amd import _lib
+        self._lib = _lib
+        V = np.asarray(V)
+        u, v = _lib.f8(u), _lib.f8(v)
+        Vre, Vim = _lib.f8(V.real), (_lib.f8(V.imag) if np.iscomplexobj(V) else None)
+        w = _lib.f8(np.atleast_1d(weights))
+        self.n = u.size
+        if v.size != self.n or Vre.size != self.n or w.size not in (1, self.n):
+            raise ValueError("u, v, V (and weights) must have matching lengths")
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.lib.fh_vis_upload(int(device), _lib.ptr(u), _lib.ptr(v), _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w),
+                                          w.size, self.n, ctypes.byref(self.handle)))
+
+    def close(self):
+        if self.handle is not None and self.handle.value:
+            self._lib.lib.fh_vis_destroy(self.handle)
+        self.handle = None
+
+    __del__ = close
+
+
+class FitGeometryGaussian(SourceGeometry):
+    """Determine the geometry by fitting a Gaussian to the visibilities in the uv-plane (geometry.py:404-497).
+
+    inc_pa = (inc, PA) [deg] and / or phase_centre = (dRA, dDec) [arcsec] fix those two instead of fitting them;
+    guess = [inc, PA, dRA, dDec] starts the fit (default 10, 10, 0, 0).  `device` (not in the reference): HIP device.
+    Residuals and the 6-column Jacobian are formed on the GPU from the resident table (fh_gauss_residuals); the
+    Levenberg-Marquardt driver is SciPy's, as in the reference.
+    """
+
+    def __init__(self, inc_pa=None, phase_centre=None, guess=None, device=None):
+        super(FitGeometryGaussian, self).__init__()
+        self._inc_pa, self._phase_centre, self._device = inc_pa, phase_centre, device
+        guess = [10.0, 10.0, 0.0, 0.0] if guess is None else list(guess)
+        guess = guess + [1.0, 1.0]  # normalisation and width of the Gaussian always start at one
+        if inc_pa is not None:
+            guess[0], guess[1] = inc_pa
+        if phase_centre is not None:
+            guess[2], guess[3] = phase_centre
+        self._guess = guess
+
+    def fit(self, u, v, V, weights):
+        if self._inc_pa and self._phase_centre:
+            logging.info('    You requested a Gaussian fit to determine the geometry, but you provided values for '
+                         'inclination, PA, and the phase offset. --> Using your provided values (not fitting for the '
+                         'geometry)')
+            self._inc, self._PA = self._inc_pa
+            self._dRA, self._dDec = self._phase_centre
+            return
+        logging.info('    Fitting Gaussian to determine geometry' +
+                     (' (not fitting for inc or PA)' if self._inc_pa else
+                      ' (not fitting for phase center)' if self._phase_centre else ''))
+        inc, PA, dRA, dDec = _fit_geometry_gaussian(u, v, V, weights, self._guess, self._inc_pa, self._phase_centre,
+                                                    device=self._device)
+        if not self._inc_pa:
+            inc, PA = _fix_inc_and_PA_ranges(inc, PA)
+        self._inc, self._PA, self._dRA, self._dDec = inc, PA, dRA, dDec
+
+
+def _fit_geometry_gaussian(u, v, V, weights, guess, inc_pa=None, phase_centre=None, device=None):
+    """(inc, PA, dRA, dDec) of the best Gaussian, `guess` = [inc, PA (deg), dRA, dDec (arcsec), norm, width]
+    (geometry.py:498-599)."""
+    from scipy.optimize import least_squares
+    from frank_amd import _lib
+    from frank_amd.hankel import default_device
+    x0 = np.array(guess, dtype=np.float64)
+    x0[:2] *= deg_to_rad
+    if inc_pa is not None:
+        x0[0], x0[1] = inc_pa[0] * deg_to_rad, inc_pa[1] * deg_to_rad
+    if phase_centre is not None:
+        x0[2], x0[3] = phase_centre
+    table = _ResidentTable(default_device() if device is None else device, u, v, V, np.broadcast_to(weights, np.shape(u)))
+    fit_ip, fit_ph = int(inc_pa is None), int(phase_centre is None)
+    pinned = x0.copy()
+
+    def params_of(x):
+        # a given pair never moves: the optimiser's value for it is ignored, as the reference's closures ignore it
+        x = np.array(x, dtype=np.float64)
+        if not fit_ip:
+            x[:2] = pinned[:2]
+        if not fit_ph:
+            x[2:4] = pinned[2:4]
+        return x
+
+    def fun(x):
+        out = np.empty(2 * table.n)
+        _lib.check(_lib.lib.fh_gauss_residuals(table.handle, _lib.ptr(params_of(x)), fit_ip, fit_ph, _lib.ptr(out), None, None))
+        return out
+
+    def jac(x):
+        out = np.empty((2 * table.n, 6))
+        _lib.check(_lib.lib.fh_gauss_residuals(table.handle, _lib.ptr(params_of(x)), fit_ip, fit_ph, None, _lib.ptr(out), None))
+        return out
+
+    try:
+        res = least_squares(fun, x0, jac=jac, method='lm')
+    finally:
+        table.close()
+    inc, PA, dRA, dDec = res.x[:4]
+    inc, PA = (inc_pa if inc_pa is not None else (inc / deg_to_rad, PA / deg_to_rad))
+    if phase_centre is not None:
+        dRA, dDec = phase_centre
+    return inc, PA, dRA, dDec
+
+
+class FitGeometryFourierBessel(SourceGeometry):
+    """Determine the geometry by minimising the chi^2 of a non-parametric (Fourier-Bessel, no prior) fit of the
+    visibilities (geometry.py:600-763): FitGeometryFourierBessel(Rmax [arcsec], N, inc_pa=None, phase_centre=None,
+    guess=None, verbose=False).  A small N keeps the prior-free fit stable.  `device` (not in the reference): HIP device.
+
+    Every evaluation of the residual is, on the resident table: one binning pass under the trial geometry, the solve
+    M I = j, and sqrt(w) (predict(u, v) - V) -- three C calls, the last one csrc/vis_residual.hip.
+    """
+
+    def __init__(self, Rmax, N, inc_pa=None, phase_centre=None, guess=None, verbose=False, device=None):
+        self._N, self._R = N, Rmax
+        self._inc_pa, self._phase_centre = inc_pa, phase_centre
+        guess = [10., 10., 0., 0.] if guess is None else guess
+        if inc_pa is not None:
+            guess[0], guess[1] = inc_pa
+        if phase_centre is not None:
+            guess[2], guess[3] = phase_centre
+        self._guess = guess
+        self._verbose = verbose
+        self._device = device
+
+    def _trial_geometry(self, params):
+        inc, pa, dRA, dDec = params
+        if self._inc_pa is not None:
+            inc, pa = self._inc_pa
+        if self._phase_centre is not None:
+            dRA, dDec = self._phase_centre
+        return FixedGeometry(inc, pa, dRA, dDec)
+
+    def _residual(self, params, uvdata=None):
+        """sqrt(w) (V_model - V), real parts then imaginary parts, of the prior-free fit under the geometry `params`
+        (geometry.py:660-694).  uvdata: (DiscreteHankelTransform, _ResidentTable)."""
+        from frank_amd import _lib
+        DHT, table = uvdata
+        geom = self._trial_geometry(params)
+        g, ctx, N, n = _lib.make_geometry(geom), DHT.context(), DHT.size, table.n
+        M, j, I = np.empty((N, N)), np.empty(N), np.empty(N)
+        H0, qmin, qmax, used_svd = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int(0)
+        thick = _lib.VIS_MODELS['opt_thick']
+        # FourierBesselFitter(R, N, geom).fit(u, v, vis, w): bin, then GaussianModel without a prior (radial_fitters.py:544-582)
+        _lib.check(_lib.lib.fh_ctx_set_scale_height(ctx, None))
+        _lib.check(_lib.lib.fh_bin_reset(ctx))
+        _lib.check(_lib.lib.fh_bin_visibilities(ctx, ctypes.byref(g), table.handle, 0, n))
+        _lib.check(_lib.lib.fh_stats_finalize(ctx, ctypes.byref(g), thick, 0, _lib.ptr(M), _lib.ptr(j), ctypes.byref(H0),
+                                              ctypes.byref(qmin), ctypes.byref(qmax)))
+        _lib.check(_lib.lib.fh_gaussian_model(ctx, _lib.ptr(M), _lib.ptr(j), None, _lib.ptr(I), None, None,
+                                              ctypes.byref(used_svd)))
+        out, ss = np.empty(2 * n), ctypes.c_double()
+        _lib.check(_lib.lib.fh_vis_residuals(ctx, ctypes.byref(g), thick, table.handle, 0, n, _lib.ptr(I), _lib.ptr(out),
+                                             ctypes.byref(ss)))
+        if self._verbose:
+            print('\n      FitGeometryFourierBessel: Iteration {}, chi^2={:.8f}, inc={:.3f} PA={:.3f} dRA={:.5f} dDec={:.5f}'
+                  ''.format(self._counter, 0.5 * ss.value / n, geom.inc, geom.PA, geom.dRA, geom.dDec), end='', flush=True)
+            self._counter += 1
+        return out
+
+    def fit(self, u, v, vis, w):
+        if self._inc_pa and self._phase_centre:
+            logging.info('    You requested a nonparametric fit to determine the geometry, but you provided values for '
+                         'inclination, PA, and the phase offset. --> Using your provided values (not fitting for the '
+                         'geometry)')
+            self._inc, self._PA = self._inc_pa
+            self._dRA, self._dDec = self._phase_centre
+            return
+        from scipy.optimize import least_squares
+        from frank_amd.hankel import DiscreteHankelTransform
+        logging.info('    Fitting nonparametric form to determine geometry' +
+                     (' (your supplied inclination and position angle will be applied at the end of the geometry '
+                      'fitting routine)' if self._inc_pa else
+                      ' (your supplied phase center will be applied at the end of the geometry fitting routine)'
+                      if self._phase_centre else ''))
+        DHT = DiscreteHankelTransform(self._R / rad_to_arcsec, self._N, device=self._device)
+        table = _ResidentTable(DHT.device, u, v, vis, np.broadcast_to(w, np.shape(u)))
+        self._counter = 0
+        try:
+            result = least_squares(self._residual, self._guess, kwargs={'uvdata': (DHT, table)}, method='lm')
+        finally:
+            table.close()
+        if not result.success:
+            raise RuntimeError("FitGeometryFourierBessel failed to converge")
+        inc, pa, dRA, dDec = result.x
+        if self._inc_pa:
+            inc, pa = self._inc_pa
+        else:
+            inc, pa = _fix_inc_and_PA_ranges(inc, pa)
+        if self._phase_centre:
+            dRA, dDec = self._phase_centre
+        self._inc, self._PA, self._dRA, self._dDec = inc, pa, dRA, dDec

@@ -279,6 +279,26 @@ int fh_fit_lognormal_batched(fh_ctx *ctx, const double *M, const double *j, int 
 int fh_posterior_update(fh_ctx *ctx, const double *map, const double *Dinv, const double *p, double alpha, double p0,
                         double wsmooth, double *p_new);
 
+/* ---- geometry fits (geometry.py:404-763): the residual functions an optimiser calls, on the resident table ---------
+ * The reference fits (inc, PA, dRA, dDec) with scipy.optimize.least_squares(method='lm') over a residual function that
+ * is evaluated on the whole table at every step.  These two entry points are those functions; the optimiser stays where it
+ * is (frank_amd.geometry hands them to the same SciPy routine).
+ *
+ * fh_vis_residuals: FitGeometryFourierBessel._residual (geometry.py:660-694) after its FBF.fit -- which is
+ *   fh_bin_reset / fh_bin_visibilities / fh_stats_finalize / fh_gaussian_model under the trial geometry --:
+ *   out[i] = sqrt(w_i) Re(Vm_i - V_i), out[count + i] = sqrt(w_i) Im(Vm_i - V_i), Vm = sol.predict(u, v)
+ *   (radial_fitters.py:56-98: deproject, H(q) I, x cos(inc) for vis_model 0 ('opt_thick'), exp(-kz^2 H2[k]) per column for
+ *   2 ('debris', fh_ctx_set_scale_height), re-phased by the phase centre).  I: N host doubles.  out (host, 2 count
+ *   doubles) and sumsq (the sum of squares of out) may each be NULL.
+ * fh_gauss_residuals: _gauss_fun / _gauss_jac of _fit_geometry_gaussian (geometry.py:535-585).  params = (inc [rad],
+ *   PA [rad], dRA [arcsec], dDec [arcsec], norm, scal) as the optimiser holds them (with a given phase centre pass it in
+ *   params[2..3] and fit_phase = 0: it is applied, its Jacobian columns are zero; fit_inc_pa = 0 zeroes columns 0, 1).
+ *   fun: 2 n host doubles (real parts, then imaginary parts) or NULL; jac: [2 n][6] row-major host doubles or NULL.   */
+int fh_vis_residuals(fh_ctx *ctx, const fh_geometry *g, int vis_model, const fh_vis *vis, int64_t first, int64_t count,
+                     const double *I, double *out, double *sumsq);
+int fh_gauss_residuals(const fh_vis *vis, const double *params, int fit_inc_pa, int fit_phase, double *fun, double *jac,
+                       double *sumsq);
+
 /* ---- utilities.UVDataBinner (utilities.py:180-400): uv-data averaged in bins of equal width ---------------------
  * fh_uvbin_create: UVDataBinner(uv, V, weights, bin_width): uv, Vre, Vim (NULL for real V), w: n host doubles.
  *   nbins = ceil(max(uv) / bin_width) (+1 under the rounding guard of :206-208); per bin the weighted means of uv

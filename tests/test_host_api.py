@@ -204,3 +204,35 @@ def test_bucket_tables_reproduce_j0(N):
             worst_mp = max(worst_mp, abs(float(mpmath.besselj(0, x) - mpmath.mpf(float(X[i, k])))))
     assert worst_mp < 2.5e-16
     _lib.lib.fh_dht_destroy(d)
+
+
+def test_geometry_fit_and_debris_classes_host_side():
+    """Signatures of frank/geometry.py:430, :643-644 and frank/debris_fitters.py:57-58, :142-146 (plus this package's
+    device=/arithmetic= keywords at the end); the range fold of geometry.py:33-39; and the call form that needs no fit."""
+    import inspect
+    from frank_amd.geometry import FitGeometryGaussian, FitGeometryFourierBessel, _fix_inc_and_PA_ranges
+    from frank_amd import debris_fitters as dfit
+
+    def names(f):
+        return list(inspect.signature(f).parameters)[1:]
+    assert names(FitGeometryGaussian.__init__)[:3] == ["inc_pa", "phase_centre", "guess"]
+    assert names(FitGeometryFourierBessel.__init__)[:6] == ["Rmax", "N", "inc_pa", "phase_centre", "guess", "verbose"]
+    assert names(dfit.FourierBesselDebrisFitter.__init__)[:8] == ["Rmax", "N", "geometry", "scale_height", "nu", "block_data",
+                                                                  "block_size", "verbose"]
+    assert names(dfit.FrankDebrisFitter.__init__)[:18] == [
+        "Rmax", "N", "geometry", "scale_height", "nu", "block_data", "block_size", "alpha", "p_0", "weights_smooth", "tol",
+        "method", "I_scale", "max_iter", "check_qbounds", "store_iteration_diagnostics", "verbose", "convergence_failure"]
+    assert _fix_inc_and_PA_ranges(190.0, 200.0) == (10.0, 20.0)
+    assert _fix_inc_and_PA_ranges(100.0, -10.0) == (80.0, 170.0)
+    assert _fix_inc_and_PA_ranges(-20.0, 180.0) == (20.0, 0.0)
+    x = np.zeros(4)
+    for g in (FitGeometryGaussian(inc_pa=(30.0, 40.0), phase_centre=(0.1, -0.2)),
+              FitGeometryFourierBessel(2.0, 20, inc_pa=(30.0, 40.0), phase_centre=(0.1, -0.2))):
+        g.fit(x, x, x, x + 1)  # both pairs given: nothing is fitted, nothing touches the device
+        assert (g.inc, g.PA, g.dRA, g.dDec) == (30.0, 40.0, 0.1, -0.2)
+        c = g.clone()
+        assert (c.inc, c.PA, c.dRA, c.dDec) == (30.0, 40.0, 0.1, -0.2)
+    # the default starting point and how given values overwrite it (geometry.py:437-447, :653-660)
+    assert FitGeometryGaussian()._guess == [10.0, 10.0, 0.0, 0.0, 1.0, 1.0]
+    assert FitGeometryGaussian(inc_pa=(5.0, 6.0), guess=[1.0, 2.0, 3.0, 4.0])._guess == [5.0, 6.0, 3.0, 4.0, 1.0, 1.0]
+    assert FitGeometryFourierBessel(2.0, 20, phase_centre=(7.0, 8.0))._guess == [10.0, 10.0, 7.0, 8.0]
