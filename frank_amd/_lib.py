@@ -58,6 +58,10 @@ SIGNATURES = {
     "fh_vis_set_multiplicity": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
     "fh_vis_residuals": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), ctypes.c_int, _vp, _i64, _i64, _dp, _dp, _dp]),
     "fh_gauss_residuals": (ctypes.c_int, [_vp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]),
+    "fh_vis_residuals_slot": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), ctypes.c_int, _vp, _dp, ctypes.c_int, _dp]),
+    "fh_residual_normal_equations": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _dp,
+                                                    _dp, _dp]),
+    "fh_gauss_normal_equations": (ctypes.c_int, [_vp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]),
     "fh_bin_reset": (ctypes.c_int, [_vp]),
     "fh_bin_visibilities": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), _vp, _i64, _i64]),
     "fh_bin_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),

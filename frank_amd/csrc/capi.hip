@@ -103,6 +103,7 @@ struct fh_vis {
     bool use_mult = false;
     unsigned long long mult_gen = 0;  // changes with every fh_vis_set_multiplicity: rows drawn zero times leave the range
     mutable DevBuf<double> resid;     // geometry fits: residuals (2 n), Jacobian (12 n), partial sums -- grown on first use
+    mutable DevBuf<double> slots;     // geometry fits on the normal equations: FH_RESIDUAL_SLOTS residual vectors of 2 n
 };
 
 struct FitSlot {
@@ -2588,10 +2589,11 @@ static int uvbin_sums(fh_uvbin *h, const double *d_uv, const double *d_w, const 
 
 // ---- geometry fits: the residual functions of geometry.py:404-763 on the resident table ---------------------------------
 static int residual_scratch(const fh_vis *vis, size_t doubles, double **partial, double **sumsq) {
-    const size_t need = doubles + (size_t)fh_residual_max_blocks() + 1;
+    const size_t nparts = (size_t)fh_residual_max_blocks() * fh_residual_sums_max();
+    const size_t need = doubles + nparts + 64;
     if (vis->resid.n < need) HIP_TRY(vis->resid.alloc(need));
     *partial = vis->resid.p + doubles;
-    *sumsq = *partial + fh_residual_max_blocks();
+    *sumsq = *partial + nparts;  // (room for the widest row of sums)
     return FH_OK;
 }
 
@@ -2678,6 +2680,123 @@ int fh_gauss_residuals(const fh_vis *vis, const double *params, int fit_inc_pa, 
     double ss = 0.0;
     HIP_TRY(hipMemcpy(&ss, d_sumsq, sizeof(double), hipMemcpyDeviceToHost));
     if (sumsq) *sumsq = ss;
+    return FH_OK;
+}
+
+
+// ---- the same fits on the normal equations: residual vectors stay on the device, only J^T J and J^T r come back ----------
+int fh_vis_residuals_slot(fh_ctx *c, const fh_geometry *g, int vis_model, const fh_vis *vis, const double *I, int slot,
+                          double *sumsq) {
+    if (!c || !g || !vis || !I) return fail(FH_ERR_INVALID, "fh_vis_residuals_slot: NULL argument");
+    if (slot < 0 || slot >= FH_RESIDUAL_SLOTS) return fail(FH_ERR_INVALID, "fh_vis_residuals_slot: slot %d of %d", slot, FH_RESIDUAL_SLOTS);
+    if (vis->device != c->device) return fail(FH_ERR_INVALID, "visibility table lives on another device");
+    if (vis_model != FH_VIS_OPT_THICK && vis_model != FH_VIS_OPT_THIN && vis_model != FH_VIS_DEBRIS)
+        return fail(FH_ERR_INVALID, "vis_model must be one of ['opt_thick', 'opt_thin', 'debris']");
+    if ((vis_model == FH_VIS_DEBRIS) != c->debris)
+        return fail(FH_ERR_INVALID, "vis_model 'debris' goes with fh_ctx_set_scale_height (and only with it)");
+    const int64_t n = vis->n;
+    if (n == 0) return fail(FH_ERR_INVALID, "fh_vis_residuals_slot: empty table");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t len = 2 * (size_t)n;
+    if (vis->slots.n < len * FH_RESIDUAL_SLOTS) HIP_TRY(vis->slots.alloc(len * FH_RESIDUAL_SLOTS));
+    const int N = c->N;
+    VisResidualParams P{};
+    table_columns(P.b, vis, 0, n);
+    P.b.dRA = g->dRA_arcsec * (2. * M_PI / kRadToArcsec);
+    P.b.dDec = g->dDec_arcsec * (2. * M_PI / kRadToArcsec);
+    const double inc = g->inc_deg * kDegToRad, PA = g->PA_deg * kDegToRad;
+    P.b.cos_t = cos(PA);
+    P.b.sin_t = sin(PA);
+    P.b.cos_i = cos(inc);
+    P.b.sin_i = sin(inc);
+    P.b.N = N;
+    P.b.inv_Qmax = 1. / c->dht->Qmax;
+    P.b.zeros = c->zeros.p;
+    P.b.j0_table = c->j0_table.p;
+    P.b.H2 = c->debris ? c->debris_H2.p : nullptr;
+    P.pref = c->pref_fwd.p;
+    P.scale = vis_model == FH_VIS_OPT_THICK ? cos(inc) : 1.0;
+    double *d_sumsq = nullptr;
+    int rc = residual_scratch(vis, 0, &P.partial, &d_sumsq);
+    if (rc) return rc;
+    P.out = vis->slots.p + len * slot;
+    if (c->scratch_I.n < (size_t)N + 1) HIP_TRY(c->scratch_I.alloc((size_t)N + 1));
+    HIP_TRY(hipMemcpyAsync(c->scratch_I.p, I, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    P.I = c->scratch_I.p;
+    HIP_TRY(fh_launch_vis_residual(P, d_sumsq, c->stream));
+    double ss = 0.0;
+    HIP_TRY(hipMemcpyAsync(&ss, d_sumsq, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (sumsq) *sumsq = ss;
+    return FH_OK;
+}
+
+int fh_residual_normal_equations(fh_ctx *c, const fh_vis *vis, int base_slot, int ncol, const int *col_slots, const double *h,
+                                 double *JtJ, double *Jtr) {
+    if (!c || !vis || !col_slots || !h || !JtJ || !Jtr || ncol < 1 || ncol > 4)
+        return fail(FH_ERR_INVALID, "fh_residual_normal_equations: bad argument");
+    const size_t len = 2 * (size_t)vis->n;
+    if (vis->slots.n < len * FH_RESIDUAL_SLOTS || len == 0)
+        return fail(FH_ERR_INVALID, "fh_residual_normal_equations: no residual vectors on the device (fh_vis_residuals_slot)");
+    HIP_TRY(hipSetDevice(c->device));
+    FdNormalParams P{};
+    if (base_slot < 0 || base_slot >= FH_RESIDUAL_SLOTS) return fail(FH_ERR_INVALID, "bad slot");
+    P.base = vis->slots.p + len * base_slot;
+    for (int k = 0; k < 4; ++k) {
+        const int sl = k < ncol ? col_slots[k] : base_slot;
+        if (sl < 0 || sl >= FH_RESIDUAL_SLOTS) return fail(FH_ERR_INVALID, "bad slot");
+        if (k < ncol && !(h[k] != 0.0)) return fail(FH_ERR_INVALID, "fh_residual_normal_equations: zero step");
+        P.col[k] = vis->slots.p + len * sl;
+        P.inv_h[k] = k < ncol ? 1.0 / h[k] : 0.0;
+    }
+    P.ncol = ncol;
+    P.len = (int64_t)len;
+    double *d_out = nullptr;
+    int rc = residual_scratch(vis, 0, &P.partial, &d_out);
+    if (rc) return rc;
+    HIP_TRY(fh_launch_fd_normal(P, d_out, c->stream));
+    double out[14];
+    HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int s = 0;
+    for (int k = 0; k < 4; ++k)
+        for (int l = k; l < 4; ++l, ++s)
+            if (l < ncol) JtJ[k * ncol + l] = JtJ[l * ncol + k] = out[s];
+    for (int k = 0; k < ncol; ++k) Jtr[k] = out[10 + k];
+    return FH_OK;
+}
+
+int fh_gauss_normal_equations(const fh_vis *vis, const double *params, int fit_inc_pa, int fit_phase, double *JtJ, double *Jtr,
+                              double *sumsq) {
+    if (!vis || !params || !JtJ || !Jtr) return fail(FH_ERR_INVALID, "fh_gauss_normal_equations: NULL argument");
+    const int64_t n = vis->n;
+    if (n == 0) return fail(FH_ERR_INVALID, "fh_gauss_normal_equations: empty table");
+    HIP_TRY(hipSetDevice(vis->device));
+    GaussResidualParams P{};
+    table_columns(P.b, vis, 0, n);
+    P.fac = 2. * M_PI / kRadToArcsec;
+    P.rad_to_arcsec = kRadToArcsec;
+    P.b.cos_i = cos(params[0]);
+    P.b.sin_i = sin(params[0]);
+    P.b.cos_t = cos(params[1]);
+    P.b.sin_t = sin(params[1]);
+    P.b.dRA = params[2] * P.fac;
+    P.b.dDec = params[3] * P.fac;
+    P.norm = params[4];
+    P.scal = params[5];
+    P.fit_inc_pa = fit_inc_pa;
+    P.fit_phase = fit_phase;
+    double *d_out = nullptr;
+    int rc = residual_scratch(vis, 0, &P.partial, &d_out);
+    if (rc) return rc;
+    HIP_TRY(fh_launch_gauss_normal(P, d_out, nullptr));
+    double out[28];
+    HIP_TRY(hipMemcpy(out, d_out, sizeof(out), hipMemcpyDeviceToHost));
+    int s = 0;
+    for (int k = 0; k < 6; ++k)
+        for (int l = k; l < 6; ++l, ++s) JtJ[k * 6 + l] = JtJ[l * 6 + k] = out[s];
+    for (int k = 0; k < 6; ++k) Jtr[k] = out[21 + k];
+    if (sumsq) *sumsq = out[27];
     return FH_OK;
 }
 

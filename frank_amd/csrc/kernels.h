@@ -299,7 +299,19 @@ struct GaussResidualParams {
     double *jac;         // [2 count][6] row-major or NULL
     double *partial;
 };
+// forward-difference normal equations from residual vectors on the device (fh_residual_normal_equations)
+struct FdNormalParams {
+    const double *base;    // r(x), len entries
+    const double *col[4];  // r(x + h_k e_k)
+    double inv_h[4];
+    int ncol;
+    int64_t len;
+    double *partial;       // [workgroups][14]
+};
 int fh_residual_max_blocks();
+int fh_residual_sums_max();  // widest row of partial sums any of these kernels writes per workgroup
+hipError_t fh_launch_fd_normal(const FdNormalParams &P, double *out14, hipStream_t stream);
+hipError_t fh_launch_gauss_normal(const GaussResidualParams &P, double *out28, hipStream_t stream);
 hipError_t fh_launch_vis_residual(const VisResidualParams &P, double *sumsq, hipStream_t stream);
 hipError_t fh_launch_gauss_residual(const GaussResidualParams &P, double *sumsq, hipStream_t stream);
 

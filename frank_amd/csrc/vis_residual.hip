@@ -141,6 +141,100 @@ __global__ __launch_bounds__(kThreads) void gauss_residual_kernel(GaussResidualP
     if (threadIdx.x == 0) P.partial[blockIdx.x] = ss;
 }
 
+
+// ---- Levenberg-Marquardt on the normal equations: J^T J, J^T r by streaming kernels, nothing of size n leaves the device ----
+// K running sums per thread -> one row of K per workgroup (wave shuffles, then the four waves through LDS)
+template <int K>
+__device__ __forceinline__ void block_sums_store(double (&acc)[K], double *row) {
+    __shared__ double redk[K][kThreads / 64];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double x = acc[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off);
+        if ((threadIdx.x & 63) == 0) redk[k][threadIdx.x >> 6] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        double r = 0.0;
+        for (int w = 0; w < kThreads / 64; ++w) r += redk[threadIdx.x][w];
+        row[threadIdx.x] = r;
+    }
+}
+
+__global__ void fold_rows_kernel(const double *partial, int nblocks, int K, double *out) {
+    const int k = threadIdx.x;
+    if (k >= K) return;
+    double a = 0.0;
+    for (int b = 0; b < nblocks; ++b) a += partial[(size_t)b * K + k];
+    out[k] = a;
+}
+
+// forward-difference Jacobian columns d_k = (r_k - r_0) / h_k of up to four parameters from residual vectors kept on the
+// device (MINPACK's fdjac2); sums: J^T J (upper triangle, row by row: 10), J^T r_0 (4)
+constexpr int kFdSums = 14;
+__global__ __launch_bounds__(kThreads) void fd_normal_kernel(FdNormalParams P) {
+    double acc[kFdSums];
+#pragma unroll
+    for (int k = 0; k < kFdSums; ++k) acc[k] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P.len; i += stride) {
+        const double r0 = P.base[i];
+        double d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = k < P.ncol ? (P.col[k][i] - r0) * P.inv_h[k] : 0.0;
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int l = k; l < 4; ++l) acc[s] = fma(d[k], d[l], acc[s]), ++s;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[10 + k] = fma(d[k], r0, acc[10 + k]);
+    }
+    block_sums_store<kFdSums>(acc, P.partial + (size_t)blockIdx.x * kFdSums);
+}
+
+// the Gaussian's residual and analytic Jacobian row by row (gauss_residual_kernel's arithmetic), summed into J^T J (upper
+// triangle, 21), J^T f (6) and f^T f (1)
+constexpr int kGaussSums = 28;
+__global__ __launch_bounds__(kThreads) void gauss_normal_kernel(GaussResidualParams P) {
+    double acc[kGaussSums];
+#pragma unroll
+    for (int k = 0; k < kGaussSums; ++k) acc[k] = 0.0;
+    const int64_t n = P.b.count, stride = (int64_t)gridDim.x * kThreads;
+    const double c_t = P.b.cos_t, s_t = P.b.sin_t, c_i = P.b.cos_i, s_i = P.b.sin_i;
+    const double sr = P.scal * P.rad_to_arcsec, inv_sr2 = 1.0 / (sr * sr);
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const VisRow r = fh_load_row(P.b, P.b.first + i);
+        const double sw = sqrt(r.w);
+        double sn, cs;
+        sincos(r.u * P.b.dRA + r.v * P.b.dDec, &sn, &cs);
+        const double Vr = r.Vre * cs + r.Vim * sn, Vi = r.Vim * cs - r.Vre * sn;
+        const double up = r.u * c_t - r.v * s_t, vp = r.u * s_t + r.v * c_t;
+        const double uv = up * up * c_i * c_i + vp * vp;
+        const double G = exp(-0.5 * uv * inv_sr2);
+        const double f[2] = {sw * (P.norm * G - Vr), -sw * Vi};
+        const double wG = sw * G, nrm = P.norm * inv_sr2;
+        const double dr = P.fit_phase ? -sw * Vi * P.fac : 0.0, di = P.fit_phase ? sw * Vr * P.fac : 0.0;
+        const double J[2][6] = {{P.fit_inc_pa ? nrm * wG * up * up * c_i * s_i : 0.0,
+                                 P.fit_inc_pa ? nrm * wG * up * vp * (c_i * c_i - 1.0) / 2.0 : 0.0, dr * r.u, dr * r.v, wG,
+                                 nrm * wG * uv / P.scal},
+                                {0.0, 0.0, di * r.u, di * r.v, 0.0, 0.0}};
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            int s = 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int l = k; l < 6; ++l) acc[s] = fma(J[part][k], J[part][l], acc[s]), ++s;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[21 + k] = fma(J[part][k], f[part], acc[21 + k]);
+            acc[27] = fma(f[part], f[part], acc[27]);
+        }
+    }
+    block_sums_store<kGaussSums>(acc, P.partial + (size_t)blockIdx.x * kGaussSums);
+}
+
 int grid_for(int64_t n, int max_blocks) {
     int64_t g = (n + kThreads - 1) / kThreads;
     if (g > max_blocks) g = max_blocks;
@@ -163,5 +257,21 @@ hipError_t fh_launch_gauss_residual(const GaussResidualParams &P, double *sumsq,
     const int grid = grid_for(P.b.count, fh_residual_max_blocks());
     hipLaunchKernelGGL(gauss_residual_kernel, dim3(grid), dim3(kThreads), 0, stream, P);
     hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(kThreads), 0, stream, P.partial, grid, sumsq);
+    return hipGetLastError();
+}
+
+int fh_residual_sums_max() { return kGaussSums; }
+
+hipError_t fh_launch_fd_normal(const FdNormalParams &P, double *out14, hipStream_t stream) {
+    const int grid = grid_for(P.len, fh_residual_max_blocks());
+    hipLaunchKernelGGL(fd_normal_kernel, dim3(grid), dim3(kThreads), 0, stream, P);
+    hipLaunchKernelGGL(fold_rows_kernel, dim3(1), dim3(64), 0, stream, P.partial, grid, kFdSums, out14);
+    return hipGetLastError();
+}
+
+hipError_t fh_launch_gauss_normal(const GaussResidualParams &P, double *out28, hipStream_t stream) {
+    const int grid = grid_for(P.b.count, fh_residual_max_blocks());
+    hipLaunchKernelGGL(gauss_normal_kernel, dim3(grid), dim3(kThreads), 0, stream, P);
+    hipLaunchKernelGGL(fold_rows_kernel, dim3(1), dim3(64), 0, stream, P.partial, grid, kGaussSums, out28);
     return hipGetLastError();
 }

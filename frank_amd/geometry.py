@@ -105,6 +105,9 @@ class FixedGeometry(SourceGeometry):
         SourceGeometry.__init__(self, inc, PA, dRA, dDec)
 
 
+_OPTIMIZERS = ('device', 'scipy')
+
+
 def _fix_inc_and_PA_ranges(inc, PA):
     """Fold a fitted inclination into [0, 90] and a position angle into [0, 180) degrees (geometry.py:33-39)."""
     inc, PA = inc % 180, PA % 180
@@ -140,14 +143,18 @@ class FitGeometryGaussian(SourceGeometry):
     """Determine the geometry by fitting a Gaussian to the visibilities in the uv-plane (geometry.py:404-497).
 
     inc_pa = (inc, PA) [deg] and / or phase_centre = (dRA, dDec) [arcsec] fix those two instead of fitting them;
-    guess = [inc, PA, dRA, dDec] starts the fit (default 10, 10, 0, 0).  `device` (not in the reference): HIP device.
-    Residuals and the 6-column Jacobian are formed on the GPU from the resident table (fh_gauss_residuals); the
-    Levenberg-Marquardt driver is SciPy's, as in the reference.
+    guess = [inc, PA, dRA, dDec] starts the fit (default 10, 10, 0, 0).  Not in the reference: `device`, the HIP device,
+    and `optimizer` -- 'device' (default): Levenberg-Marquardt on the normal equations, J^T J and J^T r summed on the GPU
+    from the resident table by one streaming kernel per step (frank_amd/_levmar.py: MINPACK's algorithm, nothing of the
+    table's size reaches the host); 'scipy': residuals and the 6-column Jacobian formed on the GPU, copied out and handed
+    to scipy.optimize.least_squares(method='lm') exactly as the reference does.
     """
 
-    def __init__(self, inc_pa=None, phase_centre=None, guess=None, device=None):
+    def __init__(self, inc_pa=None, phase_centre=None, guess=None, device=None, optimizer='device'):
         super(FitGeometryGaussian, self).__init__()
-        self._inc_pa, self._phase_centre, self._device = inc_pa, phase_centre, device
+        if optimizer not in _OPTIMIZERS:
+            raise ValueError("optimizer must be one of %r, not %r" % (_OPTIMIZERS, optimizer))
+        self._inc_pa, self._phase_centre, self._device, self._optimizer = inc_pa, phase_centre, device, optimizer
         guess = [10.0, 10.0, 0.0, 0.0] if guess is None else list(guess)
         guess = guess + [1.0, 1.0]  # normalisation and width of the Gaussian always start at one
         if inc_pa is not None:
@@ -168,13 +175,13 @@ class FitGeometryGaussian(SourceGeometry):
                      (' (not fitting for inc or PA)' if self._inc_pa else
                       ' (not fitting for phase center)' if self._phase_centre else ''))
         inc, PA, dRA, dDec = _fit_geometry_gaussian(u, v, V, weights, self._guess, self._inc_pa, self._phase_centre,
-                                                    device=self._device)
+                                                    device=self._device, optimizer=self._optimizer)
         if not self._inc_pa:
             inc, PA = _fix_inc_and_PA_ranges(inc, PA)
         self._inc, self._PA, self._dRA, self._dDec = inc, PA, dRA, dDec
 
 
-def _fit_geometry_gaussian(u, v, V, weights, guess, inc_pa=None, phase_centre=None, device=None):
+def _fit_geometry_gaussian(u, v, V, weights, guess, inc_pa=None, phase_centre=None, device=None, optimizer='device'):
     """(inc, PA, dRA, dDec) of the best Gaussian, `guess` = [inc, PA (deg), dRA, dDec (arcsec), norm, width]
     (geometry.py:498-599)."""
     from scipy.optimize import least_squares
@@ -209,11 +216,32 @@ def _fit_geometry_gaussian(u, v, V, weights, guess, inc_pa=None, phase_centre=No
         _lib.check(_lib.lib.fh_gauss_residuals(table.handle, _lib.ptr(params_of(x)), fit_ip, fit_ph, None, _lib.ptr(out), None))
         return out
 
+    def device_fit():
+        from frank_amd._levmar import levenberg_marquardt
+        free = np.array([k for k in range(6) if (k >= 4 or (k < 2 and fit_ip) or (2 <= k < 4 and fit_ph))])
+
+        def full(xf):
+            x = pinned.copy()
+            x[free] = xf
+            return x
+
+        def trial(xf):
+            ss = ctypes.c_double()
+            _lib.check(_lib.lib.fh_gauss_residuals(table.handle, _lib.ptr(full(xf)), fit_ip, fit_ph, None, None, ctypes.byref(ss)))
+            return ss.value
+
+        def normal(xf):
+            A, g = np.empty((6, 6)), np.empty(6)
+            _lib.check(_lib.lib.fh_gauss_normal_equations(table.handle, _lib.ptr(full(xf)), fit_ip, fit_ph, _lib.ptr(A), _lib.ptr(g), None))
+            return A[np.ix_(free, free)], g[free], 0
+        xf, info, _ = levenberg_marquardt(trial, lambda: None, normal, x0[free], maxfev=100 * 7)
+        return full(xf)
+
     try:
-        res = least_squares(fun, x0, jac=jac, method='lm')
+        xbest = device_fit() if optimizer == 'device' else least_squares(fun, x0, jac=jac, method='lm').x
     finally:
         table.close()
-    inc, PA, dRA, dDec = res.x[:4]
+    inc, PA, dRA, dDec = xbest[:4]
     inc, PA = (inc_pa if inc_pa is not None else (inc / deg_to_rad, PA / deg_to_rad))
     if phase_centre is not None:
         dRA, dDec = phase_centre
@@ -223,13 +251,21 @@ def _fit_geometry_gaussian(u, v, V, weights, guess, inc_pa=None, phase_centre=No
 class FitGeometryFourierBessel(SourceGeometry):
     """Determine the geometry by minimising the chi^2 of a non-parametric (Fourier-Bessel, no prior) fit of the
     visibilities (geometry.py:600-763): FitGeometryFourierBessel(Rmax [arcsec], N, inc_pa=None, phase_centre=None,
-    guess=None, verbose=False).  A small N keeps the prior-free fit stable.  `device` (not in the reference): HIP device.
+    guess=None, verbose=False).  A small N keeps the prior-free fit stable.
 
     Every evaluation of the residual is, on the resident table: one binning pass under the trial geometry, the solve
     M I = j, and sqrt(w) (predict(u, v) - V) -- three C calls, the last one csrc/vis_residual.hip.
+    Not in the reference: `device`, the HIP device, and `optimizer` -- 'device' (default): the residual vectors stay in
+    HBM and Levenberg-Marquardt runs on the normal equations of MINPACK's forward-difference Jacobian, reduced on the GPU
+    (frank_amd/_levmar.py); 'scipy': every residual vector is copied out and scipy.optimize.least_squares(method='lm')
+    drives, exactly as in the reference (at 1e7 visibilities the host-side QR of the 2e7 x 4 Jacobian is then 90 % of the
+    time).
     """
 
-    def __init__(self, Rmax, N, inc_pa=None, phase_centre=None, guess=None, verbose=False, device=None):
+    def __init__(self, Rmax, N, inc_pa=None, phase_centre=None, guess=None, verbose=False, device=None, optimizer='device'):
+        if optimizer not in _OPTIMIZERS:
+            raise ValueError("optimizer must be one of %r, not %r" % (_OPTIMIZERS, optimizer))
+        self._optimizer = optimizer
         self._N, self._R = N, Rmax
         self._inc_pa, self._phase_centre = inc_pa, phase_centre
         guess = [10., 10., 0., 0.] if guess is None else guess
@@ -249,32 +285,88 @@ class FitGeometryFourierBessel(SourceGeometry):
             dRA, dDec = self._phase_centre
         return FixedGeometry(inc, pa, dRA, dDec)
 
+    @staticmethod
+    def _profile_under(geom, DHT, table):
+        """FourierBesselFitter(R, N, geom).fit(u, v, vis, w): one binning pass, then GaussianModel without a prior
+        (radial_fitters.py:544-582).  Returns (fh_geometry, I)."""
+        from frank_amd import _lib
+        g, ctx, N = _lib.make_geometry(geom), DHT.context(), DHT.size
+        M, j, I = np.empty((N, N)), np.empty(N), np.empty(N)
+        H0, qmin, qmax, used_svd = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int(0)
+        _lib.check(_lib.lib.fh_ctx_set_scale_height(ctx, None))
+        _lib.check(_lib.lib.fh_bin_reset(ctx))
+        _lib.check(_lib.lib.fh_bin_visibilities(ctx, ctypes.byref(g), table.handle, 0, table.n))
+        _lib.check(_lib.lib.fh_stats_finalize(ctx, ctypes.byref(g), _lib.VIS_MODELS['opt_thick'], 0, _lib.ptr(M), _lib.ptr(j),
+                                              ctypes.byref(H0), ctypes.byref(qmin), ctypes.byref(qmax)))
+        _lib.check(_lib.lib.fh_gaussian_model(ctx, _lib.ptr(M), _lib.ptr(j), None, _lib.ptr(I), None, None,
+                                              ctypes.byref(used_svd)))
+        return g, I
+
+    def _report(self, sumsq, n, geom):
+        print('\n      FitGeometryFourierBessel: Iteration {}, chi^2={:.8f}, inc={:.3f} PA={:.3f} dRA={:.5f} dDec={:.5f}'
+              ''.format(self._counter, 0.5 * sumsq / n, geom.inc, geom.PA, geom.dRA, geom.dDec), end='', flush=True)
+        self._counter += 1
+
     def _residual(self, params, uvdata=None):
         """sqrt(w) (V_model - V), real parts then imaginary parts, of the prior-free fit under the geometry `params`
         (geometry.py:660-694).  uvdata: (DiscreteHankelTransform, _ResidentTable)."""
         from frank_amd import _lib
         DHT, table = uvdata
         geom = self._trial_geometry(params)
-        g, ctx, N, n = _lib.make_geometry(geom), DHT.context(), DHT.size, table.n
-        M, j, I = np.empty((N, N)), np.empty(N), np.empty(N)
-        H0, qmin, qmax, used_svd = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int(0)
-        thick = _lib.VIS_MODELS['opt_thick']
-        # FourierBesselFitter(R, N, geom).fit(u, v, vis, w): bin, then GaussianModel without a prior (radial_fitters.py:544-582)
-        _lib.check(_lib.lib.fh_ctx_set_scale_height(ctx, None))
-        _lib.check(_lib.lib.fh_bin_reset(ctx))
-        _lib.check(_lib.lib.fh_bin_visibilities(ctx, ctypes.byref(g), table.handle, 0, n))
-        _lib.check(_lib.lib.fh_stats_finalize(ctx, ctypes.byref(g), thick, 0, _lib.ptr(M), _lib.ptr(j), ctypes.byref(H0),
-                                              ctypes.byref(qmin), ctypes.byref(qmax)))
-        _lib.check(_lib.lib.fh_gaussian_model(ctx, _lib.ptr(M), _lib.ptr(j), None, _lib.ptr(I), None, None,
-                                              ctypes.byref(used_svd)))
+        n = table.n
+        g, I = self._profile_under(geom, DHT, table)
         out, ss = np.empty(2 * n), ctypes.c_double()
-        _lib.check(_lib.lib.fh_vis_residuals(ctx, ctypes.byref(g), thick, table.handle, 0, n, _lib.ptr(I), _lib.ptr(out),
-                                             ctypes.byref(ss)))
+        _lib.check(_lib.lib.fh_vis_residuals(DHT.context(), ctypes.byref(g), _lib.VIS_MODELS['opt_thick'], table.handle, 0, n,
+                                             _lib.ptr(I), _lib.ptr(out), ctypes.byref(ss)))
         if self._verbose:
-            print('\n      FitGeometryFourierBessel: Iteration {}, chi^2={:.8f}, inc={:.3f} PA={:.3f} dRA={:.5f} dDec={:.5f}'
-                  ''.format(self._counter, 0.5 * ss.value / n, geom.inc, geom.PA, geom.dRA, geom.dDec), end='', flush=True)
-            self._counter += 1
+            self._report(ss.value, n, geom)
         return out
+
+    def _fit_on_device(self, DHT, table):
+        """Levenberg-Marquardt with the residual vectors in the table's device slots: slot `base` holds r at the current
+        point, `spare` the trial point's, four more the forward-difference points'."""
+        from frank_amd import _lib
+        from frank_amd._levmar import forward_steps, levenberg_marquardt
+        free = [k for k in range(4) if (k < 2 and self._inc_pa is None) or (k >= 2 and self._phase_centre is None)]
+        x_full = np.array(self._guess, dtype=np.float64)
+        slots = {'base': 0, 'spare': 1}
+        thick = _lib.VIS_MODELS['opt_thick']
+
+        def full(xf):
+            x = x_full.copy()
+            x[free] = xf
+            return x
+
+        def evaluate(xf, slot):
+            geom = self._trial_geometry(full(xf))
+            g, I = self._profile_under(geom, DHT, table)
+            ss = ctypes.c_double()
+            _lib.check(_lib.lib.fh_vis_residuals_slot(DHT.context(), ctypes.byref(g), thick, table.handle, _lib.ptr(I), slot,
+                                                      ctypes.byref(ss)))
+            if self._verbose:
+                self._report(ss.value, table.n, geom)
+            return ss.value
+
+        def trial(xf):
+            return evaluate(xf, slots['spare'])
+
+        def accept():
+            slots['base'], slots['spare'] = slots['spare'], slots['base']
+
+        def normal(xf):
+            h = forward_steps(xf)
+            cols = (ctypes.c_int * 4)(2, 3, 4, 5)
+            for k in range(len(free)):
+                xk = np.array(xf, dtype=np.float64)
+                xk[k] += h[k]
+                evaluate(xk, cols[k])
+            A, g = np.empty((len(free), len(free))), np.empty(len(free))
+            _lib.check(_lib.lib.fh_residual_normal_equations(DHT.context(), table.handle, slots['base'], len(free), cols,
+                                                             _lib.ptr(np.ascontiguousarray(h)), _lib.ptr(A), _lib.ptr(g)))
+            return A, g, len(free)
+        # (least_squares hands MINPACK maxfev = 100 n (n + 1) with n = 4, whatever is pinned)
+        xf, info, _ = levenberg_marquardt(trial, accept, normal, x_full[free], maxfev=2000)
+        return full(xf), info in (1, 2, 3, 4)
 
     def fit(self, u, v, vis, w):
         if self._inc_pa and self._phase_centre:
@@ -295,12 +387,16 @@ class FitGeometryFourierBessel(SourceGeometry):
         table = _ResidentTable(DHT.device, u, v, vis, np.broadcast_to(w, np.shape(u)))
         self._counter = 0
         try:
-            result = least_squares(self._residual, self._guess, kwargs={'uvdata': (DHT, table)}, method='lm')
+            if self._optimizer == 'device':
+                best, success = self._fit_on_device(DHT, table)
+            else:
+                result = least_squares(self._residual, self._guess, kwargs={'uvdata': (DHT, table)}, method='lm')
+                best, success = result.x, result.success
         finally:
             table.close()
-        if not result.success:
+        if not success:
             raise RuntimeError("FitGeometryFourierBessel failed to converge")
-        inc, pa, dRA, dDec = result.x
+        inc, pa, dRA, dDec = best
         if self._inc_pa:
             inc, pa = self._inc_pa
         else:

@@ -299,6 +299,23 @@ int fh_vis_residuals(fh_ctx *ctx, const fh_geometry *g, int vis_model, const fh_
 int fh_gauss_residuals(const fh_vis *vis, const double *params, int fit_inc_pa, int fit_phase, double *fun, double *jac,
                        double *sumsq);
 
+/* The same fits with nothing of size n leaving the device: Levenberg-Marquardt needs the residual norm of a trial point and,
+ * at an accepted point, J^T J and J^T r -- a few doubles (frank_amd.geometry, optimizer='device': MINPACK's lmdif / lmder
+ * algorithm on the normal equations).  For the reference's optimiser itself use the two entry points above.
+ * fh_vis_residuals_slot: as fh_vis_residuals over the whole table, the vector written to one of FH_RESIDUAL_SLOTS device
+ *   buffers of 2 n doubles owned by the table; only its sum of squares is returned.
+ * fh_residual_normal_equations: forward-difference Jacobian columns d_k = (slot col_slots[k] - slot base_slot) / h[k],
+ *   k < ncol <= 4 (MINPACK fdjac2), reduced to JtJ [ncol x ncol] and Jtr = J^T r(base) [ncol].
+ * fh_gauss_normal_equations: JtJ [6 x 6], Jtr [6] and the sum of squares of the Gaussian's residual with its analytic
+ *   Jacobian (arguments as fh_gauss_residuals).                                                                        */
+#define FH_RESIDUAL_SLOTS 8
+int fh_vis_residuals_slot(fh_ctx *ctx, const fh_geometry *g, int vis_model, const fh_vis *vis, const double *I, int slot,
+                          double *sumsq);
+int fh_residual_normal_equations(fh_ctx *ctx, const fh_vis *vis, int base_slot, int ncol, const int *col_slots,
+                                 const double *h, double *JtJ, double *Jtr);
+int fh_gauss_normal_equations(const fh_vis *vis, const double *params, int fit_inc_pa, int fit_phase, double *JtJ, double *Jtr,
+                              double *sumsq);
+
 /* ---- utilities.UVDataBinner (utilities.py:180-400): uv-data averaged in bins of equal width ---------------------
  * fh_uvbin_create: UVDataBinner(uv, V, weights, bin_width): uv, Vre, Vim (NULL for real V), w: n host doubles.
  *   nbins = ceil(max(uv) / bin_width) (+1 under the rounding guard of :206-208); per bin the weighted means of uv

@@ -31,7 +31,7 @@ def test_fourier_bessel_residual_function(golden):
     from frank_amd.geometry import FitGeometryFourierBessel, _ResidentTable
     g = golden("geometry_fits_2e4.npz")
     u, v, V, w = table(g)
-    f = FitGeometryFourierBessel(float(g["Rmax"]), int(g["N"]))
+    f = FitGeometryFourierBessel(float(g["Rmax"]), int(g["N"]), optimizer="scipy")
     DHT = DiscreteHankelTransform(float(g["Rmax"]) / rad_to_arcsec, int(g["N"]))
     t = _ResidentTable(DHT.device, u, v, V, w)
     r = f._residual(tuple(g["trial"]), uvdata=(DHT, t))
@@ -96,11 +96,14 @@ def test_gaussian_residuals_and_jacobian():
     t.close()
 
 
+@pytest.mark.parametrize("optimizer", ["device", "scipy"])
 @pytest.mark.parametrize("tag,kw", [("free", {}), ("incpa", dict(inc_pa=(34.97, 85.76))), ("phase", dict(phase_centre=(1.9e-3, 2.5e-3)))])
-def test_geometry_fits_against_the_reference(golden, tag, kw):
+def test_geometry_fits_against_the_reference(golden, tag, kw, optimizer):
     """Both fits in the reference's three call forms, from the same starting point: the fitted (inc, PA) within 1e-4 deg and
-    (dRA, dDec) within 1e-7 arcsec of the reference's (the optimiser and its tolerances are the same SciPy routine; the
-    residuals differ in the last bits)."""
+    (dRA, dDec) within 1e-7 arcsec of the reference's -- with the reference's optimiser on residual vectors copied out
+    ('scipy': the same SciPy routine and tolerances; the residuals differ in the last bits) and with Levenberg-Marquardt on
+    the normal equations reduced on the device ('device', the default: MINPACK's algorithm and tolerances)."""
+    kw = dict(kw, optimizer=optimizer)
     from frank_amd.geometry import FitGeometryFourierBessel, FitGeometryGaussian
     g = golden("geometry_fits_2e4.npz")
     u, v, V, w = table(g)
@@ -162,4 +165,54 @@ def test_fitter_with_a_geometry_fit_and_debris_classes():
                                          _lib.ptr(out), None))
     e = np.sqrt(w) * (sol.predict(u, v) - V)
     assert np.abs(out - np.concatenate([e.real, e.imag])).max() < 1e-9 * np.abs(e).max()
+    t.close()
+
+
+def test_normal_equations_entry_points(golden):
+    """J^T J, J^T r summed on the device against the same sums of the Jacobians copied out: the Gaussian's analytic one
+    (fh_gauss_normal_equations vs fh_gauss_residuals) and the forward-difference one of residual vectors kept in slots
+    (fh_residual_normal_equations vs differences of fh_vis_residuals outputs)."""
+    from frank_amd import DiscreteHankelTransform, FixedGeometry, _lib
+    from frank_amd._levmar import forward_steps
+    from frank_amd.geometry import FitGeometryFourierBessel, _ResidentTable
+    g = golden("geometry_fits_2e4.npz")
+    u, v, V, w = table(g)
+    t = _ResidentTable(0, u, v, V, w)
+    x = np.array([0.6, 1.4, 0.003, -0.002, 0.8, 0.7])
+    for fit_ip, fit_ph in ((1, 1), (0, 1), (1, 0)):
+        fun, jac, ss = np.empty(2 * u.size), np.empty((2 * u.size, 6)), ctypes.c_double()
+        _lib.check(_lib.lib.fh_gauss_residuals(t.handle, _lib.ptr(x), fit_ip, fit_ph, _lib.ptr(fun), _lib.ptr(jac), None))
+        A, b = np.empty((6, 6)), np.empty(6)
+        _lib.check(_lib.lib.fh_gauss_normal_equations(t.handle, _lib.ptr(x), fit_ip, fit_ph, _lib.ptr(A), _lib.ptr(b), ctypes.byref(ss)))
+        JtJ, Jtf = jac.T @ jac, jac.T @ fun
+        scale = np.sqrt(np.outer(np.diag(JtJ), np.diag(JtJ))) + 1e-300
+        assert np.abs((A - JtJ) / scale).max() < 1e-12 and np.array_equal(A, A.T)
+        assert np.abs(b - Jtf).max() <= 1e-12 * np.abs(jac * fun[:, None]).sum(axis=0).max()
+        assert abs(ss.value / (fun @ fun) - 1) < 1e-13
+    DHT = DiscreteHankelTransform(float(g["Rmax"]) / rad_to_arcsec, int(g["N"]))
+    f = FitGeometryFourierBessel(float(g["Rmax"]), int(g["N"]), optimizer="scipy")
+    x4 = np.array(g["trial"])
+    h = forward_steps(x4)
+    r0 = f._residual(x4, uvdata=(DHT, t))
+    cols = []
+    for k in range(4):
+        xk = x4.copy()
+        xk[k] += h[k]
+        cols.append((f._residual(xk, uvdata=(DHT, t)) - r0) / h[k])
+    J = np.stack(cols, axis=1)
+    for slot, xk in enumerate([x4] + [x4 + h[k] * np.eye(4)[k] for k in range(4)]):
+        gg, I = f._profile_under(FixedGeometry(*xk), DHT, t)
+        _lib.check(_lib.lib.fh_vis_residuals_slot(DHT.context(), ctypes.byref(gg), 0, t.handle, _lib.ptr(I), slot + 2, None))
+    A, b = np.empty((4, 4)), np.empty(4)
+    _lib.check(_lib.lib.fh_residual_normal_equations(DHT.context(), t.handle, 2, 4, (ctypes.c_int * 4)(3, 4, 5, 6), _lib.ptr(h), _lib.ptr(A),
+                                                     _lib.ptr(b)))
+    JtJ, Jtr = J.T @ J, J.T @ r0
+    assert np.abs((A - JtJ) / np.sqrt(np.outer(np.diag(JtJ), np.diag(JtJ)))).max() < 1e-11
+    assert np.abs(b - Jtr).max() <= 1e-11 * np.abs(J * r0[:, None]).sum(axis=0).max()
+    # two free parameters only
+    A2, b2 = np.empty((2, 2)), np.empty(2)
+    _lib.check(_lib.lib.fh_residual_normal_equations(DHT.context(), t.handle, 2, 2, (ctypes.c_int * 4)(5, 6, 0, 0), _lib.ptr(h[2:]), _lib.ptr(A2),
+                                                     _lib.ptr(b2)))
+    assert np.allclose(A2, A[2:, 2:], rtol=1e-13) and np.allclose(b2, b[2:], rtol=1e-13)
+    assert _lib.lib.fh_residual_normal_equations(DHT.context(), t.handle, 2, 5, (ctypes.c_int * 4)(3, 4, 5, 6), _lib.ptr(h), _lib.ptr(A), _lib.ptr(b)) != 0
     t.close()
