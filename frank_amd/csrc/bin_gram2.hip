@@ -819,6 +819,12 @@ hipError_t fh_k1v2_launch_max(const double *q, int64_t n, double *out, hipStream
     hipLaunchKernelGGL(max_abs_kernel, dim3(1), dim3(1024), 0, stream, q, n, out);
     return hipGetLastError();
 }
+hipError_t fh_k1v2_launch_predict_coef(const double *table, int XS, int N, int nb, const double *pref, const double *I, double scale,
+                                       double *coef, hipStream_t stream) {
+    hipLaunchKernelGGL(predict_bucket_coef_kernel, dim3((nb * kTerms + 3) / 4), dim3(256), 0, stream, table, XS, N, nb, pref, I,
+                       scale, coef);
+    return hipGetLastError();
+}
 hipError_t fh_k1v2_launch_predict(const double *table, int XS, int N, int nb, const double *pref, const double *I, double scale,
                                   double *coef, const double *q, int64_t n, double inv_Q, double delta, double *V,
                                   hipStream_t stream) {

@@ -2597,6 +2597,26 @@ static int residual_scratch(const fh_vis *vis, size_t doubles, double **partial,
     return FH_OK;
 }
 
+// The model visibilities of a residual pass through the bucket tables, when the binning pass of exactly these rows under
+// exactly this geometry came before (the geometry fits: bin, solve, residuals) -- its baseline range, and with it the tables,
+// are then in place.  Anything else (another table or range, the debris model, the first kernel generation) keeps the N Bessel
+// evaluations per row.  I_dev: the profile on the device.
+static int residual_through_tables(fh_ctx *c, const fh_vis *vis, VisResidualParams &P, const double *I_dev) {
+    const double gkey[6] = {P.b.dRA, P.b.dDec, P.b.cos_t, P.b.sin_t, P.b.cos_i, P.b.sin_i};
+    const bool known = c->v2 && !c->debris && !vis->use_mult && c->range_valid && c->range_vis == vis->serial &&
+                       c->range_first == P.b.first && c->range_count == P.b.count &&
+                       memcmp(gkey, c->range_geom, sizeof gkey) == 0 && !getenv("FRANK_AMD_RESIDUAL_DIRECT");
+    if (!known) return FH_OK;
+    const double smax = c->prepass_qmax_all * P.b.inv_Qmax;
+    const int nb = (int)(smax / c->k1_delta) + 2;
+    if (!(smax == smax) || nb > 16000 || nb > c->k1_nb_built) return FH_OK;
+    if (c->predict_coef.n < (size_t)c->k1_nb_built * FH_K1_TERMS) HIP_TRY(c->predict_coef.alloc((size_t)c->k1_nb_built * FH_K1_TERMS));
+    HIP_TRY(fh_k1v2_launch_predict_coef(c->k1_table.p, c->XS, c->N, nb, c->pref_fwd.p, I_dev, P.scale, c->predict_coef.p, c->stream));
+    P.coef = c->predict_coef.p;
+    P.nb = nb;
+    return FH_OK;
+}
+
 int fh_vis_residuals(fh_ctx *c, const fh_geometry *g, int vis_model, const fh_vis *vis, int64_t first, int64_t count,
                      const double *I, double *out, double *sumsq) {
     if (!c || !g || !vis || !I) return fail(FH_ERR_INVALID, "fh_vis_residuals: NULL argument");
@@ -2635,6 +2655,9 @@ int fh_vis_residuals(fh_ctx *c, const fh_geometry *g, int vis_model, const fh_vi
     if (c->scratch_I.n < (size_t)N + 1) HIP_TRY(c->scratch_I.alloc((size_t)N + 1));
     HIP_TRY(hipMemcpyAsync(c->scratch_I.p, I, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
     P.I = c->scratch_I.p;
+    P.delta = c->k1_delta > 0 ? c->k1_delta : 1.0;
+    rc = residual_through_tables(c, vis, P, P.I);
+    if (rc) return rc;
     HIP_TRY(fh_launch_vis_residual(P, d_sumsq, c->stream));
     if (out) HIP_TRY(hipMemcpyAsync(out, vis->resid.p, sizeof(double) * 2 * (size_t)count, hipMemcpyDeviceToHost, c->stream));
     double ss = 0.0;
@@ -2723,6 +2746,9 @@ int fh_vis_residuals_slot(fh_ctx *c, const fh_geometry *g, int vis_model, const 
     if (c->scratch_I.n < (size_t)N + 1) HIP_TRY(c->scratch_I.alloc((size_t)N + 1));
     HIP_TRY(hipMemcpyAsync(c->scratch_I.p, I, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
     P.I = c->scratch_I.p;
+    P.delta = c->k1_delta > 0 ? c->k1_delta : 1.0;
+    rc = residual_through_tables(c, vis, P, P.I);
+    if (rc) return rc;
     HIP_TRY(fh_launch_vis_residual(P, d_sumsq, c->stream));
     double ss = 0.0;
     HIP_TRY(hipMemcpyAsync(&ss, d_sumsq, sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -136,6 +136,8 @@ hipError_t fh_prepass_launch(const PrepassParams &P, hipStream_t stream);       
 int fh_k1v2_moment_doubles();
 hipError_t fh_k1v2_launch_compress(const CompressParams &cp, hipStream_t stream);
 hipError_t fh_k1v2_launch_max(const double *q, int64_t n, double *out, hipStream_t stream);
+hipError_t fh_k1v2_launch_predict_coef(const double *table, int XS, int N, int nb, const double *pref, const double *I, double scale,
+                                       double *coef, hipStream_t stream);
 hipError_t fh_k1v2_launch_predict(const double *table, int XS, int N, int nb, const double *pref, const double *I, double scale,
                                   double *coef, const double *q, int64_t n, double inv_Q, double delta, double *V,
                                   hipStream_t stream);
@@ -290,6 +292,11 @@ struct VisResidualParams {
     double scale;        // cos(inc) for the optically thick model, 1 otherwise (statistical_models.py:486-490)
     double *out;         // [2 count]: real parts, then imaginary parts; NULL = sum of squares only
     double *partial;     // one sum of squares per workgroup (fh_residual_max_blocks())
+    // through the bucket tables of the binning pass (bin_gram2.hip, predict_bucket_coef_kernel): [nb][FH_K1_TERMS] Taylor
+    // coefficients of V(s) per bucket of s = q / Qmax; NULL = N Bessel evaluations per row
+    const double *coef;
+    int nb;
+    double delta;
 };
 struct GaussResidualParams {
     BinParams b;         // table + (cos, sin) of PA and inc in cos_t, sin_t, cos_i, sin_i; dRA, dDec in radians per wavelength

@@ -14,6 +14,7 @@
 
 #include "bessel.h"
 #include "deproject.h"
+#include "j0_buckets.h"
 #include "kernels.h"
 
 namespace {
@@ -31,27 +32,41 @@ __device__ __forceinline__ double block_sum(double x, double *red) {
     return r;
 }
 
+// TABLES: the model visibility of a row is a degree-11 polynomial in the offset of s = q / Qmax inside its bucket (the tables
+// the binning pass of the same rows has built, contracted with the profile: 12 numbers per bucket) instead of N Bessel
+// evaluations -- the pass is then bound by the 40 B read and 16 B written per row.
+template <bool TABLES>
 __global__ __launch_bounds__(kThreads) void vis_residual_kernel(VisResidualParams P) {
     extern __shared__ double lds[];
     double *tab = lds, *zk = tab + FH_J0_TABLE_DOUBLES, *ck = zk + P.b.N, *Ik = ck + P.b.N, *h2 = Ik + P.b.N;
     __shared__ double red[kThreads / 64];
     const int N = P.b.N;
-    for (int i = threadIdx.x; i < FH_J0_TABLE_DOUBLES; i += kThreads) tab[i] = P.b.j0_table[i];
-    for (int k = threadIdx.x; k < N; k += kThreads) {
-        zk[k] = P.b.zeros[k];
-        // H[i, k] = (pref_k J0) * scale, V = H . I  (hankel.py:201-202, statistical_models.py:486-496, :326-328)
-        ck[k] = P.pref[k];
-        Ik[k] = P.I[k];
-        if (P.b.H2) h2[k] = P.b.H2[k];
+    if (!TABLES) {
+        for (int i = threadIdx.x; i < FH_J0_TABLE_DOUBLES; i += kThreads) tab[i] = P.b.j0_table[i];
+        for (int k = threadIdx.x; k < N; k += kThreads) {
+            zk[k] = P.b.zeros[k];
+            // H[i, k] = (pref_k J0) * scale, V = H . I  (hankel.py:201-202, statistical_models.py:486-496, :326-328)
+            ck[k] = P.pref[k];
+            Ik[k] = P.I[k];
+            if (P.b.H2) h2[k] = P.b.H2[k];
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    const double inv_delta = 1.0 / P.delta, inv_half = 2.0 * inv_delta;
     double ss = 0.0;
     const int64_t stride = (int64_t)gridDim.x * kThreads;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P.b.count; i += stride) {
         const VisRow r = fh_load_row(P.b, P.b.first + i);
         const double s = fh_deproject_q(P.b, r.u, r.v) * P.b.inv_Qmax;
         double a = 0.0;
-        if (P.b.H2) {
+        if (TABLES) {
+            const int b = fh_bucket_of(s, inv_delta, P.nb);
+            const double tau = fh_bucket_tau(s, b, P.delta, inv_half);
+            const double *c = P.coef + (size_t)b * FH_K1_TERMS;
+            a = c[FH_K1_TERMS - 1];
+#pragma unroll
+            for (int m = FH_K1_TERMS - 2; m >= 0; --m) a = fma(a, tau, c[m]);
+        } else if (P.b.H2) {
             const double kz2 = fh_deproject_kz2(P.b, r.u, r.v);
             for (int k = 0; k < N; ++k) {
                 const double h = (ck[k] * fh_j0(s * zk[k], tab)) * exp(-kz2 * h2[k]);
@@ -248,7 +263,10 @@ int fh_residual_max_blocks() { return 2048; }  // 8 workgroups per compute unit
 hipError_t fh_launch_vis_residual(const VisResidualParams &P, double *sumsq, hipStream_t stream) {
     const int grid = grid_for(P.b.count, fh_residual_max_blocks());
     const size_t lds = sizeof(double) * (FH_J0_TABLE_DOUBLES + 4 * (size_t)P.b.N);
-    hipLaunchKernelGGL(vis_residual_kernel, dim3(grid), dim3(kThreads), lds, stream, P);
+    if (P.coef)
+        hipLaunchKernelGGL(vis_residual_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, P);
+    else
+        hipLaunchKernelGGL(vis_residual_kernel<false>, dim3(grid), dim3(kThreads), lds, stream, P);
     hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(kThreads), 0, stream, P.partial, grid, sumsq);
     return hipGetLastError();
 }

@@ -39,6 +39,14 @@ def test_fourier_bessel_residual_function(golden):
     assert r.shape == (2 * u.size,)
     assert np.abs(r[::8] - ref).max() < 1e-9 * np.abs(ref).max()
     assert abs(np.sum(r * r) / float(g["resid_sumsq"]) - 1) < 1e-10
+    # (that went through the bucket tables of the binning pass before it; the same with N Bessel evaluations per row)
+    import os
+    os.environ["FRANK_AMD_RESIDUAL_DIRECT"] = "1"
+    try:
+        rd = f._residual(tuple(g["trial"]), uvdata=(DHT, t))
+    finally:
+        del os.environ["FRANK_AMD_RESIDUAL_DIRECT"]
+    assert 0 < np.abs(r - rd).max() < 1e-11 * np.abs(ref).max()
     # the same function through the classes a user would combine by hand (FourierBesselFitter.fit + sol.predict)
     from frank_amd import FixedGeometry, FourierBesselFitter
     geom = FixedGeometry(*g["trial"])
