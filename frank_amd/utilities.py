@@ -155,3 +155,84 @@ def estimate_weights(u, v=None, V=None, nbins=300, log=True, use_median=False, v
     bin_id = uvBin.determine_uv_bin(q)
     assert np.all(bin_id != -1), "Error in binning"
     return 1 / var[bin_id]
+
+
+# ---- callers of the transform: mock data and direct transforms (utilities.py:634-666, 923-1146) ----------------------
+def draw_bootstrap_sample(u, v, vis, weights):
+    """One bootstrap resample of the data set: len(u) rows drawn with replacement (utilities.py:634-666; the global NumPy
+    generator, one randint call).  `frank_amd.bootstrap.bootstrap_fits` draws the same indices but keeps the table on the
+    device and hands the kernel row multiplicities instead of gathered copies."""
+    pick = np.random.randint(low=0, high=len(u), size=len(u))
+    return u[pick], v[pick], vis[pick], weights[pick]
+
+
+def add_vis_noise(vis, weights, seed=None):
+    """Visibilities plus Gaussian noise of standard deviation weights**-0.5, independently on the real and (for complex
+    input) imaginary parts (utilities.py:923-959).  The draws come from the global NumPy generator in the reference's
+    order -- one standard_normal((1 or 2,) + vis.shape) call after the optional np.random.seed(seed) -- so a seeded call
+    returns the reference's numbers."""
+    if seed is not None:
+        np.random.seed(seed)
+    vis = np.array(vis)
+    parts = 2 if np.iscomplexobj(vis) else 1
+    draws = np.random.standard_normal((parts,) + vis.shape)
+    draws *= weights ** -0.5
+    noisy = vis + draws[0]
+    if parts == 2:
+        noisy += 1j * draws[1]
+    return noisy
+
+
+def get_collocation_points(Rmax=2.0, N=500, direction='forward'):
+    """Collocation points of the transform for (Rmax [arcsec], N): radii in arcsec ('forward') or spatial frequencies in
+    lambda ('backward') (utilities.py:1041-1074)."""
+    if direction not in ['forward', 'backward']:
+        raise AttributeError("direction must be one of ['forward', 'backward']")
+    from frank_amd.constants import rad_to_arcsec
+    from frank_amd.hankel import DiscreteHankelTransform
+    r_pts, q_pts = DiscreteHankelTransform.get_collocation_points(Rmax=Rmax / rad_to_arcsec, N=N, nu=0)
+    return r_pts * rad_to_arcsec if direction == 'forward' else q_pts
+
+
+def generic_dht(x, f, Rmax=2.0, N=500, direction='forward', grid=None, inc=0.0):
+    """Visibilities of a brightness profile f(x [arcsec]) ('forward') or the profile of visibilities f(x [lambda])
+    ('backward') by the discrete Hankel transform, sampled at `grid` (default: the collocation points) and scaled by
+    cos(inc) as an optically thick disc (utilities.py:1077-1146).  f is interpolated linearly onto the collocation points;
+    the transform itself runs on the GPU (VisibilityMapping.predict_visibilities / invert_visibilities).
+    Returns (grid, transform)."""
+    if direction not in ['forward', 'backward']:
+        raise AttributeError("direction must be one of ['forward', 'backward']")
+    from frank_amd.constants import rad_to_arcsec
+    from frank_amd.geometry import FixedGeometry
+    from frank_amd.hankel import DiscreteHankelTransform
+    from frank_amd.statistical_models import VisibilityMapping
+    face_on = FixedGeometry(inc, 0, 0, 0)
+    VM = VisibilityMapping(DiscreteHankelTransform(Rmax=Rmax / rad_to_arcsec, N=N, nu=0), face_on)
+    if direction == 'forward':
+        grid = VM.q if grid is None else grid
+        return grid, VM.predict_visibilities(np.interp(VM.r, x, f), grid, geometry=face_on)
+    grid = VM.r if grid is None else grid
+    return grid, VM.invert_visibilities(np.interp(VM.q, x, f), grid, geometry=face_on)
+
+
+def make_mock_data(r, I, Rmax, u, v, projection=None, geometry=None, N=500, add_noise=False, weights=None, seed=None):
+    """Mock visibilities of a profile I(r [arcsec]) at the baselines (u, v) (utilities.py:962-1038): optionally
+    deproject / reproject the baselines with `geometry` (whose inclination then scales the flux), transform with
+    generic_dht, optionally add noise for the given weights.  Returns (baselines, vis)."""
+    allowed = [None, 'deproject', 'reproject']
+    if projection not in allowed:
+        raise AttributeError(f"projection is '{projection}'; must be one of {allowed}.")
+    from frank_amd.geometry import FixedGeometry
+    if projection is None:
+        if geometry is not None:
+            raise AttributeError("projection is None; must be one of ['deproject', 'reproject'] to perform projection.")
+        geometry = FixedGeometry(0, 0, 0, 0)
+    else:
+        if geometry is None:
+            raise AttributeError(f"geometry must be supplied to perform {projection}.")
+        u, v = geometry.deproject(u, v) if projection == 'deproject' else geometry.reproject(u, v)
+    baselines = np.hypot(u, v)
+    _, vis = generic_dht(r, I, Rmax, N, grid=baselines, inc=geometry.inc)
+    if add_noise:
+        vis = add_vis_noise(vis, weights, seed)
+    return baselines, vis

@@ -224,3 +224,47 @@ def test_normal_equations_entry_points(golden):
     assert np.allclose(A2, A[2:, 2:], rtol=1e-13) and np.allclose(b2, b[2:], rtol=1e-13)
     assert _lib.lib.fh_residual_normal_equations(DHT.context(), t.handle, 2, 5, (ctypes.c_int * 4)(3, 4, 5, 6), _lib.ptr(h), _lib.ptr(A), _lib.ptr(b)) != 0
     t.close()
+
+
+def test_mock_data_helpers_against_the_reference(golden):
+    """utilities.generic_dht / make_mock_data / add_vis_noise / get_collocation_points / draw_bootstrap_sample
+    (utilities.py:634-666, 923-1146) on the reference's inputs: transforms to 1e-12 of the largest value, the seeded noise
+    draws and the collocation points exactly."""
+    from frank_amd import FixedGeometry
+    from frank_amd.utilities import (add_vis_noise, draw_bootstrap_sample, generic_dht, get_collocation_points,
+                                     make_mock_data)
+    g = golden("mockdata_helpers.npz")
+    r, I, u, v, w, N = g["r"], g["I"], g["u"], g["v"], g["w"], int(g["N"])
+
+    def close(a, b, tol=1e-12):
+        return np.abs(a - b).max() <= tol * np.abs(b).max()
+    grid, f = generic_dht(r, I, 2.0, N)
+    assert np.array_equal(grid, g["fwd_grid"]) and close(f, g["fwd"])
+    q = np.hypot(u, v)
+    assert close(generic_dht(r, I, 2.0, N, grid=q, inc=40.0)[1], g["fwd_on_q"])
+    grid, b = generic_dht(g["fwd_grid"], g["fwd"], 2.0, N, direction="backward")
+    assert np.array_equal(grid, g["bwd_grid"]) and close(b, g["bwd"], 1e-11)
+    assert close(generic_dht(g["fwd_grid"], g["fwd"], 2.0, N, direction="backward", grid=g["rr"], inc=40.0)[1], g["bwd_on_r"], 1e-11)
+    with pytest.raises(AttributeError):
+        generic_dht(r, I, direction="sideways")
+    qq, V = make_mock_data(r, I, 2.0, u, v, N=N)
+    assert np.array_equal(qq, g["mock_plain_q"]) and close(V, g["mock_plain"])
+    geom = FixedGeometry(40.0, 70.0, 0.0, 0.0)
+    qq, V = make_mock_data(r, I, 2.0, u, v, projection="deproject", geometry=geom, N=N, add_noise=True, weights=w, seed=17)
+    assert close(qq, g["mock_deproj_q"], 1e-15) and close(V, g["mock_deproj"])
+    qq, V = make_mock_data(r, I, 2.0, u, v, projection="reproject", geometry=geom, N=N)
+    assert close(qq, g["mock_reproj_q"], 1e-15) and close(V, g["mock_reproj"])
+    for bad in (dict(projection="sideways"), dict(projection="deproject"), dict(geometry=geom)):
+        with pytest.raises(AttributeError):
+            make_mock_data(r, I, 2.0, u, v, N=N, **bad)
+    assert np.array_equal(add_vis_noise(g["noise_complex_in"], w, seed=5), g["noise_complex"])
+    assert np.array_equal(add_vis_noise(g["mock_plain"], w, seed=5), g["noise_real"])
+    assert np.array_equal(get_collocation_points(2.0, N), g["coll_r"])
+    assert np.array_equal(get_collocation_points(2.0, N, direction="backward"), g["coll_q"])
+    with pytest.raises(AttributeError):
+        get_collocation_points(direction="sideways")
+    np.random.seed(3)
+    ub, vb, Vb, wb = draw_bootstrap_sample(u, v, V, w)
+    np.random.seed(3)
+    pick = np.random.randint(low=0, high=len(u), size=len(u))
+    assert np.array_equal(ub, u[pick]) and np.array_equal(wb, w[pick]) and np.array_equal(Vb, V[pick])
