@@ -236,3 +236,55 @@ def test_geometry_fit_and_debris_classes_host_side():
     assert FitGeometryGaussian()._guess == [10.0, 10.0, 0.0, 0.0, 1.0, 1.0]
     assert FitGeometryGaussian(inc_pa=(5.0, 6.0), guess=[1.0, 2.0, 3.0, 4.0])._guess == [5.0, 6.0, 3.0, 4.0, 1.0, 1.0]
     assert FitGeometryFourierBessel(2.0, 20, phase_centre=(7.0, 8.0))._guess == [10.0, 10.0, 7.0, 8.0]
+
+
+def test_levenberg_marquardt_on_normal_equations_follows_minpack():
+    """frank_amd/_levmar.py against scipy.optimize.least_squares(method='lm') (MINPACK lmdif) on dense problems where the
+    Jacobian can be formed on the host: same minimiser to 1e-9, same number of residual evaluations on the well-conditioned
+    one; parameters of very different sizes; a zero residual; a start at the minimum."""
+    from scipy.optimize import least_squares
+    from frank_amd._levmar import forward_steps, levenberg_marquardt
+
+    def run(r, x0):
+        state = {}
+
+        def trial(x):
+            state["t"] = r(x)
+            return float(state["t"] @ state["t"])
+
+        def accept():
+            state["b"] = state["t"]
+
+        def normal(x):
+            h = forward_steps(x)
+            J = np.stack([(r(x + h[k] * np.eye(x.size)[k]) - state["b"]) / h[k] for k in range(x.size)], axis=1)
+            return J.T @ J, J.T @ state["b"], x.size
+        return levenberg_marquardt(trial, accept, normal, x0)
+
+    rng = np.random.default_rng(0)
+    t = np.linspace(0, 4, 400)
+
+    def model(x):
+        return x[0] * np.exp(-x[1] * t) + x[2] * np.sin(x[3] * t)
+    y = model([2.0, 1.3, 0.5, 3.0]) + 0.01 * rng.normal(size=t.size)
+    x, info, nfev = run(lambda x: model(x) - y, [1.0, 1.0, 1.0, 2.5])
+    ref = least_squares(lambda x: model(x) - y, [1.0, 1.0, 1.0, 2.5], method="lm")
+    assert info in (1, 2, 3) and np.abs(x - ref.x).max() < 1e-9 and nfev == ref.nfev
+    # parameters 1e4 apart in size, as an inclination in degrees and a phase centre in arcsec are
+
+    def model2(x):
+        return np.exp(-0.5 * (t - x[0] / 10.0) ** 2) * np.cos(40.0 * x[1] * t) * x[2]
+    y2 = model2([20.0, 2e-3, 1.5])
+    x, info, _ = run(lambda x: model2(x) - y2 + 1e-3 * np.sin(7 * t), [19.0, 1.8e-3, 1.2])
+    ref = least_squares(lambda x: model2(x) - y2 + 1e-3 * np.sin(7 * t), [19.0, 1.8e-3, 1.2], method="lm")
+    assert ref.status > 0 and info in (1, 2, 3, 4) and np.abs((x - ref.x) / ref.x).max() < 1e-6
+    # ... and from a start where MINPACK itself runs out of evaluations in a valley: the same count, the same point
+    x, info, nfev = run(lambda x: model2(x) - y2 + 1e-3 * np.sin(7 * t), [15.0, 1e-3, 1.0])
+    ref = least_squares(lambda x: model2(x) - y2 + 1e-3 * np.sin(7 * t), [15.0, 1e-3, 1.0], method="lm")
+    assert ref.status == 0 and info == 5 and nfev == ref.nfev and np.abs((x - ref.x) / ref.x).max() < 1e-3
+    # an exact fit (zero residual at the minimum) and a start at the minimum
+    x, info, _ = run(lambda x: model(x) - model([2.0, 1.3, 0.5, 3.0]), [1.8, 1.2, 0.6, 2.9])
+    assert info in (1, 2, 3, 4) and np.abs(x - [2.0, 1.3, 0.5, 3.0]).max() < 1e-7
+    x, info, _ = run(lambda x: model(x) - y, ref.x if ref.x.size == 4 else x)
+    assert info in (1, 2, 3, 4)
+    assert np.array_equal(forward_steps(np.array([0.0, -2.0])), np.sqrt(np.finfo(float).eps) * np.array([1.0, 2.0]))
