@@ -489,6 +489,11 @@ def extras(f, L, a):
             x, ok = fg._fit_on_device(dht, Resident)
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
+        # the reference's own driver on the same residual function (vectors copied out, MINPACK's QR on the host)
+        from scipy.optimize import least_squares
+        t0 = time.perf_counter()
+        sp = least_squares(fg._residual, [30.0, 80.0, 0.0, 0.0], kwargs={"uvdata": (dht, Resident)}, method="lm")
+        t_scipy = time.perf_counter() - t0
         g20, I20 = fg._profile_under(fg._trial_geometry(x), dht, Resident)
         ss = ctypes.c_double()
         ts = []
@@ -500,7 +505,12 @@ def extras(f, L, a):
         ex["geometry_fit"] = {"workload": "FitGeometryFourierBessel(Rmax=%g, N=20) of the %d resident visibilities, started at "
                                           "(30, 80, 0, 0); Levenberg-Marquardt on device-reduced normal equations" % (RMAX_ARCSEC, f.n),
                               "s_per_fit": best, "converged": bool(ok), "inc_PA_dRA_dDec": [float(t) for t in x],
-                              "truth": [MOCK_GEOMETRY[k] for k in ("inc", "PA", "dRA", "dDec")],
+                              "scipy_driver": {"s_per_fit": t_scipy, "inc_PA_dRA_dDec": [float(t) for t in sp.x],
+                                               "residual_evaluations": int(sp.nfev),
+                                               "max_abs_diff": float(np.abs(np.asarray(x) - sp.x).max())},
+                              "note": "the table was made with " + repr([MOCK_GEOMETRY[k] for k in ("inc", "PA", "dRA", "dDec")]) +
+                                      "; 20 collocation points reach q = %.2e against baselines to 2e6, hence the bias -- the "
+                                      "reference's, both drivers land on it" % dht.q[-1],
                               "residual_pass_ms_wall": 1e3 * min(ts),
                               "roofline_residual_pass": {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s",
                                                          "frac": gbps / 8000.0, "algorithmic_bytes_per_row": 40,

@@ -177,12 +177,14 @@ __device__ __forceinline__ void block_sums_store(double (&acc)[K], double *row) 
     }
 }
 
-__global__ void fold_rows_kernel(const double *partial, int nblocks, int K, double *out) {
-    const int k = threadIdx.x;
-    if (k >= K) return;
+// column k of the [nblocks][K] partial sums, one workgroup per column (a fixed tree: run-to-run identical)
+__global__ __launch_bounds__(kThreads) void fold_rows_kernel(const double *partial, int nblocks, int K, double *out) {
+    __shared__ double red[kThreads / 64];
+    const int k = blockIdx.x;
     double a = 0.0;
-    for (int b = 0; b < nblocks; ++b) a += partial[(size_t)b * K + k];
-    out[k] = a;
+    for (int b = threadIdx.x; b < nblocks; b += kThreads) a += partial[(size_t)b * K + k];
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) out[k] = a;
 }
 
 // forward-difference Jacobian columns d_k = (r_k - r_0) / h_k of up to four parameters from residual vectors kept on the
@@ -283,13 +285,13 @@ int fh_residual_sums_max() { return kGaussSums; }
 hipError_t fh_launch_fd_normal(const FdNormalParams &P, double *out14, hipStream_t stream) {
     const int grid = grid_for(P.len, fh_residual_max_blocks());
     hipLaunchKernelGGL(fd_normal_kernel, dim3(grid), dim3(kThreads), 0, stream, P);
-    hipLaunchKernelGGL(fold_rows_kernel, dim3(1), dim3(64), 0, stream, P.partial, grid, kFdSums, out14);
+    hipLaunchKernelGGL(fold_rows_kernel, dim3(kFdSums), dim3(kThreads), 0, stream, P.partial, grid, kFdSums, out14);
     return hipGetLastError();
 }
 
 hipError_t fh_launch_gauss_normal(const GaussResidualParams &P, double *out28, hipStream_t stream) {
     const int grid = grid_for(P.b.count, fh_residual_max_blocks());
     hipLaunchKernelGGL(gauss_normal_kernel, dim3(grid), dim3(kThreads), 0, stream, P);
-    hipLaunchKernelGGL(fold_rows_kernel, dim3(1), dim3(64), 0, stream, P.partial, grid, kGaussSums, out28);
+    hipLaunchKernelGGL(fold_rows_kernel, dim3(kGaussSums), dim3(kThreads), 0, stream, P.partial, grid, kGaussSums, out28);
     return hipGetLastError();
 }
