@@ -109,7 +109,9 @@ __global__ __launch_bounds__(kThreads) void fold_partials_kernel(const double *p
 
 // f = sqrt(w) (norm exp(-(u'^2 + v'^2) / 2) - V'), u' = (u cos PA - v sin PA) cos inc / (scal rad_to_arcsec),
 // v' = (u sin PA + v cos PA) / (scal rad_to_arcsec), V' = V exp(-i phi)  (geometry.py:535-551); the Jacobian columns of
-// :553-585 in the order (inc, PA, dRA, dDec, norm, scal), row-major [2n][6] as least_squares takes it.
+// :553-585 in the order (inc, PA, dRA, dDec, norm, scal), row-major [2n][6] as least_squares takes it.  (The PA column is the
+// reference's, which is half the derivative -- the "/ 2" of geometry.py:572; kept, so that the optimiser takes the reference's
+// steps: a scaled column moves the path, not the point where J^T f = 0.)
 __global__ __launch_bounds__(kThreads) void gauss_residual_kernel(GaussResidualParams P) {
     __shared__ double red[kThreads / 64];
     double ss = 0.0;

@@ -266,3 +266,51 @@ def uvbin_build(uv, V, w, bin_width):
                          cnt.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _p(ere), _p(eim))
     return dict(nbins=nb, uv=buv, V=(bre + 1j * bim) if cplx else bre, w=bw, count=cnt,
                 err=(ere + 1j * eim) if cplx else ere)
+
+
+# ---- geometry fits: the residual functions the optimiser sees (geometry.py:404-763) --------------------------------------
+def fourier_bessel_residual(N, Rmax, geom, u, v, V, w):
+    """FitGeometryFourierBessel._residual (geometry.py:660-694): the prior-free fit under `geom` = (inc, PA [deg], dRA,
+    dDec [arcsec]) -- map_visibilities, M I = j -- then w**0.5 * (sol.predict(u, v) - V), real parts before imaginary
+    parts.  predict (radial_fitters.py:56-98): deproject, H(q) I cos(inc), rotate by the phase centre.  Rmax in radians."""
+    inc, PA, dRA, dDec = geom
+    u, v, V = _f8(u), _f8(v), np.asarray(V, dtype=np.complex128)
+    w = np.broadcast_to(_f8(np.atleast_1d(w)), u.shape)
+    m = map_visibilities(N, Rmax, geom, u, v, V, w, vis_model=0, check_qbounds=False)
+    dht = DHT(Rmax, N)
+    I = gaussian_model(dht, m["M"], m["j"], None)[0]
+    up, vp, _, _ = apply_correction(u, v, V, inc, PA, dRA, dDec)
+    Vm = (dht.coefficients(np.hypot(up, vp)) * np.cos(inc * np.pi / 180.0)) @ I
+    phi = (u * dRA + v * dDec) * (2.0 * np.pi / (3600.0 * 180.0 / np.pi))
+    e = np.sqrt(w) * (Vm * (np.cos(phi) + 1j * np.sin(phi)) - V)
+    return np.concatenate([e.real, e.imag])
+
+
+def gaussian_residual_and_jacobian(x, u, v, V, w, fit_inc_pa=True, fit_phase=True):
+    """_gauss_fun and _gauss_jac of _fit_geometry_gaussian (geometry.py:535-585) at x = (inc, PA [rad], dRA, dDec [arcsec],
+    norm, scal): the residual (real parts, then imaginary parts) and its [2 n][6] Jacobian."""
+    r2a = 3600.0 * 180.0 / np.pi
+    fac, sw = 2 * np.pi / r2a, np.sqrt(np.broadcast_to(_f8(np.atleast_1d(w)), np.shape(u)))
+    inc, PA, dRA, dDec, norm, scal = x
+
+    def wrap(z):
+        z = np.asarray(z, dtype=np.complex128)
+        return np.concatenate([z.real, z.imag])
+    phi = dRA * fac * u + dDec * fac * v
+    Vp = V * (np.cos(phi) - 1j * np.sin(phi))
+    c_t, s_t, c_i, s_i = np.cos(PA), np.sin(PA), np.cos(inc), np.sin(inc)
+    up, vp = u * c_t - v * s_t, u * s_t + v * c_t
+    uv = up * up * c_i * c_i + vp * vp
+    G = sw * np.exp(-0.5 * uv / (scal * r2a) ** 2)
+    fun = wrap(norm * G - sw * Vp)
+    jac = np.zeros((6, 2 * len(sw)))
+    nn = norm / (scal * r2a) ** 2
+    if fit_phase:
+        dVp = -sw * V * (-np.sin(phi) - 1j * np.cos(phi)) * fac
+        jac[2], jac[3] = wrap(dVp * u), wrap(dVp * v)
+    if fit_inc_pa:
+        jac[0] = wrap(nn * G * up * up * c_i * s_i)
+        jac[1] = wrap(nn * G * up * vp * (c_i * c_i - 1) / 2)
+    jac[4] = wrap(G)
+    jac[5] = wrap(nn * G * uv / scal)
+    return fun, jac.T

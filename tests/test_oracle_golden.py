@@ -364,3 +364,31 @@ def test_oracle_loop_through_the_svd_route(golden):
     assert out["rc"] == 0 and out["niter"] == int(g["niter"]) and out["n_svd"] == int(g["n_svd"])
     assert np.max(np.abs(np.log(out["p"] / g["p"]))) < 1e-9
     assert np.max(np.abs(out["mu"] - g["I"])) < 1e-9 * np.max(np.abs(g["I"]))
+
+
+def test_oracle_geometry_residual_against_the_reference(golden):
+    """The oracle's restatement of FitGeometryFourierBessel._residual (geometry.py:660-694) against the reference's own
+    vector at a trial geometry (tests/golden/geometry_fits_2e4.npz), and its Gaussian residual against its Jacobian by
+    central differences (the reference's closures cannot be called from outside; its fits pin them on the GPU side)."""
+    import hashlib
+    from frank_amd.mock import mock_disc_visibilities
+    g = golden("geometry_fits_2e4.npz")
+    u, v, V, w = mock_disc_visibilities(int(g["n"]), seed=int(g["seed"]), noise_seed=int(g["noise_seed"]),
+                                        weight=float(g["weight"]), qmax=float(g["qmax"]))
+    assert hashlib.sha256(b"".join(np.ascontiguousarray(a).tobytes() for a in (u, v, V, w))).hexdigest() == str(g["input_sha256"])
+    r = fo.fourier_bessel_residual(int(g["N"]), float(g["Rmax"]) / rad_to_arcsec, tuple(g["trial"]), u, v, V, w)
+    ref = g["resid_every8"]
+    assert np.abs(r[::8] - ref).max() < 1e-9 * np.abs(ref).max()
+    assert abs(np.sum(r * r) / float(g["resid_sumsq"]) - 1) < 1e-10
+    x = np.array([0.6, 1.4, 0.003, -0.002, 0.8, 0.7])
+    sl = slice(0, 2000)
+    fun, jac = fo.gaussian_residual_and_jacobian(x, u[sl], v[sl], V[sl], w[sl])
+    for k, h in enumerate([1e-6, 1e-6, 1e-7, 1e-7, 1e-6, 1e-6]):
+        e = np.zeros(6)
+        e[k] = h
+        num = (fo.gaussian_residual_and_jacobian(x + e, u[sl], v[sl], V[sl], w[sl])[0] -
+               fo.gaussian_residual_and_jacobian(x - e, u[sl], v[sl], V[sl], w[sl])[0]) / (2 * h)
+        # (the reference's PA column is HALF the derivative -- the "/ 2" of geometry.py:572 --; mirrored as it is: a scaled
+        #  column changes the optimiser's steps, not where J^T r = 0)
+        want = 2.0 * jac[:, k] if k == 1 else jac[:, k]
+        assert np.abs(num - want).max() < 1e-7 * np.abs(want).max(), k
