@@ -121,15 +121,17 @@ class _ResidentTable(object):
         from frank_amd import _lib
         self._lib = _lib
         V = np.asarray(V)
-        u, v = _lib.f8(u), _lib.f8(v)
-        Vre, Vim = _lib.f8(V.real), (_lib.f8(V.imag) if np.iscomplexobj(V) else None)
-        w = _lib.f8(np.atleast_1d(weights))
+        # single-precision arrays are stored as they are (20 B per visibility) and widened as the kernels read them
+        f32 = _lib.all_float32(u, v, V, weights)
+        conv, ptr, upload = (_lib.f4, _lib.fptr, _lib.lib.fh_vis_upload_f32) if f32 else (_lib.f8, _lib.ptr, _lib.lib.fh_vis_upload)
+        u, v = conv(u), conv(v)
+        Vre, Vim = conv(V.real), (conv(V.imag) if np.iscomplexobj(V) else None)
+        w = conv(np.atleast_1d(weights))
         self.n = u.size
         if v.size != self.n or Vre.size != self.n or w.size not in (1, self.n):
             raise ValueError("u, v, V (and weights) must have matching lengths")
         self.handle = ctypes.c_void_p()
-        _lib.check(_lib.lib.fh_vis_upload(int(device), _lib.ptr(u), _lib.ptr(v), _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w),
-                                          w.size, self.n, ctypes.byref(self.handle)))
+        _lib.check(upload(int(device), ptr(u), ptr(v), ptr(Vre), ptr(Vim), ptr(w), w.size, self.n, ctypes.byref(self.handle)))
 
     def close(self):
         if self.handle is not None and self.handle.value:
@@ -193,7 +195,7 @@ def _fit_geometry_gaussian(u, v, V, weights, guess, inc_pa=None, phase_centre=No
         x0[0], x0[1] = inc_pa[0] * deg_to_rad, inc_pa[1] * deg_to_rad
     if phase_centre is not None:
         x0[2], x0[3] = phase_centre
-    table = _ResidentTable(default_device() if device is None else device, u, v, V, np.broadcast_to(weights, np.shape(u)))
+    table = _ResidentTable(default_device() if device is None else device, u, v, V, weights)
     fit_ip, fit_ph = int(inc_pa is None), int(phase_centre is None)
     pinned = x0.copy()
 
@@ -384,7 +386,7 @@ class FitGeometryFourierBessel(SourceGeometry):
                       ' (your supplied phase center will be applied at the end of the geometry fitting routine)'
                       if self._phase_centre else ''))
         DHT = DiscreteHankelTransform(self._R / rad_to_arcsec, self._N, device=self._device)
-        table = _ResidentTable(DHT.device, u, v, vis, np.broadcast_to(w, np.shape(u)))
+        table = _ResidentTable(DHT.device, u, v, vis, w)
         self._counter = 0
         try:
             if self._optimizer == 'device':

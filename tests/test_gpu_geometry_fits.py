@@ -296,3 +296,22 @@ def test_residual_functions_against_the_oracle(N, n, geom):
     assert np.abs(fun - fun_o).max() <= 1e-12 * np.abs(fun_o).max()
     assert np.all(np.abs(jac - jac_o).max(axis=0) <= 1e-12 * np.maximum(np.abs(jac_o).max(axis=0), 1e-300))
     t.close()
+
+
+def test_geometry_fits_on_single_precision_tables_and_scalar_weights(golden):
+    """float32 / complex64 arrays are stored as a 20-byte table and widened on the fly: the fits equal, bit for bit, those of
+    the double table holding the widened values; a scalar weight equals the constant array."""
+    from frank_amd.geometry import FitGeometryFourierBessel, FitGeometryGaussian
+    g = golden("geometry_fits_2e4.npz")
+    u, v, V, w = table(g)
+    u4, v4, V4, w4 = u.astype(np.float32), v.astype(np.float32), V.astype(np.complex64), w.astype(np.float32)
+    wide = (u4.astype(np.float64), v4.astype(np.float64), V4.astype(np.complex128), w4.astype(np.float64))
+    for make, ref in ((lambda: FitGeometryGaussian(guess=[30.0, 80.0, 0.0, 0.0]), g["gauss_free"]),
+                      (lambda: FitGeometryFourierBessel(2.0, 20, guess=[30.0, 80.0, 0.0, 0.0]), g["fb_free"])):
+        a, b, c = make(), make(), make()
+        a.fit(u4, v4, V4, w4)
+        b.fit(*wide)
+        c.fit(wide[0], wide[1], wide[2], float(w4[0]))
+        assert np.array_equal(geometry_of(a), geometry_of(b))
+        assert np.abs(geometry_of(c) - geometry_of(b)).max() < 1e-9
+        assert np.abs(geometry_of(a)[:2] - ref[:2]).max() < 0.05  # (and they are fits: the fp64 table's within the rounding of the data)
