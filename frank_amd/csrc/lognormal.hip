@@ -37,6 +37,8 @@ namespace {
 __shared__ long long ln_cyc[12];  // 0 eval, 1 factorisations, 2 solves, 3 Hessians, 4 Newton, 5-7 pivoted LU, 8 S^-1, 9 Tr2, 10 Tr1, 11 bands + exp
 #define LTIC() const long long _t0 = clock64()
 #define LTOC(k) do { if (threadIdx.x == 0) ln_cyc[k] += clock64() - _t0; } while (0)
+__shared__ long long ln_ev[4];  // inside an evaluation: until the command is out, own items, waiting for the helpers, combining
+#define EVT(k) do { if (threadIdx.x == 0) { const long long n_ = clock64(); ln_ev[k] += n_ - _te; _te = n_; } } while (0)
 #else
 #define LTIC() do {} while (0)
 #define LTOC(k) do {} while (0)
@@ -77,11 +79,12 @@ struct LnS {
     // cluster (see "cluster: a few workgroups on one fit" below): workgroups sharing this fit's parallel pieces, whether they
     // sit on one XCD, the flag word of the hand-overs
     int cluster;
+    int seq;  // commands dispatched so far (cluster_dispatch)
     bool same_xcd;
     int *s_cl;
 };
-enum { LN_CMD_NONE = 0, LN_CMD_SINV = 1, LN_CMD_TR2 = 2, LN_CMD_EXIT = 3, LN_CMD_HESS = 4, LN_CMD_EVAL = 5 };
-__device__ __forceinline__ void cluster_dispatch(const LogNormalParams &P, int cmd, bool same_xcd);
+enum { LN_CMD_NONE = 0, LN_CMD_SINV = 1, LN_CMD_TR2 = 2, LN_CMD_EXIT = 3, LN_CMD_HESS = 4, LN_CMD_EVAL = 5, LN_CMD_WITH_S = 16 };
+__device__ __forceinline__ void cluster_dispatch(const LogNormalParams &P, int cmd, bool same_xcd, int &seq);
 __device__ __forceinline__ bool cluster_wait(const LogNormalParams &P, int *s_flag, bool same_xcd);
 
 // Wave reductions through DPP row operations (rocprim), result broadcast to every lane.
@@ -268,17 +271,24 @@ __device__ __forceinline__ double ln_eval(const LogNormalParams &P, LnS &S, cons
                                           const double *sv, double *sdst, bool along, double lam) {
     const int N = P.N, NP = P.NP, tid = ln_tid(), nch = (N + EVW - 1) / EVW;
     LTIC();
+#ifdef LN_TIMING
+    long long _te = clock64();
+#else
+#define EVT(k) do { } while (0)
+#endif
     bool shared = false;
-    if (S.cluster > 1) {  // the helpers read the two vectors from global memory; P.ctl[7]: whether S^-1 is multiplied
+    if (S.cluster > 1) {  // the helpers read the two vectors from global memory
         double *vecs = ln_eval_vecs(P);
         for (int i = tid; i < N; i += LT) {
             if (sv) vecs[i] = sv[i];
             vecs[NP + i] = Iv[i];
         }
-        if (tid == 0) __hip_atomic_store(&P.ctl[7], sv ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cluster_dispatch(P, LN_CMD_EVAL, S.same_xcd);
+        cluster_dispatch(P, LN_CMD_EVAL | (sv ? LN_CMD_WITH_S : 0), S.same_xcd, S.seq);
+        EVT(0);
         ln_eval_items(P, sv, Iv, tid, S.cluster * LT);
+        EVT(1);
         shared = cluster_wait(P, S.s_cl, S.same_xcd);
+        EVT(2);
         if (!shared) {  // the helpers did not answer: disband, and take every item here
             if (tid == 0) __hip_atomic_store(&P.ctl[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             S.cluster = 1;
@@ -320,6 +330,7 @@ __device__ __forceinline__ double ln_eval(const LogNormalParams &P, LnS &S, cons
     double f = 0.5 * A;
     f += 0.5 * B;
     f -= C;
+    EVT(3);
     LTOC(0);
     return f;
 }
@@ -422,7 +433,7 @@ __device__ __forceinline__ void build_hess_padded(const LogNormalParams &P, LnS 
         P.rk_g[i] = S.I[i];
         P.tr2_g[i] = S.MI[i];
     }
-    cluster_dispatch(P, LN_CMD_HESS, S.same_xcd);
+    cluster_dispatch(P, LN_CMD_HESS, S.same_xcd, S.seq);
     build_hess_rows(P, S.I, S.MI, S.jv, Cp, P.NP, false, 0, S.cluster);
     if (!cluster_wait(P, S.s_cl, S.same_xcd)) {
         if (ln_tid() == 0) __hip_atomic_store(&P.ctl[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // disbanded
@@ -1690,7 +1701,7 @@ __device__ __forceinline__ void tr2_solve(const LogNormalParams &P, const double
 // N = 300) and the Tr2 triangular solve with N right-hand sides (0.25 ms) -- at its matrix-pipe rate; together they are a fifth
 // of a default-mode fit.  A cluster is `cluster` workgroups of ONE launch: workgroup ids 0, 8, 16, ... (ids go round the eight
 // XCDs, so these share an L2; the ids between them return at once).  The first runs the fit; the others wait for commands:
-//   ctl[0] sequence number (bumped by the first workgroup per command), ctl[1] the command, ctl[2] helpers done with it,
+//   ctl[0] sequence number << 8 | command (one word: one load tells a helper everything), ctl[2] helpers done with it,
 //   ctl[3] helpers that have started, ctl[4] disbanded, ctl[5] the XCDs the workgroups sit on (bit mask), ctl[6] all on one.
 // Hand-over = a release fence by thread 0 behind a barrier + an agent-scope atomic; the receiver's acquire fence invalidates its
 // L1.  Every wait is bounded (wall clock): a cluster whose helpers do not all show up within 200 us is disbanded and the first
@@ -1714,13 +1725,16 @@ __device__ __forceinline__ void cluster_acquire(bool same_xcd) {
     else __threadfence();
 }
 // first workgroup, all threads: publish a command (everything written so far becomes visible to the helpers)
-__device__ __forceinline__ void cluster_dispatch(const LogNormalParams &P, int cmd, bool same_xcd) {
+// (the command travels IN the sequence word -- sequence number << 8 | command | LN_CMD_WITH_S --: a helper that sees the word
+//  change has everything in that one load; command, flag and XCD bit in words of their own were three more L2 round trips per
+//  hand-over, one behind the other)
+__device__ __forceinline__ void cluster_dispatch(const LogNormalParams &P, int cmd, bool same_xcd, int &seq) {
     __syncthreads();
+    ++seq;
     if (ln_tid() == 0) {
         ctl_store(&P.ctl[2], 0);
-        ctl_store(&P.ctl[1], cmd);
         cluster_release(same_xcd);
-        __hip_atomic_fetch_add(&P.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctl_store(&P.ctl[0], (seq << 8) | cmd);
     }
 }
 // first workgroup, all threads: wait for the helpers; false on a timeout
@@ -1749,29 +1763,30 @@ __device__ __forceinline__ void cluster_helper(const LogNormalParams &P, int mem
         __hip_atomic_fetch_or(&P.ctl[5], 1 << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&P.ctl[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    int seen = 0;
+    int seen = 0, same = -1;
     for (;;) {
         if (tid == 0) {
             const long long t0 = wall_clock64();
             int cmd = LN_CMD_EXIT;
             for (;;) {
                 if (ctl_load(&P.ctl[4])) break;            // disbanded
-                const int seq = ctl_load(&P.ctl[0]);
-                if (seq != seen) {
-                    seen = seq;
-                    cmd = ctl_load(&P.ctl[1]);
+                const int word = ctl_load(&P.ctl[0]);
+                if (word != seen) {
+                    seen = word;
+                    cmd = word & 0xff;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
                 if (wall_clock64() - t0 > 2000000000ll) break;  // 20 s of silence
             }
-            const bool same = ctl_load(&P.ctl[6]) != 0;
-            cluster_acquire(same);  // (what the first workgroup wrote before the command)
+            if (same < 0) same = ctl_load(&P.ctl[6]) != 0;  // (settled before the first command)
+            cluster_acquire(same != 0);  // (what the first workgroup wrote before the command)
             s_cmd[0] = cmd;
             s_cmd[1] = same;
         }
         __syncthreads();
-        const int cmd = s_cmd[0];
+        const bool with_s = (s_cmd[0] & LN_CMD_WITH_S) != 0;
+        const int cmd = s_cmd[0] & 0xf;
         const bool same_xcd = s_cmd[1] != 0;
         __syncthreads();
         if (cmd == LN_CMD_EXIT || cmd == LN_CMD_NONE) return;
@@ -1780,7 +1795,6 @@ __device__ __forceinline__ void cluster_helper(const LogNormalParams &P, int mem
         } else if (cmd == LN_CMD_EVAL) {
             extern __shared__ __attribute__((aligned(16))) double smem[];  // (a helper's LDS is otherwise unused)
             const double *vecs = ln_eval_vecs(P);
-            const bool with_s = ctl_load(&P.ctl[7]) != 0;
             for (int i = tid; i < P.N; i += LT) {
                 if (with_s) smem[i] = vecs[i];
                 smem[P.NP + i] = vecs[P.NP + i];
@@ -1883,6 +1897,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         S.perm = reinterpret_cast<int *>(b);
         b += N;  // 2N ints
         S.cluster = cluster;
+        S.seq = 0;
         S.same_xcd = same_xcd;
         S.s_cl = s_cl;
         S.lu = LDS_LU ? b : P.LU;
@@ -1944,6 +1959,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
     if (tid < 9) s_tot[tid] = 0;
 #ifdef LN_TIMING
     if (tid < 12) ln_cyc[tid] = 0;
+    if (tid < 4) ln_ev[tid] = 0;
 #endif
     __syncthreads();
 
@@ -1990,7 +2006,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
 #endif
             if (S.cluster > 1) {
                 for (int i = tid; i < N; i += LT) P.rk_g[i] = S.rhs[i];
-                cluster_dispatch(P, LN_CMD_SINV, same_xcd);
+                cluster_dispatch(P, LN_CMD_SINV, same_xcd, S.seq);
                 build_sinv(P, S.rhs, 0, S.cluster);
                 if (!cluster_wait(P, s_cl, same_xcd)) {
                     status = LN_STATUS_CLUSTER;
@@ -2101,7 +2117,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
             const double *dvec = S.pan + P.NP * tilechol::PS + 16 * tilechol::PS;  // diag(L), left in LDS by cholesky_as_lu
             if (S.cluster > 1) {
                 for (int i = tid; i < P.NP; i += LT) P.dvec_g[i] = dvec[i];
-                cluster_dispatch(P, LN_CMD_TR2, same_xcd);
+                cluster_dispatch(P, LN_CMD_TR2, same_xcd, S.seq);
                 if (S.cluster > 2) tr1_sums();  // (three helpers and more take the Tr2 columns among themselves)
                 else tr2_solve(P, S.lu, dvec, Xd, Wsc, P.tr2_g, 0, S.cluster);
                 if (!cluster_wait(P, s_cl, same_xcd)) {
@@ -2187,9 +2203,11 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         for (int k = 0; k < 8; ++k) P.stats[9 + k] = ln_cyc[k];
         printf("[ln timing, Mcycles] S^-1 %.1f  Tr2 %.1f  Tr1 %.1f  bands + exp %.1f\n", ln_cyc[8] / 1e6, ln_cyc[9] / 1e6, ln_cyc[10] / 1e6,
                ln_cyc[11] / 1e6);
+        printf("[ln timing, Mcycles] inside the evaluations: command out %.1f  own items %.1f  waiting for the helpers %.1f  combining %.1f\n",
+               ln_ev[0] / 1e6, ln_ev[1] / 1e6, ln_ev[2] / 1e6, ln_ev[3] / 1e6);
 #endif
     }
-    if (S.cluster > 1) cluster_dispatch(P, LN_CMD_EXIT, same_xcd);
+    if (S.cluster > 1) cluster_dispatch(P, LN_CMD_EXIT, same_xcd, S.seq);
     if (!P.batch) return;
     __syncthreads();
     }  // next fit of the batch
