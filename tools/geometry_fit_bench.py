@@ -1,5 +1,5 @@
 """The geometry fits at size: seconds per fit, residual evaluations, and what one evaluation is made of.
-    python3 tools/geometry_fit_bench.py [nvis]"""
+    python3 tools/geometry_fit_bench.py [nvis [device|scipy]]"""
 import ctypes
 import os
 import sys
@@ -14,6 +14,7 @@ from frank_amd.geometry import FitGeometryFourierBessel, FitGeometryGaussian, _R
 from frank_amd.mock import mock_disc_visibilities  # noqa: E402
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10 ** 6
+OPTS = (sys.argv[2],) if len(sys.argv) > 2 else ("device", "scipy")
 u, v, V, w = mock_disc_visibilities(n, seed=71, noise_seed=72, weight=1e6, qmax=1e6)
 
 
@@ -27,7 +28,7 @@ class Counting(FitGeometryFourierBessel):
         return FitGeometryFourierBessel._profile_under(geom, DHT, table)
 
 
-for opt in ("device", "scipy"):
+for opt in OPTS:
     for rep in range(2):
         Counting.calls = 0
         t0 = time.perf_counter()
