@@ -288,3 +288,15 @@ def test_levenberg_marquardt_on_normal_equations_follows_minpack():
     x, info, _ = run(lambda x: model(x) - y, ref.x if ref.x.size == 4 else x)
     assert info in (1, 2, 3, 4)
     assert np.array_equal(forward_steps(np.array([0.0, -2.0])), np.sqrt(np.finfo(float).eps) * np.array([1.0, 2.0]))
+
+
+def test_header_is_plain_c():
+    """include/frank_hip.h is the boundary: it must compile as C99 on its own (no C++, no HIP, no torch types)."""
+    import subprocess
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".c", delete=False) as fh:
+        fh.write('#include "frank_hip.h"\nint main(void) { return FH_RESIDUAL_SLOTS > 0 ? 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                        "-I", os.path.join(ROOT, "include"), fh.name], capture_output=True, text=True)
+    os.unlink(fh.name)
+    assert r.returncode == 0, r.stderr
