@@ -315,3 +315,30 @@ def test_geometry_fits_on_single_precision_tables_and_scalar_weights(golden):
         assert np.array_equal(geometry_of(a), geometry_of(b))
         assert np.abs(geometry_of(c) - geometry_of(b)).max() < 1e-9
         assert np.abs(geometry_of(a)[:2] - ref[:2]).max() < 0.05  # (and they are fits: the fp64 table's within the rounding of the data)
+
+
+@pytest.mark.parametrize("N", [300, 400])
+def test_residual_pass_of_a_frank_fit_at_large_N(N):
+    """fh_vis_residuals with the profile of a full FrankFitter fit (the chi^2 a caller computes after a fit, radial_fitters.py:56-98
+    + io.py:213) against sqrt(w) (sol.predict(u, v) - V): N = 300 right after the fit's binning pass (bucket tables), N = 400 on
+    the rows path of the wide basis (N Bessel evaluations per row)."""
+    from frank_amd import FixedGeometry, FrankFitter, _lib
+    from frank_amd.geometry import _ResidentTable
+    n = 50000
+    u, v, V, w = mock_disc_visibilities(n, seed=5, noise_seed=6)
+    geom = FixedGeometry(34.97, 85.76, 1.9e-3, 2.5e-3)
+    FF = FrankFitter(2.0, N, geom, verbose=False)
+    sol = FF.fit(u, v, V, w)
+    e = np.sqrt(w) * (sol.predict(u, v) - V)
+    t = _ResidentTable(0, u, v, V, w)
+    ctx, gg = FF._DHT.context(), _lib.make_geometry(geom)
+    out, ss = np.empty(2 * n), ctypes.c_double()
+    I = np.ascontiguousarray(sol.I)
+    for bin_first in (False, True):
+        if bin_first:  # the same rows under the same geometry binned just before: the table path where it exists
+            _lib.check(_lib.lib.fh_bin_reset(ctx))
+            _lib.check(_lib.lib.fh_bin_visibilities(ctx, ctypes.byref(gg), t.handle, 0, n))
+        _lib.check(_lib.lib.fh_vis_residuals(ctx, ctypes.byref(gg), 0, t.handle, 0, n, _lib.ptr(I), _lib.ptr(out), ctypes.byref(ss)))
+        assert np.abs(out - np.concatenate([e.real, e.imag])).max() < 1e-9 * np.abs(e).max(), bin_first
+        assert abs(ss.value / np.sum(np.abs(e) ** 2) - 1) < 1e-10
+    t.close()
