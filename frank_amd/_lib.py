@@ -58,6 +58,7 @@ SIGNATURES = {
     "fh_vis_set_multiplicity": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
     "fh_vis_residuals": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), ctypes.c_int, _vp, _i64, _i64, _dp, _dp, _dp]),
     "fh_gauss_residuals": (ctypes.c_int, [_vp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]),
+    "fh_predict_sky": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), ctypes.c_int, _dp, _dp, _i64, _dp, _dp, _dp]),
     "fh_vis_residuals_slot": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), ctypes.c_int, _vp, _dp, ctypes.c_int, _dp]),
     "fh_residual_normal_equations": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _dp,
                                                     _dp, _dp]),

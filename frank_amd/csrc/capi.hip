@@ -2707,6 +2707,57 @@ int fh_gauss_residuals(const fh_vis *vis, const double *params, int fit_inc_pa, 
 }
 
 
+// FrankRadialFit.predict(u, v) (radial_fitters.py:56-98) in one pass on the device: deproject, H(q) I, scale, re-phase -- the
+// residual kernel without data.  u, v: n host doubles; Vre, Vim: n host doubles each.
+int fh_predict_sky(fh_ctx *c, const fh_geometry *g, int vis_model, const double *u, const double *v, int64_t n, const double *I,
+                   double *Vre, double *Vim) {
+    if (!c || !g || !I || n < 0 || (n > 0 && (!u || !v || !Vre || !Vim))) return fail(FH_ERR_INVALID, "fh_predict_sky: bad argument");
+    if (vis_model != FH_VIS_OPT_THICK && vis_model != FH_VIS_OPT_THIN && vis_model != FH_VIS_DEBRIS)
+        return fail(FH_ERR_INVALID, "vis_model must be one of ['opt_thick', 'opt_thin', 'debris']");
+    if ((vis_model == FH_VIS_DEBRIS) != c->debris)
+        return fail(FH_ERR_INVALID, "vis_model 'debris' goes with fh_ctx_set_scale_height (and only with it)");
+    if (n == 0) return FH_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->N;
+    const size_t nn = (size_t)n;
+    const size_t nparts = (size_t)fh_residual_max_blocks();
+    if (c->scratch_q.n < 2 * nn) HIP_TRY(c->scratch_q.alloc(2 * nn));
+    if (c->scratch_out.n < 2 * nn + nparts + 1) HIP_TRY(c->scratch_out.alloc(2 * nn + nparts + 1));
+    if (c->scratch_I.n < (size_t)N + 1) HIP_TRY(c->scratch_I.alloc((size_t)N + 1));
+    HIP_TRY(hipMemcpyAsync(c->scratch_q.p, u, sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->scratch_q.p + nn, v, sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->scratch_I.p, I, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    VisResidualParams P{};
+    P.b.u = c->scratch_q.p;
+    P.b.v = c->scratch_q.p + nn;
+    P.b.first = 0;
+    P.b.count = n;
+    P.b.dRA = g->dRA_arcsec * (2. * M_PI / kRadToArcsec);
+    P.b.dDec = g->dDec_arcsec * (2. * M_PI / kRadToArcsec);
+    const double inc = g->inc_deg * kDegToRad, PA = g->PA_deg * kDegToRad;
+    P.b.cos_t = cos(PA);
+    P.b.sin_t = sin(PA);
+    P.b.cos_i = cos(inc);
+    P.b.sin_i = sin(inc);
+    P.b.N = N;
+    P.b.inv_Qmax = 1. / c->dht->Qmax;
+    P.b.zeros = c->zeros.p;
+    P.b.j0_table = c->j0_table.p;
+    P.b.H2 = c->debris ? c->debris_H2.p : nullptr;
+    P.pref = c->pref_fwd.p;
+    P.I = c->scratch_I.p;
+    P.scale = vis_model == FH_VIS_OPT_THICK ? cos(inc) : 1.0;
+    P.delta = 1.0;
+    P.predict_only = 1;
+    P.out = c->scratch_out.p;
+    P.partial = c->scratch_out.p + 2 * nn;
+    HIP_TRY(fh_launch_vis_residual(P, P.partial + nparts, c->stream));
+    HIP_TRY(hipMemcpyAsync(Vre, P.out, sizeof(double) * nn, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(Vim, P.out + nn, sizeof(double) * nn, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
 // ---- the same fits on the normal equations: residual vectors stay on the device, only J^T J and J^T r come back ----------
 int fh_vis_residuals_slot(fh_ctx *c, const fh_geometry *g, int vis_model, const fh_vis *vis, const double *I, int slot,
                           double *sumsq) {

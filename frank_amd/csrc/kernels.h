@@ -297,6 +297,7 @@ struct VisResidualParams {
     const double *coef;
     int nb;
     double delta;
+    int predict_only;    // no data: out = the model visibilities themselves (only b.u / b.v of the table columns are read)
 };
 struct GaussResidualParams {
     BinParams b;         // table + (cos, sin) of PA and inc in cos_t, sin_t, cos_i, sin_i; dRA, dDec in radians per wavelength

@@ -56,7 +56,14 @@ __global__ __launch_bounds__(kThreads) void vis_residual_kernel(VisResidualParam
     double ss = 0.0;
     const int64_t stride = (int64_t)gridDim.x * kThreads;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P.b.count; i += stride) {
-        const VisRow r = fh_load_row(P.b, P.b.first + i);
+        VisRow r;
+        if (P.predict_only) {
+            fh_load_uv(P.b, P.b.first + i, r.u, r.v);
+            r.Vre = r.Vim = 0.0;
+            r.w = 1.0;
+        } else {
+            r = fh_load_row(P.b, P.b.first + i);
+        }
         const double s = fh_deproject_q(P.b, r.u, r.v) * P.b.inv_Qmax;
         double a = 0.0;
         if (TABLES) {

@@ -164,6 +164,24 @@ class VisibilityMapping:
                                                     float(self._scale(geometry)), _lib.ptr(V)))
         return V
 
+    def predict_sky(self, I, u, v, geometry):
+        """Model visibilities at sky-plane baselines (u, v) under `geometry`: FrankRadialFit.predict's deproject,
+        predict_visibilities and undo_correction (radial_fitters.py:85-98) as one device pass.  Not for the debris model."""
+        shape = np.shape(u)
+        u, v = _lib.f8(np.ravel(u)), _lib.f8(np.ravel(v))
+        I = _lib.f8(I)
+        if I.size != self.size:
+            raise ValueError("I must have one value per collocation point")
+        if u.size != v.size:
+            raise ValueError("u and v must have matching lengths")
+        Vre, Vim = np.empty(u.size), np.empty(u.size)
+        g = _lib.make_geometry(geometry)
+        ctx = self._DHT.context()
+        _lib.check(_lib.lib.fh_ctx_set_scale_height(ctx, None))
+        _lib.check(_lib.lib.fh_predict_sky(ctx, ctypes.byref(g), _lib.VIS_MODELS[self._vis_model], _lib.ptr(u), _lib.ptr(v),
+                                           u.size, _lib.ptr(I), _lib.ptr(Vre), _lib.ptr(Vim)))
+        return (Vre + 1j * Vim).reshape(shape)
+
     def invert_visibilities(self, V, R, geometry=None):
         r"""statistical_models.py:331-384 (backward coefficients on the GPU, 1/scale applied)."""
         R = np.atleast_1d(R)

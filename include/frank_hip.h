@@ -299,6 +299,12 @@ int fh_vis_residuals(fh_ctx *ctx, const fh_geometry *g, int vis_model, const fh_
 int fh_gauss_residuals(const fh_vis *vis, const double *params, int fit_inc_pa, int fit_phase, double *fun, double *jac,
                        double *sumsq);
 
+/* fh_predict_sky: FrankRadialFit.predict(u, v, I, geometry) (radial_fitters.py:56-98) in one pass: the sky-plane baselines are
+ *   deprojected, V = H(q) I (x cos(inc) for vis_model 0, exp(-kz^2 H2[k]) per column for 2), and re-phased by the phase centre.
+ *   u, v: n host doubles; Vre, Vim: n host doubles each (the complex model visibilities). */
+int fh_predict_sky(fh_ctx *ctx, const fh_geometry *g, int vis_model, const double *u, const double *v, int64_t n, const double *I,
+                   double *Vre, double *Vim);
+
 /* The same fits with nothing of size n leaving the device: Levenberg-Marquardt needs the residual norm of a trial point and,
  * at an accepted point, J^T J and J^T r -- a few doubles (frank_amd.geometry, optimizer='device': MINPACK's lmdif / lmder
  * algorithm on the normal equations).  For the reference's optimiser itself use the two entry points above.

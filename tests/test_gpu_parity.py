@@ -254,6 +254,12 @@ def test_predict(golden):
     Vs = sol.predict(u, v)
     assert Vs.shape == u.shape and np.iscomplexobj(Vs)
     assert rel_to_max(np.abs(Vs), np.abs(ref)) < 1e-10
+    # ... and its phase: the model is real in the source frame, the phase centre turns it (geometry.py:69-77, :238-268)
+    phi = (u * GEOM[2] + v * GEOM[3]) * (2 * np.pi / rad_to_arcsec)
+    assert rel_to_max(Vs, ref * (np.cos(phi) + 1j * np.sin(phi))) < 1e-10
+    # shapes other than 1-d, and the explicit arguments
+    V2 = sol.predict(u.reshape(40, 50), v.reshape(40, 50), I=sol.I, geometry=sol.geometry)
+    assert V2.shape == (40, 50) and np.array_equal(V2.ravel(), Vs)
 
 
 def test_linearity_and_permutation_1e6():
