@@ -43,19 +43,12 @@ class FrankRadialFit(metaclass=abc.ABCMeta):
             geometry = self._geometry
         if I is None:
             I = self.I
-        if geometry is not None and self._vis_map._vis_model != 'debris':
+        if geometry is not None:
             # one pass on the device (fh_predict_sky): deproject, H(q) I, scale, re-phase -- at 1e7 baselines the NumPy
             # deprojection and phasor of the lines below are 0.4 s, four times the fit
             return self._vis_map.predict_sky(I, u, v, geometry)
-        if geometry is not None:
-            u, v, wz = geometry.deproject(u, v, use3D=True)
-        else:
-            wz = np.zeros_like(u)
-        q = np.hypot(u, v)
-        V = self._vis_map.predict_visibilities(I, q, wz, geometry=geometry)
-        if geometry is not None:
-            _, _, V = geometry.undo_correction(u, v, V)
-        return V
+        # no geometry at all (radial_fitters.py:88-90): the baselines are taken as deprojected
+        return self._vis_map.predict_visibilities(I, np.hypot(u, v), np.zeros_like(u), geometry=geometry)
 
     def predict_deprojected(self, q=None, I=None, geometry=None, block_size=10 ** 5,
                             assume_optically_thick=True):

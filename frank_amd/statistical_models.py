@@ -166,7 +166,8 @@ class VisibilityMapping:
 
     def predict_sky(self, I, u, v, geometry):
         """Model visibilities at sky-plane baselines (u, v) under `geometry`: FrankRadialFit.predict's deproject,
-        predict_visibilities and undo_correction (radial_fitters.py:85-98) as one device pass.  Not for the debris model."""
+        predict_visibilities and undo_correction (radial_fitters.py:85-98) as one device pass (the debris model's
+        exp(-kz^2 H2[k]) per column included)."""
         shape = np.shape(u)
         u, v = _lib.f8(np.ravel(u)), _lib.f8(np.ravel(v))
         I = _lib.f8(I)
@@ -177,7 +178,8 @@ class VisibilityMapping:
         Vre, Vim = np.empty(u.size), np.empty(u.size)
         g = _lib.make_geometry(geometry)
         ctx = self._DHT.context()
-        _lib.check(_lib.lib.fh_ctx_set_scale_height(ctx, None))
+        _lib.check(_lib.lib.fh_ctx_set_scale_height(
+            ctx, _lib.ptr(_lib.f8(self._H2)) if self._vis_model == 'debris' else None))
         _lib.check(_lib.lib.fh_predict_sky(ctx, ctypes.byref(g), _lib.VIS_MODELS[self._vis_model], _lib.ptr(u), _lib.ptr(v),
                                            u.size, _lib.ptr(I), _lib.ptr(Vre), _lib.ptr(Vim)))
         return (Vre + 1j * Vim).reshape(shape)
