@@ -236,3 +236,88 @@ def make_mock_data(r, I, Rmax, u, v, projection=None, geometry=None, N=500, add_
     if add_noise:
         vis = add_vis_noise(vis, weights, seed)
     return baselines, vis
+
+
+# ---- data preparation either side of the path: units and cuts (utilities.py:31-177, 403-512; host arithmetic, no device work) ----
+def arcsec_baseline(x):
+    """A radial scale [arcsec] as the baseline [lambda] that resolves it, or the other way round: the map is its own
+    inverse, 1 / (x arcsec in radians) (utilities.py:31-50)."""
+    return 1 / (x / 60 / 60 * np.pi / 180)
+
+
+def radius_convert(x, dist, conversion='arcsec_au'):
+    """Radii between [arcsec] and [au] for a source at `dist` [pc] (utilities.py:53-83)."""
+    if conversion == 'arcsec_au':
+        return x * dist
+    if conversion == 'au_arcsec':
+        return x / dist
+    raise AttributeError("conversion must be one of {}".format(['arcsec_au', 'au_arcsec']))
+
+
+_JY_CONVERSIONS = ['beam_sterad', 'beam_arcsec2', 'arcsec2_beam', 'arcsec2_sterad', 'sterad_beam', 'sterad_arcsec2']
+
+
+def jy_convert(x, conversion, bmaj=None, bmin=None):
+    """Brightness between [Jy / beam], [Jy / arcsec^2] and [Jy / sterad]; `conversion` names source_target, e.g.
+    'beam_sterad'; conversions through the beam need its FWHMs bmaj, bmin [arcsec] (utilities.py:86-138)."""
+    from frank_amd.constants import sterad_to_arcsec
+    have_beam = bmaj is not None and bmin is not None
+    if not have_beam and conversion in ['beam_sterad', 'beam_arcsec2', 'arcsec2_beam', 'sterad_beam']:
+        raise ValueError('bmaj and bmin must be specified to perform the conversion {}'.format(conversion))
+    if conversion not in _JY_CONVERSIONS:
+        raise AttributeError("conversion must be one of {}".format(_JY_CONVERSIONS))
+    beam = np.pi * bmaj * bmin / (4 * np.log(2)) if have_beam else None  # solid angle of a Gaussian beam [arcsec^2]
+    if conversion == 'beam_arcsec2':
+        return x / beam
+    if conversion == 'arcsec2_beam':
+        return x * beam
+    if conversion == 'arcsec2_sterad':
+        return x * sterad_to_arcsec
+    if conversion == 'sterad_arcsec2':
+        return x / sterad_to_arcsec
+    if conversion == 'beam_sterad':
+        return x / beam * sterad_to_arcsec
+    return x * beam / sterad_to_arcsec  # 'sterad_beam'
+
+
+def get_fit_stat_uncer(fit, return_linear=True):
+    """1-sigma statistical uncertainty of a fitted profile from the diagonal of its covariance (a lower bound: the sparse
+    (u, v) sampling adds a systematic part); for a LogNormal fit the variance of log I is turned into that of I unless
+    return_linear is False (utilities.py:141-177)."""
+    if 'method' not in fit._info.keys():
+        raise AttributeError("'fit' object lacks '_info.method' key. Should be one of ['linear', 'log']")
+    variance = np.diag(fit.covariance)
+    if fit._info["method"] == "LogNormal" and return_linear == True:  # noqa: E712  (the reference's comparison)
+        variance = (np.exp(variance) - 1) * np.exp(2 * np.log(fit.I))
+    return np.sqrt(variance)
+
+
+def check_uv(u, v, min_q=1e3, max_q=1e8):
+    """Warn when the shortest baseline is below min_q: the table is then probably in metres, not wavelengths
+    (utilities.py:403-428; max_q is accepted and, as in the reference, not looked at)."""
+    q = np.hypot(u, v)
+    if min(q) < min_q:
+        logging.warning("WARNING: "
+                        f"Minimum baseline {min(q):.1e} < expected minimum {min_q:.1e} [lambda]. "
+                        "'u' and 'v' distances must be in units of [lambda], but it looks like they're in [m].")
+
+
+def normalize_uv(u, v, wle):
+    """(u, v) in metres -> wavelengths: divided by the observing wavelength(s) `wle` [m], one value or one per row
+    (utilities.py:431-460)."""
+    logging.info('  Normalizing u and v coordinates by provided observing wavelength of {} m'.format(wle))
+    wle = np.atleast_1d(wle).astype('f8')
+    if len(wle) != 1 and len(wle) != len(u):
+        raise ValueError("len(wle) = {}. It should be equal to len(u) = {} (or 1 if all wavelengths are the same)".format(
+            len(wle), len(u)))
+    return u / wle, v / wle
+
+
+def cut_data_by_baseline(u, v, vis, weights, cut_range, geometry=None):
+    """Rows whose baseline -- deprojected with `geometry` if given -- lies inside cut_range = [min, max] lambda, both ends
+    included (utilities.py:463-512).  Returns (u, v, vis, weights) of those rows."""
+    logging.info('  Cutting data outside of the minimum and maximum baselines of {} and {} klambda'.format(
+        cut_range[0] / 1e3, cut_range[1] / 1e3))
+    q = np.hypot(*(geometry.deproject(u, v) if geometry is not None else (u, v)))
+    keep = (q >= cut_range[0]) & (q <= cut_range[1])
+    return u[keep], v[keep], vis[keep], weights[keep]

@@ -329,3 +329,47 @@ def test_mock_data_helper_signatures_and_errors():
     a = ut.add_vis_noise(np.ones(5), 4.0 * np.ones(5), seed=1)
     np.random.seed(1)
     assert np.array_equal(a, 1.0 + 0.5 * np.random.standard_normal((1, 5))[0])
+
+
+def test_unit_and_cut_helpers():
+    """utilities.py:31-177, 403-512 (host arithmetic; checked identical to the reference's functions on random inputs in the
+    build container): known answers, round trips, the inclusive cut, the argument errors."""
+    from frank_amd import utilities as ut
+    from frank_amd.constants import sterad_to_arcsec
+    from frank_amd.geometry import FixedGeometry
+    assert ut.arcsec_baseline(1.0) == rad_to_arcsec and abs(ut.arcsec_baseline(ut.arcsec_baseline(0.37)) / 0.37 - 1) < 1e-15
+    assert ut.radius_convert(0.5, 140.0) == 70.0 and ut.radius_convert(70.0, 140.0, 'au_arcsec') == 0.5
+    with pytest.raises(AttributeError):
+        ut.radius_convert(1.0, 1.0, 'pc_au')
+    x = np.array([1.0, 2.5])
+    beam = np.pi * 0.12 * 0.08 / (4 * np.log(2))
+    assert np.array_equal(ut.jy_convert(x, 'beam_arcsec2', 0.12, 0.08), x / beam)
+    assert np.array_equal(ut.jy_convert(x, 'arcsec2_sterad'), x * sterad_to_arcsec)
+    for a, b in (('beam_sterad', 'sterad_beam'), ('beam_arcsec2', 'arcsec2_beam'), ('arcsec2_sterad', 'sterad_arcsec2')):
+        np.testing.assert_allclose(ut.jy_convert(ut.jy_convert(x, a, 0.12, 0.08), b, 0.12, 0.08), x, rtol=1e-15)
+    with pytest.raises(ValueError):
+        ut.jy_convert(x, 'beam_sterad')
+    with pytest.raises(AttributeError):
+        ut.jy_convert(x, 'beam_parsec', 1.0, 1.0)
+    u, v = np.array([3e4, 6e4, 0.0, 2e5]), np.array([4e4, 8e4, 1.5e5, 0.0])
+    un, vn = ut.normalize_uv(u, v, 2.0)
+    assert np.array_equal(un, u / 2) and np.array_equal(vn, v / 2)
+    assert np.array_equal(ut.normalize_uv(u, v, [1.0, 2.0, 4.0, 8.0])[0], u / np.array([1.0, 2.0, 4.0, 8.0]))
+    with pytest.raises(ValueError):
+        ut.normalize_uv(u, v, [1.0, 2.0])
+    V, w = np.arange(4) + 1j, np.ones(4)
+    uc, vc, Vc, wc = ut.cut_data_by_baseline(u, v, V, w, [5e4, 1.5e5])   # baselines 5e4, 1e5, 1.5e5, 2e5: ends included
+    assert np.array_equal(uc, u[:3]) and np.array_equal(Vc, V[:3]) and wc.size == 3
+    g = FixedGeometry(60.0, 0.0)                                          # u compressed by cos(60 deg) = 1/2
+    assert ut.cut_data_by_baseline(u, v, V, w, [0.0, 1.2e5], geometry=g)[0].size == 3
+
+    class Fit(object):
+        def __init__(self, method):
+            self._info, self.covariance, self.I = {"method": method}, np.diag([0.04, 0.09]), np.array([2.0, 3.0])
+    assert np.allclose(ut.get_fit_stat_uncer(Fit("Normal")), [0.2, 0.3])
+    assert np.allclose(ut.get_fit_stat_uncer(Fit("LogNormal"), return_linear=False), [0.2, 0.3])
+    assert np.allclose(ut.get_fit_stat_uncer(Fit("LogNormal")), np.sqrt((np.exp([0.04, 0.09]) - 1) * np.array([4.0, 9.0])))
+    bad = Fit("Normal")
+    bad._info = {}
+    with pytest.raises(AttributeError):
+        ut.get_fit_stat_uncer(bad)
