@@ -342,3 +342,34 @@ def test_residual_pass_of_a_frank_fit_at_large_N(N):
         assert np.abs(out - np.concatenate([e.real, e.imag])).max() < 1e-9 * np.abs(e).max(), bin_first
         assert abs(ss.value / np.sum(np.abs(e) ** 2) - 1) < 1e-10
     t.close()
+
+
+def test_save_fit_and_load_sol(tmp_path, golden):
+    """io.save_fit / load_sol (io.py:127-218) around a fit of the reference's real-data table: every file it names, the
+    residual table = data - model, the pickled solution giving back the profile and predicting again."""
+    from frank_amd import FixedGeometry, FrankFitter
+    from frank_amd import io as fio
+    from frank_amd.utilities import get_fit_stat_uncer
+    g = golden("realdata_multi_ring_N100.npz")
+    u, v, w = g["u"], g["v"], g["w"]
+    V = g["Vre"] + 1j * g["Vim"]
+    FF = FrankFitter(2.0, 100, FixedGeometry(0.0, 0.0), verbose=False, store_iteration_diagnostics=True)
+    sol = FF.fit(u, v, V, w)
+    assert np.abs(sol.I - g["I"]).max() < 1e-6 * np.abs(g["I"]).max()
+    prefix = str(tmp_path / "disc")
+    fio.save_fit(u, v, V, w, sol, prefix, save_iteration_diag=True, iteration_diag=FF.iteration_diagnostics, format="npz")
+    for tail in ("_frank_sol.obj", "_frank_iteration_diagnostics.obj", "_frank_profile_fit.txt", "_frank_vis_fit.npz",
+                 "_frank_uv_fit.npz", "_frank_uv_resid.npz"):
+        assert (tmp_path / ("disc" + tail)).exists(), tail
+    prof = np.loadtxt(prefix + "_frank_profile_fit.txt")
+    assert np.array_equal(prof[:, 0], sol.r) and np.array_equal(prof[:, 1], sol.I)
+    np.testing.assert_allclose(prof[:, 2], get_fit_stat_uncer(sol), rtol=1e-15)
+    uf, vf, Vf, wf = fio.load_uvtable(prefix + "_frank_uv_fit.npz")
+    ur, vr, Vr, wr = fio.load_uvtable(prefix + "_frank_uv_resid.npz")
+    assert np.array_equal(uf, u) and np.array_equal(wr, w) and np.array_equal(Vr, V - Vf)
+    assert np.abs(Vf - sol.predict(u, v)).max() == 0.0
+    back = fio.load_sol(prefix + "_frank_sol.obj")
+    assert np.array_equal(back.I, sol.I) and np.array_equal(back.predict(u[:100], v[:100]), Vf[:100])
+    fio.save_fit(u, v, V, w, sol, prefix + "_t", save_solution=False, save_uvtables=False, format="txt")
+    vis_fit = np.loadtxt(prefix + "_t_frank_vis_fit.txt")
+    assert np.array_equal(vis_fit[:, 0], sol.q) and vis_fit.shape == (100, 2)

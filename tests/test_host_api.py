@@ -373,3 +373,35 @@ def test_unit_and_cut_helpers():
     bad._info = {}
     with pytest.raises(AttributeError):
         ut.get_fit_stat_uncer(bad)
+
+
+def test_uvtable_files_round_trip(tmp_path, golden):
+    """frank_amd.io (io.py:29-124): text, compressed text and npz UVTables; the header and column order of the text form
+    (so that files written by the reference load, and the other way round); the extension errors."""
+    import bz2
+    import gzip
+    from frank_amd import io as fio
+    g = golden("realdata_multi_ring_N100.npz")
+    u, v, w = g["u"][:200], g["v"][:200], g["w"][:200]
+    V = g["Vre"][:200] + 1j * g["Vim"][:200]
+    for name in ("t.txt", "t.dat", "t.npz"):
+        path = str(tmp_path / name)
+        fio.save_uvtable(path, u, v, V, w)
+        got = fio.load_uvtable(path)
+        for a, b in zip(got, (u, v, V, w)):
+            assert np.array_equal(a, b), name  # (savetxt's %.18e round-trips a double)
+    txt = open(str(tmp_path / "t.txt")).read()
+    assert txt.splitlines()[0] == "# u [lambda]\tv [lambda]\tRe(V)  [Jy]\tIm(V) [Jy]\tWeight [Jy^-2]"
+    assert len(txt.splitlines()[1].split()) == 5
+    for opener, ext in ((gzip.open, ".gz"), (bz2.open, ".bz2")):
+        with opener(str(tmp_path / ("t.txt" + ext)), "wt") as fh:
+            fh.write(txt)
+        assert np.array_equal(fio.load_uvtable(str(tmp_path / ("t.txt" + ext)))[2], V)
+    np.savez(str(tmp_path / "real.npz"), u=u, v=v, V=V.real, weights=w)
+    for bad in ("t.csv", "t.npz.gz", "real.npz"):
+        with pytest.raises(ValueError):
+            fio.load_uvtable(str(tmp_path / bad))
+    with pytest.raises(ValueError):
+        fio.save_uvtable(str(tmp_path / "t.csv"), u, v, V, w)
+    with pytest.raises(ValueError):
+        fio.save_fit(u, v, V, w, None, str(tmp_path / "x"), format="csv")
