@@ -9,7 +9,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import ROOT, rel_to_max, ulp_diff
+from conftest import ROOT, rel_to_max
 from frank_amd.constants import rad_to_arcsec
 
 RMAX = 2.0 / rad_to_arcsec
