@@ -1,6 +1,8 @@
 """frank_amd: MI355X-native drop-in for the visibility-fitting hot path of discsim/frank.
 
     from frank_amd import FrankFitter, FixedGeometry            # instead of frank.radial_fitters / frank.geometry
+    from frank_amd.geometry import FitGeometryFourierBessel     # geometry fits on the resident table
+    from frank_amd import utilities, io, debris_fitters         # as frank.utilities / frank.io / frank.debris_fitters
 
 The arithmetic lives in frank_amd/libfrank_hip.so (hand-written HIP kernels for gfx950 + rocBLAS /
 rocSOLVER, C ABI in include/frank_hip.h).  Importing the fitter classes loads that library and fails

@@ -232,6 +232,9 @@ def test_geometry_fit_and_debris_classes_host_side():
         assert (g.inc, g.PA, g.dRA, g.dDec) == (30.0, 40.0, 0.1, -0.2)
         c = g.clone()
         assert (c.inc, c.PA, c.dRA, c.dDec) == (30.0, 40.0, 0.1, -0.2)
+    for bad in (lambda: FitGeometryGaussian(optimizer="minuit"), lambda: FitGeometryFourierBessel(2.0, 20, optimizer="minuit")):
+        with pytest.raises(ValueError):
+            bad()
     # the default starting point and how given values overwrite it (geometry.py:437-447, :653-660)
     assert FitGeometryGaussian()._guess == [10.0, 10.0, 0.0, 0.0, 1.0, 1.0]
     assert FitGeometryGaussian(inc_pa=(5.0, 6.0), guess=[1.0, 2.0, 3.0, 4.0])._guess == [5.0, 6.0, 3.0, 4.0, 1.0, 1.0]
