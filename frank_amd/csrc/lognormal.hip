@@ -1734,7 +1734,7 @@ __device__ __forceinline__ void cluster_dispatch(const LogNormalParams &P, int c
     if (ln_tid() == 0) {
         ctl_store(&P.ctl[2], 0);
         cluster_release(same_xcd);
-        ctl_store(&P.ctl[0], (seq << 8) | cmd);
+        ctl_store(&P.ctl[0], (int)(((unsigned)seq << 8) | (unsigned)cmd));  // (wraps after 2^24 commands: still a new word every time)
     }
 }
 // first workgroup, all threads: wait for the helpers; false on a timeout
