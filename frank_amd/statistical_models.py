@@ -62,11 +62,10 @@ class VisibilityMapping:
         As in the reference the correction always uses the geometry given at construction (:165); the
         `geometry` argument only goes into the hash.
         """
-        if frequencies is not None:
-            raise NotImplementedError("multi-frequency mapping (statistical_models.py:175-189) is unreachable "
-                                      "from FrankFitter and not built")
         if geometry is None:
             geometry = self._geometry
+        if frequencies is not None:
+            return self._map_channels(u, v, V, weights, frequencies, geometry)
         if self._verbose:
             logging.info('    Building visibility matrices M and j')
         V = np.asarray(V)
@@ -118,6 +117,56 @@ class VisibilityMapping:
             'j': j,
             'null_likelihood': H0.value,
             'hash': [False, self._DHT, geometry, self._vis_model, self._scale_height],
+        }
+
+    def _map_channels(self, u, v, V, weights, frequencies, geometry):
+        """The multi-frequency form of map_visibilities (statistical_models.py:175-237): one (M, j) per distinct value of
+        `frequencies`, one null likelihood for the lot.  The table goes to the device once; a channel is one binning pass over
+        it with the rows of the other channels given multiplicity zero (fh_vis_set_multiplicity: the bootstrap's mechanism)."""
+        if self._verbose:
+            logging.info('    Building visibility matrices M and j')
+        V = np.asarray(V)
+        f32 = _lib.all_float32(u, v, V, weights)
+        conv, ptr, upload = ((_lib.f4, _lib.fptr, _lib.lib.fh_vis_upload_f32) if f32 else
+                             (_lib.f8, _lib.ptr, _lib.lib.fh_vis_upload))
+        u, v = conv(u), conv(v)
+        Vre, Vim = conv(V.real), (conv(V.imag) if np.iscomplexobj(V) else None)
+        w = conv(np.atleast_1d(weights))
+        frequencies = np.asarray(frequencies)
+        n = u.size
+        if v.size != n or Vre.size != n or w.size not in (1, n) or frequencies.size != n:
+            raise ValueError("u, v, V, frequencies (and weights) must have matching lengths")
+        channels = np.unique(frequencies)
+        N = self.size
+        Ms, js = np.zeros((len(channels), N, N)), np.zeros((len(channels), N))
+        g, ctx, model = _lib.make_geometry(self._geometry), self._DHT.context(), _lib.VIS_MODELS[self._vis_model]
+        _lib.check(_lib.lib.fh_ctx_set_scale_height(
+            ctx, _lib.ptr(_lib.f8(self._H2)) if self._vis_model == 'debris' else None))
+        _lib.check(_lib.lib.fh_ctx_set_arithmetic(ctx, 1 if self._arithmetic == 'fp32' else 0))
+        table = ctypes.c_void_p()
+        _lib.check(upload(self._DHT.device, ptr(u), ptr(v), ptr(Vre), ptr(Vim), ptr(w), w.size, n, ctypes.byref(table)))
+        H0_all, q_lo, q_hi = 0.0, np.inf, 0.0
+        try:
+            for i, f in enumerate(channels):
+                member = np.ascontiguousarray(frequencies == f, dtype=np.int32)
+                H0, qmin, qmax = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+                _lib.check(_lib.lib.fh_vis_set_multiplicity(table, member.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+                _lib.check(_lib.lib.fh_bin_reset(ctx))
+                _lib.check(_lib.lib.fh_bin_visibilities(ctx, ctypes.byref(g), table, 0, n))
+                _lib.check(_lib.lib.fh_stats_finalize(ctx, ctypes.byref(g), model, 0, _lib.ptr(Ms[i]), _lib.ptr(js[i]),
+                                                      ctypes.byref(H0), ctypes.byref(qmin), ctypes.byref(qmax)))
+                H0_all += H0.value
+                q_lo, q_hi = min(q_lo, qmin.value), max(q_hi, qmax.value)
+        finally:
+            _lib.lib.fh_vis_destroy(table)
+        self._check_uv_range(q_lo, q_hi)
+        return {
+            'mult_freq': True,
+            'channels': channels,
+            'M': Ms,
+            'j': js,
+            'null_likelihood': H0_all,
+            'hash': [True, self._DHT, geometry, self._vis_model, self._scale_height],
         }
 
     def check_hash(self, hash, multi_freq=False, geometry=None):
