@@ -1584,7 +1584,8 @@ static int svd_pinv_solve_device(fh_ctx *c, double *A_dev, double *B_dev, int nr
 
 int fh_gaussian_model(fh_ctx *c, const double *M, const double *j, const double *p, double *mu, double *chol,
                       double *Sinv, int *used_svd) {
-    if (!c || !M || !j) return fail(FH_ERR_INVALID, "fh_gaussian_model: NULL argument");
+    if (!c || ((M == nullptr) != (j == nullptr))) return fail(FH_ERR_INVALID, "fh_gaussian_model: pass both M and j or neither");
+    if (!M && !c->have_device_Mj) return fail(FH_ERR_INVALID, "fh_gaussian_model: no device-resident M, j (run fh_stats_finalize)");
     SyncOnExit drain{c->stream};
     HIP_TRY(hipSetDevice(c->device));
     const int N = c->N;
@@ -1593,11 +1594,13 @@ int fh_gaussian_model(fh_ctx *c, const double *M, const double *j, const double 
     if (p)
         for (int k = 0; k < N; ++k)
             if (!(p[k] > 0.0)) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (p[%d] = %g)", k, p[k]);
-    HIP_TRY(hipMemcpyAsync(c->M.p, M, sizeof(double) * NN, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->j.p, j, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    if (M) {  // (else: the statistics fh_stats_finalize left on the device)
+        HIP_TRY(hipMemcpyAsync(c->M.p, M, sizeof(double) * NN, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->j.p, j, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+        c->have_device_Mj = false;
+    }
     if (p) HIP_TRY(hipMemcpyAsync(c->p.p, p, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int) * FIT_NFLAGS, c->stream));
-    c->have_device_Mj = false;
     FitState st = make_state(c);
     if (Sinv) {
         if (p) {
@@ -2761,7 +2764,7 @@ int fh_predict_sky(fh_ctx *c, const fh_geometry *g, int vis_model, const double 
 // ---- the same fits on the normal equations: residual vectors stay on the device, only J^T J and J^T r come back ----------
 int fh_vis_residuals_slot(fh_ctx *c, const fh_geometry *g, int vis_model, const fh_vis *vis, const double *I, int slot,
                           double *sumsq) {
-    if (!c || !g || !vis || !I) return fail(FH_ERR_INVALID, "fh_vis_residuals_slot: NULL argument");
+    if (!c || !g || !vis) return fail(FH_ERR_INVALID, "fh_vis_residuals_slot: NULL argument");
     if (slot < 0 || slot >= FH_RESIDUAL_SLOTS) return fail(FH_ERR_INVALID, "fh_vis_residuals_slot: slot %d of %d", slot, FH_RESIDUAL_SLOTS);
     if (vis->device != c->device) return fail(FH_ERR_INVALID, "visibility table lives on another device");
     if (vis_model != FH_VIS_OPT_THICK && vis_model != FH_VIS_OPT_THIN && vis_model != FH_VIS_DEBRIS)
@@ -2794,9 +2797,13 @@ int fh_vis_residuals_slot(fh_ctx *c, const fh_geometry *g, int vis_model, const 
     int rc = residual_scratch(vis, 0, &P.partial, &d_sumsq);
     if (rc) return rc;
     P.out = vis->slots.p + len * slot;
-    if (c->scratch_I.n < (size_t)N + 1) HIP_TRY(c->scratch_I.alloc((size_t)N + 1));
-    HIP_TRY(hipMemcpyAsync(c->scratch_I.p, I, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
-    P.I = c->scratch_I.p;
+    if (I) {
+        if (c->scratch_I.n < (size_t)N + 1) HIP_TRY(c->scratch_I.alloc((size_t)N + 1));
+        HIP_TRY(hipMemcpyAsync(c->scratch_I.p, I, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+        P.I = c->scratch_I.p;
+    } else {
+        P.I = c->mu.p;  // the profile the last solve of this context left on the device (fh_gaussian_model, fh_fit_*)
+    }
     P.delta = c->k1_delta > 0 ? c->k1_delta : 1.0;
     rc = residual_through_tables(c, vis, P, P.I);
     if (rc) return rc;

@@ -339,12 +339,21 @@ class FitGeometryFourierBessel(SourceGeometry):
             x[free] = xf
             return x
 
+        ctx = DHT.context()
+        _lib.check(_lib.lib.fh_ctx_set_scale_height(ctx, None))
+        H0, qmin, qmax, used_svd = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int(0)
+
         def evaluate(xf, slot):
+            # the whole evaluation on the device: statistics, the prior-free solve and the residual vector never leave it
             geom = self._trial_geometry(full(xf))
-            g, I = self._profile_under(geom, DHT, table)
+            g = _lib.make_geometry(geom)
             ss = ctypes.c_double()
-            _lib.check(_lib.lib.fh_vis_residuals_slot(DHT.context(), ctypes.byref(g), thick, table.handle, _lib.ptr(I), slot,
-                                                      ctypes.byref(ss)))
+            _lib.check(_lib.lib.fh_bin_reset(ctx))
+            _lib.check(_lib.lib.fh_bin_visibilities(ctx, ctypes.byref(g), table.handle, 0, table.n))
+            _lib.check(_lib.lib.fh_stats_finalize(ctx, ctypes.byref(g), thick, 0, None, None, ctypes.byref(H0), ctypes.byref(qmin),
+                                                  ctypes.byref(qmax)))
+            _lib.check(_lib.lib.fh_gaussian_model(ctx, None, None, None, None, None, None, ctypes.byref(used_svd)))
+            _lib.check(_lib.lib.fh_vis_residuals_slot(ctx, ctypes.byref(g), thick, table.handle, None, slot, ctypes.byref(ss)))
             if self._verbose:
                 self._report(ss.value, table.n, geom)
             return ss.value

@@ -184,7 +184,8 @@ int fh_map_visibilities(fh_ctx *ctx, const fh_geometry *geom, int vis_model, int
                         int64_t n, double *M, double *j, double *H0, double *qmin, double *qmax);
 
 /* ---- a11-a13: GaussianModel -------------------------------------------------------------------------------
- * statistical_models.py:650-781.  p may be NULL (no prior).  M, j, p: host.  Outputs (host, any may be NULL):
+ * statistical_models.py:650-781.  p may be NULL (no prior).  M, j, p: host; M = j = NULL: the statistics a preceding
+ * fh_stats_finalize(..., M = NULL, j = NULL, ...) left on the device.  Outputs (host, any may be NULL):
  * mu (N), chol (N*N, upper factor U with Dinv = U^T U in the upper triangle, as scipy.linalg.cho_factor),
  * Sinv (N*N).  *used_svd is set when the Cholesky failed and the SVD pseudo-inverse (:747-755) was used.    */
 int fh_gaussian_model(fh_ctx *ctx, const double *M, const double *j, const double *p, double *mu, double *chol,
@@ -309,7 +310,9 @@ int fh_predict_sky(fh_ctx *ctx, const fh_geometry *g, int vis_model, const doubl
  * at an accepted point, J^T J and J^T r -- a few doubles (frank_amd.geometry, optimizer='device': MINPACK's lmdif / lmder
  * algorithm on the normal equations).  For the reference's optimiser itself use the two entry points above.
  * fh_vis_residuals_slot: as fh_vis_residuals over the whole table, the vector written to one of FH_RESIDUAL_SLOTS device
- *   buffers of 2 n doubles owned by the table; only its sum of squares is returned.
+ *   buffers of 2 n doubles owned by the table; only its sum of squares is returned.  I == NULL: the profile the context's
+ *   last solve left on the device (fh_gaussian_model with M = j = NULL after fh_stats_finalize with M = j = NULL keeps the
+ *   whole evaluation -- statistics, solve, residuals -- on the device).
  * fh_residual_normal_equations: forward-difference Jacobian columns d_k = (slot col_slots[k] - slot base_slot) / h[k],
  *   k < ncol <= 4 (MINPACK fdjac2), reduced to JtJ [ncol x ncol] and Jtr = J^T r(base) [ncol].
  * fh_gauss_normal_equations: JtJ [6 x 6], Jtr [6] and the sum of squares of the Gaussian's residual with its analytic

@@ -22,10 +22,9 @@ class Counting(FitGeometryFourierBessel):
     calls = 0
 
 
-    @staticmethod
-    def _profile_under(geom, DHT, table):
+    def _trial_geometry(self, params):  # (called once per residual evaluation under either optimiser)
         Counting.calls += 1
-        return FitGeometryFourierBessel._profile_under(geom, DHT, table)
+        return FitGeometryFourierBessel._trial_geometry(self, params)
 
 
 for opt in OPTS:
