@@ -397,3 +397,34 @@ def test_multi_frequency_mapping(golden):
     assert vm.check_hash(m["hash"], multi_freq=True) and not vm.check_hash(m["hash"])
     with pytest.raises(ValueError):
         vm.map_visibilities(u, v, V, w, frequencies=freq[:-1])
+
+
+def test_device_resident_operands_of_an_evaluation():
+    """fh_gaussian_model with M = j = NULL solves the statistics fh_stats_finalize left on the device, fh_vis_residuals_slot with
+    I = NULL takes that solve's profile: the same numbers as handing the arrays through the host; an error without statistics."""
+    from frank_amd import DiscreteHankelTransform, FixedGeometry, _lib
+    from frank_amd.geometry import _ResidentTable
+    N, n = 20, 30000
+    u, v, V, w = mock_disc_visibilities(n, seed=3, noise_seed=4, qmax=1.5e6)
+    DHT = DiscreteHankelTransform(2.0 / rad_to_arcsec, N)
+    ctx, t = DHT.context(), _ResidentTable(0, u, v, V, w)
+    sv = ctypes.c_int()
+    assert _lib.lib.fh_gaussian_model(ctx, None, None, None, None, None, None, ctypes.byref(sv)) != 0  # nothing binned yet
+    assert _lib.lib.fh_gaussian_model(ctx, _lib.ptr(np.eye(N)), None, None, None, None, None, ctypes.byref(sv)) != 0
+    g = _lib.make_geometry(FixedGeometry(30.0, 80.0, 0.01, -0.005))
+    H0, a, b = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    M, j, I, I2 = np.empty((N, N)), np.empty(N), np.empty(N), np.empty(N)
+    s1, s2 = ctypes.c_double(), ctypes.c_double()
+    for host in (True, False):
+        _lib.check(_lib.lib.fh_bin_reset(ctx))
+        _lib.check(_lib.lib.fh_bin_visibilities(ctx, ctypes.byref(g), t.handle, 0, n))
+        if host:
+            _lib.check(_lib.lib.fh_stats_finalize(ctx, ctypes.byref(g), 0, 0, _lib.ptr(M), _lib.ptr(j), ctypes.byref(H0), ctypes.byref(a), ctypes.byref(b)))
+            _lib.check(_lib.lib.fh_gaussian_model(ctx, _lib.ptr(M), _lib.ptr(j), None, _lib.ptr(I), None, None, ctypes.byref(sv)))
+            _lib.check(_lib.lib.fh_vis_residuals_slot(ctx, ctypes.byref(g), 0, t.handle, _lib.ptr(I), 0, ctypes.byref(s1)))
+        else:
+            _lib.check(_lib.lib.fh_stats_finalize(ctx, ctypes.byref(g), 0, 0, None, None, ctypes.byref(H0), ctypes.byref(a), ctypes.byref(b)))
+            _lib.check(_lib.lib.fh_gaussian_model(ctx, None, None, None, _lib.ptr(I2), None, None, ctypes.byref(sv)))
+            _lib.check(_lib.lib.fh_vis_residuals_slot(ctx, ctypes.byref(g), 0, t.handle, None, 1, ctypes.byref(s2)))
+    assert np.array_equal(I, I2) and s1.value == s2.value
+    t.close()
