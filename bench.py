@@ -719,7 +719,9 @@ def main():
         traffic, traffic_src, bin_traffic, bin_traffic_src = None, None, None, None
         try:
             with open(os.path.join(ROOT, "profiles", "r03_pmc_fit_loop.json")) as fh:
-                traffic = json.load(fh)["fit_loop_kernel"]["hbm_bytes_per_launch"] if Nc == 300 else None
+                pm2 = json.load(fh)
+                key = [k for k in pm2 if k.startswith("fit_loop_kernel")]  # (the name carries its template argument)
+                traffic = pm2[key[0]]["hbm_bytes_per_launch"] if (Nc == 300 and key) else None
             traffic_src = ("static: profiles/r03_pmc_fit_loop.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on one fit, FETCH "
                            "doubled per the gfx950 note); not measured in this run")
         except Exception:
