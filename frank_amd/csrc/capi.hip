@@ -2725,7 +2725,8 @@ int fh_predict_sky(fh_ctx *c, const fh_geometry *g, int vis_model, const double 
     const size_t nn = (size_t)n;
     const size_t nparts = (size_t)fh_residual_max_blocks();
     if (c->scratch_q.n < 2 * nn) HIP_TRY(c->scratch_q.alloc(2 * nn));
-    if (c->scratch_out.n < 2 * nn + nparts + 1) HIP_TRY(c->scratch_out.alloc(2 * nn + nparts + 1));
+    const size_t nscal = (size_t)c->deproject_blocks * 4;  // (a range pass's per-workgroup scalars, kept apart from the binning pass's)
+    if (c->scratch_out.n < 2 * nn + nparts + 1 + nscal) HIP_TRY(c->scratch_out.alloc(2 * nn + nparts + 1 + nscal));
     if (c->scratch_I.n < (size_t)N + 1) HIP_TRY(c->scratch_I.alloc((size_t)N + 1));
     HIP_TRY(hipMemcpyAsync(c->scratch_q.p, u, sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->scratch_q.p + nn, v, sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
@@ -2754,6 +2755,38 @@ int fh_predict_sky(fh_ctx *c, const fh_geometry *g, int vis_model, const double 
     P.predict_only = 1;
     P.out = c->scratch_out.p;
     P.partial = c->scratch_out.p + 2 * nn;
+    if (c->v2 && !c->debris && n >= 65536 && !getenv("FRANK_AMD_RESIDUAL_DIRECT")) {
+        // large calls: one look at (u, v) for the longest deprojected baseline, then the model visibility of a row is the
+        // degree-11 polynomial of its bucket (the binning pass's tables contracted with the profile) instead of N Bessel
+        // evaluations -- at N = 300 those are a third of the call
+        PrepassParams R{};
+        R.bin = P.b;
+        R.unroll = 2;
+        R.partial_scalars = c->scratch_out.p + 2 * nn + nparts + 1;
+        fh_prepass_geometry(0, c->num_cu, &R.wpb, &R.blocks);
+        if ((size_t)R.blocks * 4 <= nscal) {
+            HIP_TRY(fh_prepass_launch_range(R, c->stream));
+            std::vector<double> scal((size_t)R.blocks * 4);
+            HIP_TRY(hipMemcpyAsync(scal.data(), R.partial_scalars, sizeof(double) * scal.size(), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            double qmax_all = 0.0;
+            for (int b = 0; b < R.blocks; ++b)
+                if (scal[(size_t)b * 4 + 3] > qmax_all) qmax_all = scal[(size_t)b * 4 + 3];
+            const double smax = qmax_all * P.b.inv_Qmax;
+            if (smax == smax && smax / c->k1_delta < 15000.0) {
+                const int nb = (int)(smax / c->k1_delta) + 2;
+                const int rc = k1v2_ensure_table(c, nb);
+                if (rc) return rc;
+                if (c->predict_coef.n < (size_t)c->k1_nb_built * FH_K1_TERMS)
+                    HIP_TRY(c->predict_coef.alloc((size_t)c->k1_nb_built * FH_K1_TERMS));
+                HIP_TRY(fh_k1v2_launch_predict_coef(c->k1_table.p, c->XS, N, nb, c->pref_fwd.p, P.I, P.scale, c->predict_coef.p,
+                                                    c->stream));
+                P.coef = c->predict_coef.p;
+                P.nb = nb;
+                P.delta = c->k1_delta;
+            }
+        }
+    }
     HIP_TRY(fh_launch_vis_residual(P, P.partial + nparts, c->stream));
     HIP_TRY(hipMemcpyAsync(Vre, P.out, sizeof(double) * nn, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(Vim, P.out + nn, sizeof(double) * nn, hipMemcpyDeviceToHost, c->stream));

@@ -428,3 +428,24 @@ def test_device_resident_operands_of_an_evaluation():
             _lib.check(_lib.lib.fh_vis_residuals_slot(ctx, ctypes.byref(g), 0, t.handle, None, 1, ctypes.byref(s2)))
     assert np.array_equal(I, I2) and s1.value == s2.value
     t.close()
+
+
+def test_predict_sky_through_the_bucket_tables():
+    """sol.predict(u, v) on a large call (one look at the baselines, then a polynomial per row) against the same call with N
+    Bessel evaluations per row, and a small call (always direct) on a slice."""
+    import os
+    from frank_amd import FixedGeometry, FrankFitter
+    n = 200000
+    u, v, V, w = mock_disc_visibilities(n, seed=5, noise_seed=6)
+    sol = FrankFitter(2.0, 120, FixedGeometry(34.97, 85.76, 1.9e-3, 2.5e-3), verbose=False).fit(u, v, V, w)
+    P = sol.predict(u, v)
+    os.environ["FRANK_AMD_RESIDUAL_DIRECT"] = "1"
+    try:
+        Pd = sol.predict(u, v)
+    finally:
+        del os.environ["FRANK_AMD_RESIDUAL_DIRECT"]
+    assert 0 < np.abs(P - Pd).max() < 1e-11 * np.abs(Pd).max()
+    assert np.array_equal(sol.predict(u[:5000], v[:5000]), Pd[:5000])
+    # the fit's own statistics are untouched by the call: binning the same table again gives the same fit
+    again = FrankFitter(2.0, 120, FixedGeometry(34.97, 85.76, 1.9e-3, 2.5e-3), verbose=False).fit(u, v, V, w)
+    assert np.array_equal(again.I, sol.I)
