@@ -4,7 +4,8 @@
  (b) DiscreteHankelTransform.coefficients(q) and VisibilityMapping.predict_visibilities (device Bessel / bucket tables)
      against scipy.special.j0 on the host, over basis sizes x numbers of baselines, q from 0 to beyond Qmax;
  (c) UVDataBinner (LDS histograms, global atomics above 3072 bins) against numpy.bincount over bin counts x row counts:
-     counts exact, weighted means to 1e-10.
+     counts exact, weighted means to 1e-10;
+ (d) sol.predict(u, v) through the bucket tables against the direct evaluation over basis sizes x call sizes.
      python3 tools/misc_sweep.py"""
 import os
 import sys
@@ -76,5 +77,33 @@ for n in (1, 2, 1000, 1000003):
         if not ok:
             bad.append(("uvbin", n, nb))
         print("uvbin n=%7d bins=%6d (len %6d)  counts %s  V %.1e  w %.1e %s" % (n, nb, nbin, "exact" if okc else "DIFFER", eV, ew, "" if ok else "  <-- MISMATCH"), flush=True)
+# (d) sky-plane predict (fh_predict_sky): large calls go through the bucket tables, FRANK_AMD_RESIDUAL_DIRECT=1 keeps the N Bessel
+#     evaluations per row; call sizes either side of the switch, basis sizes either side of the fused kernels' limit
+from frank_amd.radial_fitters import FrankGaussianFit  # noqa: E402
+
+
+class _Profile(FrankGaussianFit):
+    def __init__(self, vm, I, geometry):
+        FrankGaussianFit.__init__(self, vm, None, {}, geometry=geometry)
+        self._I = I
+    MAP = property(lambda self: self._I)
+
+
+uu, vv, _, _ = mock_disc_visibilities(300001, seed=43, noise_seed=44)
+for N in (3, 20, 300, 511, 640, 1000):
+    D = DiscreteHankelTransform(2.0 / 206264.80624709636, N)
+    vm = VisibilityMapping(D, geom, check_qbounds=False)
+    I = np.exp(-0.5 * (D.r / (0.4 * D.Rmax)) ** 2) * (1.5 + np.sin(7 * D.r / D.Rmax))
+    sol = _Profile(vm, I, geom)
+    for nq in (1, 65535, 65536, 300001):
+        P = sol.predict(uu[:nq], vv[:nq])
+        os.environ["FRANK_AMD_RESIDUAL_DIRECT"] = "1"
+        Pd = sol.predict(uu[:nq], vv[:nq])
+        del os.environ["FRANK_AMD_RESIDUAL_DIRECT"]
+        e = np.abs(P - Pd).max() / np.abs(Pd).max()
+        ok = e < 1e-11
+        if not ok:
+            bad.append(("predict_sky", N, nq))
+        print("predict_sky N=%4d n=%6d  tables vs direct %.1e %s" % (N, nq, e, "" if ok else "  <-- MISMATCH"), flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
