@@ -267,6 +267,7 @@ class FitGeometryFourierBessel(SourceGeometry):
     def __init__(self, Rmax, N, inc_pa=None, phase_centre=None, guess=None, verbose=False, device=None, optimizer='device'):
         if optimizer not in _OPTIMIZERS:
             raise ValueError("optimizer must be one of %r, not %r" % (_OPTIMIZERS, optimizer))
+        SourceGeometry.__init__(self)  # (inc, PA, dRA, dDec are None until fit() has run)
         self._optimizer = optimizer
         self._N, self._R = N, Rmax
         self._inc_pa, self._phase_centre = inc_pa, phase_centre
