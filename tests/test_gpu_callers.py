@@ -1,5 +1,7 @@
-"""Geometry fits (geometry.py:404-763) on the resident table, against the reference's results on the same visibilities
-(tests/golden/geometry_fits_2e4.npz, tools/make_golden_geometry.py), and the debris fitter classes."""
+"""The callers and data formats either side of the hot path, against the reference's results on the same inputs: the geometry
+fits (geometry.py:404-763, tests/golden/geometry_fits_2e4.npz) and the debris fitter classes; the mock-data helpers
+(utilities.py:923-1146, mockdata_helpers.npz); the multi-frequency mapping (statistical_models.py:175-237,
+multifreq_N50_2e4.npz); sol.predict(u, v) as one device pass; io.save_fit / load_sol."""
 import ctypes
 import hashlib
 
