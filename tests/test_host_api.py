@@ -290,6 +290,11 @@ def test_levenberg_marquardt_on_normal_equations_follows_minpack():
     assert info in (1, 2, 3, 4) and np.abs(x - [2.0, 1.3, 0.5, 3.0]).max() < 1e-7
     x, info, _ = run(lambda x: model(x) - y, ref.x if ref.x.size == 4 else x)
     assert info in (1, 2, 3, 4)
+    # a parameter the residual does not depend on (a zero Jacobian column, singular J^T J): it stays where it was, as in MINPACK
+    y3 = 1.7 * np.exp(-0.8 * t)
+    x, info, nfev = run(lambda x: x[0] * np.exp(-x[1] * t) - y3 + 0 * x[2], [1.0, 1.0, 5.0])
+    ref = least_squares(lambda x: x[0] * np.exp(-x[1] * t) - y3 + 0 * x[2], [1.0, 1.0, 5.0], method="lm")
+    assert info in (1, 2, 3, 4) and np.abs(x - ref.x).max() < 1e-9 and x[2] == 5.0 and nfev == ref.nfev
     assert np.array_equal(forward_steps(np.array([0.0, -2.0])), np.sqrt(np.finfo(float).eps) * np.array([1.0, 2.0]))
 
 
