@@ -141,6 +141,7 @@ struct FitBatch {
     bool active = false, launched = false;
     double alpha = 0, p0 = 0, tol = 0;
     int max_iter = 0;
+    int cluster = 1;  // workgroups per fit of this launch (fit_loop.hip, cluster mode)
 };
 
 struct fh_ctx {
@@ -219,8 +220,12 @@ struct fh_ctx {
     int *slot_result_host = nullptr;      // pinned: [slot][count, status]
     int pending_batch = -1;  // batch that is still collecting submissions (not launched)
     int fit_batch = kFitBatchMax;
+    int burst_next = 1;      // fits that trigger the next launch: 1, 2, 4, .. up to fit_batch while a pipeline fills up
+    hipEvent_t stream_last_done[kLaunchStreamsMax] = {};  // completion event of the last launch each launch stream was given
     size_t slot_stride = 0;
     int slots_busy = 0;
+    int last_fit_cluster = 1;             // workgroups the last fh_fit_normal ran on
+    unsigned long long cluster_fallbacks = 0;  // cluster launches that ended with FIT_STATUS_CLUSTER and were repeated on one CU
     bool have_device_Mj = false;
     hipEvent_t ev_bin0 = nullptr, ev_bin1 = nullptr;
     bool bin_timed = false;
@@ -504,8 +509,9 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
         HIP_TRY(c->Aq.alloc(PP));
         HIP_TRY(c->Cq.alloc(PP));
         HIP_TRY(c->Wq.alloc(PP));
-        HIP_TRY(c->WdT.alloc((size_t)c->NP * 16));
+        HIP_TRY(c->WdT.alloc(fh_k2_exchange_doubles(c->NP)));
         HIP_TRY(c->cs.alloc((size_t)(c->NP / 16) * (c->NP / 16) * 16));
+        HIP_TRY(hipMemsetAsync(c->WdT.p, 0, sizeof(double) * fh_k2_exchange_doubles(c->NP), c->stream));  // (control words of the cluster mode: zero between fits)
         HIP_TRY(hipMemsetAsync(c->Cq.p, 0, sizeof(double) * PP, c->stream));
         HIP_TRY(hipMemsetAsync(c->Wq.p, 0, sizeof(double) * PP, c->stream));
         HIP_TRY(c->bq.alloc(N));
@@ -1824,6 +1830,18 @@ static int prepare_qspace(fh_ctx *c, double *Aq, double *bq) {
     return FH_OK;
 }
 
+// Cluster ("latency") mode of the fit loop (fit_loop.hip, clu::): workgroups per fit.  One primary + two helpers give every
+// block column of the inverse at N <= 383 a wave of its own; FRANK_AMD_K2_CLUSTER=1 turns the mode off, 2..8 set the size.
+// Small systems (fewer than eight block rows) have nothing to hand over.
+static int env_int(const char *name, int dflt);
+static int fit_cluster_size(const fh_ctx *c) {
+    const char *e = getenv("FRANK_AMD_K2_CLUSTER");  // (read at every call: tests switch it inside one process)
+    int want = e ? atoi(e) : 3;
+    want = want < 1 ? 1 : (want > FIT_CLUSTER_MAX ? FIT_CLUSTER_MAX : want);
+    if (want <= 1 || c->NP < 128 || c->NP > fh_k2_loop_max_np()) return 1;
+    return want;
+}
+
 static FitLoopParams make_loop_params(fh_ctx *c, int mode, double alpha, double p0, double tol, int max_iter) {
     FitLoopParams P{};
     P.N = c->N;
@@ -1888,15 +1906,26 @@ int fh_fit_normal(fh_ctx *c, const double *M, const double *j, double alpha, dou
     FitLoopParams P = make_loop_params(c, FIT_MODE_FULL, alpha, p0, tol, max_iter);
     P.diag_p = want_diag ? c->diag_p.p : nullptr;
     P.diag_mu = want_diag ? c->diag_mu.p : nullptr;
-    HIP_TRY(hipEventRecord(c->ev_loop0, c->stream));
-    HIP_TRY(fh_k2_launch_loop(P, c->stream));
-    HIP_TRY(hipEventRecord(c->ev_loop1, c->stream));
-    c->loop_timed = true;
+    // a single fit is what the latency of a pass decides: on a cluster of workgroups unless something else occupies the device
+    P.cluster = (c->slots_busy == 0) ? fit_cluster_size(c) : 1;
     int result[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(result, c->loop_result.p, sizeof result, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(mu, c->mu_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(p, c->p_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIP_TRY(hipEventRecord(c->ev_loop0, c->stream));
+        HIP_TRY(fh_k2_launch_loop(P, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_loop1, c->stream));
+        c->loop_timed = true;
+        HIP_TRY(hipMemcpyAsync(result, c->loop_result.p, sizeof result, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(mu, c->mu_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(p, c->p_out.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (result[1] != FIT_STATUS_CLUSTER) break;
+        // the cluster did not assemble (helpers not resident in time, or not on one XCD) or broke: the same fit on one CU
+        if (P.cluster <= 1) return fail(FH_ERR_HIP, "fit_loop: unexpected cluster status");
+        ++c->cluster_fallbacks;
+        HIP_TRY(hipMemsetAsync(c->WdT.p, 0, sizeof(double) * fh_k2_exchange_doubles(c->NP), c->stream));
+        P.cluster = 1;
+    }
+    c->last_fit_cluster = P.cluster;
     *niter = result[0];
     const size_t nd = (size_t)result[0] * N;
     if (diag_p && nd) HIP_TRY(hipMemcpy(diag_p, c->diag_p.p, sizeof(double) * nd, hipMemcpyDeviceToHost));
@@ -2014,8 +2043,8 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
 // Defaults from a sweep of (streams, fits per launch, slots) at the headline size, fits/s at steady state: 3/32/128 825,
 // 3/43/172 858, 3/64/192 931, 3/64/240 929, 4/32/160 920, 4/48/240 905, 5/32/192 919, 2/120/240 1024, **4/64/240 966-1001**; the sixteen launches of
 // sixteen on sixteen streams this replaces: 711-740.
-static int fit_launch_streams() {  // streams the launches take turns on (FRANK_AMD_FIT_STREAMS, 1 .. 8)
-    int n = 4;
+static int fit_launch_streams() {  // streams the launches are dealt to, idle ones first (FRANK_AMD_FIT_STREAMS, 1 .. 8)
+    int n = 6;
     if (const char *e = getenv("FRANK_AMD_FIT_STREAMS")) n = atoi(e);
     return n < 1 ? 1 : (n > kLaunchStreamsMax ? kLaunchStreamsMax : n);
 }
@@ -2045,7 +2074,29 @@ static int flush_pending_batch(fh_ctx *c) {
         b.active = false;
         return FH_OK;
     }
-    b.stream = c->launch_streams[c->launches++ % (unsigned long long)c->n_launch_streams];
+    {   // a stream whose last launch has ended, if there is one (a pipeline that is filling up sends launches of 1, 2, 4, ..
+        // fits: queued behind an earlier launch on its stream such a launch would start a whole fit late); else the next in turn
+        int pick = -1;
+        for (int i = 0; i < c->n_launch_streams && pick < 0; ++i) {
+            const int j = (int)((c->launches + (unsigned long long)i) % (unsigned long long)c->n_launch_streams);
+            if (!c->stream_last_done[j] || hipEventQuery(c->stream_last_done[j]) == hipSuccess) pick = j;
+        }
+        (void)hipGetLastError();  // (hipErrorNotReady of the queries)
+        if (pick < 0) pick = (int)(c->launches % (unsigned long long)c->n_launch_streams);
+        ++c->launches;
+        b.stream = c->launch_streams[pick];
+        c->stream_last_done[pick] = b.done;
+    }
+    // few fits outstanding: every fit of this launch on a cluster of workgroups (the latency of a pass is what a shallow
+    // pipeline waits for); the compute units the clusters of all launches in flight may hold: FRANK_AMD_K2_CLUSTER_CUS (96)
+    {
+        static const int budget = env_int("FRANK_AMD_K2_CLUSTER_CUS", 96);
+        const int g = fit_cluster_size(c);
+        int held = 0;
+        for (const FitBatch &o : c->batches)
+            if (o.active && o.launched) held += o.outstanding * o.cluster;
+        b.cluster = (g > 1 && held + b.n * g <= budget) ? g : 1;
+    }
     HIP_TRY(hipEventRecord(b.ready, c->stream));  // the operands of its fits were prepared on the context's stream
     HIP_TRY(hipStreamWaitEvent(b.stream, b.ready, 0));
     FitLoopParams P = make_loop_params(c, FIT_MODE_FULL, b.alpha, b.p0, b.tol, b.max_iter);
@@ -2065,6 +2116,7 @@ static int flush_pending_batch(fh_ctx *c) {
     for (int i = 0; i < b.n; ++i) P.slot_words[i >> 3] |= (unsigned long long)b.slots[i] << (8 * (i & 7));
     P.out_host = c->slot_out_host;
     P.result_host = c->slot_result_host;
+    P.cluster = b.cluster;
     HIP_TRY(fh_k2_launch_loop_slots(P, b.n, b.stream));
     HIP_TRY(hipEventRecord(b.done, b.stream));
     b.launched = true;
@@ -2134,6 +2186,7 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
         c->fit_batch = fit_batch_size();
     }
     // a launch carries ONE (tol, max_iter); alpha, p0 and w_smooth are per fit (they travel with the slot's band LU)
+    if (c->slots_busy == 0) c->burst_next = 1;  // an empty pipeline: the first launches are small (1, 2, 4, .. fits)
     if (c->pending_batch >= 0) {
         const FitBatch &pb = c->batches[c->pending_batch];
         if (pb.tol != tol || pb.max_iter != max_iter) {
@@ -2183,7 +2236,12 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
     s.busy = true;
     ++c->slots_busy;
     *ticket = si;
-    if (b.n >= c->fit_batch) return flush_pending_batch(c);
+    static const int early = env_int("FRANK_AMD_FIT_EARLY", 1);
+    const int trigger = early ? (c->burst_next < c->fit_batch ? c->burst_next : c->fit_batch) : c->fit_batch;
+    if (b.n >= trigger) {
+        c->burst_next = 2 * trigger;
+        return flush_pending_batch(c);
+    }
     return FH_OK;
 }
 
@@ -2199,6 +2257,30 @@ int fh_fit_collect(fh_ctx *c, int ticket, double *mu, double *p, int *niter) {
     }
     const int N = c->N;
     HIP_TRY(hipEventSynchronize(b.done));  // this fit's launch (later launches on the same stream are not waited for)
+    if (c->slot_result_host[2 * ticket + 1] == FIT_STATUS_CLUSTER) {
+        // its cluster did not assemble (or broke): the same fit on one CU, now; the control words of the slot back to zero
+        ++c->cluster_fallbacks;
+        HIP_TRY(hipMemsetAsync(s.WdT.p, 0, sizeof(double) * fh_k2_exchange_doubles(c->NP), b.stream));
+        FitLoopParams P = make_loop_params(c, FIT_MODE_FULL, b.alpha, b.p0, b.tol, b.max_iter);
+        const FitSlot &s0 = c->slots[0];
+        P.A = s0.Aq.p;
+        P.bq = s0.bq.p;
+        P.band_lu = s0.band_lu.p;
+        P.C = s0.Cq.p;
+        P.W = s0.Wq.p;
+        P.WdT = s0.WdT.p;
+        P.cs = s0.cs.p;
+        P.mu_out = s0.mu_out.p;
+        P.p_out = s0.p_out.p;
+        P.result = s0.result.p;
+        P.slot_stride = c->slot_stride;
+        for (int i = 0; i < FIT_MAX_BATCH / 8; ++i) P.slot_words[i] = 0;
+        P.slot_words[0] = (unsigned long long)ticket;
+        P.out_host = c->slot_out_host;
+        P.result_host = c->slot_result_host;
+        HIP_TRY(fh_k2_launch_loop_slots(P, 1, b.stream));
+        HIP_TRY(hipStreamSynchronize(b.stream));
+    }
     const int result[2] = {c->slot_result_host[2 * ticket], c->slot_result_host[2 * ticket + 1]};
     const double *out = c->slot_out_host + (size_t)ticket * 2 * N;
     if (mu) memcpy(mu, out, sizeof(double) * N);
@@ -2210,6 +2292,13 @@ int fh_fit_collect(fh_ctx *c, int ticket, double *mu, double *p, int *niter) {
     if (niter) *niter = result[0];
     if (result[1] == FIT_STATUS_BAD_P) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (non-positive or NaN)");
     if (result[1] == FIT_STATUS_NOT_SPD) return fail(FH_ERR_NOT_SPD, "Cholesky of the posterior precision failed");
+    return FH_OK;
+}
+
+int fh_fit_cluster_info(fh_ctx *c, int *workgroups, int64_t *fallbacks) {
+    if (!c) return fail(FH_ERR_INVALID, "fh_fit_cluster_info: NULL argument");
+    if (workgroups) *workgroups = c->last_fit_cluster;
+    if (fallbacks) *fallbacks = (int64_t)c->cluster_fallbacks;
     return FH_OK;
 }
 

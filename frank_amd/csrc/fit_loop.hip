@@ -219,13 +219,176 @@ __device__ __forceinline__ void inverse_tile(const gdouble *Cu, const double *dl
     if (rg == 0) cs_IJ[lane & 15] = ssq;
 }
 
+// ---- cluster ("latency") mode: the block columns of the inverse on helper workgroups ---------------------------------------
+// One fit on one CU is a chain: factor-and-invert of a diagonal tile, the column tiles, a barrier -- 19 times per pass -- with
+// the trailing update and the rows of the inverse filling the time in between; half of a pass's matrix instructions (1 311 of
+// 2 622 tile products at N = 300) are the inverse W = L^-1, which nothing inside the factorisation waits for.  Column J of W
+// (the tiles W_JJ, W_{J+1,J}, ..) depends on L and on ITSELF only: W_rJ = -X_rr sum_{K=J}^{r-1} L_rK W_KJ.  So in cluster mode
+// `cluster - 1` helper workgroups of the same XCD (one L2) take the columns, ONE WAVE PER COLUMN, no barrier anywhere: a wave
+// waits for the first workgroup's progress word (row r of L is final when column r - 1 is: value r; X_rr: value r + 1), adds up
+// the products of its tile -- the same products in the same order as inverse_tile: the same bits --, multiplies by X_rr when
+// that is published, keeps the column's sum of squares (Tr2) and the entry of row N (m = Y mu) and hands them over at the end of
+// the pass.  The first workgroup publishes once per step: every wave waits for its stores (s_waitcnt vmcnt(0): the barrier
+// itself only waits for LDS), thread 0 raises the word behind the barrier with an agent-scope store -- executed in the L2 the
+// helpers share --, and a helper invalidates its L1 when it has seen the value it needs.  Workgroup ids 0, 8, 16, .. of a
+// launch go to one XCD; the XCC_ID register of every member is checked at start-up and a cluster that is not on one XCD, or
+// whose helpers do not show up within 200 us, ends with FIT_STATUS_CLUSTER (the host runs the fit on one CU then).  Every wait
+// is bounded by the wall clock.
+namespace clu {
+enum { PROG = 0, DONE = 1, IN = 2, XCC = 3, NCTL = 8 };  // control words (ints): zero between fits
+__device__ __forceinline__ int ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int add(int *p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf; }  // HW_REG_XCC_ID
+constexpr long long kTicksPerUs = 100;  // wall_clock64: 100 MHz
+__device__ __forceinline__ int *ctl_of(const FitLoopParams &P) { return reinterpret_cast<int *>(P.WdT + 2 * (size_t)P.NP); }
+// one wave: wait until the progress word reaches `need`; false: the fit is over (word < 0) or nothing was heard for 2 s
+__device__ __forceinline__ bool wait_prog(const int *ctl, int need, int &seen) {
+    if (seen >= need) return true;
+    const long long t0 = wall_clock64();
+    for (;;) {
+        const int v = __builtin_amdgcn_readfirstlane(ld(ctl + PROG));
+        if (v < 0) return false;
+        if (v >= need) {
+            seen = v;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (L1 invalidation: the tiles are rewritten every pass)
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > 2000000 * kTicksPerUs) return false;
+    }
+}
+// sum_{K=J}^{r-1} L_rK W_KJ: the chain of inverse_tile (same ring of hand-issued loads, same order of summation)
+__device__ __forceinline__ v4f64 chain_sum(const gdouble *Cu, const gdouble *Wu, int r, int J, int nb, int lane) {
+    const unsigned blk = (unsigned)(nb * 2048);
+    const unsigned oa = (unsigned)((J * nb + r) * 2048), ob = (unsigned)((J * nb + J) * 2048);
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    struct Operands {
+        v2f64 alo, ahi, blo, bhi;
+    };
+    const int n = r - J;
+    const unsigned lane_o = (unsigned)lane * 16u;
+    auto issue = [&](Operands &o, int p) {
+        const unsigned pa = oa + (unsigned)p * blk + lane_o, pb = ob + (unsigned)p * blk + lane_o;
+        asm volatile(
+            "global_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %4, %6 offset:1024\n\t"
+            "global_load_dwordx4 %2, %5, %7\n\tglobal_load_dwordx4 %3, %5, %7 offset:1024"
+            : "=&v"(o.alo), "=&v"(o.ahi), "=&v"(o.blo), "=&v"(o.bhi)
+            : "v"(pa), "v"(pb), "s"(Cu), "s"(Wu)
+            : "memory");
+    };
+    auto consume = [&](Operands &o, int p) {
+        if (p + 1 < n) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(o.alo), "+v"(o.ahi), "+v"(o.blo), "+v"(o.bhi));
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.alo[0], o.blo[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.alo[1], o.blo[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.ahi[0], o.bhi[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.ahi[1], o.bhi[1], acc, 0, 0, 0);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the count below is of THESE loads: nothing of the wave's own in flight)
+    Operands s0, s1;
+    issue(s0, 0);
+    for (int p = 0;; p += 2) {
+        if (p + 1 < n) issue(s1, p + 1);
+        consume(s0, p);
+        if (p + 1 >= n) break;
+        if (p + 2 < n) issue(s0, p + 2);
+        consume(s1, p + 1);
+        if (p + 2 >= n) break;
+    }
+    return acc;
+}
+// the columns J = hw, hw + T, .. of W = L^-1 for every pass of the fit, by ONE wave (hw: index of the wave among the T helper waves)
+template <int CMAX>
+__device__ __forceinline__ void helper_wave(const FitLoopParams &P, int *ctl, int hw, int T, int lane) {
+    const int N = P.N, nb = P.NP / 16;
+    const int cl = lane & 15, rg = lane >> 4;
+    const gdouble *Cg = as_global(uniform_ptr(const_cast<const double *>(P.C)));
+    gdouble *Wg = as_global(uniform_ptr(P.W));
+    double *xg = P.WdT;
+    const int aug_tile = N / 16, aug_r = N - 16 * aug_tile;
+    int seen = 0;
+    if (hw >= nb) {  // no column: wait for the end of the fit (the workgroup leaves together)
+        while (wait_prog(ctl, 0x7fffffff, seen)) {
+        }
+        return;
+    }
+    Frag ident;  // B operand: the identity
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ident.v[q] = (4 * q + rg == cl) ? 1.0 : 0.0;
+    for (int seq = 1;; ++seq) {
+        double t2[CMAX];
+#pragma unroll
+        for (int i = 0; i < CMAX; ++i) t2[i] = 0.0;
+        for (int r = 0; r < nb; ++r) {
+#pragma unroll
+            for (int i = 0; i < CMAX; ++i) {
+                const int J = hw + i * T;
+                if (J > r || J >= nb) continue;
+                v4f64 w;
+                if (J == r) {
+                    if (!wait_prog(ctl, seq * 64 + r + 1, seen)) return;
+                    w = ld_pk(Cg, (unsigned)((r * nb + r) * 2048), lane);  // X_rr = W_rr
+                } else {
+                    if (!wait_prog(ctl, seq * 64 + r, seen)) return;      // row r of L (columns < r) is final
+                    const v4f64 acc = chain_sum(Cg, Wg, r, J, nb, lane);
+                    if (!wait_prog(ctl, seq * 64 + r + 1, seen)) return;  // X_rr
+                    const v4f64 xp = ld_pk(Cg, (unsigned)((r * nb + r) * 2048), lane);
+                    // the A operand X_rr (element [cl][4 q + rg]) is the accumulator layout of X_rr^T: the packed tile used AS an
+                    // A operand is X_rr^T, times the identity (exact)
+                    v4f64 z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) z = __builtin_amdgcn_mfma_f64_16x16x4f64(xp[q], ident.v[q], z, 0, 0, 0);
+                    Frag fw, fs;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        fw.v[q] = z[q];
+                        fs.v[q] = acc[q];
+                    }
+                    w = v4f64{0.0, 0.0, 0.0, 0.0};
+                    w = mfma4(fw, fs, w, true);
+                }
+                st_pk(Wg, (unsigned)((r * nb + J) * 2048), lane, w);
+                double ssq = 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (16 * r + rg + 4 * q < N) ssq = fma(w[q], w[q], ssq);
+                ssq += __shfl_xor(ssq, 16);
+                ssq += __shfl_xor(ssq, 32);
+                t2[i] += ssq;  // (rows in order, from 0.0: the sum solve_posterior forms from the tiles' column sums)
+                if (r == aug_tile) {  // row N of W: -m
+                    double mv = w[0];
+                    mv = (aug_r >> 2) == 1 ? w[1] : mv;
+                    mv = (aug_r >> 2) == 2 ? w[2] : mv;
+                    mv = (aug_r >> 2) == 3 ? w[3] : mv;
+                    if (rg == (aug_r & 3) && 16 * J + cl < N) xg[P.NP + 16 * J + cl] = -mv;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CMAX; ++i) {
+            const int J = hw + i * T;
+            if (J < nb && rg == 0 && 16 * J + cl < N) xg[16 * J + cl] = t2[i];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have reached the L2 before the count says so
+        if (lane == 0) add(ctl + DONE, 1);
+    }
+}
+}  // namespace clu
+
 // ---- one posterior solve: C = A + diag(1/p) -> L -> W = L^-1 -> y = W b, m = W^T y, tr2 = colnorm2(W) --------------
 // Storage: C strictly-upper blocks = L^T (the mirror tiles (K, I) = L_IK^T: what the inverse reads); the lower tiles of C
 // hold the trailing matrix in progress, every tile TRANSPOSED (tile (I, J) holds T_IJ^T: the update swaps its operands, and
 // the tiles of column k + 1 are then the B operands of D = L_{k+1,k+1}^-1 T^T as they stand -- no transposition on the
 // way into the panel); W lower = L^-1.  A, C and W are stored as PACKED tiles (tile_chol.h): two contiguous 1 KB accesses.
-template <bool WIDE>
-__device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Smem &S) {
+// CLM: 0 one workgroup does everything; 1, 2: cluster mode (the rows of the inverse on the helper workgroups, clu::), with
+// every wave but the chain's on the trailing update (1) or with the two waves that share the chain's SIMD sitting out (2);
+// seq: number of this solve within the fit (the helpers count the passes the same way)
+template <bool WIDE, int CLM>
+__device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Smem &S, int seq) {
+    constexpr bool CL = CLM != 0;
+    constexpr int NWKc = CLM == 2 ? NW - NW / 4 : NWK;  // trailing-update workers
     const int N = P.N, NP = P.NP, nb = P.NP / 16, ld = P.NP;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
     const int cl = lane & 15, rg = lane >> 4;
@@ -265,7 +428,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             if (rg + 4 * r == cl) t0[r] += pinv[cl];
         const bool ok = chol_inv_tile_acc(t0, x0, lane, aug_tile == 0 ? aug_c : -1);
         if (!ok && lane == 0) *S.flag = 1;
-        store_factored_tile(t0, x0, nullptr, ld, S.dli, nullptr, nullptr, cs_ptr(0, 0), rows_valid(0), lane);  // L_00^-1 -> dli[0]
+        store_factored_tile(t0, x0, nullptr, ld, S.dli, nullptr, nullptr, CL ? nullptr : cs_ptr(0, 0), rows_valid(0), lane);  // L_00^-1 -> dli[0]
         st_pk(as_global(W), 0u, lane, x0);  // W_00
     }
     __syncthreads();
@@ -300,7 +463,11 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             }
         }
     }
+    int *const ctl = CL ? clu::ctl_of(P) : nullptr;
+    if constexpr (CL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the barrier waits for LDS only)
     __syncthreads();
+    if constexpr (CL)
+        if (tid == 0) clu::st(ctl + clu::PROG, seq * 64 + 1);  // column 0 of L and X_00 are final
     TSTAMP(2);
     const gdouble *C_inv = as_global(uniform_ptr(C));
     gdouble *W_inv = as_global(uniform_ptr(W));
@@ -356,8 +523,8 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 const bool ok = chol_inv_tile_acc(a, xi, lane, aug_tile == k + 1 ? aug_c : -1);
                 if (!ok && lane == 0) *S.flag = 1;
                 FSTAMP(9);
-                store_factored_tile(a, xi, nullptr, ld, S.dli + ((k + 1) & 1) * 16 * PS, nullptr, nullptr, cs_ptr(k + 1, k + 1),
-                                    rows_valid(k + 1), lane);
+                store_factored_tile(a, xi, nullptr, ld, S.dli + ((k + 1) & 1) * 16 * PS, nullptr, nullptr,
+                                    CL ? nullptr : cs_ptr(k + 1, k + 1), rows_valid(k + 1), lane);
                 st_pk(as_global(uniform_ptr(W)), base_pk, lane, xi);  // W_{k+1,k+1}
                 // L_{k+1,k+1}^-1 is in LDS: the waves holding tiles of column k + 1 may now turn them into panel k + 1
                 __hip_atomic_store(&S.flag[3], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -365,10 +532,13 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 TRACE(5);
             }
             if constexpr (WIDE) __syncthreads();  // (everybody has read panel k: the column tiles may overwrite it)
-            inverse_columns();
+            if constexpr (!CL) inverse_columns();
             TRACE(4);
+        } else if (CLM == 2 && (wave & 3) == (kChain & 3)) {
+            // cluster mode 2: the waves on the chain's SIMD leave its double-precision units to the factor-and-invert chain
+            if constexpr (WIDE) __syncthreads();
         } else {
-            const int widx = wave < kChain ? wave : wave - 1;  // 0..NWK-1
+            const int widx = CLM == 2 ? wave - (wave >> 2) - ((wave & 3) > (kChain & 3) ? 1 : 0) : (wave < kChain ? wave : wave - 1);  // 0..NWKc-1
 #ifdef FIT_LOOP_TIMING
             long long w_last = clock64();
 #endif
@@ -399,48 +569,48 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 a = upd(t.y, t.z, a);
                 st_pk(C_u, base_pk + (t.w & ~2047u), lane, a);
             };
-            int e = widx;  // every NWK-th tile of the enumeration
+            int e = widx;  // every NWKc-th tile of the enumeration
             if (e < cntA) {
                 uint4 ta = S.rec[e], tb = ta, tc = ta;
                 v4f64 a = ldt(ta), b = a, c = a;
-                if (e + NWK < cntA) {
-                    tb = S.rec[e + NWK];
+                if (e + NWKc < cntA) {
+                    tb = S.rec[e + NWKc];
                     b = ldt(tb);
                 }
                 for (;;) {
                     // sets in flight: a (current), b (next); c is free
-                    if (e + 2 * NWK < cntA) {
-                        tc = S.rec[e + 2 * NWK];
+                    if (e + 2 * NWKc < cntA) {
+                        tc = S.rec[e + 2 * NWKc];
                         c = ldt(tc);
                     }
                     fin(ta, a);
-                    if (e + NWK >= cntA) break;
-                    if (e + 3 * NWK < cntA) {
-                        ta = S.rec[e + 3 * NWK];
+                    if (e + NWKc >= cntA) break;
+                    if (e + 3 * NWKc < cntA) {
+                        ta = S.rec[e + 3 * NWKc];
                         a = ldt(ta);
                     }
                     fin(tb, b);
-                    if (e + 2 * NWK >= cntA) break;
-                    if (e + 4 * NWK < cntA) {
-                        tb = S.rec[e + 4 * NWK];
+                    if (e + 2 * NWKc >= cntA) break;
+                    if (e + 4 * NWKc < cntA) {
+                        tb = S.rec[e + 4 * NWKc];
                         b = ldt(tb);
                     }
                     fin(tc, c);
-                    if (e + 3 * NWK >= cntA) break;
-                    e += 3 * NWK;
+                    if (e + 3 * NWKc >= cntA) break;
+                    e += 3 * NWKc;
                 }
             }
             WSTAMP(11);
             TRACE(1);
             // ---- column k + 1: update, then the panel of step k + 1 straight from the registers ----
             // (the round-robin deal of the tiles goes on where the enumeration above stopped)
-            int cfirst = widx - cntA % NWK;
-            if (cfirst < 0) cfirst += NWK;
-            constexpr int kColMax = 4;  // (WIDE: ncol <= 38 <= 4 x NWK)
+            int cfirst = widx - cntA % NWKc;
+            if (cfirst < 0) cfirst += NWKc;
+            constexpr int kColMax = CLM == 2 ? 5 : 4;  // (WIDE: ncol <= 38 <= kColMax x NWKc)
             v4f64 dcol[WIDE ? kColMax : 1];
             if (cfirst < ncol) {
                 // L_{k+1,k+1}^-1 comes from wave 0's chain (~5 us into the step): inverse columns fill the wait
-                if (k >= 1) {
+                if (k >= 1 && !CL) {
                     int spins = 0;
                     while (__hip_atomic_load(&S.flag[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) {
                         if (!inverse_one()) {
@@ -466,7 +636,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
 #pragma unroll
                 for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[((k + 1) & 1) * 16 * PS + cl * PS + 4 * q + rg];
                 if constexpr (!WIDE) {
-                    for (int c = cfirst; c < ncol; c += NWK) {
+                    for (int c = cfirst; c < ncol; c += NWKc) {
                         const int i = c + 1;  // block row I = k + 1 + i
                         v4f64 t = ld_pk(src_u, base_pk + (unsigned)(k == 0 ? i * 2048 : i * nb * 2048), lane);
                         t = upd(0u, (unsigned)(i * 16 * PS * 8), t);  // T^T = C_{I,k+1}^T - L_{k+1,k} L_Ik^T: the tile is kept transposed
@@ -485,7 +655,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                     // one panel: the tiles stay in registers until everybody has read panel k (the barrier below)
 #pragma unroll
                     for (int u = 0; u < kColMax; ++u) {
-                        const int c = cfirst + u * NWK;
+                        const int c = cfirst + u * NWKc;
                         if (c < ncol) {
                             const int i = c + 1;
                             v4f64 t = ld_pk(src_u, base_pk + (unsigned)(k == 0 ? i * 2048 : i * nb * 2048), lane);
@@ -503,7 +673,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 __syncthreads();
 #pragma unroll
                 for (int u = 0; u < kColMax; ++u) {
-                    const int c = cfirst + u * NWK;
+                    const int c = cfirst + u * NWKc;
                     if (c < ncol) {
                         const int i = c + 1;
                         st_pk(C_u, base_pk + (unsigned)(i * 2048), lane, dcol[u]);
@@ -514,15 +684,44 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 }
             }
             TRACE(3);
-            inverse_columns();
+            if constexpr (!CL) inverse_columns();
             TRACE(4);
             WSTAMP(12);
         }
+        if constexpr (CL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's tiles are in the L2 the helpers read
         __syncthreads();
+        if constexpr (CL)
+            if (tid == 0 && m > 0) clu::st(ctl + clu::PROG, seq * 64 + k + 2);  // columns <= k + 1 of L and X_{k+1,k+1} are final
         TSTAMP(3);
     }
     if (*S.flag) return false;
     TSTAMP(4);
+
+    if constexpr (CL) {
+        // Tr2 and m = Y mu come from the helper waves that own the block columns of W (exchange area: the fit's WdT buffer)
+        const int T = (P.cluster - 1) * NW, nsig = T < nb ? T : nb;
+        if (tid == 0) {
+            const long long t0 = wall_clock64();
+            while (clu::ld(ctl + clu::DONE) < seq * nsig) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 1000000 * clu::kTicksPerUs) {  // 1 s: the helpers are gone
+                    S.flag[0] = 2;
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (*S.flag) return false;
+        const double *xg = P.WdT;
+        for (int i = tid; i < N; i += KT) {
+            S.tr2[i] = xg[i];
+            S.m[i] = xg[NP + i];
+        }
+        __syncthreads();
+        TSTAMP(7);
+        return true;
+    }
 
     // (5) m = -(row N of W),  tr2_i = sum over the block column of the tile column sums (fixed order)
     for (int i = tid; i < N; i += KT) {
@@ -545,10 +744,20 @@ template <bool WIDE> constexpr int scan_rows() { return WIDE ? 10 : 6; }  // row
 using bandscan::scan_solve;
 using bandscan::scan_tables;
 
-template <bool WIDE>
+template <bool WIDE, int CLM>
 __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_fit;
+    constexpr bool CL = CLM != 0;
+    // cluster mode: workgroup b sits on XCD b & 7 (ids go round the XCDs) as the (b >> 3)-th of the launch there; the members of
+    // a fit are `cluster` consecutive ones of ONE XCD: fit (i / cluster) * 8 + x of the launch, member i % cluster
+    int launch_index = blockIdx.x, member = 0;
+    if constexpr (CL) {
+        const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        launch_index = (i / P.cluster) * 8 + x;
+        member = i % P.cluster;
+        if (launch_index >= P.nfits) return;
+    }
     const FitLoopParams P0 = P;
     // batched launch: the workgroups pull fit indices from a counter (fits of a sweep differ ~20x in iteration count)
     for (;;) {
@@ -575,7 +784,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     if (P.slot_stride) {
         // (constant indices only: a dynamic index into the by-value parameter struct forces the WHOLE struct into scratch
         // memory, every later P.field a scratch load and the prologue 256 bytes of scratch stores)
-        const int g = blockIdx.x >> 3;  // (uniform selects between constant indices)
+        const int g = launch_index >> 3;  // (uniform selects between constant indices)
         unsigned long long wsel = P.slot_words[0];
         if (g == 1) wsel = P.slot_words[1];
         if (g == 2) wsel = P.slot_words[2];
@@ -592,7 +801,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         if (g == 13) wsel = P.slot_words[13];
         if (g == 14) wsel = P.slot_words[14];
         if (g == 15) wsel = P.slot_words[15];
-        const int sl = (int)((wsel >> (8 * (blockIdx.x & 7))) & 0xffull);
+        const int sl = (int)((wsel >> (8 * (launch_index & 7))) & 0xffull);
         const size_t off = (size_t)sl * P.slot_stride;
         P.A += off;
         P.bq += off;
@@ -613,6 +822,20 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     }
     const int N = P.N, NP = P.NP;
     const int tid = threadIdx.x;
+    int *const ctl = CL ? clu::ctl_of(P) : nullptr;
+    if constexpr (CL) {
+        if (member > 0) {  // a helper workgroup: its waves own block columns of the inverse (clu::helper_wave)
+            if (tid == 0) {
+                __hip_atomic_fetch_or(ctl + clu::XCC, 1 << clu::xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                clu::add(ctl + clu::IN, 1);
+            }
+            const int hwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            clu::helper_wave<WIDE ? 4 : 2>(P, ctl, (member - 1) * NW + hwave, (P.cluster - 1) * NW, tid & 63);
+            __syncthreads();
+            if (tid == 0) clu::add(ctl + clu::IN, -1);
+            return;
+        }
+    }
     Smem S;
     S.pan = smem;
     S.dli = S.pan + npanels<WIDE>() * NP * PS;
@@ -646,7 +869,38 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         S.rec[e] = make_uint4((unsigned)((j * (NP / 16) + i) * 2048) | (i == j ? 2u : 0u), (unsigned)(j * 16 * PS * 8),
                               (unsigned)(i * 16 * PS * 8), (unsigned)((i * (NP / 16) + j) * 2048) | (unsigned)i);
     }
-    __shared__ int s_ctl[4];  // [0] stop, [1] status
+    __shared__ int s_ctl[4];  // [0] stop, [1] status, [2] cluster assembled
+    if constexpr (CL) {
+        // the helpers have 200 us to show up, all on this XCD; otherwise the fit ends with FIT_STATUS_CLUSTER (the host runs
+        // it on one CU) and helpers that arrive later find the word negative and leave
+        if (tid == 0) {
+            const long long t0 = wall_clock64();
+            int ok = 1;
+            while (clu::ld(ctl + clu::IN) < P.cluster - 1) {
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() - t0 > 200 * clu::kTicksPerUs) {
+                    ok = 0;
+                    break;
+                }
+            }
+            const int xccs = clu::ld(ctl + clu::XCC) | (1 << clu::xcc_id());
+            if (xccs & (xccs - 1)) ok = 0;
+            if (!ok) clu::st(ctl + clu::PROG, -1);
+            s_ctl[2] = ok;
+        }
+        __syncthreads();
+        if (!s_ctl[2]) {
+            if (tid == 0) {
+                P.result[0] = 0;
+                P.result[1] = FIT_STATUS_CLUSTER;
+                if (P.result_host) {
+                    P.result_host[0] = 0;
+                    P.result_host[1] = FIT_STATUS_CLUSTER;
+                }
+            }
+            return;
+        }
+    }
 
     if (P.band_lu)
         for (int i = tid; i < 5 * NP; i += KT) {  // five bands of NP entries (padding: unit pivots, zero bands) + reciprocal pivots
@@ -670,7 +924,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         s_ctl[1] = 0;
     }
     __syncthreads();
-    int status = 0, count = 0;
+    int status = 0, count = 0, nsolve = 0;
     // One call site for the posterior solve.  phase 0: p = 1 (radial_fitters.py:744-747); phase 1: power-law
     // guess (:749-752); phase 2: the loop of :769-785 (FIT_MODE_STEP: exactly one pass, FIT_MODE_SOLVE: none).
     int phase = (P.mode == FIT_MODE_FULL) ? 0 : 2;
@@ -683,8 +937,8 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
 #ifdef FIT_LOOP_TIMING
         P.trace_on = (count == 5);
 #endif
-        if (!solve_posterior<WIDE>(P, S)) {
-            status = FIT_STATUS_NOT_SPD;
+        if (!solve_posterior<WIDE, CLM>(P, S, ++nsolve)) {
+            status = (CL && S.flag[0] == 2) ? FIT_STATUS_CLUSTER : FIT_STATUS_NOT_SPD;
             break;
         }
         if (phase == 0) {
@@ -862,6 +1116,31 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         P.p_out[i] = S.p[i];
         if (P.out_host) P.out_host[N + i] = S.p[i];
     }
+    if constexpr (CL) {
+        // the helpers leave on a negative word; when the last of them has gone the control words go back to zero (the state the
+        // next fit on these buffers expects).  A cluster that broke (FIT_STATUS_CLUSTER) is cleaned up by the host.
+        if (tid == 0) {
+            clu::st(ctl + clu::PROG, -1);
+            if (status != FIT_STATUS_CLUSTER) {
+                const long long t0 = wall_clock64();
+                bool gone = true;
+                while (clu::ld(ctl + clu::IN) > 0) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() - t0 > 1000000 * clu::kTicksPerUs) {
+                        gone = false;
+                        break;
+                    }
+                }
+                if (gone) {
+                    clu::st(ctl + clu::DONE, 0);
+                    clu::st(ctl + clu::XCC, 0);
+                    clu::st(ctl + clu::PROG, 0);
+                } else {
+                    status = FIT_STATUS_CLUSTER;
+                }
+            }
+        }
+    }
     if (tid == 0) {
         P.result[0] = count;
         P.result[1] = status;
@@ -932,23 +1211,31 @@ static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s)
         return hipGetLastError();
     }
     // the attribute per launch (cheap): it is per device, and contexts on several devices share this code
-    if (loop_is_wide(P.NP)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    auto go = [&](auto kernel, const FitLoopParams &Q, int grid) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fit_loop_kernel<true>, dim3(blocks), dim3(KT), smem, s, P);
-    } else {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fit_loop_kernel<false>, dim3(blocks), dim3(KT), smem, s, P);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(KT), smem, s, Q);
+        return hipGetLastError();
+    };
+    if (P.cluster > 1) {
+        // cluster mode: `blocks` fits, P.cluster workgroups each, the members of a fit on one XCD (see the kernel)
+        if (P.cluster > FIT_CLUSTER_MAX || P.batch) return hipErrorInvalidValue;
+        FitLoopParams Q = P;
+        Q.nfits = blocks;
+        const int grid = 8 * P.cluster * ((blocks + 7) / 8);
+        const char *we = getenv("FRANK_AMD_K2_CL_WORKERS");  // development: 9 idles the waves on the chain's SIMD
+        const int workers = we ? atoi(we) : 11;
+        if (loop_is_wide(P.NP)) return workers == 9 ? go(&fit_loop_kernel<true, 2>, Q, grid) : go(&fit_loop_kernel<true, 1>, Q, grid);
+        return workers == 9 ? go(&fit_loop_kernel<false, 2>, Q, grid) : go(&fit_loop_kernel<false, 1>, Q, grid);
     }
-    return hipGetLastError();
+    if (loop_is_wide(P.NP)) return go(&fit_loop_kernel<true, 0>, P, blocks);
+    return go(&fit_loop_kernel<false, 0>, P, blocks);
 }
 
 hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s) { return launch_loop(P, batch, s); }
 hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s) { return launch_loop(P, 1, s); }
 hipError_t fh_k2_launch_loop_slots(const FitLoopParams &P, int nslots, hipStream_t s) { return launch_loop(P, nslots, s); }
+size_t fh_k2_exchange_doubles(int NP) { return (size_t)NP * 16; }  // >= 2 NP + the control words (clu::NCTL ints)
 
 hipError_t fh_k2_launch_symmetrize(const double *Araw, const double *bq, int N, int NP, double *A, hipStream_t s) {
     hipLaunchKernelGGL(symmetrize_pad_kernel, dim3(128), dim3(256), 0, s, Araw, bq, N, NP, A);

@@ -191,7 +191,7 @@ hipError_t fh_k2_launch_pinv_scale(const double *s, int n, double *s1, hipStream
 
 // ---- K2 v2: single persistent kernel (fit_loop.hip) ---------------------------------------------------------
 enum { FIT_MODE_FULL = 0, FIT_MODE_STEP = 1, FIT_MODE_SOLVE = 2 };
-enum { FIT_STATUS_OK = 0, FIT_STATUS_BAD_P = 1, FIT_STATUS_NOT_SPD = 2 };
+enum { FIT_STATUS_OK = 0, FIT_STATUS_BAD_P = 1, FIT_STATUS_NOT_SPD = 2, FIT_STATUS_CLUSTER = 3 };
 
 struct FitLoopParams {
     int N, NP, max_iter, mode;
@@ -224,13 +224,22 @@ struct FitLoopParams {
     // stream): [mu (N), p (N)] and [count, status] per slot, strides 2 N doubles / 2 ints; NULL: none
     double *out_host;
     int *result_host;
+    // cluster ("latency") mode, fit_loop.hip: `cluster` workgroups of ONE XCD per fit -- the first runs the loop and the
+    // factorisation, the others the block columns of the inverse (one wave per column, no barriers), handed over through a
+    // progress word in global memory.  The exchange area is the fit's WdT buffer: [0, NP) Tr2, [NP, 2 NP) m = Y mu from the
+    // helpers, then the control words (ints, zero between fits: the first workgroup leaves them so).  Workgroup b of the
+    // launch: XCD x = b & 7, index i = b >> 3 on it; fit (i / cluster) * 8 + x of the launch, member i % cluster.
+    int cluster;            // 0 / 1: none
+    int nfits;              // fits of a cluster launch (slot launch: entries of slot_words; single fit: 1)
 };
 #define FIT_MAX_BATCH 128
+#define FIT_CLUSTER_MAX 8
 
 size_t fh_k2_loop_smem_bytes(int NP);
 int fh_k2_loop_max_np();  // largest padded size NP the persistent fit loop covers (640: N <= 639)
-hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s);
-hipError_t fh_k2_launch_loop_slots(const FitLoopParams &P, int nslots, hipStream_t s);
+hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s);        // P.cluster > 1: one fit on a cluster
+hipError_t fh_k2_launch_loop_slots(const FitLoopParams &P, int nslots, hipStream_t s);  // P.cluster > 1: every fit on one
+size_t fh_k2_exchange_doubles(int NP);  // doubles of a fit's WdT buffer (exchange area of the cluster mode)
 hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s);
 hipError_t fh_k2_launch_symmetrize(const double *Araw, const double *bq, int N, int NP, double *A, hipStream_t s);
 

@@ -228,6 +228,14 @@ int fh_fit_slots(void);
 int fh_fit_submit(fh_ctx *ctx, double alpha, double p0, double wsmooth, double tol, int max_iter, int *ticket);
 int fh_fit_flush(fh_ctx *ctx);
 int fh_fit_collect(fh_ctx *ctx, int ticket, double *mu, double *p, int *niter);
+/* Cluster ("latency") mode of the fit loop.  A fit whose pipeline is shallow -- fh_fit_normal on an idle context, the first
+ * launches of a pipeline -- runs on `workgroups` compute units of one XCD instead of one: the first factors the posterior
+ * precision and runs the loop (GaussianModel._fit, statistical_models.py:732-760; filter.py:154-181), the others form the
+ * block columns of the inverse of the factor that Tr2 and the mean need (one wave per column); the arithmetic of every tile
+ * is the one the single-workgroup kernel does, so the results are the same bits.  FRANK_AMD_K2_CLUSTER = 1 turns the mode
+ * off, 2 .. 8 set the size (default 3).  *workgroups: what the last fh_fit_normal ran on; *fallbacks: cluster launches of this
+ * context that did not assemble on one XCD within 200 us and were repeated on one compute unit (either may be NULL).     */
+int fh_fit_cluster_info(fh_ctx *ctx, int *workgroups, int64_t *fallbacks);
 
 /* Batched form for hyper-parameter sweeps over ONE mapping (fit.py:534-548 re-runs the whole fit per (alpha,
  * w_smooth) point although M, j do not depend on them): `batch` fits of the same M, j (host, or NULL for the
