@@ -143,6 +143,10 @@ __device__ __forceinline__ void inverse_tile(const gdouble *Cu, const double *dl
     auto issue = [&](Operands &r, int p) {
         const unsigned pa = oa + (unsigned)p * blk + lane_o, pb = ob + (unsigned)p * blk + lane_o;
         asm volatile(
+            // (s_nop: a base pointer the compiler has just restored from a spill lane with v_readlane needs five wait states before
+            //  a memory instruction may read it as its scalar address, and the hazard recogniser does not look into inline asm --
+            //  a timing build that spilled scalar registers here faulted on exactly that)
+            "s_nop 4\n\t"
             "global_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %4, %6 offset:1024\n\t"
             "global_load_dwordx4 %2, %5, %7\n\tglobal_load_dwordx4 %3, %5, %7 offset:1024"
             : "=&v"(r.alo), "=&v"(r.ahi), "=&v"(r.blo), "=&v"(r.bhi)
@@ -235,13 +239,33 @@ __device__ __forceinline__ void inverse_tile(const gdouble *Cu, const double *dl
 // whose helpers do not show up within 200 us, ends with FIT_STATUS_CLUSTER (the host runs the fit on one CU then).  Every wait
 // is bounded by the wall clock.
 namespace clu {
-enum { PROG = 0, DONE = 1, IN = 2, XCC = 3, NCTL = 8 };  // control words (ints): zero between fits
+// control words (ints), zero between fits: PROG progress of the factorisation, DONE helper waves that have handed over their
+// columns, IN helper workgroups present, XCC the XCDs the members sit on; HCOL + J: trailing tiles of block column J the helpers
+// have handed back (cumulative over the passes)
+enum { PROG = 0, DONE = 1, IN = 2, XCC = 3, HCOL = 8, NCTL = 8 + 40 };
+// exchange area (the fit's WdT buffer): [0, NP) Tr2 and [NP, 2 NP) m from the helpers, [2 NP, 3 NP) 1 / p from the first
+// workgroup, then the control words
+constexpr int kBand = 2;    // block columns right of the panel the first workgroup updates itself (see trailing_wave)
+constexpr int kTMax = 10;   // trailing tiles a helper wave keeps in registers at most
+// Members of a cluster: 0 the first workgroup, 1 .. inv the helpers of the inverse, inv + 1 .. cluster - 1 the helpers of the
+// trailing update.  A wave that held trailing tiles AND ran the load ring of an inverse column spilled both to scratch memory
+// (the spill traffic counts in the ring's hand-written waits): 20 us behind the factorisation at the end of a pass.
+__device__ __forceinline__ int inv_helpers(const FitLoopParams &P) { return P.cluster_inv; }
+__device__ __forceinline__ int trail_helpers(const FitLoopParams &P) { return P.cluster - 1 - P.cluster_inv; }
 __device__ __forceinline__ int ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int add(int *p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf; }  // HW_REG_XCC_ID
 constexpr long long kTicksPerUs = 100;  // wall_clock64: 100 MHz
-__device__ __forceinline__ int *ctl_of(const FitLoopParams &P) { return reinterpret_cast<int *>(P.WdT + 2 * (size_t)P.NP); }
+__device__ __forceinline__ int *ctl_of(const FitLoopParams &P) { return reinterpret_cast<int *>(P.WdT + 3 * (size_t)P.NP); }
+// block columns the first workgroup updates itself at every step; the tiles further right belong to the helper waves until
+// their column enters the band.  nb (everything) when the helper waves cannot hold the tiles (few helpers, wide systems).
+__device__ __forceinline__ int band_of(const FitLoopParams &P) {
+    const int nb = P.NP / 16, T = trail_helpers(P) * NW;
+    const int first = 2 + kBand, cols = nb - first;
+    const int ntl = cols > 0 ? cols * (cols + 1) / 2 : 0;
+    return (ntl > 0 && ntl <= kTMax * T) ? kBand : nb;
+}
 // one wave: wait until the progress word reaches `need`; false: the fit is over (word < 0) or nothing was heard for 2 s
 __device__ __forceinline__ bool wait_prog(const int *ctl, int need, int &seen) {
     if (seen >= need) return true;
@@ -258,19 +282,22 @@ __device__ __forceinline__ bool wait_prog(const int *ctl, int need, int &seen) {
         if (wall_clock64() - t0 > 2000000 * kTicksPerUs) return false;
     }
 }
-// sum_{K=J}^{r-1} L_rK W_KJ: the chain of inverse_tile (same ring of hand-issued loads, same order of summation)
-__device__ __forceinline__ v4f64 chain_sum(const gdouble *Cu, const gdouble *Wu, int r, int J, int nb, int lane) {
+// sum_{K=J}^{J+n-1} L_rK W_KJ: the chain of inverse_tile (same ring of hand-issued loads, same order of summation)
+__device__ __forceinline__ v4f64 chain_sum(const gdouble *Cu, const gdouble *Wu, int r, int J, int n, int nb, int lane) {
     const unsigned blk = (unsigned)(nb * 2048);
     const unsigned oa = (unsigned)((J * nb + r) * 2048), ob = (unsigned)((J * nb + J) * 2048);
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
     struct Operands {
         v2f64 alo, ahi, blo, bhi;
     };
-    const int n = r - J;
     const unsigned lane_o = (unsigned)lane * 16u;
     auto issue = [&](Operands &o, int p) {
         const unsigned pa = oa + (unsigned)p * blk + lane_o, pb = ob + (unsigned)p * blk + lane_o;
         asm volatile(
+            // (s_nop: a base pointer the compiler has just restored from a spill lane with v_readlane needs five wait states before
+            //  a memory instruction may read it as its scalar address, and the hazard recogniser does not look into inline asm --
+            //  a timing build that spilled scalar registers here faulted on exactly that)
+            "s_nop 4\n\t"
             "global_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %4, %6 offset:1024\n\t"
             "global_load_dwordx4 %2, %5, %7\n\tglobal_load_dwordx4 %3, %5, %7 offset:1024"
             : "=&v"(o.alo), "=&v"(o.ahi), "=&v"(o.blo), "=&v"(o.bhi)
@@ -278,30 +305,123 @@ __device__ __forceinline__ v4f64 chain_sum(const gdouble *Cu, const gdouble *Wu,
             : "memory");
     };
     auto consume = [&](Operands &o, int p) {
-        if (p + 1 < n) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        switch (min(3, n - 1 - p)) {  // products issued after p
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        }
         asm volatile("" : "+v"(o.alo), "+v"(o.ahi), "+v"(o.blo), "+v"(o.bhi));
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.alo[0], o.blo[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.alo[1], o.blo[1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.ahi[0], o.bhi[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.ahi[1], o.bhi[1], acc, 0, 0, 0);
     };
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the count below is of THESE loads: nothing of the wave's own in flight)
-    Operands s0, s1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the counts below are of THESE loads: nothing of the wave's own in flight)
+    // four register sets, three products in flight behind the one being multiplied: a helper wave has registers to spare, and
+    // what its column waits for in the last rows of a pass is the latency of these loads (two sets: the helpers ended ~15 us
+    // behind the factorisation)
+    Operands s0, s1, s2, s3;
     issue(s0, 0);
-    for (int p = 0;; p += 2) {
-        if (p + 1 < n) issue(s1, p + 1);
+    if (1 < n) issue(s1, 1);
+    if (2 < n) issue(s2, 2);
+    for (int p = 0;; p += 4) {
+        if (p + 3 < n) issue(s3, p + 3);
         consume(s0, p);
         if (p + 1 >= n) break;
-        if (p + 2 < n) issue(s0, p + 2);
+        if (p + 4 < n) issue(s0, p + 4);
         consume(s1, p + 1);
         if (p + 2 >= n) break;
+        if (p + 5 < n) issue(s1, p + 5);
+        consume(s2, p + 2);
+        if (p + 3 >= n) break;
+        if (p + 6 < n) issue(s2, p + 6);
+        consume(s3, p + 3);
+        if (p + 4 >= n) break;
     }
     return acc;
 }
-// the columns J = hw, hw + T, .. of W = L^-1 for every pass of the fit, by ONE wave (hw: index of the wave among the T helper waves)
+// A wave of a helper of the TRAILING UPDATE, for every pass of the fit (hw: its number among the T such waves, counted ACROSS
+// the workgroups -- wave w of helper h is number w H + h).  It owns the trailing tiles number hw, hw + T, .. of the enumeration
+// (J = 2 + band .., I = J ..) of the tiles right of the band: tile (I, J) takes the updates k = 0 .. J - 2 - band here -- in
+// REGISTERS, from the mirror tiles (k, J), (k, I) of C as they are published, the same products in the same order as the first
+// workgroup's trailing update --, goes back through memory when its column enters the band (the upper tiles of the W buffer,
+// the diagonal ones in the cs buffer) and takes its last band + 1 updates there.  An event is "column c of L is final".
+__device__ __forceinline__ void trailing_wave(const FitLoopParams &P, int *ctl, int hw, int T, int lane) {
+    const int nb = P.NP / 16;
+    const int cl = lane & 15, rg = lane >> 4;
+    const gdouble *Cg = as_global(uniform_ptr(const_cast<const double *>(P.C)));
+    const gdouble *Ag = as_global(uniform_ptr(P.A));
+    gdouble *Wg = as_global(uniform_ptr(P.W));
+    gdouble *Dg = as_global(uniform_ptr(P.cs));
+    const double *xg = P.WdT;
+    const int band = band_of(P);
+    int seen = 0;
+    int tI[kTMax], tJ[kTMax];
+    {
+        const int first = 2 + band;
+#pragma unroll
+        for (int i = 0; i < kTMax; ++i) {
+            int t = hw + i * T, J = first;
+            while (J < nb && t >= nb - J) {
+                t -= nb - J;
+                ++J;
+            }
+            tJ[i] = J < nb ? J : -1;
+            tI[i] = J + t;
+        }
+    }
+    if (tJ[0] < 0) {  // nothing to do: wait for the end of the fit (the workgroup leaves together)
+        while (wait_prog(ctl, 0x7fffffff, seen)) {
+        }
+        return;
+    }
+    for (int seq = 1;; ++seq) {
+        v4f64 tt[kTMax];
+        // first touch: tile (I, J) holds T_IJ^T, the tile (J, I) of the symmetric A (the constant of the fit: no wait)
+#pragma unroll
+        for (int i = 0; i < kTMax; ++i)
+            if (tJ[i] >= 0) tt[i] = ld_pk(Ag, (unsigned)((tJ[i] * nb + tI[i]) * 2048), lane);
+        int last = 0;  // the last event that concerns this wave
+#pragma unroll
+        for (int i = 0; i < kTMax; ++i)
+            if (tJ[i] >= 0) last = max(last, tJ[i] - 2 - band);
+        for (int c = 0; c <= last; ++c) {
+            if (!wait_prog(ctl, seq * 64 + c + 1, seen)) return;
+            int handed = 0;
+#pragma unroll
+            for (int i = 0; i < kTMax; ++i) {
+                if (tJ[i] < 0 || tJ[i] < c + 2 + band) continue;
+                if (c == 0 && tI[i] == tJ[i]) {  // diag(1 / p) (written by the first workgroup before its first word of the pass)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (rg + 4 * q == cl) tt[i][q] += xg[2 * P.NP + 16 * tI[i] + cl];
+                }
+                const v4f64 fa = ld_pk(Cg, (unsigned)((c * nb + tJ[i]) * 2048), lane);
+                const v4f64 fb = ld_pk(Cg, (unsigned)((c * nb + tI[i]) * 2048), lane);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tt[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(-fa[q], fb[q], tt[i], 0, 0, 0);
+                if (tJ[i] == c + 2 + band) {  // the column enters the band at the next step: hand the tile back
+                    if (tI[i] == tJ[i]) st_pk(Dg, (unsigned)(tJ[i] * 2048), lane, tt[i]);
+                    else st_pk(Wg, (unsigned)((tJ[i] * nb + tI[i]) * 2048), lane, tt[i]);
+                    ++handed;
+                }
+            }
+            if (handed) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) add(ctl + HCOL + c + 2 + band, handed);
+            }
+        }
+        if (!wait_prog(ctl, (seq + 1) * 64 + 1, seen)) return;  // the next pass (its first event) or the end of the fit
+    }
+}
+// A wave of a helper of the INVERSE, for every pass of the fit: the block columns J = hw, hw + T, .. of W = L^-1.  At the event
+// "column c of L and X_cc are final" it finishes row c (W_cJ = -X_cc acc1), adds the LAST product of row c + 1 from the registers
+// it has just filled (acc1 = acc2 + L_{c+1,c} W_cJ) and then, off the critical path, adds up the products K = J .. c of row c + 2
+// (acc2) -- all of them but the last, which needs W_{c+1,J}.  The sums run over K in ascending order as in inverse_tile (the same
+// bits); what is left to do after the LAST event of a pass is one tile product instead of a chain of nb - 1.
 template <int CMAX>
-__device__ __forceinline__ void helper_wave(const FitLoopParams &P, int *ctl, int hw, int T, int lane) {
+__device__ __forceinline__ void inverse_wave(const FitLoopParams &P, int *ctl, int hw, int T, int lane) {
     const int N = P.N, nb = P.NP / 16;
     const int cl = lane & 15, rg = lane >> 4;
     const gdouble *Cg = as_global(uniform_ptr(const_cast<const double *>(P.C)));
@@ -319,24 +439,28 @@ __device__ __forceinline__ void helper_wave(const FitLoopParams &P, int *ctl, in
     for (int q = 0; q < 4; ++q) ident.v[q] = (4 * q + rg == cl) ? 1.0 : 0.0;
     for (int seq = 1;; ++seq) {
         double t2[CMAX];
+        v4f64 acc1[CMAX], acc2[CMAX];
 #pragma unroll
-        for (int i = 0; i < CMAX; ++i) t2[i] = 0.0;
-        for (int r = 0; r < nb; ++r) {
+        for (int i = 0; i < CMAX; ++i) {
+            t2[i] = 0.0;
+            acc1[i] = v4f64{0.0, 0.0, 0.0, 0.0};
+            acc2[i] = v4f64{0.0, 0.0, 0.0, 0.0};
+        }
+        for (int c = hw; c < nb; ++c) {  // (the first event that concerns this wave: its first column)
+            if (!wait_prog(ctl, seq * 64 + c + 1, seen)) return;
+            const v4f64 xp = ld_pk(Cg, (unsigned)((c * nb + c) * 2048), lane);  // X_cc = W_cc
+            v4f64 la = xp;
+            if (c + 1 < nb) la = ld_pk(Cg, (unsigned)((c * nb + c + 1) * 2048), lane);  // mirror tile (c, c + 1): L_{c+1,c}
 #pragma unroll
             for (int i = 0; i < CMAX; ++i) {
                 const int J = hw + i * T;
-                if (J > r || J >= nb) continue;
+                if (J > c || J >= nb) continue;
                 v4f64 w;
-                if (J == r) {
-                    if (!wait_prog(ctl, seq * 64 + r + 1, seen)) return;
-                    w = ld_pk(Cg, (unsigned)((r * nb + r) * 2048), lane);  // X_rr = W_rr
+                if (J == c) {
+                    w = xp;
                 } else {
-                    if (!wait_prog(ctl, seq * 64 + r, seen)) return;      // row r of L (columns < r) is final
-                    const v4f64 acc = chain_sum(Cg, Wg, r, J, nb, lane);
-                    if (!wait_prog(ctl, seq * 64 + r + 1, seen)) return;  // X_rr
-                    const v4f64 xp = ld_pk(Cg, (unsigned)((r * nb + r) * 2048), lane);
-                    // the A operand X_rr (element [cl][4 q + rg]) is the accumulator layout of X_rr^T: the packed tile used AS an
-                    // A operand is X_rr^T, times the identity (exact)
+                    // the A operand X_cc (element [cl][4 q + rg]) is the accumulator layout of X_cc^T: the packed tile used AS an
+                    // A operand is X_cc^T, times the identity (exact)
                     v4f64 z = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) z = __builtin_amdgcn_mfma_f64_16x16x4f64(xp[q], ident.v[q], z, 0, 0, 0);
@@ -344,25 +468,38 @@ __device__ __forceinline__ void helper_wave(const FitLoopParams &P, int *ctl, in
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         fw.v[q] = z[q];
-                        fs.v[q] = acc[q];
+                        fs.v[q] = acc1[i][q];
                     }
                     w = v4f64{0.0, 0.0, 0.0, 0.0};
                     w = mfma4(fw, fs, w, true);
                 }
-                st_pk(Wg, (unsigned)((r * nb + J) * 2048), lane, w);
+                st_pk(Wg, (unsigned)((c * nb + J) * 2048), lane, w);
+                if (c + 1 < nb) {  // the last product of row c + 1: the accumulator registers of W_cJ are its B fragments
+                    acc1[i] = acc2[i];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc1[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], w[q], acc1[i], 0, 0, 0);
+                }
                 double ssq = 0.0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (16 * r + rg + 4 * q < N) ssq = fma(w[q], w[q], ssq);
+                    if (16 * c + rg + 4 * q < N) ssq = fma(w[q], w[q], ssq);
                 ssq += __shfl_xor(ssq, 16);
                 ssq += __shfl_xor(ssq, 32);
                 t2[i] += ssq;  // (rows in order, from 0.0: the sum solve_posterior forms from the tiles' column sums)
-                if (r == aug_tile) {  // row N of W: -m
+                if (c == aug_tile) {  // row N of W: -m
                     double mv = w[0];
                     mv = (aug_r >> 2) == 1 ? w[1] : mv;
                     mv = (aug_r >> 2) == 2 ? w[2] : mv;
                     mv = (aug_r >> 2) == 3 ? w[3] : mv;
                     if (rg == (aug_r & 3) && 16 * J + cl < N) xg[P.NP + 16 * J + cl] = -mv;
+                }
+            }
+            if (c + 2 < nb) {  // off the critical path: the products K = J .. c of row c + 2 (columns <= c of L are final)
+#pragma unroll
+                for (int i = 0; i < CMAX; ++i) {
+                    const int J = hw + i * T;
+                    if (J > c || J >= nb) continue;
+                    acc2[i] = chain_sum(Cg, Wg, c + 2, J, c - J + 1, nb, lane);
                 }
             }
         }
@@ -401,7 +538,11 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
 #endif
 
     // 1/p (padding rows: 1) -- the diagonal of C = A + diag(1/p) is added when a tile is first read from A
-    for (int i = tid; i < NP; i += KT) S.y[i] = i < N ? 1.0 / S.p[i] : 1.0;  // row N (b) and padding: 1
+    for (int i = tid; i < NP; i += KT) {
+        const double rp = i < N ? 1.0 / S.p[i] : 1.0;  // row N (b) and padding: 1
+        S.y[i] = rp;
+        if constexpr (CL) P.WdT[2 * NP + i] = rp;  // (the helpers' diagonal tiles; in the L2 before the first word of the pass)
+    }
     if (tid == 0) {
         S.flag[0] = 0;  // not positive definite
         S.flag[1] = S.flag[2] = 0;  // column counters of the inverse rows (even / odd steps)
@@ -472,6 +613,9 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
     const gdouble *C_inv = as_global(uniform_ptr(C));
     gdouble *W_inv = as_global(uniform_ptr(W));
     gdouble *C_u = as_global(uniform_ptr(C));
+    const int band = CL ? clu::band_of(P) : nb;
+    const gdouble *H_u = as_global(uniform_ptr(const_cast<const double *>(P.W)));   // cluster mode: trailing tiles from the helpers
+    const gdouble *HD_u = as_global(uniform_ptr(const_cast<const double *>(P.cs)));  // (the diagonal ones)
     for (int k = 0; k < nb; ++k) {
         if (*S.flag) return false;
         const double *src = (k == 0) ? P.A : C;
@@ -479,6 +623,22 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
         const int m = nb - k - 1;
         const int cntA = __builtin_amdgcn_readfirstlane(m * (m - 1) / 2);  // tiles with k + 1 < J <= I
         const int ncol = __builtin_amdgcn_readfirstlane(max(m - 1, 0));     // tiles (I, k + 1), I > k + 1
+        // cluster mode: only the `band` block columns right of column k + 1 are updated here (column by column: cntB tiles);
+        // the tiles of the LAST of them, from index cntH on, come back from the helper waves at this step (clu::helper_wave)
+        int cntB = cntA, cntH = cntA;
+        if constexpr (CL) {
+            if (band < nb) {
+                const int nbc = min(band, m - 1);
+                cntB = 0;
+                for (int jj = 1; jj <= nbc; ++jj) {
+                    if (jj == band) cntH = cntB;
+                    cntB += m - jj;
+                }
+                if (nbc < band || k == 0) cntH = cntB;
+                cntB = __builtin_amdgcn_readfirstlane(cntB);
+                cntH = __builtin_amdgcn_readfirstlane(cntH);
+            }
+        }
         double *pan_cur = S.pan + (WIDE ? (size_t)0 : (size_t)(k & 1) * NP * PS);
         double *pan_nxt = S.pan + (WIDE ? (size_t)0 : (size_t)((k + 1) & 1) * NP * PS);
         int *ctr_cur = S.flag + 1 + (k & 1);
@@ -550,7 +710,41 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             // trip: the loads of the tile after next are issued before the stores of the current one (vmcnt counts loads and
             // stores in order -- a load issued behind a store would wait for the store's acknowledgement) without a register
             // copy.  (2 x 2 groups of tiles with four interleaved MFMA chains were measured too: no faster.)
-            auto ldt = [&](const uint4 &t) {  // (step 0 reads A: the transpose of tile (I, J) is its tile (J, I))
+            bool hready = false;
+            auto rec_at = [&](int e) -> uint4 {
+                if constexpr (CL) {
+                    if (band < nb) {  // column by column: column j of the band holds the rows i = j .. m - 1
+                        int j = 1, i = e;
+                        while (i >= m - j) {
+                            i -= m - j;
+                            ++j;
+                        }
+                        i += j;
+                        return S.rec[(i - 1) * i / 2 + (j - 1)];
+                    }
+                }
+                return S.rec[e];
+            };
+            auto ldt = [&](const uint4 &t, int e) {  // (step 0 reads A: the transpose of tile (I, J) is its tile (J, I))
+                if constexpr (CL) {
+                    if (e >= cntH) {  // a tile of the column that enters the band: updates 0 .. k - 1 were the helpers'
+                        if (!hready) {
+                            const int J = k + 1 + band, need = seq * (nb - J);
+                            const long long t0 = wall_clock64();
+                            while (__builtin_amdgcn_readfirstlane(clu::ld(ctl + clu::HCOL + J)) < need) {
+                                __builtin_amdgcn_s_sleep(1);
+                                if (wall_clock64() - t0 > 1000000 * clu::kTicksPerUs) {
+                                    if (lane == 0) S.flag[0] = 2;
+                                    break;
+                                }
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                            hready = true;
+                        }
+                        if (e == cntH) return ld_pk(HD_u, (unsigned)((k + 1 + band) * 2048), lane);  // (its first tile: the diagonal one)
+                        return ld_pk(H_u, base_pk + (t.x & ~2047u), lane);  // tile (I, J) waits at the mirror position (J, I)
+                    }
+                }
                 return ld_pk(src_u, base_pk + ((k == 0 ? t.x : t.w) & ~2047u), lane);
             };
             auto upd = [&](unsigned pa, unsigned pb, v4f64 a) {
@@ -570,33 +764,34 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 st_pk(C_u, base_pk + (t.w & ~2047u), lane, a);
             };
             int e = widx;  // every NWKc-th tile of the enumeration
-            if (e < cntA) {
-                uint4 ta = S.rec[e], tb = ta, tc = ta;
-                v4f64 a = ldt(ta), b = a, c = a;
-                if (e + NWKc < cntA) {
-                    tb = S.rec[e + NWKc];
-                    b = ldt(tb);
+            const int cnt = CL ? cntB : cntA;
+            if (e < cnt) {
+                uint4 ta = rec_at(e), tb = ta, tc = ta;
+                v4f64 a = ldt(ta, e), b = a, c = a;
+                if (e + NWKc < cnt) {
+                    tb = rec_at(e + NWKc);
+                    b = ldt(tb, e + NWKc);
                 }
                 for (;;) {
                     // sets in flight: a (current), b (next); c is free
-                    if (e + 2 * NWKc < cntA) {
-                        tc = S.rec[e + 2 * NWKc];
-                        c = ldt(tc);
+                    if (e + 2 * NWKc < cnt) {
+                        tc = rec_at(e + 2 * NWKc);
+                        c = ldt(tc, e + 2 * NWKc);
                     }
                     fin(ta, a);
-                    if (e + NWKc >= cntA) break;
-                    if (e + 3 * NWKc < cntA) {
-                        ta = S.rec[e + 3 * NWKc];
-                        a = ldt(ta);
+                    if (e + NWKc >= cnt) break;
+                    if (e + 3 * NWKc < cnt) {
+                        ta = rec_at(e + 3 * NWKc);
+                        a = ldt(ta, e + 3 * NWKc);
                     }
                     fin(tb, b);
-                    if (e + 2 * NWKc >= cntA) break;
-                    if (e + 4 * NWKc < cntA) {
-                        tb = S.rec[e + 4 * NWKc];
-                        b = ldt(tb);
+                    if (e + 2 * NWKc >= cnt) break;
+                    if (e + 4 * NWKc < cnt) {
+                        tb = rec_at(e + 4 * NWKc);
+                        b = ldt(tb, e + 4 * NWKc);
                     }
                     fin(tc, c);
-                    if (e + 3 * NWKc >= cntA) break;
+                    if (e + 3 * NWKc >= cnt) break;
                     e += 3 * NWKc;
                 }
             }
@@ -604,7 +799,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             TRACE(1);
             // ---- column k + 1: update, then the panel of step k + 1 straight from the registers ----
             // (the round-robin deal of the tiles goes on where the enumeration above stopped)
-            int cfirst = widx - cntA % NWKc;
+            int cfirst = widx - cnt % NWKc;
             if (cfirst < 0) cfirst += NWKc;
             constexpr int kColMax = CLM == 2 ? 5 : 4;  // (WIDE: ncol <= 38 <= kColMax x NWKc)
             v4f64 dcol[WIDE ? kColMax : 1];
@@ -699,7 +894,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
 
     if constexpr (CL) {
         // Tr2 and m = Y mu come from the helper waves that own the block columns of W (exchange area: the fit's WdT buffer)
-        const int T = (P.cluster - 1) * NW, nsig = T < nb ? T : nb;
+        const int T = clu::inv_helpers(P) * NW, nsig = T < nb ? T : nb;
         if (tid == 0) {
             const long long t0 = wall_clock64();
             while (clu::ld(ctl + clu::DONE) < seq * nsig) {
@@ -830,7 +1025,9 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
                 clu::add(ctl + clu::IN, 1);
             }
             const int hwave = __builtin_amdgcn_readfirstlane(tid >> 6);
-            clu::helper_wave<WIDE ? 4 : 2>(P, ctl, (member - 1) * NW + hwave, (P.cluster - 1) * NW, tid & 63);
+            const int hi = clu::inv_helpers(P), ht = clu::trail_helpers(P);
+            if (member <= hi) clu::inverse_wave<2>(P, ctl, hwave * hi + (member - 1), hi * NW, tid & 63);
+            else clu::trailing_wave(P, ctl, hwave * ht + (member - 1 - hi), ht * NW, tid & 63);
             __syncthreads();
             if (tid == 0) clu::add(ctl + clu::IN, -1);
             return;
@@ -1132,6 +1329,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
                     }
                 }
                 if (gone) {
+                    for (int jj = 0; jj < NP / 16; ++jj) clu::st(ctl + clu::HCOL + jj, 0);
                     clu::st(ctl + clu::DONE, 0);
                     clu::st(ctl + clu::XCC, 0);
                     clu::st(ctl + clu::PROG, 0);
@@ -1222,6 +1420,16 @@ static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s)
         if (P.cluster > FIT_CLUSTER_MAX || P.batch) return hipErrorInvalidValue;
         FitLoopParams Q = P;
         Q.nfits = blocks;
+        // helpers of the inverse / of the trailing update: two of the first kind give every block column a wave of its own up
+        // to N = 383 (a wave takes two columns at most: nb <= 24 helpers' waves x 2); the others keep the trailing tiles right
+        // of the band (not for the wide systems: their tiles do not fit the registers of a few waves)
+        const int nbk = P.NP / 16, h = P.cluster - 1;
+        int inv = h >= 2 ? 2 : 1;
+        if (loop_is_wide(P.NP)) inv = h;
+        if (const char *ie = getenv("FRANK_AMD_K2_CLUSTER_INV")) inv = atoi(ie);  // development
+        inv = inv < 1 ? 1 : (inv > h ? h : inv);
+        if (nbk > 2 * inv * NW) return hipErrorInvalidValue;
+        Q.cluster_inv = inv;
         const int grid = 8 * P.cluster * ((blocks + 7) / 8);
         const char *we = getenv("FRANK_AMD_K2_CL_WORKERS");  // development: 9 idles the waves on the chain's SIMD
         const int workers = we ? atoi(we) : 11;

@@ -33,7 +33,7 @@ def fit(ctx, N, M, j, alpha, ws, reps=3):
 
 def problem(N):
     """M, j of a fixture when there is one at this size, else a synthetic SPD system of the same scaling."""
-    for name in ("fit_N300_1e7.npz", "fit_N100_1e5.npz", "fit_N320_5e4.npz"):
+    for name in ("fit_N300_1e7.npz", "fit_N100_1e5.npz"):
         g = np.load(os.path.join(GOLD, name))
         if int(g["N"]) == N:
             return np.ascontiguousarray(g["M"]), np.ascontiguousarray(g["j"]), int(g["niter"]), float(g["alpha"]), float(g["wsmooth"])
@@ -46,6 +46,8 @@ def problem(N):
 
 
 sizes = [int(a) for a in sys.argv[1:]] or [300]
+CLUSTERS = [int(x) for x in os.environ.get("CLUSTERS", "2,3,4,5").split(",")]
+WORKERS = [int(x) for x in os.environ.get("WORKERS", "11,9").split(",")]
 for N in sizes:
     M, j, ref_it, alpha, ws = problem(N)
     dht, ctx = ctypes.c_void_p(), ctypes.c_void_p()
@@ -55,8 +57,8 @@ for N in sizes:
     mu0, p0, n0, t0, k0, wg0, _ = fit(ctx, N, M, j, alpha, ws)
     print("N=%d  one workgroup: %d iterations (reference %s)  %.2f ms  kernel %.2f ms  %.1f us/pass" % (
         N, n0, ref_it, 1e3 * t0, k0, 1e3 * k0 / (n0 + 2)), flush=True)
-    for g in (2, 3, 4):
-        for workers in (11, 9):
+    for g in CLUSTERS:
+        for workers in WORKERS:
             os.environ["FRANK_AMD_K2_CLUSTER"] = str(g)
             os.environ["FRANK_AMD_K2_CL_WORKERS"] = str(workers)
             mu, p, n, t, k, wg, fb = fit(ctx, N, M, j, alpha, ws)
