@@ -1830,15 +1830,18 @@ static int prepare_qspace(fh_ctx *c, double *Aq, double *bq) {
     return FH_OK;
 }
 
-// Cluster ("latency") mode of the fit loop (fit_loop.hip, clu::): workgroups per fit.  One primary + two helpers give every
-// block column of the inverse at N <= 383 a wave of its own; FRANK_AMD_K2_CLUSTER=1 turns the mode off, 2..8 set the size.
-// Small systems (fewer than eight block rows) have nothing to hand over.
+// Cluster ("latency") mode of the fit loop (fit_loop.hip, clu::): workgroups per fit.  Five -- the first, two helpers of the
+// inverse (every block column a wave of its own up to N = 383), two of the trailing update -- run a pass at N = 300 in 98 us
+// against 136 on one compute unit (four: 103, three: 111); FRANK_AMD_K2_CLUSTER=1 turns the mode off, 2..8 set the size.
+// Small systems (fewer than eight block rows) have nothing to hand over; the wide ones (N > 335) take three (no trailing helpers).
 static int env_int(const char *name, int dflt);
 static int fit_cluster_size(const fh_ctx *c) {
     const char *e = getenv("FRANK_AMD_K2_CLUSTER");  // (read at every call: tests switch it inside one process)
-    int want = e ? atoi(e) : 3;
+    int want = e ? atoi(e) : 5;
     want = want < 1 ? 1 : (want > FIT_CLUSTER_MAX ? FIT_CLUSTER_MAX : want);
     if (want <= 1 || c->NP < 128 || c->NP > fh_k2_loop_max_np()) return 1;
+    if (c->NP > 336 && !e) want = 3;  // (the wide instantiation: helpers of the inverse only)
+    if (c->NP / 16 > 24 && want == 2) want = 3;  // (a helper wave takes two block columns at most: more than 24 need two helpers)
     return want;
 }
 
@@ -2088,9 +2091,9 @@ static int flush_pending_batch(fh_ctx *c) {
         c->stream_last_done[pick] = b.done;
     }
     // few fits outstanding: every fit of this launch on a cluster of workgroups (the latency of a pass is what a shallow
-    // pipeline waits for); the compute units the clusters of all launches in flight may hold: FRANK_AMD_K2_CLUSTER_CUS (96)
+    // pipeline waits for); the compute units the clusters of all launches in flight may hold: FRANK_AMD_K2_CLUSTER_CUS (128)
     {
-        static const int budget = env_int("FRANK_AMD_K2_CLUSTER_CUS", 96);
+        static const int budget = env_int("FRANK_AMD_K2_CLUSTER_CUS", 128);
         const int g = fit_cluster_size(c);
         int held = 0;
         for (const FitBatch &o : c->batches)
@@ -2292,6 +2295,18 @@ int fh_fit_collect(fh_ctx *c, int ticket, double *mu, double *p, int *niter) {
     if (niter) *niter = result[0];
     if (result[1] == FIT_STATUS_BAD_P) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (non-positive or NaN)");
     if (result[1] == FIT_STATUS_NOT_SPD) return fail(FH_ERR_NOT_SPD, "Cholesky of the posterior precision failed");
+    return FH_OK;
+}
+
+int fh_stats_upload(fh_ctx *c, const double *M, const double *j) {
+    if (!c || !M || !j) return fail(FH_ERR_INVALID, "fh_stats_upload: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->N;
+    // (pageable host memory: the copies have left the caller's arrays when the calls return)
+    HIP_TRY(hipMemcpyAsync(c->M.p, M, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->j.p, j, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_device_Mj = true;
     return FH_OK;
 }
 

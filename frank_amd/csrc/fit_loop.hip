@@ -96,6 +96,7 @@ constexpr int kMaxTiles = 210;  // tiles of the largest trailing triangle: NP / 
 // (its own instantiation).  Before this, 320 < N <= 512 ran the library loop: ~8 x the time per pass at N = 321.
 constexpr int kMaxTilesWide = 780;  // 39 block rows
 constexpr int kWideMinNP = 337, kWideMaxNP = 640;
+constexpr int kHandMaxNP = 320;  // cluster mode: the four hand-over tiles (8 KB) fit the LDS beside two panels up to here
 template <bool WIDE> constexpr int max_tiles() { return WIDE ? kMaxTilesWide : kMaxTiles; }
 template <bool WIDE> constexpr int npanels() { return WIDE ? 1 : 2; }
 
@@ -110,6 +111,7 @@ struct Smem {
                    // to block (k+1, k+1) (step 0 reads the transposes from A) | bit 1: diagonal tile; y, z = byte offsets of
                    // panel row blocks j, i (A and B operand of the transposed update); w = packed offset of tile (i, j) | i
     int *flag;
+    double *hand;  // cluster mode: 2 x 2 packed tiles a worker hands to the chain wave through LDS (solve_posterior_cluster)
 };
 
 // ---- (4) row-by-row inverse: W_IJ = -W_II * sum_{K=J}^{I-1} L_IK W_KJ --------------------------------------------------
@@ -934,6 +936,362 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
     return true;
 }
 
+// ---- the posterior solve of the first workgroup of a cluster (N <= 335: two panels in LDS) -----------------------------------
+// Without the rows of the inverse and with the trailing tiles right of the band on the helpers (clu::), a step of
+// solve_posterior is the chain -- factor-and-invert of the diagonal tile, ~2.5 us -- FOLLOWED by the column tiles, which need
+// its result, and the barrier: ~4.5 us, with the worker waves mostly waiting.  Here the chain wave runs ahead: after X_{k+1} it
+// forms the one column tile its next diagonal tile needs, L_{k+2,k+1}, itself, updates tile (k+2, k+2) with it straight from
+// the accumulator registers (a tile D = X T^T in the accumulator layout IS its own operand fragments) and goes on factoring,
+// while the workers turn the rest of column k + 1 into panel k + 1.  What the chain wave needs from the workers' step k -- the
+// panel and the band tiles they stored -- it needs only AFTER X_{k+2}; so it joins the barrier that ends their step k there.
+// Every wave still executes one s_barrier per step; a step is the chain alone, ~3 us.  The products, their operands and their
+// order are those of solve_posterior: the same bits.
+// Progress is published to the helpers without waiting for that barrier: every wave counts itself in (LDS) when its stores of
+// the step have reached the L2, the last one raises the word.
+template <int CLM>
+__device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, const Smem &S, int seq) {
+    constexpr int NWKc = CLM == 2 ? NW - NW / 4 : NW - 1;  // trailing-update workers
+    const int N = P.N, NP = P.NP, nb = P.NP / 16, ld = P.NP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 15, rg = lane >> 4;
+    double *C = P.C;
+    int *const ctl = clu::ctl_of(P);
+#ifdef FIT_LOOP_TIMING
+    long long t_last = clock64();
+#endif
+    for (int i = tid; i < NP; i += KT) {
+        const double rp = i < N ? 1.0 / S.p[i] : 1.0;  // row N (b) and padding: 1
+        S.y[i] = rp;
+        P.WdT[2 * NP + i] = rp;  // (the helpers' diagonal tiles; in the L2 before the first word of the pass)
+    }
+    if (tid == 0) {
+        S.flag[0] = 0;  // 1: not positive definite, 2: the helpers are gone
+        S.flag[3] = 0;  // index of the last diagonal tile whose inverse is in LDS
+        S.flag[4] = 0;  // waves whose stores of the steps so far are in the L2
+    }
+    __syncthreads();
+    const double *pinv = S.y;
+    TSTAMP(0);
+    const int aug_tile = N / 16, aug_c = N - 16 * aug_tile;
+    auto rows_valid = [&](int I) { return min(16, max(0, N - 16 * I)); };
+    if (wave == 0) {
+        v4f64 t0 = ld_pk(as_global(P.A), 0u, lane), x0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (rg + 4 * r == cl) t0[r] += pinv[cl];
+        const bool ok = chol_inv_tile_acc(t0, x0, lane, aug_tile == 0 ? aug_c : -1);
+        if (!ok && lane == 0) *S.flag = 1;
+        store_factored_tile(t0, x0, nullptr, ld, S.dli, nullptr, nullptr, nullptr, rows_valid(0), lane);  // L_00^-1 -> dli[0]
+        st_pk(as_global(C), 0u, lane, x0);  // X_00 (the helpers' W_00)
+    }
+    __syncthreads();
+    TSTAMP(1);
+    {   // panel 0 from memory: D = L_00^-1 (C_I0)^T for I > 0; D -> block (0, I), D -> LDS panel 0
+        Frag fa;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fa.v[q] = S.dli[cl * PS + 4 * q + rg];
+        constexpr int kPanelMax = 3;  // ceil((NP / 16 - 1) / NW)
+        Frag fb[kPanelMax];
+#pragma unroll
+        for (int u = 0; u < kPanelMax; ++u) {
+            const int I = 1 + wave + u * NW;
+            if (I < nb) {
+                const v4f64 t = ld_pk(as_global(P.A), (unsigned)(I * 2048), lane);  // tile (0, I) = (A_I0)^T: A is symmetric
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fb[u].v[q] = t[q];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kPanelMax; ++u) {
+            const int I = 1 + wave + u * NW;
+            if (I < nb) {
+                v4f64 d = {0.0, 0.0, 0.0, 0.0};
+                d = mfma4(fa, fb[u], d, false);
+                st_pk(as_global(C), (unsigned)(I * 2048), lane, d);  // tile (0, I) = L_I0^T
+                double *pr = S.pan + (size_t)((I - 1) * 16 + cl) * PS + rg;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the barrier waits for LDS only)
+    __syncthreads();
+    if (tid == 0) clu::st(ctl + clu::PROG, seq * 64 + 1);  // column 0 of L and X_00 are final
+    TSTAMP(2);
+    gdouble *C_u = as_global(uniform_ptr(C));
+    const gdouble *A_u = as_global(uniform_ptr(P.A));
+    const int band = clu::band_of(P);
+    const gdouble *H_u = as_global(uniform_ptr(const_cast<const double *>(P.W)));   // trailing tiles from the helpers
+    const gdouble *HD_u = as_global(uniform_ptr(const_cast<const double *>(P.cs)));  // (the diagonal ones)
+    const unsigned lane_p = (unsigned)((cl * PS + rg) * 8);
+    // every wave counts itself in when its stores of step k have reached the L2; the last one publishes "columns <= k + 1 of L
+    // and X_{k+1,k+1} are final" (all arrivals of step k precede the barrier that ends it, all of step k + 1 follow it)
+    auto arrive = [&](int k) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const int old = atomicAdd(&S.flag[4], 1);
+            if (old + 1 == (k + 1) * NW) clu::st(ctl + clu::PROG, seq * 64 + k + 2);
+        }
+    };
+    v4f64 dg = {0.0, 0.0, 0.0, 0.0};  // the chain wave's next diagonal tile, all updates applied
+    if (wave == kChain && nb > 1) {
+        dg = ld_pk(A_u, (unsigned)((nb + 1) * 2048), lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (rg + 4 * r == cl) dg[r] += pinv[16 + cl];
+        const double *pa1 = reinterpret_cast<const double *>(reinterpret_cast<const char *>(S.pan) + lane_p);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dg = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s], pa1[4 * s], dg, 0, 0, 0);
+    }
+    for (int k = 0; k + 1 < nb; ++k) {
+        const gdouble *src_u = k == 0 ? A_u : as_global(uniform_ptr(const_cast<const double *>(C)));
+        const int m = nb - k - 1;
+        double *pan_cur = S.pan + (size_t)(k & 1) * NP * PS;
+        double *pan_nxt = S.pan + (size_t)((k + 1) & 1) * NP * PS;
+        const unsigned base_pk = (unsigned)((k + 1) * (nb + 1) * 2048);  // tile (k+1, k+1), packed
+        const char *pan_b = reinterpret_cast<const char *>(pan_cur);
+        auto upd = [&](unsigned pa, unsigned pb, v4f64 a) {
+            const double *pa1 = reinterpret_cast<const double *>(pan_b + pa + lane_p);
+            const double *pb1 = reinterpret_cast<const double *>(pan_b + pb + lane_p);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s], pb1[4 * s], a, 0, 0, 0);
+            return a;
+        };
+        TRACE(0);
+        if (wave == kChain) {
+#ifdef FIT_LOOP_TIMING
+            long long f_last = clock64();
+#endif
+            v4f64 xi;
+            const bool ok = chol_inv_tile_acc(dg, xi, lane, aug_tile == k + 1 ? aug_c : -1);
+            if (!ok && lane == 0) *S.flag = 1;
+            FSTAMP(9);
+            store_factored_tile(dg, xi, nullptr, ld, S.dli + ((k + 1) & 1) * 16 * PS, nullptr, nullptr, nullptr, rows_valid(k + 1), lane);
+            st_pk(C_u, base_pk, lane, xi);  // X_{k+1,k+1} (the helpers' W_{k+1,k+1})
+            __hip_atomic_store(&S.flag[3], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            FSTAMP(10);
+            TRACE(5);
+            if (k >= 1) __syncthreads();  // the barrier that ends the workers' step k - 1: panel k and their band tiles are complete
+            if (m >= 2) {
+                // column tile (k+2, k+1): T^T = C^T - L_{k+1,k} L_{k+2,k}^T, D = X T^T = L_{k+2,k+1}^T -- what a worker did
+                v4f64 t, nd;  // tiles (k+2, k+1) and (k+2, k+2), updates < k applied
+                if (k == 0 || !S.hand) {
+                    t = ld_pk(src_u, base_pk + (unsigned)(k == 0 ? 2048 : nb * 2048), lane);
+                    nd = ld_pk(src_u, base_pk + (unsigned)((nb + 1) * 2048), lane);
+                } else {  // left in LDS by the workers that updated them at step k - 1
+                    const v2f64 *hp = reinterpret_cast<const v2f64 *>(S.hand + (((k - 1) & 1) * 2) * 256) + lane;
+                    const v2f64 a0 = hp[0], a1 = hp[64], b0 = hp[128], b1 = hp[192];
+                    t = v4f64{a0[0], a0[1], a1[0], a1[1]};
+                    nd = v4f64{b0[0], b0[1], b1[0], b1[1]};
+                }
+                t = upd(0u, (unsigned)(16 * PS * 8), t);
+                Frag fx, ft;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    fx.v[q] = S.dli[((k + 1) & 1) * 16 * PS + cl * PS + 4 * q + rg];
+                    ft.v[q] = t[q];
+                }
+                const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
+                const v4f64 d = mfma4(fx, ft, z4, false);
+                st_pk(C_u, base_pk + 2048u, lane, d);  // tile (k+1, k+2): the block the inverse reads
+                double *pr = pan_nxt + (size_t)cl * PS + rg;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
+                // the next diagonal tile: update k from the panel, update k + 1 from the registers of D (its rows are the
+                // operand fragments of both sides)
+                if (k == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (rg + 4 * r == cl) nd[r] += pinv[32 + cl];
+                }
+                nd = upd((unsigned)(16 * PS * 8), (unsigned)(16 * PS * 8), nd);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) nd = __builtin_amdgcn_mfma_f64_16x16x4f64(-d[s], d[s], nd, 0, 0, 0);
+                dg = nd;
+            } else {
+                dg = v4f64{1.0, 1.0, 1.0, 1.0};
+            }
+            FSTAMP(8);
+            arrive(k);
+            TRACE(4);
+        } else if (CLM == 2 && (wave & 3) == (kChain & 3)) {
+            // the waves on the chain's SIMD leave its double-precision units to the chain
+            arrive(k);
+            __syncthreads();
+        } else {
+            const int widx = CLM == 2 ? wave - (wave >> 2) - ((wave & 3) > (kChain & 3) ? 1 : 0) : (wave < kChain ? wave : wave - 1);  // 0..NWKc-1
+#ifdef FIT_LOOP_TIMING
+            long long w_last = clock64();
+#endif
+            // ---- the band: tiles (I, J), k + 1 < J <= k + 1 + band, J <= I, without tile (k+2, k+2) (the chain wave's) ----
+            // enumeration column by column (row by row when there are no helpers of the trailing update: band = nb); the tiles
+            // of the LAST band column, from index cntH on, come back from the helper waves at this step
+            int cntB = m * (m - 1) / 2, cntH = cntB;
+            if (band < nb) {
+                const int nbc = min(band, m - 1);
+                cntB = 0;
+                for (int jj = 1; jj <= nbc; ++jj) {
+                    if (jj == band) cntH = cntB;
+                    cntB += m - jj;
+                }
+                if (nbc < band || k == 0) cntH = cntB;
+            }
+            cntB = __builtin_amdgcn_readfirstlane(cntB);
+            cntH = __builtin_amdgcn_readfirstlane(cntH);
+            bool hready = false;
+            auto rec_at = [&](int e) -> uint4 {
+                if (band < nb) {  // column by column: column j of the band holds the rows i = j .. m - 1
+                    int j = 1, i = e;
+                    while (i >= m - j) {
+                        i -= m - j;
+                        ++j;
+                    }
+                    i += j;
+                    return S.rec[(i - 1) * i / 2 + (j - 1)];
+                }
+                return S.rec[e];
+            };
+            auto ldt = [&](const uint4 &t, int e) {  // (step 0 reads A: the transpose of tile (I, J) is its tile (J, I))
+                if (e >= cntH) {  // a tile of the column that enters the band: updates 0 .. k - 1 were the helpers'
+                    if (!hready) {
+                        const int J = k + 1 + band, need = seq * (nb - J);
+                        const long long t0 = wall_clock64();
+                        while (__builtin_amdgcn_readfirstlane(clu::ld(ctl + clu::HCOL + J)) < need) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (wall_clock64() - t0 > 1000000 * clu::kTicksPerUs) {
+                                if (lane == 0) S.flag[0] = 2;
+                                break;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        hready = true;
+                    }
+                    if (e == cntH) return ld_pk(HD_u, (unsigned)((k + 1 + band) * 2048), lane);  // (its first tile: the diagonal one)
+                    return ld_pk(H_u, base_pk + (t.x & ~2047u), lane);  // tile (I, J) waits at the mirror position (J, I)
+                }
+                return ld_pk(src_u, base_pk + ((k == 0 ? t.x : t.w) & ~2047u), lane);
+            };
+            auto fin = [&](const uint4 &t, v4f64 a) {
+                if (k == 0 && (t.x & 2u)) {  // first touch: add diag(1/p) on diagonal tiles
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (rg + 4 * r == cl) a[r] += pinv[16 * (1 + (t.w & 127u)) + cl];  // (w: packed offset | i)
+                }
+                a = upd(t.y, t.z, a);
+                st_pk(C_u, base_pk + (t.w & ~2047u), lane, a);
+                // tiles (k+3, k+2) and (k+3, k+3) are what the chain wave needs right after X_{k+2}: also through LDS (a reload
+                // from the L2 behind the barrier was ~0.7 us of every step's chain)
+                if (S.hand && (t.w & 127u) == 2u && t.y <= (unsigned)(2 * 16 * PS * 8)) {
+                    v2f64 *hp = reinterpret_cast<v2f64 *>(S.hand + ((k & 1) * 2 + (t.y == (unsigned)(16 * PS * 8) ? 0 : 1)) * 256) + lane;
+                    hp[0] = v2f64{a[0], a[1]};
+                    hp[64] = v2f64{a[2], a[3]};
+                }
+            };
+            // (tile 0 of either enumeration is (k+2, k+2): skipped -- indices below are shifted by one)
+            const int cnt = cntB - 1;
+            int e = widx;
+            if (e < cnt) {
+                uint4 ta = rec_at(e + 1), tb = ta, tc = ta;
+                v4f64 a = ldt(ta, e + 1), b = a, c = a;
+                if (e + NWKc < cnt) {
+                    tb = rec_at(e + NWKc + 1);
+                    b = ldt(tb, e + NWKc + 1);
+                }
+                for (;;) {
+                    if (e + 2 * NWKc < cnt) {
+                        tc = rec_at(e + 2 * NWKc + 1);
+                        c = ldt(tc, e + 2 * NWKc + 1);
+                    }
+                    fin(ta, a);
+                    if (e + NWKc >= cnt) break;
+                    if (e + 3 * NWKc < cnt) {
+                        ta = rec_at(e + 3 * NWKc + 1);
+                        a = ldt(ta, e + 3 * NWKc + 1);
+                    }
+                    fin(tb, b);
+                    if (e + 2 * NWKc >= cnt) break;
+                    if (e + 4 * NWKc < cnt) {
+                        tb = rec_at(e + 4 * NWKc + 1);
+                        b = ldt(tb, e + 4 * NWKc + 1);
+                    }
+                    fin(tc, c);
+                    if (e + 3 * NWKc >= cnt) break;
+                    e += 3 * NWKc;
+                }
+            }
+            WSTAMP(11);
+            TRACE(1);
+            // ---- column k + 1 without its first tile (the chain wave's): update, then the panel of step k + 1 ----
+            const int ncol = max(m - 2, 0);  // tiles (I, k + 1), I > k + 2
+            int cfirst = widx - max(cnt, 0) % NWKc;
+            if (cfirst < 0) cfirst += NWKc;
+            if (cfirst < ncol) {
+                int spins = 0;
+                while (__hip_atomic_load(&S.flag[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 22)) {  // (never observed; a stuck flag must not hang the device)
+                        if (lane == 0) *S.flag = 1;
+                        break;
+                    }
+                }
+                TRACE(2);
+                Frag fx;  // L_{k+1,k+1}^-1: as A operand X, as B operand X^T
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[((k + 1) & 1) * 16 * PS + cl * PS + 4 * q + rg];
+                for (int c = cfirst; c < ncol; c += NWKc) {
+                    const int i = c + 2;  // block row I = k + 1 + i
+                    v4f64 t = ld_pk(src_u, base_pk + (unsigned)(k == 0 ? i * 2048 : i * nb * 2048), lane);
+                    t = upd(0u, (unsigned)(i * 16 * PS * 8), t);  // T^T = C_{I,k+1}^T - L_{k+1,k} L_Ik^T: the tile is kept transposed
+                    Frag ft;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ft.v[q] = t[q];
+                    const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
+                    const v4f64 d = mfma4(fx, ft, z4, false);  // D = X T^T = L_{I,k+1}^T
+                    st_pk(C_u, base_pk + (unsigned)(i * 2048), lane, d);  // tile (k+1, I): the block the inverse reads
+                    double *pr = pan_nxt + (size_t)((i - 1) * 16 + cl) * PS + rg;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
+                }
+            }
+            TRACE(3);
+            arrive(k);
+            TRACE(4);
+            WSTAMP(12);
+            __syncthreads();
+        }
+        TSTAMP(3);
+    }
+    if (wave == kChain && nb > 1) __syncthreads();  // (the barrier that ends the workers' last step)
+    __syncthreads();
+    if (*S.flag) return false;
+    TSTAMP(4);
+    {
+        // Tr2 and m = Y mu come from the helper waves that own the block columns of W (exchange area: the fit's WdT buffer)
+        const int T = clu::inv_helpers(P) * NW, nsig = T < nb ? T : nb;
+        if (tid == 0) {
+            const long long t0 = wall_clock64();
+            while (clu::ld(ctl + clu::DONE) < seq * nsig) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 1000000 * clu::kTicksPerUs) {  // 1 s: the helpers are gone
+                    S.flag[0] = 2;
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (*S.flag) return false;
+        const double *xg = P.WdT;
+        for (int i = tid; i < N; i += KT) {
+            S.tr2[i] = xg[i];
+            S.m[i] = xg[NP + i];
+        }
+        __syncthreads();
+        TSTAMP(7);
+    }
+    return true;
+}
+
 // ---- (T + I) tau = rhs by a wave scan: band_scan.h ----
 template <bool WIDE> constexpr int scan_rows() { return WIDE ? 10 : 6; }  // rows per lane: 64 * 6 = 384, 64 * 10 = 640 >= NP
 using bandscan::scan_solve;
@@ -1019,7 +1377,8 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     const int tid = threadIdx.x;
     int *const ctl = CL ? clu::ctl_of(P) : nullptr;
     if constexpr (CL) {
-        if (member > 0) {  // a helper workgroup: its waves own block columns of the inverse (clu::helper_wave)
+        if (member > 0) {  // a helper workgroup: block columns of the inverse (clu::inverse_wave) or trailing tiles (clu::trailing_wave)
+            if (P.cluster_break) return;
             if (tid == 0) {
                 __hip_atomic_fetch_or(ctl + clu::XCC, 1 << clu::xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 clu::add(ctl + clu::IN, 1);
@@ -1048,8 +1407,9 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         // the band factors and the scan tables (48 KB at NP = 512) in global memory -- the workgroup's W buffer, unused since
         // W lives in the dead tiles of C --: wave 0 reads them once per pass (band_scan.h takes either address space), and
         // the one panel, the vectors and the tile table of NP = 512 fit the LDS beside nothing else
-        S.band = P.W;
-        S.scanQ = P.W + 6 * NP;
+        // (cluster mode: the helpers of the inverse write W there; the cs buffer, (NP / 16)^2 x 16 doubles, is free instead)
+        S.band = CL ? P.cs : P.W;
+        S.scanQ = S.band + 6 * NP;
         S.rec = reinterpret_cast<uint4 *>(S.red + NP);
     } else {
         S.band = S.red + NP;
@@ -1057,6 +1417,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         S.rec = reinterpret_cast<uint4 *>(S.scanQ + 2 * 6 * 4 * 64);  // (16-byte aligned: every region before it is an even number of doubles)
     }
     S.flag = reinterpret_cast<int *>(S.rec + max_tiles<WIDE>());  // [0] not positive definite, [1] column counter of the inverse row
+    S.hand = (!WIDE && NP <= kHandMaxNP) ? reinterpret_cast<double *>(S.flag + 8) : nullptr;  // (32 bytes of flags; 16-byte aligned)
     for (int e = tid; e < max_tiles<WIDE>(); e += KT) {  // tile e = (i - 1) i / 2 + (j - 1), 1 <= j <= i
         int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while ((i + 1) * (i + 2) / 2 <= e) ++i;
@@ -1134,7 +1495,10 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
 #ifdef FIT_LOOP_TIMING
         P.trace_on = (count == 5);
 #endif
-        if (!solve_posterior<WIDE, CLM>(P, S, ++nsolve)) {
+        bool solved;
+        if constexpr (CL && !WIDE) solved = solve_posterior_cluster<CLM>(P, S, ++nsolve);
+        else solved = solve_posterior<WIDE, CLM>(P, S, ++nsolve);
+        if (!solved) {
             status = (CL && S.flag[0] == 2) ? FIT_STATUS_CLUSTER : FIT_STATUS_NOT_SPD;
             break;
         }
@@ -1377,7 +1741,7 @@ int fh_k2_loop_max_np() { return kWideMaxNP; }
 size_t fh_k2_loop_smem_bytes(int NP) {
     const bool wide = loop_is_wide(NP);
     return sizeof(double) * (size_t)((wide ? 1 : 2) * NP * PS + 2 * 16 * PS + 7 * NP + NP + (wide ? 0 : 6 * NP + 2 * 6 * 4 * 64)) +
-           16 * (size_t)(wide ? kMaxTilesWide : kMaxTiles) + 32;
+           16 * (size_t)(wide ? kMaxTilesWide : kMaxTiles) + 32 + ((wide || NP > kHandMaxNP) ? 0 : 4 * 2048);  // (+ the hand-over tiles of the cluster mode)
 }
 
 // Development experiment (FRANK_AMD_K2_DUMMY=<milliseconds>): a workgroup that occupies a CU exactly like the fit loop
@@ -1430,11 +1794,12 @@ static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s)
         inv = inv < 1 ? 1 : (inv > h ? h : inv);
         if (nbk > 2 * inv * NW) return hipErrorInvalidValue;
         Q.cluster_inv = inv;
+        if (const char *be = getenv("FRANK_AMD_K2_CLUSTER_BREAK")) Q.cluster_break = atoi(be);  // tests: the fall-back to one CU
         const int grid = 8 * P.cluster * ((blocks + 7) / 8);
-        const char *we = getenv("FRANK_AMD_K2_CL_WORKERS");  // development: 9 idles the waves on the chain's SIMD
-        const int workers = we ? atoi(we) : 11;
-        if (loop_is_wide(P.NP)) return workers == 9 ? go(&fit_loop_kernel<true, 2>, Q, grid) : go(&fit_loop_kernel<true, 1>, Q, grid);
-        return workers == 9 ? go(&fit_loop_kernel<false, 2>, Q, grid) : go(&fit_loop_kernel<false, 1>, Q, grid);
+        // (CLM = 2, the two waves on the chain's SIMD sitting the trailing update out, was measured at every stage of this mode:
+        //  never faster -- 99.1 against 97.6 us per pass at the end -- and is not instantiated)
+        if (loop_is_wide(P.NP)) return go(&fit_loop_kernel<true, 1>, Q, grid);
+        return go(&fit_loop_kernel<false, 1>, Q, grid);
     }
     if (loop_is_wide(P.NP)) return go(&fit_loop_kernel<true, 0>, P, blocks);
     return go(&fit_loop_kernel<false, 0>, P, blocks);

@@ -231,6 +231,7 @@ struct FitLoopParams {
     // launch: XCD x = b & 7, index i = b >> 3 on it; fit (i / cluster) * 8 + x of the launch, member i % cluster.
     int cluster;            // 0 / 1: none
     int cluster_inv;        // helpers of the inverse among the cluster - 1 helpers (the others: helpers of the trailing update)
+    int cluster_break;      // tests (FRANK_AMD_K2_CLUSTER_BREAK=1): the helpers leave at once, the cluster never assembles
     int nfits;              // fits of a cluster launch (slot launch: entries of slot_words; single fit: 1)
 };
 #define FIT_MAX_BATCH 128

@@ -224,6 +224,11 @@ int fh_fit_normal(fh_ctx *ctx, const double *M, const double *j, double alpha, d
  * fh_fit_flush launches what has been staged so far -- call it after the last submission; fh_fit_collect on a fit
  * whose launch is still open does the same.  fh_fit_collect waits for that fit and returns mu, p, niter exactly as
  * fh_fit_normal does.  Tickets are collected in any order; at most fh_fit_slots() fits may be outstanding.     */
+/* fh_stats_upload: M (N*N, row-major) and j (N) from the HOST become the context's device-resident normal equations -- what
+ * fh_stats_finalize leaves there after a binning pass -- so that fh_fit_submit / fh_fit_normal(ctx, NULL, NULL, ..) can run on
+ * statistics computed elsewhere (a saved mapping, the sum of several tables: statistical_models.py:220-237 hands them around as
+ * a dict).                                                                                                           */
+int fh_stats_upload(fh_ctx *ctx, const double *M, const double *j);
 int fh_fit_slots(void);
 int fh_fit_submit(fh_ctx *ctx, double alpha, double p0, double wsmooth, double tol, int max_iter, int *ticket);
 int fh_fit_flush(fh_ctx *ctx);
@@ -233,7 +238,7 @@ int fh_fit_collect(fh_ctx *ctx, int ticket, double *mu, double *p, int *niter);
  * precision and runs the loop (GaussianModel._fit, statistical_models.py:732-760; filter.py:154-181), the others form the
  * block columns of the inverse of the factor that Tr2 and the mean need (one wave per column); the arithmetic of every tile
  * is the one the single-workgroup kernel does, so the results are the same bits.  FRANK_AMD_K2_CLUSTER = 1 turns the mode
- * off, 2 .. 8 set the size (default 3).  *workgroups: what the last fh_fit_normal ran on; *fallbacks: cluster launches of this
+ * off, 2 .. 8 set the size (default 5: two helpers of the inverse, two of the trailing update; 3 for N > 335).  *workgroups: what the last fh_fit_normal ran on; *fallbacks: cluster launches of this
  * context that did not assemble on one XCD within 200 us and were repeated on one compute unit (either may be NULL).     */
 int fh_fit_cluster_info(fh_ctx *ctx, int *workgroups, int64_t *fallbacks);
 

@@ -1299,3 +1299,91 @@ def test_sweep_point_continues_through_the_svd_route(golden):
     ref = FF2.fit_preprocessed(m2)
     assert nits[1] == FF2.iteration_diagnostics["num_iterations"]
     assert rel_to_max(sols[1].I, ref.I) < 1e-9
+
+
+def _cluster_problem(N, n=200000):
+    """M, j of a mock table at basis size N (device binning; the same arrays for every mode of the fit loop)."""
+    from frank_amd import FrankFitter
+    u, v, V, w = mock_disc_visibilities(n, seed=31, noise_seed=32)
+    FF = FrankFitter(2.0, N, geom(), verbose=False)
+    m = FF.preprocess_visibilities(u, v, V, w)
+    return FF, np.ascontiguousarray(m["M"]), np.ascontiguousarray(m["j"])
+
+
+def _fit_normal(ctx, N, M, j, alpha=1.05, ws=1e-4, max_iter=2000):
+    import ctypes
+    from frank_amd import _lib
+    mu, p, nit = np.empty(N), np.empty(N), ctypes.c_int(0)
+    rc = _lib.lib.fh_fit_normal(ctx, _lib.ptr(M), _lib.ptr(j), alpha, 1e-15, ws, 1e-3, max_iter, _lib.ptr(mu), _lib.ptr(p),
+                                ctypes.byref(nit), None, None)
+    wg, fb = ctypes.c_int(0), ctypes.c_int64(0)
+    _lib.check(_lib.lib.fh_fit_cluster_info(ctx, ctypes.byref(wg), ctypes.byref(fb)))
+    return rc, mu, p, nit.value, wg.value, fb.value
+
+
+@pytest.mark.parametrize("N,cluster,ran_on", [(130, "5", 5), (300, "5", 5), (300, "4", 4), (300, "3", 3), (300, "2", 2), (320, "5", 5),
+                                               (335, "5", 5), (400, "3", 3), (639, "3", 3), (100, "5", 1)])
+def test_cluster_mode_equals_one_workgroup(monkeypatch, N, cluster, ran_on):
+    """The fit loop on a cluster of workgroups (fit_loop.hip, clu::: helpers of the inverse and of the trailing update on the
+    same XCD, run-ahead chain) forms every tile with the arithmetic of the one-workgroup kernel: mu, p and the iteration count
+    are the same BITS, whatever the size of the cluster; small systems stay on one workgroup."""
+    FF, M, j = _cluster_problem(N, 60000 if N > 400 else 200000)
+    ctx = FF._DHT.context()
+    monkeypatch.setenv("FRANK_AMD_K2_CLUSTER", "1")
+    rc0, mu0, p0, n0, wg0, fb0 = _fit_normal(ctx, N, M, j, max_iter=300)
+    assert rc0 == 0 and wg0 == 1
+    monkeypatch.setenv("FRANK_AMD_K2_CLUSTER", cluster)
+    rc, mu, p, n, wg, fb = _fit_normal(ctx, N, M, j, max_iter=300)
+    assert rc == 0 and wg == ran_on and fb == fb0
+    assert n == n0 and np.array_equal(mu, mu0) and np.array_equal(p, p0)
+
+
+def test_cluster_mode_failure_paths(monkeypatch):
+    """(i) A cluster that does not assemble (the helpers leave at once: FRANK_AMD_K2_CLUSTER_BREAK) ends with FIT_STATUS_CLUSTER
+    and the host repeats the fit on one compute unit: same result, one fall-back counted.  (ii) A posterior precision that is not
+    positive definite ends the cluster cleanly (FH_ERR_NOT_SPD, as on one workgroup) and the next fit runs on a cluster again."""
+    from frank_amd import _lib
+    N = 130
+    FF, M, j = _cluster_problem(N)
+    ctx = FF._DHT.context()
+    monkeypatch.setenv("FRANK_AMD_K2_CLUSTER", "1")
+    rc0, mu0, p0, n0, _, fb0 = _fit_normal(ctx, N, M, j)
+    assert rc0 == 0
+    monkeypatch.setenv("FRANK_AMD_K2_CLUSTER", "5")
+    monkeypatch.setenv("FRANK_AMD_K2_CLUSTER_BREAK", "1")
+    rc, mu, p, n, wg, fb = _fit_normal(ctx, N, M, j)
+    assert rc == 0 and wg == 1 and fb == fb0 + 1
+    assert n == n0 and np.array_equal(mu, mu0) and np.array_equal(p, p0)
+    monkeypatch.delenv("FRANK_AMD_K2_CLUSTER_BREAK")
+    # (ii) flip the sign of M: C = A + diag(1/p) loses positive definiteness at the first pass
+    rc, *_ = _fit_normal(ctx, N, -M, j)
+    assert rc == _lib.FH_ERR_NOT_SPD
+    rc, mu, p, n, wg, fb2 = _fit_normal(ctx, N, M, j)
+    assert rc == 0 and wg == 5 and fb2 == fb0 + 1
+    assert n == n0 and np.array_equal(mu, mu0) and np.array_equal(p, p0)
+
+
+def test_pipelined_fits_on_clusters(monkeypatch):
+    """A shallow pipeline (fh_fit_submit with few fits outstanding) launches its fits on clusters, the first launches small
+    (1, 2, 4, .. fits); the results are those of the synchronous one-workgroup fit, bit for bit, for every hyper-parameter set."""
+    import ctypes
+    from frank_amd import _lib
+    N = 300
+    FF, M, j = _cluster_problem(N)
+    ctx = FF._DHT.context()
+    hyper = [(1.05, 1e-4), (1.3, 1e-2), (1.05, 1e-4), (1.2, 1e-3), (1.05, 1e-4), (1.4, 1e-1), (1.05, 1e-4)]
+    monkeypatch.setenv("FRANK_AMD_K2_CLUSTER", "1")
+    ref = {h: _fit_normal(ctx, N, M, j, *h) for h in set(hyper)}
+    monkeypatch.setenv("FRANK_AMD_K2_CLUSTER", "5")
+    tickets = []
+    for a, ws in hyper:
+        _lib.check(_lib.lib.fh_stats_upload(ctx, _lib.ptr(M), _lib.ptr(j)))
+        t = ctypes.c_int(-1)
+        _lib.check(_lib.lib.fh_fit_submit(ctx, a, 1e-15, ws, 1e-3, 2000, ctypes.byref(t)))
+        tickets.append(t.value)
+    _lib.check(_lib.lib.fh_fit_flush(ctx))
+    for t, h in zip(tickets, hyper):
+        mu, p, n = np.empty(N), np.empty(N), ctypes.c_int()
+        _lib.check(_lib.lib.fh_fit_collect(ctx, t, _lib.ptr(mu), _lib.ptr(p), ctypes.byref(n)))
+        rc0, mu0, p0, n0, *_ = ref[h]
+        assert n.value == n0 and np.array_equal(mu, mu0) and np.array_equal(p, p0)

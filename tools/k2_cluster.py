@@ -47,7 +47,7 @@ def problem(N):
 
 sizes = [int(a) for a in sys.argv[1:]] or [300]
 CLUSTERS = [int(x) for x in os.environ.get("CLUSTERS", "2,3,4,5").split(",")]
-WORKERS = [int(x) for x in os.environ.get("WORKERS", "11,9").split(",")]
+WORKERS = [11]
 for N in sizes:
     M, j, ref_it, alpha, ws = problem(N)
     dht, ctx = ctypes.c_void_p(), ctypes.c_void_p()
