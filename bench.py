@@ -191,6 +191,12 @@ class Fitter:
     def sync(self):
         self.L.check(self.L.lib.fh_ctx_synchronize(self.ctx))
 
+    def cluster_info(self):
+        """(workgroups the last synchronous fit ran on, cluster launches of this context that fell back to one CU)"""
+        wg, fb = ctypes.c_int(0), ctypes.c_int64(0)
+        self.L.check(self.L.lib.fh_fit_cluster_info(self.ctx, ctypes.byref(wg), ctypes.byref(fb)))
+        return wg.value, fb.value
+
 
 def steady_state(f, L, steps=0, ring=0, min_seconds=2.0):
     """fits/s of the pipeline over a run of at least `min_seconds` (the one drain of the last iterations, ~0.1 s, is then
@@ -327,6 +333,71 @@ def extras(f, L, a):
     def finalize():
         L.check(L.lib.fh_stats_finalize(f.ctx, ctypes.byref(f.geom), 0, 1, None, None, ctypes.byref(H0),
                                         ctypes.byref(qmn), ctypes.byref(qmx)))
+    # -- BASELINE configs[1] as a user runs it (fit.py:455-471 hands NumPy arrays): FrankFitter.fit(u, v, V, w) from HOST arrays --
+    #    upload over PCIe + binning pass + fit --, and the upload alone from pageable and from pinned host memory
+    try:
+        from frank_amd import FixedGeometry, FrankFitter
+        from frank_amd.mock import MOCK_GEOMETRY, mock_disc_visibilities
+        u, v, V, w = mock_disc_visibilities(f.nfit, seed=0, noise_seed=50)
+        FF = FrankFitter(RMAX_ARCSEC, N, FixedGeometry(**MOCK_GEOMETRY), alpha=h["alpha"], weights_smooth=h["wsmooth"],
+                         tol=h["tol"], max_iter=h["max_iter"], verbose=False, store_iteration_diagnostics=True)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            FF.fit(u, v, V, w)
+            ts.append(time.perf_counter() - t0)
+        nit_h = int(FF.iteration_diagnostics["num_iterations"])
+        FF2 = FrankFitter(RMAX_ARCSEC, N, FixedGeometry(**MOCK_GEOMETRY), alpha=h["alpha"], weights_smooth=h["wsmooth"],
+                          tol=h["tol"], max_iter=h["max_iter"], verbose=False)
+        t0 = time.perf_counter(); m = FF2.preprocess_visibilities(u, v, V, w); t_map = time.perf_counter() - t0
+        t0 = time.perf_counter(); FF2.fit_preprocessed(m); t_fit = time.perf_counter() - t0
+        Vre, Vim = np.ascontiguousarray(V.real), np.ascontiguousarray(V.imag)
+        nbytes = 8.0 * (u.size * 4 + w.size)
+
+        def upload(arrs):
+            best = None
+            for _ in range(3):
+                vis = ctypes.c_void_p()
+                t0 = time.perf_counter()
+                L.check(L.lib.fh_vis_upload(f.device, L.ptr(arrs[0]), L.ptr(arrs[1]), L.ptr(arrs[2]), L.ptr(arrs[3]), L.ptr(arrs[4]),
+                                            arrs[4].size, arrs[0].size, ctypes.byref(vis)))
+                dt = time.perf_counter() - t0
+                L.lib.fh_vis_destroy(vis)
+                best = dt if best is None else min(best, dt)
+            return best
+        t_page = upload((u, v, Vre, Vim, w))
+        pinned = None
+        try:  # the same five columns in pinned host memory (hipHostMalloc through the HIP runtime the library already loaded)
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipHostMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+            bufs, arrs = [], []
+            for x in (u, v, Vre, Vim, w):
+                ptr = ctypes.c_void_p()
+                if hip.hipHostMalloc(ctypes.byref(ptr), x.nbytes, 0) != 0:
+                    raise RuntimeError("hipHostMalloc failed")
+                bufs.append(ptr)
+                a_ = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_double)), shape=(x.size,))
+                a_[:] = x
+                arrs.append(a_)
+            pinned = upload(arrs)
+            del arrs
+            for ptr in bufs:
+                hip.hipHostFree(ptr)
+        except Exception as e:  # noqa: BLE001
+            pinned = repr(e)
+        ex["from_host_arrays"] = {
+            "workload": "FrankFitter(Rmax=%g, N=%d).fit(u, v, V, w) from NumPy arrays, %d visibilities (BASELINE configs[1] as "
+                        "fit.py:455-471 runs it): upload + binning pass + fit" % (RMAX_ARCSEC, N, u.size),
+            "s_per_fit": min(ts), "s_first_call": ts[0], "iterations": nit_h,
+            "preprocess_visibilities_s": t_map, "fit_preprocessed_s": t_fit,
+            "upload_bytes": nbytes, "upload_pageable_s": t_page, "upload_pageable_GBps": nbytes / t_page / 1e9,
+            "upload_pinned_s": pinned if isinstance(pinned, float) else None,
+            "upload_pinned_GBps": (nbytes / pinned / 1e9) if isinstance(pinned, float) else pinned,
+            "note": "the headline `value` starts with the table resident in HBM; this is the same fit paying PCIe (and the "
+                    "host's split of the complex visibilities into two columns)"}
+        del u, v, V, w, Vre, Vim
+    except Exception as e:  # noqa: BLE001
+        ex["from_host_arrays"] = {"error": repr(e)}
     # -- BASELINE configs[2]: LogNormal fit (alpha = 1.3, w_smooth = 1e-2 as the reference's own LogNormal test,
     #    tests.py:350) of the resident table, end to end; with the default line search (S^-1 (x + lam p) by linearity) and
     #    with the reference's arithmetic (every trial point multiplied out) -- include/frank_hip.h
@@ -673,12 +744,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # split of one step (untimed, after the measured region)
+    fallbacks_timed = f.cluster_info()[1]
+    # split of one step (untimed, after the measured region): the fit loop as a single fit runs it (a cluster of workgroups,
+    # include/frank_hip.h: fh_fit_cluster_info) and on ONE compute unit, the form the steady state runs
     t0 = time.perf_counter(); f.bin(); f.sync(); t_bin = time.perf_counter() - t0
     t0 = time.perf_counter(); f.solve(); f.sync(); t_solve = time.perf_counter() - t0
     kms_alone = f.kernel_ms()
     pre_alone = f.prepass_ms()
     loop_ms = f.loop_kernel_ms()
+    loop_wgs = f.cluster_info()[0]
+    prev = os.environ.get("FRANK_AMD_K2_CLUSTER")
+    os.environ["FRANK_AMD_K2_CLUSTER"] = "1"
+    f.solve(); f.sync()
+    loop_ms_one = f.loop_kernel_ms()
+    if prev is None:
+        del os.environ["FRANK_AMD_K2_CLUSTER"]
+    else:
+        os.environ["FRANK_AMD_K2_CLUSTER"] = prev
 
     sharded = sweep_multi = None
     hung = False
@@ -713,6 +795,7 @@ def main():
         flops_pass = 2.0 * n_aug ** 3 / 3.0
         flops_fit = flops_pass * (nit + 2)
         achieved = flops_fit / (loop_ms * 1e-3) / 1e12
+        achieved_one = flops_fit / (loop_ms_one * 1e-3) / 1e12
         peak_cu = FP64_MFMA_PEAK_TFLOPS / N_CU
         # HBM bytes per launch: STATIC values, read from the PMC summaries committed under profiles/ (rocprofv3 cannot run inside
         # bench.py); they describe the build the profile was taken from, named in the *_source fields
@@ -750,6 +833,7 @@ def main():
         flops_sym = a.nvis * (Nc * (Nc + 1) + 2 * Nc)       # what binning the visibilities row by row costs
         out = {
             "metric": "FrankFitter solves/sec (N=%d, %.0e visibilities per fit, Normal, fp64, end-to-end)" % (Nc, a.nvis),
+            "library": L.lib.fh_version().decode(),
             "value": value, "unit": "fits/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -762,14 +846,25 @@ def main():
             "breakdown_ms": {"single_fit_latency": 1e3 * (t_bin + t_solve), "bin_gram_pass": 1e3 * t_bin,
                              "finalize_plus_iterate": 1e3 * t_solve, "us_per_iteration": 1e6 * t_solve / max(nit, 1),
                              "binning_pass_by_events": pre_alone + kms_alone, "fit_loop_kernel": loop_ms,
-                             "note": "steps are pipelined: fit i's iteration (one CU) overlaps fit i+1's binning; the "
-                                     "timed region = steps x (binning + hand-over) + one drain of finalize_plus_iterate"},
-            "roofline": {"kernel": K2_KERNEL_NAME, "bound": "mfma", "achieved": achieved, "peak": peak_cu, "unit": "TFLOP/s",
-                         "frac": achieved / peak_cu, "traffic": traffic, "traffic_source": traffic_src,
+                             "fit_loop_workgroups": loop_wgs, "fit_loop_kernel_on_one_cu": loop_ms_one,
+                             "us_per_pass_cluster": 1e3 * loop_ms / (nit + 2), "us_per_pass_one_cu": 1e3 * loop_ms_one / (nit + 2),
+                             "cluster_fallbacks_in_the_timed_region": fallbacks_timed,
+                             "note": "steps are pipelined: fit i's iteration overlaps fit i+1's binning; a shallow pipeline (this "
+                                     "region) runs every fit on a cluster of workgroups of one XCD (fit_loop.hip, clu::), a deep "
+                                     "one (extra.steady_state) on one compute unit each; the timed region = steps x (binning + "
+                                     "hand-over) + one drain of finalize_plus_iterate"},
+            "roofline": {"kernel": K2_KERNEL_NAME + " (cluster mode: %d workgroups per fit, as the timed region runs it)" % loop_wgs,
+                         "bound": "mfma", "achieved": achieved, "peak": peak_cu * loop_wgs, "unit": "TFLOP/s",
+                         "frac": achieved / (peak_cu * loop_wgs), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": loop_ms, "passes": nit + 2, "algorithmic_flops_per_pass": flops_pass,
-                         "peak_note": "the kernel is one workgroup: peak = one CU's share (1/256) of the 78.6 TFLOP/s "
-                                      "fp64 matrix peak; a pipeline of fits keeps one CU per outstanding fit busy",
-                         "why_this_kernel": "most of the GPU time of the timed region (profiles/r03_kernel_stats.csv)"},
+                         "peak_note": "peak = the share of the 78.6 TFLOP/s fp64 matrix peak of the %d compute units a fit holds "
+                                      "in cluster mode (%d/256); the mode buys latency (a pass is a chain of 19 dependent tile "
+                                      "factorisations) with compute units that mostly wait -- the fraction per CU is lower "
+                                      "than on one CU by design" % (loop_wgs, loop_wgs),
+                         "why_this_kernel": "most of the GPU time of the timed region (profiles/)",
+                         "one_cu": {"kernel": K2_KERNEL_NAME + " on one compute unit (FRANK_AMD_K2_CLUSTER=1: the form of the steady "
+                                              "state and of the batched sweeps)", "achieved": achieved_one, "peak": peak_cu,
+                                    "frac": achieved_one / peak_cu, "kernel_ms": loop_ms_one}},
             "roofline_binning": {"kernel": "binning pass: uv_hist, bucket_scan, deproject_scatter, piece_moments, bucket_factor2, "
                                            + K1_KERNEL_NAME + ", vr_finish (bin_prepass.hip)",
                                  "bound": "hbm", "achieved": bin_GBps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -795,9 +890,8 @@ def main():
             ss = out["extra"].get("steady_state", {})
             if "fits_per_s" in ss:  # the same algorithmic flops against the WHOLE chip, at the rate the pipeline sustains
                 out["roofline"]["chip_fraction_at_steady_state"] = ss["fits_per_s"] * flops_fit / 1e12 / FP64_MFMA_PEAK_TFLOPS
-                out["roofline"]["chip_note"] = ("one fit loop is one CU: frac above is against 1/256 of the chip; at steady state up "
-                                                "to %d fits are outstanding, in launches of up to 64 fit loops on four streams "
-                                                "(~190 loops resident)" % ss.get("fit_slots", 0))
+                out["roofline"]["chip_note"] = ("at steady state a fit loop is one CU and up to %d fits are outstanding, in "
+                                                "launches of up to 64 fit loops (~190 loops resident)" % ss.get("fit_slots", 0))
         if not a.no_cpu_baseline and world == 1:  # the CPU leg is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(a.ncoll, a.nvis, nit)
         print(json.dumps(out), flush=True)

@@ -221,6 +221,7 @@ struct fh_ctx {
     int pending_batch = -1;  // batch that is still collecting submissions (not launched)
     int fit_batch = kFitBatchMax;
     int burst_next = 1;      // fits that trigger the next launch: 1, 2, 4, .. up to fit_batch while a pipeline fills up
+    int next_xcd = 0;        // XCD of the first fit of the next cluster launch
     hipEvent_t stream_last_done[kLaunchStreamsMax] = {};  // completion event of the last launch each launch stream was given
     size_t slot_stride = 0;
     int slots_busy = 0;
@@ -2091,14 +2092,14 @@ static int flush_pending_batch(fh_ctx *c) {
         c->stream_last_done[pick] = b.done;
     }
     // few fits outstanding: every fit of this launch on a cluster of workgroups (the latency of a pass is what a shallow
-    // pipeline waits for); the compute units the clusters of all launches in flight may hold: FRANK_AMD_K2_CLUSTER_CUS (128)
+    // pipeline waits for).  A fit on a cluster works on ~2 MB (A, the factor, its inverse, the trailing tiles in flight)
+    // against 1.1 MB on one compute unit, and an XCD's L2 holds 4 MB: one cluster per XCD runs a pass at N = 300 in 107 us
+    // (8 fits at once; one CU each: 138), two in 123, with twenty on the device a pass takes the 142 us it takes on one CU
+    // (tools/k2_concurrency.py).  So: clusters while at most FRANK_AMD_K2_CLUSTER_FITS (8) fits are outstanding.
     {
-        static const int budget = env_int("FRANK_AMD_K2_CLUSTER_CUS", 128);
+        static const int most = env_int("FRANK_AMD_K2_CLUSTER_FITS", 8);
         const int g = fit_cluster_size(c);
-        int held = 0;
-        for (const FitBatch &o : c->batches)
-            if (o.active && o.launched) held += o.outstanding * o.cluster;
-        b.cluster = (g > 1 && held + b.n * g <= budget) ? g : 1;
+        b.cluster = (g > 1 && c->slots_busy <= most) ? g : 1;  // (slots_busy counts the fits of this launch too)
     }
     HIP_TRY(hipEventRecord(b.ready, c->stream));  // the operands of its fits were prepared on the context's stream
     HIP_TRY(hipStreamWaitEvent(b.stream, b.ready, 0));
@@ -2120,6 +2121,10 @@ static int flush_pending_batch(fh_ctx *c) {
     P.out_host = c->slot_out_host;
     P.result_host = c->slot_result_host;
     P.cluster = b.cluster;
+    if (b.cluster > 1) {  // the fits of consecutive cluster launches go round the XCDs
+        P.cluster_xcd0 = c->next_xcd & 7;
+        c->next_xcd = (c->next_xcd + b.n) & 7;
+    }
     HIP_TRY(fh_k2_launch_loop_slots(P, b.n, b.stream));
     HIP_TRY(hipEventRecord(b.done, b.stream));
     b.launched = true;
@@ -2239,8 +2244,20 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
     s.busy = true;
     ++c->slots_busy;
     *ticket = si;
-    static const int early = env_int("FRANK_AMD_FIT_EARLY", 1);
-    const int trigger = early ? (c->burst_next < c->fit_batch ? c->burst_next : c->fit_batch) : c->fit_batch;
+    // A pipeline that is filling up sends its first launches small (1, 2, 4 fits) so that the first fits start at once -- but
+    // only while fewer than three launches are in flight: the command processor runs about four queues at a time, a fifth
+    // launch waits for a whole fit loop to end (measured: 20 fits in launches of 1, 2, 4, 8, 5 took 229 ms against 116 in one),
+    // and the binning stream needs its own.
+    // OFF by default (FRANK_AMD_FIT_EARLY=1 turns it on): the first fits come back a launch earlier, but the fits of the small
+    // launches run on clusters and the later ones, on one CU each, beside them: 20 fits 128 ms against 115 in one launch, and the
+    // driver's 20-step region 178 fits/s against 200 -- that region ends with the LAST fit's iteration whenever it is launched.
+    static const int early = env_int("FRANK_AMD_FIT_EARLY", 0);
+    int in_flight = 0;
+    for (const FitBatch &o : c->batches)
+        if (o.active && o.launched && hipEventQuery(o.done) != hipSuccess) ++in_flight;
+    (void)hipGetLastError();
+    const bool small_ok = early && in_flight < 3 && c->burst_next < c->fit_batch;
+    const int trigger = small_ok ? c->burst_next : c->fit_batch;
     if (b.n >= trigger) {
         c->burst_next = 2 * trigger;
         return flush_pending_batch(c);

@@ -238,7 +238,7 @@ __device__ __forceinline__ void inverse_tile(const gdouble *Cu, const double *dl
 // itself only waits for LDS), thread 0 raises the word behind the barrier with an agent-scope store -- executed in the L2 the
 // helpers share --, and a helper invalidates its L1 when it has seen the value it needs.  Workgroup ids 0, 8, 16, .. of a
 // launch go to one XCD; the XCC_ID register of every member is checked at start-up and a cluster that is not on one XCD, or
-// whose helpers do not show up within 200 us, ends with FIT_STATUS_CLUSTER (the host runs the fit on one CU then).  Every wait
+// whose helpers do not show up within 3 ms, ends with FIT_STATUS_CLUSTER (the host runs the fit on one CU then).  Every wait
 // is bounded by the wall clock.
 namespace clu {
 // control words (ints), zero between fits: PROG progress of the factorisation, DONE helper waves that have handed over their
@@ -1306,7 +1306,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     // a fit are `cluster` consecutive ones of ONE XCD: fit (i / cluster) * 8 + x of the launch, member i % cluster
     int launch_index = blockIdx.x, member = 0;
     if constexpr (CL) {
-        const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int x = (blockIdx.x - P.cluster_xcd0) & 7, i = blockIdx.x >> 3;
         launch_index = (i / P.cluster) * 8 + x;
         member = i % P.cluster;
         if (launch_index >= P.nfits) return;
@@ -1429,14 +1429,16 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     }
     __shared__ int s_ctl[4];  // [0] stop, [1] status, [2] cluster assembled
     if constexpr (CL) {
-        // the helpers have 200 us to show up, all on this XCD; otherwise the fit ends with FIT_STATUS_CLUSTER (the host runs
-        // it on one CU) and helpers that arrive later find the word negative and leave
+        // the helpers have 3 ms to show up (beside a binning pass their workgroups queue behind its thousands: 200 us, the first
+        // value, made a quarter of a pipeline's clusters fall back), all on this XCD; otherwise the fit ends with
+        // FIT_STATUS_CLUSTER (the host runs it on one CU) and helpers that arrive later find the word negative and leave
+        constexpr long long kAssembleUs = 3000;
         if (tid == 0) {
             const long long t0 = wall_clock64();
             int ok = 1;
             while (clu::ld(ctl + clu::IN) < P.cluster - 1) {
                 __builtin_amdgcn_s_sleep(2);
-                if (wall_clock64() - t0 > 200 * clu::kTicksPerUs) {
+                if (wall_clock64() - t0 > kAssembleUs * clu::kTicksPerUs) {
                     ok = 0;
                     break;
                 }

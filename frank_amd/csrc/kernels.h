@@ -232,6 +232,8 @@ struct FitLoopParams {
     int cluster;            // 0 / 1: none
     int cluster_inv;        // helpers of the inverse among the cluster - 1 helpers (the others: helpers of the trailing update)
     int cluster_break;      // tests (FRANK_AMD_K2_CLUSTER_BREAK=1): the helpers leave at once, the cluster never assembles
+    int cluster_xcd0;       // the XCD the first fit of the launch goes to (fit f sits on XCD (cluster_xcd0 + f) & 7): the host
+                            // deals the small launches of a filling pipeline round the XCDs (a cluster wants an L2 to itself)
     int nfits;              // fits of a cluster launch (slot launch: entries of slot_words; single fit: 1)
 };
 #define FIT_MAX_BATCH 128

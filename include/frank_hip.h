@@ -239,7 +239,7 @@ int fh_fit_collect(fh_ctx *ctx, int ticket, double *mu, double *p, int *niter);
  * block columns of the inverse of the factor that Tr2 and the mean need (one wave per column); the arithmetic of every tile
  * is the one the single-workgroup kernel does, so the results are the same bits.  FRANK_AMD_K2_CLUSTER = 1 turns the mode
  * off, 2 .. 8 set the size (default 5: two helpers of the inverse, two of the trailing update; 3 for N > 335).  *workgroups: what the last fh_fit_normal ran on; *fallbacks: cluster launches of this
- * context that did not assemble on one XCD within 200 us and were repeated on one compute unit (either may be NULL).     */
+ * context that did not assemble on one XCD within 3 ms and were repeated on one compute unit (either may be NULL).     */
 int fh_fit_cluster_info(fh_ctx *ctx, int *workgroups, int64_t *fallbacks);
 
 /* Batched form for hyper-parameter sweeps over ONE mapping (fit.py:534-548 re-runs the whole fit per (alpha,
