@@ -596,13 +596,17 @@ def sharded_leg(f, L, a, dist, rank, world, local_rank, barrier, out, out2):
     every rank bins its slab, ONE RCCL all-reduce sums the packed upper-triangle Gram + scalars (and a 2-double
     max-reduce the baseline range), then every rank holds M, j and solves (rank 0's solve is the fit)."""
     import torch
-    from frank_amd.distributed import RcclComm
+    from frank_amd.distributed import make_comm
 
     def bcast(ident):
         t = torch.tensor(list(ident if ident is not None else bytes(128)), dtype=torch.uint8)
         dist.broadcast(t, 0)
         return bytes(t.tolist())
-    comm = RcclComm(rank, world, f.device, bcast)
+    # RCCL over xGMI, one rank per GPU; ranks that share a device (more ranks than GPUs: RCCL refuses that) reduce through the
+    # host over gloo instead (frank_amd.distributed.HostComm) -- the leg then says so under "comm"
+    if world > max(L.device_count(), 1):
+        os.environ["FRANK_AMD_COMM"] = "host"
+    comm = make_comm(rank, world, f.device, bcast)
     shard = f.n_shard
     times, ar_ms, bin_ms = [], [], []
     nit_s = 0
@@ -628,7 +632,7 @@ def sharded_leg(f, L, a, dist, rank, world, local_rank, barrier, out, out2):
     nbytes = payload.value * 8
     out.update({"workload": "BASELINE configs[3]: one N=%d fit of %d visibilities sharded over %d ranks "
                             "(%d per rank)" % (a.ncoll, shard * world, world, shard),
-                "nvis_total": shard * world, "nvis_per_rank": shard, "rccl_ranks": comm.size(),
+                "nvis_total": shard * world, "nvis_per_rank": shard, "rccl_ranks": comm.size(), "comm": type(comm).__name__,
                 "s_per_fit": float(t.item()), "fits_per_s": 1.0 / float(t.item()),
                 "vis_per_s": shard * world / float(t.item()),
                 "allreduce_us": 1e3 * float(np.median(ar_ms)),
@@ -638,8 +642,10 @@ def sharded_leg(f, L, a, dist, rank, world, local_rank, barrier, out, out2):
                                                "a few microseconds each" % (nbytes / 1024.0)},
                 "binning_pass_ms_per_rank": [float(x.item()) for x in pass_all],
                 "iterations": nit_s,
-                "collective": "ncclAllReduce(sum) of %d doubles (%.0f KB) + ncclAllReduce(max) of 2 doubles, on the "
-                              "context's stream" % (payload.value, nbytes / 1024.0)})
+                "collective": ("ncclAllReduce(sum) of %d doubles (%.0f KB) + ncclAllReduce(max) of 2 doubles, on the "
+                               "context's stream" if type(comm).__name__ == "RcclComm" else
+                               "gloo all_reduce(sum) of %d doubles (%.0f KB) + all_reduce(max) of 2 doubles, staged through the "
+                               "host (the ranks share a device)") % (payload.value, nbytes / 1024.0)})
     # -- BASELINE configs[4] over the ranks: 512 fits (32 alpha x 16 w_smooth) of ONE mapping of 1e6 visibilities.  Rank 0
     #    bins the table; the packed statistics (380 KB) reach every rank through the same all-reduce (the other ranks
     #    contribute zeros); every rank runs its contiguous slice of the grid in one batched launch, no further communication

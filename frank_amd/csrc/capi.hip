@@ -2315,6 +2315,34 @@ int fh_fit_collect(fh_ctx *c, int ticket, double *mu, double *p, int *niter) {
     return FH_OK;
 }
 
+// The packed statistics of the last binning pass to / from the host: what a reduction over ranks that does not go through
+// RCCL needs (frank_amd.distributed.HostComm: two processes on ONE device, which RCCL refuses; any torch.distributed backend).
+int fh_stats_get_packed(fh_ctx *c, double *sum_stats, int64_t n, double *minmax) {
+    double *dsum = nullptr, *dmm = nullptr;
+    int64_t len = 0;
+    const int rc = fh_stats_device(c, &dsum, &len, &dmm);
+    if (rc) return rc;
+    if (!sum_stats || !minmax || n != len) return fail(FH_ERR_INVALID, "fh_stats_get_packed: the packed statistics hold %lld doubles", (long long)len);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(sum_stats, dsum, sizeof(double) * (size_t)len, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(minmax, dmm, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+int fh_stats_set_packed(fh_ctx *c, const double *sum_stats, int64_t n, const double *minmax) {
+    double *dsum = nullptr, *dmm = nullptr;
+    int64_t len = 0;
+    const int rc = fh_stats_device(c, &dsum, &len, &dmm);
+    if (rc) return rc;
+    if (!sum_stats || !minmax || n != len) return fail(FH_ERR_INVALID, "fh_stats_set_packed: the packed statistics hold %lld doubles", (long long)len);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dsum, sum_stats, sizeof(double) * (size_t)len, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dmm, minmax, sizeof(double) * 2, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_device_Mj = false;
+    return FH_OK;
+}
+
 int fh_stats_upload(fh_ctx *c, const double *M, const double *j) {
     if (!c || !M || !j) return fail(FH_ERR_INVALID, "fh_stats_upload: NULL argument");
     HIP_TRY(hipSetDevice(c->device));

@@ -34,6 +34,57 @@ def allreduce_mapping(M, j, H0, qmin, qmax, group=None):
     return out[:N * N].reshape(N, N).copy(), out[N * N:N * N + N].copy(), float(out[-1]), -float(mm[0]), float(mm[1])
 
 
+class HostComm:
+    """The same reduction as RcclComm.allreduce_stats, staged through the host over any torch.distributed backend (gloo): the
+    packed statistics come off the device (fh_stats_get_packed, ~380 KB at N = 300), are summed over the ranks of the default
+    process group, and go back (fh_stats_set_packed).  For ranks that SHARE a device -- RCCL refuses two ranks on one GPU --
+    and for boxes without RCCL; FRANK_AMD_COMM=host selects it in make_comm."""
+
+    def __init__(self, rank, world, device=0, broadcast_bytes=None, group=None):
+        from frank_amd import _lib
+        self._lib, self._world, self._group = _lib, int(world), group
+        self.handle = True
+        self._ms = 0.0
+
+    def allreduce_stats(self, ctx):
+        import ctypes
+        import time
+        import torch
+        import torch.distributed as dist
+        L = self._lib
+        n = ctypes.c_int64(0)
+        L.check(L.lib.fh_stats_device(ctx, None, ctypes.byref(n), None))
+        buf, mm = np.empty(n.value), np.empty(2)
+        L.check(L.lib.fh_stats_get_packed(ctx, L.ptr(buf), n.value, L.ptr(mm)))
+        t0 = time.perf_counter()
+        tb = torch.from_numpy(buf)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM, group=self._group)
+        # (-qmin, qmax): NaN is the device's neutral element "nothing binned"; a max over ranks wants -inf instead
+        tm = torch.from_numpy(np.where(np.isnan(mm), -np.inf, mm))
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX, group=self._group)
+        self._ms = 1e3 * (time.perf_counter() - t0)
+        mm = tm.numpy()
+        mm = np.ascontiguousarray(np.where(np.isinf(mm) & (mm < 0), np.nan, mm))
+        L.check(L.lib.fh_stats_set_packed(ctx, L.ptr(buf), n.value, L.ptr(mm)))
+
+    def last_allreduce_ms(self):
+        return self._ms
+
+    def size(self):
+        return self._world
+
+    def close(self):
+        self.handle = None
+
+
+def make_comm(rank, world, device, broadcast_bytes, group=None):
+    """RcclComm, or HostComm when FRANK_AMD_COMM=host (ranks sharing a device, no RCCL)."""
+    import os
+    if os.environ.get("FRANK_AMD_COMM", "rccl").lower() == "host":
+        return HostComm(rank, world, device, broadcast_bytes, group)
+    return RcclComm(rank, world, device, broadcast_bytes)
+
+
 class RcclComm:
     """RCCL communicator for the device-resident statistics (one rank per GPU)."""
 

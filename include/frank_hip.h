@@ -224,6 +224,12 @@ int fh_fit_normal(fh_ctx *ctx, const double *M, const double *j, double alpha, d
  * fh_fit_flush launches what has been staged so far -- call it after the last submission; fh_fit_collect on a fit
  * whose launch is still open does the same.  fh_fit_collect waits for that fit and returns mu, p, niter exactly as
  * fh_fit_normal does.  Tickets are collected in any order; at most fh_fit_slots() fits may be outstanding.     */
+/* The packed statistics of the last binning pass (what fh_comm_allreduce_stats reduces in place on the device: n doubles, n from
+ * fh_stats_device; minmax = (-qmin, qmax), NaN where nothing was binned) copied to / replaced from the host: for a reduction over
+ * ranks that does not go through RCCL (two ranks on one device, any torch.distributed backend -- frank_amd.distributed.HostComm);
+ * the sums are those of statistical_models.py:210-211, 218.                                                                  */
+int fh_stats_get_packed(fh_ctx *ctx, double *sum_stats, int64_t n, double *minmax);
+int fh_stats_set_packed(fh_ctx *ctx, const double *sum_stats, int64_t n, const double *minmax);
 /* fh_stats_upload: M (N*N, row-major) and j (N) from the HOST become the context's device-resident normal equations -- what
  * fh_stats_finalize leaves there after a binning pass -- so that fh_fit_submit / fh_fit_normal(ctx, NULL, NULL, ..) can run on
  * statistics computed elsewhere (a saved mapping, the sum of several tables: statistical_models.py:220-237 hands them around as

@@ -392,6 +392,56 @@ def test_two_device_rccl_allreduce(case):
         assert abs(r["H0"] - single["null_likelihood"]) <= 1e-12 * abs(single["null_likelihood"])
 
 
+@pytest.mark.parametrize("case", ["tiles_N300", "wide_N320", "debris_N40"])
+def test_two_processes_sharded_fit_on_this_box(tmp_path, case):
+    """BASELINE configs[3] in small, with TWO REAL PROCESSES under the driver's launcher (tests/dist_worker.py): each rank
+    bins its shard_range slab of one table on the GPU, the packed statistics are all-reduced -- over RCCL when the box has two
+    devices, staged through the host over gloo (frank_amd.distributed.HostComm) when both ranks share device 0, which RCCL
+    refuses --, every rank finalises and fits.  Against the unsharded fit on this process's device: M, j to 1e-13 of the
+    maximum (the order of the sums differs), H0 to 1e-12, the SAME iteration count, the profile to 1e-9; both ranks hold
+    identical bits.  For the packed tile triangle (N = 300), N = 320 and the debris model's dense Gram."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from frank_amd import _lib, FourierBesselFitter
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import dist_worker as dw
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dist_worker.py"), case, str(tmp_path)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    ranks = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(2)]
+    N, nvis, vis_model, sh = dw.CASES[case]
+    u, v, V, w = mock_disc_visibilities(nvis, seed=41, noise_seed=42)
+    kw = dict(verbose=False)
+    if vis_model == "debris":
+        kw.update(assume_optically_thick=False, scale_height=sh)
+    FB = FourierBesselFitter(2.0, N, geom(), **kw)
+    single = FB.preprocess_visibilities(u, v, V, w)
+    h = dw.HYPER
+    mu, p, nit = np.empty(N), np.empty(N), ctypes.c_int(0)
+    _lib.check(_lib.lib.fh_fit_normal(FB._DHT.context(), _lib.ptr(np.ascontiguousarray(single["M"])),
+                                      _lib.ptr(np.ascontiguousarray(single["j"])), h["alpha"], h["p0"], h["wsmooth"], h["tol"],
+                                      h["max_iter"], _lib.ptr(mu), _lib.ptr(p), ctypes.byref(nit), None, None))
+    a, b = ranks
+    assert int(a["ranks"]) == 2 and int(a["rows"]) + int(b["rows"]) == nvis and int(a["rows"]) > 0 and int(b["rows"]) > 0
+    expect = "RcclComm" if _lib.device_count() >= 2 else "HostComm"
+    assert str(a["kind"]) == expect and str(b["kind"]) == expect
+    assert np.array_equal(a["M"], b["M"]) and np.array_equal(a["j"], b["j"]) and float(a["H0"]) == float(b["H0"])
+    assert np.array_equal(a["mu"], b["mu"]) and int(a["niter"]) == int(b["niter"])
+    for rk in ranks:
+        assert rel_to_max(rk["M"], single["M"]) < 1e-13 and rel_to_max(rk["j"], single["j"]) < 1e-13
+        assert abs(float(rk["H0"]) - single["null_likelihood"]) <= 1e-12 * abs(single["null_likelihood"])
+        assert int(rk["niter"]) == nit.value
+        assert rel_to_max(rk["mu"], mu) < 1e-9
+
+
 # ---- fp32 arithmetic (BASELINE configs[2], north_star "1e-3 fp32") ---------------------------------------------------
 @pytest.mark.parametrize("name,N", [("fit_N100_1e5.npz", 100), ("fit_N300_1e6.npz", 300)])
 def test_fp32_arithmetic_binning(golden, name, N):
