@@ -38,6 +38,8 @@ class fh_geometry(ctypes.Structure):
 # name -> (restype, argtypes); every symbol include/frank_hip.h declares
 SIGNATURES = {
     "fh_last_error": (ctypes.c_char_p, []),
+    "fh_init": (ctypes.c_int, []),
+    "fh_last_warning": (ctypes.c_char_p, []),
     "fh_version": (ctypes.c_char_p, []),
     "fh_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     "fh_dht_create": (ctypes.c_int, [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
@@ -134,8 +136,21 @@ for _name, (_res, _args) in SIGNATURES.items():
     _f.argtypes = _args
 
 
+# The one thing this package changes in the process: GPU_MAX_HW_QUEUES=24 unless the variable is set (include/frank_hip.h:
+# fh_init) -- HIP reads it at its first call, and the launches of a pipeline of fits want more than the default four queues.
+lib.fh_init()
+
+
 def last_error():
     return lib.fh_last_error().decode("utf-8", "replace")
+
+
+def warn_if_any():
+    """Turn the library's warning about the last context (too few hardware queues) into a Python RuntimeWarning."""
+    msg = lib.fh_last_warning().decode("utf-8", "replace")
+    if msg:
+        import warnings
+        warnings.warn("frank_amd: " + msg, RuntimeWarning, stacklevel=3)
 
 
 def check(rc, value_error_codes=(FH_ERR_INVALID, FH_ERR_QRANGE, FH_ERR_BAD_P, FH_ERR_NUMERIC)):
@@ -171,6 +186,17 @@ def all_float32(u, v, V, weights):
     dts = [np.asarray(x).dtype for x in (u, v, weights)]
     vd = np.asarray(V).dtype
     return all(d == np.float32 for d in dts) and vd in (np.dtype(np.complex64), np.dtype(np.float32))
+
+
+def require_scipy(what):
+    """scipy.optimize for the few callers that hand work to SciPy as the reference does (the 'scipy' optimizer of the geometry
+    fits, NNLS); the hot path and every default need NumPy + ctypes only."""
+    try:
+        import scipy.optimize
+    except ImportError as e:  # pragma: no cover
+        raise ImportError("frank_amd: %s needs SciPy, an optional dependency of this package (everything else runs on NumPy "
+                          "+ the HIP library); install scipy or use the default options" % what) from e
+    return scipy.optimize
 
 
 def device_count():

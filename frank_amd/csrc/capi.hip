@@ -256,12 +256,25 @@ struct fh_comm {
     const char *(*errstr)(int) = nullptr;
 };
 
-// The default of 4 hardware queues would serialise the fit_loop kernels of independent fits; this must be in the
-// environment before the HIP runtime initialises (first HIP call), so it is set when the library is loaded and never
-// overrides a value the user chose.
-__attribute__((constructor)) static void fh_raise_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+// HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels whose streams share a queue serialise: the
+// launches of a pipeline of fits (up to six streams beside the binning stream) want at least eight.  The variable is read when
+// the HIP runtime initialises (the first HIP call of the process), so it can only be set before that -- by the embedding
+// application, or by an explicit fh_init(); loading this library changes nothing in the process (rounds 1-3 did it in a
+// constructor).  A context created with fewer queues records a warning (fh_last_warning).
+static thread_local std::string g_warn;
+constexpr int kHwQueuesWanted = 8;
+static int hw_queues_env() {
+    const char *e = getenv("GPU_MAX_HW_QUEUES");
+    return e ? atoi(e) : 4;  // (the runtime's default)
+}
 
 extern "C" {
+
+int fh_init(void) {
+    setenv("GPU_MAX_HW_QUEUES", "24", 0);  // never overrides a value the user chose
+    return hw_queues_env();
+}
+const char *fh_last_warning(void) { return g_warn.c_str(); }
 
 const char *fh_last_error(void) { return g_err.c_str(); }
 const char *fh_version(void) { return "frank_amd 0.1 (gfx950)"; }
@@ -525,6 +538,15 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     }
     const int rc = fh_bin_reset(c);
     if (rc != FH_OK) return rc;
+    g_warn.clear();
+    if (hw_queues_env() < kHwQueuesWanted) {
+        char buf[320];
+        snprintf(buf, sizeof buf, "GPU_MAX_HW_QUEUES=%d: pipelined fits (fh_fit_submit) put their launches on up to six streams beside "
+                 "the binning stream; with fewer than %d hardware queues HIP lets streams share a queue and their kernels serialise. "
+                 "Call fh_init() -- or export GPU_MAX_HW_QUEUES=24 -- before the first HIP call of the process.", hw_queues_env(),
+                 kHwQueuesWanted);
+        g_warn = buf;
+    }
     *out = guard.release();
     return FH_OK;
 }

@@ -186,7 +186,6 @@ class FitGeometryGaussian(SourceGeometry):
 def _fit_geometry_gaussian(u, v, V, weights, guess, inc_pa=None, phase_centre=None, device=None, optimizer='device'):
     """(inc, PA, dRA, dDec) of the best Gaussian, `guess` = [inc, PA (deg), dRA, dDec (arcsec), norm, width]
     (geometry.py:498-599)."""
-    from scipy.optimize import least_squares
     from frank_amd import _lib
     from frank_amd.hankel import default_device
     x0 = np.array(guess, dtype=np.float64)
@@ -240,7 +239,8 @@ def _fit_geometry_gaussian(u, v, V, weights, guess, inc_pa=None, phase_centre=No
         return full(xf)
 
     try:
-        xbest = device_fit() if optimizer == 'device' else least_squares(fun, x0, jac=jac, method='lm').x
+        xbest = device_fit() if optimizer == 'device' else _lib.require_scipy(
+            "optimizer='scipy' of the geometry fits").least_squares(fun, x0, jac=jac, method='lm').x
     finally:
         table.close()
     inc, PA, dRA, dDec = xbest[:4]
@@ -388,7 +388,6 @@ class FitGeometryFourierBessel(SourceGeometry):
             self._inc, self._PA = self._inc_pa
             self._dRA, self._dDec = self._phase_centre
             return
-        from scipy.optimize import least_squares
         from frank_amd.hankel import DiscreteHankelTransform
         logging.info('    Fitting nonparametric form to determine geometry' +
                      (' (your supplied inclination and position angle will be applied at the end of the geometry '
@@ -402,7 +401,9 @@ class FitGeometryFourierBessel(SourceGeometry):
             if self._optimizer == 'device':
                 best, success = self._fit_on_device(DHT, table)
             else:
-                result = least_squares(self._residual, self._guess, kwargs={'uvdata': (DHT, table)}, method='lm')
+                from frank_amd import _lib
+                result = _lib.require_scipy("optimizer='scipy' of the geometry fits").least_squares(
+                    self._residual, self._guess, kwargs={'uvdata': (DHT, table)}, method='lm')
                 best, success = result.x, result.success
         finally:
             table.close()

@@ -76,6 +76,7 @@ class DiscreteHankelTransform(object):
         if c is None:
             c = ctypes.c_void_p()
             _lib.check(_lib.lib.fh_ctx_create(self._handle, device, ctypes.byref(c)))
+            _lib.warn_if_any()
             self._ctx[device] = c
         return c
 

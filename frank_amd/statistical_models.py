@@ -441,10 +441,11 @@ class GaussianModel:
 
     def solve_non_negative(self):
         """statistical_models.py:858-866 (SciPy NNLS on the host; off the hot path)."""
-        import scipy.optimize
+        from frank_amd import _lib
+        nnls = _lib.require_scipy("solve_non_negative (scipy.optimize.nnls)").nnls
         Sinv = self._sinv()
         Dinv = self._M + (Sinv if Sinv is not None else 0)
-        return scipy.optimize.nnls(Dinv, self._j, maxiter=100 * len(self._j))[0]
+        return nnls(Dinv, self._j, maxiter=100 * len(self._j))[0]
 
     @property
     def mean(self):

@@ -52,6 +52,14 @@ typedef struct fh_geometry {
 } fh_geometry;
 
 const char *fh_last_error(void);
+/* Optional, ONCE, before the first HIP call of the process (any other entry point that touches the device, or the embedding
+ * application's own HIP code): exports GPU_MAX_HW_QUEUES=24 unless the variable is already set -- HIP maps streams onto that many
+ * hardware queues (default 4) and kernels whose streams share a queue serialise; a pipeline of fits (fh_fit_submit) uses up to six
+ * launch streams beside the binning stream.  Returns the value in effect.  Loading the library has no side effect on the process;
+ * a context created with fewer than eight queues leaves a message in fh_last_warning() ("" otherwise; valid until the next
+ * fh_ctx_create on this thread).  The Python package calls fh_init() when it is imported.                                  */
+int fh_init(void);
+const char *fh_last_warning(void);
 const char *fh_version(void);
 /* Number of usable HIP devices (0 => every device entry point returns FH_ERR_HIP). */
 int fh_device_count(int *count);
