@@ -433,6 +433,71 @@ def extras(f, L, a):
             np.abs(I_lin - I_ref).max() / np.abs(I_ref).max())
     except Exception as e:
         ex.setdefault("lognormal_fullsize", {})["error"] = repr(e)
+    # -- the binning pass when the baselines REACH the last collocation frequency -- how frank is normally set up (N chosen so
+    #    that q[-1] just clears the data, statistical_models.py:512-535): the same rows stretched to 0.95 Q_max fall into ~1 900
+    #    buckets of J0 arguments (55 MB of Taylor tables) instead of the 243 of the headline table (13 % of Q_max)
+    try:
+        from frank_amd.mock import mock_disc_visibilities
+        from frank_amd.constants import rad_to_arcsec
+        u, v, V, w = mock_disc_visibilities(f.nfit, seed=0, noise_seed=50)
+        from frank_amd import FixedGeometry
+        from frank_amd.mock import MOCK_GEOMETRY
+        ud, vd = FixedGeometry(**MOCK_GEOMETRY).deproject(u, v)
+        qmax_data = float(np.hypot(ud, vd).max())
+        del ud, vd
+        dht_q = np.empty(N)
+        L.check(L.lib.fh_dht_get(f.dht, None, L.ptr(dht_q), None, None, None, None, None))
+        stretch = 0.95 * dht_q[-1] / qmax_data
+        u *= stretch
+        v *= stretch
+        keep, keepn = f.vis, f.n
+        f.upload(u, v, V, w)
+        wide = f.tables.pop()
+        f.vis, f.n = keep, keepn
+        try:
+            ms = []
+            for _ in range(5):
+                f.bin(vis=wide)
+                f.sync()
+                ms.append(f.prepass_ms() + f.kernel_ms())
+            Mw, jw = np.empty((N, N)), np.empty(N)
+            L.check(L.lib.fh_stats_finalize(f.ctx, ctypes.byref(f.geom), 0, 1, L.ptr(Mw), L.ptr(jw), ctypes.byref(H0),
+                                            ctypes.byref(qmn), ctypes.byref(qmx)))
+            # parity: the rows themselves on the matrix pipe (FRANK_AMD_K1=rows, a second context), 1e6 of the rows
+            nchk = min(f.nfit, 1_000_000)
+            f.bin(nchk, vis=wide)
+            Mm, jm = np.empty((N, N)), np.empty(N)
+            L.check(L.lib.fh_stats_finalize(f.ctx, ctypes.byref(f.geom), 0, 0, L.ptr(Mm), L.ptr(jm), ctypes.byref(H0),
+                                            ctypes.byref(qmn), ctypes.byref(qmx)))
+            os.environ["FRANK_AMD_K1"] = "rows"
+            try:
+                ctx2 = ctypes.c_void_p()
+                L.check(L.lib.fh_ctx_create(f.dht, f.device, ctypes.byref(ctx2)))
+            finally:
+                del os.environ["FRANK_AMD_K1"]
+            try:
+                L.check(L.lib.fh_bin_reset(ctx2))
+                L.check(L.lib.fh_bin_visibilities(ctx2, ctypes.byref(f.geom), wide, 0, nchk))
+                Mr, jr = np.empty((N, N)), np.empty(N)
+                L.check(L.lib.fh_stats_finalize(ctx2, ctypes.byref(f.geom), 0, 0, L.ptr(Mr), L.ptr(jr), ctypes.byref(H0),
+                                                ctypes.byref(qmn), ctypes.byref(qmx)))
+            finally:
+                L.lib.fh_ctx_destroy(ctx2)
+            pm = float(np.median(ms[2:]))
+            ex["wide_uv"] = {"workload": "the headline rows stretched by %.2f: baselines to 0.95 x the last collocation frequency "
+                                         "(q_max = %.3e of q[-1] = %.3e)" % (stretch, 0.95 * dht_q[-1], dht_q[-1]),
+                             "binning_pass_ms": pm, "first_pass_ms": ms[0],
+                             "GBps_of_40B_per_vis": 40.0 * f.nfit / (pm * 1e-3) / 1e9,
+                             "frac_of_hbm_peak": 40.0 * f.nfit / (pm * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "rows_checked_against_the_rows_path": nchk,
+                             "M_max_rel_diff_vs_rows_path": float(np.abs(Mm - Mr).max() / np.abs(Mr).max()),
+                             "j_max_rel_diff_vs_rows_path": float(np.abs(jm - jr).max() / np.abs(jr).max()),
+                             "finite": bool(np.all(np.isfinite(Mw)) and np.all(np.isfinite(jw)))}
+        finally:
+            L.lib.fh_vis_destroy(wide)
+        del u, v, V, w
+    except Exception as e:  # noqa: BLE001
+        ex["wide_uv"] = {"error": repr(e)}
     # -- "fp32" of BASELINE configs[2] = single-precision STORAGE: the table handed over as float32 / complex64 (20 B per
     #    visibility, fh_vis_upload_f32) is widened as the pre-pass reads it and binned by the same fp64 moments pass.
     #    (Single-precision ARITHMETIC of the design block exists for tables up to 2e6 rows -- fh_ctx_set_arithmetic,

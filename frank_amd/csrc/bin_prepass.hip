@@ -765,7 +765,7 @@ static hipError_t launch_scatter(const PrepassParams &P, size_t lds, hipStream_t
     return P.unroll == 2 ? launch_scatter_u<2>(P, lds, stream) : launch_scatter_u<1>(P, lds, stream);
 }
 
-hipError_t fh_prepass_launch(const PrepassParams &P, hipStream_t stream) {
+hipError_t fh_prepass_launch(const PrepassParams &P, hipStream_t stream, int skip_hist) {
     const size_t lds1 = sizeof(int) * (size_t)P.nb, lds2 = sizeof(int) * (size_t)P.nb * (P.wpb + 1);
     const size_t lds3 = sizeof(int) * ((size_t)P.nb + 1);
     hipError_t e;
@@ -779,8 +779,10 @@ hipError_t fh_prepass_launch(const PrepassParams &P, hipStream_t stream) {
                                 (int)lds3);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(uv_hist_kernel<true>, dim3(P.blocks), dim3(64 * P.wpb), lds1, stream, P);
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3((P.nb + 15) / 16), dim3(1024), 0, stream, P);
+    if (!skip_hist) {
+        hipLaunchKernelGGL(uv_hist_kernel<true>, dim3(P.blocks), dim3(64 * P.wpb), lds1, stream, P);
+        hipLaunchKernelGGL(bucket_scan_kernel, dim3((P.nb + 15) / 16), dim3(1024), 0, stream, P);
+    }
     e = launch_scatter(P, lds2, stream);
     if (e != hipSuccess) return e;
     const int64_t max_pieces = fh_prepass_max_pieces(P.bin.count, P.nb, P.seg_rows);

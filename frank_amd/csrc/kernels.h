@@ -131,7 +131,8 @@ int fh_prepass_moment_doubles();
 void fh_prepass_geometry(int nb, int num_cu, int *wpb, int *blocks);
 int64_t fh_prepass_max_pieces(int64_t count, int nb, int seg_rows);
 hipError_t fh_prepass_launch_range(const PrepassParams &P, hipStream_t stream);  // baseline range only (partial_scalars)
-hipError_t fh_prepass_launch(const PrepassParams &P, hipStream_t stream);        // P1, scan, P2, P3, factor
+// P1, scan, P2, P3, factor; skip_hist: the histograms, their scan and the layout of the last pass still describe these rows
+hipError_t fh_prepass_launch(const PrepassParams &P, hipStream_t stream, int skip_hist = 0);
 
 int fh_k1v2_moment_doubles();
 hipError_t fh_k1v2_launch_compress(const CompressParams &cp, hipStream_t stream);

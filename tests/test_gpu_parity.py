@@ -1387,3 +1387,52 @@ def test_pipelined_fits_on_clusters(monkeypatch):
         _lib.check(_lib.lib.fh_fit_collect(ctx, t, _lib.ptr(mu), _lib.ptr(p), ctypes.byref(n)))
         rc0, mu0, p0, n0, *_ = ref[h]
         assert n.value == n0 and np.array_equal(mu, mu0) and np.array_equal(p, p0)
+
+
+def test_histograms_are_reused_only_for_the_same_rows(monkeypatch):
+    """A binning pass over the rows, geometry and multiplicities of the context's LAST pass skips the (u, v) histogram and its
+    scan (bin_prepass.hip P1; capi.hip: hist_valid): the statistics must be the bits of a pass that looks at (u, v) again --
+    after another table, another geometry, other multiplicities or another row range nothing may be reused."""
+    import ctypes
+    from frank_amd import _lib, DiscreteHankelTransform, FixedGeometry
+    N = 100
+    D = DiscreteHankelTransform(RMAX, N)  # (owns the context)
+    ctx = D.context()
+    tabs = []
+    for seed in (11, 12):
+        u, v, V, w = mock_disc_visibilities(150000, seed=seed, noise_seed=seed + 50)
+        vis = ctypes.c_void_p()
+        Vre, Vim = np.ascontiguousarray(V.real), np.ascontiguousarray(V.imag)
+        _lib.check(_lib.lib.fh_vis_upload(0, _lib.ptr(u), _lib.ptr(v), _lib.ptr(Vre), _lib.ptr(Vim), _lib.ptr(w), w.size, u.size,
+                                          ctypes.byref(vis)))
+        tabs.append(vis)
+    g1 = _lib.make_geometry(geom())
+    g2 = _lib.make_geometry(FixedGeometry(20.0, 40.0, 1e-3, -2e-3))
+
+    def stats(vis, g, count=150000):
+        _lib.check(_lib.lib.fh_bin_reset(ctx))
+        _lib.check(_lib.lib.fh_bin_visibilities(ctx, ctypes.byref(g), vis, 0, count))
+        M, j = np.empty((N, N)), np.empty(N)
+        H0, a, b = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(_lib.lib.fh_stats_finalize(ctx, ctypes.byref(g), 0, 0, _lib.ptr(M), _lib.ptr(j), ctypes.byref(H0), ctypes.byref(a),
+                                              ctypes.byref(b)))
+        return sha(M, j, np.array([H0.value, a.value, b.value]))
+    monkeypatch.setenv("FRANK_AMD_K1_NO_HIST_CACHE", "1")
+    ref = {(t, k, n): stats(tabs[t], g, n) for t in (0, 1) for k, g in ((1, g1), (2, g2)) for n in (150000, 99999)}
+    monkeypatch.delenv("FRANK_AMD_K1_NO_HIST_CACHE")
+    order = [(0, 1, 150000), (0, 1, 150000), (0, 1, 150000), (1, 1, 150000), (0, 1, 150000), (0, 2, 150000), (0, 2, 150000),
+             (0, 1, 99999), (0, 1, 99999), (0, 1, 150000), (1, 2, 99999), (1, 2, 99999)]
+    for t, k, n in order:
+        assert stats(tabs[t], g1 if k == 1 else g2, n) == ref[(t, k, n)], (t, k, n)
+    # other multiplicities on the same rows: a new key
+    cnt = np.ones(150000, dtype=np.int32)
+    cnt[::3] = 0
+    a0 = stats(tabs[0], g1)
+    _lib.check(_lib.lib.fh_vis_set_multiplicity(tabs[0], cnt.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+    a1 = stats(tabs[0], g1)
+    a2 = stats(tabs[0], g1)
+    assert a1 == a2 and a1 != a0
+    _lib.check(_lib.lib.fh_vis_set_multiplicity(tabs[0], None))
+    assert stats(tabs[0], g1) == ref[(0, 1, 150000)]
+    for vis in tabs:
+        _lib.lib.fh_vis_destroy(vis)
