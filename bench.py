@@ -559,6 +559,21 @@ def extras(f, L, a):
                           "iterations_min_median_max": [int(its.min()), int(np.median(its)), int(its.max())],
                           "failed": int(np.sum(np.array(list(status)) != 0)),
                           "not_converged": int(np.sum(its >= h["max_iter"]))}
+        # ranking the sweep: marginal likelihood, log prior and Laplace evidence of all points, batched on the device
+        # (fh_sweep_evidence; the reference: dense O(N^3) host algebra per point, radial_fitters.py:951-967)
+        try:
+            sll, lpr, lev = np.empty(B), np.empty(B), np.empty(B)
+            t0 = time.perf_counter()
+            L.check(L.lib.fh_sweep_evidence(f.ctx, None, None, float(H0.value), B, L.ptr(pp), L.ptr(mu), L.ptr(al), L.ptr(p0),
+                                            L.ptr(ws), L.ptr(sll), L.ptr(lpr), L.ptr(lev), None))
+            dte = time.perf_counter() - t0
+            ok = np.isfinite(lev)
+            best = int(np.nanargmax(lev))
+            ex["sweep512"]["evidence"] = {"s_total": dte, "points_per_s": B / dte, "finite": int(ok.sum()),
+                                          "best_point": {"alpha": float(al[best]), "w_smooth": float(ws[best]),
+                                                         "log_evidence": float(lev[best])}}
+        except Exception as e:  # noqa: BLE001
+            ex["sweep512"]["evidence"] = {"error": repr(e)}
     except Exception as e:
         ex["sweep512"] = {"error": repr(e)}
     # -- LogNormal fits in one launch, one compute unit each (fh_fit_lognormal_batched): 64 points of an (alpha, w_smooth) grid

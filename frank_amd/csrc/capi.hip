@@ -1741,6 +1741,28 @@ int fh_svd_solve_as_reference(fh_ctx *c, const double *A, double *B, int nrhs) {
 
 // spectral_smoothing_matrix (filter.py:23-62) as bands, then LU of (T + I) without pivoting (T + I is SPD).
 // out: f1[N] (multiplier of row i-1), f2[N] (row i-2), d0[N] (pivots), u1[N], u2[N] (upper bands of U).
+// the five bands of T / weights_smooth (filter.py:23-62): band[(d + 2) N + i] = T_unit[i][i + d], d = -2 .. 2
+static void smoothing_bands(const fh_dht &d, std::vector<double> &band) {
+    const int N = d.N;
+    std::vector<double> lq(N), dc(N, 0.0), de(N, 0.0), D0(N, 0.0), D1(N, 0.0), D2(N, 0.0);
+    band.assign(5 * (size_t)N, 0.0);
+    for (int i = 0; i < N; ++i) lq[i] = log(d.q[i]);
+    for (int i = 0; i + 2 < N; ++i) dc[i] = (lq[i + 2] - lq[i]) / 2;  // filter.py:42
+    for (int i = 0; i + 1 < N; ++i) de[i] = lq[i + 1] - lq[i];        // filter.py:43
+    for (int i = 1; i + 1 < N; ++i) {                                 // filter.py:48-50
+        D0[i] = 1 / (dc[i - 1] * de[i - 1]);
+        D1[i] = -(1 / de[i] + 1 / de[i - 1]) / dc[i - 1];
+        D2[i] = 1 / (dc[i - 1] * de[i]);
+    }
+    for (int i = 1; i + 1 < N; ++i) {  // T = Delta^T (dce Delta), filter.py:55-60
+        const double dce = dc[i - 1];
+        const int cols[3] = {i - 1, i, i + 1};
+        const double vals[3] = {D0[i], D1[i], D2[i]};
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) band[(size_t)(cols[b] - cols[a] + 2) * N + cols[a]] += vals[a] * (dce * vals[b]);
+    }
+}
+
 static void smoothing_band_lu(const fh_dht &d, double weights, std::vector<double> &out) {
     const int N = d.N;
     std::vector<double> lq(N), dc(N, 0.0), de(N, 0.0), D0(N, 0.0), D1(N, 0.0), D2(N, 0.0);
@@ -2393,6 +2415,100 @@ int fh_stats_upload(fh_ctx *c, const double *M, const double *j) {
     HIP_TRY(hipMemcpyAsync(c->j.p, j, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_device_Mj = true;
+    return FH_OK;
+}
+
+// Posterior extras of a sweep, batched on the device (evidence.hip): see include/frank_hip.h
+int fh_sweep_evidence(fh_ctx *c, const double *M, const double *j, double H0, int batch, const double *p, const double *mu,
+                      const double *alpha, const double *p0, const double *wsmooth, double *sol_log_likelihood, double *log_prior,
+                      double *log_evidence, double *pscov_diag) {
+    if (!c || batch < 1 || !p || !mu || !alpha || !p0 || !wsmooth) return fail(FH_ERR_INVALID, "fh_sweep_evidence: bad argument");
+    if ((M == nullptr) != (j == nullptr)) return fail(FH_ERR_INVALID, "pass both M and j or neither");
+    if (!M && !c->have_device_Mj) return fail(FH_ERR_INVALID, "no device-resident M, j (run fh_stats_finalize)");
+    if (c->N > FIT_MAX_N) return fail(FH_ERR_UNSUPPORTED, "N = %d > %d", c->N, FIT_MAX_N);
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->N;
+    const size_t NN = (size_t)N * N;
+    for (size_t i = 0; i < (size_t)batch * N; ++i)
+        if (!(p[i] > 0.0)) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (point %d)", (int)(i / N));
+    SyncOnExit guard{c->stream};
+    if (M) {
+        HIP_TRY(hipMemcpyAsync(c->M.p, M, sizeof(double) * NN, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->j.p, j, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+        c->have_device_Mj = false;
+    }
+    std::vector<double> jh(N);
+    HIP_TRY(hipMemcpyAsync(jh.data(), c->j.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    int rc = prepare_qspace(c, c->Aq.p, c->bq.p);  // Araw = Y^-T M Y^-1 (row-major)
+    if (rc) return rc;
+    std::vector<double> band;
+    smoothing_bands(*c->dht, band);
+    const int CH = batch < 128 ? batch : 128;
+    DevBuf<double> Cb, Hb, pb, mub, mqb, p0b, wsb, bandb, ldC, ldH, dg;
+    DevBuf<int> info;
+    if (Cb.alloc((size_t)CH * NN) != hipSuccess || Hb.alloc((size_t)CH * NN) != hipSuccess || pb.alloc((size_t)CH * N) != hipSuccess ||
+        mub.alloc((size_t)CH * N) != hipSuccess || mqb.alloc((size_t)CH * N) != hipSuccess || p0b.alloc(CH) != hipSuccess ||
+        wsb.alloc(CH) != hipSuccess || bandb.alloc(band.size()) != hipSuccess || ldC.alloc(CH) != hipSuccess ||
+        ldH.alloc(CH) != hipSuccess || dg.alloc((size_t)CH * N) != hipSuccess || info.alloc(2 * (size_t)CH) != hipSuccess)
+        return fail(FH_ERR_NOMEM, "fh_sweep_evidence: device allocation failed");
+    HIP_TRY(hipMemcpyAsync(bandb.p, band.data(), sizeof(double) * band.size(), hipMemcpyHostToDevice, c->stream));
+    std::vector<double> hC(CH), hH(CH);
+    std::vector<int> hinfo(2 * (size_t)CH);
+    const double one = 1.0, zero = 0.0;
+    for (int first = 0; first < batch; first += CH) {
+        const int n = batch - first < CH ? batch - first : CH;
+        HIP_TRY(hipMemcpyAsync(pb.p, p + (size_t)first * N, sizeof(double) * (size_t)n * N, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(mub.p, mu + (size_t)first * N, sizeof(double) * (size_t)n * N, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(p0b.p, p0 + first, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(wsb.p, wsmooth + first, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        // Dqq = C^-1, C = A + diag(1/p): Cholesky (log det C), inverse
+        HIP_TRY(fh_evidence_launch_build_c(c->Araw.p, pb.p, N, n, Cb.p, c->stream));
+        ROC_TRY(rocsolver_dpotrf_strided_batched(c->blas, rocblas_fill_lower, N, Cb.p, N, (rocblas_stride)NN, info.p, n));
+        HIP_TRY(fh_evidence_launch_logdet(Cb.p, N, n, ldC.p, c->stream));
+        ROC_TRY(rocsolver_dpotri_strided_batched(c->blas, rocblas_fill_lower, N, Cb.p, N, (rocblas_stride)NN, info.p + CH, n));
+        // mq = Y mu for every point: the row-major Y buffer is Y^T in rocBLAS's column-major reading
+        ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, N, n, N, &one, c->Y.p, N, mub.p, N, &zero,
+                              mqb.p, N));
+        HIP_TRY(fh_evidence_launch_hessian(Cb.p, mqb.p, pb.p, p0b.p, wsb.p, bandb.p, N, n, Hb.p, c->stream));
+        HIP_TRY(hipMemcpyAsync(hinfo.data(), info.p, sizeof(int) * (size_t)CH, hipMemcpyDeviceToHost, c->stream));
+        ROC_TRY(rocsolver_dpotrf_strided_batched(c->blas, rocblas_fill_lower, N, Hb.p, N, (rocblas_stride)NN, info.p, n));
+        HIP_TRY(fh_evidence_launch_logdet(Hb.p, N, n, ldH.p, c->stream));
+        HIP_TRY(hipMemcpyAsync(hinfo.data() + CH, info.p, sizeof(int) * (size_t)CH, hipMemcpyDeviceToHost, c->stream));
+        if (pscov_diag) {
+            ROC_TRY(rocsolver_dpotri_strided_batched(c->blas, rocblas_fill_lower, N, Hb.p, N, (rocblas_stride)NN, info.p + CH, n));
+            HIP_TRY(fh_evidence_launch_diag(Hb.p, N, n, dg.p, c->stream));
+            HIP_TRY(hipMemcpyAsync(pscov_diag + (size_t)first * N, dg.p, sizeof(double) * (size_t)n * N, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(hC.data(), ldC.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(hH.data(), ldH.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int b = 0; b < n; ++b) {
+            const double *pp = p + (size_t)(first + b) * N, *mm = mu + (size_t)(first + b) * N;
+            // GaussianModel.log_likelihood (statistical_models.py:836-841): 1/2 j.mu + 1/2 log det(D S^-1) + H0
+            double jm = 0.0, slp = 0.0;
+            for (int i = 0; i < N; ++i) {
+                jm += jh[i] * mm[i];
+                slp += log(pp[i]);
+            }
+            const bool okC = hinfo[b] == 0, okH = hinfo[CH + b] == 0;
+            const double sll = okC ? 0.5 * jm + 0.5 * (-slp - hC[b]) + H0 : NAN;
+            // CriticalFilter.log_prior (filter.py:253-261)
+            double lp = 0.0, quad = 0.0;
+            for (int i = 0; i < N; ++i) {
+                const double xi = p0[first + b] / pp[i];
+                lp -= xi + (alpha[first + b] - 1.0) * log(xi);
+                double ti = 0.0;
+                for (int d = -2; d <= 2; ++d)
+                    if (i + d >= 0 && i + d < N) ti += band[(size_t)(d + 2) * N + i] * log(pp[i + d]);
+                quad += log(pp[i]) * ti;
+            }
+            lp -= 0.5 * wsmooth[first + b] * quad;
+            if (sol_log_likelihood) sol_log_likelihood[first + b] = sll;
+            if (log_prior) log_prior[first + b] = lp;
+            // radial_fitters.py:963-965: log P(p, V) - 1/2 log det(Hessian / 2 pi)
+            if (log_evidence) log_evidence[first + b] = (okC && okH) ? lp + sll - 0.5 * (hH[b] - N * log(2.0 * M_PI)) : NAN;
+        }
+    }
     return FH_OK;
 }
 

@@ -248,6 +248,13 @@ size_t fh_k2_exchange_doubles(int NP);  // doubles of a fit's WdT buffer (exchan
 hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s);
 hipError_t fh_k2_launch_symmetrize(const double *Araw, const double *bq, int N, int NP, double *A, hipStream_t s);
 
+// ---- posterior extras of a sweep (evidence.hip) ---------------------------------------------------------------------
+hipError_t fh_evidence_launch_build_c(const double *Araw, const double *p, int N, int batch, double *C, hipStream_t s);
+hipError_t fh_evidence_launch_logdet(const double *L, int N, int batch, double *out, hipStream_t s);
+hipError_t fh_evidence_launch_hessian(const double *Dqq, const double *mq, const double *p, const double *p0, const double *ws,
+                                      const double *Tband, int N, int batch, double *H, hipStream_t s);
+hipError_t fh_evidence_launch_diag(const double *A, int N, int batch, double *out, hipStream_t s);
+
 // ---- LogNormal (lognormal.hip): Newton MAP of the log-brightness + the power-spectrum loop, one workgroup per fit
 enum { LN_MODE_MAP = 0, LN_MODE_FIT = 1, LN_MODE_UPDATE = 2 };
 enum { LN_STATUS_OK = 0, LN_STATUS_BAD_P = 1, LN_STATUS_SLOPE = 2, LN_STATUS_CLUSTER = 3 };

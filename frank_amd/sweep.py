@@ -165,3 +165,37 @@ class _LazyLogNormal(LogNormalMAPModel):
             self._fit(keep_s.reshape(-1))  # converges at once: starts at the MAP
             self._s_MAP, self._newton_stats = keep_s, keep_stats
         return object.__getattribute__(self, name)
+
+
+def sweep_evidence(fitter, preproc_vis, sols, alphas, weights_smooth, p_0=None, covariance=False, device=None):
+    """Rank the points of a sweep: for every solution of `sweep_fits` (same order as alphas / weights_smooth) the posterior's
+    marginal likelihood, the log prior of its power spectrum and the Laplace evidence -- FrankFitter.log_likelihood /
+    log_prior / log_evidence_laplace (radial_fitters.py:892-967, filter.py:184-263) for ALL points in a few batched device
+    calls (fh_sweep_evidence) instead of dense O(N^3) host algebra per point.
+
+    Returns a dict of arrays of length len(sols): 'log_likelihood' (= log_prior + the solution's marginal likelihood, what
+    FrankFitter.log_likelihood() returns), 'sol_log_likelihood', 'log_prior', 'log_evidence', and with covariance=True
+    'spectrum_covariance_diag' (len(sols) x N: the diagonal of MAP_spectrum_covariance)."""
+    alphas = _lib.f8(np.atleast_1d(alphas))
+    ws = _lib.f8(np.atleast_1d(weights_smooth))
+    B, N = len(sols), fitter.size
+    if alphas.size != B or ws.size != B:
+        raise ValueError("alphas and weights_smooth must match the solutions")
+    if fitter._method == 'LogNormal':
+        raise NotImplementedError("sweep_evidence: the Laplace evidence of the reference is defined for method='Normal' "
+                                  "(filter.py:184-227 takes the Gaussian posterior's covariance)")
+    p0 = _lib.f8(np.full(B, 1e-15 if p_0 is None else p_0))
+    fitter._build_matrices(preproc_vis)
+    M, j = _lib.f8(fitter._M), _lib.f8(fitter._j)
+    p = _lib.f8(np.array([s.power_spectrum for s in sols]).reshape(B, N))
+    mu = _lib.f8(np.array([s.I for s in sols]).reshape(B, N))
+    sll, lp, lev = np.empty(B), np.empty(B), np.empty(B)
+    cov = np.empty((B, N)) if covariance else None
+    ctx = fitter._DHT.context(fitter._DHT.device if device is None else device)
+    _lib.check(_lib.lib.fh_sweep_evidence(ctx, _lib.ptr(M), _lib.ptr(j), float(fitter._H0), B, _lib.ptr(p), _lib.ptr(mu),
+                                          _lib.ptr(alphas), _lib.ptr(p0), _lib.ptr(ws), _lib.ptr(sll), _lib.ptr(lp), _lib.ptr(lev),
+                                          _lib.ptr(cov) if covariance else None))
+    out = {'log_likelihood': lp + sll, 'sol_log_likelihood': sll, 'log_prior': lp, 'log_evidence': lev}
+    if covariance:
+        out['spectrum_covariance_diag'] = cov
+    return out

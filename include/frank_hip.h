@@ -247,6 +247,22 @@ int fh_fit_slots(void);
 int fh_fit_submit(fh_ctx *ctx, double alpha, double p0, double wsmooth, double tol, int max_iter, int *ticket);
 int fh_fit_flush(fh_ctx *ctx);
 int fh_fit_collect(fh_ctx *ctx, int ticket, double *mu, double *p, int *niter);
+/* Posterior extras of a whole sweep, batched on the device: for each of `batch` points (p, mu: batch x N, the MAP power spectra
+ * and brightness profiles fh_fit_normal_batched returned; alpha, p0, wsmooth: their hyper-parameters) over ONE mapping (M, j from
+ * the host, or NULL, NULL = the context's device-resident statistics; H0 its null likelihood)
+ *   sol_log_likelihood[b] = GaussianModel.log_likelihood()        1/2 j.mu + 1/2 log det(D S^-1) + H0   statistical_models.py:836-841
+ *   log_prior[b]          = CriticalFilter.log_prior(p)                                                filter.py:253-261
+ *   log_evidence[b]       = FrankFitter.log_evidence_laplace()    log P(p, V) - 1/2 log det(H / 2 pi)  radial_fitters.py:951-967
+ *   pscov_diag[b][N]      = diag of CriticalFilter.covariance_MAP (H^-1)                               filter.py:184-227
+ * (any output may be NULL; FrankFitter.log_likelihood() is log_prior + sol_log_likelihood).  The reference forms Y D Y^T and the
+ * Hessian H with dense host products per point; here Y D Y^T = (A + diag(1/p))^-1 in the basis of the fit loop, and a point is
+ * two Cholesky factorisations and inversions of N x N matrices in rocSOLVER's strided-batched routines, 128 points at a time --
+ * ranking a 512-point sweep by evidence (what fit.py:534-548 exists for) without 512 host O(N^3) passes.  A point whose
+ * Hessian is not positive definite gets NaN evidence.                                                                  */
+int fh_sweep_evidence(fh_ctx *ctx, const double *M, const double *j, double H0, int batch, const double *p, const double *mu,
+                      const double *alpha, const double *p0, const double *wsmooth, double *sol_log_likelihood,
+                      double *log_prior, double *log_evidence, double *pscov_diag);
+
 /* Cluster ("latency") mode of the fit loop.  A fit whose pipeline is shallow -- fh_fit_normal on an idle context, the first
  * launches of a pipeline -- runs on `workgroups` compute units of one XCD instead of one: the first factors the posterior
  * precision and runs the loop (GaussianModel._fit, statistical_models.py:732-760; filter.py:154-181), the others form the

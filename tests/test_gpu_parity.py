@@ -1436,3 +1436,41 @@ def test_histograms_are_reused_only_for_the_same_rows(monkeypatch):
     assert stats(tabs[0], g1) == ref[(0, 1, 150000)]
     for vis in tabs:
         _lib.lib.fh_vis_destroy(vis)
+
+
+def test_sweep_evidence_on_the_device(golden):
+    """fh_sweep_evidence (evidence.hip + rocSOLVER's strided-batched potrf / potri): the marginal likelihood, the log prior, the
+    Laplace evidence and the diagonal of the power spectrum's covariance of the points of a sweep -- against the reference's
+    values for the two points of sweep_N50_2e4.npz (radial_fitters.py:892-967, filter.py:184-263) and, at N = 300 over a
+    10-point grid, against this package's own one-point-at-a-time host algebra (FrankFitter.log_evidence_laplace)."""
+    from frank_amd import FrankFitter
+    from frank_amd.sweep import sweep_evidence, sweep_fits
+    g = golden("sweep_N50_2e4.npz")
+    u, v, V, w = mock_disc_visibilities(int(g["n"]), seed=int(g["seed"]), noise_seed=int(g["noise_seed"]))
+    FF = FrankFitter(2.0, 50, geom(), verbose=False)
+    pre = FF.preprocess_visibilities(u, v, V, w)
+    al = np.array([float(g["alpha_a"]), float(g["alpha_b"])])
+    ws = np.array([float(g["wsmooth_a"]), float(g["wsmooth_b"])])
+    sols, _ = sweep_fits(FF, pre, al, ws)
+    ev = sweep_evidence(FF, pre, sols, al, ws, covariance=True)
+    for k, tag in enumerate("ab"):
+        np.testing.assert_allclose(ev["sol_log_likelihood"][k], float(g["loglike_" + tag]), rtol=1e-9)
+        np.testing.assert_allclose(ev["log_prior"][k], float(g["logprior_" + tag]), rtol=1e-8)
+        np.testing.assert_allclose(ev["log_evidence"][k], float(g["logevidence_" + tag]), rtol=1e-8)
+        np.testing.assert_allclose(ev["spectrum_covariance_diag"][k], g["pscov_diag_" + tag], rtol=1e-5)
+    # N = 300: the batched device path against the host algebra of one fitter per point
+    u, v, V, w = mock_disc_visibilities(200000, seed=31, noise_seed=32)
+    FF = FrankFitter(2.0, 300, geom(), verbose=False)
+    pre = FF.preprocess_visibilities(u, v, V, w)
+    al, ws = np.meshgrid(np.linspace(1.05, 1.4, 5), np.array([1e-4, 1e-2]))
+    al, ws = al.ravel(), ws.ravel()
+    sols, _ = sweep_fits(FF, pre, al, ws)
+    ev = sweep_evidence(FF, pre, sols, al, ws, covariance=True)
+    for k in (0, 4, 7, 9):
+        F1 = FrankFitter(2.0, 300, geom(), alpha=float(al[k]), weights_smooth=float(ws[k]), verbose=False)
+        s1 = F1.fit_preprocessed(pre)
+        assert rel_to_max(s1.I, sols[k].I) < 1e-9
+        np.testing.assert_allclose(ev["log_likelihood"][k], F1.log_likelihood(), rtol=1e-9)
+        np.testing.assert_allclose(ev["log_evidence"][k], F1.log_evidence_laplace(), rtol=1e-8)
+        np.testing.assert_allclose(ev["spectrum_covariance_diag"][k], np.diag(F1.MAP_spectrum_covariance), rtol=1e-5)
+    assert np.all(np.isfinite(ev["log_evidence"]))
