@@ -1292,6 +1292,263 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
     return true;
 }
 
+// ---- the posterior solve, left-looking (one workgroup, N <= 335) -----------------------------------------------------------
+// solve_posterior above is right-looking: step k rewrites every tile of the trailing triangle -- 1 140 loads and as many stores
+// of 2 KB per pass at N = 300 -- and the rows of the inverse read both their operands from memory (2 622 loads): 10.9 MB per
+// pass through the L1 of the one compute unit, and, with ~16 fit loops per XCD sharing 4 MB of L2, most of it beyond the L2
+// (137 us per pass alone, 200-270 with the device full).  Here a tile is formed ONCE: at step J the tiles (I, J) of block column
+// J take all their updates k < J at a stretch, T_IJ = A_IJ - sum_k L_Ik L_Jk^T, one operand -- row J of L, the same for every
+// tile of the column -- from LDS, the other from memory, are multiplied by X_JJ^T when the chain wave has factored the
+// diagonal tile, and stored once; row J of the inverse, W_JK = -X_JJ sum_m L_Jm W_mK, takes its L operands from the SAME LDS
+// row.  Row J + 1 is staged in a second buffer while step J runs (its last tile comes straight from the wave that forms it).
+// The diagonal tiles stay right-looking, in LDS: the wave that forms L_IJ updates diagonal tile I at once, so the chain wave
+// finds tile (J, J) complete at the start of step J.  6.4 MB per pass instead of 10.9, a quarter of the stores.
+// Every tile sees the operations of solve_posterior in the same order -- first touch (A, 1 / p on the diagonal), the updates
+// k = 0, 1, .., the product with X^T; the chains of the inverse over ascending m -- so the results are the same bits.
+// Work of step J: nb - 1 items (nb - 1 - J column tiles of J products, J inverse tiles of J .. 1 products), dealt longest
+// first to the eleven worker waves, at most two each; a wave forms the sums of its items, waits for the chain wave's flag,
+// and finishes them.  LDS: the two row buffers take the place of the two panels, the diagonal tiles that of the band factors,
+// scan tables and tile table (the bands and tables move to the W buffer in global memory, as in the wide instantiation).
+__device__ __forceinline__ v4f64 lds_tile(const double *t, int lane) {
+    const v2f64 *hp = reinterpret_cast<const v2f64 *>(t) + lane;
+    const v2f64 lo = hp[0], hi = hp[64];
+    return v4f64{lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ void lds_tile_store(double *t, int lane, const v4f64 &v) {
+    v2f64 *hp = reinterpret_cast<v2f64 *>(t) + lane;
+    hp[0] = v2f64{v[0], v[1]};
+    hp[64] = v2f64{v[2], v[3]};
+}
+// acc (+/-)= sum_{t < n} Ltile[t] x Btile[t]: the A operands are consecutive packed tiles of an LDS row, the B operands packed
+// tiles `blk` bytes apart in memory, fetched through a ring of four register sets with the loads issued and waited for by hand
+// (three products in flight behind the one being multiplied; the order of the sum is t ascending)
+template <bool NEG>
+__device__ __forceinline__ v4f64 ll_chain(const double *arow, const gdouble *Bu, unsigned ob, unsigned blk, int n, v4f64 acc, int lane) {
+    struct Operands {
+        v2f64 lo, hi;
+    };
+    const unsigned lane_o = (unsigned)lane * 16u;
+    auto issue = [&](Operands &o, int t) {
+        const unsigned pb = ob + (unsigned)t * blk + lane_o;
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
+                     : "=&v"(o.lo), "=&v"(o.hi)
+                     : "v"(pb), "s"(Bu)
+                     : "memory");
+    };
+    auto consume = [&](Operands &o, int t) {
+        const v4f64 fa = lds_tile(arow + (size_t)t * 256, lane);
+        switch (min(3, n - 1 - t)) {  // products issued after t (two loads each)
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        }
+        asm volatile("" : "+v"(o.lo), "+v"(o.hi));
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -fa[0] : fa[0], o.lo[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -fa[1] : fa[1], o.lo[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -fa[2] : fa[2], o.hi[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -fa[3] : fa[3], o.hi[1], acc, 0, 0, 0);
+    };
+    if (n <= 0) return acc;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the counts are of THESE loads)
+    Operands s0, s1, s2, s3;
+    issue(s0, 0);
+    if (1 < n) issue(s1, 1);
+    if (2 < n) issue(s2, 2);
+    for (int t = 0;; t += 4) {
+        if (t + 3 < n) issue(s3, t + 3);
+        consume(s0, t);
+        if (t + 1 >= n) break;
+        if (t + 4 < n) issue(s0, t + 4);
+        consume(s1, t + 1);
+        if (t + 2 >= n) break;
+        if (t + 5 < n) issue(s1, t + 5);
+        consume(s2, t + 2);
+        if (t + 3 >= n) break;
+        if (t + 6 < n) issue(s2, t + 6);
+        consume(s3, t + 3);
+        if (t + 4 >= n) break;
+    }
+    return acc;
+}
+__device__ __forceinline__ bool solve_posterior_ll(const FitLoopParams &P, const Smem &S) {
+    constexpr int NWK_ = NW - 1;
+    const int N = P.N, NP = P.NP, nb = P.NP / 16, ld = P.NP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 15, rg = lane >> 4;
+    double *C = P.C;  // upper tiles (k, I): L_Ik^T; lower tiles (r, K): W = L^-1; diagonal tiles: X_kk
+    double *rowL[2] = {S.pan, S.pan + (size_t)(nb - 1) * 256};
+    double *dg = S.band;  // (LDS: solve_posterior's band / scan / tile-table region) the diagonal tiles, packed
+#ifdef FIT_LOOP_TIMING
+    long long t_last = clock64();
+#endif
+    for (int i = tid; i < NP; i += KT) S.y[i] = i < N ? 1.0 / S.p[i] : 1.0;  // row N (b) and padding: 1
+    if (tid == 0) {
+        S.flag[0] = 0;  // not positive definite
+        S.flag[3] = 0;  // diagonal tiles factored so far
+    }
+    __syncthreads();
+    const double *pinv = S.y;
+    const gdouble *A_u = as_global(uniform_ptr(P.A));
+    gdouble *C_u = as_global(uniform_ptr(C));
+    const gdouble *Cr_u = as_global(uniform_ptr(const_cast<const double *>(C)));
+    // diagonal tiles: A_JJ + diag(1 / p)
+    for (int J = wave; J < nb; J += NW) {
+        v4f64 t = ld_pk(A_u, (unsigned)(J * (nb + 1) * 2048), lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (rg + 4 * r == cl) t[r] += pinv[16 * J + cl];
+        lds_tile_store(dg + (size_t)J * 256, lane, t);
+    }
+    __syncthreads();
+    TSTAMP(0);
+    const int aug_tile = N / 16, aug_c = N - 16 * aug_tile;
+    auto cs_ptr = [&](int I, int J) { return P.cs + ((size_t)I * nb + J) * 16; };
+    auto rows_valid = [&](int I) { return min(16, max(0, N - 16 * I)); };
+    for (int J = 0; J < nb; ++J) {
+        const double *rowc = rowL[J & 1];
+        double *rown = rowL[(J + 1) & 1];
+        double *dli_J = S.dli + (J & 1) * 16 * PS;
+        [[maybe_unused]] const int k = J;  // (the trace macros of the timing build index the step by this name)
+        TRACE(0);
+        if (wave == kChain) {
+#ifdef FIT_LOOP_TIMING
+            long long f_last = clock64();
+#endif
+            v4f64 a = lds_tile(dg + (size_t)J * 256, lane), xi;
+            FSTAMP(8);
+            const bool ok = chol_inv_tile_acc(a, xi, lane, aug_tile == J ? aug_c : -1);
+            if (!ok && lane == 0) *S.flag = 1;
+            FSTAMP(9);
+            store_factored_tile(a, xi, nullptr, ld, dli_J, nullptr, nullptr, cs_ptr(J, J), rows_valid(J), lane);
+            st_pk(C_u, (unsigned)(J * (nb + 1) * 2048), lane, xi);  // W_JJ = X_JJ
+            __hip_atomic_store(&S.flag[3], J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            FSTAMP(10);
+            TRACE(5);
+        } else {
+            const int widx = wave < kChain ? wave : wave - 1;  // 0 .. 10
+#ifdef FIT_LOOP_TIMING
+            long long w_last = clock64();
+#endif
+            // items of step J, longest first: the inverse tile (J, 0) [J products], the column tiles (I, J), I = J + 1 .. nb - 1
+            // [J products each], the inverse tiles (J, K), K = 1 .. J - 1 [J - K products]
+            const int ncolt = nb - 1 - J, nit = ncolt + J;
+            v4f64 acc[2];
+            int kind[2], idx[2];  // kind 0: none, 1: column tile (I = idx), 2: inverse tile (K = idx)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                // (dealt back and forth: wave w takes item w and item 2 NWK_ - 1 - w, a long one and a short one)
+                const int it = s2 == 0 ? widx : 2 * NWK_ - 1 - widx;
+                kind[s2] = 0;
+                idx[s2] = 0;
+                if (it < nit) {
+                    if (J > 0 && it == 0) {
+                        kind[s2] = 2;
+                        idx[s2] = 0;
+                    } else if (it - (J > 0 ? 1 : 0) < ncolt) {
+                        kind[s2] = 1;
+                        idx[s2] = J + 1 + it - (J > 0 ? 1 : 0);
+                    } else {
+                        kind[s2] = 2;
+                        idx[s2] = it - ncolt;  // K = 1 .. J - 1
+                    }
+                }
+            }
+            // staging of row J + 1 for the next step: mirror tiles (k, J + 1), k < J (tile k = J comes from its column item)
+            v4f64 stg[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int k = widx + s2 * NWK_;
+                if (J + 1 < nb && k < J) stg[s2] = ld_pk(Cr_u, (unsigned)((k * nb + J + 1) * 2048), lane);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if (kind[s2] == 1) {  // T_IJ^T = A_JI - sum_k L_Jk L_Ik^T (kept transposed, as solve_posterior keeps it)
+                    const int I = idx[s2];
+                    const v4f64 a = ld_pk(A_u, (unsigned)((J * nb + I) * 2048), lane);
+                    acc[s2] = ll_chain<true>(rowc, Cr_u, (unsigned)(I * 2048), (unsigned)(nb * 2048), J, a, lane);
+                } else if (kind[s2] == 2) {  // sum_{m=K}^{J-1} L_Jm W_mK
+                    const int K = idx[s2];
+                    const v4f64 a = {0.0, 0.0, 0.0, 0.0};
+                    acc[s2] = ll_chain<false>(rowc + (size_t)K * 256, Cr_u, (unsigned)((K * nb + K) * 2048), (unsigned)(nb * 2048),
+                                              J - K, a, lane);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int k = widx + s2 * NWK_;
+                if (J + 1 < nb && k < J) lds_tile_store(rown + (size_t)k * 256, lane, stg[s2]);
+            }
+            WSTAMP(11);
+            TRACE(1);
+            if (kind[0]) {
+                int spins = 0;
+                while (__hip_atomic_load(&S.flag[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < J + 1) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 22)) {  // (never observed; a stuck flag must not hang the device)
+                        if (lane == 0) *S.flag = 1;
+                        break;
+                    }
+                }
+                TRACE(2);
+                Frag fx;  // X_JJ as A operand
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fx.v[q] = dli_J[cl * PS + 4 * q + rg];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    Frag ft;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ft.v[q] = acc[s2][q];
+                    const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
+                    if (kind[s2] == 1) {
+                        const int I = idx[s2];
+                        const v4f64 d = mfma4(fx, ft, z4, false);  // D = X T^T = L_IJ^T
+                        st_pk(C_u, (unsigned)((J * nb + I) * 2048), lane, d);  // mirror tile (J, I)
+                        if (I == J + 1) lds_tile_store(rown + (size_t)J * 256, lane, d);
+                        // diagonal tile I: update J (the rows of D are the operand fragments of both sides)
+                        v4f64 nd = lds_tile(dg + (size_t)I * 256, lane);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) nd = __builtin_amdgcn_mfma_f64_16x16x4f64(-d[q], d[q], nd, 0, 0, 0);
+                        lds_tile_store(dg + (size_t)I * 256, lane, nd);
+                    } else if (kind[s2] == 2) {
+                        const int K = idx[s2];
+                        const v4f64 w = mfma4(fx, ft, z4, true);  // W_JK = -X_JJ sum
+                        st_pk(C_u, (unsigned)((J * nb + K) * 2048), lane, w);
+                        double ssq = 0.0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (16 * J + rg + 4 * r < N) ssq = fma(w[r], w[r], ssq);
+                        ssq += __shfl_xor(ssq, 16);
+                        ssq += __shfl_xor(ssq, 32);
+                        if (rg == 0) cs_ptr(J, K)[lane & 15] = ssq;
+                    }
+                }
+            }
+            TRACE(3);
+            TRACE(4);
+            WSTAMP(12);
+        }
+        __syncthreads();
+        if (*S.flag) return false;
+        TSTAMP(3);
+    }
+    TSTAMP(4);
+    // m = -(row N of W),  tr2_i = sum over the block column of the tile column sums (fixed order)
+    for (int i = tid; i < N; i += KT) {
+        const int J = i >> 4, c = i & 15;
+        double t2 = 0.0;
+        for (int I = J; I < nb; ++I) t2 += cs_ptr(I, J)[c];
+        S.tr2[i] = t2;
+        {
+            const int rr = N - 16 * aug_tile, q = rr >> 2, ln = (rr & 3) * 16 + c;
+            S.m[i] = -C[((size_t)aug_tile * nb + J) * 256 + (q >> 1) * 128 + ln * 2 + (q & 1)];
+        }
+    }
+    __syncthreads();
+    TSTAMP(7);
+    return true;
+}
+
 // ---- (T + I) tau = rhs by a wave scan: band_scan.h ----
 template <bool WIDE> constexpr int scan_rows() { return WIDE ? 10 : 6; }  // rows per lane: 64 * 6 = 384, 64 * 10 = 640 >= NP
 using bandscan::scan_solve;
@@ -1301,7 +1558,9 @@ template <bool WIDE, int CLM>
 __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_fit;
-    constexpr bool CL = CLM != 0;
+    constexpr bool CL = CLM == 1 || CLM == 2;
+    constexpr bool LL = CLM == 3;  // left-looking solve on one workgroup (solve_posterior_ll), N <= 335
+    static_assert(!(LL && WIDE), "the left-looking solve keeps two rows of L in LDS: N <= 335");
     // cluster mode: workgroup b sits on XCD b & 7 (ids go round the XCDs) as the (b >> 3)-th of the launch there; the members of
     // a fit are `cluster` consecutive ones of ONE XCD: fit (i / cluster) * 8 + x of the launch, member i % cluster
     int launch_index = blockIdx.x, member = 0;
@@ -1411,6 +1670,11 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         S.band = CL ? P.cs : P.W;
         S.scanQ = S.band + 6 * NP;
         S.rec = reinterpret_cast<uint4 *>(S.red + NP);
+    } else if constexpr (LL) {
+        // (the LDS region of the bands, scan tables and tile table holds the diagonal tiles: solve_posterior_ll)
+        S.band = P.W;
+        S.scanQ = S.band + 6 * NP;
+        S.rec = reinterpret_cast<uint4 *>(S.red + NP + 6 * NP + 2 * 6 * 4 * 64);
     } else {
         S.band = S.red + NP;
         S.scanQ = S.band + 6 * NP;  // [2 directions][6 levels][4 entries][64 lanes]
@@ -1418,7 +1682,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     }
     S.flag = reinterpret_cast<int *>(S.rec + max_tiles<WIDE>());  // [0] not positive definite, [1] column counter of the inverse row
     S.hand = (!WIDE && NP <= kHandMaxNP) ? reinterpret_cast<double *>(S.flag + 8) : nullptr;  // (32 bytes of flags; 16-byte aligned)
-    for (int e = tid; e < max_tiles<WIDE>(); e += KT) {  // tile e = (i - 1) i / 2 + (j - 1), 1 <= j <= i
+    for (int e = tid; e < (LL ? 0 : max_tiles<WIDE>()); e += KT) {  // tile e = (i - 1) i / 2 + (j - 1), 1 <= j <= i
         int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while ((i + 1) * (i + 2) / 2 <= e) ++i;
         while (i * (i + 1) / 2 > e) --i;
@@ -1499,7 +1763,11 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
 #endif
         bool solved;
         if constexpr (CL && !WIDE) solved = solve_posterior_cluster<CLM>(P, S, ++nsolve);
-        else solved = solve_posterior<WIDE, CLM>(P, S, ++nsolve);
+        else if constexpr (LL) {
+            Smem SL = S;
+            SL.band = smem + (S.red + NP - smem);  // the LDS region behind the vectors: the diagonal tiles
+            solved = solve_posterior_ll(P, SL);
+        } else solved = solve_posterior<WIDE, CLM>(P, S, ++nsolve);
         if (!solved) {
             status = (CL && S.flag[0] == 2) ? FIT_STATUS_CLUSTER : FIT_STATUS_NOT_SPD;
             break;
@@ -1804,6 +2072,13 @@ static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s)
         return go(&fit_loop_kernel<false, 1>, Q, grid);
     }
     if (loop_is_wide(P.NP)) return go(&fit_loop_kernel<true, 0>, P, blocks);
+    // FRANK_AMD_K2_LL=1: the left-looking solve (solve_posterior_ll).  Measured (round 4) and NOT the default: the same bits with
+    // 6.4 instead of 10.9 MB through the L1 per pass, but 156-163 us per pass alone against 136 -- its work piles up in the late
+    // steps (171 tile products in step 18 against a 4.4 us chain in the first ones) and the chain's LDS shuffles queue behind the
+    // operand reads (5.3 us per diagonal tile) -- and with the device full it only draws level (200 loops: 227 against 233 us,
+    // steady state 1 078 against 1 056 fits/s).
+    const char *le = getenv("FRANK_AMD_K2_LL");
+    if (le && atoi(le) != 0) return go(&fit_loop_kernel<false, 3>, P, blocks);
     return go(&fit_loop_kernel<false, 0>, P, blocks);
 }
 

@@ -1474,3 +1474,18 @@ def test_sweep_evidence_on_the_device(golden):
         np.testing.assert_allclose(ev["log_evidence"][k], F1.log_evidence_laplace(), rtol=1e-8)
         np.testing.assert_allclose(ev["spectrum_covariance_diag"][k], np.diag(F1.MAP_spectrum_covariance), rtol=1e-5)
     assert np.all(np.isfinite(ev["log_evidence"]))
+
+
+@pytest.mark.parametrize("N", [47, 130, 300, 335])
+def test_left_looking_solve_equals_right_looking(monkeypatch, N):
+    """FRANK_AMD_K2_LL=1 (fit_loop.hip, solve_posterior_ll: every tile of the factor formed once, one operand from an LDS row)
+    against the default right-looking solve: mu, p and the iteration count are the same bits."""
+    FF, M, j = _cluster_problem(N, 100000)
+    ctx = FF._DHT.context()
+    monkeypatch.setenv("FRANK_AMD_K2_CLUSTER", "1")
+    monkeypatch.setenv("FRANK_AMD_K2_LL", "0")
+    rc0, mu0, p0, n0, *_ = _fit_normal(ctx, N, M, j, max_iter=200)
+    monkeypatch.setenv("FRANK_AMD_K2_LL", "1")
+    rc, mu, p, n, *_ = _fit_normal(ctx, N, M, j, max_iter=200)
+    assert rc0 == 0 and rc == 0
+    assert n == n0 and np.array_equal(mu, mu0) and np.array_equal(p, p0)

@@ -54,9 +54,15 @@ for N in sizes:
     L.check(L.lib.fh_dht_create(2.0 / rad_to_arcsec, N, 0, ctypes.byref(dht)))
     L.check(L.lib.fh_ctx_create(dht, 0, ctypes.byref(ctx)))
     os.environ["FRANK_AMD_K2_CLUSTER"] = "1"
+    os.environ["FRANK_AMD_K2_LL"] = "0"
     mu0, p0, n0, t0, k0, wg0, _ = fit(ctx, N, M, j, alpha, ws)
-    print("N=%d  one workgroup: %d iterations (reference %s)  %.2f ms  kernel %.2f ms  %.1f us/pass" % (
+    print("N=%d  one workgroup, right-looking: %d iterations (reference %s)  %.2f ms  kernel %.2f ms  %.1f us/pass" % (
         N, n0, ref_it, 1e3 * t0, k0, 1e3 * k0 / (n0 + 2)), flush=True)
+    os.environ["FRANK_AMD_K2_LL"] = "1"
+    mu, p, n, t, k, wg, fb = fit(ctx, N, M, j, alpha, ws)
+    print("N=%d  one workgroup, left-looking:  %d iterations  %.2f ms  kernel %.2f ms  %.1f us/pass  bitwise equal: %s  max|dmu|/max %.2e" % (
+        N, n, 1e3 * t, k, 1e3 * k / (n + 2), bool(n == n0 and np.array_equal(mu, mu0) and np.array_equal(p, p0)),
+        np.abs(mu - mu0).max() / np.abs(mu0).max()), flush=True)
     for g in CLUSTERS:
         for workers in WORKERS:
             os.environ["FRANK_AMD_K2_CLUSTER"] = str(g)
