@@ -1189,43 +1189,10 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
             };
             // (tile 0 of either enumeration is (k+2, k+2): skipped -- indices below are shifted by one)
             const int cnt = cntB - 1;
-            int e = widx;
-            if (e < cnt) {
-                uint4 ta = rec_at(e + 1), tb = ta, tc = ta;
-                v4f64 a = ldt(ta, e + 1), b = a, c = a;
-                if (e + NWKc < cnt) {
-                    tb = rec_at(e + NWKc + 1);
-                    b = ldt(tb, e + NWKc + 1);
-                }
-                for (;;) {
-                    if (e + 2 * NWKc < cnt) {
-                        tc = rec_at(e + 2 * NWKc + 1);
-                        c = ldt(tc, e + 2 * NWKc + 1);
-                    }
-                    fin(ta, a);
-                    if (e + NWKc >= cnt) break;
-                    if (e + 3 * NWKc < cnt) {
-                        ta = rec_at(e + 3 * NWKc + 1);
-                        a = ldt(ta, e + 3 * NWKc + 1);
-                    }
-                    fin(tb, b);
-                    if (e + 2 * NWKc >= cnt) break;
-                    if (e + 4 * NWKc < cnt) {
-                        tb = rec_at(e + 4 * NWKc + 1);
-                        b = ldt(tb, e + 4 * NWKc + 1);
-                    }
-                    fin(tc, c);
-                    if (e + 3 * NWKc >= cnt) break;
-                    e += 3 * NWKc;
-                }
-            }
-            WSTAMP(11);
-            TRACE(1);
-            // ---- column k + 1 without its first tile (the chain wave's): update, then the panel of step k + 1 ----
-            const int ncol = max(m - 2, 0);  // tiles (I, k + 1), I > k + 2
-            int cfirst = widx - max(cnt, 0) % NWKc;
+            const int ncol = max(m - 2, 0);  // tiles (I, k + 1), I > k + 2 (the first one is the chain wave's)
+            int cfirst = widx - max(cnt, 0) % NWKc;  // (the round-robin deal goes on where the band stopped)
             if (cfirst < 0) cfirst += NWKc;
-            if (cfirst < ncol) {
+            auto wait_flag = [&]() {
                 int spins = 0;
                 while (__hip_atomic_load(&S.flag[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) {
                     __builtin_amdgcn_s_sleep(1);
@@ -1234,23 +1201,117 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
                         break;
                     }
                 }
-                TRACE(2);
-                Frag fx;  // L_{k+1,k+1}^-1: as A operand X, as B operand X^T
+            };
+            auto column_finish = [&](int i, v4f64 t, const Frag &fx) {  // D = X T^T = L_{I,k+1}^T -> tile (k+1, I), panel k + 1
+                Frag ft;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[((k + 1) & 1) * 16 * PS + cl * PS + 4 * q + rg];
-                for (int c = cfirst; c < ncol; c += NWKc) {
-                    const int i = c + 2;  // block row I = k + 1 + i
-                    v4f64 t = ld_pk(src_u, base_pk + (unsigned)(k == 0 ? i * 2048 : i * nb * 2048), lane);
-                    t = upd(0u, (unsigned)(i * 16 * PS * 8), t);  // T^T = C_{I,k+1}^T - L_{k+1,k} L_Ik^T: the tile is kept transposed
-                    Frag ft;
+                for (int q = 0; q < 4; ++q) ft.v[q] = t[q];
+                const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
+                const v4f64 d = mfma4(fx, ft, z4, false);
+                st_pk(C_u, base_pk + (unsigned)(i * 2048), lane, d);
+                double *pr = pan_nxt + (size_t)((i - 1) * 16 + cl) * PS + rg;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) ft.v[q] = t[q];
-                    const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
-                    const v4f64 d = mfma4(fx, ft, z4, false);  // D = X T^T = L_{I,k+1}^T
-                    st_pk(C_u, base_pk + (unsigned)(i * 2048), lane, d);  // tile (k+1, I): the block the inverse reads
-                    double *pr = pan_nxt + (size_t)((i - 1) * 16 + cl) * PS + rg;
+                for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
+            };
+            if (band < nb && !(P.cluster_break & 2)) {
+                // With helpers of the trailing update a wave has at most four band tiles and two column tiles per step: ALL their
+                // loads go out at the start of the step (the tiles that come back from the helpers behind one look at their
+                // column's counter), the column tiles take update k BEFORE the chain wave's flag, and what is left behind the
+                // flag is one product and the stores.  (The three-set rotation below, made for dozens of tiles per wave, left
+                // one L2 round trip behind the flag and one per tile in front of it: ~1.5 us per tile product in the early steps.)
+                constexpr int TB = 4, TC = 2;
+                uint4 tr[TB];
+                v4f64 tt[TB], ct[TC];
+                bool viaH = false;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
+                for (int u = 0; u < TB; ++u) {
+                    const int e = widx + u * NWKc;
+                    if (e < cnt) {
+                        tr[u] = rec_at(e + 1);
+                        if (e + 1 >= cntH) viaH = true;
+                        else tt[u] = ldt(tr[u], e + 1);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < TC; ++u) {
+                    const int c = cfirst + u * NWKc;
+                    if (c < ncol) ct[u] = ld_pk(src_u, base_pk + (unsigned)(k == 0 ? (c + 2) * 2048 : (c + 2) * nb * 2048), lane);
+                }
+                if (viaH) {
+#pragma unroll
+                    for (int u = 0; u < TB; ++u) {
+                        const int e = widx + u * NWKc;
+                        if (e < cnt && e + 1 >= cntH) tt[u] = ldt(tr[u], e + 1);  // (the first of them waits for the column's counter)
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < TB; ++u)
+                    if (widx + u * NWKc < cnt) fin(tr[u], tt[u]);
+#pragma unroll
+                for (int u = 0; u < TC; ++u) {
+                    const int c = cfirst + u * NWKc;
+                    if (c < ncol) ct[u] = upd(0u, (unsigned)((c + 2) * 16 * PS * 8), ct[u]);  // T^T = C_{I,k+1}^T - L_{k+1,k} L_Ik^T
+                }
+                WSTAMP(11);
+                TRACE(1);
+                if (cfirst < ncol) {
+                    wait_flag();
+                    TRACE(2);
+                    Frag fx;  // L_{k+1,k+1}^-1: as A operand X, as B operand X^T
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[((k + 1) & 1) * 16 * PS + cl * PS + 4 * q + rg];
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) {
+                        const int c = cfirst + u * NWKc;
+                        if (c < ncol) column_finish(c + 2, ct[u], fx);
+                    }
+                }
+            } else {
+                int e = widx;
+                if (e < cnt) {
+                    uint4 ta = rec_at(e + 1), tb = ta, tc = ta;
+                    v4f64 a = ldt(ta, e + 1), b = a, c = a;
+                    if (e + NWKc < cnt) {
+                        tb = rec_at(e + NWKc + 1);
+                        b = ldt(tb, e + NWKc + 1);
+                    }
+                    for (;;) {
+                        if (e + 2 * NWKc < cnt) {
+                            tc = rec_at(e + 2 * NWKc + 1);
+                            c = ldt(tc, e + 2 * NWKc + 1);
+                        }
+                        fin(ta, a);
+                        if (e + NWKc >= cnt) break;
+                        if (e + 3 * NWKc < cnt) {
+                            ta = rec_at(e + 3 * NWKc + 1);
+                            a = ldt(ta, e + 3 * NWKc + 1);
+                        }
+                        fin(tb, b);
+                        if (e + 2 * NWKc >= cnt) break;
+                        if (e + 4 * NWKc < cnt) {
+                            tb = rec_at(e + 4 * NWKc + 1);
+                            b = ldt(tb, e + 4 * NWKc + 1);
+                        }
+                        fin(tc, c);
+                        if (e + 3 * NWKc >= cnt) break;
+                        e += 3 * NWKc;
+                    }
+                }
+                WSTAMP(11);
+                TRACE(1);
+                // ---- column k + 1 without its first tile (the chain wave's): update, then the panel of step k + 1 ----
+                if (cfirst < ncol) {
+                    wait_flag();
+                    TRACE(2);
+                    Frag fx;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[((k + 1) & 1) * 16 * PS + cl * PS + 4 * q + rg];
+                    for (int c = cfirst; c < ncol; c += NWKc) {
+                        const int i = c + 2;  // block row I = k + 1 + i
+                        v4f64 t = ld_pk(src_u, base_pk + (unsigned)(k == 0 ? i * 2048 : i * nb * 2048), lane);
+                        t = upd(0u, (unsigned)(i * 16 * PS * 8), t);
+                        column_finish(i, t, fx);
+                    }
                 }
             }
             TRACE(3);
@@ -1637,7 +1698,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     int *const ctl = CL ? clu::ctl_of(P) : nullptr;
     if constexpr (CL) {
         if (member > 0) {  // a helper workgroup: block columns of the inverse (clu::inverse_wave) or trailing tiles (clu::trailing_wave)
-            if (P.cluster_break) return;
+            if (P.cluster_break & 1) return;
             if (tid == 0) {
                 __hip_atomic_fetch_or(ctl + clu::XCC, 1 << clu::xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 clu::add(ctl + clu::IN, 1);
