@@ -1904,8 +1904,10 @@ static int fit_cluster_size(const fh_ctx *c) {
     int want = e ? atoi(e) : 5;
     want = want < 1 ? 1 : (want > FIT_CLUSTER_MAX ? FIT_CLUSTER_MAX : want);
     if (want <= 1 || c->NP < 128 || c->NP > fh_k2_loop_max_np()) return 1;
-    if (c->NP > 336 && !e) want = 3;  // (the wide instantiation: helpers of the inverse only)
-    if (c->NP / 16 > 24 && want == 2) want = 3;  // (a helper wave takes two block columns at most: more than 24 need two helpers)
+    // the wide instantiations: helpers of the inverse only, a helper wave takes two block columns at most (24 per helper)
+    const int need = 1 + (c->NP / 16 + 23) / 24;
+    if (c->NP > 336 && !e) want = need > 3 ? need : 3;
+    if (want < need) want = need;
     return want;
 }
 
@@ -1950,7 +1952,7 @@ int fh_fit_normal(fh_ctx *c, const double *M, const double *j, double alpha, dou
     if ((M == nullptr) != (j == nullptr)) return fail(FH_ERR_INVALID, "fh_fit_normal: pass both M and j or neither");
     if (!M && !c->have_device_Mj) return fail(FH_ERR_INVALID, "fh_fit_normal: no device-resident M, j (run fh_stats_finalize)");
     if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
-    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 639", c->N);
+    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 1023", c->N);
     HIP_TRY(hipSetDevice(c->device));
     const int N = c->N;
     const size_t NN = (size_t)N * N;
@@ -2046,7 +2048,7 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
         return fail(FH_ERR_INVALID, "fh_fit_normal_batched: bad argument");
     if ((M == nullptr) != (j == nullptr)) return fail(FH_ERR_INVALID, "pass both M and j or neither");
     if (!M && !c->have_device_Mj) return fail(FH_ERR_INVALID, "no device-resident M, j (run fh_stats_finalize)");
-    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 639", c->N);
+    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 1023", c->N);
     HIP_TRY(hipSetDevice(c->device));
     const int N = c->N, NP = c->NP, nbk = NP / 16;
     const size_t NN = (size_t)N * N, PP = (size_t)NP * NP;
@@ -2203,7 +2205,7 @@ int fh_fit_flush(fh_ctx *c) {
 int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol, int max_iter, int *ticket) {
     if (!c || !ticket) return fail(FH_ERR_INVALID, "fh_fit_submit: NULL argument");
     if (!c->have_device_Mj) return fail(FH_ERR_INVALID, "fh_fit_submit: no device-resident M, j (run fh_stats_finalize)");
-    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 639", c->N);
+    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 1023", c->N);
     if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
     HIP_TRY(hipSetDevice(c->device));
     int si = -1;
@@ -2524,7 +2526,7 @@ int fh_update_power_spectrum(fh_ctx *c, const double *M, const double *j, const 
     if (!c || !M || !j || !p) return fail(FH_ERR_INVALID, "fh_update_power_spectrum: NULL argument");
     if (c->use_rocsolver_loop || c->NP > fh_k2_loop_max_np())
         return update_power_spectrum_rocsolver(c, M, j, p, alpha, p0, wsmooth, mu, p_new);
-    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 639", c->N);
+    if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 1023", c->N);
     HIP_TRY(hipSetDevice(c->device));
     const int N = c->N;
     for (int k = 0; k < N; ++k)

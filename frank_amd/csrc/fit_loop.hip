@@ -96,9 +96,14 @@ constexpr int kMaxTiles = 210;  // tiles of the largest trailing triangle: NP / 
 // (its own instantiation).  Before this, 320 < N <= 512 ran the library loop: ~8 x the time per pass at N = 321.
 constexpr int kMaxTilesWide = 780;  // 39 block rows
 constexpr int kWideMinNP = 337, kWideMaxNP = 640;
+// XWIDE (640 < NP <= 1024, N <= 1023; WIDE = 2): the one panel alone takes 139 KB at NP = 1024.  The vectors of the outer loop (p,
+// m, Tr2, the right-hand side, ..: 8 NP doubles) join the band factors and scan tables in global memory (L2), the tile table is
+// computed instead of stored, the wave scan takes sixteen rows per lane.  Before this, N >= 640 ran the library loop (rocBLAS +
+// rocSOLVER per pass, ~2.5 ms): a 2.4 x cliff at N = 640.
+constexpr int kXWideMinNP = 641, kXWideMaxNP = 1024;
 constexpr int kHandMaxNP = 320;  // cluster mode: the four hand-over tiles (8 KB) fit the LDS beside two panels up to here
-template <bool WIDE> constexpr int max_tiles() { return WIDE ? kMaxTilesWide : kMaxTiles; }
-template <bool WIDE> constexpr int npanels() { return WIDE ? 1 : 2; }
+template <int WIDE> constexpr int max_tiles() { return WIDE == 2 ? 0 : (WIDE ? kMaxTilesWide : kMaxTiles); }
+template <int WIDE> constexpr int npanels() { return WIDE ? 1 : 2; }
 
 struct Smem {
     double *pan;   // panels of the current and the next block column: 2 x NP x PS doubles
@@ -244,7 +249,8 @@ namespace clu {
 // control words (ints), zero between fits: PROG progress of the factorisation, DONE helper waves that have handed over their
 // columns, IN helper workgroups present, XCC the XCDs the members sit on; HCOL + J: trailing tiles of block column J the helpers
 // have handed back (cumulative over the passes)
-enum { PROG = 0, DONE = 1, IN = 2, XCC = 3, HCOL = 8, NCTL = 8 + 40 };
+enum { PROG = 0, DONE = 1, IN = 2, XCC = 3, HCOL = 8, NCTL = 8 + 64 };
+constexpr int kSeq = 128;  // progress word = pass * kSeq + block columns of L that are final (<= 64)
 // exchange area (the fit's WdT buffer): [0, NP) Tr2 and [NP, 2 NP) m from the helpers, [2 NP, 3 NP) 1 / p from the first
 // workgroup, then the control words
 constexpr int kBand = 2;    // block columns right of the panel the first workgroup updates itself (see trailing_wave)
@@ -389,7 +395,7 @@ __device__ __forceinline__ void trailing_wave(const FitLoopParams &P, int *ctl, 
         for (int i = 0; i < kTMax; ++i)
             if (tJ[i] >= 0) last = max(last, tJ[i] - 2 - band);
         for (int c = 0; c <= last; ++c) {
-            if (!wait_prog(ctl, seq * 64 + c + 1, seen)) return;
+            if (!wait_prog(ctl, seq * clu::kSeq + c + 1, seen)) return;
             int handed = 0;
 #pragma unroll
             for (int i = 0; i < kTMax; ++i) {
@@ -414,7 +420,7 @@ __device__ __forceinline__ void trailing_wave(const FitLoopParams &P, int *ctl, 
                 if (lane == 0) add(ctl + HCOL + c + 2 + band, handed);
             }
         }
-        if (!wait_prog(ctl, (seq + 1) * 64 + 1, seen)) return;  // the next pass (its first event) or the end of the fit
+        if (!wait_prog(ctl, (seq + 1) * clu::kSeq + 1, seen)) return;  // the next pass (its first event) or the end of the fit
     }
 }
 // A wave of a helper of the INVERSE, for every pass of the fit: the block columns J = hw, hw + T, .. of W = L^-1.  At the event
@@ -449,7 +455,7 @@ __device__ __forceinline__ void inverse_wave(const FitLoopParams &P, int *ctl, i
             acc2[i] = v4f64{0.0, 0.0, 0.0, 0.0};
         }
         for (int c = hw; c < nb; ++c) {  // (the first event that concerns this wave: its first column)
-            if (!wait_prog(ctl, seq * 64 + c + 1, seen)) return;
+            if (!wait_prog(ctl, seq * clu::kSeq + c + 1, seen)) return;
             const v4f64 xp = ld_pk(Cg, (unsigned)((c * nb + c) * 2048), lane);  // X_cc = W_cc
             v4f64 la = xp;
             if (c + 1 < nb) la = ld_pk(Cg, (unsigned)((c * nb + c + 1) * 2048), lane);  // mirror tile (c, c + 1): L_{c+1,c}
@@ -524,7 +530,7 @@ __device__ __forceinline__ void inverse_wave(const FitLoopParams &P, int *ctl, i
 // CLM: 0 one workgroup does everything; 1, 2: cluster mode (the rows of the inverse on the helper workgroups, clu::), with
 // every wave but the chain's on the trailing update (1) or with the two waves that share the chain's SIMD sitting out (2);
 // seq: number of this solve within the fit (the helpers count the passes the same way)
-template <bool WIDE, int CLM>
+template <int WIDE, int CLM>
 __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Smem &S, int seq) {
     constexpr bool CL = CLM != 0;
     constexpr int NWKc = CLM == 2 ? NW - NW / 4 : NWK;  // trailing-update workers
@@ -582,7 +588,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
         Frag fa;
 #pragma unroll
         for (int q = 0; q < 4; ++q) fa.v[q] = S.dli[cl * PS + 4 * q + rg];
-        constexpr int kPanelMax = WIDE ? 4 : 3;  // ceil((NP / 16 - 1) / NW): 4 for NP <= 640
+        constexpr int kPanelMax = WIDE == 2 ? 6 : (WIDE ? 4 : 3);  // ceil((NP / 16 - 1) / NW): 4 for NP <= 640, 6 for NP <= 1024
         Frag fb[kPanelMax];
 #pragma unroll
         for (int u = 0; u < kPanelMax; ++u) {
@@ -610,7 +616,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
     if constexpr (CL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the barrier waits for LDS only)
     __syncthreads();
     if constexpr (CL)
-        if (tid == 0) clu::st(ctl + clu::PROG, seq * 64 + 1);  // column 0 of L and X_00 are final
+        if (tid == 0) clu::st(ctl + clu::PROG, seq * clu::kSeq + 1);  // column 0 of L and X_00 are final
     TSTAMP(2);
     const gdouble *C_inv = as_global(uniform_ptr(C));
     gdouble *W_inv = as_global(uniform_ptr(W));
@@ -725,7 +731,17 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                         return S.rec[(i - 1) * i / 2 + (j - 1)];
                     }
                 }
-                return S.rec[e];
+                if constexpr (WIDE == 2) {  // no table in LDS: tile e = (i - 1) i / 2 + (j - 1), 1 <= j <= i (e is wave-uniform)
+                    int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                    while ((i + 1) * (i + 2) / 2 <= e) ++i;
+                    while (i * (i + 1) / 2 > e) --i;
+                    const int j = e - i * (i + 1) / 2 + 1;
+                    ++i;
+                    return make_uint4((unsigned)((j * nb + i) * 2048) | (i == j ? 2u : 0u), (unsigned)(j * 16 * PS * 8),
+                                      (unsigned)(i * 16 * PS * 8), (unsigned)((i * nb + j) * 2048) | (unsigned)i);
+                } else {
+                    return S.rec[e];
+                }
             };
             auto ldt = [&](const uint4 &t, int e) {  // (step 0 reads A: the transpose of tile (I, J) is its tile (J, I))
                 if constexpr (CL) {
@@ -803,7 +819,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             // (the round-robin deal of the tiles goes on where the enumeration above stopped)
             int cfirst = widx - cnt % NWKc;
             if (cfirst < 0) cfirst += NWKc;
-            constexpr int kColMax = CLM == 2 ? 5 : 4;  // (WIDE: ncol <= 38 <= kColMax x NWKc)
+            constexpr int kColMax = WIDE == 2 ? 6 : (CLM == 2 ? 5 : 4);  // (WIDE: ncol <= 38, XWIDE: <= 62 <= kColMax x NWKc)
             v4f64 dcol[WIDE ? kColMax : 1];
             if (cfirst < ncol) {
                 // L_{k+1,k+1}^-1 comes from wave 0's chain (~5 us into the step): inverse columns fill the wait
@@ -888,7 +904,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
         if constexpr (CL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's tiles are in the L2 the helpers read
         __syncthreads();
         if constexpr (CL)
-            if (tid == 0 && m > 0) clu::st(ctl + clu::PROG, seq * 64 + k + 2);  // columns <= k + 1 of L and X_{k+1,k+1} are final
+            if (tid == 0 && m > 0) clu::st(ctl + clu::PROG, seq * clu::kSeq + k + 2);  // columns <= k + 1 of L and X_{k+1,k+1} are final
         TSTAMP(3);
     }
     if (*S.flag) return false;
@@ -1016,7 +1032,7 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the barrier waits for LDS only)
     __syncthreads();
-    if (tid == 0) clu::st(ctl + clu::PROG, seq * 64 + 1);  // column 0 of L and X_00 are final
+    if (tid == 0) clu::st(ctl + clu::PROG, seq * clu::kSeq + 1);  // column 0 of L and X_00 are final
     TSTAMP(2);
     gdouble *C_u = as_global(uniform_ptr(C));
     const gdouble *A_u = as_global(uniform_ptr(P.A));
@@ -1030,7 +1046,7 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
             const int old = atomicAdd(&S.flag[4], 1);
-            if (old + 1 == (k + 1) * NW) clu::st(ctl + clu::PROG, seq * 64 + k + 2);
+            if (old + 1 == (k + 1) * NW) clu::st(ctl + clu::PROG, seq * clu::kSeq + k + 2);
         }
     };
     v4f64 dg = {0.0, 0.0, 0.0, 0.0};  // the chain wave's next diagonal tile, all updates applied
@@ -1611,11 +1627,11 @@ __device__ __forceinline__ bool solve_posterior_ll(const FitLoopParams &P, const
 }
 
 // ---- (T + I) tau = rhs by a wave scan: band_scan.h ----
-template <bool WIDE> constexpr int scan_rows() { return WIDE ? 10 : 6; }  // rows per lane: 64 * 6 = 384, 64 * 10 = 640 >= NP
+template <int WIDE> constexpr int scan_rows() { return WIDE == 2 ? 16 : (WIDE ? 10 : 6); }  // rows per lane: 64 * 6 = 384, 64 * 10 = 640, 64 * 16 = 1024 >= NP
 using bandscan::scan_solve;
 using bandscan::scan_tables;
 
-template <bool WIDE, int CLM>
+template <int WIDE, int CLM>
 __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_fit;
@@ -1715,7 +1731,10 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     Smem S;
     S.pan = smem;
     S.dli = S.pan + npanels<WIDE>() * NP * PS;
-    S.p = S.dli + 2 * 16 * PS;
+    // (XWIDE: the vectors live behind the band factors and scan tables in global memory -- the W buffer, or the cs buffer in
+    //  cluster mode --, only the panel, the inverse of the diagonal tile and the flags in LDS)
+    double *const gscratch = CL ? P.cs : P.W;
+    S.p = WIDE == 2 ? gscratch + 6 * NP + 2 * 6 * 4 * 64 : S.dli + 2 * 16 * PS;
     S.pold = S.p + NP;
     S.m = S.pold + NP;
     S.y = S.m + NP;
@@ -1728,9 +1747,9 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         // W lives in the dead tiles of C --: wave 0 reads them once per pass (band_scan.h takes either address space), and
         // the one panel, the vectors and the tile table of NP = 512 fit the LDS beside nothing else
         // (cluster mode: the helpers of the inverse write W there; the cs buffer, (NP / 16)^2 x 16 doubles, is free instead)
-        S.band = CL ? P.cs : P.W;
+        S.band = gscratch;
         S.scanQ = S.band + 6 * NP;
-        S.rec = reinterpret_cast<uint4 *>(S.red + NP);
+        S.rec = reinterpret_cast<uint4 *>(WIDE == 2 ? S.dli + 2 * 16 * PS : S.red + NP);
     } else if constexpr (LL) {
         // (the LDS region of the bands, scan tables and tile table holds the diagonal tiles: solve_posterior_ll)
         S.band = P.W;
@@ -1858,7 +1877,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
             if (P.diag_mu) {  // MAP of this pass: mu = Y^-1 m   (radial_fitters.py:783)
                 // (the loads of four rows are issued together: a row at a time the wave waited for one L2 round trip per row,
                 //  24 us of a 160 us pass with store_iteration_diagnostics on; the sums are formed in the same order)
-                constexpr int RB = 4, CB = WIDE ? 10 : 6;  // column chunks of 64: N < 336, N <= 639
+                constexpr int RB = WIDE == 2 ? 1 : 4, CB = WIDE == 2 ? 16 : (WIDE ? 10 : 6);  // column chunks of 64: N < 336, <= 639, <= 1023
                 const int ln = tid & 63;
                 double ms[CB];
 #pragma unroll
@@ -2068,8 +2087,10 @@ __global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int 
 }  // namespace
 
 static bool loop_is_wide(int NP) { return NP >= kWideMinNP; }
-int fh_k2_loop_max_np() { return kWideMaxNP; }
+static bool loop_is_xwide(int NP) { return NP >= kXWideMinNP; }
+int fh_k2_loop_max_np() { return kXWideMaxNP; }
 size_t fh_k2_loop_smem_bytes(int NP) {
+    if (loop_is_xwide(NP)) return sizeof(double) * (size_t)(NP * PS + 2 * 16 * PS) + 64;  // the panel, L_kk^-1 (two), the flags
     const bool wide = loop_is_wide(NP);
     return sizeof(double) * (size_t)((wide ? 1 : 2) * NP * PS + 2 * 16 * PS + 7 * NP + NP + (wide ? 0 : 6 * NP + 2 * 6 * 4 * 64)) +
            16 * (size_t)(wide ? kMaxTilesWide : kMaxTiles) + 32 + ((wide || NP > kHandMaxNP) ? 0 : 4 * 2048);  // (+ the hand-over tiles of the cluster mode)
@@ -2095,7 +2116,7 @@ __global__ __launch_bounds__(KT) void fit_loop_dummy_kernel(long long cycles, in
 // one launch of `blocks` workgroups of the instantiation that covers P.NP
 static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s) {
     const size_t smem = fh_k2_loop_smem_bytes(P.NP);
-    if (P.NP > kWideMaxNP) return hipErrorInvalidValue;
+    if (P.NP > kXWideMaxNP) return hipErrorInvalidValue;
     if (const char *d = getenv("FRANK_AMD_K2_DUMMY")) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_dummy_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -2129,18 +2150,20 @@ static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s)
         const int grid = 8 * P.cluster * ((blocks + 7) / 8);
         // (CLM = 2, the two waves on the chain's SIMD sitting the trailing update out, was measured at every stage of this mode:
         //  never faster -- 99.1 against 97.6 us per pass at the end -- and is not instantiated)
-        if (loop_is_wide(P.NP)) return go(&fit_loop_kernel<true, 1>, Q, grid);
-        return go(&fit_loop_kernel<false, 1>, Q, grid);
+        if (loop_is_xwide(P.NP)) return go(&fit_loop_kernel<2, 1>, Q, grid);
+        if (loop_is_wide(P.NP)) return go(&fit_loop_kernel<1, 1>, Q, grid);
+        return go(&fit_loop_kernel<0, 1>, Q, grid);
     }
-    if (loop_is_wide(P.NP)) return go(&fit_loop_kernel<true, 0>, P, blocks);
+    if (loop_is_xwide(P.NP)) return go(&fit_loop_kernel<2, 0>, P, blocks);
+    if (loop_is_wide(P.NP)) return go(&fit_loop_kernel<1, 0>, P, blocks);
     // FRANK_AMD_K2_LL=1: the left-looking solve (solve_posterior_ll).  Measured (round 4) and NOT the default: the same bits with
     // 6.4 instead of 10.9 MB through the L1 per pass, but 156-163 us per pass alone against 136 -- its work piles up in the late
     // steps (171 tile products in step 18 against a 4.4 us chain in the first ones) and the chain's LDS shuffles queue behind the
     // operand reads (5.3 us per diagonal tile) -- and with the device full it only draws level (200 loops: 227 against 233 us,
     // steady state 1 078 against 1 056 fits/s).
     const char *le = getenv("FRANK_AMD_K2_LL");
-    if (le && atoi(le) != 0) return go(&fit_loop_kernel<false, 3>, P, blocks);
-    return go(&fit_loop_kernel<false, 0>, P, blocks);
+    if (le && atoi(le) != 0) return go(&fit_loop_kernel<0, 3>, P, blocks);
+    return go(&fit_loop_kernel<0, 0>, P, blocks);
 }
 
 hipError_t fh_k2_launch_loop_batched(const FitLoopParams &P, int batch, hipStream_t s) { return launch_loop(P, batch, s); }

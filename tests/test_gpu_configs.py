@@ -573,13 +573,14 @@ def test_moments_path_beyond_N511_against_oracle(N):
     assert np.array_equal(m["M"], m["M"].T)
 
 
-@pytest.mark.parametrize("N", [340, 400, 478, 511, 600, 639])
+@pytest.mark.parametrize("N", [340, 400, 478, 511, 600, 639, 640, 700, 1000, 1023])
 def test_wide_fit_loop_against_the_library_loop(monkeypatch, N):
-    """320 < N <= 639: the persistent fit loop with ONE LDS panel (fit_loop.hip, WIDE; the band factors and scan tables of the
-    smoothing solve in global memory, so that NP = 640 fits the LDS) against the library loop (rocBLAS +
-    rocSOLVER per iteration, FRANK_AMD_K2=rocsolver) that used to serve these sizes -- whole fits to convergence: the same
-    number of iterations, profiles to 1e-8 of the maximum -- and, at N = 400, the first 20 iterations against the oracle
-    (radial_fitters.py:737-832)."""
+    """320 < N <= 1023: the persistent fit loop with ONE LDS panel (fit_loop.hip, WIDE; the band factors and scan tables of the
+    smoothing solve in global memory, so that NP = 640 fits the LDS; from N = 640 on XWIDE: the vectors of the outer loop in
+    global memory too, the tile table computed) against the library loop (rocBLAS + rocSOLVER per iteration,
+    FRANK_AMD_K2=rocsolver) that used to serve these sizes -- whole fits to convergence: the same number of iterations,
+    profiles to 1e-8 of the maximum -- and, at N = 400, the first 20 iterations against the oracle (radial_fitters.py:737-832).
+    (The synchronous fit runs on a cluster of workgroups; test_cluster_mode_equals_one_workgroup pins that to one workgroup.)"""
     from frank_amd import FrankFitter
     from oracle import oracle as fo
     n = 60000
