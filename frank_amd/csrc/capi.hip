@@ -282,7 +282,9 @@ int fh_init(void) {
 const char *fh_last_warning(void) { return g_warn.c_str(); }
 
 const char *fh_last_error(void) { return g_err.c_str(); }
-const char *fh_version(void) { return "frank_amd 0.1 (gfx950)"; }
+// (the build stamp ties a profile under profiles/ to the binary it was taken from: tools/profile_r04.sh records it, bench.py
+//  prints the loaded library's beside the profile's)
+const char *fh_version(void) { return "frank_amd 0.4 (gfx950; built " __DATE__ " " __TIME__ ")"; }
 
 int fh_device_count(int *count) {
     int n = 0;

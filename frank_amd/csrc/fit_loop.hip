@@ -264,6 +264,11 @@ __device__ __forceinline__ int ld(const int *p) { return __hip_atomic_load(p, __
 __device__ __forceinline__ void st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int add(int *p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf; }  // HW_REG_XCC_ID
+// Acquire on the receiving side of a hand-over: this compute unit's L1 only (buffer_inv sc0, the "workgroup scope" invalidate of
+// the threadgroup-split mode).  The members of a cluster share ONE L2 -- checked at start-up -- and that is where the other
+// side's stores and the flag live; the agent-scope form (buffer_inv sc1) also walks the L2 for lines other XCDs might have
+// written, and with it a fit on five workgroups wrote 843 MB back to memory (127 MB on one workgroup): every tile once per pass.
+__device__ __forceinline__ void acquire_l1() { asm volatile("buffer_inv sc0" ::: "memory"); }
 constexpr long long kTicksPerUs = 100;  // wall_clock64: 100 MHz
 __device__ __forceinline__ int *ctl_of(const FitLoopParams &P) { return reinterpret_cast<int *>(P.WdT + 3 * (size_t)P.NP); }
 // block columns the first workgroup updates itself at every step; the tiles further right belong to the helper waves until
@@ -283,7 +288,7 @@ __device__ __forceinline__ bool wait_prog(const int *ctl, int need, int &seen) {
         if (v < 0) return false;
         if (v >= need) {
             seen = v;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (L1 invalidation: the tiles are rewritten every pass)
+            clu::acquire_l1();  // (L1 invalidation: the tiles are rewritten every pass)
             return true;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -756,7 +761,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                                     break;
                                 }
                             }
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                            clu::acquire_l1();
                             hready = true;
                         }
                         if (e == cntH) return ld_pk(HD_u, (unsigned)((k + 1 + band) * 2048), lane);  // (its first tile: the diagonal one)
@@ -922,7 +927,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                     break;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            clu::acquire_l1();
         }
         __syncthreads();
         if (*S.flag) return false;
@@ -1179,7 +1184,7 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
                                 break;
                             }
                         }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        clu::acquire_l1();
                         hready = true;
                     }
                     if (e == cntH) return ld_pk(HD_u, (unsigned)((k + 1 + band) * 2048), lane);  // (its first tile: the diagonal one)
@@ -1354,7 +1359,7 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
                     break;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            clu::acquire_l1();
         }
         __syncthreads();
         if (*S.flag) return false;
