@@ -885,24 +885,35 @@ def main():
         peak_cu = FP64_MFMA_PEAK_TFLOPS / N_CU
         # HBM bytes per launch: STATIC values, read from the PMC summaries committed under profiles/ (rocprofv3 cannot run inside
         # bench.py); they describe the build the profile was taken from, named in the *_source fields
-        traffic, traffic_src, bin_traffic, bin_traffic_src = None, None, None, None
+        traffic, traffic_one, traffic_src, bin_traffic, bin_traffic_src, profile_lib = None, None, None, None, None, None
+
+        def pmc(name):
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                return json.load(fh)
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_fit_loop.json")) as fh:
-                pm2 = json.load(fh)
-                key = [k for k in pm2 if k.startswith("fit_loop_kernel")]  # (the name carries its template argument)
-                traffic = pm2[key[0]]["hbm_bytes_per_launch"] if (Nc == 300 and key) else None
-            traffic_src = ("static: profiles/r03_pmc_fit_loop.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on one fit, FETCH "
-                           "doubled per the gfx950 note); not measured in this run")
+            pm2, pm1 = pmc("r04_pmc_fit_loop_cluster.json"), pmc("r04_pmc_fit_loop.json")
+            profile_lib = pm2.get("_library")
+            if Nc == 300:
+                # (the profiled fit is the 1e6-visibility fixture: 825 passes; scaled to the passes of this fit)
+                traffic = int([e for k, e in pm2.items() if k.startswith("fit_loop_kernel")][0]["hbm_bytes_per_launch"] * (nit + 2) / 825.0)
+                traffic_one = int([e for k, e in pm1.items() if k.startswith("fit_loop_kernel")][0]["hbm_bytes_per_launch"] * (nit + 2) / 825.0)
+            traffic_src = ("static: profiles/r04_pmc_fit_loop_cluster.json / r04_pmc_fit_loop.json (rocprofv3 --pmc FETCH_SIZE / "
+                           "WRITE_SIZE on one fit of 825 passes, scaled to this fit's passes; FETCH doubled per the gfx950 note), "
+                           "taken from the library build '%s'; not measured in this run" % profile_lib)
         except Exception:
             traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_binning.json")) as fh:
-                pm = json.load(fh)
+            pm, pmf = pmc("r04_pmc_binning.json"), pmc("r04_pmc_binning_first_sight.json")
             if Nc == 300 and a.nvis == N_VIS:
-                bin_traffic = {k: int(e["hbm_bytes_per_launch"]) for k, e in pm.items() if "hbm_bytes_per_launch" in e}
+                # a pass over rows the context binned last keeps the (u, v) histogram and its scan: those two kernels do not run
+                first = {k: int(e["hbm_bytes_per_launch"]) for k, e in pmf.items() if isinstance(e, dict) and "hbm_bytes_per_launch" in e}
+                bin_traffic = {k: int(e["hbm_bytes_per_launch"]) for k, e in pm.items()
+                               if isinstance(e, dict) and "hbm_bytes_per_launch" in e and not k.startswith(("uv_hist", "bucket_scan"))}
                 bin_traffic["total"] = int(sum(bin_traffic.values()))
-            bin_traffic_src = ("static: profiles/r03_pmc_binning.json (one pass of 1e7 visibilities at N = 300, per kernel; "
-                               "2 x FETCH_SIZE + WRITE_SIZE); not measured in this run")
+                bin_traffic["total_at_first_sight_of_a_table"] = int(sum(first.values()))
+            bin_traffic_src = ("static: profiles/r04_pmc_binning.json, r04_pmc_binning_first_sight.json (one pass of 1e7 visibilities "
+                               "at N = 300, per kernel; 2 x FETCH_SIZE + WRITE_SIZE), library build '%s'; not measured in this run"
+                               % pm.get("_library"))
         except Exception:
             bin_traffic = None
         # the reference's own run of this very input (tests/golden/fit_N300_1e7.npz: 667 iterations) -- rank 0, default sizes
@@ -947,7 +958,8 @@ def main():
                                       "in cluster mode (%d/256); the mode buys latency (a pass is a chain of 19 dependent tile "
                                       "factorisations) with compute units that mostly wait -- the fraction per CU is lower "
                                       "than on one CU by design" % (loop_wgs, loop_wgs),
-                         "why_this_kernel": "most of the GPU time of the timed region (profiles/)",
+                         "why_this_kernel": "most of the GPU time of the timed region (profiles/r04_kernel_stats.csv)",
+                         "traffic_one_cu": traffic_one, "profile_library": profile_lib,
                          "one_cu": {"kernel": K2_KERNEL_NAME + " on one compute unit (FRANK_AMD_K2_CLUSTER=1: the form of the steady "
                                               "state and of the batched sweeps)", "achieved": achieved_one, "peak": peak_cu,
                                     "frac": achieved_one / peak_cu, "kernel_ms": loop_ms_one}},
