@@ -531,7 +531,7 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
         HIP_TRY(c->Cq.alloc(PP));
         HIP_TRY(c->Wq.alloc(PP));
         HIP_TRY(c->WdT.alloc(fh_k2_exchange_doubles(c->NP)));
-        HIP_TRY(c->cs.alloc((size_t)(c->NP / 16) * (c->NP / 16) * 16));
+        HIP_TRY(c->cs.alloc(fh_k2_cs_doubles(c->NP)));
         HIP_TRY(hipMemsetAsync(c->WdT.p, 0, sizeof(double) * fh_k2_exchange_doubles(c->NP), c->stream));  // (control words of the cluster mode: zero between fits)
         HIP_TRY(hipMemsetAsync(c->Cq.p, 0, sizeof(double) * PP, c->stream));
         HIP_TRY(hipMemsetAsync(c->Wq.p, 0, sizeof(double) * PP, c->stream));
@@ -2052,7 +2052,7 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     if (!M && !c->have_device_Mj) return fail(FH_ERR_INVALID, "no device-resident M, j (run fh_stats_finalize)");
     if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 1023", c->N);
     HIP_TRY(hipSetDevice(c->device));
-    const int N = c->N, NP = c->NP, nbk = NP / 16;
+    const int N = c->N, NP = c->NP;
     const size_t NN = (size_t)N * N, PP = (size_t)NP * NP;
     if (M) {
         HIP_TRY(hipMemcpyAsync(c->M.p, M, sizeof(double) * NN, hipMemcpyHostToDevice, c->stream));
@@ -2071,7 +2071,7 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     if (counter.alloc(1) != hipSuccess) return fail(FH_ERR_NOMEM, "device allocation failed");
     HIP_TRY(hipMemsetAsync(counter.p, 0, sizeof(int), c->stream));
     if (Cb.alloc(G * PP) != hipSuccess || Wb.alloc(G * PP) != hipSuccess ||
-        WdTb.alloc(G * NP * 16) != hipSuccess || csb.alloc(G * nbk * nbk * 16) != hipSuccess ||
+        WdTb.alloc(G * NP * 16) != hipSuccess || csb.alloc(G * fh_k2_cs_doubles(NP)) != hipSuccess ||
         mub.alloc(B * N) != hipSuccess || pb.alloc(B * N) != hipSuccess || lub.alloc(B * 5 * N) != hipSuccess ||
         alb.alloc(B) != hipSuccess || p0b.alloc(B) != hipSuccess || resb.alloc(2 * B) != hipSuccess)
         return fail(FH_ERR_NOMEM, "fh_fit_normal_batched: device allocation for %d fits failed", batch);
@@ -2222,8 +2222,7 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
     if (!c->slot_pool.p) {
         // all slots at once, carved from ONE allocation: a hipMalloc per buffer costs ~0.7 ms of host time, and paying
         // 11 of them whenever a fresh slot is first used put an 8 ms hole after every binning pass of a pipeline
-        const size_t nbk = (size_t)(c->NP / 16);
-        const size_t per_slot = 3 * PP + (size_t)c->NP * 16 + nbk * nbk * 16 + 3 * (size_t)N + 5 * (size_t)N + 2;
+        const size_t per_slot = 3 * PP + (size_t)c->NP * 16 + fh_k2_cs_doubles(c->NP) + 3 * (size_t)N + 5 * (size_t)N + 2;
         HIP_TRY(c->slot_pool.alloc(per_slot * kFitSlots));
         HIP_TRY(c->slot_results.alloc(2 * kFitSlots));
         HIP_TRY(hipMemsetAsync(c->slot_pool.p, 0, sizeof(double) * per_slot * kFitSlots, c->stream));
@@ -2235,7 +2234,7 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
             t.Cq.adopt(b, PP); b += PP;
             t.Wq.adopt(b, PP); b += PP;
             t.WdT.adopt(b, (size_t)c->NP * 16); b += (size_t)c->NP * 16;
-            t.cs.adopt(b, nbk * nbk * 16); b += nbk * nbk * 16;
+            t.cs.adopt(b, fh_k2_cs_doubles(c->NP)); b += fh_k2_cs_doubles(c->NP);
             t.bq.adopt(b, N); b += N;
             t.mu_out.adopt(b, N); b += N;
             t.p_out.adopt(b, N); b += N;

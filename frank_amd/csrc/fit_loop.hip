@@ -95,7 +95,7 @@ constexpr int kMaxTiles = 210;  // tiles of the largest trailing triangle: NP / 
 // finish reading panel k, and only then panel k + 1 overwrites it.  Two barriers per step instead of one; N <= 320 is untouched
 // (its own instantiation).  Before this, 320 < N <= 512 ran the library loop: ~8 x the time per pass at N = 321.
 constexpr int kMaxTilesWide = 780;  // 39 block rows
-constexpr int kWideMinNP = 337, kWideMaxNP = 640;
+constexpr int kWideMinNP = 337;  // (up to NP = 640)
 // XWIDE (640 < NP <= 1024, N <= 1023; WIDE = 2): the one panel alone takes 139 KB at NP = 1024.  The vectors of the outer loop (p,
 // m, Tr2, the right-hand side, ..: 8 NP doubles) join the band factors and scan tables in global memory (L2), the tile table is
 // computed instead of stored, the wave scan takes sixteen rows per lane.  Before this, N >= 640 ran the library loop (rocBLAS +
@@ -264,11 +264,13 @@ __device__ __forceinline__ int ld(const int *p) { return __hip_atomic_load(p, __
 __device__ __forceinline__ void st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int add(int *p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf; }  // HW_REG_XCC_ID
-// Acquire on the receiving side of a hand-over: this compute unit's L1 only (buffer_inv sc0, the "workgroup scope" invalidate of
-// the threadgroup-split mode).  The members of a cluster share ONE L2 -- checked at start-up -- and that is where the other
-// side's stores and the flag live; the agent-scope form (buffer_inv sc1) also walks the L2 for lines other XCDs might have
-// written, and with it a fit on five workgroups wrote 843 MB back to memory (127 MB on one workgroup): every tile once per pass.
-__device__ __forceinline__ void acquire_l1() { asm volatile("buffer_inv sc0" ::: "memory"); }
+// Acquire on the receiving side of a hand-over: the agent-scope invalidate (buffer_inv sc1).  The members of a cluster share ONE
+// L2, so invalidating this compute unit's L1 would do -- but the "workgroup scope" form (buffer_inv sc0) is not that: outside
+// the threadgroup-split mode it leaves the L1 alone, and a sweep over the basis size (tools/size_sweep_cluster.py) found helpers
+// reading LAST pass's tiles from their L1 wherever a compute unit's share of the matrices is small enough to stay there
+// (N < 128 with five workgroups, N <= 144 with eight).  The price of sc1: the L2's dirty lines are written back on the way (a fit
+// on five workgroups writes 843 MB to memory against 127 MB on one); the time per pass is the same either way.
+__device__ __forceinline__ void acquire_l1() { asm volatile("buffer_inv sc1" ::: "memory"); }
 constexpr long long kTicksPerUs = 100;  // wall_clock64: 100 MHz
 __device__ __forceinline__ int *ctl_of(const FitLoopParams &P) { return reinterpret_cast<int *>(P.WdT + 3 * (size_t)P.NP); }
 // block columns the first workgroup updates itself at every step; the tiles further right belong to the helper waves until
@@ -1662,7 +1664,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         const int f = s_fit;
         __syncthreads();
         if (f >= P.batch) return;
-        const size_t PP = (size_t)P.NP * P.NP, nbk = (size_t)(P.NP / 16);
+        const size_t PP = (size_t)P.NP * P.NP;
         const size_t slot = blockIdx.x;  // work buffers belong to the workgroup, outputs to the fit
         P.alpha = P.batch_alpha[f];
         P.p0 = P.batch_p0[f];
@@ -1670,7 +1672,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         P.C += slot * PP;
         P.W += slot * PP;
         P.WdT += slot * (size_t)P.NP * 16;
-        P.cs += slot * nbk * nbk * 16;
+        P.cs += slot * fh_k2_cs_doubles(P.NP);
         P.mu_out += (size_t)f * P.N;
         P.p_out += (size_t)f * P.N;
         P.result += 2 * f;

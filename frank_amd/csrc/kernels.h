@@ -239,6 +239,14 @@ struct FitLoopParams {
 };
 #define FIT_MAX_BATCH 128
 #define FIT_CLUSTER_MAX 8
+// doubles of a fit's cs buffer: (NP / 16)^2 x 16 column sums of the tiles of W, and -- cluster mode -- room for NP / 16 packed
+// diagonal tiles that come back from the helpers of the trailing update (256 doubles each: more than the column sums below
+// sixteen block rows; the first version wrote them past the end of the buffer there -- a memory fault at N = 128 and 150 that
+// tools/size_sweep_cluster.py found), and for the vectors of the widest instantiation (14 NP + 3 072)
+constexpr size_t fh_k2_cs_doubles(int NP) {
+    const size_t nb = (size_t)NP / 16, a = nb * nb * 16, b = nb * 256, c = 14 * (size_t)NP + 3072;
+    return (a > b ? a : b) > c ? (a > b ? a : b) : c;
+}
 
 size_t fh_k2_loop_smem_bytes(int NP);
 int fh_k2_loop_max_np();  // largest padded size NP the persistent fit loop covers (640: N <= 639)

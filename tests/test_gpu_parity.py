@@ -1323,11 +1323,13 @@ def _fit_normal(ctx, N, M, j, alpha=1.05, ws=1e-4, max_iter=2000):
 
 @pytest.mark.parametrize("N,cluster,ran_on", [(130, "5", 5), (300, "5", 5), (300, "4", 4), (300, "3", 3), (300, "2", 2), (320, "5", 5),
                                                (335, "5", 5), (400, "3", 3), (639, "3", 3), (100, "5", 1), (700, "3", 3), (1000, "4", 4),
-                                               (1023, "2", 4)])
+                                               (1023, "2", 4), (112, "5", 5), (112, "8", 8), (128, "5", 5), (150, "5", 5), (144, "8", 8)])
 def test_cluster_mode_equals_one_workgroup(monkeypatch, N, cluster, ran_on):
     """The fit loop on a cluster of workgroups (fit_loop.hip, clu::: helpers of the inverse and of the trailing update on the
     same XCD, run-ahead chain) forms every tile with the arithmetic of the one-workgroup kernel: mu, p and the iteration count
-    are the same BITS, whatever the size of the cluster; small systems stay on one workgroup."""
+    are the same BITS, whatever the size of the cluster; small systems stay on one workgroup.  (N = 112 ... 150: the sizes at
+    which tools/size_sweep_cluster.py found helpers reading last pass's tiles from their L1 behind a workgroup-scope
+    invalidate, and the returned diagonal tiles overrunning the column-sum buffer below sixteen block rows.)"""
     FF, M, j = _cluster_problem(N, 60000 if N > 400 else 200000)
     ctx = FF._DHT.context()
     monkeypatch.setenv("FRANK_AMD_K2_CLUSTER", "1")
