@@ -12,8 +12,8 @@ from frank_amd import FixedGeometry, FrankFitter, _lib  # noqa: E402
 from frank_amd.mock import MOCK_GEOMETRY, mock_disc_visibilities  # noqa: E402
 
 a = [int(x) for x in sys.argv[1:4]] if len(sys.argv) > 3 else [5, 420, 7]
-sizes = sorted(set(list(range(a[0], a[1], a[2])) + [k + d for k in (16, 32, 64, 128, 192, 256, 304, 320, 336, 384, 448, 480, 512, 576, 640) for d in (-1, 0, 1)]))
-sizes = [n for n in sizes if 3 <= n <= 660]
+sizes = sorted(set(list(range(a[0], a[1], a[2])) + [k + d for k in (16, 32, 64, 128, 192, 256, 304, 320, 336, 384, 448, 480, 512, 576, 640, 768, 896, 1008, 1022) for d in (-1, 0, 1) if a[0] <= k + d <= a[1]]))
+sizes = [n for n in sizes if 3 <= n <= 1023]
 u, v, V, w = mock_disc_visibilities(60000, seed=31, noise_seed=32)
 kw = dict(alpha=1.3, weights_smooth=1e-2, verbose=False, check_qbounds=False)
 bad = []
