@@ -4,6 +4,7 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -227,6 +228,7 @@ struct fh_ctx {
     int fit_batch = kFitBatchMax;
     int burst_next = 1;      // fits that trigger the next launch: 1, 2, 4, .. up to fit_batch while a pipeline fills up
     int next_xcd = 0;        // XCD of the first fit of the next cluster launch
+    bool force_cluster_launch = false;  // the launch being flushed runs on clusters whatever is outstanding (fh_fit_normal_batched)
     hipEvent_t stream_last_done[kLaunchStreamsMax] = {};  // completion event of the last launch each launch stream was given
     size_t slot_stride = 0;
     int slots_busy = 0;
@@ -2075,14 +2077,54 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
         mub.alloc(B * N) != hipSuccess || pb.alloc(B * N) != hipSuccess || lub.alloc(B * 5 * N) != hipSuccess ||
         alb.alloc(B) != hipSuccess || p0b.alloc(B) != hipSuccess || resb.alloc(2 * B) != hipSuccess)
         return fail(FH_ERR_NOMEM, "fh_fit_normal_batched: device allocation for %d fits failed", batch);
-    std::vector<double> lu_all(B * 5 * N), lu;
-    for (int b = 0; b < batch; ++b) {
-        smoothing_band_lu(*c->dht, wsmooth[b], lu);
-        memcpy(lu_all.data() + (size_t)b * 5 * N, lu.data(), sizeof(double) * 5 * N);
+    // The workgroups pull the fits in launch order, and the launch ends with its slowest fit: the points most likely to run
+    // long go first.  The iteration count grows as alpha approaches 1 (filter.py:172: the update of p is damped by alpha - 1/2)
+    // and, at equal alpha, with a weaker smoothing prior; on the 32 x 16 grid of BASELINE configs[4] the seven points that reach
+    // max_iter all have alpha = 1.01 -- in grid order the last of them started 100 ms into the launch.  order[k] = the caller's
+    // index of the fit launched k-th; the outputs are put back in the caller's order.
+    std::vector<int> order(B);
+    for (int b = 0; b < batch; ++b) order[b] = b;
+    if (!getenv("FRANK_AMD_SWEEP_GRID_ORDER"))
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+            return alpha[x] != alpha[y] ? alpha[x] < alpha[y] : wsmooth[x] < wsmooth[y];
+        });
+    // ... and the first K of them -- the ones that will still be iterating when every other fit of the sweep has ended -- do not
+    // join the batch at all: they are launched on CLUSTERS of workgroups (fit_loop.hip: 98 instead of 136 us per pass once the
+    // device has emptied) through the fit slots, beside the batched launch of the rest on the compute units they leave free.
+    int K = 0;
+    {
+        const int g = fit_cluster_size(c);
+        if (g > 1 && batch >= 64 && c->slots_busy == 0 && c->pending_batch < 0 && !getenv("FRANK_AMD_SWEEP_NO_CLUSTERS")) {
+            K = batch / 8 < 16 ? batch / 8 : 16;
+            if (K * g > c->num_cu / 2) K = c->num_cu / 2 / g;
+        }
     }
-    HIP_TRY(hipMemcpyAsync(lub.p, lu_all.data(), sizeof(double) * lu_all.size(), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(alb.p, alpha, sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(p0b.p, p0, sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
+    std::vector<int> tickets(K, -1);
+    if (K > 0) {
+        const bool had = c->have_device_Mj;
+        c->have_device_Mj = true;  // (M, j are on the device: uploaded above or by the caller's finalisation)
+        int rcs = FH_OK;
+        for (int k = 0; k < K && rcs == FH_OK; ++k)
+            rcs = fh_fit_submit(c, alpha[order[k]], p0[order[k]], wsmooth[order[k]], tol, max_iter, &tickets[k]);
+        c->force_cluster_launch = true;
+        if (rcs == FH_OK) rcs = fh_fit_flush(c);
+        c->force_cluster_launch = false;
+        c->have_device_Mj = had;
+        if (rcs != FH_OK) return rcs;
+    }
+    const size_t BR = B - (size_t)K;  // fits of the batched launch: order[K ..]
+    std::vector<double> lu_all(BR * 5 * N + 1), lu, al_o(BR + 1), p0_o(BR + 1);
+    for (int k = K; k < batch; ++k) {
+        smoothing_band_lu(*c->dht, wsmooth[order[k]], lu);
+        memcpy(lu_all.data() + (size_t)(k - K) * 5 * N, lu.data(), sizeof(double) * 5 * N);
+        al_o[k - K] = alpha[order[k]];
+        p0_o[k - K] = p0[order[k]];
+    }
+    if (BR > 0) {
+        HIP_TRY(hipMemcpyAsync(lub.p, lu_all.data(), sizeof(double) * BR * 5 * N, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(alb.p, al_o.data(), sizeof(double) * BR, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(p0b.p, p0_o.data(), sizeof(double) * BR, hipMemcpyHostToDevice, c->stream));
+    }
     FitLoopParams P = make_loop_params(c, FIT_MODE_FULL, 0.0, 0.0, tol, max_iter);
     P.band_lu = lub.p;
     P.C = Cb.p;
@@ -2092,21 +2134,39 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     P.mu_out = mub.p;
     P.p_out = pb.p;
     P.result = resb.p;
-    P.batch = batch;
+    P.batch = (int)BR;
     P.batch_alpha = alb.p;
     P.batch_p0 = p0b.p;
     P.batch_counter = counter.p;
-    HIP_TRY(fh_k2_launch_loop_batched(P, (int)G, c->stream));
+    {
+        // (workgroups of the batched launch: one per fit, at most the compute units the clusters leave free)
+        int free_cus = c->num_cu - K * fit_cluster_size(c);
+        if (free_cus < 1) free_cus = 1;
+        const int grid = (int)(BR < (size_t)free_cus ? BR : (size_t)free_cus);
+        if (BR > 0) HIP_TRY(fh_k2_launch_loop_batched(P, grid < (int)G ? grid : (int)G, c->stream));
+    }
     std::vector<int> res(2 * B);
-    HIP_TRY(hipMemcpyAsync(res.data(), resb.p, sizeof(int) * 2 * B, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(mu, mub.p, sizeof(double) * B * N, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(p, pb.p, sizeof(double) * B * N, hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> mu_o(B * N), p_o(B * N);
+    if (BR > 0) {
+        HIP_TRY(hipMemcpyAsync(res.data(), resb.p, sizeof(int) * 2 * BR, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(mu_o.data(), mub.p, sizeof(double) * BR * N, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(p_o.data(), pb.p, sizeof(double) * BR * N, hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int b = 0; b < batch; ++b) {
-        niter[b] = res[2 * b];
+    for (int k = K; k < batch; ++k) {
+        const int b = order[k], kb = k - K;
+        memcpy(mu + (size_t)b * N, mu_o.data() + (size_t)kb * N, sizeof(double) * N);
+        memcpy(p + (size_t)b * N, p_o.data() + (size_t)kb * N, sizeof(double) * N);
+        niter[b] = res[2 * kb];
         if (status)
-            status[b] = res[2 * b + 1] == FIT_STATUS_BAD_P ? FH_ERR_BAD_P
-                        : res[2 * b + 1] == FIT_STATUS_NOT_SPD ? FH_ERR_NOT_SPD : FH_OK;
+            status[b] = res[2 * kb + 1] == FIT_STATUS_BAD_P ? FH_ERR_BAD_P
+                        : res[2 * kb + 1] == FIT_STATUS_NOT_SPD ? FH_ERR_NOT_SPD : FH_OK;
+    }
+    for (int k = 0; k < K; ++k) {  // the fits that ran on clusters
+        const int b = order[k];
+        const int rcc = fh_fit_collect(c, tickets[k], mu + (size_t)b * N, p + (size_t)b * N, &niter[b]);
+        if (rcc != FH_OK && rcc != FH_ERR_BAD_P && rcc != FH_ERR_NOT_SPD) return rcc;
+        if (status) status[b] = rcc;
     }
     return FH_OK;
 }
@@ -2166,7 +2226,7 @@ static int flush_pending_batch(fh_ctx *c) {
     {
         static const int most = env_int("FRANK_AMD_K2_CLUSTER_FITS", 8);
         const int g = fit_cluster_size(c);
-        b.cluster = (g > 1 && c->slots_busy <= most) ? g : 1;  // (slots_busy counts the fits of this launch too)
+        b.cluster = (g > 1 && (c->slots_busy <= most || c->force_cluster_launch)) ? g : 1;  // (slots_busy counts the fits of this launch too)
     }
     HIP_TRY(hipEventRecord(b.ready, c->stream));  // the operands of its fits were prepared on the context's stream
     HIP_TRY(hipStreamWaitEvent(b.stream, b.ready, 0));
