@@ -393,8 +393,8 @@ def extras(f, L, a):
             "upload_bytes": nbytes, "upload_pageable_s": t_page, "upload_pageable_GBps": nbytes / t_page / 1e9,
             "upload_pinned_s": pinned if isinstance(pinned, float) else None,
             "upload_pinned_GBps": (nbytes / pinned / 1e9) if isinstance(pinned, float) else pinned,
-            "note": "the headline `value` starts with the table resident in HBM; this is the same fit paying PCIe (and the "
-                    "host's split of the complex visibilities into two columns)"}
+            "note": "the headline `value` starts with the table resident in HBM; this is the same fit paying PCIe (the complex "
+                    "visibilities go up as NumPy holds them and are split into two columns on the device)"}
         del u, v, V, w, Vre, Vim
     except Exception as e:  # noqa: BLE001
         ex["from_host_arrays"] = {"error": repr(e)}

@@ -55,6 +55,7 @@ SIGNATURES = {
     "fh_predict_visibilities": (ctypes.c_int, [_vp, _dp, _i64, _dp, ctypes.c_double, _dp]),
     "fh_vis_upload": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _i64, _i64, ctypes.POINTER(_vp)]),
     "fh_vis_upload_f32": (ctypes.c_int, [ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _i64, _i64, ctypes.POINTER(_vp)]),
+    "fh_vis_upload_c128": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, _dp, _i64, _i64, ctypes.POINTER(_vp)]),
     "fh_vis_destroy": (None, [_vp]),
     "fh_vis_size": (_i64, [_vp]),
     "fh_vis_set_multiplicity": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
@@ -85,6 +86,8 @@ SIGNATURES = {
                                          _dp, _dp]),
     "fh_map_visibilities": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), ctypes.c_int, ctypes.c_int, _dp, _dp,
                                            _dp, _dp, _dp, _i64, _i64, _dp, _dp, _dp, _dp, _dp]),
+    "fh_map_visibilities_c128": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), ctypes.c_int, ctypes.c_int, _dp, _dp,
+                                                _dp, _dp, _i64, _i64, _dp, _dp, _dp, _dp, _dp]),
     "fh_gaussian_model": (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, ctypes.POINTER(ctypes.c_int)]),
     "fh_cho_solve": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int]),
     "fh_svd_solve": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int]),

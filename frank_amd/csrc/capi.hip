@@ -694,6 +694,39 @@ int fh_vis_upload(int device, const double *u, const double *v, const double *Vr
     *out = t;
     return FH_OK;
 }
+// The same table from a complex128 array as NumPy holds it (re, im interleaved): one contiguous copy of 16 n bytes and a split on
+// the device instead of two strided host copies into separate columns (30 ms of a 45 ms mapping call at 1e7 visibilities).
+int fh_vis_upload_c128(int device, const double *u, const double *v, const double *Vc, const double *w, int64_t n_w, int64_t n,
+                       fh_vis **out) {
+    if (!out || n < 0 || (n > 0 && (!u || !v || !Vc || !w))) return fail(FH_ERR_INVALID, "fh_vis_upload_c128: bad argument");
+    if (n_w != 1 && n_w != n) return fail(FH_ERR_INVALID, "fh_vis_upload_c128: weights must have 1 or n entries");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(FH_ERR_HIP, "no HIP device available: frank_amd has no CPU fallback for device work");
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<fh_vis> t(new fh_vis());
+    t->device = device;
+    t->n = n;
+    t->w_scalar = (n_w == 1 && n != 1) ? 1 : 0;
+    t->has_im = 1;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    DevBuf<double> tmp;
+    if (t->u.alloc(nn) != hipSuccess || t->v.alloc(nn) != hipSuccess || t->Vre.alloc(nn) != hipSuccess || t->Vim.alloc(nn) != hipSuccess ||
+        t->w.alloc(t->w_scalar ? 1 : nn) != hipSuccess || tmp.alloc(2 * nn) != hipSuccess)
+        return fail(FH_ERR_NOMEM, "fh_vis_upload_c128: hipMalloc failed");
+    if (n > 0) {
+        const size_t b = sizeof(double) * (size_t)n;
+        HIP_TRY(hipMemcpy(tmp.p, Vc, 2 * b, hipMemcpyHostToDevice));
+        HIP_TRY(fh_launch_split_complex(tmp.p, n, t->Vre.p, t->Vim.p, nullptr));
+        HIP_TRY(hipMemcpy(t->u.p, u, b, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t->v.p, v, b, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t->w.p, w, t->w_scalar ? sizeof(double) : b, hipMemcpyHostToDevice));
+        HIP_TRY(hipDeviceSynchronize());  // (the split runs on the null stream; tmp goes away with this scope)
+    }
+    *out = t.release();
+    return FH_OK;
+}
+
 int fh_vis_upload_f32(int device, const float *u, const float *v, const float *Vre, const float *Vim, const float *w,
                       int64_t n_w, int64_t n, fh_vis **out) {
     if (!out || n < 0 || (n > 0 && (!u || !v || !Vre || !w))) return fail(FH_ERR_INVALID, "fh_vis_upload_f32: bad argument");
@@ -1536,7 +1569,8 @@ int fh_map_visibilities(fh_ctx *c, const fh_geometry *g, int vis_model, int chec
                         double *M, double *j, double *H0, double *qmin, double *qmax) {
     if (!c) return fail(FH_ERR_INVALID, "ctx is NULL");
     fh_vis *vis = nullptr;
-    int rc = fh_vis_upload(c->device, u, v, Vre, Vim, w, n_w, n, &vis);
+    // Vre == NULL: Vim holds the visibilities as n (re, im) pairs -- a NumPy complex128 array as it is (fh_map_visibilities_c128)
+    int rc = Vre ? fh_vis_upload(c->device, u, v, Vre, Vim, w, n_w, n, &vis) : fh_vis_upload_c128(c->device, u, v, Vim, w, n_w, n, &vis);
     if (rc) return rc;
     rc = fh_bin_reset(c);
     c->check_q_before_bin = check_qbounds != 0;
@@ -1553,6 +1587,13 @@ int fh_map_visibilities(fh_ctx *c, const fh_geometry *g, int vis_model, int chec
     }
     fh_vis_destroy(vis);
     return rc;
+}
+
+int fh_map_visibilities_c128(fh_ctx *c, const fh_geometry *g, int vis_model, int check_qbounds, const double *u, const double *v,
+                             const double *Vc, const double *w, int64_t n_w, int64_t n, double *M, double *j, double *H0,
+                             double *qmin, double *qmax) {
+    if (!Vc) return fail(FH_ERR_INVALID, "fh_map_visibilities_c128: V is NULL");
+    return fh_map_visibilities(c, g, vis_model, check_qbounds, u, v, nullptr, Vc, w, n_w, n, M, j, H0, qmin, qmax);
 }
 
 // ---- K2 -----------------------------------------------------------------------------------------------------------

@@ -64,8 +64,21 @@ __global__ void evidence_diag_kernel(const double *A, int N, int batch, double *
     }
 }
 
+// complex visibilities as NumPy holds them (re, im interleaved) -> the two columns of the table
+__global__ void split_complex_kernel(const double *vc, int64_t n, double *re, double *im) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double2 z = reinterpret_cast<const double2 *>(vc)[i];
+        re[i] = z.x;
+        im[i] = z.y;
+    }
+}
+
 }  // namespace
 
+hipError_t fh_launch_split_complex(const double *vc, int64_t n, double *re, double *im, hipStream_t s) {
+    hipLaunchKernelGGL(split_complex_kernel, dim3(2048), dim3(256), 0, s, vc, n, re, im);
+    return hipGetLastError();
+}
 hipError_t fh_evidence_launch_build_c(const double *Araw, const double *p, int N, int batch, double *C, hipStream_t s) {
     hipLaunchKernelGGL(evidence_build_c_kernel, dim3(1024), dim3(256), 0, s, Araw, p, N, batch, C);
     return hipGetLastError();

@@ -262,6 +262,7 @@ hipError_t fh_evidence_launch_logdet(const double *L, int N, int batch, double *
 hipError_t fh_evidence_launch_hessian(const double *Dqq, const double *mq, const double *p, const double *p0, const double *ws,
                                       const double *Tband, int N, int batch, double *H, hipStream_t s);
 hipError_t fh_evidence_launch_diag(const double *A, int N, int batch, double *out, hipStream_t s);
+hipError_t fh_launch_split_complex(const double *vc, int64_t n, double *re, double *im, hipStream_t s);  // (re, im) pairs -> columns
 
 // ---- LogNormal (lognormal.hip): Newton MAP of the log-brightness + the power-spectrum loop, one workgroup per fit
 enum { LN_MODE_MAP = 0, LN_MODE_FIT = 1, LN_MODE_UPDATE = 2 };

@@ -82,11 +82,14 @@ class VisibilityMapping:
         model = _lib.VIS_MODELS[self._vis_model]
         conv = _lib.f4 if f32 else _lib.f8
         u, v = conv(u), conv(v)
-        Vre = conv(V.real)
-        Vim = conv(V.imag) if np.iscomplexobj(V) else None
+        # a complex128 array goes to the device as it is (re, im interleaved) and is split there: the two strided host copies
+        # into separate columns were 30 ms of a 45 ms call at 1e7 visibilities
+        as_pairs = (not f32) and V.dtype == np.complex128 and V.ndim == 1 and V.flags.c_contiguous
+        Vre = None if as_pairs else conv(V.real)
+        Vim = None if as_pairs else (conv(V.imag) if np.iscomplexobj(V) else None)
         w = conv(np.atleast_1d(weights))
         n = u.size
-        if v.size != n or Vre.size != n or w.size not in (1, n):
+        if v.size != n or V.size != n or w.size not in (1, n):
             raise ValueError("u, v, V (and weights) must have matching lengths")
         if f32:
             # a table handed over in single precision (float32 u, v, weights, complex64 / float32 V) is stored and
@@ -102,6 +105,13 @@ class VisibilityMapping:
                                                       ctypes.byref(H0), ctypes.byref(qmin), ctypes.byref(qmax)))
             finally:
                 _lib.lib.fh_vis_destroy(vis)
+        elif as_pairs:
+            rc = _lib.lib.fh_map_visibilities_c128(
+                ctx, ctypes.byref(g), model, 1 if self.check_qbounds else 0, _lib.ptr(u), _lib.ptr(v),
+                V.view(np.float64).ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _lib.ptr(w), w.size, n, _lib.ptr(M), _lib.ptr(j),
+                ctypes.byref(H0), ctypes.byref(qmin), ctypes.byref(qmax))
+            if rc != _lib.FH_ERR_QRANGE:
+                _lib.check(rc)
         else:
             rc = _lib.lib.fh_map_visibilities(
                 ctx, ctypes.byref(g), model, 1 if self.check_qbounds else 0, _lib.ptr(u), _lib.ptr(v),

@@ -101,6 +101,11 @@ int fh_predict_visibilities(fh_ctx *ctx, const double *q, int64_t n, const doubl
  * n_w == 1 broadcasts a scalar weight (statistical_models.py:173).                                         */
 int fh_vis_upload(int device, const double *u, const double *v, const double *Vre, const double *Vim,
                   const double *w, int64_t n_w, int64_t n, fh_vis **out);
+/* fh_vis_upload_c128: the same table from a complex128 array of visibilities as NumPy holds it -- Vc = n (re, im) pairs --: one
+ * contiguous copy and a split on the device instead of two strided host copies (the reference's map_visibilities takes V complex,
+ * statistical_models.py:109).                                                                                            */
+int fh_vis_upload_c128(int device, const double *u, const double *v, const double *Vc, const double *w, int64_t n_w, int64_t n,
+                       fh_vis **out);
 /* The same table stored as five fp32 columns (20 B / visibility; BASELINE configs with fp32 data).  The columns are
  * widened to fp64 as the pre-pass reads them and everything downstream is the fp64 path: the result equals that of
  * fh_vis_upload on the widened values bit for bit (the reference also computes in fp64 whatever dtype it is handed:
@@ -190,6 +195,10 @@ int fh_stats_finalize(fh_ctx *ctx, const fh_geometry *geom, int vis_model, int c
 int fh_map_visibilities(fh_ctx *ctx, const fh_geometry *geom, int vis_model, int check_qbounds, const double *u,
                         const double *v, const double *Vre, const double *Vim, const double *w, int64_t n_w,
                         int64_t n, double *M, double *j, double *H0, double *qmin, double *qmax);
+/* The same with the visibilities as ONE complex128 array (n (re, im) pairs, as NumPy holds `V`): fh_vis_upload_c128 underneath. */
+int fh_map_visibilities_c128(fh_ctx *ctx, const fh_geometry *geom, int vis_model, int check_qbounds, const double *u,
+                             const double *v, const double *Vc, const double *w, int64_t n_w, int64_t n, double *M, double *j,
+                             double *H0, double *qmin, double *qmax);
 
 /* ---- a11-a13: GaussianModel -------------------------------------------------------------------------------
  * statistical_models.py:650-781.  p may be NULL (no prior).  M, j, p: host; M = j = NULL: the statistics a preceding
