@@ -264,13 +264,34 @@ __device__ __forceinline__ int ld(const int *p) { return __hip_atomic_load(p, __
 __device__ __forceinline__ void st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int add(int *p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf; }  // HW_REG_XCC_ID
-// Acquire on the receiving side of a hand-over: the agent-scope invalidate (buffer_inv sc1).  The members of a cluster share ONE
-// L2, so invalidating this compute unit's L1 would do -- but the "workgroup scope" form (buffer_inv sc0) is not that: outside
-// the threadgroup-split mode it leaves the L1 alone, and a sweep over the basis size (tools/size_sweep_cluster.py) found helpers
-// reading LAST pass's tiles from their L1 wherever a compute unit's share of the matrices is small enough to stay there
-// (N < 128 with five workgroups, N <= 144 with eight).  The price of sc1: the L2's dirty lines are written back on the way (a fit
-// on five workgroups writes 843 MB to memory against 127 MB on one); the time per pass is the same either way.
-__device__ __forceinline__ void acquire_l1() { asm volatile("buffer_inv sc1" ::: "memory"); }
+// The receiving side of a hand-over reads what another compute unit wrote with DEVICE-SCOPE loads (sc1: served by the L2 the
+// members of a cluster share, never by this compute unit's L1) -- no invalidate.  What was tried before: the agent-scope
+// invalidate (buffer_inv sc1) also writes the L2's dirty lines back (843 MB to memory per fit against 127 MB on one workgroup)
+// and cost 4-15 us per pass, in two modes from run to run; the workgroup-scope one (buffer_inv sc0) leaves the L1 alone outside
+// the threadgroup-split mode -- helpers then read LAST pass's tiles wherever a compute unit's share of the matrices is small
+// enough to stay in its L1 (N < 128 with five workgroups, found by tools/size_sweep_cluster.py).
+__device__ __forceinline__ v4f64 ld_pk_dev(const gdouble *base, unsigned tile_byte_off, int lane) {
+    v2f64 lo, hi;
+    const unsigned a = tile_byte_off + (unsigned)lane * 16u;
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3 sc1\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(a), "s"(base)
+                 : "memory");
+    return v4f64{lo[0], lo[1], hi[0], hi[1]};
+}
+// two tiles with one wait
+__device__ __forceinline__ void ld_pk_dev2(const gdouble *ba, unsigned oa, const gdouble *bb, unsigned ob, int lane, v4f64 &ta, v4f64 &tb) {
+    v2f64 alo, ahi, blo, bhi;
+    const unsigned a = oa + (unsigned)lane * 16u, b = ob + (unsigned)lane * 16u;
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %6 sc1\n\tglobal_load_dwordx4 %1, %4, %6 offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %2, %5, %7 sc1\n\tglobal_load_dwordx4 %3, %5, %7 offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(alo), "=&v"(ahi), "=&v"(blo), "=&v"(bhi)
+                 : "v"(a), "v"(b), "s"(ba), "s"(bb)
+                 : "memory");
+    ta = v4f64{alo[0], alo[1], ahi[0], ahi[1]};
+    tb = v4f64{blo[0], blo[1], bhi[0], bhi[1]};
+}
+__device__ __forceinline__ double ld_dev(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 constexpr long long kTicksPerUs = 100;  // wall_clock64: 100 MHz
 __device__ __forceinline__ int *ctl_of(const FitLoopParams &P) { return reinterpret_cast<int *>(P.WdT + 3 * (size_t)P.NP); }
 // block columns the first workgroup updates itself at every step; the tiles further right belong to the helper waves until
@@ -290,7 +311,6 @@ __device__ __forceinline__ bool wait_prog(const int *ctl, int need, int &seen) {
         if (v < 0) return false;
         if (v >= need) {
             seen = v;
-            clu::acquire_l1();  // (L1 invalidation: the tiles are rewritten every pass)
             return true;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -313,8 +333,8 @@ __device__ __forceinline__ v4f64 chain_sum(const gdouble *Cu, const gdouble *Wu,
             //  a memory instruction may read it as its scalar address, and the hazard recogniser does not look into inline asm --
             //  a timing build that spilled scalar registers here faulted on exactly that)
             "s_nop 4\n\t"
-            "global_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %4, %6 offset:1024\n\t"
-            "global_load_dwordx4 %2, %5, %7\n\tglobal_load_dwordx4 %3, %5, %7 offset:1024"
+            "global_load_dwordx4 %0, %4, %6 sc1\n\tglobal_load_dwordx4 %1, %4, %6 offset:1024 sc1\n\t"  // (the first workgroup's tiles)
+            "global_load_dwordx4 %2, %5, %7\n\tglobal_load_dwordx4 %3, %5, %7 offset:1024"  // (this wave's own)
             : "=&v"(o.alo), "=&v"(o.ahi), "=&v"(o.blo), "=&v"(o.bhi)
             : "v"(pa), "v"(pb), "s"(Cu), "s"(Wu)
             : "memory");
@@ -410,10 +430,10 @@ __device__ __forceinline__ void trailing_wave(const FitLoopParams &P, int *ctl, 
                 if (c == 0 && tI[i] == tJ[i]) {  // diag(1 / p) (written by the first workgroup before its first word of the pass)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (rg + 4 * q == cl) tt[i][q] += xg[2 * P.NP + 16 * tI[i] + cl];
+                        if (rg + 4 * q == cl) tt[i][q] += ld_dev(xg + 2 * P.NP + 16 * tI[i] + cl);
                 }
-                const v4f64 fa = ld_pk(Cg, (unsigned)((c * nb + tJ[i]) * 2048), lane);
-                const v4f64 fb = ld_pk(Cg, (unsigned)((c * nb + tI[i]) * 2048), lane);
+                v4f64 fa, fb;
+                ld_pk_dev2(Cg, (unsigned)((c * nb + tJ[i]) * 2048), Cg, (unsigned)((c * nb + tI[i]) * 2048), lane, fa, fb);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) tt[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(-fa[q], fb[q], tt[i], 0, 0, 0);
                 if (tJ[i] == c + 2 + band) {  // the column enters the band at the next step: hand the tile back
@@ -463,9 +483,8 @@ __device__ __forceinline__ void inverse_wave(const FitLoopParams &P, int *ctl, i
         }
         for (int c = hw; c < nb; ++c) {  // (the first event that concerns this wave: its first column)
             if (!wait_prog(ctl, seq * clu::kSeq + c + 1, seen)) return;
-            const v4f64 xp = ld_pk(Cg, (unsigned)((c * nb + c) * 2048), lane);  // X_cc = W_cc
-            v4f64 la = xp;
-            if (c + 1 < nb) la = ld_pk(Cg, (unsigned)((c * nb + c + 1) * 2048), lane);  // mirror tile (c, c + 1): L_{c+1,c}
+            v4f64 xp, la;  // X_cc = W_cc; mirror tile (c, c + 1): L_{c+1,c}
+            ld_pk_dev2(Cg, (unsigned)((c * nb + c) * 2048), Cg, (unsigned)((c * nb + (c + 1 < nb ? c + 1 : c)) * 2048), lane, xp, la);
 #pragma unroll
             for (int i = 0; i < CMAX; ++i) {
                 const int J = hw + i * T;
@@ -763,11 +782,10 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                                     break;
                                 }
                             }
-                            clu::acquire_l1();
                             hready = true;
                         }
-                        if (e == cntH) return ld_pk(HD_u, (unsigned)((k + 1 + band) * 2048), lane);  // (its first tile: the diagonal one)
-                        return ld_pk(H_u, base_pk + (t.x & ~2047u), lane);  // tile (I, J) waits at the mirror position (J, I)
+                        if (e == cntH) return clu::ld_pk_dev(HD_u, (unsigned)((k + 1 + band) * 2048), lane);  // (its first tile: the diagonal one)
+                        return clu::ld_pk_dev(H_u, base_pk + (t.x & ~2047u), lane);  // tile (I, J) waits at the mirror position (J, I)
                     }
                 }
                 return ld_pk(src_u, base_pk + ((k == 0 ? t.x : t.w) & ~2047u), lane);
@@ -929,14 +947,13 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                     break;
                 }
             }
-            clu::acquire_l1();
         }
         __syncthreads();
         if (*S.flag) return false;
         const double *xg = P.WdT;
-        for (int i = tid; i < N; i += KT) {
-            S.tr2[i] = xg[i];
-            S.m[i] = xg[NP + i];
+        for (int i = tid; i < N; i += KT) {  // (device-scope loads: the helpers' stores, not this compute unit's L1)
+            S.tr2[i] = clu::ld_dev(xg + i);
+            S.m[i] = clu::ld_dev(xg + NP + i);
         }
         __syncthreads();
         TSTAMP(7);
@@ -1066,6 +1083,10 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
 #pragma unroll
         for (int s = 0; s < 4; ++s) dg = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s], pa1[4 * s], dg, 0, 0, 0);
     }
+    // The step loop, once per ROLE: the chain wave's and the workers' bodies share nothing but the barriers (the same number in
+    // both), and in one loop the registers a worker keeps from step to step (rA, rB) were live across the chain wave's tile
+    // routine too -- the kernel spilled 828 bytes per lane and every form ran at less than half speed.
+    if (wave == kChain) {
     for (int k = 0; k + 1 < nb; ++k) {
         const gdouble *src_u = k == 0 ? A_u : as_global(uniform_ptr(const_cast<const double *>(C)));
         const int m = nb - k - 1;
@@ -1081,7 +1102,7 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
             return a;
         };
         TRACE(0);
-        if (wave == kChain) {
+        {
 #ifdef FIT_LOOP_TIMING
             long long f_last = clock64();
 #endif
@@ -1137,7 +1158,31 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
             FSTAMP(8);
             arrive(k);
             TRACE(4);
-        } else if (CLM == 2 && (wave & 3) == (kChain & 3)) {
+        }
+        TSTAMP(3);
+    }
+    } else {
+    // Worker rows (band < nb): block row I >= 3 belongs to worker (I - 3) mod NWKc for as long as it has tiles in the band
+    // (steps 0 .. I - 3); its tiles of columns k + 1 and k + 2 STAY IN REGISTERS from step to step (rA, rB)
+    v4f64 rA[2], rB[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) rA[s2] = rB[s2] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k + 1 < nb; ++k) {
+        const gdouble *src_u = k == 0 ? A_u : as_global(uniform_ptr(const_cast<const double *>(C)));
+        const int m = nb - k - 1;
+        double *pan_cur = S.pan + (size_t)(k & 1) * NP * PS;
+        double *pan_nxt = S.pan + (size_t)((k + 1) & 1) * NP * PS;
+        const unsigned base_pk = (unsigned)((k + 1) * (nb + 1) * 2048);  // tile (k+1, k+1), packed
+        const char *pan_b = reinterpret_cast<const char *>(pan_cur);
+        auto upd = [&](unsigned pa, unsigned pb, v4f64 a) {
+            const double *pa1 = reinterpret_cast<const double *>(pan_b + pa + lane_p);
+            const double *pb1 = reinterpret_cast<const double *>(pan_b + pb + lane_p);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s], pb1[4 * s], a, 0, 0, 0);
+            return a;
+        };
+        TRACE(0);
+        if (CLM == 2 && (wave & 3) == (kChain & 3)) {
             // the waves on the chain's SIMD leave its double-precision units to the chain
             arrive(k);
             __syncthreads();
@@ -1186,11 +1231,10 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
                                 break;
                             }
                         }
-                        clu::acquire_l1();
                         hready = true;
                     }
-                    if (e == cntH) return ld_pk(HD_u, (unsigned)((k + 1 + band) * 2048), lane);  // (its first tile: the diagonal one)
-                    return ld_pk(H_u, base_pk + (t.x & ~2047u), lane);  // tile (I, J) waits at the mirror position (J, I)
+                    if (e == cntH) return clu::ld_pk_dev(HD_u, (unsigned)((k + 1 + band) * 2048), lane);  // (its first tile: the diagonal one)
+                    return clu::ld_pk_dev(H_u, base_pk + (t.x & ~2047u), lane);  // tile (I, J) waits at the mirror position (J, I)
                 }
                 return ld_pk(src_u, base_pk + ((k == 0 ? t.x : t.w) & ~2047u), lane);
             };
@@ -1236,57 +1280,84 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
             };
-            if (band < nb && !(P.cluster_break & 2)) {
-                // With helpers of the trailing update a wave has at most four band tiles and two column tiles per step: ALL their
-                // loads go out at the start of the step (the tiles that come back from the helpers behind one look at their
-                // column's counter), the column tiles take update k BEFORE the chain wave's flag, and what is left behind the
-                // flag is one product and the stores.  (The three-set rotation below, made for dozens of tiles per wave, left
-                // one L2 round trip behind the flag and one per tile in front of it: ~1.5 us per tile product in the early steps.)
-                constexpr int TB = 4, TC = 2;
-                uint4 tr[TB];
-                v4f64 tt[TB], ct[TC];
-                bool viaH = false;
+            if (band == 2 && band < nb) {
+                // ROWS IN REGISTERS.  A tile of the band lives three steps in the first workgroup: it enters from the helpers
+                // (column k + 3), is updated again as column k + 2, and is finalised as column k + 1.  Dealt tile by tile (below),
+                // a different wave took it at every step -- a store and a reload through the L2 between any two of them, and
+                // the early steps, with their ~40 tiles, were worker-bound at ~1.5 us per tile product.  Dealt ROW by row, the
+                // same wave has the tile all three times: it stays in registers (rA: column k + 1, rB: column k + 2), the band
+                // is never stored, and what a step loads is the one tile per row that enters.  Same operations per tile in the
+                // same order: same bits.
+                v4f64 rowC[2];
 #pragma unroll
-                for (int u = 0; u < TB; ++u) {
-                    const int e = widx + u * NWKc;
-                    if (e < cnt) {
-                        tr[u] = rec_at(e + 1);
-                        if (e + 1 >= cntH) viaH = true;
-                        else tt[u] = ldt(tr[u], e + 1);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int I = 3 + widx + s2 * NWKc;
+                    if (I >= nb || k > I - 3) continue;
+                    const int i = I - k - 1;  // row block of the panel
+                    v4f64 tC;
+                    if (k == 0) {  // first touch: the transposes from A (tile (J, I) of the symmetric A), 1 / p on the diagonal
+                        rA[s2] = ld_pk(src_u, base_pk + (unsigned)(i * 2048), lane);
+                        rB[s2] = ld_pk(src_u, base_pk + (unsigned)((nb + i) * 2048), lane);
+                        tC = ld_pk(src_u, base_pk + (unsigned)((2 * nb + i) * 2048), lane);
+                        if (I == 3) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (rg + 4 * r == cl) tC[r] += pinv[16 * 3 + cl];
+                        }
+                    } else {  // column k + 3 comes back from the helpers of the trailing update (updates 0 .. k - 1 applied)
+                        if (!hready) {
+                            const int J = k + 3, need = seq * (nb - J);
+                            const long long t0 = wall_clock64();
+                            while (__builtin_amdgcn_readfirstlane(clu::ld(ctl + clu::HCOL + J)) < need) {
+                                __builtin_amdgcn_s_sleep(1);
+                                if (wall_clock64() - t0 > 1000000 * clu::kTicksPerUs) {
+                                    if (lane == 0) S.flag[0] = 2;
+                                    break;
+                                }
+                            }
+                            hready = true;
+                        }
+                        tC = (I == k + 3) ? clu::ld_pk_dev(HD_u, (unsigned)((k + 3) * 2048), lane)
+                                          : clu::ld_pk_dev(H_u, (unsigned)(((k + 3) * nb + I) * 2048), lane);
                     }
-                }
-#pragma unroll
-                for (int u = 0; u < TC; ++u) {
-                    const int c = cfirst + u * NWKc;
-                    if (c < ncol) ct[u] = ld_pk(src_u, base_pk + (unsigned)(k == 0 ? (c + 2) * 2048 : (c + 2) * nb * 2048), lane);
-                }
-                if (viaH) {
-#pragma unroll
-                    for (int u = 0; u < TB; ++u) {
-                        const int e = widx + u * NWKc;
-                        if (e < cnt && e + 1 >= cntH) tt[u] = ldt(tr[u], e + 1);  // (the first of them waits for the column's counter)
+                    rA[s2] = upd(0u, (unsigned)(i * 16 * PS * 8), rA[s2]);
+                    rB[s2] = upd((unsigned)(16 * PS * 8), (unsigned)(i * 16 * PS * 8), rB[s2]);
+                    tC = upd((unsigned)(2 * 16 * PS * 8), (unsigned)(i * 16 * PS * 8), tC);
+                    if (k == I - 3) {  // the row's last step here: tiles (I, I - 1) and (I, I) go to the chain wave
+                        if (S.hand) {
+                            v2f64 *hp = reinterpret_cast<v2f64 *>(S.hand + ((k & 1) * 2) * 256) + lane;
+                            hp[0] = v2f64{rB[s2][0], rB[s2][1]};
+                            hp[64] = v2f64{rB[s2][2], rB[s2][3]};
+                            hp[128] = v2f64{tC[0], tC[1]};
+                            hp[192] = v2f64{tC[2], tC[3]};
+                        } else {
+                            st_pk(C_u, base_pk + (unsigned)((2 * nb + 1) * 2048), lane, rB[s2]);
+                            st_pk(C_u, base_pk + (unsigned)((2 * nb + 2) * 2048), lane, tC);
+                        }
                     }
-                }
-#pragma unroll
-                for (int u = 0; u < TB; ++u)
-                    if (widx + u * NWKc < cnt) fin(tr[u], tt[u]);
-#pragma unroll
-                for (int u = 0; u < TC; ++u) {
-                    const int c = cfirst + u * NWKc;
-                    if (c < ncol) ct[u] = upd(0u, (unsigned)((c + 2) * 16 * PS * 8), ct[u]);  // T^T = C_{I,k+1}^T - L_{k+1,k} L_Ik^T
+                    rowC[s2] = tC;  // (rA is finalised behind the flag; rB and this tile become next step's rA, rB there)
                 }
                 WSTAMP(11);
                 TRACE(1);
-                if (cfirst < ncol) {
+                bool any = false;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int I = 3 + widx + s2 * NWKc;
+                    any = any || (I < nb && k <= I - 3);
+                }
+                if (any) {
                     wait_flag();
                     TRACE(2);
                     Frag fx;  // L_{k+1,k+1}^-1: as A operand X, as B operand X^T
 #pragma unroll
                     for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[((k + 1) & 1) * 16 * PS + cl * PS + 4 * q + rg];
 #pragma unroll
-                    for (int u = 0; u < TC; ++u) {
-                        const int c = cfirst + u * NWKc;
-                        if (c < ncol) column_finish(c + 2, ct[u], fx);
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const int I = 3 + widx + s2 * NWKc;
+                        if (I >= nb || k > I - 3) continue;
+                        column_finish(I - k - 1, rA[s2], fx);
+                        rA[s2] = rB[s2];
+                        rB[s2] = rowC[s2];
                     }
                 }
             } else {
@@ -1345,6 +1416,7 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
         }
         TSTAMP(3);
     }
+    }
     if (wave == kChain && nb > 1) __syncthreads();  // (the barrier that ends the workers' last step)
     __syncthreads();
     if (*S.flag) return false;
@@ -1361,14 +1433,13 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
                     break;
                 }
             }
-            clu::acquire_l1();
         }
         __syncthreads();
         if (*S.flag) return false;
         const double *xg = P.WdT;
-        for (int i = tid; i < N; i += KT) {
-            S.tr2[i] = xg[i];
-            S.m[i] = xg[NP + i];
+        for (int i = tid; i < N; i += KT) {  // (device-scope loads: the helpers' stores, not this compute unit's L1)
+            S.tr2[i] = clu::ld_dev(xg + i);
+            S.m[i] = clu::ld_dev(xg + NP + i);
         }
         __syncthreads();
         TSTAMP(7);
