@@ -2260,12 +2260,13 @@ static int flush_pending_batch(fh_ctx *c) {
         c->stream_last_done[pick] = b.done;
     }
     // few fits outstanding: every fit of this launch on a cluster of workgroups (the latency of a pass is what a shallow
-    // pipeline waits for).  A fit on a cluster works on ~2 MB (A, the factor, its inverse, the trailing tiles in flight)
-    // against 1.1 MB on one compute unit, and an XCD's L2 holds 4 MB: one cluster per XCD runs a pass at N = 300 in 107 us
-    // (8 fits at once; one CU each: 138), two in 123, with twenty on the device a pass takes the 142 us it takes on one CU
-    // (tools/k2_concurrency.py).  So: clusters while at most FRANK_AMD_K2_CLUSTER_FITS (8) fits are outstanding.
+    // pipeline waits for).  Passes at N = 300 with n fits at once (tools/k2_concurrency.py): on clusters of five 95 us (8 fits), 96
+    // (16), 101 (20), 105 (32); on one CU each 138-146.  (The first version of the mode -- agent-scope invalidates that wrote the
+    // L2 back, band tiles stored and reloaded every step -- moved so many bytes that twenty clusters ran no faster than twenty
+    // single loops; with device-scope loads and the workers' rows in registers they do.)  So: clusters while at most
+    // FRANK_AMD_K2_CLUSTER_FITS (32: 160 of the 256 compute units) fits are outstanding.
     {
-        static const int most = env_int("FRANK_AMD_K2_CLUSTER_FITS", 8);
+        static const int most = env_int("FRANK_AMD_K2_CLUSTER_FITS", 32);
         const int g = fit_cluster_size(c);
         b.cluster = (g > 1 && (c->slots_busy <= most || c->force_cluster_launch)) ? g : 1;  // (slots_busy counts the fits of this launch too)
     }
