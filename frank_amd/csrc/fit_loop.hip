@@ -601,9 +601,9 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (rg + 4 * r == cl) t0[r] += pinv[cl];
-        const bool ok = chol_inv_tile_acc(t0, x0, lane, aug_tile == 0 ? aug_c : -1);
+        const bool ok = factor_invert_tile(t0, x0, S.dli, lane, aug_tile == 0 ? aug_c : -1);  // L_00^-1 -> dli[0]
         if (!ok && lane == 0) *S.flag = 1;
-        store_factored_tile(t0, x0, nullptr, ld, S.dli, nullptr, nullptr, CL ? nullptr : cs_ptr(0, 0), rows_valid(0), lane);  // L_00^-1 -> dli[0]
+        if (!CL) store_col_ssq(x0, cs_ptr(0, 0), rows_valid(0), lane);
         st_pk(as_global(W), 0u, lane, x0);  // W_00
     }
     __syncthreads();
@@ -714,11 +714,10 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 for (int s = 0; s < 4; ++s) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s], pa1[4 * s], a, 0, 0, 0);
                 FSTAMP(8);
                 // factor and invert in the accumulator layout (DPP row broadcasts, no LDS round trip, no transposition)
-                const bool ok = chol_inv_tile_acc(a, xi, lane, aug_tile == k + 1 ? aug_c : -1);
+                const bool ok = factor_invert_tile(a, xi, S.dli + ((k + 1) & 1) * 16 * PS, lane, aug_tile == k + 1 ? aug_c : -1);
                 if (!ok && lane == 0) *S.flag = 1;
                 FSTAMP(9);
-                store_factored_tile(a, xi, nullptr, ld, S.dli + ((k + 1) & 1) * 16 * PS, nullptr, nullptr,
-                                    CL ? nullptr : cs_ptr(k + 1, k + 1), rows_valid(k + 1), lane);
+                if (!CL) store_col_ssq(xi, cs_ptr(k + 1, k + 1), rows_valid(k + 1), lane);
                 st_pk(as_global(uniform_ptr(W)), base_pk, lane, xi);  // W_{k+1,k+1}
                 // L_{k+1,k+1}^-1 is in LDS: the waves holding tiles of column k + 1 may now turn them into panel k + 1
                 __hip_atomic_store(&S.flag[3], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1019,9 +1018,8 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (rg + 4 * r == cl) t0[r] += pinv[cl];
-        const bool ok = chol_inv_tile_acc(t0, x0, lane, aug_tile == 0 ? aug_c : -1);
+        const bool ok = factor_invert_tile(t0, x0, S.dli, lane, aug_tile == 0 ? aug_c : -1);  // L_00^-1 -> dli[0]
         if (!ok && lane == 0) *S.flag = 1;
-        store_factored_tile(t0, x0, nullptr, ld, S.dli, nullptr, nullptr, nullptr, rows_valid(0), lane);  // L_00^-1 -> dli[0]
         st_pk(as_global(C), 0u, lane, x0);  // X_00 (the helpers' W_00)
     }
     __syncthreads();
@@ -1107,10 +1105,9 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
             long long f_last = clock64();
 #endif
             v4f64 xi;
-            const bool ok = chol_inv_tile_acc(dg, xi, lane, aug_tile == k + 1 ? aug_c : -1);
+            const bool ok = factor_invert_tile(dg, xi, S.dli + ((k + 1) & 1) * 16 * PS, lane, aug_tile == k + 1 ? aug_c : -1);
             if (!ok && lane == 0) *S.flag = 1;
             FSTAMP(9);
-            store_factored_tile(dg, xi, nullptr, ld, S.dli + ((k + 1) & 1) * 16 * PS, nullptr, nullptr, nullptr, rows_valid(k + 1), lane);
             st_pk(C_u, base_pk, lane, xi);  // X_{k+1,k+1} (the helpers' W_{k+1,k+1})
             __hip_atomic_store(&S.flag[3], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             FSTAMP(10);
@@ -1572,10 +1569,10 @@ __device__ __forceinline__ bool solve_posterior_ll(const FitLoopParams &P, const
 #endif
             v4f64 a = lds_tile(dg + (size_t)J * 256, lane), xi;
             FSTAMP(8);
-            const bool ok = chol_inv_tile_acc(a, xi, lane, aug_tile == J ? aug_c : -1);
+            const bool ok = factor_invert_tile(a, xi, dli_J, lane, aug_tile == J ? aug_c : -1);
             if (!ok && lane == 0) *S.flag = 1;
             FSTAMP(9);
-            store_factored_tile(a, xi, nullptr, ld, dli_J, nullptr, nullptr, cs_ptr(J, J), rows_valid(J), lane);
+            store_col_ssq(xi, cs_ptr(J, J), rows_valid(J), lane);
             st_pk(C_u, (unsigned)(J * (nb + 1) * 2048), lane, xi);  // W_JJ = X_JJ
             __hip_atomic_store(&S.flag[3], J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             FSTAMP(10);

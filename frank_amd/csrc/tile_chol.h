@@ -98,6 +98,186 @@ __device__ __forceinline__ bool chol_inv_tile_acc(v4f64 &T, v4f64 &X, int lane, 
     return ok;
 }
 
+// ---- the same, transposed outputs (round 4): 20 instead of 48 instructions per column, hand-scheduled --------------------------
+// A lone wave issues one instruction per ~4 cycles whatever its kind, in order, and a dependent one ~10 cycles after its
+// producer; the step above costs ~48 instructions per column (4.1 k cycles per tile; a pass of the fit loop is a chain of 19
+// tiles).  This form keeps Z = X^T = L^-T instead of X:
+//   X[i][:] -= L[i][C] X[C][:] / sqrt(d)   reads, in Z's layout, Z's own column C inside a 16-lane DPP row (row_newbcast) and
+//   the SAME per-lane multiplier b = T[C][cl] / d the update of T uses -- one cross-row broadcast per column instead of two,
+//   no lane-dependent selects of the pivot's register (the mask is per COLUMN index cl), and each update is one
+//   v_fmac_f64_dpp (the only 64-bit operation that takes a DPP operand): five per column (registers 0..R of Z, R..3 of T).
+// Only 1 / d is needed per column (v_rcp_f64 + one cubic correction folded into b); the pivots stay on T's diagonal and row C
+// of X is scaled at the end (Z *= rsqrt(d_cl), one vector rsqrt per tile); positivity is read off the pivots.
+// Rows of T travel to the four DPP rows TWO columns ahead (the LDS round trip of ds_bpermute is ~120 cycles, a column ~100):
+// row C + 2 is read BEFORE column C's update and receives the two updates it misses as one fma each (w - w[C] b: the
+// broadcast row is the same in every DPP row, so its own column C is a row_newbcast) -- bit-identical to what the updates make
+// of the row in T.  The chain per column is then  b -> row C + 1 -> its pivot (DPP) -> v_rcp_f64 -> e = 1 - d r -> b, and the
+// whole column is ONE asm block in issue order (the compiler sank the next reciprocal behind the updates, and a
+// DPP operand needs two wait states behind its VALU write, which inline asm is not scanned for): every dependent pair has
+// independent instructions between it, two updates of column C - 1 (registers no row broadcast reads) fill the gaps of
+// column C.  Masks are arithmetic (clamp(cl - C)): 64-bit selects need sub-registers, which inline asm cannot name.
+// T is updated as T[i][j] -= T[i][C] (T[C][j] / d): symmetric to rounding only (both triangles are kept: row C feeds the
+// multiplier, column C the DPP operand); the factor's backward error is unchanged.
+// Out: Z = L^-T and, if WANT_L, T = L^T, both in the accumulator layout (register r of lane (rg, cl) = element (rg + 4 r, cl)),
+// which makes register q of Z the k-step-q A fragment of X = L^-1 (element [cl][4 q + rg]) and the B fragment of X^T.
+template <int Q>
+__device__ __forceinline__ double xrow(double v, int addr4) {  // the value of lane (Q, cl) to the lanes (*, cl); addr4 = 4 cl
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr4 + 64 * Q, __double2hiint(v)),
+                            __builtin_amdgcn_ds_bpermute(addr4 + 64 * Q, __double2loint(v)));
+}
+struct ZState {
+    double t[4], z[4];
+    double bun;     // row C of T as column C's update finds it (unnormalised), in every DPP row
+    double u;       // row C + 1, read before column C - 1's update (that update still missing)
+    double d, r0;   // pivot of column C, v_rcp_f64 of it (2^-24)
+    double bp;      // b of column C - 1 (two of its updates are still to come)
+    double clm;     // cl - C + 1
+};
+#define FH_DPPC(c) " row_newbcast:%c[" #c "] row_mask:0xf bank_mask:0xf\n"
+#define FH_UPD(reg, b, c) "v_fmac_f64_dpp %[" #reg "], -%[" #reg "], %[" #b "]" FH_DPPC(c)
+#define FH_Z_OPERANDS                                                                                                           \
+    [z0] "+v"(S.z[0]), [z1] "+v"(S.z[1]), [z2] "+v"(S.z[2]), [z3] "+v"(S.z[3]), [t0] "+v"(S.t[0]), [t1] "+v"(S.t[1]),           \
+        [t2] "+v"(S.t[2]), [t3] "+v"(S.t[3]), [u] "+v"(S.u), [d] "+v"(S.d), [r0] "+v"(S.r0), [clm] "+v"(S.clm), [b] "=&v"(b),   \
+        [x] "=&v"(x), [e] "=&v"(e), [ope] "=&v"(ope)
+#define FH_Z_MINI FH_UPD(u, bp, cm)  /* row C + 1: column C - 1's update */
+#define FH_Z_NEXT(f0, f1, f2)                                                                                \
+    FH_UPD(u, b, cc) /* row C + 1 as this column leaves it */ FH_UPD(f0, b, cc) FH_UPD(f1, b, cc)           \
+        "v_mov_b64_dpp %[d], %[u]" FH_DPPC(c1) FH_UPD(f2, b, cc) "v_rcp_f64 %[r0], %[d]\n"
+template <int C, bool FORCE, bool WANT_L>
+__device__ __forceinline__ void chol_z_step(ZState &S, double (&lt)[4], int rg, int cl, int addr4, int force_c) {
+    constexpr int R = C >> 2, Q = C & 3, R2 = (C + 2) >> 2, Q2 = (C + 2) & 3;
+    double wn = 0.0;
+    if constexpr (C + 2 <= 15) wn = xrow<Q2>(S.t[R2], addr4);  // row C + 2, two updates short (consumed in the NEXT block)
+    if constexpr (WANT_L) lt[R] = (rg == Q && cl >= C) ? S.bun : lt[R];
+    double b, x, e, ope;
+    // postponed pair of a column: (t3, z0) while R = 0, (z0, z1) after that -- never a register a row broadcast still reads
+    if constexpr (C == 0) {
+        asm volatile("v_add_f64 %[clm], %[clm], -1.0\n"
+                     "v_max_f64 %[x], %[clm], %[clm] clamp\n"
+                     "v_mul_f64 %[x], %[bun], %[x]\n"
+                     "v_fma_f64 %[e], -%[d], %[r0], 1.0\n"
+                     "v_mul_f64 %[x], %[x], %[r0]\n"
+                     "v_add_f64 %[ope], %[e], 1.0\n"
+                     "v_mul_f64 %[b], %[x], %[e]\n"
+                     "v_fma_f64 %[b], %[b], %[ope], %[x]\n" FH_Z_NEXT(t0, t1, t2)
+                     : FH_Z_OPERANDS
+                     : [bun] "v"(S.bun), [bp] "v"(S.bp), [cc] "i"(C), [c1] "i"(C + 1), [cm] "i"(0));
+    } else if constexpr (C < 15) {
+#define FH_Z_COL(p0, p1, f0, f1, f2, TAIL)                                                                              \
+    asm volatile("v_add_f64 %[clm], %[clm], -1.0\n"                                                                     \
+                 "v_max_f64 %[x], %[clm], %[clm] clamp\n" FH_Z_MINI "v_mul_f64 %[x], %[bun], %[x]\n"                     \
+                 "v_fma_f64 %[e], -%[d], %[r0], 1.0\n"                                                                  \
+                 "v_mul_f64 %[x], %[x], %[r0]\n"                                                                        \
+                 "v_add_f64 %[ope], %[e], 1.0\n"                                                                        \
+                 "v_mul_f64 %[b], %[x], %[e]\n" FH_UPD(p0, bp, cm) "v_fma_f64 %[b], %[b], %[ope], %[x]\n"                \
+                     FH_UPD(p1, bp, cm) TAIL                                                                            \
+                 : FH_Z_OPERANDS                                                                                        \
+                 : [bun] "v"(S.bun), [bp] "v"(S.bp), [cc] "i"(C), [c1] "i"(C + 1), [cm] "i"(C - 1))
+        if constexpr (C <= 3)
+            FH_Z_COL(t3, z0, t0, t1, t2, FH_Z_NEXT(t0, t1, t2));
+        else if constexpr (C == 4)  // (column 3 left t3 and z0)
+            FH_Z_COL(t3, z0, t1, t2, t3, FH_Z_NEXT(t1, t2, t3));
+        else if constexpr (C <= 7)
+            FH_Z_COL(z0, z1, t1, t2, t3, FH_Z_NEXT(t1, t2, t3));
+        else if constexpr (C <= 11)
+            FH_Z_COL(z0, z1, t2, t3, z2, FH_Z_NEXT(t2, t3, z2));
+        else if constexpr (C <= 13)
+            FH_Z_COL(z0, z1, t3, z2, z3, FH_Z_NEXT(t3, z2, z3));
+        else  // column 14: no pivot needed any more (it stays on T's diagonal)
+            FH_Z_COL(z0, z1, t3, z2, z3, FH_UPD(u, b, cc) FH_UPD(t3, b, cc) FH_UPD(z2, b, cc) FH_UPD(z3, b, cc));
+#undef FH_Z_COL
+    } else {  // what column 14 left
+        asm volatile(FH_UPD(z0, bp, cm) FH_UPD(z1, bp, cm) : [z0] "+v"(S.z[0]), [z1] "+v"(S.z[1]) : [bp] "v"(S.bp), [cm] "i"(14));
+    }
+    if constexpr (C < 15) {
+        S.bun = S.u;
+        S.u = wn;
+        S.bp = b;
+        if constexpr (FORCE) {
+            const bool f = C + 1 == force_c;
+            S.d = f ? 1.0 : S.d;
+            S.r0 = f ? 1.0 : S.r0;
+        }
+    }
+}
+#undef FH_Z_MINI
+#undef FH_Z_NEXT
+#undef FH_Z_OPERANDS
+#undef FH_UPD
+#undef FH_DPPC
+template <bool FORCE, bool WANT_L, int... Cs>
+__device__ __forceinline__ void chol_z_steps(ZState &S, double (&lt)[4], int rg, int cl, int addr4, int force_c,
+                                             std::integer_sequence<int, Cs...>) {
+    (chol_z_step<Cs, FORCE, WANT_L>(S, lt, rg, cl, addr4, force_c), ...);
+}
+template <bool FORCE, bool WANT_L>
+__device__ __forceinline__ bool chol_inv_tile_z(v4f64 &T, v4f64 &Z, int lane, int force_c) {
+    int rg = lane >> 4, cl = lane & 15;
+    asm volatile("" : "+v"(rg), "+v"(cl));
+    const int addr4 = cl * 4;
+    ZState S;
+    double lt[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S.t[r] = T[r], S.z[r] = (rg + 4 * r == cl) ? 1.0 : 0.0;
+    S.bun = xrow<0>(S.t[0], addr4);
+    S.u = xrow<1>(S.t[0], addr4);
+    S.d = dpp_row_bcast_c<0>(S.bun);
+    if constexpr (FORCE) S.d = (0 == force_c) ? 1.0 : S.d;
+    S.r0 = __builtin_amdgcn_rcp(S.d);
+    S.bp = 0.0;
+    S.clm = (double)(cl + 1);
+    chol_z_steps<FORCE, WANT_L>(S, lt, rg, cl, addr4, force_c, std::make_integer_sequence<int, 16>{});
+    // the pivots are still on T's diagonal (lane cl of a row of T is masked from column cl on): lane (cl & 3, cl) of register
+    // cl >> 2 -> every lane of column cl
+    const int rsel = cl >> 2;
+    double dvec = rsel == 0 ? S.t[0] : (rsel == 1 ? S.t[1] : (rsel == 2 ? S.t[2] : S.t[3]));
+    dvec = __shfl(dvec, (cl & 3) * 16 + cl);
+    if constexpr (FORCE) dvec = (cl == force_c) ? 1.0 : dvec;
+    const double dc = rsqrt_f64(dvec);  // 1 / sqrt(d_cl): scales column cl of Z (row cl of X) ...
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Z[r] = S.z[r] * dc;
+    if constexpr (WANT_L) {  // ... and, moved to the lanes' ROW indices, the rows of L^T
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[r] = lt[r] * __shfl(dc, rg + 4 * r);
+    }
+    return __builtin_amdgcn_ballot_w64(!(dvec > 0.0 && dvec < __builtin_inf())) == 0;
+}
+
+// Z = L^-T (accumulator layout) -> X = L^-1 row-major in the LDS panel-solve operand dli (stride PS), and X back in the
+// accumulator layout (a wave's DS operations execute in order: its own reads behind its own writes need no barrier).
+__device__ __forceinline__ v4f64 store_inverse_z(const v4f64 &Z, double *dli, int lane) {
+    const int rg = lane >> 4, cl = lane & 15;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dli[cl * PS + rg + 4 * q] = Z[q];  // Z[rg + 4 q][cl] = X[cl][rg + 4 q]
+    v4f64 X;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[r] = dli[(rg + 4 * r) * PS + cl];
+    return X;
+}
+// cs[c] = sum over the first rows_valid rows of X[r][c]^2 (X in the accumulator layout)
+__device__ __forceinline__ void store_col_ssq(const v4f64 &X, double *cs, int rows_valid, int lane) {
+    const int rg = lane >> 4, cl = lane & 15;
+    double ssq = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (rg + 4 * r < rows_valid) ssq = fma(X[r], X[r], ssq);
+    ssq += __shfl_xor(ssq, 16);
+    ssq += __shfl_xor(ssq, 32);
+    if (rg == 0) cs[cl] = ssq;
+}
+// factor + invert a diagonal tile: X = L^-1 into dli and (accumulator layout) x; T is consumed.  force_c >= 0 (wave-uniform): the
+// pivot of that column is taken as 1 (the augmented row of the fit loop).
+__device__ __forceinline__ bool factor_invert_tile(v4f64 &T, v4f64 &x, double *dli, int lane, int force_c) {
+    v4f64 z;
+    bool ok;
+    if (force_c >= 0)
+        ok = chol_inv_tile_z<true, false>(T, z, lane, force_c);
+    else
+        ok = chol_inv_tile_z<false, false>(T, z, lane, -1);
+    x = store_inverse_z(z, dli, lane);
+    return ok;
+}
+
 // Outputs of a factored + inverted diagonal tile (both in the accumulator layout): L into the row-major matrix block
 // `Cblk` (leading dimension ld; NULL: skip), X = L^-1 into the LDS panel-solve operand dli (stride PS), into the row-major
 // block `Wblk` and, transposed, into WdT_k (256 doubles: WdT_k[c][r] = X[r][c]); cs[c] = sum over the first rows_valid rows
