@@ -249,12 +249,13 @@ namespace clu {
 // control words (ints), zero between fits: PROG progress of the factorisation, DONE helper waves that have handed over their
 // columns, IN helper workgroups present, XCC the XCDs the members sit on; HCOL + J: trailing tiles of block column J the helpers
 // have handed back (cumulative over the passes)
-enum { PROG = 0, DONE = 1, IN = 2, XCC = 3, HCOL = 8, NCTL = 8 + 64 };
+enum { PROG = 0, DONE = 32, IN = 33, XCC = 34, HCOL = 64, NCTL = 64 + 64 };  // (128-byte lines: the word every helper polls, the
+                                                                              //  rarely written ones, the counters of the hand-back)
 constexpr int kSeq = 128;  // progress word = pass * kSeq + block columns of L that are final (<= 64)
 // exchange area (the fit's WdT buffer): [0, NP) Tr2 and [NP, 2 NP) m from the helpers, [2 NP, 3 NP) 1 / p from the first
 // workgroup, then the control words
 constexpr int kBand = 2;    // block columns right of the panel the first workgroup updates itself (see trailing_wave)
-constexpr int kTMax = 10;   // trailing tiles a helper wave keeps in registers at most
+constexpr int kTMax = 7;    // trailing tiles a helper wave keeps in registers at most (N <= 335 with two helpers' 24 waves: 153)
 // Members of a cluster: 0 the first workgroup, 1 .. inv the helpers of the inverse, inv + 1 .. cluster - 1 the helpers of the
 // trailing update.  A wave that held trailing tiles AND ran the load ring of an inverse column spilled both to scratch memory
 // (the spill traffic counts in the ring's hand-written waits): 20 us behind the factorisation at the end of a pass.
@@ -278,6 +279,14 @@ __device__ __forceinline__ v4f64 ld_pk_dev(const gdouble *base, unsigned tile_by
                  : "v"(a), "s"(base)
                  : "memory");
     return v4f64{lo[0], lo[1], hi[0], hi[1]};
+}
+// issue only: the caller waits (s_waitcnt vmcnt) and fences the registers before it reads them
+__device__ __forceinline__ void ld_pk_dev_issue(const gdouble *base, unsigned tile_byte_off, int lane, v2f64 &lo, v2f64 &hi) {
+    const unsigned a = tile_byte_off + (unsigned)lane * 16u;
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3 sc1\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024 sc1"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(a), "s"(base)
+                 : "memory");
 }
 // two tiles with one wait
 __device__ __forceinline__ void ld_pk_dev2(const gdouble *ba, unsigned oa, const gdouble *bb, unsigned ob, int lane, v4f64 &ta, v4f64 &tb) {
@@ -382,7 +391,14 @@ __device__ __forceinline__ v4f64 chain_sum(const gdouble *Cu, const gdouble *Wu,
 // REGISTERS, from the mirror tiles (k, J), (k, I) of C as they are published, the same products in the same order as the first
 // workgroup's trailing update --, goes back through memory when its column enters the band (the upper tiles of the W buffer,
 // the diagonal ones in the cs buffer) and takes its last band + 1 updates there.  An event is "column c of L is final".
-__device__ __forceinline__ void trailing_wave(const FitLoopParams &P, int *ctl, int hw, int T, int lane) {
+// OPERANDS THROUGH LDS (round 4, second half).  Every product read its two operand tiles (c, J), (c, I) from the L2 with
+// device-scope loads and waited for them: ~0.9 us per product in situ (an in-kernel timeline of one helper wave; 0.22 us for an
+// undisturbed pair, tools/microbench/xcu_latency.hip -- but the same few tiles of row c are asked for by up to 24 waves at
+// once and never served from the L1), 7 us for the first events of a pass, and the first workgroup waited ~1.1 us of every
+// 3.4 us step for the column that enters its band.  Now the workgroup reads row c ONCE per event -- each wave one or two of
+// the <= 15 tiles (c, x), x >= c + 2 + band, into a double-buffered 30 KB stage in LDS, one barrier -- and every product takes
+// its operands from there.  Same products in the same order per tile: same bits.
+__device__ __forceinline__ void trailing_wave(const FitLoopParams &P, int *ctl, int hw, int T, int lane, double *stage, int wv) {
     const int nb = P.NP / 16;
     const int cl = lane & 15, rg = lane >> 4;
     const gdouble *Cg = as_global(uniform_ptr(const_cast<const double *>(P.C)));
@@ -391,52 +407,56 @@ __device__ __forceinline__ void trailing_wave(const FitLoopParams &P, int *ctl, 
     gdouble *Dg = as_global(uniform_ptr(P.cs));
     const double *xg = P.WdT;
     const int band = band_of(P);
+    const int first = 2 + band, last = nb - 1 - first;  // the events: columns first .. nb - 1 leave at events 0 .. last
     int seen = 0;
     int tI[kTMax], tJ[kTMax];
-    {
-        const int first = 2 + band;
 #pragma unroll
-        for (int i = 0; i < kTMax; ++i) {
-            int t = hw + i * T, J = first;
-            while (J < nb && t >= nb - J) {
-                t -= nb - J;
-                ++J;
-            }
-            tJ[i] = J < nb ? J : -1;
-            tI[i] = J + t;
+    for (int i = 0; i < kTMax; ++i) {
+        int t = hw + i * T, J = first;
+        while (J < nb && t >= nb - J) {
+            t -= nb - J;
+            ++J;
         }
+        tJ[i] = J < nb ? J : -1;
+        tI[i] = J + t;
     }
-    if (tJ[0] < 0) {  // nothing to do: wait for the end of the fit (the workgroup leaves together)
-        while (wait_prog(ctl, 0x7fffffff, seen)) {
-        }
-        return;
-    }
-    for (int seq = 1;; ++seq) {
-        v4f64 tt[kTMax];
-        // first touch: tile (I, J) holds T_IJ^T, the tile (J, I) of the symmetric A (the constant of the fit: no wait)
+    v4f64 tt[kTMax];
+    auto first_touch = [&]() {  // tile (I, J) holds T_IJ^T, the tile (J, I) of the symmetric A (the constant of the fit: no wait)
 #pragma unroll
         for (int i = 0; i < kTMax; ++i)
             if (tJ[i] >= 0) tt[i] = ld_pk(Ag, (unsigned)((tJ[i] * nb + tI[i]) * 2048), lane);
-        int last = 0;  // the last event that concerns this wave
-#pragma unroll
-        for (int i = 0; i < kTMax; ++i)
-            if (tJ[i] >= 0) last = max(last, tJ[i] - 2 - band);
+    };
+    first_touch();
+    const int stage_tiles = nb - first;  // (per buffer)
+    for (int seq = 1;; ++seq) {
         for (int c = 0; c <= last; ++c) {
             if (!wait_prog(ctl, seq * clu::kSeq + c + 1, seen)) return;
+            const int x0 = c + first;
+            double *buf = stage + (size_t)(c & 1) * stage_tiles * 256;
+            for (int x = x0 + wv; x < nb; x += NW) {
+                const v4f64 v = ld_pk_dev(Cg, (unsigned)((c * nb + x) * 2048), lane);
+                v2f64 *q = reinterpret_cast<v2f64 *>(buf + (size_t)(x - x0) * 256) + lane;
+                q[0] = v2f64{v[0], v[1]};
+                q[64] = v2f64{v[2], v[3]};
+            }
+            __syncthreads();  // (one per event: a wave cannot be two events ahead, the buffers alternate)
             int handed = 0;
 #pragma unroll
             for (int i = 0; i < kTMax; ++i) {
-                if (tJ[i] < 0 || tJ[i] < c + 2 + band) continue;
+                if (tJ[i] < 0 || tJ[i] < x0) continue;
                 if (c == 0 && tI[i] == tJ[i]) {  // diag(1 / p) (written by the first workgroup before its first word of the pass)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (rg + 4 * q == cl) tt[i][q] += ld_dev(xg + 2 * P.NP + 16 * tI[i] + cl);
                 }
-                v4f64 fa, fb;
-                ld_pk_dev2(Cg, (unsigned)((c * nb + tJ[i]) * 2048), Cg, (unsigned)((c * nb + tI[i]) * 2048), lane, fa, fb);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) tt[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(-fa[q], fb[q], tt[i], 0, 0, 0);
-                if (tJ[i] == c + 2 + band) {  // the column enters the band at the next step: hand the tile back
+                const v2f64 *qa = reinterpret_cast<const v2f64 *>(buf + (size_t)(tJ[i] - x0) * 256) + lane;
+                const v2f64 *qb = reinterpret_cast<const v2f64 *>(buf + (size_t)(tI[i] - x0) * 256) + lane;
+                const v2f64 a0 = qa[0], a1 = qa[64], b0 = qb[0], b1 = qb[64];
+                tt[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[0], b0[0], tt[i], 0, 0, 0);
+                tt[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[1], b0[1], tt[i], 0, 0, 0);
+                tt[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[0], b1[0], tt[i], 0, 0, 0);
+                tt[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[1], b1[1], tt[i], 0, 0, 0);
+                if (tJ[i] == x0) {  // the column enters the band at the next step: hand the tile back
                     if (tI[i] == tJ[i]) st_pk(Dg, (unsigned)(tJ[i] * 2048), lane, tt[i]);
                     else st_pk(Wg, (unsigned)((tJ[i] * nb + tI[i]) * 2048), lane, tt[i]);
                     ++handed;
@@ -444,9 +464,10 @@ __device__ __forceinline__ void trailing_wave(const FitLoopParams &P, int *ctl, 
             }
             if (handed) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) add(ctl + HCOL + c + 2 + band, handed);
+                if (lane == 0) add(ctl + HCOL + x0, handed);
             }
         }
+        first_touch();  // (for the next pass, before the wait for it)
         if (!wait_prog(ctl, (seq + 1) * clu::kSeq + 1, seen)) return;  // the next pass (its first event) or the end of the fit
     }
 }
@@ -1162,6 +1183,7 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
     // Worker rows (band < nb): block row I >= 3 belongs to worker (I - 3) mod NWKc for as long as it has tiles in the band
     // (steps 0 .. I - 3); its tiles of columns k + 1 and k + 2 STAY IN REGISTERS from step to step (rA, rB)
     v4f64 rA[2], rB[2];
+    bool colready = false;  // the column that enters the band at the next step is known to be back from the helpers
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) rA[s2] = rB[s2] = v4f64{0.0, 0.0, 0.0, 0.0};
     for (int k = 0; k + 1 < nb; ++k) {
@@ -1203,6 +1225,8 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
             }
             cntB = __builtin_amdgcn_readfirstlane(cntB);
             cntH = __builtin_amdgcn_readfirstlane(cntH);
+            int hc = 0;
+            bool anyn = false;
             bool hready = false;
             auto rec_at = [&](int e) -> uint4 {
                 if (band < nb) {  // column by column: column j of the band holds the rows i = j .. m - 1
@@ -1285,40 +1309,71 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
                 // same wave has the tile all three times: it stays in registers (rA: column k + 1, rB: column k + 2), the band
                 // is never stored, and what a step loads is the one tile per row that enters.  Same operations per tile in the
                 // same order: same bits.
+                // THE COLUMN THAT ENTERS THE BAND, AHEAD OF THE STEP.  A wave's poll of the helpers' counter and its device-scope
+                // load of the returned tile cost ~1.2 + ~0.4 us at the head of every step (in-kernel timeline; the helpers had
+                // delivered long before) -- a third of the step.  Now the word of column k + 4 is asked for late in step k
+                // (asynchronously, in front of the column tiles), read behind arrive()'s wait, and if the column is there step
+                // k + 1 issues the loads of its tiles at once and waits for them behind the products of its other two tiles.
+                // (Asked for in the middle of step k it was not there yet: the helpers need ~1.6 us from the end of step k - 1;
+                // registers in flight across the loop's back edge are not safe from the compiler's copies.)
+                v2f64 rNlo[2], rNhi[2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) rNlo[s2] = rNhi[s2] = v2f64{0.0, 0.0};
+                if (k > 0 && colready) {  // (issue and use inside one step: no register in flight across the loop's back edge)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const int I = 3 + widx + s2 * NWKc;
+                        if (I >= nb || k > I - 3) continue;
+                        if (I == k + 3) clu::ld_pk_dev_issue(HD_u, (unsigned)((k + 3) * 2048), lane, rNlo[s2], rNhi[s2]);
+                        else clu::ld_pk_dev_issue(H_u, (unsigned)(((k + 3) * nb + I) * 2048), lane, rNlo[s2], rNhi[s2]);
+                    }
+                }
                 v4f64 rowC[2];
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const int I = 3 + widx + s2 * NWKc;
                     if (I >= nb || k > I - 3) continue;
                     const int i = I - k - 1;  // row block of the panel
-                    v4f64 tC;
                     if (k == 0) {  // first touch: the transposes from A (tile (J, I) of the symmetric A), 1 / p on the diagonal
                         rA[s2] = ld_pk(src_u, base_pk + (unsigned)(i * 2048), lane);
                         rB[s2] = ld_pk(src_u, base_pk + (unsigned)((nb + i) * 2048), lane);
-                        tC = ld_pk(src_u, base_pk + (unsigned)((2 * nb + i) * 2048), lane);
+                        rowC[s2] = ld_pk(src_u, base_pk + (unsigned)((2 * nb + i) * 2048), lane);
                         if (I == 3) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                if (rg + 4 * r == cl) tC[r] += pinv[16 * 3 + cl];
+                                if (rg + 4 * r == cl) rowC[s2][r] += pinv[16 * 3 + cl];
                         }
-                    } else {  // column k + 3 comes back from the helpers of the trailing update (updates 0 .. k - 1 applied)
-                        if (!hready) {
-                            const int J = k + 3, need = seq * (nb - J);
-                            const long long t0 = wall_clock64();
-                            while (__builtin_amdgcn_readfirstlane(clu::ld(ctl + clu::HCOL + J)) < need) {
-                                __builtin_amdgcn_s_sleep(1);
-                                if (wall_clock64() - t0 > 1000000 * clu::kTicksPerUs) {
-                                    if (lane == 0) S.flag[0] = 2;
-                                    break;
-                                }
-                            }
-                            hready = true;
-                        }
-                        tC = (I == k + 3) ? clu::ld_pk_dev(HD_u, (unsigned)((k + 3) * 2048), lane)
-                                          : clu::ld_pk_dev(H_u, (unsigned)(((k + 3) * nb + I) * 2048), lane);
                     }
                     rA[s2] = upd(0u, (unsigned)(i * 16 * PS * 8), rA[s2]);
                     rB[s2] = upd((unsigned)(16 * PS * 8), (unsigned)(i * 16 * PS * 8), rB[s2]);
+                }
+                if (k > 0 && colready) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rNlo[0]), "+v"(rNhi[0]), "+v"(rNlo[1]), "+v"(rNhi[1])::"memory");
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int I = 3 + widx + s2 * NWKc;
+                    if (I >= nb || k > I - 3) continue;
+                    const int i = I - k - 1;
+                    v4f64 tC = rowC[s2];
+                    if (k > 0) {  // column k + 3 comes back from the helpers of the trailing update (updates 0 .. k - 1 applied)
+                        if (colready) {
+                            tC = v4f64{rNlo[s2][0], rNlo[s2][1], rNhi[s2][0], rNhi[s2][1]};
+                        } else {
+                            if (!hready) {
+                                const int J = k + 3, need = seq * (nb - J);
+                                const long long t0 = wall_clock64();
+                                while (__builtin_amdgcn_readfirstlane(clu::ld(ctl + clu::HCOL + J)) < need) {
+                                    __builtin_amdgcn_s_sleep(1);
+                                    if (wall_clock64() - t0 > 1000000 * clu::kTicksPerUs) {
+                                        if (lane == 0) S.flag[0] = 2;
+                                        break;
+                                    }
+                                }
+                                hready = true;
+                            }
+                            tC = (I == k + 3) ? clu::ld_pk_dev(HD_u, (unsigned)((k + 3) * 2048), lane)
+                                              : clu::ld_pk_dev(H_u, (unsigned)(((k + 3) * nb + I) * 2048), lane);
+                        }
+                    }
                     tC = upd((unsigned)(2 * 16 * PS * 8), (unsigned)(i * 16 * PS * 8), tC);
                     if (k == I - 3) {  // the row's last step here: tiles (I, I - 1) and (I, I) go to the chain wave
                         if (S.hand) {
@@ -1342,6 +1397,13 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
                     const int I = 3 + widx + s2 * NWKc;
                     any = any || (I < nb && k <= I - 3);
                 }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int I = 3 + widx + s2 * NWKc;
+                    anyn = anyn || (I < nb && k + 1 <= I - 3);
+                }
+                if (anyn)
+                    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1" : "=&v"(hc) : "v"(0), "s"(ctl + clu::HCOL + k + 4) : "memory");
                 if (any) {
                     wait_flag();
                     TRACE(2);
@@ -1407,6 +1469,11 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
             }
             TRACE(3);
             arrive(k);
+            colready = false;
+            if (anyn) {  // (arrive() has waited for the word)
+                asm volatile("" : "+v"(hc));
+                colready = __builtin_amdgcn_readfirstlane(hc) >= seq * (nb - (k + 4));
+            }
             TRACE(4);
             WSTAMP(12);
             __syncthreads();
@@ -1797,7 +1864,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
             const int hwave = __builtin_amdgcn_readfirstlane(tid >> 6);
             const int hi = clu::inv_helpers(P), ht = clu::trail_helpers(P);
             if (member <= hi) clu::inverse_wave<2>(P, ctl, hwave * hi + (member - 1), hi * NW, tid & 63);
-            else clu::trailing_wave(P, ctl, hwave * ht + (member - 1 - hi), ht * NW, tid & 63);
+            else clu::trailing_wave(P, ctl, hwave * ht + (member - 1 - hi), ht * NW, tid & 63, smem, hwave);
             __syncthreads();
             if (tid == 0) clu::add(ctl + clu::IN, -1);
             return;
