@@ -1946,7 +1946,7 @@ static int prepare_qspace(fh_ctx *c, double *Aq, double *bq) {
 static int env_int(const char *name, int dflt);
 static int fit_cluster_size(const fh_ctx *c) {
     const char *e = getenv("FRANK_AMD_K2_CLUSTER");  // (read at every call: tests switch it inside one process)
-    int want = e ? atoi(e) : 5;
+    int want = e ? atoi(e) : 6;  // (1 + 3 helpers of the inverse + 2 of the trailing update: 74 us per pass at N = 300; five: 77, seven: 72)
     want = want < 1 ? 1 : (want > FIT_CLUSTER_MAX ? FIT_CLUSTER_MAX : want);
     if (want <= 1 || c->NP < 128 || c->NP > fh_k2_loop_max_np()) return 1;
     // the wide instantiations: helpers of the inverse only, a helper wave takes two block columns at most (24 per helper)

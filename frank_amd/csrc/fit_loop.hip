@@ -2282,7 +2282,7 @@ static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s)
         // to N = 383 (a wave takes two columns at most: nb <= 24 helpers' waves x 2); the others keep the trailing tiles right
         // of the band (not for the wide systems: their tiles do not fit the registers of a few waves)
         const int nbk = P.NP / 16, h = P.cluster - 1;
-        int inv = h >= 2 ? 2 : 1;
+        int inv = h >= 4 ? h - 2 : (h >= 2 ? 2 : 1);  // (two helpers of the trailing update are enough from five workgroups on)
         if (loop_is_wide(P.NP)) inv = h;
         if (const char *ie = getenv("FRANK_AMD_K2_CLUSTER_INV")) inv = atoi(ie);  // development
         inv = inv < 1 ? 1 : (inv > h ? h : inv);
