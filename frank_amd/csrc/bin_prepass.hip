@@ -331,11 +331,13 @@ __global__ __launch_bounds__(1024) void deproject_scatter_kernel(PrepassParams P
                 if (__builtin_expect(__any(ex == 0 || ex == 0x7ff || (long long)bits < 0), 0)) {
                     m1 = frexp(w1, &e1);
                     if (!(w1 > 0.0)) m1 = w1 == 0.0 ? 0.0 : NAN;  // log(0) = -inf, log(negative) = NaN, as the reference's sum
+                    if (ex == 0x7ff && w1 > 0.0) m1 = INFINITY;   // log(+inf) = +inf (frexp returns inf: the mantissa mask below
+                                                                  // would have turned the product into a finite number)
                 }
                 pm *= m1;  // in [0.25, 1): back to [0.5, 1)
                 const unsigned long long pb = __double_as_longlong(pm);
                 const int e2 = (int)((pb >> 52) & 0x7ff) - 1022;  // 0 or -1 (0, NaN: whatever, the product stays what it is)
-                if (pm > 0.0) {
+                if (pm > 0.0 && pm < INFINITY) {
                     pm = __longlong_as_double((pb & 0x800fffffffffffffull) | 0x3fe0000000000000ull);
                     pe += e1 + e2;
                 }

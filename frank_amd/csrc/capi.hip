@@ -196,6 +196,7 @@ struct fh_ctx {
     hipEvent_t ev_pre0 = nullptr;
     hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;  // around the fit_loop kernel of the last fh_fit_normal
     bool loop_timed = false;
+    bool have_device_mu = false;  // a solve of this context has left a profile in `mu` (fh_vis_residuals_slot with I = NULL reads it)
     float last_prepass_ms = 0.f;
     // N > 303: rows to memory + rocBLAS dsyrk; stats_sum then holds the dense (N+1)^2 Gram (upper triangle) + 2 scalars
     bool wide = false;
@@ -1626,6 +1627,7 @@ static FitState make_state(fh_ctx *c) {
 static int solve_posterior(fh_ctx *c, const FitState &st, bool with_prior, bool want_tr2) {
     const int N = c->N;
     const double one = 1.0;
+    c->have_device_mu = true;  // (whatever the factorisation says: the callers replace a failed solve by the SVD route's)
     if (with_prior) {
         HIP_TRY(fh_k2_launch_prep(st, c->stream));
         ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, N, N, N, &one, c->Y.p, N,
@@ -3219,7 +3221,18 @@ int fh_vis_residuals_slot(fh_ctx *c, const fh_geometry *g, int vis_model, const 
     if (n == 0) return fail(FH_ERR_INVALID, "fh_vis_residuals_slot: empty table");
     HIP_TRY(hipSetDevice(c->device));
     const size_t len = 2 * (size_t)n;
-    if (vis->slots.n < len * FH_RESIDUAL_SLOTS) HIP_TRY(vis->slots.alloc(len * FH_RESIDUAL_SLOTS));
+    // the buffer grows with the highest slot asked for (a fit uses 2 + its free parameters, not FH_RESIDUAL_SLOTS: 128 B per
+    // visibility were 1.3 GB at 1e7 rows); the vectors already there move with it
+    if (vis->slots.n < len * (size_t)(slot + 1)) {
+        DevBuf<double> grown;
+        HIP_TRY(grown.alloc(len * (size_t)(slot + 1)));
+        if (vis->slots.n) HIP_TRY(hipMemcpyAsync(grown.p, vis->slots.p, sizeof(double) * vis->slots.n, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::swap(vis->slots.p, grown.p);
+        std::swap(vis->slots.n, grown.n);
+        std::swap(vis->slots.owned, grown.owned);
+        grown.release();
+    }
     const int N = c->N;
     VisResidualParams P{};
     table_columns(P.b, vis, 0, n);
@@ -3246,6 +3259,8 @@ int fh_vis_residuals_slot(fh_ctx *c, const fh_geometry *g, int vis_model, const 
         HIP_TRY(hipMemcpyAsync(c->scratch_I.p, I, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
         P.I = c->scratch_I.p;
     } else {
+        if (!c->have_device_mu)
+            return fail(FH_ERR_INVALID, "fh_vis_residuals_slot: I = NULL, but no solve of this context has left a profile on the device");
         P.I = c->mu.p;  // the profile the last solve of this context left on the device (fh_gaussian_model, fh_fit_*)
     }
     P.delta = c->k1_delta > 0 ? c->k1_delta : 1.0;
@@ -3264,7 +3279,9 @@ int fh_residual_normal_equations(fh_ctx *c, const fh_vis *vis, int base_slot, in
     if (!c || !vis || !col_slots || !h || !JtJ || !Jtr || ncol < 1 || ncol > 4)
         return fail(FH_ERR_INVALID, "fh_residual_normal_equations: bad argument");
     const size_t len = 2 * (size_t)vis->n;
-    if (vis->slots.n < len * FH_RESIDUAL_SLOTS || len == 0)
+    int top = base_slot;
+    for (int k = 0; k < ncol; ++k) top = col_slots[k] > top ? col_slots[k] : top;
+    if (len == 0 || top < 0 || vis->slots.n < len * (size_t)(top + 1))
         return fail(FH_ERR_INVALID, "fh_residual_normal_equations: no residual vectors on the device (fh_vis_residuals_slot)");
     HIP_TRY(hipSetDevice(c->device));
     FdNormalParams P{};

@@ -11,7 +11,11 @@ The geometry fits are CALLERS of the hot path: the reference hands a residual fu
 scipy.optimize.least_squares(method='lm'), and for the non-parametric fit every evaluation of it is a binning pass, a
 solve and a prediction under a trial geometry.  Here the table is uploaded once and stays in HBM; a residual evaluation is
 fh_bin_visibilities + fh_gaussian_model + fh_vis_residuals (csrc/vis_residual.hip) under the trial geometry, or
-fh_gauss_residuals for the Gaussian; the optimiser is the same SciPy routine with the same arguments.
+fh_gauss_residuals for the Gaussian.  The optimiser: by default (`optimizer='device'`) MINPACK's Levenberg-Marquardt
+algorithm on normal equations summed on the device (frank_amd/_levmar.py) -- over the FREE parameters only, where the
+reference keeps pinned ones in x with zero Jacobian columns: xnorm, the first trust radius and the `delta <= xtol xnorm`
+test see a shorter vector, and function evaluations are counted differently (same geometry to the tolerances of the tests,
+a different path); `optimizer='scipy'` is the reference's routine with the reference's arguments.
 """
 import ctypes
 import logging
@@ -119,6 +123,7 @@ class _ResidentTable(object):
 
     def __init__(self, device, u, v, V, weights):
         from frank_amd import _lib
+        self.handle = None  # (close() / __del__ must work on an object whose construction failed)
         self._lib = _lib
         V = np.asarray(V)
         # single-precision arrays are stored as they are (20 B per visibility) and widened as the kernels read them
@@ -235,7 +240,7 @@ def _fit_geometry_gaussian(u, v, V, weights, guess, inc_pa=None, phase_centre=No
             A, g = np.empty((6, 6)), np.empty(6)
             _lib.check(_lib.lib.fh_gauss_normal_equations(table.handle, _lib.ptr(full(xf)), fit_ip, fit_ph, _lib.ptr(A), _lib.ptr(g), None))
             return A[np.ix_(free, free)], g[free], 0
-        xf, info, _ = levenberg_marquardt(trial, lambda: None, normal, x0[free], maxfev=100 * 7)
+        xf, info, _ = levenberg_marquardt(trial, lambda: None, normal, x0[free], maxfev=100 * 6)  # (least_squares with a callable jac: 100 n, n = 6)
         return full(xf)
 
     try:

@@ -122,6 +122,17 @@ def test_map_edge_cases():
     e = np.empty(0)
     m0 = FB.preprocess_visibilities(e, e, e + 0j, e)
     assert not m0["M"].any() and not m0["j"].any() and m0["null_likelihood"] == 0.0
+    # weights the logarithm of which is not finite: H0 = 0.5 sum(log(w / 2 pi) - V w V) follows the reference's sum
+    # (statistical_models.py:218): -inf with a zero weight, NaN with a negative one, NaN with an infinite one (inf - inf; the
+    # running mantissa / exponent product of the binning pass once turned log(+inf) into a finite number)
+    u, v, V, w = mock_disc_visibilities(700, seed=5, noise_seed=6)
+    for bad in (0.0, -1.0, np.inf):
+        wb = w.copy()
+        wb[123] = bad
+        with np.errstate(all="ignore"):
+            h = FB.preprocess_visibilities(u, v, V, wb)["null_likelihood"]
+            href = 0.5 * np.sum(np.log(wb / (2 * np.pi)) - (V * wb * np.conj(V)).real)
+        assert (np.isnan(h) and np.isnan(href)) or h == href, (bad, h, href)
 
 
 def test_map_qrange_error():
