@@ -1503,3 +1503,24 @@ def test_left_looking_solve_equals_right_looking(monkeypatch, N):
     rc, mu, p, n, *_ = _fit_normal(ctx, N, M, j, max_iter=200)
     assert rc0 == 0 and rc == 0
     assert n == n0 and np.array_equal(mu, mu0) and np.array_equal(p, p0)
+
+
+def test_diagonal_tile_routines():
+    """tile_chol.h: the transposed factor-and-invert routine of round 4 (chol_inv_tile_z, what the fit loop runs) against the
+    routine of rounds 2-3 and against the tiles themselves, on 32 random SPD tiles; with and without L^T out it returns the
+    same inverse; and it is the faster one (tools/microbench/tile_bench.hip, built by __graft_entry__.build())."""
+    import os
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "microbench", "tile_bench")
+    if not os.path.exists(exe):
+        pytest.skip("tools/microbench/tile_bench is not built (__graft_entry__.build())")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300).stdout
+    cyc = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"^(.+?)\s+(\d+) shader cycles per tile \(ok = 1\)", out, re.M)}
+    res = {m.group(1).strip(): (float(m.group(2)), float(m.group(3)))
+           for m in re.finditer(r"^(.+?)\s+\|L L\^T - A\|/\|A\| = (\S+)\s+\|X L - I\| = (\S+)", out, re.M)}
+    assert set(cyc) == {"rounds2-4", "z, L", "z"}, out
+    assert res["rounds2-4"][0] < 1e-14 and res["rounds2-4"][1] < 1e-14 and res["z, L"][0] < 1e-14 and res["z, L"][1] < 1e-14, out
+    m = re.search(r"new against old: max \|dL\| = (\S+), max \|dX\| = (\S+); with against without L: (\S+)", out)
+    assert m and float(m.group(1).rstrip(",")) < 1e-14 and float(m.group(2).rstrip(";")) < 1e-14 and float(m.group(3)) == 0.0, out
+    assert cyc["z"] < 0.6 * cyc["rounds2-4"], out
