@@ -567,6 +567,174 @@ __device__ __forceinline__ void inverse_wave(const FitLoopParams &P, int *ctl, i
         if (lane == 0) add(ctl + DONE, 1);
     }
 }
+
+// ---- TWO WAVES PER BLOCK COLUMN (round 4, second half; N <= 335, every wave at most one column) -----------------------------------
+// The wave of block column J adds up, at event c, the products K = J .. c of row c + 2: c - J + 1 of them, each waiting for a
+// device-scope tile of L.  At the end of a pass the first columns have ~17 per event against a step of ~2.7 us: they fall ~10 us
+// behind the factorisation, and the first workgroup waits for them at the end of EVERY pass (in-kernel timeline: 12 of 76 us).
+// Most waves of the helpers' workgroups have no column (36 waves, 19 columns).  So a column gets a SECOND wave of its workgroup:
+// B adds up K = J .. r - 4 of row r as soon as the column's own wave A has stored W_{r-4,J} (two events before A needs the sum),
+// hands the accumulator over through LDS, and A adds K = r - 3, r - 2 (at event r - 2: W from its registers, two tiles of L
+// loaded with X_cc) and K = r - 1 (the "last product", as before).  A's work per event no longer grows with c.  The products
+// enter every accumulator in the same ascending order of K: the same bits.
+// LDS of the workgroup: words [0, NW) rows A has stored (pass * 64 + c), [NW, 2 NW) rows B has summed, [2 NW] quit; behind them
+// two 2 KB slots per column (rows of alternating parity).
+__device__ __forceinline__ void inverse_wave_paired(const FitLoopParams &P, int *ctl, int hi, int m1, int wv, int lane, double *lds) {
+    const int N = P.N, nb = P.NP / 16;
+    const int cl = lane & 15, rg = lane >> 4;
+    const gdouble *Cg = as_global(uniform_ptr(const_cast<const double *>(P.C)));
+    gdouble *Wg = as_global(uniform_ptr(P.W));
+    double *xg = P.WdT;
+    const int aug_tile = N / 16, aug_r = N - 16 * aug_tile;
+    int *words = reinterpret_cast<int *>(lds);
+    double *slots = lds + 64;  // (512 bytes of words)
+    if (wv == 0 && lane < 2 * NW + 1) words[lane] = 0;
+    __syncthreads();
+    const int nA = (nb - m1 + hi - 1) / hi;  // waves of this workgroup with a column: w hi + m1 < nb
+    int seen = 0;
+    auto quit = [&]() { return __hip_atomic_load(words + 2 * NW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; };
+    if (wv >= nA) {
+        const int a = wv - nA, J = a * hi + m1;
+        if (a >= nA || J + 4 >= nb) {  // nobody to help: wait for the end of the fit (the workgroup leaves together)
+            while (wait_prog(ctl, 0x7fffffff, seen)) {
+            }
+            return;
+        }
+        v2f64 *slot = reinterpret_cast<v2f64 *>(slots + (size_t)a * 512);
+        for (int seq = 1;; ++seq) {
+            for (int r = J + 4; r < nb; ++r) {
+                const int need = seq * 64 + r - 4;  // A has stored W_{r-4,J} (and seen the progress word of that row)
+                int spins = 0;
+                while (__hip_atomic_load(words + a, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if ((++spins & 1023) == 0) {
+                        if (quit()) return;
+                        if (clu::ld(ctl + PROG) < 0) return;  // (the fit is over and A has gone without a word)
+                    }
+                }
+                const v4f64 acc = chain_sum(Cg, Wg, r, J, r - 3 - J, nb, lane);
+                v2f64 *q = slot + (size_t)(r & 1) * 128 + lane;
+                q[0] = v2f64{acc[0], acc[1]};
+                q[64] = v2f64{acc[2], acc[3]};
+                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the tile is in LDS
+                if (lane == 0) __hip_atomic_store(words + NW + a, seq * 64 + r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    // ---- A: the column's own wave ----
+    const int J = wv * hi + m1;
+    const bool hasB = nA + wv < NW && J + 4 < nb;
+    const v2f64 *slot = reinterpret_cast<const v2f64 *>(slots + (size_t)wv * 512);
+    Frag ident;  // B operand: the identity
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ident.v[q] = (4 * q + rg == cl) ? 1.0 : 0.0;
+    auto leave = [&]() {
+        if (lane == 0) __hip_atomic_store(words + 2 * NW, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    for (int seq = 1;; ++seq) {
+        double t2 = 0.0;
+        v4f64 acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = acc1, wprev = acc1;
+        for (int c = J; c < nb; ++c) {
+            if (!wait_prog(ctl, seq * clu::kSeq + c + 1, seen)) {
+                leave();
+                return;
+            }
+            v4f64 xp, la;  // X_cc = W_cc; mirror tile (c, c + 1): L_{c+1,c}
+            v4f64 l2a = {0.0, 0.0, 0.0, 0.0}, l2b = l2a;  // mirror tiles (c - 1, c + 2), (c, c + 2): L_{c+2,c-1}, L_{c+2,c}
+            if (hasB && c + 2 < nb) {
+                v2f64 t0, t1, t2r, t3, t4, t5, t6, t7;
+                const unsigned o0 = (unsigned)((c * nb + c) * 2048) + (unsigned)lane * 16u, o1 = o0 + 2048u, o3 = o0 + 4096u;
+                const unsigned o2 = (unsigned)(((c > J ? c - 1 : c) * nb + c + 2) * 2048) + (unsigned)lane * 16u;
+                asm volatile("s_nop 4\n\t"
+                             "global_load_dwordx4 %0, %8, %12 sc1\n\tglobal_load_dwordx4 %1, %8, %12 offset:1024 sc1\n\t"
+                             "global_load_dwordx4 %2, %9, %12 sc1\n\tglobal_load_dwordx4 %3, %9, %12 offset:1024 sc1\n\t"
+                             "global_load_dwordx4 %4, %10, %12 sc1\n\tglobal_load_dwordx4 %5, %10, %12 offset:1024 sc1\n\t"
+                             "global_load_dwordx4 %6, %11, %12 sc1\n\tglobal_load_dwordx4 %7, %11, %12 offset:1024 sc1\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(t0), "=&v"(t1), "=&v"(t2r), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+                             : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(Cg)
+                             : "memory");
+                xp = v4f64{t0[0], t0[1], t1[0], t1[1]};
+                la = v4f64{t2r[0], t2r[1], t3[0], t3[1]};
+                l2a = v4f64{t4[0], t4[1], t5[0], t5[1]};
+                l2b = v4f64{t6[0], t6[1], t7[0], t7[1]};
+            } else {
+                ld_pk_dev2(Cg, (unsigned)((c * nb + c) * 2048), Cg, (unsigned)((c * nb + (c + 1 < nb ? c + 1 : c)) * 2048), lane, xp, la);
+            }
+            v4f64 w;
+            if (J == c) {
+                w = xp;
+            } else {
+                // the A operand X_cc (element [cl][4 q + rg]) is the accumulator layout of X_cc^T: the packed tile used AS an A
+                // operand is X_cc^T, times the identity (exact)
+                v4f64 z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z = __builtin_amdgcn_mfma_f64_16x16x4f64(xp[q], ident.v[q], z, 0, 0, 0);
+                Frag fw, fs;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    fw.v[q] = z[q];
+                    fs.v[q] = acc1[q];
+                }
+                w = v4f64{0.0, 0.0, 0.0, 0.0};
+                w = mfma4(fw, fs, w, true);
+            }
+            st_pk(Wg, (unsigned)((c * nb + J) * 2048), lane, w);
+            if (c + 1 < nb) {  // the last product of row c + 1: the accumulator registers of W_cJ are its B fragments
+                acc1 = acc2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], w[q], acc1, 0, 0, 0);
+            }
+            double ssq = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (16 * c + rg + 4 * q < N) ssq = fma(w[q], w[q], ssq);
+            ssq += __shfl_xor(ssq, 16);
+            ssq += __shfl_xor(ssq, 32);
+            t2 += ssq;  // (rows in order, from 0.0: the sum solve_posterior forms from the tiles' column sums)
+            if (c == aug_tile) {  // row N of W: -m
+                double mv = w[0];
+                mv = (aug_r >> 2) == 1 ? w[1] : mv;
+                mv = (aug_r >> 2) == 2 ? w[2] : mv;
+                mv = (aug_r >> 2) == 3 ? w[3] : mv;
+                if (rg == (aug_r & 3) && 16 * J + cl < N) xg[P.NP + 16 * J + cl] = -mv;
+            }
+            if (c + 2 < nb) {  // the products K = J .. c of row c + 2 (columns <= c of L are final)
+                if (hasB) {
+                    v4f64 part = {0.0, 0.0, 0.0, 0.0};
+                    if (c - 2 >= J) {  // K = J .. c - 2: B's
+                        const int need = seq * 64 + c + 2;
+                        int spins = 0;
+                        while (__hip_atomic_load(words + NW + wv, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > (1 << 24)) break;  // (never observed; B gone: the fit ends with a wrong sum rather than hanging)
+                        }
+                        const v2f64 *q = slot + (size_t)((c + 2) & 1) * 128 + lane;
+                        const v2f64 p0 = q[0], p1 = q[64];
+                        part = v4f64{p0[0], p0[1], p1[0], p1[1]};
+                    }
+                    if (c - 1 >= J) {  // K = c - 1: W_{c-1,J} from last event's registers
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) part = __builtin_amdgcn_mfma_f64_16x16x4f64(l2a[q], wprev[q], part, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) part = __builtin_amdgcn_mfma_f64_16x16x4f64(l2b[q], w[q], part, 0, 0, 0);  // K = c
+                    acc2 = part;
+                } else {
+                    acc2 = chain_sum(Cg, Wg, c + 2, J, c - J + 1, nb, lane);
+                }
+            }
+            wprev = w;
+            if (hasB) {  // W_cJ is in the L2 (and this wave's L1): B may read it
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(words + wv, seq * 64 + c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (rg == 0 && 16 * J + cl < N) xg[16 * J + cl] = t2;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have reached the L2 before the count says so
+        if (lane == 0) add(ctl + DONE, 1);
+    }
+}
 }  // namespace clu
 
 // ---- one posterior solve: C = A + diag(1/p) -> L -> W = L^-1 -> y = W b, m = W^T y, tr2 = colnorm2(W) --------------
@@ -1863,7 +2031,11 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
             }
             const int hwave = __builtin_amdgcn_readfirstlane(tid >> 6);
             const int hi = clu::inv_helpers(P), ht = clu::trail_helpers(P);
-            if (member <= hi) clu::inverse_wave<2>(P, ctl, hwave * hi + (member - 1), hi * NW, tid & 63);
+            if (member <= hi) {
+                // (every wave at most one block column: the columns' second waves, see inverse_wave_paired)
+                if (!WIDE && hi * NW >= NP / 16) clu::inverse_wave_paired(P, ctl, hi, member - 1, hwave, tid & 63, smem);
+                else clu::inverse_wave<2>(P, ctl, hwave * hi + (member - 1), hi * NW, tid & 63);
+            }
             else clu::trailing_wave(P, ctl, hwave * ht + (member - 1 - hi), ht * NW, tid & 63, smem, hwave);
             __syncthreads();
             if (tid == 0) clu::add(ctl + clu::IN, -1);
