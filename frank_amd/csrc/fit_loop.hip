@@ -427,17 +427,42 @@ __device__ __forceinline__ void trailing_wave(const FitLoopParams &P, int *ctl, 
             if (tJ[i] >= 0) tt[i] = ld_pk(Ag, (unsigned)((tJ[i] * nb + tI[i]) * 2048), lane);
     };
     first_touch();
+    if (last < 0) {  // no band (too few helper waves for the tiles: band_of): nothing to do but leave with the others
+        while (wait_prog(ctl, 0x7fffffff, seen)) {
+        }
+        return;
+    }
     const int stage_tiles = nb - first;  // (per buffer)
+    volatile int *wflag = reinterpret_cast<volatile int *>(stage + 2 * (size_t)stage_tiles * 256);  // (behind the two buffers)
     for (int seq = 1;; ++seq) {
         for (int c = 0; c <= last; ++c) {
-            if (!wait_prog(ctl, seq * clu::kSeq + c + 1, seen)) return;
+            // ONE wave of the workgroup polls the progress word (sixty helper waves polling the same line slowed every poll of
+            // it, the first workgroup's included); the others hear of it at a barrier
+            if (wv == 0) {
+                const bool ok = wait_prog(ctl, seq * clu::kSeq + c + 1, seen);
+                if (lane == 0) *wflag = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (*wflag == 0) return;
             const int x0 = c + first;
             double *buf = stage + (size_t)(c & 1) * stage_tiles * 256;
-            for (int x = x0 + wv; x < nb; x += NW) {
-                const v4f64 v = ld_pk_dev(Cg, (unsigned)((c * nb + x) * 2048), lane);
-                v2f64 *q = reinterpret_cast<v2f64 *>(buf + (size_t)(x - x0) * 256) + lane;
-                q[0] = v2f64{v[0], v[1]};
-                q[64] = v2f64{v[2], v[3]};
+            {   // (at most two tiles per wave: nb - x0 <= 2 NW; both loads in flight together)
+                const int xa = x0 + wv, xb = xa + NW;
+                if (xb < nb) {
+                    v4f64 va, vb;
+                    ld_pk_dev2(Cg, (unsigned)((c * nb + xa) * 2048), Cg, (unsigned)((c * nb + xb) * 2048), lane, va, vb);
+                    v2f64 *qa = reinterpret_cast<v2f64 *>(buf + (size_t)(xa - x0) * 256) + lane;
+                    v2f64 *qb = reinterpret_cast<v2f64 *>(buf + (size_t)(xb - x0) * 256) + lane;
+                    qa[0] = v2f64{va[0], va[1]};
+                    qa[64] = v2f64{va[2], va[3]};
+                    qb[0] = v2f64{vb[0], vb[1]};
+                    qb[64] = v2f64{vb[2], vb[3]};
+                } else if (xa < nb) {
+                    const v4f64 v = ld_pk_dev(Cg, (unsigned)((c * nb + xa) * 2048), lane);
+                    v2f64 *q = reinterpret_cast<v2f64 *>(buf + (size_t)(xa - x0) * 256) + lane;
+                    q[0] = v2f64{v[0], v[1]};
+                    q[64] = v2f64{v[2], v[3]};
+                }
             }
             __syncthreads();  // (one per event: a wave cannot be two events ahead, the buffers alternate)
             int handed = 0;
@@ -467,8 +492,7 @@ __device__ __forceinline__ void trailing_wave(const FitLoopParams &P, int *ctl, 
                 if (lane == 0) add(ctl + HCOL + x0, handed);
             }
         }
-        first_touch();  // (for the next pass, before the wait for it)
-        if (!wait_prog(ctl, (seq + 1) * clu::kSeq + 1, seen)) return;  // the next pass (its first event) or the end of the fit
+        first_touch();  // (for the next pass, before the wait for it: its first event, or the end of the fit)
     }
 }
 // A wave of a helper of the INVERSE, for every pass of the fit: the block columns J = hw, hw + T, .. of W = L^-1.  At the event
