@@ -1594,8 +1594,6 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
                     const int I = 3 + widx + s2 * NWKc;
                     anyn = anyn || (I < nb && k + 1 <= I - 3);
                 }
-                if (anyn)
-                    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1" : "=&v"(hc) : "v"(0), "s"(ctl + clu::HCOL + k + 4) : "memory");
                 if (any) {
                     wait_flag();
                     TRACE(2);
@@ -1611,6 +1609,10 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
                         rB[s2] = rowC[s2];
                     }
                 }
+                // (as late as it can be and still return under arrive()'s wait for the stores above: the helpers hand the column
+                //  back ~1.5 us after the end of the step before; asked in front of the column tiles the word was often short)
+                if (anyn)
+                    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1" : "=&v"(hc) : "v"(0), "s"(ctl + clu::HCOL + k + 4) : "memory");
             } else {
                 int e = widx;
                 if (e < cnt) {
