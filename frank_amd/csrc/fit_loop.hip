@@ -731,7 +731,10 @@ __device__ __forceinline__ void inverse_wave_paired(const FitLoopParams &P, int 
                         int spins = 0;
                         while (__hip_atomic_load(words + NW + wv, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
                             __builtin_amdgcn_s_sleep(1);
-                            if (++spins > (1 << 24)) break;  // (never observed; B gone: the fit ends with a wrong sum rather than hanging)
+                            if (++spins > (1 << 22)) {  // (never observed.  B gone: this column is never reported done, the first
+                                leave();                //  workgroup's wait for the columns runs out and the host repeats the fit
+                                return;                 //  on one compute unit -- FIT_STATUS_CLUSTER -- rather than a wrong sum)
+                            }
                         }
                         const v2f64 *q = slot + (size_t)((c + 2) & 1) * 128 + lane;
                         const v2f64 p0 = q[0], p1 = q[64];
