@@ -287,7 +287,8 @@ const char *fh_last_warning(void) { return g_warn.c_str(); }
 const char *fh_last_error(void) { return g_err.c_str(); }
 // (the build stamp ties a profile under profiles/ to the binary it was taken from: tools/profile_r04.sh records it, bench.py
 //  prints the loaded library's beside the profile's)
-const char *fh_version(void) { return "frank_amd 0.4 (gfx950; built " __DATE__ " " __TIME__ ")"; }
+extern "C" const char *fh_build_stamp(void);  // version_stamp.cpp: compiled again whenever any object of the library changes
+const char *fh_version(void) { return fh_build_stamp(); }
 
 int fh_device_count(int *count) {
     int n = 0;
@@ -2898,14 +2899,25 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
         resb.alloc(2 * B) != hipSuccess || counter.alloc(1) != hipSuccess || stb.alloc(17 * B) != hipSuccess)
         return fail(FH_ERR_NOMEM, "fh_fit_lognormal_batched: device allocation for %d fits failed", batch);
     HIP_TRY(hipMemsetAsync(counter.p, 0, sizeof(int), c->stream));
-    std::vector<double> lu_all(B * 5 * N), lu;
-    for (int b = 0; b < batch; ++b) {
-        smoothing_band_lu(*c->dht, wsmooth[b], lu);
-        memcpy(lu_all.data() + (size_t)b * 5 * N, lu.data(), sizeof(double) * 5 * N);
+    // The workgroups pull the fits in launch order and the launch ends with its slowest fit: as in fh_fit_normal_batched the
+    // points most likely to run to max_iter -- alpha next to 1 (filter.py:172), then the weaker smoothing prior -- go first.
+    // order[k] = the caller's index of the fit launched k-th; the outputs are put back in the caller's order.
+    std::vector<int> order(B);
+    for (int b = 0; b < batch; ++b) order[b] = b;
+    if (!getenv("FRANK_AMD_SWEEP_GRID_ORDER"))
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+            return alpha[x] != alpha[y] ? alpha[x] < alpha[y] : wsmooth[x] < wsmooth[y];
+        });
+    std::vector<double> lu_all(B * 5 * N), lu, al_o(B), p0_o(B);
+    for (int k = 0; k < batch; ++k) {
+        smoothing_band_lu(*c->dht, wsmooth[order[k]], lu);
+        memcpy(lu_all.data() + (size_t)k * 5 * N, lu.data(), sizeof(double) * 5 * N);
+        al_o[k] = alpha[order[k]];
+        p0_o[k] = p0[order[k]];
     }
     HIP_TRY(hipMemcpyAsync(lub.p, lu_all.data(), sizeof(double) * lu_all.size(), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(alb.p, alpha, sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(p0b.p, p0, sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(alb.p, al_o.data(), sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(p0b.p, p0_o.data(), sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
     P.mode = LN_MODE_FIT;
     P.max_iter = max_iter;
     P.tol = tol;
@@ -2929,16 +2941,19 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
     std::vector<long long> st(17 * B);
     HIP_TRY(hipMemcpyAsync(res.data(), resb.p, sizeof(int) * 2 * B, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(st.data(), stb.p, sizeof(long long) * 17 * B, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(s_map, sb.p, sizeof(double) * B * N, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(p, pb.p, sizeof(double) * B * N, hipMemcpyDeviceToHost, c->stream));
+    for (int k = 0; k < batch; ++k) {  // launch order -> the caller's
+        HIP_TRY(hipMemcpyAsync(s_map + (size_t)order[k] * N, sb.p + (size_t)k * N, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(p + (size_t)order[k] * N, pb.p + (size_t)k * N, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int b = 0; b < batch; ++b) {
-        niter[b] = res[2 * b];
+    for (int k = 0; k < batch; ++k) {
+        const int b = order[k];
+        niter[b] = res[2 * k];
         if (status)
-            status[b] = res[2 * b + 1] == LN_STATUS_BAD_P ? FH_ERR_BAD_P
-                        : res[2 * b + 1] == LN_STATUS_SLOPE ? FH_ERR_NUMERIC : FH_OK;
+            status[b] = res[2 * k + 1] == LN_STATUS_BAD_P ? FH_ERR_BAD_P
+                        : res[2 * k + 1] == LN_STATUS_SLOPE ? FH_ERR_NUMERIC : FH_OK;
         if (stats)
-            for (int k = 0; k < 9; ++k) stats[9 * b + k] = st[17 * (size_t)b + k];
+            for (int q = 0; q < 9; ++q) stats[9 * b + q] = st[17 * (size_t)k + q];
     }
     return FH_OK;
 }

@@ -573,8 +573,9 @@ def test_lognormal_sweep_batched(golden):
     _load_mapping(FF, g)
     pre = dict(M=FF._M, j=FF._j, null_likelihood=FF._H0, hash=None)
     FF._vis_map.check_hash = lambda *a, **k: True
-    alphas = [1.05, 1.05, 1.2, 1.2, 1.3, 1.3]
-    ws = [1e-4, 1e-2, 1e-4, 1e-2, 1e-4, 1e-1]
+    # (not in the order the launch takes them -- ascending alpha, then w_smooth --: the outputs come back in the caller's)
+    alphas = [1.3, 1.05, 1.2, 1.2, 1.05, 1.3]
+    ws = [1e-1, 1e-2, 1e-4, 1e-2, 1e-4, 1e-4]
     sols, niters = sweep_fits(FF, pre, alphas, ws, max_iter=60)
     assert len(sols) == 6
     for b in (0, 3, 5):
