@@ -245,6 +245,9 @@ struct fh_ctx {
     DevBuf<int> ln_result, ln_ctl;
     DevBuf<double> ln_cluster_vecs;  // 1 / p, diag(L), Tr2: what the helper workgroups of a cluster exchange with the first
     DevBuf<long long> ln_stats;
+    // LogNormal beyond N = 320 (lognormal_wide.hip)
+    DevBuf<double> lnw_Sinv, lnw_H, lnw_vec, lnw_scal, lnw_diag_s;
+    DevBuf<rocblas_int> lnw_ipiv;
 };
 
 // bits [first, last) of a 256-bit compute-unit mask
@@ -2747,11 +2750,367 @@ static int ln_finish(fh_ctx *c, double *s, double *p, double *Dinv, int64_t *sta
     return FH_OK;
 }
 
+// ---- method='LogNormal' for 320 < N <= 1023: MinimizeNewton / LineSearch on the host, everything else on the device ----------
+// (lognormal_wide.hip; minimizer.py:70-283, statistical_models.py:1064-1160.  The persistent kernel ends at N = 320.)
+struct LnWide {
+    fh_ctx *c;
+    LnWideParams P{};
+    double *dir_nj = nullptr, *pdir = nullptr;  // -jac (steepest descent), the limited step
+    double reduction = NAN;                     // LineSearch.reduction (None until the first success)
+    long long nfev = 0, nhess = 0, nstep = 0;
+    double scal[8];
+
+    int setup(double s0) {
+        const int N = c->N;
+        const size_t NN = (size_t)N * N;
+        if (!c->lnw_Sinv.p) {
+            HIP_TRY(c->lnw_Sinv.alloc(NN));
+            HIP_TRY(c->lnw_H.alloc(NN));
+            HIP_TRY(c->lnw_vec.alloc(12 * (size_t)N));
+            HIP_TRY(c->lnw_scal.alloc(8));
+            HIP_TRY(c->lnw_ipiv.alloc(N));
+        }
+        FitState st = make_state(c);
+        P.N = N;
+        P.s0 = s0;
+        P.transform_norm = st.transform_norm;
+        P.M = c->M.p;
+        P.j = c->j.p;
+        P.Y = c->Y.p;
+        P.Ykm = c->Ykm.p;
+        P.q = c->q.p;
+        P.mu = c->mu.p;
+        P.Sinv = c->lnw_Sinv.p;
+        P.W = c->W.p;
+        P.p = c->p.p;
+        P.p_old = c->p_old.p;
+        P.flags = c->flags.p;
+        double *v = c->lnw_vec.p;
+        P.x = v, P.xn = v + N, P.I = v + 2 * N, P.t1 = v + 3 * N, P.t2 = v + 4 * N, P.fr = v + 5 * N, P.jx = v + 6 * N, P.dx = v + 7 * N;
+        dir_nj = v + 8 * N;
+        pdir = v + 9 * N;
+        P.scal = c->lnw_scal.p;
+        return FH_OK;
+    }
+    int read_scal() {
+        HIP_TRY(hipMemcpyAsync(scal, P.scal, sizeof scal, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return FH_OK;
+    }
+    // H(x + lam dir) (dir = NULL: H(x)); the trial point and its products stay in xn, I, t1, t2
+    int fun(const double *dir, double lam, double *f, bool *same) {
+        HIP_TRY(fh_lnw_launch_eval(P, P.x, dir, lam, c->stream));
+        int rc = read_scal();
+        if (rc) return rc;
+        *f = scal[0];
+        if (same) *same = scal[1] != 0.0;
+        return FH_OK;
+    }
+    int accept() {  // x <- xn
+        HIP_TRY(hipMemcpyAsync(P.x, P.xn, sizeof(double) * c->N, hipMemcpyDeviceToDevice, c->stream));
+        return FH_OK;
+    }
+    // LineSearch.__call__(func, jac, x0, p, f0, root=False) with reduce_step = limit_step (minimizer.py:70-187).
+    // failed: 0 / 1; returns FH_ERR_NUMERIC for "Round off in slope calculation" (the reference raises ValueError there).
+    int line_search(const double *dir, double *f0, int *failed) {
+        const double armijo = 1e-4, l_min = 0.1;
+        const double cost = *f0;
+        HIP_TRY(fh_lnw_launch_limit_step(P, P.x, dir, pdir, c->stream));
+        int rc = read_scal();
+        if (rc) return rc;
+        const double delta_f = scal[3];
+        if (delta_f > 0) return FH_ERR_NUMERIC;
+        double lam = 1.0, cost_save = 0, lam_save = 0;
+        for (;;) {
+            double cost_new;
+            bool same;
+            rc = fun(pdir, lam, &cost_new, &same);
+            if (rc) return rc;
+            if (same) {  // (the reference tests x_new == x0 before it evaluates: no evaluation counted)
+                *failed = 1;
+                return FH_OK;
+            }
+            ++nfev;
+            if (cost_new <= (cost + armijo * lam * delta_f)) {
+                reduction = lam;
+                rc = accept();
+                if (rc) return rc;
+                *f0 = cost_new;
+                *failed = 0;
+                return FH_OK;
+            }
+            double lam_new;
+            if (lam == 1.0) {
+                lam_new = -0.5 * delta_f / (cost_new - cost - delta_f);
+            } else {
+                const double r1 = (cost_new - cost - lam * delta_f) / (lam * lam);
+                const double r2 = (cost_save - cost - lam_save * delta_f) / (lam_save * lam_save);
+                const double a = (r1 - r2) / (lam - lam_save);
+                const double b = (lam * r2 - lam_save * r1) / (lam - lam_save);
+                if (a == 0) {
+                    lam_new = -0.5 * delta_f / b;
+                } else {
+                    const double d = b * b - 3 * a * delta_f;
+                    if (d < 0) lam_new = 0.5 * lam;
+                    else if (b <= 0) lam_new = (-b + sqrt(d)) / (3 * a);
+                    else lam_new = -1 * delta_f / (b + sqrt(d));
+                    lam_new = (lam_new < 0.5 * lam) ? lam_new : 0.5 * lam;  // min(0.5 lam, lam_new)
+                }
+            }
+            if (lam_new != lam_new) lam_new = l_min * lam;
+            lam_save = lam;
+            cost_save = cost_new;
+            lam = (l_min * lam > lam_new) ? l_min * lam : lam_new;  // max(lam_new, l_min lam)
+        }
+    }
+    // MinimizeNewton(fun, jac, hess, x, LineSearch(reduce_step=limit_step), tol) (minimizer.py:190-283); x in P.x.
+    // status: 0 converged, 1 no improvement, 2 max steps, 3 max Hessians, 4 slope round-off
+    int minimize(double tol, long long max_step, long long max_hev, int *status) {
+        const int N = c->N;
+        bool need_hess = true;
+        nfev = 1, nhess = 0, nstep = 0;
+        reduction = NAN;
+        double fx;
+        int rc = fun(nullptr, 0.0, &fx, nullptr);
+        if (rc) return rc;
+        for (nstep = 0; nstep < max_step; ++nstep) {
+            // (xn, I, t1, t2 hold the products of x here: the evaluation in front of the loop, or the one that ends a step)
+            if (need_hess) {
+                if (nhess == max_hev) {
+                    *status = 3;
+                    return FH_OK;
+                }
+                HIP_TRY(fh_lnw_launch_hess(P, c->lnw_H.p, c->stream));
+                ROC_TRY(rocsolver_dgetrf(c->blas, N, N, c->lnw_H.p, N, c->lnw_ipiv.p, c->info.p));  // (symmetric: either major)
+                ++nhess;
+            }
+            HIP_TRY(fh_lnw_launch_jac(P, c->stream));  // jx, dx = -jx
+            ROC_TRY(rocsolver_dgetrs(c->blas, rocblas_operation_none, N, 1, c->lnw_H.p, N, c->lnw_ipiv.p, P.dx, N));
+            // dot(jac, dx) < 0 ?  (the limit-step kernel also gives jac . dir)
+            HIP_TRY(fh_lnw_launch_limit_step(P, P.x, P.dx, pdir, c->stream));
+            rc = read_scal();
+            if (rc) return rc;
+            int failed = 1;
+            if (scal[4] < 0) {
+                rc = line_search(P.dx, &fx, &failed);
+                if (rc == FH_ERR_NUMERIC) {
+                    *status = 4;
+                    return FH_OK;
+                }
+                if (rc) return rc;
+            }
+            if (failed) {
+                // steepest descent (minimizer.py:236-244).  A failed search has left x alone but its trials have replaced the
+                // products: evaluate x again (not one of the reference's evaluations), then jx and dx = -jx
+                double fx_again;
+                rc = fun(nullptr, 0.0, &fx_again, nullptr);
+                if (rc) return rc;
+                HIP_TRY(fh_lnw_launch_jac(P, c->stream));
+                HIP_TRY(hipMemcpyAsync(dir_nj, P.dx, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
+                int failed_descent = 1;
+                rc = line_search(dir_nj, &fx, &failed_descent);
+                if (rc == FH_ERR_NUMERIC) {
+                    *status = 4;
+                    return FH_OK;
+                }
+                if (rc) return rc;
+                if (failed_descent) {  // minimizer.py:246-262: ten ever smaller steps along the limited steepest descent
+                    HIP_TRY(fh_lnw_launch_limit_step(P, P.x, dir_nj, pdir, c->stream));
+                    double scale = 1.0, fn = fx;
+                    bool improved = false;
+                    for (int it = 0; it < 10; ++it) {
+                        rc = fun(pdir, scale, &fn, nullptr);
+                        if (rc) return rc;
+                        ++nfev;
+                        if (fn < fx) {
+                            improved = true;
+                            break;
+                        }
+                        scale *= 0.0625;
+                    }
+                    if (!improved) {
+                        *status = 1;
+                        return FH_OK;
+                    }
+                    fx = fn;
+                    rc = accept();
+                    if (rc) return rc;
+                }
+            }
+            need_hess = failed || (reduction != 1.0);
+            rc = fun(nullptr, 0.0, &fx, nullptr);  // the products of the new x
+            if (rc) return rc;
+            HIP_TRY(fh_lnw_launch_jac(P, c->stream));
+            rc = read_scal();
+            if (rc) return rc;
+            const double g = scal[2], scl = fabs(fx) > 1 ? fabs(fx) : 1;
+            if (g < tol * scl) {
+                *status = 0;
+                return FH_OK;
+            }
+        }
+        *status = 2;
+        nstep = max_step - 1;  // (python: the loop variable after exhaustion)
+        return FH_OK;
+    }
+    // LogNormalMAPModel(DHT, M, j, p, guess, s0): p in c->p, the guess in P.x; MAP -> P.x, hess(MAP) -> c->lnw_H.
+    // totals: [0] solves, [1] steps, [2] evaluations, [3] Hessians, [4 + status] exits
+    int map(long long totals[9]) {
+        const int N = c->N;
+        const double one = 1.0, zero = 0.0;
+        HIP_TRY(fh_lnw_launch_scale(P, c->stream));
+        // S^-1 = Y^T diag(1/p) Y: column-major views of the row-major buffers are the transposes; S^-1 is symmetric
+        ROC_TRY(rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, N, N, N, &one, c->Y.p, N, c->W.p, N,
+                              &zero, c->lnw_Sinv.p, N));
+        int status = 2;
+        int rc = minimize(1e-7, 100000, 1000, &status);  // statistical_models.py:1141, minimizer.py:190
+        if (rc) return rc;
+        ++totals[0];
+        totals[1] += nstep;
+        totals[2] += nfev;
+        totals[3] += nhess;
+        ++totals[4 + status];
+        if (status == 4) return fail(FH_ERR_NUMERIC, "Round off in slope calculation (LineSearch)");
+        double f;
+        rc = fun(nullptr, 0.0, &f, nullptr);
+        if (rc) return rc;
+        HIP_TRY(fh_lnw_launch_hess(P, c->lnw_H.p, c->stream));  // Dinv = hess(s_MAP), statistical_models.py:1147
+        return FH_OK;
+    }
+};
+
+static int ln_wide_ready(fh_ctx *c, const double *M, const double *j) {
+    const int N = c->N;
+    if (N > FIT_MAX_N - 1) return fail(FH_ERR_UNSUPPORTED, "N = %d > %d", N, FIT_MAX_N - 1);
+    if ((M == nullptr) != (j == nullptr)) return fail(FH_ERR_INVALID, "pass both M and j or neither");
+    if (!M && !c->have_device_Mj) return fail(FH_ERR_INVALID, "no device-resident M, j (run fh_stats_finalize)");
+    HIP_TRY(hipSetDevice(c->device));
+    if (M) {
+        HIP_TRY(hipMemcpyAsync(c->M.p, M, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->j.p, j, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+        c->have_device_Mj = false;
+    }
+    return FH_OK;
+}
+
+// CriticalFilter.update_power_spectrum(fit) for a posterior (map in c->mu, precision in c->D) on the library loop's kernels:
+// Cholesky of the precision, Tr2 from the triangular solve of Y^T, fit_update_kernel (filter.py:154-177)
+static int ln_wide_factor_for_update(fh_ctx *c) {
+    const int N = c->N;
+    const double one = 1.0;
+    HIP_TRY(hipMemcpyAsync(c->Z.p, c->Y.p, sizeof(double) * (size_t)N * N, hipMemcpyDeviceToDevice, c->stream));
+    ROC_TRY(rocsolver_dpotrf(c->blas, rocblas_fill_lower, N, c->D.p, N, c->info.p));
+    ROC_TRY(rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, N,
+                          &one, c->D.p, N, c->Z.p, N));
+    return FH_OK;
+}
+
+static int lognormal_model_wide(fh_ctx *c, const double *M, const double *j, const double *p, const double *guess, double s0,
+                                double *s_map, double *Dinv, int64_t *stats) {
+    int rc = ln_wide_ready(c, M, j);
+    if (rc) return rc;
+    const int N = c->N;
+    LnWide w{c};
+    rc = w.setup(s0);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->p.p, p, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(w.P.x, guess, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    long long totals[9] = {0};
+    rc = w.map(totals);
+    if (stats)
+        for (int k = 0; k < 9; ++k) stats[k] = totals[k];
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(s_map, w.P.x, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    if (Dinv) HIP_TRY(hipMemcpyAsync(Dinv, c->lnw_H.p, sizeof(double) * (size_t)N * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
+static int fit_lognormal_wide(fh_ctx *c, const double *M, const double *j, double alpha, double p0, double wsmooth, double tol,
+                              int max_iter, double I_scale, double *s_map, double *p, int *niter, double *Dinv, int64_t *stats,
+                              double *diag_p, double *diag_s) {
+    int rc = ln_wide_ready(c, M, j);
+    if (rc) return rc;
+    const int N = c->N;
+    const size_t NN = (size_t)N * N;
+    std::vector<double> lu;
+    smoothing_band_lu(*c->dht, wsmooth, lu);
+    HIP_TRY(hipMemcpyAsync(c->band_lu.p, lu.data(), sizeof(double) * lu.size(), hipMemcpyHostToDevice, c->stream));
+    const bool want_diag = diag_p != nullptr;
+    if (want_diag) {
+        const size_t need = (size_t)(max_iter + 1) * N;
+        if (c->diag_p.n < need) HIP_TRY(c->diag_p.alloc(need));
+        if (c->lnw_diag_s.n < need) HIP_TRY(c->lnw_diag_s.alloc(need));
+    }
+    FitState st = make_state(c);
+    st.alpha = alpha;
+    st.p0 = p0;
+    st.tol = tol;
+    st.max_iter = max_iter;
+    st.diag_p = want_diag ? c->diag_p.p : nullptr;
+    st.diag_mu = nullptr;
+    // radial_fitters.py:744-752: p = 1 -> Normal fit -> power-law guess -> Normal fit (the library loop's kernels)
+    HIP_TRY(fh_k2_launch_init(st, c->stream));
+    rc = solve_posterior(c, st, true, false);
+    if (rc) return rc;
+    HIP_TRY(fh_k2_launch_powerlaw(st, c->stream));
+    rc = solve_posterior(c, st, true, false);
+    if (rc) return rc;
+    int flags[FIT_NFLAGS] = {0}, info = 0;
+    HIP_TRY(hipMemcpyAsync(flags, c->flags.p, sizeof flags, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&info, c->info.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (flags[FIT_FLAG_NOT_SPD] || info != 0)
+        return fail(FH_ERR_NOT_SPD, "Cholesky of a seed fit failed (the reference would switch to an SVD)");
+    LnWide w{c};
+    rc = w.setup(log(I_scale));  // radial_fitters.py:712
+    if (rc) return rc;
+    HIP_TRY(fh_lnw_launch_seed(w.P, c->stream));  // :756-768
+    long long totals[9] = {0};
+    rc = w.map(totals);
+    int count = 0;
+    while (rc == FH_OK) {  // `while not converged and count <= max_iter` (:769-785); the update kernel holds the condition
+        HIP_TRY(hipMemcpyAsync(c->D.p, c->lnw_H.p, sizeof(double) * NN, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->mu.p, w.P.x, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
+        rc = ln_wide_factor_for_update(c);
+        if (rc) break;
+        HIP_TRY(fh_k2_launch_update(st, c->stream));
+        HIP_TRY(hipMemcpyAsync(flags, c->flags.p, sizeof flags, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        count = flags[FIT_FLAG_COUNT];
+        if (flags[FIT_FLAG_NOT_SPD]) {
+            rc = fail(FH_ERR_NOT_SPD, "Cholesky of the Hessian at the MAP failed at iteration %d (the reference would switch to an SVD)", count);
+            break;
+        }
+        if (flags[FIT_FLAG_DONE]) break;
+        rc = w.map(totals);
+        if (rc == FH_OK && want_diag)
+            HIP_TRY(hipMemcpyAsync(c->lnw_diag_s.p + (size_t)(count - 1) * N, w.P.x, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (stats)
+        for (int k = 0; k < 9; ++k) stats[k] = totals[k];
+    *niter = count;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(flags, c->flags.p, sizeof flags, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(s_map, w.P.x, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(p, c->p.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    if (Dinv) HIP_TRY(hipMemcpyAsync(Dinv, c->lnw_H.p, sizeof(double) * NN, hipMemcpyDeviceToHost, c->stream));
+    const size_t nd = (size_t)count * N;
+    if (want_diag && nd) {
+        HIP_TRY(hipMemcpyAsync(diag_p, c->diag_p.p, sizeof(double) * nd, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(diag_s, c->lnw_diag_s.p, sizeof(double) * nd, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (flags[FIT_FLAG_BAD_P]) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (non-positive or NaN)");
+    return FH_OK;
+}
+
 int fh_lognormal_model(fh_ctx *c, const double *M, const double *j, const double *p, const double *guess, double s0,
                        double *s_map, double *Dinv, int64_t *stats) {
     if (!c || !p || !guess || !s_map) return fail(FH_ERR_INVALID, "fh_lognormal_model: NULL argument");
     for (int k = 0; k < c->N; ++k)
         if (!(p[k] > 0.0)) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (p[%d] = %g)", k, p[k]);
+    if (c->N > 320) return lognormal_model_wide(c, M, j, p, guess, s0, s_map, Dinv, stats);  // (the host-driven route)
     LogNormalParams P;
     int rc = ln_prepare(c, M, j, P);
     if (rc) return rc;
@@ -2773,8 +3132,8 @@ int fh_fit_lognormal(fh_ctx *c, const double *M, const double *j, double alpha, 
     if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
     if (!(I_scale > 0)) return fail(FH_ERR_INVALID, "I_scale must be positive");
     if ((diag_p == nullptr) != (diag_s == nullptr)) return fail(FH_ERR_INVALID, "pass both diag_p and diag_s or neither");
-    if (c->N > 320 || c->NP > fh_k2_loop_max_np())  // (the two Normal seed fits run on the fit loop)
-        return fail(FH_ERR_UNSUPPORTED, "N = %d: the LogNormal kernel covers N <= 320", c->N);
+    if (c->N > 320)  // (beyond the persistent kernel: the host-driven route, lognormal_wide.hip)
+        return fit_lognormal_wide(c, M, j, alpha, p0, wsmooth, tol, max_iter, I_scale, s_map, p, niter, Dinv, stats, diag_p, diag_s);
     LogNormalParams P;
     int rc = ln_prepare(c, M, j, P);
     if (rc) return rc;
@@ -2843,6 +3202,32 @@ int fh_posterior_update(fh_ctx *c, const double *map, const double *Dinv, const 
     const int N = c->N;
     for (int k = 0; k < N; ++k)
         if (!(p[k] > 0.0)) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (p[%d] = %g)", k, p[k]);
+    if (N > 320) {  // beyond the persistent kernel: the library loop's kernels (Cholesky of the precision; filter.py:154-177)
+        HIP_TRY(hipSetDevice(c->device));
+        std::vector<double> luw;
+        smoothing_band_lu(*c->dht, wsmooth, luw);
+        HIP_TRY(hipMemcpyAsync(c->band_lu.p, luw.data(), sizeof(double) * luw.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->p.p, p, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(c->p_old.p, 0, sizeof(double) * N, c->stream));  // (|p - 0| <= tol p fails: the kernel updates)
+        HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int) * FIT_NFLAGS, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->mu.p, map, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->D.p, Dinv, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, c->stream));
+        int rcw = ln_wide_factor_for_update(c);
+        if (rcw) return rcw;
+        FitState st = make_state(c);
+        st.alpha = alpha;
+        st.p0 = p0;
+        st.tol = 0.0;
+        st.max_iter = 1 << 30;
+        HIP_TRY(fh_k2_launch_update(st, c->stream));
+        int flags[FIT_NFLAGS];
+        HIP_TRY(hipMemcpyAsync(flags, c->flags.p, sizeof flags, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(p_new, c->p.p, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (flags[FIT_FLAG_NOT_SPD])
+            return fail(FH_ERR_NOT_SPD, "Cholesky of the posterior precision failed (the reference would switch to an SVD)");
+        return FH_OK;
+    }
     LogNormalParams P;
     const bool keep = c->have_device_Mj;
     c->have_device_Mj = true;  // M, j are not touched by this mode
@@ -2872,8 +3257,21 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
         return fail(FH_ERR_INVALID, "fh_fit_lognormal_batched: bad argument");
     if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
     if (!(I_scale > 0)) return fail(FH_ERR_INVALID, "I_scale must be positive");
-    if (c->N > 320 || c->NP > fh_k2_loop_max_np())  // (the two Normal seed fits run on the fit loop)
-        return fail(FH_ERR_UNSUPPORTED, "N = %d: the LogNormal kernel covers N <= 320", c->N);
+    if (c->N > 320) {  // beyond the persistent kernel: the host-driven route, one point after the other
+        for (int b = 0; b < batch; ++b) {
+            const int rcb = fit_lognormal_wide(c, b == 0 ? M : nullptr, b == 0 ? j : nullptr, alpha[b], p0[b], wsmooth[b], tol, max_iter,
+                                               I_scale, s_map + (size_t)b * c->N, p + (size_t)b * c->N, niter + b, nullptr,
+                                               stats ? stats + 9 * (size_t)b : nullptr, nullptr, nullptr);
+            if (b == 0 && M) c->have_device_Mj = true;  // (uploaded by the first point)
+            if (status) status[b] = rcb == FH_ERR_BAD_P || rcb == FH_ERR_NUMERIC ? rcb : FH_OK;
+            if (rcb != FH_OK && rcb != FH_ERR_BAD_P && rcb != FH_ERR_NUMERIC) {
+                if (M) c->have_device_Mj = false;
+                return rcb;
+            }
+        }
+        if (M) c->have_device_Mj = false;
+        return FH_OK;
+    }
     LogNormalParams P;
     int rc = ln_prepare(c, M, j, P);
     if (rc) return rc;

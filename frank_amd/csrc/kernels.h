@@ -190,6 +190,25 @@ hipError_t fh_k2_launch_update(const FitState &st, hipStream_t s);
 hipError_t fh_k2_launch_record(const FitState &st, hipStream_t s);
 hipError_t fh_k2_launch_pinv_scale(const double *s, int n, double *s1, hipStream_t st);
 
+// ---- method='LogNormal' for 320 < N <= 1023 (lognormal_wide.hip; the host drives MinimizeNewton, capi.hip) ----------------
+struct LnWideParams {
+    int N;
+    double s0, transform_norm;
+    const double *M, *j, *Y, *Ykm, *q;  // device
+    const double *mu;                   // the Normal seed fit (seed kernel)
+    double *Sinv, *W;                   // N*N each: S^-1 = Y^T diag(1/p) Y, its left factor diag(1/p) Y
+    double *p, *p_old;                  // the power spectrum (the fit loop's buffers)
+    int *flags;                         // FIT_NFLAGS (the library loop's)
+    double *x, *xn, *I, *t1, *t2, *fr, *jx, *dx;  // N each: the point, the last trial point and its I, S^-1 xn, M I, summands
+    double *scal;                       // 8: [0] H(xn), [1] xn == x, [2] max |jac||x|, [3] jac.p, [4] jac.dir
+};
+hipError_t fh_lnw_launch_seed(const LnWideParams &P, hipStream_t s);
+hipError_t fh_lnw_launch_scale(const LnWideParams &P, hipStream_t s);
+hipError_t fh_lnw_launch_eval(const LnWideParams &P, const double *x, const double *dir, double lam, hipStream_t s);
+hipError_t fh_lnw_launch_jac(const LnWideParams &P, hipStream_t s);
+hipError_t fh_lnw_launch_hess(const LnWideParams &P, double *H, hipStream_t s);
+hipError_t fh_lnw_launch_limit_step(const LnWideParams &P, const double *x, const double *dir, double *p, hipStream_t s);
+
 // ---- K2 v2: single persistent kernel (fit_loop.hip) ---------------------------------------------------------
 enum { FIT_MODE_FULL = 0, FIT_MODE_STEP = 1, FIT_MODE_SOLVE = 2 };
 enum { FIT_STATUS_OK = 0, FIT_STATUS_BAD_P = 1, FIT_STATUS_NOT_SPD = 2, FIT_STATUS_CLUSTER = 3 };
