@@ -304,7 +304,9 @@ int fh_update_power_spectrum(fh_ctx *ctx, const double *M, const double *j, cons
  * 1147; may be NULL); stats (9 x int64, may be NULL): MAP solves, Newton steps, function evaluations, Hessian
  * factorisations, then the number of MinimizeNewton exits with status 0 (converged), 1 (no improvement), 2 (max
  * steps), 3 (max Hessians), 4 (slope round-off -> FH_ERR_NUMERIC).  As in the reference the exit status of the
- * minimiser is otherwise ignored (statistical_models.py:1142-1145).                                             */
+ * minimiser is otherwise ignored (statistical_models.py:1142-1145).  N <= 320: one persistent kernel (lognormal.hip);
+ * 320 < N <= 1023: the minimiser's control flow on the host over device kernels (lognormal_wide.hip), the reference's
+ * line search; the same holds for fh_fit_lognormal, fh_fit_lognormal_batched and fh_posterior_update.           */
 int fh_lognormal_model(fh_ctx *ctx, const double *M, const double *j, const double *p, const double *guess, double s0,
                        double *s_map, double *Dinv, int64_t *stats);
 
