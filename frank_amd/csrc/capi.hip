@@ -246,7 +246,7 @@ struct fh_ctx {
     DevBuf<double> ln_cluster_vecs;  // 1 / p, diag(L), Tr2: what the helper workgroups of a cluster exchange with the first
     DevBuf<long long> ln_stats;
     // LogNormal beyond N = 320 (lognormal_wide.hip)
-    DevBuf<double> lnw_Sinv, lnw_H, lnw_vec, lnw_scal, lnw_diag_s;
+    DevBuf<double> lnw_Sinv, lnw_H, lnw_Hinv, lnw_vec, lnw_scal, lnw_diag_s;
     DevBuf<rocblas_int> lnw_ipiv;
 };
 
@@ -2757,6 +2757,7 @@ struct LnWide {
     LnWideParams P{};
     double *dir_nj = nullptr, *pdir = nullptr;  // -jac (steepest descent), the limited step
     double reduction = NAN;                     // LineSearch.reduction (None until the first success)
+    bool linear = true;                         // S^-1 (x + lam p) = S^-1 x + lam S^-1 p along a search ('linear'); false: multiplied out
     long long nfev = 0, nhess = 0, nstep = 0;
     double scal[8];
 
@@ -2766,6 +2767,7 @@ struct LnWide {
         if (!c->lnw_Sinv.p) {
             HIP_TRY(c->lnw_Sinv.alloc(NN));
             HIP_TRY(c->lnw_H.alloc(NN));
+            HIP_TRY(c->lnw_Hinv.alloc(NN));
             HIP_TRY(c->lnw_vec.alloc(12 * (size_t)N));
             HIP_TRY(c->lnw_scal.alloc(8));
             HIP_TRY(c->lnw_ipiv.alloc(N));
@@ -2789,6 +2791,9 @@ struct LnWide {
         P.x = v, P.xn = v + N, P.I = v + 2 * N, P.t1 = v + 3 * N, P.t2 = v + 4 * N, P.fr = v + 5 * N, P.jx = v + 6 * N, P.dx = v + 7 * N;
         dir_nj = v + 8 * N;
         pdir = v + 9 * N;
+        P.Sx = v + 10 * N;
+        P.Sp = v + 11 * N;
+        linear = !c->ln_fresh_products;
         P.scal = c->lnw_scal.p;
         return FH_OK;
     }
@@ -2798,34 +2803,47 @@ struct LnWide {
         return FH_OK;
     }
     // H(x + lam dir) (dir = NULL: H(x)); the trial point and its products stay in xn, I, t1, t2
-    int fun(const double *dir, double lam, double *f, bool *same) {
-        HIP_TRY(fh_lnw_launch_eval(P, P.x, dir, lam, c->stream));
+    int fun(const double *dir, double lam, double *f, bool *same, int mode = 0) {
+        HIP_TRY(fh_lnw_launch_eval(P, P.x, dir, lam, mode, c->stream));
         int rc = read_scal();
         if (rc) return rc;
         *f = scal[0];
         if (same) *same = scal[1] != 0.0;
         return FH_OK;
     }
-    int accept() {  // x <- xn
+    int accept() {  // x <- xn (and its S^-1 x)
         HIP_TRY(hipMemcpyAsync(P.x, P.xn, sizeof(double) * c->N, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(P.Sx, P.t1, sizeof(double) * c->N, hipMemcpyDeviceToDevice, c->stream));
         return FH_OK;
     }
     // LineSearch.__call__(func, jac, x0, p, f0, root=False) with reduce_step = limit_step (minimizer.py:70-187).
     // failed: 0 / 1; returns FH_ERR_NUMERIC for "Round off in slope calculation" (the reference raises ValueError there).
-    int line_search(const double *dir, double *f0, int *failed) {
+    // have_first: limit_step(dir) and the trial at lam = 1 were submitted with the step and are in `scal` already
+    int line_search(const double *dir, double *f0, int *failed, bool have_first = false) {
         const double armijo = 1e-4, l_min = 0.1;
         const double cost = *f0;
-        HIP_TRY(fh_lnw_launch_limit_step(P, P.x, dir, pdir, c->stream));
-        int rc = read_scal();
-        if (rc) return rc;
+        int rc;
+        if (!have_first) {
+            HIP_TRY(fh_lnw_launch_limit_step(P, P.x, dir, pdir, c->stream));
+            rc = read_scal();
+            if (rc) return rc;
+        }
         const double delta_f = scal[3];
         if (delta_f > 0) return FH_ERR_NUMERIC;
         double lam = 1.0, cost_save = 0, lam_save = 0;
+        bool first_trial = true;
         for (;;) {
             double cost_new;
             bool same;
-            rc = fun(pdir, lam, &cost_new, &same);
-            if (rc) return rc;
+            if (have_first) {
+                cost_new = scal[0];
+                same = scal[1] != 0.0;
+                have_first = false;
+            } else {
+                rc = fun(pdir, lam, &cost_new, &same, linear ? (first_trial ? 1 : 2) : 0);
+                if (rc) return rc;
+            }
+            first_trial = false;
             if (same) {  // (the reference tests x_new == x0 before it evaluates: no evaluation counted)
                 *failed = 1;
                 return FH_OK;
@@ -2873,26 +2891,47 @@ struct LnWide {
         double fx;
         int rc = fun(nullptr, 0.0, &fx, nullptr);
         if (rc) return rc;
+        // One submission and one read per step on the common path (a frozen Hessian, the first trial accepted): the Jacobian of x --
+        // which also carries the convergence measure of the step BEFORE --, the solve, limit_step and the trial at lam = 1 go to
+        // the device together; a step that turns out to follow convergence is discarded with its evaluation.  A step that needs a
+        // new Hessian reads the measure first (the factorisation must not be counted if the minimiser has already stopped).
         for (nstep = 0; nstep < max_step; ++nstep) {
-            // (xn, I, t1, t2 hold the products of x here: the evaluation in front of the loop, or the one that ends a step)
+            // (xn, I, t1, t2 hold the products of x here: the evaluation in front of the loop, or the accepted trial of a step)
+            HIP_TRY(fh_lnw_launch_jac(P, c->stream));  // jx, dx = -jx, scal[2] = max |jac| |x|
             if (need_hess) {
+                if (nstep > 0) {
+                    rc = read_scal();
+                    if (rc) return rc;
+                    if (scal[2] < tol * (fabs(fx) > 1 ? fabs(fx) : 1)) {
+                        *status = 0;
+                        --nstep;  // (the step that converged)
+                        return FH_OK;
+                    }
+                }
                 if (nhess == max_hev) {
                     *status = 3;
                     return FH_OK;
                 }
                 HIP_TRY(fh_lnw_launch_hess(P, c->lnw_H.p, c->stream));
                 ROC_TRY(rocsolver_dgetrf(c->blas, N, N, c->lnw_H.p, N, c->lnw_ipiv.p, c->info.p));  // (symmetric: either major)
+                // lu_solve for hundreds of steps on one factorisation: the inverse once (N columns), a product per step
+                HIP_TRY(fh_lnw_launch_identity(c->lnw_Hinv.p, N, c->stream));
+                ROC_TRY(rocsolver_dgetrs(c->blas, rocblas_operation_none, N, N, c->lnw_H.p, N, c->lnw_ipiv.p, c->lnw_Hinv.p, N));
                 ++nhess;
             }
-            HIP_TRY(fh_lnw_launch_jac(P, c->stream));  // jx, dx = -jx
-            ROC_TRY(rocsolver_dgetrs(c->blas, rocblas_operation_none, N, 1, c->lnw_H.p, N, c->lnw_ipiv.p, P.dx, N));
-            // dot(jac, dx) < 0 ?  (the limit-step kernel also gives jac . dir)
-            HIP_TRY(fh_lnw_launch_limit_step(P, P.x, P.dx, pdir, c->stream));
+            HIP_TRY(fh_lnw_launch_dir(P, c->lnw_Hinv.p, c->stream));  // dx = -H^-1 jac
+            HIP_TRY(fh_lnw_launch_limit_step(P, P.x, P.dx, pdir, c->stream));  // scal[3] = jac . p, scal[4] = jac . dx
+            HIP_TRY(fh_lnw_launch_eval(P, P.x, pdir, 1.0, linear ? 1 : 0, c->stream));  // the first trial, speculatively
             rc = read_scal();
             if (rc) return rc;
+            if (!need_hess && nstep > 0 && scal[2] < tol * (fabs(fx) > 1 ? fabs(fx) : 1)) {
+                *status = 0;
+                --nstep;
+                return FH_OK;
+            }
             int failed = 1;
             if (scal[4] < 0) {
-                rc = line_search(P.dx, &fx, &failed);
+                rc = line_search(P.dx, &fx, &failed, true);
                 if (rc == FH_ERR_NUMERIC) {
                     *status = 4;
                     return FH_OK;
@@ -2900,8 +2939,8 @@ struct LnWide {
                 if (rc) return rc;
             }
             if (failed) {
-                // steepest descent (minimizer.py:236-244).  A failed search has left x alone but its trials have replaced the
-                // products: evaluate x again (not one of the reference's evaluations), then jx and dx = -jx
+                // steepest descent (minimizer.py:236-244).  x is where it was but the trials have replaced its products:
+                // evaluate x again (not one of the reference's evaluations), then jx and dx = -jx
                 double fx_again;
                 rc = fun(nullptr, 0.0, &fx_again, nullptr);
                 if (rc) return rc;
@@ -2935,19 +2974,25 @@ struct LnWide {
                     fx = fn;
                     rc = accept();
                     if (rc) return rc;
+                } else {
+                    // (the accepted trial's products are those of the new x)
                 }
             }
             need_hess = failed || (reduction != 1.0);
-            rc = fun(nullptr, 0.0, &fx, nullptr);  // the products of the new x
-            if (rc) return rc;
-            HIP_TRY(fh_lnw_launch_jac(P, c->stream));
-            rc = read_scal();
-            if (rc) return rc;
-            const double g = scal[2], scl = fabs(fx) > 1 ? fabs(fx) : 1;
-            if (g < tol * scl) {
-                *status = 0;
-                return FH_OK;
+            if (failed) {  // the slow paths may have left another point's products behind: those of the new x again
+                double fx_again;
+                rc = fun(nullptr, 0.0, &fx_again, nullptr);
+                if (rc) return rc;
             }
+        }
+        // the measure of the last step
+        HIP_TRY(fh_lnw_launch_jac(P, c->stream));
+        rc = read_scal();
+        if (rc) return rc;
+        if (scal[2] < tol * (fabs(fx) > 1 ? fabs(fx) : 1)) {
+            *status = 0;
+            nstep = max_step - 1;
+            return FH_OK;
         }
         *status = 2;
         nstep = max_step - 1;  // (python: the loop variable after exhaustion)

@@ -200,14 +200,17 @@ struct LnWideParams {
     double *p, *p_old;                  // the power spectrum (the fit loop's buffers)
     int *flags;                         // FIT_NFLAGS (the library loop's)
     double *x, *xn, *I, *t1, *t2, *fr, *jx, *dx;  // N each: the point, the last trial point and its I, S^-1 xn, M I, summands
+    double *Sx, *Sp;                    // N each: S^-1 x of the point, S^-1 of the current search's direction
     double *scal;                       // 8: [0] H(xn), [1] xn == x, [2] max |jac||x|, [3] jac.p, [4] jac.dir
 };
 hipError_t fh_lnw_launch_seed(const LnWideParams &P, hipStream_t s);
 hipError_t fh_lnw_launch_scale(const LnWideParams &P, hipStream_t s);
-hipError_t fh_lnw_launch_eval(const LnWideParams &P, const double *x, const double *dir, double lam, hipStream_t s);
+hipError_t fh_lnw_launch_eval(const LnWideParams &P, const double *x, const double *dir, double lam, int mode, hipStream_t s);
 hipError_t fh_lnw_launch_jac(const LnWideParams &P, hipStream_t s);
 hipError_t fh_lnw_launch_hess(const LnWideParams &P, double *H, hipStream_t s);
 hipError_t fh_lnw_launch_limit_step(const LnWideParams &P, const double *x, const double *dir, double *p, hipStream_t s);
+hipError_t fh_lnw_launch_dir(const LnWideParams &P, const double *Hinv, hipStream_t s);
+hipError_t fh_lnw_launch_identity(double *A, int N, hipStream_t s);
 
 // ---- K2 v2: single persistent kernel (fit_loop.hip) ---------------------------------------------------------
 enum { FIT_MODE_FULL = 0, FIT_MODE_STEP = 1, FIT_MODE_SOLVE = 2 };

@@ -91,7 +91,11 @@ __global__ void lnw_scale_kernel(LnWideParams P) {
 // One function evaluation's O(N^2) part at xn = x + lam * dir (dir may be NULL: xn = x): I = exp(xn + s0), t1 = S^-1 xn,
 // t2 = M I, and per row the summand of H(s) = 0.5 s.S^-1 s + 0.5 I.M I - I.j (statistical_models.py:1075-1085).
 // Eight rows per workgroup, a wave per row; every workgroup forms xn and I for itself in LDS.
-__global__ void __launch_bounds__(512) lnw_eval_kernel(LnWideParams P, const double *x, const double *dir, double lam) {
+// mode 0: S^-1 xn multiplied out (the reference's arithmetic; at dir = NULL it also refreshes Sx = S^-1 x);
+// mode 1: the first trial of a search: Sp = S^-1 dir multiplied out and kept, t1 = Sx + lam Sp;  mode 2: later trials of the
+// same search: t1 = Sx + lam Sp, M only -- S^-1 is linear (the persistent kernel's default line search does the same: a trial
+// point's S^-1 x carries no fresh rounding of its own, the searches accept at the first trial and the Hessian stays frozen)
+__global__ void __launch_bounds__(512) lnw_eval_kernel(LnWideParams P, const double *x, const double *dir, double lam, int mode) {
     __shared__ double xs[1024], Is[1024];
     __shared__ int s_diff;
     const int N = P.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -101,7 +105,7 @@ __global__ void __launch_bounds__(512) lnw_eval_kernel(LnWideParams P, const dou
     for (int k = tid; k < N; k += 512) {
         const double x0 = x[k], v = dir ? x0 + lam * dir[k] : x0;
         diff |= v != x0;
-        xs[k] = v;
+        xs[k] = mode == 1 ? dir[k] : v;  // (the vector S^-1 multiplies)
         Is[k] = exp(v + P.s0);
     }
     if (diff) s_diff = 1;
@@ -110,9 +114,13 @@ __global__ void __launch_bounds__(512) lnw_eval_kernel(LnWideParams P, const dou
     if (i < N) {
         const double *sr = P.Sinv + (size_t)i * N, *mr = P.M + (size_t)i * N;
         double a = 0.0, b = 0.0;
-        for (int k = lane; k < N; k += 64) {
-            a = fma(sr[k], xs[k], a);
-            b = fma(mr[k], Is[k], b);
+        if (mode != 2) {
+            for (int k = lane; k < N; k += 64) {
+                a = fma(sr[k], xs[k], a);
+                b = fma(mr[k], Is[k], b);
+            }
+        } else {
+            for (int k = lane; k < N; k += 64) b = fma(mr[k], Is[k], b);
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -120,12 +128,21 @@ __global__ void __launch_bounds__(512) lnw_eval_kernel(LnWideParams P, const dou
             b += __shfl_xor(b, off);
         }
         if (lane == 0) {
-            const double Ii = Is[i], xi = xs[i];
+            const double x0 = x[i], xi = dir ? x0 + lam * dir[i] : x0, Ii = Is[i];
+            double t1 = a;
+            if (mode == 1) {
+                P.Sp[i] = a;
+                t1 = P.Sx[i] + lam * a;
+            } else if (mode == 2) {
+                t1 = P.Sx[i] + lam * P.Sp[i];
+            } else if (!dir) {
+                P.Sx[i] = a;
+            }
             P.xn[i] = xi;
             P.I[i] = Ii;
-            P.t1[i] = a;
+            P.t1[i] = t1;
             P.t2[i] = b;
-            P.fr[i] = 0.5 * (xi * a) + 0.5 * (Ii * b) - Ii * P.j[i];
+            P.fr[i] = 0.5 * (xi * t1) + 0.5 * (Ii * b) - Ii * P.j[i];
         }
     }
     if (blockIdx.x == 0 && tid == 0) P.scal[1] = s_diff ? 0.0 : 1.0;  // x + lam dir == x in every component (minimizer.py:128)
@@ -191,8 +208,38 @@ __global__ void __launch_bounds__(kT) lnw_limit_step_kernel(LnWideParams P, cons
     }
 }
 
+// The Newton direction dx = -H^-1 jac from the explicit inverse of the factored Hessian (a Hessian serves hundreds of steps: one
+// N-column solve per factorisation, a wave per row here per step, instead of two triangular solves of one column per step)
+__global__ void __launch_bounds__(512) lnw_dir_kernel(LnWideParams P, const double *Hinv) {
+    __shared__ double js[1024];
+    const int N = P.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < N; k += 512) js[k] = P.jx[k];
+    __syncthreads();
+    const int i = blockIdx.x * 8 + wave;
+    if (i >= N) return;
+    const double *hr = Hinv + (size_t)i * N;
+    double a = 0.0;
+    for (int k = lane; k < N; k += 64) a = fma(hr[k], js[k], a);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
+    if (lane == 0) P.dx[i] = -a;
+}
+__global__ void lnw_identity_kernel(double *A, int N) {
+    const size_t NN = (size_t)N * N;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < NN; e += (size_t)gridDim.x * blockDim.x)
+        A[e] = (e / N == e % N) ? 1.0 : 0.0;
+}
+
 }  // namespace
 
+hipError_t fh_lnw_launch_dir(const LnWideParams &P, const double *Hinv, hipStream_t s) {
+    hipLaunchKernelGGL(lnw_dir_kernel, dim3((P.N + 7) / 8), dim3(512), 0, s, P, Hinv);
+    return hipGetLastError();
+}
+hipError_t fh_lnw_launch_identity(double *A, int N, hipStream_t s) {
+    hipLaunchKernelGGL(lnw_identity_kernel, dim3(256), dim3(256), 0, s, A, N);
+    return hipGetLastError();
+}
 hipError_t fh_lnw_launch_seed(const LnWideParams &P, hipStream_t s) {
     hipLaunchKernelGGL(lnw_seed_kernel, dim3(1), dim3(kT), 0, s, P);
     return hipGetLastError();
@@ -201,8 +248,8 @@ hipError_t fh_lnw_launch_scale(const LnWideParams &P, hipStream_t s) {
     hipLaunchKernelGGL(lnw_scale_kernel, dim3(256), dim3(256), 0, s, P);
     return hipGetLastError();
 }
-hipError_t fh_lnw_launch_eval(const LnWideParams &P, const double *x, const double *dir, double lam, hipStream_t s) {
-    hipLaunchKernelGGL(lnw_eval_kernel, dim3((P.N + 7) / 8), dim3(512), 0, s, P, x, dir, lam);
+hipError_t fh_lnw_launch_eval(const LnWideParams &P, const double *x, const double *dir, double lam, int mode, hipStream_t s) {
+    hipLaunchKernelGGL(lnw_eval_kernel, dim3((P.N + 7) / 8), dim3(512), 0, s, P, x, dir, lam, mode);
     hipLaunchKernelGGL(lnw_sum_kernel, dim3(1), dim3(kT), 0, s, P);
     return hipGetLastError();
 }

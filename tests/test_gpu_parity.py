@@ -1030,8 +1030,14 @@ def test_lognormal_beyond_the_persistent_kernel_against_oracle():
         ref = fo.lognormal_map(D, m["M"], m["j"], p_seed, s_guess, s0)
         assert ref["stats"][0] == 0  # (a problem the reference's minimiser converges on)
         d = DiscreteHankelTransform(rmax, N)
-        fit = LogNormalMAPModel(d, m["M"], m["j"], p_seed, guess=s_guess, s0=s0)
-        I, Iref = np.exp(fit.MAP + s0), np.exp(ref["s"] + s0)
+        # the default line search forms S^-1 (x + lam p) from S^-1 x and S^-1 p (as the persistent kernel's default): the same MAP
+        fit_l = LogNormalMAPModel(d, m["M"], m["j"], p_seed, guess=s_guess, s0=s0)
+        Iref = np.exp(ref["s"] + s0)
+        assert np.abs(np.exp(fit_l.MAP + s0) - Iref).max() / Iref.max() < 1e-6 and fit_l._newton_stats[4] == 1, N
+        assert fit_l._newton_stats[2] < 1.5 * fit_l._newton_stats[1]  # (evaluations per step)
+        # linesearch='reference' multiplies S^-1 x out at every trial point as the reference does, and follows its counts
+        fit = LogNormalMAPModel(d, m["M"], m["j"], p_seed, guess=s_guess, s0=s0, linesearch="reference")
+        I = np.exp(fit.MAP + s0)
         assert np.abs(I - Iref).max() / Iref.max() < 1e-6, N  # the north_star tolerance on the brightness profile
         # (the faint outer disc is held loosely: the reference itself moves by ~1e-4 in s there when M is perturbed by 1e-15
         #  relative -- test_lognormal_map_model_N300, map_selfsens_* --; where the disc is bright the MAP is determined)
@@ -1046,7 +1052,7 @@ def test_lognormal_beyond_the_persistent_kernel_against_oracle():
             assert p_new.shape == (N,) and np.all(p_new > 0)
             # a few passes of the whole loop
             FF = FrankFitter(rmax_as, N, geom(), method="LogNormal", max_iter=2, convergence_failure="ignore",
-                             store_iteration_diagnostics=True, verbose=False, check_qbounds=False)
+                             store_iteration_diagnostics=True, verbose=False, check_qbounds=False, lognormal_linesearch="reference")
             FF._M, FF._j, FF._H0 = m["M"], m["j"], m["null_likelihood"]
             FF._fit()
             o = fo.frank_fit_lognormal(N, rmax, m["M"], m["j"], max_iter=2, diagnostics=True)

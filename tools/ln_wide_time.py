@@ -17,7 +17,7 @@ for N in [int(a) for a in sys.argv[1:]] or [300, 330, 400, 640, 1000]:
     t0 = time.perf_counter()
     sol = FF.fit(u, v, V, w)
     dt = time.perf_counter() - t0
-    st = getattr(FF, "_newton_totals", None)
+    st = getattr(getattr(sol, "_fit", None), "_newton_stats", None) or getattr(getattr(FF, "_sol", None), "_fit", None) and FF._sol._fit._newton_stats
     print("N = %4d: %.2f s, %d passes, I in [%.3g, %.3g]%s" % (
         N, dt, FF.iteration_diagnostics["num_iterations"], sol.I.min(), sol.I.max(),
         "" if st is None else "  (MAP solves %d, Newton steps %d, evaluations %d, Hessians %d)" % tuple(st[:4])), flush=True)
