@@ -34,6 +34,7 @@ Rank 0 at N=1 also reports, outside the timed region and bounded to about a minu
   extra.steady_state         fits/s of the same pipeline over a >= 2 s run (the drain is < 5 % of it), fit loops resident
   extra.distinct_tables      the same with every step binning a different table of a ring of four, range cache off
   extra.lognormal_fullsize   BASELINE configs[2] (N=300, 1e7 visibilities, LogNormal) on the resident table
+  extra.lognormal_N640       the same table at N=640: LogNormal beyond the persistent kernel (host-driven route)
   extra.fp32_table           the same table stored in single precision (configs[2]'s "fp32": 20 B per visibility)
   extra.sweep512             BASELINE configs[4] on one GPU (512 fits of one 1e6-visibility mapping)
   extra.uvbin                UVDataBinner streaming passes at 1e7 rows (HBM roofline)
@@ -433,6 +434,34 @@ def extras(f, L, a):
             np.abs(I_lin - I_ref).max() / np.abs(I_ref).max())
     except Exception as e:
         ex.setdefault("lognormal_fullsize", {})["error"] = repr(e)
+    # -- method='LogNormal' beyond the persistent kernel's basis size (N = 640: the host-driven route, lognormal_wide.hip) on the
+    #    same resident table, at most 200 passes of the power-spectrum loop
+    try:
+        f2 = Fitter(L, 640, f.device)
+        f2.vis, f2.nfit, f2.n = f.vis, f.nfit, f.n
+        s2, p2 = np.empty(640), np.empty(640)
+        nit2 = ctypes.c_int(0)
+        st2 = (ctypes.c_int64 * 9)()
+        H0, qmn, qmx = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        t0 = time.perf_counter()
+        f2.bin()
+        L.check(L.lib.fh_stats_finalize(f2.ctx, ctypes.byref(f2.geom), 0, 1, None, None, ctypes.byref(H0), ctypes.byref(qmn),
+                                        ctypes.byref(qmx)))
+        t1 = time.perf_counter()
+        L.check(L.lib.fh_fit_lognormal(f2.ctx, None, None, 1.3, 1e-35, 1e-2, h["tol"], 200, 1e5, L.ptr(s2), L.ptr(p2),
+                                       ctypes.byref(nit2), None, st2, None, None))
+        t2 = time.perf_counter()
+        I2 = np.exp(s2 + np.log(1e5))
+        ex["lognormal_N640"] = {
+            "workload": "N=640, %d visibilities, LogNormal, alpha=1.3, w_smooth=1e-2, max_iter=200: beyond the persistent "
+                        "kernel (N <= 320) MinimizeNewton runs on the host over device kernels" % f.nfit,
+            "s_per_fit": t2 - t0, "bin_s": t1 - t0, "fit_s": t2 - t1, "power_spectrum_iterations": nit2.value,
+            "newton_steps": int(st2[1]), "function_evaluations": int(st2[2]), "hessian_factorisations": int(st2[3]),
+            "ms_per_power_spectrum_iteration": 1e3 * (t2 - t1) / max(nit2.value, 1),
+            "I_max": float(I2.max()), "finite": bool(np.all(np.isfinite(I2)))}
+        del f2
+    except Exception as e:  # noqa: BLE001
+        ex["lognormal_N640"] = {"error": repr(e)}
     # -- the binning pass when the baselines REACH the last collocation frequency -- how frank is normally set up (N chosen so
     #    that q[-1] just clears the data, statistical_models.py:512-535): the same rows stretched to 0.95 Q_max fall into ~1 900
     #    buckets of J0 arguments (55 MB of Taylor tables) instead of the 243 of the headline table (13 % of Q_max)
