@@ -246,7 +246,7 @@ struct fh_ctx {
     DevBuf<double> ln_cluster_vecs;  // 1 / p, diag(L), Tr2: what the helper workgroups of a cluster exchange with the first
     DevBuf<long long> ln_stats;
     // LogNormal beyond N = 320 (lognormal_wide.hip)
-    DevBuf<double> lnw_Sinv, lnw_H, lnw_Hinv, lnw_vec, lnw_scal, lnw_diag_s;
+    DevBuf<double> lnw_Sinv, lnw_H, lnw_Hinv, lnw_Hc, lnw_vec, lnw_scal, lnw_diag_s;
     DevBuf<rocblas_int> lnw_ipiv;
 };
 
@@ -2756,7 +2756,9 @@ struct LnWide {
     fh_ctx *c;
     LnWideParams P{};
     double *dir_nj = nullptr, *pdir = nullptr;  // -jac (steepest descent), the limited step
+    double *d0 = nullptr, *res = nullptr;       // the unrefined Newton direction, its residual
     double reduction = NAN;                     // LineSearch.reduction (None until the first success)
+    bool use_inverse = false;
     bool linear = true;                         // S^-1 (x + lam p) = S^-1 x + lam S^-1 p along a search ('linear'); false: multiplied out
     long long nfev = 0, nhess = 0, nstep = 0;
     double scal[8];
@@ -2768,7 +2770,8 @@ struct LnWide {
             HIP_TRY(c->lnw_Sinv.alloc(NN));
             HIP_TRY(c->lnw_H.alloc(NN));
             HIP_TRY(c->lnw_Hinv.alloc(NN));
-            HIP_TRY(c->lnw_vec.alloc(12 * (size_t)N));
+            HIP_TRY(c->lnw_Hc.alloc(NN));
+            HIP_TRY(c->lnw_vec.alloc(14 * (size_t)N));
             HIP_TRY(c->lnw_scal.alloc(8));
             HIP_TRY(c->lnw_ipiv.alloc(N));
         }
@@ -2793,7 +2796,10 @@ struct LnWide {
         pdir = v + 9 * N;
         P.Sx = v + 10 * N;
         P.Sp = v + 11 * N;
+        d0 = v + 12 * N;
+        res = v + 13 * N;
         linear = !c->ln_fresh_products;
+        use_inverse = env_int("FRANK_AMD_LNW_INVERSE", 1) != 0;  // (0: rocSOLVER's getrs at every step, ~4x slower)
         P.scal = c->lnw_scal.p;
         return FH_OK;
     }
@@ -2913,13 +2919,21 @@ struct LnWide {
                     return FH_OK;
                 }
                 HIP_TRY(fh_lnw_launch_hess(P, c->lnw_H.p, c->stream));
+                if (use_inverse) HIP_TRY(hipMemcpyAsync(c->lnw_Hc.p, c->lnw_H.p, sizeof(double) * (size_t)N * N, hipMemcpyDeviceToDevice, c->stream));
                 ROC_TRY(rocsolver_dgetrf(c->blas, N, N, c->lnw_H.p, N, c->lnw_ipiv.p, c->info.p));  // (symmetric: either major)
-                // lu_solve for hundreds of steps on one factorisation: the inverse once (N columns), a product per step
-                HIP_TRY(fh_lnw_launch_identity(c->lnw_Hinv.p, N, c->stream));
-                ROC_TRY(rocsolver_dgetrs(c->blas, rocblas_operation_none, N, N, c->lnw_H.p, N, c->lnw_ipiv.p, c->lnw_Hinv.p, N));
+                if (use_inverse) {  // lu_solve for hundreds of steps on one factorisation: the inverse once (N columns)
+                    HIP_TRY(fh_lnw_launch_identity(c->lnw_Hinv.p, N, c->stream));
+                    ROC_TRY(rocsolver_dgetrs(c->blas, rocblas_operation_none, N, N, c->lnw_H.p, N, c->lnw_ipiv.p, c->lnw_Hinv.p, N));
+                }
                 ++nhess;
             }
-            HIP_TRY(fh_lnw_launch_dir(P, c->lnw_Hinv.p, c->stream));  // dx = -H^-1 jac
+            if (use_inverse) {  // dx = H^-1 (-jac) with one step of refinement (P.dx holds -jac)
+                HIP_TRY(fh_lnw_launch_matvec(N, c->lnw_Hinv.p, P.dx, 1.0, nullptr, d0, c->stream));
+                HIP_TRY(fh_lnw_launch_matvec(N, c->lnw_Hc.p, d0, -1.0, P.dx, res, c->stream));
+                HIP_TRY(fh_lnw_launch_matvec(N, c->lnw_Hinv.p, res, 1.0, d0, P.dx, c->stream));
+            } else {
+                ROC_TRY(rocsolver_dgetrs(c->blas, rocblas_operation_none, N, 1, c->lnw_H.p, N, c->lnw_ipiv.p, P.dx, N));  // lu_solve
+            }
             HIP_TRY(fh_lnw_launch_limit_step(P, P.x, P.dx, pdir, c->stream));  // scal[3] = jac . p, scal[4] = jac . dx
             HIP_TRY(fh_lnw_launch_eval(P, P.x, pdir, 1.0, linear ? 1 : 0, c->stream));  // the first trial, speculatively
             rc = read_scal();

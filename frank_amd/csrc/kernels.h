@@ -209,7 +209,7 @@ hipError_t fh_lnw_launch_eval(const LnWideParams &P, const double *x, const doub
 hipError_t fh_lnw_launch_jac(const LnWideParams &P, hipStream_t s);
 hipError_t fh_lnw_launch_hess(const LnWideParams &P, double *H, hipStream_t s);
 hipError_t fh_lnw_launch_limit_step(const LnWideParams &P, const double *x, const double *dir, double *p, hipStream_t s);
-hipError_t fh_lnw_launch_dir(const LnWideParams &P, const double *Hinv, hipStream_t s);
+hipError_t fh_lnw_launch_matvec(int N, const double *A, const double *x, double alpha, const double *z, double *y, hipStream_t s);
 hipError_t fh_lnw_launch_identity(double *A, int N, hipStream_t s);
 
 // ---- K2 v2: single persistent kernel (fit_loop.hip) ---------------------------------------------------------

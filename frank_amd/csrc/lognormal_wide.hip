@@ -208,21 +208,24 @@ __global__ void __launch_bounds__(kT) lnw_limit_step_kernel(LnWideParams P, cons
     }
 }
 
-// The Newton direction dx = -H^-1 jac from the explicit inverse of the factored Hessian (a Hessian serves hundreds of steps: one
-// N-column solve per factorisation, a wave per row here per step, instead of two triangular solves of one column per step)
-__global__ void __launch_bounds__(512) lnw_dir_kernel(LnWideParams P, const double *Hinv) {
-    __shared__ double js[1024];
-    const int N = P.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int k = tid; k < N; k += 512) js[k] = P.jx[k];
+// y = alpha A x + z (z may be NULL), a wave per row.  The Newton direction of a step comes from the EXPLICIT inverse of the factored
+// Hessian -- a Hessian serves hundreds of steps; rocSOLVER's two triangular solves of one column cost ~250 us per step, three of
+// these products ~25 -- with one step of iterative refinement against the unfactored Hessian (d0 = H^-1 b, r = b - H d0,
+// dx = d0 + H^-1 r), which gives the solve the residual of an LU solve back.
+__global__ void __launch_bounds__(512) lnw_matvec_kernel(int N, const double *A, const double *x, double alpha, const double *z,
+                                                        double *y) {
+    __shared__ double xs[1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < N; k += 512) xs[k] = x[k];
     __syncthreads();
     const int i = blockIdx.x * 8 + wave;
     if (i >= N) return;
-    const double *hr = Hinv + (size_t)i * N;
+    const double *ar = A + (size_t)i * N;
     double a = 0.0;
-    for (int k = lane; k < N; k += 64) a = fma(hr[k], js[k], a);
+    for (int k = lane; k < N; k += 64) a = fma(ar[k], xs[k], a);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
-    if (lane == 0) P.dx[i] = -a;
+    if (lane == 0) y[i] = alpha * a + (z ? z[i] : 0.0);
 }
 __global__ void lnw_identity_kernel(double *A, int N) {
     const size_t NN = (size_t)N * N;
@@ -232,8 +235,8 @@ __global__ void lnw_identity_kernel(double *A, int N) {
 
 }  // namespace
 
-hipError_t fh_lnw_launch_dir(const LnWideParams &P, const double *Hinv, hipStream_t s) {
-    hipLaunchKernelGGL(lnw_dir_kernel, dim3((P.N + 7) / 8), dim3(512), 0, s, P, Hinv);
+hipError_t fh_lnw_launch_matvec(int N, const double *A, const double *x, double alpha, const double *z, double *y, hipStream_t s) {
+    hipLaunchKernelGGL(lnw_matvec_kernel, dim3((N + 7) / 8), dim3(512), 0, s, N, A, x, alpha, z, y);
     return hipGetLastError();
 }
 hipError_t fh_lnw_launch_identity(double *A, int N, hipStream_t s) {
