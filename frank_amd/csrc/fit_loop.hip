@@ -2062,7 +2062,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
             const int hi = clu::inv_helpers(P), ht = clu::trail_helpers(P);
             if (member <= hi) {
                 // (every wave at most one block column: the columns' second waves, see inverse_wave_paired)
-                if (!WIDE && hi * NW >= NP / 16) clu::inverse_wave_paired(P, ctl, hi, member - 1, hwave, tid & 63, smem);
+                if (hi * NW >= NP / 16) clu::inverse_wave_paired(P, ctl, hi, member - 1, hwave, tid & 63, smem);
                 else clu::inverse_wave<2>(P, ctl, hwave * hi + (member - 1), hi * NW, tid & 63);
             }
             else clu::trailing_wave(P, ctl, hwave * ht + (member - 1 - hi), ht * NW, tid & 63, smem, hwave);
