@@ -1062,6 +1062,19 @@ def test_lognormal_beyond_the_persistent_kernel_against_oracle():
                 Ik, Ok = np.exp(FF.iteration_diagnostics["MAP"][k]), np.exp(o["diag_s"][k])
                 assert np.abs(Ik - Ok).max() / Ok.max() < 2e-5  # (each pass solves for ITS p, which follows the MAP before it)
             np.testing.assert_allclose(p_new, FF.iteration_diagnostics["power_spectrum"][0], rtol=1.0)  # (same order of magnitude: other hyper-parameters)
+            # the batched entry point takes the same route, one point after the other: equal to single fits of the points
+            from frank_amd.sweep import sweep_fits
+            kw = dict(method="LogNormal", max_iter=2, convergence_failure="ignore", verbose=False, check_qbounds=False)
+            FS = FrankFitter(rmax_as, N, geom(), **kw)
+            FS._M, FS._j, FS._H0 = m["M"], m["j"], m["null_likelihood"]
+            FS._vis_map.check_hash = lambda *a, **k: True
+            pre = dict(M=m["M"], j=m["j"], null_likelihood=m["null_likelihood"], hash=None)
+            sols, niters = sweep_fits(FS, pre, [1.3, 1.05], [1e-2, 1e-4], max_iter=2)
+            for b_, (al, ws) in enumerate(((1.3, 1e-2), (1.05, 1e-4))):
+                F1 = FrankFitter(rmax_as, N, geom(), alpha=al, weights_smooth=ws, **kw)
+                F1._M, F1._j, F1._H0 = m["M"], m["j"], m["null_likelihood"]
+                s1 = F1._fit()
+                assert niters[b_] == 3 and rel_to_max(sols[b_].I, s1.I) < 1e-9
 
 
 def _oracle_seed_problem(N, nvis, seed):
