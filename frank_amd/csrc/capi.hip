@@ -216,6 +216,7 @@ struct fh_ctx {
     DevBuf<double> Yinv, T1, Araw, Aq, bq, Cq, Wq, WdT, cs, mu_out, p_out, p_init;
     DevBuf<int> loop_result;
     DevBuf<long long> loop_timing;  // FIT_LOOP_TIMING debug builds only
+    DevBuf<unsigned long long> loop_clocks;  // fh_ctx_loop_clocks: [cycles, 100 MHz ticks, passes] summed over the fits since the last read
     DevBuf<double> slot_pool;   // backing store of every slot's buffers
     DevBuf<int> slot_results;
     FitSlot slots[kFitSlots];
@@ -1987,6 +1988,7 @@ static FitLoopParams make_loop_params(fh_ctx *c, int mode, double alpha, double 
     P.mu_out = c->mu_out.p;
     P.p_out = c->p_out.p;
     P.result = c->loop_result.p;
+    P.clk_out = c->loop_clocks.p;  // (NULL unless fh_ctx_loop_clocks switched the probe on)
 #ifdef FIT_LOOP_TIMING
     if (!c->loop_timing.p && c->loop_timing.alloc(16 + 2048) == hipSuccess) (void)hipMemset(c->loop_timing.p, 0, (16 + 2048) * sizeof(long long));
     P.timing = c->loop_timing.p;
@@ -2620,6 +2622,30 @@ int fh_sweep_evidence(fh_ctx *c, const double *M, const double *j, double H0, in
             if (log_evidence) log_evidence[first + b] = (okC && okH) ? lp + sll - 0.5 * (hH[b] - N * log(2.0 * M_PI)) : NAN;
         }
     }
+    return FH_OK;
+}
+
+// The clock the fit loops ran at.  on != 0 switches the probe on (every fit loop of this context then adds its shader-clock
+// cycles, its ticks of the constant 100 MHz wall clock and its passes to three device counters: two clock reads and three
+// atomics per FIT); out3 (may be NULL) receives the sums since the last call and resets them.  mean clock = 100 MHz x
+// out3[0] / out3[1]; mean pass = out3[1] / 100 / out3[2] us.  A measurement aid: with 240 loops resident the question is
+// whether a pass is slower in CYCLES (memory system) or in time only (the device's clock under an fp64 matrix load).
+int fh_ctx_loop_clocks(fh_ctx *c, int on, int64_t *out3) {
+    if (!c) return fail(FH_ERR_INVALID, "fh_ctx_loop_clocks: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->loop_clocks.p && out3) {
+        unsigned long long h[3];
+        HIP_TRY(hipMemcpy(h, c->loop_clocks.p, sizeof h, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 3; ++i) out3[i] = (int64_t)h[i];
+        HIP_TRY(hipMemset(c->loop_clocks.p, 0, sizeof h));
+    } else if (out3) {
+        out3[0] = out3[1] = out3[2] = 0;
+    }
+    if (on && !c->loop_clocks.p) {
+        if (c->loop_clocks.alloc(3) != hipSuccess) return fail(FH_ERR_NOMEM, "device allocation failed");
+        HIP_TRY(hipMemset(c->loop_clocks.p, 0, 3 * sizeof(unsigned long long)));
+    }
+    if (!on && c->loop_clocks.p) c->loop_clocks.release();
     return FH_OK;
 }
 

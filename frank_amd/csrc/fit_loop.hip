@@ -1020,6 +1020,11 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 }
                 a = upd(t.y, t.z, a);
                 st_pk(C_u, base_pk + (t.w & ~2047u), lane, a);
+#ifdef K2_PROBE_STORE2
+                // sensitivity probe (make probe; never shipped): every trailing tile stored a second time, into the unused W
+                // buffer -- what 2 MB more of stores per pass cost a loaded device (all stores leave the L2)
+                if constexpr (!CL && !WIDE) st_pk(as_global(uniform_ptr(P.W)), base_pk + (t.w & ~2047u), lane, a);
+#endif
             };
             int e = widx;  // every NWKc-th tile of the enumeration
             const int cnt = CL ? cntB : cntA;
@@ -1987,6 +1992,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         if (launch_index >= P.nfits) return;
     }
     const FitLoopParams P0 = P;
+    __shared__ long long s_clk[2];  // (fh_ctx_loop_clocks: shader clock and wall clock at the start of a fit)
     // batched launch: the workgroups pull fit indices from a counter (fits of a sweep differ ~20x in iteration count)
     for (;;) {
     P = P0;
@@ -2050,6 +2056,10 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     }
     const int N = P.N, NP = P.NP;
     const int tid = threadIdx.x;
+    if (P.clk_out && tid == 0) {
+        s_clk[0] = clock64();
+        s_clk[1] = wall_clock64();
+    }
     int *const ctl = CL ? clu::ctl_of(P) : nullptr;
     if constexpr (CL) {
         if (member > 0) {  // a helper workgroup: block columns of the inverse (clu::inverse_wave) or trailing tiles (clu::trailing_wave)
@@ -2189,6 +2199,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         else if constexpr (LL) {
             Smem SL = S;
             SL.band = smem + (S.red + NP - smem);  // the LDS region behind the vectors: the diagonal tiles
+            ++nsolve;
             solved = solve_posterior_ll(P, SL);
         } else solved = solve_posterior<WIDE, CLM>(P, S, ++nsolve);
         if (!solved) {
@@ -2402,6 +2413,11 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         if (P.result_host) {
             P.result_host[0] = count;
             P.result_host[1] = status;
+        }
+        if (P.clk_out) {
+            atomicAdd(P.clk_out, (unsigned long long)(clock64() - s_clk[0]));
+            atomicAdd(P.clk_out + 1, (unsigned long long)(wall_clock64() - s_clk[1]));
+            atomicAdd(P.clk_out + 2, (unsigned long long)nsolve);
         }
     }
     if (!P.batch) return;

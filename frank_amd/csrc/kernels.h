@@ -234,6 +234,8 @@ struct FitLoopParams {
     double *diag_p, *diag_mu;
     long long *timing;      // debug builds (FIT_LOOP_TIMING): cycles per phase
     int trace_on;           // debug builds: record per-wave time stamps of this pass behind timing[16]
+    unsigned long long *clk_out;  // fh_ctx_loop_clocks(ctx, 1): every fit adds [0] shader-clock cycles, [1] ticks of the 100 MHz
+                                  // wall clock, [2] passes of its loop (the clock the compute units ran at with the device loaded)
     // batched launch (one workgroup per fit; A, bq, Yinv, q shared): per-fit alpha / p0, band_lu[f][5N], and the
     // work / output buffers strided by fit
     int batch;

@@ -281,6 +281,12 @@ int fh_sweep_evidence(fh_ctx *ctx, const double *M, const double *j, double H0, 
  * context that did not assemble on one XCD within 3 ms and were repeated on one compute unit (either may be NULL).     */
 int fh_fit_cluster_info(fh_ctx *ctx, int *workgroups, int64_t *fallbacks);
 
+/* Measurement aid (no counterpart in the reference): the clock the fit loops of this context ran at.  on != 0 switches a
+ * probe on -- every fit loop then adds its shader-clock cycles, its ticks of the constant 100 MHz wall clock and its passes
+ * (posterior solves) to three device counters --, on == 0 off; out3 (may be NULL) receives the sums since the last call and
+ * clears them: mean clock = 100 MHz x out3[0] / out3[1], mean pass = out3[1] / 100 / out3[2] microseconds.                  */
+int fh_ctx_loop_clocks(fh_ctx *ctx, int on, int64_t *out3);
+
 /* Batched form for hyper-parameter sweeps over ONE mapping (fit.py:534-548 re-runs the whole fit per (alpha,
  * w_smooth) point although M, j do not depend on them): `batch` fits of the same M, j (host, or NULL for the
  * context's device copies) with per-fit alpha[b], p0[b], wsmooth[b]; one fit_loop workgroup (one CU) per fit, all in
