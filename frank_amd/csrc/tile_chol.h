@@ -116,6 +116,9 @@ __device__ __forceinline__ bool chol_inv_tile_acc(v4f64 &T, v4f64 &X, int lane, 
 // DPP operand needs two wait states behind its VALU write, which inline asm is not scanned for): every dependent pair has
 // independent instructions between it, two updates of column C - 1 (registers no row broadcast reads) fill the gaps of
 // column C.  Masks are arithmetic (clamp(cl - C)): 64-bit selects need sub-registers, which inline asm cannot name.
+// The block ENDS on v_rcp_f64 + s_nop 0: a VALU read of a transcendental's result needs one wait state, the hazard recogniser does
+// not look into inline asm, and the FORCE instantiation's selects (compiler-generated, directly behind the block) read r0 -- the
+// s_nop closes the hazard inside the block whatever the compiler schedules next (one cycle on a ~100-cycle column).
 // T is updated as T[i][j] -= T[i][C] (T[C][j] / d): symmetric to rounding only (both triangles are kept: row C feeds the
 // multiplier, column C the DPP operand); the factor's backward error is unchanged.
 // Out: Z = L^-T and, if WANT_L, T = L^T, both in the accumulator layout (register r of lane (rg, cl) = element (rg + 4 r, cl)),
@@ -142,7 +145,7 @@ struct ZState {
 #define FH_Z_MINI FH_UPD(u, bp, cm)  /* row C + 1: column C - 1's update */
 #define FH_Z_NEXT(f0, f1, f2)                                                                                \
     FH_UPD(u, b, cc) /* row C + 1 as this column leaves it */ FH_UPD(f0, b, cc) FH_UPD(f1, b, cc)           \
-        "v_mov_b64_dpp %[d], %[u]" FH_DPPC(c1) FH_UPD(f2, b, cc) "v_rcp_f64 %[r0], %[d]\n"
+        "v_mov_b64_dpp %[d], %[u]" FH_DPPC(c1) FH_UPD(f2, b, cc) "v_rcp_f64 %[r0], %[d]\ns_nop 0\n"
 template <int C, bool FORCE, bool WANT_L>
 __device__ __forceinline__ void chol_z_step(ZState &S, double (&lt)[4], int rg, int cl, int addr4, int force_c) {
     constexpr int R = C >> 2, Q = C & 3, R2 = (C + 2) >> 2, Q2 = (C + 2) & 3;

@@ -413,3 +413,16 @@ def test_uvtable_files_round_trip(tmp_path, golden):
         fio.save_uvtable(str(tmp_path / "t.csv"), u, v, V, w)
     with pytest.raises(ValueError):
         fio.save_fit(u, v, V, w, None, str(tmp_path / "x"), format="csv")
+
+
+def test_no_transcendental_result_is_read_in_the_next_slot():
+    """tile_chol.h ends its hand-written column block on v_rcp_f64 (+ s_nop 0): a VALU read of a transcendental's result needs one
+    wait state and the compiler's hazard recogniser does not look into inline asm.  tools/check_trans_hazard.py compiles
+    fit_loop.hip to assembly and scans every transcendental instruction for a reader in the slot directly behind it."""
+    import subprocess
+    import sys
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_trans_hazard.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 read in the next slot" in r.stdout

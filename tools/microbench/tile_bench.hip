@@ -11,7 +11,7 @@ using namespace tilechol;
 
 template <int V>
 __global__ void __launch_bounds__(64) bench(const double *tiles, int ntile, int reps, double *outL, double *outX, long long *cyc,
-                                            int *okout) {
+                                            int *okout, int force_c) {
     const int lane = threadIdx.x, rg = lane >> 4, cl = lane & 15;
     long long total = 0;
     int okall = 1;
@@ -23,7 +23,11 @@ __global__ void __launch_bounds__(64) bench(const double *tiles, int ntile, int 
             const long long t0 = __builtin_readcyclecounter();
             bool ok;
             if constexpr (V == 0) {
-                ok = chol_inv_tile_acc(T, X, lane, -1);
+                ok = chol_inv_tile_acc(T, X, lane, force_c);
+            } else if constexpr (V == 3) {  // the FORCE instantiation (the augmented row of the fit loop: pivot force_c is 1)
+                v4f64 Z;
+                ok = chol_inv_tile_z<true, true>(T, Z, lane, force_c);
+                X = Z;
             } else {
                 v4f64 Z;
                 ok = chol_inv_tile_z<false, (V & 1) != 0>(T, Z, lane, -1);
@@ -67,15 +71,15 @@ static void check(const char *name, const std::vector<double> &tiles, const std:
 }
 
 template <int V>
-static void run(const char *name, const std::vector<double> &tiles, int nt, std::vector<double> &L, std::vector<double> &X) {
+static void run(const char *name, const std::vector<double> &tiles, int nt, std::vector<double> &L, std::vector<double> &X, int force_c = -1) {
     double *dT, *dL, *dX;
     long long *dc;
     int *dok;
     hipMalloc(&dT, tiles.size() * 8), hipMalloc(&dL, tiles.size() * 8), hipMalloc(&dX, tiles.size() * 8), hipMalloc(&dc, 8), hipMalloc(&dok, 4);
     hipMemcpy(dT, tiles.data(), tiles.size() * 8, hipMemcpyHostToDevice);
     const int reps = 200;
-    bench<V><<<1, 64>>>(dT, nt, 2, dL, dX, dc, dok);
-    bench<V><<<1, 64>>>(dT, nt, reps, dL, dX, dc, dok);
+    bench<V><<<1, 64>>>(dT, nt, 2, dL, dX, dc, dok, force_c);
+    bench<V><<<1, 64>>>(dT, nt, reps, dL, dX, dc, dok, force_c);
     hipDeviceSynchronize();
     long long c;
     int ok;
@@ -83,7 +87,7 @@ static void run(const char *name, const std::vector<double> &tiles, int nt, std:
     L.resize(tiles.size()), X.resize(tiles.size());
     hipMemcpy(L.data(), dL, tiles.size() * 8, hipMemcpyDeviceToHost), hipMemcpy(X.data(), dX, tiles.size() * 8, hipMemcpyDeviceToHost);
     printf("%-10s %8.0f shader cycles per tile (ok = %d)\n", name, (double)c / (reps * nt), ok);
-    check(name, tiles, L, X, nt);
+    if (force_c < 0) check(name, tiles, L, X, nt);  // (with a forced pivot L L^T is not the tile)
     hipFree(dT), hipFree(dL), hipFree(dX), hipFree(dc), hipFree(dok);
 }
 
@@ -112,5 +116,17 @@ int main() {
         d12 = fmax(d12, fmax(fabs(L1[i] - L2[i]), fabs(X1[i] - X2[i])));
     }
     printf("new against old: max |dL| = %.2e, max |dX| = %.2e; with against without L: %.1e (must be 0)\n", dl, dx, d12);
+    // the FORCE instantiation (pivot of one column forced to 1: the row of the fit loop's padded system that carries b) against the
+    // routine of rounds 2-4 with the same forced column, every column in turn being the forced one over the tiles
+    double fl = 0, fx = 0;
+    for (int fc : {0, 1, 5, 12, 14, 15}) {
+        std::vector<double> La, Xa, Lb, Xb;
+        char na[32], nb[32];
+        snprintf(na, sizeof na, "old, f=%d", fc), snprintf(nb, sizeof nb, "z force f=%d", fc);
+        run<0>(na, tiles, nt, La, Xa, fc);
+        run<3>(nb, tiles, nt, Lb, Xb, fc);
+        for (size_t i = 0; i < La.size(); ++i) fl = fmax(fl, fabs(La[i] - Lb[i])), fx = fmax(fx, fabs(Xa[i] - Xb[i]));
+    }
+    printf("forced pivot, new against old: max |dL| = %.2e, max |dX| = %.2e\n", fl, fx);
     return 0;
 }
