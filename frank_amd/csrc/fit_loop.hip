@@ -116,6 +116,7 @@ struct Smem {
                    // to block (k+1, k+1) (step 0 reads the transposes from A) | bit 1: diagonal tile; y, z = byte offsets of
                    // panel row blocks j, i (A and B operand of the transposed update); w = packed offset of tile (i, j) | i
     int *flag;
+    int *dcnt;     // deferred mode (CLM = 4): entries of the two tile tables with i <= row, [parity][24]
     double *hand;  // cluster mode: 2 x 2 packed tiles a worker hands to the chain wave through LDS (solve_posterior_cluster)
 };
 
@@ -772,9 +773,20 @@ __device__ __forceinline__ void inverse_wave_paired(const FitLoopParams &P, int 
 // CLM: 0 one workgroup does everything; 1, 2: cluster mode (the rows of the inverse on the helper workgroups, clu::), with
 // every wave but the chain's on the trailing update (1) or with the two waves that share the chain's SIMD sitting out (2);
 // seq: number of this solve within the fit (the helpers count the passes the same way)
+// CLM = 4: DEFERRED trailing update (round 5, one workgroup, N <= 319).  With the device full a pass is bound by the bytes it moves
+// beyond the L2 (profiles/r05_pmc_fit_loop_loaded.json: every store leaves the L2, 85 % of the L1's read misses too; 2.4 MB read
+// + 2.7 MB written per pass, 4.9 TB/s chip-wide), and 2.0 of the 2.7 MB written are the trailing tiles, loaded, updated by ONE
+// panel and stored again at every step.  Here a tile right of column k + 2 is touched at every OTHER step -- the steps of its
+// own parity (I + J + k even) -- and takes the two panels it then misses, k - 1 and k, in that order, from THREE panels in LDS
+// (k - 1, k and the k + 1 being formed); the tiles of column k + 2 (next step's column tiles) are always brought up to date.
+// Same products, same operands, same order per tile: the same bits.  Half the loads and stores of the trailing update; both
+// parities work at every step, so the steps stay balanced.  The band factors and scan tables move to the W buffer (global
+// memory, as the wide instantiations have them) to make room for the third panel.
 template <int WIDE, int CLM>
 __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Smem &S, int seq) {
-    constexpr bool CL = CLM != 0;
+    constexpr bool CL = CLM == 1 || CLM == 2;
+    constexpr bool DF = CLM == 4;
+    static_assert(!(DF && WIDE), "the deferred update keeps three panels in LDS: N <= 319");
     constexpr int NWKc = CLM == 2 ? NW - NW / 4 : NWK;  // trailing-update workers
     const int N = P.N, NP = P.NP, nb = P.NP / 16, ld = P.NP;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
@@ -889,8 +901,12 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 cntH = __builtin_amdgcn_readfirstlane(cntH);
             }
         }
-        double *pan_cur = S.pan + (WIDE ? (size_t)0 : (size_t)(k & 1) * NP * PS);
-        double *pan_nxt = S.pan + (WIDE ? (size_t)0 : (size_t)((k + 1) & 1) * NP * PS);
+        double *pan_cur = S.pan + (WIDE ? (size_t)0 : (size_t)(DF ? k % 3 : (k & 1)) * NP * PS);
+        double *pan_nxt = S.pan + (WIDE ? (size_t)0 : (size_t)(DF ? (k + 1) % 3 : ((k + 1) & 1)) * NP * PS);
+        // deferred mode: panel k - 1 is still in LDS; the tiles of this step's parity come from one of two filtered tables
+        const char *pan_p = reinterpret_cast<const char *>(S.pan + (DF ? (size_t)((k + 2) % 3) * NP * PS : (size_t)0));
+        const int dpar = k & 1;
+        if constexpr (DF) cntB = __builtin_amdgcn_readfirstlane(m > 0 ? S.dcnt[dpar * 24 + m - 1] : 0);
         int *ctr_cur = S.flag + 1 + (k & 1);
         if (tid == 0) S.flag[1 + ((k + 1) & 1)] = 0;  // column counter of the NEXT step's inverse row (nobody reads it now)
         const unsigned base_pk = (unsigned)((k + 1) * (nb + 1) * 2048);   // tile (k+1, k+1), packed
@@ -961,6 +977,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             // copy.  (2 x 2 groups of tiles with four interleaved MFMA chains were measured too: no faster.)
             bool hready = false;
             auto rec_at = [&](int e) -> uint4 {
+                if constexpr (DF) return S.rec[dpar * 128 + e];
                 if constexpr (CL) {
                     if (band < nb) {  // column by column: column j of the band holds the rows i = j .. m - 1
                         int j = 1, i = e;
@@ -1003,6 +1020,13 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                         return clu::ld_pk_dev(H_u, base_pk + (t.x & ~2047u), lane);  // tile (I, J) waits at the mirror position (J, I)
                     }
                 }
+                if constexpr (DF) {
+                    // first touch of a tile: step 0 for its own parity and for column 2, step 1 for the other parity (bit 2 of x:
+                    // a tile of column k + 2 that only takes panel k)
+                    const bool fromA = k == 0 || (k == 1 && !(t.x & 4u));
+                    return ld_pk(as_global(uniform_ptr(fromA ? P.A : const_cast<const double *>(C))),
+                                 base_pk + ((fromA ? t.x : t.w) & ~2047u), lane);
+                }
                 return ld_pk(src_u, base_pk + ((k == 0 ? t.x : t.w) & ~2047u), lane);
             };
             auto upd = [&](unsigned pa, unsigned pb, v4f64 a) {
@@ -1018,16 +1042,24 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                     for (int r = 0; r < 4; ++r)
                         if (rg + 4 * r == cl) a[r] += pinv[16 * (1 + (t.w & 127u)) + cl];  // (w: packed offset | i)
                 }
+                if constexpr (DF) {
+                    if (k >= 1 && !(t.x & 4u)) {  // the panel this tile sat out: k - 1 (its rows sit one block further down)
+                        const double *pa0 = reinterpret_cast<const double *>(pan_p + t.y + 16 * PS * 8 + lane_p);
+                        const double *pb0 = reinterpret_cast<const double *>(pan_p + t.z + 16 * PS * 8 + lane_p);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa0[4 * s], pb0[4 * s], a, 0, 0, 0);
+                    }
+                }
                 a = upd(t.y, t.z, a);
                 st_pk(C_u, base_pk + (t.w & ~2047u), lane, a);
 #ifdef K2_PROBE_STORE2
                 // sensitivity probe (make probe; never shipped): every trailing tile stored a second time, into the unused W
                 // buffer -- what 2 MB more of stores per pass cost a loaded device (all stores leave the L2)
-                if constexpr (!CL && !WIDE) st_pk(as_global(uniform_ptr(P.W)), base_pk + (t.w & ~2047u), lane, a);
+                if constexpr (!CL && !WIDE && !DF) st_pk(as_global(uniform_ptr(P.W)), base_pk + (t.w & ~2047u), lane, a);
 #endif
             };
             int e = widx;  // every NWKc-th tile of the enumeration
-            const int cnt = CL ? cntB : cntA;
+            const int cnt = (CL || DF) ? cntB : cntA;
             if (e < cnt) {
                 uint4 ta = rec_at(e), tb = ta, tc = ta;
                 v4f64 a = ldt(ta, e), b = a, c = a;
@@ -1981,6 +2013,8 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     __shared__ int s_fit;
     constexpr bool CL = CLM == 1 || CLM == 2;
     constexpr bool LL = CLM == 3;  // left-looking solve on one workgroup (solve_posterior_ll), N <= 335
+    constexpr bool DF = CLM == 4;  // deferred trailing update on one workgroup (solve_posterior<0, 4>), N <= 319
+    static_assert(!(DF && WIDE), "the deferred update keeps three panels in LDS");
     static_assert(!(LL && WIDE), "the left-looking solve keeps two rows of L in LDS: N <= 335");
     // cluster mode: workgroup b sits on XCD b & 7 (ids go round the XCDs) as the (b >> 3)-th of the launch there; the members of
     // a fit are `cluster` consecutive ones of ONE XCD: fit (i / cluster) * 8 + x of the launch, member i % cluster
@@ -2083,7 +2117,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     }
     Smem S;
     S.pan = smem;
-    S.dli = S.pan + npanels<WIDE>() * NP * PS;
+    S.dli = S.pan + (DF ? 3 : npanels<WIDE>()) * NP * PS;
     // (XWIDE: the vectors live behind the band factors and scan tables in global memory -- the W buffer, or the cs buffer in
     //  cluster mode --, only the panel, the inverse of the diagonal tile and the flags in LDS)
     double *const gscratch = CL ? P.cs : P.W;
@@ -2108,14 +2142,43 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         S.band = P.W;
         S.scanQ = S.band + 6 * NP;
         S.rec = reinterpret_cast<uint4 *>(S.red + NP + 6 * NP + 2 * 6 * 4 * 64);
+    } else if constexpr (DF) {
+        // (three panels in LDS: the band factors and scan tables in the W buffer, which the one-workgroup solve does not use --
+        //  W lives in the dead tiles of C --; wave 0 reads them once per pass, as in the wide instantiations)
+        S.band = P.W;
+        S.scanQ = S.band + 6 * NP;
+        S.rec = reinterpret_cast<uint4 *>(S.red + NP);  // two filtered tile tables of 128 entries (see below)
     } else {
         S.band = S.red + NP;
         S.scanQ = S.band + 6 * NP;  // [2 directions][6 levels][4 entries][64 lanes]
         S.rec = reinterpret_cast<uint4 *>(S.scanQ + 2 * 6 * 4 * 64);  // (16-byte aligned: every region before it is an even number of doubles)
     }
-    S.flag = reinterpret_cast<int *>(S.rec + max_tiles<WIDE>());  // [0] not positive definite, [1] column counter of the inverse row
-    S.hand = (!WIDE && NP <= kHandMaxNP) ? reinterpret_cast<double *>(S.flag + 8) : nullptr;  // (32 bytes of flags; 16-byte aligned)
-    for (int e = tid; e < (LL ? 0 : max_tiles<WIDE>()); e += KT) {  // tile e = (i - 1) i / 2 + (j - 1), 1 <= j <= i
+    S.flag = reinterpret_cast<int *>(S.rec + (DF ? 256 : max_tiles<WIDE>()));  // [0] not positive definite, [1] column counter of the inverse row
+    S.hand = (!WIDE && !DF && NP <= kHandMaxNP) ? reinterpret_cast<double *>(S.flag + 8) : nullptr;  // (32 bytes of flags; 16-byte aligned)
+    S.dcnt = S.flag + 8;  // (deferred mode: 2 x 24 ints behind the flags)
+    if constexpr (DF) {
+        // Deferred mode: at a step of parity par the tiles (i, j) relative to block (k + 1, k + 1), 1 <= j <= i, that are touched
+        // are those with (i + j + par) even -- they take panels k - 1 and k -- and, bit 2 of x set, the other tiles of column
+        // j = 1 (next step's column tiles), which take panel k only.  Row-wise enumeration as in the full table: the tiles of
+        // step k are the entries with i <= nb - k - 2, a prefix; dcnt[par][i] = entries with row <= i.  Built by two threads,
+        // once per fit (~120 entries each).
+        if (tid < 2) {
+            const int par = tid, nbk = NP / 16;
+            int n = 0;
+            S.dcnt[par * 24] = 0;
+            for (int i = 1; i <= 20; ++i) {
+                for (int j = 1; j <= i; ++j) {
+                    const bool own = ((i + j + par) & 1) == 0;
+                    if (!own && j != 1) continue;
+                    S.rec[par * 128 + n++] = make_uint4((unsigned)((j * nbk + i) * 2048) | (i == j ? 2u : 0u) | (own ? 0u : 4u),
+                                                       (unsigned)(j * 16 * PS * 8), (unsigned)(i * 16 * PS * 8),
+                                                       (unsigned)((i * nbk + j) * 2048) | (unsigned)i);
+                }
+                S.dcnt[par * 24 + i] = n;
+            }
+        }
+    }
+    for (int e = tid; e < ((LL || DF) ? 0 : max_tiles<WIDE>()); e += KT) {  // tile e = (i - 1) i / 2 + (j - 1), 1 <= j <= i
         int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while ((i + 1) * (i + 2) / 2 <= e) ++i;
         while (i * (i + 1) / 2 > e) --i;
@@ -2448,6 +2511,11 @@ __global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int 
 static bool loop_is_wide(int NP) { return NP >= kWideMinNP; }
 static bool loop_is_xwide(int NP) { return NP >= kXWideMinNP; }
 int fh_k2_loop_max_np() { return kXWideMaxNP; }
+// deferred mode (fit_loop_kernel<0, 4>): three panels, L_kk^-1 (two), the vectors, two tile tables, flags and counts
+static size_t loop_smem_bytes_deferred(int NP) {
+    return sizeof(double) * (size_t)(3 * NP * PS + 2 * 16 * PS + 8 * NP) + 16 * 256 + 32 + 4 * 48;
+}
+constexpr int kDeferMaxNP = 320;  // (159.7 KB of the 160 KB at NP = 320)
 size_t fh_k2_loop_smem_bytes(int NP) {
     if (loop_is_xwide(NP)) return sizeof(double) * (size_t)(NP * PS + 2 * 16 * PS) + 64;  // the panel, L_kk^-1 (two), the flags
     const bool wide = loop_is_wide(NP);
@@ -2474,7 +2542,7 @@ __global__ __launch_bounds__(KT) void fit_loop_dummy_kernel(long long cycles, in
 
 // one launch of `blocks` workgroups of the instantiation that covers P.NP
 static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s) {
-    const size_t smem = fh_k2_loop_smem_bytes(P.NP);
+    size_t smem = fh_k2_loop_smem_bytes(P.NP);
     if (P.NP > kXWideMaxNP) return hipErrorInvalidValue;
     if (const char *d = getenv("FRANK_AMD_K2_DUMMY")) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_dummy_kernel),
@@ -2522,6 +2590,14 @@ static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s)
     // steady state 1 078 against 1 056 fits/s).
     const char *le = getenv("FRANK_AMD_K2_LL");
     if (le && atoi(le) != 0) return go(&fit_loop_kernel<0, 3>, P, blocks);
+    // The deferred trailing update (round 5; solve_posterior, CLM = 4): the same bits with half the loads and stores of the
+    // trailing update -- what a pass moves beyond the L2 is what bounds a loaded device.  FRANK_AMD_K2_DEFER=0 keeps the
+    // kernel of rounds 2-4 (read at every launch: the tests compare the two inside one process).
+    const char *de = getenv("FRANK_AMD_K2_DEFER");
+    if (P.NP <= kDeferMaxNP && !(de && atoi(de) == 0)) {
+        smem = loop_smem_bytes_deferred(P.NP);
+        return go(&fit_loop_kernel<0, 4>, P, blocks);
+    }
     return go(&fit_loop_kernel<0, 0>, P, blocks);
 }
 

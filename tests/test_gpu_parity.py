@@ -1576,6 +1576,56 @@ def test_left_looking_solve_equals_right_looking(monkeypatch, N):
     assert n == n0 and np.array_equal(mu, mu0) and np.array_equal(p, p0)
 
 
+@pytest.mark.parametrize("N", [15, 16, 33, 47, 130, 200, 300, 303, 304, 319])
+def test_deferred_trailing_update_equals_the_step_by_step_one(monkeypatch, N):
+    """fit_loop.hip, solve_posterior<0, 4> (round 5, the default for N <= 319): a trailing tile is loaded and stored at every
+    OTHER step and takes the two panels it then misses in their order -- against the kernel of rounds 2-4
+    (FRANK_AMD_K2_DEFER=0), which touches every tile at every step: mu, p and the iteration count are the same BITS, for a
+    synchronous fit, for the fits of a batched launch (per-fit hyper-parameters) and for pipelined fits."""
+    import ctypes
+    from frank_amd import _lib
+    FF, M, j = _cluster_problem(N, 100000)
+    ctx = FF._DHT.context()
+    monkeypatch.setenv("FRANK_AMD_K2_CLUSTER", "1")
+    monkeypatch.setenv("FRANK_AMD_SWEEP_NO_CLUSTERS", "1")
+    B = 5
+    al = np.array([1.05, 1.2, 1.05, 1.3, 1.1])
+    p0 = np.full(B, 1e-15)
+    ws = np.array([1e-4, 1e-2, 1e-1, 1e-3, 1e-4])
+
+    def run():
+        out = [_fit_normal(ctx, N, M, j, max_iter=150)[:4]]
+        mu, pp = np.empty((B, N)), np.empty((B, N))
+        nit, st = (ctypes.c_int * B)(), (ctypes.c_int * B)()
+        _lib.check(_lib.lib.fh_fit_normal_batched(ctx, _lib.ptr(M), _lib.ptr(j), B, _lib.ptr(al), _lib.ptr(p0), _lib.ptr(ws), 1e-3, 150,
+                                                  _lib.ptr(mu), _lib.ptr(pp), nit, st))
+        out.append((list(st), mu.copy(), pp.copy(), list(nit)))
+        _lib.check(_lib.lib.fh_stats_upload(ctx, _lib.ptr(M), _lib.ptr(j)))
+        tickets = []
+        for b in range(B):
+            t = ctypes.c_int(-1)
+            _lib.check(_lib.lib.fh_fit_submit(ctx, al[b], 1e-15, ws[b], 1e-3, 150, ctypes.byref(t)))
+            tickets.append(t.value)
+        _lib.check(_lib.lib.fh_fit_flush(ctx))
+        for b, t in enumerate(tickets):
+            m1, p1, n1 = np.empty(N), np.empty(N), ctypes.c_int(0)
+            _lib.check(_lib.lib.fh_fit_collect(ctx, t, _lib.ptr(m1), _lib.ptr(p1), ctypes.byref(n1)))
+            out.append((0, m1, p1, n1.value))
+        return out
+
+    monkeypatch.setenv("FRANK_AMD_K2_DEFER", "0")
+    ref = run()
+    monkeypatch.setenv("FRANK_AMD_K2_DEFER", "1")
+    new = run()
+    assert len(ref) == len(new) == 2 + B
+    for a, b in zip(ref, new):
+        assert a[0] == b[0] and a[3] == b[3], (a[0], b[0], a[3], b[3])
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    # ... and the pipelined / batched fits are the synchronous ones (same hyper-parameters: fit 0)
+    assert new[0][3] == new[1][3][0] == new[2][3]
+    assert np.array_equal(new[0][1], new[1][1][0]) and np.array_equal(new[0][1], new[2][1])
+
+
 def test_diagonal_tile_routines():
     """tile_chol.h: the transposed factor-and-invert routine of round 4 (chol_inv_tile_z, what the fit loop runs) against the
     routine of rounds 2-3 and against the tiles themselves, on 32 random SPD tiles; with and without L^T out it returns the
