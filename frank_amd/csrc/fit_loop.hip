@@ -231,6 +231,89 @@ __device__ __forceinline__ void inverse_tile(const gdouble *Cu, const double *dl
     if (rg == 0) cs_IJ[lane & 15] = ssq;
 }
 
+// TWO rows of the inverse at once (round 5, deferred mode): W_{I-1,J} and W_{I,J}.  With the device full a pass is bound by the
+// bytes it moves beyond the L2, and the row-by-row inverse reads every tile of W so far once per ROW: 1 330 tile loads of W per
+// pass at N = 300 that nothing else shares (the tiles of L of a row are read by every column's wave and come from the L1).
+// Here the sums of the two rows run side by side over K = J .. I - 2 with ONE load of W_KJ for two products; row I then takes
+// its last product, L_{I,I-1} W_{I-1,J}, with W_{I-1,J} straight from the registers it was formed in (the accumulator layout is
+// the B-operand layout).  The same products in the same order into each accumulator as inverse_tile: the same bits.
+// Column J pairs its rows (J + 1, J + 2), (J + 3, J + 4), ..: at step I the columns with J + I even are due; a last single row
+// is left to inverse_tile at the last step.  dli_a, dli_b: L^-1 of the diagonal tiles I - 1 and I (A operands, from LDS).
+#ifndef K2_PAIR
+#define K2_PAIR 1
+#endif
+__device__ __forceinline__ void inverse_pair(const gdouble *Cu, const double *dli_a, const double *dli_b, gdouble *Wu, double *cs_a,
+                                             double *cs_b, int I, int J, int N, int nb, int lane) {
+    const int rg = lane >> 4, cl = lane & 15;
+    const unsigned blk = (unsigned)(nb * 2048);
+    const unsigned oa = (unsigned)((J * nb + I - 1) * 2048);  // tile (K, I - 1) of C = L_{I-1,K}^T; tile (K, I) is the next one
+    const unsigned ob = (unsigned)((J * nb + J) * 2048);      // tile (K, J) of W, K = J
+    const int n = I - 1 - J;                                  // shared products, K = J .. I - 2 (>= 1)
+    v4f64 acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+    struct Operands {
+        v2f64 a1lo, a1hi, a2lo, a2hi, blo, bhi;
+    };
+    const unsigned lane_o = (unsigned)lane * 16u;
+    auto issue = [&](Operands &r, int p) {
+        const unsigned pa = oa + (unsigned)p * blk + lane_o, pb = ob + (unsigned)p * blk + lane_o;
+        asm volatile(
+            "s_nop 4\n\t"  // (see inverse_tile)
+            "global_load_dwordx4 %0, %6, %8\n\tglobal_load_dwordx4 %1, %6, %8 offset:1024\n\t"
+            "global_load_dwordx4 %2, %6, %8 offset:2048\n\tglobal_load_dwordx4 %3, %6, %8 offset:3072\n\t"
+            "global_load_dwordx4 %4, %7, %9\n\tglobal_load_dwordx4 %5, %7, %9 offset:1024"
+            : "=&v"(r.a1lo), "=&v"(r.a1hi), "=&v"(r.a2lo), "=&v"(r.a2hi), "=&v"(r.blo), "=&v"(r.bhi)
+            : "v"(pa), "v"(pb), "s"(Cu), "s"(Wu)
+            : "memory");
+    };
+    auto consume = [&](Operands &r, int p) {
+        if (p + 1 < n) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // (one later product in flight: six loads)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(r.a1lo), "+v"(r.a1hi), "+v"(r.a2lo), "+v"(r.a2hi), "+v"(r.blo), "+v"(r.bhi));
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(r.a1lo[0], r.blo[0], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(r.a2lo[0], r.blo[0], acc2, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(r.a1lo[1], r.blo[1], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(r.a2lo[1], r.blo[1], acc2, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(r.a1hi[0], r.bhi[0], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(r.a2hi[0], r.bhi[0], acc2, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(r.a1hi[1], r.bhi[1], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(r.a2hi[1], r.bhi[1], acc2, 0, 0, 0);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the counts below are of THESE loads)
+    Operands s0, s1;
+    issue(s0, 0);
+    for (int p = 0;; p += 2) {
+        if (p + 1 < n) issue(s1, p + 1);
+        consume(s0, p);
+        if (p + 1 >= n) break;
+        if (p + 2 < n) issue(s0, p + 2);
+        consume(s1, p + 1);
+        if (p + 2 >= n) break;
+    }
+    const v4f64 tl = ld_pk(Cu, (unsigned)(((I - 1) * nb + I) * 2048), lane);  // L_{I,I-1}^T, the A operand of row I's last product
+    auto finish = [&](const v4f64 &acc, const double *dli, int R, double *cs) {
+        Frag fs, fw;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fs.v[q] = acc[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fw.v[q] = dli[cl * PS + 4 * q + rg];
+        v4f64 w = {0.0, 0.0, 0.0, 0.0};
+        w = mfma4(fw, fs, w, true);
+        st_pk(Wu, (unsigned)((R * nb + J) * 2048), lane, w);
+        double ssq = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (16 * R + rg + 4 * r < N) ssq = fma(w[r], w[r], ssq);
+        ssq += __shfl_xor(ssq, 16);
+        ssq += __shfl_xor(ssq, 32);
+        if (rg == 0) cs[lane & 15] = ssq;
+        return w;
+    };
+    const v4f64 w1 = finish(acc1, dli_a, I - 1, cs_a);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tl[q], w1[q], acc2, 0, 0, 0);
+    (void)finish(acc2, dli_b, I, cs_b);
+}
+
 // ---- cluster ("latency") mode: the block columns of the inverse on helper workgroups ---------------------------------------
 // One fit on one CU is a chain: factor-and-invert of a diagonal tile, the column tiles, a barrier -- 19 times per pass -- with
 // the trailing update and the rows of the inverse filling the time in between; half of a pass's matrix instructions (1 311 of
@@ -914,11 +997,30 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
         const char *pan_b = reinterpret_cast<const char *>(pan_cur);
         // columns of row k of the inverse, pulled from an LDS counter, longest chain (J = 0) first (which wave computes a tile
         // does not change its bits); row k of L is final since the panel of step k - 1
-        const double *dli_k = S.dli + (k & 1) * 16 * PS;  // L_kk^-1 = W_kk, left there by the chain of step k - 1
+        // L^-1 of the diagonal tiles in LDS: two buffers in turn -- three in deferred mode, where the rows k - 1 and k of the
+        // inverse are formed together at step k (inverse_pair) while the chain writes that of tile k + 1
+        auto dli_of = [&](int t) { return S.dli + (DF ? t % 3 : (t & 1)) * 16 * PS; };
+        const double *dli_k = dli_of(k);  // L_kk^-1 = W_kk, left there by the chain of step k - 1
         auto inverse_one = [&]() {
             int J = 0;
             if (lane == 0) J = atomicAdd(ctr_cur, 1);
             J = __builtin_amdgcn_readfirstlane(J);
+            if constexpr (DF && K2_PAIR) {
+                // rows k - 1 and k together for the columns with J + k even (inverse_pair); the other columns wait for step
+                // k + 1 -- or, at the last step, take their last row alone
+                if (k < nb - 1) {
+                    J = 2 * J + (k & 1);
+                    if (J > k - 2) return false;
+                } else {
+                    if (J >= k) return false;
+                    if ((J + k) & 1) {
+                        inverse_tile(C_inv, dli_k, W_inv, cs_ptr(k, J), k, J, N, nb, lane);
+                        return true;
+                    }
+                }
+                inverse_pair(C_inv, dli_of(k - 1), dli_k, W_inv, cs_ptr(k - 1, J), cs_ptr(k, J), k, J, N, nb, lane);
+                return true;
+            }
             if (J >= k) return false;
             inverse_tile(C_inv, dli_k, W_inv, cs_ptr(k, J), k, J, N, nb, lane);
             return true;
@@ -946,7 +1048,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 for (int s = 0; s < 4; ++s) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s], pa1[4 * s], a, 0, 0, 0);
                 FSTAMP(8);
                 // factor and invert in the accumulator layout (DPP row broadcasts, no LDS round trip, no transposition)
-                const bool ok = factor_invert_tile(a, xi, S.dli + ((k + 1) & 1) * 16 * PS, lane, aug_tile == k + 1 ? aug_c : -1);
+                const bool ok = factor_invert_tile(a, xi, dli_of(k + 1), lane, aug_tile == k + 1 ? aug_c : -1);
                 if (!ok && lane == 0) *S.flag = 1;
                 FSTAMP(9);
                 if (!CL) store_col_ssq(xi, cs_ptr(k + 1, k + 1), rows_valid(k + 1), lane);
@@ -1124,7 +1226,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
                 TRACE(2);
                 Frag fx;  // L_{k+1,k+1}^-1: as A operand X, as B operand X^T
 #pragma unroll
-                for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[((k + 1) & 1) * 16 * PS + cl * PS + 4 * q + rg];
+                for (int q = 0; q < 4; ++q) fx.v[q] = dli_of(k + 1)[cl * PS + 4 * q + rg];
                 if constexpr (!WIDE) {
                     for (int c = cfirst; c < ncol; c += NWKc) {
                         const int i = c + 1;  // block row I = k + 1 + i
@@ -2121,7 +2223,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     // (XWIDE: the vectors live behind the band factors and scan tables in global memory -- the W buffer, or the cs buffer in
     //  cluster mode --, only the panel, the inverse of the diagonal tile and the flags in LDS)
     double *const gscratch = CL ? P.cs : P.W;
-    S.p = WIDE == 2 ? gscratch + 6 * NP + 2 * 6 * 4 * 64 : S.dli + 2 * 16 * PS;
+    S.p = WIDE == 2 ? gscratch + 6 * NP + 2 * 6 * 4 * 64 : S.dli + (DF ? 3 : 2) * 16 * PS;
     S.pold = S.p + NP;
     S.m = S.pold + NP;
     S.y = S.m + NP;
@@ -2513,9 +2615,9 @@ static bool loop_is_xwide(int NP) { return NP >= kXWideMinNP; }
 int fh_k2_loop_max_np() { return kXWideMaxNP; }
 // deferred mode (fit_loop_kernel<0, 4>): three panels, L_kk^-1 (two), the vectors, two tile tables, flags and counts
 static size_t loop_smem_bytes_deferred(int NP) {
-    return sizeof(double) * (size_t)(3 * NP * PS + 2 * 16 * PS + 8 * NP) + 16 * 256 + 32 + 4 * 48;
+    return sizeof(double) * (size_t)(3 * NP * PS + 3 * 16 * PS + 8 * NP) + 16 * 256 + 32 + 4 * 48;
 }
-constexpr int kDeferMaxNP = 320;  // (159.7 KB of the 160 KB at NP = 320)
+constexpr int kDeferMaxNP = 320;  // (161 888 of the 163 840 bytes at NP = 320)
 size_t fh_k2_loop_smem_bytes(int NP) {
     if (loop_is_xwide(NP)) return sizeof(double) * (size_t)(NP * PS + 2 * 16 * PS) + 64;  // the panel, L_kk^-1 (two), the flags
     const bool wide = loop_is_wide(NP);

@@ -1576,7 +1576,7 @@ def test_left_looking_solve_equals_right_looking(monkeypatch, N):
     assert n == n0 and np.array_equal(mu, mu0) and np.array_equal(p, p0)
 
 
-@pytest.mark.parametrize("N", [15, 16, 33, 47, 130, 200, 300, 303, 304, 319])
+@pytest.mark.parametrize("N", [47, 48, 63, 64, 79, 130, 200, 300, 303, 304, 319])
 def test_deferred_trailing_update_equals_the_step_by_step_one(monkeypatch, N):
     """fit_loop.hip, solve_posterior<0, 4> (round 5, the default for N <= 319): a trailing tile is loaded and stored at every
     OTHER step and takes the two panels it then misses in their order -- against the kernel of rounds 2-4

@@ -1,6 +1,6 @@
 """The deferred trailing update of the fit loop (fit_loop.hip, solve_posterior<0, 4>, FRANK_AMD_K2_DEFER) against the kernel of
 rounds 2-4 over the basis sizes it covers: mu, p and the iteration count must be the same bits.
-    python3 tools/defer_sweep.py [first=16] [last=319] [step=3]
+    python3 tools/defer_sweep.py [first=47] [last=319] [step=3]
 """
 import ctypes
 import os
@@ -13,7 +13,7 @@ os.environ["FRANK_AMD_K2_CLUSTER"] = "1"
 from frank_amd import FixedGeometry, FrankFitter, _lib  # noqa: E402
 from frank_amd.mock import MOCK_GEOMETRY, mock_disc_visibilities  # noqa: E402
 
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 47
 last = int(sys.argv[2]) if len(sys.argv) > 2 else 319
 step = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 u, v, V, w = mock_disc_visibilities(100000, seed=31, noise_seed=32)
