@@ -125,7 +125,7 @@ struct FitSlot {
 // HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; raised to 24 below, so that the streams of several
 // contexts never share one) and two kernels whose streams share a queue serialise (seen in the kernel trace as 190 ms
 // stalls with 32 streams).  But the command processor SERVES about four queues at a time: see FitBatch below.
-constexpr int kFitSlots = 240;  // capacity; fh_fit_slots() is what a context hands out at a time (FRANK_AMD_FIT_SLOTS)
+constexpr int kFitSlots = 255;  // capacity; fh_fit_slots() is what a context hands out at a time (FRANK_AMD_FIT_SLOTS)
 constexpr int kFitBatchMax = FIT_MAX_BATCH;
 constexpr int kFitBatches = 16;
 constexpr int kLaunchStreamsMax = 8;
@@ -2234,7 +2234,7 @@ static int fit_batch_size() {  // fit loops per launch (FRANK_AMD_FIT_BATCH = 1 
     return b < 1 ? 1 : (b > kFitBatchMax ? kFitBatchMax : b);
 }
 static int fit_slots_wanted() {  // fit loops in flight: every one holds a compute unit for the ~0.1 s of its iteration
-    int n = 240;
+    int n = 240;  // (kFitSlots = 255 is the capacity: a slot id is a byte)
     if (const char *e = getenv("FRANK_AMD_FIT_SLOTS")) n = atoi(e);
     return n < 1 ? 1 : (n > kFitSlots ? kFitSlots : n);
 }
@@ -2298,6 +2298,7 @@ static int flush_pending_batch(fh_ctx *c) {
     P.out_host = c->slot_out_host;
     P.result_host = c->slot_result_host;
     P.cluster = b.cluster;
+    P.loaded = c->slots_busy - b.n;  // (fits outstanding beside this launch's: the form of the one-workgroup kernel follows the load)
     if (b.cluster > 1) {  // the fits of consecutive cluster launches go round the XCDs
         P.cluster_xcd0 = c->next_xcd & 7;
         c->next_xcd = (c->next_xcd + b.n) & 7;

@@ -239,9 +239,6 @@ __device__ __forceinline__ void inverse_tile(const gdouble *Cu, const double *dl
 // the B-operand layout).  The same products in the same order into each accumulator as inverse_tile: the same bits.
 // Column J pairs its rows (J + 1, J + 2), (J + 3, J + 4), ..: at step I the columns with J + I even are due; a last single row
 // is left to inverse_tile at the last step.  dli_a, dli_b: L^-1 of the diagonal tiles I - 1 and I (A operands, from LDS).
-#ifndef K2_PAIR
-#define K2_PAIR 1
-#endif
 __device__ __forceinline__ void inverse_pair(const gdouble *Cu, const double *dli_a, const double *dli_b, gdouble *Wu, double *cs_a,
                                              double *cs_b, int I, int J, int N, int nb, int lane) {
     const int rg = lane >> 4, cl = lane & 15;
@@ -868,7 +865,8 @@ __device__ __forceinline__ void inverse_wave_paired(const FitLoopParams &P, int 
 template <int WIDE, int CLM>
 __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Smem &S, int seq) {
     constexpr bool CL = CLM == 1 || CLM == 2;
-    constexpr bool DF = CLM == 4;
+    constexpr bool DF = CLM == 4 || CLM == 5;
+    constexpr bool PAIR = CLM == 5;  // ... and the rows of the inverse in pairs (inverse_pair)
     static_assert(!(DF && WIDE), "the deferred update keeps three panels in LDS: N <= 319");
     constexpr int NWKc = CLM == 2 ? NW - NW / 4 : NWK;  // trailing-update workers
     const int N = P.N, NP = P.NP, nb = P.NP / 16, ld = P.NP;
@@ -1005,7 +1003,7 @@ __device__ __forceinline__ bool solve_posterior(const FitLoopParams &P, const Sm
             int J = 0;
             if (lane == 0) J = atomicAdd(ctr_cur, 1);
             J = __builtin_amdgcn_readfirstlane(J);
-            if constexpr (DF && K2_PAIR) {
+            if constexpr (PAIR) {
                 // rows k - 1 and k together for the columns with J + k even (inverse_pair); the other columns wait for step
                 // k + 1 -- or, at the last step, take their last row alone
                 if (k < nb - 1) {
@@ -2115,7 +2113,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     __shared__ int s_fit;
     constexpr bool CL = CLM == 1 || CLM == 2;
     constexpr bool LL = CLM == 3;  // left-looking solve on one workgroup (solve_posterior_ll), N <= 335
-    constexpr bool DF = CLM == 4;  // deferred trailing update on one workgroup (solve_posterior<0, 4>), N <= 319
+    constexpr bool DF = CLM == 4 || CLM == 5;  // deferred trailing update on one workgroup (solve_posterior<0, 4 | 5>), N <= 319
     static_assert(!(DF && WIDE), "the deferred update keeps three panels in LDS");
     static_assert(!(LL && WIDE), "the left-looking solve keeps two rows of L in LDS: N <= 335");
     // cluster mode: workgroup b sits on XCD b & 7 (ids go round the XCDs) as the (b >> 3)-th of the launch there; the members of
@@ -2698,6 +2696,14 @@ static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s)
     const char *de = getenv("FRANK_AMD_K2_DEFER");
     if (P.NP <= kDeferMaxNP && !(de && atoi(de) == 0)) {
         smem = loop_smem_bytes_deferred(P.NP);
+        // ... and the rows of the inverse in pairs (CLM = 5: one load of W per two products) where the device is FULL: with 256
+        // loops resident a pass takes 186 us against 217 without the pairs (and 264 for the kernel of rounds 2-4), but alone
+        // 156 against 135 (133) -- half as many, twice as long chains per step leave waves idle in the late steps --, level
+        // at ~190 loops.  P.loaded: fit loops that will be resident beside this launch's (the host's count); the same bits
+        // either way.  FRANK_AMD_K2_PAIR = 0 / 1 forces the choice.
+        bool pair = blocks + P.loaded >= 192;
+        if (const char *pe = getenv("FRANK_AMD_K2_PAIR")) pair = atoi(pe) != 0;
+        if (pair) return go(&fit_loop_kernel<0, 5>, P, blocks);
         return go(&fit_loop_kernel<0, 4>, P, blocks);
     }
     return go(&fit_loop_kernel<0, 0>, P, blocks);

@@ -260,6 +260,8 @@ struct FitLoopParams {
     int cluster_xcd0;       // the XCD the first fit of the launch goes to (fit f sits on XCD (cluster_xcd0 + f) & 7): the host
                             // deals the small launches of a filling pipeline round the XCDs (a cluster wants an L2 to itself)
     int nfits;              // fits of a cluster launch (slot launch: entries of slot_words; single fit: 1)
+    int loaded;             // host hint: fit loops already resident on the device when this launch starts (launch_loop picks the
+                            // form of the one-workgroup kernel that suits a full device: the rows of the inverse in pairs)
 };
 #define FIT_MAX_BATCH 128
 #define FIT_CLUSTER_MAX 8
