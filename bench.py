@@ -1023,7 +1023,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.ncoll, a.nvis, nit)
         print(json.dumps(out), flush=True)
     if hung:
-        os._exit(0)  # a collective that never returned cannot be torn down cleanly
+        # a collective that never returned cannot be torn down cleanly; the line (with the leg's error under its key) is out,
+        # and a process that has touched the GPU and gives up says so in its exit code
+        sys.stdout.flush()
+        os._exit(3)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

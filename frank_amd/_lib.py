@@ -6,6 +6,7 @@ every device entry point raises RuntimeError (FH_ERR_HIP) -- there is no CPU pat
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -73,6 +74,7 @@ SIGNATURES = {
     "fh_fit_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "fh_fit_cluster_info": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_i64)]),
     "fh_ctx_loop_clocks": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_i64)]),
+    "fh_ctx_reload_env": (ctypes.c_int, [_vp]),
     "fh_stats_upload": (ctypes.c_int, [_vp, _dp, _dp]),
     "fh_sweep_evidence": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_double, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "fh_stats_get_packed": (ctypes.c_int, [_vp, _dp, _i64, _dp]),
@@ -143,7 +145,19 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 # The one thing this package changes in the process: GPU_MAX_HW_QUEUES=24 unless the variable is set (include/frank_hip.h:
 # fh_init) -- HIP reads it at its first call, and the launches of a pipeline of fits want more than the default four queues.
+_queues_preset = "GPU_MAX_HW_QUEUES" in os.environ
 lib.fh_init()
+# ... which only helps if HIP has not been initialised yet.  The library cannot see that (its check reads the variable it has just
+# set); the one common way to get there from Python -- torch imported first and its HIP runtime already up -- is checked here.
+_torch = sys.modules.get("torch")
+try:
+    if _torch is not None and not _queues_preset and _torch.cuda.is_initialized():
+        import warnings
+        warnings.warn("frank_amd: torch initialised the HIP runtime before frank_amd was imported: GPU_MAX_HW_QUEUES=24 comes too "
+                      "late (the runtime keeps its 4 hardware queues and the launches of a pipeline of fits will share them). "
+                      "Import frank_amd first or export GPU_MAX_HW_QUEUES=24.", RuntimeWarning, stacklevel=2)
+except Exception:
+    pass
 
 
 def last_error():

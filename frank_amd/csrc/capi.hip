@@ -125,7 +125,7 @@ struct FitSlot {
 // HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; raised to 24 below, so that the streams of several
 // contexts never share one) and two kernels whose streams share a queue serialise (seen in the kernel trace as 190 ms
 // stalls with 32 streams).  But the command processor SERVES about four queues at a time: see FitBatch below.
-constexpr int kFitSlots = 255;  // capacity; fh_fit_slots() is what a context hands out at a time (FRANK_AMD_FIT_SLOTS)
+constexpr int kFitSlots = 512;  // capacity; fh_fit_slots() is what a context hands out at a time (FRANK_AMD_FIT_SLOTS)
 constexpr int kFitBatchMax = FIT_MAX_BATCH;
 constexpr int kFitBatches = 16;
 constexpr int kLaunchStreamsMax = 8;
@@ -137,7 +137,7 @@ constexpr int kLaunchStreamsMax = 8;
 struct FitBatch {
     hipStream_t stream = nullptr;  // (one of the context's launch streams; not owned)
     hipEvent_t ready = nullptr, done = nullptr;
-    unsigned char slots[kFitBatchMax];
+    unsigned short slots[kFitBatchMax];
     int n = 0, outstanding = 0;
     bool active = false, launched = false;
     double alpha = 0, p0 = 0, tol = 0;
@@ -177,6 +177,13 @@ struct fh_ctx {
     DevBuf<int> k1_piece0;          // bin_prepass.hip: first partial-moment slot of every bucket
     int bin_cus = 0;                // fh_ctx_set_cu_partition
     bool no_range_cache = false;    // fh_ctx_set_range_cache(ctx, 0): look at (u, v) on every pass (benchmarks of distinct tables)
+    // development switches of the binning pass (FRANK_AMD_K1_*, FRANK_AMD_NO_RANGE_CACHE), read ONCE when the context is created
+    // -- a pass used to make a dozen getenv calls -- and again on fh_ctx_reload_env (tests that switch them inside one process)
+    struct K1Env {
+        int unroll = 2, seg = 4096, wpb = 0, blocks = 0, vrwaves = 8, vrsplit = 8, vrblocks = 0;
+        bool no_range_cache = false, safe_trig = false, no_hist_cache = false, vr_slabs = false, dynamic = false;
+        double reserve_mult = -1.0;
+    } k1env;
     // baseline range of the last pre-pass, keyed by (table, row range, geometry): binning the same rows under the same geometry
     // again (bootstrap draws, pipelines of fits, sweeps) needs no second look at the range before the sort is sized
     unsigned long long range_vis = 0, range_mult_gen = 0;
@@ -220,6 +227,7 @@ struct fh_ctx {
     DevBuf<double> slot_pool;   // backing store of every slot's buffers
     DevBuf<int> slot_results;
     FitSlot slots[kFitSlots];
+    int n_slots = 0;  // slots this context has carved (fit_slots_wanted() when its pool was made; 0: no pool yet)
     FitBatch batches[kFitBatches];
     hipStream_t launch_streams[kLaunchStreamsMax] = {};
     int n_launch_streams = 0;
@@ -341,6 +349,7 @@ int fh_dht_bucket_tables(const fh_dht *d, int b0, int b1, double *table, double 
 }
 
 // ---- contexts -------------------------------------------------------------------------------------------------
+static void load_k1_env(fh_ctx *c);  // (the FRANK_AMD_K1_* switches, read once per context)
 int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     if (!dht || !out) return fail(FH_ERR_INVALID, "fh_ctx_create: NULL argument");
     int ndev = 0;
@@ -353,6 +362,7 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     fh_ctx *c = guard.get();
     c->dht = dht;
     c->device = device;
+    load_k1_env(c);
     const int N = c->N = dht->N;
     const size_t NN = (size_t)N * N;
     hipDeviceProp_t prop;
@@ -967,7 +977,7 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     HIP_TRY(fh_k1_launch_deproject(p, dblocks, c->stream));
     const double gkey[6] = {p.dRA, p.dDec, p.cos_t, p.sin_t, p.cos_i, p.sin_i};
     const bool known = c->range_valid && c->range_vis == vis_serial && c->range_mult_gen == mult_gen && c->range_first == p.first && c->range_count == count &&
-                       memcmp(gkey, c->range_geom, sizeof gkey) == 0 && !c->no_range_cache && !getenv("FRANK_AMD_NO_RANGE_CACHE");
+                       memcmp(gkey, c->range_geom, sizeof gkey) == 0 && !c->no_range_cache && !c->k1env.no_range_cache;
     // qmax_all: over every row of the range whatever its multiplicity -- the sort is sized from it, because rows drawn
     // zero times are still sorted (with weight 0) and must land in a bucket of their own argument
     double qmax = 0.0, qmin = INFINITY, qmax_all = 0.0;
@@ -1045,7 +1055,7 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     const int running = running_fit_loops(c);
     // throughput mode while fit_loop kernels hold CUs (a workgroup that starts late simply takes fewer runs); fits of a
     // pipeline are run-dependent in their last bits anyway; synchronous fits stay static = bitwise reproducible
-    const bool dynamic = (running > 0 || c->slots_busy > 0 || getenv("FRANK_AMD_K1_DYNAMIC") != nullptr) && !c->force_static;
+    const bool dynamic = (running > 0 || c->slots_busy > 0 || c->k1env.dynamic) && !c->force_static;
     Bin2Params bp{};
     bp.N = c->N;
     bp.rows = c->k1_rows.p;
@@ -1092,17 +1102,41 @@ static int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
     return e && *e ? atoi(e) : dflt;
 }
+static void load_k1_env(fh_ctx *c) {
+    fh_ctx::K1Env e;
+    e.unroll = env_int("FRANK_AMD_K1_UNROLL", 2) == 2 ? 2 : 1;
+    e.seg = env_int("FRANK_AMD_K1_SEG", 4096);
+    e.wpb = env_int("FRANK_AMD_K1_WPB", 0);
+    e.blocks = env_int("FRANK_AMD_K1_BLOCKS", 0);
+    e.vrwaves = env_int("FRANK_AMD_K1_VRWAVES", 8);
+    e.vrsplit = env_int("FRANK_AMD_K1_VRSPLIT", 8);
+    e.vrblocks = env_int("FRANK_AMD_K1_VRBLOCKS", 0);
+    e.no_range_cache = getenv("FRANK_AMD_NO_RANGE_CACHE") != nullptr;
+    e.safe_trig = getenv("FRANK_AMD_K1_SAFE_TRIG") != nullptr;
+    e.no_hist_cache = getenv("FRANK_AMD_K1_NO_HIST_CACHE") != nullptr;
+    const char *vr = getenv("FRANK_AMD_K1_VR");
+    e.vr_slabs = vr && !strcmp(vr, "slabs");
+    e.dynamic = getenv("FRANK_AMD_K1_DYNAMIC") != nullptr;
+    if (const char *r = getenv("FRANK_AMD_K1_RESERVE_MULT")) e.reserve_mult = atof(r);
+    c->k1env = e;
+}
+int fh_ctx_reload_env(fh_ctx *c) {
+    if (!c) return fail(FH_ERR_INVALID, "fh_ctx_reload_env: NULL argument");
+    load_k1_env(c);
+    return FH_OK;
+}
 static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned long long vis_serial,
                                unsigned long long mult_gen) {
     PrepassParams P{};
     P.bin = p;
     P.partial_scalars = c->partial_scalars.p;
-    P.unroll = env_int("FRANK_AMD_K1_UNROLL", 2) == 2 ? 2 : 1;
+    const fh_ctx::K1Env &E = c->k1env;
+    P.unroll = E.unroll;
     HIP_TRY(hipEventRecord(c->ev_pre0, c->stream));
     const double gkey[6] = {p.dRA, p.dDec, p.cos_t, p.sin_t, p.cos_i, p.sin_i};
     const bool known = c->range_valid && c->range_vis == vis_serial && c->range_mult_gen == mult_gen && c->range_first == p.first &&
                        c->range_count == count && memcmp(gkey, c->range_geom, sizeof gkey) == 0 && !c->no_range_cache &&
-                       !getenv("FRANK_AMD_NO_RANGE_CACHE");
+                       !E.no_range_cache;
     // qmax_all: over every row of the range whatever its multiplicity -- the sort is sized from it, because rows drawn
     // zero times are still sorted (with weight 0) and must land in a bucket of their own argument
     double qmax = 0.0, qmin = INFINITY, qmax_all = 0.0;
@@ -1148,12 +1182,12 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
                     "raise N", smax, nb);
     int rc = k1v2_ensure_table(c, nb);
     if (rc) return rc;
-    int seg = env_int("FRANK_AMD_K1_SEG", 4096);
+    int seg = E.seg;
     seg = seg < 128 ? 128 : ((seg + 127) & ~127);
     fh_prepass_geometry(nb, c->num_cu, &P.wpb, &P.blocks);
-    if (const int w = env_int("FRANK_AMD_K1_WPB", 0)) {  // development: waves per workgroup / workgroups of P1, P2
+    if (const int w = E.wpb) {  // development: waves per workgroup / workgroups of P1, P2
         P.wpb = w;
-        P.blocks = env_int("FRANK_AMD_K1_BLOCKS", P.blocks);
+        if (E.blocks > 0) P.blocks = E.blocks;
     }
     if (P.blocks > c->deproject_blocks) P.blocks = c->deproject_blocks;  // (entries of partial_scalars)
     // workspaces (grow on demand)
@@ -1181,7 +1215,7 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     P.seg_rows = seg;
     P.dummy_row = (int64_t)nrows;  // (the buffer holds nrows + 341 rows)
     // |u|, |v| <= q / cos(inc), so |phase| <= (|dRA| + |dDec|) qmax / |cos(inc)|: beyond 1e5 rad the library's sincos
-    P.safe_trig = !((fabs(p.dRA) + fabs(p.dDec)) * qmax_all < 1.0e5 * fabs(p.cos_i)) || getenv("FRANK_AMD_K1_SAFE_TRIG");
+    P.safe_trig = !((fabs(p.dRA) + fabs(p.dDec)) * qmax_all < 1.0e5 * fabs(p.cos_i)) || E.safe_trig;
     P.hist = c->k1_hist.p;
     P.totals = c->k1_totals.p;
     P.starts = c->k1_starts.p;
@@ -1195,7 +1229,7 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     // the same rows under the same geometry as the last pass of this context (bootstrap-free pipelines, sweeps that re-bin, the
     // bench's steps): the histograms, their scan and the table layout are still in place -- P1 and the scan are skipped
     const bool reuse = known && c->hist_valid && c->hist_nb == nb && c->hist_blocks == P.blocks && c->hist_wpb == P.wpb &&
-                       c->hist_unroll == P.unroll && c->hist_seg == seg && !getenv("FRANK_AMD_K1_NO_HIST_CACHE");
+                       c->hist_unroll == P.unroll && c->hist_seg == seg && !E.no_hist_cache;
     c->hist_valid = false;
     HIP_TRY(fh_prepass_launch(P, c->stream, reuse ? 1 : 0));
     c->hist_valid = true;
@@ -1207,8 +1241,7 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
 
     // the Gram of the virtual rows: one 16-row chunk per non-empty bucket (a few hundred to a few thousand chunks); one
     // workgroup (or a few) per output tile, no slabs (vr_gram_kernel).  FRANK_AMD_K1_VR=slabs keeps bin_gram2_kernel<.., VR>.
-    const char *vrenv = getenv("FRANK_AMD_K1_VR");
-    if (!(vrenv && !strcmp(vrenv, "slabs") && c->rows_ok)) {  // (bin_gram2_kernel's tile maps stop at N = 511)
+    if (!(E.vr_slabs && c->rows_ok)) {  // (bin_gram2_kernel's tile maps stop at N = 511)
         VrGramParams G{};
         G.N = c->N;
         G.NBT = c->NBT;
@@ -1216,9 +1249,9 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
         G.ntiles = c->ntiles;
         // eight workgroups per tile -- workgroup ids go round the eight XCDs, so an XCD's L2 holds one eighth of the tables
         // (7 MB at N = 300: read once per workgroup they came from memory, 42 us) -- of eight waves each
-        G.waves = env_int("FRANK_AMD_K1_VRWAVES", 8);
+        G.waves = E.vrwaves;
         G.waves = G.waves < 4 ? 4 : (G.waves > 16 ? 16 : G.waves);  // (the tile is folded by the workgroup's first 256 threads)
-        int split = env_int("FRANK_AMD_K1_VRSPLIT", 8);
+        int split = E.vrsplit;
         G.split = split < 1 ? 1 : (split > 8 ? 8 : split);
         G.vrows = c->k1_vrows.p;
         G.vbucket = c->k1_vbucket.p;
@@ -1253,7 +1286,7 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     ReduceParams rp{};
     rp.nparts = c->nparts;
     rp.ntiles = c->ntiles;
-    int vr_blocks = env_int("FRANK_AMD_K1_VRBLOCKS", nb < 512 ? 32 : 64);
+    int vr_blocks = E.vrblocks > 0 ? E.vrblocks : (nb < 512 ? 32 : 64);
     int G = 0;
     for (int Pt = 0; Pt < c->nparts; ++Pt) G += c->part_blocks[Pt];
     if (vr_blocks > G) vr_blocks = G;
@@ -1393,7 +1426,7 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     // throughput mode while such kernels hold CUs (see bin_gram.hip)
     // (also while fits of a pipeline are merely outstanding: the dynamic hand-out is 2 % faster even on an empty GPU,
     // 26.7 vs 27.2 ms, and a pipeline's sums are run-dependent in their last bits anyway; synchronous fits stay static)
-    const bool dynamic = (running > 0 || c->slots_busy > 0 || getenv("FRANK_AMD_K1_DYNAMIC") != nullptr) && !c->force_static;
+    const bool dynamic = (running > 0 || c->slots_busy > 0 || c->k1env.dynamic) && !c->force_static;
     p.work_counter = dynamic ? c->work_counter.p : nullptr;
     if (dynamic) HIP_TRY(hipMemsetAsync(c->work_counter.p, 0, 2 * sizeof(int), c->stream));
     ReduceParams rp{};
@@ -1401,7 +1434,7 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
     rp.ntiles = c->ntiles;
     // leave one CU per outstanding fit_loop kernel (each occupies a whole CU) so every bin_gram workgroup is resident
     int reserve = running;
-    if (const char *e = getenv("FRANK_AMD_K1_RESERVE_MULT")) reserve = (int)(running * atof(e));  // development switch
+    if (c->k1env.reserve_mult >= 0.0) reserve = (int)(running * c->k1env.reserve_mult);  // development switch
     if (reserve > c->num_cu / 4) reserve = c->num_cu / 4;
     const int G = c->part_blocks[0] + c->part_blocks[1];
     for (int P = 0; P < 2; ++P) {
@@ -2094,6 +2127,22 @@ static int update_power_spectrum_rocsolver(fh_ctx *c, const double *M, const dou
     return FH_OK;
 }
 
+// Launch order of the points of a sweep: ascending alpha, then ascending w_smooth (the long fits first, see fh_fit_normal_batched).
+// The caller's values are not validated here -- a NaN hyper-parameter is a per-point status, as before --, so the comparison
+// runs on keys that send NaN to +infinity: a strict weak ordering whatever the input (std::stable_sort on `<` of raw doubles
+// with a NaN among them is undefined behaviour).
+static std::vector<int> sweep_launch_order(const double *alpha, const double *wsmooth, int batch) {
+    std::vector<int> order((size_t)batch);
+    for (int b = 0; b < batch; ++b) order[b] = b;
+    if (getenv("FRANK_AMD_SWEEP_GRID_ORDER")) return order;
+    auto key = [](double x) { return std::isnan(x) ? INFINITY : x; };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+        const double ax = key(alpha[x]), ay = key(alpha[y]);
+        return ax != ay ? ax < ay : key(wsmooth[x]) < key(wsmooth[y]);
+    });
+    return order;
+}
+
 int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch, const double *alpha, const double *p0,
                           const double *wsmooth, double tol, int max_iter, double *mu, double *p, int *niter,
                           int *status) {
@@ -2131,12 +2180,7 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     // and, at equal alpha, with a weaker smoothing prior; on the 32 x 16 grid of BASELINE configs[4] the seven points that reach
     // max_iter all have alpha = 1.01 -- in grid order the last of them started 100 ms into the launch.  order[k] = the caller's
     // index of the fit launched k-th; the outputs are put back in the caller's order.
-    std::vector<int> order(B);
-    for (int b = 0; b < batch; ++b) order[b] = b;
-    if (!getenv("FRANK_AMD_SWEEP_GRID_ORDER"))
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-            return alpha[x] != alpha[y] ? alpha[x] < alpha[y] : wsmooth[x] < wsmooth[y];
-        });
+    const std::vector<int> order = sweep_launch_order(alpha, wsmooth, batch);
     // ... and the first K of them -- the ones that will still be iterating when every other fit of the sweep has ended -- do not
     // join the batch at all: they are launched on CLUSTERS of workgroups (fit_loop.hip: 98 instead of 136 us per pass once the
     // device has emptied) through the fit slots, beside the batched launch of the rest on the compute units they leave free.
@@ -2149,6 +2193,19 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
         }
     }
     std::vector<int> tickets(K, -1);
+    // whatever path leaves this function: every ticket issued and not yet collected is collected (results dropped) -- a slot left
+    // busy would shrink the pool and keep later fits of this context off the clusters (slots_busy never back to 0)
+    struct TicketGuard {
+        fh_ctx *c;
+        std::vector<int> &t;
+        ~TicketGuard() {
+            for (int &x : t)
+                if (x >= 0 && c->slots[x].busy) {
+                    (void)fh_fit_collect(c, x, nullptr, nullptr, nullptr);
+                    x = -1;
+                }
+        }
+    } ticket_guard{c, tickets};
     if (K > 0) {
         const bool had = c->have_device_Mj;
         c->have_device_Mj = true;  // (M, j are on the device: uploaded above or by the caller's finalisation)
@@ -2214,6 +2271,7 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     for (int k = 0; k < K; ++k) {  // the fits that ran on clusters
         const int b = order[k];
         const int rcc = fh_fit_collect(c, tickets[k], mu + (size_t)b * N, p + (size_t)b * N, &niter[b]);
+        tickets[k] = -1;  // (collected, whatever it returned)
         if (rcc != FH_OK && rcc != FH_ERR_BAD_P && rcc != FH_ERR_NOT_SPD) return rcc;
         if (status) status[b] = rcc;
     }
@@ -2234,7 +2292,7 @@ static int fit_batch_size() {  // fit loops per launch (FRANK_AMD_FIT_BATCH = 1 
     return b < 1 ? 1 : (b > kFitBatchMax ? kFitBatchMax : b);
 }
 static int fit_slots_wanted() {  // fit loops in flight: every one holds a compute unit for the ~0.1 s of its iteration
-    int n = 240;  // (kFitSlots = 255 is the capacity: a slot id is a byte)
+    int n = 240;  // (kFitSlots = 512 is the capacity)
     if (const char *e = getenv("FRANK_AMD_FIT_SLOTS")) n = atoi(e);
     return n < 1 ? 1 : (n > kFitSlots ? kFitSlots : n);
 }
@@ -2293,12 +2351,12 @@ static int flush_pending_batch(fh_ctx *c) {
     P.p_out = s0.p_out.p;
     P.result = s0.result.p;
     P.slot_stride = c->slot_stride;
-    for (int i = 0; i < FIT_MAX_BATCH / 8; ++i) P.slot_words[i] = 0;
-    for (int i = 0; i < b.n; ++i) P.slot_words[i >> 3] |= (unsigned long long)b.slots[i] << (8 * (i & 7));
+    for (int i = 0; i < FIT_MAX_BATCH / 4; ++i) P.slot_words[i] = 0;
+    for (int i = 0; i < b.n; ++i) P.slot_words[i >> 2] |= (unsigned long long)b.slots[i] << (16 * (i & 3));
     P.out_host = c->slot_out_host;
     P.result_host = c->slot_result_host;
     P.cluster = b.cluster;
-    P.loaded = c->slots_busy - b.n;  // (fits outstanding beside this launch's: the form of the one-workgroup kernel follows the load)
+    P.loaded = env_int("FRANK_AMD_FIT_LOADED", 0);  // (development: what launch_loop takes for the loops resident beside this launch's)
     if (b.cluster > 1) {  // the fits of consecutive cluster launches go round the XCDs
         P.cluster_xcd0 = c->next_xcd & 7;
         c->next_xcd = (c->next_xcd + b.n) & 7;
@@ -2321,24 +2379,25 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
     if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 1023", c->N);
     if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
     HIP_TRY(hipSetDevice(c->device));
+    if (!c->n_slots) c->n_slots = fit_slots_wanted();
     int si = -1;
-    for (int i = 0; i < kFitSlots; ++i)
+    for (int i = 0; i < c->n_slots; ++i)
         if (!c->slots[i].busy) {
             si = i;
             break;
         }
-    if (si < 0) return fail(FH_ERR_INVALID, "fh_fit_submit: all %d fit slots are outstanding; collect one first", kFitSlots);
+    if (si < 0) return fail(FH_ERR_INVALID, "fh_fit_submit: all %d fit slots are outstanding; collect one first", c->n_slots);
     const int N = c->N;
     const size_t PP = (size_t)c->NP * c->NP;
     if (!c->slot_pool.p) {
         // all slots at once, carved from ONE allocation: a hipMalloc per buffer costs ~0.7 ms of host time, and paying
         // 11 of them whenever a fresh slot is first used put an 8 ms hole after every binning pass of a pipeline
         const size_t per_slot = 3 * PP + (size_t)c->NP * 16 + fh_k2_cs_doubles(c->NP) + 3 * (size_t)N + 5 * (size_t)N + 2;
-        HIP_TRY(c->slot_pool.alloc(per_slot * kFitSlots));
-        HIP_TRY(c->slot_results.alloc(2 * kFitSlots));
-        HIP_TRY(hipMemsetAsync(c->slot_pool.p, 0, sizeof(double) * per_slot * kFitSlots, c->stream));
+        HIP_TRY(c->slot_pool.alloc(per_slot * (size_t)c->n_slots));
+        HIP_TRY(c->slot_results.alloc(2 * (size_t)c->n_slots));
+        HIP_TRY(hipMemsetAsync(c->slot_pool.p, 0, sizeof(double) * per_slot * (size_t)c->n_slots, c->stream));
         c->slot_stride = per_slot;
-        for (int i = 0; i < kFitSlots; ++i) {
+        for (int i = 0; i < c->n_slots; ++i) {
             FitSlot &t = c->slots[i];
             double *b = c->slot_pool.p + per_slot * i;
             t.Aq.adopt(b, PP); b += PP;
@@ -2366,8 +2425,8 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
             HIP_TRY(hipEventCreateWithFlags(&bt.ready, hipEventDisableTiming | hipEventReleaseToDevice));  // (same device: no system-scope write-back)
             HIP_TRY(hipEventCreateWithFlags(&bt.done, hipEventDisableTiming));  // (system-scope release: the host reads the mirrors)
         }
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->slot_out_host), sizeof(double) * 2 * (size_t)N * kFitSlots, hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->slot_result_host), sizeof(int) * 2 * kFitSlots, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->slot_out_host), sizeof(double) * 2 * (size_t)N * (size_t)c->n_slots, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->slot_result_host), sizeof(int) * 2 * (size_t)c->n_slots, hipHostMallocDefault));
         c->fit_batch = fit_batch_size();
     }
     // a launch carries ONE (tol, max_iter); alpha, p0 and w_smooth are per fit (they travel with the slot's band LU)
@@ -2415,7 +2474,7 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
     int rc = prepare_qspace(c, s.Aq.p, s.bq.p);  // on the context's stream, after the finalize that produced M, j
     if (rc) return rc;
     FitBatch &b = c->batches[c->pending_batch];
-    b.slots[b.n++] = (unsigned char)si;
+    b.slots[b.n++] = (unsigned short)si;
     ++b.outstanding;
     s.batch = c->pending_batch;
     s.busy = true;
@@ -2443,7 +2502,7 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
 }
 
 int fh_fit_collect(fh_ctx *c, int ticket, double *mu, double *p, int *niter) {
-    if (!c || ticket < 0 || ticket >= kFitSlots || !c->slots[ticket].busy)
+    if (!c || ticket < 0 || ticket >= c->n_slots || !c->slots[ticket].busy)
         return fail(FH_ERR_INVALID, "fh_fit_collect: bad ticket %d", ticket);
     HIP_TRY(hipSetDevice(c->device));
     FitSlot &s = c->slots[ticket];
@@ -2471,7 +2530,7 @@ int fh_fit_collect(fh_ctx *c, int ticket, double *mu, double *p, int *niter) {
         P.p_out = s0.p_out.p;
         P.result = s0.result.p;
         P.slot_stride = c->slot_stride;
-        for (int i = 0; i < FIT_MAX_BATCH / 8; ++i) P.slot_words[i] = 0;
+        for (int i = 0; i < FIT_MAX_BATCH / 4; ++i) P.slot_words[i] = 0;
         P.slot_words[0] = (unsigned long long)ticket;
         P.out_host = c->slot_out_host;
         P.result_host = c->slot_result_host;
@@ -3386,12 +3445,7 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
     // The workgroups pull the fits in launch order and the launch ends with its slowest fit: as in fh_fit_normal_batched the
     // points most likely to run to max_iter -- alpha next to 1 (filter.py:172), then the weaker smoothing prior -- go first.
     // order[k] = the caller's index of the fit launched k-th; the outputs are put back in the caller's order.
-    std::vector<int> order(B);
-    for (int b = 0; b < batch; ++b) order[b] = b;
-    if (!getenv("FRANK_AMD_SWEEP_GRID_ORDER"))
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-            return alpha[x] != alpha[y] ? alpha[x] < alpha[y] : wsmooth[x] < wsmooth[y];
-        });
+    const std::vector<int> order = sweep_launch_order(alpha, wsmooth, batch);
     std::vector<double> lu_all(B * 5 * N), lu, al_o(B), p0_o(B);
     for (int k = 0; k < batch; ++k) {
         smoothing_band_lu(*c->dht, wsmooth[order[k]], lu);

@@ -2152,24 +2152,16 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     if (P.slot_stride) {
         // (constant indices only: a dynamic index into the by-value parameter struct forces the WHOLE struct into scratch
         // memory, every later P.field a scratch load and the prologue 256 bytes of scratch stores)
-        const int g = launch_index >> 3;  // (uniform selects between constant indices)
+        const int g = launch_index >> 2;  // (uniform selects between constant indices; four 16-bit slot ids to a word)
         unsigned long long wsel = P.slot_words[0];
-        if (g == 1) wsel = P.slot_words[1];
-        if (g == 2) wsel = P.slot_words[2];
-        if (g == 3) wsel = P.slot_words[3];
-        if (g == 4) wsel = P.slot_words[4];
-        if (g == 5) wsel = P.slot_words[5];
-        if (g == 6) wsel = P.slot_words[6];
-        if (g == 7) wsel = P.slot_words[7];
-        if (g == 8) wsel = P.slot_words[8];
-        if (g == 9) wsel = P.slot_words[9];
-        if (g == 10) wsel = P.slot_words[10];
-        if (g == 11) wsel = P.slot_words[11];
-        if (g == 12) wsel = P.slot_words[12];
-        if (g == 13) wsel = P.slot_words[13];
-        if (g == 14) wsel = P.slot_words[14];
-        if (g == 15) wsel = P.slot_words[15];
-        const int sl = (int)((wsel >> (8 * (launch_index & 7))) & 0xffull);
+#define FH_SLOT_WORD(i) if (g == (i)) wsel = P.slot_words[i];
+        FH_SLOT_WORD(1) FH_SLOT_WORD(2) FH_SLOT_WORD(3) FH_SLOT_WORD(4) FH_SLOT_WORD(5) FH_SLOT_WORD(6) FH_SLOT_WORD(7)
+        FH_SLOT_WORD(8) FH_SLOT_WORD(9) FH_SLOT_WORD(10) FH_SLOT_WORD(11) FH_SLOT_WORD(12) FH_SLOT_WORD(13) FH_SLOT_WORD(14)
+        FH_SLOT_WORD(15) FH_SLOT_WORD(16) FH_SLOT_WORD(17) FH_SLOT_WORD(18) FH_SLOT_WORD(19) FH_SLOT_WORD(20) FH_SLOT_WORD(21)
+        FH_SLOT_WORD(22) FH_SLOT_WORD(23) FH_SLOT_WORD(24) FH_SLOT_WORD(25) FH_SLOT_WORD(26) FH_SLOT_WORD(27) FH_SLOT_WORD(28)
+        FH_SLOT_WORD(29) FH_SLOT_WORD(30) FH_SLOT_WORD(31)
+#undef FH_SLOT_WORD
+        const int sl = (int)((wsel >> (16 * (launch_index & 3))) & 0xffffull);
         const size_t off = (size_t)sl * P.slot_stride;
         P.A += off;
         P.bq += off;

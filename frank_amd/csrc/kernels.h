@@ -244,7 +244,7 @@ struct FitLoopParams {
     // slot launch (pipelined fits, one workgroup per fit, every operand per fit): the pointers above are those of slot 0,
     // slot i lives slot_stride doubles further (results: 2 ints further); workgroup b runs slot slot_ids[b]
     size_t slot_stride;
-    unsigned long long slot_words[16];  // 128 slot ids, eight to a word (FIT_MAX_BATCH)
+    unsigned long long slot_words[32];  // 128 slot ids of 16 bits, four to a word (FIT_MAX_BATCH)
     // pinned host mirrors of a slot's outputs (the pipeline reads them after the launch's completion event, no copy on any
     // stream): [mu (N), p (N)] and [count, status] per slot, strides 2 N doubles / 2 ints; NULL: none
     double *out_host;

@@ -140,6 +140,30 @@ class DiscreteHankelTransform(object):
             return 0.5 * self._j_nN * norm * self._Ykm
         return self._device_coefficients(q, direction, 1.0)
 
+    def interpolation_coefficients(self, q, space='Real'):
+        """hankel.py:206-236: the matrix Y with f(q) = np.dot(Y, f) of the Fourier-Bessel interpolation,
+        Y[i, k] = J0(x_i) [x_i < j_N] * 2 j_k / J1(j_k) / (j_k^2 - x_i^2), x = 2 pi q Qmax ('Real') or 2 pi q Rmax ('Fourier').
+        J0(x_i) comes from the device generator of `coefficients` (its first column evaluated at q_i = x_i Qmax / j_1), J1(j_k)
+        from the scale factor 1 / J1(j_k)^2 the transform already holds (the sign alternates from zero to zero)."""
+        if space == 'Real':
+            x = np.atleast_1d(2 * np.pi * np.asarray(q, dtype=float) * self._Qmax)
+        elif space == 'Fourier':
+            x = np.atleast_1d(2 * np.pi * np.asarray(q, dtype=float) * self._Rmax)
+        else:
+            raise ValueError("Space must be one of 'Real' or 'Fourier', not "
+                             f"{space}.")
+        x = x.reshape(-1)
+        norm = 1 / (np.pi * self._Qmax ** 2)
+        H = self._device_coefficients(x * (self._Qmax / self._j_nk[0]), 'forward', 1.0)
+        j0x = H[:, 0] / (norm * self._scale_factor[0])
+        jnup = np.where(np.arange(self._N) % 2 == 0, 1.0, -1.0) / np.sqrt(self._scale_factor)  # J1 at the zeros of J0
+        coeff = np.outer(np.where(x < self._j_nN, j0x, 0), 2 * self._j_nk / jnup)
+        return coeff / (self._j_nk.reshape(1, -1) ** 2 - x.reshape(-1, 1) ** 2)
+
+    def interpolate(self, f, q, space='Real'):
+        """hankel.py:238-263: f (given at the collocation points) at the points q, consistent with the Fourier-Bessel series."""
+        return np.dot(self.interpolation_coefficients(q, space), f)
+
     def _device_coefficients(self, q, direction, scale):
         q = _lib.f8(np.atleast_1d(q)).reshape(-1)
         H = np.empty((q.size, self._N))

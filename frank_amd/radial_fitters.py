@@ -50,6 +50,14 @@ class FrankRadialFit(metaclass=abc.ABCMeta):
         # no geometry at all (radial_fitters.py:88-90): the baselines are taken as deprojected
         return self._vis_map.predict_visibilities(I, np.hypot(u, v), np.zeros_like(u), geometry=geometry)
 
+    def interpolate_brightness(self, Rpts, I=None):
+        """radial_fitters.py:146-176: the brightness profile at the radii Rpts (arcsec) by the Fourier-Bessel series.  I: the
+        profile at the collocation points; None takes the MAP (what the reference documents -- its code hands None on)."""
+        Rpts = np.array(Rpts)
+        if I is None:
+            I = self.I
+        return self._vis_map.interpolate(I, Rpts, space='Real')
+
     def predict_deprojected(self, q=None, I=None, geometry=None, block_size=10 ** 5,
                             assume_optically_thick=True):
         r"""Predict the visibilities in the deprojected-plane (radial_fitters.py:100-144)."""

@@ -209,6 +209,21 @@ class VisibilityMapping:
             return np.cos(geometry.inc * deg_to_rad)
         return 1.0
 
+    def interpolate(self, f, r, space='Real'):
+        """statistical_models.py:435-481: f (at the collocation points) interpolated to the points r -- arcsec in 'Real' space,
+        lambda in 'Fourier' space --, in chunks when the mapping was built with block_data."""
+        if space == 'Real':
+            r = r / rad_to_arcsec
+        r = np.array(r)
+        shape = r.shape
+        r = r.reshape(-1)
+        Ni = int(self._chunk_size / len(r) + 1) if self._chunking else len(r)
+        out, end = [], 0
+        while end < len(r):
+            start, end = end, end + Ni
+            out.append(self._DHT.interpolate(f, r[start:end], space))
+        return np.concatenate(out).reshape(*shape)
+
     def predict_visibilities(self, I, q, k=None, geometry=None):
         r"""V(q) = H(q) I on the GPU (statistical_models.py:279-329)."""
         q = _lib.f8(np.atleast_1d(q)).reshape(-1)

@@ -281,6 +281,10 @@ int fh_sweep_evidence(fh_ctx *ctx, const double *M, const double *j, double H0, 
  * context that did not assemble on one XCD within 3 ms and were repeated on one compute unit (either may be NULL).     */
 int fh_fit_cluster_info(fh_ctx *ctx, int *workgroups, int64_t *fallbacks);
 
+/* The development switches of the binning pass (FRANK_AMD_K1_*, FRANK_AMD_NO_RANGE_CACHE) are read from the environment ONCE,
+ * when a context is created; this reads them again (tests that switch them inside one process).                          */
+int fh_ctx_reload_env(fh_ctx *ctx);
+
 /* Measurement aid (no counterpart in the reference): the clock the fit loops of this context ran at.  on != 0 switches a
  * probe on -- every fit loop then adds its shader-clock cycles, its ticks of the constant 100 MHz wall clock and its passes
  * (posterior solves) to three device counters --, on == 0 off; out3 (may be NULL) receives the sums since the last call and

@@ -20,7 +20,12 @@ CASES = {  # N, rows, vis_model, scale height
     "tiles_N300": (300, 200001, "opt_thick", None),
     "wide_N320": (320, 60001, "opt_thick", None),
     "debris_N40": (40, 6001, "debris", lambda r: 0.05 + 0.02 * r),
+    # the reference's own headline run (tests/golden/fit_N300_1e7.npz: seeds 0 / 50), 5e6 rows per rank
+    "ref_N300_1e7": (300, 10000000, "opt_thick", None),
+    # the per-GPU share of BASELINE configs[3] (1e8 rows over eight GPUs): two ranks of 1.25e7 rows each
+    "share_2x1p25e7": (300, 25000000, "opt_thick", None),
 }
+SEEDS = {"ref_N300_1e7": (0, 50), "share_2x1p25e7": (0, 50)}
 HYPER = dict(alpha=1.05, p0=1e-15, wsmooth=1e-4, tol=1e-3, max_iter=2000)
 
 
@@ -38,7 +43,8 @@ def main():
         os.environ["FRANK_AMD_COMM"] = "host"
     device = rank % ndev
     N, nvis, vis_model, sh = CASES[case]
-    u, v, V, w = mock_disc_visibilities(nvis, seed=41, noise_seed=42)
+    sd, nsd = SEEDS.get(case, (41, 42))
+    u, v, V, w = mock_disc_visibilities(nvis, seed=sd, noise_seed=nsd)
     kw = dict(verbose=False, device=device)
     if vis_model == "debris":
         kw.update(assume_optically_thick=False, scale_height=sh)

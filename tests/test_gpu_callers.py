@@ -451,3 +451,45 @@ def test_predict_sky_through_the_bucket_tables():
     # the fit's own statistics are untouched by the call: binning the same table again gives the same fit
     again = FrankFitter(2.0, 120, FixedGeometry(34.97, 85.76, 1.9e-3, 2.5e-3), verbose=False).fit(u, v, V, w)
     assert np.array_equal(again.I, sol.I)
+
+
+def test_fourier_bessel_interpolation_against_the_reference(golden):
+    """DiscreteHankelTransform.interpolation_coefficients / interpolate, VisibilityMapping.interpolate and
+    FrankRadialFit.interpolate_brightness (hankel.py:206-263, statistical_models.py:435-481, radial_fitters.py:146-176)
+    against the reference's own outputs (tools/make_golden_interp.py): both spaces, points beyond Rmax / Qmax (the series is
+    cut there), r = 0, a point between two collocation points, an array of any shape in chunks; and the gaussian of the
+    reference's test_hankel_gauss between its collocation points (tests.py:37-82: atol 1e-4 for generic points)."""
+    from frank_amd import DiscreteHankelTransform, FixedGeometry, VisibilityMapping
+    from frank_amd.constants import rad_to_arcsec
+    g = golden("interpolate.npz")
+    for N, Rmax in ((100, 5.0), (300, 2.0 / rad_to_arcsec)):
+        d = DiscreteHankelTransform(Rmax, N)
+        for pts, space, Y, fin, fout in (("rpts", "Real", "Yreal", "f", "freal"), ("qpts", "Fourier", "Yfourier", "g", "gfourier")):
+            Yd = d.interpolation_coefficients(g["N%d_%s" % (N, pts)], space)
+            Yr = g["N%d_%s" % (N, Y)]
+            assert Yd.shape == Yr.shape
+            assert np.abs(Yd - Yr).max() <= 1e-11 * np.abs(Yr).max()
+            out = d.interpolate(g["N%d_%s" % (N, fin)], g["N%d_%s" % (N, pts)], space)
+            np.testing.assert_allclose(out, g["N%d_%s" % (N, fout)], rtol=0, atol=1e-11 * np.abs(g["N%d_%s" % (N, fout)]).max())
+        with pytest.raises(ValueError):
+            d.interpolation_coefficients(np.array([0.1]), "sideways")    # hankel.py:229-231
+    d = DiscreteHankelTransform(5.0, 100)
+    out = d.interpolate(np.exp(-0.5 * d.r ** 2), g["gauss_r"], "Real")
+    np.testing.assert_allclose(out, g["gauss_interp"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out[:-1], np.exp(-0.5 * g["gauss_r"][:-1] ** 2), rtol=0, atol=1e-4)   # (r = Rmax: the series is 0)
+    d = DiscreteHankelTransform(2.0 / rad_to_arcsec, 50)
+    vm = VisibilityMapping(d, FixedGeometry(30., 40., 0., 0.), block_size=700, verbose=False)
+    o = vm.interpolate(g["vm_I"], g["vm_R"], space="Real")
+    assert o.shape == g["vm_out"].shape
+    np.testing.assert_allclose(o, g["vm_out"], rtol=0, atol=1e-12 * np.abs(g["vm_out"]).max())
+    # FrankRadialFit.interpolate_brightness: the MAP when no profile is given
+    from frank_amd import FrankFitter
+    u, v, V, w = mock_disc_visibilities(20000, seed=21, noise_seed=22)
+    from frank_amd.mock import MOCK_GEOMETRY
+    FF = FrankFitter(2.0, 60, FixedGeometry(**MOCK_GEOMETRY), alpha=1.3, weights_smooth=1e-2, verbose=False)
+    sol = FF.fit(u, v, V, w)
+    Rp = np.array([0.0, 0.31, 0.77, 1.5])
+    a, b = sol.interpolate_brightness(Rp), sol.interpolate_brightness(Rp, sol.I)
+    assert np.array_equal(a, b) and a.shape == Rp.shape
+    # (AT a collocation point the reference's formula is 0 / 0; a hair beside it the series returns the point's value)
+    np.testing.assert_allclose(sol.interpolate_brightness(sol.r[5:8] * (1 + 1e-7)), sol.I[5:8], rtol=1e-4)

@@ -442,6 +442,101 @@ def test_two_processes_sharded_fit_on_this_box(tmp_path, case):
         assert rel_to_max(rk["mu"], mu) < 1e-9
 
 
+def _launch_two_ranks(tmp_path, case, timeout=1500):
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dist_worker.py"), case, str(tmp_path)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(2)]
+
+
+def test_two_processes_sharded_fit_against_the_reference(golden, tmp_path):
+    """BASELINE configs[3] against the REFERENCE's numbers, not against this library's unsharded fit: two real processes, each
+    binning 5e6 rows of the table of tests/golden/fit_N300_1e7.npz (the reference's own map_visibilities + fit of 1e7 mock
+    visibilities), the packed statistics reduced across the ranks (RCCL with two devices, HostComm over gloo on one), every
+    rank finalising and fitting: M, j within 5e-13 of the reference's, H0 to 1e-12, 667 iterations, the profile to 1e-6 --
+    the same bars the unsharded fit is held to (test_fit_N300_1e7_against_the_reference).
+    statistical_models.py:192-218, radial_fitters.py:737-832."""
+    g = golden("fit_N300_1e7.npz")
+    ranks = _launch_two_ranks(tmp_path, "ref_N300_1e7")
+    a, b = ranks
+    assert int(a["ranks"]) == 2 and int(a["rows"]) + int(b["rows"]) == 10 ** 7 and abs(int(a["rows"]) - int(b["rows"])) <= 1
+    assert np.array_equal(a["M"], b["M"]) and np.array_equal(a["j"], b["j"]) and np.array_equal(a["mu"], b["mu"])
+    for rk in ranks:
+        assert rel_to_max(rk["M"], g["M"]) < 5e-13 and rel_to_max(rk["j"], g["j"]) < 5e-13
+        assert abs(float(rk["H0"]) - float(g["H0"])) <= 1e-12 * abs(float(g["H0"]))
+        assert int(rk["niter"]) == int(g["niter"]) == 667
+        assert rel_to_max(rk["mu"], g["I"]) < 1e-6
+        np.testing.assert_allclose(rk["p"], g["p"], rtol=1e-4)
+
+
+def test_two_processes_at_the_per_gpu_share_of_1e8(tmp_path):
+    """... and at the PER-GPU SHARE of configs[3] (1e8 rows over eight GPUs = 1.25e7 rows per rank): two ranks of 1.25e7 rows
+    of one 2.5e7-row table.  No reference run of that size exists; the size-independent properties: both ranks hold the same
+    bits; the sums are those of the unsharded pass over the same table on one device (M, j to 1e-13: the order of the
+    partial sums differs); M symmetric; the quadratic form of M on a random vector is non-negative; the fit converges
+    in the number of passes of the unsharded fit."""
+    from frank_amd import FourierBesselFitter, _lib
+    ranks = _launch_two_ranks(tmp_path, "share_2x1p25e7", timeout=2400)
+    a, b = ranks
+    assert int(a["rows"]) == int(b["rows"]) == 12500000
+    assert np.array_equal(a["M"], b["M"]) and np.array_equal(a["j"], b["j"]) and float(a["H0"]) == float(b["H0"])
+    assert np.array_equal(a["mu"], b["mu"]) and int(a["niter"]) == int(b["niter"])
+    M = a["M"]
+    assert np.array_equal(M, M.T)
+    x = np.random.default_rng(5).normal(size=300)
+    assert x @ M @ x > 0
+    u, v, V, w = mock_disc_visibilities(25000000, seed=0, noise_seed=50)
+    FB = FourierBesselFitter(2.0, 300, geom(), verbose=False)
+    single = FB.preprocess_visibilities(u, v, V, w)
+    assert rel_to_max(M, single["M"]) < 1e-13 and rel_to_max(a["j"], single["j"]) < 1e-13
+    assert abs(float(a["H0"]) - single["null_likelihood"]) <= 1e-12 * abs(single["null_likelihood"])
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import dist_worker as dw
+    h = dw.HYPER
+    mu, p, nit = np.empty(300), np.empty(300), ctypes.c_int(0)
+    _lib.check(_lib.lib.fh_fit_normal(FB._DHT.context(), _lib.ptr(np.ascontiguousarray(single["M"])),
+                                      _lib.ptr(np.ascontiguousarray(single["j"])), h["alpha"], h["p0"], h["wsmooth"], h["tol"],
+                                      h["max_iter"], _lib.ptr(mu), _lib.ptr(p), ctypes.byref(nit), None, None))
+    assert int(a["niter"]) == nit.value and rel_to_max(a["mu"], mu) < 1e-9
+
+
+@pytest.mark.parametrize("N,cluster", [(700, "1"), (700, "3"), (1000, "1"), (1000, "4")])
+def test_xwide_fit_loop_against_oracle(monkeypatch, N, cluster):
+    """640 <= N <= 1023 (fit_loop_kernel<2, *>: one LDS panel, the vectors of the outer loop in global memory, the tile table
+    computed; hankel.py:70-78 has no size limit): the first 10 power-spectrum passes against the ORACLE
+    (radial_fitters.py:737-832), on one workgroup and on a cluster -- until now this instantiation had only been compared with
+    the library loop, i.e. with this library."""
+    from frank_amd import FrankFitter
+    from oracle import oracle as fo
+    it = 10
+    u, v, V, w = mock_disc_visibilities(40000, seed=24, noise_seed=25)
+    monkeypatch.setenv("FRANK_AMD_K2_CLUSTER", cluster)
+    FF = FrankFitter(2.0, N, geom(), alpha=1.3, weights_smooth=1e-2, verbose=False, max_iter=it, convergence_failure="ignore",
+                     store_iteration_diagnostics=True)
+    pre = FF.preprocess_visibilities(u, v, V, w)
+    sol = FF.fit_preprocessed(pre)
+    wg = ctypes.c_int(0)
+    from frank_amd import _lib
+    _lib.check(_lib.lib.fh_fit_cluster_info(FF._DHT.context(), ctypes.byref(wg), None))
+    assert wg.value == int(cluster)
+    ref = fo.frank_fit_normal(N, RMAX, pre["M"], pre["j"], alpha=1.3, wsmooth=1e-2, max_iter=it)
+    assert ref["rc"] == 0 and FF.iteration_diagnostics["num_iterations"] == ref["niter"] == it + 1
+    assert rel_to_max(sol.I, ref["mu"]) < 1e-6
+    np.testing.assert_allclose(sol.power_spectrum, ref["p"], rtol=1e-6)
+
+
 # ---- fp32 arithmetic (BASELINE configs[2], north_star "1e-3 fp32") ---------------------------------------------------
 @pytest.mark.parametrize("name,N", [("fit_N100_1e5.npz", 100), ("fit_N300_1e6.npz", 300)])
 def test_fp32_arithmetic_binning(golden, name, N):

@@ -1503,8 +1503,10 @@ def test_histograms_are_reused_only_for_the_same_rows(monkeypatch):
                                               ctypes.byref(b)))
         return sha(M, j, np.array([H0.value, a.value, b.value]))
     monkeypatch.setenv("FRANK_AMD_K1_NO_HIST_CACHE", "1")
+    _lib.check(_lib.lib.fh_ctx_reload_env(ctx))  # (the switches are read once per context)
     ref = {(t, k, n): stats(tabs[t], g, n) for t in (0, 1) for k, g in ((1, g1), (2, g2)) for n in (150000, 99999)}
     monkeypatch.delenv("FRANK_AMD_K1_NO_HIST_CACHE")
+    _lib.check(_lib.lib.fh_ctx_reload_env(ctx))
     order = [(0, 1, 150000), (0, 1, 150000), (0, 1, 150000), (1, 1, 150000), (0, 1, 150000), (0, 2, 150000), (0, 2, 150000),
              (0, 1, 99999), (0, 1, 99999), (0, 1, 150000), (1, 2, 99999), (1, 2, 99999)]
     for t, k, n in order:
