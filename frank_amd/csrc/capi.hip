@@ -59,6 +59,48 @@ struct SyncOnExit {
     ~SyncOnExit() { (void)hipStreamSynchronize(s); }
 };
 
+// ---- the allocation cache of the visibility tables' columns (see DevBuf::alloc_pooled) ----------------------------------------
+constexpr size_t kPoolBytes = (size_t)3 << 29;  // 1.5 GB held at most
+struct PoolEntry {
+    void *p;
+    size_t bytes;
+    int device;
+};
+static std::mutex g_pool_mutex;
+static std::vector<PoolEntry> g_pool;
+static size_t g_pool_held = 0;
+static void *pool_take(size_t bytes, int device) {
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    for (size_t i = 0; i < g_pool.size(); ++i)
+        if (g_pool[i].bytes == bytes && g_pool[i].device == device) {
+            void *p = g_pool[i].p;
+            g_pool_held -= bytes;
+            g_pool.erase(g_pool.begin() + (long)i);
+            return p;
+        }
+    return nullptr;
+}
+static void pool_put(void *p, size_t bytes, int device) {
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    if (bytes < ((size_t)1 << 20) || bytes > kPoolBytes / 2) {  // small ones are cheap to allocate; huge ones are not worth holding
+        (void)hipFree(p);
+        return;
+    }
+    while (!g_pool.empty() && g_pool_held + bytes > kPoolBytes) {  // oldest out
+        (void)hipFree(g_pool.front().p);
+        g_pool_held -= g_pool.front().bytes;
+        g_pool.erase(g_pool.begin());
+    }
+    g_pool.push_back({p, bytes, device});
+    g_pool_held += bytes;
+}
+static void pool_clear() {
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    for (const PoolEntry &e : g_pool) (void)hipFree(e.p);
+    g_pool.clear();
+    g_pool_held = 0;
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -82,9 +124,39 @@ struct DevBuf {
         owned = false;
     }
     void release() {
-        if (p && owned) (void)hipFree(p);
+        if (p && owned) {
+            if (pooled) pool_put(p, n * sizeof(T), pool_device);
+            else (void)hipFree(p);
+        }
         p = nullptr;
         n = 0;
+        pooled = false;
+    }
+    // The columns of a visibility table go through a small cache of freed allocations (per device, exact size, at most
+    // kPoolBytes held): VisibilityMapping.map_visibilities(u, v, V, w) uploads a table, bins it and frees it at every call, and
+    // six hipMalloc + six hipFree of 80-160 MB were ~10 ms of its 19 ms at 1e7 rows.  fh_cache_release() empties the cache.
+    bool pooled = false;
+    int pool_device = 0;
+    hipError_t alloc_pooled(size_t count, int device) {
+        release();
+        owned = true;
+        void *q = pool_take(count * sizeof(T), device);
+        if (!q) {
+            const hipError_t e = hipMalloc(&q, count * sizeof(T));
+            if (e != hipSuccess) {
+                pool_clear();  // (the cache may be what is in the way)
+                const hipError_t e2 = hipMalloc(&q, count * sizeof(T));
+                if (e2 != hipSuccess) {
+                    p = nullptr;
+                    return e2;
+                }
+            }
+        }
+        p = reinterpret_cast<T *>(q);
+        n = count;
+        pooled = true;
+        pool_device = device;
+        return hipSuccess;
     }
     ~DevBuf() { release(); }
 };
@@ -686,11 +758,11 @@ int fh_vis_upload(int device, const double *u, const double *v, const double *Vr
     t->w_scalar = (n_w == 1 && n != 1) ? 1 : 0;
     t->has_im = Vim ? 1 : 0;
     const size_t nn = (size_t)(n > 0 ? n : 1);
-    hipError_t e = t->u.alloc(nn);
-    if (e == hipSuccess) e = t->v.alloc(nn);
-    if (e == hipSuccess) e = t->Vre.alloc(nn);
-    if (e == hipSuccess && Vim) e = t->Vim.alloc(nn);
-    if (e == hipSuccess) e = t->w.alloc(t->w_scalar ? 1 : nn);
+    hipError_t e = t->u.alloc_pooled(nn, device);
+    if (e == hipSuccess) e = t->v.alloc_pooled(nn, device);
+    if (e == hipSuccess) e = t->Vre.alloc_pooled(nn, device);
+    if (e == hipSuccess && Vim) e = t->Vim.alloc_pooled(nn, device);
+    if (e == hipSuccess) e = t->w.alloc_pooled(t->w_scalar ? 1 : nn, device);
     if (e != hipSuccess) {
         delete t;
         return fail(FH_ERR_NOMEM, "fh_vis_upload: hipMalloc failed: %s", hipGetErrorString(e));
@@ -727,8 +799,9 @@ int fh_vis_upload_c128(int device, const double *u, const double *v, const doubl
     t->has_im = 1;
     const size_t nn = (size_t)(n > 0 ? n : 1);
     DevBuf<double> tmp;
-    if (t->u.alloc(nn) != hipSuccess || t->v.alloc(nn) != hipSuccess || t->Vre.alloc(nn) != hipSuccess || t->Vim.alloc(nn) != hipSuccess ||
-        t->w.alloc(t->w_scalar ? 1 : nn) != hipSuccess || tmp.alloc(2 * nn) != hipSuccess)
+    if (t->u.alloc_pooled(nn, device) != hipSuccess || t->v.alloc_pooled(nn, device) != hipSuccess ||
+        t->Vre.alloc_pooled(nn, device) != hipSuccess || t->Vim.alloc_pooled(nn, device) != hipSuccess ||
+        t->w.alloc_pooled(t->w_scalar ? 1 : nn, device) != hipSuccess || tmp.alloc_pooled(2 * nn, device) != hipSuccess)
         return fail(FH_ERR_NOMEM, "fh_vis_upload_c128: hipMalloc failed");
     if (n > 0) {
         const size_t b = sizeof(double) * (size_t)n;
@@ -782,9 +855,18 @@ int fh_vis_upload_f32(int device, const float *u, const float *v, const float *V
     *out = t;
     return FH_OK;
 }
+// empties the cache of freed table columns (DevBuf::alloc_pooled: at most 1.5 GB of device memory held between calls)
+int fh_cache_release(void) {
+    pool_clear();
+    return FH_OK;
+}
+
 void fh_vis_destroy(fh_vis *vis) {
     if (!vis) return;
     (void)hipSetDevice(vis->device);
+    // (hipFree waited for the device; the columns now go back to a cache and may be handed out again at once: kernels of any
+    //  stream that still read them must have ended)
+    (void)hipDeviceSynchronize();
     delete vis;
 }
 int64_t fh_vis_size(const fh_vis *vis) { return vis ? vis->n : 0; }
@@ -2413,9 +2495,12 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
         }
         c->n_launch_streams = fit_launch_streams();
         for (int i = 0; i < c->n_launch_streams; ++i) {
-            if (c->bin_cus > 0) {  // fh_ctx_set_cu_partition: the fit loops keep to the compute units the binning pass leaves alone
+            // FRANK_AMD_FIT_RESERVE_CUS = B (development): the fit loops keep off the first B compute units, the binning stream
+            // stays free to use every unit -- a floor under the binning pass of a deep pipeline instead of a partition
+            const int reserve = env_int("FRANK_AMD_FIT_RESERVE_CUS", 0);
+            if (c->bin_cus > 0 || (reserve >= 8 && reserve <= c->num_cu - 8)) {  // fh_ctx_set_cu_partition: the fit loops keep to the compute units the binning pass leaves alone
                 uint32_t mask[8];
-                cu_mask(c->bin_cus, c->num_cu, mask);
+                cu_mask(c->bin_cus > 0 ? c->bin_cus : reserve, c->num_cu, mask);
                 HIP_TRY(hipExtStreamCreateWithCUMask(&c->launch_streams[i], 8, mask));
             } else {
                 HIP_TRY(hipStreamCreateWithFlags(&c->launch_streams[i], hipStreamNonBlocking));

@@ -281,6 +281,11 @@ int fh_sweep_evidence(fh_ctx *ctx, const double *M, const double *j, double H0, 
  * context that did not assemble on one XCD within 3 ms and were repeated on one compute unit (either may be NULL).     */
 int fh_fit_cluster_info(fh_ctx *ctx, int *workgroups, int64_t *fallbacks);
 
+/* The columns of the visibility tables (fh_vis_upload, fh_vis_upload_c128; fh_map_visibilities underneath) come from a cache of
+ * freed allocations -- exact size, per device, at most 1.5 GB held -- so that a caller that maps one table after another
+ * (VisibilityMapping.map_visibilities, fit.py:455-471) does not pay six hipMalloc + six hipFree per call.  This empties it.   */
+int fh_cache_release(void);
+
 /* The development switches of the binning pass (FRANK_AMD_K1_*, FRANK_AMD_NO_RANGE_CACHE) are read from the environment ONCE,
  * when a context is created; this reads them again (tests that switch them inside one process).                          */
 int fh_ctx_reload_env(fh_ctx *ctx);
