@@ -2271,6 +2271,8 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
         const int g = fit_cluster_size(c);
         if (g > 1 && batch >= 64 && c->slots_busy == 0 && c->pending_batch < 0 && !getenv("FRANK_AMD_SWEEP_NO_CLUSTERS")) {
             K = batch / 8 < 16 ? batch / 8 : 16;
+            K = env_int("FRANK_AMD_SWEEP_CLUSTERS", K);  // (development: how many of the longest points go to clusters)
+            if (K > batch) K = batch;
             if (K * g > c->num_cu / 2) K = c->num_cu / 2 / g;
         }
     }
@@ -2326,6 +2328,7 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     P.batch_alpha = alb.p;
     P.batch_p0 = p0b.p;
     P.batch_counter = counter.p;
+    P.loaded = K * fit_cluster_size(c);  // (compute units the clusters hold beside this launch)
     {
         // (workgroups of the batched launch: one per fit, at most the compute units the clusters leave free)
         int free_cus = c->num_cu - K * fit_cluster_size(c);
