@@ -183,6 +183,7 @@ struct FitSlot {
     DevBuf<double> Aq, bq, Cq, Wq, WdT, cs, mu_out, p_out, band_lu;
     DevBuf<int> result;
     std::vector<double> lu_host;  // stays alive while the asynchronous copy of the band LU may still read it
+    std::vector<double> resume_host;  // the state of a paused fit on its way to the slot (behind the band LU), likewise
     double lu_key[3] = {0, 0, 0};  // (w_smooth, alpha, p0) of the factors the device copy holds
     bool lu_valid = false;
     bool busy = false;
@@ -215,6 +216,7 @@ struct FitBatch {
     double alpha = 0, p0 = 0, tol = 0;
     int max_iter = 0;
     int cluster = 1;  // workgroups per fit of this launch (fit_loop.hip, cluster mode)
+    int mode = FIT_MODE_FULL;  // FIT_MODE_RESUME: every fit of the launch continues from a paused state (the sweeps' second stage)
 };
 
 struct fh_ctx {
@@ -2225,6 +2227,149 @@ static std::vector<int> sweep_launch_order(const double *alpha, const double *ws
     return order;
 }
 
+// The STAGED schedule of a sweep (round 5).  A launch of a sweep ends with its slowest fit, and the fits of a grid differ ~20 x in
+// length (BASELINE configs[4]: 102 ... 2 003 passes, median 230; 15 of the 512 run to max_iter).  Which ones are long is only
+// known once they run -- so every fit first runs on ONE compute unit in one launch that fills the device (the form of the
+// kernel that suits a full device), but PAUSES after `cap` passes (fit_loop.hip: FIT_STATUS_PAUSED; the state of the iteration
+// is p and the p before it); then the few that are left -- the long ones, by construction -- continue where they stopped: as
+// many as the device holds on CLUSTERS of workgroups (a pass in half the time), the others on one compute unit each beside them.
+// Every form of the kernel makes the same bits and a paused fit continues exactly: the results are those of the single launch.
+// order[k] = the caller's index of the fit launched k-th.
+static int fit_submit_impl(fh_ctx *c, double alpha, double p0, double wsmooth, double tol, int max_iter, int *ticket, const double *resume);
+static int sweep_staged(fh_ctx *c, int batch, const std::vector<int> &order, const double *alpha, const double *p0, const double *wsmooth,
+                        double tol, int max_iter, int cap, double *mu, double *p, int *niter, int *status) {
+    const int N = c->N, NP = c->NP, g = fit_cluster_size(c);
+    const size_t PP = (size_t)NP * NP, B = (size_t)batch, RS = 2 * (size_t)N + 1;
+    const size_t G = (size_t)(batch < c->num_cu ? batch : c->num_cu);
+    DevBuf<double> Cb, Wb, WdTb, csb, mub, pb, lub, alb, p0b, rsb;
+    DevBuf<int> resb, counter;
+    if (counter.alloc(1) != hipSuccess || Cb.alloc(G * PP) != hipSuccess || Wb.alloc(G * PP) != hipSuccess ||
+        WdTb.alloc(G * NP * 16) != hipSuccess || csb.alloc(G * fh_k2_cs_doubles(NP)) != hipSuccess || mub.alloc(B * N) != hipSuccess ||
+        pb.alloc(B * N) != hipSuccess || lub.alloc(B * 5 * N) != hipSuccess || alb.alloc(B) != hipSuccess || p0b.alloc(B) != hipSuccess ||
+        resb.alloc(2 * B) != hipSuccess || rsb.alloc(B * RS) != hipSuccess)
+        return fail(FH_ERR_NOMEM, "fh_fit_normal_batched: device allocation for %d fits failed", batch);
+    std::vector<double> lu_all(B * 5 * N), lu, al_o(B), p0_o(B);
+    for (int k = 0; k < batch; ++k) {
+        smoothing_band_lu(*c->dht, wsmooth[order[k]], lu);
+        memcpy(lu_all.data() + (size_t)k * 5 * N, lu.data(), sizeof(double) * 5 * N);
+        al_o[k] = alpha[order[k]];
+        p0_o[k] = p0[order[k]];
+    }
+    std::vector<int> res(2 * B);
+    std::vector<double> mu_o(B * N), p_o(B * N);
+    // one batched launch over n fits whose per-fit inputs sit in the first n entries of the host arrays; results into res / mu_o / p_o
+    auto launch = [&](int n, int mode, int pass_cap, int grid, int loaded) -> int {
+        HIP_TRY(hipMemsetAsync(counter.p, 0, sizeof(int), c->stream));
+        HIP_TRY(hipMemcpyAsync(lub.p, lu_all.data(), sizeof(double) * (size_t)n * 5 * N, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(alb.p, al_o.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(p0b.p, p0_o.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        FitLoopParams P = make_loop_params(c, mode, 0.0, 0.0, tol, max_iter);
+        P.band_lu = lub.p;
+        P.C = Cb.p;
+        P.W = Wb.p;
+        P.WdT = WdTb.p;
+        P.cs = csb.p;
+        P.mu_out = mub.p;
+        P.p_out = pb.p;
+        P.result = resb.p;
+        P.batch = n;
+        P.batch_alpha = alb.p;
+        P.batch_p0 = p0b.p;
+        P.batch_counter = counter.p;
+        P.pass_cap = pass_cap;
+        P.resume = mode == FIT_MODE_RESUME ? rsb.p : nullptr;
+        P.loaded = loaded;
+        HIP_TRY(fh_k2_launch_loop_batched(P, grid, c->stream));
+        HIP_TRY(hipMemcpyAsync(res.data(), resb.p, sizeof(int) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(mu_o.data(), mub.p, sizeof(double) * (size_t)n * N, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(p_o.data(), pb.p, sizeof(double) * (size_t)n * N, hipMemcpyDeviceToHost, c->stream));
+        return FH_OK;
+    };
+    auto finish = [&](int k, int slot) {  // fit launched k-th, its results in entry `slot` of res / mu_o / p_o
+        const int b = order[k];
+        memcpy(mu + (size_t)b * N, mu_o.data() + (size_t)slot * N, sizeof(double) * N);
+        memcpy(p + (size_t)b * N, p_o.data() + (size_t)slot * N, sizeof(double) * N);
+        niter[b] = res[2 * slot];
+        if (status)
+            status[b] = res[2 * slot + 1] == FIT_STATUS_BAD_P ? FH_ERR_BAD_P : res[2 * slot + 1] == FIT_STATUS_NOT_SPD ? FH_ERR_NOT_SPD : FH_OK;
+    };
+    // ---- stage 1: every fit, at most `cap` passes ----
+    int rc = launch(batch, FIT_MODE_FULL, cap, (int)G, batch > (int)G ? c->num_cu : 0);  // (more fits than units: the device stays full)
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<int> paused;                 // launch-order indices of the fits that stopped at the cap
+    std::vector<double> state;               // their states, RS doubles each
+    for (int k = 0; k < batch; ++k) {
+        if (res[2 * k + 1] != FIT_STATUS_PAUSED) {
+            finish(k, k);
+            continue;
+        }
+        paused.push_back(k);
+        const size_t o = state.size();
+        state.resize(o + RS);
+        memcpy(&state[o], p_o.data() + (size_t)k * N, sizeof(double) * N);           // p
+        memcpy(&state[o + N], mu_o.data() + (size_t)k * N, sizeof(double) * N);      // p_old (in the place of mu)
+        state[o + 2 * N] = (double)res[2 * k];
+    }
+    const int np = (int)paused.size();
+    if (np == 0) return FH_OK;
+    // ---- stage 2: the first Kc of them (launch order: the longest first) on clusters, the others on one compute unit each ----
+    int Kc = np * g <= c->num_cu ? np : (c->num_cu - np) / (g - 1);
+    Kc = Kc < 0 ? 0 : (Kc > np ? np : Kc);
+    if (Kc > c->num_cu / g) Kc = c->num_cu / g;
+    Kc = env_int("FRANK_AMD_SWEEP_STAGE2_CLUSTERS", Kc) < np ? env_int("FRANK_AMD_SWEEP_STAGE2_CLUSTERS", Kc) : np;
+    std::vector<int> tickets(Kc, -1);
+    struct TicketGuard {
+        fh_ctx *c;
+        std::vector<int> &t;
+        ~TicketGuard() {
+            for (int &x : t)
+                if (x >= 0 && c->slots[x].busy) {
+                    (void)fh_fit_collect(c, x, nullptr, nullptr, nullptr);
+                    x = -1;
+                }
+        }
+    } ticket_guard{c, tickets};
+    if (Kc > 0) {
+        const bool had = c->have_device_Mj;
+        c->have_device_Mj = true;  // (M, j are on the device: uploaded by the caller of this function or by its caller's finalisation)
+        int rcs = FH_OK;
+        for (int i = 0; i < Kc && rcs == FH_OK; ++i) {
+            const int b = order[paused[i]];
+            rcs = fit_submit_impl(c, alpha[b], p0[b], wsmooth[b], tol, max_iter, &tickets[i], &state[(size_t)i * RS]);
+        }
+        c->force_cluster_launch = true;
+        if (rcs == FH_OK) rcs = fh_fit_flush(c);
+        c->force_cluster_launch = false;
+        c->have_device_Mj = had;
+        if (rcs != FH_OK) return rcs;
+    }
+    const int n2 = np - Kc;
+    if (n2 > 0) {  // the per-fit inputs of the others, compacted to the front of the host arrays
+        for (int i = 0; i < n2; ++i) {
+            const int k = paused[Kc + i];
+            memmove(lu_all.data() + (size_t)i * 5 * N, lu_all.data() + (size_t)k * 5 * N, sizeof(double) * 5 * N);  // (i <= k)
+            al_o[i] = al_o[k];
+            p0_o[i] = p0_o[k];
+        }
+        HIP_TRY(hipMemcpyAsync(rsb.p, &state[(size_t)Kc * RS], sizeof(double) * (size_t)n2 * RS, hipMemcpyHostToDevice, c->stream));
+        int free_cus = c->num_cu - Kc * g;
+        if (free_cus < 1) free_cus = 1;
+        rc = launch(n2, FIT_MODE_RESUME, 0, n2 < free_cus ? n2 : free_cus, 0);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < n2; ++i) finish(paused[Kc + i], i);
+    }
+    for (int i = 0; i < Kc; ++i) {
+        const int b = order[paused[i]];
+        const int rcc = fh_fit_collect(c, tickets[i], mu + (size_t)b * N, p + (size_t)b * N, &niter[b]);
+        tickets[i] = -1;
+        if (rcc != FH_OK && rcc != FH_ERR_BAD_P && rcc != FH_ERR_NOT_SPD) return rcc;
+        if (status) status[b] = rcc;
+    }
+    return FH_OK;
+}
+
 int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch, const double *alpha, const double *p0,
                           const double *wsmooth, double tol, int max_iter, double *mu, double *p, int *niter,
                           int *status) {
@@ -2263,6 +2408,14 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     // max_iter all have alpha = 1.01 -- in grid order the last of them started 100 ms into the launch.  order[k] = the caller's
     // index of the fit launched k-th; the outputs are put back in the caller's order.
     const std::vector<int> order = sweep_launch_order(alpha, wsmooth, batch);
+    // the staged schedule (sweep_staged above): sweeps of at least 64 points on an idle context, sizes the deferred kernel covers
+    {
+        const int gsz = fit_cluster_size(c);
+        const int cap = env_int("FRANK_AMD_SWEEP_CAP", 640);
+        if (cap > 0 && gsz > 1 && batch >= 64 && c->slots_busy == 0 && c->pending_batch < 0 && !getenv("FRANK_AMD_SWEEP_NO_CLUSTERS") &&
+            max_iter > cap)
+            return sweep_staged(c, batch, order, alpha, p0, wsmooth, tol, max_iter, cap, mu, p, niter, status);
+    }
     // ... and the first K of them -- the ones that will still be iterating when every other fit of the sweep has ended -- do not
     // join the batch at all: they are launched on CLUSTERS of workgroups (fit_loop.hip: 98 instead of 136 us per pass once the
     // device has emptied) through the fit slots, beside the batched launch of the rest on the compute units they leave free.
@@ -2423,7 +2576,7 @@ static int flush_pending_batch(fh_ctx *c) {
     }
     HIP_TRY(hipEventRecord(b.ready, c->stream));  // the operands of its fits were prepared on the context's stream
     HIP_TRY(hipStreamWaitEvent(b.stream, b.ready, 0));
-    FitLoopParams P = make_loop_params(c, FIT_MODE_FULL, b.alpha, b.p0, b.tol, b.max_iter);
+    FitLoopParams P = make_loop_params(c, b.mode, b.alpha, b.p0, b.tol, b.max_iter);
     const FitSlot &s0 = c->slots[0];
     P.A = s0.Aq.p;
     P.bq = s0.bq.p;
@@ -2458,7 +2611,12 @@ int fh_fit_flush(fh_ctx *c) {
     return flush_pending_batch(c);
 }
 
+static int fit_submit_impl(fh_ctx *c, double alpha, double p0, double wsmooth, double tol, int max_iter, int *ticket, const double *resume);
 int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol, int max_iter, int *ticket) {
+    return fit_submit_impl(c, alpha, p0, wsmooth, tol, max_iter, ticket, nullptr);
+}
+// resume != NULL: the fit continues from a paused state, [p (N), p_old (N), passes made] (kernels.h: FIT_MODE_RESUME)
+static int fit_submit_impl(fh_ctx *c, double alpha, double p0, double wsmooth, double tol, int max_iter, int *ticket, const double *resume) {
     if (!c || !ticket) return fail(FH_ERR_INVALID, "fh_fit_submit: NULL argument");
     if (!c->have_device_Mj) return fail(FH_ERR_INVALID, "fh_fit_submit: no device-resident M, j (run fh_stats_finalize)");
     if (c->NP > fh_k2_loop_max_np()) return fail(FH_ERR_UNSUPPORTED, "N = %d: the fit_loop kernel covers N <= 1023", c->N);
@@ -2477,7 +2635,7 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
     if (!c->slot_pool.p) {
         // all slots at once, carved from ONE allocation: a hipMalloc per buffer costs ~0.7 ms of host time, and paying
         // 11 of them whenever a fresh slot is first used put an 8 ms hole after every binning pass of a pipeline
-        const size_t per_slot = 3 * PP + (size_t)c->NP * 16 + fh_k2_cs_doubles(c->NP) + 3 * (size_t)N + 5 * (size_t)N + 2;
+        const size_t per_slot = 3 * PP + (size_t)c->NP * 16 + fh_k2_cs_doubles(c->NP) + 3 * (size_t)N + 7 * (size_t)N + 4;
         HIP_TRY(c->slot_pool.alloc(per_slot * (size_t)c->n_slots));
         HIP_TRY(c->slot_results.alloc(2 * (size_t)c->n_slots));
         HIP_TRY(hipMemsetAsync(c->slot_pool.p, 0, sizeof(double) * per_slot * (size_t)c->n_slots, c->stream));
@@ -2493,7 +2651,7 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
             t.bq.adopt(b, N); b += N;
             t.mu_out.adopt(b, N); b += N;
             t.p_out.adopt(b, N); b += N;
-            t.band_lu.adopt(b, 5 * (size_t)N + 2);  // + alpha, p0 of the fit (read by the slot launch)
+            t.band_lu.adopt(b, 7 * (size_t)N + 4);  // + alpha, p0 of the fit (read by the slot launch) + the state of a paused fit
             t.result.adopt(c->slot_results.p + 2 * i, 2);
         }
         c->n_launch_streams = fit_launch_streams();
@@ -2521,7 +2679,8 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
     if (c->slots_busy == 0) c->burst_next = 1;  // an empty pipeline: the first launches are small (1, 2, 4, .. fits)
     if (c->pending_batch >= 0) {
         const FitBatch &pb = c->batches[c->pending_batch];
-        if (pb.tol != tol || pb.max_iter != max_iter) {
+        const int mode = resume ? FIT_MODE_RESUME : FIT_MODE_FULL;
+        if (pb.tol != tol || pb.max_iter != max_iter || pb.mode != mode) {
             int rc = flush_pending_batch(c);
             if (rc) return rc;
         }
@@ -2542,6 +2701,7 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
         nb.p0 = p0;
         nb.tol = tol;
         nb.max_iter = max_iter;
+        nb.mode = resume ? FIT_MODE_RESUME : FIT_MODE_FULL;
         c->pending_batch = bi;
     }
     FitSlot &s = c->slots[si];
@@ -2558,6 +2718,11 @@ int fh_fit_submit(fh_ctx *c, double alpha, double p0, double wsmooth, double tol
         s.lu_key[1] = alpha;
         s.lu_key[2] = p0;
         s.lu_valid = true;
+    }
+    if (resume) {
+        s.resume_host.assign(resume, resume + 2 * (size_t)N + 1);
+        HIP_TRY(hipMemcpyAsync(s.band_lu.p + 5 * (size_t)N + 2, s.resume_host.data(), sizeof(double) * s.resume_host.size(),
+                               hipMemcpyHostToDevice, c->stream));
     }
     int rc = prepare_qspace(c, s.Aq.p, s.bq.p);  // on the context's stream, after the finalize that produced M, j
     if (rc) return rc;
@@ -2605,7 +2770,7 @@ int fh_fit_collect(fh_ctx *c, int ticket, double *mu, double *p, int *niter) {
         // its cluster did not assemble (or broke): the same fit on one CU, now; the control words of the slot back to zero
         ++c->cluster_fallbacks;
         HIP_TRY(hipMemsetAsync(s.WdT.p, 0, sizeof(double) * fh_k2_exchange_doubles(c->NP), b.stream));
-        FitLoopParams P = make_loop_params(c, FIT_MODE_FULL, b.alpha, b.p0, b.tol, b.max_iter);
+        FitLoopParams P = make_loop_params(c, b.mode, b.alpha, b.p0, b.tol, b.max_iter);
         const FitSlot &s0 = c->slots[0];
         P.A = s0.Aq.p;
         P.bq = s0.bq.p;

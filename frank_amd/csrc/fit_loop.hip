@@ -2148,6 +2148,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         P.mu_out += (size_t)f * P.N;
         P.p_out += (size_t)f * P.N;
         P.result += 2 * f;
+        if (P.resume) P.resume += (size_t)f * (2 * P.N + 1);
     }
     if (P.slot_stride) {
         // (constant indices only: a dynamic index into the by-value parameter struct forces the WHOLE struct into scratch
@@ -2179,6 +2180,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         }
         P.alpha = P.band_lu[5 * P.N];  // per-fit hyper-parameters travel behind the slot's band LU
         P.p0 = P.band_lu[5 * P.N + 1];
+        P.resume = P.mode == FIT_MODE_RESUME ? P.band_lu + 5 * P.N + 2 : nullptr;  // (... and the state of a paused fit behind them)
     }
     const int N = P.N, NP = P.NP;
     const int tid = threadIdx.x;
@@ -2330,17 +2332,21 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         S.b[i] = i < N ? P.bq[i] : 0.0;
         S.p[i] = i < N ? (P.p_init ? P.p_init[i] : 1.0) : 1.0;  // radial_fitters.py:744 (p = 1)
         S.pold[i] = 0.0;                                        // radial_fitters.py:768 (pi_old = 0)
+        if (P.mode == FIT_MODE_RESUME && i < N) {               // a paused fit: its power spectrum and the one before
+            S.p[i] = P.resume[i];
+            S.pold[i] = P.resume[N + i];
+        }
     }
     if (tid == 0) {
         s_ctl[0] = 0;
         s_ctl[1] = 0;
     }
     __syncthreads();
-    int status = 0, count = 0, nsolve = 0;
+    int status = 0, count = P.mode == FIT_MODE_RESUME ? (int)P.resume[2 * N] : 0, nsolve = 0;
     // One call site for the posterior solve.  phase 0: p = 1 (radial_fitters.py:744-747); phase 1: power-law
     // guess (:749-752); phase 2: the loop of :769-785 (FIT_MODE_STEP: exactly one pass, FIT_MODE_SOLVE: none).
     int phase = (P.mode == FIT_MODE_FULL) ? 0 : 2;
-    bool in_pass = false;
+    bool in_pass = P.mode == FIT_MODE_RESUME;  // (a paused fit stopped behind an update of p: its next solve ends a pass)
 #ifdef FIT_LOOP_TIMING
     long long o_last = clock64();
 #endif
@@ -2518,9 +2524,19 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
             break;
         }
         in_pass = true;
+        if (P.pass_cap > 0 && count >= P.pass_cap) {  // pause here: (p, p_old, count) is the whole state of the iteration
+            status = FIT_STATUS_PAUSED;
+            break;
+        }
     }
 
-    // outputs: mu = Y^-1 m, p, count, status
+    // outputs: mu = Y^-1 m, p, count, status (a paused fit: p_old in the place of mu)
+    if (status == FIT_STATUS_PAUSED) {
+        for (int i = tid; i < N; i += KT) {
+            P.mu_out[i] = S.pold[i];
+            if (P.out_host) P.out_host[i] = S.pold[i];
+        }
+    } else
     for (int r = __builtin_amdgcn_readfirstlane(tid >> 6); r < N; r += NW) {
         const double *yr = P.Yinv + (size_t)r * N;
         double a = 0.0;

@@ -213,8 +213,8 @@ hipError_t fh_lnw_launch_matvec(int N, const double *A, const double *x, double 
 hipError_t fh_lnw_launch_identity(double *A, int N, hipStream_t s);
 
 // ---- K2 v2: single persistent kernel (fit_loop.hip) ---------------------------------------------------------
-enum { FIT_MODE_FULL = 0, FIT_MODE_STEP = 1, FIT_MODE_SOLVE = 2 };
-enum { FIT_STATUS_OK = 0, FIT_STATUS_BAD_P = 1, FIT_STATUS_NOT_SPD = 2, FIT_STATUS_CLUSTER = 3 };
+enum { FIT_MODE_FULL = 0, FIT_MODE_STEP = 1, FIT_MODE_SOLVE = 2, FIT_MODE_RESUME = 3 };
+enum { FIT_STATUS_OK = 0, FIT_STATUS_BAD_P = 1, FIT_STATUS_NOT_SPD = 2, FIT_STATUS_CLUSTER = 3, FIT_STATUS_PAUSED = 4 };
 
 struct FitLoopParams {
     int N, NP, max_iter, mode;
@@ -260,6 +260,13 @@ struct FitLoopParams {
     int cluster_xcd0;       // the XCD the first fit of the launch goes to (fit f sits on XCD (cluster_xcd0 + f) & 7): the host
                             // deals the small launches of a filling pipeline round the XCDs (a cluster wants an L2 to itself)
     int nfits;              // fits of a cluster launch (slot launch: entries of slot_words; single fit: 1)
+    // Pause / resume (the sweeps' two-stage schedule, capi.hip: fh_fit_normal_batched).  pass_cap > 0: a fit that has made
+    // pass_cap passes without converging stops with FIT_STATUS_PAUSED, its power spectrum in p_out and the one before in mu_out
+    // -- the whole state of the iteration (radial_fitters.py:769-785 carries nothing else from pass to pass).
+    // mode FIT_MODE_RESUME continues from such a state: `resume` = [p (N), p_old (N), passes made] per fit (batched launch:
+    // 2 N + 1 doubles per fit; slot launch: behind the slot's band LU and hyper-parameters, the pointer is set by the kernel).
+    int pass_cap;
+    const double *resume;
     int loaded;             // host hint: fit loops already resident on the device when this launch starts (launch_loop picks the
                             // form of the one-workgroup kernel that suits a full device: the rows of the inverse in pairs)
 };

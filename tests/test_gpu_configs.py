@@ -293,6 +293,47 @@ def test_sweep_512_points_work_queue():
         assert np.array_equal(s1.power_spectrum, sols[b].power_spectrum)
 
 
+@pytest.mark.parametrize("N,cap,stage2", [(130, "25", None), (130, "25", "0"), (300, "60", "3"), (319, "40", None), (335, "40", None), (400, "30", None)])
+def test_staged_sweep_equals_the_single_launch(monkeypatch, N, cap, stage2):
+    """The staged schedule of a sweep (capi.hip: sweep_staged): every fit runs at most `cap` passes in a first launch and
+    PAUSES (fit_loop.hip: the state of the iteration radial_fitters.py:769-785 is p and the p before it), the ones that are
+    left continue where they stopped -- on clusters of workgroups and on one compute unit each.  Against the single launch
+    (FRANK_AMD_SWEEP_CAP=0): the same bits and the same iteration counts for all 96 points, whatever the cap and the split of
+    the second stage, on the deferred kernel (N <= 319), the one of rounds 2-4 (335) and the wide instantiation (400)."""
+    import ctypes
+    from frank_amd import _lib
+    FF, M, j = _problem_for_sweeps(N)
+    ctx = FF._DHT.context()
+    B = 96
+    al = np.linspace(1.02, 1.4, B)[np.random.default_rng(3).permutation(B)]
+    ws = np.logspace(-4, -1, B)
+    p0 = np.full(B, 1e-15)
+
+    def run():
+        mu, pp = np.empty((B, N)), np.empty((B, N))
+        nit, st = (ctypes.c_int * B)(), (ctypes.c_int * B)()
+        _lib.check(_lib.lib.fh_fit_normal_batched(ctx, _lib.ptr(M), _lib.ptr(j), B, _lib.ptr(al), _lib.ptr(p0), _lib.ptr(ws), 1e-3, 400,
+                                                  _lib.ptr(mu), _lib.ptr(pp), nit, st))
+        return mu, pp, np.array(list(nit)), np.array(list(st))
+    monkeypatch.setenv("FRANK_AMD_SWEEP_CAP", "0")
+    mu0, p0_, n0, s0 = run()
+    assert n0.max() > 3 * int(cap) and (n0 < int(cap)).sum() > 5   # (some fits end inside the cap, some far beyond it)
+    monkeypatch.setenv("FRANK_AMD_SWEEP_CAP", cap)
+    if stage2 is not None:
+        monkeypatch.setenv("FRANK_AMD_SWEEP_STAGE2_CLUSTERS", stage2)
+    mu1, p1, n1, s1 = run()
+    assert np.array_equal(n0, n1) and np.array_equal(s0, s1)
+    assert np.array_equal(mu0, mu1) and np.array_equal(p0_, p1)
+
+
+def _problem_for_sweeps(N):
+    from frank_amd import FrankFitter
+    u, v, V, w = mock_disc_visibilities(100000, seed=31, noise_seed=32)
+    FF = FrankFitter(2.0, N, geom(), verbose=False)
+    m = FF.preprocess_visibilities(u, v, V, w)
+    return FF, np.ascontiguousarray(m["M"]), np.ascontiguousarray(m["j"])
+
+
 def test_sweep_split_over_devices_is_placement_independent(golden):
     """sweep_fits(devices=[...]): the grid split over devices (broadcast (M, j), split the fits, no
     further communication) gives the same bits as one device.  With one visible GPU the same device is listed twice:

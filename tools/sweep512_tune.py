@@ -41,3 +41,5 @@ print("%s: %.0f fits/s (best of 3: %.3f s); passes: total %d, max %d, %d at max_
     " ".join("%s=%s" % (k[10:], v) for k, v in sorted(os.environ.items()) if k.startswith("FRANK_AMD_")) or "defaults",
     B / best, best, int(its.sum()) + 2 * B, int(its.max()), int((its >= h["max_iter"]).sum()),
     __import__("hashlib").sha256(mu.tobytes() + pp.tobytes()).hexdigest()[:12]), flush=True)
+if os.environ.get("PRINT_ITS"):
+    print("passes per fit, descending:", " ".join(str(int(x) + 2) for x in np.sort(its)[::-1]))
