@@ -5,6 +5,7 @@
 #include <rocsolver/rocsolver.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -2293,6 +2294,9 @@ static int sweep_staged(fh_ctx *c, int batch, const std::vector<int> &order, con
         if (status)
             status[b] = res[2 * slot + 1] == FIT_STATUS_BAD_P ? FH_ERR_BAD_P : res[2 * slot + 1] == FIT_STATUS_NOT_SPD ? FH_ERR_NOT_SPD : FH_OK;
     };
+    const bool trace = getenv("FRANK_AMD_SWEEP_TRACE") != nullptr;  // development: stage times on stderr
+    const auto t_start = std::chrono::steady_clock::now();
+    auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     // ---- stage 1: every fit, at most `cap` passes ----
     int rc = launch(batch, FIT_MODE_FULL, cap, (int)G, batch > (int)G ? c->num_cu : 0);  // (more fits than units: the device stays full)
     if (rc) return rc;
@@ -2312,11 +2316,21 @@ static int sweep_staged(fh_ctx *c, int batch, const std::vector<int> &order, con
         state[o + 2 * N] = (double)res[2 * k];
     }
     const int np = (int)paused.size();
+    const double t_stage1 = ms_since();
     if (np == 0) return FH_OK;
     // ---- stage 2: the first Kc of them (launch order: the longest first) on clusters, the others on one compute unit each ----
-    int Kc = np * g <= c->num_cu ? np : (c->num_cu - np) / (g - 1);
-    Kc = Kc < 0 ? 0 : (Kc > np ? np : Kc);
-    if (Kc > c->num_cu / g) Kc = c->num_cu / g;
+    // (workgroup ids go round the eight XCDs and the members of a cluster share one: the clusters come in eights, and an XCD's
+    //  32 units must hold its clusters AND its share of the one-unit loops -- an XCD asked for more makes clusters wait for units
+    //  beyond the 3 ms they are given to assemble, and a cluster that does not assemble is rerun on one unit at collection)
+    int Kc = 0;
+    for (int k8 = 8 * ((np + 7) / 8); k8 >= 0; k8 -= 8) {
+        const int kc = k8 < np ? k8 : np, rest = np - kc;
+        const int per_xcd = ((kc + 7) / 8) * g + (rest + 7) / 8;
+        if (per_xcd <= c->num_cu / 8) {
+            Kc = kc;
+            break;
+        }
+    }
     Kc = env_int("FRANK_AMD_SWEEP_STAGE2_CLUSTERS", Kc) < np ? env_int("FRANK_AMD_SWEEP_STAGE2_CLUSTERS", Kc) : np;
     std::vector<int> tickets(Kc, -1);
     struct TicketGuard {
@@ -2360,6 +2374,8 @@ static int sweep_staged(fh_ctx *c, int batch, const std::vector<int> &order, con
         HIP_TRY(hipStreamSynchronize(c->stream));
         for (int i = 0; i < n2; ++i) finish(paused[Kc + i], i);
     }
+    const double t_batched2 = ms_since();
+    const unsigned long long fb0 = c->cluster_fallbacks;
     for (int i = 0; i < Kc; ++i) {
         const int b = order[paused[i]];
         const int rcc = fh_fit_collect(c, tickets[i], mu + (size_t)b * N, p + (size_t)b * N, &niter[b]);
@@ -2367,6 +2383,10 @@ static int sweep_staged(fh_ctx *c, int batch, const std::vector<int> &order, con
         if (rcc != FH_OK && rcc != FH_ERR_BAD_P && rcc != FH_ERR_NOT_SPD) return rcc;
         if (status) status[b] = rcc;
     }
+    if (trace)
+        fprintf(stderr, "[sweep_staged] %d fits, cap %d: stage 1 %.1f ms, %d paused -> %d on clusters of %d + %d on one unit; one-unit part done at "
+                "%.1f ms, clusters at %.1f ms (%llu fall-backs)\n", batch, cap, t_stage1, np, Kc, g, n2, t_batched2, ms_since(),
+                (unsigned long long)(c->cluster_fallbacks - fb0));
     return FH_OK;
 }
 

@@ -1628,10 +1628,15 @@ __device__ __forceinline__ bool solve_posterior_cluster(const FitLoopParams &P, 
                 for (int q = 0; q < 4; ++q) ft.v[q] = t[q];
                 const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
                 const v4f64 d = mfma4(fx, ft, z4, false);
-                st_pk(C_u, base_pk + (unsigned)(i * 2048), lane, d);
-                double *pr = pan_nxt + (size_t)((i - 1) * 16 + cl) * PS + rg;
+                // (the panel first, and its address formed HERE from the lane index: hoisted out of the step loop, cl and rg were
+                //  spilled -- five scratch reloads per step in the workers' loop -- and the reload behind the tile's global stores
+                //  made the wave wait for their acknowledgement, s_waitcnt vmcnt(0), before it could write the panel)
+                int l2 = lane;
+                asm volatile("" : "+v"(l2));
+                double *pr = pan_nxt + (size_t)((i - 1) * 16 + (l2 & 15)) * PS + (l2 >> 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
+                st_pk(C_u, base_pk + (unsigned)(i * 2048), l2, d);
             };
             if (band == 2 && band < nb) {
                 // ROWS IN REGISTERS.  A tile of the band lives three steps in the first workgroup: it enters from the helpers

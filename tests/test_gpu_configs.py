@@ -293,7 +293,7 @@ def test_sweep_512_points_work_queue():
         assert np.array_equal(s1.power_spectrum, sols[b].power_spectrum)
 
 
-@pytest.mark.parametrize("N,cap,stage2", [(130, "25", None), (130, "25", "0"), (300, "60", "3"), (319, "40", None), (335, "40", None), (400, "30", None)])
+@pytest.mark.parametrize("N,cap,stage2", [(130, "200", None), (130, "180", "0"), (300, "220", "3"), (319, "250", None), (335, "200", None), (400, "200", None)])
 def test_staged_sweep_equals_the_single_launch(monkeypatch, N, cap, stage2):
     """The staged schedule of a sweep (capi.hip: sweep_staged): every fit runs at most `cap` passes in a first launch and
     PAUSES (fit_loop.hip: the state of the iteration radial_fitters.py:769-785 is p and the p before it), the ones that are
@@ -317,7 +317,7 @@ def test_staged_sweep_equals_the_single_launch(monkeypatch, N, cap, stage2):
         return mu, pp, np.array(list(nit)), np.array(list(st))
     monkeypatch.setenv("FRANK_AMD_SWEEP_CAP", "0")
     mu0, p0_, n0, s0 = run()
-    assert n0.max() > 3 * int(cap) and (n0 < int(cap)).sum() > 5   # (some fits end inside the cap, some far beyond it)
+    assert (n0 > int(cap) + 20).sum() > 5 and (n0 < int(cap)).sum() > 5   # (some fits end inside the cap, some well beyond it)
     monkeypatch.setenv("FRANK_AMD_SWEEP_CAP", cap)
     if stage2 is not None:
         monkeypatch.setenv("FRANK_AMD_SWEEP_STAGE2_CLUSTERS", stage2)
