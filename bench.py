@@ -330,6 +330,46 @@ def extras(f, L, a):
         del f.tables[1:]
     except Exception as e:
         ex.setdefault("steady_state", {})["error"] = repr(e)
+    # -- the fit loop with the DEVICE FULL: 256 identical fits of the headline mapping resident in one launch, one compute unit
+    #    each (fh_fit_normal_batched), with the clock probe on -- the form a deep sweep runs, and the roofline of the loaded kernel
+    #    (a loaded pass is bound by the bytes it moves beyond the L2: profiles/r05_pmc_fit_loop_loaded.json)
+    try:
+        prev = os.environ.get("FRANK_AMD_SWEEP_NO_CLUSTERS")
+        os.environ["FRANK_AMD_SWEEP_NO_CLUSTERS"] = "1"
+        Bf = 256
+        o3 = (ctypes.c_int64 * 3)()
+        f.bin()
+        L.check(L.lib.fh_stats_finalize(f.ctx, ctypes.byref(f.geom), 0, 0, None, None, None, None, None))
+        al, p0v, wsv = np.full(Bf, h["alpha"]), np.full(Bf, h["p0"]), np.full(Bf, h["wsmooth"])
+        mu_b, p_b = np.empty((Bf, N)), np.empty((Bf, N))
+        nit_b, st_b = (ctypes.c_int * Bf)(), (ctypes.c_int * Bf)()
+        best = None
+        for _ in range(2):
+            L.check(L.lib.fh_ctx_loop_clocks(f.ctx, 1, o3))
+            f.sync()
+            t0 = time.perf_counter()
+            L.check(L.lib.fh_fit_normal_batched(f.ctx, None, None, Bf, L.ptr(al), L.ptr(p0v), L.ptr(wsv), h["tol"], h["max_iter"],
+                                                L.ptr(mu_b), L.ptr(p_b), nit_b, st_b))
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        L.check(L.lib.fh_ctx_loop_clocks(f.ctx, 0, o3))
+        passes = nit_b[0] + 2
+        tf = Bf / best * passes * (2.0 * (N + 1) ** 3 / 3.0) / 1e12
+        ex["device_full"] = {"workload": "%d identical N=%d fits resident in ONE launch, one compute unit each (the batched form of "
+                                         "the sweeps; deferred trailing update + paired rows of the inverse)" % (Bf, N),
+                             "fits_per_s": Bf / best, "s_total": best, "passes_per_fit": passes,
+                             "us_per_pass_on_the_device": o3[1] / 100.0 / max(o3[2], 1), "clock_MHz": 100.0 * o3[0] / max(o3[1], 1),
+                             "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": tf / FP64_MFMA_PEAK_TFLOPS,
+                                          "note": "algorithmic flops (2 n^3 / 3 per pass) of all fits over the wall time of the launch, "
+                                                  "against the whole chip's fp64 matrix peak; what holds it there is memory traffic "
+                                                  "beyond the L2, 3.5 MB per pass (profiles/r05_pmc_fit_loop_256_resident.json)"}}
+        if prev is None:
+            del os.environ["FRANK_AMD_SWEEP_NO_CLUSTERS"]
+        else:
+            os.environ["FRANK_AMD_SWEEP_NO_CLUSTERS"] = prev
+    except Exception as e:
+        ex["device_full"] = {"error": repr(e)}
 
     def finalize():
         L.check(L.lib.fh_stats_finalize(f.ctx, ctypes.byref(f.geom), 0, 1, None, None, ctypes.byref(H0),
@@ -916,9 +956,16 @@ def main():
         # bench.py); they describe the build the profile was taken from, named in the *_source fields
         traffic, traffic_one, traffic_src, bin_traffic, bin_traffic_src, profile_lib = None, None, None, None, None, None
 
-        def pmc(name):
-            with open(os.path.join(ROOT, "profiles", name)) as fh:
-                return json.load(fh)
+        def pmc(name):  # (the round-5 profile if it has been taken, else round 4's)
+            for nm in (name.replace("r04_", "r05_"), name):
+                try:
+                    with open(os.path.join(ROOT, "profiles", nm)) as fh:
+                        d = json.load(fh)
+                    d["_file"] = nm
+                    return d
+                except OSError:
+                    continue
+            raise OSError(name)
         try:
             pm2, pm1 = pmc("r04_pmc_fit_loop_cluster.json"), pmc("r04_pmc_fit_loop.json")
             profile_lib = pm2.get("_library")
@@ -926,9 +973,9 @@ def main():
                 # (the profiled fit is the 1e6-visibility fixture: 825 passes; scaled to the passes of this fit)
                 traffic = int([e for k, e in pm2.items() if k.startswith("fit_loop_kernel")][0]["hbm_bytes_per_launch"] * (nit + 2) / 825.0)
                 traffic_one = int([e for k, e in pm1.items() if k.startswith("fit_loop_kernel")][0]["hbm_bytes_per_launch"] * (nit + 2) / 825.0)
-            traffic_src = ("static: profiles/r04_pmc_fit_loop_cluster.json / r04_pmc_fit_loop.json (rocprofv3 --pmc FETCH_SIZE / "
+            traffic_src = ("static: profiles/%s / %s (rocprofv3 --pmc FETCH_SIZE / "
                            "WRITE_SIZE on one fit of 825 passes, scaled to this fit's passes; FETCH doubled per the gfx950 note), "
-                           "taken from the library build '%s'; not measured in this run" % profile_lib)
+                           "taken from the library build '%s'; not measured in this run" % (pm2.get("_file"), pm1.get("_file"), profile_lib))
         except Exception:
             traffic = None
         try:
@@ -940,9 +987,9 @@ def main():
                                if isinstance(e, dict) and "hbm_bytes_per_launch" in e and not k.startswith(("uv_hist", "bucket_scan"))}
                 bin_traffic["total"] = int(sum(bin_traffic.values()))
                 bin_traffic["total_at_first_sight_of_a_table"] = int(sum(first.values()))
-            bin_traffic_src = ("static: profiles/r04_pmc_binning.json, r04_pmc_binning_first_sight.json (one pass of 1e7 visibilities "
+            bin_traffic_src = ("static: profiles/%s, %s (one pass of 1e7 visibilities "
                                "at N = 300, per kernel; 2 x FETCH_SIZE + WRITE_SIZE), library build '%s'; not measured in this run"
-                               % pm.get("_library"))
+                               % (pm.get("_file"), pmf.get("_file"), pm.get("_library")))
         except Exception:
             bin_traffic = None
         # the reference's own run of this very input (tests/golden/fit_N300_1e7.npz: 667 iterations) -- rank 0, default sizes
@@ -987,7 +1034,7 @@ def main():
                                       "in cluster mode (%d/256); the mode buys latency (a pass is a chain of 19 dependent tile "
                                       "factorisations) with compute units that mostly wait -- the fraction per CU is lower "
                                       "than on one CU by design" % (loop_wgs, loop_wgs),
-                         "why_this_kernel": "most of the GPU time of the timed region (profiles/r04_kernel_stats.csv)",
+                         "why_this_kernel": "most of the GPU time of the timed region (profiles/r05_kernel_stats.csv)",
                          "traffic_one_cu": traffic_one, "profile_library": profile_lib,
                          "one_cu": {"kernel": K2_KERNEL_NAME + " on one compute unit (FRANK_AMD_K2_CLUSTER=1: the form of the steady "
                                               "state and of the batched sweeps)", "achieved": achieved_one, "peak": peak_cu,

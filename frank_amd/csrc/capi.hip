@@ -2326,7 +2326,9 @@ static int sweep_staged(fh_ctx *c, int batch, const std::vector<int> &order, con
     for (int k8 = 8 * ((np + 7) / 8); k8 >= 0; k8 -= 8) {
         const int kc = k8 < np ? k8 : np, rest = np - kc;
         const int per_xcd = ((kc + 7) / 8) * g + (rest + 7) / 8;
-        if (per_xcd <= c->num_cu / 8) {
+        if (per_xcd <= c->num_cu / 8 - 4) {  // (four units of an XCD left free: the small kernels of the stage -- the q-space
+                                             //  operands of every submission -- need somewhere to run; with 31 of 32 units
+                                             //  spoken for, 4-6 of 40 clusters missed their 3 ms in one run of three)
             Kc = kc;
             break;
         }
@@ -2431,7 +2433,9 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     // the staged schedule (sweep_staged above): sweeps of at least 64 points on an idle context, sizes the deferred kernel covers
     {
         const int gsz = fit_cluster_size(c);
-        const int cap = env_int("FRANK_AMD_SWEEP_CAP", 640);
+        // (the cap: BASELINE configs[4], 512 fits: 640 / 800 / 900 / 1 000 / 1 200 passes -> 1 508 / 2 047 / 2 014 / 1 914 / 1 826 fits/s,
+        //  the single launch with its sixteen longest on clusters 1 515-1 650; 0 turns the schedule off)
+        const int cap = env_int("FRANK_AMD_SWEEP_CAP", 800);
         if (cap > 0 && gsz > 1 && batch >= 64 && c->slots_busy == 0 && c->pending_batch < 0 && !getenv("FRANK_AMD_SWEEP_NO_CLUSTERS") &&
             max_iter > cap)
             return sweep_staged(c, batch, order, alpha, p0, wsmooth, tol, max_iter, cap, mu, p, niter, status);
