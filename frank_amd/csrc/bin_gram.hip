@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void deproject_kernel(BinParams p) {
         ps[0] = s;
         ps[1] = mn;
         ps[2] = mx;
-        ps[3] = ma;  // every row whatever its multiplicity: sizes the bucket sort (capi.hip)
+        ps[3] = ma;  // every row whatever its multiplicity: sizes the bucket sort (capi_map.hip)
     }
 }
 

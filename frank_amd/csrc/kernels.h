@@ -1,4 +1,4 @@
-// Internal launch interface between the C-ABI glue (capi.hip) and the kernels.
+// Internal launch interface between the C-ABI glue (capi_*.hip, capi_internal.h) and the kernels.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -190,7 +190,7 @@ hipError_t fh_k2_launch_update(const FitState &st, hipStream_t s);
 hipError_t fh_k2_launch_record(const FitState &st, hipStream_t s);
 hipError_t fh_k2_launch_pinv_scale(const double *s, int n, double *s1, hipStream_t st);
 
-// ---- method='LogNormal' for 320 < N <= 1023 (lognormal_wide.hip; the host drives MinimizeNewton, capi.hip) ----------------
+// ---- method='LogNormal' for 320 < N <= 1023 (lognormal_wide.hip; the host drives MinimizeNewton, capi_lognormal.hip) ----------------
 struct LnWideParams {
     int N;
     double s0, transform_norm;
@@ -260,7 +260,7 @@ struct FitLoopParams {
     int cluster_xcd0;       // the XCD the first fit of the launch goes to (fit f sits on XCD (cluster_xcd0 + f) & 7): the host
                             // deals the small launches of a filling pipeline round the XCDs (a cluster wants an L2 to itself)
     int nfits;              // fits of a cluster launch (slot launch: entries of slot_words; single fit: 1)
-    // Pause / resume (the sweeps' two-stage schedule, capi.hip: fh_fit_normal_batched).  pass_cap > 0: a fit that has made
+    // Pause / resume (the sweeps' two-stage schedule, capi_fit.hip: sweep_staged).  pass_cap > 0: a fit that has made
     // pass_cap passes without converging stops with FIT_STATUS_PAUSED, its power spectrum in p_out and the one before in mu_out
     // -- the whole state of the iteration (radial_fitters.py:769-785 carries nothing else from pass to pass).
     // mode FIT_MODE_RESUME continues from such a state: `resume` = [p (N), p_old (N), passes made] per fit (batched launch:

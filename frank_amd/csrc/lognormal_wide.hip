@@ -1,5 +1,5 @@
 // method='LogNormal' beyond the persistent kernel's basis size (320 < N <= 1023): the pieces of LogNormalMAPModel's Newton
-// minimisation as plain device kernels, driven from the host (capi.hip: LnWide) with rocSOLVER's LU for the Newton system.
+// minimisation as plain device kernels, driven from the host (capi_lognormal.hip: LnWide) with rocSOLVER's LU for the Newton system.
 //
 // Reference: LogNormalMAPModel._fit (statistical_models.py:1064-1160): H(s), jac(s), hess(s) (:1075-1122), limit_step (:1126-
 // 1130); MinimizeNewton and LineSearch (minimizer.py:70-283) -- the control flow of those two lives on the host, every array

@@ -295,7 +295,7 @@ def test_sweep_512_points_work_queue():
 
 @pytest.mark.parametrize("N,cap,stage2", [(130, "200", None), (130, "180", "0"), (300, "220", "3"), (319, "250", None), (335, "200", None), (400, "200", None)])
 def test_staged_sweep_equals_the_single_launch(monkeypatch, N, cap, stage2):
-    """The staged schedule of a sweep (capi.hip: sweep_staged): every fit runs at most `cap` passes in a first launch and
+    """The staged schedule of a sweep (capi_fit.hip: sweep_staged): every fit runs at most `cap` passes in a first launch and
     PAUSES (fit_loop.hip: the state of the iteration radial_fitters.py:769-785 is p and the p before it), the ones that are
     left continue where they stopped -- on clusters of workgroups and on one compute unit each.  Against the single launch
     (FRANK_AMD_SWEEP_CAP=0): the same bits and the same iteration counts for all 96 points, whatever the cap and the split of

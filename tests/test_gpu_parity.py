@@ -1476,7 +1476,7 @@ def test_pipelined_fits_on_clusters(monkeypatch):
 
 def test_histograms_are_reused_only_for_the_same_rows(monkeypatch):
     """A binning pass over the rows, geometry and multiplicities of the context's LAST pass skips the (u, v) histogram and its
-    scan (bin_prepass.hip P1; capi.hip: hist_valid): the statistics must be the bits of a pass that looks at (u, v) again --
+    scan (bin_prepass.hip P1; capi_map.hip: hist_valid): the statistics must be the bits of a pass that looks at (u, v) again --
     after another table, another geometry, other multiplicities or another row range nothing may be reused."""
     import ctypes
     from frank_amd import _lib, DiscreteHankelTransform, FixedGeometry
