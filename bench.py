@@ -382,14 +382,18 @@ def extras(f, L, a):
         u, v, V, w = mock_disc_visibilities(f.nfit, seed=0, noise_seed=50)
         FF = FrankFitter(RMAX_ARCSEC, N, FixedGeometry(**MOCK_GEOMETRY), alpha=h["alpha"], weights_smooth=h["wsmooth"],
                          tol=h["tol"], max_iter=h["max_iter"], verbose=False, store_iteration_diagnostics=True)
-        ts = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            FF.fit(u, v, V, w)
-            ts.append(time.perf_counter() - t0)
+        FF.fit(u, v, V, w)
         nit_h = int(FF.iteration_diagnostics["num_iterations"])
+        # (timed on a fitter that does not keep per-iteration diagnostics -- 3 MB of copies and a GEMV per pass --: the first call
+        #  of a fresh fitter pays its context's workspaces and first look at the table, the later ones are what a loop over
+        #  tables pays per fit)
         FF2 = FrankFitter(RMAX_ARCSEC, N, FixedGeometry(**MOCK_GEOMETRY), alpha=h["alpha"], weights_smooth=h["wsmooth"],
                           tol=h["tol"], max_iter=h["max_iter"], verbose=False)
+        ts = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            FF2.fit(u, v, V, w)
+            ts.append(time.perf_counter() - t0)
         t0 = time.perf_counter(); m = FF2.preprocess_visibilities(u, v, V, w); t_map = time.perf_counter() - t0
         t0 = time.perf_counter(); FF2.fit_preprocessed(m); t_fit = time.perf_counter() - t0
         Vre, Vim = np.ascontiguousarray(V.real), np.ascontiguousarray(V.imag)
@@ -615,16 +619,23 @@ def extras(f, L, a):
         niter = (ctypes.c_int * B)()
         status = (ctypes.c_int * B)()
         nv = min(f.n, 1_000_000)
-        t0 = time.perf_counter()
-        f.bin(nv)
-        finalize()
-        L.check(L.lib.fh_fit_normal_batched(f.ctx, None, None, B, L.ptr(al), L.ptr(p0), L.ptr(ws), h["tol"],
-                                            h["max_iter"], L.ptr(mu), L.ptr(pp), niter, status))
-        dt = time.perf_counter() - t0
+        dt = None
+        for _ in range(2):  # (the first sweep of a process pays ~50 ms of allocations and code loading; the second is what a user's
+                            #  next sweep costs: the better of the two is reported, both are in `s_total_both`)
+            t0 = time.perf_counter()
+            f.bin(nv)
+            finalize()
+            L.check(L.lib.fh_fit_normal_batched(f.ctx, None, None, B, L.ptr(al), L.ptr(p0), L.ptr(ws), h["tol"],
+                                                h["max_iter"], L.ptr(mu), L.ptr(pp), niter, status))
+            d1 = time.perf_counter() - t0
+            both = [d1] if dt is None else both + [d1]
+            dt = d1 if dt is None else min(dt, d1)
         its = np.array(list(niter))
         ex["sweep512"] = {"workload": "BASELINE configs[4] on ONE GPU: %d fits (alpha x w_smooth grid), N=%d, %d "
                                       "visibilities, shared (M, j) as fit.py:534-548" % (B, N, nv),
-                          "fits_per_s": B / dt, "s_total": dt,
+                          "fits_per_s": B / dt, "s_total": dt, "s_total_both": both,
+                          "schedule": "staged (capi_fit.hip: sweep_staged): every fit at most 800 passes on one compute unit in a launch "
+                                      "that fills the device, the fits still running then continue on clusters of workgroups",
                           "iterations_min_median_max": [int(its.min()), int(np.median(its)), int(its.max())],
                           "failed": int(np.sum(np.array(list(status)) != 0)),
                           "not_converged": int(np.sum(its >= h["max_iter"]))}

@@ -75,6 +75,7 @@ SIGNATURES = {
     "fh_fit_cluster_info": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_i64)]),
     "fh_ctx_loop_clocks": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_i64)]),
     "fh_ctx_reload_env": (ctypes.c_int, [_vp]),
+    "fh_ctx_bucket_tables": (ctypes.c_int, [_vp, ctypes.c_int, _dp]),
     "fh_cache_release": (ctypes.c_int, []),
     "fh_stats_upload": (ctypes.c_int, [_vp, _dp, _dp]),
     "fh_sweep_evidence": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_double, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),

@@ -147,6 +147,37 @@ int k1v2_ensure_table(fh_ctx *c, int nb_needed) {
         return fail(FH_ERR_UNSUPPORTED, "baselines reach %.1f x Qmax: the bucket tables of bin_gram would need %.1f GB",
                     nb_needed * c->k1_delta, nb_needed * per * 8e-9);
     if ((size_t)nb_new * per * sizeof(double) > cap_bytes) nb_new = nb_needed;
+    // Built on the device (round 5, j0_buckets_device.hip): the host seeds every 16th bucket in long double, one thread per
+    // (chain, column) marches the Taylor expansion in double-double arithmetic -- 35 ms of host work and a 55 MB upload for a table
+    // that reaches Q_max at N = 300 become ~3 ms.  FRANK_AMD_K1_TABLES=host keeps the long-double construction (and the
+    // single-precision arithmetic keeps it too: its tables are rounded on the host).
+    static const bool host_tables = [] { const char *e = getenv("FRANK_AMD_K1_TABLES"); return e && !strcmp(e, "host"); }();
+    if (!host_tables && !c->arith32) {
+        const int have = c->k1_nb_built, stride = fh_k1_seed_stride();
+        const int chains = (nb_new - have + stride - 1) / stride;
+        std::vector<double> seeds((size_t)chains * c->N * 4);
+        if (fh_k1_bucket_seeds(c->dht->zeros.data(), c->N, have, nb_new, stride, seeds.data()) != 0)
+            return fail(FH_ERR_INVALID, "fh_k1_bucket_seeds failed");
+        DevBuf<double> grown, dseeds;
+        if (grown.alloc((size_t)nb_new * per) != hipSuccess || dseeds.alloc(seeds.size()) != hipSuccess)
+            return fail(FH_ERR_NOMEM, "hipMalloc of the bucket tables failed");
+        HIP_TRY(hipStreamSynchronize(c->stream));  // nothing in flight may still read the old device table
+        HIP_TRY(hipMemcpyAsync(dseeds.p, seeds.data(), sizeof(double) * seeds.size(), hipMemcpyHostToDevice, c->stream));
+        if (have) HIP_TRY(hipMemcpyAsync(grown.p, c->k1_table.p, sizeof(double) * (size_t)have * per, hipMemcpyDeviceToDevice, c->stream));
+        // (columns k >= N of a bucket's rows are zero: the kernels read XS of them)
+        HIP_TRY(hipMemsetAsync(grown.p + (size_t)have * per, 0, sizeof(double) * (size_t)(nb_new - have) * per, c->stream));
+        HIP_TRY(fh_k1_bucket_table_device(c->zeros.p, c->N, c->XS, have, nb_new, c->k1_delta, dseeds.p, grown.p + (size_t)have * per, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // (seeds and dseeds go out of scope)
+        c->k1_nb_built = 0;
+        c->k1_table.release();
+        c->k1_table.p = grown.p;
+        c->k1_table.n = grown.n;
+        c->k1_table.owned = true;
+        grown.p = nullptr;  // (ownership moved)
+        grown.n = 0;
+        c->k1_nb_built = nb_new;
+        return FH_OK;
+    }
     std::shared_ptr<std::vector<double>> tab;
     {
         std::lock_guard<std::mutex> lk(g_k1_tables.mu);
@@ -170,6 +201,19 @@ int k1v2_ensure_table(fh_ctx *c, int nb_needed) {
     HIP_TRY(hipMemcpy(c->k1_table.p, tab->data(), sizeof(double) * (size_t)nb_up * per, hipMemcpyHostToDevice));
     c->k1_nb_built = nb_up;
     if (c->arith32) return k1v2_upload_table32(c, *tab, nb_up);
+    return FH_OK;
+}
+
+// The context's device-resident Taylor tables of the first nb buckets (built if need be), layout [bucket][12][N]: tests compare
+// the tables built on the device with the long-double construction of the host (fh_dht_bucket_tables).
+int fh_ctx_bucket_tables(fh_ctx *c, int nb, double *table) {
+    if (!c || nb < 1 || !table) return fail(FH_ERR_INVALID, "fh_ctx_bucket_tables: bad argument");
+    if (!c->v2) return fail(FH_ERR_UNSUPPORTED, "fh_ctx_bucket_tables: this context does not use the bucket tables");
+    HIP_TRY(hipSetDevice(c->device));
+    const int rc = k1v2_ensure_table(c, nb);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2D(table, sizeof(double) * c->N, c->k1_table.p, sizeof(double) * c->XS, sizeof(double) * c->N,
+                        (size_t)nb * FH_K1_TERMS, hipMemcpyDeviceToHost));
     return FH_OK;
 }
 

@@ -42,6 +42,41 @@ void fill_range(const double *zeros, int N, int XS, double Delta, int b0, int bl
 }
 }  // namespace
 
+// Seeds of the device-side construction (j0_buckets_device.hip): J0 and J0' = -J1 at the centres of the buckets b0, b0 + stride,
+// .. < b1 for every column, in long double, as double-double pairs: out[(c * N + k) * 4] = y hi, y lo, y' hi, y' lo.
+int fh_k1_bucket_seeds(const double *zeros, int N, int b0, int b1, int stride, double *out) {
+    if (!zeros || !out || N < 1 || b0 < 0 || b1 < b0 || stride < 1) return -1;
+    const double Delta = fh_k1_bucket_width(zeros, N);
+    const int chains = (b1 - b0 + stride - 1) / stride;
+    auto fill = [&](int c0, int c1) {
+        for (int c = c0; c < c1; ++c) {
+            const long double s0 = (long double)fh_k1_bucket_centre(b0 + c * stride, Delta);
+            for (int k = 0; k < N; ++k) {
+                const long double x0 = s0 * (long double)zeros[k];
+                const long double y = j0l(x0), yp = -j1l(x0);
+                double *o = out + ((size_t)c * N + k) * 4;
+                o[0] = (double)y;
+                o[1] = (double)(y - (long double)o[0]);
+                o[2] = (double)yp;
+                o[3] = (double)(yp - (long double)o[2]);
+            }
+        }
+    };
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)(hw ? hw : 1);
+    if (nt > 16) nt = 16;
+    if ((long long)chains * N < 20000) nt = 1;
+    if (nt > chains) nt = chains;
+    if (nt <= 1) {
+        fill(0, chains);
+        return 0;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(fill, (int)((long long)chains * t / nt), (int)((long long)chains * (t + 1) / nt));
+    for (auto &x : th) x.join();
+    return 0;
+}
+
 int fh_k1_bucket_table(const double *zeros, int N, int XS, int b0, int b1, double *out) {
     if (!zeros || !out || N < 1 || XS < N || b0 < 0 || b1 < b0) return -1;
     const int nb = b1 - b0;

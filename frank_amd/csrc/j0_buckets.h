@@ -19,3 +19,5 @@ inline double fh_k1_bucket_centre(int b, double Delta) { return ((double)b + 0.5
 // Fill out[(b - b0) * 12 * XS + n * XS + k] for buckets b0 <= b < b1; columns k >= N are zero.  Long-double arithmetic,
 // multi-threaded.  Returns 0, or -1 on a bad argument.
 int fh_k1_bucket_table(const double *zeros, int N, int XS, int b0, int b1, double *out);
+// seeds for the construction on the device (j0_buckets_device.hip): see j0_buckets.cpp
+int fh_k1_bucket_seeds(const double *zeros, int N, int b0, int b1, int stride, double *out);

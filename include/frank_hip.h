@@ -79,6 +79,10 @@ int fh_dht_get(const fh_dht *dht, double *r, double *q, double *zeros, double *Y
  *     J0(s j_k) = sum_{n < 12} table[(b - b0) * 12 * N + n * N + k] * tau^n        (truncation error 1.2e-16).
  * table: (b1 - b0) * 12 * N doubles, or NULL to query delta only.                                                    */
 int fh_dht_bucket_tables(const fh_dht *dht, int b0, int b1, double *table, double *delta);
+/* The same tables as a context holds them on the device for its first nb buckets, [bucket][12][N] -- since round 5 they are built
+ * THERE (host seeds every 16th bucket, double-double Taylor marching in between; FRANK_AMD_K1_TABLES=host keeps the long-double
+ * construction): the tests hold them to one unit in the last place of fh_dht_bucket_tables.                                */
+int fh_ctx_bucket_tables(fh_ctx *ctx, int nb, double *table);
 
 /* ---- contexts ------------------------------------------------------------------------------------------- */
 int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out);

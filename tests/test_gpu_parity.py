@@ -1653,3 +1653,31 @@ def test_diagonal_tile_routines():
     if not cyc["z"] < 0.6 * cyc["rounds2-4"]:  # (a speed, not a correctness property: a shared or throttled GPU must not fail the suite)
         import warnings
         warnings.warn("chol_inv_tile_z took %.0f cycles per tile against %.0f for the routine of rounds 2-4" % (cyc["z"], cyc["rounds2-4"]))
+
+
+@pytest.mark.parametrize("N,nb", [(20, 60), (100, 500), (300, 2400), (1000, 700)])
+def test_bucket_tables_built_on_the_device(N, nb):
+    """j0_buckets_device.hip (round 5): the Taylor tables of the J0 buckets built on the device -- long-double seeds at every 16th
+    bucket, double-double marching in between -- against the long-double construction of the host (j0_buckets.cpp,
+    fh_dht_bucket_tables): every entry within one unit in the last place (entries below a twentieth of the largest of their order n
+    -- next to a zero of that coefficient, where both constructions hold a small difference -- within the unit of that twentieth),
+    most of them equal; grown in two steps like a context whose
+    second table reaches further (hankel.py:187-204 is what the tables stand for)."""
+    import ctypes
+    from frank_amd import DiscreteHankelTransform, _lib
+    d = DiscreteHankelTransform(RMAX, N)
+    ctx = d.context()
+    dev = np.empty((nb, 12, N))
+    _lib.check(_lib.lib.fh_ctx_bucket_tables(ctx, nb // 3, _lib.ptr(dev)))       # a first, shorter table ...
+    first = dev[:nb // 3].copy()
+    _lib.check(_lib.lib.fh_ctx_bucket_tables(ctx, nb, _lib.ptr(dev)))            # ... grown
+    assert np.array_equal(first, dev[:nb // 3])
+    host = np.empty((nb, 12, N))
+    delta = ctypes.c_double()
+    _lib.check(_lib.lib.fh_dht_bucket_tables(d._handle, 0, nb, _lib.ptr(host), ctypes.byref(delta)))
+    assert np.isfinite(dev).all()
+    scale = np.abs(host).max(axis=(0, 2), keepdims=True)          # the size of order n's entries
+    ulp = np.spacing(np.maximum(np.abs(host), 0.05 * scale))
+    err = np.abs(dev - host) / ulp
+    assert err.max() <= 1.0, (float(err.max()), np.unravel_index(err.argmax(), err.shape))
+    assert (dev == host).mean() > 0.9
