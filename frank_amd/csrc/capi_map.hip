@@ -153,10 +153,12 @@ int k1v2_ensure_table(fh_ctx *c, int nb_needed) {
     // single-precision arithmetic keeps it too: its tables are rounded on the host).
     static const bool host_tables = [] { const char *e = getenv("FRANK_AMD_K1_TABLES"); return e && !strcmp(e, "host"); }();
     if (!host_tables && !c->arith32) {
-        const int have = c->k1_nb_built, stride = fh_k1_seed_stride();
-        const int chains = (nb_new - have + stride - 1) / stride;
+        const int have = c->k1_nb_built;
+        const int chains = fh_k1_seed_chains(have, nb_new);
+        std::vector<int> seed_buckets((size_t)chains);
+        for (int i = 0; i < chains; ++i) seed_buckets[i] = fh_k1_seed_bucket(have, i);
         std::vector<double> seeds((size_t)chains * c->N * 4);
-        if (fh_k1_bucket_seeds(c->dht->zeros.data(), c->N, have, nb_new, stride, seeds.data()) != 0)
+        if (fh_k1_bucket_seeds(c->dht->zeros.data(), c->N, seed_buckets.data(), chains, seeds.data()) != 0)
             return fail(FH_ERR_INVALID, "fh_k1_bucket_seeds failed");
         DevBuf<double> grown, dseeds;
         if (grown.alloc((size_t)nb_new * per) != hipSuccess || dseeds.alloc(seeds.size()) != hipSuccess)

@@ -42,15 +42,14 @@ void fill_range(const double *zeros, int N, int XS, double Delta, int b0, int bl
 }
 }  // namespace
 
-// Seeds of the device-side construction (j0_buckets_device.hip): J0 and J0' = -J1 at the centres of the buckets b0, b0 + stride,
-// .. < b1 for every column, in long double, as double-double pairs: out[(c * N + k) * 4] = y hi, y lo, y' hi, y' lo.
-int fh_k1_bucket_seeds(const double *zeros, int N, int b0, int b1, int stride, double *out) {
-    if (!zeros || !out || N < 1 || b0 < 0 || b1 < b0 || stride < 1) return -1;
+// Seeds of the device-side construction (j0_buckets_device.hip): J0 and J0' = -J1 at the centres of the `chains` buckets
+// listed in `buckets`, for every column, in long double, as double-double pairs: out[(c * N + k) * 4] = y hi, y lo, y' hi, y' lo.
+int fh_k1_bucket_seeds(const double *zeros, int N, const int *buckets, int chains, double *out) {
+    if (!zeros || !out || !buckets || N < 1 || chains < 0) return -1;
     const double Delta = fh_k1_bucket_width(zeros, N);
-    const int chains = (b1 - b0 + stride - 1) / stride;
     auto fill = [&](int c0, int c1) {
         for (int c = c0; c < c1; ++c) {
-            const long double s0 = (long double)fh_k1_bucket_centre(b0 + c * stride, Delta);
+            const long double s0 = (long double)fh_k1_bucket_centre(buckets[c], Delta);
             for (int k = 0; k < N; ++k) {
                 const long double x0 = s0 * (long double)zeros[k];
                 const long double y = j0l(x0), yp = -j1l(x0);

@@ -20,4 +20,4 @@ inline double fh_k1_bucket_centre(int b, double Delta) { return ((double)b + 0.5
 // multi-threaded.  Returns 0, or -1 on a bad argument.
 int fh_k1_bucket_table(const double *zeros, int N, int XS, int b0, int b1, double *out);
 // seeds for the construction on the device (j0_buckets_device.hip): see j0_buckets.cpp
-int fh_k1_bucket_seeds(const double *zeros, int N, int b0, int b1, int stride, double *out);
+int fh_k1_bucket_seeds(const double *zeros, int N, const int *buckets, int chains, double *out);

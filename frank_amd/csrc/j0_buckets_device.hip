@@ -10,8 +10,10 @@
 //         a_{n+2} = -[(n+1)^2 a_{n+1} + x0 a_n + a_{n-1}] / (x0 (n+2)(n+1))            (j0_buckets.cpp, the same recurrence)
 //     the first twelve, scaled by h^n, h = j_k Delta / 2, are the bucket's table entries (rounded to double);
 //   * y and y' at the NEXT centre (x0 + 2h) by Horner over kTerms = 24 of them.
-// Rounding excites the Y0-like solution, whose coefficients grow like eps x0^-n; they are used at |t| <= 2h <= 2 x0 (bucket 0)
-// and <= x0 beyond, so that part stays below 2^24 eps_dd = 1e-25 (the host's bound, with its eps, is what its header states).
+// Rounding excites the Y0-like solution, whose coefficients grow like eps x0^-n.  The SEEDS carry the host's eps (1e-19): from
+// bucket b the march evaluates at t = 2h = 2 x0 / (2b + 1), so that part is eps (2 / (2b + 1))^n -- harmless from bucket 1 on
+// (<= (2/3)^n), but 2^24 eps = 1e-12 out of bucket 0, whose centre is as far from the singularity at 0 as its neighbour's is from
+// it.  So bucket 0 is a chain of its own: the host seeds buckets 0 and 1 (first_len = 1 when the range starts at bucket 0).
 // tests/test_gpu_parity.py::test_bucket_tables_built_on_the_device holds the result to <= 1 ulp of the host's tables.
 #include <hip/hip_runtime.h>
 
@@ -68,17 +70,18 @@ __device__ __forceinline__ dd dd_div(dd a, dd b) {
     return dd_add(q, dd{q3, 0.0});
 }
 
-// seeds[(c * N + k) * 4 + {0, 1, 2, 3}] = y hi, y lo, y' hi, y' lo at the centre of bucket b0 + c * stride, column k
-__global__ __launch_bounds__(256) void bucket_table_kernel(const double *zeros, int N, int XS, int b0, int b1, int stride, double Delta,
-                                                           const double *seeds, double *table) {
+// seeds[(c * N + k) * 4 + {0, 1, 2, 3}] = y hi, y lo, y' hi, y' lo at the centre of the first bucket of chain c, column k; chain 0
+// covers first_len buckets from b0, chain c >= 1 the `stride` buckets from b0 + first_len + (c - 1) stride
+__global__ __launch_bounds__(256) void bucket_table_kernel(const double *zeros, int N, int XS, int b0, int b1, int first_len, int stride,
+                                                           double Delta, const double *seeds, double *table) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
     if (k >= N) return;
     const double jk = zeros[k];
     const double *sd = seeds + ((size_t)c * N + k) * 4;
     dd y = {sd[0], sd[1]}, yp = {sd[2], sd[3]};
     const dd h = dd_mul_d(two_prod(jk, Delta), 0.5);  // j_k Delta / 2 (the halving is exact)
-    const int bfirst = b0 + c * stride;
-    for (int b = bfirst; b < bfirst + stride && b < b1; ++b) {
+    const int bfirst = c == 0 ? b0 : b0 + first_len + (c - 1) * stride, blen = c == 0 ? first_len : stride;
+    for (int b = bfirst; b < bfirst + blen && b < b1; ++b) {
         const double s0 = ((double)b + 0.5) * Delta;  // fh_k1_bucket_centre: the same fp64 expression as the host
         const dd x0 = two_prod(s0, jk);
         dd a[kTermsDD];
@@ -112,12 +115,19 @@ __global__ __launch_bounds__(256) void bucket_table_kernel(const double *zeros, 
 }  // namespace
 
 int fh_k1_seed_stride() { return 16; }
+// chains of the range [b0, b1) and the first bucket of chain c (the layout of the seeds): bucket 0 is a chain of its own
+int fh_k1_seed_first_len(int b0) { return b0 == 0 ? 1 : fh_k1_seed_stride(); }
+int fh_k1_seed_chains(int b0, int b1) {
+    if (b1 <= b0) return 0;
+    const int fl = fh_k1_seed_first_len(b0), st = fh_k1_seed_stride();
+    return b1 - b0 <= fl ? 1 : 1 + (b1 - b0 - fl + st - 1) / st;
+}
+int fh_k1_seed_bucket(int b0, int c) { return c == 0 ? b0 : b0 + fh_k1_seed_first_len(b0) + (c - 1) * fh_k1_seed_stride(); }
 
 hipError_t fh_k1_bucket_table_device(const double *zeros_dev, int N, int XS, int b0, int b1, double Delta, const double *seeds_dev,
                                      double *table_dev, hipStream_t stream) {
     if (b1 <= b0) return hipSuccess;
-    const int stride = fh_k1_seed_stride(), chains = (b1 - b0 + stride - 1) / stride;
-    hipLaunchKernelGGL(bucket_table_kernel, dim3((N + 255) / 256, chains), dim3(256), 0, stream, zeros_dev, N, XS, b0, b1, stride, Delta,
-                       seeds_dev, table_dev);
+    hipLaunchKernelGGL(bucket_table_kernel, dim3((N + 255) / 256, fh_k1_seed_chains(b0, b1)), dim3(256), 0, stream, zeros_dev, N, XS, b0,
+                       b1, fh_k1_seed_first_len(b0), fh_k1_seed_stride(), Delta, seeds_dev, table_dev);
     return hipGetLastError();
 }

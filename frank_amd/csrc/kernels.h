@@ -139,6 +139,8 @@ hipError_t fh_k1v2_launch_compress(const CompressParams &cp, hipStream_t stream)
 hipError_t fh_k1v2_launch_max(const double *q, int64_t n, double *out, hipStream_t stream);
 // the Taylor tables of the buckets b0 <= b < b1 built on the device from host seeds (j0_buckets_device.hip)
 int fh_k1_seed_stride();
+int fh_k1_seed_chains(int b0, int b1);   // chains of the range [b0, b1) ...
+int fh_k1_seed_bucket(int b0, int c);    // ... and the bucket the seeds of chain c belong to
 hipError_t fh_k1_bucket_table_device(const double *zeros_dev, int N, int XS, int b0, int b1, double Delta, const double *seeds_dev,
                                      double *table_dev, hipStream_t stream);
 hipError_t fh_k1v2_launch_predict_coef(const double *table, int XS, int N, int nb, const double *pref, const double *I, double scale,

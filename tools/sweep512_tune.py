@@ -17,7 +17,9 @@ from frank_amd.mock import mock_disc_visibilities  # noqa: E402
 N = bench.N_COLL
 f = bench.Fitter(L, N, 0)
 f.nfit = 1_000_000
-f.upload(*mock_disc_visibilities(f.nfit, seed=0, noise_seed=50))
+# BENCH_TABLE=1: the bench's own workload -- the first 1e6 rows of the 1e7-row headline table (another draw than 1e6 rows of seed 0)
+nrows = 10_000_000 if os.environ.get("BENCH_TABLE") else f.nfit
+f.upload(*mock_disc_visibilities(nrows, seed=0, noise_seed=50))
 h = bench.HYPER
 f.fit()
 al, ws = np.meshgrid(np.linspace(1.01, 1.5, 32), np.logspace(-4, -1, 16))
