@@ -526,7 +526,7 @@ static int sweep_staged(fh_ctx *c, int batch, const std::vector<int> &order, con
     const size_t G = (size_t)(batch < c->num_cu ? batch : c->num_cu);
     DevBuf<double> Cb, Wb, WdTb, csb, mub, pb, lub, alb, p0b, rsb;
     DevBuf<int> resb, counter;
-    if (counter.alloc(1) != hipSuccess || Cb.alloc(G * PP) != hipSuccess || Wb.alloc(G * PP) != hipSuccess ||
+    if (counter.alloc(2) != hipSuccess || Cb.alloc(G * PP) != hipSuccess || Wb.alloc(G * PP) != hipSuccess ||
         WdTb.alloc(G * NP * 16) != hipSuccess || csb.alloc(G * fh_k2_cs_doubles(NP)) != hipSuccess || mub.alloc(B * N) != hipSuccess ||
         pb.alloc(B * N) != hipSuccess || lub.alloc(B * 5 * N) != hipSuccess || alb.alloc(B) != hipSuccess || p0b.alloc(B) != hipSuccess ||
         resb.alloc(2 * B) != hipSuccess || rsb.alloc(B * RS) != hipSuccess)
@@ -542,7 +542,7 @@ static int sweep_staged(fh_ctx *c, int batch, const std::vector<int> &order, con
     std::vector<double> mu_o(B * N), p_o(B * N);
     // one batched launch over n fits whose per-fit inputs sit in the first n entries of the host arrays; results into res / mu_o / p_o
     auto launch = [&](int n, int mode, int pass_cap, int grid, int loaded) -> int {
-        HIP_TRY(hipMemsetAsync(counter.p, 0, sizeof(int), c->stream));
+        HIP_TRY(hipMemsetAsync(counter.p, 0, 2 * sizeof(int), c->stream));
         HIP_TRY(hipMemcpyAsync(lub.p, lu_all.data(), sizeof(double) * (size_t)n * 5 * N, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(alb.p, al_o.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(p0b.p, p0_o.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
@@ -559,7 +559,11 @@ static int sweep_staged(fh_ctx *c, int batch, const std::vector<int> &order, con
         P.batch_alpha = alb.p;
         P.batch_p0 = p0b.p;
         P.batch_counter = counter.p;
-        P.pass_cap = pass_cap;
+        P.pass_cap = pass_cap > 0 ? pass_cap : 0;
+        if (pass_cap < 0) {  // adaptive: the last -pass_cap fits still running pause together
+            P.pause_when_left = -pass_cap;
+            P.done_counter = counter.p + 1;
+        }
         P.resume = mode == FIT_MODE_RESUME ? rsb.p : nullptr;
         P.loaded = loaded;
         HIP_TRY(fh_k2_launch_loop_batched(P, grid, c->stream));
@@ -579,8 +583,10 @@ static int sweep_staged(fh_ctx *c, int batch, const std::vector<int> &order, con
     const bool trace = getenv("FRANK_AMD_SWEEP_TRACE") != nullptr;  // development: stage times on stderr
     const auto t_start = std::chrono::steady_clock::now();
     auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
-    // ---- stage 1: every fit, at most `cap` passes ----
-    int rc = launch(batch, FIT_MODE_FULL, cap, (int)G, batch > (int)G ? c->num_cu : 0);  // (more fits than units: the device stays full)
+    // ---- stage 1: every fit; cap > 0: at most `cap` passes; cap == 0: until the fits still running are few enough for the
+    //      clusters of stage 2 (four clusters per XCD: 32 on this device) -- they then pause together, wherever they are ----
+    const int left = env_int("FRANK_AMD_SWEEP_LEFT", 4 * 8);
+    int rc = launch(batch, FIT_MODE_FULL, cap > 0 ? cap : -left, (int)G, batch > (int)G ? c->num_cu : 0);  // (more fits than units: the device stays full)
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<int> paused;                 // launch-order indices of the fits that stopped at the cap
@@ -715,10 +721,12 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     // the staged schedule (sweep_staged above): sweeps of at least 64 points on an idle context, sizes the deferred kernel covers
     {
         const int gsz = fit_cluster_size(c);
-        // (the cap: BASELINE configs[4], 512 fits: 640 / 800 / 900 / 1 000 / 1 200 passes -> 1 508 / 2 047 / 2 014 / 1 914 / 1 826 fits/s,
-        //  the single launch with its sixteen longest on clusters 1 515-1 650; 0 turns the schedule off)
-        const int cap = env_int("FRANK_AMD_SWEEP_CAP", 800);
-        if (cap > 0 && gsz > 1 && batch >= 64 && c->slots_busy == 0 && c->pending_batch < 0 && !getenv("FRANK_AMD_SWEEP_NO_CLUSTERS") &&
+        // (FRANK_AMD_SWEEP_CAP: 0, the default: the fits pause when only as many are still running as the clusters of the second
+        //  stage hold; n > 0: every fit pauses after n passes -- the best constant depends on the grid: 800 for one draw of
+        //  BASELINE configs[4] (2 047 fits/s; 1 000: 1 914), 1 000 for another (1 963; 800: 1 592), the single launch with its
+        //  sixteen longest points on clusters 1 515-1 650 on both; -1: that single launch)
+        const int cap = env_int("FRANK_AMD_SWEEP_CAP", 0);
+        if (cap >= 0 && gsz > 1 && batch >= 64 && c->slots_busy == 0 && c->pending_batch < 0 && !getenv("FRANK_AMD_SWEEP_NO_CLUSTERS") &&
             max_iter > cap)
             return sweep_staged(c, batch, order, alpha, p0, wsmooth, tol, max_iter, cap, mu, p, niter, status);
     }

@@ -2533,6 +2533,18 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
             status = FIT_STATUS_PAUSED;
             break;
         }
+        if (P.pause_when_left > 0 && (count & 15) == 0) {  // ... or when this fit is one of the last few of its batch still running
+            if (tid == 0)
+                s_ctl[3] = __hip_atomic_load(P.batch_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.batch &&
+                           P.batch - __hip_atomic_load(P.done_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= P.pause_when_left;
+            __syncthreads();
+            const int stop = s_ctl[3];
+            __syncthreads();
+            if (stop) {
+                status = FIT_STATUS_PAUSED;
+                break;
+            }
+        }
     }
 
     // outputs: mu = Y^-1 m, p, count, status (a paused fit: p_old in the place of mu)
@@ -2590,6 +2602,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
             P.result_host[0] = count;
             P.result_host[1] = status;
         }
+        if (P.done_counter && status != FIT_STATUS_PAUSED) atomicAdd(P.done_counter, 1);
         if (P.clk_out) {
             atomicAdd(P.clk_out, (unsigned long long)(clock64() - s_clk[0]));
             atomicAdd(P.clk_out + 1, (unsigned long long)(wall_clock64() - s_clk[1]));

@@ -273,6 +273,11 @@ struct FitLoopParams {
     // 2 N + 1 doubles per fit; slot launch: behind the slot's band LU and hyper-parameters, the pointer is set by the kernel).
     int pass_cap;
     const double *resume;
+    // ... or adaptively (batched launches): pause_when_left > 0 -- a fit pauses, at a pass that is a multiple of 16, once every fit
+    // of the batch has been handed out (batch_counter >= batch) and at most pause_when_left of them have not ended (done_counter
+    // counts the ended ones): the stragglers of a sweep stop together, when they are few enough for the clusters
+    int pause_when_left;
+    int *done_counter;
     int loaded;             // host hint: fit loops already resident on the device when this launch starts (launch_loop picks the
                             // form of the one-workgroup kernel that suits a full device: the rows of the inverse in pairs)
 };

@@ -293,12 +293,13 @@ def test_sweep_512_points_work_queue():
         assert np.array_equal(s1.power_spectrum, sols[b].power_spectrum)
 
 
-@pytest.mark.parametrize("N,cap,stage2", [(130, "200", None), (130, "180", "0"), (300, "220", "3"), (319, "250", None), (335, "200", None), (400, "200", None)])
+@pytest.mark.parametrize("N,cap,stage2", [(130, "200", None), (130, "180", "0"), (300, "220", "3"), (319, "250", None), (335, "200", None), (400, "200", None),
+                                          (130, "0", None), (300, "0", "5"), (335, "0", None)])
 def test_staged_sweep_equals_the_single_launch(monkeypatch, N, cap, stage2):
     """The staged schedule of a sweep (capi_fit.hip: sweep_staged): every fit runs at most `cap` passes in a first launch and
     PAUSES (fit_loop.hip: the state of the iteration radial_fitters.py:769-785 is p and the p before it), the ones that are
-    left continue where they stopped -- on clusters of workgroups and on one compute unit each.  Against the single launch
-    (FRANK_AMD_SWEEP_CAP=0): the same bits and the same iteration counts for all 96 points, whatever the cap and the split of
+    left continue where they stopped -- on clusters of workgroups and on one compute unit each; with cap 0 (the default) the
+    fits pause together when only a few are still running.  Against the single launch (FRANK_AMD_SWEEP_CAP=-1): the same bits and the same iteration counts for all 96 points, whatever the cap and the split of
     the second stage, on the deferred kernel (N <= 319), the one of rounds 2-4 (335) and the wide instantiation (400)."""
     import ctypes
     from frank_amd import _lib
@@ -315,9 +316,12 @@ def test_staged_sweep_equals_the_single_launch(monkeypatch, N, cap, stage2):
         _lib.check(_lib.lib.fh_fit_normal_batched(ctx, _lib.ptr(M), _lib.ptr(j), B, _lib.ptr(al), _lib.ptr(p0), _lib.ptr(ws), 1e-3, 400,
                                                   _lib.ptr(mu), _lib.ptr(pp), nit, st))
         return mu, pp, np.array(list(nit)), np.array(list(st))
-    monkeypatch.setenv("FRANK_AMD_SWEEP_CAP", "0")
+    monkeypatch.setenv("FRANK_AMD_SWEEP_CAP", "-1")   # (the single launch)
     mu0, p0_, n0, s0 = run()
-    assert (n0 > int(cap) + 20).sum() > 5 and (n0 < int(cap)).sum() > 5   # (some fits end inside the cap, some well beyond it)
+    if int(cap) > 0:
+        assert (n0 > int(cap) + 20).sum() > 5 and (n0 < int(cap)).sum() > 5   # (some fits end inside the cap, some well beyond it)
+    else:
+        monkeypatch.setenv("FRANK_AMD_SWEEP_LEFT", "24")   # (cap 0: the last 24 fits still running pause together)
     monkeypatch.setenv("FRANK_AMD_SWEEP_CAP", cap)
     if stage2 is not None:
         monkeypatch.setenv("FRANK_AMD_SWEEP_STAGE2_CLUSTERS", stage2)
