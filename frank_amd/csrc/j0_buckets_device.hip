@@ -9,7 +9,7 @@
 //   * at a bucket centre x0 with y = J0(x0), y' = J0'(x0) known: the Taylor coefficients about x0 from Bessel's equation,
 //         a_{n+2} = -[(n+1)^2 a_{n+1} + x0 a_n + a_{n-1}] / (x0 (n+2)(n+1))            (j0_buckets.cpp, the same recurrence)
 //     the first twelve, scaled by h^n, h = j_k Delta / 2, are the bucket's table entries (rounded to double);
-//   * y and y' at the NEXT centre (x0 + 2h) by Horner over kTerms = 24 of them.
+//   * y and y' at the NEXT centre (the next ROUNDED centre: its distance is formed in double-double) by Horner over 24 of them.
 // Rounding excites the Y0-like solution, whose coefficients grow like eps x0^-n.  The SEEDS carry the host's eps (1e-19): from
 // bucket b the march evaluates at t = 2h = 2 x0 / (2b + 1), so that part is eps (2 / (2b + 1))^n -- harmless from bucket 1 on
 // (<= (2/3)^n), but 2^24 eps = 1e-12 out of bucket 0, whose centre is as far from the singularity at 0 as its neighbour's is from
@@ -100,8 +100,11 @@ __global__ __launch_bounds__(256) void bucket_table_kernel(const double *zeros, 
             tb[(size_t)n * XS] = e.hi + e.lo;
             p = dd_mul(p, h);
         }
-        // y, y' at the next centre: t = 2 h
-        const dd t = {2.0 * h.hi, 2.0 * h.lo};
+        // y, y' at the next centre.  The centres are ROUNDED fp64 expressions ((b + 1/2) Delta, as the host and the kernels
+        // that use the tables form them): the step is the difference of the two products, not 2 h -- which is off by the
+        // rounding of a centre, 1e-17 of x0, and through y' by as much in y
+        const double s1 = ((double)(b + 1) + 0.5) * Delta;
+        const dd t = dd_add(two_prod(s1, jk), dd_neg(x0));
         dd sy = a[kTermsDD - 1], syp = dd_mul_d(a[kTermsDD - 1], (double)(kTermsDD - 1));
         for (int n = kTermsDD - 2; n >= 0; --n) {
             sy = dd_add(dd_mul(sy, t), a[n]);
