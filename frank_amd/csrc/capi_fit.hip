@@ -637,11 +637,13 @@ static int sweep_staged(fh_ctx *c, int batch, const std::vector<int> &order, con
     if (Kc > 0) {
         const bool had = c->have_device_Mj;
         c->have_device_Mj = true;  // (M, j are on the device: uploaded by the caller of this function or by its caller's finalisation)
+        c->qspace_shared = true;   // (... and their q-space operands in the context's buffers: fh_fit_normal_batched prepared them)
         int rcs = FH_OK;
         for (int i = 0; i < Kc && rcs == FH_OK; ++i) {
             const int b = order[paused[i]];
             rcs = fit_submit_impl(c, alpha[b], p0[b], wsmooth[b], tol, max_iter, &tickets[i], &state[(size_t)i * RS]);
         }
+        c->qspace_shared = false;
         c->force_cluster_launch = true;
         if (rcs == FH_OK) rcs = fh_fit_flush(c);
         c->force_cluster_launch = false;
@@ -1038,7 +1040,13 @@ static int fit_submit_impl(fh_ctx *c, double alpha, double p0, double wsmooth, d
         HIP_TRY(hipMemcpyAsync(s.band_lu.p + 5 * (size_t)N + 2, s.resume_host.data(), sizeof(double) * s.resume_host.size(),
                                hipMemcpyHostToDevice, c->stream));
     }
-    int rc = prepare_qspace(c, s.Aq.p, s.bq.p);  // on the context's stream, after the finalize that produced M, j
+    int rc = FH_OK;
+    if (c->qspace_shared) {  // (a sweep: every fit has the M, j whose q-space operands the context already holds)
+        HIP_TRY(hipMemcpyAsync(s.Aq.p, c->Aq.p, sizeof(double) * PP, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(s.bq.p, c->bq.p, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        rc = prepare_qspace(c, s.Aq.p, s.bq.p);  // on the context's stream, after the finalize that produced M, j
+    }
     if (rc) return rc;
     FitBatch &b = c->batches[c->pending_batch];
     b.slots[b.n++] = (unsigned short)si;

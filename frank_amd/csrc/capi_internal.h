@@ -277,6 +277,7 @@ struct fh_ctx {
     int fit_batch = kFitBatchMax;
     int burst_next = 1;      // fits that trigger the next launch: 1, 2, 4, .. up to fit_batch while a pipeline fills up
     int next_xcd = 0;        // XCD of the first fit of the next cluster launch
+    bool qspace_shared = false;  // fit_submit_impl copies the context's q-space operands instead of forming them again (sweeps)
     bool force_cluster_launch = false;  // the launch being flushed runs on clusters whatever is outstanding (fh_fit_normal_batched)
     hipEvent_t stream_last_done[kLaunchStreamsMax] = {};  // completion event of the last launch each launch stream was given
     size_t slot_stride = 0;
