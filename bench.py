@@ -1076,7 +1076,8 @@ def main():
             if "fits_per_s" in ss:  # the same algorithmic flops against the WHOLE chip, at the rate the pipeline sustains
                 out["roofline"]["chip_fraction_at_steady_state"] = ss["fits_per_s"] * flops_fit / 1e12 / FP64_MFMA_PEAK_TFLOPS
                 out["roofline"]["chip_note"] = ("at steady state a fit loop is one CU and up to %d fits are outstanding, in "
-                                                "launches of up to 64 fit loops (~190 loops resident)" % ss.get("fit_slots", 0))
+                                                "launches of up to 64 fit loops (~150 loops resident: fits/s x time per fit); the rate is set by the "
+                                                "bytes both the loops and the binning passes move beyond the L2" % ss.get("fit_slots", 0))
         if not a.no_cpu_baseline and world == 1:  # the CPU leg is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(a.ncoll, a.nvis, nit)
         print(json.dumps(out), flush=True)

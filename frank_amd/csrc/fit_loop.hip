@@ -2715,12 +2715,15 @@ static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s)
     // operand reads (5.3 us per diagonal tile) -- and with the device full it only draws level (200 loops: 227 against 233 us,
     // steady state 1 078 against 1 056 fits/s).
     const char *le = getenv("FRANK_AMD_K2_LL");
-    if (le && atoi(le) != 0) return go(&fit_loop_kernel<0, 3>, P, blocks);
+    if (le && atoi(le) != 0 && P.NP >= 64) return go(&fit_loop_kernel<0, 3>, P, blocks);  // (its tables live in the W buffer too: see below)
     // The deferred trailing update (round 5; solve_posterior, CLM = 4): the same bits with half the loads and stores of the
     // trailing update -- what a pass moves beyond the L2 is what bounds a loaded device.  FRANK_AMD_K2_DEFER=0 keeps the
     // kernel of rounds 2-4 (read at every launch: the tests compare the two inside one process).
     const char *de = getenv("FRANK_AMD_K2_DEFER");
-    if (P.NP <= kDeferMaxNP && !(de && atoi(de) == 0)) {
+    // (from NP = 64 on: the band factors and scan tables of this form, 6 NP + 3 072 doubles, live in the fit's W buffer of NP^2
+    //  doubles -- at NP = 48 they overran it by a third, which the suite only noticed as a memory fault when a small LogNormal
+    //  fit's seed loop followed a test that had left unmapped pages behind the buffer)
+    if (P.NP >= 64 && P.NP <= kDeferMaxNP && !(de && atoi(de) == 0)) {
         smem = loop_smem_bytes_deferred(P.NP);
         // ... and the rows of the inverse in pairs (CLM = 5: one load of W per two products) where the device is FULL: with 256
         // loops resident a pass takes 186 us against 217 without the pairs (and 264 for the kernel of rounds 2-4), but alone
