@@ -706,81 +706,25 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
     HIP_TRY(hipMemcpyAsync(lub.p, lu_all.data(), sizeof(double) * lu_all.size(), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(alb.p, al_o.data(), sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(p0b.p, p0_o.data(), sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
-    // The launch ends with its slowest fit, and the first point in launch order is the one most likely to run to max_iter
-    // (bench extra.lognormal_batched64: one 2 001-pass point held 64 compute units for 3.5 s).  From N = 160 on -- where a
-    // single fit runs its parallel pieces on a CLUSTER of eight workgroups, the same bits (lognormal.hip,
-    // test_lognormal_cluster_equals_single_workgroup) at about half the time per pass -- that point does not join the batch: it
-    // runs as a cluster fit on a stream of its own, beside the batched launch of the others.  FRANK_AMD_LN_SWEEP_CLUSTERS=0:
-    // everything in the one launch (rounds 2-4).
-    const bool lead = N >= 160 && batch >= 8 && env_int("FRANK_AMD_LN_SWEEP_CLUSTERS", 1) != 0 && env_int("FRANK_AMD_LN_CLUSTER", 8) > 1;
-    const int K = lead ? 1 : 0;
-    LogNormalParams P1 = P;  // (the context's own work buffers: ln_prepare)
-    hipStream_t side = nullptr;
-    hipEvent_t ready = nullptr;
-    struct SideGuard {
-        hipStream_t &s;
-        hipEvent_t &e;
-        ~SideGuard() {
-            if (s) {
-                (void)hipStreamSynchronize(s);
-                (void)hipStreamDestroy(s);
-            }
-            if (e) (void)hipEventDestroy(e);
-        }
-    } side_guard{side, ready};
-    if (K) {
-        int cl = env_int("FRANK_AMD_LN_CLUSTER", 8);
-        cl = cl < 1 ? 1 : (cl > 8 ? 8 : cl);
-        const size_t nv = (size_t)2 * N + P.NP;
-        if (!c->ln_ctl.p) HIP_TRY(c->ln_ctl.alloc(8));
-        if (c->ln_cluster_vecs.n < nv) HIP_TRY(c->ln_cluster_vecs.alloc(nv));
-        HIP_TRY(hipMemsetAsync(c->ln_ctl.p, 0, 8 * sizeof(int), c->stream));
-        HIP_TRY(hipMemcpyAsync(c->band_lu.p, lu_all.data(), sizeof(double) * 5 * N, hipMemcpyHostToDevice, c->stream));  // (of order[0])
-        P1.mode = LN_MODE_FIT;
-        P1.max_iter = max_iter;
-        P1.tol = tol;
-        P1.s0 = log(I_scale);
-        P1.guess = c->mu_out.p;
-        P1.alpha = al_o[0];
-        P1.p0 = p0_o[0];
-        P1.cluster = cl;
-        P1.ctl = c->ln_ctl.p;
-        P1.rk_g = c->ln_cluster_vecs.p;
-        P1.tr2_g = c->ln_cluster_vecs.p + N;
-        P1.dvec_g = c->ln_cluster_vecs.p + 2 * N;
-        HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(ready, c->stream));  // (seeds, band factors, control words: all queued on the context's stream)
-        HIP_TRY(hipStreamWaitEvent(side, ready, 0));
-        HIP_TRY(fh_ln_launch(P1, 1, side));
-    }
     P.mode = LN_MODE_FIT;
     P.max_iter = max_iter;
     P.tol = tol;
     P.s0 = log(I_scale);
     P.guess = c->mu_out.p;
-    // (the fits of the batched launch are order[K ..]: entry k of every per-fit array stays fit k's)
-    P.band_lu = lub.p + (size_t)K * 5 * N;
+    P.band_lu = lub.p;
     P.Sinv = Sb.p;
     P.LU = LUb.p;
     P.Hinv = Hib.p;
-    P.H = Hb.p + (size_t)K * NN;
-    P.s_out = sb.p + (size_t)K * N;
-    P.p_out = pb.p + (size_t)K * N;
-    P.result = resb.p + 2 * K;
-    P.stats = stb.p + 17 * K;
-    P.batch = batch - K;
+    P.H = Hb.p;
+    P.s_out = sb.p;
+    P.p_out = pb.p;
+    P.result = resb.p;
+    P.stats = stb.p;
+    P.batch = batch;
     P.batch_counter = counter.p;
-    P.batch_alpha = alb.p + K;
-    P.batch_p0 = p0b.p + K;
-    if (batch > K) HIP_TRY(fh_ln_launch(P, (int)(G > (size_t)(batch - K) ? (size_t)(batch - K) : G), c->stream));
-    if (K) {  // the cluster fit's results into entry 0 of the per-fit arrays
-        HIP_TRY(hipStreamSynchronize(side));
-        HIP_TRY(hipMemcpyAsync(sb.p, c->ln_s.p, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(pb.p, c->ln_p.p, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(resb.p, c->ln_result.p, sizeof(int) * 2, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(stb.p, c->ln_stats.p, sizeof(long long) * 17, hipMemcpyDeviceToDevice, c->stream));
-    }
+    P.batch_alpha = alb.p;
+    P.batch_p0 = p0b.p;
+    HIP_TRY(fh_ln_launch(P, (int)G, c->stream));
     std::vector<int> res(2 * B);
     std::vector<long long> st(17 * B);
     HIP_TRY(hipMemcpyAsync(res.data(), resb.p, sizeof(int) * 2 * B, hipMemcpyDeviceToHost, c->stream));
@@ -790,9 +734,6 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
         HIP_TRY(hipMemcpyAsync(p + (size_t)order[k] * N, pb.p + (size_t)k * N, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (K && res[1] == LN_STATUS_CLUSTER)
-        return fail(FH_ERR_HIP, "the helper workgroups of the LogNormal cluster did not answer within 2 s (FRANK_AMD_LN_SWEEP_CLUSTERS=0 "
-                    "keeps every point of the sweep on one workgroup)");
     for (int k = 0; k < batch; ++k) {
         const int b = order[k];
         niter[b] = res[2 * k];

@@ -163,38 +163,6 @@ def test_lognormal_cluster_equals_single_workgroup(golden, monkeypatch):
         assert np.array_equal(out[cl][0], out["1"][0]) and np.array_equal(out[cl][1], out["1"][1])
 
 
-def test_lognormal_sweep_lead_point_on_a_cluster(golden, monkeypatch):
-    """fh_fit_lognormal_batched from N = 160 on (round 5): the first point in launch order -- the one most likely to run to
-    max_iter, which used to hold the whole launch -- runs as a cluster fit on a stream of its own beside the batched launch of the
-    others.  Against everything in the one launch (FRANK_AMD_LN_SWEEP_CLUSTERS=0): the same bits, iteration counts and Newton
-    statistics for all ten points (statistical_models.py:1088-1158, minimizer.py:187-284 per point)."""
-    import ctypes
-    from frank_amd import FrankFitter, _lib
-    src = golden("fit_N300_1e6.npz")
-    N, B = 300, 10
-    FF = FrankFitter(2.0, N, geom(), method="LogNormal", verbose=False, check_qbounds=False)
-    M, j = np.ascontiguousarray(src["M"]), np.ascontiguousarray(src["j"])
-    al = np.array([1.3, 1.05, 1.2, 1.5, 1.1, 1.3, 1.05, 1.4, 1.25, 1.15])
-    ws = np.array([1e-2, 1e-4, 1e-2, 1e-1, 1e-3, 1e-4, 1e-2, 1e-2, 1e-1, 1e-3])
-    p0 = np.full(B, 1e-35)
-
-    def run():
-        s_map, p = np.empty((B, N)), np.empty((B, N))
-        nit, st = (ctypes.c_int * B)(), (ctypes.c_int * B)()
-        stats = np.zeros(9 * B, dtype=np.int64)
-        _lib.check(_lib.lib.fh_fit_lognormal_batched(FF._DHT.context(), _lib.ptr(M), _lib.ptr(j), B, _lib.ptr(al), _lib.ptr(p0), _lib.ptr(ws), 1e-3, 8,
-                                                     float(np.exp(FF._s_scale)), _lib.ptr(s_map), _lib.ptr(p), nit, st,
-                                                     stats.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
-        return s_map, p, list(nit), list(st), stats
-    monkeypatch.setenv("FRANK_AMD_LN_SWEEP_CLUSTERS", "0")
-    ref = run()
-    monkeypatch.delenv("FRANK_AMD_LN_SWEEP_CLUSTERS")
-    new = run()
-    assert ref[2] == new[2] and ref[3] == new[3] and np.array_equal(ref[4], new[4])
-    assert np.array_equal(ref[0], new[0]) and np.array_equal(ref[1], new[1])
-    assert max(new[2]) == 9 and all(x == 0 for x in new[3])
-
-
 def test_lognormal_full_size_fp32_table():
     """BASELINE configs[2] as stated: N = 300, 1e7 visibilities handed over in single precision, method='LogNormal'
     (alpha = 1.3, w_smooth = 1e-2 as in the reference's LogNormal test, frank/tests.py:350).  No reference run exists at
