@@ -910,7 +910,7 @@ static int flush_pending_batch(fh_ctx *c) {
     P.out_host = c->slot_out_host;
     P.result_host = c->slot_result_host;
     P.cluster = b.cluster;
-    P.loaded = env_int("FRANK_AMD_FIT_LOADED", 0);  // (development: what launch_loop takes for the loops resident beside this launch's)
+    // (P.loaded stays 0: the ~150 loops a pipeline keeps resident are below the load at which the paired rows of the inverse pay)
     if (b.cluster > 1) {  // the fits of consecutive cluster launches go round the XCDs
         P.cluster_xcd0 = c->next_xcd & 7;
         c->next_xcd = (c->next_xcd + b.n) & 7;
@@ -972,12 +972,11 @@ static int fit_submit_impl(fh_ctx *c, double alpha, double p0, double wsmooth, d
         }
         c->n_launch_streams = fit_launch_streams();
         for (int i = 0; i < c->n_launch_streams; ++i) {
-            // FRANK_AMD_FIT_RESERVE_CUS = B (development): the fit loops keep off the first B compute units, the binning stream
-            // stays free to use every unit -- a floor under the binning pass of a deep pipeline instead of a partition
-            const int reserve = env_int("FRANK_AMD_FIT_RESERVE_CUS", 0);
-            if (c->bin_cus > 0 || (reserve >= 8 && reserve <= c->num_cu - 8)) {  // fh_ctx_set_cu_partition: the fit loops keep to the compute units the binning pass leaves alone
+            // (compute units reserved for the binning stream -- the fit loops keeping off the first B units while binning may use
+            //  all -- were measured in round 5 and taken out: flat to B = 64, worse beyond; the hard partition below is worse still)
+            if (c->bin_cus > 0) {  // fh_ctx_set_cu_partition: the fit loops keep to the compute units the binning pass leaves alone
                 uint32_t mask[8];
-                cu_mask(c->bin_cus > 0 ? c->bin_cus : reserve, c->num_cu, mask);
+                cu_mask(c->bin_cus, c->num_cu, mask);
                 HIP_TRY(hipExtStreamCreateWithCUMask(&c->launch_streams[i], 8, mask));
             } else {
                 HIP_TRY(hipStreamCreateWithFlags(&c->launch_streams[i], hipStreamNonBlocking));
