@@ -2107,6 +2107,277 @@ __device__ __forceinline__ bool solve_posterior_ll(const FitLoopParams &P, const
     return true;
 }
 
+// ---- the posterior solve with the matrix RESIDENT IN REGISTERS (round 5; fit_loop_rr.hip: 512 threads, CLM = 6) -------------------
+// With the device full a pass of the one-workgroup solve is bound by the bytes it moves beyond the L2 (3.5-5 MB per pass at N = 300,
+// profiles/r05_pmc_fit_loop_256_resident.json), and every form so far kept the working matrix in memory: the lower triangle of
+// N = 300 is 190 tiles of 2 KB = 380 KB, more than twice the LDS.  But a CU has 512 KB of vector registers.  Eight waves (two
+// per SIMD, 256 registers each) hold 24 tiles apiece: wave w owns whole block ROWS -- (18 - w, 4 + w) for w < 7, (11, 3, 2, 1, 0)
+// for w = 7: 24 tiles each, 22 for the last -- and a tile never leaves its registers from the load of A to the end of the pass:
+//   * slot (I, J) holds T_IJ^T while the factorisation runs, L_IJ^T from step J - 1 on (the accumulator layout of a matrix is the
+//     B fragment of itself and the A fragment of its transpose: D = X T^T takes the slot as it stands, the inverse takes L_IK from
+//     it as it stands), then the running sum S_IJ = sum_K L_IK W_KJ of the inverse, then W_IJ;
+//   * what the OTHER waves need travels through LDS in the packed tile format: panel k (the tiles L_Ik^T, I > k: both operands of the
+//     trailing update) and row K of W (the B operands of the inverse).  At step k the panel occupies the positions I > k of a
+//     buffer of nb tiles and row k - 1 of W its positions J < k: two buffers of nb tiles (76 KB) carry both, double buffered;
+//   * the inverse runs IN PLACE, one step behind the factorisation: at step k every wave adds L_{I,k-1} W_{k-1,J} to its sums
+//     (rows I >= k, visited with J descending: slot (I, k - 1) still holds the L tile when the row is entered and becomes the sum
+//     S_{I,k-1} = L_{I,k-1} W_{k-1,k-1}; the sums left of it take their next product); row k is then complete and its owner
+//     multiplies by -X_kk and publishes it for step k + 1.  The sums run over K ascending into one accumulator, as inverse_tile's.
+// Per pass the workgroup reads A (380 KB, from the L2 or beyond) and nothing else: no C, no W, no cs buffer.
+// One barrier per step; the owner of row k + 1 updates, factors and inverts tile (k + 1, k + 1) FIRST (the chain every form of this
+// kernel waits for), the others meet its result behind their own products.  The same products, the same operands, the same order
+// per tile as solve_posterior: the same bits.  N <= 303 (nb <= 19).
+#ifdef FIT_LOOP_RR
+constexpr int kRRSlots = 24, kRRMaxNB = 19;
+// slot s of wave w: (I << 8) | J, or -1 (no tile); the rows of a wave follow each other, J descending within a row
+__device__ __forceinline__ int rr_slot_ij(int w, int s, int nb) {
+    int I, J;
+    if (w < 7) {
+        const int Ra = 18 - w, Rb = 4 + w;
+        if (s <= Ra) {
+            I = Ra;
+            J = Ra - s;
+        } else {
+            I = Rb;
+            J = Rb - (s - Ra - 1);
+        }
+    } else {
+        if (s < 12) I = 11, J = 11 - s;
+        else if (s < 16) I = 3, J = 15 - s;
+        else if (s < 19) I = 2, J = 18 - s;
+        else if (s < 21) I = 1, J = 20 - s;
+        else if (s == 21) I = 0, J = 0;
+        else return -1;
+    }
+    return I < nb ? ((I << 8) | J) : -1;
+}
+#define RR_KEEP_BRANCH asm volatile("" ::: "memory")  // (a branch, not 8 selects per slot: the condition is wave-uniform)
+// T += A B for one k-step quadruple, IN PLACE: the accumulator is tied to its own registers (the builtin leaves the destination to
+// the register allocator, which under 24 live tiles answered with copies of whole tiles behind s_nop 14).  The hazard recogniser
+// does not look into inline asm: a VALU write of an operand needs a wait state before the matrix instruction reads it (s_nop 1 in
+// front), and whoever reads T with anything but the next in-place product waits 19 states first (RR_MFMA_SETTLE).
+__device__ __forceinline__ void rr_mfma4(v4f64 &T, const v4f64 &a, const v4f64 &b) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0"
+                 : "+v"(T)
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+}
+#define RR_MFMA_SETTLE asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")
+
+__device__ __forceinline__ bool solve_posterior_rr(const FitLoopParams &P, const Smem &S) {
+    const int N = P.N, NP = P.NP, nb = P.NP / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 15, rg = lane >> 4;
+    for (int i = tid; i < NP; i += KT) S.y[i] = i < N ? 1.0 / S.p[i] : 1.0;  // row N (b) and padding: 1
+    if (tid == 0) {
+        S.flag[0] = 0;  // not positive definite
+        S.flag[3] = 0;  // index of the last diagonal tile whose inverse is in LDS
+    }
+    __syncthreads();
+    const double *pinv = S.y;
+    const int aug_tile = N / 16, aug_c = N - 16 * aug_tile;
+    auto rows_valid = [&](int I) { return min(16, max(0, N - 16 * I)); };
+    const gdouble *A_u = as_global(uniform_ptr(P.A));
+    const int tile_doubles = 256;
+
+    int ij[kRRSlots];
+    v4f64 T[kRRSlots];
+#pragma unroll
+    for (int s = 0; s < kRRSlots; ++s) ij[s] = __builtin_amdgcn_readfirstlane(rr_slot_ij(wave, s, nb));
+    // (1) the tiles from A: T_IJ^T is tile (J, I) of the symmetric A; 1/p on the diagonal before anything else touches the tile
+#pragma unroll
+    for (int s = 0; s < kRRSlots; ++s) {
+        T[s] = v4f64{0.0, 0.0, 0.0, 0.0};
+        if (ij[s] >= 0) {
+            const int I = ij[s] >> 8, J = ij[s] & 255;
+            T[s] = ld_pk(A_u, (unsigned)((J * nb + I) * 2048), lane);
+            if (I == J) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rg + 4 * r == cl) T[s][r] += pinv[16 * I + cl];
+            }
+        }
+    }
+    // m = -(row N of W): element (N - 16 aug_tile, c) of the tiles of the last block row
+    auto put_m = [&](const v4f64 &w, int J) {
+        const int rr = N - 16 * aug_tile, r = rr >> 2;
+        const double v = r == 0 ? w[0] : (r == 1 ? w[1] : (r == 2 ? w[2] : w[3]));
+        if (rg == (rr & 3)) S.m[16 * J + cl] = -v;
+    };
+    // The factor-and-invert chain needs ~50 registers of its own: the wave that runs it parks eight of its tiles in LDS meanwhile
+    // (one chain at a time: one area of 16 KB) instead of leaving the choice, and scratch memory, to the register allocator.
+    constexpr int kPark0 = 14, kParkN = 8;  // slots 14 .. 21
+    double *const park = S.hand;
+    // tile (0, 0): wave 7, slot 21
+    if (wave == 7) {
+        v4f64 t0 = T[21], x0;
+#pragma unroll
+        for (int s = 0; s < kParkN; ++s) lds_tile_store(park + s * 256, lane, T[kPark0 + s]);
+        const bool ok = factor_invert_tile(t0, x0, S.dli, lane, aug_tile == 0 ? aug_c : -1);
+        if (!ok && lane == 0) S.flag[0] = 1;
+        store_col_ssq(x0, S.tr2, rows_valid(0), lane);
+#pragma unroll
+        for (int s = 0; s < kParkN; ++s) T[kPark0 + s] = lds_tile(park + s * 256, lane);
+        T[21] = x0;
+    }
+    __syncthreads();
+    // column 0: L_I0^T = X_00 T_I0^T into the slot and into panel 0 (buffer 0, position I)
+    {
+        Frag fx;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[cl * PS + 4 * q + rg];
+#pragma unroll
+        for (int s = 0; s < kRRSlots; ++s) {
+            if (ij[s] > 255 && (ij[s] & 255) == 0) {  // I > 0, J = 0
+                RR_KEEP_BRANCH;
+                Frag ft;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ft.v[q] = T[s][q];
+                const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
+                T[s] = mfma4(fx, ft, z4, false);
+                lds_tile_store(S.pan + (size_t)(ij[s] >> 8) * tile_doubles, lane, T[s]);
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int k = 0; k < nb; ++k) {
+        if (S.flag[0]) return false;
+        const int m = nb - k - 1;
+        double *const bufk = S.pan + (size_t)(k & 1) * nb * tile_doubles;        // panel k (positions > k), row k - 1 of W (< k)
+        double *const bufn = S.pan + (size_t)((k + 1) & 1) * nb * tile_doubles;  // panel k + 1, row k of W: written at this step
+        const double *const dli_k = S.dli + (k & 1) * 16 * PS;
+        double *const dli_n = S.dli + ((k + 1) & 1) * 16 * PS;
+        // ---- the chain: tile (k + 1, k + 1) updated, factored and inverted by the owner of row k + 1, before anything else ----
+        if (m > 0) {
+            const int key = ((k + 1) << 8) | (k + 1);
+            bool mine = false;
+            v4f64 a = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < kRRSlots; ++s) {
+                if (ij[s] == key) {
+                    RR_KEEP_BRANCH;
+                    a = T[s];
+                    mine = true;
+                }
+            }
+            if (mine) {
+#pragma unroll
+                for (int s = 0; s < kParkN; ++s) lds_tile_store(park + s * 256, lane, T[kPark0 + s]);
+                const v4f64 pa = lds_tile(bufk + (size_t)(k + 1) * tile_doubles, lane);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[q], pa[q], a, 0, 0, 0);
+                v4f64 xi;
+                const bool ok = factor_invert_tile(a, xi, dli_n, lane, aug_tile == k + 1 ? aug_c : -1);
+                if (!ok && lane == 0) S.flag[0] = 1;
+                store_col_ssq(xi, S.tr2 + 16 * (k + 1), rows_valid(k + 1), lane);
+#pragma unroll
+                for (int s = 0; s < kParkN; ++s) T[kPark0 + s] = lds_tile(park + s * 256, lane);
+#pragma unroll
+                for (int s = 0; s < kRRSlots; ++s) {
+                    if (ij[s] == key) {
+                        RR_KEEP_BRANCH;
+                        T[s] = xi;
+                    }
+                }
+                __hip_atomic_store(&S.flag[3], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        // ---- one pass over the slots: the trailing update with panel k; step K = k - 1 of the inverse; row k of W finished ----
+        // (one register set for the operand a row shares: -L_Ik^T of the trailing update, then L_{I,k-1}^T of the inverse)
+        int curI = -1;
+        v4f64 ro = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < kRRSlots; ++s) {
+            const int I = ij[s] >> 8, J = ij[s] & 255;
+            if (J > k && I > k + 1) {  // T_IJ^T -= L_Jk L_Ik^T  (the sign on the row's operand: once per row)
+                RR_KEEP_BRANCH;
+                if (I != curI) {
+                    const v4f64 t = lds_tile(bufk + (size_t)I * tile_doubles, lane);
+                    ro = -t;
+                    curI = I;
+                }
+                const v4f64 pa = lds_tile(bufk + (size_t)J * tile_doubles, lane);
+                rr_mfma4(T[s], pa, ro);
+            }
+            if (I >= k && J < k) {  // S_IJ += L_{I,k-1} W_{k-1,J}
+                RR_KEEP_BRANCH;
+                const v4f64 bw = lds_tile(bufk + (size_t)J * tile_doubles, lane);
+                if (J == k - 1) {
+                    RR_KEEP_BRANCH;
+                    ro = T[s];
+                    asm volatile("" : "+v"(ro));  // (a copy: the slot starts its sum from zero)
+                    curI = -1;
+                    T[s] = v4f64{0.0, 0.0, 0.0, 0.0};
+                }
+                rr_mfma4(T[s], ro, bw);
+                if (I == k) {  // the sum is complete: W_kJ = -X_kk S_kJ
+                    RR_KEEP_BRANCH;
+                    RR_MFMA_SETTLE;
+                    Frag fs, fw;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) fs.v[q] = T[s][q];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) fw.v[q] = dli_k[cl * PS + 4 * q + rg];
+                    v4f64 w = {0.0, 0.0, 0.0, 0.0};
+                    w = mfma4(fw, fs, w, true);
+                    T[s] = w;
+                    lds_tile_store(bufn + (size_t)J * tile_doubles, lane, w);
+                    double ssq = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * k + rg + 4 * r < N) ssq = fma(w[r], w[r], ssq);
+                    ssq += __shfl_xor(ssq, 16);
+                    ssq += __shfl_xor(ssq, 32);
+                    if (rg == 0) S.tr2[16 * J + cl] += ssq;  // (column J's sum over the rows in ascending order: cs_JJ came first)
+                    if (k == aug_tile) put_m(w, J);
+                }
+            }
+            if (I == k && J == k) {  // W_kk = X_kk: the last tile of row k of W
+                RR_KEEP_BRANCH;
+                lds_tile_store(bufn + (size_t)k * tile_doubles, lane, T[s]);
+                if (k == aug_tile) put_m(T[s], k);
+            }
+        }
+        RR_MFMA_SETTLE;  // (the column tiles below read their slots as operands)
+        // ---- column k + 1: L_{I,k+1}^T = X_{k+1,k+1} T_{I,k+1}^T into the slot and into panel k + 1 ----
+        if (m > 1) {
+            int spins = 0;
+            while (__hip_atomic_load(&S.flag[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) {  // (a stuck flag must not hang the device)
+                    if (lane == 0) S.flag[0] = 1;
+                    break;
+                }
+            }
+            Frag fx;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fx.v[q] = dli_n[cl * PS + 4 * q + rg];
+#pragma unroll
+            for (int s = 0; s < kRRSlots; ++s) {
+                const int I = ij[s] >> 8, J = ij[s] & 255;
+                if (J == k + 1 && I > k + 1) {
+                    RR_KEEP_BRANCH;
+                    Frag ft;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ft.v[q] = T[s][q];
+                    const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
+                    T[s] = mfma4(fx, ft, z4, false);
+                    lds_tile_store(bufn + (size_t)I * tile_doubles, lane, T[s]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (S.flag[0]) return false;
+    return true;
+}
+#undef RR_KEEP_BRANCH
+#endif  // FIT_LOOP_RR
+
 // ---- (T + I) tau = rhs by a wave scan: band_scan.h ----
 template <int WIDE> constexpr int scan_rows() { return WIDE == 2 ? 16 : (WIDE ? 10 : 6); }  // rows per lane: 64 * 6 = 384, 64 * 10 = 640, 64 * 16 = 1024 >= NP
 using bandscan::scan_solve;
@@ -2119,7 +2390,9 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     constexpr bool CL = CLM == 1 || CLM == 2;
     constexpr bool LL = CLM == 3;  // left-looking solve on one workgroup (solve_posterior_ll), N <= 335
     constexpr bool DF = CLM == 4 || CLM == 5;  // deferred trailing update on one workgroup (solve_posterior<0, 4 | 5>), N <= 319
+    constexpr bool RR = CLM == 6;  // the matrix resident in registers (solve_posterior_rr: 512 threads, fit_loop_rr.hip), N <= 303
     static_assert(!(DF && WIDE), "the deferred update keeps three panels in LDS");
+    static_assert(!(RR && WIDE), "24 tiles per wave: N <= 303");
     static_assert(!(LL && WIDE), "the left-looking solve keeps two rows of L in LDS: N <= 335");
     // cluster mode: workgroup b sits on XCD b & 7 (ids go round the XCDs) as the (b >> 3)-th of the launch there; the members of
     // a fit are `cluster` consecutive ones of ONE XCD: fit (i / cluster) * 8 + x of the launch, member i % cluster
@@ -2216,7 +2489,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     }
     Smem S;
     S.pan = smem;
-    S.dli = S.pan + (DF ? 3 : npanels<WIDE>()) * NP * PS;
+    S.dli = S.pan + (RR ? (size_t)2 * (NP / 16) * 256 : (size_t)(DF ? 3 : npanels<WIDE>()) * NP * PS);  // (RR: two buffers of nb packed tiles)
     // (XWIDE: the vectors live behind the band factors and scan tables in global memory -- the W buffer, or the cs buffer in
     //  cluster mode --, only the panel, the inverse of the diagonal tile and the flags in LDS)
     double *const gscratch = CL ? P.cs : P.W;
@@ -2252,8 +2525,8 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         S.scanQ = S.band + 6 * NP;  // [2 directions][6 levels][4 entries][64 lanes]
         S.rec = reinterpret_cast<uint4 *>(S.scanQ + 2 * 6 * 4 * 64);  // (16-byte aligned: every region before it is an even number of doubles)
     }
-    S.flag = reinterpret_cast<int *>(S.rec + (DF ? 256 : max_tiles<WIDE>()));  // [0] not positive definite, [1] column counter of the inverse row
-    S.hand = (!WIDE && !DF && NP <= kHandMaxNP) ? reinterpret_cast<double *>(S.flag + 8) : nullptr;  // (32 bytes of flags; 16-byte aligned)
+    S.flag = reinterpret_cast<int *>(S.rec + (RR ? 0 : (DF ? 256 : max_tiles<WIDE>())));  // [0] not positive definite, [1] column counter of the inverse row
+    S.hand = RR ? reinterpret_cast<double *>(S.flag + 8 + 48) : (!WIDE && !DF && NP <= kHandMaxNP) ? reinterpret_cast<double *>(S.flag + 8) : nullptr;  // (32 bytes of flags; 16-byte aligned)
     S.dcnt = S.flag + 8;  // (deferred mode: 2 x 24 ints behind the flags)
     if constexpr (DF) {
         // Deferred mode: at a step of parity par the tiles (i, j) relative to block (k + 1, k + 1), 1 <= j <= i, that are touched
@@ -2277,7 +2550,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
             }
         }
     }
-    for (int e = tid; e < ((LL || DF) ? 0 : max_tiles<WIDE>()); e += KT) {  // tile e = (i - 1) i / 2 + (j - 1), 1 <= j <= i
+    for (int e = tid; e < ((LL || DF || RR) ? 0 : max_tiles<WIDE>()); e += KT) {  // tile e = (i - 1) i / 2 + (j - 1), 1 <= j <= i
         int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while ((i + 1) * (i + 2) / 2 <= e) ++i;
         while (i * (i + 1) / 2 > e) --i;
@@ -2367,7 +2640,14 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
             SL.band = smem + (S.red + NP - smem);  // the LDS region behind the vectors: the diagonal tiles
             ++nsolve;
             solved = solve_posterior_ll(P, SL);
-        } else solved = solve_posterior<WIDE, CLM>(P, S, ++nsolve);
+        }
+#ifdef FIT_LOOP_RR
+        else if constexpr (RR) {
+            ++nsolve;
+            solved = solve_posterior_rr(P, S);
+        }
+#endif
+        else solved = solve_posterior<WIDE, CLM>(P, S, ++nsolve);
         if (!solved) {
             status = (CL && S.flag[0] == 2) ? FIT_STATUS_CLUSTER : FIT_STATUS_NOT_SPD;
             break;
@@ -2634,6 +2914,21 @@ __global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int 
 
 }  // namespace
 
+#ifdef FIT_LOOP_RR
+// the register-resident instantiation only (fit_loop_rr.hip compiles this file with 512 threads per workgroup)
+size_t fh_k2_loop_rr_smem_bytes(int NP) {
+    // two buffers of nb packed tiles, L_kk^-1 (two), the vectors, the band factors and scan tables, the flags
+    return sizeof(double) * (size_t)(2 * (NP / 16) * 256 + 2 * 16 * PS + 8 * NP + 6 * NP + 2 * 6 * 4 * 64) + 32 + 4 * 48 + 8 * 2048;  // (+ the park area)
+}
+hipError_t fh_k2_launch_loop_rr(const FitLoopParams &P, int blocks, hipStream_t s) {
+    if (P.NP / 16 > kRRMaxNB || P.cluster > 1) return hipErrorInvalidValue;
+    const size_t smem = fh_k2_loop_rr_smem_bytes(P.NP);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_kernel<0, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((fit_loop_kernel<0, 6>), dim3(blocks), dim3(KT), smem, s, P);
+    return hipGetLastError();
+}
+#else
 static bool loop_is_wide(int NP) { return NP >= kWideMinNP; }
 static bool loop_is_xwide(int NP) { return NP >= kXWideMinNP; }
 int fh_k2_loop_max_np() { return kXWideMaxNP; }
@@ -2641,7 +2936,8 @@ int fh_k2_loop_max_np() { return kXWideMaxNP; }
 static size_t loop_smem_bytes_deferred(int NP) {
     return sizeof(double) * (size_t)(3 * NP * PS + 3 * 16 * PS + 8 * NP) + 16 * 256 + 32 + 4 * 48;
 }
-constexpr int kDeferMaxNP = 320;  // (161 888 of the 163 840 bytes at NP = 320)
+constexpr int kDeferMaxNP = 320;
+constexpr int kRegResidentMaxNP = 304;  // 19 block rows: 24 tiles per wave  // (161 888 of the 163 840 bytes at NP = 320)
 size_t fh_k2_loop_smem_bytes(int NP) {
     if (loop_is_xwide(NP)) return sizeof(double) * (size_t)(NP * PS + 2 * 16 * PS) + 64;  // the panel, L_kk^-1 (two), the flags
     const bool wide = loop_is_wide(NP);
@@ -2719,6 +3015,10 @@ static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s)
     // The deferred trailing update (round 5; solve_posterior, CLM = 4): the same bits with half the loads and stores of the
     // trailing update -- what a pass moves beyond the L2 is what bounds a loaded device.  FRANK_AMD_K2_DEFER=0 keeps the
     // kernel of rounds 2-4 (read at every launch: the tests compare the two inside one process).
+    // The matrix resident in registers (round 5; solve_posterior_rr, fit_loop_rr.hip): the same bits, and per pass only A is read.
+    // FRANK_AMD_K2_RR=1 selects it (not the default yet: 235 us per pass against 135 alone, 242 against 184 with 256 loops resident).
+    const char *re = getenv("FRANK_AMD_K2_RR");
+    if (P.NP >= 64 && P.NP <= kRegResidentMaxNP && re && atoi(re) != 0) return fh_k2_launch_loop_rr(P, blocks, s);
     const char *de = getenv("FRANK_AMD_K2_DEFER");
     // (from NP = 64 on: the band factors and scan tables of this form, 6 NP + 3 072 doubles, live in the fit's W buffer of NP^2
     //  doubles -- at NP = 48 they overran it by a third, which the suite only noticed as a memory fault when a small LogNormal
@@ -2747,3 +3047,4 @@ hipError_t fh_k2_launch_symmetrize(const double *Araw, const double *bq, int N, 
     hipLaunchKernelGGL(symmetrize_pad_kernel, dim3(128), dim3(256), 0, s, Araw, bq, N, NP, A);
     return hipGetLastError();
 }
+#endif  // FIT_LOOP_RR

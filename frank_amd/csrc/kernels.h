@@ -294,6 +294,8 @@ constexpr size_t fh_k2_cs_doubles(int NP) {
 
 size_t fh_k2_loop_smem_bytes(int NP);
 int fh_k2_loop_max_np();  // largest padded size NP the persistent fit loop covers (640: N <= 639)
+hipError_t fh_k2_launch_loop_rr(const FitLoopParams &P, int blocks, hipStream_t s);  // fit_loop_rr.hip: the matrix in registers (NP <= 304)
+size_t fh_k2_loop_rr_smem_bytes(int NP);
 hipError_t fh_k2_launch_loop(const FitLoopParams &P, hipStream_t s);        // P.cluster > 1: one fit on a cluster
 hipError_t fh_k2_launch_loop_slots(const FitLoopParams &P, int nslots, hipStream_t s);  // P.cluster > 1: every fit on one
 size_t fh_k2_exchange_doubles(int NP);  // doubles of a fit's WdT buffer (exchange area of the cluster mode)
