@@ -2128,44 +2128,102 @@ __device__ __forceinline__ bool solve_posterior_ll(const FitLoopParams &P, const
 // kernel waits for), the others meet its result behind their own products.  The same products, the same operands, the same order
 // per tile as solve_posterior: the same bits.  N <= 303 (nb <= 19).
 #ifdef FIT_LOOP_RR
-constexpr int kRRSlots = 24, kRRMaxNB = 19;
-// slot s of wave w: (I << 8) | J, or -1 (no tile); the rows of a wave follow each other, J descending within a row
-__device__ __forceinline__ int rr_slot_ij(int w, int s, int nb) {
-    int I, J;
-    if (w < 7) {
-        const int Ra = 18 - w, Rb = 4 + w;
-        if (s <= Ra) {
-            I = Ra;
-            J = Ra - s;
-        } else {
-            I = Rb;
-            J = Rb - (s - Ra - 1);
+constexpr int kRRSlots = 25, kRRMaxNB = 19, kRRRows = 6, kRRSpec = 7;
+// Who holds what.  Wave 7, the SPECIALIST, runs the factor-and-invert chain of every step and nothing else -- the chain is what a
+// step waits for, and a wave that had its share of the step's products to do as well made the step chain + share (5 + 4 us of
+// 10).  It holds no tiles: the 19 DIAGONAL tiles live in LDS (38 KB; a diagonal tile takes one product per step, formed by the
+// worker that holds its row, whose operands are the row's shared operand it has in registers anyway).  The WORKERS,
+// waves 0 .. 6, hold the tiles left of the diagonal by whole block rows, J = I - 1 .. 0 in consecutive slots: (18, 7), (17, 8),
+// (16, 9), (15, 10), (14, 11), (13, 12) -- 25 tiles each -- and the six short rows 6 .. 1 (21 tiles) on wave 3, the wave that
+// shares the specialist's SIMD (double-precision vector and matrix instructions share a SIMD's units: the chain runs at
+// full speed once that neighbour has nothing left to do).
+__device__ __forceinline__ void rr_rows(int w, int nb, int (&rI)[kRRRows], int (&rS)[kRRRows]) {
+#pragma unroll
+    for (int r = 0; r < kRRRows; ++r) rI[r] = -100, rS[r] = 0;
+    if (w == 3) {
+        int st = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            rI[r] = 6 - r;
+            rS[r] = st;
+            st += 6 - r;
         }
-    } else {
-        if (s < 12) I = 11, J = 11 - s;
-        else if (s < 16) I = 3, J = 15 - s;
-        else if (s < 19) I = 2, J = 18 - s;
-        else if (s < 21) I = 1, J = 20 - s;
-        else if (s == 21) I = 0, J = 0;
-        else return -1;
+    } else if (w < kRRSpec) {
+        const int a = w < 3 ? 18 - w : 19 - w;  // 18, 17, 16, -, 15, 14, 13
+        rI[0] = a, rS[0] = 0;
+        rI[1] = 25 - a, rS[1] = a;
     }
-    return I < nb ? ((I << 8) | J) : -1;
+#pragma unroll
+    for (int r = 0; r < kRRRows; ++r)
+        if (rI[r] >= nb) rI[r] = -100;
+}
+// slot s of wave w: (I << 8) | J, or 0xffff (no tile)
+__device__ __forceinline__ unsigned rr_slot_ij(int w, int s, int nb) {
+    if (w == kRRSpec) return 0xffffu;
+    int rI[kRRRows], rS[kRRRows];
+    rr_rows(w, nb, rI, rS);
+    unsigned e = 0xffffu;
+#pragma unroll
+    for (int r = 0; r < kRRRows; ++r)
+        if (rI[r] > 0 && s >= rS[r] && s < rS[r] + rI[r]) e = (unsigned)((rI[r] << 8) | (rI[r] - 1 - (s - rS[r])));
+    return e;
 }
 #define RR_KEEP_BRANCH asm volatile("" ::: "memory")  // (a branch, not 8 selects per slot: the condition is wave-uniform)
 // T += A B for one k-step quadruple, IN PLACE: the accumulator is tied to its own registers (the builtin leaves the destination to
 // the register allocator, which under 24 live tiles answered with copies of whole tiles behind s_nop 14).  The hazard recogniser
 // does not look into inline asm: a VALU write of an operand needs a wait state before the matrix instruction reads it (s_nop 1 in
-// front), and whoever reads T with anything but the next in-place product waits 19 states first (RR_MFMA_SETTLE).
-__device__ __forceinline__ void rr_mfma4(v4f64 &T, const v4f64 &a, const v4f64 &b) {
+// front), and a read of T by anything but the next in-place product must come 18 wait states after the last product -- also
+// the copies and spills the register allocator may place directly behind a block, which is why the block itself ends on them
+// (a first version waited once per step, before its own reads: its results depended on where the allocator put its copies).
+// (the operand a row shares travels as four separate 64-bit pairs: a whole-tile operand was copied in front of every product)
+__device__ __forceinline__ void rr_mfma4_b(v4f64 &T, const v4f64 &a, double b0, double b1, double b2, double b3) {
     asm volatile("s_nop 1\n\t"
                  "v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\t"
                  "v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\t"
                  "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\t"
-                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0"
+                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n\t"
+                 "s_nop 15\n\ts_nop 2"  /* the results settle before anything the compiler may place behind the block reads them */
                  : "+v"(T)
-                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+__device__ __forceinline__ void rr_mfma4_a(v4f64 &T, double a0, double a1, double a2, double a3, const v4f64 &b) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n\t"
+                 "s_nop 15\n\ts_nop 2"  /* the results settle before anything the compiler may place behind the block reads them */
+                 : "+v"(T)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
 }
 #define RR_MFMA_SETTLE asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")
+// The operand tile of a slot, read from LDS ONE SLOT AHEAD by hand (two ds_read_b128, issued and waited for explicitly: the wait is
+// "all but the two reads issued last", which the compiler's own counting cannot express across the branches of the slots).  The
+// reads are issued at every slot, used or not -- no register of the double buffer is ever defined under a branch.
+__device__ __forceinline__ void rr_lds_issue(v2f64 &lo, v2f64 &hi, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory");
+}
+#define RR_LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+__device__ __forceinline__ void rr_mfma4_bp(v4f64 &T, const v2f64 &alo, const v2f64 &ahi, double b0, double b1, double b2, double b3) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n\t"
+                 "s_nop 15\n\ts_nop 2"  /* the results settle before anything the compiler may place behind the block reads them */
+                 : "+v"(T)
+                 : "v"(alo[0]), "v"(alo[1]), "v"(ahi[0]), "v"(ahi[1]), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+__device__ __forceinline__ void rr_mfma4_ap(v4f64 &T, double a0, double a1, double a2, double a3, const v2f64 &blo, const v2f64 &bhi) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n\t"
+                 "s_nop 15\n\ts_nop 2"  /* the results settle before anything the compiler may place behind the block reads them */
+                 : "+v"(T)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(blo[0]), "v"(blo[1]), "v"(bhi[0]), "v"(bhi[1]));
+}
 
 __device__ __forceinline__ bool solve_posterior_rr(const FitLoopParams &P, const Smem &S) {
     const int N = P.N, NP = P.NP, nb = P.NP / 16;
@@ -2175,6 +2233,9 @@ __device__ __forceinline__ bool solve_posterior_rr(const FitLoopParams &P, const
     if (tid == 0) {
         S.flag[0] = 0;  // not positive definite
         S.flag[3] = 0;  // index of the last diagonal tile whose inverse is in LDS
+        S.flag[4] = 0;  // rows of the inverse whose raw sums are in LDS
+        S.flag[7] = 0;
+        S.flag[5] = S.flag[6] = 0;  // work items of a step that any wave may take (even / odd steps)
     }
     __syncthreads();
     const double *pinv = S.y;
@@ -2182,17 +2243,39 @@ __device__ __forceinline__ bool solve_posterior_rr(const FitLoopParams &P, const
     auto rows_valid = [&](int I) { return min(16, max(0, N - 16 * I)); };
     const gdouble *A_u = as_global(uniform_ptr(P.A));
     const int tile_doubles = 256;
+    const bool spec = wave == kRRSpec;
 
-    int ij[kRRSlots];
-    v4f64 T[kRRSlots];
+    // the slots' (I, J), two to a scalar register (16 bits each), and the rows of this wave
+    unsigned ijp[(kRRSlots + 1) / 2];
 #pragma unroll
-    for (int s = 0; s < kRRSlots; ++s) ij[s] = __builtin_amdgcn_readfirstlane(rr_slot_ij(wave, s, nb));
+    for (int h = 0; h < (kRRSlots + 1) / 2; ++h)
+        ijp[h] = __builtin_amdgcn_readfirstlane(rr_slot_ij(wave, 2 * h, nb) | ((2 * h + 1 < kRRSlots ? rr_slot_ij(wave, 2 * h + 1, nb) : 0xffffu) << 16));
+#define RR_E(s) ((ijp[(s) >> 1] >> (16 * ((s) & 1))) & 0xffffu)
+    // (inside the step loop the packed words go through an opaque move first: hoisted out of the loop, the 25 operand offsets and the
+    //  25 row indices were 50 scalar registers, spilled to vector lanes and read back with a v_readlane per use -- and with two
+    //  waves on a SIMD a VECTOR instruction issued while the other wave's matrix instructions run costs ~65 cycles
+    //  (tools/microbench/tile_step_bench.hip), a scalar one nothing)
+    auto slot_e = [&](int s) __attribute__((always_inline)) {
+        unsigned w = ijp[s >> 1];
+        asm volatile("" : "+s"(w));
+        return (w >> (16 * (s & 1))) & 0xffffu;
+    };
+    int rI[kRRRows], rS[kRRRows];
+    rr_rows(wave, nb, rI, rS);
+#pragma unroll
+    for (int r = 0; r < kRRRows; ++r) {
+        rI[r] = __builtin_amdgcn_readfirstlane(rI[r]);
+        rS[r] = __builtin_amdgcn_readfirstlane(rS[r]);
+    }
+
+    v4f64 T[kRRSlots];
     // (1) the tiles from A: T_IJ^T is tile (J, I) of the symmetric A; 1/p on the diagonal before anything else touches the tile
 #pragma unroll
     for (int s = 0; s < kRRSlots; ++s) {
         T[s] = v4f64{0.0, 0.0, 0.0, 0.0};
-        if (ij[s] >= 0) {
-            const int I = ij[s] >> 8, J = ij[s] & 255;
+        const unsigned e = RR_E(s);
+        if (e != 0xffffu) {
+            const int I = e >> 8, J = e & 255;
             T[s] = ld_pk(A_u, (unsigned)((J * nb + I) * 2048), lane);
             if (I == J) {
 #pragma unroll
@@ -2207,38 +2290,48 @@ __device__ __forceinline__ bool solve_posterior_rr(const FitLoopParams &P, const
         const double v = r == 0 ? w[0] : (r == 1 ? w[1] : (r == 2 ? w[2] : w[3]));
         if (rg == (rr & 3)) S.m[16 * J + cl] = -v;
     };
-    // The factor-and-invert chain needs ~50 registers of its own: the wave that runs it parks eight of its tiles in LDS meanwhile
-    // (one chain at a time: one area of 16 KB) instead of leaving the choice, and scratch memory, to the register allocator.
-    constexpr int kPark0 = 14, kParkN = 8;  // slots 14 .. 21
-    double *const park = S.hand;
-    // tile (0, 0): wave 7, slot 21
-    if (wave == 7) {
-        v4f64 t0 = T[21], x0;
+    double *const diag = S.hand;  // the diagonal tiles (packed, nb x 2 KB): T_II^T, then X_II = W_II from step I - 1 on
+    auto diag_from_A = [&](int I) {
+        v4f64 t = ld_pk(A_u, (unsigned)((I * nb + I) * 2048), lane);
 #pragma unroll
-        for (int s = 0; s < kParkN; ++s) lds_tile_store(park + s * 256, lane, T[kPark0 + s]);
+        for (int r = 0; r < 4; ++r)
+            if (rg + 4 * r == cl) t[r] += pinv[16 * I + cl];
+        return t;
+    };
+    // the diagonal tiles from A into LDS: every worker those of its rows
+    if (!spec) {
+#pragma unroll
+        for (int r = 0; r < kRRRows; ++r)
+            if (rI[r] > 0) lds_tile_store(diag + (size_t)rI[r] * tile_doubles, lane, diag_from_A(rI[r]));
+    }
+    // tile (0, 0)
+    if (spec) {
+        v4f64 t0 = diag_from_A(0), x0;
         const bool ok = factor_invert_tile(t0, x0, S.dli, lane, aug_tile == 0 ? aug_c : -1);
         if (!ok && lane == 0) S.flag[0] = 1;
         store_col_ssq(x0, S.tr2, rows_valid(0), lane);
-#pragma unroll
-        for (int s = 0; s < kParkN; ++s) T[kPark0 + s] = lds_tile(park + s * 256, lane);
-        T[21] = x0;
+        lds_tile_store(diag, lane, x0);
     }
     __syncthreads();
-    // column 0: L_I0^T = X_00 T_I0^T into the slot and into panel 0 (buffer 0, position I)
-    {
+    // column 0: L_I0^T = X_00 T_I0^T into the slot and into panel 0 (buffer 0, position I) -- the last slot of every row
+    if (!spec) {
         Frag fx;
 #pragma unroll
         for (int q = 0; q < 4; ++q) fx.v[q] = S.dli[cl * PS + 4 * q + rg];
+        unsigned mC0 = 0;
+#pragma unroll
+        for (int r = 0; r < kRRRows; ++r)
+            if (rI[r] > 0) mC0 |= 1u << (rS[r] + rI[r] - 1);
 #pragma unroll
         for (int s = 0; s < kRRSlots; ++s) {
-            if (ij[s] > 255 && (ij[s] & 255) == 0) {  // I > 0, J = 0
+            if (mC0 & (1u << s)) {
                 RR_KEEP_BRANCH;
                 Frag ft;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ft.v[q] = T[s][q];
                 const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
                 T[s] = mfma4(fx, ft, z4, false);
-                lds_tile_store(S.pan + (size_t)(ij[s] >> 8) * tile_doubles, lane, T[s]);
+                lds_tile_store(S.pan + (size_t)(RR_E(s) >> 8) * tile_doubles, lane, T[s]);
             }
         }
     }
@@ -2247,131 +2340,214 @@ __device__ __forceinline__ bool solve_posterior_rr(const FitLoopParams &P, const
     for (int k = 0; k < nb; ++k) {
         if (S.flag[0]) return false;
         const int m = nb - k - 1;
+        if (tid == KT - 1) S.flag[5 + ((k + 1) & 1)] = 0;  // (the next step's counter: nobody reads it during this one)
         double *const bufk = S.pan + (size_t)(k & 1) * nb * tile_doubles;        // panel k (positions > k), row k - 1 of W (< k)
         double *const bufn = S.pan + (size_t)((k + 1) & 1) * nb * tile_doubles;  // panel k + 1, row k of W: written at this step
         const double *const dli_k = S.dli + (k & 1) * 16 * PS;
         double *const dli_n = S.dli + ((k + 1) & 1) * 16 * PS;
-        // ---- the chain: tile (k + 1, k + 1) updated, factored and inverted by the owner of row k + 1, before anything else ----
-        if (m > 0) {
-            const int key = ((k + 1) << 8) | (k + 1);
-            bool mine = false;
-            v4f64 a = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s = 0; s < kRRSlots; ++s) {
-                if (ij[s] == key) {
-                    RR_KEEP_BRANCH;
-                    a = T[s];
-                    mine = true;
-                }
-            }
-            if (mine) {
-#pragma unroll
-                for (int s = 0; s < kParkN; ++s) lds_tile_store(park + s * 256, lane, T[kPark0 + s]);
+        TRACE(0);
+        if (spec) {
+            // ---- the chain: tile (k + 1, k + 1) takes its last update, is factored and inverted ----
+            if (m > 0) {
+                v4f64 a = lds_tile(diag + (size_t)(k + 1) * tile_doubles, lane);
                 const v4f64 pa = lds_tile(bufk + (size_t)(k + 1) * tile_doubles, lane);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[q], pa[q], a, 0, 0, 0);
                 v4f64 xi;
                 const bool ok = factor_invert_tile(a, xi, dli_n, lane, aug_tile == k + 1 ? aug_c : -1);
                 if (!ok && lane == 0) S.flag[0] = 1;
+                __hip_atomic_store(&S.flag[3], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                TRACE(1);
                 store_col_ssq(xi, S.tr2 + 16 * (k + 1), rows_valid(k + 1), lane);
+                lds_tile_store(diag + (size_t)(k + 1) * tile_doubles, lane, xi);
+            }
+            // ---- W_kk = X_kk, the last tile of row k of W, into the buffer of the next step ----
+            {
+                const v4f64 wkk = lds_tile(diag + (size_t)k * tile_doubles, lane);
+                lds_tile_store(bufn + (size_t)k * tile_doubles, lane, wkk);
+                if (k == aug_tile) put_m(wkk, k);
+            }
+            TRACE(2);
+            // (the slots are the workers': nothing of them survives this branch, so the chain may have their registers)
 #pragma unroll
-                for (int s = 0; s < kParkN; ++s) T[kPark0 + s] = lds_tile(park + s * 256, lane);
+            for (int s = 0; s < kRRSlots; ++s) asm volatile("" : "=v"(T[s]));
+        } else {
+            // What this step asks of each slot, as bit masks (one scalar test per slot instead of four comparisons of its (I, J): a
+            // lone wave issues an instruction every ~5 cycles, and 24 slots x ~30 scalar instructions was 1.5 us of every step).
+            // A row I of this wave starting at slot st holds J = I - 1, .., 0:
+            //   trailing update (J > k): slots st .. st + I - k - 2; the last of them is the tile of column k + 1
+            //   inverse step K = k - 1 (J < k, I >= k >= 1): slots st + I - k .. st + I - 1; the first of them (J = k - 1) starts its sum
+            unsigned mT = 0, mCol = 0, mInv = 0, mStart = 0, mFin = 0;
+#pragma unroll
+            for (int r = 0; r < kRRRows; ++r) {
+                const int I = rI[r], st = rS[r];
+                if (I > k + 1) {
+                    mT |= ((1u << (I - k - 1)) - 1u) << st;
+                    mCol |= 1u << (st + I - k - 2);
+                }
+                if (I >= k && k >= 1) {
+                    const unsigned bits = ((1u << k) - 1u) << (st + I - k);
+                    if (I == k) mFin |= bits;
+                    else mInv |= bits;
+                    mStart |= 1u << (st + I - k);
+                }
+            }
+            double ro0 = 0.0, ro1 = 0.0, ro2 = 0.0, ro3 = 0.0;  // the operand a row shares: -L_Ik^T (trailing), L_{I,k-1}^T (inverse)
+            // ---- row k of the inverse first (its owner): the last products of its sums, the raw sums into LDS; EVERY worker then
+            //      takes a share of the products with -X_kk below (at the owner alone they were 5 us of a 12 us step)
+            if (mFin != 0) {
 #pragma unroll
                 for (int s = 0; s < kRRSlots; ++s) {
-                    if (ij[s] == key) {
+                    if (mFin & (1u << s)) {
                         RR_KEEP_BRANCH;
-                        T[s] = xi;
+                        const int J = slot_e(s) & 255;
+                        const v4f64 bw = lds_tile(bufk + (size_t)J * tile_doubles, lane);
+                        if (mStart & (1u << s)) {
+                            RR_KEEP_BRANCH;
+                            ro0 = T[s][0], ro1 = T[s][1], ro2 = T[s][2], ro3 = T[s][3];
+                            asm volatile("" : "+v"(ro0), "+v"(ro1), "+v"(ro2), "+v"(ro3));  // (a copy: the slot starts its sum from zero)
+                            T[s] = v4f64{0.0, 0.0, 0.0, 0.0};
+                        }
+                        rr_mfma4_a(T[s], ro0, ro1, ro2, ro3, bw);
                     }
                 }
-                __hip_atomic_store(&S.flag[3], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                RR_MFMA_SETTLE;
+#pragma unroll
+                for (int s = 0; s < kRRSlots; ++s) {
+                    if (mFin & (1u << s)) {
+                        RR_KEEP_BRANCH;
+                        lds_tile_store(bufn + (size_t)(slot_e(s) & 255) * tile_doubles, lane, T[s]);
+                    }
+                }
+                __hip_atomic_store(&S.flag[4], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            // ---- one pass over the slots: the trailing update with panel k; step K = k - 1 of the inverse for the rows below k ----
+            // (both kinds take ONE operand tile from position J of the step's buffer: read one slot ahead, see rr_lds_issue)
+            if ((mT | mInv) != 0) {
+                RR_KEEP_BRANCH;
+                int curI = -1;
+                const unsigned lbase = (unsigned)reinterpret_cast<unsigned long long>(bufk) + (unsigned)lane * 16u;
+                v2f64 oLo[2], oHi[2];
+                rr_lds_issue(oLo[0], oHi[0], lbase + ((slot_e(0) & 31u) << 11));
+#pragma unroll
+                for (int s = 0; s < kRRSlots; ++s) {
+                    if (s + 1 < kRRSlots) {
+                        rr_lds_issue(oLo[(s + 1) & 1], oHi[(s + 1) & 1], lbase + ((slot_e(s + 1) & 31u) << 11));
+                        RR_LDS_WAIT(2);
+                    } else {
+                        RR_LDS_WAIT(0);
+                    }
+                    if (mT & (1u << s)) {  // T_IJ^T -= L_Jk L_Ik^T  (the sign on the row's operand: once per row)
+                        RR_KEEP_BRANCH;
+                        const int I = slot_e(s) >> 8;
+                        if (I != curI) {
+                            RR_KEEP_BRANCH;
+                            const v4f64 t = lds_tile(bufk + (size_t)I * tile_doubles, lane);
+                            ro0 = -t[0], ro1 = -t[1], ro2 = -t[2], ro3 = -t[3];
+                            curI = I;
+                        }
+                        rr_mfma4_bp(T[s], oLo[s & 1], oHi[s & 1], ro0, ro1, ro2, ro3);
+                    }
+                    if (mInv & (1u << s)) {  // S_IJ += L_{I,k-1} W_{k-1,J}
+                        RR_KEEP_BRANCH;
+                        if (mStart & (1u << s)) {
+                            RR_KEEP_BRANCH;
+                            ro0 = T[s][0], ro1 = T[s][1], ro2 = T[s][2], ro3 = T[s][3];
+                            asm volatile("" : "+v"(ro0), "+v"(ro1), "+v"(ro2), "+v"(ro3));  // (a copy: the slot starts its sum from zero)
+                            curI = -1;
+                            T[s] = v4f64{0.0, 0.0, 0.0, 0.0};
+                        }
+                        rr_mfma4_ap(T[s], ro0, ro1, ro2, ro3, oLo[s & 1], oHi[s & 1]);
+                    }
+                }
+            }
+            TRACE(2);
+            // ---- column k + 1: L_{I,k+1}^T = X_{k+1,k+1} T_{I,k+1}^T into the slot and into panel k + 1 ----
+            // (in a pass of its own: inside the pass above -- behind the tile's last product -- the step took 0.3 us longer)
+            if (m > 1 && mCol != 0) {
+                int spins = 0;
+                while (__hip_atomic_load(&S.flag[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 22)) {  // (a stuck flag must not hang the device)
+                        if (lane == 0) S.flag[0] = 1;
+                        break;
+                    }
+                }
+                TRACE(3);
+                Frag fx;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fx.v[q] = dli_n[cl * PS + 4 * q + rg];
+#pragma unroll
+                for (int s = 0; s < kRRSlots; ++s) {
+                    if (mCol & (1u << s)) {
+                        RR_KEEP_BRANCH;
+                        const int I = slot_e(s) >> 8;
+                        Frag ft;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) ft.v[q] = T[s][q];
+                        const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
+                        T[s] = mfma4(fx, ft, z4, false);
+                        lds_tile_store(bufn + (size_t)I * tile_doubles, lane, T[s]);
+                    }
+                }
+            }
+            TRACE(4);
         }
-        // ---- one pass over the slots: the trailing update with panel k; step K = k - 1 of the inverse; row k of W finished ----
-        // (one register set for the operand a row shares: -L_Ik^T of the trailing update, then L_{I,k-1}^T of the inverse)
-        int curI = -1;
-        v4f64 ro = {0.0, 0.0, 0.0, 0.0};
+        // ---- work that lives in LDS and that ANY wave may take, off a counter (the specialist once its chain is done, a worker when
+        //      its own slots are): the diagonal tiles I > k + 1 take their product of this step, T_II^T -= L_Ik L_Ik^T; then row k of
+        //      W, W_kJ = -X_kk S_kJ in place, Tr2 and m on the way
+        {
+            const int nd = m > 1 ? m - 1 : 0, nitems = nd + k;
+            int *const ctr = S.flag + 5 + (k & 1);
+            bool sums_in = false;
+            for (;;) {
+                int it = 0;
+                if (lane == 0) it = atomicAdd(ctr, 1);
+                it = __builtin_amdgcn_readfirstlane(it);
+                if (it >= nitems) break;
+                if (it < nd) {
+                    const int I = k + 2 + it;
+                    v4f64 d = lds_tile(diag + (size_t)I * tile_doubles, lane);
+                    const v4f64 pa = lds_tile(bufk + (size_t)I * tile_doubles, lane);
 #pragma unroll
-        for (int s = 0; s < kRRSlots; ++s) {
-            const int I = ij[s] >> 8, J = ij[s] & 255;
-            if (J > k && I > k + 1) {  // T_IJ^T -= L_Jk L_Ik^T  (the sign on the row's operand: once per row)
-                RR_KEEP_BRANCH;
-                if (I != curI) {
-                    const v4f64 t = lds_tile(bufk + (size_t)I * tile_doubles, lane);
-                    ro = -t;
-                    curI = I;
+                    for (int q = 0; q < 4; ++q) d = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[q], pa[q], d, 0, 0, 0);
+                    lds_tile_store(diag + (size_t)I * tile_doubles, lane, d);
+                    continue;
                 }
-                const v4f64 pa = lds_tile(bufk + (size_t)J * tile_doubles, lane);
-                rr_mfma4(T[s], pa, ro);
-            }
-            if (I >= k && J < k) {  // S_IJ += L_{I,k-1} W_{k-1,J}
-                RR_KEEP_BRANCH;
-                const v4f64 bw = lds_tile(bufk + (size_t)J * tile_doubles, lane);
-                if (J == k - 1) {
-                    RR_KEEP_BRANCH;
-                    ro = T[s];
-                    asm volatile("" : "+v"(ro));  // (a copy: the slot starts its sum from zero)
-                    curI = -1;
-                    T[s] = v4f64{0.0, 0.0, 0.0, 0.0};
+                const int J = it - nd;
+                if (!sums_in) {
+                    int spins = 0;
+                    while (__hip_atomic_load(&S.flag[4], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1 << 22)) {
+                            if (lane == 0) S.flag[0] = 1;
+                            break;
+                        }
+                    }
+                    sums_in = true;
                 }
-                rr_mfma4(T[s], ro, bw);
-                if (I == k) {  // the sum is complete: W_kJ = -X_kk S_kJ
-                    RR_KEEP_BRANCH;
-                    RR_MFMA_SETTLE;
-                    Frag fs, fw;
+                Frag fs, fw;
+                const v4f64 sv = lds_tile(bufn + (size_t)J * tile_doubles, lane);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) fs.v[q] = T[s][q];
+                for (int q = 0; q < 4; ++q) fs.v[q] = sv[q];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) fw.v[q] = dli_k[cl * PS + 4 * q + rg];
-                    v4f64 w = {0.0, 0.0, 0.0, 0.0};
-                    w = mfma4(fw, fs, w, true);
-                    T[s] = w;
-                    lds_tile_store(bufn + (size_t)J * tile_doubles, lane, w);
-                    double ssq = 0.0;
+                for (int q = 0; q < 4; ++q) fw.v[q] = dli_k[cl * PS + 4 * q + rg];
+                v4f64 w = {0.0, 0.0, 0.0, 0.0};
+                w = mfma4(fw, fs, w, true);
+                lds_tile_store(bufn + (size_t)J * tile_doubles, lane, w);
+                double ssq = 0.0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (16 * k + rg + 4 * r < N) ssq = fma(w[r], w[r], ssq);
-                    ssq += __shfl_xor(ssq, 16);
-                    ssq += __shfl_xor(ssq, 32);
-                    if (rg == 0) S.tr2[16 * J + cl] += ssq;  // (column J's sum over the rows in ascending order: cs_JJ came first)
-                    if (k == aug_tile) put_m(w, J);
-                }
-            }
-            if (I == k && J == k) {  // W_kk = X_kk: the last tile of row k of W
-                RR_KEEP_BRANCH;
-                lds_tile_store(bufn + (size_t)k * tile_doubles, lane, T[s]);
-                if (k == aug_tile) put_m(T[s], k);
-            }
-        }
-        RR_MFMA_SETTLE;  // (the column tiles below read their slots as operands)
-        // ---- column k + 1: L_{I,k+1}^T = X_{k+1,k+1} T_{I,k+1}^T into the slot and into panel k + 1 ----
-        if (m > 1) {
-            int spins = 0;
-            while (__hip_atomic_load(&S.flag[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 22)) {  // (a stuck flag must not hang the device)
-                    if (lane == 0) S.flag[0] = 1;
-                    break;
-                }
-            }
-            Frag fx;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) fx.v[q] = dli_n[cl * PS + 4 * q + rg];
-#pragma unroll
-            for (int s = 0; s < kRRSlots; ++s) {
-                const int I = ij[s] >> 8, J = ij[s] & 255;
-                if (J == k + 1 && I > k + 1) {
-                    RR_KEEP_BRANCH;
-                    Frag ft;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) ft.v[q] = T[s][q];
-                    const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
-                    T[s] = mfma4(fx, ft, z4, false);
-                    lds_tile_store(bufn + (size_t)I * tile_doubles, lane, T[s]);
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (16 * k + rg + 4 * r < N) ssq = fma(w[r], w[r], ssq);
+                ssq += __shfl_xor(ssq, 16);
+                ssq += __shfl_xor(ssq, 32);
+                if (rg == 0) S.tr2[16 * J + cl] += ssq;  // (column J's sum over the rows in ascending order: cs_JJ came first)
+                if (k == aug_tile) put_m(w, J);
             }
         }
         __syncthreads();
     }
+#undef RR_E
     if (S.flag[0]) return false;
     return true;
 }
@@ -2514,8 +2690,8 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         S.band = P.W;
         S.scanQ = S.band + 6 * NP;
         S.rec = reinterpret_cast<uint4 *>(S.red + NP + 6 * NP + 2 * 6 * 4 * 64);
-    } else if constexpr (DF) {
-        // (three panels in LDS: the band factors and scan tables in the W buffer, which the one-workgroup solve does not use --
+    } else if constexpr (DF || RR) {
+        // (three panels in LDS -- RR: two buffers of tiles and the diagonal tiles --: the band factors and scan tables in the W buffer, which the one-workgroup solve does not use --
         //  W lives in the dead tiles of C --; wave 0 reads them once per pass, as in the wide instantiations)
         S.band = P.W;
         S.scanQ = S.band + 6 * NP;
@@ -2525,6 +2701,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
         S.scanQ = S.band + 6 * NP;  // [2 directions][6 levels][4 entries][64 lanes]
         S.rec = reinterpret_cast<uint4 *>(S.scanQ + 2 * 6 * 4 * 64);  // (16-byte aligned: every region before it is an even number of doubles)
     }
+    if constexpr (RR) S.rec = reinterpret_cast<uint4 *>(S.red + NP);  // (no tile table: the flags follow the vectors)
     S.flag = reinterpret_cast<int *>(S.rec + (RR ? 0 : (DF ? 256 : max_tiles<WIDE>())));  // [0] not positive definite, [1] column counter of the inverse row
     S.hand = RR ? reinterpret_cast<double *>(S.flag + 8 + 48) : (!WIDE && !DF && NP <= kHandMaxNP) ? reinterpret_cast<double *>(S.flag + 8) : nullptr;  // (32 bytes of flags; 16-byte aligned)
     S.dcnt = S.flag + 8;  // (deferred mode: 2 x 24 ints behind the flags)
@@ -2917,8 +3094,8 @@ __global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int 
 #ifdef FIT_LOOP_RR
 // the register-resident instantiation only (fit_loop_rr.hip compiles this file with 512 threads per workgroup)
 size_t fh_k2_loop_rr_smem_bytes(int NP) {
-    // two buffers of nb packed tiles, L_kk^-1 (two), the vectors, the band factors and scan tables, the flags
-    return sizeof(double) * (size_t)(2 * (NP / 16) * 256 + 2 * 16 * PS + 8 * NP + 6 * NP + 2 * 6 * 4 * 64) + 32 + 4 * 48 + 8 * 2048;  // (+ the park area)
+    // two buffers of nb packed tiles and the nb diagonal tiles, L_kk^-1 (two), the vectors, the flags (bands, scan tables: W buffer)
+    return sizeof(double) * (size_t)(3 * (NP / 16) * 256 + 2 * 16 * PS + 8 * NP) + 32 + 4 * 48;
 }
 hipError_t fh_k2_launch_loop_rr(const FitLoopParams &P, int blocks, hipStream_t s) {
     if (P.NP / 16 > kRRMaxNB || P.cluster > 1) return hipErrorInvalidValue;

@@ -1629,6 +1629,74 @@ def test_deferred_trailing_update_equals_the_step_by_step_one(monkeypatch, N):
     assert np.array_equal(new[0][1], new[1][1][0]) and np.array_equal(new[0][1], new[2][1])
 
 
+@pytest.mark.parametrize("N", [62, 63, 64, 79, 95, 96, 111, 112, 130, 200, 255, 300, 303, 304])
+def test_register_resident_fit_loop_equals_the_others(monkeypatch, N):
+    """fit_loop.hip, solve_posterior_rr (round 5, FRANK_AMD_K2_RR=1; fit_loop_rr.hip: 512 threads): the lower triangle of the
+    posterior precision never leaves the vector registers of the one compute unit -- seven waves hold its tiles by block rows, the
+    eighth runs the factor-and-invert chain, operands travel through LDS -- and per pass only A is read from memory.  Against the
+    forms that work in memory (the default): mu, p and the iteration count are the same BITS, for a synchronous fit, for the fits
+    of a batched launch (per-fit hyper-parameters) and for pipelined fits.  N <= 303 (19 block rows) and N >= 63; outside, the
+    switch changes nothing."""
+    import ctypes
+    from frank_amd import _lib
+    FF, M, j = _cluster_problem(N, 100000)
+    ctx = FF._DHT.context()
+    monkeypatch.setenv("FRANK_AMD_K2_CLUSTER", "1")
+    monkeypatch.setenv("FRANK_AMD_SWEEP_NO_CLUSTERS", "1")
+    B = 5
+    al = np.array([1.05, 1.2, 1.05, 1.3, 1.1])
+    p0 = np.full(B, 1e-15)
+    ws = np.array([1e-4, 1e-2, 1e-1, 1e-3, 1e-4])
+
+    def run():
+        out = [_fit_normal(ctx, N, M, j, max_iter=150)[:4]]
+        mu, pp = np.empty((B, N)), np.empty((B, N))
+        nit, st = (ctypes.c_int * B)(), (ctypes.c_int * B)()
+        _lib.check(_lib.lib.fh_fit_normal_batched(ctx, _lib.ptr(M), _lib.ptr(j), B, _lib.ptr(al), _lib.ptr(p0), _lib.ptr(ws), 1e-3, 150,
+                                                  _lib.ptr(mu), _lib.ptr(pp), nit, st))
+        out.append((list(st), mu.copy(), pp.copy(), list(nit)))
+        _lib.check(_lib.lib.fh_stats_upload(ctx, _lib.ptr(M), _lib.ptr(j)))
+        tickets = []
+        for b in range(B):
+            t = ctypes.c_int(-1)
+            _lib.check(_lib.lib.fh_fit_submit(ctx, al[b], 1e-15, ws[b], 1e-3, 150, ctypes.byref(t)))
+            tickets.append(t.value)
+        _lib.check(_lib.lib.fh_fit_flush(ctx))
+        for b, t in enumerate(tickets):
+            m1, p1, n1 = np.empty(N), np.empty(N), ctypes.c_int(0)
+            _lib.check(_lib.lib.fh_fit_collect(ctx, t, _lib.ptr(m1), _lib.ptr(p1), ctypes.byref(n1)))
+            out.append((0, m1, p1, n1.value))
+        return out
+
+    monkeypatch.setenv("FRANK_AMD_K2_RR", "0")
+    ref = run()
+    monkeypatch.setenv("FRANK_AMD_K2_RR", "1")
+    new = run()
+    assert len(ref) == len(new) == 2 + B
+    for a, b in zip(ref, new):
+        assert a[0] == b[0] and a[3] == b[3], (a[0], b[0], a[3], b[3])
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_register_resident_fit_loop_reports_a_matrix_that_is_not_positive_definite(monkeypatch):
+    """... and fails the way the others do: a precision matrix with a negative eigenvalue ends the fit with FH_ERR_NOT_SPD at the
+    same pass (the chain wave's flag reaches every wave behind the step's barrier)."""
+    from frank_amd import _lib
+    N = 130
+    FF, M, j = _cluster_problem(N, 100000)
+    ctx = FF._DHT.context()
+    Mb = M.copy()
+    Mb[40, 40] = -1e3 * abs(M).max()
+    monkeypatch.setenv("FRANK_AMD_K2_CLUSTER", "1")
+    res = []
+    for d in ("0", "1"):
+        monkeypatch.setenv("FRANK_AMD_K2_RR", d)
+        rc, mu, p, n, *_ = _fit_normal(ctx, N, Mb, j, max_iter=50)
+        res.append((rc, n))
+    assert res[0][0] == -4, res  # FH_ERR_NOT_SPD
+    assert res[0] == res[1], res
+
+
 def test_diagonal_tile_routines():
     """tile_chol.h: the transposed factor-and-invert routine of round 4 (chol_inv_tile_z, what the fit loop runs) against the
     routine of rounds 2-3 and against the tiles themselves, on 32 random SPD tiles; with and without L^T out it returns the

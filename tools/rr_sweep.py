@@ -25,7 +25,7 @@ for N in sizes:
     M, j = np.ascontiguousarray(m["M"]), np.ascontiguousarray(m["j"])
     ctx = FF._DHT.context()
     res = []
-    for d in ("0", "1"):
+    for d in ("0", "1"):  # (the other forms first)
         os.environ["FRANK_AMD_K2_RR"] = d
         mu, p, nit = np.empty(N), np.empty(N), ctypes.c_int(0)
         rc = _lib.lib.fh_fit_normal(ctx, _lib.ptr(M), _lib.ptr(j), 1.05, 1e-15, 1e-4, 1e-3, 80, _lib.ptr(mu), _lib.ptr(p),
