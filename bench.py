@@ -42,6 +42,7 @@ Rank 0 at N=1 also reports, outside the timed region and bounded to about a minu
   cpu_baseline               the CPU oracle on one core and on all host cores (independent fits per core)
 """
 import argparse
+import hashlib
 import ctypes
 import json
 import os
@@ -324,6 +325,19 @@ def extras(f, L, a):
     # -- what the pipeline of the headline does at steady state (>= 2 s runs), and on tables it has never seen
     try:
         ex["steady_state"] = steady_state(f, L)
+        # ... and with the fit loops in their register-resident form (fit_loop_rr.hip, FRANK_AMD_K2_RR=1, read at every launch;
+        # same bits): opt-in -- a loop ALONE takes 172 us per pass in that form against 135, with the device full 183 against
+        # 196 --, so the drained runs above and the sweeps keep the forms that work in memory
+        prev_rr = os.environ.get("FRANK_AMD_K2_RR")
+        os.environ["FRANK_AMD_K2_RR"] = "1"
+        try:
+            ex["steady_state_register_resident"] = steady_state(f, L)
+            ex["steady_state_register_resident"]["workload"] += "; fit loops with the matrix resident in registers (FRANK_AMD_K2_RR=1)"
+        finally:
+            if prev_rr is None:
+                del os.environ["FRANK_AMD_K2_RR"]
+            else:
+                os.environ["FRANK_AMD_K2_RR"] = prev_rr
         ex["distinct_tables"] = steady_state(f, L, ring=4)
         for t in f.tables[1:]:
             L.lib.fh_vis_destroy(t)
@@ -343,16 +357,31 @@ def extras(f, L, a):
         al, p0v, wsv = np.full(Bf, h["alpha"]), np.full(Bf, h["p0"]), np.full(Bf, h["wsmooth"])
         mu_b, p_b = np.empty((Bf, N)), np.empty((Bf, N))
         nit_b, st_b = (ctypes.c_int * Bf)(), (ctypes.c_int * Bf)()
-        best = None
-        for _ in range(2):
-            L.check(L.lib.fh_ctx_loop_clocks(f.ctx, 1, o3))
-            f.sync()
-            t0 = time.perf_counter()
-            L.check(L.lib.fh_fit_normal_batched(f.ctx, None, None, Bf, L.ptr(al), L.ptr(p0v), L.ptr(wsv), h["tol"], h["max_iter"],
-                                                L.ptr(mu_b), L.ptr(p_b), nit_b, st_b))
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
-        L.check(L.lib.fh_ctx_loop_clocks(f.ctx, 0, o3))
+        def resident_launch():
+            best = None
+            for _ in range(2):
+                L.check(L.lib.fh_ctx_loop_clocks(f.ctx, 1, o3))
+                f.sync()
+                t0 = time.perf_counter()
+                L.check(L.lib.fh_fit_normal_batched(f.ctx, None, None, Bf, L.ptr(al), L.ptr(p0v), L.ptr(wsv), h["tol"], h["max_iter"],
+                                                    L.ptr(mu_b), L.ptr(p_b), nit_b, st_b))
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            L.check(L.lib.fh_ctx_loop_clocks(f.ctx, 0, o3))
+            return best
+        prev_rr = os.environ.get("FRANK_AMD_K2_RR")
+        os.environ["FRANK_AMD_K2_RR"] = "1"
+        try:
+            best_rr = resident_launch()
+            rr = {"fits_per_s": Bf / best_rr, "s_total": best_rr, "us_per_pass_on_the_device": o3[1] / 100.0 / max(o3[2], 1),
+                  "sha256_mu_p": hashlib.sha256(mu_b.tobytes() + p_b.tobytes()).hexdigest()}
+        finally:
+            if prev_rr is None:
+                del os.environ["FRANK_AMD_K2_RR"]
+            else:
+                os.environ["FRANK_AMD_K2_RR"] = prev_rr
+        best = resident_launch()
+        rr["same_bits_as_the_default_form"] = rr.pop("sha256_mu_p") == hashlib.sha256(mu_b.tobytes() + p_b.tobytes()).hexdigest()
         passes = nit_b[0] + 2
         tf = Bf / best * passes * (2.0 * (N + 1) ** 3 / 3.0) / 1e12
         ex["device_full"] = {"workload": "%d identical N=%d fits resident in ONE launch, one compute unit each (the batched form of "
@@ -363,7 +392,8 @@ def extras(f, L, a):
                                           "frac": tf / FP64_MFMA_PEAK_TFLOPS,
                                           "note": "algorithmic flops (2 n^3 / 3 per pass) of all fits over the wall time of the launch, "
                                                   "against the whole chip's fp64 matrix peak; what holds it there is memory traffic "
-                                                  "beyond the L2, 3.5 MB per pass (profiles/r05_pmc_fit_loop_256_resident.json)"}}
+                                                  "beyond the L2, 3.5 MB per pass (profiles/r05_pmc_fit_loop_256_resident.json)"},
+                             "register_resident_form": rr}
         if prev is None:
             del os.environ["FRANK_AMD_SWEEP_NO_CLUSTERS"]
         else:

@@ -2168,6 +2168,27 @@ __device__ __forceinline__ unsigned rr_slot_ij(int w, int s, int nb) {
         if (rI[r] > 0 && s >= rS[r] && s < rS[r] + rI[r]) e = (unsigned)((rI[r] << 8) | (rI[r] - 1 - (s - rS[r])));
     return e;
 }
+// the tables of all eight waves, built once per fit (thread e: one word): per wave kRRTabStride ints -- [0, 13) the slots' (I, J),
+// two to a word; [16, 22) the rows' block rows; [22, 28) their first slots
+constexpr int kRRTabStride = 32;
+__device__ __forceinline__ void rr_tables(int *tab, int nb, int tid) {
+    for (int e = tid; e < 8 * kRRTabStride; e += KT) {
+        const int w = e / kRRTabStride, i = e % kRRTabStride;
+        int v = 0;
+        if (i < (kRRSlots + 1) / 2) {
+            v = (int)(rr_slot_ij(w, 2 * i, nb) | ((2 * i + 1 < kRRSlots ? rr_slot_ij(w, 2 * i + 1, nb) : 0xffffu) << 16));
+        } else if (i >= 16 && i < 16 + 2 * kRRRows) {
+            int rI[kRRRows], rS[kRRRows];
+            rr_rows(w, nb, rI, rS);
+#pragma unroll
+            for (int r = 0; r < kRRRows; ++r) {
+                if (i == 16 + r) v = rI[r];
+                if (i == 16 + kRRRows + r) v = rS[r];
+            }
+        }
+        tab[e] = v;
+    }
+}
 #define RR_KEEP_BRANCH asm volatile("" ::: "memory")  // (a branch, not 8 selects per slot: the condition is wave-uniform)
 // T += A B for one k-step quadruple, IN PLACE: the accumulator is tied to its own registers (the builtin leaves the destination to
 // the register allocator, which under 24 live tiles answered with copies of whole tiles behind s_nop 14).  The hazard recogniser
@@ -2244,12 +2265,16 @@ __device__ __forceinline__ bool solve_posterior_rr(const FitLoopParams &P, const
     const gdouble *A_u = as_global(uniform_ptr(P.A));
     const int tile_doubles = 256;
     const bool spec = wave == kRRSpec;
+#ifdef FIT_LOOP_TIMING
+    const long long t_entry = clock64();
+#endif
 
     // the slots' (I, J), two to a scalar register (16 bits each), and the rows of this wave
+    // (from a table in LDS built once per fit, rr_tables: formed here they were ~3 000 scalar instructions of every pass)
+    const int *const tab = S.dcnt + wave * kRRTabStride;
     unsigned ijp[(kRRSlots + 1) / 2];
 #pragma unroll
-    for (int h = 0; h < (kRRSlots + 1) / 2; ++h)
-        ijp[h] = __builtin_amdgcn_readfirstlane(rr_slot_ij(wave, 2 * h, nb) | ((2 * h + 1 < kRRSlots ? rr_slot_ij(wave, 2 * h + 1, nb) : 0xffffu) << 16));
+    for (int h = 0; h < (kRRSlots + 1) / 2; ++h) ijp[h] = (unsigned)__builtin_amdgcn_readfirstlane(tab[h]);
 #define RR_E(s) ((ijp[(s) >> 1] >> (16 * ((s) & 1))) & 0xffffu)
     // (inside the step loop the packed words go through an opaque move first: hoisted out of the loop, the 25 operand offsets and the
     //  25 row indices were 50 scalar registers, spilled to vector lanes and read back with a v_readlane per use -- and with two
@@ -2261,11 +2286,10 @@ __device__ __forceinline__ bool solve_posterior_rr(const FitLoopParams &P, const
         return (w >> (16 * (s & 1))) & 0xffffu;
     };
     int rI[kRRRows], rS[kRRRows];
-    rr_rows(wave, nb, rI, rS);
 #pragma unroll
     for (int r = 0; r < kRRRows; ++r) {
-        rI[r] = __builtin_amdgcn_readfirstlane(rI[r]);
-        rS[r] = __builtin_amdgcn_readfirstlane(rS[r]);
+        rI[r] = __builtin_amdgcn_readfirstlane(tab[16 + r]);
+        rS[r] = __builtin_amdgcn_readfirstlane(tab[16 + kRRRows + r]);
     }
 
     v4f64 T[kRRSlots];
@@ -2346,6 +2370,9 @@ __device__ __forceinline__ bool solve_posterior_rr(const FitLoopParams &P, const
         const double *const dli_k = S.dli + (k & 1) * 16 * PS;
         double *const dli_n = S.dli + ((k + 1) & 1) * 16 * PS;
         TRACE(0);
+#ifdef FIT_LOOP_TIMING
+        if (P.trace_on && lane == 0 && k == 0) P.timing[16 + (wave * 20 + 0) * 6 + 5] = t_entry;  // (tools/rr_trace.py: the prologue)
+#endif
         if (spec) {
             // ---- the chain: tile (k + 1, k + 1) takes its last update, is factored and inverted ----
             if (m > 0) {
@@ -2393,30 +2420,19 @@ __device__ __forceinline__ bool solve_posterior_rr(const FitLoopParams &P, const
                 }
             }
             double ro0 = 0.0, ro1 = 0.0, ro2 = 0.0, ro3 = 0.0;  // the operand a row shares: -L_Ik^T (trailing), L_{I,k-1}^T (inverse)
-            // ---- row k of the inverse first (its owner): the last products of its sums, the raw sums into LDS; EVERY worker then
-            //      takes a share of the products with -X_kk below (at the owner alone they were 5 us of a 12 us step)
+            // ---- row k of the inverse first: its owner hands the row over in LDS as it stands -- the sums S_kJ still one product short
+            //      (positions J < k - 1 of the next step's buffer) and L_{k,k-1}^T, the tile that starts the last sum (position k of
+            //      THIS step's buffer, which nothing else uses) -- and every wave takes tiles of it off the counter below: the last
+            //      product S_kJ += L_{k,k-1} W_{k-1,J}, then W_kJ = -X_kk S_kJ.  (With the last products formed here, by the one
+            //      wave that holds the row, the late steps were that wave's: 18 tiles, 5 us of a 6.5 us step at k = 18.)
             if (mFin != 0) {
 #pragma unroll
                 for (int s = 0; s < kRRSlots; ++s) {
                     if (mFin & (1u << s)) {
                         RR_KEEP_BRANCH;
                         const int J = slot_e(s) & 255;
-                        const v4f64 bw = lds_tile(bufk + (size_t)J * tile_doubles, lane);
-                        if (mStart & (1u << s)) {
-                            RR_KEEP_BRANCH;
-                            ro0 = T[s][0], ro1 = T[s][1], ro2 = T[s][2], ro3 = T[s][3];
-                            asm volatile("" : "+v"(ro0), "+v"(ro1), "+v"(ro2), "+v"(ro3));  // (a copy: the slot starts its sum from zero)
-                            T[s] = v4f64{0.0, 0.0, 0.0, 0.0};
-                        }
-                        rr_mfma4_a(T[s], ro0, ro1, ro2, ro3, bw);
-                    }
-                }
-                RR_MFMA_SETTLE;
-#pragma unroll
-                for (int s = 0; s < kRRSlots; ++s) {
-                    if (mFin & (1u << s)) {
-                        RR_KEEP_BRANCH;
-                        lds_tile_store(bufn + (size_t)(slot_e(s) & 255) * tile_doubles, lane, T[s]);
+                        if (mStart & (1u << s)) lds_tile_store(bufk + (size_t)k * tile_doubles, lane, T[s]);
+                        else lds_tile_store(bufn + (size_t)J * tile_doubles, lane, T[s]);
                     }
                 }
                 __hip_atomic_store(&S.flag[4], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2527,7 +2543,13 @@ __device__ __forceinline__ bool solve_posterior_rr(const FitLoopParams &P, const
                     sums_in = true;
                 }
                 Frag fs, fw;
-                const v4f64 sv = lds_tile(bufn + (size_t)J * tile_doubles, lane);
+                v4f64 sv = {0.0, 0.0, 0.0, 0.0};
+                if (J < k - 1) sv = lds_tile(bufn + (size_t)J * tile_doubles, lane);
+                {   // the last product of the sum: L_{k,k-1} W_{k-1,J}
+                    const v4f64 la = lds_tile(bufk + (size_t)k * tile_doubles, lane), bw = lds_tile(bufk + (size_t)J * tile_doubles, lane);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sv = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], bw[q], sv, 0, 0, 0);
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) fs.v[q] = sv[q];
 #pragma unroll
@@ -2705,6 +2727,12 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     S.flag = reinterpret_cast<int *>(S.rec + (RR ? 0 : (DF ? 256 : max_tiles<WIDE>())));  // [0] not positive definite, [1] column counter of the inverse row
     S.hand = RR ? reinterpret_cast<double *>(S.flag + 8 + 48) : (!WIDE && !DF && NP <= kHandMaxNP) ? reinterpret_cast<double *>(S.flag + 8) : nullptr;  // (32 bytes of flags; 16-byte aligned)
     S.dcnt = S.flag + 8;  // (deferred mode: 2 x 24 ints behind the flags)
+#ifdef FIT_LOOP_RR
+    if constexpr (RR) {
+        S.dcnt = reinterpret_cast<int *>(S.hand + (size_t)(NP / 16) * 256);  // (register-resident mode: the slot tables, behind the diagonal tiles)
+        rr_tables(S.dcnt, NP / 16, tid);
+    }
+#endif
     if constexpr (DF) {
         // Deferred mode: at a step of parity par the tiles (i, j) relative to block (k + 1, k + 1), 1 <= j <= i, that are touched
         // are those with (i + j + par) even -- they take panels k - 1 and k -- and, bit 2 of x set, the other tiles of column
@@ -3095,7 +3123,7 @@ __global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int 
 // the register-resident instantiation only (fit_loop_rr.hip compiles this file with 512 threads per workgroup)
 size_t fh_k2_loop_rr_smem_bytes(int NP) {
     // two buffers of nb packed tiles and the nb diagonal tiles, L_kk^-1 (two), the vectors, the flags (bands, scan tables: W buffer)
-    return sizeof(double) * (size_t)(3 * (NP / 16) * 256 + 2 * 16 * PS + 8 * NP) + 32 + 4 * 48;
+    return sizeof(double) * (size_t)(3 * (NP / 16) * 256 + 2 * 16 * PS + 8 * NP) + 32 + 4 * 48 + 4 * 8 * 32;  // (+ the slot tables)
 }
 hipError_t fh_k2_launch_loop_rr(const FitLoopParams &P, int blocks, hipStream_t s) {
     if (P.NP / 16 > kRRMaxNB || P.cluster > 1) return hipErrorInvalidValue;

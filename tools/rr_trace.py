@@ -29,6 +29,9 @@ _lib.lib.fh_debug_loop_trace(FF._DHT.context(), tr)
 t = np.array(tr[: nw * 120], dtype=np.int64).reshape(nw, 20, 6)
 t0 = t[:, :, 0][t[:, :, 0] > 0].min()
 us = lambda v: (v - t0) / 2.4e3
+print("prologue (entry of the solve to the start of step 0), per wave: " + " ".join("%.2f" % ((t[w, 0, 0] - t[w, 0, 5]) / 2.4e3) for w in range(nw)) + " us")
+last = t[:, 18, :][t[:, 18, :] > 0].max()
+print("entry to the end of step 18: %.1f us" % ((last - t[:, 0, 5][t[:, 0, 5] > 0].min()) / 2.4e3))
 print("step: start | per wave: [chain done] pass done, flag seen, columns done   (us after the start of the step; * = the chain wave)")
 for k in range(19):
     row = "%2d %7.2f |" % (k, us(t[:, k, 0][t[:, k, 0] > 0].min()))
