@@ -910,7 +910,12 @@ static int flush_pending_batch(fh_ctx *c) {
     P.out_host = c->slot_out_host;
     P.result_host = c->slot_result_host;
     P.cluster = b.cluster;
-    // (P.loaded stays 0: the ~150 loops a pipeline keeps resident are below the load at which the paired rows of the inverse pay)
+    // (the fits in flight beside this launch: from ~128 resident loops on the register-resident form of the loop is the faster one,
+    //  fit_loop.hip.  The slots that are out stand for the loops that run -- a pipeline that keeps 128 fits in flight is a loaded
+    //  device; counting the loops exactly means a query per launch in flight, and with the threshold on that count a pipeline at
+    //  steady state, ~140 running, went back and forth between the forms: 1 369 against 1 430 fits/s.  A run of 20 or 100 fits that
+    //  drains at once -- bench.py's timed region -- never gets there and keeps the form that is faster alone.)
+    P.loaded = c->slots_busy >= 128 ? c->slots_busy : 0;
     if (b.cluster > 1) {  // the fits of consecutive cluster launches go round the XCDs
         P.cluster_xcd0 = c->next_xcd & 7;
         c->next_xcd = (c->next_xcd + b.n) & 7;

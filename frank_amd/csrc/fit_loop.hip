@@ -2197,13 +2197,17 @@ __device__ __forceinline__ void rr_tables(int *tab, int nb, int tid) {
 // the copies and spills the register allocator may place directly behind a block, which is why the block itself ends on them
 // (a first version waited once per step, before its own reads: its results depended on where the allocator put its copies).
 // (the operand a row shares travels as four separate 64-bit pairs: a whole-tile operand was copied in front of every product)
+#ifdef RR_NO_BLOCK_NOPS
+#define RR_BLOCK_TAIL
+#else
+#define RR_BLOCK_TAIL "\n\ts_nop 15\n\ts_nop 2" /* the results settle before anything the compiler may place behind the block reads them */
+#endif
 __device__ __forceinline__ void rr_mfma4_b(v4f64 &T, const v4f64 &a, double b0, double b1, double b2, double b3) {
     asm volatile("s_nop 1\n\t"
                  "v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\t"
                  "v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\t"
                  "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\t"
-                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n\t"
-                 "s_nop 15\n\ts_nop 2"  /* the results settle before anything the compiler may place behind the block reads them */
+                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0" RR_BLOCK_TAIL
                  : "+v"(T)
                  : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
 }
@@ -2212,8 +2216,7 @@ __device__ __forceinline__ void rr_mfma4_a(v4f64 &T, double a0, double a1, doubl
                  "v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\t"
                  "v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\t"
                  "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\t"
-                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n\t"
-                 "s_nop 15\n\ts_nop 2"  /* the results settle before anything the compiler may place behind the block reads them */
+                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0" RR_BLOCK_TAIL
                  : "+v"(T)
                  : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
 }
@@ -2224,14 +2227,26 @@ __device__ __forceinline__ void rr_mfma4_a(v4f64 &T, double a0, double a1, doubl
 __device__ __forceinline__ void rr_lds_issue(v2f64 &lo, v2f64 &hi, unsigned addr) {
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory");
 }
+// ... with the address as a row's base + a compile-time offset: within a row the slots go down the columns one by one, J = c - s, so
+// the operand of slot s is at (buffer + (c - 24) tiles) + (24 - s) tiles -- one vector add per ROW (2 - 6 per pass) instead of
+// one per slot.  (The buffers sit behind >= 48 KB of LDS -- the vectors, the diagonal tiles, padding for the small sizes -- so
+// that a base never falls below the start of LDS.)
+template <int OFF>
+__device__ __forceinline__ void rr_lds_issue_imm(v2f64 &lo, v2f64 &hi, unsigned base) {
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(lo), "=&v"(hi) : "v"(base), "n"(OFF), "n"(OFF + 1024) : "memory");
+}
+template <typename F, int... Ss>
+__device__ __forceinline__ void rr_for_slots(F &&f, std::integer_sequence<int, Ss...>) {
+    (f(std::integral_constant<int, Ss>{}), ...);
+}
+constexpr int kRRBufferMinOffset = 24 * 2048;  // bytes of LDS in front of the tile buffers
 #define RR_LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 __device__ __forceinline__ void rr_mfma4_bp(v4f64 &T, const v2f64 &alo, const v2f64 &ahi, double b0, double b1, double b2, double b3) {
     asm volatile("s_nop 1\n\t"
                  "v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\t"
                  "v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\t"
                  "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\t"
-                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n\t"
-                 "s_nop 15\n\ts_nop 2"  /* the results settle before anything the compiler may place behind the block reads them */
+                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0" RR_BLOCK_TAIL
                  : "+v"(T)
                  : "v"(alo[0]), "v"(alo[1]), "v"(ahi[0]), "v"(ahi[1]), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
 }
@@ -2240,8 +2255,7 @@ __device__ __forceinline__ void rr_mfma4_ap(v4f64 &T, double a0, double a1, doub
                  "v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\t"
                  "v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\t"
                  "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\t"
-                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n\t"
-                 "s_nop 15\n\ts_nop 2"  /* the results settle before anything the compiler may place behind the block reads them */
+                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0" RR_BLOCK_TAIL
                  : "+v"(T)
                  : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(blo[0]), "v"(blo[1]), "v"(bhi[0]), "v"(bhi[1]));
 }
@@ -2291,6 +2305,10 @@ __device__ __forceinline__ bool solve_posterior_rr(const FitLoopParams &P, const
         rI[r] = __builtin_amdgcn_readfirstlane(tab[16 + r]);
         rS[r] = __builtin_amdgcn_readfirstlane(tab[16 + kRRRows + r]);
     }
+    unsigned mRow = 0;  // the first slots of this wave's rows
+#pragma unroll
+    for (int r = 0; r < kRRRows; ++r)
+        if (rI[r] > 0) mRow |= 1u << rS[r];
 
     v4f64 T[kRRSlots];
     // (1) the tiles from A: T_IJ^T is tile (J, I) of the symmetric A; 1/p on the diagonal before anything else touches the tile
@@ -2443,12 +2461,26 @@ __device__ __forceinline__ bool solve_posterior_rr(const FitLoopParams &P, const
                 RR_KEEP_BRANCH;
                 int curI = -1;
                 const unsigned lbase = (unsigned)reinterpret_cast<unsigned long long>(bufk) + (unsigned)lane * 16u;
+                auto rowbase = [&](int t) __attribute__((always_inline)) {  // the base of the row that starts at slot t (c = J_t + t)
+                    return lbase + (unsigned)(((int)(slot_e(t) & 31u) + t - 24) * 2048);
+                };
+                unsigned curbase = lbase;
                 v2f64 oLo[2], oHi[2];
-                rr_lds_issue(oLo[0], oHi[0], lbase + ((slot_e(0) & 31u) << 11));
-#pragma unroll
-                for (int s = 0; s < kRRSlots; ++s) {
-                    if (s + 1 < kRRSlots) {
-                        rr_lds_issue(oLo[(s + 1) & 1], oHi[(s + 1) & 1], lbase + ((slot_e(s + 1) & 31u) << 11));
+                unsigned mRowK = mRow;  // (opaque per step: its 25 bit tests, hoisted out of the step loop, were 25 spilled masks)
+                asm volatile("" : "+s"(mRowK));
+                if (mRowK & 1u) {
+                    RR_KEEP_BRANCH;
+                    curbase = rowbase(0);
+                }
+                rr_lds_issue_imm<24 * 2048>(oLo[0], oHi[0], curbase);
+                rr_for_slots([&](auto sc) __attribute__((always_inline)) {
+                    constexpr int s = decltype(sc)::value;
+                    if constexpr (s + 1 < kRRSlots) {
+                        if (mRowK & (1u << (s + 1))) {
+                            RR_KEEP_BRANCH;
+                            curbase = rowbase(s + 1);
+                        }
+                        rr_lds_issue_imm<(24 - (s + 1)) * 2048>(oLo[(s + 1) & 1], oHi[(s + 1) & 1], curbase);
                         RR_LDS_WAIT(2);
                     } else {
                         RR_LDS_WAIT(0);
@@ -2475,8 +2507,9 @@ __device__ __forceinline__ bool solve_posterior_rr(const FitLoopParams &P, const
                         }
                         rr_mfma4_ap(T[s], ro0, ro1, ro2, ro3, oLo[s & 1], oHi[s & 1]);
                     }
-                }
+                }, std::make_integer_sequence<int, kRRSlots>{});
             }
+            RR_MFMA_SETTLE;  // (the column tiles below read their slots as operands)
             TRACE(2);
             // ---- column k + 1: L_{I,k+1}^T = X_{k+1,k+1} T_{I,k+1}^T into the slot and into panel k + 1 ----
             // (in a pass of its own: inside the pass above -- behind the tile's last product -- the step took 0.3 us longer)
@@ -2687,7 +2720,7 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     }
     Smem S;
     S.pan = smem;
-    S.dli = S.pan + (RR ? (size_t)2 * (NP / 16) * 256 : (size_t)(DF ? 3 : npanels<WIDE>()) * NP * PS);  // (RR: two buffers of nb packed tiles)
+    S.dli = RR ? smem : S.pan + (size_t)(DF ? 3 : npanels<WIDE>()) * NP * PS;  // (RR: the two buffers of nb packed tiles come LAST, see below)
     // (XWIDE: the vectors live behind the band factors and scan tables in global memory -- the W buffer, or the cs buffer in
     //  cluster mode --, only the panel, the inverse of the diagonal tile and the flags in LDS)
     double *const gscratch = CL ? P.cs : P.W;
@@ -2731,6 +2764,9 @@ __global__ __launch_bounds__(KT) void fit_loop_kernel(FitLoopParams P) {
     if constexpr (RR) {
         S.dcnt = reinterpret_cast<int *>(S.hand + (size_t)(NP / 16) * 256);  // (register-resident mode: the slot tables, behind the diagonal tiles)
         rr_tables(S.dcnt, NP / 16, tid);
+        size_t off = (size_t)(reinterpret_cast<double *>(S.dcnt + 8 * kRRTabStride) - smem);  // (doubles: every region is a multiple of 16 bytes)
+        if (off < (size_t)kRRBufferMinOffset / 8) off = (size_t)kRRBufferMinOffset / 8;
+        S.pan = smem + off;
     }
 #endif
     if constexpr (DF) {
@@ -3122,8 +3158,11 @@ __global__ void symmetrize_pad_kernel(const double *Araw, const double *bq, int 
 #ifdef FIT_LOOP_RR
 // the register-resident instantiation only (fit_loop_rr.hip compiles this file with 512 threads per workgroup)
 size_t fh_k2_loop_rr_smem_bytes(int NP) {
-    // two buffers of nb packed tiles and the nb diagonal tiles, L_kk^-1 (two), the vectors, the flags (bands, scan tables: W buffer)
-    return sizeof(double) * (size_t)(3 * (NP / 16) * 256 + 2 * 16 * PS + 8 * NP) + 32 + 4 * 48 + 4 * 8 * 32;  // (+ the slot tables)
+    // L_kk^-1 (two), the vectors, the flags, the nb diagonal tiles, the slot tables -- at least 48 KB --, then two buffers of nb
+    // packed tiles (the band factors and scan tables: the W buffer)
+    size_t front = sizeof(double) * (size_t)((NP / 16) * 256 + 2 * 16 * PS + 8 * NP) + 32 + 4 * 48 + 4 * 8 * kRRTabStride;
+    if (front < (size_t)kRRBufferMinOffset) front = kRRBufferMinOffset;
+    return front + sizeof(double) * (size_t)(2 * (NP / 16) * 256);
 }
 hipError_t fh_k2_launch_loop_rr(const FitLoopParams &P, int blocks, hipStream_t s) {
     if (P.NP / 16 > kRRMaxNB || P.cluster > 1) return hipErrorInvalidValue;
@@ -3142,7 +3181,8 @@ static size_t loop_smem_bytes_deferred(int NP) {
     return sizeof(double) * (size_t)(3 * NP * PS + 3 * 16 * PS + 8 * NP) + 16 * 256 + 32 + 4 * 48;
 }
 constexpr int kDeferMaxNP = 320;
-constexpr int kRegResidentMaxNP = 304;  // 19 block rows: 24 tiles per wave  // (161 888 of the 163 840 bytes at NP = 320)
+constexpr int kRegResidentMaxNP = 304;  // 19 block rows: 25 tiles per worker wave
+constexpr int kRegResidentMinLoops = 128;  // (161 888 of the 163 840 bytes at NP = 320)
 size_t fh_k2_loop_smem_bytes(int NP) {
     if (loop_is_xwide(NP)) return sizeof(double) * (size_t)(NP * PS + 2 * 16 * PS) + 64;  // the panel, L_kk^-1 (two), the flags
     const bool wide = loop_is_wide(NP);
@@ -3221,9 +3261,15 @@ static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s)
     // trailing update -- what a pass moves beyond the L2 is what bounds a loaded device.  FRANK_AMD_K2_DEFER=0 keeps the
     // kernel of rounds 2-4 (read at every launch: the tests compare the two inside one process).
     // The matrix resident in registers (round 5; solve_posterior_rr, fit_loop_rr.hip): the same bits, and per pass only A is read.
-    // FRANK_AMD_K2_RR=1 selects it (not the default yet: 235 us per pass against 135 alone, 242 against 184 with 256 loops resident).
-    const char *re = getenv("FRANK_AMD_K2_RR");
-    if (P.NP >= 64 && P.NP <= kRegResidentMaxNP && re && atoi(re) != 0) return fh_k2_launch_loop_rr(P, blocks, s);
+    // A loop ALONE takes 148 us per pass in this form against 135 -- eight waves, and a wave cannot issue its matrix instructions
+    // faster than one per 64 cycles (tools/microbench/mfma_f64_bench.hip) --, level at ~64 resident loops (150 us both), and from
+    // there on it is the faster one: 161 against 196 us with 256 resident.  (A run that fills the device only to drain at once pays
+    // for the slower lone passes of its last fits: 100 fits in flight 689 against 727 fits/s -- hence 128 and not 64.)  So it runs where the device is loaded: this launch and
+    // the loops resident beside it (P.loaded, the host's count) make kRegResidentMinLoops.  FRANK_AMD_K2_RR = 0 / 1 forces the choice
+    // (read at every launch: the tests compare the forms inside one process).
+    bool rr = blocks + P.loaded >= kRegResidentMinLoops;
+    if (const char *re = getenv("FRANK_AMD_K2_RR")) rr = atoi(re) != 0;
+    if (rr && P.NP >= 64 && P.NP <= kRegResidentMaxNP) return fh_k2_launch_loop_rr(P, blocks, s);
     const char *de = getenv("FRANK_AMD_K2_DEFER");
     // (from NP = 64 on: the band factors and scan tables of this form, 6 NP + 3 072 doubles, live in the fit's W buffer of NP^2
     //  doubles -- at NP = 48 they overran it by a third, which the suite only noticed as a memory fault when a small LogNormal

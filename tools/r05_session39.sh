@@ -1,0 +1,6 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=gpurun_out/r05s39; mkdir -p $OUT
+export FRANK_AMD_LIB=$PWD/frank_amd/libfrank_hip_rrx.so
+FRANK_AMD_K2_RR=1 timeout 600 python3 tools/rr_sweep.py 47 303 16 > $OUT/rr_sweep.txt 2>&1
+FRANK_AMD_K2_RR=1 timeout 600 python3 tools/k2_loaded.py 1 256 256 > $OUT/loaded.txt 2>&1
