@@ -426,3 +426,22 @@ def test_no_transcendental_result_is_read_in_the_next_slot():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_trans_hazard.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 read in the next slot" in r.stdout
+
+
+def test_no_accumulator_of_an_inline_matrix_instruction_is_read_too_early():
+    """fit_loop.hip, rr_mfma4_*: the register-resident fit loop issues its tile products from inline asm with the accumulator tied in
+    place (the builtin left the destination to the register allocator: whole-tile copies and scratch under 25 live tiles), and the
+    hazard recogniser does not look into inline asm -- a copy or spill of the tile placed directly behind a block reads registers
+    the matrix pipe has not written yet (seen: a Cholesky that failed at step 5 or 4 depending on the build).  The blocks end on 18
+    wait states; tools/check_mfma_hazard.py compiles fit_loop_rr.hip to assembly and checks every block's surroundings."""
+    import subprocess
+    import sys
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_mfma_hazard.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 followed by a read" in r.stdout
+    # ... and the check bites: without the wait states the same scan finds readers
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_mfma_hazard.py"), "-DRR_NO_BLOCK_NOPS"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 1, r.stdout + r.stderr

@@ -40,8 +40,10 @@ run_group k1first "FRANK_AMD_K1_NO_HIST_CACHE=1" "" python3 $ROOT/tools/k1_pass.
 # ... and the fit loop kernel on one N = 300 fit: one compute unit, and a cluster of five workgroups
 run_group k2 "FRANK_AMD_K2_CLUSTER=1" mfma python3 $ROOT/tools/k2_quick.py 300
 run_group k2cl "" mfma python3 $ROOT/tools/k2_quick.py 300
-# ... and the loaded form: 256 fits resident in one launch (deferred + paired kernel)
+# ... and the loaded form: 256 fits resident in one launch -- the register-resident kernel (fit_loop_kernel<0, 6>: what launch_loop
+#     picks from 128 resident loops on) and, with FRANK_AMD_K2_RR=0, the deferred + paired kernel that works in memory
 ( export FRANK_AMD_SWEEP_NO_CLUSTERS=1; run_group k2full "FRANK_AMD_SWEEP_NO_CLUSTERS=1" mfma python3 $ROOT/tools/k2_batch_pmc.py 256 )
+( export FRANK_AMD_SWEEP_NO_CLUSTERS=1 FRANK_AMD_K2_RR=0; run_group k2fullmem "FRANK_AMD_K2_RR=0" mfma python3 $ROOT/tools/k2_batch_pmc.py 256 )
 cd $ROOT
 python3 - $OUT <<'PY'
 import json, sys, os
@@ -52,7 +54,8 @@ for src, dst, pred in (("k1_all.json", "pmc_binning.json", lambda k: any(s in k 
                        ("k1first_all.json", "pmc_binning_first_sight.json", lambda k: any(s in k for s in keep1) and "<false>" not in k),
                        ("k2_all.json", "pmc_fit_loop.json", lambda k: "fit_loop" in k),
                        ("k2cl_all.json", "pmc_fit_loop_cluster.json", lambda k: "fit_loop" in k),
-                       ("k2full_all.json", "pmc_fit_loop_256_resident.json", lambda k: "fit_loop" in k)):
+                       ("k2full_all.json", "pmc_fit_loop_256_resident.json", lambda k: "fit_loop" in k),
+                       ("k2fullmem_all.json", "pmc_fit_loop_256_resident_in_memory.json", lambda k: "fit_loop" in k)):
     try:
         d = json.load(open(os.path.join(out, src)))
     except Exception as e:
