@@ -385,15 +385,19 @@ def extras(f, L, a):
         passes = nit_b[0] + 2
         tf = Bf / best * passes * (2.0 * (N + 1) ** 3 / 3.0) / 1e12
         ex["device_full"] = {"workload": "%d identical N=%d fits resident in ONE launch, one compute unit each (the batched form of "
-                                         "the sweeps; deferred trailing update + paired rows of the inverse)" % (Bf, N),
+                                         "the sweeps; the form launch_loop takes for a launch that fills the device: the matrix "
+                                         "resident in the vector registers of its compute unit, fit_loop_rr.hip)" % (Bf, N),
                              "fits_per_s": Bf / best, "s_total": best, "passes_per_fit": passes,
                              "us_per_pass_on_the_device": o3[1] / 100.0 / max(o3[2], 1), "clock_MHz": 100.0 * o3[0] / max(o3[1], 1),
                              "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                           "frac": tf / FP64_MFMA_PEAK_TFLOPS,
                                           "note": "algorithmic flops (2 n^3 / 3 per pass) of all fits over the wall time of the launch, "
-                                                  "against the whole chip's fp64 matrix peak; what holds it there is memory traffic "
-                                                  "beyond the L2, 3.5 MB per pass (profiles/r05_pmc_fit_loop_256_resident.json)"},
-                             "register_resident_form": rr}
+                                                  "against the whole chip's fp64 matrix peak; what holds it there is instruction issue "
+                                                  "(a wave issues a matrix instruction per 64 cycles at most, and with two waves on a SIMD "
+                                                  "a vector instruction costs ~65 cycles while the other's matrix instruction runs: "
+                                                  "profiles/r05_mfma_f64_issue.txt), not memory: 0.23 MB per pass beyond the L2 against the "
+                                                  "5.0 MB of the forms that work in memory (profiles/r05_pmc_fit_loop_256_resident*.json)"},
+                             "forced_register_resident_form": rr}
         if prev is None:
             del os.environ["FRANK_AMD_SWEEP_NO_CLUSTERS"]
         else:
@@ -1106,8 +1110,10 @@ def main():
             if "fits_per_s" in ss:  # the same algorithmic flops against the WHOLE chip, at the rate the pipeline sustains
                 out["roofline"]["chip_fraction_at_steady_state"] = ss["fits_per_s"] * flops_fit / 1e12 / FP64_MFMA_PEAK_TFLOPS
                 out["roofline"]["chip_note"] = ("at steady state a fit loop is one CU and up to %d fits are outstanding, in "
-                                                "launches of up to 64 fit loops (~150 loops resident: fits/s x time per fit); the rate is set by the "
-                                                "bytes both the loops and the binning passes move beyond the L2" % ss.get("fit_slots", 0))
+                                                "launches of up to 64 fit loops (~150 loops resident: fits/s x time per fit), which from 128 "
+                                                "fits in flight on keep their matrix in registers (fit_loop_rr.hip: 0.23 MB per pass beyond the "
+                                                "L2 instead of 5.0); the rate is set by what a pass of that form costs (instruction issue, 150-160 "
+                                                "us) and by the compute units the binning passes take" % ss.get("fit_slots", 0))
         if not a.no_cpu_baseline and world == 1:  # the CPU leg is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(a.ncoll, a.nvis, nit)
         print(json.dumps(out), flush=True)
