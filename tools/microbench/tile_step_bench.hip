@@ -115,6 +115,19 @@ __global__ void bench(long long *out, int iters, double seed) {
                 if (VAR == 22) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
                 if (VAR == 23) asm volatile("s_sleep 1");
                 if (VAR == 24) asm volatile("s_sleep 2");
+            } else if (VAR >= 30 && VAR <= 36) {  // read ahead, wait, four products, a tail of wait states of varying length
+                ISSUE(lo[(s + 1) & 1], hi[(s + 1) & 1], nxt);
+                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\tv_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\t"
+                             "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\tv_mfma_f64_16x16x4_f64 %0, %4, %8, %0"
+                             : "+v"(T[s]) : "v"(lo[s & 1][0]), "v"(lo[s & 1][1]), "v"(hi[s & 1][0]), "v"(hi[s & 1][1]), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+                if (VAR == 30) asm volatile("s_nop 5");
+                if (VAR == 31) asm volatile("s_nop 11");
+                if (VAR == 32) asm volatile("s_nop 15\n\ts_nop 7");
+                if (VAR == 33) asm volatile("s_nop 15\n\ts_nop 15");
+                if (VAR == 34) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15");
+                if (VAR == 35) asm volatile("s_sleep 1");
+                if (VAR == 36) asm volatile("s_nop 15\n\ts_nop 2\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0");
             } else if (VAR == 3) {  // products only (no LDS)
                 asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\tv_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\t"
                              "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\tv_mfma_f64_16x16x4_f64 %0, %4, %8, %0"
@@ -142,11 +155,18 @@ void run(int threads, long long *d, const char *what) {
 int main() {
     long long *d;
     (void)hipMalloc(&d, 64 * sizeof(long long));
-    for (int threads : {64, 256, 512}) {
+    for (int threads : {512}) {
         run<3>(threads, d, "four products, no LDS:");
         run<1>(threads, d, "read ahead, wait, four products:");
         run<0>(threads, d, "read ahead, wait, four products, 18 wait states:");
         run<2>(threads, d, "reads between the products:");
+        run<30>(threads, d, "read ahead, wait, products, 6 wait states:");
+        run<31>(threads, d, "read ahead, wait, products, 12 wait states:");
+        run<32>(threads, d, "read ahead, wait, products, 24 wait states:");
+        run<33>(threads, d, "read ahead, wait, products, 32 wait states:");
+        run<34>(threads, d, "read ahead, wait, products, 48 wait states:");
+        run<35>(threads, d, "read ahead, wait, products, s_sleep 1:");
+        run<36>(threads, d, "read ahead, wait, products, 18 wait states + 10 scalar:");
         run<20>(threads, d, "products, reads, 18 wait states:");
         run<21>(threads, d, "products, reads, 32 wait states:");
         run<22>(threads, d, "products, reads, 64 wait states:");
