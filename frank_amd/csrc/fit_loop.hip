@@ -2196,38 +2196,18 @@ __device__ __forceinline__ void rr_tables(int *tab, int nb, int tid) {
 // front), and a read of T by anything but the next in-place product must come 18 wait states after the last product -- also
 // the copies and spills the register allocator may place directly behind a block, which is why the block itself ends on them
 // (a first version waited once per step, before its own reads: its results depended on where the allocator put its copies).
-// (the operand a row shares travels as four separate 64-bit pairs: a whole-tile operand was copied in front of every product)
+// (the operand a row shares travels as four separate 64-bit pairs: a whole-tile operand was copied in front of every product;
+//  RR_NO_BLOCK_NOPS: the blocks without their wait states, for tools/check_mfma_hazard.py's self-test only)
 #ifdef RR_NO_BLOCK_NOPS
 #define RR_BLOCK_TAIL
 #else
 #define RR_BLOCK_TAIL "\n\ts_nop 15\n\ts_nop 2" /* the results settle before anything the compiler may place behind the block reads them */
 #endif
-__device__ __forceinline__ void rr_mfma4_b(v4f64 &T, const v4f64 &a, double b0, double b1, double b2, double b3) {
-    asm volatile("s_nop 1\n\t"
-                 "v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\t"
-                 "v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\t"
-                 "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\t"
-                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0" RR_BLOCK_TAIL
-                 : "+v"(T)
-                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
-}
-__device__ __forceinline__ void rr_mfma4_a(v4f64 &T, double a0, double a1, double a2, double a3, const v4f64 &b) {
-    asm volatile("s_nop 1\n\t"
-                 "v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\t"
-                 "v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\t"
-                 "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\t"
-                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0" RR_BLOCK_TAIL
-                 : "+v"(T)
-                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
-}
 #define RR_MFMA_SETTLE asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")
 // The operand tile of a slot, read from LDS ONE SLOT AHEAD by hand (two ds_read_b128, issued and waited for explicitly: the wait is
 // "all but the two reads issued last", which the compiler's own counting cannot express across the branches of the slots).  The
 // reads are issued at every slot, used or not -- no register of the double buffer is ever defined under a branch.
-__device__ __forceinline__ void rr_lds_issue(v2f64 &lo, v2f64 &hi, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory");
-}
-// ... with the address as a row's base + a compile-time offset: within a row the slots go down the columns one by one, J = c - s, so
+// The address is a row's base + a compile-time offset: within a row the slots go down the columns one by one, J = c - s, so
 // the operand of slot s is at (buffer + (c - 24) tiles) + (24 - s) tiles -- one vector add per ROW (2 - 6 per pass) instead of
 // one per slot.  (The buffers sit behind >= 48 KB of LDS -- the vectors, the diagonal tiles, padding for the small sizes -- so
 // that a base never falls below the start of LDS.)
@@ -2269,7 +2249,6 @@ __device__ __forceinline__ bool solve_posterior_rr(const FitLoopParams &P, const
         S.flag[0] = 0;  // not positive definite
         S.flag[3] = 0;  // index of the last diagonal tile whose inverse is in LDS
         S.flag[4] = 0;  // rows of the inverse whose raw sums are in LDS
-        S.flag[7] = 0;
         S.flag[5] = S.flag[6] = 0;  // work items of a step that any wave may take (even / odd steps)
     }
     __syncthreads();
