@@ -718,15 +718,18 @@ __global__ __launch_bounds__(256) void vr_finish_kernel(VrGramParams G, double *
 int fh_prepass_moment_doubles() { return kMomAll; }
 
 // Geometry of P1 / P2 for nb buckets on a device of num_cu compute units: waves per workgroup, workgroups.  P2 keeps
-// (waves + 1) counters per bucket in LDS; two workgroups of eight waves per compute unit (one's barriers and stores beside the
-// other's arithmetic: 154 against 189 us per 1e7 rows for one of sixteen) while that fits 72 KB each -- 2 048 buckets --,
+// (waves + 1) counters per bucket in LDS; workgroups of eight waves, two resident per compute unit (one's barriers and stores beside
+// the other's arithmetic: 154 against 189 us per 1e7 rows for one of sixteen) while that fits 72 KB each -- 2 048 buckets --,
 // fewer waves per workgroup beyond (one at 9 000 buckets and more: 128 KB at the 16 000 the sort admits).
 void fh_prepass_geometry(int nb, int num_cu, int *wpb, int *blocks) {
     int w = 8;
     const size_t n = (size_t)(nb > 0 ? nb : 1);
     while (w > 1 && (size_t)(w + 1) * n * sizeof(int) > (w == 1 ? 144 : 72) * 1024) w >>= 1;
     *wpb = w;
-    *blocks = (num_cu > 0 ? num_cu : 256) * (16 / w);
+    // (round 5: THREE workgroups of eight waves per compute unit's worth, not two -- the same 0.27 ms per 1e7 rows with the device
+    //  to itself, but a pipeline's binning passes find ~110 units free beside the resident fit loops, where 512 workgroups run in
+    //  three rounds the last of which fills a third of them: 1 400-1 412 against 1 368-1 378 fits/s at steady state)
+    *blocks = (num_cu > 0 ? num_cu : 256) * (w == 8 ? 3 : 16 / w);
 }
 
 int64_t fh_prepass_max_pieces(int64_t count, int nb, int seg_rows) { return count / seg_rows + 2 * (int64_t)nb + 2; }

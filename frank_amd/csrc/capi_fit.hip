@@ -911,11 +911,15 @@ static int flush_pending_batch(fh_ctx *c) {
     P.result_host = c->slot_result_host;
     P.cluster = b.cluster;
     // (the fits in flight beside this launch: from ~128 resident loops on the register-resident form of the loop is the faster one,
-    //  fit_loop.hip.  The slots that are out stand for the loops that run -- a pipeline that keeps 128 fits in flight is a loaded
-    //  device; counting the loops exactly means a query per launch in flight, and with the threshold on that count a pipeline at
-    //  steady state, ~140 running, went back and forth between the forms: 1 369 against 1 430 fits/s.  A run of 20 or 100 fits that
-    //  drains at once -- bench.py's timed region -- never gets there and keeps the form that is faster alone.)
-    P.loaded = c->slots_busy >= 128 ? c->slots_busy : 0;
+    //  fit_loop.hip.  The slots that are out stand for the loops that run -- counting the loops exactly means a query per launch in
+    //  flight, and with the threshold on that count a pipeline at steady state, ~140 running, went back and forth between the
+    //  forms: 1 369 against 1 430 fits/s.  A context whose pipeline has once held 128 fits is a throughput context from then on:
+    //  when it fills again after a drain its first launches do not go back to the form that works in memory, whose loops then hold
+    //  their compute units for the next 0.13 s beside everything that follows -- 1 380-1 440 against 1 490-1 520 fits/s over 2 s
+    //  windows.  A run of 20 or 100 fits that drains at once -- bench.py's timed region -- never gets there and keeps the form that
+    //  is faster alone.)
+    if (c->slots_busy >= 128) c->throughput_context = true;
+    P.loaded = c->throughput_context ? (c->slots_busy > 128 ? c->slots_busy : 128) : 0;
     if (b.cluster > 1) {  // the fits of consecutive cluster launches go round the XCDs
         P.cluster_xcd0 = c->next_xcd & 7;
         c->next_xcd = (c->next_xcd + b.n) & 7;

@@ -282,6 +282,8 @@ struct fh_ctx {
     hipEvent_t stream_last_done[kLaunchStreamsMax] = {};  // completion event of the last launch each launch stream was given
     size_t slot_stride = 0;
     int slots_busy = 0;
+    bool throughput_context = false;      // the pipeline of this context has had 128 fits in flight: its launches take the form of
+                                          // the fit loop that is faster on a loaded device (capi_fit.hip, fit_loop.hip: launch_loop)
     int last_fit_cluster = 1;             // workgroups the last fh_fit_normal ran on
     unsigned long long cluster_fallbacks = 0;  // cluster launches that ended with FIT_STATUS_CLUSTER and were repeated on one CU
     bool have_device_Mj = false;
