@@ -429,6 +429,7 @@ void load_k1_env(fh_ctx *c) {
 int fh_ctx_reload_env(fh_ctx *c) {
     if (!c) return fail(FH_ERR_INVALID, "fh_ctx_reload_env: NULL argument");
     load_k1_env(c);
+    c->throughput_context = false;  // (the pipeline's memory of having been full: capi_fit.hip)
     return FH_OK;
 }
 static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned long long vis_serial,

@@ -291,7 +291,9 @@ int fh_fit_cluster_info(fh_ctx *ctx, int *workgroups, int64_t *fallbacks);
 int fh_cache_release(void);
 
 /* The development switches of the binning pass (FRANK_AMD_K1_*, FRANK_AMD_NO_RANGE_CACHE) are read from the environment ONCE,
- * when a context is created; this reads them again (tests that switch them inside one process).                          */
+ * when a context is created; this reads them again (tests that switch them inside one process).  It also makes the context
+ * forget that its pipeline has once held 128 fits (from then on its one-unit fit loops keep the form that is faster on a loaded
+ * device, fit_loop_rr.hip; FRANK_AMD_K2_RR, read at every launch, overrides the choice either way).                        */
 int fh_ctx_reload_env(fh_ctx *ctx);
 
 /* Measurement aid (no counterpart in the reference): the clock the fit loops of this context ran at.  on != 0 switches a
