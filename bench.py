@@ -242,6 +242,21 @@ def steady_state(f, L, steps=0, ring=0, min_seconds=2.0):
                         ("the headline step on a ring of %d different resident tables, baseline-range cache off" % ring)}
 
 
+class _stdout_to_stderr:
+    """File descriptor 1 pointed at file descriptor 2 for the duration (output of C++ libraries included)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def usable_cpus():
     """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container on a 256-thread
     host is often given a few cores; oversubscribing them 30x is what a naive os.cpu_count() pool does)."""
@@ -918,11 +933,24 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # (gloo announces its mesh on STDOUT from C++ -- "[Gloo] Rank 3 is connected to 7 peer ranks ..." -- from every rank and no
+        #  environment switch turns that off; this program's stdout is ONE JSON line: file descriptor 1 is pointed at stderr while
+        #  the group forms and while the first barrier runs.  That barrier comes AFTER this process has created its device context:
+        #  torch.distributed probes torch's own HIP runtime in it, and a process whose first HIP call went to that runtime finds
+        #  no device through the library's)
+        with _stdout_to_stderr():
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    first_barrier = [dist is not None]
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            if first_barrier[0]:
+                first_barrier[0] = False
+                with _stdout_to_stderr():
+                    dist.barrier()
+            else:
+                dist.barrier()
 
     ndev = max(L.device_count(), 1)
     f = Fitter(L, a.ncoll, local_rank % ndev)  # (more ranks than GPUs only happens in the 1-GPU smoke run of this path)
