@@ -858,3 +858,30 @@ def test_predict_through_bucket_tables(golden):
     assert np.abs(V_tab - V_dir).max() < 1e-13 * scale
     H = fo.DHT(RMAX, N).coefficients(q[:3000]) * np.cos(MOCK_GEOMETRY["inc"] * np.pi / 180)
     assert np.abs(V_tab[:3000] - H @ I).max() < 1e-12 * scale
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_from_two_ranks():
+    """The driver's contract for bench.py: rank 0 prints ONE JSON line on stdout, nothing else comes from any rank -- also when the
+    ranks share the one device of the box (HostComm) and gloo announces its mesh ("[Gloo] Rank 1 is connected to 1 peer ranks
+    ...", which it prints to stdout from C++ in every rank: bench.py sends that to stderr).  Two ranks, three steps of a small table."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--nvis", "200000",
+           "--no-sharded", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["unit"] == "fits/s"
