@@ -155,7 +155,7 @@ void run(int threads, long long *d, const char *what) {
 int main() {
     long long *d;
     (void)hipMalloc(&d, 64 * sizeof(long long));
-    for (int threads : {512}) {
+    for (int threads : {64, 256, 512, 768, 1024}) {
         run<3>(threads, d, "four products, no LDS:");
         run<1>(threads, d, "read ahead, wait, four products:");
         run<0>(threads, d, "read ahead, wait, four products, 18 wait states:");
