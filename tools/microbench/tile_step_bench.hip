@@ -128,6 +128,19 @@ __global__ void bench(long long *out, int iters, double seed) {
                 if (VAR == 34) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15");
                 if (VAR == 35) asm volatile("s_sleep 1");
                 if (VAR == 36) asm volatile("s_nop 15\n\ts_nop 2\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0");
+            } else if (VAR == 40 || VAR == 41) {  // ONE operand for TWO tile products (no copies): two rows of a wave share the column
+                if ((s & 1) == 0) {
+                    ISSUE(lo[((s >> 1) + 1) & 1], hi[((s >> 1) + 1) & 1], nxt);
+                    asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                    asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\tv_mfma_f64_16x16x4_f64 %1, %2, %10, %1\n\t"
+                                 "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\tv_mfma_f64_16x16x4_f64 %1, %3, %11, %1\n\t"
+                                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n\tv_mfma_f64_16x16x4_f64 %1, %4, %12, %1\n\t"
+                                 "v_mfma_f64_16x16x4_f64 %0, %5, %9, %0\n\tv_mfma_f64_16x16x4_f64 %1, %5, %13, %1"
+                                 : "+v"(T[s]), "+v"(T[s + 1])
+                                 : "v"(lo[(s >> 1) & 1][0]), "v"(lo[(s >> 1) & 1][1]), "v"(hi[(s >> 1) & 1][0]), "v"(hi[(s >> 1) & 1][1]), "v"(b0), "v"(b1),
+                                   "v"(b2), "v"(b3), "v"(b3), "v"(b2), "v"(b1), "v"(b0));
+                    if (VAR == 41) asm volatile("s_nop 15\n\ts_nop 2");
+                }
             } else if (VAR == 3) {  // products only (no LDS)
                 asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\tv_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\t"
                              "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\tv_mfma_f64_16x16x4_f64 %0, %4, %8, %0"
@@ -167,6 +180,8 @@ int main() {
         run<34>(threads, d, "read ahead, wait, products, 48 wait states:");
         run<35>(threads, d, "read ahead, wait, products, s_sleep 1:");
         run<36>(threads, d, "read ahead, wait, products, 18 wait states + 10 scalar:");
+        run<40>(threads, d, "ONE operand read for TWO tile products:");
+        run<41>(threads, d, "ONE operand read for TWO tile products, 18 wait states:");
         run<20>(threads, d, "products, reads, 18 wait states:");
         run<21>(threads, d, "products, reads, 32 wait states:");
         run<22>(threads, d, "products, reads, 64 wait states:");
