@@ -505,7 +505,7 @@ __global__ __launch_bounds__(1024) void bucket_factor2_kernel(PrepassParams P) {
     const int c = P.cidx[b];
     if (threadIdx.x == 0) P.vbucket[c] = b;
     double *out = P.vrows + (size_t)c * 256;
-    if (tot <= 16) {
+    if (tot <= 16 && !P.fused) {
         if (threadIdx.x < 16) {
             const double *rp = P.rows + ((size_t)P.starts[b] + lane) * 3;  // (rows past the bucket's last one are zero rows)
             const double tau = rp[0], sw = rp[1], swV = rp[2];
@@ -792,6 +792,23 @@ hipError_t fh_prepass_launch(const PrepassParams &P, hipStream_t stream, int ski
     if (e != hipSuccess) return e;
     const int64_t max_pieces = fh_prepass_max_pieces(P.bin.count, P.nb, P.seg_rows);
     hipLaunchKernelGGL(piece_moments_kernel, dim3((unsigned)((max_pieces + 3) / 4)), dim3(256), lds3, stream, P);
+    hipLaunchKernelGGL(bucket_factor2_kernel, dim3(P.nb), dim3(1024), 0, stream, P);
+    return hipGetLastError();
+}
+
+// the pieces of fh_prepass_launch the fused form (bin_fused.hip) uses: P1 + scan, and the factorisation of the buckets' moments
+hipError_t fh_prepass_launch_hist(const PrepassParams &P, hipStream_t stream) {
+    const size_t lds1 = sizeof(int) * (size_t)P.nb;
+    if (lds1 > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&uv_hist_kernel<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(uv_hist_kernel<true>, dim3(P.blocks), dim3(64 * P.wpb), lds1, stream, P);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3((P.nb + 15) / 16), dim3(1024), 0, stream, P);
+    return hipGetLastError();
+}
+hipError_t fh_prepass_launch_factor(const PrepassParams &P, hipStream_t stream) {
     hipLaunchKernelGGL(bucket_factor2_kernel, dim3(P.nb), dim3(1024), 0, stream, P);
     return hipGetLastError();
 }

@@ -214,6 +214,7 @@ struct fh_ctx {
     DevBuf<double> k1_vrows;        // compressed rows (fh_k1v2_launch_compress): one 16 x 16 chunk per non-empty bucket
     DevBuf<int> k1_cidx, k1_vbucket;
     DevBuf<int> k1_piece0;          // bin_prepass.hip: first partial-moment slot of every bucket
+    DevBuf<int> k1_slot_tab;        // bin_fused.hip: accumulator slots of every bucket, [nb] then the number of slots
     int bin_cus = 0;                // fh_ctx_set_cu_partition
     bool no_range_cache = false;    // fh_ctx_set_range_cache(ctx, 0): look at (u, v) on every pass (benchmarks of distinct tables)
     // development switches of the binning pass (FRANK_AMD_K1_*, FRANK_AMD_NO_RANGE_CACHE), read ONCE when the context is created
@@ -222,6 +223,7 @@ struct fh_ctx {
         int unroll = 2, seg = 4096, wpb = 0, blocks = 0, vrwaves = 8, vrsplit = 8, vrblocks = 0;
         bool no_range_cache = false, safe_trig = false, no_hist_cache = false, vr_slabs = false, dynamic = false;
         double reserve_mult = -1.0;
+        int fused = 0;  // FRANK_AMD_K1_FUSED: the one-pass form of the moments pre-pass (bin_fused.hip)
     } k1env;
     // baseline range of the last pre-pass, keyed by (table, row range, geometry): binning the same rows under the same geometry
     // again (bootstrap draws, pipelines of fits, sweeps) needs no second look at the range before the sort is sized
@@ -234,6 +236,7 @@ struct fh_ctx {
     // launch geometry: a pass over the same rows skips P1 and the scan (16 of its 104 bytes per row)
     bool hist_valid = false;
     int hist_nb = 0, hist_blocks = 0, hist_wpb = 0, hist_unroll = 0, hist_seg = 0;
+    bool hist_fused = false;
     std::vector<double> a_host;      // finalize scale vector (stays alive behind an asynchronous copy)
     bool a_scale_valid = false;
     double a_scale_value = 0.0;

@@ -423,6 +423,7 @@ void load_k1_env(fh_ctx *c) {
     const char *vr = getenv("FRANK_AMD_K1_VR");
     e.vr_slabs = vr && !strcmp(vr, "slabs");
     e.dynamic = getenv("FRANK_AMD_K1_DYNAMIC") != nullptr;
+    e.fused = env_int("FRANK_AMD_K1_FUSED", 0);
     if (const char *r = getenv("FRANK_AMD_K1_RESERVE_MULT")) e.reserve_mult = atof(r);
     c->k1env = e;
 }
@@ -535,11 +536,33 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     P.vbucket = c->k1_vbucket.p;
     // the same rows under the same geometry as the last pass of this context (bootstrap-free pipelines, sweeps that re-bin, the
     // bench's steps): the histograms, their scan and the table layout are still in place -- P1 and the scan are skipped
+    // the fused form (bin_fused.hip, opt-in): one pass over the table, the buckets' moments accumulated in LDS -- when every bucket
+    // has an accumulator slot there; not for multiplicities or fp32 tables (they keep the sorted path)
+    const int fused_slots = fh_fused_max_slots(nb);
+    const bool fused = E.fused > 0 && !p.mult && !p.u32 && fused_slots >= nb;
+    const int fused_G = c->num_cu > 0 ? c->num_cu : 256;
+    if (fused) {
+        const size_t need = (size_t)nb * fused_G * md;
+        if (c->k1_partial.n < need && c->k1_partial.alloc(need + 4096) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc (moments) failed");
+        P.partial = c->k1_partial.p;
+        if (c->k1_slot_tab.n < (size_t)nb + 1 && c->k1_slot_tab.alloc((size_t)nb + 257) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc failed");
+        P.fused = 1;
+    }
     const bool reuse = known && c->hist_valid && c->hist_nb == nb && c->hist_blocks == P.blocks && c->hist_wpb == P.wpb &&
-                       c->hist_unroll == P.unroll && c->hist_seg == seg && !E.no_hist_cache;
+                       c->hist_unroll == P.unroll && c->hist_seg == seg && c->hist_fused == fused && !E.no_hist_cache;
     c->hist_valid = false;
-    HIP_TRY(fh_prepass_launch(P, c->stream, reuse ? 1 : 0));
+    if (fused) {
+        if (!reuse) {
+            HIP_TRY(fh_prepass_launch_hist(P, c->stream));
+            HIP_TRY(fh_fused_launch_layout(P, fused_G, fused_slots, c->k1_slot_tab.p, c->k1_slot_tab.p + nb, c->stream));
+        }
+        HIP_TRY(fh_fused_launch(P, c->k1_slot_tab.p, fused_slots, fused_G, P.blocks, c->stream));
+        HIP_TRY(fh_prepass_launch_factor(P, c->stream));
+    } else {
+        HIP_TRY(fh_prepass_launch(P, c->stream, reuse ? 1 : 0));
+    }
     c->hist_valid = true;
+    c->hist_fused = fused;
     c->hist_nb = nb;
     c->hist_blocks = P.blocks;
     c->hist_wpb = P.wpb;

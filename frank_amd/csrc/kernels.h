@@ -112,6 +112,7 @@ struct PrepassParams {
     double *vrows;            // [non-empty bucket][16][16]: the input of bin_gram2_kernel<.., VR = true>
     int *vbucket;             // [non-empty bucket]
     double *partial_scalars;  // [workgroup][4]: sum log(w / 2 pi), qmin, qmax (rows of multiplicity > 0), qmax (all rows)
+    int fused;                // bin_fused.hip: every bucket's moments come from `partial` (piece0[b] = b x workgroups), no sorted rows
 };
 // Gram of the virtual rows, one workgroup (x split) per output tile (bin_prepass.hip)
 struct VrGramParams {
@@ -133,6 +134,13 @@ int64_t fh_prepass_max_pieces(int64_t count, int nb, int seg_rows);
 hipError_t fh_prepass_launch_range(const PrepassParams &P, hipStream_t stream);  // baseline range only (partial_scalars)
 // P1, scan, P2, P3, factor; skip_hist: the histograms, their scan and the layout of the last pass still describe these rows
 hipError_t fh_prepass_launch(const PrepassParams &P, hipStream_t stream, int skip_hist = 0);
+// the fused form (bin_fused.hip): P1 + scan as above (skip_hist), then the layout of the accumulator slots and ONE pass over the table
+hipError_t fh_prepass_launch_hist(const PrepassParams &P, hipStream_t stream);
+hipError_t fh_prepass_launch_factor(const PrepassParams &P, hipStream_t stream);
+int fh_fused_slot_doubles();
+int fh_fused_max_slots(int nb);
+hipError_t fh_fused_launch_layout(const PrepassParams &P, int G, int max_slots, int *slot_tab, int *nslots_out, hipStream_t stream);
+hipError_t fh_fused_launch(const PrepassParams &P, const int *slot_tab, int max_slots, int G, int scalar_blocks, hipStream_t stream);
 
 int fh_k1v2_moment_doubles();
 hipError_t fh_k1v2_launch_compress(const CompressParams &cp, hipStream_t stream);
