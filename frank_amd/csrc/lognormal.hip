@@ -415,30 +415,85 @@ __device__ __forceinline__ void build_hess_rows(const LogNormalParams &P, const 
         }
     }
 }
+// The copy of the Hessian that the tiled Cholesky factors (cholesky_as_lu), in PACKED 16 x 16 tiles (tile_chol.h: tile (I, J) at
+// (I nb + J) * 256 doubles, two contiguous 1 KB halves in the register layout of the matrix instructions): the lower tiles
+// I >= J and the tiles (0, I) of the first block row -- what the factorisation reads before it has written it.  Element (row b,
+// column a) is (I_a M_ab) I_b + ..., the bits of build_hess_rows(.., outer_first = false); rows and columns past N hold the
+// identity.  A wave builds whole tiles: tiles gw, gw + nwaves, .. of one enumeration (the cluster deals them round its
+// workgroups: the same bits whoever builds a tile).  Round 5 kept this copy row-major: a tile of the factorisation was then four
+// 8-byte loads per lane over four 128-byte rows, ~3 000 cycles per trailing tile against ~600 for a packed one (LABNOTES).
+__device__ __forceinline__ void build_hess_tiles(const LogNormalParams &P, const double *Iv, const double *MIv, const double *jv,
+                                                 double *Cp, int part, int nparts) {
+    using namespace tilechol;
+    const int N = P.N, nb = P.NP / 16;
+    const int tid = ln_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 15, rg = lane >> 4;
+    const int nlow = nb * (nb + 1) / 2, ntiles = nlow + nb - 1;
+    gdouble *Cg = as_global(Cp);
+    const gdouble *Mg = as_global(P.M), *Sg = as_global(P.Sinv);
+    for (int t = part * LNW + wave; t < ntiles; t += nparts * LNW) {
+        int I, J;
+        if (t < nlow) {
+            I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while ((I + 1) * (I + 2) / 2 <= t) ++I;
+            while (I * (I + 1) / 2 > t) --I;
+            J = t - I * (I + 1) / 2;
+        } else {
+            I = 0;
+            J = t - nlow + 1;
+        }
+        const int a = 16 * J + cl, ac = min(a, N - 1);
+        double vm[4], vs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // (every load issued: rows and columns past N are clamped and replaced below)
+            const int bc = min(16 * I + rg + 4 * q, N - 1);
+            vm[q] = Mg[(size_t)bc * N + ac];
+            vs[q] = Sg[(size_t)bc * N + ac];
+        }
+        const double Ia = Iv[ac];
+        v4f64 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = 16 * I + rg + 4 * q;
+            double v = Ia * vm[q] * Iv[min(b, N - 1)];
+            if (a == b) v += Ia * MIv[ac] - Ia * jv[ac];
+            v += vs[q];
+            o[q] = (a < N && b < N) ? v : (a == b ? 1.0 : 0.0);
+        }
+        st_pk(Cg, (unsigned)((I * nb + J) * 2048), lane, o);
+    }
+}
+// element (i, j) of the padded matrix in the packed layout (doubles)
+__device__ __forceinline__ size_t pk_elem(int i, int j, int nb) {
+    const int r = i & 15, c = j & 15, q = r >> 2, ln = (r & 3) * 16 + c;
+    return ((size_t)((i >> 4) * nb + (j >> 4))) * 256 + (size_t)((q >> 1) * 128 + ln * 2 + (q & 1));
+}
 __device__ __forceinline__ void build_hess(const LogNormalParams &P, LnS &S, double *out, int ld, bool outer_first) {
     LTIC();
     build_hess_rows(P, S.I, S.MI, S.jv, out, ld, outer_first, 0, 1);
     __syncthreads();
     LTOC(3);
 }
-// The padded copy the tiled Cholesky factors, built by the whole cluster (single fits): I and M I go to the helpers through the
+// The packed copy the tiled Cholesky factors, built by the whole cluster (single fits): I and M I go to the helpers through the
 // two global vectors that S^-1 and Tr2 use at other times; a cluster that does not answer is disbanded and the copy rebuilt here.
 __device__ __forceinline__ void build_hess_padded(const LogNormalParams &P, LnS &S, double *Cp) {
+    LTIC();
     if (S.cluster <= 1) {
-        build_hess(P, S, Cp, P.NP, false);
+        build_hess_tiles(P, S.I, S.MI, S.jv, Cp, 0, 1);
+        __syncthreads();
+        LTOC(3);
         return;
     }
-    LTIC();
     for (int i = ln_tid(); i < P.N; i += LT) {
         P.rk_g[i] = S.I[i];
         P.tr2_g[i] = S.MI[i];
     }
     cluster_dispatch(P, LN_CMD_HESS, S.same_xcd, S.seq);
-    build_hess_rows(P, S.I, S.MI, S.jv, Cp, P.NP, false, 0, S.cluster);
+    build_hess_tiles(P, S.I, S.MI, S.jv, Cp, 0, S.cluster);
     if (!cluster_wait(P, S.s_cl, S.same_xcd)) {
         if (ln_tid() == 0) __hip_atomic_store(&P.ctl[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // disbanded
         S.cluster = 1;
-        build_hess_rows(P, S.I, S.MI, S.jv, Cp, P.NP, false, 0, 1);
+        build_hess_tiles(P, S.I, S.MI, S.jv, Cp, 0, 1);
         __syncthreads();
     }
     LTOC(3);
@@ -452,28 +507,49 @@ __device__ __forceinline__ void build_hess_padded(const LogNormalParams &P, LnS 
 // as the unit-lower / upper pair the solves expect: H = (L D^-1)(D L^T), D = diag(L), identity permutation -- the LU
 // factorisation WITHOUT pivoting, which is what partial pivoting would also choose for a diagonally dominant matrix and
 // equally backward stable for a positive definite one.  A non-positive pivot leaves S.lu untouched and the pivoted LU
-// runs as before.  Cp: the padded copy (row-major, symmetric, leading dimension NP), factored in place: lower blocks = L,
-// strictly-upper blocks = L^T (mirror).
+// runs as before.  Cp: the padded copy in packed tiles (build_hess_tiles); its trailing tiles are updated in place.
+// Round 6: the copy is in PACKED tiles (build_hess_tiles), and a step has ONE barrier, as the fit loop's factorisation
+// (fit_loop.hip: solve_posterior): wave 0 -- the chain -- updates, factors and inverts diagonal tile k + 1 while the other seven
+// update the tiles right of column k + 1; a worker then takes its tiles of column k + 1, waits for the chain's flag and turns
+// them into panel k + 1 straight from the registers -- two panels in LDS in turn -- and into the two triangles of the factors.
+// Same products, same operands and the same order into every tile as the routine of rounds 3-5 (two barriers per step, panel
+// from the mirror tiles in memory): the same bits (tests: the LogNormal fits land on the Newton counts they had).
+// LDS: the solve vectors' space and the LU panel behind it (fh_ln_chol_doubles): two panels, two L_kk^-1, diag(L) and its
+// reciprocals, flags, the tile table.
+constexpr int kCholMaxTiles = 171;  // tiles right of column 1 at nb = 20
+__host__ __device__ constexpr int fh_ln_chol_doubles(int NP) {
+    return 2 * NP * tilechol::PS + 2 * 16 * tilechol::PS + 2 * NP + 4 + (kCholMaxTiles + 1) / 2;
+}
+__device__ __forceinline__ double *chol_dvec(const LnS &S, int NP) { return S.wsol + 2 * NP * tilechol::PS + 2 * 16 * tilechol::PS; }
 __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S, double *Cp, double *Xd = nullptr) {
     using namespace tilechol;
-    const int N = P.N, NP = P.NP, nb = NP / 16, ld = NP;
+    const int N = P.N, NP = P.NP, nb = NP / 16;
     const int tid = ln_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
     const int cl = lane & 15, rg = lane >> 4;
-    double *pan = S.pan;                 // NP x PS panel (the LU panel's space: N * LU_NB doubles)
-    double *dli = pan + NP * PS, *dvec = dli + 16 * PS, *rdv = dvec + NP;  // inverse of the current diagonal tile; diag(L), 1 / diag(L)
-    int *flag = reinterpret_cast<int *>(rdv + NP);
-    int *lst = flag + 2;                 // tile list of the current trailing update: nb (nb - 1) / 2 entries at most
-    gdouble *Cg = as_global(Cp);
+    double *pan0 = S.wsol, *dli0 = pan0 + 2 * NP * PS;
+    double *dvec = chol_dvec(S, NP), *rdv = dvec + NP;  // diag(L), 1 / diag(L)
+    int *flag = reinterpret_cast<int *>(rdv + NP);      // [0] a pivot that is not positive, [1] last diagonal tile whose inverse is in LDS
+    int *tab = flag + 8;                                // tile e = (i - 1) i / 2 + (j - 1), 1 <= j <= i, relative to block (k+1, k+1): i << 8 | j
+    auto pan_of = [&](int k) { return pan0 + (size_t)(k & 1) * NP * PS; };
+    auto dli_of = [&](int k) { return dli0 + (k & 1) * 16 * PS; };
+    gdouble *Cg = as_global(uniform_ptr(Cp));
     gdouble *lu = as_global(S.lu);       // the factors go straight to their final place: column-major N x N, unit-lower L D^-1
                                          // below the diagonal, D L^T on and above it (both scalings need the diagonal of block
                                          // column k only, known when its tile is factored)
     LTIC();
-    if (tid == 0) *flag = 0;
+    if (tid == 0) flag[0] = flag[1] = 0;
+    for (int e = tid; e < (nb - 1) * (nb - 2) / 2; e += LT) {
+        int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        while ((i + 1) * (i + 2) / 2 <= e) ++i;
+        while (i * (i + 1) / 2 > e) --i;
+        tab[e] = ((i + 1) << 8) | (e - i * (i + 1) / 2 + 1);
+    }
     // factor + invert diagonal tile k (held in `t`, accumulator layout); write its part of the factors
     auto diag_tile = [&](int k, v4f64 t) {
         v4f64 x;
+        double *dli = dli_of(k);
         const bool ok = chol_inv_tile_acc(t, x, lane, -1);
-        if (!ok && lane == 0) *flag = 1;
+        if (!ok && lane == 0) flag[0] = 1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             dli[(rg + 4 * r) * PS + cl] = x[r];
@@ -501,123 +577,153 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
             }
         }
     };
-    auto load_acc = [&](int I, int J) {
-        v4f64 a;
-        const gdouble *c1 = Cg + (size_t)(16 * I + rg) * ld + 16 * J + cl;
+    // a panel tile: D = L_kk^-1 T^T = L_Ik^T from T^T (accumulator layout) -> LDS panel `pan` (unscaled, for the trailing updates)
+    // and, scaled, into the factors.  Element (a, b) of D is L[16 I + b][16 k + a]: its store runs along a column of the
+    // unit-lower part; the upper part wants the transposed tile, which is the same product with the operands exchanged (the
+    // accumulator registers of T^T are the A fragments of T, the A fragments of X the B fragments of X^T).
+    auto panel_tile = [&](int k, int I, const Frag &fx, const Frag &ft, double *pan) {
+        const v4f64 z = {0.0, 0.0, 0.0, 0.0};
+        const v4f64 d = mfma4(fx, ft, z, false);
+        const v4f64 dt = mfma4(ft, fx, z, false);
+        const double dck = dvec[16 * k + cl];
+        double *pr = pan + (size_t)((I - k - 1) * 16 + cl) * PS + rg;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = c1[(size_t)(4 * r) * ld];
-        return a;
+        for (int r = 0; r < 4; ++r) {
+            pr[4 * r] = d[r];
+            const int a = 16 * k + rg + 4 * r, b = 16 * I + cl;
+            if (a < N && b < N) lu[(size_t)a * N + b] = d[r] * rdv[a];  // (L D^-1)[b][a]
+            const int bt = 16 * I + rg + 4 * r, at = 16 * k + cl;
+            if (at < N && bt < N) lu[(size_t)bt * N + at] = dck * dt[r];  // (D L^T)[at][bt]
+        }
     };
-    if (wave == 0) diag_tile(0, load_acc(0, 0));
+    if (wave == 0) diag_tile(0, ld_pk(Cg, 0u, lane));
     __syncthreads();
-    for (int k = 0; k < nb; ++k) {
-        if (*flag) return false;
-        const int m = nb - k - 1, cnt = __builtin_amdgcn_readfirstlane(m * (m + 1) / 2);
-        // tile list of this step's trailing update, (I << 8) | J for k < J <= I (read after the next barrier)
-        for (int e = tid; e < cnt; e += LT) {
-            int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-            while ((i + 1) * (i + 2) / 2 <= e) ++i;
-            while (i * (i + 1) / 2 > e) --i;
-            lst[e] = ((k + 1 + i) << 8) | (k + 1 + (e - i * (i + 1) / 2));
-        }
-        // look-ahead: wave 0 starts loading tile (k+1, k+1) now; it is there when the panel is done
-        v4f64 la = {0.0, 0.0, 0.0, 0.0};
-        if (wave == 0 && cnt > 0) la = load_acc(k + 1, k + 1);
-        // panel: D = L_kk^-1 (C_Ik)^T = L_Ik^T for I > k -> LDS panel (unscaled, for the trailing update) and, scaled, into
-        // the factors.  Element (a, b) of D is L[16 I + b][16 k + a]: its store runs along a column of the unit-lower part;
-        // the upper part wants the transposed tile, which is the same product with the operands exchanged (the B fragment
-        // of C_kI is the A fragment of C_Ik, the A fragment of X the B fragment of X^T): four more MFMAs instead of 64
-        // scattered 8-byte stores per tile.
-        {
-            Frag fa;
+    if (flag[0]) return false;
+    {   // panel 0 from memory: the tiles (0, I) of the first block row ARE (C_I0)^T
+        Frag fx;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) fa.v[q] = dli[cl * PS + 4 * q + rg];
-            // a wave's (up to three) panel tiles: all loads first, then the products -- one L2 latency per step, not per tile
-            constexpr int kPanelMax = 3;  // ceil((NP / 16 - 1) / LNW) for NP <= 400
-            Frag fb[kPanelMax];
+        for (int q = 0; q < 4; ++q) fx.v[q] = dli_of(0)[cl * PS + 4 * q + rg];
+        constexpr int kPanelMax = 3;  // ceil((NP / 16 - 1) / LNW) for NP <= 400
+        Frag fb[kPanelMax];
 #pragma unroll
-            for (int u = 0; u < kPanelMax; ++u) {
-                const int I = k + 1 + wave + u * LNW;
-                if (I < nb) fb[u] = load_rows(Cg + (size_t)(16 * k) * ld + 16 * I, ld, cl, rg);
-            }
-            const double dck = dvec[16 * k + cl];
+        for (int u = 0; u < kPanelMax; ++u) {
+            const int I = 1 + wave + u * LNW;
+            if (I < nb) {
+                const v4f64 t = ld_pk(Cg, (unsigned)(I * 2048), lane);
 #pragma unroll
-            for (int u = 0; u < kPanelMax; ++u) {
-                const int I = k + 1 + wave + u * LNW;
-                if (I < nb) {
-                    const v4f64 z = {0.0, 0.0, 0.0, 0.0};
-                    const v4f64 d = mfma4(fa, fb[u], z, false);
-                    const v4f64 dt = mfma4(fb[u], fa, z, false);
-                    double *pr = pan + (size_t)((I - k - 1) * 16 + cl) * PS + rg;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        pr[4 * r] = d[r];
-                        const int a = 16 * k + rg + 4 * r, b = 16 * I + cl;
-                        if (a < N && b < N) lu[(size_t)a * N + b] = d[r] * rdv[a];  // (L D^-1)[b][a]
-                        const int bt = 16 * I + rg + 4 * r, at = 16 * k + cl;
-                        if (at < N && bt < N) lu[(size_t)bt * N + at] = dck * dt[r];  // (D L^T)[at][bt]
-                    }
-                }
+                for (int q = 0; q < 4; ++q) fb[u].v[q] = t[q];
             }
         }
-        __syncthreads();
-        // trailing update C_IJ -= L_Ik L_Jk^T for k < J <= I.  Wave 0 takes tile (k+1, k+1) first and goes on to factor and
-        // invert it while the other waves update the rest (look-ahead); the tiles of column k + 1 also feed the next panel
-        // as mirrors.
-        auto load_tile = [&](int t) { return load_acc(t >> 8, t & 255); };
-        auto update_tile = [&](int t, v4f64 a) {
-            const double *pa1 = pan + (size_t)(((t >> 8) - k - 1) * 16 + cl) * PS + rg;
-            const double *pb1 = pan + (size_t)(((t & 255) - k - 1) * 16 + cl) * PS + rg;
+#pragma unroll
+        for (int u = 0; u < kPanelMax; ++u) {
+            const int I = 1 + wave + u * LNW;
+            if (I < nb) panel_tile(0, I, fx, fb[u], pan_of(0));
+        }
+    }
+    __syncthreads();
+    double ident[4];  // B fragments of the 16 x 16 identity: four matrix instructions against it transpose a tile
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ident[q] = (4 * q + rg == cl) ? 1.0 : 0.0;
+    for (int k = 0; k + 1 < nb; ++k) {
+        const int m = nb - k - 1;
+        const int cntA = __builtin_amdgcn_readfirstlane(m * (m - 1) / 2);  // tiles with k + 1 < J <= I
+        const int ncol = m - 1;                                             // tiles (I, k + 1), I > k + 1
+        const double *pan_cur = pan_of(k);
+        const unsigned base = (unsigned)((k + 1) * (nb + 1) * 2048);        // tile (k+1, k+1)
+        auto update = [&](int i, int j, v4f64 a) {  // a -= L_{k+1+i,k} L_{k+1+j,k}^T
+            const double *pa1 = pan_cur + (size_t)(i * 16 + cl) * PS + rg;
+            const double *pb1 = pan_cur + (size_t)(j * 16 + cl) * PS + rg;
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s2], pb1[4 * s2], a, 0, 0, 0);
             return a;
         };
         if (wave == 0) {
-            if (cnt > 0) diag_tile(k + 1, update_tile(lst[0], la));
+            // the chain: diagonal tile k + 1 updated, factored and inverted while the other waves update the rest
+            diag_tile(k + 1, update(0, 0, ld_pk(Cg, base, lane)));
+            __hip_atomic_store(&flag[1], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
-            // two tiles in flight, in two named register sets (ta/a and tb/b): the loads of the tile after next are issued
-            // before the four dependent MFMAs of the current one (the fit loop's scheme, fit_loop.hip)
             constexpr int NWK = LNW - 1;
-            auto finish = [&](int t, v4f64 a) {
-                a = update_tile(t, a);
-                store_tile(Cg, ld, t >> 8, t & 255, a, cl, rg, (t & 255) == k + 1 && (t >> 8) != k + 1);
-            };
-            int e = wave;  // tiles 1.. of the list
-            if (e < cnt) {
-                int ta = lst[e], tb = 0;
-                v4f64 a = load_tile(ta), b = a;
-                bool hb = e + NWK < cnt;
+            const int widx = wave - 1;
+            // ---- the tiles right of column k + 1: every NWK-th tile of the table, two in flight in two named register sets ----
+            auto off_of = [&](int t) { return base + (unsigned)(((t >> 8) * nb + (t & 255)) * 2048); };
+            auto finish = [&](int t, v4f64 a) { st_pk(Cg, off_of(t), lane, update(t >> 8, t & 255, a)); };
+            int e = widx;
+            if (e < cntA) {
+                int ta = tab[e], tb = 0;
+                v4f64 a = ld_pk(Cg, off_of(ta), lane), b = a;
+                bool hb = e + NWK < cntA;
                 if (hb) {
-                    tb = lst[e + NWK];
-                    b = load_tile(tb);
+                    tb = tab[e + NWK];
+                    b = ld_pk(Cg, off_of(tb), lane);
                 }
                 e += 2 * NWK;
                 for (;;) {
                     const int tc = ta;
                     const v4f64 c = a;
-                    const bool ha = e < cnt;
+                    const bool ha = e < cntA;
                     if (ha) {
-                        ta = lst[e];
-                        a = load_tile(ta);
+                        ta = tab[e];
+                        a = ld_pk(Cg, off_of(ta), lane);
                     }
                     finish(tc, c);
                     if (!hb) break;
                     const int td = tb;
                     const v4f64 d = b;
-                    hb = e + NWK < cnt;
+                    hb = e + NWK < cntA;
                     if (hb) {
-                        tb = lst[e + NWK];
-                        b = load_tile(tb);
+                        tb = tab[e + NWK];
+                        b = ld_pk(Cg, off_of(tb), lane);
                     }
                     finish(td, d);
                     if (!ha) break;
                     e += 2 * NWK;
                 }
             }
+            // ---- column k + 1 (the round-robin deal goes on where the table stopped): update, then panel k + 1 from the registers ----
+            int cfirst = widx - cntA % NWK;
+            if (cfirst < 0) cfirst += NWK;
+            constexpr int kColMax = 3;  // ceil(18 / 7)
+            v4f64 tc[kColMax];
+#pragma unroll
+            for (int u = 0; u < kColMax; ++u) {
+                const int c = cfirst + u * NWK;
+                if (c < ncol) tc[u] = ld_pk(Cg, base + (unsigned)((c + 1) * nb * 2048), lane);
+            }
+            Frag ft[kColMax];
+#pragma unroll
+            for (int u = 0; u < kColMax; ++u) {
+                const int c = cfirst + u * NWK;
+                if (c < ncol) {
+                    const v4f64 t = update(c + 1, 0, tc[u]);  // T = C_{I,k+1} - L_Ik L_{k+1,k}^T
+                    v4f64 tt = {0.0, 0.0, 0.0, 0.0};          // T^T: what the mirror tile held in rounds 3-5
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tt = __builtin_amdgcn_mfma_f64_16x16x4f64(t[q], ident[q], tt, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ft[u].v[q] = tt[q];
+                }
+            }
+            if (cfirst < ncol) {
+                int spins = 0;  // L_{k+1,k+1}^-1 comes from the chain
+                while (__hip_atomic_load(&flag[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 22)) {  // (a stuck flag must not hang the device)
+                        if (lane == 0) flag[0] = 1;
+                        break;
+                    }
+                }
+                Frag fx;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fx.v[q] = dli_of(k + 1)[cl * PS + 4 * q + rg];
+#pragma unroll
+                for (int u = 0; u < kColMax; ++u) {
+                    const int c = cfirst + u * NWK;
+                    if (c < ncol) panel_tile(k + 1, k + 2 + c, fx, ft[u], pan_of(k + 1));
+                }
+            }
         }
         __syncthreads();
+        if (flag[0]) return false;
     }
-    if (*flag) return false;
     LTOC(1);
     return true;
 }
@@ -1802,7 +1908,7 @@ __device__ __forceinline__ void cluster_helper(const LogNormalParams &P, int mem
             __syncthreads();
             ln_eval_items(P, with_s ? smem : nullptr, smem + P.NP, member * LT + tid, P.cluster * LT);
         } else if (cmd == LN_CMD_HESS) {
-            build_hess_rows(P, P.rk_g, P.tr2_g, P.j, P.LU + P.N * P.N, P.NP, false, member, P.cluster);
+            build_hess_tiles(P, P.rk_g, P.tr2_g, P.j, P.LU + P.N * P.N, member, P.cluster);
         } else if (cmd == LN_CMD_TR2) {
             double *const Cp = P.LU + P.N * P.N, *const Wsc = Cp + P.NP * P.NP, *const Xd = Wsc + P.NP * P.NP;
             if (P.cluster > 2) tr2_solve(P, P.LU, P.dvec_g, Xd, Wsc, P.tr2_g, member - 1, P.cluster - 1);  // (the helpers alone)
@@ -1884,10 +1990,8 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         double *b = smem;
         S.red = b;  // 2 x 32 reduction partials + the pivot value
         b += 72;
-        S.part = b;  // (fixed-size arrays first: part and wsol start on 16-byte boundaries for every N)
+        S.part = b;  // (fixed-size array first: part starts on a 16-byte boundary for every N)
         b += 2 * LT;
-        S.wsol = b;  // one solve vector per wave
-        b += LNW * N;
         double **vecs[] = {&S.x,  &S.xn, &S.I, &S.In,   &S.Sx,  &S.Sxn, &S.MI,  &S.MIn,  &S.jx,   &S.dx,
                            &S.pd, &S.jv, &S.p, &S.pold, &S.rhs, &S.tr2, &S.col, &S.rowk, &S.rdiag};
         for (auto v : vecs) {
@@ -1896,6 +2000,8 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         }
         S.perm = reinterpret_cast<int *>(b);
         b += N;  // 2N ints
+        S.wsol = b;  // one solve vector per wave (72 + 2 LT + 20 N doubles in front: a 16-byte boundary for every N); the tiled
+        b += LNW * N;  // Cholesky works in this space AND the panel's behind it (cholesky_as_lu, fh_ln_chol_doubles)
         S.cluster = cluster;
         S.seq = 0;
         S.same_xcd = same_xcd;
@@ -1917,13 +2023,6 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         }
         __syncthreads();
         if (tid < 64) bandscan::scan_tables<6>(band_g, N, scan_g, tid);  // (6 rows per lane: N <= 320 < 384)
-    }
-    if (!LDS_LU) {  // identity in the padding rows / columns of the Cholesky's copy of the Hessian (see build_hess)
-        double *Cp = P.LU + N * N;
-        for (int e = tid; e < P.NP * P.NP; e += LT) {
-            const int i = e / P.NP, j = e - i * P.NP;
-            if (i >= N || j >= N) Cp[e] = (i == j) ? 1.0 : 0.0;
-        }
     }
     S.redsel = 0;
     S.nch = min(LT / N, N);
@@ -2050,9 +2149,11 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         if (S.lu_nb > 0 && !P.no_cholesky) {
             if (P.mode != LN_MODE_UPDATE) {
                 build_hess_padded(P, S, Cp);
-            } else {
-                for (int b = tid >> 5; b < N; b += LT / 32)
-                    for (int a = tid & 31; a < N; a += 32) Cp[b * P.NP + a] = P.H[a * N + b];
+            } else {  // (a caller's posterior: every element of the padded matrix, packed)
+                const int nbk = P.NP / 16;
+                for (int b = tid >> 5; b < P.NP; b += LT / 32)
+                    for (int a = tid & 31; a < P.NP; a += 32)
+                        Cp[pk_elem(b, a, nbk)] = (a < N && b < N) ? P.H[a * N + b] : (a == b ? 1.0 : 0.0);
                 __syncthreads();
             }
             chol = cholesky_as_lu(P, S, Cp, Xd);
@@ -2114,7 +2215,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         };
         const bool tr1_early = chol && S.cluster > 2;  // formed while the helpers solve for Tr2
         if (chol) {
-            const double *dvec = S.pan + P.NP * tilechol::PS + 16 * tilechol::PS;  // diag(L), left in LDS by cholesky_as_lu
+            const double *dvec = chol_dvec(S, P.NP);  // diag(L), left in LDS by cholesky_as_lu
             if (S.cluster > 1) {
                 for (int i = tid; i < P.NP; i += LT) P.dvec_g[i] = dvec[i];
                 cluster_dispatch(P, LN_CMD_TR2, same_xcd, S.seq);
@@ -2226,6 +2327,9 @@ size_t fh_ln_smem_bytes(int N, int *lu_in_lds, int *lu_nb) {
     } else {
         nb = LU_NB;
         doubles += (size_t)N * nb;
+        // the tiled Cholesky works in the solve vectors' space and the panel's behind it
+        const size_t chol = (size_t)fh_ln_chol_doubles((N + 15) / 16 * 16), have = (size_t)(LNW + nb) * N;
+        if (chol > have) doubles += chol - have;
     }
     if (lu_nb) *lu_nb = nb;
     return doubles * sizeof(double);

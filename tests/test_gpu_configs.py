@@ -661,6 +661,23 @@ def test_moment_path_equals_row_path(monkeypatch, n):
         assert rel_to_max(sols[0][0].I, sols[1][0].I) < 1e-9
 
 
+@pytest.mark.parametrize("n", [3000, 1000000])
+def test_fused_prepass_agrees_with_the_sorted_one(monkeypatch, n):
+    """The one-pass form of the moments pre-pass (bin_fused.hip, FRANK_AMD_K1_FUSED=1: the buckets' 36 moment sums accumulated in
+    LDS, no sorted table; opt-in -- profiles/r06_binning_fused.txt is its kill line) against the sorted path: the same M, j, H0 to
+    round-off.  n = 3000: buckets of <= 16 rows, which the sorted path keeps as rows and the fused one sends through their
+    (rank-deficient) moment matrices.  Its sums are not the same bits from run to run (LDS atomics): no bit-equality here."""
+    from frank_amd import DiscreteHankelTransform, VisibilityMapping
+    u, v, V, w = mock_disc_visibilities(n, seed=0, noise_seed=50)
+    ms = VisibilityMapping(DiscreteHankelTransform(RMAX, 300), geom(), verbose=False).map_visibilities(u, v, V, w)
+    monkeypatch.setenv("FRANK_AMD_K1_FUSED", "1")
+    mf = VisibilityMapping(DiscreteHankelTransform(RMAX, 300), geom(), verbose=False).map_visibilities(u, v, V, w)
+    monkeypatch.delenv("FRANK_AMD_K1_FUSED")
+    assert rel_to_max(mf["M"], ms["M"]) < 1e-13 and rel_to_max(mf["j"], ms["j"]) < 1e-13
+    assert abs(mf["null_likelihood"] - ms["null_likelihood"]) <= 1e-12 * abs(ms["null_likelihood"])
+    assert np.array_equal(mf["M"], mf["M"].T)
+
+
 def test_moment_path_degenerate_buckets():
     """Buckets whose moment matrix is singular: (i) every baseline has the same length (one bucket, one value of tau:
     rank 1, plus the data column); (ii) two lengths in one bucket; (iii) a bucket of 17 rows -- the smallest that is

@@ -3,6 +3,7 @@ FRANK_AMD_LIB pointing at the `make timing` build, the in-kernel phase timers (p
     python tools/ln_fullsize.py [nvis [linear|reference]]
 """
 import ctypes
+import hashlib
 import os
 import sys
 import time
@@ -35,6 +36,6 @@ for rep in range(2):
     dt = time.perf_counter() - t1
     I = np.exp(s_map + np.log(1e5))
     print("fit %.3f s  iterations %d  newton steps %d  evaluations %d  hessians %d  -> %.3f ms/hessian all-in, "
-          "%.1f evaluations/step; I in [%.4g, %.4g]" % (dt, nit.value, stats[1], stats[2], stats[3],
+          "%.1f evaluations/step; I in [%.4g, %.4g]  sha(s, p) %s" % (dt, nit.value, stats[1], stats[2], stats[3],
                                                        1e3 * dt / max(stats[3], 1), stats[2] / max(stats[1], 1),
-                                                       I.min(), I.max()), flush=True)
+                                                       I.min(), I.max(), hashlib.sha1(s_map.tobytes() + p.tobytes()).hexdigest()[:12]), flush=True)
