@@ -38,10 +38,14 @@ __shared__ long long ln_cyc[12];  // 0 eval, 1 factorisations, 2 solves, 3 Hessi
 #define LTIC() const long long _t0 = clock64()
 #define LTOC(k) do { if (threadIdx.x == 0) ln_cyc[k] += clock64() - _t0; } while (0)
 __shared__ long long ln_ev[4];  // inside an evaluation: until the command is out, own items, waiting for the helpers, combining
+__shared__ long long ln_ch[8];  // inside the Cholesky: chain until its flag, chain's global outputs, chain at the barrier; worker wave 1: trailing
+                                // tiles, column tiles until the wait, waiting for the flag, panel, at the barrier
+#define CHT(k) do { if (lane == 0) { const long long n_ = clock64(); ln_ch[k] += n_ - _tc; _tc = n_; } } while (0)
 #define EVT(k) do { if (threadIdx.x == 0) { const long long n_ = clock64(); ln_ev[k] += n_ - _te; _te = n_; } } while (0)
 #else
 #define LTIC() do {} while (0)
 #define LTOC(k) do {} while (0)
+#define CHT(k) do {} while (0)
 #endif
 
 constexpr int LT = 512;        // threads per workgroup
@@ -544,26 +548,29 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
         while (i * (i + 1) / 2 > e) --i;
         tab[e] = ((i + 1) << 8) | (e - i * (i + 1) / 2 + 1);
     }
-    // factor + invert diagonal tile k (held in `t`, accumulator layout); write its part of the factors
-    auto diag_tile = [&](int k, v4f64 t) {
-        v4f64 x;
+    // factor + invert diagonal tile k (held in `t`, accumulator layout): what the other waves wait for goes to LDS first
+    // (diag_factor: L_kk^-1, diag(L), its reciprocals; the chain raises its flag behind it), its part of the factors to memory
+    // afterwards (diag_outputs)
+    auto diag_factor = [&](int k, v4f64 &t, v4f64 &x) {
         double *dli = dli_of(k);
         const bool ok = chol_inv_tile_acc(t, x, lane, -1);
         if (!ok && lane == 0) flag[0] = 1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             dli[(rg + 4 * r) * PS + cl] = x[r];
-            if (Xd) Xd[k * 256 + (rg + 4 * r) * 16 + cl] = x[r];  // L_kk^-1, row-major (the Tr2 solve's A operand)
             if (rg + 4 * r == cl) {
                 dvec[16 * k + cl] = t[r];
                 rdv[16 * k + cl] = 1.0 / t[r];
             }
         }
+    };
+    auto diag_outputs = [&](int k, const v4f64 &t, const v4f64 &x) {
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         const double dc = dvec[16 * k + cl], rdc = rdv[16 * k + cl];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            if (Xd) Xd[k * 256 + (rg + 4 * r) * 16 + cl] = x[r];  // L_kk^-1, row-major (the Tr2 solve's A operand)
             const int i = 16 * k + rg + 4 * r, j = 16 * k + cl;  // element (i, j) of L, i >= j holds data
             if (i < N && j < N && i >= j) {
                 if (i > j) {
@@ -596,7 +603,11 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
             if (at < N && bt < N) lu[(size_t)bt * N + at] = dck * dt[r];  // (D L^T)[at][bt]
         }
     };
-    if (wave == 0) diag_tile(0, ld_pk(Cg, 0u, lane));
+    if (wave == 0) {
+        v4f64 t = ld_pk(Cg, 0u, lane), x;
+        diag_factor(0, t, x);
+        diag_outputs(0, t, x);
+    }
     __syncthreads();
     if (flag[0]) return false;
     {   // panel 0 from memory: the tiles (0, I) of the first block row ARE (C_I0)^T
@@ -637,10 +648,17 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
             for (int s2 = 0; s2 < 4; ++s2) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa1[4 * s2], pb1[4 * s2], a, 0, 0, 0);
             return a;
         };
+#ifdef LN_TIMING
+        long long _tc = clock64();
+#endif
         if (wave == 0) {
             // the chain: diagonal tile k + 1 updated, factored and inverted while the other waves update the rest
-            diag_tile(k + 1, update(0, 0, ld_pk(Cg, base, lane)));
+            v4f64 t = update(0, 0, ld_pk(Cg, base, lane)), x;
+            diag_factor(k + 1, t, x);
             __hip_atomic_store(&flag[1], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            CHT(0);
+            diag_outputs(k + 1, t, x);
+            CHT(1);
         } else {
             constexpr int NWK = LNW - 1;
             const int widx = wave - 1;
@@ -679,6 +697,9 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
                     e += 2 * NWK;
                 }
             }
+#ifdef LN_TIMING
+            if (wave == 1) CHT(3);
+#endif
             // ---- column k + 1 (the round-robin deal goes on where the table stopped): update, then panel k + 1 from the registers ----
             int cfirst = widx - cntA % NWK;
             if (cfirst < 0) cfirst += NWK;
@@ -702,6 +723,9 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
                     for (int q = 0; q < 4; ++q) ft[u].v[q] = tt[q];
                 }
             }
+#ifdef LN_TIMING
+            if (wave == 1) CHT(4);
+#endif
             if (cfirst < ncol) {
                 int spins = 0;  // L_{k+1,k+1}^-1 comes from the chain
                 while (__hip_atomic_load(&flag[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) {
@@ -711,6 +735,9 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
                         break;
                     }
                 }
+#ifdef LN_TIMING
+                if (wave == 1) CHT(5);
+#endif
                 Frag fx;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) fx.v[q] = dli_of(k + 1)[cl * PS + 4 * q + rg];
@@ -719,9 +746,16 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
                     const int c = cfirst + u * NWK;
                     if (c < ncol) panel_tile(k + 1, k + 2 + c, fx, ft[u], pan_of(k + 1));
                 }
+#ifdef LN_TIMING
+                if (wave == 1) CHT(6);
+#endif
             }
         }
         __syncthreads();
+#ifdef LN_TIMING
+        if (wave == 0) CHT(2);
+        if (wave == 1) CHT(7);
+#endif
         if (flag[0]) return false;
     }
     LTOC(1);
@@ -2059,6 +2093,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
 #ifdef LN_TIMING
     if (tid < 12) ln_cyc[tid] = 0;
     if (tid < 4) ln_ev[tid] = 0;
+    if (tid < 8) ln_ch[tid] = 0;
 #endif
     __syncthreads();
 
@@ -2304,6 +2339,8 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         for (int k = 0; k < 8; ++k) P.stats[9 + k] = ln_cyc[k];
         printf("[ln timing, Mcycles] S^-1 %.1f  Tr2 %.1f  Tr1 %.1f  bands + exp %.1f\n", ln_cyc[8] / 1e6, ln_cyc[9] / 1e6, ln_cyc[10] / 1e6,
                ln_cyc[11] / 1e6);
+        printf("[ln timing, Mcycles] inside the Cholesky: chain to its flag %.1f, its outputs %.1f, at the barrier %.1f; worker 1: trailing tiles %.1f, column tiles %.1f, waiting for the flag %.1f, panel %.1f, at the barrier %.1f\n",
+               ln_ch[0] / 1e6, ln_ch[1] / 1e6, ln_ch[2] / 1e6, ln_ch[3] / 1e6, ln_ch[4] / 1e6, ln_ch[5] / 1e6, ln_ch[6] / 1e6, ln_ch[7] / 1e6);
         printf("[ln timing, Mcycles] inside the evaluations: command out %.1f  own items %.1f  waiting for the helpers %.1f  combining %.1f\n",
                ln_ev[0] / 1e6, ln_ev[1] / 1e6, ln_ev[2] / 1e6, ln_ev[3] / 1e6);
 #endif
