@@ -6,11 +6,12 @@ A "step" is ONE complete fit, end to end on the device, of the configuration the
 resident in HBM, Normal GP fit, fp64:
     bin_gram (deproject + J0 design block + Gram)  ->  [RCCL all-reduce in --mode shard]
     ->  scale/unpack M, j  ->  the full power-spectrum iteration to convergence (tol 1e-3).
-Every step streams the whole table and runs the whole iteration; the one thing a context remembers between steps is the
-baseline range (qmin, qmax) of a (table, rows, geometry) it has binned before, which saves the host round trip that sizes
-the bucket sort (extra.distinct_tables measures the pipeline without it: a ring of different tables, range cache off).
-Nothing of the data is remembered otherwise; a fit slot keeps the band factors of the smoothing matrix T + I for the
-hyper-parameters it last ran (they depend on (w_smooth, alpha, p0) and the collocation points only).
+Every step streams the whole table and runs the whole iteration, and NOTHING is remembered between steps: the timed region takes
+turns on a ring of four different resident tables with the context's baseline-range cache off, so every step pays its one look at
+(u, v) (the range that sizes the bucket sort, one host round trip) and the histogram + scan of its table
+(extra.headline_with_caches is the same region on one table with both kept: what a bootstrap or a sweep that re-bins pays).
+A fit slot keeps the band factors of the smoothing matrix T + I for the hyper-parameters it last ran (they depend on
+(w_smooth, alpha, p0) and the collocation points only).
 `value` = fits completed by all ranks / max-over-ranks wall time.  The timed region holds `steps` binning passes and ONE
 drain of the last fits' iterations (~0.09 s), so `value` grows with --steps; extra.steady_state is the rate of a >= 2 s run.
 
@@ -32,7 +33,10 @@ GPU; no N > 1 value has been measured by the builder, the scaling curve is the d
 
 Rank 0 at N=1 also reports, outside the timed region and bounded to about a minute in total:
   extra.steady_state         fits/s of the same pipeline over a >= 2 s run (the drain is < 5 % of it), fit loops resident
-  extra.distinct_tables      the same with every step binning a different table of a ring of four, range cache off
+  extra.headline_with_caches the timed region of the headline on ONE table, range and histogram caches on (rounds 1-5's `value`)
+  extra.steady_state_cached  the steady state on one table with the caches on
+  extra.from_host_pipelined  fits from HOST arrays back to back: the upload of fit i + 1 beside the iterations of fit i
+  extra.sweep512_distinct    configs[4] with every fit binning its own 1e6-visibility table
   extra.lognormal_fullsize   BASELINE configs[2] (N=300, 1e7 visibilities, LogNormal) on the resident table
   extra.lognormal_N640       the same table at N=640: LogNormal beyond the persistent kernel (host-driven route)
   extra.fp32_table           the same table stored in single precision (configs[2]'s "fp32": 20 B per visibility)
@@ -344,21 +348,34 @@ def extras(f, L, a):
     H0, qmn, qmx = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
     # -- what the pipeline of the headline does at steady state (>= 2 s runs), and on tables it has never seen
     try:
-        ex["steady_state"] = steady_state(f, L)
+        # the timed region of rounds 1-5: the same steps on ONE table, baseline-range and histogram caches on
+        f.run_steps(a.warmup)
+        f.sync()
+        t0 = time.perf_counter()
+        f.run_steps(a.steps)
+        f.sync()
+        dtc = time.perf_counter() - t0
+        ex["headline_with_caches"] = {"fits_per_s": a.steps / dtc, "steps": a.steps, "ms_per_step": 1e3 * dtc / a.steps,
+                                      "workload": "the timed region of the headline on one resident table: the context keeps the "
+                                                  "baseline range and the (u, v) histogram + scan of the rows it binned last"}
+    except Exception as e:
+        ex["headline_with_caches"] = {"error": repr(e)}
+    try:
+        ex["steady_state"] = steady_state(f, L, ring=4)
+        ex["steady_state_cached"] = steady_state(f, L)
         # ... and with the fit loops in their register-resident form (fit_loop_rr.hip, FRANK_AMD_K2_RR=1, read at every launch;
         # same bits): opt-in -- a loop ALONE takes 172 us per pass in that form against 135, with the device full 183 against
         # 196 --, so the drained runs above and the sweeps keep the forms that work in memory
         prev_rr = os.environ.get("FRANK_AMD_K2_RR")
         os.environ["FRANK_AMD_K2_RR"] = "1"
         try:
-            ex["steady_state_register_resident"] = steady_state(f, L)
+            ex["steady_state_register_resident"] = steady_state(f, L, ring=4)
             ex["steady_state_register_resident"]["workload"] += "; fit loops with the matrix resident in registers (FRANK_AMD_K2_RR=1)"
         finally:
             if prev_rr is None:
                 del os.environ["FRANK_AMD_K2_RR"]
             else:
                 os.environ["FRANK_AMD_K2_RR"] = prev_rr
-        ex["distinct_tables"] = steady_state(f, L, ring=4)
         for t in f.tables[1:]:
             L.lib.fh_vis_destroy(t)
         del f.tables[1:]
@@ -367,9 +384,9 @@ def extras(f, L, a):
     # -- the fit loop with the DEVICE FULL: 256 identical fits of the headline mapping resident in one launch, one compute unit
     #    each (fh_fit_normal_batched), with the clock probe on -- the form a deep sweep runs, and the roofline of the loaded kernel
     #    (a loaded pass is bound by the bytes it moves beyond the L2: profiles/r05_pmc_fit_loop_loaded.json)
+    prev = os.environ.get("FRANK_AMD_SWEEP_NO_CLUSTERS")
+    os.environ["FRANK_AMD_SWEEP_NO_CLUSTERS"] = "1"
     try:
-        prev = os.environ.get("FRANK_AMD_SWEEP_NO_CLUSTERS")
-        os.environ["FRANK_AMD_SWEEP_NO_CLUSTERS"] = "1"
         Bf = 256
         o3 = (ctypes.c_int64 * 3)()
         f.bin()
@@ -418,12 +435,13 @@ def extras(f, L, a):
                                                   "profiles/r05_mfma_f64_issue.txt), not memory: 0.23 MB per pass beyond the L2 against the "
                                                   "5.0 MB of the forms that work in memory (profiles/r05_pmc_fit_loop_256_resident*.json)"},
                              "forced_register_resident_form": rr}
+    except Exception as e:
+        ex["device_full"] = {"error": repr(e)}
+    finally:
         if prev is None:
             del os.environ["FRANK_AMD_SWEEP_NO_CLUSTERS"]
         else:
             os.environ["FRANK_AMD_SWEEP_NO_CLUSTERS"] = prev
-    except Exception as e:
-        ex["device_full"] = {"error": repr(e)}
 
     def finalize():
         L.check(L.lib.fh_stats_finalize(f.ctx, ctypes.byref(f.geom), 0, 1, None, None, ctypes.byref(H0),
@@ -494,12 +512,80 @@ def extras(f, L, a):
             "upload_pinned_GBps": (nbytes / pinned / 1e9) if isinstance(pinned, float) else pinned,
             "note": "the headline `value` starts with the table resident in HBM; this is the same fit paying PCIe (the complex "
                     "visibilities go up as NumPy holds them and are split into two columns on the device)"}
+        # ... and fits from host arrays BACK TO BACK through the pipeline: the upload of table i + 1 (a blocking copy of the host
+        # thread) runs beside the iterations of the fits before it (their loops sit on the launch streams): the rate is what
+        # PCIe and the host-side split of the complex column allow, not upload + fit one behind the other
+        try:
+            K = 48
+            pend, alive = [], []
+
+            def one():
+                vis = ctypes.c_void_p()
+                L.check(L.lib.fh_vis_upload(f.device, L.ptr(u), L.ptr(v), L.ptr(Vre), L.ptr(Vim), L.ptr(w), w.size, u.size, ctypes.byref(vis)))
+                alive.append(vis)
+                pend.append(f.submit(vis))
+                L.check(L.lib.fh_fit_flush(f.ctx))  # (the fit starts now, on a cluster of workgroups: the device is far from full)
+                while len(alive) > 16:  # (a table is freed behind the fit that binned it; sixteen tables = 6.4 GB in flight)
+                    f.collect(pend.pop(0))
+                    L.lib.fh_vis_destroy(alive.pop(0))
+            L.check(L.lib.fh_ctx_set_range_cache(f.ctx, 0))
+            for _ in range(20):  # (the pipeline full: sixteen fits in flight when the clock starts)
+                one()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                one()
+            L.check(L.lib.fh_fit_flush(f.ctx))
+            while pend:
+                f.collect(pend.pop(0))
+            f.sync()
+            dtp = time.perf_counter() - t0
+            for vis in alive:
+                L.lib.fh_vis_destroy(vis)
+            ex["from_host_pipelined"] = {
+                "workload": "%d fits of %d visibilities each from HOST arrays (five fp64 columns, pageable), back to back: upload of "
+                            "table i + 1 beside the iterations of the fits before it; range cache off" % (K, u.size),
+                "fits_per_s": K / dtp, "s_total": dtp, "ms_per_fit": 1e3 * dtp / K,
+                "upload_bound_fits_per_s": 1.0 / t_page,
+                "note": "bound by the upload (%.1f ms per table at %.0f GB/s): the copy is the host thread's, the device iterates "
+                        "meanwhile" % (1e3 * t_page, nbytes / t_page / 1e9)}
+        except Exception as e:  # noqa: BLE001
+            ex["from_host_pipelined"] = {"error": repr(e)}
+        finally:
+            L.check(L.lib.fh_ctx_set_range_cache(f.ctx, 1))
         del u, v, V, w, Vre, Vim
     except Exception as e:  # noqa: BLE001
         ex["from_host_arrays"] = {"error": repr(e)}
     # -- BASELINE configs[2]: LogNormal fit (alpha = 1.3, w_smooth = 1e-2 as the reference's own LogNormal test,
     #    tests.py:350) of the resident table, end to end; with the default line search (S^-1 (x + lam p) by linearity) and
     #    with the reference's arithmetic (every trial point multiplied out) -- include/frank_hip.h
+    def lognormal_roofline(n, iters, steps, nfev, nhess, seconds, workgroups=8):
+        """Algorithmic flops of a LogNormal fit from its own counters against the fp64 matrix peak of the compute
+        units the fit holds (a cluster of eight workgroups of one XCD from N = 160 on)."""
+        fl = {"S^-1 = Y^T diag(1/p) Y, symmetric half (per iteration)": iters * 1.0 * n ** 3,
+              "Tr2: triangular solve with n right-hand sides (per iteration)": iters * 1.0 * n ** 3,
+              "Cholesky of the Hessian (per Newton Hessian and per iteration, for Tr2)": (nhess + iters) * n ** 3 / 3.0,
+              "Newton directions: two triangular solves (per step)": steps * 2.0 * n ** 2,
+              "objective: M I (per evaluation) and S^-1 p (per step)": (nfev + steps) * 2.0 * n ** 2,
+              "Hessian builds": (nhess + iters) * 3.0 * n ** 2}
+        total = float(sum(fl.values()))
+        peak = FP64_MFMA_PEAK_TFLOPS * workgroups / N_CU
+        traffic, src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r06_pmc_lognormal.json")) as fh:
+                d = json.load(fh)
+            e = [v for k, v in d.items() if k.startswith("lognormal_kernel")][0]
+            traffic = int(e["hbm_bytes_per_launch"])
+            src = "static: profiles/r06_pmc_lognormal.json (rocprofv3 --pmc on tools/ln_fullsize.py), library build '%s'" % d.get("_library")
+        except Exception:  # noqa: BLE001
+            pass
+        return {"kernel": "lognormal_kernel (cluster of %d workgroups)" % workgroups, "bound": "mfma", "achieved": total / seconds / 1e12,
+                "peak": peak, "unit": "TFLOP/s", "frac": total / seconds / 1e12 / peak, "algorithmic_flops": total,
+                "flops_by_phase": fl, "traffic": traffic, "traffic_source": src,
+                "note": "the matrix peak is the nominal roof (the products run on v_mfma_f64_16x16x4_f64); what holds the kernel is "
+                        "what ONE compute unit moves to and from the L2, ~25 B per cycle: a factorisation of the Hessian is 4.6 MB "
+                        "of tile traffic (184 k cycles of its 366 k), a Newton direction 0.72 MB of factors, an evaluation 0.72 MB of M "
+                        "-- profiles/r06_lognormal_phases.txt"}
+
     def lognormal(reference_products):
         s_map, p = np.empty(N), np.empty(N)
         nit = ctypes.c_int(0)
@@ -521,7 +607,8 @@ def extras(f, L, a):
                 "power_spectrum_iterations": nit.value, "newton_steps": int(stats[1]),
                 "function_evaluations": int(stats[2]), "hessian_factorisations": int(stats[3]),
                 "ms_per_power_spectrum_iteration": 1e3 * (t2 - t1) / max(nit.value, 1),
-                "I_min": float(I.min()), "I_max": float(I.max()), "finite": bool(np.all(np.isfinite(I)))}, I
+                "I_min": float(I.min()), "I_max": float(I.max()), "finite": bool(np.all(np.isfinite(I))),
+                "roofline": lognormal_roofline(N, nit.value, int(stats[1]), int(stats[2]), int(stats[3]), t2 - t1)}, I
     try:
         ex["lognormal_fullsize"], I_lin = lognormal(0)
         ex["lognormal_fullsize_reference_linesearch"], I_ref = lognormal(1)
@@ -530,6 +617,10 @@ def extras(f, L, a):
             "Hessians, and with them the seconds, depend on 1e-16-level changes of M")
         ex["lognormal_fullsize"]["profile_vs_reference_linesearch_max_abs_diff_over_max"] = float(
             np.abs(I_lin - I_ref).max() / np.abs(I_ref).max())
+        ex["lognormal_fullsize"]["note"] = (
+            "the DEFAULT line search forms S^-1 (x + lam p) by linearity: not the reference's arithmetic (held to the reference's whole "
+            "fit at 1e-4 of the maximum, tests/test_gpu_configs.py); the mode that multiplies every trial point out as the reference "
+            "does is lognormal_fullsize_reference_linesearch -- quote both")
     except Exception as e:
         ex.setdefault("lognormal_fullsize", {})["error"] = repr(e)
     # -- method='LogNormal' beyond the persistent kernel's basis size (N = 640: the host-driven route, lognormal_wide.hip) on the
@@ -688,8 +779,11 @@ def extras(f, L, a):
         ex["sweep512"] = {"workload": "BASELINE configs[4] on ONE GPU: %d fits (alpha x w_smooth grid), N=%d, %d "
                                       "visibilities, shared (M, j) as fit.py:534-548" % (B, N, nv),
                           "fits_per_s": B / dt, "s_total": dt, "s_total_both": both,
-                          "schedule": "staged (capi_fit.hip: sweep_staged): every fit at most 800 passes on one compute unit in a launch "
-                                      "that fills the device, the fits still running then continue on clusters of workgroups",
+                          "schedule": ("single launch, no clusters (FRANK_AMD_SWEEP_NO_CLUSTERS)" if os.environ.get("FRANK_AMD_SWEEP_NO_CLUSTERS") else
+                                       "staged (capi_fit.hip: sweep_staged): every fit on one compute unit in a launch that fills the "
+                                       "device until %s; the fits still running then continue on clusters of workgroups"
+                                       % (("it has made %s passes" % os.environ["FRANK_AMD_SWEEP_CAP"]) if int(os.environ.get("FRANK_AMD_SWEEP_CAP", "0")) > 0
+                                          else "every fit has been handed out and 32 are left (checked every 16 passes)")),
                           "iterations_min_median_max": [int(its.min()), int(np.median(its)), int(its.max())],
                           "failed": int(np.sum(np.array(list(status)) != 0)),
                           "not_converged": int(np.sum(its >= h["max_iter"]))}
@@ -710,6 +804,52 @@ def extras(f, L, a):
             ex["sweep512"]["evidence"] = {"error": repr(e)}
     except Exception as e:
         ex["sweep512"] = {"error": repr(e)}
+    # -- BASELINE configs[4], the distinct-datasets variant SURVEY 8(d) asks for beside the shared-(M, j) sweep: every one of the 512
+    #    fits bins its OWN 1e6-visibility table (eight resident tables, seeds 0 .. 7, taken in turn: generating 512 on the host would
+    #    take minutes and the device work is the same) and runs its grid point, through the pipeline
+    try:
+        NT, NV = 8, 1_000_000
+        f5 = Fitter(L, N, f.device)
+        f5.nfit = NV
+        tabs = []
+        for sd in range(NT):
+            f5.upload(*mock_disc_visibilities(NV, seed=sd, noise_seed=50 + sd))
+            tabs.append(f5.vis)
+        L.check(L.lib.fh_ctx_set_range_cache(f5.ctx, 0))
+        grid = [(float(x), float(y)) for x in np.linspace(1.01, 1.5, 32) for y in np.logspace(-4, -1, 16)]
+        slots = L.lib.fh_fit_slots()
+
+        def run_grid(points):
+            pend, its = [], []
+            for i, (ga, gw) in enumerate(points):
+                if len(pend) == slots:
+                    its.append(f5.collect(pend.pop(0)))
+                f5.bin(vis=tabs[i % NT])
+                L.check(L.lib.fh_stats_finalize(f5.ctx, ctypes.byref(f5.geom), 0, 0, None, None, None, None, None))
+                t = ctypes.c_int(-1)
+                L.check(L.lib.fh_fit_submit(f5.ctx, ga, h["p0"], gw, h["tol"], h["max_iter"], ctypes.byref(t)))
+                pend.append(t.value)
+            L.check(L.lib.fh_fit_flush(f5.ctx))
+            its += [f5.collect(t) for t in pend]
+            return its
+        run_grid(grid[:32])
+        f5.sync()
+        t0 = time.perf_counter()
+        its5 = run_grid(grid)
+        f5.sync()
+        dt5 = time.perf_counter() - t0
+        ex["sweep512_distinct"] = {
+            "workload": "BASELINE configs[4], distinct datasets: 512 fits (alpha x w_smooth grid), each binning its own %d-visibility "
+                        "table (%d resident tables in turn, range cache off), N=%d, through the pipeline" % (NV, NT, N),
+            "fits_per_s": len(grid) / dt5, "s_total": dt5,
+            "iterations_min_median_max": [int(np.min(its5)), int(np.median(its5)), int(np.max(its5))],
+            "note": "a pipeline hands out its launches in submission order: a launch of 64 fit loops ends with its longest fit "
+                    "(the grid's fits differ 20 x in length), where the shared-(M, j) sweep pauses its stragglers and moves them to clusters"}
+        for t in tabs:
+            L.lib.fh_vis_destroy(t)
+        del f5
+    except Exception as e:  # noqa: BLE001
+        ex["sweep512_distinct"] = {"error": repr(e)}
     # -- LogNormal fits in one launch, one compute unit each (fh_fit_lognormal_batched): 64 points of an (alpha, w_smooth) grid
     #    over the same 1e6-visibility mapping, default line search
     try:
@@ -961,16 +1101,28 @@ def main():
     u, v, V, w = mock_disc_visibilities(nrows, seed=1000 * rank, noise_seed=50 + rank)
     f.upload(u, v, V, w)
     del u, v, V, w
+    # the ring of the headline: three more resident tables of this rank's own (fits are independent objects); every step bins the
+    # next one with the baseline-range cache off -- nothing the context learned from an earlier step is used
+    RING = 4
+    for k in range(1, RING):
+        u, v, V, w = mock_disc_visibilities(a.nvis, seed=1000 * rank + 7000 + k, noise_seed=7100 + rank + 50 * k)
+        keep, keep_n = f.vis, f.n
+        f.upload(u, v, V, w)
+        f.vis, f.n = keep, keep_n
+        del u, v, V, w
+    ring = f.tables[:RING]
+    L.check(L.lib.fh_ctx_set_range_cache(f.ctx, 0))
 
-    f.run_steps(a.warmup)
+    f.run_steps(a.warmup, ring=ring)
     f.sync()
     barrier()
     kernel_ms = []
     t0 = time.perf_counter()
-    nit = f.run_steps(a.steps, kernel_ms)
+    f.run_steps(a.steps, kernel_ms, ring=ring)
     f.sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    L.check(L.lib.fh_ctx_set_range_cache(f.ctx, 1))
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -981,7 +1133,7 @@ def main():
     # split of one step (untimed, after the measured region): the fit loop as a single fit runs it (a cluster of workgroups,
     # include/frank_hip.h: fh_fit_cluster_info) and on ONE compute unit, the form the steady state runs
     t0 = time.perf_counter(); f.bin(); f.sync(); t_bin = time.perf_counter() - t0
-    t0 = time.perf_counter(); f.solve(); f.sync(); t_solve = time.perf_counter() - t0
+    t0 = time.perf_counter(); nit = f.solve(); f.sync(); t_solve = time.perf_counter() - t0  # (table 0: the reference's input)
     kms_alone = f.kernel_ms()
     pre_alone = f.prepass_ms()
     loop_ms = f.loop_kernel_ms()
@@ -1089,7 +1241,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: N=%d, %d mock-disc visibilities resident in HBM, Normal GP "
-                                   "fit, one independent fit per GPU per step" % (Nc, a.nvis),
+                                   "fit, one independent fit per GPU per step; the steps take turns on a ring of %d different "
+                                   "resident tables with the baseline-range cache off: nothing is remembered between steps "
+                                   "(iterations_to_converge: table 0, the reference's input)" % (Nc, a.nvis, RING),
                        "alpha": HYPER["alpha"], "wsmooth": HYPER["wsmooth"], "tol": HYPER["tol"],
                        "iterations_to_converge": nit, "iterations_of_the_reference_on_this_input": ref_iters,
                        "iterations_match_the_reference": (nit == ref_iters) if ref_iters is not None else None,

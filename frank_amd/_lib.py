@@ -145,21 +145,10 @@ for _name, (_res, _args) in SIGNATURES.items():
     _f.argtypes = _args
 
 
-# The one thing this package changes in the process: GPU_MAX_HW_QUEUES=24 unless the variable is set (include/frank_hip.h:
-# fh_init) -- HIP reads it at its first call, and the launches of a pipeline of fits want more than the default four queues.
-_queues_preset = "GPU_MAX_HW_QUEUES" in os.environ
-lib.fh_init()
-# ... which only helps if HIP has not been initialised yet.  The library cannot see that (its check reads the variable it has just
-# set); the one common way to get there from Python -- torch imported first and its HIP runtime already up -- is checked here.
-_torch = sys.modules.get("torch")
-try:
-    if _torch is not None and not _queues_preset and _torch.cuda.is_initialized():
-        import warnings
-        warnings.warn("frank_amd: torch initialised the HIP runtime before frank_amd was imported: GPU_MAX_HW_QUEUES=24 comes too "
-                      "late (the runtime keeps its 4 hardware queues and the launches of a pipeline of fits will share them). "
-                      "Import frank_amd first or export GPU_MAX_HW_QUEUES=24.", RuntimeWarning, stacklevel=2)
-except Exception:
-    pass
+# Importing this package changes nothing in the process.  GPU_MAX_HW_QUEUES (HIP reads it when the ROCm runtime comes up) is
+# settled by the library at the first entry point that touches the device (include/frank_hip.h: fh_init); a context created on a
+# runtime that came up with fewer than eight hardware queues -- torch imported first and its HIP runtime already initialised, say --
+# says so through fh_last_warning(), which warn_if_any() turns into a RuntimeWarning.
 
 
 def last_error():

@@ -1,4 +1,9 @@
 // capi_core.hip -- see capi_internal.h for the map of the C-ABI files.
+#include <dirent.h>
+#include <unistd.h>
+
+#include <mutex>
+
 #include "capi_internal.h"
 
 thread_local std::string g_err;
@@ -50,23 +55,55 @@ void pool_clear() {
 }
 
 // HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels whose streams share a queue serialise: the
-// launches of a pipeline of fits (up to six streams beside the binning stream) want at least eight.  The variable is read when
-// the HIP runtime initialises (the first HIP call of the process), so it can only be set before that -- by the embedding
-// application, or by an explicit fh_init(); loading this library changes nothing in the process (rounds 1-3 did it in a
-// constructor).  A context created with fewer queues records a warning (fh_last_warning).
+// launches of a pipeline of fits (up to six streams beside the binning stream) want at least eight.  The variable is read when the
+// ROCm runtime comes up (the first HIP call of the process).  Round 6: neither loading the library nor importing the Python package
+// touches the process any more; the FIRST entry point of this library that is about to make a HIP call (fh_ctx_create,
+// fh_vis_upload*, fh_device_count) looks whether the runtime is up already -- /dev/kfd among the process's descriptors -- and, if
+// it is not, exports GPU_MAX_HW_QUEUES=24 unless the variable is set.  What the runtime latched is then known: the variable's value
+// if it came up under this library's eyes (or was set by the user), the default 4 if somebody else (torch imported first, say)
+// brought it up with the variable unset -- and that, not the environment of the moment, is what a context's warning is keyed on.
 static thread_local std::string g_warn;
 constexpr int kHwQueuesWanted = 8;
 static int hw_queues_env() {
     const char *e = getenv("GPU_MAX_HW_QUEUES");
     return e ? atoi(e) : 4;  // (the runtime's default)
 }
+static bool rocm_runtime_up() {
+    DIR *d = opendir("/proc/self/fd");
+    if (!d) return false;
+    bool up = false;
+    char path[64], target[256];
+    while (const dirent *e = readdir(d)) {
+        if (e->d_name[0] == '.') continue;
+        snprintf(path, sizeof path, "/proc/self/fd/%s", e->d_name);
+        const ssize_t n = readlink(path, target, sizeof target - 1);
+        if (n <= 0) continue;
+        target[n] = 0;
+        if (!strcmp(target, "/dev/kfd")) {
+            up = true;
+            break;
+        }
+    }
+    closedir(d);
+    return up;
+}
+static int g_hw_queues_latched = 0;  // what the runtime read when it came up, as far as this library can tell (0: not settled yet)
+void settle_hw_queues() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const bool up = rocm_runtime_up();
+        const bool had = getenv("GPU_MAX_HW_QUEUES") != nullptr;
+        if (!up) setenv("GPU_MAX_HW_QUEUES", "24", 0);  // never overrides a value the user chose
+        g_hw_queues_latched = (up && !had) ? 4 : hw_queues_env();
+    });
+}
 
 extern "C" {
 
 
 int fh_init(void) {
-    setenv("GPU_MAX_HW_QUEUES", "24", 0);  // never overrides a value the user chose
-    return hw_queues_env();
+    settle_hw_queues();
+    return g_hw_queues_latched;
 }
 const char *fh_last_warning(void) { return g_warn.c_str(); }
 
@@ -77,6 +114,7 @@ extern "C" const char *fh_build_stamp(void);  // version_stamp.cpp: compiled aga
 const char *fh_version(void) { return fh_build_stamp(); }
 
 int fh_device_count(int *count) {
+    settle_hw_queues();
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) n = 0;
@@ -125,6 +163,7 @@ int fh_dht_bucket_tables(const fh_dht *d, int b0, int b1, double *table, double 
 // ---- contexts -------------------------------------------------------------------------------------------------
 void load_k1_env(fh_ctx *c);  // (the FRANK_AMD_K1_* switches, read once per context)
 int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
+    settle_hw_queues();
     if (!dht || !out) return fail(FH_ERR_INVALID, "fh_ctx_create: NULL argument");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -230,7 +269,7 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
                 const int t0 = fh_k1_part_ntiles(c->NBT, 0), t1 = fh_k1_part_ntiles(c->NBT, 1);
                 const double w0 = t0 + 3.3 * c->NBT, w1 = t1 + 3.3 * (c->NBT - 7);
                 int g0 = (int)llround((double)G * w0 / (w0 + w1));
-                if (const char *e = getenv("FRANK_AMD_K1_SPLIT")) g0 = atoi(e);  // development: workgroups of part 0
+                if (const char *e = FH_DEV_STR("FRANK_AMD_K1_SPLIT")) g0 = atoi(e);  // development: workgroups of part 0
                 if (g0 < 1) g0 = 1;
                 if (g0 > G - 1) g0 = G - 1;
                 c->part_blocks[0] = g0;
@@ -338,12 +377,12 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     const int rc = fh_bin_reset(c);
     if (rc != FH_OK) return rc;
     g_warn.clear();
-    if (hw_queues_env() < kHwQueuesWanted) {
-        char buf[320];
-        snprintf(buf, sizeof buf, "GPU_MAX_HW_QUEUES=%d: pipelined fits (fh_fit_submit) put their launches on up to six streams beside "
-                 "the binning stream; with fewer than %d hardware queues HIP lets streams share a queue and their kernels serialise. "
-                 "Call fh_init() -- or export GPU_MAX_HW_QUEUES=24 -- before the first HIP call of the process.", hw_queues_env(),
-                 kHwQueuesWanted);
+    if (g_hw_queues_latched < kHwQueuesWanted) {
+        char buf[400];
+        snprintf(buf, sizeof buf, "the ROCm runtime of this process came up with %d hardware queues (GPU_MAX_HW_QUEUES): pipelined fits "
+                 "(fh_fit_submit) put their launches on up to six streams beside the binning stream; with fewer than %d queues HIP lets "
+                 "streams share a queue and their kernels serialise.  Export GPU_MAX_HW_QUEUES=24 -- or call fh_init() -- before the "
+                 "first HIP call of the process (e.g. before importing torch).", g_hw_queues_latched, kHwQueuesWanted);
         g_warn = buf;
     }
     *out = guard.release();
@@ -383,6 +422,7 @@ void *fh_ctx_stream(fh_ctx *c) { return c ? (void *)c->stream : nullptr; }
 // ---- visibility tables -------------------------------------------------------------------------------------------
 int fh_vis_upload(int device, const double *u, const double *v, const double *Vre, const double *Vim, const double *w,
                   int64_t n_w, int64_t n, fh_vis **out) {
+    settle_hw_queues();
     if (!out || n < 0 || (n > 0 && (!u || !v || !Vre || !w))) return fail(FH_ERR_INVALID, "fh_vis_upload: bad argument");
     if (n_w != 1 && n_w != n) return fail(FH_ERR_INVALID, "fh_vis_upload: weights must have 1 or n entries");
     int ndev = 0;
@@ -423,6 +463,7 @@ int fh_vis_upload(int device, const double *u, const double *v, const double *Vr
 // the device instead of two strided host copies into separate columns (30 ms of a 45 ms mapping call at 1e7 visibilities).
 int fh_vis_upload_c128(int device, const double *u, const double *v, const double *Vc, const double *w, int64_t n_w, int64_t n,
                        fh_vis **out) {
+    settle_hw_queues();
     if (!out || n < 0 || (n > 0 && (!u || !v || !Vc || !w))) return fail(FH_ERR_INVALID, "fh_vis_upload_c128: bad argument");
     if (n_w != 1 && n_w != n) return fail(FH_ERR_INVALID, "fh_vis_upload_c128: weights must have 1 or n entries");
     int ndev = 0;
@@ -435,7 +476,17 @@ int fh_vis_upload_c128(int device, const double *u, const double *v, const doubl
     t->w_scalar = (n_w == 1 && n != 1) ? 1 : 0;
     t->has_im = 1;
     const size_t nn = (size_t)(n > 0 ? n : 1);
+    // (every way out, the error returns included, waits for the device before tmp -- and, through the unique_ptr declared before it,
+    //  the table's columns -- go back to the pool: a buffer released while the split kernel of the null stream may still touch it
+    //  would be handed to the next upload)
     DevBuf<double> tmp;
+    struct ReleaseAfterSync {  // tmp's memory returns to the pool only behind a device synchronisation
+        DevBuf<double> &b;
+        ~ReleaseAfterSync() {
+            (void)hipDeviceSynchronize();
+            b.release();
+        }
+    } tmp_guard{tmp};
     if (t->u.alloc_pooled(nn, device) != hipSuccess || t->v.alloc_pooled(nn, device) != hipSuccess ||
         t->Vre.alloc_pooled(nn, device) != hipSuccess || t->Vim.alloc_pooled(nn, device) != hipSuccess ||
         t->w.alloc_pooled(t->w_scalar ? 1 : nn, device) != hipSuccess || tmp.alloc_pooled(2 * nn, device) != hipSuccess)
@@ -455,6 +506,7 @@ int fh_vis_upload_c128(int device, const double *u, const double *v, const doubl
 
 int fh_vis_upload_f32(int device, const float *u, const float *v, const float *Vre, const float *Vim, const float *w,
                       int64_t n_w, int64_t n, fh_vis **out) {
+    settle_hw_queues();
     if (!out || n < 0 || (n > 0 && (!u || !v || !Vre || !w))) return fail(FH_ERR_INVALID, "fh_vis_upload_f32: bad argument");
     if (n_w != 1 && n_w != n) return fail(FH_ERR_INVALID, "fh_vis_upload_f32: weights must have 1 or n entries");
     int ndev = 0;

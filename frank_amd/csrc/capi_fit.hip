@@ -501,7 +501,7 @@ static int update_power_spectrum_rocsolver(fh_ctx *c, const double *M, const dou
 std::vector<int> sweep_launch_order(const double *alpha, const double *wsmooth, int batch) {
     std::vector<int> order((size_t)batch);
     for (int b = 0; b < batch; ++b) order[b] = b;
-    if (getenv("FRANK_AMD_SWEEP_GRID_ORDER")) return order;
+    if (FH_DEV_SET("FRANK_AMD_SWEEP_GRID_ORDER")) return order;
     auto key = [](double x) { return std::isnan(x) ? INFINITY : x; };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
         const double ax = key(alpha[x]), ay = key(alpha[y]);
@@ -580,7 +580,7 @@ static int sweep_staged(fh_ctx *c, int batch, const std::vector<int> &order, con
         if (status)
             status[b] = res[2 * slot + 1] == FIT_STATUS_BAD_P ? FH_ERR_BAD_P : res[2 * slot + 1] == FIT_STATUS_NOT_SPD ? FH_ERR_NOT_SPD : FH_OK;
     };
-    const bool trace = getenv("FRANK_AMD_SWEEP_TRACE") != nullptr;  // development: stage times on stderr
+    const bool trace = FH_DEV_SET("FRANK_AMD_SWEEP_TRACE");  // development: stage times on stderr
     const auto t_start = std::chrono::steady_clock::now();
     auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     // ---- stage 1: every fit; cap > 0: at most `cap` passes; cap == 0: until the fits still running are few enough for the
@@ -700,6 +700,26 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
     }
     int rc = prepare_qspace(c, c->Aq.p, c->bq.p);
     if (rc) return rc;
+    // The workgroups pull the fits in launch order, and the launch ends with its slowest fit: the points most likely to run
+    // long go first.  The iteration count grows as alpha approaches 1 (filter.py:172: the update of p is damped by alpha - 1/2)
+    // and, at equal alpha, with a weaker smoothing prior; on the 32 x 16 grid of BASELINE configs[4] the seven points that reach
+    // max_iter all have alpha = 1.01 -- in grid order the last of them started 100 ms into the launch.  order[k] = the caller's
+    // index of the fit launched k-th; the outputs are put back in the caller's order.
+    const std::vector<int> order = sweep_launch_order(alpha, wsmooth, batch);
+    // the staged schedule (sweep_staged above): sweeps of at least 64 points on an idle context.  Decided BEFORE this function's own
+    // work buffers exist: sweep_staged allocates its set, and 2 x G x NP^2 doubles of C and W (0.38 GB at N = 300, G = 256) held
+    // twice was a second hipMalloc / hipFree round and twice the memory of every staged sweep
+    {
+        const int gsz = fit_cluster_size(c);
+        // (FRANK_AMD_SWEEP_CAP: 0, the default: the fits pause when only as many are still running as the clusters of the second
+        //  stage hold; n > 0: every fit pauses after n passes -- the best constant depends on the grid: 800 for one draw of
+        //  BASELINE configs[4] (2 047 fits/s; 1 000: 1 914), 1 000 for another (1 963; 800: 1 592), the single launch with its
+        //  sixteen longest points on clusters 1 515-1 650 on both; -1: that single launch)
+        const int cap = env_int("FRANK_AMD_SWEEP_CAP", 0);
+        if (cap >= 0 && gsz > 1 && batch >= 64 && c->slots_busy == 0 && c->pending_batch < 0 && !getenv("FRANK_AMD_SWEEP_NO_CLUSTERS") &&
+            max_iter > cap)
+            return sweep_staged(c, batch, order, alpha, p0, wsmooth, tol, max_iter, cap, mu, p, niter, status);
+    }
     // per-fit work buffers and parameters
     DevBuf<double> Cb, Wb, WdTb, csb, mub, pb, lub, alb, p0b;
     DevBuf<int> resb;
@@ -714,24 +734,6 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
         mub.alloc(B * N) != hipSuccess || pb.alloc(B * N) != hipSuccess || lub.alloc(B * 5 * N) != hipSuccess ||
         alb.alloc(B) != hipSuccess || p0b.alloc(B) != hipSuccess || resb.alloc(2 * B) != hipSuccess)
         return fail(FH_ERR_NOMEM, "fh_fit_normal_batched: device allocation for %d fits failed", batch);
-    // The workgroups pull the fits in launch order, and the launch ends with its slowest fit: the points most likely to run
-    // long go first.  The iteration count grows as alpha approaches 1 (filter.py:172: the update of p is damped by alpha - 1/2)
-    // and, at equal alpha, with a weaker smoothing prior; on the 32 x 16 grid of BASELINE configs[4] the seven points that reach
-    // max_iter all have alpha = 1.01 -- in grid order the last of them started 100 ms into the launch.  order[k] = the caller's
-    // index of the fit launched k-th; the outputs are put back in the caller's order.
-    const std::vector<int> order = sweep_launch_order(alpha, wsmooth, batch);
-    // the staged schedule (sweep_staged above): sweeps of at least 64 points on an idle context, sizes the deferred kernel covers
-    {
-        const int gsz = fit_cluster_size(c);
-        // (FRANK_AMD_SWEEP_CAP: 0, the default: the fits pause when only as many are still running as the clusters of the second
-        //  stage hold; n > 0: every fit pauses after n passes -- the best constant depends on the grid: 800 for one draw of
-        //  BASELINE configs[4] (2 047 fits/s; 1 000: 1 914), 1 000 for another (1 963; 800: 1 592), the single launch with its
-        //  sixteen longest points on clusters 1 515-1 650 on both; -1: that single launch)
-        const int cap = env_int("FRANK_AMD_SWEEP_CAP", 0);
-        if (cap >= 0 && gsz > 1 && batch >= 64 && c->slots_busy == 0 && c->pending_batch < 0 && !getenv("FRANK_AMD_SWEEP_NO_CLUSTERS") &&
-            max_iter > cap)
-            return sweep_staged(c, batch, order, alpha, p0, wsmooth, tol, max_iter, cap, mu, p, niter, status);
-    }
     // ... and the first K of them -- the ones that will still be iterating when every other fit of the sweep has ended -- do not
     // join the batch at all: they are launched on CLUSTERS of workgroups (fit_loop.hip: 98 instead of 136 us per pass once the
     // device has emptied) through the fit slots, beside the batched launch of the rest on the compute units they leave free.
@@ -740,7 +742,7 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
         const int g = fit_cluster_size(c);
         if (g > 1 && batch >= 64 && c->slots_busy == 0 && c->pending_batch < 0 && !getenv("FRANK_AMD_SWEEP_NO_CLUSTERS")) {
             K = batch / 8 < 16 ? batch / 8 : 16;
-            K = env_int("FRANK_AMD_SWEEP_CLUSTERS", K);  // (development: how many of the longest points go to clusters)
+            K = FH_DEV_INT("FRANK_AMD_SWEEP_CLUSTERS", K);  // (development: how many of the longest points go to clusters)
             if (K > batch) K = batch;
             if (K * g > c->num_cu / 2) K = c->num_cu / 2 / g;
         }
@@ -837,17 +839,17 @@ int fh_fit_normal_batched(fh_ctx *c, const double *M, const double *j, int batch
 // sixteen on sixteen streams this replaces: 711-740.
 static int fit_launch_streams() {  // streams the launches are dealt to, idle ones first (FRANK_AMD_FIT_STREAMS, 1 .. 8)
     int n = 6;
-    if (const char *e = getenv("FRANK_AMD_FIT_STREAMS")) n = atoi(e);
+    if (const char *e = FH_DEV_STR("FRANK_AMD_FIT_STREAMS")) n = atoi(e);
     return n < 1 ? 1 : (n > kLaunchStreamsMax ? kLaunchStreamsMax : n);
 }
 static int fit_batch_size() {  // fit loops per launch (FRANK_AMD_FIT_BATCH = 1 (launch at once) .. 128)
     int b = 64;
-    if (const char *e = getenv("FRANK_AMD_FIT_BATCH")) b = atoi(e);
+    if (const char *e = FH_DEV_STR("FRANK_AMD_FIT_BATCH")) b = atoi(e);
     return b < 1 ? 1 : (b > kFitBatchMax ? kFitBatchMax : b);
 }
 static int fit_slots_wanted() {  // fit loops in flight: every one holds a compute unit for the ~0.1 s of its iteration
     int n = 240;  // (kFitSlots = 512 is the capacity)
-    if (const char *e = getenv("FRANK_AMD_FIT_SLOTS")) n = atoi(e);
+    if (const char *e = FH_DEV_STR("FRANK_AMD_FIT_SLOTS")) n = atoi(e);
     return n < 1 ? 1 : (n > kFitSlots ? kFitSlots : n);
 }
 int fh_fit_slots(void) {  // fits that may be outstanding: bounded by the slots and by the launches in flight
@@ -886,7 +888,7 @@ static int flush_pending_batch(fh_ctx *c) {
     // single loops; with device-scope loads and the workers' rows in registers they do.)  So: clusters while at most
     // FRANK_AMD_K2_CLUSTER_FITS (32: 160 of the 256 compute units) fits are outstanding.
     {
-        static const int most = env_int("FRANK_AMD_K2_CLUSTER_FITS", 32);
+        static const int most = FH_DEV_INT("FRANK_AMD_K2_CLUSTER_FITS", 32);
         const int g = fit_cluster_size(c);
         b.cluster = (g > 1 && (c->slots_busy <= most || c->force_cluster_launch)) ? g : 1;  // (slots_busy counts the fits of this launch too)
     }
@@ -1070,7 +1072,7 @@ static int fit_submit_impl(fh_ctx *c, double alpha, double p0, double wsmooth, d
     // OFF by default (FRANK_AMD_FIT_EARLY=1 turns it on): the first fits come back a launch earlier, but the fits of the small
     // launches run on clusters and the later ones, on one CU each, beside them: 20 fits 128 ms against 115 in one launch, and the
     // driver's 20-step region 178 fits/s against 200 -- that region ends with the LAST fit's iteration whenever it is launched.
-    static const int early = env_int("FRANK_AMD_FIT_EARLY", 0);
+    static const int early = FH_DEV_INT("FRANK_AMD_FIT_EARLY", 0);
     int in_flight = 0;
     for (const FitBatch &o : c->batches)
         if (o.active && o.launched && hipEventQuery(o.done) != hipSuccess) ++in_flight;

@@ -76,7 +76,11 @@ struct DevBuf {
     hipError_t alloc(size_t count) {
         release();
         owned = true;
-        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e != hipSuccess) {  // (up to kPoolBytes of freed table columns may be what is in the way: give them back and try once more)
+            pool_clear();
+            e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        }
         if (e != hipSuccess) {  // leave the buffer empty so that a later grow-on-demand check allocates again
             p = nullptr;
             return e;
@@ -326,6 +330,21 @@ static inline int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
     return e && *e ? atoi(e) : dflt;
 }
+// Environment switches.  Two kinds:
+//   * FORM switches select among forms of a kernel that give the same results -- the parity tests compare them inside one process
+//     (FRANK_AMD_K1, _K1_FUSED, _K1_NO_HIST_CACHE, _K1_SAFE_TRIG, _NO_RANGE_CACHE, _K2, _K2_CLUSTER, _K2_CLUSTER_BREAK, _K2_RR, _K2_DEFER,
+//     _K2_LL, _SWEEP_CAP, _SWEEP_LEFT, _SWEEP_STAGE2_CLUSTERS, _SWEEP_NO_CLUSTERS, _LN_CLUSTER, _LN_PIVOTED, _RESIDUAL_DIRECT): read with
+//     env_int / getenv, listed in INTEGRATION.md;
+//   * DEVELOPMENT switches (tuning knobs, probes, kill-line forms) exist only in builds with -DFRANK_AMD_DEV (`make dev`: the tools
+//     under tools/ that sweep them load libfrank_hip_dev.so through FRANK_AMD_LIB): the shipped library reads none of them.
+#ifdef FRANK_AMD_DEV
+#define FH_DEV_INT(name, dflt) env_int(name, dflt)
+#define FH_DEV_STR(name) getenv(name)
+#else
+#define FH_DEV_INT(name, dflt) (dflt)
+#define FH_DEV_STR(name) (static_cast<const char *>(nullptr))
+#endif
+#define FH_DEV_SET(name) (FH_DEV_STR(name) != nullptr)
 
 // ---- helpers shared by the entry-point families (defined in the file named) ---------------------------------------------
 extern "C" {

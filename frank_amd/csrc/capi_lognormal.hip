@@ -135,7 +135,7 @@ struct LnWide {
         d0 = v + 12 * N;
         res = v + 13 * N;
         linear = !c->ln_fresh_products;
-        use_inverse = env_int("FRANK_AMD_LNW_INVERSE", 1) != 0;  // (0: rocSOLVER's getrs at every step, ~4x slower)
+        use_inverse = FH_DEV_INT("FRANK_AMD_LNW_INVERSE", 1) != 0;  // (0: rocSOLVER's getrs at every step, ~4x slower)
         P.scal = c->lnw_scal.p;
         return FH_OK;
     }

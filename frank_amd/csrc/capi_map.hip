@@ -151,7 +151,7 @@ int k1v2_ensure_table(fh_ctx *c, int nb_needed) {
     // (chain, column) marches the Taylor expansion in double-double arithmetic -- 35 ms of host work and a 55 MB upload for a table
     // that reaches Q_max at N = 300 become ~3 ms.  FRANK_AMD_K1_TABLES=host keeps the long-double construction (and the
     // single-precision arithmetic keeps it too: its tables are rounded on the host).
-    static const bool host_tables = [] { const char *e = getenv("FRANK_AMD_K1_TABLES"); return e && !strcmp(e, "host"); }();
+    static const bool host_tables = [] { const char *e = FH_DEV_STR("FRANK_AMD_K1_TABLES"); return e && !strcmp(e, "host"); }();
     if (!host_tables && !c->arith32) {
         const int have = c->k1_nb_built;
         const int chains = fh_k1_seed_chains(have, nb_new);
@@ -410,21 +410,21 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned 
 // scatter -> P3 segment moments -> factor -> bin_gram2 on the 13 virtual rows per bucket -> slab reduction (bin_prepass.hip).
 void load_k1_env(fh_ctx *c) {
     fh_ctx::K1Env e;
-    e.unroll = env_int("FRANK_AMD_K1_UNROLL", 2) == 2 ? 2 : 1;
-    e.seg = env_int("FRANK_AMD_K1_SEG", 4096);
-    e.wpb = env_int("FRANK_AMD_K1_WPB", 0);
-    e.blocks = env_int("FRANK_AMD_K1_BLOCKS", 0);
-    e.vrwaves = env_int("FRANK_AMD_K1_VRWAVES", 8);
-    e.vrsplit = env_int("FRANK_AMD_K1_VRSPLIT", 8);
-    e.vrblocks = env_int("FRANK_AMD_K1_VRBLOCKS", 0);
+    e.unroll = FH_DEV_INT("FRANK_AMD_K1_UNROLL", 2) == 2 ? 2 : 1;
+    e.seg = FH_DEV_INT("FRANK_AMD_K1_SEG", 4096);
+    e.wpb = FH_DEV_INT("FRANK_AMD_K1_WPB", 0);
+    e.blocks = FH_DEV_INT("FRANK_AMD_K1_BLOCKS", 0);
+    e.vrwaves = FH_DEV_INT("FRANK_AMD_K1_VRWAVES", 8);
+    e.vrsplit = FH_DEV_INT("FRANK_AMD_K1_VRSPLIT", 8);
+    e.vrblocks = FH_DEV_INT("FRANK_AMD_K1_VRBLOCKS", 0);
     e.no_range_cache = getenv("FRANK_AMD_NO_RANGE_CACHE") != nullptr;
     e.safe_trig = getenv("FRANK_AMD_K1_SAFE_TRIG") != nullptr;
     e.no_hist_cache = getenv("FRANK_AMD_K1_NO_HIST_CACHE") != nullptr;
-    const char *vr = getenv("FRANK_AMD_K1_VR");
+    const char *vr = FH_DEV_STR("FRANK_AMD_K1_VR");
     e.vr_slabs = vr && !strcmp(vr, "slabs");
-    e.dynamic = getenv("FRANK_AMD_K1_DYNAMIC") != nullptr;
+    e.dynamic = FH_DEV_SET("FRANK_AMD_K1_DYNAMIC");
     e.fused = env_int("FRANK_AMD_K1_FUSED", 0);
-    if (const char *r = getenv("FRANK_AMD_K1_RESERVE_MULT")) e.reserve_mult = atof(r);
+    if (const char *r = FH_DEV_STR("FRANK_AMD_K1_RESERVE_MULT")) e.reserve_mult = atof(r);
     c->k1env = e;
 }
 int fh_ctx_reload_env(fh_ctx *c) {
@@ -730,7 +730,7 @@ int fh_bin_visibilities(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, int6
         for (int64_t r0 = 0; r0 < count; r0 += c->wide_rows) {
             const int64_t rows = count - r0 < c->wide_rows ? count - r0 : c->wide_rows;
             HIP_TRY(fh_k1_launch_wide_rows(p, r0, rows, c->wide_X.p, c->stream));
-            if (getenv("FRANK_AMD_WIDE_SYRK")) {
+            if (FH_DEV_SET("FRANK_AMD_WIDE_SYRK")) {
                 ROC_TRY(rocblas_dsyrk(c->blas, rocblas_fill_upper, rocblas_operation_none, N1, (rocblas_int)rows, &one,
                                       c->wide_X.p, N1, &one, G, N1));
             } else {

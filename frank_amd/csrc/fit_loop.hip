@@ -3169,6 +3169,7 @@ size_t fh_k2_loop_smem_bytes(int NP) {
            16 * (size_t)(wide ? kMaxTilesWide : kMaxTiles) + 32 + ((wide || NP > kHandMaxNP) ? 0 : 4 * 2048);  // (+ the hand-over tiles of the cluster mode)
 }
 
+#ifdef FRANK_AMD_DEV
 // Development experiment (FRANK_AMD_K2_DUMMY=<milliseconds>): a workgroup that occupies a CU exactly like the fit loop
 // (threads, LDS) but only spins -- separates what co-running fit loops cost bin_gram through the CU they hold from what
 // they cost through the memory system.  Results are garbage.
@@ -3185,11 +3186,13 @@ __global__ __launch_bounds__(KT) void fit_loop_dummy_kernel(long long cycles, in
         result[1] = 0;
     }
 }
+#endif
 
 // one launch of `blocks` workgroups of the instantiation that covers P.NP
 static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s) {
     size_t smem = fh_k2_loop_smem_bytes(P.NP);
     if (P.NP > kXWideMaxNP) return hipErrorInvalidValue;
+#ifdef FRANK_AMD_DEV
     if (const char *d = getenv("FRANK_AMD_K2_DUMMY")) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_loop_dummy_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -3197,6 +3200,7 @@ static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s)
         hipLaunchKernelGGL(fit_loop_dummy_kernel, dim3(blocks), dim3(KT), smem, s, (long long)(atof(d) * 2.4e6), P.result);
         return hipGetLastError();
     }
+#endif
     // the attribute per launch (cheap): it is per device, and contexts on several devices share this code
     auto go = [&](auto kernel, const FitLoopParams &Q, int grid) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -3215,7 +3219,9 @@ static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s)
         const int nbk = P.NP / 16, h = P.cluster - 1;
         int inv = h >= 4 ? h - 2 : (h >= 2 ? 2 : 1);  // (two helpers of the trailing update are enough from five workgroups on)
         if (loop_is_wide(P.NP)) inv = h;
-        if (const char *ie = getenv("FRANK_AMD_K2_CLUSTER_INV")) inv = atoi(ie);  // development
+#ifdef FRANK_AMD_DEV
+        if (const char *ie = getenv("FRANK_AMD_K2_CLUSTER_INV")) inv = atoi(ie);
+#endif
         inv = inv < 1 ? 1 : (inv > h ? h : inv);
         if (nbk > 2 * inv * NW) return hipErrorInvalidValue;
         Q.cluster_inv = inv;
@@ -3259,9 +3265,11 @@ static hipError_t launch_loop(const FitLoopParams &P, int blocks, hipStream_t s)
         // loops resident a pass takes 186 us against 217 without the pairs (and 264 for the kernel of rounds 2-4), but alone
         // 156 against 135 (133) -- half as many, twice as long chains per step leave waves idle in the late steps --, level
         // at ~190 loops.  P.loaded: fit loops that will be resident beside this launch's (the host's count); the same bits
-        // either way.  FRANK_AMD_K2_PAIR = 0 / 1 forces the choice.
+        // either way.  FRANK_AMD_K2_PAIR = 0 / 1 forces the choice in development builds (-DFRANK_AMD_DEV).
         bool pair = blocks + P.loaded >= 192;
+#ifdef FRANK_AMD_DEV
         if (const char *pe = getenv("FRANK_AMD_K2_PAIR")) pair = atoi(pe) != 0;
+#endif
         if (pair) return go(&fit_loop_kernel<0, 5>, P, blocks);
         return go(&fit_loop_kernel<0, 4>, P, blocks);
     }

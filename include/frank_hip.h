@@ -52,12 +52,15 @@ typedef struct fh_geometry {
 } fh_geometry;
 
 const char *fh_last_error(void);
-/* Optional, ONCE, before the first HIP call of the process (any other entry point that touches the device, or the embedding
- * application's own HIP code): exports GPU_MAX_HW_QUEUES=24 unless the variable is already set -- HIP maps streams onto that many
- * hardware queues (default 4) and kernels whose streams share a queue serialise; a pipeline of fits (fh_fit_submit) uses up to six
- * launch streams beside the binning stream.  Returns the value in effect.  Loading the library has no side effect on the process;
- * a context created with fewer than eight queues leaves a message in fh_last_warning() ("" otherwise; valid until the next
- * fh_ctx_create on this thread).  The Python package calls fh_init() when it is imported.                                  */
+/* Hardware queues.  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; read when the ROCm runtime comes up, at the
+ * first HIP call of the process) and kernels whose streams share a queue serialise; a pipeline of fits (fh_fit_submit) uses up to
+ * six launch streams beside the binning stream.  Loading the library -- and importing the Python package -- changes nothing in the
+ * process.  The first entry point that is about to touch the device (fh_ctx_create, fh_vis_upload*, fh_device_count) exports
+ * GPU_MAX_HW_QUEUES=24 if the runtime is not up yet and the variable is unset; fh_init() does the same on request (an embedding
+ * application with HIP code of its own calls it, or exports the variable, before that code runs).  Returns the number of queues the
+ * runtime came up with, as far as the library can tell (the variable's value, or 4 when somebody else initialised the runtime with
+ * the variable unset).  A context created on fewer than eight leaves a message in fh_last_warning() ("" otherwise; valid until the
+ * next fh_ctx_create on this thread).                                                                                          */
 int fh_init(void);
 const char *fh_last_warning(void);
 const char *fh_version(void);
@@ -81,7 +84,9 @@ int fh_dht_get(const fh_dht *dht, double *r, double *q, double *zeros, double *Y
 int fh_dht_bucket_tables(const fh_dht *dht, int b0, int b1, double *table, double *delta);
 /* The same tables as a context holds them on the device for its first nb buckets, [bucket][12][N] -- since round 5 they are built
  * THERE (host seeds every 16th bucket, double-double Taylor marching in between; FRANK_AMD_K1_TABLES=host keeps the long-double
- * construction): the tests hold them to one unit in the last place of fh_dht_bucket_tables.                                */
+ * construction): the tests hold them to fh_dht_bucket_tables ABSOLUTELY -- |device - host| <= 2.2e-16 (one ulp of 1) per entry,
+ * 4 ulp of 1 per (bucket, column): every entry multiplies |tau|^n <= 1; relatively the high orders of the first buckets differ
+ * by ~1e-7 (they are 1e-7-relative round-off in the host's tables too).                                                     */
 int fh_ctx_bucket_tables(fh_ctx *ctx, int nb, double *table);
 
 /* ---- contexts ------------------------------------------------------------------------------------------- */
