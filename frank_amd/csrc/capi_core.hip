@@ -407,6 +407,14 @@ void fh_ctx_destroy(fh_ctx *c) {
     if (c->ev_bin0) (void)hipEventDestroy(c->ev_bin0);
     if (c->ev_bin1) (void)hipEventDestroy(c->ev_bin1);
     if (c->ev_pre0) (void)hipEventDestroy(c->ev_pre0);
+    if (c->pf_stream) {
+        (void)hipStreamSynchronize(c->pf_stream);
+        (void)hipStreamDestroy(c->pf_stream);
+    }
+    for (auto &la : c->pf) {
+        if (la.event) (void)hipEventDestroy(la.event);
+        if (la.host) (void)hipHostFree(la.host);
+    }
     if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);
     if (c->ev_loop1) (void)hipEventDestroy(c->ev_loop1);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -235,6 +235,21 @@ struct fh_ctx {
     int64_t range_first = -1, range_count = -1;
     double range_geom[6] = {0, 0, 0, 0, 0, 0};
     bool range_valid = false;
+    // fh_bin_prefetch_range: the range pass of the NEXT table on a stream of its own; (-, qmin, qmax, qmax_all) per workgroup land in
+    // pinned host memory behind an event
+    hipStream_t pf_stream = nullptr;
+    struct LookAhead {  // (two are kept: the one for the next pass is asked for BEFORE the current pass is queued, so that its kernel
+                        //  runs in front of that pass and not behind it)
+        hipEvent_t event = nullptr;
+        DevBuf<double> dev;
+        double *host = nullptr;
+        int blocks = 0;
+        bool valid = false;
+        unsigned long long vis = 0, mult_gen = 0;
+        int64_t first = -1, count = -1;
+        double geom[6] = {0, 0, 0, 0, 0, 0};
+    } pf[2];
+    int pf_next = 0;
     // the per-workgroup bucket histograms, their scan and the layout of the sorted table (bin_prepass.hip: P1 + scan) of the LAST
     // pre-pass of the moments path, valid for exactly the rows / geometry / multiplicities of the range key above and this
     // launch geometry: a pass over the same rows skips P1 and the scan (16 of its 104 bytes per row)

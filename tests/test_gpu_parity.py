@@ -1521,6 +1521,26 @@ def test_histograms_are_reused_only_for_the_same_rows(monkeypatch):
     assert a1 == a2 and a1 != a0
     _lib.check(_lib.lib.fh_vis_set_multiplicity(tabs[0], None))
     assert stats(tabs[0], g1) == ref[(0, 1, 150000)]
+    # the range taken ahead of time on the look-ahead stream (fh_bin_prefetch_range), with the range cache off: the same bits when
+    # the pass that follows is for the rows that were looked at, and ignored when it is for other rows, another geometry or count
+    _lib.check(_lib.lib.fh_ctx_set_range_cache(ctx, 0))
+    for look, then in (((0, 1, 150000), (0, 1, 150000)), ((1, 2, 99999), (1, 2, 99999)), ((0, 1, 150000), (1, 1, 150000)),
+                       ((0, 1, 150000), (0, 2, 150000)), ((0, 1, 99999), (0, 1, 150000)), ((1, 1, 150000), (1, 1, 150000))):
+        t, k, n = look
+        _lib.check(_lib.lib.fh_bin_prefetch_range(ctx, ctypes.byref(g1 if k == 1 else g2), tabs[t], 0, n))
+        t, k, n = then
+        assert stats(tabs[t], g1 if k == 1 else g2, n) == ref[(t, k, n)], (look, then)
+    # two look-aheads at once, consumed in either order; a third replaces the older one (which then takes the ordinary route)
+    for first, second in (((0, 1, 150000), (1, 2, 99999)), ((1, 1, 150000), (0, 2, 150000))):
+        for t, k, n in (first, second):
+            _lib.check(_lib.lib.fh_bin_prefetch_range(ctx, ctypes.byref(g1 if k == 1 else g2), tabs[t], 0, n))
+        for t, k, n in (second, first):
+            assert stats(tabs[t], g1 if k == 1 else g2, n) == ref[(t, k, n)], (first, second)
+    for t, k, n in ((0, 1, 150000), (1, 1, 150000), (0, 2, 150000)):
+        _lib.check(_lib.lib.fh_bin_prefetch_range(ctx, ctypes.byref(g1 if k == 1 else g2), tabs[t], 0, n))
+    for t, k, n in ((0, 1, 150000), (1, 1, 150000), (0, 2, 150000)):
+        assert stats(tabs[t], g1 if k == 1 else g2, n) == ref[(t, k, n)], (t, k, n)
+    _lib.check(_lib.lib.fh_ctx_set_range_cache(ctx, 1))
     for vis in tabs:
         _lib.lib.fh_vis_destroy(vis)
 
