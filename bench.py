@@ -885,10 +885,16 @@ def extras(f, L, a):
         dt = time.perf_counter() - t0
         its = np.array(list(niter))
         ex["lognormal_batched64"] = {"workload": "%d LogNormal fits (alpha x w_smooth grid) of one mapping of %d visibilities, "
-                                                 "N=%d, one compute unit each, one launch" % (B, nv, N),
+                                                 "N=%d, staged: one compute unit each until a sixth of them is left, those "
+                                                 "paused and continued on clusters of eight workgroups" % (B, nv, N),
                                      "linesearch": "linear", "fits_per_s": B / dt, "s_total": dt,
                                      "iterations_min_median_max": [int(its.min()), int(np.median(its)), int(its.max())],
-                                     "failed": int(np.sum(np.array(list(status)) != 0))}
+                                     "at_max_iter": int(np.sum(its >= h["max_iter"])),
+                                     "failed": int(np.sum(np.array(list(status)) != 0)),
+                                     "note": "the points that run to max_iter (alpha >= 1.4: the LogNormal iteration does not converge "
+                                             "there) set the time: 2 001 passes heavy in Newton work (4 ms each on one compute unit at "
+                                             "the end, 2.6 ms on a cluster); the single launch of rounds 3-5 took 4.4 s for this grid "
+                                             "(tools/ln_batched64.py: same bits either way)"}
     except Exception as e:
         ex["lognormal_batched64"] = {"error": repr(e)}
     # -- UVDataBinner (next-tier row f4): three streaming passes, 72 algorithmic bytes per row

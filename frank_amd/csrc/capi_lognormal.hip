@@ -1,4 +1,6 @@
 // capi_lognormal.hip -- see capi_internal.h for the map of the C-ABI files.
+#include <chrono>
+
 #include "capi_internal.h"
 
 extern "C" {
@@ -724,11 +726,121 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
     P.batch_counter = counter.p;
     P.batch_alpha = alb.p;
     P.batch_p0 = p0b.p;
+    // The staged schedule (round 6; the Normal sweeps have had it since round 5: capi_fit.hip, sweep_staged).  A launch ends with its
+    // slowest fit, and which points run long is only known once they run (the bench's 64-point grid: eleven of them to max_iter,
+    // 2 001 passes of 1.75 ms on one compute unit each, scattered over the grid).  So every fit first runs on one compute unit,
+    // but PAUSES -- behind an update of p; its state is (s, p, the p before, the count) -- once every fit has been handed out and
+    // only as many are still running as the second stage has clusters for; those continue where they stopped on clusters of eight
+    // workgroups of one XCD each (the form of a single fit: S^-1, Tr2, the Hessian builds and the evaluations shared), up to 32
+    // clusters in one launch.  From N = 160 on (below, a cluster does not pay); FRANK_AMD_LN_CLUSTER=1 keeps the single launch.
+    const int cl2 = env_int("FRANK_AMD_LN_CLUSTER", N >= 160 ? 8 : 1) > 1 && !P.no_cholesky ? 8 : 1;
+    const int max_groups = c->num_cu / cl2 > 0 ? c->num_cu / cl2 : 1;
+    const bool staged = cl2 > 1 && N > 112 && batch >= 8;
+    DevBuf<int> done;
+    if (staged) {
+        if (done.alloc(1) != hipSuccess) return fail(FH_ERR_NOMEM, "device allocation failed");
+        HIP_TRY(hipMemsetAsync(done.p, 0, sizeof(int), c->stream));
+        // (how many: the bench's 64 points, ten of them to max_iter -- 8, 10, 12 left: 3.64 s; 16: 3.78; 24: 3.99; 32: 4.15; the single
+        //  launch 4.44: the passes of a point that does not converge are heavy in Newton work, where a cluster gains 1.5 x, not the
+        //  2.2 x of a converging fit's passes -- so only the true stragglers move: a sixth of the batch)
+        P.pause_when_left = batch / 6 > 2 ? batch / 6 : 2;
+        if (P.pause_when_left > max_groups) P.pause_when_left = max_groups;
+        P.pause_when_left = FH_DEV_INT("FRANK_AMD_LN_STAGE_LEFT", P.pause_when_left);  // (development: tools/ln_batched64.py sweeps it)
+        P.done_counter = done.p;
+    }
+    const bool trace = FH_DEV_SET("FRANK_AMD_SWEEP_TRACE");  // development: stage times on stderr
+    const auto t_stage = std::chrono::steady_clock::now();
     HIP_TRY(fh_ln_launch(P, (int)G, c->stream));
     std::vector<int> res(2 * B);
     std::vector<long long> st(17 * B);
     HIP_TRY(hipMemcpyAsync(res.data(), resb.p, sizeof(int) * 2 * B, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(st.data(), stb.p, sizeof(long long) * 17 * B, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<int> paused;
+    if (trace) {
+        int np = 0, passes = 0;
+        for (int k = 0; k < batch; ++k)
+            if (res[2 * k + 1] == LN_STATUS_PAUSED) {
+                ++np;
+                passes += res[2 * k];
+            }
+        fprintf(stderr, "[ln sweep] stage 1: %.3f s, %d of %d fits paused (mean count %d)\n",
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_stage).count(), np, batch, np ? passes / np : 0);
+    }
+    for (int k = 0; k < batch; ++k)
+        if (res[2 * k + 1] == LN_STATUS_PAUSED) paused.push_back(k);
+    if (!paused.empty()) {
+        // second stage: the paused fits, in the order of the first, on clusters
+        const size_t K = paused.size();
+        const int groups = (int)(K < (size_t)max_groups ? K : (size_t)max_groups);
+        const size_t vstride = (size_t)2 * N + P.NP;
+        DevBuf<double> rs, sb2, pb2, Hb2, lub2, alb2, p0b2, vecs;
+        DevBuf<int> resb2, ctl2;
+        DevBuf<long long> stb2;
+        if (rs.alloc(K * (3 * (size_t)N + 1)) != hipSuccess || sb2.alloc(K * N) != hipSuccess || pb2.alloc(K * N) != hipSuccess ||
+            Hb2.alloc(K * NN) != hipSuccess || lub2.alloc(K * 5 * N) != hipSuccess || alb2.alloc(K) != hipSuccess ||
+            p0b2.alloc(K) != hipSuccess || vecs.alloc((size_t)groups * vstride) != hipSuccess || resb2.alloc(2 * K) != hipSuccess ||
+            ctl2.alloc((size_t)8 * groups) != hipSuccess || stb2.alloc(17 * K) != hipSuccess)
+            return fail(FH_ERR_NOMEM, "fh_fit_lognormal_batched: device allocation for the second stage failed");
+        std::vector<double> al2(K), p02(K), lu2(K * 5 * N), cnt(K);
+        for (size_t q = 0; q < K; ++q) {
+            const int k = paused[q];
+            double *dst = rs.p + q * (3 * (size_t)N + 1);
+            HIP_TRY(hipMemcpyAsync(dst, sb.p + (size_t)k * N, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(dst + N, pb.p + (size_t)k * N, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(dst + 2 * N, Hb.p + (size_t)k * NN, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
+            cnt[q] = (double)res[2 * k];
+            HIP_TRY(hipMemcpyAsync(dst + 3 * N, &cnt[q], sizeof(double), hipMemcpyHostToDevice, c->stream));
+            al2[q] = al_o[k];
+            p02[q] = p0_o[k];
+            memcpy(lu2.data() + q * 5 * N, lu_all.data() + (size_t)k * 5 * N, sizeof(double) * 5 * N);
+        }
+        HIP_TRY(hipMemcpyAsync(lub2.p, lu2.data(), sizeof(double) * lu2.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(alb2.p, al2.data(), sizeof(double) * K, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(p0b2.p, p02.data(), sizeof(double) * K, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(counter.p, 0, sizeof(int), c->stream));
+        HIP_TRY(hipMemsetAsync(ctl2.p, 0, sizeof(int) * 8 * (size_t)groups, c->stream));
+        LogNormalParams P2 = P;
+        P2.batch = (int)K;
+        P2.band_lu = lub2.p;
+        P2.batch_alpha = alb2.p;
+        P2.batch_p0 = p0b2.p;
+        P2.H = Hb2.p;
+        P2.s_out = sb2.p;
+        P2.p_out = pb2.p;
+        P2.result = resb2.p;
+        P2.stats = stb2.p;
+        P2.resume = rs.p;
+        P2.pause_when_left = 0;
+        P2.done_counter = nullptr;
+        P2.cluster = cl2;
+        P2.groups = groups;
+        P2.ctl = ctl2.p;
+        P2.group_vec_stride = (int)vstride;
+        P2.rk_g = vecs.p;
+        P2.tr2_g = vecs.p + N;
+        P2.dvec_g = vecs.p + 2 * N;
+        HIP_TRY(fh_ln_launch(P2, groups, c->stream));
+        std::vector<int> res2(2 * K);
+        std::vector<long long> st2(17 * K);
+        HIP_TRY(hipMemcpyAsync(res2.data(), resb2.p, sizeof(int) * 2 * K, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(st2.data(), stb2.p, sizeof(long long) * 17 * K, hipMemcpyDeviceToHost, c->stream));
+        for (size_t q = 0; q < K; ++q) {  // the second stage's results in the places of the first's
+            const int k = paused[q];
+            HIP_TRY(hipMemcpyAsync(sb.p + (size_t)k * N, sb2.p + q * N, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(pb.p + (size_t)k * N, pb2.p + q * N, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (trace)
+            fprintf(stderr, "[ln sweep] both stages: %.3f s, %zu fits on %d clusters of %d\n",
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_stage).count(), K, groups, cl2);
+        for (size_t q = 0; q < K; ++q) {
+            const int k = paused[q];
+            res[2 * k] = res2[2 * q];
+            res[2 * k + 1] = res2[2 * q + 1];
+            for (int e = 0; e < 9; ++e) st[17 * (size_t)k + e] += st2[17 * q + e];
+        }
+    }
     for (int k = 0; k < batch; ++k) {  // launch order -> the caller's
         HIP_TRY(hipMemcpyAsync(s_map + (size_t)order[k] * N, sb.p + (size_t)k * N, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(p + (size_t)order[k] * N, pb.p + (size_t)k * N, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));

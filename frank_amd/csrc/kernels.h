@@ -320,7 +320,7 @@ hipError_t fh_launch_split_complex(const double *vc, int64_t n, double *re, doub
 
 // ---- LogNormal (lognormal.hip): Newton MAP of the log-brightness + the power-spectrum loop, one workgroup per fit
 enum { LN_MODE_MAP = 0, LN_MODE_FIT = 1, LN_MODE_UPDATE = 2 };
-enum { LN_STATUS_OK = 0, LN_STATUS_BAD_P = 1, LN_STATUS_SLOPE = 2, LN_STATUS_CLUSTER = 3 };
+enum { LN_STATUS_OK = 0, LN_STATUS_BAD_P = 1, LN_STATUS_SLOPE = 2, LN_STATUS_CLUSTER = 3, LN_STATUS_PAUSED = 4 };
 
 struct LogNormalParams {
     int N, max_iter, mode, lu_in_lds, lu_nb;  // lu_nb: panel width of the blocked LU (set by fh_ln_launch)
@@ -358,6 +358,16 @@ struct LogNormalParams {
     int cluster;                  // workgroups of the cluster (1: none)
     int *ctl;                     // [0] sequence number, [1] command, [2] helpers done, [3] helpers alive, [4] disbanded (zeroed per launch)
     double *rk_g, *dvec_g, *tr2_g;  // N: 1 / p; NP: diagonal of the Cholesky factor; N: Tr2 -- the operands the helpers cannot read from the first workgroup's LDS
+    // several clusters in one launch (round 6: the stragglers of a batched sweep): `groups` clusters, group g on XCD g % 8; ctl
+    // (8 ints), the three exchange vectors (group_vec_stride doubles) and the Sinv / LU / Hinv work buffers are strided by group;
+    // a group pulls fits from the batch counter like a lone workgroup does
+    int groups, group_vec_stride;
+    // staged sweeps: a fit pauses behind an update of p -- its state is (s, p, the p before, the count): s_out, p_out, the first N
+    // entries of its H, result[0]; status LN_STATUS_PAUSED -- once every fit of the batch has been handed out and at most
+    // pause_when_left have not ended (checked every 16 passes); resume: [fit][3 N + 1] = s, p, p_old, count of a paused fit
+    int pause_when_left;
+    int *done_counter;
+    const double *resume;
 };
 
 constexpr size_t fh_ln_lu_doubles(int N, int NP) {

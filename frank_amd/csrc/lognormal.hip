@@ -1964,9 +1964,23 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
     __shared__ int s_cl[2];  // cluster: command / flag hand-over inside the workgroup
     int cluster = 1;         // workgroups that share this fit's parallel pieces (1: this one alone)
     bool same_xcd = false;
+    int slot = blockIdx.x;  // which set of work buffers (Sinv, LU, Hinv) this workgroup's fits use
     if (!LDS_LU && P.cluster > 1) {
-        if (blockIdx.x & 7) return;  // (ids 0, 8, 16, ..: one XCD when the dispatcher deals a fresh launch round-robin)
-        const int member = blockIdx.x >> 3;
+        // workgroup ids go round the eight XCDs: id b sits on XCD b & 7 as the (b >> 3)-th of the launch there; the members of
+        // group g are `cluster` consecutive ones of XCD g & 7 (a single fit: group 0 = ids 0, 8, 16, ..)
+        const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int group = (i / P.cluster) * 8 + x, member = i % P.cluster;
+        if (group >= (P.groups > 0 ? P.groups : 1)) return;
+        slot = group;
+        P.ctl += 8 * group;
+        P.rk_g += (size_t)group * P.group_vec_stride;
+        P.tr2_g += (size_t)group * P.group_vec_stride;
+        P.dvec_g += (size_t)group * P.group_vec_stride;
+        if (P.batch) {  // (the helpers work on the group's buffers, whatever fit its first workgroup is on)
+            P.Sinv += (size_t)slot * P.N * P.N;
+            P.LU += (size_t)slot * fh_ln_lu_doubles(P.N, P.NP);
+            P.Hinv += (size_t)slot * P.N * P.N;
+        }
         if (member > 0) {
             cluster_helper(P, member, s_cl);
             return;
@@ -1995,6 +2009,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         __syncthreads();
     }
     const LogNormalParams P0 = P;
+    int cl_seq = 0;  // commands dispatched to this group's helpers so far (the words must never repeat: carried from fit to fit)
     // batched launch: the workgroups pull fit indices from a counter; work buffers belong to the workgroup, outputs to
     // the fit (per-fit alpha, p0, band_lu)
     for (;;) {
@@ -2004,14 +2019,20 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         __syncthreads();
         const int f = s_fit;
         __syncthreads();
-        if (f >= P.batch) return;
+        if (f >= P.batch) {
+            if (cluster > 1) cluster_dispatch(P, LN_CMD_EXIT, same_xcd, cl_seq);  // (the helpers of a group leave with its last fit)
+            return;
+        }
         const int NN = P.N * P.N;
         P.alpha = P.batch_alpha[f];
         P.p0 = P.batch_p0[f];
         P.band_lu += (size_t)f * 5 * P.N;
-        P.Sinv += (size_t)blockIdx.x * NN;
-        P.LU += (size_t)blockIdx.x * fh_ln_lu_doubles(P.N, P.NP);
-        P.Hinv += (size_t)blockIdx.x * NN;
+        if (!(P.cluster > 1)) {  // (a group's buffers were selected above, once)
+            P.Sinv += (size_t)slot * NN;
+            P.LU += (size_t)slot * fh_ln_lu_doubles(P.N, P.NP);
+            P.Hinv += (size_t)slot * NN;
+        }
+        if (P.resume) P.resume += (size_t)f * (3 * P.N + 1);
         P.H += (size_t)f * NN;
         P.s_out += (size_t)f * P.N;
         P.p_out += (size_t)f * P.N;
@@ -2037,7 +2058,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         S.wsol = b;  // one solve vector per wave (72 + 2 LT + 20 N doubles in front: a 16-byte boundary for every N); the tiled
         b += LNW * N;  // Cholesky works in this space AND the panel's behind it (cholesky_as_lu, fh_ln_chol_doubles)
         S.cluster = cluster;
-        S.seq = 0;
+        S.seq = cl_seq;
         S.same_xcd = same_xcd;
         S.s_cl = s_cl;
         S.lu = LDS_LU ? b : P.LU;
@@ -2120,10 +2141,19 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
             S.p[i] = P.p_in[i];
         }
     }
+    const bool resumed = P.mode == LN_MODE_FIT && P.resume != nullptr;
+    if (resumed) {  // a paused fit: it stopped behind an update of p
+        __syncthreads();
+        for (int i = tid; i < N; i += LT) {
+            S.x[i] = P.resume[i];
+            S.p[i] = P.resume[N + i];
+            S.pold[i] = P.resume[2 * N + i];
+        }
+    }
     __syncthreads();
 
-    int status = LN_STATUS_OK, count = 0;
-    bool in_pass = false;
+    int status = LN_STATUS_OK, count = resumed ? (int)P.resume[3 * N] : 0;
+    bool in_pass = resumed;
     for (;;) {
         if (P.mode != LN_MODE_UPDATE) {
             // ---- LogNormalMAPModel(DHT, M, j, p, guess=s, s0)  (statistical_models.py:1012-1160) ----
@@ -2324,8 +2354,24 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
 #endif
         if (P.mode == LN_MODE_UPDATE) break;
         in_pass = true;
+        // a staged sweep: pause here -- (s, p, p_old, count) is the whole state of the iteration -- once every fit of the batch has
+        // been handed out and only a few have not ended: those continue on clusters of workgroups (capi_lognormal.hip)
+        if (P.pause_when_left > 0 && P.batch && (count & 15) == 0) {
+            if (tid == 0)
+                s_fit = __hip_atomic_load(P.batch_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.batch &&
+                        P.batch - __hip_atomic_load(P.done_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= P.pause_when_left;
+            __syncthreads();
+            const int stop = s_fit;
+            __syncthreads();
+            if (stop) {
+                status = LN_STATUS_PAUSED;
+                break;
+            }
+        }
     }
     if (P.mode == LN_MODE_FIT && status == LN_STATUS_OK) build_hess(P, S, P.H, N, true);  // Dinv = hess(s_MAP) (:1147), row-major
+    if (status == LN_STATUS_PAUSED)
+        for (int i = tid; i < N; i += LT) P.H[i] = S.pold[i];  // (the power spectrum before the last update travels in the fit's H)
 
     for (int i = tid; i < N; i += LT) {
         P.s_out[i] = S.x[i];
@@ -2345,8 +2391,13 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
                ln_ev[0] / 1e6, ln_ev[1] / 1e6, ln_ev[2] / 1e6, ln_ev[3] / 1e6);
 #endif
     }
-    if (S.cluster > 1) cluster_dispatch(P, LN_CMD_EXIT, same_xcd, S.seq);
-    if (!P.batch) return;
+    if (tid == 0 && P.done_counter && status != LN_STATUS_PAUSED) atomicAdd(P.done_counter, 1);
+    if (!P.batch) {
+        if (S.cluster > 1) cluster_dispatch(P, LN_CMD_EXIT, same_xcd, S.seq);
+        return;
+    }
+    cluster = S.cluster;  // (a cluster that was disbanded stays so)
+    cl_seq = S.seq;
     __syncthreads();
     }  // next fit of the batch
 }
@@ -2380,9 +2431,16 @@ hipError_t fh_ln_launch(const LogNormalParams &P0, int nblocks, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)smem);
     if (e != hipSuccess) return e;
-    // a cluster: workgroup ids 0, 8, 16, .. of one launch (single fits with the factors in global memory only)
-    const int grid = (P.cluster > 1 && !P.batch && !P.lu_in_lds) ? 8 * (P.cluster - 1) + 1 : nblocks;
-    if (grid == nblocks) P.cluster = 1;
+    // clusters: group g of a launch = `cluster` workgroup ids of XCD g % 8 (factors in global memory only); a single fit is one
+    // group, a staged sweep's second stage up to 256 / cluster of them (P.groups)
+    int grid = nblocks;
+    if (P.cluster > 1 && !P.lu_in_lds && (!P.batch || P.groups > 0)) {
+        if (P.groups < 1) P.groups = 1;
+        grid = P.groups == 1 ? 8 * (P.cluster - 1) + 1 : 8 * P.cluster * ((P.groups + 7) / 8);
+    } else {
+        P.cluster = 1;
+        P.groups = 0;
+    }
     fn<<<grid, LT, smem, s>>>(P);
     return hipGetLastError();
 }

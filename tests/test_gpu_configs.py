@@ -661,6 +661,34 @@ def test_moment_path_equals_row_path(monkeypatch, n):
         assert rel_to_max(sols[0][0].I, sols[1][0].I) < 1e-9
 
 
+def test_lognormal_staged_sweep_equals_single_launch(golden, monkeypatch):
+    """fh_fit_lognormal_batched, round 6: from N = 160 on a sweep of at least eight points runs STAGED -- every fit on one compute
+    unit until only as many are still running as the second stage has clusters for, those paused behind an update of p (state:
+    s, p, the p before, the count) and continued on clusters of eight workgroups, several clusters in one launch.  Pause / resume
+    and the cluster form are exact: the same s, p and counts, bit for bit, as the single launch (FRANK_AMD_LN_CLUSTER=1), whose
+    points that do not converge each hold a compute unit -- and the launch -- to max_iter."""
+    from frank_amd import FrankFitter
+    from frank_amd.sweep import sweep_fits
+    g = golden("lognormal_N300.npz")
+    kw = dict(method="LogNormal", verbose=False, check_qbounds=False, max_iter=160, convergence_failure="ignore")
+    al, ws = np.meshgrid([1.2, 1.3, 1.4, 1.5], [1e-3, 1e-2, 1e-1])
+    al, ws = list(al.ravel()), list(ws.ravel())
+    out = {}
+    for mode in ("staged", "single"):
+        if mode == "single":
+            monkeypatch.setenv("FRANK_AMD_LN_CLUSTER", "1")
+        FF = FrankFitter(2.0, 300, geom(), **kw)
+        _load_mapping(FF, g)
+        FF._vis_map.check_hash = lambda *a, **k: True
+        pre = dict(M=FF._M, j=FF._j, null_likelihood=FF._H0, hash=None)
+        sols, niters = sweep_fits(FF, pre, al, ws, max_iter=160)
+        out[mode] = (sha(*[x.I for x in sols], *[x.power_spectrum for x in sols]), niters)
+    monkeypatch.delenv("FRANK_AMD_LN_CLUSTER")
+    assert out["staged"][1] == out["single"][1]
+    assert out["staged"][0] == out["single"][0]
+    assert min(out["staged"][1]) < max(out["staged"][1])  # (points of different lengths: some ended before the others paused)
+
+
 @pytest.mark.parametrize("n", [3000, 1000000])
 def test_fused_prepass_agrees_with_the_sorted_one(monkeypatch, n):
     """The one-pass form of the moments pre-pass (bin_fused.hip, FRANK_AMD_K1_FUSED=1: the buckets' 36 moment sums accumulated in
