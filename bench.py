@@ -141,6 +141,11 @@ class Fitter:
         self.L.check(self.L.lib.fh_bin_last_prepass_ms(self.ctx, ctypes.byref(ms)))
         return ms.value
 
+    def range_ms(self):
+        ms = ctypes.c_float(0)
+        self.L.check(self.L.lib.fh_bin_last_range_ms(self.ctx, ctypes.byref(ms)))
+        return ms.value
+
     def loop_kernel_ms(self):
         ms = ctypes.c_float(0)
         self.L.check(self.L.lib.fh_fit_last_kernel_ms(self.ctx, ctypes.byref(ms)))
@@ -885,15 +890,17 @@ def extras(f, L, a):
         dt = time.perf_counter() - t0
         its = np.array(list(niter))
         ex["lognormal_batched64"] = {"workload": "%d LogNormal fits (alpha x w_smooth grid) of one mapping of %d visibilities, "
-                                                 "N=%d, staged: one compute unit each until a sixth of them is left, those "
-                                                 "paused and continued on clusters of eight workgroups" % (B, nv, N),
+                                                 "N=%d, staged: every fit on a cluster of four workgroups (64 fits leave three quarters of "
+                                                 "the device idle otherwise) until a sixth of them is left, those paused and continued on "
+                                                 "clusters of eight" % (B, nv, N),
                                      "linesearch": "linear", "fits_per_s": B / dt, "s_total": dt,
                                      "iterations_min_median_max": [int(its.min()), int(np.median(its)), int(its.max())],
                                      "at_max_iter": int(np.sum(its >= h["max_iter"])),
                                      "failed": int(np.sum(np.array(list(status)) != 0)),
                                      "note": "the points that run to max_iter (alpha >= 1.4: the LogNormal iteration does not converge "
                                              "there) set the time: 2 001 passes heavy in Newton work (4 ms each on one compute unit at "
-                                             "the end, 2.6 ms on a cluster); the single launch of rounds 3-5 took 4.4 s for this grid "
+                                             "the end, 2.5 ms on a cluster of eight); the single launch of rounds 3-5 took 4.4 s for this grid, "
+                                             "staged with one compute unit per fit in the first stage 3.6 s "
                                              "(tools/ln_batched64.py: same bits either way)"}
     except Exception as e:
         ex["lognormal_batched64"] = {"error": repr(e)}
@@ -1152,10 +1159,18 @@ def main():
     fallbacks_timed = f.cluster_info()[1]
     # split of one step (untimed, after the measured region): the fit loop as a single fit runs it (a cluster of workgroups,
     # include/frank_hip.h: fh_fit_cluster_info) and on ONE compute unit, the form the steady state runs
+    # (the pass as the timed region runs it: nothing remembered, the range kernel looked ahead)
+    L.check(L.lib.fh_ctx_set_range_cache(f.ctx, 0))
+    L.check(L.lib.fh_bin_prefetch_range(f.ctx, ctypes.byref(f.geom), ring[1], 0, f.nfit))
+    f.bin(vis=ring[1]); f.sync()
+    L.check(L.lib.fh_bin_prefetch_range(f.ctx, ctypes.byref(f.geom), f.vis, 0, f.nfit))
+    f.sync()
     t0 = time.perf_counter(); f.bin(); f.sync(); t_bin = time.perf_counter() - t0
+    L.check(L.lib.fh_ctx_set_range_cache(f.ctx, 1))
     t0 = time.perf_counter(); nit = f.solve(); f.sync(); t_solve = time.perf_counter() - t0  # (table 0: the reference's input)
     kms_alone = f.kernel_ms()
-    pre_alone = f.prepass_ms()
+    rng_alone = f.range_ms()
+    pre_alone = f.prepass_ms() + rng_alone
     loop_ms = f.loop_kernel_ms()
     loop_wgs = f.cluster_info()[0]
     prev = os.environ.get("FRANK_AMD_K2_CLUSTER")
@@ -1291,10 +1306,10 @@ def main():
                          "one_cu": {"kernel": K2_KERNEL_NAME + " on one compute unit (FRANK_AMD_K2_CLUSTER=1: the form of the steady "
                                               "state and of the batched sweeps)", "achieved": achieved_one, "peak": peak_cu,
                                     "frac": achieved_one / peak_cu, "kernel_ms": loop_ms_one}},
-            "roofline_binning": {"kernel": "binning pass: uv_hist, bucket_scan, deproject_scatter, piece_moments, bucket_factor2, "
+            "roofline_binning": {"kernel": "binning pass of rows the context has not binned last: uv_hist (range), uv_hist (histogram), bucket_scan, deproject_scatter, piece_moments, bucket_factor2, "
                                            + K1_KERNEL_NAME + ", vr_finish (bin_prepass.hip)",
                                  "bound": "hbm", "achieved": bin_GBps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                 "frac": bin_GBps / HBM_PEAK_GBPS, "pass_ms": pass_ms, "gram_kernel_ms": kms_alone,
+                                 "frac": bin_GBps / HBM_PEAK_GBPS, "pass_ms": pass_ms, "gram_kernel_ms": kms_alone, "range_kernel_ms": rng_alone,
                                  "algorithmic_bytes_per_vis": 40, "traffic": bin_traffic, "traffic_source": bin_traffic_src,
                                  "achieved_on_traffic_GBps": (bin_traffic["total"] / (pass_ms * 1e-3) / 1e9) if bin_traffic else None,
                                  "row_by_row_equivalent_TFLOPs": flops_sym / (pass_ms * 1e-3) / 1e12,

@@ -72,6 +72,7 @@ SIGNATURES = {
     "fh_bin_prefetch_range": (ctypes.c_int, [_vp, ctypes.POINTER(fh_geometry), _vp, _i64, _i64]),
     "fh_bin_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "fh_bin_last_prepass_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    "fh_bin_last_range_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "fh_fit_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "fh_fit_cluster_info": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_i64)]),
     "fh_ctx_loop_clocks": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_i64)]),

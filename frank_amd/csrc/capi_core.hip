@@ -226,6 +226,8 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     c->k1_moments = !(k1env && !strcmp(k1env, "rows"));  // FRANK_AMD_K1=rows: the v2 kernel on the visibilities themselves
     c->NBT = want_wide ? 0 : (generic ? (N + 1 + 15) / 16 : (c->v2 ? fh_k1v2_nbt_for(N) : fh_k1_nbt_for(N)));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_pre0, hipEventDisableSystemFence));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_rng0, hipEventDisableSystemFence));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_rng1, hipEventDisableSystemFence));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_loop0, hipEventDisableSystemFence));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_loop1, hipEventDisableSystemFence));
     if (c->NBT) {
@@ -411,8 +413,12 @@ void fh_ctx_destroy(fh_ctx *c) {
         (void)hipStreamSynchronize(c->pf_stream);
         (void)hipStreamDestroy(c->pf_stream);
     }
+    if (c->ev_rng0) (void)hipEventDestroy(c->ev_rng0);
+    if (c->ev_rng1) (void)hipEventDestroy(c->ev_rng1);
     for (auto &la : c->pf) {
         if (la.event) (void)hipEventDestroy(la.event);
+        if (la.ev0) (void)hipEventDestroy(la.ev0);
+        if (la.ev1) (void)hipEventDestroy(la.ev1);
         if (la.host) (void)hipHostFree(la.host);
     }
     if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);

@@ -240,7 +240,7 @@ struct fh_ctx {
     hipStream_t pf_stream = nullptr;
     struct LookAhead {  // (two are kept: the one for the next pass is asked for BEFORE the current pass is queued, so that its kernel
                         //  runs in front of that pass and not behind it)
-        hipEvent_t event = nullptr;
+        hipEvent_t event = nullptr, ev0 = nullptr, ev1 = nullptr;  // the copy has landed; around the range kernel (fh_bin_last_range_ms)
         DevBuf<double> dev;
         double *host = nullptr;
         int blocks = 0;
@@ -250,6 +250,7 @@ struct fh_ctx {
         double geom[6] = {0, 0, 0, 0, 0, 0};
     } pf[2];
     int pf_next = 0;
+    LookAhead *rng_la = nullptr;  // the look-ahead whose range the last pass took (its events time the kernel)
     // the per-workgroup bucket histograms, their scan and the layout of the sorted table (bin_prepass.hip: P1 + scan) of the LAST
     // pre-pass of the moments path, valid for exactly the rows / geometry / multiplicities of the range key above and this
     // launch geometry: a pass over the same rows skips P1 and the scan (16 of its 104 bytes per row)
@@ -262,6 +263,8 @@ struct fh_ctx {
     bool k1_moments = true;         // FRANK_AMD_K1=rows: bin the visibilities themselves (the v2 path, kept for cross-checks)
     std::vector<double> k1_scalars_host;
     hipEvent_t ev_pre0 = nullptr;
+    hipEvent_t ev_rng0 = nullptr, ev_rng1 = nullptr;  // around the range pass of the last binning pass that needed one, on whichever stream
+    bool rng_timed = false;
     hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;  // around the fit_loop kernel of the last fh_fit_normal
     bool loop_timed = false;
     bool have_device_mu = false;  // a solve of this context has left a profile in `mu` (fh_vis_residuals_slot with I = NULL reads it)

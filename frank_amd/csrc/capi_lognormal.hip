@@ -736,7 +736,31 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
     const int cl2 = env_int("FRANK_AMD_LN_CLUSTER", N >= 160 ? 8 : 1) > 1 && !P.no_cholesky ? 8 : 1;
     const int max_groups = c->num_cu / cl2 > 0 ? c->num_cu / cl2 : 1;
     const bool staged = cl2 > 1 && N > 112 && batch >= 8;
-    DevBuf<int> done;
+    DevBuf<int> done, ctl1;
+    DevBuf<double> vecs1;
+    // ... and a batch that leaves compute units idle -- 64 points on 256 units -- runs its FIRST stage on clusters too: the largest of
+    // 8, 4, 2 workgroups per fit that keeps every fit resident at once
+    int cl1 = 1;
+    if (staged)
+        for (int cc = 8; cc >= 2; cc >>= 1)
+            if ((long long)batch * cc <= (long long)c->num_cu) {
+                cl1 = cc;
+                break;
+            }
+    cl1 = FH_DEV_INT("FRANK_AMD_LN_STAGE1_CLUSTER", cl1);
+    if (cl1 > 1) {
+        const size_t vstride1 = (size_t)2 * N + P.NP;
+        if (ctl1.alloc((size_t)8 * G) != hipSuccess || vecs1.alloc(G * vstride1) != hipSuccess)
+            return fail(FH_ERR_NOMEM, "device allocation failed");
+        HIP_TRY(hipMemsetAsync(ctl1.p, 0, sizeof(int) * 8 * G, c->stream));
+        P.cluster = cl1;
+        P.groups = (int)G;
+        P.ctl = ctl1.p;
+        P.group_vec_stride = (int)vstride1;
+        P.rk_g = vecs1.p;
+        P.tr2_g = vecs1.p + N;
+        P.dvec_g = vecs1.p + 2 * N;
+    }
     if (staged) {
         if (done.alloc(1) != hipSuccess) return fail(FH_ERR_NOMEM, "device allocation failed");
         HIP_TRY(hipMemsetAsync(done.p, 0, sizeof(int), c->stream));

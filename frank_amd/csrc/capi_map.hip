@@ -291,6 +291,7 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     // qmax_all: over every row of the range whatever its multiplicity -- the sort is sized from it, because rows drawn
     // zero times are still sorted (with weight 0) and must land in a bucket of their own argument
     double qmax = 0.0, qmin = INFINITY, qmax_all = 0.0;
+    c->rng_timed = false;
     if (known) {  // same rows, same geometry: the range is the one read back last time, no host round trip
         qmin = c->prepass_qmin;
         qmax = c->prepass_qmax;
@@ -440,7 +441,6 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     P.partial_scalars = c->partial_scalars.p;
     const fh_ctx::K1Env &E = c->k1env;
     P.unroll = E.unroll;
-    HIP_TRY(hipEventRecord(c->ev_pre0, c->stream));
     const double gkey[6] = {p.dRA, p.dDec, p.cos_t, p.sin_t, p.cos_i, p.sin_i};
     const bool known = c->range_valid && c->range_vis == vis_serial && c->range_mult_gen == mult_gen && c->range_first == p.first &&
                        c->range_count == count && memcmp(gkey, c->range_geom, sizeof gkey) == 0 && !c->no_range_cache &&
@@ -466,10 +466,16 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
             sc = hit->host;
             rblocks = hit->blocks;
             hit->valid = false;
+            c->rng_la = hit;
+            c->rng_timed = true;
         } else {
             fh_prepass_geometry(0, c->num_cu, &P.wpb, &P.blocks);
             rblocks = P.blocks;
+            HIP_TRY(hipEventRecord(c->ev_rng0, c->stream));
             HIP_TRY(fh_prepass_launch_range(P, c->stream));
+            HIP_TRY(hipEventRecord(c->ev_rng1, c->stream));
+            c->rng_la = nullptr;
+            c->rng_timed = true;
             c->k1_scalars_host.resize((size_t)rblocks * 4);
             HIP_TRY(hipMemcpyAsync(c->k1_scalars_host.data(), c->partial_scalars.p, sizeof(double) * (size_t)rblocks * 4,
                                    hipMemcpyDeviceToHost, c->stream));
@@ -566,6 +572,9 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     const bool reuse = known && c->hist_valid && c->hist_nb == nb && c->hist_blocks == P.blocks && c->hist_wpb == P.wpb &&
                        c->hist_unroll == P.unroll && c->hist_seg == seg && c->hist_fused == fused && !E.no_hist_cache;
     c->hist_valid = false;
+    // (the events of fh_bin_last_prepass_ms start HERE: behind the range -- cached, looked ahead, or waited for above; its kernel has
+    //  events of its own, fh_bin_last_range_ms)
+    HIP_TRY(hipEventRecord(c->ev_pre0, c->stream));
     if (fused) {
         if (!reuse) {
             HIP_TRY(fh_prepass_launch_hist(P, c->stream));
@@ -711,7 +720,11 @@ int fh_bin_prefetch_range(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, in
     if (!c->pf_stream) HIP_TRY(hipStreamCreateWithFlags(&c->pf_stream, hipStreamNonBlocking));
     fh_ctx::LookAhead &la = c->pf[c->pf_next];
     c->pf_next ^= 1;
-    if (!la.event) HIP_TRY(hipEventCreateWithFlags(&la.event, hipEventDisableSystemFence));
+    if (!la.event) {
+        HIP_TRY(hipEventCreateWithFlags(&la.event, hipEventDisableSystemFence));
+        HIP_TRY(hipEventCreateWithFlags(&la.ev0, hipEventDisableSystemFence));
+        HIP_TRY(hipEventCreateWithFlags(&la.ev1, hipEventDisableSystemFence));
+    }
     if (la.blocks < P.blocks) {
         if (la.host) (void)hipHostFree(la.host);
         la.host = nullptr;
@@ -721,7 +734,9 @@ int fh_bin_prefetch_range(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, in
     la.valid = false;
     la.blocks = P.blocks;
     P.partial_scalars = la.dev.p;
+    HIP_TRY(hipEventRecord(la.ev0, c->pf_stream));
     HIP_TRY(fh_prepass_launch_range(P, c->pf_stream));
+    HIP_TRY(hipEventRecord(la.ev1, c->pf_stream));
     HIP_TRY(hipMemcpyAsync(la.host, la.dev.p, sizeof(double) * (size_t)P.blocks * 4, hipMemcpyDeviceToHost, c->pf_stream));
     HIP_TRY(hipEventRecord(la.event, c->pf_stream));
     const double gkey[6] = {P.bin.dRA, P.bin.dDec, P.bin.cos_t, P.bin.sin_t, P.bin.cos_i, P.bin.sin_i};
@@ -865,6 +880,20 @@ int fh_bin_last_prepass_ms(fh_ctx *c, float *ms) {
     if (!c->bin_timed || !c->v2) return fail(FH_ERR_INVALID, "no bin_gram (v2) launch recorded yet");
     HIP_TRY(hipEventSynchronize(c->ev_bin0));
     HIP_TRY(hipEventElapsedTime(ms, c->ev_pre0, c->ev_bin0));
+    return FH_OK;
+}
+
+int fh_bin_last_range_ms(fh_ctx *c, float *ms) {
+    if (!c || !ms) return fail(FH_ERR_INVALID, "fh_bin_last_range_ms: NULL argument");
+    *ms = 0.0f;
+    if (!c->rng_timed) return FH_OK;  // (the last pass took its range from the cache: no kernel)
+    if (c->rng_la) {
+        HIP_TRY(hipEventSynchronize(c->rng_la->ev1));
+        HIP_TRY(hipEventElapsedTime(ms, c->rng_la->ev0, c->rng_la->ev1));
+    } else {
+        HIP_TRY(hipEventSynchronize(c->ev_rng1));
+        HIP_TRY(hipEventElapsedTime(ms, c->ev_rng0, c->ev_rng1));
+    }
     return FH_OK;
 }
 

@@ -152,10 +152,13 @@ int fh_bin_reset(fh_ctx *ctx);
 int fh_bin_visibilities(fh_ctx *ctx, const fh_geometry *geom, const fh_vis *vis, int64_t first, int64_t count);
 /* Device time (ms, HIP events on the context's stream) of the most recent bin_gram launch alone. */
 int fh_bin_last_kernel_ms(fh_ctx *ctx, float *ms);
-/* Time (ms) from the start of the binning pass to the start of its Gram kernel: the host's look at the baseline range when the
- * context has not seen the rows before (the _check_uv_range input, statistical_models.py:166-169), the (u, v) histogram, the
- * fused deprojection + bucket sort and the bucket moments (default path), or deprojection + bucket sort (rows path).       */
+/* Device time (ms, HIP events) of the binning pass in front of its Gram kernel: the (u, v) histogram + scan when the rows are not
+ * the ones binned last, the fused deprojection + bucket sort and the bucket moments (default path), or deprojection + bucket sort
+ * (rows path).  Since round 6 WITHOUT the look at the baseline range (the _check_uv_range input, statistical_models.py:166-169):
+ * that kernel runs in front of the pass -- on the look-ahead stream after fh_bin_prefetch_range -- and has events of its own:  */
 int fh_bin_last_prepass_ms(fh_ctx *ctx, float *ms);
+/* ... device time (ms) of the range kernel the most recent binning pass needed; 0 when it took the range from the cache.      */
+int fh_bin_last_range_ms(fh_ctx *ctx, float *ms);
 /* Duration of the fit_loop kernel of the last fh_fit_normal call, by HIP events on the context's stream (bench.py). */
 int fh_fit_last_kernel_ms(fh_ctx *ctx, float *ms);
 /* Arithmetic of bin_gram (BASELINE configs[2], "fp32").  fp32 != 0: the Bessel design block and the tile products of the

@@ -21,7 +21,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 else:
     sizes = [113, 120, 127, 128, 129, 144, 159, 160, 161, 176, 191, 192, 193, 208, 224, 239, 240, 241, 255, 256, 257, 272, 288, 300, 303, 304, 305, 319, 320]
     res = {}
-    for tag, env in (("cluster8", {}), ("single", {"FRANK_AMD_LN_CLUSTER": "1"}), ("cluster3", {"FRANK_AMD_LN_CLUSTER": "3"})):
+    runs = [("cluster8", {}), ("single", {"FRANK_AMD_LN_CLUSTER": "1"}), ("cluster3", {"FRANK_AMD_LN_CLUSTER": "3"})]
+    # (round 6: the Cholesky on packed tiles against the routine of rounds 3-5 -- a library built with the older lognormal.hip)
+    old_lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "frank_amd", "libfrank_hip_old.so")
+    if os.path.exists(old_lib):
+        runs.append(("older_kernel", {"FRANK_AMD_LIB": old_lib}))
+    for tag, env in runs:
         path = "/tmp/ln_sweep_%s.npz" % tag
         subprocess.run([sys.executable, os.path.abspath(__file__), "child", ",".join(map(str, sizes)), path], env=dict(os.environ, **env), check=True)
         res[tag] = np.load(path)
@@ -29,7 +34,9 @@ else:
     for N in sizes:
         a, b, c = res["cluster8"][str(N)], res["single"][str(N)], res["cluster3"][str(N)]
         same = np.array_equal(a, b) and np.array_equal(a, c) and np.all(np.isfinite(a))
+        if "older_kernel" in res:
+            same = same and np.array_equal(a, res["older_kernel"][str(N)])
         if not same:
             bad.append(N)
-        print("N=%3d  cluster 8 == single == cluster 3: %s  (max rel diff %.1e)" % (N, same, np.abs(a - b).max() / np.abs(b).max()), flush=True)
+        print("N=%3d  cluster 8 == single == cluster 3 (== the kernel of rounds 3-5, if its library is there): %s  (max rel diff %.1e)" % (N, same, np.abs(a - b).max() / np.abs(b).max()), flush=True)
     print("sizes checked: %d, mismatches: %s" % (len(sizes), bad))
