@@ -1221,8 +1221,8 @@ def main():
         # bench.py); they describe the build the profile was taken from, named in the *_source fields
         traffic, traffic_one, traffic_src, bin_traffic, bin_traffic_src, profile_lib = None, None, None, None, None, None
 
-        def pmc(name):  # (the round-5 profile if it has been taken, else round 4's)
-            for nm in (name.replace("r04_", "r05_"), name):
+        def pmc(name):  # (the newest profile that has been taken: round 6, 5, 4)
+            for nm in (name.replace("r04_", "r06_"), name.replace("r04_", "r05_"), name):
                 try:
                     with open(os.path.join(ROOT, "profiles", nm)) as fh:
                         d = json.load(fh)
@@ -1247,11 +1247,12 @@ def main():
             pm, pmf = pmc("r04_pmc_binning.json"), pmc("r04_pmc_binning_first_sight.json")
             if Nc == 300 and a.nvis == N_VIS:
                 # a pass over rows the context binned last keeps the (u, v) histogram and its scan: those two kernels do not run
-                first = {k: int(e["hbm_bytes_per_launch"]) for k, e in pmf.items() if isinstance(e, dict) and "hbm_bytes_per_launch" in e}
-                bin_traffic = {k: int(e["hbm_bytes_per_launch"]) for k, e in pm.items()
-                               if isinstance(e, dict) and "hbm_bytes_per_launch" in e and not k.startswith(("uv_hist", "bucket_scan"))}
+                # the pass of the timed region looks at (u, v) twice (range, histogram) and scans: every kernel of the first-sight profile
+                bin_traffic = {k: int(e["hbm_bytes_per_launch"]) for k, e in pmf.items() if isinstance(e, dict) and "hbm_bytes_per_launch" in e}
+                cached = sum(int(e["hbm_bytes_per_launch"]) for k, e in pm.items()
+                             if isinstance(e, dict) and "hbm_bytes_per_launch" in e and not k.startswith(("uv_hist", "bucket_scan")))
                 bin_traffic["total"] = int(sum(bin_traffic.values()))
-                bin_traffic["total_at_first_sight_of_a_table"] = int(sum(first.values()))
+                bin_traffic["total_with_the_caches_on"] = int(cached)
             bin_traffic_src = ("static: profiles/%s, %s (one pass of 1e7 visibilities "
                                "at N = 300, per kernel; 2 x FETCH_SIZE + WRITE_SIZE), library build '%s'; not measured in this run"
                                % (pm.get("_file"), pmf.get("_file"), pm.get("_library")))
@@ -1301,7 +1302,7 @@ def main():
                                       "in cluster mode (%d/256); the mode buys latency (a pass is a chain of 19 dependent tile "
                                       "factorisations) with compute units that mostly wait -- the fraction per CU is lower "
                                       "than on one CU by design" % (loop_wgs, loop_wgs),
-                         "why_this_kernel": "most of the GPU time of the timed region (profiles/r05_kernel_stats.csv)",
+                         "why_this_kernel": "most of the GPU time of the timed region (profiles/r06_kernel_stats.csv)",
                          "traffic_one_cu": traffic_one, "profile_library": profile_lib,
                          "one_cu": {"kernel": K2_KERNEL_NAME + " on one compute unit (FRANK_AMD_K2_CLUSTER=1: the form of the steady "
                                               "state and of the batched sweeps)", "achieved": achieved_one, "peak": peak_cu,
@@ -1316,8 +1317,11 @@ def main():
                                  "note": "the rows of a J0 bucket enter the Gram through 12 x 12 moments, so the pass is "
                                          "memory-bound; row_by_row_equivalent is what binning every visibility on the "
                                          "matrix pipe (the rows kernel, 15.2 ms = 0.76 of the fp64 matrix peak) would need; "
-                                         "what the pass moves: 16 B (u, v) + 40 B (all columns) + 24 B written + 24 B read = "
-                                         "104 B per visibility"},
+                                         "what the pass moves: 16 B (u, v: the range) + 16 B (u, v: the histogram) + 40 B (all columns) + "
+                                         "24 B written + 24 B read = 120 B per visibility when nothing is remembered, as the timed region runs it "
+                                         "(104 B with the range cached, 88 B with the histogram kept too: extra.headline_with_caches); the fused "
+                                         "one-pass form, 42 B per visibility, is slower: profiles/r06_binning_fused.txt; pass_ms = the range "
+                                         "kernel (on the look-ahead stream) + the pre-pass + the Gram kernels, by events"},
         }
         if ref_iters is not None and nit != ref_iters:
             out["parity_error"] = "the fit took %d iterations, the reference %d on the same input" % (nit, ref_iters)
