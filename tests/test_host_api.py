@@ -445,3 +445,30 @@ def test_no_accumulator_of_an_inline_matrix_instruction_is_read_too_early():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_mfma_hazard.py"), "-DRR_NO_BLOCK_NOPS"], capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 1, r.stdout + r.stderr
+
+
+def test_shipped_library_reads_only_the_form_switches():
+    """Round 6 hygiene: the tuning knobs, probes and kill-line forms of the earlier rounds (~25 FRANK_AMD_* variables, one of them a
+    kernel whose results are garbage) are compiled out of the shipped library (capi_internal.h: FH_DEV_*; `make dev` builds them in).
+    What is left selects among forms that give the same results and is listed in INTEGRATION.md."""
+    import re
+    from frank_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as fh:
+        names = set(m.decode() for m in re.findall(rb"FRANK_AMD_[A-Z0-9_]+", fh.read()))
+    allowed = {"FRANK_AMD_K1", "FRANK_AMD_K1_FUSED", "FRANK_AMD_K1_NO_HIST_CACHE", "FRANK_AMD_K1_SAFE_TRIG", "FRANK_AMD_NO_RANGE_CACHE",
+               "FRANK_AMD_K2", "FRANK_AMD_K2_CLUSTER", "FRANK_AMD_K2_CLUSTER_BREAK", "FRANK_AMD_K2_RR", "FRANK_AMD_K2_DEFER",
+               "FRANK_AMD_K2_LL", "FRANK_AMD_SWEEP_CAP", "FRANK_AMD_SWEEP_LEFT", "FRANK_AMD_SWEEP_STAGE2_CLUSTERS",
+               "FRANK_AMD_SWEEP_NO_CLUSTERS", "FRANK_AMD_LN_CLUSTER", "FRANK_AMD_LN_PIVOTED", "FRANK_AMD_RESIDUAL_DIRECT"}
+    assert names <= allowed, sorted(names - allowed)
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for n in names:
+        assert n in text or n.replace("FRANK_AMD", "") in text, n + " is not documented in INTEGRATION.md"
+    # importing the package leaves the environment alone (the hardware-queue variable is settled at the first device entry)
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-c", "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import frank_amd; "
+                          "from frank_amd import _lib; import ctypes; print(ctypes.CDLL(None).getenv(b'GPU_MAX_HW_QUEUES'))"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode == 0, out.stderr[-800:]
+    assert out.stdout.strip().splitlines()[-1] in ("0", "None"), out.stdout
+
