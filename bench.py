@@ -1307,7 +1307,7 @@ def main():
                          "one_cu": {"kernel": K2_KERNEL_NAME + " on one compute unit (FRANK_AMD_K2_CLUSTER=1: the form of the steady "
                                               "state and of the batched sweeps)", "achieved": achieved_one, "peak": peak_cu,
                                     "frac": achieved_one / peak_cu, "kernel_ms": loop_ms_one}},
-            "roofline_binning": {"kernel": "binning pass of rows the context has not binned last: uv_hist (range), uv_hist (histogram), bucket_scan, deproject_scatter, piece_moments, bucket_factor2, "
+            "roofline_binning": {"kernel": "binning pass of rows the context has not binned last: uv_hist (range + histograms: one look), bucket_scan, deproject_scatter, piece_moments, bucket_factor2, "
                                            + K1_KERNEL_NAME + ", vr_finish (bin_prepass.hip)",
                                  "bound": "hbm", "achieved": bin_GBps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                  "frac": bin_GBps / HBM_PEAK_GBPS, "pass_ms": pass_ms, "gram_kernel_ms": kms_alone, "range_kernel_ms": rng_alone,
@@ -1317,9 +1317,9 @@ def main():
                                  "note": "the rows of a J0 bucket enter the Gram through 12 x 12 moments, so the pass is "
                                          "memory-bound; row_by_row_equivalent is what binning every visibility on the "
                                          "matrix pipe (the rows kernel, 15.2 ms = 0.76 of the fp64 matrix peak) would need; "
-                                         "what the pass moves: 16 B (u, v: the range) + 16 B (u, v: the histogram) + 40 B (all columns) + "
-                                         "24 B written + 24 B read = 120 B per visibility when nothing is remembered, as the timed region runs it "
-                                         "(104 B with the range cached, 88 B with the histogram kept too: extra.headline_with_caches); the fused "
+                                         "what the pass moves: 16 B (u, v: ONE look gives the range and the histograms -- on the look-ahead stream) + "
+                                         "40 B (all columns) + 24 B written + 24 B read = 104 B per visibility when nothing is remembered, as the "
+                                         "timed region runs it (88 B with the histograms kept: extra.headline_with_caches); the fused "
                                          "one-pass form, 42 B per visibility, is slower: profiles/r06_binning_fused.txt; pass_ms = the range "
                                          "kernel (on the look-ahead stream) + the pre-pass + the Gram kernels, by events"},
         }

@@ -87,7 +87,12 @@ __global__ __launch_bounds__(1024) void uv_hist_kernel(PrepassParams P) {
     }
     __syncthreads();
     if (HIST) {  // bucket-major: hist[b][workgroup]
-        for (int b = threadIdx.x; b < P.nb; b += blockDim.x) P.hist[(size_t)b * P.hist_stride + blockIdx.x] = lds_i[b];
+        // (one look: the count of buckets is an upper bound, ~8 x the buckets the rows reach -- 1.45 M four-byte stores per pass at
+        //  N = 300, 50 us; the buffer is cleared in front of the kernel instead, 6 MB at memory speed, and only counts are stored)
+        for (int b = threadIdx.x; b < P.nb; b += blockDim.x) {
+            const int v = lds_i[b];
+            if (v != 0 || !P.hist_zeroed) P.hist[(size_t)b * P.hist_stride + blockIdx.x] = v;
+        }
     }
     if (threadIdx.x == 0) {
         double mn = INFINITY, mx = -INFINITY, ma = -INFINITY;
@@ -784,10 +789,8 @@ hipError_t fh_prepass_launch(const PrepassParams &P, hipStream_t stream, int ski
                                 (int)lds3);
         if (e != hipSuccess) return e;
     }
-    if (!skip_hist) {
-        hipLaunchKernelGGL(uv_hist_kernel<true>, dim3(P.blocks), dim3(64 * P.wpb), lds1, stream, P);
-        hipLaunchKernelGGL(bucket_scan_kernel, dim3((P.nb + 15) / 16), dim3(1024), 0, stream, P);
-    }
+    if (skip_hist == 0) hipLaunchKernelGGL(uv_hist_kernel<true>, dim3(P.blocks), dim3(64 * P.wpb), lds1, stream, P);
+    if (skip_hist != 1) hipLaunchKernelGGL(bucket_scan_kernel, dim3((P.nb + 15) / 16), dim3(1024), 0, stream, P);  // (2: the histograms exist)
     e = launch_scatter(P, lds2, stream);
     if (e != hipSuccess) return e;
     const int64_t max_pieces = fh_prepass_max_pieces(P.bin.count, P.nb, P.seg_rows);
@@ -805,6 +808,30 @@ hipError_t fh_prepass_launch_hist(const PrepassParams &P, hipStream_t stream) {
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(uv_hist_kernel<true>, dim3(P.blocks), dim3(64 * P.wpb), lds1, stream, P);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3((P.nb + 15) / 16), dim3(1024), 0, stream, P);
+    return hipGetLastError();
+}
+// (a kernel of this library's own: hipMemsetAsync of a few MB held the calling thread until the stream had caught up, 0.25 ms per
+//  step of a pipeline)
+__global__ __launch_bounds__(256) void zero_ints_kernel(int4 *p, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = make_int4(0, 0, 0, 0);
+}
+hipError_t fh_prepass_launch_zero(int *p, size_t n, hipStream_t stream) {  // n a multiple of 4, p 16-byte aligned
+    hipLaunchKernelGGL(zero_ints_kernel, dim3(512), dim3(256), 0, stream, reinterpret_cast<int4 *>(p), n / 4);
+    return hipGetLastError();
+}
+// P1 alone with a bucket count that is an upper bound (the look at (u, v) that gives the range AND the histograms, round 6)
+hipError_t fh_prepass_launch_look(const PrepassParams &P, hipStream_t stream) {
+    const size_t lds1 = sizeof(int) * (size_t)P.nb;
+    if (lds1 > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&uv_hist_kernel<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(uv_hist_kernel<true>, dim3(P.blocks), dim3(64 * P.wpb), lds1, stream, P);
+    return hipGetLastError();
+}
+hipError_t fh_prepass_launch_scan(const PrepassParams &P, hipStream_t stream) {
     hipLaunchKernelGGL(bucket_scan_kernel, dim3((P.nb + 15) / 16), dim3(1024), 0, stream, P);
     return hipGetLastError();
 }

@@ -415,10 +415,12 @@ void fh_ctx_destroy(fh_ctx *c) {
     }
     if (c->ev_rng0) (void)hipEventDestroy(c->ev_rng0);
     if (c->ev_rng1) (void)hipEventDestroy(c->ev_rng1);
-    for (auto &la : c->pf) {
+    for (auto &lp : c->pf) {
+        fh_ctx::LookAhead &la = *lp;
         if (la.event) (void)hipEventDestroy(la.event);
         if (la.ev0) (void)hipEventDestroy(la.ev0);
         if (la.ev1) (void)hipEventDestroy(la.ev1);
+        if (la.consumed) (void)hipEventDestroy(la.consumed);
         if (la.host) (void)hipHostFree(la.host);
     }
     if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);

@@ -238,18 +238,29 @@ struct fh_ctx {
     // fh_bin_prefetch_range: the range pass of the NEXT table on a stream of its own; (-, qmin, qmax, qmax_all) per workgroup land in
     // pinned host memory behind an event
     hipStream_t pf_stream = nullptr;
-    struct LookAhead {  // (two are kept: the one for the next pass is asked for BEFORE the current pass is queued, so that its kernel
-                        //  runs in front of that pass and not behind it)
+    struct LookAhead {  // (the one for the next pass is asked for BEFORE the current pass is queued, so that its kernel runs in front of
+                        //  that pass and not behind it)
         hipEvent_t event = nullptr, ev0 = nullptr, ev1 = nullptr;  // the copy has landed; around the range kernel (fh_bin_last_range_ms)
         DevBuf<double> dev;
+        DevBuf<int> hist;           // one look: the per-workgroup bucket histograms of these rows for nb_cap buckets (has_hist)
+        bool has_hist = false;
+        hipEvent_t consumed = nullptr;  // on the binning stream, behind the kernels that read `hist`: the next look into this slot waits for it
+        bool consumed_pending = false;
+        int nb_cap = 0, hist_stride = 0, wpb = 0, unroll = 0;
         double *host = nullptr;
         int blocks = 0;
         bool valid = false;
+        unsigned long long seq = 0;  // order of the fh_bin_prefetch_range calls
         unsigned long long vis = 0, mult_gen = 0;
         int64_t first = -1, count = -1;
         double geom[6] = {0, 0, 0, 0, 0, 0};
-    } pf[2];
-    int pf_next = 0;
+    };
+    // A pool: a look-ahead is free once the pass that took its histograms has run on the binning stream (`consumed`); a pipeline
+    // whose host runs K passes ahead of the device has K in use (the driver's 20 steps: ~20 x 6 MB).  Capped at kMaxLookAheads:
+    // beyond, the oldest is waited for.
+    static constexpr int kMaxLookAheads = 48;
+    std::vector<std::unique_ptr<LookAhead>> pf;
+    unsigned long long pf_seq = 0;
     LookAhead *rng_la = nullptr;  // the look-ahead whose range the last pass took (its events time the kernel)
     // the per-workgroup bucket histograms, their scan and the layout of the sorted table (bin_prepass.hip: P1 + scan) of the LAST
     // pre-pass of the moments path, valid for exactly the rows / geometry / multiplicities of the range key above and this

@@ -870,6 +870,10 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
         HIP_TRY(hipMemcpyAsync(p + (size_t)order[k] * N, pb.p + (size_t)k * N, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < batch; ++k)
+        if (res[2 * k + 1] == LN_STATUS_CLUSTER || res[2 * k + 1] == LN_STATUS_PAUSED)  // (never a result: fail loudly, as a single fit does)
+            return fail(FH_ERR_HIP, "fh_fit_lognormal_batched: a cluster of workgroups stopped answering in the middle of fit %d "
+                        "(FRANK_AMD_LN_CLUSTER=1 runs every fit on one workgroup, one launch)", order[k]);
     for (int k = 0; k < batch; ++k) {
         const int b = order[k];
         niter[b] = res[2 * k];

@@ -258,6 +258,17 @@ int running_fit_loops(fh_ctx *c) {
 // K1 v2: deproject -> (host: baseline range, bucket tables) -> bucket sort -> bin_gram2 -> slab reduction.
 // The one host round trip (64 KB of per-block scalars) is what _check_uv_range needs before any binning in the reference
 // too (statistical_models.py:166-169); it costs the stream ~20 us of idle time per call.
+// ONE LOOK (round 6).  The range pass and the histogram pass of a table the context has not binned last both read (u, v) and form
+// every row's baseline; the histogram only needs the bucket COUNT to be an upper bound -- s = q / Qmax <= q_N / Qmax for every table
+// that passes the range check, and the histograms of a larger count are the same numbers with zeros behind them --, so one launch of
+// uv_hist_kernel<true> with that bound gives the range and the histograms: 16 B per row and ~35 us less per pass.  Where the bound
+// keeps the launch geometry of the sort (eight waves per workgroup: <= 2 048 buckets, N <~ 320); a table that reaches beyond the
+// bound (range check off) takes the two looks of rounds 3-5.
+static int one_look_buckets(const fh_ctx *c) {
+    const double cap = c->dht->q[c->N - 1] / c->dht->Qmax * (1.0 + 1e-9) / c->k1_delta + 3.0;
+    return cap <= 2048.0 ? (int)cap : 0;
+}
+
 static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned long long vis_serial,
                                unsigned long long mult_gen);
 
@@ -291,7 +302,6 @@ static int bin_visibilities_v2(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     // qmax_all: over every row of the range whatever its multiplicity -- the sort is sized from it, because rows drawn
     // zero times are still sorted (with weight 0) and must land in a bucket of their own argument
     double qmax = 0.0, qmin = INFINITY, qmax_all = 0.0;
-    c->rng_timed = false;
     if (known) {  // same rows, same geometry: the range is the one read back last time, no host round trip
         qmin = c->prepass_qmin;
         qmax = c->prepass_qmax;
@@ -448,6 +458,13 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     // qmax_all: over every row of the range whatever its multiplicity -- the sort is sized from it, because rows drawn
     // zero times are still sorted (with weight 0) and must land in a bucket of their own argument
     double qmax = 0.0, qmin = INFINITY, qmax_all = 0.0;
+    c->rng_timed = false;
+    // one look (see one_look_buckets): the histograms of these rows for look_cap >= nb buckets, from the look-ahead or from this call
+    int *look_hist = nullptr;
+    int look_cap = 0, look_stride = 0, look_wpb = 0, look_blocks = 0;
+    const double *look_scalars = nullptr;
+    hipEvent_t look_event = nullptr;
+    fh_ctx::LookAhead *look_la = nullptr;
     if (known) {  // same rows, same geometry: the range is the one read back last time, no host round trip
         qmin = c->prepass_qmin;
         qmax = c->prepass_qmax;
@@ -456,10 +473,10 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
         const double *sc = nullptr;
         int rblocks = 0;
         fh_ctx::LookAhead *hit = nullptr;
-        for (auto &la : c->pf)
-            if (la.valid && la.vis == vis_serial && la.mult_gen == mult_gen && la.first == p.first && la.count == count &&
-                memcmp(gkey, la.geom, sizeof gkey) == 0)
-                hit = &la;
+        for (auto &lp : c->pf)
+            if (lp->valid && lp->vis == vis_serial && lp->mult_gen == mult_gen && lp->first == p.first && lp->count == count &&
+                memcmp(gkey, lp->geom, sizeof gkey) == 0)
+                hit = lp.get();
         if (hit) {
             // ... taken ahead of time on the look-ahead stream (fh_bin_prefetch_range): wait for THAT pass only
             HIP_TRY(hipEventSynchronize(hit->event));
@@ -468,11 +485,45 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
             hit->valid = false;
             c->rng_la = hit;
             c->rng_timed = true;
+            if (hit->has_hist && hit->unroll == P.unroll) {
+                look_hist = hit->hist.p;
+                look_cap = hit->nb_cap;
+                look_stride = hit->hist_stride;
+                look_wpb = hit->wpb;
+                look_blocks = hit->blocks;
+                look_scalars = hit->dev.p;
+                look_event = hit->event;
+                look_la = hit;
+            }
         } else {
             fh_prepass_geometry(0, c->num_cu, &P.wpb, &P.blocks);
+            if (P.blocks > c->deproject_blocks) P.blocks = c->deproject_blocks;
             rblocks = P.blocks;
+            const int cap = E.wpb ? 0 : one_look_buckets(c);  // (development geometries of P1 / P2: two looks)
             HIP_TRY(hipEventRecord(c->ev_rng0, c->stream));
-            HIP_TRY(fh_prepass_launch_range(P, c->stream));
+            if (cap > 0 && !E.no_hist_cache) {  // one look: range + histograms (the context's own buffer)
+                const int stride = (P.blocks + 255) & ~255;
+                if (c->k1_hist.n < (size_t)stride * cap) {
+                    if (c->k1_hist.alloc((size_t)stride * cap + 1024) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc (histograms) failed");
+                    HIP_TRY(hipMemsetAsync(c->k1_hist.p, 0, sizeof(int) * c->k1_hist.n, c->stream));
+                }
+                PrepassParams Q = P;
+                Q.nb = cap;
+                Q.inv_delta = 1.0 / c->k1_delta;
+                Q.delta = c->k1_delta;
+                Q.hist = c->k1_hist.p;
+                Q.hist_stride = stride;
+                Q.hist_zeroed = 1;
+                HIP_TRY(fh_prepass_launch_zero(c->k1_hist.p, (size_t)stride * cap, c->stream));
+                HIP_TRY(fh_prepass_launch_look(Q, c->stream));
+                look_hist = c->k1_hist.p;
+                look_cap = cap;
+                look_stride = stride;
+                look_wpb = P.wpb;
+                look_blocks = P.blocks;
+            } else {
+                HIP_TRY(fh_prepass_launch_range(P, c->stream));
+            }
             HIP_TRY(hipEventRecord(c->ev_rng1, c->stream));
             c->rng_la = nullptr;
             c->rng_timed = true;
@@ -519,12 +570,15 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
         if (E.blocks > 0) P.blocks = E.blocks;
     }
     if (P.blocks > c->deproject_blocks) P.blocks = c->deproject_blocks;  // (entries of partial_scalars)
+    // the histograms of a look serve if they cover the buckets and were counted by the workgroups that will scatter
+    if (look_hist && (nb > look_cap || look_wpb != P.wpb || look_blocks != P.blocks)) look_hist = nullptr;
     // workspaces (grow on demand)
     const size_t nrows = (size_t)count + 16 * (size_t)nb + 16, max_pc = (size_t)fh_prepass_max_pieces(count, nb, seg);
     const size_t md = (size_t)fh_prepass_moment_doubles();
     if (c->k1_rows.n < nrows * 3 && c->k1_rows.alloc(nrows * 3 + 1024) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc (sorted rows) failed");
     P.hist_stride = (P.blocks + 255) & ~255;
-    if (c->k1_hist.n < (size_t)P.hist_stride * nb) {
+    if (look_hist && look_stride != P.hist_stride) look_hist = nullptr;
+    if (!look_hist && c->k1_hist.n < (size_t)P.hist_stride * nb) {
         c->hist_valid = false;
         if (c->k1_hist.alloc((size_t)P.hist_stride * nb + 1024) != hipSuccess) return fail(FH_ERR_NOMEM, "hipMalloc (histograms) failed");
         HIP_TRY(hipMemsetAsync(c->k1_hist.p, 0, sizeof(int) * c->k1_hist.n, c->stream));  // (the padding of the rows stays zero)
@@ -545,7 +599,7 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     P.dummy_row = (int64_t)nrows;  // (the buffer holds nrows + 341 rows)
     // |u|, |v| <= q / cos(inc), so |phase| <= (|dRA| + |dDec|) qmax / |cos(inc)|: beyond 1e5 rad the library's sincos
     P.safe_trig = !((fabs(p.dRA) + fabs(p.dDec)) * qmax_all < 1.0e5 * fabs(p.cos_i)) || E.safe_trig;
-    P.hist = c->k1_hist.p;
+    P.hist = look_hist ? look_hist : c->k1_hist.p;
     P.totals = c->k1_totals.p;
     P.starts = c->k1_starts.p;
     P.cidx = c->k1_cidx.p;
@@ -574,18 +628,30 @@ static int bin_visibilities_v4(fh_ctx *c, BinParams &p, int64_t count, unsigned 
     c->hist_valid = false;
     // (the events of fh_bin_last_prepass_ms start HERE: behind the range -- cached, looked ahead, or waited for above; its kernel has
     //  events of its own, fh_bin_last_range_ms)
+    if (look_hist && look_event) {
+        // the look-ahead's histograms and per-workgroup ranges (vr_finish folds those) were written on its stream
+        HIP_TRY(hipStreamWaitEvent(c->stream, look_event, 0));
+        HIP_TRY(hipMemcpyAsync(c->partial_scalars.p, look_scalars, sizeof(double) * (size_t)P.blocks * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
     HIP_TRY(hipEventRecord(c->ev_pre0, c->stream));
+    const int hist_mode = reuse ? 1 : (look_hist ? 2 : 0);  // 1: histograms, scan and layout stand; 2: the histograms exist (one look)
     if (fused) {
-        if (!reuse) {
-            HIP_TRY(fh_prepass_launch_hist(P, c->stream));
-            HIP_TRY(fh_fused_launch_layout(P, fused_G, fused_slots, c->k1_slot_tab.p, c->k1_slot_tab.p + nb, c->stream));
-        }
+        if (hist_mode == 0) HIP_TRY(fh_prepass_launch_hist(P, c->stream));
+        if (hist_mode == 2) HIP_TRY(fh_prepass_launch_scan(P, c->stream));
+        if (hist_mode != 1) HIP_TRY(fh_fused_launch_layout(P, fused_G, fused_slots, c->k1_slot_tab.p, c->k1_slot_tab.p + nb, c->stream));
         HIP_TRY(fh_fused_launch(P, c->k1_slot_tab.p, fused_slots, fused_G, P.blocks, c->stream));
         HIP_TRY(fh_prepass_launch_factor(P, c->stream));
     } else {
-        HIP_TRY(fh_prepass_launch(P, c->stream, reuse ? 1 : 0));
+        HIP_TRY(fh_prepass_launch(P, c->stream, hist_mode));
     }
-    c->hist_valid = true;
+    if (look_hist && look_la) {
+        // the pre-pass kernels above read the look-ahead's histograms when the binning stream gets to them, which may be long after
+        // this call returns (a pipeline queues passes ahead): the next look into that slot waits for this event
+        HIP_TRY(hipEventRecord(look_la->consumed, c->stream));
+        look_la->consumed_pending = true;
+    }
+    // (the histograms the context keeps between passes are its own: those of a look-ahead belong to the look-ahead)
+    c->hist_valid = !(look_hist && look_event);
     c->hist_fused = fused;
     c->hist_nb = nb;
     c->hist_blocks = P.blocks;
@@ -718,12 +784,31 @@ int fh_bin_prefetch_range(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, in
     fh_prepass_geometry(0, c->num_cu, &P.wpb, &P.blocks);
     P.unroll = c->k1env.unroll;
     if (!c->pf_stream) HIP_TRY(hipStreamCreateWithFlags(&c->pf_stream, hipStreamNonBlocking));
-    fh_ctx::LookAhead &la = c->pf[c->pf_next];
-    c->pf_next ^= 1;
+    // a free look-ahead: not waiting to be taken, and the pass that took its histograms has run; else a new one; else the oldest
+    fh_ctx::LookAhead *pick = nullptr, *oldest = nullptr;
+    for (auto &lp : c->pf) {
+        if (!oldest || lp->seq < oldest->seq) oldest = lp.get();
+        if (pick || lp->valid) continue;
+        if (lp->consumed_pending && hipEventQuery(lp->consumed) != hipSuccess) continue;
+        lp->consumed_pending = false;
+        pick = lp.get();
+    }
+    if (!pick && (int)c->pf.size() < fh_ctx::kMaxLookAheads) {
+        c->pf.emplace_back(new fh_ctx::LookAhead());
+        pick = c->pf.back().get();
+    }
+    if (!pick) pick = oldest;  // (its look, if nobody took it, is dropped; its consumer, if still queued, is waited for below)
+    fh_ctx::LookAhead &la = *pick;
+    la.seq = ++c->pf_seq;
     if (!la.event) {
         HIP_TRY(hipEventCreateWithFlags(&la.event, hipEventDisableSystemFence));
         HIP_TRY(hipEventCreateWithFlags(&la.ev0, hipEventDisableSystemFence));
         HIP_TRY(hipEventCreateWithFlags(&la.ev1, hipEventDisableSystemFence));
+        HIP_TRY(hipEventCreateWithFlags(&la.consumed, hipEventDisableSystemFence));
+    }
+    if (la.consumed_pending) {  // (a queued pass still reads this slot's histograms)
+        HIP_TRY(hipStreamWaitEvent(c->pf_stream, la.consumed, 0));
+        la.consumed_pending = false;
     }
     if (la.blocks < P.blocks) {
         if (la.host) (void)hipHostFree(la.host);
@@ -734,8 +819,32 @@ int fh_bin_prefetch_range(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, in
     la.valid = false;
     la.blocks = P.blocks;
     P.partial_scalars = la.dev.p;
+    la.has_hist = false;
+    const int cap = (c->k1env.wpb || c->k1env.no_hist_cache) ? 0 : one_look_buckets(c);
+    if (cap > 0) {  // one look: the histograms of these rows beside the range (see one_look_buckets)
+        if (P.blocks > c->deproject_blocks) P.blocks = c->deproject_blocks;
+        la.blocks = P.blocks;
+        const int stride = (P.blocks + 255) & ~255;
+        if (la.hist.n < (size_t)stride * cap) HIP_TRY(la.hist.alloc((size_t)stride * cap + 1024));
+        P.nb = cap;
+        P.inv_delta = 1.0 / c->k1_delta;
+        P.delta = c->k1_delta;
+        P.hist = la.hist.p;
+        P.hist_stride = stride;
+        la.nb_cap = cap;
+        la.hist_stride = stride;
+        la.wpb = P.wpb;
+        la.unroll = P.unroll;
+    }
     HIP_TRY(hipEventRecord(la.ev0, c->pf_stream));
-    HIP_TRY(fh_prepass_launch_range(P, c->pf_stream));
+    if (cap > 0) {
+        P.hist_zeroed = 1;
+        HIP_TRY(fh_prepass_launch_zero(la.hist.p, (size_t)la.hist_stride * cap, c->pf_stream));
+        HIP_TRY(fh_prepass_launch_look(P, c->pf_stream));
+        la.has_hist = true;
+    } else {
+        HIP_TRY(fh_prepass_launch_range(P, c->pf_stream));
+    }
     HIP_TRY(hipEventRecord(la.ev1, c->pf_stream));
     HIP_TRY(hipMemcpyAsync(la.host, la.dev.p, sizeof(double) * (size_t)P.blocks * 4, hipMemcpyDeviceToHost, c->pf_stream));
     HIP_TRY(hipEventRecord(la.event, c->pf_stream));

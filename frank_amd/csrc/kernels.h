@@ -112,6 +112,7 @@ struct PrepassParams {
     double *vrows;            // [non-empty bucket][16][16]: the input of bin_gram2_kernel<.., VR = true>
     int *vbucket;             // [non-empty bucket]
     double *partial_scalars;  // [workgroup][4]: sum log(w / 2 pi), qmin, qmax (rows of multiplicity > 0), qmax (all rows)
+    int hist_zeroed;          // P1 of a one-look pass: `hist` was cleared in front of the kernel, only the non-zero counts are stored
     int fused;                // bin_fused.hip: every bucket's moments come from `partial` (piece0[b] = b x workgroups), no sorted rows
 };
 // Gram of the virtual rows, one workgroup (x split) per output tile (bin_prepass.hip)
@@ -132,10 +133,14 @@ int fh_prepass_moment_doubles();
 void fh_prepass_geometry(int nb, int num_cu, int *wpb, int *blocks);
 int64_t fh_prepass_max_pieces(int64_t count, int nb, int seg_rows);
 hipError_t fh_prepass_launch_range(const PrepassParams &P, hipStream_t stream);  // baseline range only (partial_scalars)
-// P1, scan, P2, P3, factor; skip_hist: the histograms, their scan and the layout of the last pass still describe these rows
+// P1, scan, P2, P3, factor; skip_hist = 1: the histograms, their scan and the layout of the last pass still describe these rows;
+// 2: the histograms of these rows exist (fh_prepass_launch_look), scan and layout do not
 hipError_t fh_prepass_launch(const PrepassParams &P, hipStream_t stream, int skip_hist = 0);
 // the fused form (bin_fused.hip): P1 + scan as above (skip_hist), then the layout of the accumulator slots and ONE pass over the table
 hipError_t fh_prepass_launch_hist(const PrepassParams &P, hipStream_t stream);
+hipError_t fh_prepass_launch_zero(int *p, size_t n, hipStream_t stream);
+hipError_t fh_prepass_launch_look(const PrepassParams &P, hipStream_t stream);  // P1 alone, P.nb an upper bound: range + histograms in one look
+hipError_t fh_prepass_launch_scan(const PrepassParams &P, hipStream_t stream);  // the scan + layout over histograms that exist
 hipError_t fh_prepass_launch_factor(const PrepassParams &P, hipStream_t stream);
 int fh_fused_slot_doubles();
 int fh_fused_max_slots(int nb);

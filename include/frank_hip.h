@@ -198,9 +198,10 @@ int fh_ctx_set_range_cache(fh_ctx *ctx, int on);
  * context's own beside whatever the binning stream is doing, so that the fh_bin_visibilities call that follows for the SAME rows,
  * geometry and multiplicities finds the range on the host when it gets there instead of waiting for the pass in front of it (the
  * one look at (u, v), 16 B per row, and the host round trip of _check_uv_range, statistical_models.py:166-169, are still paid --
- * overlapped).  Two look-aheads are kept (ask for the next pass's BEFORE queueing the current pass: its kernel then runs in front
- * of that pass); a third call replaces the older one; nothing of an EARLIER pass is remembered.  A no-op outside the default
- * (moments) binning path.                                                                                 */
+ * overlapped).  Ask for the next pass's BEFORE queueing the current pass: its kernel then runs in front of that pass.  Where the
+ * bucket count has an upper bound that keeps the launch geometry (N <~ 320) the look also leaves the table's (u, v) histograms
+ * for the pass -- ONE look at (u, v) instead of two.  Look-aheads that no pass has taken yet are kept (up to 48; the oldest is
+ * dropped beyond); nothing of an EARLIER pass is remembered.  A no-op outside the default (moments) binning path.                                                                                 */
 int fh_bin_prefetch_range(fh_ctx *ctx, const fh_geometry *geom, const fh_vis *vis, int64_t first, int64_t count);
 /* Pipelines of fits (fh_fit_submit): confine the binning pass to the first bin_cus compute units and the fit loops to the
  * others, so that a fit loop -- one workgroup that holds a compute unit for the whole iteration (radial_fitters.py:765-785) --

@@ -1530,7 +1530,7 @@ def test_histograms_are_reused_only_for_the_same_rows(monkeypatch):
         _lib.check(_lib.lib.fh_bin_prefetch_range(ctx, ctypes.byref(g1 if k == 1 else g2), tabs[t], 0, n))
         t, k, n = then
         assert stats(tabs[t], g1 if k == 1 else g2, n) == ref[(t, k, n)], (look, then)
-    # two look-aheads at once, consumed in either order; a third replaces the older one (which then takes the ordinary route)
+    # several look-aheads at once, consumed in any order (each leaves its table's range AND, at this N, its (u, v) histograms: one look)
     for first, second in (((0, 1, 150000), (1, 2, 99999)), ((1, 1, 150000), (0, 2, 150000))):
         for t, k, n in (first, second):
             _lib.check(_lib.lib.fh_bin_prefetch_range(ctx, ctypes.byref(g1 if k == 1 else g2), tabs[t], 0, n))
