@@ -362,7 +362,7 @@ static inline int env_int(const char *name, int dflt) {
 // Environment switches.  Two kinds:
 //   * FORM switches select among forms of a kernel that give the same results -- the parity tests compare them inside one process
 //     (FRANK_AMD_K1, _K1_FUSED, _K1_NO_HIST_CACHE, _K1_SAFE_TRIG, _NO_RANGE_CACHE, _K2, _K2_CLUSTER, _K2_CLUSTER_BREAK, _K2_RR, _K2_DEFER,
-//     _K2_LL, _SWEEP_CAP, _SWEEP_LEFT, _SWEEP_STAGE2_CLUSTERS, _SWEEP_NO_CLUSTERS, _LN_CLUSTER, _LN_PIVOTED, _RESIDUAL_DIRECT): read with
+//     _K2_LL, _SWEEP_CAP, _SWEEP_LEFT, _SWEEP_STAGE2_CLUSTERS, _SWEEP_NO_CLUSTERS, _LN_CLUSTER, _LN_PIVOTED, _LN_WIDE, _RESIDUAL_DIRECT): read with
 //     env_int / getenv, listed in INTEGRATION.md;
 //   * DEVELOPMENT switches (tuning knobs, probes, kill-line forms) exist only in builds with -DFRANK_AMD_DEV (`make dev`: the tools
 //     under tools/ that sweep them load libfrank_hip_dev.so through FRANK_AMD_LIB): the shipped library reads none of them.

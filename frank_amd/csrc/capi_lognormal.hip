@@ -11,7 +11,7 @@ static int ln_np(int N) { return 16 * ((N + 15) / 16); }
 static int ln_prepare(fh_ctx *c, const double *M, const double *j, LogNormalParams &P) {
     const int N = c->N;
     const size_t NN = (size_t)N * N;
-    if (N > 320) return fail(FH_ERR_UNSUPPORTED, "N = %d: the LogNormal kernel covers N <= 320", N);
+    if (N > 640) return fail(FH_ERR_UNSUPPORTED, "N = %d: the LogNormal kernel covers N <= 640", N);
     if ((M == nullptr) != (j == nullptr)) return fail(FH_ERR_INVALID, "pass both M and j or neither");
     if (!M && !c->have_device_Mj) return fail(FH_ERR_INVALID, "no device-resident M, j (run fh_stats_finalize)");
     HIP_TRY(hipSetDevice(c->device));
@@ -61,6 +61,15 @@ static int ln_prepare(fh_ctx *c, const double *M, const double *j, LogNormalPara
     return FH_OK;
 }
 
+// 320 < N <= 640: the persistent kernel in its WIDE form (round 6; vectors in global memory, one panel) unless
+// FRANK_AMD_LN_WIDE=host keeps the host-driven route of round 4 (lognormal_wide.hip) -- which also takes over when the kernel's
+// Cholesky fails (it has rocSOLVER's pivoted LU) and for N >= 640
+static bool ln_kernel_covers(const fh_ctx *c) {
+    if (c->N <= 320) return true;
+    const char *e = getenv("FRANK_AMD_LN_WIDE"), *pv = getenv("FRANK_AMD_LN_PIVOTED");
+    return c->N <= 640 && !(e && !strcmp(e, "host")) && !(pv && pv[0] == '1');
+}
+
 static int ln_finish(fh_ctx *c, double *s, double *p, double *Dinv, int64_t *stats, int result[2]) {
     const int N = c->N;
     long long st[9];
@@ -82,6 +91,7 @@ static int ln_finish(fh_ctx *c, double *s, double *p, double *Dinv, int64_t *sta
 #endif
     if (result[1] == LN_STATUS_BAD_P) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (non-positive or NaN)");
     if (result[1] == LN_STATUS_SLOPE) return fail(FH_ERR_NUMERIC, "Round off in slope calculation (LineSearch)");
+    if (result[1] == LN_STATUS_NOT_SPD) return fail(FH_ERR_NOT_SPD, "Cholesky of a Hessian failed (N > 320: no pivoted LU in the kernel)");
     if (result[1] == LN_STATUS_CLUSTER)
         return fail(FH_ERR_HIP, "the helper workgroups of the LogNormal cluster did not answer within 2 s (FRANK_AMD_LN_CLUSTER=1 "
                     "runs the fit on one workgroup)");
@@ -507,7 +517,7 @@ int fh_lognormal_model(fh_ctx *c, const double *M, const double *j, const double
     if (!c || !p || !guess || !s_map) return fail(FH_ERR_INVALID, "fh_lognormal_model: NULL argument");
     for (int k = 0; k < c->N; ++k)
         if (!(p[k] > 0.0)) return fail(FH_ERR_BAD_P, "Bad value in power spectrum (p[%d] = %g)", k, p[k]);
-    if (c->N > 320) return lognormal_model_wide(c, M, j, p, guess, s0, s_map, Dinv, stats);  // (the host-driven route)
+    if (!ln_kernel_covers(c)) return lognormal_model_wide(c, M, j, p, guess, s0, s_map, Dinv, stats);  // (the host-driven route)
     LogNormalParams P;
     int rc = ln_prepare(c, M, j, P);
     if (rc) return rc;
@@ -519,7 +529,9 @@ int fh_lognormal_model(fh_ctx *c, const double *M, const double *j, const double
     P.guess = c->ln_guess.p;
     HIP_TRY(fh_ln_launch(P, 1, c->stream));
     int result[2];
-    return ln_finish(c, s_map, nullptr, Dinv, stats, result);
+    rc = ln_finish(c, s_map, nullptr, Dinv, stats, result);
+    if (rc == FH_ERR_NOT_SPD && c->N > 320) return lognormal_model_wide(c, nullptr, nullptr, p, guess, s0, s_map, Dinv, stats);
+    return rc;
 }
 
 int fh_fit_lognormal(fh_ctx *c, const double *M, const double *j, double alpha, double p0, double wsmooth, double tol,
@@ -529,7 +541,7 @@ int fh_fit_lognormal(fh_ctx *c, const double *M, const double *j, double alpha, 
     if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
     if (!(I_scale > 0)) return fail(FH_ERR_INVALID, "I_scale must be positive");
     if ((diag_p == nullptr) != (diag_s == nullptr)) return fail(FH_ERR_INVALID, "pass both diag_p and diag_s or neither");
-    if (c->N > 320)  // (beyond the persistent kernel: the host-driven route, lognormal_wide.hip)
+    if (!ln_kernel_covers(c))  // (beyond the persistent kernel: the host-driven route, lognormal_wide.hip)
         return fit_lognormal_wide(c, M, j, alpha, p0, wsmooth, tol, max_iter, I_scale, s_map, p, niter, Dinv, stats, diag_p, diag_s);
     LogNormalParams P;
     int rc = ln_prepare(c, M, j, P);
@@ -584,6 +596,8 @@ int fh_fit_lognormal(fh_ctx *c, const double *M, const double *j, double alpha, 
     int result[2];
     rc = ln_finish(c, s_map, p, Dinv, stats, result);
     *niter = result[0];
+    if (rc == FH_ERR_NOT_SPD && N > 320)  // (the kernel has no pivoted LU beyond N = 320: the route that has rocSOLVER's starts over)
+        return fit_lognormal_wide(c, nullptr, nullptr, alpha, p0, wsmooth, tol, max_iter, I_scale, s_map, p, niter, Dinv, stats, diag_p, diag_s);
     if (rc) return rc;
     const size_t nd = (size_t)result[0] * N;
     if (diag_p && nd) {
@@ -654,7 +668,7 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
         return fail(FH_ERR_INVALID, "fh_fit_lognormal_batched: bad argument");
     if (max_iter < 0) return fail(FH_ERR_INVALID, "max_iter must be >= 0");
     if (!(I_scale > 0)) return fail(FH_ERR_INVALID, "I_scale must be positive");
-    if (c->N > 320) {  // beyond the persistent kernel: the host-driven route, one point after the other
+    if (!ln_kernel_covers(c)) {  // beyond the persistent kernel: the host-driven route, one point after the other
         for (int b = 0; b < batch; ++b) {
             const int rcb = fit_lognormal_wide(c, b == 0 ? M : nullptr, b == 0 ? j : nullptr, alpha[b], p0[b], wsmooth[b], tol, max_iter,
                                                I_scale, s_map + (size_t)b * c->N, p + (size_t)b * c->N, niter + b, nullptr,
@@ -870,6 +884,10 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
         HIP_TRY(hipMemcpyAsync(p + (size_t)order[k] * N, pb.p + (size_t)k * N, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < batch; ++k)
+        if (res[2 * k + 1] == LN_STATUS_NOT_SPD)
+            return fail(FH_ERR_NOT_SPD, "fh_fit_lognormal_batched: Cholesky of a Hessian failed in fit %d (N > 320: FRANK_AMD_LN_WIDE=host "
+                        "takes the route with the pivoted LU)", order[k]);
     for (int k = 0; k < batch; ++k)
         if (res[2 * k + 1] == LN_STATUS_CLUSTER || res[2 * k + 1] == LN_STATUS_PAUSED)  // (never a result: fail loudly, as a single fit does)
             return fail(FH_ERR_HIP, "fh_fit_lognormal_batched: a cluster of workgroups stopped answering in the middle of fit %d "

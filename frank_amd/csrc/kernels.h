@@ -325,7 +325,7 @@ hipError_t fh_launch_split_complex(const double *vc, int64_t n, double *re, doub
 
 // ---- LogNormal (lognormal.hip): Newton MAP of the log-brightness + the power-spectrum loop, one workgroup per fit
 enum { LN_MODE_MAP = 0, LN_MODE_FIT = 1, LN_MODE_UPDATE = 2 };
-enum { LN_STATUS_OK = 0, LN_STATUS_BAD_P = 1, LN_STATUS_SLOPE = 2, LN_STATUS_CLUSTER = 3, LN_STATUS_PAUSED = 4 };
+enum { LN_STATUS_OK = 0, LN_STATUS_BAD_P = 1, LN_STATUS_SLOPE = 2, LN_STATUS_CLUSTER = 3, LN_STATUS_PAUSED = 4, LN_STATUS_NOT_SPD = 5 };
 
 struct LogNormalParams {
     int N, max_iter, mode, lu_in_lds, lu_nb;  // lu_nb: panel width of the blocked LU (set by fh_ln_launch)
@@ -377,7 +377,8 @@ struct LogNormalParams {
 
 constexpr size_t fh_ln_lu_doubles(int N, int NP) {
     return (size_t)N * N + 2 * (size_t)NP * NP + 16 * (size_t)NP + 6 * (size_t)NP + 3072  // (3072: bandscan::kTableDoubles)
-           + 2 * (size_t)NP + 2 * ((size_t)NP / 16) * NP;  // two vectors and [2][NP / 16][NP] partial sums of the evaluations
+           + 2 * (size_t)NP + 2 * ((size_t)NP / 16) * NP  // two vectors and [2][NP / 16][NP] partial sums of the evaluations
+           + (N > 320 ? 29 * (size_t)N + 64 : 0);         // WIDE kernel (320 < N <= 639): its twenty vectors, the solve vectors, the permutation
 }
 size_t fh_ln_smem_bytes(int N, int *lu_in_lds, int *lu_nb);
 hipError_t fh_ln_launch(const LogNormalParams &P, int nblocks, hipStream_t s);

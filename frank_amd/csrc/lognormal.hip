@@ -71,6 +71,8 @@ struct LnS {
     int *perm;
     double *lu;    // N*N column-major: LDS or global
     double *pan;   // global-LU kernels: LDS panel of the blocked factorisation (N * LU_NB)
+    double *cpan, *bak;  // WIDE: the Cholesky's one panel ALIASES the eighteen vectors behind rdiag (they wait in `bak`, global, meanwhile)
+    double *chol;  // LDS of the tiled Cholesky (cholesky_as_lu): N <= 320 the solve vectors' space and the LU panel's behind it; WIDE: its own
     int lu_nb;
     int redsel;
     int row, c0, c1, slot;  // ln_eval work split: this thread sums columns [c0, c1) of output `row` into pbuf[slot]
@@ -271,6 +273,8 @@ __device__ __forceinline__ void ln_eval_items(const LogNormalParams &P, const do
         }
     }
 }
+// WIDE (320 < N <= 640, round 6): the vectors live in global memory (L2), a thread may own two rows, a row has up to 40 chunks
+template <bool WIDE>
 __device__ __forceinline__ double ln_eval(const LogNormalParams &P, LnS &S, const double *xv, double *Iv, double *Sxv, double *MIv,
                                           const double *sv, double *sdst, bool along, double lam) {
     const int N = P.N, NP = P.NP, tid = ln_tid(), nch = (N + EVW - 1) / EVW;
@@ -301,6 +305,36 @@ __device__ __forceinline__ double ln_eval(const LogNormalParams &P, LnS &S, cons
     if (!shared) ln_eval_items(P, sv, Iv, tid, LT);
     __syncthreads();
     double A = 0.0, B = 0.0, C = 0.0;
+    if constexpr (WIDE) {
+        const double *part_s = ln_eval_parts(P), *part_m = part_s + (size_t)nch * NP;
+        constexpr int CHB = 10;  // chunks per batch of loads (clamped, never predicated); the sums run over the chunks in order
+        for (int r = tid; r < N; r += LT) {
+            double a = 0.0, b = 0.0;
+            for (int c0 = 0; c0 < nch; c0 += CHB) {
+                double pm[CHB], ps[CHB];
+#pragma unroll
+                for (int ch = 0; ch < CHB; ++ch) {
+                    pm[ch] = part_m[(size_t)min(c0 + ch, nch - 1) * NP + r];
+                    if (sv) ps[ch] = part_s[(size_t)min(c0 + ch, nch - 1) * NP + r];
+                }
+#pragma unroll
+                for (int ch = 0; ch < CHB; ++ch)
+                    if (c0 + ch < nch) {
+                        b += pm[ch];
+                        if (sv) a += ps[ch];
+                    }
+            }
+            if (sv) sdst[r] = a;
+            if (along) {
+                a = fma(lam, S.col[r], S.Sx[r]);
+                Sxv[r] = a;
+            }
+            MIv[r] = b;
+            A += xv[r] * a;
+            B += Iv[r] * b;
+            C += Iv[r] * S.jv[r];
+        }
+    } else
     if (tid < N) {
         const double *part_s = ln_eval_parts(P), *part_m = part_s + (size_t)nch * NP;
         // (the chunks of a row are loaded as one batch -- clamped, never predicated -- and added in order: one L2 round trip,
@@ -524,23 +558,44 @@ constexpr int kCholMaxTiles = 171;  // tiles right of column 1 at nb = 20
 __host__ __device__ constexpr int fh_ln_chol_doubles(int NP) {
     return 2 * NP * tilechol::PS + 2 * 16 * tilechol::PS + 2 * NP + 4 + (kCholMaxTiles + 1) / 2;
 }
-__device__ __forceinline__ double *chol_dvec(const LnS &S, int NP) { return S.wsol + 2 * NP * tilechol::PS + 2 * 16 * tilechol::PS; }
+// WIDE (320 < N <= 640): ONE panel -- two of 640 x 17 doubles do not fit --; the column tiles wait in the dead upper tiles of the
+// copy until everybody has read panel k (a second barrier per step), the tile table has 741 entries
+constexpr int kCholMaxTilesWide = 741;  // nb = 40
+__host__ __device__ constexpr int fh_ln_chol_small_wide(int NP) {  // L_kk^-1 (two), diag(L) and its reciprocals, flags, the tile table
+    return 2 * 16 * tilechol::PS + 2 * NP + 4 + (kCholMaxTilesWide + 1) / 2 + 1;
+}
+template <bool WIDE>
+__device__ __forceinline__ double *chol_dvec(const LnS &S, int NP) { return S.chol + (WIDE ? 0 : 2 * NP * tilechol::PS) + 2 * 16 * tilechol::PS; }
+template <bool WIDE>
 __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S, double *Cp, double *Xd = nullptr) {
     using namespace tilechol;
     const int N = P.N, NP = P.NP, nb = NP / 16;
     const int tid = ln_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
     const int cl = lane & 15, rg = lane >> 4;
-    double *pan0 = S.wsol, *dli0 = pan0 + 2 * NP * PS;
-    double *dvec = chol_dvec(S, NP), *rdv = dvec + NP;  // diag(L), 1 / diag(L)
+    double *pan0 = WIDE ? S.cpan : S.chol, *dli0 = WIDE ? S.chol : pan0 + 2 * NP * PS;
+    double *dvec = chol_dvec<WIDE>(S, NP), *rdv = dvec + NP;  // diag(L), 1 / diag(L)
     int *flag = reinterpret_cast<int *>(rdv + NP);      // [0] a pivot that is not positive, [1] last diagonal tile whose inverse is in LDS
     int *tab = flag + 8;                                // tile e = (i - 1) i / 2 + (j - 1), 1 <= j <= i, relative to block (k+1, k+1): i << 8 | j
-    auto pan_of = [&](int k) { return pan0 + (size_t)(k & 1) * NP * PS; };
+    auto pan_of = [&](int k) { return pan0 + (WIDE ? (size_t)0 : (size_t)(k & 1) * NP * PS); };
     auto dli_of = [&](int k) { return dli0 + (k & 1) * 16 * PS; };
     gdouble *Cg = as_global(uniform_ptr(Cp));
     gdouble *lu = as_global(S.lu);       // the factors go straight to their final place: column-major N x N, unit-lower L D^-1
                                          // below the diagonal, D L^T on and above it (both scalings need the diagonal of block
                                          // column k only, known when its tile is factored)
     LTIC();
+    if constexpr (WIDE) {  // the panel takes the place of the vectors: 18 N doubles out (and back in at the end), 2 x 92 KB against
+                           // the factorisation's 43 MB of tiles
+        for (int i = tid; i < 18 * N; i += LT) S.bak[i] = S.cpan[i];
+        __syncthreads();
+    }
+    auto leave = [&](bool ok) {
+        if constexpr (WIDE) {
+            __syncthreads();
+            for (int i = tid; i < 18 * N; i += LT) S.cpan[i] = S.bak[i];
+            __syncthreads();
+        }
+        return ok;
+    };
     if (tid == 0) flag[0] = flag[1] = 0;
     for (int e = tid; e < (nb - 1) * (nb - 2) / 2; e += LT) {
         int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
@@ -588,15 +643,18 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
     // and, scaled, into the factors.  Element (a, b) of D is L[16 I + b][16 k + a]: its store runs along a column of the
     // unit-lower part; the upper part wants the transposed tile, which is the same product with the operands exchanged (the
     // accumulator registers of T^T are the A fragments of T, the A fragments of X the B fragments of X^T).
+    // (pan == nullptr, WIDE: the one panel is still being read -- D waits in the dead upper tile (k, I) of the copy and goes to
+    //  the panel behind the step's first barrier, panel_from_park)
     auto panel_tile = [&](int k, int I, const Frag &fx, const Frag &ft, double *pan) {
         const v4f64 z = {0.0, 0.0, 0.0, 0.0};
         const v4f64 d = mfma4(fx, ft, z, false);
         const v4f64 dt = mfma4(ft, fx, z, false);
         const double dck = dvec[16 * k + cl];
-        double *pr = pan + (size_t)((I - k - 1) * 16 + cl) * PS + rg;
+        if (!pan) st_pk(Cg, (unsigned)((k * nb + I) * 2048), lane, d);
+        double *pr = (pan ? pan : pan0) + (size_t)((I - k - 1) * 16 + cl) * PS + rg;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            pr[4 * r] = d[r];
+            if (pan) pr[4 * r] = d[r];
             const int a = 16 * k + rg + 4 * r, b = 16 * I + cl;
             if (a < N && b < N) lu[(size_t)a * N + b] = d[r] * rdv[a];  // (L D^-1)[b][a]
             const int bt = 16 * I + rg + 4 * r, at = 16 * k + cl;
@@ -609,11 +667,20 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
         diag_outputs(0, t, x);
     }
     __syncthreads();
-    if (flag[0]) return false;
+    if (flag[0]) return leave(false);
     {   // panel 0 from memory: the tiles (0, I) of the first block row ARE (C_I0)^T
         Frag fx;
 #pragma unroll
         for (int q = 0; q < 4; ++q) fx.v[q] = dli_of(0)[cl * PS + 4 * q + rg];
+        if constexpr (WIDE) {
+            for (int I = 1 + wave; I < nb; I += LNW) {  // (once per factorisation: tile by tile)
+                const v4f64 t = ld_pk(Cg, (unsigned)(I * 2048), lane);
+                Frag fb1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fb1.v[q] = t[q];
+                panel_tile(0, I, fx, fb1, pan_of(0));
+            }
+        } else {
         constexpr int kPanelMax = 3;  // ceil((NP / 16 - 1) / LNW) for NP <= 400
         Frag fb[kPanelMax];
 #pragma unroll
@@ -629,6 +696,7 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
         for (int u = 0; u < kPanelMax; ++u) {
             const int I = 1 + wave + u * LNW;
             if (I < nb) panel_tile(0, I, fx, fb[u], pan_of(0));
+        }
         }
     }
     __syncthreads();
@@ -703,6 +771,34 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
             // ---- column k + 1 (the round-robin deal goes on where the table stopped): update, then panel k + 1 from the registers ----
             int cfirst = widx - cntA % NWK;
             if (cfirst < 0) cfirst += NWK;
+            if constexpr (WIDE) {
+                // up to six tiles per wave: one at a time; D is parked in the copy's dead upper tile until the panel is free
+                bool waited = false;
+                Frag fx;
+                for (int c = cfirst; c < ncol; c += NWK) {
+                    const v4f64 t = update(c + 1, 0, ld_pk(Cg, base + (unsigned)((c + 1) * nb * 2048), lane));
+                    v4f64 tt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tt = __builtin_amdgcn_mfma_f64_16x16x4f64(t[q], ident[q], tt, 0, 0, 0);
+                    Frag ft1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ft1.v[q] = tt[q];
+                    if (!waited) {
+                        int spins = 0;
+                        while (__hip_atomic_load(&flag[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > (1 << 22)) {
+                                if (lane == 0) flag[0] = 1;
+                                break;
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) fx.v[q] = dli_of(k + 1)[cl * PS + 4 * q + rg];
+                        waited = true;
+                    }
+                    panel_tile(k + 1, k + 2 + c, fx, ft1, nullptr);
+                }
+            } else {
             constexpr int kColMax = 3;  // ceil(18 / 7)
             v4f64 tc[kColMax];
 #pragma unroll
@@ -750,16 +846,30 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
                 if (wave == 1) CHT(6);
 #endif
             }
+            }
+        }
+        if constexpr (WIDE) {
+            __syncthreads();  // everybody has read panel k: the parked tiles of column k + 1 become panel k + 1
+            if (wave > 0) {
+                int cfirst = (wave - 1) - cntA % (LNW - 1);
+                if (cfirst < 0) cfirst += LNW - 1;
+                for (int c = cfirst; c < ncol; c += LNW - 1) {
+                    const v4f64 d = ld_pk(Cg, (unsigned)(((k + 1) * nb + k + 2 + c) * 2048), lane);
+                    double *pr = pan0 + (size_t)(c * 16 + cl) * PS + rg;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pr[4 * r] = d[r];
+                }
+            }
         }
         __syncthreads();
 #ifdef LN_TIMING
         if (wave == 0) CHT(2);
         if (wave == 1) CHT(7);
 #endif
-        if (flag[0]) return false;
+        if (flag[0]) return leave(false);
     }
     LTOC(1);
-    return true;
+    return leave(true);
 }
 
 // Partial-pivoting LU in place (column-major, unit lower); perm[i] = source row of row i, rdiag[i] = 1 / U_ii.
@@ -1367,6 +1477,7 @@ __device__ __forceinline__ void accept_trial(LnS &S, int N) {
 //                      16 each time, accepted as soon as the objective decreases.
 // amin = min |x / dir| and slope = jac . dir come from the caller's reduction.
 // returns 0 accepted (x, fx updated; reduction too for the line search), 1 failed, -1 "Round off in slope calculation".
+template <bool WIDE>
 __device__ __forceinline__ int backtrack(const LogNormalParams &P, LnS &S, const double *dir, double amin, double slope,
                                          bool fallback, double &fx, int &nfev, double &reduction) {
     const int N = P.N, tid = ln_tid();
@@ -1402,7 +1513,7 @@ __device__ __forceinline__ int backtrack(const LogNormalParams &P, LnS &S, const
         // (fresh_products: S^-1 x_n multiplied out for every trial point, the reference's arithmetic)
         const bool fresh = P.fresh_products != 0;
         const double *sv = fresh ? S.xn : (trial == 0 ? p : nullptr);
-        const double cost_new = ln_eval(P, S, S.xn, S.In, S.Sxn, S.MIn, sv, fresh ? S.Sxn : S.col, !fresh, lam);
+        const double cost_new = ln_eval<WIDE>(P, S, S.xn, S.In, S.Sxn, S.MIn, sv, fresh ? S.Sxn : S.col, !fresh, lam);
         ++nfev;
         if (fallback ? (cost_new < cost) : (cost_new <= (cost + armijo * lam * delta_f))) {
             if (!fallback) reduction = lam;
@@ -1445,6 +1556,7 @@ struct NewtonExit {
 };
 
 // MinimizeNewton(H, jac, hess, S.x, LineSearch(reduce_step=limit_step), tol=1e-7)  (minimizer.py:190-283)
+template <bool WIDE>
 __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, LnS &S) {
     const int N = P.N, tid = ln_tid();
     bool need_hess = true;
@@ -1455,7 +1567,7 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
     const int inv_after = max(2, N >> 3);
     for (int i = tid; i < N; i += LT) S.I[i] = exp(S.x[i] + P.s0);
     __syncthreads();
-    double fx = ln_eval(P, S, S.x, S.I, S.Sx, S.MI, S.x, S.Sx, false, 0.0);
+    double fx = ln_eval<WIDE>(P, S, S.x, S.I, S.Sx, S.MI, S.x, S.Sx, false, 0.0);
     for (int i = tid; i < N; i += LT) S.jx[i] = ln_grad(S, i);
     __syncthreads();
     for (int nstep = 0; nstep < P.max_step; ++nstep) {
@@ -1464,7 +1576,10 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
             double *Cp = S.lu_nb > 0 ? P.LU + N * N : nullptr;
             if (S.lu_nb > 0) {
                 if (!P.no_cholesky) build_hess_padded(P, S, Cp);
-                if (P.no_cholesky || !cholesky_as_lu(P, S, Cp)) {  // not positive definite: the attempt has written into S.lu
+                if constexpr (WIDE) {  // (no pivoted LU beyond N = 320: its panel keeps a row per thread; the host takes the other route)
+                    if (!cholesky_as_lu<true>(P, S, Cp)) return {5, nstep, nfev, nhess};
+                } else
+                if (P.no_cholesky || !cholesky_as_lu<false>(P, S, Cp)) {  // not positive definite: the attempt has written into S.lu
 #ifdef LN_TIMING
                     if (tid == 0) ln_cyc[6] += 1;
 #endif
@@ -1484,7 +1599,7 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
         // it has served N/8 solves -- N wave-solves shared by the 8 waves cost as much as that -- and every later
         // step is a matrix-vector product over all threads instead of a substitution chain in one wave.
         LTIC();
-        if (!have_inv && reuse >= inv_after) {
+        if (!WIDE && !have_inv && reuse >= inv_after) {  // (WIDE: the row / chunk split of the product below assumes N <= 512 threads' worth)
             for (int r = __builtin_amdgcn_readfirstlane(tid >> 6); r < N; r += LNW) {
                 double *xs = S.wsol + (tid >> 6) * N;
                 wave_solve(S, N, S.lu, nullptr, r, 1.0, xs);
@@ -1567,7 +1682,7 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
                 }
                 block_min_sum(S, am, d);
             }
-            res = backtrack(P, S, S.dx, am, d, attempt == 2, fx, nfev, reduction);
+            res = backtrack<WIDE>(P, S, S.dx, am, d, attempt == 2, fx, nfev, reduction);
             if (res < 0) return {4, nstep, nfev, nhess};
             if (attempt == 0) failed = res;
             if (res == 0) break;
@@ -1692,12 +1807,12 @@ __device__ __forceinline__ void build_sinv(const LogNormalParams &P, const doubl
 // product (285 k cycles per pass on four workgroups against 523 k on one); the sums run over J in the same order either way.
 template <int NC, int JB>
 __device__ __forceinline__ void tr2_solve_t(const LogNormalParams &P, const double *lu_p, const double *dvec, const double *Xd,
-                                            double *Wsc, double *tr2, int part, int nparts) {
+                                            double *Wsc, double *tr2, int part, int nparts, int cbase = 0) {
     using namespace tilechol;
     const int N = P.N, NP = P.NP, nb = NP / 16;
     const int tid = ln_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: loop control on the SALU)
     const int cl = lane & 15, rg = lane >> 4;
-    const int cw = wave * nparts + part, cstride = nparts * LNW;  // this wave's first block column (dealt round the workgroups:
+    const int cw = cbase + wave * nparts + part, cstride = nparts * LNW;  // this wave's first block column (dealt round the workgroups:
                                                                   // each gets as many busy waves as the others), the stride to its next
     const gdouble *lu = as_global(lu_p), *Y = as_global(P.Y), *X = as_global(Xd);
     gdouble *W = as_global(Wsc);
@@ -1830,10 +1945,13 @@ __device__ __forceinline__ void tr2_solve_t(const LogNormalParams &P, const doub
     }
 }
 
+template <bool WIDE>
 __device__ __forceinline__ void tr2_solve(const LogNormalParams &P, const double *lu_p, const double *dvec, const double *Xd,
                                           double *Wsc, double *tr2, int part = 0, int nparts = 1) {
     if (P.NP / 16 <= nparts * LNW) tr2_solve_t<1, 2>(P, lu_p, dvec, Xd, Wsc, tr2, part, nparts);  // a column per wave at most
-    else tr2_solve_t<3, 0>(P, lu_p, dvec, Xd, Wsc, tr2, part, nparts);                            // up to three: nb <= 24
+    else if constexpr (!WIDE) tr2_solve_t<3, 0>(P, lu_p, dvec, Xd, Wsc, tr2, part, nparts);       // up to three: nb <= 24
+    else  // 320 < N <= 639 on few workgroups: up to three per wave and round, round after round
+        for (int cb = 0; cb < P.NP / 16; cb += 3 * nparts * LNW) tr2_solve_t<3, 0>(P, lu_p, dvec, Xd, Wsc, tr2, part, nparts, cb);
 }
 
 // ---- cluster: a few workgroups on one fit ---------------------------------------------------------------------------------
@@ -1897,6 +2015,7 @@ __device__ __forceinline__ bool cluster_wait(const LogNormalParams &P, int *s_fl
     return *s_flag != 0;
 }
 // a helper workgroup (member 1 .. cluster - 1): serve commands until told to leave
+template <bool WIDE>
 __device__ __forceinline__ void cluster_helper(const LogNormalParams &P, int member, int *s_cmd) {
     const int tid = ln_tid();
     if (tid == 0) {
@@ -1945,8 +2064,8 @@ __device__ __forceinline__ void cluster_helper(const LogNormalParams &P, int mem
             build_hess_tiles(P, P.rk_g, P.tr2_g, P.j, P.LU + P.N * P.N, member, P.cluster);
         } else if (cmd == LN_CMD_TR2) {
             double *const Cp = P.LU + P.N * P.N, *const Wsc = Cp + P.NP * P.NP, *const Xd = Wsc + P.NP * P.NP;
-            if (P.cluster > 2) tr2_solve(P, P.LU, P.dvec_g, Xd, Wsc, P.tr2_g, member - 1, P.cluster - 1);  // (the helpers alone)
-            else tr2_solve(P, P.LU, P.dvec_g, Xd, Wsc, P.tr2_g, member, P.cluster);
+            if (P.cluster > 2) tr2_solve<WIDE>(P, P.LU, P.dvec_g, Xd, Wsc, P.tr2_g, member - 1, P.cluster - 1);  // (the helpers alone)
+            else tr2_solve<WIDE>(P, P.LU, P.dvec_g, Xd, Wsc, P.tr2_g, member, P.cluster);
         }
         __syncthreads();
         if (tid == 0) {
@@ -1957,7 +2076,10 @@ __device__ __forceinline__ void cluster_helper(const LogNormalParams &P, int mem
 }
 
 // LDS_LU: the LU factors live in LDS (N <= 112), else in global memory (L2)
-template <bool LDS_LU>
+// WIDE: 320 < N <= 640 (round 6; LDS_LU false): the twenty vectors and the solve vectors in global memory, LDS for the reductions
+// and the one panel of the tiled Cholesky only; no pivoted LU (a Cholesky that fails ends the fit with LN_STATUS_NOT_SPD: the host
+// takes the host-driven route, lognormal_wide.hip), no explicit inverse of a re-used Hessian
+template <bool LDS_LU, bool WIDE = false>
 __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_fit;
@@ -1982,7 +2104,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
             P.Hinv += (size_t)slot * P.N * P.N;
         }
         if (member > 0) {
-            cluster_helper(P, member, s_cl);
+            cluster_helper<WIDE>(P, member, s_cl);
             return;
         }
         // the helpers have 200 us to show up; otherwise this workgroup runs alone and they leave when they see the flag
@@ -2047,16 +2169,33 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         b += 72;
         S.part = b;  // (fixed-size array first: part starts on a 16-byte boundary for every N)
         b += 2 * LT;
+        double *const gscratch = ln_eval_parts(P) + 2 * (size_t)((N + EVW - 1) / EVW) * P.NP;  // (WIDE: 29 N + 64 doubles behind the partial sums)
+        if constexpr (WIDE) {
+            // LDS: the Cholesky's small arrays, rdiag and the permutation (written during a factorisation), then the other eighteen
+            // vectors -- with the Cholesky's one panel over them; the solve vectors and the vectors' backup in global memory
+            S.chol = b;
+            b += fh_ln_chol_small_wide(P.NP) + (fh_ln_chol_small_wide(P.NP) & 1);
+            S.rdiag = b;
+            b += N;
+            S.perm = reinterpret_cast<int *>(b);
+            b += N;
+            S.cpan = b;
+            S.bak = gscratch + LNW * N;
+        }
         double **vecs[] = {&S.x,  &S.xn, &S.I, &S.In,   &S.Sx,  &S.Sxn, &S.MI,  &S.MIn,  &S.jx,   &S.dx,
                            &S.pd, &S.jv, &S.p, &S.pold, &S.rhs, &S.tr2, &S.col, &S.rowk, &S.rdiag};
         for (auto v : vecs) {
+            if (WIDE && v == &S.rdiag) continue;
             *v = b;
             b += N;
         }
-        S.perm = reinterpret_cast<int *>(b);
-        b += N;  // 2N ints
-        S.wsol = b;  // one solve vector per wave (72 + 2 LT + 20 N doubles in front: a 16-byte boundary for every N); the tiled
+        if constexpr (!WIDE) {
+            S.perm = reinterpret_cast<int *>(b);
+            b += N;  // 2N ints
+        }
+        S.wsol = WIDE ? gscratch : b;  // one solve vector per wave (72 + 2 LT + 20 N doubles in front: a 16-byte boundary for every N); the tiled
         b += LNW * N;  // Cholesky works in this space AND the panel's behind it (cholesky_as_lu, fh_ln_chol_doubles)
+        if constexpr (!WIDE) S.chol = S.wsol;
         S.cluster = cluster;
         S.seq = cl_seq;
         S.same_xcd = same_xcd;
@@ -2077,7 +2216,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
             if (bnd == 2) band_g[5 * N + c] = 1.0 / v;
         }
         __syncthreads();
-        if (tid < 64) bandscan::scan_tables<6>(band_g, N, scan_g, tid);  // (6 rows per lane: N <= 320 < 384)
+        if (tid < 64) bandscan::scan_tables<WIDE ? 10 : 6>(band_g, N, scan_g, tid);  // (6 rows per lane: N <= 320 < 384; ten: <= 640)
     }
     S.redsel = 0;
     S.nch = min(LT / N, N);
@@ -2184,7 +2323,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
             if (tid == 0) ln_cyc[8] += clock64() - _ts;
             const long long _tn = clock64();
 #endif
-            const NewtonExit ex = minimize_newton(P, S);
+            const NewtonExit ex = minimize_newton<WIDE>(P, S);
 #ifdef LN_TIMING
             if (tid == 0) ln_cyc[4] += clock64() - _tn;
 #endif
@@ -2197,6 +2336,10 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
             }
             if (ex.status == 4) {
                 status = LN_STATUS_SLOPE;
+                break;
+            }
+            if (ex.status == 5) {  // (WIDE: a Hessian the tiled Cholesky could not factor)
+                status = LN_STATUS_NOT_SPD;
                 break;
             }
             // Dinv = hess(s_MAP) (:1147), row-major for the host
@@ -2221,7 +2364,11 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
                         Cp[pk_elem(b, a, nbk)] = (a < N && b < N) ? P.H[a * N + b] : (a == b ? 1.0 : 0.0);
                 __syncthreads();
             }
-            chol = cholesky_as_lu(P, S, Cp, Xd);
+            chol = cholesky_as_lu<WIDE>(P, S, Cp, Xd);
+            if (WIDE && !chol) {
+                status = LN_STATUS_NOT_SPD;
+                break;
+            }
         }
         if (!chol) {
             if (P.mode != LN_MODE_UPDATE) {
@@ -2253,7 +2400,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         // (Y s)_r into S.rhs: a wave takes rows w, w + 8, ...; the loads of four rows are issued together (a row at a time the
         // wave waited for one L2 round trip per row), the sums are formed in the same order
         auto tr1_sums = [&]() {
-            constexpr int RB = 4, CB = 5;  // N <= 320: five column chunks of 64
+            constexpr int RB = WIDE ? 2 : 4, CB = WIDE ? 10 : 5;  // N <= 320: five column chunks of 64; WIDE: ten
             double xs[CB];
 #pragma unroll
             for (int cc = 0; cc < CB; ++cc) xs[cc] = (lane + 64 * cc < N) ? S.x[lane + 64 * cc] : 0.0;
@@ -2280,19 +2427,19 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         };
         const bool tr1_early = chol && S.cluster > 2;  // formed while the helpers solve for Tr2
         if (chol) {
-            const double *dvec = chol_dvec(S, P.NP);  // diag(L), left in LDS by cholesky_as_lu
+            const double *dvec = chol_dvec<WIDE>(S, P.NP);  // diag(L), left in LDS by cholesky_as_lu
             if (S.cluster > 1) {
                 for (int i = tid; i < P.NP; i += LT) P.dvec_g[i] = dvec[i];
                 cluster_dispatch(P, LN_CMD_TR2, same_xcd, S.seq);
                 if (S.cluster > 2) tr1_sums();  // (three helpers and more take the Tr2 columns among themselves)
-                else tr2_solve(P, S.lu, dvec, Xd, Wsc, P.tr2_g, 0, S.cluster);
+                else tr2_solve<WIDE>(P, S.lu, dvec, Xd, Wsc, P.tr2_g, 0, S.cluster);
                 if (!cluster_wait(P, s_cl, same_xcd)) {
                     status = LN_STATUS_CLUSTER;
                     break;
                 }
                 for (int i = tid; i < N; i += LT) S.tr2[i] = P.tr2_g[i];
             } else {
-                tr2_solve(P, S.lu, dvec, Xd, Wsc, S.tr2);
+                tr2_solve<WIDE>(P, S.lu, dvec, Xd, Wsc, S.tr2);
             }
             __syncthreads();
         }
@@ -2343,8 +2490,8 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
                          // (one thread took 2 N dependent steps with its operands in L2: 70 us of a 1.2 ms pass at N = 300)
             int t = tid;
             asm volatile("" : "+v"(t));
-            bandscan::scan_solve<6>(band_g, N, scan_g, S.rhs, 0, t);
-            bandscan::scan_solve<6>(band_g, N, scan_g, S.rhs, 1, t);
+            bandscan::scan_solve<WIDE ? 10 : 6>(band_g, N, scan_g, S.rhs, 0, t);
+            bandscan::scan_solve<WIDE ? 10 : 6>(band_g, N, scan_g, S.rhs, 1, t);
         }
         __syncthreads();
         for (int i = tid; i < N; i += LT) S.p[i] = exp(S.rhs[i]);  // filter.py:177
@@ -2406,6 +2553,14 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
 
 // lu_nb: panel width of the blocked LU (0: factors in LDS, unblocked); N = 320 with a 32-column panel takes 159 KB
 size_t fh_ln_smem_bytes(int N, int *lu_in_lds, int *lu_nb) {
+    if (N > 320) {  // WIDE kernel: the reductions' partials and the Cholesky's one panel
+        if (lu_in_lds) *lu_in_lds = 0;
+        if (lu_nb) *lu_nb = LU_NB;
+        const int NPw = (N + 15) / 16 * 16;
+        const size_t small = (size_t)fh_ln_chol_small_wide(NPw) + (fh_ln_chol_small_wide(NPw) & 1);
+        const size_t vec18 = 18 * (size_t)N, panel = (size_t)NPw * tilechol::PS;
+        return sizeof(double) * (72 + 2 * LT + small + 2 * (size_t)N + (vec18 > panel ? vec18 : panel));
+    }
     size_t doubles = (19 + LNW) * N + 72 + 2 * LT + N;
     const int fits = (N <= 112);
     if (lu_in_lds) *lu_in_lds = fits;
@@ -2427,7 +2582,8 @@ hipError_t fh_ln_launch(const LogNormalParams &P0, int nblocks, hipStream_t s) {
     LogNormalParams P = P0;
     const size_t smem = fh_ln_smem_bytes(P.N, &P.lu_in_lds, &P.lu_nb);
     using Kernel = void (*)(LogNormalParams);
-    Kernel fn = P.lu_in_lds ? lognormal_kernel<true> : lognormal_kernel<false>;
+    Kernel fn = P.lu_in_lds ? lognormal_kernel<true, false> : (P.N > 320 ? lognormal_kernel<false, true> : lognormal_kernel<false, false>);
+    if (P.N > 640) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)smem);
     if (e != hipSuccess) return e;

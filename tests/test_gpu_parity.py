@@ -1007,14 +1007,19 @@ def test_lognormal_large_basis_against_oracle():
         assert np.abs(FF.iteration_diagnostics["MAP"][k] - o["diag_s"][k]).max() < 1e-6
 
 
-def test_lognormal_beyond_the_persistent_kernel_against_oracle():
-    """320 < N <= 1023: method='LogNormal' takes the host-driven route (lognormal_wide.hip: MinimizeNewton / LineSearch on the
+@pytest.mark.parametrize("route", ["kernel", "host"])
+def test_lognormal_beyond_the_persistent_kernel_against_oracle(monkeypatch, route):
+    """320 < N <= 640 (round 6): method='LogNormal' runs on the persistent kernel in its WIDE form (vectors in global memory, one
+    panel for the tiled Cholesky: the same code as N <= 320); route = 'host' (FRANK_AMD_LN_WIDE=host, and every N up to 1023): the
+    host-driven route of round 4 (lognormal_wide.hip: MinimizeNewton / LineSearch on the
     host, the products, the Hessian and its LU on the device) -- LogNormalMAPModel at N = 330 and N = 400, a few passes of the
     whole fit and CriticalFilter.update_power_spectrum(fit) at N = 330, against the pinned oracle (no reference fixture at these
     sizes).  The step count follows the reference's to the per cent (different summation orders move a frozen-Hessian
     iteration of several hundred steps by a few)."""
     from frank_amd import CriticalFilter, DiscreteHankelTransform, FrankFitter, LogNormalMAPModel
     from oracle import oracle as fo
+    if route == "host":
+        monkeypatch.setenv("FRANK_AMD_LN_WIDE", "host")
     for N, rmax_as, nvis in ((330, 2.0, 400000), (400, 1.0, 100000)):
         rmax = rmax_as / rad_to_arcsec
         u, v, V, w = mock_disc_visibilities(nvis, seed=51, noise_seed=52)
