@@ -39,7 +39,7 @@ Rank 0 at N=1 also reports, outside the timed region and bounded to about a minu
   extra.from_host_pipelined  fits from HOST arrays back to back: the upload of fit i + 1 beside the iterations of fit i
   extra.sweep512_distinct    configs[4] with every fit binning its own 1e6-visibility table
   extra.lognormal_fullsize   BASELINE configs[2] (N=300, 1e7 visibilities, LogNormal) on the resident table
-  extra.lognormal_N640       the same table at N=640: LogNormal beyond the persistent kernel (host-driven route)
+  extra.lognormal_N640       the same table at N=640: LogNormal on the persistent kernel's WIDE form (320 < N <= 640, round 6)
   extra.fp32_table           the same table stored in single precision (configs[2]'s "fp32": 20 B per visibility)
   extra.sweep512             BASELINE configs[4] on one GPU (512 fits of one 1e6-visibility mapping)
   extra.uvbin                UVDataBinner streaming passes at 1e7 rows (HBM roofline)
@@ -640,8 +640,9 @@ def extras(f, L, a):
             "does is lognormal_fullsize_reference_linesearch -- quote both")
     except Exception as e:
         ex.setdefault("lognormal_fullsize", {})["error"] = repr(e)
-    # -- method='LogNormal' beyond the persistent kernel's basis size (N = 640: the host-driven route, lognormal_wide.hip) on the
-    #    same resident table, at most 200 passes of the power-spectrum loop
+    # -- method='LogNormal' at N = 640 (the persistent kernel's WIDE form, 320 < N <= 640; rounds 4-5: the host-driven route,
+    #    lognormal_wide.hip, which FRANK_AMD_LN_WIDE=host still selects) on the same resident table, at most 200 passes of the
+    #    power-spectrum loop
     try:
         f2 = Fitter(L, 640, f.device)
         f2.vis, f2.nfit, f2.n = f.vis, f.nfit, f.n
@@ -659,8 +660,9 @@ def extras(f, L, a):
         t2 = time.perf_counter()
         I2 = np.exp(s2 + np.log(1e5))
         ex["lognormal_N640"] = {
-            "workload": "N=640, %d visibilities, LogNormal, alpha=1.3, w_smooth=1e-2, max_iter=200: beyond the persistent "
-                        "kernel (N <= 320) MinimizeNewton runs on the host over device kernels" % f.nfit,
+            "workload": "N=640, %d visibilities, LogNormal, alpha=1.3, w_smooth=1e-2, max_iter=200: the persistent kernel in its "
+                        "WIDE form (320 < N <= 640: one LDS panel for the Cholesky laid over the work vectors, round 6; "
+                        "FRANK_AMD_LN_WIDE=host keeps round 4's host-driven MinimizeNewton: 39 ms per iteration)" % f.nfit,
             "s_per_fit": t2 - t0, "bin_s": t1 - t0, "fit_s": t2 - t1, "power_spectrum_iterations": nit2.value,
             "newton_steps": int(st2[1]), "function_evaluations": int(st2[2]), "hessian_factorisations": int(st2[3]),
             "ms_per_power_spectrum_iteration": 1e3 * (t2 - t1) / max(nit2.value, 1),

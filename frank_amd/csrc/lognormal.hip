@@ -1458,6 +1458,135 @@ __device__ __forceinline__ void block_solve(LnS &S, int N, const double *A, cons
     }
 }
 
+// block_solve for the WIDE form (320 < N <= 640: ten blocks of 64 rows, 3.3 MB of factors per direction, from beyond the L2).
+// Two changes to the schedule, none to the substitution: (i) the product of a block's rows with the x of all blocks but the one just
+// solved does not wait for that one -- waves 1..7 form it WHILE wave 0 runs the chain of the block before, and only the last 64
+// columns (eight per wave) follow behind the chain; (ii) sixteen columns in flight per wave instead of eight (one compute unit
+// takes ~25 B per cycle from the L2 side only with ~60 KB outstanding).  part: two sets of LNW x 64 partial sums.
+__device__ __forceinline__ double wide_cols(const double *A, int N, int rc, const double *xs, int c, int c1, double acc) {
+    const double *a = A + (size_t)c * N + rc;
+    for (; c + 16 <= c1; c += 16, a += 16 * (size_t)N) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = a[u * (size_t)N];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = fma(v[u], xs[c + u], acc);
+    }
+    for (; c + 4 <= c1; c += 4, a += 4 * (size_t)N) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = a[u * (size_t)N];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = fma(v[u], xs[c + u], acc);
+    }
+    for (; c < c1; ++c, a += N) acc = fma(*a, xs[c], acc);
+    return acc;
+}
+
+__device__ __forceinline__ void block_solve_wide(LnS &S, int N, const double *A, const double *b, double sign, double *xs) {
+    const int tid = ln_tid(), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *part = S.part;
+    for (int jj = tid; jj < N; jj += LT) xs[jj] = sign * b[S.perm[jj]];
+    __syncthreads();
+    const int nblk = (N + 63) >> 6;
+    auto chain_lower = [&](int kb) {  // wave 0: the 64 x 64 unit-lower diagonal block, as block_solve runs it
+        const int k0 = kb << 6, r = k0 + lane, rc = min(r, N - 1);
+        const double *pp = part + (kb & 1) * (LNW * 64);
+        const int ng = (min(64, N - k0) + 7) >> 3;
+        double acc = (r < N) ? xs[r] : 0.0;
+#pragma unroll
+        for (int w = 0; w < LNW; ++w) acc -= pp[w * 64 + lane];
+        double nxt[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nxt[u] = A[min(k0 + u, N - 1) * N + rc];
+#pragma unroll 1
+        for (int g = 0; g < ng; ++g) {
+            double cur[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+            if (g + 1 < ng) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) nxt[u] = A[min(k0 + 8 * g + 8 + u, N - 1) * N + rc];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = 8 * g + u;
+                acc = fma(-((lane > c && r < N) ? cur[u] : 0.0), lane_bcast(acc, c), acc);
+            }
+        }
+        if (r < N) xs[r] = acc;
+    };
+    auto chain_upper = [&](int kb, int t) {  // wave 0: the upper diagonal block with its reciprocal pivots
+        const int k0 = kb << 6, r = k0 + lane, rc = min(r, N - 1);
+        const double *pp = part + (t & 1) * (LNW * 64);
+        const int ng = (min(64, N - k0) + 7) >> 3;
+        double acc = (r < N) ? xs[r] : 0.0;
+#pragma unroll
+        for (int w = 0; w < LNW; ++w) acc -= pp[w * 64 + lane];
+        const double rd = (r < N) ? S.rdiag[r] : 0.0;
+        double nxt[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nxt[u] = A[min(k0 + 8 * (ng - 1) + u, N - 1) * N + rc];
+#pragma unroll 1
+        for (int g = ng - 1; g >= 0; --g) {
+            double cur[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+            if (g > 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) nxt[u] = A[(k0 + 8 * g - 8 + u) * N + rc];
+            }
+#pragma unroll
+            for (int u = 7; u >= 0; --u) {
+                const int c = 8 * g + u;
+                const double xi = lane_bcast(acc * rd, c);
+                acc = (lane == c) ? xi : acc;
+                acc = fma(-((lane < c) ? cur[u] : 0.0), xi, acc);
+            }
+        }
+        if (r < N) xs[r] = acc;
+    };
+    for (int kb = 0; kb < nblk; ++kb) {  // L y = P b, unit lower
+        const int k0 = kb << 6, rc = min(k0 + lane, N - 1);
+        const int early = max(0, k0 - 64);
+        double acc = 0.0;
+        if (wv == 0) {
+            if (kb > 0) chain_lower(kb - 1);
+        } else {
+            acc = wide_cols(A, N, rc, xs, (wv - 1) * early / (LNW - 1), wv * early / (LNW - 1), 0.0);
+        }
+        __syncthreads();
+        {
+            const int late = k0 - early;
+            acc = wide_cols(A, N, rc, xs, early + wv * late / LNW, early + (wv + 1) * late / LNW, acc);
+            part[(kb & 1) * (LNW * 64) + wv * 64 + lane] = acc;
+        }
+        __syncthreads();
+    }
+    if (wv == 0) chain_lower(nblk - 1);
+    __syncthreads();
+    for (int t = 0; t < nblk; ++t) {  // U x = y
+        const int kb = nblk - 1 - t, k0 = kb << 6, rc = min(k0 + lane, N - 1);
+        const int lo = min(N, k0 + 64), mid = min(N, lo + 64);  // [lo, mid): the block just solved; [mid, N): the ones before it
+        double acc = 0.0;
+        if (wv == 0) {
+            if (t > 0) chain_upper(kb + 1, t - 1);
+        } else {
+            const int span = N - mid;
+            acc = wide_cols(A, N, rc, xs, mid + (wv - 1) * span / (LNW - 1), mid + wv * span / (LNW - 1), 0.0);
+        }
+        __syncthreads();
+        {
+            const int late = mid - lo;
+            acc = wide_cols(A, N, rc, xs, lo + wv * late / LNW, lo + (wv + 1) * late / LNW, acc);
+            part[(t & 1) * (LNW * 64) + wv * 64 + lane] = acc;
+        }
+        __syncthreads();
+    }
+    if (wv == 0) chain_upper(0, nblk - 1);
+    __syncthreads();
+}
+
 __device__ __forceinline__ void accept_trial(LnS &S, int N) {
     for (int i = ln_tid(); i < N; i += LT) {
         S.x[i] = S.xn[i];
@@ -1654,7 +1783,10 @@ __device__ __forceinline__ NewtonExit minimize_newton(const LogNormalParams &P, 
                 S.dx[tid] = -a;
             }
         } else if (S.lu_nb > 0) {
-            block_solve(S, N, S.lu, S.jx, -1.0, S.dx);  // factors in L2: every wave streams its share of them
+            if constexpr (WIDE)
+                block_solve_wide(S, N, S.lu, S.jx, -1.0, S.dx);
+            else
+                block_solve(S, N, S.lu, S.jx, -1.0, S.dx);  // factors in L2: every wave streams its share of them
         } else if (tid < 64) {
             wave_solve(S, N, S.lu, S.jx, -1, -1.0, S.dx);
         }
