@@ -531,22 +531,27 @@ def extras(f, L, a):
         # thread) runs beside the iterations of the fits before it (their loops sit on the launch streams): the rate is what
         # PCIe and the host-side split of the complex column allow, not upload + fit one behind the other
         try:
-            K = 48
+            K = 96
             pend, alive = [], []
+            count = [0]
 
             def one():
                 vis = ctypes.c_void_p()
                 L.check(L.lib.fh_vis_upload(f.device, L.ptr(u), L.ptr(v), L.ptr(Vre), L.ptr(Vim), L.ptr(w), w.size, u.size, ctypes.byref(vis)))
                 alive.append(vis)
                 pend.append(f.submit(vis))
-                # (no flush here: a fit flushed at once -- one launch per fit -- was measured at 19 fits/s, every collect waiting a whole
-                #  fit; the staged fits of the window start together when the first collect asks for one of them)
-                while len(alive) > 12:  # (a table is freed behind the fit that binned it; twelve tables = 4.8 GB in flight, and at most
-                                        #  sixteen launches of a context are outstanding)
+                count[0] += 1
+                # (a context runs four launches at a time and a collect that meets a fit still staged launches it and waits a whole
+                #  fit for it: the staged fits go out every eight submissions -- launches of eight fits on clusters, 45 ms each, one
+                #  every 60 ms -- so that the fit a collect asks for, submitted 24 uploads ago, has long ended.  tools/from_host_phases.py)
+                if count[0] % 8 == 0:
+                    L.check(L.lib.fh_fit_flush(f.ctx))
+                while len(alive) > 24:  # (a table is freed behind the fit that binned it -- fh_vis_destroy waits for the streams that
+                                        #  read tables, not for the fit loops in flight --; 24 tables = 9.6 GB)
                     f.collect(pend.pop(0))
                     L.lib.fh_vis_destroy(alive.pop(0))
             L.check(L.lib.fh_ctx_set_range_cache(f.ctx, 0))
-            for _ in range(16):  # (the pipeline full: twelve fits in flight when the clock starts)
+            for _ in range(32):  # (the pipeline full when the clock starts)
                 one()
             t0 = time.perf_counter()
             for _ in range(K):

@@ -54,6 +54,27 @@ void pool_clear() {
     g_pool_held = 0;
 }
 
+static std::mutex g_reader_mutex;
+static std::vector<std::pair<int, hipStream_t>> g_reader_streams;
+void reader_stream_add(int device, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_reader_mutex);
+    g_reader_streams.emplace_back(device, s);
+}
+void reader_stream_remove(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_reader_mutex);
+    for (size_t i = 0; i < g_reader_streams.size(); ++i)
+        if (g_reader_streams[i].second == s) {
+            g_reader_streams.erase(g_reader_streams.begin() + (long)i);
+            return;
+        }
+}
+void reader_streams_sync(int device) {
+    std::lock_guard<std::mutex> lk(g_reader_mutex);  // (held across the waits: a stream in the list is not destroyed meanwhile)
+    for (const auto &e : g_reader_streams)
+        if (e.first == device) (void)hipStreamSynchronize(e.second);
+    (void)hipStreamSynchronize(nullptr);  // (the split of a complex column, the synchronous entry points' kernels)
+}
+
 // HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels whose streams share a queue serialise: the
 // launches of a pipeline of fits (up to six streams beside the binning stream) want at least eight.  The variable is read when the
 // ROCm runtime comes up (the first HIP call of the process).  Round 6: neither loading the library nor importing the Python package
@@ -182,6 +203,7 @@ int fh_ctx_create(const fh_dht *dht, int device, fh_ctx **out) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    reader_stream_add(c->device, c->stream);
     HIP_TRY(hipEventCreateWithFlags(&c->ev_bin0, hipEventDisableSystemFence));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_bin1, hipEventDisableSystemFence));
     ROC_TRY(rocblas_create_handle(&c->blas));
@@ -411,6 +433,7 @@ void fh_ctx_destroy(fh_ctx *c) {
     if (c->ev_pre0) (void)hipEventDestroy(c->ev_pre0);
     if (c->pf_stream) {
         (void)hipStreamSynchronize(c->pf_stream);
+        reader_stream_remove(c->pf_stream);
         (void)hipStreamDestroy(c->pf_stream);
     }
     if (c->ev_rng0) (void)hipEventDestroy(c->ev_rng0);
@@ -425,7 +448,10 @@ void fh_ctx_destroy(fh_ctx *c) {
     }
     if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);
     if (c->ev_loop1) (void)hipEventDestroy(c->ev_loop1);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream) {
+        reader_stream_remove(c->stream);
+        (void)hipStreamDestroy(c->stream);
+    }
     delete c;
 }
 int fh_ctx_synchronize(fh_ctx *c) {
@@ -499,7 +525,7 @@ int fh_vis_upload_c128(int device, const double *u, const double *v, const doubl
     struct ReleaseAfterSync {  // tmp's memory returns to the pool only behind a device synchronisation
         DevBuf<double> &b;
         ~ReleaseAfterSync() {
-            (void)hipDeviceSynchronize();
+            (void)hipStreamSynchronize(nullptr);  // (tmp is written by a null-stream copy and read by the null-stream split kernel only)
             b.release();
         }
     } tmp_guard{tmp};
@@ -514,7 +540,7 @@ int fh_vis_upload_c128(int device, const double *u, const double *v, const doubl
         HIP_TRY(hipMemcpy(t->u.p, u, b, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(t->v.p, v, b, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(t->w.p, w, t->w_scalar ? sizeof(double) : b, hipMemcpyHostToDevice));
-        HIP_TRY(hipDeviceSynchronize());  // (the split runs on the null stream; tmp goes away with this scope)
+        HIP_TRY(hipStreamSynchronize(nullptr));  // (the split runs on the null stream; tmp goes away with this scope)
     }
     *out = t.release();
     return FH_OK;
@@ -569,9 +595,9 @@ int fh_cache_release(void) {
 void fh_vis_destroy(fh_vis *vis) {
     if (!vis) return;
     (void)hipSetDevice(vis->device);
-    // (hipFree waited for the device; the columns now go back to a cache and may be handed out again at once: kernels of any
-    //  stream that still read them must have ended)
-    (void)hipDeviceSynchronize();
+    // (hipFree waited for the device; the columns now go back to a cache and may be handed out again at once: the kernels that
+    //  still read them must have ended -- those run on the contexts' binning and look-ahead streams and on the null stream)
+    reader_streams_sync(vis->device);
     delete vis;
 }
 int64_t fh_vis_size(const fh_vis *vis) { return vis ? vis->n : 0; }

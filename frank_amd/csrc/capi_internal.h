@@ -64,6 +64,12 @@ struct PoolEntry {
     size_t bytes;
     int device;
 };
+// The streams on which kernels READ the columns of a visibility table: every context's binning stream and its look-ahead stream
+// (fit loops read the operands of their slot, never a table).  fh_vis_destroy waits for these and the null stream, not for the
+// device: a pipeline that frees a table behind its fit no longer waits for every fit loop in flight (45 ms apiece).
+void reader_stream_add(int device, hipStream_t s);  // capi_core.hip
+void reader_stream_remove(hipStream_t s);
+void reader_streams_sync(int device);
 void *pool_take(size_t bytes, int device);   // capi_core.hip
 void pool_put(void *p, size_t bytes, int device);
 void pool_clear();

@@ -783,7 +783,10 @@ int fh_bin_prefetch_range(fh_ctx *c, const fh_geometry *g, const fh_vis *vis, in
     bin_params(c, g, vis, first, count, P.bin);
     fh_prepass_geometry(0, c->num_cu, &P.wpb, &P.blocks);
     P.unroll = c->k1env.unroll;
-    if (!c->pf_stream) HIP_TRY(hipStreamCreateWithFlags(&c->pf_stream, hipStreamNonBlocking));
+    if (!c->pf_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->pf_stream, hipStreamNonBlocking));
+        reader_stream_add(c->device, c->pf_stream);
+    }
     // a free look-ahead: not waiting to be taken, and the pass that took its histograms has run; else a new one; else the oldest
     fh_ctx::LookAhead *pick = nullptr, *oldest = nullptr;
     for (auto &lp : c->pf) {

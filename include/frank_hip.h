@@ -261,7 +261,11 @@ int fh_fit_normal(fh_ctx *ctx, const double *M, const double *j, double alpha, d
  * max_iter, alpha, p0 and w_smooth are per fit):
  * fh_fit_flush launches what has been staged so far -- call it after the last submission; fh_fit_collect on a fit
  * whose launch is still open does the same.  fh_fit_collect waits for that fit and returns mu, p, niter exactly as
- * fh_fit_normal does.  Tickets are collected in any order; at most fh_fit_slots() fits may be outstanding.     */
+ * fh_fit_normal does.  Tickets are collected in any order; at most fh_fit_slots() fits may be outstanding.
+ * A caller whose host thread is busy between submissions (uploading the next table: bench.py extra.from_host_pipelined) should
+ * flush every few submissions: a collect that meets a fit still staged launches it and then waits a whole fit for it, and a context
+ * runs about four launches at a time (one fit per launch = four fits in flight).  fh_vis_destroy of a table waits for the streams
+ * that read tables (binning, look-ahead), not for the fit loops in flight.                                            */
 /* The packed statistics of the last binning pass (what fh_comm_allreduce_stats reduces in place on the device: n doubles, n from
  * fh_stats_device; minmax = (-qmin, qmax), NaN where nothing was binned) copied to / replaced from the host: for a reduction over
  * ranks that does not go through RCCL (two ranks on one device, any torch.distributed backend -- frank_amd.distributed.HostComm);
