@@ -1020,8 +1020,12 @@ def test_lognormal_beyond_the_persistent_kernel_against_oracle(monkeypatch, rout
     from oracle import oracle as fo
     if route == "host":
         monkeypatch.setenv("FRANK_AMD_LN_WIDE", "host")
-    for N, rmax_as, nvis in ((330, 2.0, 400000), (400, 1.0, 100000)):
+    # (N = 639, the last size of the WIDE form's 40 x 40 tile grid, on the kernel only: the oracle's share is a minute of the host)
+    for N, rmax_as, nvis in ((330, 2.0, 400000), (400, 1.0, 100000)) + (((639, 1.0, 100000),) if route == "kernel" else ()):
         rmax = rmax_as / rad_to_arcsec
+        # (at N = 639 the Hessian's condition number leaves the minimisers ~3e-6 of the peak apart -- two stopping rules on a valley
+        #  that flat; north_star's tolerance on the profile is 1e-3 -- and the Hessian count may differ by a few)
+        tol, dh = (1e-6, 0) if N < 600 else (1e-5, 3)
         u, v, V, w = mock_disc_visibilities(nvis, seed=51, noise_seed=52)
         m = fo.map_visibilities(N, rmax, GEOM, u, v, V, w, check_qbounds=False)
         assert m["rc"] == 0
@@ -1038,19 +1042,19 @@ def test_lognormal_beyond_the_persistent_kernel_against_oracle(monkeypatch, rout
         # the default line search forms S^-1 (x + lam p) from S^-1 x and S^-1 p (as the persistent kernel's default): the same MAP
         fit_l = LogNormalMAPModel(d, m["M"], m["j"], p_seed, guess=s_guess, s0=s0)
         Iref = np.exp(ref["s"] + s0)
-        assert np.abs(np.exp(fit_l.MAP + s0) - Iref).max() / Iref.max() < 1e-6 and fit_l._newton_stats[4] == 1, N
+        assert np.abs(np.exp(fit_l.MAP + s0) - Iref).max() / Iref.max() < tol and fit_l._newton_stats[4] == 1, N
         assert fit_l._newton_stats[2] < 1.5 * fit_l._newton_stats[1]  # (evaluations per step)
         # linesearch='reference' multiplies S^-1 x out at every trial point as the reference does, and follows its counts
         fit = LogNormalMAPModel(d, m["M"], m["j"], p_seed, guess=s_guess, s0=s0, linesearch="reference")
         I = np.exp(fit.MAP + s0)
-        assert np.abs(I - Iref).max() / Iref.max() < 1e-6, N  # the north_star tolerance on the brightness profile
+        assert np.abs(I - Iref).max() / Iref.max() < tol, N  # (north_star's tolerance on the brightness profile: 1e-3)
         # (the faint outer disc is held loosely: the reference itself moves by ~1e-4 in s there when M is perturbed by 1e-15
         #  relative -- test_lognormal_map_model_N300, map_selfsens_* --; where the disc is bright the MAP is determined)
         bright = Iref > 0.1 * Iref.max()
-        assert np.abs(fit.MAP - ref["s"])[bright].max() < 1e-6 and np.abs(fit.MAP - ref["s"]).max() < 5e-4, N
-        assert rel_to_max(fit._Dinv, ref["Dinv"]) < 1e-6, N
+        assert np.abs(fit.MAP - ref["s"])[bright].max() < tol and np.abs(fit.MAP - ref["s"]).max() < 5e-4, N
+        assert rel_to_max(fit._Dinv, ref["Dinv"]) < tol, N
         st = fit._newton_stats
-        assert st[0] == 1 and st[4] == 1 and st[3] == ref["stats"][3], (N, st, ref["stats"])
+        assert st[0] == 1 and st[4] == 1 and abs(st[3] - ref["stats"][3]) <= dh, (N, st, ref["stats"])
         assert abs(st[1] - ref["stats"][1]) <= 0.02 * ref["stats"][1] + 2, (N, st, ref["stats"])
         if N == 330:
             p_new = CriticalFilter(d, 1.3, 1e-35, 1e-2).update_power_spectrum(fit)
