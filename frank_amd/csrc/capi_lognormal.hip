@@ -39,6 +39,8 @@ static int ln_prepare(fh_ctx *c, const double *M, const double *j, LogNormalPara
     {
         const char *e = getenv("FRANK_AMD_LN_PIVOTED");
         P.no_cholesky = (e && e[0] == '1') ? 1 : 0;
+        const char *d = getenv("FRANK_AMD_LN_CLUSTER_CHOL");
+        P.dist_cholesky = (d && d[0] == '0') ? 0 : 1;
     }
     P.max_step = 100000;  // minimizer.py:190
     P.max_hev = 1000;
@@ -582,9 +584,9 @@ int fh_fit_lognormal(fh_ctx *c, const double *M, const double *j, double alpha, 
         cl = cl < 1 ? 1 : (cl > 8 ? 8 : cl);
         if (cl > 1) {
             const size_t nv = (size_t)2 * N + P.NP;
-            if (!c->ln_ctl.p) HIP_TRY(c->ln_ctl.alloc(8));
+            if (!c->ln_ctl.p) HIP_TRY(c->ln_ctl.alloc(LN_CTL_WORDS));
             if (c->ln_cluster_vecs.n < nv) HIP_TRY(c->ln_cluster_vecs.alloc(nv));
-            HIP_TRY(hipMemsetAsync(c->ln_ctl.p, 0, 8 * sizeof(int), c->stream));
+            HIP_TRY(hipMemsetAsync(c->ln_ctl.p, 0, LN_CTL_WORDS * sizeof(int), c->stream));
             P.cluster = cl;
             P.ctl = c->ln_ctl.p;
             P.rk_g = c->ln_cluster_vecs.p;
@@ -764,9 +766,9 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
     cl1 = FH_DEV_INT("FRANK_AMD_LN_STAGE1_CLUSTER", cl1);
     if (cl1 > 1) {
         const size_t vstride1 = (size_t)2 * N + P.NP;
-        if (ctl1.alloc((size_t)8 * G) != hipSuccess || vecs1.alloc(G * vstride1) != hipSuccess)
+        if (ctl1.alloc((size_t)LN_CTL_WORDS * G) != hipSuccess || vecs1.alloc(G * vstride1) != hipSuccess)
             return fail(FH_ERR_NOMEM, "device allocation failed");
-        HIP_TRY(hipMemsetAsync(ctl1.p, 0, sizeof(int) * 8 * G, c->stream));
+        HIP_TRY(hipMemsetAsync(ctl1.p, 0, sizeof(int) * LN_CTL_WORDS * G, c->stream));
         P.cluster = cl1;
         P.groups = (int)G;
         P.ctl = ctl1.p;
@@ -818,7 +820,7 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
         if (rs.alloc(K * (3 * (size_t)N + 1)) != hipSuccess || sb2.alloc(K * N) != hipSuccess || pb2.alloc(K * N) != hipSuccess ||
             Hb2.alloc(K * NN) != hipSuccess || lub2.alloc(K * 5 * N) != hipSuccess || alb2.alloc(K) != hipSuccess ||
             p0b2.alloc(K) != hipSuccess || vecs.alloc((size_t)groups * vstride) != hipSuccess || resb2.alloc(2 * K) != hipSuccess ||
-            ctl2.alloc((size_t)8 * groups) != hipSuccess || stb2.alloc(17 * K) != hipSuccess)
+            ctl2.alloc((size_t)LN_CTL_WORDS * groups) != hipSuccess || stb2.alloc(17 * K) != hipSuccess)
             return fail(FH_ERR_NOMEM, "fh_fit_lognormal_batched: device allocation for the second stage failed");
         std::vector<double> al2(K), p02(K), lu2(K * 5 * N), cnt(K);
         for (size_t q = 0; q < K; ++q) {
@@ -837,7 +839,7 @@ int fh_fit_lognormal_batched(fh_ctx *c, const double *M, const double *j, int ba
         HIP_TRY(hipMemcpyAsync(alb2.p, al2.data(), sizeof(double) * K, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(p0b2.p, p02.data(), sizeof(double) * K, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(counter.p, 0, sizeof(int), c->stream));
-        HIP_TRY(hipMemsetAsync(ctl2.p, 0, sizeof(int) * 8 * (size_t)groups, c->stream));
+        HIP_TRY(hipMemsetAsync(ctl2.p, 0, sizeof(int) * LN_CTL_WORDS * (size_t)groups, c->stream));
         LogNormalParams P2 = P;
         P2.batch = (int)K;
         P2.band_lu = lub2.p;

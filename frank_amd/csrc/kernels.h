@@ -326,6 +326,10 @@ hipError_t fh_launch_split_complex(const double *vc, int64_t n, double *re, doub
 // ---- LogNormal (lognormal.hip): Newton MAP of the log-brightness + the power-spectrum loop, one workgroup per fit
 enum { LN_MODE_MAP = 0, LN_MODE_FIT = 1, LN_MODE_UPDATE = 2 };
 enum { LN_STATUS_OK = 0, LN_STATUS_BAD_P = 1, LN_STATUS_SLOPE = 2, LN_STATUS_CLUSTER = 3, LN_STATUS_PAUSED = 4, LN_STATUS_NOT_SPD = 5 };
+// control words of a cluster of LogNormal workgroups (ints per group): [0, 8) command / counters / flags (lognormal.hip), then,
+// each in a 128-byte line of its own, the progress word of a distributed Cholesky (panels stored, cumulative over the
+// factorisations of the launch) and the counters of the block columns its helpers have handed back
+constexpr int LN_CTL_WORDS = 128, LN_CTL_PROG = 32, LN_CTL_COL = 64;
 
 struct LogNormalParams {
     int N, max_iter, mode, lu_in_lds, lu_nb;  // lu_nb: panel width of the blocked LU (set by fh_ln_launch)
@@ -344,6 +348,8 @@ struct LogNormalParams {
                                   // place, [NP*NP] the solved tiles of the Tr2 triangular solve, [16*NP] inverses of the
                                   // diagonal tiles, [6*NP + 3072] bands and scan tables of the pentadiagonal solve (band_scan.h), [2*NP + NP*NP/8] vectors and
                                   // partial sums of the objective evaluations
+    int dist_cholesky;            // 1: the trailing tiles of the tiled Cholesky live in the registers of the cluster's helpers (lognormal.hip:
+                                  // chol_helper; the same bits; FRANK_AMD_LN_CLUSTER_CHOL=0 keeps the factorisation on the first workgroup)
     int no_cholesky;              // 1: skip the tiled Cholesky attempts, always the pivoted LU (FRANK_AMD_LN_PIVOTED=1: the route a
                                   // non-positive pivot takes, kept testable)
     int fresh_products;           // 1: every trial point of the line search gets its own S^-1 x product, as the reference's

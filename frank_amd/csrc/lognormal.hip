@@ -86,10 +86,11 @@ struct LnS {
     // sit on one XCD, the flag word of the hand-overs
     int cluster;
     int seq;  // commands dispatched so far (cluster_dispatch)
+    int chol_epoch;  // distributed factorisations so far (cholesky_as_lu / chol_helper count them separately, in step)
     bool same_xcd;
     int *s_cl;
 };
-enum { LN_CMD_NONE = 0, LN_CMD_SINV = 1, LN_CMD_TR2 = 2, LN_CMD_EXIT = 3, LN_CMD_HESS = 4, LN_CMD_EVAL = 5, LN_CMD_WITH_S = 16 };
+enum { LN_CMD_NONE = 0, LN_CMD_SINV = 1, LN_CMD_TR2 = 2, LN_CMD_EXIT = 3, LN_CMD_HESS = 4, LN_CMD_EVAL = 5, LN_CMD_CHOL = 6, LN_CMD_WITH_S = 16 };
 __device__ __forceinline__ void cluster_dispatch(const LogNormalParams &P, int cmd, bool same_xcd, int &seq);
 __device__ __forceinline__ bool cluster_wait(const LogNormalParams &P, int *s_flag, bool same_xcd);
 
@@ -554,6 +555,133 @@ __device__ __forceinline__ void build_hess_padded(const LogNormalParams &P, LnS 
 // from the mirror tiles in memory): the same bits (tests: the LogNormal fits land on the Newton counts they had).
 // LDS: the solve vectors' space and the LU panel behind it (fh_ln_chol_doubles): two panels, two L_kk^-1, diag(L) and its
 // reciprocals, flags, the tile table.
+// ---- the trailing tiles on the cluster's other units (round 6) -------------------------------------------------------------------
+// One compute unit moves ~25 B per cycle to and from the L2, and the right-looking update streams every trailing tile in and out
+// at every step: 4.6 MB = 184 k of a factorisation's 366 k cycles at N = 300 (43 MB at N = 640).  With a cluster, the tiles (I, J),
+// J >= 2, live in the REGISTERS of the helpers' waves instead (tile e of the column-major list on wave e mod W: three tiles per wave
+// at N = 300 with seven helpers): the first workgroup parks every panel tile L_Ik^T it forms in the dead upper tile (k, I) of the
+// copy and raises a progress word; a helper wave takes the two panel tiles of each of its tiles from the L2 (device-scope loads),
+// updates in registers, and hands a tile back -- store + a counter per block column -- after panel J - 3; the first workgroup keeps
+// a BAND of two block columns: at step k it applies panel k to column k + 1 (and factors it, as before) and to column k + 2, which
+// it took back from the helpers at this step and keeps in the copy until the next -- so a hand-over has two steps' time and is
+// off the chain's path (with a band of one the chain waited ~5 k cycles per step for its column: 286 k cycles per factorisation;
+// the hand-over is six L2 round trips).
+// Same products, same operands, same order into every tile: the same bits.  Hand-overs as in the fit loop's cluster form
+// (fit_loop.hip, clu::): the writer waits for its stores (s_waitcnt vmcnt(0)) before an agent-scope atomic, the reader loads with
+// sc1 (served by the XCD's L2, never by its own L1) -- the cluster sits on one XCD (ctl[6]); no invalidate.  Progress word and
+// column counters are cumulative over the factorisations of a launch (both sides count them: `epoch`), every wait is bounded.
+constexpr int kCholHelperTiles = 16;  // tiles a helper wave holds at most (128 of its registers)
+__device__ __forceinline__ int ctl_load(const int *p);
+__device__ __forceinline__ void ctl_store(int *p, int v);
+__device__ __forceinline__ v4f64 ld_pk_dev(const tilechol::gdouble *base, unsigned tile_byte_off, int lane) {
+    v2f64 lo, hi;
+    const unsigned a = tile_byte_off + (unsigned)lane * 16u;
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3 sc1\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(a), "s"(base)
+                 : "memory");
+    return v4f64{lo[0], lo[1], hi[0], hi[1]};
+}
+// two tiles with one wait
+__device__ __forceinline__ void ld_pk_dev2(const tilechol::gdouble *base, unsigned oa, unsigned ob, int lane, v4f64 &ta, v4f64 &tb) {
+    v2f64 alo, ahi, blo, bhi;
+    const unsigned a = oa + (unsigned)lane * 16u, b = ob + (unsigned)lane * 16u;
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %6 sc1\n\tglobal_load_dwordx4 %1, %4, %6 offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %2, %5, %6 sc1\n\tglobal_load_dwordx4 %3, %5, %6 offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(alo), "=&v"(ahi), "=&v"(blo), "=&v"(bhi)
+                 : "v"(a), "v"(b), "s"(base)
+                 : "memory");
+    ta = v4f64{alo[0], alo[1], ahi[0], ahi[1]};
+    tb = v4f64{blo[0], blo[1], bhi[0], bhi[1]};
+}
+// four tiles with one wait (a helper wave's two panel tiles for two of its tiles)
+__device__ __forceinline__ void ld_pk_dev4(const tilechol::gdouble *base, unsigned o0, unsigned o1, unsigned o2, unsigned o3, int lane,
+                                           v4f64 &t0, v4f64 &t1, v4f64 &t2, v4f64 &t3) {
+    v2f64 l0, h0, l1, h1, l2, h2, l3, h3;
+    const unsigned ln = (unsigned)lane * 16u, a0 = o0 + ln, a1 = o1 + ln, a2 = o2 + ln, a3 = o3 + ln;
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %8, %12 sc1\n\tglobal_load_dwordx4 %1, %8, %12 offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %2, %9, %12 sc1\n\tglobal_load_dwordx4 %3, %9, %12 offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %4, %10, %12 sc1\n\tglobal_load_dwordx4 %5, %10, %12 offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %6, %11, %12 sc1\n\tglobal_load_dwordx4 %7, %11, %12 offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "s"(base)
+                 : "memory");
+    t0 = v4f64{l0[0], l0[1], h0[0], h0[1]};
+    t1 = v4f64{l1[0], l1[1], h1[0], h1[1]};
+    t2 = v4f64{l2[0], l2[1], h2[0], h2[1]};
+    t3 = v4f64{l3[0], l3[1], h3[0], h3[1]};
+}
+__device__ __forceinline__ bool chol_dist_ok(const LogNormalParams &P, int cluster, bool same_xcd) {
+    const int nb = P.NP / 16;
+    return P.dist_cholesky && cluster > 1 && same_xcd && nb >= 5 && (nb - 3) * (nb - 2) / 2 <= kCholHelperTiles * (cluster - 1) * LNW;
+}
+// a helper workgroup's part of one factorisation (command LN_CMD_CHOL); epoch: distributed factorisations so far, this one included
+__device__ __forceinline__ void chol_helper(const LogNormalParams &P, int member, int epoch) {
+    using namespace tilechol;
+    const int nb = P.NP / 16, tid = ln_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = P.cluster - 1, W = H * LNW, w = wave * H + (member - 1);  // (consecutive tiles of a column on different units)
+    const int nT = (nb - 3) * (nb - 2) / 2;  // the tiles (I, J), 3 <= J <= I
+    gdouble *Cg = as_global(uniform_ptr(P.LU + P.N * P.N));
+    int *const prog = P.ctl + LN_CTL_PROG, *const col = P.ctl + LN_CTL_COL;
+    v4f64 T[kCholHelperTiles];
+    int ij[kCholHelperTiles];  // I << 8 | J, -1: no tile (any more)
+    {
+        int J = 3, cum = 0;  // cum: tiles of the columns before J
+#pragma unroll
+        for (int s = 0; s < kCholHelperTiles; ++s) {
+            const int e = w + s * W;
+            ij[s] = -1;
+            T[s] = v4f64{0.0, 0.0, 0.0, 0.0};
+            if (e < nT) {
+                while (e - cum >= nb - J) {
+                    cum += nb - J;
+                    ++J;
+                }
+                const int I = J + (e - cum);
+                ij[s] = (I << 8) | J;
+                T[s] = ld_pk(Cg, (unsigned)((I * nb + J) * 2048), lane);
+            }
+        }
+    }
+    for (int p = 0; p + 3 < nb; ++p) {
+        {   // panel p is in the L2 when the progress word says so
+            const long long t0 = wall_clock64();
+            int v;
+            while ((v = ctl_load(prog)) < epoch * 64 + p + 1) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 5000000ll) return;  // (50 ms: the first workgroup has given up or gone; nothing hangs)
+            }
+            if ((v & 63) == 63 && (v >> 6) == epoch) return;  // abandoned (a pivot that is not positive)
+        }
+        bool any = false;
+        auto apply = [&](int s, const v4f64 &dI, const v4f64 &dJ) __attribute__((always_inline)) {
+            const int I = ij[s] >> 8, J = ij[s] & 255;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) T[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-dI[q], dJ[q], T[s], 0, 0, 0);
+            if (J == p + 3) {  // the column the first workgroup takes into its band next: back to the copy, counted
+                st_pk(Cg, (unsigned)((I * nb + J) * 2048), lane, T[s]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(col + J, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ij[s] = -1;
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < kCholHelperTiles; s += 2) {  // two tiles per wait: their four panel tiles in flight together
+            const bool l0 = ij[s] >= 0, l1 = ij[s + 1] >= 0;
+            if (l0 || l1) {
+                any = true;
+                const int e0 = l0 ? ij[s] : ij[s + 1], e1 = l1 ? ij[s + 1] : ij[s];
+                v4f64 dI0, dJ0, dI1, dJ1;
+                ld_pk_dev4(Cg, (unsigned)((p * nb + (e0 >> 8)) * 2048), (unsigned)((p * nb + (e0 & 255)) * 2048),
+                           (unsigned)((p * nb + (e1 >> 8)) * 2048), (unsigned)((p * nb + (e1 & 255)) * 2048), lane, dI0, dJ0, dI1, dJ1);
+                if (l0) apply(s, dI0, dJ0);
+                if (l1) apply(s + 1, dI1, dJ1);
+            }
+        }
+        if (!any) break;
+    }
+}
+
 constexpr int kCholMaxTiles = 171;  // tiles right of column 1 at nb = 20
 __host__ __device__ constexpr int fh_ln_chol_doubles(int NP) {
     return 2 * NP * tilechol::PS + 2 * 16 * tilechol::PS + 2 * NP + 4 + (kCholMaxTiles + 1) / 2;
@@ -583,12 +711,27 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
                                          // below the diagonal, D L^T on and above it (both scalings need the diagonal of block
                                          // column k only, known when its tile is factored)
     LTIC();
+    // the trailing tiles on the helpers (chol_helper): decided per factorisation (a cluster may have been disbanded since the last)
+    const bool dist = chol_dist_ok(P, S.cluster, S.same_xcd);
+    const int epoch = dist ? ++S.chol_epoch : 0;
+    int *const prog = P.ctl + LN_CTL_PROG;
+    if (dist) cluster_dispatch(P, LN_CMD_CHOL, S.same_xcd, S.seq);  // (the copy is complete: its builders were waited for)
     if constexpr (WIDE) {  // the panel takes the place of the vectors: 18 N doubles out (and back in at the end), 2 x 92 KB against
                            // the factorisation's 43 MB of tiles
         for (int i = tid; i < 18 * N; i += LT) S.bak[i] = S.cpan[i];
         __syncthreads();
     }
     auto leave = [&](bool ok) {
+        if (dist) {
+            if (!ok) {  // the helpers stop waiting for panels
+                __syncthreads();
+                if (tid == 0) ctl_store(prog, epoch * 64 + 63);
+            }
+            if (!cluster_wait(P, S.s_cl, S.same_xcd)) {
+                if (tid == 0) __hip_atomic_store(&P.ctl[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // disbanded
+                S.cluster = 1;
+            }
+        }
         if constexpr (WIDE) {
             __syncthreads();
             for (int i = tid; i < 18 * N; i += LT) S.cpan[i] = S.bak[i];
@@ -650,7 +793,7 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
         const v4f64 d = mfma4(fx, ft, z, false);
         const v4f64 dt = mfma4(ft, fx, z, false);
         const double dck = dvec[16 * k + cl];
-        if (!pan) st_pk(Cg, (unsigned)((k * nb + I) * 2048), lane, d);
+        if (!pan || dist) st_pk(Cg, (unsigned)((k * nb + I) * 2048), lane, d);  // (dist: where the helpers take the panel from)
         double *pr = (pan ? pan : pan0) + (size_t)((I - k - 1) * 16 + cl) * PS + rg;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -699,7 +842,28 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
         }
         }
     }
+    auto publish = [&](int panels) {  // every wave's stores have left the unit before the word is raised behind the barrier
+        if (tid == 0) ctl_store(prog, epoch * 64 + panels);
+    };
+    if (dist) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (dist) publish(1);
+    // block column J >= 3 comes back from the helpers (updated through panel J - 3): its counter, then device-scope loads
+    auto column_in = [&](int J) {
+        int *const cw = P.ctl + LN_CTL_COL + J;
+        const int want = epoch * (nb - J);
+        const long long t0 = wall_clock64();
+        while (ctl_load(cw) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 2000000ll) {  // (20 ms: the factorisation fails, the fit goes on without the distributed form)
+                if (lane == 0) flag[0] = 1;
+                break;
+            }
+        }
+    };
+    // distributed, N <= 320: a worker has at most six tiles per step, and the chain is what the step waits for -- wave 4, which shares
+    // the chain's SIMD (a vector instruction issued while the mate's matrix instructions run waits for them), sits the steps out
+    const bool idle_mate = dist && !WIDE;
     double ident[4];  // B fragments of the 16 x 16 identity: four matrix instructions against it transpose a tile
 #pragma unroll
     for (int q = 0; q < 4; ++q) ident[q] = (4 * q + rg == cl) ? 1.0 : 0.0;
@@ -721,20 +885,60 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
 #endif
         if (wave == 0) {
             // the chain: diagonal tile k + 1 updated, factored and inverted while the other waves update the rest
-            v4f64 t = update(0, 0, ld_pk(Cg, base, lane)), x;
+            // (distributed, two panels: the diagonal tile was left in LDS by the worker that gave it panel k - 1 -- the spare tile
+            //  behind the nb - 1 tiles of this step's panel buffer -- instead of going through the L2: ~2 k cycles of the chain's path)
+            v4f64 t0;
+            if (!WIDE && dist && k >= 1) {
+                const v2f64 *dsl = reinterpret_cast<const v2f64 *>(pan_of(k) + (size_t)(nb - 1) * 16 * PS);
+                const v2f64 lo = dsl[2 * lane], hi = dsl[2 * lane + 1];
+                t0 = v4f64{lo[0], lo[1], hi[0], hi[1]};
+            } else {
+                t0 = ld_pk(Cg, base, lane);
+            }
+            v4f64 t = update(0, 0, t0), x;
             diag_factor(k + 1, t, x);
             __hip_atomic_store(&flag[1], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             CHT(0);
             diag_outputs(k + 1, t, x);
             CHT(1);
-        } else {
-            constexpr int NWK = LNW - 1;
-            const int widx = wave - 1;
+        } else if (!(idle_mate && wave == 4)) {
+            const int NWK = idle_mate ? LNW - 2 : LNW - 1;
+            const int widx = idle_mate && wave > 4 ? wave - 2 : wave - 1;
+            if (dist && k + 2 < nb) {
+                // ---- the band's second column: tiles (I, k + 2), I >= k + 2, take panel k here and wait in the copy for the next step
+                //      (from step 1 on they come back from the helpers, updated through panel k - 1: counter, device-scope loads)
+                const bool back = k >= 1;
+                const int n2 = nb - k - 2;
+                if (back && widx < n2) column_in(k + 2);
+                auto band_out = [&](int c2, unsigned co, const v4f64 &u2) {
+                    if (!WIDE && c2 == 0) {  // the next step's diagonal tile: to the chain through LDS (the other panel buffer's spare tile)
+                        v2f64 *dsl = reinterpret_cast<v2f64 *>(pan_of(k + 1) + (size_t)(nb - 1) * 16 * PS);
+                        dsl[2 * lane] = v2f64{u2[0], u2[1]};
+                        dsl[2 * lane + 1] = v2f64{u2[2], u2[3]};
+                    } else {
+                        st_pk(Cg, co, lane, u2);
+                    }
+                };
+                auto off2 = [&](int c2) { return (unsigned)(((k + 2 + c2) * nb + (k + 2)) * 2048); };
+                int c2 = widx;
+                for (; c2 + NWK < n2; c2 += 2 * NWK) {  // two tiles per wait
+                    v4f64 ta, tb;
+                    if (back) {
+                        ld_pk_dev2(Cg, off2(c2), off2(c2 + NWK), lane, ta, tb);
+                    } else {
+                        ta = ld_pk(Cg, off2(c2), lane);
+                        tb = ld_pk(Cg, off2(c2 + NWK), lane);
+                    }
+                    band_out(c2, off2(c2), update(c2 + 1, 1, ta));
+                    band_out(c2 + NWK, off2(c2 + NWK), update(c2 + NWK + 1, 1, tb));
+                }
+                if (c2 < n2) band_out(c2, off2(c2), update(c2 + 1, 1, back ? ld_pk_dev(Cg, off2(c2), lane) : ld_pk(Cg, off2(c2), lane)));
+            }
             // ---- the tiles right of column k + 1: every NWK-th tile of the table, two in flight in two named register sets ----
             auto off_of = [&](int t) { return base + (unsigned)(((t >> 8) * nb + (t & 255)) * 2048); };
             auto finish = [&](int t, v4f64 a) { st_pk(Cg, off_of(t), lane, update(t >> 8, t & 255, a)); };
             int e = widx;
-            if (e < cntA) {
+            if (!dist && e < cntA) {
                 int ta = tab[e], tb = 0;
                 v4f64 a = ld_pk(Cg, off_of(ta), lane), b = a;
                 bool hb = e + NWK < cntA;
@@ -848,8 +1052,10 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
             }
             }
         }
+        if (dist) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the parked tiles of panel k + 1)
         if constexpr (WIDE) {
             __syncthreads();  // everybody has read panel k: the parked tiles of column k + 1 become panel k + 1
+            if (dist) publish(k + 2);
             if (wave > 0) {
                 int cfirst = (wave - 1) - cntA % (LNW - 1);
                 if (cfirst < 0) cfirst += LNW - 1;
@@ -862,6 +1068,7 @@ __device__ __forceinline__ bool cholesky_as_lu(const LogNormalParams &P, LnS &S,
             }
         }
         __syncthreads();
+        if (!WIDE && dist) publish(k + 2);
 #ifdef LN_TIMING
         if (wave == 0) CHT(2);
         if (wave == 1) CHT(7);
@@ -2154,7 +2361,7 @@ __device__ __forceinline__ void cluster_helper(const LogNormalParams &P, int mem
         __hip_atomic_fetch_or(&P.ctl[5], 1 << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&P.ctl[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    int seen = 0, same = -1;
+    int seen = 0, same = -1, chol_epoch = 0;
     for (;;) {
         if (tid == 0) {
             const long long t0 = wall_clock64();
@@ -2192,6 +2399,8 @@ __device__ __forceinline__ void cluster_helper(const LogNormalParams &P, int mem
             }
             __syncthreads();
             ln_eval_items(P, with_s ? smem : nullptr, smem + P.NP, member * LT + tid, P.cluster * LT);
+        } else if (cmd == LN_CMD_CHOL) {
+            chol_helper(P, member, ++chol_epoch);
         } else if (cmd == LN_CMD_HESS) {
             build_hess_tiles(P, P.rk_g, P.tr2_g, P.j, P.LU + P.N * P.N, member, P.cluster);
         } else if (cmd == LN_CMD_TR2) {
@@ -2226,7 +2435,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         const int group = (i / P.cluster) * 8 + x, member = i % P.cluster;
         if (group >= (P.groups > 0 ? P.groups : 1)) return;
         slot = group;
-        P.ctl += 8 * group;
+        P.ctl += LN_CTL_WORDS * group;
         P.rk_g += (size_t)group * P.group_vec_stride;
         P.tr2_g += (size_t)group * P.group_vec_stride;
         P.dvec_g += (size_t)group * P.group_vec_stride;
@@ -2264,6 +2473,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
     }
     const LogNormalParams P0 = P;
     int cl_seq = 0;  // commands dispatched to this group's helpers so far (the words must never repeat: carried from fit to fit)
+    int cl_epoch = 0;  // ... and the distributed factorisations (the helpers count them too)
     // batched launch: the workgroups pull fit indices from a counter; work buffers belong to the workgroup, outputs to
     // the fit (per-fit alpha, p0, band_lu)
     for (;;) {
@@ -2330,6 +2540,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
         if constexpr (!WIDE) S.chol = S.wsol;
         S.cluster = cluster;
         S.seq = cl_seq;
+        S.chol_epoch = cl_epoch;
         S.same_xcd = same_xcd;
         S.s_cl = s_cl;
         S.lu = LDS_LU ? b : P.LU;
@@ -2677,6 +2888,7 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
     }
     cluster = S.cluster;  // (a cluster that was disbanded stays so)
     cl_seq = S.seq;
+    cl_epoch = S.chol_epoch;
     __syncthreads();
     }  // next fit of the batch
 }

@@ -689,6 +689,30 @@ def test_lognormal_staged_sweep_equals_single_launch(golden, monkeypatch):
     assert min(out["staged"][1]) < max(out["staged"][1])  # (points of different lengths: some ended before the others paused)
 
 
+@pytest.mark.parametrize("N", [300, 208, 400])
+def test_lognormal_cholesky_on_the_helpers_equals_the_local_one(golden, monkeypatch, N):
+    """Round 6: with a cluster, the trailing tiles of the Hessian's tiled Cholesky live in the registers of the helper workgroups
+    (lognormal.hip: chol_helper; the first workgroup keeps a band of two block columns, panels and columns change hands through
+    the XCD's L2 with device-scope loads).  Same products, same operands, same order into every tile: whole fits land on the same
+    bits as with the factorisation on the first workgroup alone (FRANK_AMD_LN_CLUSTER_CHOL=0) and on one workgroup
+    (FRANK_AMD_LN_CLUSTER=1) -- N = 300 (19 block columns), 208 (13: a different deal of tiles to waves), 400 (the WIDE form: one
+    panel, tiles parked in the copy)."""
+    from frank_amd import FrankFitter
+    u, v, V, w = mock_disc_visibilities(200000, seed=31, noise_seed=32)
+    out = {}
+    for mode, env in (("helpers", {}), ("local", {"FRANK_AMD_LN_CLUSTER_CHOL": "0"}), ("one workgroup", {"FRANK_AMD_LN_CLUSTER": "1"})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        FF = FrankFitter(2.0, N, geom(), alpha=1.3, weights_smooth=1e-2, method="LogNormal", max_iter=8, convergence_failure="ignore",
+                         verbose=False, check_qbounds=False, store_iteration_diagnostics=True)
+        sol = FF.fit(u, v, V, w)
+        out[mode] = (sha(sol.I, sol.power_spectrum), tuple(int(x) for x in sol._fit._newton_stats[:4]))
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    assert out["helpers"] == out["local"] == out["one workgroup"], out
+    assert out["helpers"][1][3] >= 8  # (Hessians: every pass factors at least one)
+
+
 @pytest.mark.parametrize("n", [3000, 1000000])
 def test_fused_prepass_agrees_with_the_sorted_one(monkeypatch, n):
     """The one-pass form of the moments pre-pass (bin_fused.hip, FRANK_AMD_K1_FUSED=1: the buckets' 36 moment sums accumulated in

@@ -458,7 +458,7 @@ def test_shipped_library_reads_only_the_form_switches():
     allowed = {"FRANK_AMD_K1", "FRANK_AMD_K1_FUSED", "FRANK_AMD_K1_NO_HIST_CACHE", "FRANK_AMD_K1_SAFE_TRIG", "FRANK_AMD_NO_RANGE_CACHE",
                "FRANK_AMD_K2", "FRANK_AMD_K2_CLUSTER", "FRANK_AMD_K2_CLUSTER_BREAK", "FRANK_AMD_K2_RR", "FRANK_AMD_K2_DEFER",
                "FRANK_AMD_K2_LL", "FRANK_AMD_SWEEP_CAP", "FRANK_AMD_SWEEP_LEFT", "FRANK_AMD_SWEEP_STAGE2_CLUSTERS",
-               "FRANK_AMD_SWEEP_NO_CLUSTERS", "FRANK_AMD_LN_CLUSTER", "FRANK_AMD_LN_PIVOTED", "FRANK_AMD_LN_WIDE", "FRANK_AMD_RESIDUAL_DIRECT"}
+               "FRANK_AMD_SWEEP_NO_CLUSTERS", "FRANK_AMD_LN_CLUSTER", "FRANK_AMD_LN_CLUSTER_CHOL", "FRANK_AMD_LN_PIVOTED", "FRANK_AMD_LN_WIDE", "FRANK_AMD_RESIDUAL_DIRECT"}
     assert names <= allowed, sorted(names - allowed)
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for n in names:
