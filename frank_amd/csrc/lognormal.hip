@@ -71,6 +71,7 @@ struct LnS {
     int *perm;
     double *lu;    // N*N column-major: LDS or global
     double *pan;   // global-LU kernels: LDS panel of the blocked factorisation (N * LU_NB)
+    double *stage;  // WIDE: 64 x 64 doubles of LDS: the diagonal block of the factors the next substitution chain runs on (block_solve_wide)
     double *cpan, *bak;  // WIDE: the Cholesky's one panel ALIASES the eighteen vectors behind rdiag (they wait in `bak`, global, meanwhile)
     double *chol;  // LDS of the tiled Cholesky (cholesky_as_lu): N <= 320 the solve vectors' space and the LU panel's behind it; WIDE: its own
     int lu_nb;
@@ -1693,32 +1694,47 @@ __device__ __forceinline__ double wide_cols(const double *A, int N, int rc, cons
 __device__ __forceinline__ void block_solve_wide(LnS &S, int N, const double *A, const double *b, double sign, double *xs) {
     const int tid = ln_tid(), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *part = S.part;
+#ifdef LN_TIMING
+    const long long _tw0 = clock64();
+    long long _tchain = 0;
+#define SVT(stmt) do { const long long a_ = clock64(); stmt; _tchain += clock64() - a_; } while (0)
+#else
+#define SVT(stmt) stmt
+#endif
     for (int jj = tid; jj < N; jj += LT) xs[jj] = sign * b[S.perm[jj]];
     __syncthreads();
     const int nblk = (N + 63) >> 6;
-    auto chain_lower = [&](int kb) {  // wave 0: the 64 x 64 unit-lower diagonal block, as block_solve runs it
+    // The chains of the WIDE form run on a diagonal block that is already in LDS: at these sizes the factors stream from beyond the L2
+    // (~2-3 k cycles), and the eight-columns-ahead prefetch of block_solve stalled at every group -- 12.8 k cycles per block instead of
+    // 3.8 k (timing build, N = 640); with the lane's whole row loaded first the chain still paid one such latency, 7.7 k.  So the block
+    // of the NEXT chain is staged (stage_block: eight columns per wave, beside the loads of the step's last 64 columns) while nothing
+    // reads the buffer -- a chain copies its row into registers first thing.  Same operations in the same order: the same bits.
+    auto stage_block = [&](int kb) {  // every wave; barrier before the chain that uses it
+        const int k0 = kb << 6, rc = min(k0 + lane, N - 1);
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = A[min(k0 + 8 * wv + u, N - 1) * N + rc];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) S.stage[(8 * wv + u) * 64 + lane] = v[u];
+    };
+    auto chain_lower = [&](int kb) {  // wave 0: the 64 x 64 unit-lower diagonal block
         const int k0 = kb << 6, r = k0 + lane, rc = min(r, N - 1);
         const double *pp = part + (kb & 1) * (LNW * 64);
         const int ng = (min(64, N - k0) + 7) >> 3;
+        double dv[64];
+#pragma unroll
+        for (int c = 0; c < 64; ++c) dv[c] = S.stage[c * 64 + lane];
         double acc = (r < N) ? xs[r] : 0.0;
 #pragma unroll
         for (int w = 0; w < LNW; ++w) acc -= pp[w * 64 + lane];
-        double nxt[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) nxt[u] = A[min(k0 + u, N - 1) * N + rc];
-#pragma unroll 1
-        for (int g = 0; g < ng; ++g) {
-            double cur[8];
+        for (int g = 0; g < 8; ++g) {
+            if (g < ng) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
-            if (g + 1 < ng) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) nxt[u] = A[min(k0 + 8 * g + 8 + u, N - 1) * N + rc];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c = 8 * g + u;
-                acc = fma(-((lane > c && r < N) ? cur[u] : 0.0), lane_bcast(acc, c), acc);
+                for (int u = 0; u < 8; ++u) {
+                    const int c = 8 * g + u;
+                    acc = fma(-((lane > c && r < N) ? dv[c] : 0.0), lane_bcast(acc, c), acc);
+                }
             }
         }
         if (r < N) xs[r] = acc;
@@ -1727,57 +1743,57 @@ __device__ __forceinline__ void block_solve_wide(LnS &S, int N, const double *A,
         const int k0 = kb << 6, r = k0 + lane, rc = min(r, N - 1);
         const double *pp = part + (t & 1) * (LNW * 64);
         const int ng = (min(64, N - k0) + 7) >> 3;
+        double dv[64];
+#pragma unroll
+        for (int c = 0; c < 64; ++c) dv[c] = S.stage[c * 64 + lane];
         double acc = (r < N) ? xs[r] : 0.0;
 #pragma unroll
         for (int w = 0; w < LNW; ++w) acc -= pp[w * 64 + lane];
         const double rd = (r < N) ? S.rdiag[r] : 0.0;
-        double nxt[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) nxt[u] = A[min(k0 + 8 * (ng - 1) + u, N - 1) * N + rc];
-#pragma unroll 1
-        for (int g = ng - 1; g >= 0; --g) {
-            double cur[8];
+        for (int g = 7; g >= 0; --g) {
+            if (g < ng) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
-            if (g > 0) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) nxt[u] = A[(k0 + 8 * g - 8 + u) * N + rc];
-            }
-#pragma unroll
-            for (int u = 7; u >= 0; --u) {
-                const int c = 8 * g + u;
-                const double xi = lane_bcast(acc * rd, c);
-                acc = (lane == c) ? xi : acc;
-                acc = fma(-((lane < c) ? cur[u] : 0.0), xi, acc);
+                for (int u = 7; u >= 0; --u) {
+                    const int c = 8 * g + u;
+                    const double xi = lane_bcast(acc * rd, c);
+                    acc = (lane == c) ? xi : acc;
+                    acc = fma(-((lane < c) ? dv[c] : 0.0), xi, acc);
+                }
             }
         }
         if (r < N) xs[r] = acc;
     };
+    stage_block(0);
+    __syncthreads();
     for (int kb = 0; kb < nblk; ++kb) {  // L y = P b, unit lower
         const int k0 = kb << 6, rc = min(k0 + lane, N - 1);
         const int early = max(0, k0 - 64);
         double acc = 0.0;
         if (wv == 0) {
-            if (kb > 0) chain_lower(kb - 1);
+            if (kb > 0) SVT(chain_lower(kb - 1));
         } else {
             acc = wide_cols(A, N, rc, xs, (wv - 1) * early / (LNW - 1), wv * early / (LNW - 1), 0.0);
         }
         __syncthreads();
         {
             const int late = k0 - early;
+            if (kb > 0) stage_block(kb);  // (chain(kb - 1) has its block in registers since before the barrier above; block 0 is in already)
             acc = wide_cols(A, N, rc, xs, early + wv * late / LNW, early + (wv + 1) * late / LNW, acc);
             part[(kb & 1) * (LNW * 64) + wv * 64 + lane] = acc;
         }
         __syncthreads();
     }
-    if (wv == 0) chain_lower(nblk - 1);
+    if (wv == 0) SVT(chain_lower(nblk - 1));
+    __syncthreads();
+    stage_block(nblk - 1);
     __syncthreads();
     for (int t = 0; t < nblk; ++t) {  // U x = y
         const int kb = nblk - 1 - t, k0 = kb << 6, rc = min(k0 + lane, N - 1);
         const int lo = min(N, k0 + 64), mid = min(N, lo + 64);  // [lo, mid): the block just solved; [mid, N): the ones before it
         double acc = 0.0;
         if (wv == 0) {
-            if (t > 0) chain_upper(kb + 1, t - 1);
+            if (t > 0) SVT(chain_upper(kb + 1, t - 1));
         } else {
             const int span = N - mid;
             acc = wide_cols(A, N, rc, xs, mid + (wv - 1) * span / (LNW - 1), mid + wv * span / (LNW - 1), 0.0);
@@ -1785,13 +1801,21 @@ __device__ __forceinline__ void block_solve_wide(LnS &S, int N, const double *A,
         __syncthreads();
         {
             const int late = mid - lo;
+            if (t > 0) stage_block(kb);
             acc = wide_cols(A, N, rc, xs, lo + wv * late / LNW, lo + (wv + 1) * late / LNW, acc);
             part[(t & 1) * (LNW * 64) + wv * 64 + lane] = acc;
         }
         __syncthreads();
     }
-    if (wv == 0) chain_upper(0, nblk - 1);
+    if (wv == 0) SVT(chain_upper(0, nblk - 1));
     __syncthreads();
+#ifdef LN_TIMING
+    if (tid == 0) {  // (timing build: the chains' share of the directions in the slots of the pivoted LU, which this form does not have)
+        ln_cyc[5] += _tchain;
+        ln_cyc[7] += clock64() - _tw0;
+    }
+#endif
+#undef SVT
 }
 
 __device__ __forceinline__ void accept_trial(LnS &S, int N) {
@@ -2523,6 +2547,10 @@ __global__ __launch_bounds__(LT) void lognormal_kernel(LogNormalParams P) {
             b += N;
             S.cpan = b;
             S.bak = gscratch + LNW * N;
+            {   // behind the larger of the eighteen vectors and the panel that lies over them (fh_ln_smem_bytes)
+                const size_t v18 = 18 * (size_t)N, pnl = (size_t)P.NP * tilechol::PS;
+                S.stage = b + ((v18 > pnl ? v18 : pnl) + 1) / 2 * 2;
+            }
         }
         double **vecs[] = {&S.x,  &S.xn, &S.I, &S.In,   &S.Sx,  &S.Sxn, &S.MI,  &S.MIn,  &S.jx,   &S.dx,
                            &S.pd, &S.jv, &S.p, &S.pold, &S.rhs, &S.tr2, &S.col, &S.rowk, &S.rdiag};
@@ -2903,7 +2931,7 @@ size_t fh_ln_smem_bytes(int N, int *lu_in_lds, int *lu_nb) {
         const int NPw = (N + 15) / 16 * 16;
         const size_t small = (size_t)fh_ln_chol_small_wide(NPw) + (fh_ln_chol_small_wide(NPw) & 1);
         const size_t vec18 = 18 * (size_t)N, panel = (size_t)NPw * tilechol::PS;
-        return sizeof(double) * (72 + 2 * LT + small + 2 * (size_t)N + (vec18 > panel ? vec18 : panel));
+        return sizeof(double) * (72 + 2 * LT + small + 2 * (size_t)N + ((vec18 > panel ? vec18 : panel) + 1) / 2 * 2 + 64 * 64);  // (+ the staged diagonal block)
     }
     size_t doubles = (19 + LNW) * N + 72 + 2 * LT + N;
     const int fits = (N <= 112);
