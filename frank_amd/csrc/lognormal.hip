@@ -1721,19 +1721,23 @@ __device__ __forceinline__ void block_solve_wide(LnS &S, int N, const double *A,
         const int k0 = kb << 6, r = k0 + lane, rc = min(r, N - 1);
         const double *pp = part + (kb & 1) * (LNW * 64);
         const int ng = (min(64, N - k0) + 7) >> 3;
-        double dv[64];
-#pragma unroll
-        for (int c = 0; c < 64; ++c) dv[c] = S.stage[c * 64 + lane];
         double acc = (r < N) ? xs[r] : 0.0;
 #pragma unroll
         for (int w = 0; w < LNW; ++w) acc -= pp[w * 64 + lane];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            if (g < ng) {
+        for (int h = 0; h < 2; ++h) {  // (the row in two halves of 32 registers: LDS reads, no latency to hide -- and 64 more live
+                                       //  registers here once made the compiler's spill code of this kernel fault on the device)
+            double dv[32];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = 8 * g + u;
-                    acc = fma(-((lane > c && r < N) ? dv[c] : 0.0), lane_bcast(acc, c), acc);
+            for (int c = 0; c < 32; ++c) dv[c] = S.stage[(32 * h + c) * 64 + lane];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (4 * h + g < ng) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = 32 * h + 8 * g + u;
+                        acc = fma(-((lane > c && r < N) ? dv[8 * g + u] : 0.0), lane_bcast(acc, c), acc);
+                    }
                 }
             }
         }
@@ -1743,22 +1747,25 @@ __device__ __forceinline__ void block_solve_wide(LnS &S, int N, const double *A,
         const int k0 = kb << 6, r = k0 + lane, rc = min(r, N - 1);
         const double *pp = part + (t & 1) * (LNW * 64);
         const int ng = (min(64, N - k0) + 7) >> 3;
-        double dv[64];
-#pragma unroll
-        for (int c = 0; c < 64; ++c) dv[c] = S.stage[c * 64 + lane];
         double acc = (r < N) ? xs[r] : 0.0;
 #pragma unroll
         for (int w = 0; w < LNW; ++w) acc -= pp[w * 64 + lane];
         const double rd = (r < N) ? S.rdiag[r] : 0.0;
 #pragma unroll
-        for (int g = 7; g >= 0; --g) {
-            if (g < ng) {
+        for (int h = 1; h >= 0; --h) {
+            double dv[32];
 #pragma unroll
-                for (int u = 7; u >= 0; --u) {
-                    const int c = 8 * g + u;
-                    const double xi = lane_bcast(acc * rd, c);
-                    acc = (lane == c) ? xi : acc;
-                    acc = fma(-((lane < c) ? dv[c] : 0.0), xi, acc);
+            for (int c = 0; c < 32; ++c) dv[c] = S.stage[(32 * h + c) * 64 + lane];
+#pragma unroll
+            for (int g = 3; g >= 0; --g) {
+                if (4 * h + g < ng) {
+#pragma unroll
+                    for (int u = 7; u >= 0; --u) {
+                        const int c = 32 * h + 8 * g + u;
+                        const double xi = lane_bcast(acc * rd, c);
+                        acc = (lane == c) ? xi : acc;
+                        acc = fma(-((lane < c) ? dv[8 * g + u] : 0.0), xi, acc);
+                    }
                 }
             }
         }
