@@ -604,9 +604,11 @@ def extras(f, L, a):
                 "peak": peak, "unit": "TFLOP/s", "frac": total / seconds / 1e12 / peak, "algorithmic_flops": total,
                 "flops_by_phase": fl, "traffic": traffic, "traffic_source": src,
                 "note": "the matrix peak is the nominal roof (the products run on v_mfma_f64_16x16x4_f64); what holds the kernel is "
-                        "what ONE compute unit moves to and from the L2, ~25 B per cycle: a factorisation of the Hessian is 4.6 MB "
-                        "of tile traffic (184 k cycles of its 366 k), a Newton direction 0.72 MB of factors, an evaluation 0.72 MB of M "
-                        "-- profiles/r06_lognormal_phases.txt"}
+                        "what runs on ONE compute unit: a Newton direction is two substitutions on 0.72 MB of factors (~25 B per cycle "
+                        "from the L2, a 64-step chain per 64-row block), an evaluation 0.72 MB of M; the Hessian's factorisation keeps "
+                        "its trailing tiles in the registers of the cluster's helpers since the second half of round 6 (366 k -> 254 k "
+                        "cycles: the chain of diagonal tiles and the panel behind it are what a step waits for) -- "
+                        "profiles/r06_lognormal_phases.txt, r06_lognormal_dist_cholesky.txt"}
 
     def lognormal(reference_products):
         s_map, p = np.empty(N), np.empty(N)
