@@ -78,6 +78,10 @@ def parse():
     # ~0.24 s): the default K amortises it, a small K mostly measures it
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--prewarm-seconds", type=float, default=2.0,
+                    help="untimed run of the same pipeline in front of the W warm-up steps: a device that has been idle takes its "
+                         "first seconds of load to reach its clocks (the first process on a fresh box measured 328 fits/s at 20 steps, "
+                         "the second one 358); 0: none")
     ap.add_argument("--nvis", type=int, default=N_VIS)
     ap.add_argument("--ncoll", type=int, default=N_COLL)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1157,6 +1161,11 @@ def main():
     ring = f.tables[:RING]
     L.check(L.lib.fh_ctx_set_range_cache(f.ctx, 0))
 
+    if a.prewarm_seconds > 0:  # (untimed; see --prewarm-seconds)
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < a.prewarm_seconds:
+            f.run_steps(20, ring=ring)
+            f.sync()
     f.run_steps(a.warmup, ring=ring)
     f.sync()
     barrier()
@@ -1300,7 +1309,10 @@ def main():
                        "alpha": HYPER["alpha"], "wsmooth": HYPER["wsmooth"], "tol": HYPER["tol"],
                        "iterations_to_converge": nit, "iterations_of_the_reference_on_this_input": ref_iters,
                        "iterations_match_the_reference": (nit == ref_iters) if ref_iters is not None else None,
-                       "parallelism": "independent fits x%d" % world},
+                       "parallelism": "independent fits x%d" % world,
+                       "prewarm_seconds": a.prewarm_seconds,
+                       "prewarm": "untimed run of the same pipeline in front of the W warm-up steps (a device that has been idle "
+                                  "reaches its clocks over its first seconds of load); --prewarm-seconds 0 turns it off"},
             "breakdown_ms": {"single_fit_latency": 1e3 * (t_bin + t_solve), "bin_gram_pass": 1e3 * t_bin,
                              "finalize_plus_iterate": 1e3 * t_solve, "us_per_iteration": 1e6 * t_solve / max(nit, 1),
                              "binning_pass_by_events": pre_alone + kms_alone, "fit_loop_kernel": loop_ms,
