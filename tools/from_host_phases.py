@@ -3,6 +3,7 @@ arrays back to back.   python3 tools/from_host_phases.py [K] [window] [low]
 window: tables alive at most; low: a collect brings them down to this many (the fits staged meanwhile then share ONE launch: a
 context runs four launches at a time, so one fit per launch means four fits in flight)."""
 import ctypes
+import hashlib
 import os
 import sys
 import time
@@ -24,6 +25,7 @@ Vre, Vim = np.ascontiguousarray(V.real), np.ascontiguousarray(V.imag)
 f.nfit = u.size
 L.check(L.lib.fh_ctx_set_range_cache(f.ctx, 0))
 pend, alive = [], []
+results = []  # (iterations, sha of mu and p) of every fit collected: a table freed too early would show here
 draining = [False]
 count = [0]
 T = {"upload": 0.0, "submit": 0.0, "collect": 0.0, "destroy": 0.0}
@@ -45,7 +47,7 @@ def one():
     while len(alive) > (LOW if draining[0] else WIN):
         draining[0] = True
         t3 = time.perf_counter()
-        f.collect(pend.pop(0))
+        results.append((f.collect(pend.pop(0)), hashlib.sha1(f.mu.tobytes() + f.p.tobytes()).hexdigest()[:12]))
         t4 = time.perf_counter()
         L.lib.fh_vis_destroy(alive.pop(0))
         t5 = time.perf_counter()
@@ -64,7 +66,7 @@ for _ in range(K):
 t_loop = time.perf_counter() - t0
 L.check(L.lib.fh_fit_flush(f.ctx))
 while pend:
-    f.collect(pend.pop(0))
+    results.append((f.collect(pend.pop(0)), hashlib.sha1(f.mu.tobytes() + f.p.tobytes()).hexdigest()[:12]))
 f.sync()
 dt = time.perf_counter() - t0
 print("K=%d window=%d low=%d flush every %d: %.1f fits/s over the loop alone (%.2f ms per fit), %.1f with the drain (%.0f ms)" % (K, WIN, LOW, EVERY, K / t_loop, 1e3 * t_loop / K, K / dt, 1e3 * (dt - t_loop)))
@@ -72,3 +74,4 @@ print("host ms per fit: " + ", ".join("%s %.2f" % (k, 1e3 * T[k] / K) for k in T
 wg, fb = ctypes.c_int(0), ctypes.c_int64(0)
 L.check(L.lib.fh_fit_cluster_info(f.ctx, ctypes.byref(wg), ctypes.byref(fb)))
 print("workgroups of the last fit: %d; clusters that did not assemble and were rerun on one unit: %d" % (wg.value, fb.value))
+print("results of the %d fits collected: %s" % (len(results), {r: results.count(r) for r in set(results)}))
